@@ -1,0 +1,448 @@
+"""ctypes mirror of include/centrolign_amd.h (the C ABI of the MI355X stitch path).
+
+Plumbing only: numpy arrays in, numpy arrays out.  There is NO CPU fallback here: if the HIP shared
+library is missing or no gfx950 device is visible, loading / context creation raises.
+
+The flat batch layout (`StitchBatch`) is the C struct `cl_stitch_batch`: per graph side the concatenated
+SubGraphInfo fields of every between-anchor subproblem (reference:
+include/centrolign/subgraph_extraction.hpp:14-33).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcentrolign_amd.so")
+
+CL_GAP = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+ROUTE_NAMES = {0: "po", 1: "pd1", 2: "pd2", 3: "ad1", 4: "ad2", 5: "w", 6: "u"}
+
+ERRORS = {
+    0: "CL_OK", -1: "CL_ERR_INVALID_ARGUMENT", -2: "CL_ERR_BAD_GAP_PARAMS", -3: "CL_ERR_NO_DEVICE",
+    -4: "CL_ERR_HIP", -5: "CL_ERR_OUT_OF_MEMORY", -6: "CL_ERR_UNSUPPORTED_ROUTE", -7: "CL_ERR_CYCLIC_GRAPH",
+    -8: "CL_ERR_UNREACHABLE_SINK",
+}
+
+
+class ClError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (ERRORS.get(code, "CL_ERR_?"), code, (": " + msg) if msg else ""))
+
+
+class AlignParams(C.Structure):
+    """cl_align_params == AlignmentParameters<3> (include/centrolign/alignment.hpp:56-65)"""
+    _fields_ = [("match", C.c_uint32), ("mismatch", C.c_uint32),
+                ("gap_open", C.c_uint32 * 3), ("gap_extend", C.c_uint32 * 3)]
+
+
+class StitchParams(C.Structure):
+    """cl_stitch_params == Stitcher public tunables (include/centrolign/stitcher.hpp:48-64)"""
+    _fields_ = [("alignment_params", AlignParams),
+                ("max_trivial_size", C.c_uint64), ("min_wfa_size", C.c_uint64), ("max_wfa_size", C.c_uint64),
+                ("max_wfa_ratio", C.c_double), ("wfa_pruning_dist", C.c_uint64),
+                ("deletion_alignment_ratio", C.c_uint64),
+                ("deletion_alignment_short_max_size", C.c_uint64),
+                ("deletion_alignment_long_min_size", C.c_uint64)]
+
+
+def default_stitch_params():
+    """The values the centrolign CLI runs with (src/parameters.cpp:74-85)."""
+    p = StitchParams()
+    p.alignment_params.match = 20
+    p.alignment_params.mismatch = 80
+    p.alignment_params.gap_open[:] = [60, 800, 2500]
+    p.alignment_params.gap_extend[:] = [30, 5, 1]
+    p.max_trivial_size = 30000
+    p.min_wfa_size = 40000000
+    p.max_wfa_size = 75000000
+    p.max_wfa_ratio = 1.05
+    p.wfa_pruning_dist = 25
+    p.deletion_alignment_ratio = 8
+    p.deletion_alignment_short_max_size = 1500
+    p.deletion_alignment_long_min_size = 2000
+    return p
+
+
+def make_align_params(match, mismatch, gap_open, gap_extend):
+    p = AlignParams()
+    p.match, p.mismatch = match, mismatch
+    go = list(gap_open) + [gap_open[-1]] * (3 - len(gap_open))
+    ge = list(gap_extend) + [gap_extend[-1]] * (3 - len(gap_extend))
+    p.gap_open[:] = go
+    p.gap_extend[:] = ge
+    return p
+
+
+class GraphSideC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("node_off", "label", "prev_off", "prev_idx", "next_off", "next_idx",
+                 "src_off", "src_idx", "snk_off", "snk_idx", "back_translation")]
+
+
+class StitchBatchC(C.Structure):
+    _fields_ = [("n_problems", C.c_uint64), ("side", GraphSideC * 2), ("only_deletion_alns", C.c_void_p)]
+
+
+class StitchResultC(C.Structure):
+    _fields_ = [("n_problems", C.c_uint64), ("aln_off", C.POINTER(C.c_uint64)), ("pairs", C.POINTER(C.c_uint64)),
+                ("score", C.POINTER(C.c_int64)), ("route", C.POINTER(C.c_uint8)), ("num_pw", C.POINTER(C.c_uint8))]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("n_problems", "n_po_poa", "dp_cells", "dp_bytes", "n_linear", "max_cells", "workspace_bytes",
+                 "n_launches")]
+
+
+_SIDE_DTYPES = dict(node_off=np.uint64, label=np.uint8, prev_off=np.uint64, prev_idx=np.uint32,
+                    next_off=np.uint64, next_idx=np.uint32, src_off=np.uint64, src_idx=np.uint32,
+                    snk_off=np.uint64, snk_idx=np.uint32, back_translation=np.uint64)
+
+
+class GraphSide:
+    """numpy holder for one cl_graph_side"""
+
+    def __init__(self, **arrays):
+        for name, dt in _SIDE_DTYPES.items():
+            a = arrays.get(name)
+            setattr(self, name, None if a is None else np.ascontiguousarray(a, dtype=dt))
+
+    @property
+    def n_problems(self):
+        return len(self.node_off) - 1
+
+    def as_c(self):
+        c = GraphSideC()
+        for name in _SIDE_DTYPES:
+            a = getattr(self, name)
+            setattr(c, name, None if a is None else a.ctypes.data)
+        return c
+
+    def problem(self, k):
+        """(n, label, prev lists, sources, sinks) of problem k as python objects (debug / tiny tests)"""
+        b, e = int(self.node_off[k]), int(self.node_off[k + 1])
+        prevs = [list(map(int, self.prev_idx[int(self.prev_off[v]):int(self.prev_off[v + 1])])) for v in range(b, e)]
+        src = list(map(int, self.src_idx[int(self.src_off[k]):int(self.src_off[k + 1])]))
+        snk = list(map(int, self.snk_idx[int(self.snk_off[k]):int(self.snk_off[k + 1])]))
+        return e - b, bytes(self.label[b:e]), prevs, src, snk
+
+
+class StitchBatch:
+    """numpy holder for a cl_stitch_batch"""
+
+    def __init__(self, side1, side2, only_deletion_alns=None):
+        assert side1.n_problems == side2.n_problems
+        self.side = (side1, side2)
+        self.only_deletion_alns = (None if only_deletion_alns is None
+                                   else np.ascontiguousarray(only_deletion_alns, dtype=np.uint8))
+
+    @property
+    def n_problems(self):
+        return self.side[0].n_problems
+
+    def sizes(self):
+        n1 = np.diff(self.side[0].node_off).astype(np.int64)
+        n2 = np.diff(self.side[1].node_off).astype(np.int64)
+        return n1, n2
+
+    def dp_cells(self):
+        n1, n2 = self.sizes()
+        m = (n1 > 0) & (n2 > 0)
+        return int(((n1[m] + 1) * (n2[m] + 1)).sum())
+
+    def as_c(self):
+        c = StitchBatchC()
+        c.n_problems = self.n_problems
+        c.side[0] = self.side[0].as_c()
+        c.side[1] = self.side[1].as_c()
+        c.only_deletion_alns = None if self.only_deletion_alns is None else self.only_deletion_alns.ctypes.data
+        return c
+
+    def subset(self, idx):
+        """a new batch holding the problems idx (in that order)"""
+        idx = np.asarray(idx, dtype=np.int64)
+        sides = []
+        for s in self.side:
+            sides.append(_subset_side(s, idx))
+        od = None if self.only_deletion_alns is None else self.only_deletion_alns[idx]
+        return StitchBatch(sides[0], sides[1], od)
+
+    @staticmethod
+    def concat(batches):
+        sides = []
+        for si in range(2):
+            sides.append(_concat_sides([b.side[si] for b in batches]))
+        if any(b.only_deletion_alns is not None for b in batches):
+            od = np.concatenate([b.only_deletion_alns if b.only_deletion_alns is not None
+                                 else np.zeros(b.n_problems, np.uint8) for b in batches])
+        else:
+            od = None
+        return StitchBatch(sides[0], sides[1], od)
+
+
+def _ranges(starts, lens):
+    """concatenated aranges: for each i, starts[i] .. starts[i]+lens[i]-1"""
+    lens = np.asarray(lens, dtype=np.int64)
+    starts = np.asarray(starts, dtype=np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    out_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    rep = np.repeat(starts - out_off, lens)
+    return rep + np.arange(total, dtype=np.int64)
+
+
+def _subset_side(s, idx):
+    nb = s.node_off[idx].astype(np.int64)
+    nl = (s.node_off[idx + 1] - s.node_off[idx]).astype(np.int64)
+    nodes = _ranges(nb, nl)
+    out = {}
+    out["node_off"] = np.concatenate([[0], np.cumsum(nl)]).astype(np.uint64)
+    out["label"] = s.label[nodes]
+    for pre in ("prev", "next"):
+        off = getattr(s, pre + "_off")
+        if off is None:
+            continue
+        ib = off[nodes].astype(np.int64)
+        il = (off[nodes + 1] - off[nodes]).astype(np.int64) if len(nodes) else np.zeros(0, np.int64)
+        out[pre + "_off"] = np.concatenate([[0], np.cumsum(il)]).astype(np.uint64)
+        out[pre + "_idx"] = getattr(s, pre + "_idx")[_ranges(ib, il)]
+    for pre in ("src", "snk"):
+        off = getattr(s, pre + "_off")
+        ib = off[idx].astype(np.int64)
+        il = (off[idx + 1] - off[idx]).astype(np.int64)
+        out[pre + "_off"] = np.concatenate([[0], np.cumsum(il)]).astype(np.uint64)
+        out[pre + "_idx"] = getattr(s, pre + "_idx")[_ranges(ib, il)]
+    if s.back_translation is not None:
+        out["back_translation"] = s.back_translation[nodes]
+    return GraphSide(**out)
+
+
+def _concat_sides(sides):
+    out = {}
+    out["label"] = np.concatenate([s.label for s in sides])
+
+    def cat_off(name):
+        parts, base = [np.zeros(1, np.uint64)], np.uint64(0)
+        for s in sides:
+            o = getattr(s, name)
+            parts.append(o[1:] + base)
+            base = base + o[-1]
+        return np.concatenate(parts)
+
+    out["node_off"] = cat_off("node_off")
+    for pre in ("prev", "next"):
+        if any(getattr(s, pre + "_off") is None for s in sides):
+            continue
+        out[pre + "_off"] = cat_off(pre + "_off")
+        out[pre + "_idx"] = np.concatenate([getattr(s, pre + "_idx") for s in sides])
+    for pre in ("src", "snk"):
+        out[pre + "_off"] = cat_off(pre + "_off")
+        out[pre + "_idx"] = np.concatenate([getattr(s, pre + "_idx") for s in sides])
+    if all(s.back_translation is not None for s in sides):
+        out["back_translation"] = np.concatenate([s.back_translation for s in sides])
+    return GraphSide(**out)
+
+
+class StitchResult:
+    """numpy copy of a cl_stitch_result"""
+
+    def __init__(self, aln_off, pairs, score, route, num_pw):
+        self.aln_off, self.pairs, self.score, self.route, self.num_pw = aln_off, pairs, score, route, num_pw
+
+    @property
+    def n_problems(self):
+        return len(self.aln_off) - 1
+
+    def alignment(self, k):
+        b, e = int(self.aln_off[k]), int(self.aln_off[k + 1])
+        return self.pairs[b:e]
+
+    @staticmethod
+    def from_c(rc):
+        n = int(rc.n_problems)
+        aln_off = np.ctypeslib.as_array(rc.aln_off, shape=(n + 1,)).copy()
+        tot = int(aln_off[-1])
+        pairs = (np.ctypeslib.as_array(rc.pairs, shape=(max(tot, 1) * 2,))[:tot * 2].copy().reshape(tot, 2))
+        score = np.ctypeslib.as_array(rc.score, shape=(max(n, 1),))[:n].copy()
+        route = np.ctypeslib.as_array(rc.route, shape=(max(n, 1),))[:n].copy()
+        num_pw = np.ctypeslib.as_array(rc.num_pw, shape=(max(n, 1),))[:n].copy()
+        return StitchResult(aln_off, pairs, score, route, num_pw)
+
+    def same_as(self, other, check_score=True, check_route=True):
+        """None if identical, else a short description of the first difference"""
+        if self.n_problems != other.n_problems:
+            return "n_problems %d vs %d" % (self.n_problems, other.n_problems)
+        if not np.array_equal(self.aln_off, other.aln_off):
+            k = int(np.argmax(np.diff(self.aln_off.astype(np.int64)) != np.diff(other.aln_off.astype(np.int64))))
+            return "alignment length differs first at problem %d" % k
+        if not np.array_equal(self.pairs, other.pairs):
+            row = int(np.argmax((self.pairs != other.pairs).any(axis=1)))
+            k = int(np.searchsorted(self.aln_off, row, side="right") - 1)
+            return "aligned pair differs first at problem %d (pair %d): %s vs %s" % (
+                k, row - int(self.aln_off[k]), self.pairs[row], other.pairs[row])
+        if check_route and not np.array_equal(self.route, other.route):
+            return "route differs at problem %d" % int(np.argmax(self.route != other.route))
+        if check_route and not np.array_equal(self.num_pw, other.num_pw):
+            return "num_pw differs at problem %d" % int(np.argmax(self.num_pw != other.num_pw))
+        if check_score:
+            m = self.route == 0
+            if not np.array_equal(self.score[m], other.score[m]):
+                k = int(np.flatnonzero(m)[np.argmax(self.score[m] != other.score[m])])
+                return "score differs at problem %d: %d vs %d" % (k, self.score[k], other.score[k])
+        return None
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP product library; raises if it is not built (no fallback by design)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("centrolign_amd HIP library not built: %s is missing "
+                          "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C centrolign_amd/csrc`)" % p)
+    lib = C.CDLL(p)
+    lib.cl_abi_version.restype = C.c_int
+    lib.cl_device_count.restype = C.c_int
+    lib.cl_context_create.restype = C.c_void_p
+    lib.cl_context_create.argtypes = [C.c_int]
+    lib.cl_context_destroy.argtypes = [C.c_void_p]
+    lib.cl_last_error.restype = C.c_char_p
+    lib.cl_last_error.argtypes = [C.c_void_p]
+    lib.cl_device_name.restype = C.c_char_p
+    lib.cl_device_name.argtypes = [C.c_void_p]
+    lib.cl_stitch_params_default.argtypes = [C.POINTER(StitchParams)]
+    lib.cl_po_poa_batch.restype = C.c_int
+    lib.cl_po_poa_batch.argtypes = [C.c_void_p, C.POINTER(StitchBatchC), C.c_void_p, C.POINTER(AlignParams),
+                                    C.POINTER(StitchResultC)]
+    lib.cl_stitch_batch_align.restype = C.c_int
+    lib.cl_stitch_batch_align.argtypes = [C.c_void_p, C.POINTER(StitchBatchC), C.POINTER(StitchParams),
+                                          C.POINTER(StitchResultC)]
+    lib.cl_stitch_result_free.argtypes = [C.POINTER(StitchResultC)]
+    lib.cl_stitch_plan_create.restype = C.c_int
+    lib.cl_stitch_plan_create.argtypes = [C.c_void_p, C.POINTER(StitchBatchC), C.POINTER(StitchParams), C.c_void_p,
+                                          C.POINTER(C.c_void_p)]
+    lib.cl_stitch_plan_execute.restype = C.c_int
+    lib.cl_stitch_plan_execute.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cl_stitch_plan_sync.restype = C.c_int
+    lib.cl_stitch_plan_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.cl_stitch_plan_collect.restype = C.c_int
+    lib.cl_stitch_plan_collect.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(StitchResultC)]
+    lib.cl_stitch_plan_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cl_stitch_plan_stats.restype = C.c_int
+    lib.cl_stitch_plan_stats.argtypes = [C.c_void_p, C.POINTER(PlanStats)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
+    "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
+    "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_sync",
+    "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
+]
+
+
+class Plan:
+    def __init__(self, ctx, handle, batch):
+        self.ctx, self.handle, self._batch = ctx, handle, batch
+
+    def execute(self):
+        self.ctx._check(self.ctx.lib.cl_stitch_plan_execute(self.ctx.handle, self.handle))
+
+    def sync(self):
+        ms = C.c_float(0)
+        self.ctx._check(self.ctx.lib.cl_stitch_plan_sync(self.ctx.handle, self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def collect(self):
+        rc = StitchResultC()
+        self.ctx._check(self.ctx.lib.cl_stitch_plan_collect(self.ctx.handle, self.handle, C.byref(rc)))
+        try:
+            return StitchResult.from_c(rc)
+        finally:
+            self.ctx.lib.cl_stitch_result_free(C.byref(rc))
+
+    def stats(self):
+        st = PlanStats()
+        self.ctx._check(self.ctx.lib.cl_stitch_plan_stats(self.handle, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in PlanStats._fields_}
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.lib.cl_stitch_plan_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Context:
+    """cl_context: one HIP device + stream.  Raises ClError(CL_ERR_NO_DEVICE) without a GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = self.lib.cl_context_create(device)
+        if not self.handle:
+            msg = self.lib.cl_last_error(None)
+            raise ClError(-3, msg.decode() if msg else "")
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.cl_last_error(self.handle)
+            raise ClError(rc, msg.decode() if msg else "")
+
+    def device_name(self):
+        return self.lib.cl_device_name(self.handle).decode()
+
+    def po_poa_batch(self, batch, num_pw, params):
+        num_pw = np.ascontiguousarray(num_pw, dtype=np.uint8)
+        assert len(num_pw) == batch.n_problems
+        bc, rc = batch.as_c(), StitchResultC()
+        self._check(self.lib.cl_po_poa_batch(self.handle, C.byref(bc), num_pw.ctypes.data, C.byref(params), C.byref(rc)))
+        try:
+            return StitchResult.from_c(rc)
+        finally:
+            self.lib.cl_stitch_result_free(C.byref(rc))
+
+    def stitch_batch_align(self, batch, params=None):
+        params = params or default_stitch_params()
+        bc, rc = batch.as_c(), StitchResultC()
+        self._check(self.lib.cl_stitch_batch_align(self.handle, C.byref(bc), C.byref(params), C.byref(rc)))
+        try:
+            return StitchResult.from_c(rc)
+        finally:
+            self.lib.cl_stitch_result_free(C.byref(rc))
+
+    def plan(self, batch, params=None, force_num_pw=None):
+        params = params or default_stitch_params()
+        bc = batch.as_c()
+        h = C.c_void_p()
+        f = None
+        if force_num_pw is not None:
+            f = np.ascontiguousarray(force_num_pw, dtype=np.uint8)
+        self._check(self.lib.cl_stitch_plan_create(self.handle, C.byref(bc), C.byref(params),
+                                                   None if f is None else f.ctypes.data, C.byref(h)))
+        return Plan(self, h, batch)
+
+    def close(self):
+        if self.handle:
+            self.lib.cl_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,255 @@
+"""Synthetic inputs for the stitch path (no real centromeres are available).
+
+* `hor_sequences`      — HOR-like tandem arrays: 171-bp monomer x 12-mer HOR, tiled and mutated (the family
+                         BASELINE.md's CPU numbers were measured on).
+* `random_dag_batch`   — random graph pairs with bubbles / multiple sources and sinks, for parity tests.
+* `linear_batch`       — pairwise (chain x chain) stitch subproblems of chosen sizes.
+* `hor_stitch_batch`   — the between-anchor subproblem batch of a synthetic HOR pair, derived from the known
+                         true alignment of the simulated pair: maximal exact-match runs >= `min_anchor` play
+                         the anchors, the stretches between them are the stitch subproblems.  It reproduces
+                         the shape of the batch the reference extracts for the same pair (thousands of small
+                         chain x chain matrices, a few hundred large ones) without needing the
+                         reference's match finder and chainer on the GPU box.
+"""
+import random
+
+import numpy as np
+
+from .capi import GraphSide, StitchBatch
+
+_B = "ACGT"
+_ENC = {"A": 1, "C": 2, "G": 3, "T": 4}  # any injective code works: the DP only compares labels
+
+
+def encode(seq):
+    lut = np.zeros(256, dtype=np.uint8)
+    for c, v in _ENC.items():
+        lut[ord(c)] = v
+    return lut[np.frombuffer(seq.encode(), dtype=np.uint8)]
+
+
+def _mut_track(rng, s, r):
+    """mutate s at rate r (80% substitution, 10% deletion, 10% insertion); also returns, for every output
+    position, the index in s it descends from (or -1 for inserted bases)"""
+    out, src = [], []
+    for i, c in enumerate(s):
+        x = rng.random()
+        if x < r * 0.8:
+            out.append(rng.choice(_B)); src.append(i)
+        elif x < r * 0.9:
+            continue
+        elif x < r:
+            out.append(c); src.append(i)
+            out.append(rng.choice(_B)); src.append(-1)
+        else:
+            out.append(c); src.append(i)
+    return out, src
+
+
+def hor_sequences(seed, total_len, n_seq, mono_len=171, hor_n=12, mono_div=0.25, hor_div=0.02, seq_div=0.005,
+                  indel_hor=2, track=False):
+    """n_seq HOR-array sequences descending from one ancestor array.  With track=True also returns per
+    sequence the ancestor coordinate of every base (-1 = inserted), which gives the true alignment."""
+    rng = random.Random(seed)
+    base = [rng.choice(_B) for _ in range(mono_len)]
+    monos = [_mut_track(rng, base, mono_div)[0] for _ in range(hor_n)]
+    hor = [c for m in monos for c in m]
+    n_hor = total_len // len(hor) + 1
+    anc = []
+    for _ in range(n_hor):
+        anc.extend(_mut_track(rng, hor, hor_div)[0])
+    anc = anc[:total_len]
+    seqs, srcs = [], []
+    for _ in range(n_seq):
+        s, src = _mut_track(rng, anc, seq_div)
+        for _ in range(indel_hor):
+            p = rng.randrange(0, max(1, len(s) - len(hor)))
+            p -= p % len(hor)
+            if rng.random() < 0.5:
+                s = s[:p] + s[p + len(hor):]
+                src = src[:p] + src[p + len(hor):]
+            else:
+                s = s[:p] + s[p:p + len(hor)] + s[p:]
+                src = src[:p] + [-1] * len(hor) + src[p:]
+        seqs.append("".join(s))
+        srcs.append(np.array(src, dtype=np.int64))
+    return (seqs, srcs) if track else seqs
+
+
+def write_fasta(path, seqs, names=None):
+    with open(path, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">%s\n" % (names[i] if names else "seq%d" % i))
+            for j in range(0, len(s), 80):
+                f.write(s[j:j + 80] + "\n")
+
+
+class _SideBuilder:
+    def __init__(self):
+        self.node_off = [0]
+        self.label, self.prev_off, self.prev_idx = [], [0], []
+        self.next_off, self.next_idx = [0], []
+        self.src_off, self.src_idx, self.snk_off, self.snk_idx = [0], [], [0], []
+        self.back = []
+        self._ne = 0
+        self._np = 0
+
+    def add_chain(self, labels, back0):
+        """a simple path graph: node i -> i+1; source = node 0, sink = last node"""
+        n = len(labels)
+        self.label.append(np.asarray(labels, dtype=np.uint8))
+        ne = max(n - 1, 0)
+        self.prev_idx.append(np.arange(0, ne, dtype=np.uint32))
+        self.next_idx.append(np.arange(1, n, dtype=np.uint32))
+        # cumulative list lengths after each node: prev -> v, next -> min(v+1, n-1)
+        self.prev_off.append(self._np + np.arange(0, n, dtype=np.int64))
+        self.next_off.append(self._ne + np.minimum(np.arange(1, n + 1, dtype=np.int64), ne))
+        self._np += ne
+        self._ne += ne
+        self.node_off.append(self.node_off[-1] + n)
+        if n:
+            self.src_idx.append(0); self.snk_idx.append(n - 1)
+        self.src_off.append(len(self.src_idx)); self.snk_off.append(len(self.snk_idx))
+        self.back.append(np.arange(back0, back0 + n, dtype=np.uint64))
+
+    def add_graph(self, labels, edges, sources, sinks, back=None):
+        """general DAG: edges is the edge-insertion sequence [(u, v)...] (defines previous()/next() order)"""
+        n = len(labels)
+        prevs = [[] for _ in range(n)]
+        nexts = [[] for _ in range(n)]
+        for u, v in edges:
+            prevs[v].append(u); nexts[u].append(v)
+        self.label.append(np.asarray(labels, dtype=np.uint8))
+        po, no = [], []
+        for v in range(n):
+            self._np += len(prevs[v]); po.append(self._np)
+            self._ne += len(nexts[v]); no.append(self._ne)
+        self.prev_idx.append(np.array([u for l in prevs for u in l], dtype=np.uint32))
+        self.next_idx.append(np.array([u for l in nexts for u in l], dtype=np.uint32))
+        self.prev_off.append(np.array(po, dtype=np.int64)); self.next_off.append(np.array(no, dtype=np.int64))
+        self.node_off.append(self.node_off[-1] + n)
+        self.src_idx.extend(sources); self.snk_idx.extend(sinks)
+        self.src_off.append(len(self.src_idx)); self.snk_off.append(len(self.snk_idx))
+        self.back.append(np.arange(n, dtype=np.uint64) if back is None else np.asarray(back, dtype=np.uint64))
+
+    def finish(self):
+        cat = lambda parts, dt: (np.concatenate([np.asarray(p, dtype=dt).ravel() for p in parts])
+                                 if parts else np.zeros(0, dt))
+        return GraphSide(
+            node_off=np.array(self.node_off, np.uint64), label=cat(self.label, np.uint8),
+            prev_off=np.concatenate([[0], cat(self.prev_off[1:], np.int64)]).astype(np.uint64),
+            prev_idx=cat(self.prev_idx, np.uint32),
+            next_off=np.concatenate([[0], cat(self.next_off[1:], np.int64)]).astype(np.uint64),
+            next_idx=cat(self.next_idx, np.uint32),
+            src_off=np.array(self.src_off, np.uint64), src_idx=np.array(self.src_idx, np.uint32),
+            snk_off=np.array(self.snk_off, np.uint64), snk_idx=np.array(self.snk_idx, np.uint32),
+            back_translation=cat(self.back, np.uint64))
+
+
+def linear_batch(sizes, seed=0, divergence=0.1):
+    """chain x chain problems; sizes = [(n1, n2), ...]; second sequence is a mutated copy of the first"""
+    rng = np.random.default_rng(seed)
+    b1, b2 = _SideBuilder(), _SideBuilder()
+    for n1, n2 in sizes:
+        a = rng.integers(1, 5, size=n1, dtype=np.uint8)
+        if n2 <= n1:
+            b = a[:n2].copy()
+        else:
+            b = np.concatenate([a, rng.integers(1, 5, size=n2 - n1, dtype=np.uint8)])
+        mut = rng.random(n2) < divergence
+        b[mut] = rng.integers(1, 5, size=int(mut.sum()), dtype=np.uint8)
+        b1.add_chain(a, 0); b2.add_chain(b, 0)
+    return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
+
+
+def _random_dag(rng, n, extra_edge_p, skip_max, n_alt_src, n_alt_snk, alphabet):
+    """a connected DAG on n nodes given in a random (non-topological) id order.  Built as a backbone chain plus
+    forward skip edges, then ids are shuffled; the edge insertion order is shuffled too, so previous() orders
+    are arbitrary.  Every node lies on a source->sink walk, as in extracted stitch graphs
+    (include/centrolign/subgraph_extraction.hpp:85-91)."""
+    topo_edges = [(i, i + 1) for i in range(n - 1)]
+    for i in range(n):
+        if rng.random() < extra_edge_p:
+            j = i + 2 + int(rng.integers(0, skip_max))
+            if j < n:
+                topo_edges.append((i, j))
+    topo_edges = list(dict.fromkeys(topo_edges))
+    perm = rng.permutation(n)  # topo position -> node id
+    order = rng.permutation(len(topo_edges))
+    edges = [(int(perm[topo_edges[k][0]]), int(perm[topo_edges[k][1]])) for k in order]
+    sources = [int(perm[0])]
+    sinks = [int(perm[n - 1])]
+    # extra sources/sinks: like nodes adjacent to the anchor end through a bubble
+    for _ in range(n_alt_src):
+        c = int(perm[int(rng.integers(0, max(1, min(n, 4))))])
+        if c not in sources:
+            sources.append(c)
+    for _ in range(n_alt_snk):
+        c = int(perm[n - 1 - int(rng.integers(0, max(1, min(n, 4))))])
+        if c not in sinks:
+            sinks.append(c)
+    rng.shuffle(sources); rng.shuffle(sinks)
+    labels = rng.integers(1, 1 + alphabet, size=n, dtype=np.uint8)
+    return labels, edges, [int(s) for s in sources], [int(s) for s in sinks]
+
+
+def random_dag_batch(n_problems, seed=0, max_n=40, extra_edge_p=0.3, skip_max=4, alphabet=4, allow_empty=True,
+                     related=True):
+    """random graph pairs; graph2 is (usually) a relabelled/perturbed sibling of graph1 so alignments have
+    long diagonals and plenty of score ties"""
+    rng = np.random.default_rng(seed)
+    b1, b2 = _SideBuilder(), _SideBuilder()
+    for k in range(n_problems):
+        n1 = int(rng.integers(0 if allow_empty else 1, max_n + 1))
+        n2 = int(rng.integers(0 if allow_empty else 1, max_n + 1))
+        if allow_empty and rng.random() < 0.05:
+            n2 = 0
+        for bld, n in ((b1, n1), (b2, n2)):
+            if n == 0:
+                bld.add_graph(np.zeros(0, np.uint8), [], [], [], None)
+                continue
+            lab, edges, src, snk = _random_dag(rng, n, extra_edge_p, skip_max, int(rng.integers(0, 3)),
+                                               int(rng.integers(0, 3)), alphabet)
+            bld.add_graph(lab, edges, src, snk, rng.integers(0, 1 << 40, size=n, dtype=np.uint64))
+    return StitchBatch(b1.finish(), b2.finish(), (rng.random(n_problems) < 0.2).astype(np.uint8))
+
+
+def hor_stitch_batch(seed, total_len, min_anchor=20, seq_div=0.005, hor_div=0.02, indel_hor=2, max_cells=40000000):
+    """between-anchor subproblems of a simulated HOR pair (see module docstring).  Returns (batch, info)."""
+    (s1, s2), (a1, a2) = hor_sequences(seed, total_len, 2, seq_div=seq_div, hor_div=hor_div, indel_hor=indel_hor,
+                                       track=True)
+    e1, e2 = encode(s1), encode(s2)
+    # true alignment: positions of the two sequences that descend from the same ancestor base
+    pos1 = np.flatnonzero(a1 >= 0); pos2 = np.flatnonzero(a2 >= 0)
+    anc1, anc2 = a1[pos1], a2[pos2]
+    # a HOR duplication keeps ancestry only for one copy, so ancestor coordinates are strictly increasing
+    common, i1, i2 = np.intersect1d(anc1, anc2, assume_unique=True, return_indices=True)
+    p1, p2 = pos1[i1], pos2[i2]
+    good = e1[p1] == e2[p2]
+    # maximal runs of consecutive (p1+1, p2+1) matching pairs
+    brk = np.ones(len(p1), dtype=bool)
+    brk[1:] = (np.diff(p1) != 1) | (np.diff(p2) != 1) | ~good[1:] | ~good[:-1]
+    run_id = np.cumsum(brk) - 1
+    run_start = np.flatnonzero(brk)
+    run_len = np.diff(np.concatenate([run_start, [len(p1)]]))
+    keep = (run_len >= min_anchor) & good[run_start]
+    anchors = [(int(p1[s]), int(p2[s]), int(l)) for s, l, k in zip(run_start, run_len, keep) if k]
+    b1, b2 = _SideBuilder(), _SideBuilder()
+    only_del = []
+    prev1, prev2 = 0, 0
+    n_skipped = 0
+    gaps = []
+    for (x1, x2, l) in anchors + [(len(e1), len(e2), 0)]:
+        g1, g2 = (prev1, x1), (prev2, x2)
+        gaps.append((g1, g2))
+        prev1, prev2 = x1 + l, x2 + l
+    for idx, (g1, g2) in enumerate(gaps):
+        n1, n2 = g1[1] - g1[0], g2[1] - g2[0]
+        if (n1 + 1) * (n2 + 1) > max_cells:
+            n_skipped += 1
+            continue
+        b1.add_chain(e1[g1[0]:g1[1]], g1[0]); b2.add_chain(e2[g2[0]:g2[1]], g2[0])
+        only_del.append(1 if idx in (0, len(gaps) - 1) else 0)
+    batch = StitchBatch(b1.finish(), b2.finish(), np.array(only_del, np.uint8))
+    info = dict(n_anchors=len(anchors), len1=len(e1), len2=len(e2), n_skipped=n_skipped)
+    return batch, info

@@ -1,0 +1,181 @@
+/*
+ * centrolign_amd.h — C ABI of the MI355X-native anchor-and-stitch hot path.
+ *
+ * This is the drop-in boundary for centrolign's between-anchor alignment path.  centrolign has no
+ * FFI layer of its own (it is one C++ library), so every entry point below names the C++ seam of
+ * the reference that it replaces (paths relative to the reference repository root):
+ *
+ *   cl_po_poa_batch          <-> po_poa<NumPW>(graph1, graph2, sources1, sources2, sinks1, sinks2,
+ *                                params, score_out)                include/centrolign/alignment.hpp:78-85
+ *                                (implementation po_poa_internal<true,NumPW>, alignment.hpp:753-1163),
+ *                                applied to a whole batch of independent subproblems.
+ *   cl_stitch_batch_align    <-> the loop of Stitcher::subalign calls inside Stitcher::stitch /
+ *                                Stitcher::internal_stitch        include/centrolign/stitcher.hpp:157-203,216-231
+ *                                i.e. subalign (src/stitcher.cpp:24-78) + do_alignment<NumPW>
+ *                                (stitcher.hpp:237-370) + translate (src/alignment.cpp:26-45) for every
+ *                                extracted SubGraphInfo pair.
+ *   cl_stitch_plan_*         <-> the same, split into prepare / execute / collect so that a caller can keep
+ *                                a batch resident in HBM, overlap batches, and time the device part.
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the ABI (negative int = error, text via
+ * cl_last_error); all node ids are SUBGRAPH-LOCAL ids exactly as in SubGraphInfo
+ * (include/centrolign/subgraph_extraction.hpp:14-33); neighbour lists keep BaseGraph::previous()/next()
+ * order because the reference's traceback tie-breaks depend on it (alignment.hpp:1069-1136).
+ * Results are bit-identical to the reference: same int32 scores, same AlignedPair sequence.
+ */
+#ifndef CENTROLIGN_AMD_H
+#define CENTROLIGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CL_ABI_VERSION 1
+
+/* AlignedPair::gap (src/alignment.cpp:11) */
+#define CL_GAP UINT64_MAX
+
+/* error codes */
+enum {
+    CL_OK = 0,
+    CL_ERR_INVALID_ARGUMENT = -1,   /* malformed batch (offsets not monotone, id out of range, ...) */
+    CL_ERR_BAD_GAP_PARAMS = -2,     /* src/stitcher.cpp:34-37: gap_open must increase, gap_extend decrease */
+    CL_ERR_NO_DEVICE = -3,          /* no HIP device / HIP runtime failure at context creation */
+    CL_ERR_HIP = -4,                /* a HIP call failed; see cl_last_error */
+    CL_ERR_OUT_OF_MEMORY = -5,
+    CL_ERR_UNSUPPORTED_ROUTE = -6,  /* subproblem routed to a heuristic this build does not provide */
+    CL_ERR_CYCLIC_GRAPH = -7,       /* a subgraph is not a DAG (topological_order.hpp:56 asserts) */
+    CL_ERR_UNREACHABLE_SINK = -8    /* no (source..sink) connection; the reference has UB here (alignment.hpp:76-77) */
+};
+
+/* which algorithm a subproblem was routed to; same meaning as the reference's instrument tags
+ * (stitcher.hpp:274-358: "pd1","pd2","po","ad1","ad2","w","u") */
+enum {
+    CL_ROUTE_PO_POA = 0,
+    CL_ROUTE_PURE_DELETION_1 = 1,   /* graph2 empty  -> pure_deletion_alignment(graph1) */
+    CL_ROUTE_PURE_DELETION_2 = 2,   /* graph1 empty  -> pure_deletion_alignment(graph2) + swap_graphs */
+    CL_ROUTE_DELETION_WFA_1 = 3,
+    CL_ROUTE_DELETION_WFA_2 = 4,
+    CL_ROUTE_PWFA = 5,
+    CL_ROUTE_GREEDY_PARTIAL = 6
+};
+
+/* AlignmentParameters<3> (alignment.hpp:56-65).  A NumPW<3 alignment uses the leading NumPW
+ * (gap_open, gap_extend) pairs, as truncate_parameters does (alignment.hpp:208-219). */
+typedef struct cl_align_params {
+    uint32_t match;
+    uint32_t mismatch;
+    uint32_t gap_open[3];
+    uint32_t gap_extend[3];
+} cl_align_params;
+
+/* public tunables of Stitcher (stitcher.hpp:48-64) that steer subalign/do_alignment */
+typedef struct cl_stitch_params {
+    cl_align_params alignment_params;
+    uint64_t max_trivial_size;
+    uint64_t min_wfa_size;
+    uint64_t max_wfa_size;
+    double   max_wfa_ratio;
+    uint64_t wfa_pruning_dist;
+    uint64_t deletion_alignment_ratio;
+    uint64_t deletion_alignment_short_max_size;
+    uint64_t deletion_alignment_long_min_size;
+} cl_stitch_params;
+
+/* Fills the values the centrolign CLI runs with (src/parameters.cpp:74-85), NOT the class defaults. */
+void cl_stitch_params_default(cl_stitch_params* p);
+
+/*
+ * One side (graph1 or graph2) of every subproblem of a batch, concatenated.
+ * Problem k owns nodes [node_off[k], node_off[k+1]) of label/prev_off/back_translation; ids stored in
+ * prev_idx/next_idx/src_idx/snk_idx are local to the problem (0 .. node count-1).
+ * prev_off/next_off index prev_idx/next_idx globally and have node_off[n_problems]+1 entries.
+ */
+typedef struct cl_graph_side {
+    const uint64_t* node_off;          /* [n_problems + 1] */
+    const uint8_t*  label;             /* BaseGraph::label(node) */
+    const uint64_t* prev_off;          /* CSR of BaseGraph::previous(node), order preserved */
+    const uint32_t* prev_idx;
+    const uint64_t* next_off;          /* CSR of BaseGraph::next(node); may be NULL (derived from prev) */
+    const uint32_t* next_idx;
+    const uint64_t* src_off;           /* [n_problems + 1] SubGraphInfo::sources, order preserved */
+    const uint32_t* src_idx;
+    const uint64_t* snk_off;           /* [n_problems + 1] SubGraphInfo::sinks, order preserved */
+    const uint32_t* snk_idx;
+    const uint64_t* back_translation;  /* SubGraphInfo::back_translation; NULL => results keep local ids */
+} cl_graph_side;
+
+typedef struct cl_stitch_batch {
+    uint64_t       n_problems;
+    cl_graph_side  side[2];
+    const uint8_t* only_deletion_alns; /* [n_problems] 4th argument of Stitcher::subalign; NULL => all 0 */
+} cl_stitch_batch;
+
+/* Library-allocated result; release with cl_stitch_result_free.  pairs has the memory layout of
+ * centrolign::AlignedPair[] (two uint64_t: node_id1, node_id2; CL_GAP marks a gap). */
+typedef struct cl_stitch_result {
+    uint64_t  n_problems;
+    uint64_t* aln_off;   /* [n_problems + 1], in pairs */
+    uint64_t* pairs;     /* [2 * aln_off[n_problems]] */
+    int64_t*  score;     /* [n_problems] score_out of the routed aligner (po_poa: best sink-pair M) */
+    uint8_t*  route;     /* [n_problems] CL_ROUTE_* */
+    uint8_t*  num_pw;    /* [n_problems] NumPW chosen by subalign (src/stitcher.cpp:47-64) */
+} cl_stitch_result;
+
+typedef struct cl_context cl_context;
+typedef struct cl_stitch_plan cl_stitch_plan;
+
+int         cl_abi_version(void);
+int         cl_device_count(void);
+/* Binds a HIP device (gfx950), creates the stream all work of this context runs on. NULL on failure
+ * (reason via cl_last_error(NULL)). Contexts are independent; one context is not thread-safe. */
+cl_context* cl_context_create(int device_ordinal);
+void        cl_context_destroy(cl_context* ctx);
+const char* cl_last_error(const cl_context* ctx);
+const char* cl_device_name(const cl_context* ctx);
+
+/* po_poa<NumPW> for every problem of the batch; num_pw[k] in {1,2,3}. */
+int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw,
+                    const cl_align_params* params, cl_stitch_result* out);
+
+/* Stitcher::subalign for every problem of the batch (NumPW choice, routing, translate). */
+int cl_stitch_batch_align(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params,
+                          cl_stitch_result* out);
+
+void cl_stitch_result_free(cl_stitch_result* r);
+
+/* --- split form: prepare once, execute many times, collect ------------------------------------------- */
+/* Validates, routes, topologically orders and packs the batch, and copies it to HBM (synchronous).
+ * force_num_pw may be NULL (subalign semantics) or per-problem NumPW with every non-empty problem forced
+ * to PO-POA (cl_po_poa_batch semantics). */
+int  cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params,
+                           const uint8_t* force_num_pw, cl_stitch_plan** plan_out);
+/* Enqueues the DP + traceback kernels for the whole plan on the context's stream; asynchronous. */
+int  cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* plan);
+/* Waits for the stream; returns the device time of the LAST execute in ms (HIP events on the context's
+ * stream) through *ms_out if not NULL. */
+int  cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* plan, float* ms_out);
+/* Copies alignments back (synchronous) and assembles the result. */
+int  cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* plan, cl_stitch_result* out);
+void cl_stitch_plan_destroy(cl_context* ctx, cl_stitch_plan* plan);
+
+/* plan statistics, for measurement */
+typedef struct cl_plan_stats {
+    uint64_t n_problems;
+    uint64_t n_po_poa;           /* problems routed to the device PO-POA kernels */
+    uint64_t dp_cells;           /* sum (n1+1)*(n2+1) over those */
+    uint64_t dp_bytes;           /* sum (n1+1)*(n2+1)*sizeof(cell_t<NumPW>) = 4*(1+2*NumPW) B per cell */
+    uint64_t n_linear;           /* PO-POA problems whose two graphs are simple chains */
+    uint64_t max_cells;          /* largest single matrix */
+    uint64_t workspace_bytes;    /* HBM bytes held by the plan */
+    uint64_t n_launches;         /* kernel launches per execute */
+} cl_plan_stats;
+int cl_stitch_plan_stats(const cl_stitch_plan* plan, cl_plan_stats* stats_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENTROLIGN_AMD_H */

@@ -1,0 +1,149 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes bindings for the CPU oracle (oracle/popoa_oracle.c) and, when it
+has been built in this container, the compiled reference (oracle/_ref/libref_driver.so, see
+oracle/Makefile).  Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from centrolign_amd.capi import (AlignParams, StitchParams, StitchBatchC, StitchResultC, StitchResult,
+                                 GraphSide, StitchBatch, default_stitch_params)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(_HERE, "_build", "libcl_oracle.so")
+REF_LIB = os.path.join(_HERE, "_ref", "libref_driver.so")
+
+
+class CloGraph(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("label", C.c_void_p), ("prev_off", C.c_void_p), ("prev_idx", C.c_void_p),
+                ("next_off", C.c_void_p), ("next_idx", C.c_void_p), ("n_src", C.c_uint64), ("src", C.c_void_p),
+                ("n_snk", C.c_uint64), ("snk", C.c_void_p)]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+
+
+def build_ref():
+    """compile the reference from /root/reference (only possible in the build container)"""
+    subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
+
+
+_oracle = None
+_ref = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_LIB):
+            build_oracle()
+        lib = C.CDLL(ORACLE_LIB)
+        lib.clo_stitch_batch.restype = C.c_int
+        lib.clo_stitch_batch.argtypes = [C.POINTER(StitchBatchC), C.POINTER(StitchParams), C.c_void_p, C.POINTER(StitchResultC)]
+        lib.clo_result_free.argtypes = [C.POINTER(StitchResultC)]
+        lib.clo_po_poa.restype = C.c_int
+        lib.clo_po_poa.argtypes = [C.POINTER(CloGraph), C.POINTER(CloGraph), C.c_int, C.POINTER(AlignParams), C.c_void_p,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+        lib.clo_choose_num_pw.restype = C.c_int
+        lib.clo_choose_num_pw.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(AlignParams)]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            raise RuntimeError("compiled reference not present (oracle/_ref); run `make -C oracle ref` in the build container")
+        lib = C.CDLL(REF_LIB)
+        lib.ref_stitch_batch.restype = C.c_int
+        lib.ref_stitch_batch.argtypes = [C.POINTER(StitchBatchC), C.POINTER(StitchParams), C.c_void_p,
+                                         C.POINTER(StitchResultC), C.POINTER(C.c_double)]
+        lib.ref_result_free.argtypes = [C.POINTER(StitchResultC)]
+        lib.ref_po_poa.restype = C.c_int
+        lib.ref_po_poa.argtypes = [C.POINTER(CloGraph), C.POINTER(CloGraph), C.c_int, C.POINTER(AlignParams), C.c_void_p,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+        lib.ref_msa_dump.restype = C.c_int
+        lib.ref_msa_dump.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_longlong, C.c_int,
+                                     C.POINTER(C.c_double)]
+        _ref = lib
+    return _ref
+
+
+def _run_batch(fn, free, batch, params, force_num_pw, timed=False):
+    params = params or default_stitch_params()
+    bc, rc = batch.as_c(), StitchResultC()
+    f = None if force_num_pw is None else np.ascontiguousarray(force_num_pw, dtype=np.uint8)
+    secs = C.c_double(0)
+    args = [C.byref(bc), C.byref(params), None if f is None else f.ctypes.data, C.byref(rc)]
+    if timed:
+        args.append(C.byref(secs))
+    code = fn(*args)
+    if code != 0:
+        raise RuntimeError("oracle/reference batch failed with code %d" % code)
+    try:
+        res = StitchResult.from_c(rc)
+    finally:
+        free(C.byref(rc))
+    return (res, secs.value) if timed else res
+
+
+def oracle_stitch_batch(batch, params=None, force_num_pw=None):
+    """Stitcher::subalign per problem by the C restatement (po_poa per problem when force_num_pw is given)"""
+    lib = oracle_lib()
+    return _run_batch(lib.clo_stitch_batch, lib.clo_result_free, batch, params, force_num_pw)
+
+
+def ref_stitch_batch(batch, params=None, force_num_pw=None):
+    """the same through the compiled reference; returns (result, seconds inside reference calls)"""
+    lib = ref_lib()
+    return _run_batch(lib.ref_stitch_batch, lib.ref_result_free, batch, params, force_num_pw, timed=True)
+
+
+_DT = {0: np.uint8, 1: np.uint32, 2: np.uint64, 3: np.int64, 4: np.float64}
+
+
+def read_dump(path):
+    """parse the CLDUMP1 container written by ref_driver.cpp into {name: ndarray}"""
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    assert data[:8] == b"CLDUMP1\n"
+    pos = 8
+    while pos < len(data):
+        nl = int(np.frombuffer(data, np.uint32, 1, pos)[0]); pos += 4
+        name = data[pos:pos + nl].decode(); pos += nl
+        dt = _DT[data[pos]]; pos += 1
+        cnt = int(np.frombuffer(data, np.uint64, 1, pos)[0]); pos += 8
+        out[name] = np.frombuffer(data, dt, cnt, pos).copy(); pos += cnt * np.dtype(dt).itemsize
+    return out
+
+
+def batch_from_dump(d, prefix):
+    """StitchBatch + reference per-problem result from one merge of a dump"""
+    sides = []
+    for g in ("g1.", "g2."):
+        sides.append(GraphSide(**{k: d[prefix + g + k] for k in
+                                  ("node_off", "label", "prev_off", "prev_idx", "next_off", "next_idx", "src_off",
+                                   "src_idx", "snk_off", "snk_idx", "back_translation")}))
+    batch = StitchBatch(sides[0], sides[1], d[prefix + "only_deletion_alns"])
+    return batch, d[prefix + "aln_off"], d[prefix + "pairs"].reshape(-1, 2)
+
+
+def ref_msa_dump(fasta_path, newick_path=None, dump_path=None, out_path=None, skip_calibration=False,
+                 max_num_match_pairs=0, verbosity=0):
+    lib = ref_lib()
+    t = (C.c_double * 8)()
+    code = lib.ref_msa_dump(fasta_path.encode(), (newick_path or "").encode(), (dump_path or "").encode(),
+                            (out_path or "").encode(), int(skip_calibration), int(max_num_match_pairs), int(verbosity), t)
+    if code != 0:
+        raise RuntimeError("ref_msa_dump failed with code %d" % code)
+    keys = ("calibration", "match_finding", "chaining", "partition", "extraction", "subalign", "fuse", "total")
+    return dict(zip(keys, [float(x) for x in t]))

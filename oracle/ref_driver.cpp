@@ -1,0 +1,445 @@
+/*
+ * ref_driver.cpp — TEST INFRASTRUCTURE ONLY.  Our own glue code that links against the UNMODIFIED
+ * reference (compiled from /root/reference by oracle/Makefile into oracle/_ref/) and exposes it through a
+ * small C ABI so that tests, the golden-vector generator and bench.py's cpu_baseline leg can call the real
+ * thing.  It contains no reference source; it reaches the reference's protected members the same way the
+ * reference's own tests do (derive + using-declarations, src/test/test_stitcher.cpp:23-28).
+ *
+ *   ref_po_poa        -> centrolign::po_poa<NumPW>              (include/centrolign/alignment.hpp:78-85)
+ *   ref_stitch_batch  -> centrolign::Stitcher::subalign per problem (src/stitcher.cpp:24-78)
+ *   ref_msa_dump      -> the CLI pipeline (src/main.cpp:239-301, include/centrolign/core.hpp:182-403) with the
+ *                        stitch subproblems of every merge written out as flat arrays
+ */
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "centrolign/alignment.hpp"
+#include "centrolign/core.hpp"
+#include "centrolign/gfa.hpp"
+#include "centrolign/parameters.hpp"
+#include "centrolign/stitcher.hpp"
+#include "centrolign/utility.hpp"
+
+#include "cl_oracle.h"
+
+using namespace centrolign;
+
+namespace {
+
+/* Rebuild a BaseGraph whose previous() AND next() lists have exactly the given orders.  Both orders come
+ * from one edge-insertion sequence (BaseGraph::add_edge appends to both lists, src/graph.cpp), so a greedy
+ * merge that emits an edge when it heads both of its lists reproduces a valid sequence. */
+BaseGraph build_graph(const clo_graph* g) {
+    BaseGraph bg;
+    for (uint64_t v = 0; v < g->n; ++v) bg.add_node((char)g->label[v]);
+    if (!g->next_off) {
+        for (uint64_t v = 0; v < g->n; ++v)
+            for (uint64_t e = g->prev_off[v]; e < g->prev_off[v + 1]; ++e) bg.add_edge(g->prev_idx[e], v);
+        return bg;
+    }
+    std::vector<uint64_t> np(g->n), pp(g->n);
+    for (uint64_t v = 0; v < g->n; ++v) { np[v] = g->next_off[v]; pp[v] = g->prev_off[v]; }
+    std::vector<uint64_t> work;
+    for (uint64_t v = g->n; v-- > 0;) work.push_back(v);
+    auto ready = [&](uint64_t u) -> bool {
+        if (np[u] >= g->next_off[u + 1]) return false;
+        uint64_t v = g->next_idx[np[u]];
+        return pp[v] < g->prev_off[v + 1] && g->prev_idx[pp[v]] == u;
+    };
+    uint64_t emitted = 0, total = g->n ? g->prev_off[g->n] - g->prev_off[0] : 0;
+    while (!work.empty()) {
+        uint64_t u = work.back();
+        work.pop_back();
+        while (ready(u)) {
+            uint64_t v = g->next_idx[np[u]];
+            bg.add_edge(u, v);
+            ++emitted; ++np[u]; ++pp[v];
+            if (pp[v] < g->prev_off[v + 1]) work.push_back(g->prev_idx[pp[v]]);
+        }
+    }
+    if (emitted != total) {
+        /* inconsistent orders: honour previous() (the only order results depend on) */
+        BaseGraph bg2;
+        for (uint64_t v = 0; v < g->n; ++v) bg2.add_node((char)g->label[v]);
+        for (uint64_t v = 0; v < g->n; ++v)
+            for (uint64_t e = g->prev_off[v]; e < g->prev_off[v + 1]; ++e) bg2.add_edge(g->prev_idx[e], v);
+        return bg2;
+    }
+    return bg;
+}
+
+std::vector<uint64_t> to_vec(const uint32_t* p, uint64_t n) { return std::vector<uint64_t>(p, p + n); }
+
+template <int NumPW>
+AlignmentParameters<NumPW> make_params(const cl_align_params* p) {
+    AlignmentParameters<NumPW> ap;
+    ap.match = p->match;
+    ap.mismatch = p->mismatch;
+    for (int i = 0; i < NumPW; ++i) { ap.gap_open[i] = p->gap_open[i]; ap.gap_extend[i] = p->gap_extend[i]; }
+    return ap;
+}
+
+struct DumpStitcher : public Stitcher {
+    using Stitcher::subalign;
+    using Stitcher::do_alignment;
+    using Extractor::extract_graphs_between;
+    using Extractor::source_sink_minmax;
+};
+
+void set_stitcher(DumpStitcher& st, const cl_stitch_params* sp) {
+    st.alignment_params = make_params<3>(&sp->alignment_params);
+    st.max_trivial_size = sp->max_trivial_size;
+    st.min_wfa_size = sp->min_wfa_size;
+    st.max_wfa_size = sp->max_wfa_size;
+    st.max_wfa_ratio = sp->max_wfa_ratio;
+    st.wfa_pruning_dist = sp->wfa_pruning_dist;
+    st.deletion_alignment_ratio = sp->deletion_alignment_ratio;
+    st.deletion_alignment_short_max_size = sp->deletion_alignment_short_max_size;
+    st.deletion_alignment_long_min_size = sp->deletion_alignment_long_min_size;
+}
+
+void side_graph(const cl_graph_side* s, uint64_t k, clo_graph* g) {
+    uint64_t b = s->node_off[k];
+    g->n = s->node_off[k + 1] - b;
+    g->label = s->label + b;
+    g->prev_off = s->prev_off + b;
+    g->prev_idx = s->prev_idx;
+    g->next_off = s->next_off ? s->next_off + b : nullptr;
+    g->next_idx = s->next_idx;
+    g->n_src = s->src_off[k + 1] - s->src_off[k];
+    g->src = s->src_idx + s->src_off[k];
+    g->n_snk = s->snk_off[k + 1] - s->snk_off[k];
+    g->snk = s->snk_idx + s->snk_off[k];
+}
+
+SubGraphInfo make_info(const cl_graph_side* s, uint64_t k) {
+    clo_graph g;
+    side_graph(s, k, &g);
+    SubGraphInfo info;
+    info.subgraph = build_graph(&g);
+    info.sources = to_vec(g.src, g.n_src);
+    info.sinks = to_vec(g.snk, g.n_snk);
+    info.back_translation.resize(g.n);
+    for (uint64_t v = 0; v < g.n; ++v)
+        info.back_translation[v] = s->back_translation ? s->back_translation[s->node_off[k] + v] : v;
+    return info;
+}
+
+/* ---- flat dump writer ------------------------------------------------------------------------------ */
+struct Dump {
+    FILE* f = nullptr;
+    bool open(const std::string& path) {
+        f = fopen(path.c_str(), "wb");
+        if (!f) return false;
+        fwrite("CLDUMP1\n", 1, 8, f);
+        return true;
+    }
+    void put(const std::string& name, uint8_t dtype, const void* data, uint64_t count, size_t esz) {
+        uint32_t nl = (uint32_t)name.size();
+        fwrite(&nl, 4, 1, f);
+        fwrite(name.data(), 1, nl, f);
+        fwrite(&dtype, 1, 1, f);
+        fwrite(&count, 8, 1, f);
+        if (count) fwrite(data, esz, count, f);
+    }
+    void u8(const std::string& n, const std::vector<uint8_t>& v) { put(n, 0, v.data(), v.size(), 1); }
+    void u32(const std::string& n, const std::vector<uint32_t>& v) { put(n, 1, v.data(), v.size(), 4); }
+    void u64(const std::string& n, const std::vector<uint64_t>& v) { put(n, 2, v.data(), v.size(), 8); }
+    void i64(const std::string& n, const std::vector<int64_t>& v) { put(n, 3, v.data(), v.size(), 8); }
+    void f64(const std::string& n, const std::vector<double>& v) { put(n, 4, v.data(), v.size(), 8); }
+    void str(const std::string& n, const std::string& s) { put(n, 0, s.data(), s.size(), 1); }
+    void close() { if (f) fclose(f); f = nullptr; }
+};
+
+struct FlatSide {
+    std::vector<uint64_t> node_off{0}, prev_off{0}, next_off{0}, src_off{0}, snk_off{0}, back;
+    std::vector<uint8_t> label;
+    std::vector<uint32_t> prev_idx, next_idx, src_idx, snk_idx;
+    void add(const SubGraphInfo& info) {
+        const auto& g = info.subgraph;
+        for (uint64_t v = 0; v < g.node_size(); ++v) {
+            label.push_back((uint8_t)g.label(v));
+            for (auto p : g.previous(v)) prev_idx.push_back((uint32_t)p);
+            prev_off.push_back(prev_idx.size());
+            for (auto q : g.next(v)) next_idx.push_back((uint32_t)q);
+            next_off.push_back(next_idx.size());
+            back.push_back(info.back_translation[v]);
+        }
+        node_off.push_back(label.size());
+        for (auto s : info.sources) src_idx.push_back((uint32_t)s);
+        src_off.push_back(src_idx.size());
+        for (auto s : info.sinks) snk_idx.push_back((uint32_t)s);
+        snk_off.push_back(snk_idx.size());
+    }
+    void write(Dump& d, const std::string& pre) {
+        d.u64(pre + "node_off", node_off); d.u8(pre + "label", label);
+        d.u64(pre + "prev_off", prev_off); d.u32(pre + "prev_idx", prev_idx);
+        d.u64(pre + "next_off", next_off); d.u32(pre + "next_idx", next_idx);
+        d.u64(pre + "src_off", src_off); d.u32(pre + "src_idx", src_idx);
+        d.u64(pre + "snk_off", snk_off); d.u32(pre + "snk_idx", snk_idx);
+        d.u64(pre + "back_translation", back);
+    }
+};
+
+/* The CLI pipeline with the stitch loop opened up.  Follows Core::do_execution (core.hpp:256-403) and
+ * Core::align (core.hpp:182-254) call for call; only Stitcher::stitch (stitcher.hpp:104-206) is unrolled here
+ * so that each subalign input/output can be recorded. */
+struct DumpCore : public Core {
+    DumpCore(std::vector<std::pair<std::string, std::string>>&& seqs, Tree&& tree) : Core(std::move(seqs), std::move(tree)) {}
+
+    double t_match = 0, t_chain = 0, t_partition = 0, t_extract = 0, t_subalign = 0, t_fuse = 0, t_calib = 0;
+
+    template <class XMerge>
+    Alignment align_dump(std::vector<match_set_t>& matches, const Subproblem& sp1, const Subproblem& sp2,
+                         XMerge& x1, XMerge& x2, Dump* dump, const std::string& pre) {
+        using clk = std::chrono::steady_clock;
+        auto t0 = clk::now();
+        bool restrain_memory = (sp1.graph.path_size() * sp2.graph.path_size() * anchorer.max_num_match_pairs *
+                                    log2(anchorer.max_num_match_pairs) > memory_restraint_size);
+        auto anchors = anchorer.anchor_chain(matches, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, restrain_memory);
+        auto t1 = clk::now();
+        auto segments = partitioner.partition_anchors(anchors, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, false);
+        for (auto& seg : segments) stitcher.despecify_indel_breakpoints(seg);
+        auto t2 = clk::now();
+
+        DumpStitcher st;
+        static_cast<Stitcher&>(st) = stitcher;
+        std::vector<std::vector<std::pair<SubGraphInfo, SubGraphInfo>>> within;
+        std::vector<std::pair<SubGraphInfo, SubGraphInfo>> between;
+        std::tie(within, between) = st.extract_graphs_between(segments, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2);
+        auto t3 = clk::now();
+
+        FlatSide f1, f2;
+        std::vector<uint8_t> only_del;
+        std::vector<uint64_t> aln_off{0}, pairs;
+        /* Stitcher::stitch emits  P0 A0 P1 A1 ... A(K-2) P(K-1): every subproblem but the first is preceded by
+         * exactly one copied anchor (stitcher.hpp:157-203), so the anchors are dumped as a flat list. */
+        std::vector<uint64_t> anchor_off{0}, anchor_pairs;
+        Alignment stitched;
+        double sub_s = 0;
+        auto run = [&](const std::pair<SubGraphInfo, SubGraphInfo>& pr, bool od) {
+            f1.add(pr.first); f2.add(pr.second);
+            only_del.push_back(od ? 1 : 0);
+            size_t before = stitched.size();
+            auto a = clk::now();
+            st.subalign(pr.first, pr.second, stitched, od);
+            sub_s += std::chrono::duration<double>(clk::now() - a).count();
+            for (size_t i = before; i < stitched.size(); ++i) { pairs.push_back(stitched[i].node_id1); pairs.push_back(stitched[i].node_id2); }
+            aln_off.push_back(pairs.size() / 2);
+        };
+        for (size_t i = 0; i < between.size(); ++i) {
+            if (i != 0) {
+                const auto& seg_graphs = within[i - 1];
+                const auto& seg = segments[i - 1];
+                for (size_t j = 0; j < seg.size(); ++j) {
+                    if (j != 0) run(seg_graphs[j - 1], false);
+                    const auto& anchor = seg[j];
+                    for (size_t k = 0; k < anchor.walk1.size(); ++k) {
+                        stitched.emplace_back(anchor.walk1[k], anchor.walk2[k]);
+                        anchor_pairs.push_back(anchor.walk1[k]); anchor_pairs.push_back(anchor.walk2[k]);
+                    }
+                    anchor_off.push_back(anchor_pairs.size() / 2);
+                }
+            }
+            run(between[i], true);
+        }
+        auto t4 = clk::now();
+        t_chain += std::chrono::duration<double>(t1 - t0).count();
+        t_partition += std::chrono::duration<double>(t2 - t1).count();
+        t_extract += std::chrono::duration<double>(t3 - t2).count();
+        t_subalign += sub_s;
+        (void)t4;
+        if (dump) {
+            dump->put(pre + "n_problems", 2, std::vector<uint64_t>{(uint64_t)only_del.size()}.data(), 1, 8);
+            f1.write(*dump, pre + "g1.");
+            f2.write(*dump, pre + "g2.");
+            dump->u8(pre + "only_deletion_alns", only_del);
+            dump->u64(pre + "aln_off", aln_off);
+            dump->u64(pre + "pairs", pairs);
+            dump->u64(pre + "anchor_off", anchor_off);
+            dump->u64(pre + "anchor_pairs", anchor_pairs);
+            std::vector<uint64_t> full;
+            full.reserve(stitched.size() * 2);
+            for (const auto& ap : stitched) { full.push_back(ap.node_id1); full.push_back(ap.node_id2); }
+            dump->u64(pre + "stitched", full);
+            dump->f64(pre + "subalign_seconds", std::vector<double>{sub_s});
+        }
+        return stitched;
+    }
+
+    void run(Dump* dump) {
+        using clk = std::chrono::steady_clock;
+        auto c0 = clk::now();
+        if (!skip_calibration) calibrate_anchor_scores_and_identify_bonds(); /* core.cpp:63-68 */
+        t_calib = std::chrono::duration<double>(clk::now() - c0).count();
+        size_t merge = 0;
+        while (!main_execution.finished()) {
+            auto ptrs = main_execution.next();
+            auto& next_problem = *std::get<0>(ptrs);
+            auto& sp1 = *std::get<1>(ptrs);
+            auto& sp2 = *std::get<2>(ptrs);
+            reassign_sentinels(sp1.graph, sp1.tableau, 5, 6);
+            reassign_sentinels(sp2.graph, sp2.tableau, 7, 8);
+            auto m0 = clk::now();
+            auto matches = path_match_finder.find_matches(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau);
+            t_match += std::chrono::duration<double>(clk::now() - m0).count();
+            std::string pre = "m" + std::to_string(merge) + ".";
+            /* core.hpp:296-357: this driver covers the default SparseAffine / PathMerge<uint32,uint8> branch */
+            PathMerge<uint32_t, uint8_t> pm1(sp1.graph, sp1.tableau);
+            PathMerge<uint32_t, uint8_t> pm2(sp2.graph, sp2.tableau);
+            next_problem.alignment = align_dump(matches, sp1, sp2, pm1, pm2, dump, pre);
+            auto f0 = clk::now();
+            BaseGraph fused = sp1.graph;
+            fuse(fused, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment);
+            next_problem.graph = std::move(fused);
+            next_problem.tableau = sp1.tableau;
+            next_problem.complete = true;
+            t_fuse += std::chrono::duration<double>(clk::now() - f0).count();
+            ++merge;
+        }
+        if (dump) dump->put("n_merges", 2, std::vector<uint64_t>{(uint64_t)merge}.data(), 1, 8);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ref_po_poa(const clo_graph* g1, const clo_graph* g2, int npw, const cl_align_params* prm, uint64_t* pairs_out,
+               uint64_t* n_pairs_out, int64_t* score_out) {
+    BaseGraph b1 = build_graph(g1), b2 = build_graph(g2);
+    auto s1 = to_vec(g1->src, g1->n_src), s2 = to_vec(g2->src, g2->n_src);
+    auto k1 = to_vec(g1->snk, g1->n_snk), k2 = to_vec(g2->snk, g2->n_snk);
+    Alignment aln;
+    int64_t score = 0;
+    if (npw == 1) aln = po_poa(b1, b2, s1, s2, k1, k2, make_params<1>(prm), &score);
+    else if (npw == 2) aln = po_poa(b1, b2, s1, s2, k1, k2, make_params<2>(prm), &score);
+    else if (npw == 3) aln = po_poa(b1, b2, s1, s2, k1, k2, make_params<3>(prm), &score);
+    else return CL_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < aln.size(); ++i) { pairs_out[2 * i] = aln[i].node_id1; pairs_out[2 * i + 1] = aln[i].node_id2; }
+    *n_pairs_out = aln.size();
+    if (score_out) *score_out = score;
+    return 0;
+}
+
+/* Stitcher::subalign (or po_poa when force_num_pw is given) over a flat batch; same output contract as
+ * clo_stitch_batch.  seconds_out (optional) receives the time spent inside the reference calls only. */
+int ref_stitch_batch(const cl_stitch_batch* batch, const cl_stitch_params* sp, const uint8_t* force_num_pw,
+                     cl_stitch_result* out, double* seconds_out) {
+    uint64_t n = batch->n_problems;
+    memset(out, 0, sizeof(*out));
+    out->n_problems = n;
+    out->aln_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
+    out->score = (int64_t*)calloc(n ? n : 1, sizeof(int64_t));
+    out->route = (uint8_t*)calloc(n ? n : 1, 1);
+    out->num_pw = (uint8_t*)calloc(n ? n : 1, 1);
+    DumpStitcher st;
+    set_stitcher(st, sp);
+    std::vector<uint64_t> pairs;
+    double secs = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        SubGraphInfo i1 = make_info(&batch->side[0], k), i2 = make_info(&batch->side[1], k);
+        Alignment aln;
+        auto a = std::chrono::steady_clock::now();
+        if (force_num_pw && i1.subgraph.node_size() && i2.subgraph.node_size()) {
+            int64_t score = 0;
+            int npw = force_num_pw[k];
+            if (npw == 1) aln = po_poa(i1.subgraph, i2.subgraph, i1.sources, i2.sources, i1.sinks, i2.sinks, make_params<1>(&sp->alignment_params), &score);
+            else if (npw == 2) aln = po_poa(i1.subgraph, i2.subgraph, i1.sources, i2.sources, i1.sinks, i2.sinks, make_params<2>(&sp->alignment_params), &score);
+            else aln = po_poa(i1.subgraph, i2.subgraph, i1.sources, i2.sources, i1.sinks, i2.sinks, make_params<3>(&sp->alignment_params), &score);
+            translate(aln, i1.back_translation, i2.back_translation);
+            out->score[k] = score;
+            out->num_pw[k] = (uint8_t)npw;
+        } else {
+            st.subalign(i1, i2, aln, batch->only_deletion_alns ? batch->only_deletion_alns[k] != 0 : false);
+        }
+        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        for (const auto& ap : aln) { pairs.push_back(ap.node_id1); pairs.push_back(ap.node_id2); }
+        out->aln_off[k + 1] = pairs.size() / 2;
+    }
+    out->pairs = (uint64_t*)malloc((pairs.size() ? pairs.size() : 1) * sizeof(uint64_t));
+    if (!pairs.empty()) memcpy(out->pairs, pairs.data(), pairs.size() * sizeof(uint64_t));
+    if (seconds_out) *seconds_out = secs;
+    return 0;
+}
+
+void ref_result_free(cl_stitch_result* r) {
+    if (!r) return;
+    free(r->aln_off); free(r->pairs); free(r->score); free(r->route); free(r->num_pw);
+    memset(r, 0, sizeof(*r));
+}
+
+/* FASTA (+ optional Newick file) -> CIGAR (2 sequences) or GFA, with the CLI's parameters
+ * (Parameters defaults, src/parameters.cpp:22-108; src/main.cpp:239-301).  dump_path may be NULL.
+ * skip_calibration mirrors --skip-calibration; max_num_match_pairs <= 0 keeps the default.
+ * timings_out[8] = calibration, match finding, chaining, partition, extraction, subalign, fuse, total */
+int ref_msa_dump(const char* fasta_path, const char* newick_path, const char* dump_path, const char* out_path,
+                 int skip_calibration, long long max_num_match_pairs, int verbosity, double* timings_out) {
+    try {
+        auto T0 = std::chrono::steady_clock::now();
+        Parameters params;
+        if (skip_calibration) params.set<bool>("skip_calibration", true);
+        if (max_num_match_pairs > 0) params.set<int64_t>("max_num_match_pairs", (int64_t)max_num_match_pairs);
+        params.validate();
+        logging::level = (logging::LoggingLevel)verbosity;
+        std::ifstream fin(fasta_path);
+        if (!fin) return -100;
+        auto parsed = parse_fasta(fin);
+        std::vector<std::string> names;
+        for (const auto& p : parsed) names.push_back(p.first);
+        std::string newick;
+        if (newick_path && *newick_path) {
+            std::ifstream tin(newick_path);
+            std::stringstream ss;
+            ss << tin.rdbuf();
+            newick = ss.str();
+        } else {
+            newick = in_order_newick_string(names);
+        }
+        Tree tree(newick);
+        DumpCore core(std::move(parsed), std::move(tree));
+        if (names.size() == 2) params.set<bool>("preserve_subproblems", true);
+        params.apply(core);
+        core.preserve_subproblems = true;
+        Dump dump;
+        Dump* dp = nullptr;
+        if (dump_path && *dump_path) {
+            if (!dump.open(dump_path)) return -101;
+            dp = &dump;
+        }
+        core.run(dp);
+        std::string text;
+        if (names.size() == 2) {
+            const auto& root = core.root_subproblem();
+            text = explicit_cigar(root.alignment, core.leaf_subproblem(names.front()).graph, core.leaf_subproblem(names.back()).graph) + "\n";
+        } else {
+            std::stringstream ss;
+            const auto& root = core.root_subproblem();
+            write_gfa(root.graph, root.tableau, ss);
+            text = ss.str();
+        }
+        if (dp) { dump.str("output", text); dump.close(); }
+        if (out_path && *out_path) {
+            std::ofstream fo(out_path);
+            fo << text;
+        }
+        if (timings_out) {
+            timings_out[0] = core.t_calib; timings_out[1] = core.t_match; timings_out[2] = core.t_chain;
+            timings_out[3] = core.t_partition; timings_out[4] = core.t_extract; timings_out[5] = core.t_subalign;
+            timings_out[6] = core.t_fuse;
+            timings_out[7] = std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+        }
+        return 0;
+    } catch (std::exception& ex) {
+        fprintf(stderr, "ref_msa_dump: %s\n", ex.what());
+        return -102;
+    }
+}
+
+}  // extern "C"
