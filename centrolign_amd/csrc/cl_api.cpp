@@ -1,0 +1,812 @@
+// cl_api.cpp — host side of the C ABI declared in include/centrolign_amd.h.
+//
+// Mirrors, for a whole batch of between-anchor subproblems at once, what the reference does per
+// subproblem on one CPU thread:
+//   Stitcher::subalign      (src/stitcher.cpp:24-78)              -> choose_num_pw(), translate in collect
+//   Stitcher::do_alignment  (include/centrolign/stitcher.hpp:237-370) -> route_problem()
+//   pure_deletion_alignment (include/centrolign/alignment.hpp:1178-1210) -> pure_deletion() (host, O(n))
+//   po_poa                  (alignment.hpp:753-1163)              -> packed to rank space here, DP + traceback
+//                                                                    on the GPU (popoa_kernels.hip)
+// There is no CPU implementation of the DP in this library: without a gfx950 device the entry points
+// return CL_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/centrolign_amd.h"
+#include "popoa_device.h"
+
+hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
+                                   const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
+hipError_t cl_launch_popoa_linear(int npw, int R, int W, uint32_t n_blocks, const ClDeviceBatch& B,
+                                  const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
+size_t cl_linear_workspace_bytes(uint32_t n1, uint32_t n2, int npw, int R);
+
+namespace {
+
+thread_local std::string g_error;
+
+// test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
+const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
+
+constexpr int kNumAuxStreams = 4;
+
+}  // namespace
+
+struct cl_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t aux[kNumAuxStreams] = {};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[kNumAuxStreams] = {};
+    std::string error;
+    std::string name;
+};
+
+namespace {
+
+void set_error(cl_context* ctx, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    if (ctx) ctx->error = buf;
+}
+
+#define HIP_TRY(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;                 \
+        }                                                                                         \
+    } while (0)
+
+// ---- one graph of one problem, as a view into the flat batch -------------------------------------------
+struct GraphView {
+    uint64_t n = 0;
+    const uint8_t* label = nullptr;
+    const uint64_t* prev_off = nullptr;  // n+1 entries, absolute into prev_idx
+    const uint32_t* prev_idx = nullptr;
+    const uint64_t* next_off = nullptr;  // may be null
+    const uint32_t* next_idx = nullptr;
+    uint64_t n_src = 0, n_snk = 0;
+    const uint32_t* src = nullptr;
+    const uint32_t* snk = nullptr;
+};
+
+GraphView view(const cl_graph_side& s, uint64_t k) {
+    GraphView g;
+    uint64_t b = s.node_off[k];
+    g.n = s.node_off[k + 1] - b;
+    g.label = s.label + b;
+    g.prev_off = s.prev_off + b;
+    g.prev_idx = s.prev_idx;
+    g.next_off = s.next_off ? s.next_off + b : nullptr;
+    g.next_idx = s.next_idx;
+    g.n_src = s.src_off[k + 1] - s.src_off[k];
+    g.src = s.src_idx + s.src_off[k];
+    g.n_snk = s.snk_off[k + 1] - s.snk_off[k];
+    g.snk = s.snk_idx + s.snk_off[k];
+    return g;
+}
+
+int validate_side(cl_context* ctx, const cl_graph_side& s, uint64_t n, int which) {
+    if (!s.node_off || !s.prev_off || !s.src_off || !s.snk_off) {
+        set_error(ctx, "graph side %d: missing offset array", which);
+        return CL_ERR_INVALID_ARGUMENT;
+    }
+    if (s.node_off[0] != 0 || s.src_off[0] != 0 || s.snk_off[0] != 0) {
+        set_error(ctx, "graph side %d: offsets must start at 0", which);
+        return CL_ERR_INVALID_ARGUMENT;
+    }
+    for (uint64_t k = 0; k < n; ++k) {
+        if (s.node_off[k + 1] < s.node_off[k] || s.src_off[k + 1] < s.src_off[k] || s.snk_off[k + 1] < s.snk_off[k]) {
+            set_error(ctx, "graph side %d: offsets not monotone at problem %llu", which, (unsigned long long)k);
+            return CL_ERR_INVALID_ARGUMENT;
+        }
+        uint64_t nn = s.node_off[k + 1] - s.node_off[k];
+        if (nn >= (1ull << 31)) {
+            set_error(ctx, "graph side %d: problem %llu has too many nodes", which, (unsigned long long)k);
+            return CL_ERR_INVALID_ARGUMENT;
+        }
+        for (uint64_t i = s.src_off[k]; i < s.src_off[k + 1]; ++i)
+            if (s.src_idx[i] >= nn) { set_error(ctx, "graph side %d: source id out of range in problem %llu", which, (unsigned long long)k); return CL_ERR_INVALID_ARGUMENT; }
+        for (uint64_t i = s.snk_off[k]; i < s.snk_off[k + 1]; ++i)
+            if (s.snk_idx[i] >= nn) { set_error(ctx, "graph side %d: sink id out of range in problem %llu", which, (unsigned long long)k); return CL_ERR_INVALID_ARGUMENT; }
+        for (uint64_t v = s.node_off[k]; v < s.node_off[k + 1]; ++v) {
+            if (s.prev_off[v + 1] < s.prev_off[v]) { set_error(ctx, "graph side %d: prev_off not monotone", which); return CL_ERR_INVALID_ARGUMENT; }
+            for (uint64_t e = s.prev_off[v]; e < s.prev_off[v + 1]; ++e)
+                if (s.prev_idx[e] >= nn) { set_error(ctx, "graph side %d: predecessor id out of range in problem %llu", which, (unsigned long long)k); return CL_ERR_INVALID_ARGUMENT; }
+        }
+    }
+    return CL_OK;
+}
+
+// next lists (ids local), derived from prev lists when the caller did not pass them.  Only the order inside
+// a list could differ from BaseGraph's, and nothing downstream depends on it.
+struct NextLists {
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> idx;
+    const uint64_t* o = nullptr;
+    const uint32_t* i = nullptr;
+    uint64_t base = 0;  // o[v] - base indexes i when derived; absolute otherwise
+    void build(const GraphView& g) {
+        if (g.next_off) { o = g.next_off; i = g.next_idx; base = 0; return; }
+        uint64_t n = g.n;
+        off.assign(n + 2, 0);
+        for (uint64_t v = 0; v < n; ++v)
+            for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) off[g.prev_idx[e] + 2]++;
+        for (uint64_t v = 0; v < n; ++v) off[v + 2] += off[v + 1];
+        idx.resize(off[n + 1] ? off[n + 1] : 1);
+        for (uint64_t v = 0; v < n; ++v)
+            for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) idx[off[g.prev_idx[e] + 1]++] = (uint32_t)v;
+        o = off.data(); i = idx.data(); base = 0;
+    }
+    uint64_t begin(uint64_t v) const { return o[v]; }
+    uint64_t end(uint64_t v) const { return o[v + 1]; }
+};
+
+// Kahn's algorithm, LIFO stack seeded in ascending id order (topological_order.hpp:12-60).
+// false if the graph has a cycle.
+bool topological_order(const GraphView& g, const NextLists& nx, std::vector<uint32_t>& order,
+                       std::vector<uint32_t>& scratch_stack, std::vector<uint32_t>& indeg) {
+    uint64_t n = g.n;
+    order.clear();
+    order.reserve(n);
+    scratch_stack.clear();
+    indeg.resize(n);
+    for (uint64_t v = 0; v < n; ++v) {
+        indeg[v] = (uint32_t)(g.prev_off[v + 1] - g.prev_off[v]);
+        if (indeg[v] == 0) scratch_stack.push_back((uint32_t)v);
+    }
+    while (!scratch_stack.empty()) {
+        uint32_t v = scratch_stack.back();
+        scratch_stack.pop_back();
+        order.push_back(v);
+        for (uint64_t e = nx.begin(v); e < nx.end(v); ++e) {
+            uint32_t w = nx.i[e];
+            if (--indeg[w] == 0) scratch_stack.push_back(w);
+        }
+    }
+    return order.size() == n;
+}
+
+// src/stitcher.cpp:31-52
+int choose_num_pw(uint64_t n1, uint64_t n2, const cl_align_params& p) {
+    uint64_t cutoffs[2];
+    for (int i = 1; i < 3; ++i) {
+        if (p.gap_open[i - 1] > p.gap_open[i] || p.gap_extend[i - 1] < p.gap_extend[i]) return CL_ERR_BAD_GAP_PARAMS;
+        uint32_t diff_open = p.gap_open[i] - p.gap_open[i - 1];
+        uint32_t diff_extend = p.gap_extend[i - 1] - p.gap_extend[i];
+        if (diff_extend == 0) return CL_ERR_BAD_GAP_PARAMS;  // the reference would divide by zero
+        cutoffs[i - 1] = (diff_open + diff_extend - 1) / diff_extend;
+    }
+    int c = 0;
+    while (c < 2 && n1 > cutoffs[c] && n2 > cutoffs[c]) ++c;
+    return c + 1;
+}
+
+// Extractor::source_sink_minmax (src/anchorer.cpp:14-23) over minmax_distance (minmax_distance.hpp:16-72)
+bool source_sink_minmax(const GraphView& g, int64_t& mn_out, int64_t& mx_out) {
+    NextLists nx;
+    nx.build(g);
+    std::vector<uint32_t> order, st, indeg;
+    if (!topological_order(g, nx, order, st, indeg)) return false;
+    const int64_t INF = std::numeric_limits<int64_t>::max();
+    std::vector<int64_t> mn(g.n, INF), mx(g.n, -1);
+    for (uint64_t i = 0; i < g.n_src; ++i) { mn[g.src[i]] = 0; mx[g.src[i]] = 0; }
+    for (uint32_t v : order) {
+        if (mn[v] == INF) continue;
+        for (uint64_t e = nx.begin(v); e < nx.end(v); ++e) {
+            uint32_t w = nx.i[e];
+            mn[w] = std::min(mn[w], mn[v] + 1);
+            mx[w] = std::max(mx[w], mx[v] + 1);
+        }
+    }
+    mn_out = INF;
+    mx_out = -1;
+    for (uint64_t i = 0; i < g.n_snk; ++i) {
+        mn_out = std::min(mn_out, mn[g.snk[i]]);
+        mx_out = std::max(mx_out, mx[g.snk[i]]);
+    }
+    return true;
+}
+
+// include/centrolign/stitcher.hpp:268-360
+int route_problem(const GraphView& g1, const GraphView& g2, bool only_del, const cl_stitch_params& sp) {
+    if (g2.n == 0) return CL_ROUTE_PURE_DELETION_1;
+    if (g1.n == 0) return CL_ROUTE_PURE_DELETION_2;
+    uint64_t mat = (g1.n + 1) * (g2.n + 1);
+    if (mat <= sp.min_wfa_size && (!only_del || mat <= sp.max_trivial_size)) return CL_ROUTE_PO_POA;
+    int64_t a1, b1, a2, b2;
+    if (!source_sink_minmax(g1, a1, b1) || !source_sink_minmax(g2, a2, b2)) return CL_ERR_CYCLIC_GRAPH;
+    uint64_t min1 = (uint64_t)a1, max1 = (uint64_t)b1, min2 = (uint64_t)a2, max2 = (uint64_t)b2;  // size_t in the reference
+    if (max1 * sp.deletion_alignment_ratio <= min2 && max1 <= sp.deletion_alignment_short_max_size &&
+        min2 >= sp.deletion_alignment_long_min_size)
+        return CL_ROUTE_DELETION_WFA_1;
+    if (max2 * sp.deletion_alignment_ratio <= min1 && max2 <= sp.deletion_alignment_short_max_size &&
+        min1 >= sp.deletion_alignment_long_min_size)
+        return CL_ROUTE_DELETION_WFA_2;
+    double r = sp.max_wfa_ratio;
+    if (mat < sp.max_wfa_size &&
+        ((min2 * r >= min1 && min2 <= max1 * r) || (max2 * r >= min1 && max2 <= max1 * r) ||
+         (min1 * r >= min2 && min1 <= max2 * r) || (max1 * r >= min2 && max1 <= max2 * r)) &&
+        !only_del)
+        return CL_ROUTE_PWFA;
+    return CL_ROUTE_GREEDY_PARTIAL;
+}
+
+// pure_deletion_alignment (alignment.hpp:1178-1210): shortest source->sink path (shortest_path.hpp:32-100)
+// emitted as a run of gaps.  Returns the path in LOCAL node ids.
+int pure_deletion(const GraphView& g, std::vector<uint32_t>& path) {
+    path.clear();
+    if (g.n == 0) return CL_OK;
+    NextLists nx;
+    nx.build(g);
+    std::vector<uint32_t> order, st, indeg;
+    if (!topological_order(g, nx, order, st, indeg)) return CL_ERR_CYCLIC_GRAPH;
+    const uint64_t INF = (uint64_t)std::numeric_limits<int64_t>::max();
+    std::vector<uint64_t> dp(g.n, INF);
+    for (uint64_t i = 0; i < g.n_src; ++i) dp[g.src[i]] = 0;
+    for (uint32_t v : order) {
+        uint64_t thru = dp[v] + 1;
+        for (uint64_t e = nx.begin(v); e < nx.end(v); ++e) dp[nx.i[e]] = std::min(dp[nx.i[e]], thru);
+    }
+    uint64_t best = UINT64_MAX;
+    for (uint64_t i = 0; i < g.n_snk; ++i) {
+        uint32_t v = g.snk[i];
+        if (dp[v] != INF && (best == UINT64_MAX || dp[v] < dp[best])) best = v;
+    }
+    if (best == UINT64_MAX) return CL_OK;
+    uint64_t cur = best;
+    path.push_back((uint32_t)cur);
+    while (dp[cur] != 0) {
+        uint64_t nxt = UINT64_MAX;
+        for (uint64_t e = g.prev_off[cur]; e < g.prev_off[cur + 1]; ++e)
+            if (dp[g.prev_idx[e]] + 1 == dp[cur]) { nxt = g.prev_idx[e]; break; }
+        if (nxt == UINT64_MAX) return CL_ERR_INVALID_ARGUMENT;
+        cur = nxt;
+        path.push_back((uint32_t)cur);
+    }
+    std::reverse(path.begin(), path.end());
+    return CL_OK;
+}
+
+int64_t pure_deletion_score(size_t path_len, int npw, const cl_align_params& p) {
+    if (path_len == 0) return 0;
+    // alignment.hpp:1202-1205 evaluates -open - extend in uint32_t before widening; reproduced literally
+    int64_t s = std::numeric_limits<int64_t>::max();
+    for (int k = 0; k < npw; ++k) s = std::min<int64_t>(s, (int64_t)(uint32_t)(0u - p.gap_open[k] - p.gap_extend[k]));
+    return s;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(cl_context* ctx, size_t count) {
+        n = count;
+        if (count == 0) count = 1;
+        HIP_TRY(ctx, hipMalloc((void**)&p, count * sizeof(T)));
+        return CL_OK;
+    }
+    int upload(cl_context* ctx, const std::vector<T>& h) {
+        int rc = alloc(ctx, h.size());
+        if (rc) return rc;
+        if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return CL_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct LaunchGroup {
+    int kind = 0;
+    int npw = 0;
+    int block = 0;       // general kernel: workgroup size
+    int rows = 0, waves = 0;  // linear kernel: rows per lane, waves per workgroup
+    uint32_t first = 0;  // into plist
+    uint32_t count = 0;
+};
+
+}  // namespace
+
+struct cl_stitch_plan {
+    uint64_t n_problems = 0;
+    cl_align_params aparams{};
+    // per input problem
+    std::vector<uint8_t> route, num_pw;
+    std::vector<int32_t> po_index;                 // index among PO-POA problems or -1
+    std::vector<std::vector<uint32_t>> pd_path;    // pure-deletion paths (local ids), indexed by input problem (sparse)
+    std::vector<uint32_t> pd_problem;              // list of problems with a pd path
+    // per PO-POA problem
+    std::vector<ClProbDesc> desc;
+    std::vector<uint8_t> lin_rows, lin_waves;      // linear-kernel geometry per PO-POA problem (0 = general kernel)
+    std::vector<uint64_t> po_problem;              // input problem index
+    std::vector<uint32_t> order[2];                // rank -> local node id, concatenated (node_base)
+    // translation back to caller ids
+    std::vector<uint64_t> back[2];                 // copy of back_translation (or empty)
+    std::vector<uint64_t> node_off[2];
+    bool has_back[2] = {false, false};
+    // device
+    DevBuf<ClProbDesc> d_desc;
+    DevBuf<uint8_t> d_lab[2];
+    DevBuf<uint32_t> d_poff[2], d_pidx[2], d_snk[2];
+    DevBuf<int32_t> d_planes;
+    DevBuf<uint2> d_out_pairs;
+    DevBuf<uint32_t> d_out_len, d_out_status, d_plist;
+    DevBuf<int32_t> d_out_score;
+    std::vector<LaunchGroup> groups;
+    ClDeviceBatch dev{};
+    ClScoreParams sparams{};
+    cl_plan_stats stats{};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool executed = false;
+};
+
+namespace {
+
+void plan_free(cl_stitch_plan* pl) {
+    if (!pl) return;
+    pl->d_desc.release();
+    for (int s = 0; s < 2; ++s) {
+        pl->d_lab[s].release(); pl->d_poff[s].release(); pl->d_pidx[s].release(); pl->d_snk[s].release();
+    }
+    pl->d_planes.release(); pl->d_out_pairs.release(); pl->d_out_len.release(); pl->d_out_status.release();
+    pl->d_plist.release(); pl->d_out_score.release();
+    if (pl->ev_start) (void)hipEventDestroy(pl->ev_start);
+    if (pl->ev_stop) (void)hipEventDestroy(pl->ev_stop);
+    delete pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cl_abi_version(void) { return CL_ABI_VERSION; }
+
+void cl_stitch_params_default(cl_stitch_params* p) {
+    // src/parameters.cpp:74-85 (the CLI's values; Stitcher's class defaults differ)
+    p->alignment_params.match = 20;
+    p->alignment_params.mismatch = 80;
+    const uint32_t go[3] = {60, 800, 2500}, ge[3] = {30, 5, 1};
+    for (int i = 0; i < 3; ++i) { p->alignment_params.gap_open[i] = go[i]; p->alignment_params.gap_extend[i] = ge[i]; }
+    p->max_trivial_size = 30000;
+    p->min_wfa_size = 40000000;
+    p->max_wfa_size = 75000000;
+    p->max_wfa_ratio = 1.05;
+    p->wfa_pruning_dist = 25;
+    p->deletion_alignment_ratio = 8;
+    p->deletion_alignment_short_max_size = 1500;
+    p->deletion_alignment_long_min_size = 2000;
+}
+
+int cl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* cl_last_error(const cl_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+const char* cl_device_name(const cl_context* ctx) { return ctx ? ctx->name.c_str() : ""; }
+
+cl_context* cl_context_create(int device_ordinal) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(nullptr, "no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        set_error(nullptr, "device ordinal %d out of range (0..%d)", device_ordinal, n - 1);
+        return nullptr;
+    }
+    cl_context* ctx = new (std::nothrow) cl_context();
+    if (!ctx) return nullptr;
+    ctx->device = device_ordinal;
+    hipDeviceProp_t prop;
+    bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < kNumAuxStreams; ++i)
+        ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        set_error(nullptr, "HIP context setup failed on device %d: %s", device_ordinal, hipGetErrorString(hipGetLastError()));
+        cl_context_destroy(ctx);
+        return nullptr;
+    }
+    ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    return ctx;
+}
+
+void cl_context_destroy(cl_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < kNumAuxStreams; ++i) {
+        if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void cl_stitch_result_free(cl_stitch_result* r) {
+    if (!r) return;
+    free(r->aln_off); free(r->pairs); free(r->score); free(r->route); free(r->num_pw);
+    memset(r, 0, sizeof(*r));
+}
+
+int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params,
+                          const uint8_t* force_num_pw, cl_stitch_plan** plan_out) {
+    if (!ctx || !batch || !params || !plan_out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    *plan_out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = batch->n_problems;
+    int rc;
+    if ((rc = validate_side(ctx, batch->side[0], n, 1)) || (rc = validate_side(ctx, batch->side[1], n, 2))) return rc;
+    const cl_align_params& ap = params->alignment_params;
+    if (ap.match > (1u << 20) || ap.mismatch > (1u << 20)) { set_error(ctx, "match/mismatch too large"); return CL_ERR_INVALID_ARGUMENT; }
+    for (int k = 0; k < 3; ++k)
+        if (ap.gap_open[k] > (1u << 24) || ap.gap_extend[k] > (1u << 24)) { set_error(ctx, "gap penalties too large"); return CL_ERR_INVALID_ARGUMENT; }
+
+    cl_stitch_plan* pl = new (std::nothrow) cl_stitch_plan();
+    if (!pl) return CL_ERR_OUT_OF_MEMORY;
+    pl->n_problems = n;
+    pl->aparams = ap;
+    pl->route.assign(n, 0);
+    pl->num_pw.assign(n, 0);
+    pl->po_index.assign(n, -1);
+    pl->pd_path.resize(n);
+    for (int s = 0; s < 2; ++s) {
+        pl->node_off[s].assign(batch->side[s].node_off, batch->side[s].node_off + n + 1);
+        if (batch->side[s].back_translation) {
+            pl->has_back[s] = true;
+            pl->back[s].assign(batch->side[s].back_translation, batch->side[s].back_translation + batch->side[s].node_off[n]);
+        }
+    }
+
+    // host-side packing into rank space
+    std::vector<uint8_t> lab[2];
+    std::vector<uint32_t> poff[2], pidx[2], snk[2];
+    poff[0].push_back(0);
+    poff[1].push_back(0);
+    std::vector<uint32_t> order, st, indeg, rank;
+    uint64_t plane_cursor = 0, out_cursor = 0;
+
+    for (uint64_t k = 0; k < n; ++k) {
+        GraphView g[2] = {view(batch->side[0], k), view(batch->side[1], k)};
+        int npw = force_num_pw ? force_num_pw[k] : choose_num_pw(g[0].n, g[1].n, ap);
+        if (npw < 1 || npw > 3) {
+            set_error(ctx, npw == CL_ERR_BAD_GAP_PARAMS ? "Affine gap parameters must be increasing in gap open penalty and decreasing in gap extend penalty"
+                                                        : "num_pw must be 1, 2 or 3 (problem %llu)", (unsigned long long)k);
+            plan_free(pl);
+            return npw < 0 ? npw : CL_ERR_INVALID_ARGUMENT;
+        }
+        bool only_del = batch->only_deletion_alns && batch->only_deletion_alns[k];
+        int route;
+        if (force_num_pw) route = g[1].n == 0 ? CL_ROUTE_PURE_DELETION_1 : g[0].n == 0 ? CL_ROUTE_PURE_DELETION_2 : CL_ROUTE_PO_POA;
+        else route = route_problem(g[0], g[1], only_del, *params);
+        if (route < 0) { set_error(ctx, "problem %llu: subgraph is not acyclic", (unsigned long long)k); plan_free(pl); return route; }
+        pl->route[k] = (uint8_t)route;
+        pl->num_pw[k] = (uint8_t)npw;
+        if (route == CL_ROUTE_PURE_DELETION_1 || route == CL_ROUTE_PURE_DELETION_2) {
+            rc = pure_deletion(route == CL_ROUTE_PURE_DELETION_1 ? g[0] : g[1], pl->pd_path[k]);
+            if (rc) { set_error(ctx, "problem %llu: pure deletion failed", (unsigned long long)k); plan_free(pl); return rc; }
+            pl->pd_problem.push_back((uint32_t)k);
+            continue;
+        }
+        if (route != CL_ROUTE_PO_POA) {
+            set_error(ctx, "problem %llu (%llu x %llu nodes) is routed to heuristic %d (deletion-WFA / WFA / greedy), which this build does not provide",
+                      (unsigned long long)k, (unsigned long long)g[0].n, (unsigned long long)g[1].n, route);
+            plan_free(pl);
+            return CL_ERR_UNSUPPORTED_ROUTE;
+        }
+        uint64_t cells = (g[0].n + 1) * (g[1].n + 1);
+        if (cells >= (1ull << 31) || g[0].n_src == 0 || g[1].n_src == 0 || g[0].n_snk == 0 || g[1].n_snk == 0) {
+            set_error(ctx, "problem %llu: matrix too large for the device path or no sources/sinks", (unsigned long long)k);
+            plan_free(pl);
+            return cells >= (1ull << 31) ? CL_ERR_INVALID_ARGUMENT : CL_ERR_UNREACHABLE_SINK;
+        }
+        ClProbDesc d{};
+        d.n1 = (uint32_t)g[0].n;
+        d.n2 = (uint32_t)g[1].n;
+        d.npw = (uint8_t)npw;
+        bool linear = true;
+        for (int s = 0; s < 2; ++s) {
+            NextLists nx;
+            nx.build(g[s]);
+            if (!topological_order(g[s], nx, order, st, indeg)) {
+                set_error(ctx, "problem %llu: graph %d is not acyclic", (unsigned long long)k, s + 1);
+                plan_free(pl);
+                return CL_ERR_CYCLIC_GRAPH;
+            }
+            rank.resize(g[s].n);
+            for (uint32_t r = 0; r < g[s].n; ++r) rank[order[r]] = r;
+            if (lab[s].size() + g[s].n >= (1ull << 32) || pidx[s].size() + (g[s].prev_off[g[s].n] - g[s].prev_off[0]) >= (1ull << 32)) {
+                set_error(ctx, "batch too large for 32-bit device offsets");
+                plan_free(pl);
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+            d.node_base[s] = (uint32_t)lab[s].size();
+            size_t lab0 = lab[s].size();
+            for (uint32_t r = 0; r < g[s].n; ++r) {
+                uint32_t v = order[r];
+                lab[s].push_back(g[s].label[v] & 0x7f);
+                uint64_t deg = g[s].prev_off[v + 1] - g[s].prev_off[v];
+                for (uint64_t e = g[s].prev_off[v]; e < g[s].prev_off[v + 1]; ++e) pidx[s].push_back(rank[g[s].prev_idx[e]] + 1);
+                poff[s].push_back((uint32_t)pidx[s].size());
+                if (r == 0 ? deg != 0 : (deg != 1 || rank[g[s].prev_idx[g[s].prev_off[v]]] != r - 1)) linear = false;
+                if (g[s].label[v] & 0x80) { set_error(ctx, "labels must be < 128"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
+            }
+            for (uint64_t i = 0; i < g[s].n_src; ++i) lab[s][lab0 + rank[g[s].src[i]]] |= 0x80;
+            if (g[s].n_src != 1 || rank[g[s].src[0]] != 0) linear = false;
+            if (g[s].n_snk != 1 || rank[g[s].snk[0]] != g[s].n - 1) linear = false;
+            d.snk_base[s] = (uint32_t)snk[s].size();
+            d.snk_cnt[s] = (uint32_t)g[s].n_snk;
+            for (uint64_t i = 0; i < g[s].n_snk; ++i) snk[s].push_back(rank[g[s].snk[i]] + 1);
+            pl->order[s].insert(pl->order[s].end(), order.begin(), order.end());
+        }
+        d.kind = (linear && !g_force_general) ? CL_KIND_LINEAR : CL_KIND_GENERAL;
+        d.plane_base = plane_cursor;
+        uint8_t lr = 0, lw = 0;
+        if (d.kind == CL_KIND_LINEAR) {
+            // rows per lane / waves per workgroup by the number of graph-1 nodes
+            lr = d.n1 <= 64 ? 1 : d.n1 <= 128 ? 2 : 4;
+            lw = d.n1 <= 256 ? 1 : d.n1 <= 1024 ? 4 : 16;
+            plane_cursor += (cl_linear_workspace_bytes(d.n1, d.n2, npw, lr) + 15) / 16 * 4;
+        } else {
+            plane_cursor += (cells * (uint64_t)(1 + 2 * npw) + 3) / 4 * 4;
+        }
+        pl->lin_rows.push_back(lr);
+        pl->lin_waves.push_back(lw);
+        if (out_cursor + d.n1 + d.n2 >= (1ull << 32)) { set_error(ctx, "batch too large for 32-bit output offsets"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
+        d.out_base = (uint32_t)out_cursor;
+        out_cursor += d.n1 + d.n2;
+        pl->po_index[k] = (int32_t)pl->desc.size();
+        pl->desc.push_back(d);
+        pl->po_problem.push_back(k);
+        pl->stats.dp_cells += cells;
+        pl->stats.dp_bytes += cells * 4ull * (1 + 2 * npw);
+        pl->stats.max_cells = std::max<uint64_t>(pl->stats.max_cells, cells);
+        if (d.kind == CL_KIND_LINEAR) pl->stats.n_linear++;
+    }
+    pl->stats.n_problems = n;
+    pl->stats.n_po_poa = pl->desc.size();
+
+    // launch groups, largest matrices first inside a group:
+    //   linear kernel  : (NumPW, rows per lane, waves per workgroup)
+    //   general kernel : (NumPW, workgroup size by widest anti-diagonal)
+    std::vector<uint32_t> plist;
+    auto cells_of = [&](uint32_t x) { return (uint64_t)(pl->desc[x].n1 + 1) * (pl->desc[x].n2 + 1); };
+    auto close_group = [&](LaunchGroup grp) {
+        grp.count = (uint32_t)plist.size() - grp.first;
+        if (!grp.count) return;
+        std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
+        pl->groups.push_back(grp);
+    };
+    const int lin_geom[5][2] = {{4, 16}, {4, 4}, {4, 1}, {2, 1}, {1, 1}};
+    for (int gi = 0; gi < 5; ++gi)
+        for (int npw = 3; npw >= 1; --npw) {
+            LaunchGroup grp;
+            grp.kind = CL_KIND_LINEAR; grp.npw = npw; grp.rows = lin_geom[gi][0]; grp.waves = lin_geom[gi][1];
+            grp.first = (uint32_t)plist.size();
+            for (uint32_t i = 0; i < pl->desc.size(); ++i)
+                if (pl->desc[i].kind == CL_KIND_LINEAR && pl->desc[i].npw == npw && pl->lin_rows[i] == grp.rows && pl->lin_waves[i] == grp.waves)
+                    plist.push_back(i);
+            close_group(grp);
+        }
+    const int blocks[3] = {64, 256, 1024};
+    for (int bi = 2; bi >= 0; --bi)
+        for (int npw = 3; npw >= 1; --npw) {
+            LaunchGroup grp;
+            grp.kind = CL_KIND_GENERAL; grp.npw = npw; grp.block = blocks[bi];
+            grp.first = (uint32_t)plist.size();
+            for (uint32_t i = 0; i < pl->desc.size(); ++i) {
+                const ClProbDesc& d = pl->desc[i];
+                uint32_t width = std::min(d.n1, d.n2) + 1;
+                int b = width <= 64 ? 0 : width <= 256 ? 1 : 2;
+                if (d.kind == CL_KIND_GENERAL && d.npw == npw && b == bi) plist.push_back(i);
+            }
+            close_group(grp);
+        }
+    pl->stats.n_launches = pl->groups.size();
+
+    // HBM
+    if ((rc = pl->d_desc.upload(ctx, pl->desc)) || (rc = pl->d_plist.upload(ctx, plist))) { plan_free(pl); return rc; }
+    for (int s = 0; s < 2; ++s)
+        if ((rc = pl->d_lab[s].upload(ctx, lab[s])) || (rc = pl->d_poff[s].upload(ctx, poff[s])) ||
+            (rc = pl->d_pidx[s].upload(ctx, pidx[s])) || (rc = pl->d_snk[s].upload(ctx, snk[s]))) { plan_free(pl); return rc; }
+    if ((rc = pl->d_planes.alloc(ctx, plane_cursor)) || (rc = pl->d_out_pairs.alloc(ctx, out_cursor)) ||
+        (rc = pl->d_out_len.alloc(ctx, pl->desc.size())) || (rc = pl->d_out_status.alloc(ctx, pl->desc.size())) ||
+        (rc = pl->d_out_score.alloc(ctx, pl->desc.size()))) { plan_free(pl); return rc; }
+    pl->stats.workspace_bytes = plane_cursor * 4 + out_cursor * 8 + lab[0].size() + lab[1].size() +
+                                4 * (poff[0].size() + poff[1].size() + pidx[0].size() + pidx[1].size());
+    pl->dev.desc = pl->d_desc.p;
+    for (int s = 0; s < 2; ++s) {
+        pl->dev.lab[s] = pl->d_lab[s].p; pl->dev.poff[s] = pl->d_poff[s].p; pl->dev.pidx[s] = pl->d_pidx[s].p; pl->dev.snk[s] = pl->d_snk[s].p;
+    }
+    pl->dev.planes = pl->d_planes.p;
+    pl->dev.out_pairs = pl->d_out_pairs.p;
+    pl->dev.out_len = pl->d_out_len.p;
+    pl->dev.out_score = pl->d_out_score.p;
+    pl->dev.out_status = pl->d_out_status.p;
+    pl->sparams.match = (int32_t)ap.match;
+    pl->sparams.mismatch = (int32_t)ap.mismatch;
+    for (int k = 0; k < 3; ++k) { pl->sparams.oe[k] = (int32_t)(ap.gap_open[k] + ap.gap_extend[k]); pl->sparams.ext[k] = (int32_t)ap.gap_extend[k]; }
+    if (hipEventCreate(&pl->ev_start) != hipSuccess || hipEventCreate(&pl->ev_stop) != hipSuccess) {
+        set_error(ctx, "hipEventCreate failed");
+        plan_free(pl);
+        return CL_ERR_HIP;
+    }
+    *plan_out = pl;
+    return CL_OK;
+}
+
+int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
+    if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
+    // fork: independent launch groups run concurrently on the auxiliary streams
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    bool used[kNumAuxStreams] = {};
+    for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
+        const LaunchGroup& g = pl->groups[gi];
+        int si = (int)(gi % kNumAuxStreams);
+        if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
+        if (g.kind == CL_KIND_LINEAR)
+            HIP_TRY(ctx, cl_launch_popoa_linear(g.npw, g.rows, g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
+        else
+            HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
+    }
+    for (int si = 0; si < kNumAuxStreams; ++si)
+        if (used[si]) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join[si], ctx->aux[si]));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[si], 0));
+        }
+    HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
+    pl->executed = true;
+    return CL_OK;
+}
+
+int cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* pl, float* ms_out) {
+    if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ms_out) {
+        *ms_out = 0.f;
+        if (pl->executed) HIP_TRY(ctx, hipEventElapsedTime(ms_out, pl->ev_start, pl->ev_stop));
+    }
+    return CL_OK;
+}
+
+int cl_stitch_plan_stats(const cl_stitch_plan* pl, cl_plan_stats* out) {
+    if (!pl || !out) return CL_ERR_INVALID_ARGUMENT;
+    *out = pl->stats;
+    return CL_OK;
+}
+
+int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result* out) {
+    if (!ctx || !pl || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    if (!pl->executed && !pl->desc.empty()) { set_error(ctx, "plan was not executed"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t npo = pl->desc.size();
+    std::vector<uint32_t> len(npo), status(npo);
+    std::vector<int32_t> score(npo);
+    std::vector<uint2> pairs(pl->d_out_pairs.n);
+    if (npo) {
+        HIP_TRY(ctx, hipMemcpy(len.data(), pl->d_out_len.p, npo * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(status.data(), pl->d_out_status.p, npo * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(score.data(), pl->d_out_score.p, npo * 4, hipMemcpyDeviceToHost));
+        if (!pairs.empty()) HIP_TRY(ctx, hipMemcpy(pairs.data(), pl->d_out_pairs.p, pairs.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+    }
+    const uint64_t n = pl->n_problems;
+    uint64_t total = 0;
+    for (size_t i = 0; i < npo; ++i) {
+        if (status[i] != 0) {
+            set_error(ctx, "device traceback failed on problem %llu (status %u): no source..sink connection or corrupt input",
+                      (unsigned long long)pl->po_problem[i], status[i]);
+            return CL_ERR_UNREACHABLE_SINK;
+        }
+        total += len[i];
+    }
+    for (uint32_t k : pl->pd_problem) total += pl->pd_path[k].size();
+    out->n_problems = n;
+    out->aln_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
+    out->pairs = (uint64_t*)malloc((total ? total : 1) * 2 * sizeof(uint64_t));
+    out->score = (int64_t*)calloc(n ? n : 1, sizeof(int64_t));
+    out->route = (uint8_t*)calloc(n ? n : 1, 1);
+    out->num_pw = (uint8_t*)calloc(n ? n : 1, 1);
+    if (!out->aln_off || !out->pairs || !out->score || !out->route || !out->num_pw) {
+        cl_stitch_result_free(out);
+        return CL_ERR_OUT_OF_MEMORY;
+    }
+    uint64_t cur = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        out->route[k] = pl->route[k];
+        out->num_pw[k] = pl->num_pw[k];
+        const uint64_t nb1 = pl->node_off[0][k], nb2 = pl->node_off[1][k];
+        if (pl->po_index[k] >= 0) {
+            const size_t i = (size_t)pl->po_index[k];
+            const ClProbDesc& d = pl->desc[i];
+            const uint32_t cap = d.n1 + d.n2;
+            const uint2* src = pairs.data() + d.out_base + (cap - len[i]);
+            const uint32_t* o1 = pl->order[0].data() + d.node_base[0];
+            const uint32_t* o2 = pl->order[1].data() + d.node_base[1];
+            for (uint32_t t = 0; t < len[i]; ++t) {
+                // rank+1 -> local id -> (translate, src/alignment.cpp:26-39) caller id
+                uint64_t a = CL_GAP, b = CL_GAP;
+                if (src[t].x) { a = o1[src[t].x - 1]; if (pl->has_back[0]) a = pl->back[0][nb1 + a]; }
+                if (src[t].y) { b = o2[src[t].y - 1]; if (pl->has_back[1]) b = pl->back[1][nb2 + b]; }
+                out->pairs[2 * cur] = a;
+                out->pairs[2 * cur + 1] = b;
+                ++cur;
+            }
+            out->score[k] = score[i];
+        } else {
+            const std::vector<uint32_t>& path = pl->pd_path[k];
+            const bool first = pl->route[k] == CL_ROUTE_PURE_DELETION_1;
+            for (uint32_t v : path) {
+                uint64_t id = v;
+                if (first) { if (pl->has_back[0]) id = pl->back[0][nb1 + v]; }
+                else if (pl->has_back[1]) id = pl->back[1][nb2 + v];
+                out->pairs[2 * cur] = first ? id : CL_GAP;       // swap_graphs for the graph2 case (src/alignment.cpp:41-45)
+                out->pairs[2 * cur + 1] = first ? CL_GAP : id;
+                ++cur;
+            }
+            out->score[k] = pure_deletion_score(path.size(), pl->num_pw[k], pl->aparams);
+        }
+        out->aln_off[k + 1] = cur;
+    }
+    return CL_OK;
+}
+
+void cl_stitch_plan_destroy(cl_context* ctx, cl_stitch_plan* pl) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    plan_free(pl);
+}
+
+static int run_whole(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* sp, const uint8_t* force,
+                     cl_stitch_result* out) {
+    cl_stitch_plan* pl = nullptr;
+    int rc = cl_stitch_plan_create(ctx, batch, sp, force, &pl);
+    if (rc) return rc;
+    rc = cl_stitch_plan_execute(ctx, pl);
+    if (!rc) rc = cl_stitch_plan_collect(ctx, pl, out);
+    cl_stitch_plan_destroy(ctx, pl);
+    return rc;
+}
+
+int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw, const cl_align_params* params,
+                    cl_stitch_result* out) {
+    if (!ctx || !batch || !num_pw || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    cl_stitch_params sp;
+    cl_stitch_params_default(&sp);
+    sp.alignment_params = *params;
+    return run_whole(ctx, batch, &sp, num_pw, out);
+}
+
+int cl_stitch_batch_align(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params, cl_stitch_result* out) {
+    if (!ctx || !batch || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    return run_whole(ctx, batch, params, nullptr, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// popoa_device.h — device-side data layout of a packed stitch batch (shared by host packer and kernels).
+//
+// Everything the kernels read is in TOPOLOGICAL-RANK space: the host packer (cl_api.cpp) orders every
+// subgraph once (Kahn, as include/centrolign/topological_order.hpp:12-60 of the reference) and rewrites
+// labels / predecessor lists / sinks in rank order, so that an anti-diagonal  a + b = d  of the
+// (n1+1) x (n2+1) matrix only depends on earlier anti-diagonals.  Index 0 on each axis is the reference's
+// extra boundary row/column ("nothing consumed yet", alignment.hpp:788-790), real node of rank r is r+1.
+#ifndef CL_POPOA_DEVICE_H
+#define CL_POPOA_DEVICE_H
+
+#include <stdint.h>
+
+#define CL_NEG_INF (INT32_MIN / 2)  // cell_t::mininf, alignment.hpp:740
+
+// kernel families
+enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1 };
+
+struct ClProbDesc {
+    uint32_t n1, n2;          // node counts (both > 0)
+    uint32_t node_base[2];    // first node of this problem in lab[] / poff[] of each side
+    uint32_t snk_base[2];     // first sink of this problem in snk[] of each side
+    uint32_t snk_cnt[2];
+    uint64_t plane_base;      // int32 index of this problem's first DP plane in the workspace
+    uint32_t out_base;        // first pair slot of this problem in the alignment output (capacity n1+n2)
+    uint8_t  npw;             // 1..3
+    uint8_t  kind;            // CL_KIND_*
+    uint16_t pad;
+};
+
+struct ClScoreParams {
+    int32_t match;            // +match
+    int32_t mismatch;         // -mismatch is applied by the kernels
+    int32_t oe[3];            // gap_open[k] + gap_extend[k]
+    int32_t ext[3];           // gap_extend[k]
+};
+
+// pointers to the packed batch in HBM
+struct ClDeviceBatch {
+    const ClProbDesc* desc;
+    const uint8_t*  lab[2];   // label (low 7 bits) | 0x80 if the node is a source, rank order
+    const uint32_t* poff[2];  // CSR offsets (global) of predecessor lists, rank order, node_count+1 entries per side
+    const uint32_t* pidx[2];  // predecessor rank+1, in BaseGraph::previous() order
+    const uint32_t* snk[2];   // sink rank+1, in SubGraphInfo::sinks order
+    int32_t*  planes;         // DP workspace
+    uint2*    out_pairs;      // (a, b) with 0 = gap, rank+1 otherwise; each problem fills its slot range from the END
+    uint32_t* out_len;        // pairs emitted per problem
+    int32_t*  out_score;      // best sink-pair score per problem
+    uint32_t* out_status;     // 0 = ok
+};
+
+#endif

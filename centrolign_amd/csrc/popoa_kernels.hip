@@ -1,0 +1,289 @@
+// popoa_kernels.hip — hand-written gfx950 kernels for centrolign's between-anchor graph x graph DP
+// (reference: po_poa_internal<true,NumPW>, include/centrolign/alignment.hpp:753-1151).
+//
+// popoa_general_kernel: one workgroup per subproblem, any DAG pair.  The (n1+1) x (n2+1) matrix is swept
+// by anti-diagonals in topological-rank space; every lane owns one cell of the current anti-diagonal.  The
+// 1 + 2*NumPW score planes (M, I_k, D_k; cell_t of alignment.hpp:738-751) live in HBM in ANTI-DIAGONAL-MAJOR
+// order, so the lanes of a wave write one contiguous run per plane and, for chain-like graphs, read three
+// contiguous runs (coalesced).  Lane 0 then picks the best sink pair and walks the traceback with exactly
+// the reference's equality tests and tie-break order (alignment.hpp:979-1138).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "popoa_device.h"
+
+namespace {
+
+// geometry of the anti-diagonal-major storage of one (n1+1) x (n2+1) matrix
+struct DiagGeom {
+    uint32_t n1, n2, m, mx, tri;
+    __device__ DiagGeom(uint32_t n1_, uint32_t n2_) : n1(n1_), n2(n2_) {
+        m = n1 < n2 ? n1 : n2;
+        mx = n1 < n2 ? n2 : n1;
+        tri = m * (m + 1) / 2;
+    }
+    __device__ __forceinline__ uint32_t lo(uint32_t d) const { return d > n2 ? d - n2 : 0; }
+    __device__ __forceinline__ uint32_t hi(uint32_t d) const { return d < n1 ? d : n1; }
+    // number of cells on anti-diagonals 0 .. d-1
+    __device__ __forceinline__ uint32_t off(uint32_t d) const {
+        if (d <= m) return d * (d + 1) / 2;
+        if (d <= mx) return tri + (d - m) * (m + 1);
+        uint32_t k = d - mx;
+        return tri + (mx - m) * (m + 1) + k * (m + 1) - k * (k - 1) / 2;
+    }
+    __device__ __forceinline__ uint32_t idx(uint32_t a, uint32_t b) const {
+        uint32_t d = a + b;
+        return off(d) + a - lo(d);
+    }
+};
+
+__device__ __forceinline__ int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+template <int NPW>
+struct Planes {
+    int32_t* base;
+    uint32_t cells;
+    __device__ __forceinline__ int32_t* M() const { return base; }
+    __device__ __forceinline__ int32_t* I(int k) const { return base + (size_t)(1 + k) * cells; }
+    __device__ __forceinline__ int32_t* D(int k) const { return base + (size_t)(1 + NPW + k) * cells; }
+};
+
+// One DP cell in pull form (equivalent to the reference's push form, alignment.hpp:813-938):
+//   boundary column b == 0 : I_k = max(-(o_k+e_k) [a is a source], I_k(p,0) - e_k)        (:832-845)
+//   boundary row    a == 0 : D_k symmetric                                               (:864-877)
+//   interior               : I_k = max_p max(Mf(p,b) - (o_k+e_k), I_k(p,b) - e_k)         (:907-916, :878-885)
+//                            D_k = max_q max(Mf(a,q) - (o_k+e_k), D_k(a,q) - e_k)         (:918-927, :846-853)
+//                            M   = s(a,b) + max_{p,q} Mf(p,q), with Mf(corner) == 0       (:929-936, :814-818, :854-861, :886-893)
+//   Mf = max(M, I_k, D_k)                                                                 (:837, :869, :903-905)
+// p ranges over previous1(a) plus the boundary index when a is a source; q likewise.
+template <int NPW>
+__device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClProbDesc& pd, const DiagGeom& G,
+                                             const Planes<NPW>& pl, const ClScoreParams& P, uint32_t a, uint32_t b,
+                                             uint32_t self_idx) {
+    const uint8_t* lab1 = B.lab[0] + pd.node_base[0];
+    const uint8_t* lab2 = B.lab[1] + pd.node_base[1];
+    const uint32_t* poff1 = B.poff[0] + pd.node_base[0];
+    const uint32_t* poff2 = B.poff[1] + pd.node_base[1];
+    int32_t M = CL_NEG_INF, I[NPW], D[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) { I[k] = CL_NEG_INF; D[k] = CL_NEG_INF; }
+
+    uint32_t e1b = 0, e1e = 0, e2b = 0, e2e = 0;
+    uint32_t l1 = 0, l2 = 0;
+    if (a) { e1b = poff1[a - 1]; e1e = poff1[a]; l1 = lab1[a - 1]; }
+    if (b) { e2b = poff2[b - 1]; e2e = poff2[b]; l2 = lab2[b - 1]; }
+    const bool src1 = l1 & 0x80, src2 = l2 & 0x80;
+
+    if (a) {
+        if (b == 0) {
+            for (uint32_t e = e1b; e < e1e; ++e) {
+                uint32_t c = G.idx(B.pidx[0][e], 0);
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], pl.I(k)[c] - P.ext[k]);
+            }
+            if (src1) {
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], -P.oe[k]);
+            }
+        } else {
+            for (uint32_t e = e1b; e < e1e; ++e) {
+                uint32_t c = G.idx(B.pidx[0][e], b);
+                int32_t m = pl.M()[c];
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], pl.I(k)[c] - P.ext[k]));
+            }
+            if (src1) {
+                int32_t m = pl.M()[G.idx(0, b)];
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], m - P.oe[k]);
+            }
+        }
+    }
+    if (b) {
+        if (a == 0) {
+            for (uint32_t f = e2b; f < e2e; ++f) {
+                uint32_t c = G.idx(0, B.pidx[1][f]);
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], pl.D(k)[c] - P.ext[k]);
+            }
+            if (src2) {
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], -P.oe[k]);
+            }
+        } else {
+            for (uint32_t f = e2b; f < e2e; ++f) {
+                uint32_t c = G.idx(a, B.pidx[1][f]);
+                int32_t m = pl.M()[c];
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], pl.D(k)[c] - P.ext[k]));
+            }
+            if (src2) {
+                int32_t m = pl.M()[G.idx(a, 0)];
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], m - P.oe[k]);
+            }
+        }
+    }
+    if (a && b) {
+        const int32_t s = ((l1 & 0x7f) == (l2 & 0x7f)) ? P.match : -P.mismatch;
+        const uint32_t e1x = e1e + (src1 ? 1u : 0u), e2x = e2e + (src2 ? 1u : 0u);
+        for (uint32_t e = e1b; e < e1x; ++e) {
+            uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
+            for (uint32_t f = e2b; f < e2x; ++f) {
+                uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
+                int32_t v = (pa | pb) ? pl.M()[G.idx(pa, pb)] : 0;
+                M = imax(M, v + s);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        M = imax(M, imax(I[k], D[k]));
+        pl.I(k)[self_idx] = I[k];
+        pl.D(k)[self_idx] = D[k];
+    }
+    pl.M()[self_idx] = M;
+}
+
+// best sink pair + traceback by one lane; alignment.hpp:979-1138, rule for rule
+template <int NPW>
+__device__ void traceback(const ClDeviceBatch& B, const ClProbDesc& pd, const DiagGeom& G, const Planes<NPW>& pl,
+                          const ClScoreParams& P, uint32_t prob) {
+    const uint8_t* lab1 = B.lab[0] + pd.node_base[0];
+    const uint8_t* lab2 = B.lab[1] + pd.node_base[1];
+    const uint32_t* poff1 = B.poff[0] + pd.node_base[0];
+    const uint32_t* poff2 = B.poff[1] + pd.node_base[1];
+    const uint32_t* snk1 = B.snk[0] + pd.snk_base[0];
+    const uint32_t* snk2 = B.snk[1] + pd.snk_base[1];
+    const int32_t* Mp = pl.M();
+
+    // first strictly better in the given sink order (:982-989)
+    uint32_t a = 0, b = 0;
+    int32_t best = 0;
+    bool have = false;
+    for (uint32_t i = 0; i < pd.snk_cnt[0]; ++i)
+        for (uint32_t j = 0; j < pd.snk_cnt[1]; ++j) {
+            int32_t v = Mp[G.idx(snk1[i], snk2[j])];
+            if (!have || v > best) { have = true; best = v; a = snk1[i]; b = snk2[j]; }
+        }
+    B.out_score[prob] = have ? best : 0;
+    uint32_t status = 0, len = 0;
+    const uint32_t cap = pd.n1 + pd.n2;
+    uint2* out = B.out_pairs + pd.out_base;
+    int comp = 0;
+    while (have) {
+        if (len >= cap) { status = 2; break; }  // cannot happen on a DAG; keeps a corrupt input from overrunning
+        const uint32_t c = G.idx(a, b);
+        const int32_t Mv = Mp[c];
+        if (comp == 0) {  // gap close test order I_0, D_0, I_1, D_1, ... (:1048-1066)
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) {
+                if (Mv == pl.I(k)[c]) { comp = k + 1; break; }
+                if (Mv == pl.D(k)[c]) { comp = -k - 1; break; }
+            }
+        }
+        uint32_t e1b = 0, e1e = 0, e2b = 0, e2e = 0, x1 = 0, x2 = 0, l1 = 0, l2 = 0;
+        if (a) { e1b = poff1[a - 1]; e1e = poff1[a]; l1 = lab1[a - 1]; x1 = l1 >> 7; }
+        if (b) { e2b = poff2[b - 1]; e2e = poff2[b]; l2 = lab2[b - 1]; x2 = l2 >> 7; }
+        uint32_t na = 0xFFFFFFFFu, nb = 0xFFFFFFFFu;
+        if (comp == 0) {
+            if (!a || !b) { status = 3; break; }
+            out[cap - 1 - len] = make_uint2(a, b);
+            ++len;
+            const int32_t s = ((l1 & 0x7f) == (l2 & 0x7f)) ? P.match : -P.mismatch;
+            // the inner break leaves only the inner loop: LAST prev1 with a hit, its FIRST prev2 (:1091-1099)
+            for (uint32_t e = e1b; e < e1e + x1; ++e) {
+                uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
+                for (uint32_t f = e2b; f < e2e + x2; ++f) {
+                    uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
+                    if (Mp[G.idx(pa, pb)] + s == Mv) { na = pa; nb = pb; break; }
+                }
+            }
+        } else if (comp > 0) {
+            if (!a) { status = 3; break; }
+            out[cap - 1 - len] = make_uint2(a, 0u);
+            ++len;
+            const int k = comp - 1;
+            const int32_t Iv = pl.I(k)[c];
+            for (uint32_t e = e1b; e < e1e + x1; ++e) {  // open before extend, first predecessor wins (:1105-1118)
+                uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
+                uint32_t pc = G.idx(pa, b);
+                if (Iv == Mp[pc] - P.oe[k]) { comp = 0; na = pa; nb = b; break; }
+                if (Iv == pl.I(k)[pc] - P.ext[k]) { na = pa; nb = b; break; }
+            }
+        } else {
+            if (!b) { status = 3; break; }
+            out[cap - 1 - len] = make_uint2(0u, b);
+            ++len;
+            const int k = -comp - 1;
+            const int32_t Dv = pl.D(k)[c];
+            for (uint32_t f = e2b; f < e2e + x2; ++f) {  // (:1123-1136)
+                uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
+                uint32_t pc = G.idx(a, pb);
+                if (Dv == Mp[pc] - P.oe[k]) { comp = 0; na = a; nb = pb; break; }
+                if (Dv == pl.D(k)[pc] - P.ext[k]) { na = a; nb = pb; break; }
+            }
+        }
+        if (na == 0xFFFFFFFFu) break;
+        a = na;
+        b = nb;
+    }
+    B.out_len[prob] = len;
+    B.out_status[prob] = status;
+}
+
+template <int NPW, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
+                                                              ClScoreParams P) {
+    const uint32_t prob = plist[blockIdx.x];
+    const ClProbDesc pd = B.desc[prob];
+    const DiagGeom G(pd.n1, pd.n2);
+    Planes<NPW> pl;
+    pl.base = B.planes + pd.plane_base;
+    pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
+    const uint32_t tid = threadIdx.x;
+
+    if (tid == 0) {  // the corner stays -inf in memory; the diagonal term treats it as 0 (alignment.hpp:814-818)
+        pl.M()[0] = CL_NEG_INF;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) { pl.I(k)[0] = CL_NEG_INF; pl.D(k)[0] = CL_NEG_INF; }
+    }
+    const uint32_t last = pd.n1 + pd.n2;
+    uint32_t off = 1;  // G.off(1)
+    for (uint32_t d = 1; d <= last; ++d) {
+        const uint32_t lo = G.lo(d), cnt = G.hi(d) - lo + 1;
+        for (uint32_t t = tid; t < cnt; t += BLOCK) {
+            const uint32_t a = lo + t;
+            compute_cell<NPW>(B, pd, G, pl, P, a, d - a, off + t);
+        }
+        off += cnt;
+        __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
+    }
+    if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
+}
+
+template <int NPW>
+void launch_general_npw(int block, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
+                        const ClScoreParams& P, hipStream_t stream) {
+    if (block <= 64)
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 64>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P);
+    else if (block <= 256)
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 256>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P);
+    else
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P);
+}
+
+}  // namespace
+
+// host-callable launcher (C++ linkage, used by cl_api.cpp only)
+hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
+                                   const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    switch (npw) {
+    case 1: launch_general_npw<1>(block, n_blocks, B, plist, P, stream); break;
+    case 2: launch_general_npw<2>(block, n_blocks, B, plist, P, stream); break;
+    case 3: launch_general_npw<3>(block, n_blocks, B, plist, P, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -253,3 +253,36 @@ def hor_stitch_batch(seed, total_len, min_anchor=20, seq_div=0.005, hor_div=0.02
     batch = StitchBatch(b1.finish(), b2.finish(), np.array(only_del, np.uint8))
     info = dict(n_anchors=len(anchors), len1=len(e1), len2=len(e2), n_skipped=n_skipped)
     return batch, info
+
+
+def batch_from_intervals(seq1, seq2, intervals, only_del=None):
+    """chain x chain stitch batch from (start1, len1, start2, len2) rows over two sequences; this is how the
+    between-anchor subproblems of a PAIRWISE alignment look (every subgraph is a stretch of one sequence)."""
+    e1 = encode(seq1) if isinstance(seq1, str) else np.asarray(seq1, np.uint8)
+    e2 = encode(seq2) if isinstance(seq2, str) else np.asarray(seq2, np.uint8)
+    iv = np.asarray(intervals, dtype=np.int64)
+    sides = []
+    for e, st, ln in ((e1, iv[:, 0], iv[:, 1]), (e2, iv[:, 2], iv[:, 3])):
+        n = len(ln)
+        node_off = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+        tot = int(node_off[-1])
+        within = np.arange(tot, dtype=np.int64) - np.repeat(node_off[:-1], ln)
+        pos = np.repeat(st, ln) + within
+        ne = np.maximum(ln - 1, 0)
+        edge_off = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
+        etot = int(edge_off[-1])
+        ewithin = np.arange(etot, dtype=np.int64) - np.repeat(edge_off[:-1], ne)
+        # node v of problem k: prev list = [v-1] for v >= 1 -> cumulative count after node v is edge_off[k] + v
+        prev_off = np.concatenate([[0], np.repeat(edge_off[:-1], ln) + within]).astype(np.uint64)
+        next_off = np.concatenate([[0], np.repeat(edge_off[:-1], ln) + np.minimum(within + 1, np.repeat(ne, ln))]).astype(np.uint64)
+        has = (ln > 0).astype(np.int64)
+        one_off = np.concatenate([[0], np.cumsum(has)]).astype(np.uint64)
+        sides.append(GraphSide(
+            node_off=node_off.astype(np.uint64), label=e[pos] if tot else np.zeros(0, np.uint8),
+            prev_off=prev_off, prev_idx=ewithin.astype(np.uint32),
+            next_off=next_off, next_idx=(ewithin + 1).astype(np.uint32),
+            src_off=one_off, src_idx=np.zeros(int(has.sum()), np.uint32),
+            snk_off=one_off, snk_idx=(ln[ln > 0] - 1).astype(np.uint32),
+            back_translation=pos.astype(np.uint64)))
+    od = np.zeros(len(iv), np.uint8) if only_del is None else np.asarray(only_del, np.uint8)
+    return StitchBatch(sides[0], sides[1], od)

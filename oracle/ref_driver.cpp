@@ -384,6 +384,7 @@ int ref_msa_dump(const char* fasta_path, const char* newick_path, const char* du
     try {
         auto T0 = std::chrono::steady_clock::now();
         Parameters params;
+        params.set<std::string>("fasta_name", fasta_path);
         if (skip_calibration) params.set<bool>("skip_calibration", true);
         if (max_num_match_pairs > 0) params.set<int64_t>("max_num_match_pairs", (int64_t)max_num_match_pairs);
         params.validate();
