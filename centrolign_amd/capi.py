@@ -97,6 +97,11 @@ class PlanStats(C.Structure):
                  "n_launches")]
 
 
+class LaunchInfo(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
+                ("dp_bytes", C.c_uint64), ("last_ms", C.c_float)]
+
+
 _SIDE_DTYPES = dict(node_off=np.uint64, label=np.uint8, prev_off=np.uint64, prev_idx=np.uint32,
                     next_off=np.uint64, next_idx=np.uint32, src_off=np.uint64, src_idx=np.uint32,
                     snk_off=np.uint64, snk_idx=np.uint32, back_translation=np.uint64)
@@ -338,6 +343,10 @@ def load_library(path=None):
     lib.cl_stitch_plan_destroy.argtypes = [C.c_void_p, C.c_void_p]
     lib.cl_stitch_plan_stats.restype = C.c_int
     lib.cl_stitch_plan_stats.argtypes = [C.c_void_p, C.POINTER(PlanStats)]
+    lib.cl_stitch_plan_launch_count.restype = C.c_int
+    lib.cl_stitch_plan_launch_count.argtypes = [C.c_void_p]
+    lib.cl_stitch_plan_launch_info.restype = C.c_int
+    lib.cl_stitch_plan_launch_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(LaunchInfo)]
     if path is None:
         _lib = lib
     return lib
@@ -348,6 +357,7 @@ EXPORTED_SYMBOLS = [
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
+    "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
 ]
 
 
@@ -375,6 +385,16 @@ class Plan:
         st = PlanStats()
         self.ctx._check(self.ctx.lib.cl_stitch_plan_stats(self.handle, C.byref(st)))
         return {n: int(getattr(st, n)) for n, _ in PlanStats._fields_}
+
+    def launches(self):
+        """per-kernel-launch info of the last execute (call after sync)"""
+        out = []
+        for i in range(self.ctx.lib.cl_stitch_plan_launch_count(self.handle)):
+            li = LaunchInfo()
+            self.ctx._check(self.ctx.lib.cl_stitch_plan_launch_info(self.ctx.handle, self.handle, i, C.byref(li)))
+            out.append(dict(kernel=li.kernel.decode(), n_problems=int(li.n_problems), dp_cells=int(li.dp_cells),
+                            dp_bytes=int(li.dp_bytes), ms=float(li.last_ms)))
+        return out
 
     def destroy(self):
         if self.handle:

@@ -321,6 +321,8 @@ struct LaunchGroup {
     int rows = 0, waves = 0;  // linear kernel: rows per lane, waves per workgroup
     uint32_t first = 0;  // into plist
     uint32_t count = 0;
+    uint64_t cells = 0, bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 }  // namespace
@@ -368,6 +370,10 @@ void plan_free(cl_stitch_plan* pl) {
     }
     pl->d_planes.release(); pl->d_out_pairs.release(); pl->d_out_len.release(); pl->d_out_status.release();
     pl->d_plist.release(); pl->d_out_score.release();
+    for (auto& g : pl->groups) {
+        if (g.ev0) (void)hipEventDestroy(g.ev0);
+        if (g.ev1) (void)hipEventDestroy(g.ev1);
+    }
     if (pl->ev_start) (void)hipEventDestroy(pl->ev_start);
     if (pl->ev_stop) (void)hipEventDestroy(pl->ev_stop);
     delete pl;
@@ -598,6 +604,11 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     auto close_group = [&](LaunchGroup grp) {
         grp.count = (uint32_t)plist.size() - grp.first;
         if (!grp.count) return;
+        for (uint32_t i = grp.first; i < plist.size(); ++i) {
+            grp.cells += cells_of(plist[i]);
+            grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * grp.npw);
+        }
+        if (hipEventCreate(&grp.ev0) != hipSuccess || hipEventCreate(&grp.ev1) != hipSuccess) grp.ev0 = grp.ev1 = nullptr;
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
         pl->groups.push_back(grp);
     };
@@ -670,10 +681,12 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
         const LaunchGroup& g = pl->groups[gi];
         int si = (int)(gi % kNumAuxStreams);
         if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
+        if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
         if (g.kind == CL_KIND_LINEAR)
             HIP_TRY(ctx, cl_launch_popoa_linear(g.npw, g.rows, g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
         else
             HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
+        if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->aux[si]));
     }
     for (int si = 0; si < kNumAuxStreams; ++si)
         if (used[si]) {
@@ -699,6 +712,24 @@ int cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* pl, float* ms_out) {
 int cl_stitch_plan_stats(const cl_stitch_plan* pl, cl_plan_stats* out) {
     if (!pl || !out) return CL_ERR_INVALID_ARGUMENT;
     *out = pl->stats;
+    return CL_OK;
+}
+
+int cl_stitch_plan_launch_count(const cl_stitch_plan* pl) { return pl ? (int)pl->groups.size() : 0; }
+
+int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int index, cl_launch_info* out) {
+    if (!ctx || !pl || !out || index < 0 || index >= (int)pl->groups.size()) return CL_ERR_INVALID_ARGUMENT;
+    const LaunchGroup& g = pl->groups[index];
+    memset(out, 0, sizeof(*out));
+    if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear<npw=%d,rows=%d,waves=%d>", g.npw, g.rows, g.waves);
+    else snprintf(out->kernel, sizeof(out->kernel), "popoa_general<npw=%d,block=%d>", g.npw, g.block);
+    out->n_problems = g.count;
+    out->dp_cells = g.cells;
+    out->dp_bytes = g.bytes;
+    if (pl->executed && g.ev0 && g.ev1) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (hipEventElapsedTime(&out->last_ms, g.ev0, g.ev1) != hipSuccess) out->last_ms = 0.f;
+    }
     return CL_OK;
 }
 

@@ -175,6 +175,18 @@ typedef struct cl_plan_stats {
 } cl_plan_stats;
 int cl_stitch_plan_stats(const cl_stitch_plan* plan, cl_plan_stats* stats_out);
 
+/* one kernel launch of a plan (a group of subproblems that share a kernel variant) */
+typedef struct cl_launch_info {
+    char     kernel[64];         /* e.g. "popoa_linear<npw=2,rows=4,waves=1>" */
+    uint64_t n_problems;
+    uint64_t dp_cells;
+    uint64_t dp_bytes;           /* algorithmic bytes: cells * sizeof(cell_t<NumPW>) */
+    float    last_ms;            /* device duration of this launch in the LAST execute (HIP events on its stream);
+                                    valid after cl_stitch_plan_sync */
+} cl_launch_info;
+int cl_stitch_plan_launch_count(const cl_stitch_plan* plan);
+int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int index, cl_launch_info* info_out);
+
 #ifdef __cplusplus
 }
 #endif

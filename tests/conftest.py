@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs the compiled reference in oracle/_ref (build container only)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    from centrolign_amd import capi
+    ctx = capi.Context(0)  # raises loudly without a GPU or without the HIP library
+    yield ctx
+    ctx.close()

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Regenerates the golden vectors under tests/golden/ from the COMPILED REFERENCE (oracle/_ref, built from
+/root/reference by `make -C oracle ref`).  Runs only in the build container.  Every fixture stores inputs
+and the reference's outputs; nothing of the reference's source is stored.
+
+  popoa_random_dags.npz      400 seeded random DAG pairs -> Stitcher::subalign and po_poa<1|2|3> results
+  popoa_tie_params.npz       the same kind of batch under tie-heavy unit scoring (match=mismatch=1, open 1/2/3, extend 3/2/1;
+                             cf. the reference's own tests, src/test/test_alignment.cpp:711-715) on a 2-letter alphabet
+  c2_pair_seed7_intervals.npz  the stitch subproblems the reference extracts for the 2 x 1 Mbp HOR pair (seed 7):
+                             (start1,len1,start2,len2) per subproblem, sha256 of the reference's full result,
+                             and the full expected alignments of the first 600 subproblems
+  msa4_stitch_*.npz          stitch batches of a 4-sequence progressive MSA (graph x graph subproblems with bubbles)
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from centrolign_amd import capi, synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+SIDE_KEYS = ("node_off", "label", "prev_off", "prev_idx", "next_off", "next_idx", "src_off", "src_idx", "snk_off",
+             "snk_idx", "back_translation")
+
+
+def pack_batch(batch, prefix=""):
+    out = {}
+    for si, s in enumerate(batch.side):
+        for k in SIDE_KEYS:
+            out["%sg%d.%s" % (prefix, si + 1, k)] = getattr(s, k)
+    out[prefix + "only_deletion_alns"] = batch.only_deletion_alns
+    return out
+
+
+def pack_result(res, prefix):
+    return {prefix + "aln_off": res.aln_off, prefix + "pairs": res.pairs, prefix + "score": res.score,
+            prefix + "route": res.route, prefix + "num_pw": res.num_pw}
+
+
+def result_digest(aln_off, pairs):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(aln_off, dtype=np.uint64).tobytes())
+    h.update(np.ascontiguousarray(pairs, dtype=np.uint64).tobytes())
+    return h.hexdigest()
+
+
+def ref_results(batch, params, with_forced=True):
+    out = {}
+    res, _ = po.ref_stitch_batch(batch, params)
+    # the reference does not report route / NumPW / score from subalign; take the oracle's, which the
+    # parity tests separately pin to the reference's alignments
+    orc = po.oracle_stitch_batch(batch, params)
+    assert res.same_as(orc, check_score=False, check_route=False) is None
+    res.route, res.num_pw, res.score = orc.route, orc.num_pw, orc.score
+    out.update(pack_result(res, "subalign."))
+    if with_forced:
+        for npw in (1, 2, 3):
+            f = np.full(batch.n_problems, npw, np.uint8)
+            r, _ = po.ref_stitch_batch(batch, params, force_num_pw=f)
+            o = po.oracle_stitch_batch(batch, params, force_num_pw=f)
+            r.route = o.route
+            out.update(pack_result(r, "po_poa%d." % npw))
+    return out
+
+
+def main():
+    sp = capi.default_stitch_params()
+    # 1. random DAG pairs, CLI scoring
+    b = synth.random_dag_batch(400, seed=20261002, max_n=36)
+    d = pack_batch(b)
+    d.update(ref_results(b, sp))
+    np.savez_compressed(os.path.join(HERE, "popoa_random_dags.npz"), **d)
+    # 2. tie-heavy scoring
+    tp = capi.default_stitch_params()
+    tp.alignment_params.match = 1
+    tp.alignment_params.mismatch = 1
+    # (all-equal penalties would make the reference's subalign divide by zero, src/stitcher.cpp:43)
+    tp.alignment_params.gap_open[:] = [1, 2, 3]
+    tp.alignment_params.gap_extend[:] = [3, 2, 1]
+    b = synth.random_dag_batch(300, seed=77, max_n=30, alphabet=2)
+    d = pack_batch(b)
+    d.update(ref_results(b, tp))
+    np.savez_compressed(os.path.join(HERE, "popoa_tie_params.npz"), **d)
+    # 3. the 2 x 1 Mbp pair: needs the dump made by ref_msa_dump (94 s); reuse it if present
+    dump = "/tmp/c2/s7_1000000_2.fa.dump"
+    if not os.path.exists(dump):
+        os.makedirs("/tmp/c2", exist_ok=True)
+        seqs = synth.hor_sequences(7, 1000000, 2)
+        synth.write_fasta("/tmp/c2/s7_1000000_2.fa", seqs)
+        po.ref_msa_dump("/tmp/c2/s7_1000000_2.fa", None, dump, "/tmp/c2/s7_1000000_2.fa.out")
+    dd = po.read_dump(dump)
+    batch, aln_off, pairs = po.batch_from_dump(dd, "m0.")
+    iv = []
+    for s in batch.side:
+        no = s.node_off.astype(np.int64)
+        bt = s.back_translation.astype(np.int64)
+        ln = np.diff(no)
+        st = np.where(ln > 0, bt[np.minimum(no[:-1], len(bt) - 1)], 0)
+        assert np.array_equal(bt, np.repeat(st, ln) + np.arange(len(bt)) - np.repeat(no[:-1], ln))
+        iv += [st, ln]
+    head = 600
+    np.savez_compressed(os.path.join(HERE, "c2_pair_seed7_intervals.npz"),
+                        intervals=np.stack(iv, 1).astype(np.int64), only_del=batch.only_deletion_alns,
+                        ref_sha256=np.frombuffer(result_digest(aln_off, pairs).encode(), dtype=np.uint8),
+                        n_pairs=np.array([len(pairs)], np.int64), dp_cells=np.array([batch.dp_cells()], np.int64),
+                        head_aln_off=aln_off[:head + 1], head_pairs=pairs[:int(aln_off[head])],
+                        cigar_sha256=np.frombuffer(hashlib.sha256(dd["output"].tobytes()).hexdigest().encode(), dtype=np.uint8))
+    # 4. MSA-derived graph x graph batches (dump made by /tmp/c2/run_msa.py-style call)
+    for tag, path in (("msa4_40k", "/tmp/c2/msa_s13_40000_4.fa.dump"),):
+        if not os.path.exists(path):
+            print("skip", tag, "(no dump at %s)" % path)
+            continue
+        try:
+            dd = po.read_dump(path)
+            n_merges = int(dd["n_merges"][0])
+        except Exception as ex:  # dump still being written
+            print("skip", tag, "(%s)" % ex)
+            continue
+        for m in range(n_merges):
+            batch, aln_off, pairs = po.batch_from_dump(dd, "m%d." % m)
+            d = pack_batch(batch)
+            d["subalign.aln_off"], d["subalign.pairs"] = aln_off, pairs
+            np.savez_compressed(os.path.join(HERE, "%s_merge%d.npz" % (tag, m)), **d)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

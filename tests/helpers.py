@@ -1,0 +1,122 @@
+"""shared helpers for the parity tests"""
+import hashlib
+import os
+
+import numpy as np
+
+from centrolign_amd import capi, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SIDE_KEYS = ("node_off", "label", "prev_off", "prev_idx", "next_off", "next_idx", "src_off", "src_idx", "snk_off",
+             "snk_idx", "back_translation")
+
+
+def load_batch(z, prefix=""):
+    sides = [capi.GraphSide(**{k: z["%sg%d.%s" % (prefix, si, k)] for k in SIDE_KEYS}) for si in (1, 2)]
+    return capi.StitchBatch(sides[0], sides[1], z[prefix + "only_deletion_alns"])
+
+
+def load_result(z, prefix):
+    n = len(z[prefix + "aln_off"]) - 1
+    get = lambda k, dt: z[prefix + k] if (prefix + k) in z.files else np.zeros(n, dt)
+    return capi.StitchResult(z[prefix + "aln_off"], z[prefix + "pairs"].reshape(-1, 2), get("score", np.int64),
+                             get("route", np.uint8), get("num_pw", np.uint8))
+
+
+def result_digest(aln_off, pairs):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(aln_off, dtype=np.uint64).tobytes())
+    h.update(np.ascontiguousarray(pairs, dtype=np.uint64).tobytes())
+    return h.hexdigest()
+
+
+def tie_params():
+    tp = capi.default_stitch_params()
+    tp.alignment_params.match = 1
+    tp.alignment_params.mismatch = 1
+    tp.alignment_params.gap_open[:] = [1, 2, 3]
+    tp.alignment_params.gap_extend[:] = [3, 2, 1]
+    return tp
+
+
+_c2 = {}
+
+
+def c2_batch():
+    """the reference's stitch batch for the 2 x 1 Mbp HOR pair, rebuilt from the seed + dumped intervals"""
+    if "b" not in _c2:
+        z = np.load(os.path.join(GOLDEN, "c2_pair_seed7_intervals.npz"))
+        seqs = synth.hor_sequences(7, 1000000, 2)
+        _c2["b"] = synth.batch_from_intervals(seqs[0], seqs[1], z["intervals"], z["only_del"])
+        _c2["z"] = z
+    return _c2["b"], _c2["z"]
+
+
+def check_alignment_valid(batch, res, k):
+    """structural validity of one alignment in LOCAL ids (back_translation removed by the caller):
+    every node appears at most once per side, ids increase along graph edges is not checked here"""
+    aln = res.alignment(k)
+    for col in (0, 1):
+        ids = aln[:, col]
+        ids = ids[ids != capi.CL_GAP]
+        assert len(np.unique(ids)) == len(ids)
+
+
+# the reference's own fixed expectations, transcribed as data -------------------------------------------------
+def _graph(labels, edges, sources, sinks):
+    return dict(labels=[ord(c) for c in labels], edges=edges, sources=sources, sinks=sinks)
+
+
+def known_answer_cases():
+    """(graph1, graph2, num_pw, params, expected pairs) from src/test/test_alignment.cpp:684-773.
+    -1 marks a gap."""
+    bubbles = [(0, 1), (0, 2), (1, 3), (2, 3), (3, 4), (3, 5), (4, 6), (5, 6)]
+    unit = capi.make_align_params(1, 1, [1], [1])
+    g1 = _graph("ACGTGCA", bubbles, [0], [6])
+    g2 = _graph("AGTTTGA", bubbles, [0], [6])
+    cases = [(g1, g2, 1, unit, [(0, 0), (2, 1), (3, 3), (4, 5), (6, 6)])]
+    g1t = _graph("ACGTGCAT", bubbles + [(7, 0)], [7], [6])
+    g2t = _graph("AGTTTGAT", bubbles + [(6, 7)], [0], [7])
+    cases.append((g1t, g2t, 1, unit, [(7, -1), (0, 0), (2, 1), (3, 3), (4, 5), (6, 6), (-1, 7)]))
+    cases.append((g2t, g1t, 1, unit, [(-1, 7), (0, 0), (1, 2), (3, 3), (5, 4), (6, 6), (7, -1)]))
+    return cases
+
+
+def stitcher_known_answer():
+    """src/test/test_stitcher.cpp:321-438: the four between-anchor subproblems Stitcher::stitch extracts for that
+    fixture (derived by hand from extract_connecting_graph, include/centrolign/subgraph_extraction.hpp:52-125),
+    the anchors copied between them, and the expected stitched alignment.  Stitcher class defaults
+    (src/stitcher.cpp:13-22, stitcher.hpp:48-64)."""
+    s1, s2 = "ACCAGTCGTTGA", "GATCGTGAACTATGC"
+    L = lambda s, ids: [ord(s[i]) for i in ids]
+    subs = [
+        # (graph1 nodes, edges, sources, sinks, back), (graph2 ...), only_deletion_alns
+        (dict(labels=[], edges=[], sources=[], sinks=[], back=[]),
+         dict(labels=L(s2, [0]), edges=[], sources=[0], sinks=[0], back=[0]), 1),
+        (dict(labels=L(s1, [3]), edges=[], sources=[0], sinks=[0], back=[3]),
+         dict(labels=[], edges=[], sources=[], sinks=[], back=[]), 0),
+        (dict(labels=L(s1, [6, 7, 8]), edges=[(1, 2), (0, 2)], sources=[0, 1], sinks=[2], back=[6, 7, 8]),
+         dict(labels=L(s2, [7, 8, 9, 10]), edges=[(0, 1), (0, 2), (2, 3), (1, 3)], sources=[0], sinks=[3],
+              back=[7, 8, 9, 10]), 0),
+        (dict(labels=L(s1, [11]), edges=[], sources=[0], sinks=[0], back=[11]),
+         dict(labels=L(s2, [14]), edges=[], sources=[0], sinks=[0], back=[14]), 1),
+    ]
+    anchors = [[(0, 1), (1, 3)], [(4, 4), (5, 5)], [(9, 12), (10, 13)]]
+    expected = [(-1, 0), (0, 1), (1, 3), (3, -1), (4, 4), (5, 5), (-1, 7), (6, 9), (8, 10), (9, 12), (10, 13), (11, 14)]
+    sp = capi.default_stitch_params()
+    sp.max_trivial_size, sp.min_wfa_size, sp.max_wfa_size = 30000, 10000000, 50000000
+    sp.deletion_alignment_ratio, sp.deletion_alignment_short_max_size, sp.deletion_alignment_long_min_size = 4, 4000, 2000
+    return subs, anchors, expected, sp
+
+
+def batch_from_graphs(pairs_of_graphs, only_del=None):
+    b1, b2 = synth._SideBuilder(), synth._SideBuilder()
+    for g1, g2 in pairs_of_graphs:
+        for bld, g in ((b1, g1), (b2, g2)):
+            bld.add_graph(np.array(g["labels"], np.uint8), g["edges"], g["sources"], g["sinks"], g.get("back"))
+    n = len(pairs_of_graphs)
+    return capi.StitchBatch(b1.finish(), b2.finish(), np.zeros(n, np.uint8) if only_del is None else only_del)
+
+
+def as_signed_pairs(pairs):
+    return [(-1 if a == capi.CL_GAP else int(a), -1 if b == capi.CL_GAP else int(b)) for a, b in pairs]

@@ -1,0 +1,124 @@
+"""CPU suite (-m "not gpu"): pins the oracle (oracle/popoa_oracle.c) to the reference.
+
+* against every committed golden vector (outputs of the compiled reference, tests/golden/make_golden.py);
+* against the reference's own fixed expectations (src/test/test_alignment.cpp:684-773,
+  src/test/test_stitcher.cpp:321-438), transcribed as data in tests/helpers.py;
+* live against oracle/_ref when it is present (build container), on fresh random inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from centrolign_amd import capi, synth
+from oracle import pyoracle as po
+from tests import helpers as H
+
+
+def test_oracle_matches_golden_random_dags():
+    z = np.load(os.path.join(H.GOLDEN, "popoa_random_dags.npz"))
+    b = H.load_batch(z)
+    assert po.oracle_stitch_batch(b).same_as(H.load_result(z, "subalign.")) is None
+    for npw in (1, 2, 3):
+        f = np.full(b.n_problems, npw, np.uint8)
+        got = po.oracle_stitch_batch(b, force_num_pw=f)
+        assert got.same_as(H.load_result(z, "po_poa%d." % npw), check_route=False) is None
+
+
+def test_oracle_matches_golden_tie_params():
+    z = np.load(os.path.join(H.GOLDEN, "popoa_tie_params.npz"))
+    b = H.load_batch(z)
+    tp = H.tie_params()
+    assert po.oracle_stitch_batch(b, tp).same_as(H.load_result(z, "subalign.")) is None
+    for npw in (1, 2, 3):
+        f = np.full(b.n_problems, npw, np.uint8)
+        got = po.oracle_stitch_batch(b, tp, force_num_pw=f)
+        assert got.same_as(H.load_result(z, "po_poa%d." % npw), check_route=False) is None
+
+
+def test_oracle_matches_reference_on_c2_pair():
+    """the whole 2 x 1 Mbp stitch batch: digest of all 13 245 alignments + the first 600 in full"""
+    b, z = H.c2_batch()
+    assert b.n_problems == 13245 and b.dp_cells() == int(z["dp_cells"][0]) == 42416142
+    r = po.oracle_stitch_batch(b)
+    assert len(r.pairs) == int(z["n_pairs"][0])
+    assert H.result_digest(r.aln_off, r.pairs) == bytes(z["ref_sha256"]).decode()
+    head = len(z["head_aln_off"]) - 1
+    assert np.array_equal(r.aln_off[:head + 1], z["head_aln_off"])
+    assert np.array_equal(r.pairs[:int(z["head_aln_off"][-1])], z["head_pairs"])
+    assert np.bincount(r.route).tolist() == [12304, 938, 3]
+    assert np.bincount(r.num_pw).tolist() == [0, 8847, 4394, 4]
+
+
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("msa4_")))
+def test_oracle_matches_golden_msa(name):
+    z = np.load(os.path.join(H.GOLDEN, name))
+    b = H.load_batch(z)
+    want = H.load_result(z, "subalign.")
+    got = po.oracle_stitch_batch(b)
+    assert got.same_as(want, check_score=False, check_route=False) is None
+
+
+def test_known_answers_po_poa():
+    for g1, g2, npw, params, expected in H.known_answer_cases():
+        b = H.batch_from_graphs([(g1, g2)])
+        sp = capi.default_stitch_params()
+        sp.alignment_params = params
+        r = po.oracle_stitch_batch(b, sp, force_num_pw=np.array([npw], np.uint8))
+        assert H.as_signed_pairs(r.alignment(0)) == expected
+
+
+def test_known_answer_stitcher():
+    subs, anchors, expected, sp = H.stitcher_known_answer()
+    b = H.batch_from_graphs([(s[0], s[1]) for s in subs], np.array([s[2] for s in subs], np.uint8))
+    r = po.oracle_stitch_batch(b, sp)
+    stitched = []
+    for k in range(len(subs)):
+        stitched += H.as_signed_pairs(r.alignment(k))
+        if k < len(anchors):
+            stitched += anchors[k]
+    assert stitched == expected
+    assert r.route.tolist() == [2, 1, 0, 0]
+
+
+def test_num_pw_cutoffs():
+    """src/stitcher.cpp:31-52 with the CLI parameters: cutoffs 30 and 425"""
+    lib = po.oracle_lib()
+    p = capi.default_stitch_params().alignment_params
+    f = lambda a, b: lib.clo_choose_num_pw(a, b, p)
+    assert [f(30, 30), f(31, 31), f(31, 30), f(425, 9999), f(426, 426), f(5000, 31)] == [1, 2, 1, 2, 3, 2]
+    bad = capi.make_align_params(20, 80, [60, 50, 2500], [30, 5, 1])
+    assert lib.clo_choose_num_pw(10, 10, bad) == -2
+
+
+def test_empty_and_degenerate_problems():
+    lb = synth.linear_batch([(0, 0), (0, 4), (5, 0), (1, 1), (1, 7), (7, 1)], seed=5)
+    r = po.oracle_stitch_batch(lb)
+    assert r.route.tolist() == [1, 2, 1, 0, 0, 0]
+    assert len(r.alignment(0)) == 0
+    assert H.as_signed_pairs(r.alignment(1)) == [(-1, i) for i in range(4)]
+    assert H.as_signed_pairs(r.alignment(2)) == [(i, -1) for i in range(5)]
+
+
+def test_unsupported_route_is_reported():
+    lb = synth.linear_batch([(300, 200)], seed=1)
+    lb.only_deletion_alns[:] = 1  # 60k cells > max_trivial_size between segments -> heuristic route
+    with pytest.raises(RuntimeError):
+        po.oracle_stitch_batch(lb)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not po.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_vs_compiled_reference_live():
+    for seed, max_n in ((101, 10), (102, 45), (103, 120)):
+        b = synth.random_dag_batch(150 if max_n < 100 else 40, seed=seed, max_n=max_n)
+        ref, _ = po.ref_stitch_batch(b)
+        assert po.oracle_stitch_batch(b).same_as(ref, check_score=False, check_route=False) is None
+        for npw in (1, 2, 3):
+            f = np.full(b.n_problems, npw, np.uint8)
+            ref, _ = po.ref_stitch_batch(b, force_num_pw=f)
+            got = po.oracle_stitch_batch(b, force_num_pw=f)
+            assert got.same_as(ref, check_route=False, check_score=False) is None
+            n1, n2 = b.sizes()
+            m = (n1 > 0) & (n2 > 0)
+            assert np.array_equal(got.score[m], ref.score[m])
