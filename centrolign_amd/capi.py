@@ -336,6 +336,8 @@ def load_library(path=None):
                                           C.POINTER(C.c_void_p)]
     lib.cl_stitch_plan_execute.restype = C.c_int
     lib.cl_stitch_plan_execute.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cl_stitch_plan_execute_profiled.restype = C.c_int
+    lib.cl_stitch_plan_execute_profiled.argtypes = [C.c_void_p, C.c_void_p]
     lib.cl_stitch_plan_sync.restype = C.c_int
     lib.cl_stitch_plan_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.cl_stitch_plan_collect.restype = C.c_int
@@ -355,7 +357,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
-    "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_sync",
+    "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
 ]
@@ -367,6 +369,9 @@ class Plan:
 
     def execute(self):
         self.ctx._check(self.ctx.lib.cl_stitch_plan_execute(self.ctx.handle, self.handle))
+
+    def execute_profiled(self):
+        self.ctx._check(self.ctx.lib.cl_stitch_plan_execute_profiled(self.ctx.handle, self.handle))
 
     def sync(self):
         ms = C.c_float(0)

@@ -26,9 +26,9 @@
 
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
-hipError_t cl_launch_popoa_linear(int npw, int R, int W, uint32_t n_blocks, const ClDeviceBatch& B,
-                                  const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
-size_t cl_linear_workspace_bytes(uint32_t n1, uint32_t n2, int npw, int R);
+hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
+                                  const ClScoreParams& P, hipStream_t stream);
+size_t cl_linear_workspace_bytes(uint32_t nr, uint32_t nc, int npw, int R);
 
 namespace {
 
@@ -36,8 +36,10 @@ thread_local std::string g_error;
 
 // test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
+// test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
+const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && *e == '1'; }();
 
-constexpr int kNumAuxStreams = 4;
+constexpr int kNumAuxStreams = 12;
 
 }  // namespace
 
@@ -319,6 +321,7 @@ struct LaunchGroup {
     int npw = 0;
     int block = 0;       // general kernel: workgroup size
     int rows = 0, waves = 0;  // linear kernel: rows per lane, waves per workgroup
+    bool swap = false;        // linear kernel: graph 2 laid across the lanes
     uint32_t first = 0;  // into plist
     uint32_t count = 0;
     uint64_t cells = 0, bytes = 0;
@@ -337,7 +340,7 @@ struct cl_stitch_plan {
     std::vector<uint32_t> pd_problem;              // list of problems with a pd path
     // per PO-POA problem
     std::vector<ClProbDesc> desc;
-    std::vector<uint8_t> lin_rows, lin_waves;      // linear-kernel geometry per PO-POA problem (0 = general kernel)
+    std::vector<uint8_t> lin_rows, lin_waves, lin_swap;  // chain-kernel geometry per PO-POA problem (0 = general kernel)
     std::vector<uint64_t> po_problem;              // input problem index
     std::vector<uint32_t> order[2];                // rank -> local node id, concatenated (node_base)
     // translation back to caller ids
@@ -357,7 +360,10 @@ struct cl_stitch_plan {
     ClScoreParams sparams{};
     cl_plan_stats stats{};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool executed = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_tried = false;
+    bool executed = false, profiled = false;
 };
 
 namespace {
@@ -374,6 +380,8 @@ void plan_free(cl_stitch_plan* pl) {
         if (g.ev0) (void)hipEventDestroy(g.ev0);
         if (g.ev1) (void)hipEventDestroy(g.ev1);
     }
+    if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
+    if (pl->graph) (void)hipGraphDestroy(pl->graph);
     if (pl->ev_start) (void)hipEventDestroy(pl->ev_start);
     if (pl->ev_stop) (void)hipEventDestroy(pl->ev_stop);
     delete pl;
@@ -571,17 +579,23 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
         d.kind = (linear && !g_force_general) ? CL_KIND_LINEAR : CL_KIND_GENERAL;
         d.plane_base = plane_cursor;
-        uint8_t lr = 0, lw = 0;
+        uint8_t lr = 0, lw = 0, ls = 0;
         if (d.kind == CL_KIND_LINEAR) {
-            // rows per lane / waves per workgroup by the number of graph-1 nodes
-            lr = d.n1 <= 64 ? 1 : d.n1 <= 128 ? 2 : 4;
-            lw = d.n1 <= 256 ? 1 : d.n1 <= 1024 ? 4 : 16;
-            plane_cursor += (cl_linear_workspace_bytes(d.n1, d.n2, npw, lr) + 15) / 16 * 4;
+            // the shorter graph goes across the lanes; strips of 64 rows are pipelined over the waves
+            ls = d.n2 < d.n1;
+            const uint32_t nshort = std::min(d.n1, d.n2), nlong = std::max(d.n1, d.n2);
+            if (nshort <= 64) { lr = 1; lw = 1; }
+            else if (nshort <= 128 && nlong < 300) { lr = 2; lw = 1; }
+            else if (nshort <= 256) { lr = 1; lw = 4; }
+            else { lr = 1; lw = 16; }
+            d.pad = (uint16_t)(ls | (lr << 1));  // read by linear_dispatch
+            plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
         } else {
             plane_cursor += (cells * (uint64_t)(1 + 2 * npw) + 3) / 4 * 4;
         }
         pl->lin_rows.push_back(lr);
         pl->lin_waves.push_back(lw);
+        pl->lin_swap.push_back(ls);
         if (out_cursor + d.n1 + d.n2 >= (1ull << 32)) { set_error(ctx, "batch too large for 32-bit output offsets"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
         d.out_base = (uint32_t)out_cursor;
         out_cursor += d.n1 + d.n2;
@@ -612,17 +626,25 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
         pl->groups.push_back(grp);
     };
-    const int lin_geom[5][2] = {{4, 16}, {4, 4}, {4, 1}, {2, 1}, {1, 1}};
-    for (int gi = 0; gi < 5; ++gi)
-        for (int npw = 3; npw >= 1; --npw) {
-            LaunchGroup grp;
-            grp.kind = CL_KIND_LINEAR; grp.npw = npw; grp.rows = lin_geom[gi][0]; grp.waves = lin_geom[gi][1];
-            grp.first = (uint32_t)plist.size();
-            for (uint32_t i = 0; i < pl->desc.size(); ++i)
-                if (pl->desc[i].kind == CL_KIND_LINEAR && pl->desc[i].npw == npw && pl->lin_rows[i] == grp.rows && pl->lin_waves[i] == grp.waves)
-                    plist.push_back(i);
-            close_group(grp);
+    // chain kernel: one launch per workgroup shape; the problems are ordered by the length of their sweep
+    const int lin_waves[3] = {16, 4, 1};
+    for (int gi = 0; gi < 3; ++gi) {
+        LaunchGroup grp;
+        grp.kind = CL_KIND_LINEAR; grp.npw = 0; grp.waves = lin_waves[gi];
+        grp.first = (uint32_t)plist.size();
+        for (uint32_t i = 0; i < pl->desc.size(); ++i)
+            if (pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == grp.waves) plist.push_back(i);
+        grp.count = (uint32_t)plist.size() - grp.first;
+        if (!grp.count) continue;
+        for (uint32_t i = grp.first; i < plist.size(); ++i) {
+            grp.cells += cells_of(plist[i]);
+            grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * pl->desc[plist[i]].npw);
         }
+        auto sweep = [&](uint32_t x) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 + (pl->desc[x].npw == 3 ? 64 : 0); };
+        std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return sweep(x) > sweep(y); });
+        if (hipEventCreate(&grp.ev0) != hipSuccess || hipEventCreate(&grp.ev1) != hipSuccess) grp.ev0 = grp.ev1 = nullptr;
+        pl->groups.push_back(grp);
+    }
     const int blocks[3] = {64, 256, 1024};
     for (int bi = 2; bi >= 0; --bi)
         for (int npw = 3; npw >= 1; --npw) {
@@ -637,6 +659,16 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             }
             close_group(grp);
         }
+    // longest-running launch first: a group's duration is set by its longest anti-diagonal sweep
+    {
+        auto crit = [&](const LaunchGroup& g) {
+            uint64_t c = 0;
+            for (uint32_t i = g.first; i < g.first + g.count; ++i)
+                c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
+            return c * (g.kind == CL_KIND_GENERAL ? 8 : 1);
+        };
+        std::stable_sort(pl->groups.begin(), pl->groups.end(), [&](const LaunchGroup& x, const LaunchGroup& y) { return crit(x) > crit(y); });
+    }
     pl->stats.n_launches = pl->groups.size();
 
     // HBM
@@ -670,31 +702,74 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     return CL_OK;
 }
 
-int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
-    if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
-    // fork: independent launch groups run concurrently on the auxiliary streams
+// Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
+// HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
+static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     bool used[kNumAuxStreams] = {};
     for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
         const LaunchGroup& g = pl->groups[gi];
         int si = (int)(gi % kNumAuxStreams);
         if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
-        if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
+        if (timed && g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
         if (g.kind == CL_KIND_LINEAR)
-            HIP_TRY(ctx, cl_launch_popoa_linear(g.npw, g.rows, g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
+            HIP_TRY(ctx, cl_launch_popoa_linear(g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
         else
             HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
-        if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->aux[si]));
+        if (timed && g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->aux[si]));
     }
     for (int si = 0; si < kNumAuxStreams; ++si)
         if (used[si]) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join[si], ctx->aux[si]));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[si], 0));
         }
+    return CL_OK;
+}
+
+int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
+    if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // The launch DAG (one kernel per group, all independent) is captured once into a hipGraph and replayed:
+    // a dozen kernels start together instead of trickling out at the host's enqueue rate.
+    if (!pl->graph_tried && !g_no_graph && !pl->groups.empty()) {
+        pl->graph_tried = true;
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = enqueue_groups(ctx, pl, false);
+            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (rc == CL_OK && e == hipSuccess && graph &&
+                hipGraphInstantiate(&pl->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                pl->graph = graph;
+            } else {
+                if (graph) (void)hipGraphDestroy(graph);
+                pl->graph_exec = nullptr;
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
+    if (pl->graph_exec) {
+        HIP_TRY(ctx, hipGraphLaunch(pl->graph_exec, ctx->stream));
+    } else {
+        int rc = enqueue_groups(ctx, pl, false);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
     pl->executed = true;
+    return CL_OK;
+}
+
+int cl_stitch_plan_execute_profiled(cl_context* ctx, cl_stitch_plan* pl) {
+    if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
+    int rc = enqueue_groups(ctx, pl, true);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
+    pl->executed = true;
+    pl->profiled = true;
     return CL_OK;
 }
 
@@ -721,12 +796,12 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     if (!ctx || !pl || !out || index < 0 || index >= (int)pl->groups.size()) return CL_ERR_INVALID_ARGUMENT;
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
-    if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear<npw=%d,rows=%d,waves=%d>", g.npw, g.rows, g.waves);
-    else snprintf(out->kernel, sizeof(out->kernel), "popoa_general<npw=%d,block=%d>", g.npw, g.block);
+    if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
+    else snprintf(out->kernel, sizeof(out->kernel), "popoa_general_kernel<%d, %d>", g.npw, g.block);
     out->n_problems = g.count;
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;
-    if (pl->executed && g.ev0 && g.ev1) {
+    if (pl->profiled && g.ev0 && g.ev1) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (hipEventElapsedTime(&out->last_ms, g.ev0, g.ev1) != hipSuccess) out->last_ms = 0.f;
     }

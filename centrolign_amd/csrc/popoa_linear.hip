@@ -5,8 +5,9 @@
 // (include/centrolign/alignment.hpp:753-1151), specialised to graphs whose nodes form one path
 // (previous(r) == {r-1}, one source = rank 0, one sink = last rank):
 //
-//   * a wave owns a STRIP of 64*R consecutive rows (graph-1 nodes), lane l holds rows l*R .. l*R+R-1;
-//   * it sweeps the columns (graph-2 nodes) as a systolic array: at step t lane l works on column
+//   * the shorter graph is laid across the lanes ("rows"; SWAP when that is graph 2): a wave owns a STRIP of
+//     64*R consecutive rows, lane l holds rows l*R .. l*R+R-1;
+//   * it sweeps the columns (the longer graph) as a systolic array: at step t lane l works on column
 //     t - l + 1, so the cell above (lane l-1, one step earlier) and the diagonal cell (two steps earlier)
 //     arrive through a single wave_shr:1 DPP move per value; graph-2 labels travel the same way;
 //   * scores never leave registers.  What goes to HBM is one TRACEBACK CODE per cell (1 byte for
@@ -16,11 +17,11 @@
 //         bit 3+k   I_k(a,b) was reached by OPENING from Mf(a-1,b) (tested before extend, :1107-1117)
 //         bit 3+NumPW+k  same for D_k
 //     written as one coalesced run per wave and step;
-//   * strips of one matrix are pipelined over the W waves of the workgroup: strip s+1 trails strip s by two
-//     64-step chunks and receives the last row of strip s (Mf, I_k per column) through a small HBM/L2
-//     buffer, one coalesced 64-column load per chunk;
+//   * strips of one matrix are pipelined over the W waves of the workgroup: strip s+1 trails strip s by kLag
+//     kChunk-step chunks and receives the last row of strip s (Mf, I_k per column) through a small HBM/L2
+//     buffer, one coalesced load per chunk;
 //   * the boundary row/column are closed forms for a chain (-(open_k) - len*extend_k, alignment.hpp:832-894),
-//     so they are never stored; lane 0 of wave 0 walks the traceback over the codes.
+//     so they are never stored; wave 0 walks the traceback over the codes, 64 cells per memory round trip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -60,101 +61,106 @@ __device__ __forceinline__ int32_t boundary_gap(const ClScoreParams& P, int k, u
     return -P.oe[k] - (int32_t)(len - 1) * P.ext[k];
 }
 
+// A strip's sweep is cut into chunks of kChunk steps; the workgroup barriers once per chunk.  Strip s+1 may read
+// the columns of chunk c from strip s only after strip s has finished chunk c + kLag - 1 (its lane 63 reaches
+// column C(c+1) at step C(c+1)+62), hence the start offset of kLag chunks between consecutive strips.
+constexpr uint32_t kChunk = 32;
+constexpr uint32_t kLag = 2 + 62 / kChunk;
+
+// rows = the graph laid across the lanes (graph 1, or graph 2 when SWAP), cols = the graph that is swept
 struct LinearGeom {
-    uint32_t n1, n2, S, Cn;
+    uint32_t nr, nc, S, Cn, steps;
     template <int R>
-    __device__ void init(uint32_t n1_, uint32_t n2_) {
-        n1 = n1_; n2 = n2_;
-        S = (n1 + 64 * R - 1) / (64 * R);
-        Cn = (n2 + 63 + 63) / 64;  // steps 0 .. n2+62
+    __device__ void init(uint32_t nr_, uint32_t nc_) {
+        nr = nr_; nc = nc_;
+        S = (nr + 64 * R - 1) / (64 * R);
+        Cn = (nc + 63 + kChunk - 1) / kChunk;  // steps 0 .. nc+62
+        steps = Cn * kChunk;
     }
 };
 
 // Wave-cooperative traceback over the codes; same walk as alignment.hpp:1036-1138 for a chain pair, but the
 // 64 lanes of wave 0 read the codes of the next 64 cells ALONG THE CURRENT DIRECTION (diagonal while in the
-// match state, up while in an I_k gap, left while in a D_k gap) with one coalesced-by-direction load, find
-// with a ballot where the run ends, and emit the whole run at once.  A traceback of length L with g gap
-// events costs about L/64 + 3g dependent memory round trips instead of L.
-template <int NPW, int R>
+// match state, along the gap while in an I_k / D_k state) with one load, find with a ballot where the run
+// ends, and emit the whole run at once.  A traceback of length L with g gap events costs about L/64 + 3g
+// dependent memory round trips instead of L.
+// Works in kernel space (ra = row index, cb = column index, 1-based, 0 = boundary).  A "vertical" gap consumes
+// a row node: it is the reference's I_k when rows are graph 1, its D_k when SWAP.
+template <int NPW, int R, bool SWAP>
 __device__ void linear_traceback(const ClDeviceBatch& B, const ClProbDesc& pd, const LinearGeom& G,
                                  const typename CodeT<NPW>::type* codes, const ClScoreParams& P, uint32_t prob,
                                  uint32_t lane) {
-    uint32_t a = pd.n1, b = pd.n2, len = 0, status = 0;
+    uint32_t ra = G.nr, cb = G.nc, len = 0, status = 0;
     const uint32_t cap = pd.n1 + pd.n2;
     uint2* out = B.out_pairs + pd.out_base;
-    int comp = 0;
-    auto code_at = [&](uint32_t ca, uint32_t cb) -> uint32_t {
-        const uint32_t row = ca - 1, s = row / (64 * R), rr = row - s * 64 * R, l = rr / R, r = rr - l * R;
-        const uint32_t t = (cb - 1) + l;
-        return codes[(((size_t)s * G.Cn * 64 + t) * 64 + l) * R + r];
+    int comp = 0;  // reference convention: > 0 in I_{comp-1}, < 0 in D_{-comp-1}
+    auto code_at = [&](uint32_t r1, uint32_t c1) -> uint32_t {
+        const uint32_t row = r1 - 1, s = row / (64 * R), rr = row - s * 64 * R, l = rr / R, r = rr - l * R;
+        const uint32_t t = (c1 - 1) + l;
+        return codes[(((size_t)s * G.steps + t) * 64 + l) * R + r];
     };
+    auto pair_of = [&](uint32_t r1, uint32_t c1) { return SWAP ? make_uint2(c1, r1) : make_uint2(r1, c1); };
     while (true) {
         if (len > cap) { status = 2; break; }
-        if (a && b) {
+        if (ra && cb) {
             if (comp == 0) {
-                // diagonal run: lanes look at (a-j, b-j)
-                const bool valid = lane < a && lane < b;
-                const uint32_t code = valid ? code_at(a - lane, b - lane) : 0u;
+                const bool valid = lane < ra && lane < cb;
+                const uint32_t code = valid ? code_at(ra - lane, cb - lane) : 0u;
                 const uint32_t cc = code & 7u;
                 const unsigned long long stop = __ballot(!valid || cc != 0u);
                 const uint32_t first = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                if (lane < first) out[cap - 1 - (len + lane)] = make_uint2(a - lane, b - lane);
+                if (lane < first) out[cap - 1 - (len + lane)] = pair_of(ra - lane, cb - lane);
                 len += first;
-                a -= first; b -= first;
-                if (first < 64u && a && b) {
+                ra -= first; cb -= first;
+                if (first < 64u && ra && cb) {
                     // a gap closes at this cell (first hit in the order I_0, D_0, I_1, ... ; :1048-1066)
                     const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)cc, (int)first);
                     comp = (c1 & 1u) ? (int)((c1 + 1) >> 1) : -(int)(c1 >> 1);
-                } else if (a == 0 && b == 0) {
-                    break;  // emitted (1,1): the stored corner is -inf, no predecessor matches (:1091-1099)
+                } else if (ra == 0 && cb == 0) {
+                    break;  // emitted the (1,1) cell: the stored corner is -inf, no predecessor matches (:1091-1099)
                 }
-            } else if (comp > 0) {
-                // I_k run: lanes look at (a-j, b); the run ends at the first cell reached by OPENING (:1105-1118)
-                const bool valid = lane < a;
-                const uint32_t code = valid ? code_at(a - lane, b) : 0u;
-                const bool open = valid && ((code >> (3 + comp - 1)) & 1u);
-                const unsigned long long mo = __ballot(open), mi = __ballot(!valid);
-                const uint32_t fo = mo ? (uint32_t)__builtin_ctzll(mo) : 64u, fi = mi ? (uint32_t)__builtin_ctzll(mi) : 64u;
-                const uint32_t n = fo < fi ? fo + 1 : fi;
-                if (lane < n) out[cap - 1 - (len + lane)] = make_uint2(a - lane, 0u);
-                len += n; a -= n;
-                if (fo < fi) comp = 0;
             } else {
-                const bool valid = lane < b;
-                const uint32_t code = valid ? code_at(a, b - lane) : 0u;
-                const bool open = valid && ((code >> (3 + NPW - comp - 1)) & 1u);
+                const bool vert = SWAP ? comp < 0 : comp > 0;
+                const int k = comp > 0 ? comp - 1 : -comp - 1;
+                const uint32_t x = vert ? ra : cb;
+                const bool valid = lane < x;
+                const uint32_t code = valid ? (vert ? code_at(ra - lane, cb) : code_at(ra, cb - lane)) : 0u;
+                // the run ends at the first cell that was reached by OPENING (tested before extend, :1105-1136)
+                const bool open = valid && ((code >> (vert ? 3 + k : 3 + NPW + k)) & 1u);
                 const unsigned long long mo = __ballot(open), mi = __ballot(!valid);
                 const uint32_t fo = mo ? (uint32_t)__builtin_ctzll(mo) : 64u, fi = mi ? (uint32_t)__builtin_ctzll(mi) : 64u;
                 const uint32_t n = fo < fi ? fo + 1 : fi;
-                if (lane < n) out[cap - 1 - (len + lane)] = make_uint2(0u, b - lane);
-                len += n; b -= n;
+                if (lane < n) out[cap - 1 - (len + lane)] = vert ? pair_of(ra - lane, 0u) : pair_of(0u, cb - lane);
+                len += n;
+                if (vert) ra -= n; else cb -= n;
                 if (fo < fi) comp = 0;
             }
-        } else if (a == 0 && b == 0) {
+        } else if (ra == 0 && cb == 0) {
             status = 3; break;
         } else {
-            // boundary row (a == 0) or column (b == 0): closed forms, M = max_k G_k, G_k = -(open_k) - x*extend_k,
+            // boundary row (ra == 0) or column (cb == 0): closed forms, M = max_k G_k, G_k = -(open_k) - x*extend_k,
             // the other gap family is -inf.  Walk exactly as :1048-1066 / :1101-1137 do on those cells.
-            const bool row = a == 0;
-            uint32_t x = row ? b : a;
+            const bool vert = cb == 0;             // boundary column: gaps consume row nodes
+            const bool is_i = vert != SWAP;        // ... which are I_k unless the graphs are swapped
+            uint32_t x = vert ? ra : cb;
             if (comp == 0) {
                 const int32_t Mv = boundary_m<NPW>(P, x);
 #pragma unroll
-                for (int k = NPW - 1; k >= 0; --k) if (Mv == boundary_gap<NPW>(P, k, x)) comp = row ? -k - 1 : k + 1;
+                for (int k = NPW - 1; k >= 0; --k) if (Mv == boundary_gap<NPW>(P, k, x)) comp = is_i ? k + 1 : -k - 1;
             }
-            if (row ? comp >= 0 : comp <= 0) { status = 3; break; }
-            const int k = row ? -comp - 1 : comp - 1;
-            // lanes look at x-j; the run ends after the first cell whose gap value also equals an OPEN from the
-            // previous boundary cell, or at x == 1 (its predecessor is the corner: nothing matches)
+            if (is_i ? comp <= 0 : comp >= 0) { status = 3; break; }
+            const int k = is_i ? comp - 1 : -comp - 1;
+            // the run ends after the first cell whose gap value also equals an OPEN from the previous boundary cell,
+            // or at x == 1 (its predecessor is the corner: nothing matches)
             const bool valid = lane < x;
             const uint32_t xj = x - lane;
             const bool open = valid && xj >= 2 && boundary_gap<NPW>(P, k, xj) == boundary_m<NPW>(P, xj - 1) - P.oe[k];
             const unsigned long long mo = __ballot(open), mi = __ballot(!valid);
             const uint32_t fo = mo ? (uint32_t)__builtin_ctzll(mo) : 64u, fi = mi ? (uint32_t)__builtin_ctzll(mi) : 64u;
             const uint32_t n = fo < fi ? fo + 1 : fi;
-            if (lane < n) out[cap - 1 - (len + lane)] = row ? make_uint2(0u, xj) : make_uint2(xj, 0u);
+            if (lane < n) out[cap - 1 - (len + lane)] = vert ? pair_of(xj, 0u) : pair_of(0u, xj);
             len += n; x -= n;
-            if (row) b = x; else a = x;
+            if (vert) ra = x; else cb = x;
             if (fo < fi) comp = 0;
             else if (x == 0) break;  // emitted the cell next to the corner
         }
@@ -165,202 +171,203 @@ __device__ void linear_traceback(const ClDeviceBatch& B, const ClProbDesc& pd, c
     }
 }
 
-template <int NPW, int R, int W>
-__global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
-                                                              ClScoreParams P) {
+// lane l <- lane l+1 (wave_shl:1); lane 63 keeps its value
+__device__ __forceinline__ int32_t rotate_down(int32_t v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);
+}
+
+template <int NPW, int R, int W, bool SWAP>
+__device__ __forceinline__ void linear_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob,
+                                            const ClScoreParams& P) {
     using code_t = typename CodeT<NPW>::type;
     using pack_t = typename PackT<R * sizeof(code_t)>::type;
-    const uint32_t prob = plist[blockIdx.x];
-    const ClProbDesc pd = B.desc[prob];
+    constexpr uint32_t C = kChunk;
     LinearGeom G;
-    G.init<R>(pd.n1, pd.n2);
-    const uint32_t n1 = pd.n1, n2 = pd.n2;
-    const uint8_t* lab1 = B.lab[0] + pd.node_base[0];
-    const uint8_t* lab2 = B.lab[1] + pd.node_base[1];
+    G.init<R>(SWAP ? pd.n2 : pd.n1, SWAP ? pd.n1 : pd.n2);
+    const uint32_t nr = G.nr, nc = G.nc, steps = G.steps;
+    const uint8_t* labR = B.lab[SWAP ? 1 : 0] + pd.node_base[SWAP ? 1 : 0];
+    const uint8_t* labC = B.lab[SWAP ? 0 : 1] + pd.node_base[SWAP ? 0 : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t steps = G.Cn * 64;  // steps per strip, padded to whole chunks
     code_t* codes = reinterpret_cast<code_t*>(B.planes + pd.plane_base);
     // hand-off rows between strips: [strip][1 + NPW][steps] int32, after the codes (16-byte aligned by the packer)
     const size_t code_bytes = ((size_t)G.S * steps * 64 * R * sizeof(code_t) + 15) & ~(size_t)15;
     int32_t* brow = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(codes) + code_bytes);
 
-    const uint32_t Pm = G.Cn > 2u * W ? G.Cn : 2u * W;  // macro-step period of one round of W strips
-    const uint32_t total = ((G.S - 1) / W) * Pm + 2 * ((G.S - 1) % W) + G.Cn;
+    const uint32_t Pm = G.Cn > kLag * W ? G.Cn : kLag * W;  // macro-step period of one round of W strips
+    const uint32_t total = ((G.S - 1) / W) * Pm + kLag * ((G.S - 1) % W) + G.Cn;
 
-    // per-strip register state
-    int32_t Mleft[R], Dleft[R][NPW], lab1r[R];
-    int32_t lastM = 0, lastI[NPW], prevUpM = 0, c2 = 0xff;
-    int32_t outv[1 + NPW];
-    int32_t bM = 0, bI[NPW], myc2 = 0xff;
-    int32_t my_score = 0;
+    // per-strip register state.  V_k = gap family that consumes row nodes (vertical), H_k = column nodes.
+    int32_t Mleft[R], Hleft[R][NPW], labr[R];
+    int32_t lastM = 0, lastV[NPW], prevUpM = 0, c2 = 0xff;
+    int32_t bM = 0, bV[NPW], myc2 = 0xff;
 #pragma unroll
-    for (int k = 0; k < NPW; ++k) { lastI[k] = CL_NEG_INF; bI[k] = CL_NEG_INF; }
-#pragma unroll
-    for (int i = 0; i < 1 + NPW; ++i) outv[i] = 0;
+    for (int k = 0; k < NPW; ++k) { lastV[k] = CL_NEG_INF; bV[k] = CL_NEG_INF; }
 
     for (uint32_t m = 0; m < total; ++m) {
-        const int32_t mm = (int32_t)m - 2 * (int32_t)wave;
+        const int32_t mm = (int32_t)m - (int32_t)(kLag * wave);
         if (mm >= 0) {
             const uint32_t j = (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = j * W + wave;
             if (s < G.S && c < G.Cn) {
-                const uint32_t row0 = s * 64 * R + lane * R;  // 0-based first row of this lane; a = row + 1
+                const uint32_t row0 = s * 64 * R + lane * R;  // 0-based first row of this lane; row index = row0 + r + 1
                 if (c == 0) {
-                    // boundary column (b == 0): Mf(a,0) closed form, D_k(a,0) = -inf (alignment.hpp:832-862)
+                    // boundary column: Mf closed form, H_k = -inf (alignment.hpp:832-862 / :864-894)
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const uint32_t a = row0 + r + 1;
                         Mleft[r] = boundary_m<NPW>(P, a);
 #pragma unroll
-                        for (int k = 0; k < NPW; ++k) Dleft[r][k] = CL_NEG_INF;
-                        lab1r[r] = a <= n1 ? (int32_t)(lab1[a - 1] & 0x7f) : 0xfe;
+                        for (int k = 0; k < NPW; ++k) Hleft[r][k] = CL_NEG_INF;
+                        labr[r] = a <= nr ? (int32_t)(labR[a - 1] & 0x7f) : 0xfe;
                     }
                     lastM = Mleft[R - 1];
-                    // diagonal term of the lane's first row at column 1: Mf(a-1, 0); the corner counts as 0 (:814-818)
+                    // diagonal term of the lane's first row at column 1: Mf(row-1, 0); the corner counts as 0 (:814-818)
                     prevUpM = row0 == 0 ? 0 : boundary_m<NPW>(P, row0);
                     c2 = 0xff;
                 }
-                const uint32_t t0 = c * 64;
-                {   // this chunk's 64 columns as seen by lane 0: labels and the row above the strip
+                const uint32_t t0 = c * C;
+                {   // this chunk's C columns as seen by lane 0: labels and the row above the strip
                     const uint32_t colb = t0 + lane + 1;
-                    const bool v = colb <= n2;
-                    myc2 = v ? (int32_t)(lab2[colb - 1] & 0x7f) : 0xff;
+                    const bool v = lane < C && colb <= nc;
+                    myc2 = v ? (int32_t)(labC[colb - 1] & 0x7f) : 0xff;
                     if (s == 0) {
-                        bM = v ? boundary_m<NPW>(P, colb) : CL_NEG_INF;  // boundary row: Mf(0,b), I_k(0,b) = -inf
+                        bM = v ? boundary_m<NPW>(P, colb) : CL_NEG_INF;  // boundary row: Mf, V_k = -inf
                     } else {
                         const int32_t* src = brow + (size_t)(s - 1) * (1 + NPW) * steps + (colb - 1);
                         bM = v ? src[0] : CL_NEG_INF;
 #pragma unroll
-                        for (int k = 0; k < NPW; ++k) bI[k] = v ? src[(size_t)(1 + k) * steps] : CL_NEG_INF;
+                        for (int k = 0; k < NPW; ++k) bV[k] = v ? src[(size_t)(1 + k) * steps] : CL_NEG_INF;
                     }
                 }
                 pack_t* cw = reinterpret_cast<pack_t*>(codes) + ((size_t)s * steps + t0) * 64 + lane;
                 int32_t* bout = brow + (size_t)s * (1 + NPW) * steps;
-                const bool hand_off = s + 1 < G.S;
+                const bool hand_off_lane = s + 1 < G.S && lane == 63;
 #pragma unroll 2
-                for (uint32_t jj = 0; jj < 64; ++jj) {
+                for (uint32_t jj = 0; jj < C; ++jj) {
                     const uint32_t t = t0 + jj;
-                    const int32_t upM = shift_in(lastM, __builtin_amdgcn_readlane(bM, jj));
-                    int32_t upI[NPW];
+                    // lane 0 takes the next column of the row above the strip (kept rotating in bM/bV/myc2),
+                    // every other lane takes what its upper neighbour produced one step ago
+                    const int32_t upM = shift_in(lastM, bM);
+                    bM = rotate_down(bM);
+                    int32_t upV[NPW];
 #pragma unroll
-                    for (int k = 0; k < NPW; ++k) upI[k] = shift_in(lastI[k], __builtin_amdgcn_readlane(bI[k], jj));
-                    c2 = shift_in(c2, __builtin_amdgcn_readlane(myc2, jj));
+                    for (int k = 0; k < NPW; ++k) { upV[k] = shift_in(lastV[k], bV[k]); bV[k] = rotate_down(bV[k]); }
+                    c2 = shift_in(c2, myc2);
+                    myc2 = rotate_down(myc2);
                     const uint32_t b = t - lane + 1;  // this lane's column (1-based); wraps when not started
-                    if ((uint32_t)(b - 1) < n2) {
-                        int32_t diag = prevUpM, uM = upM, uI[NPW];
+                    if ((uint32_t)(b - 1) < nc) {
+                        int32_t diag = prevUpM, uM = upM, uV[NPW];
 #pragma unroll
-                        for (int k = 0; k < NPW; ++k) uI[k] = upI[k];
+                        for (int k = 0; k < NPW; ++k) uV[k] = upV[k];
                         uint64_t pack = 0;
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            const int32_t sc = lab1r[r] == c2 ? P.match : -P.mismatch;
+                            const int32_t sc = labr[r] == c2 ? P.match : -P.mismatch;
                             int32_t Mf = diag + sc;
-                            int32_t I[NPW], D[NPW];
+                            int32_t V[NPW], H[NPW];
                             uint32_t code = 0;
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) {
-                                const int32_t io = uM - P.oe[k], dopen = Mleft[r] - P.oe[k];
-                                I[k] = imax(io, uI[k] - P.ext[k]);
-                                D[k] = imax(dopen, Dleft[r][k] - P.ext[k]);
-                                code |= (I[k] == io ? 1u : 0u) << (3 + k);
-                                code |= (D[k] == dopen ? 1u : 0u) << (3 + NPW + k);
-                                Mf = imax(Mf, imax(I[k], D[k]));
+                                const int32_t vo = uM - P.oe[k], ho = Mleft[r] - P.oe[k];
+                                V[k] = imax(vo, uV[k] - P.ext[k]);
+                                H[k] = imax(ho, Hleft[r][k] - P.ext[k]);
+                                code |= (V[k] == vo ? 1u : 0u) << (3 + k);
+                                code |= (H[k] == ho ? 1u : 0u) << (3 + NPW + k);
+                                Mf = imax(Mf, imax(V[k], H[k]));
                             }
                             uint32_t cc = 0;
 #pragma unroll
                             for (int k = NPW - 1; k >= 0; --k) {  // lowest k, I before D, wins (:1048-1066)
-                                cc = Mf == D[k] ? 2u * k + 2u : cc;
-                                cc = Mf == I[k] ? 2u * k + 1u : cc;
+                                if (SWAP) {
+                                    cc = Mf == V[k] ? 2u * k + 2u : cc;  // rows are graph 2: vertical gaps are D_k
+                                    cc = Mf == H[k] ? 2u * k + 1u : cc;
+                                } else {
+                                    cc = Mf == H[k] ? 2u * k + 2u : cc;
+                                    cc = Mf == V[k] ? 2u * k + 1u : cc;
+                                }
                             }
                             code |= cc;
                             pack |= (uint64_t)code << (8 * sizeof(code_t) * r);
-                            if (row0 + r + 1 == n1 && b == n2) my_score = Mf;
                             diag = Mleft[r];
                             Mleft[r] = Mf;
                             uM = Mf;
 #pragma unroll
-                            for (int k = 0; k < NPW; ++k) { Dleft[r][k] = D[k]; uI[k] = I[k]; }
+                            for (int k = 0; k < NPW; ++k) { Hleft[r][k] = H[k]; uV[k] = V[k]; }
                         }
                         lastM = uM;
 #pragma unroll
-                        for (int k = 0; k < NPW; ++k) lastI[k] = uI[k];
+                        for (int k = 0; k < NPW; ++k) lastV[k] = uV[k];
                         cw[(size_t)jj * 64] = (pack_t)pack;
-                    }
-                    prevUpM = upM;
-                    if (hand_off) {
-                        // last row of the strip (lane 63, row R-1) has just finished column t-62
-                        const uint32_t b63 = t - 62;
-                        if ((uint32_t)(b63 - 1) < n2) {
-                            const uint32_t slot = (b63 - 1) & 63u;
-                            const int32_t vM = __builtin_amdgcn_readlane(lastM, 63);
-                            outv[0] = lane == slot ? vM : outv[0];
+                        if (hand_off_lane) {  // last row of a full strip: Mf and V_k of this column feed the next strip
+                            bout[b - 1] = uM;
 #pragma unroll
-                            for (int k = 0; k < NPW; ++k) {
-                                const int32_t vI = __builtin_amdgcn_readlane(lastI[k], 63);
-                                outv[1 + k] = lane == slot ? vI : outv[1 + k];
-                            }
-                            if (slot == 63u || b63 == n2) {
-                                const uint32_t col = (b63 - 1) - slot + lane;  // 0-based column held by this lane
-                                if (lane <= slot) {
-#pragma unroll
-                                    for (int i = 0; i < 1 + NPW; ++i) bout[(size_t)i * steps + col] = outv[i];
-                                }
-                            }
+                            for (int k = 0; k < NPW; ++k) bout[(size_t)(1 + k) * steps + (b - 1)] = uV[k];
                         }
                     }
+                    prevUpM = upM;
                 }
                 if (s + 1 == G.S && c + 1 == G.Cn) {
-                    const uint32_t rr = (n1 - 1) - s * 64 * R;
-                    if (lane == rr / R) B.out_score[prob] = my_score;
+                    // Mf(n1, n2): the lane holding the last row has it in Mleft after the last column
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (row0 + r + 1 == nr) B.out_score[prob] = Mleft[r];
                 }
             }
         }
         __syncthreads();
     }
-    if (wave == 0) linear_traceback<NPW, R>(B, pd, G, codes, P, prob, lane);
+    if (wave == 0) linear_traceback<NPW, R, SWAP>(B, pd, G, codes, P, prob, lane);
 }
 
-template <int NPW, int R>
-hipError_t launch_w(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P,
-                    hipStream_t stream) {
-    switch (W) {
-    case 1: hipLaunchKernelGGL((popoa_linear_kernel<NPW, R, 1>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P); break;
-    case 4: hipLaunchKernelGGL((popoa_linear_kernel<NPW, R, 4>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P); break;
-    case 16: hipLaunchKernelGGL((popoa_linear_kernel<NPW, R, 16>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P); break;
-    default: return hipErrorInvalidValue;
+// One kernel per workgroup shape (W waves).  The (NumPW, rows per lane, orientation) variant of each subproblem
+// is picked at run time from its descriptor, so a whole stitch pass is three launches that start together
+// instead of a dozen that queue behind each other on the hardware queues.
+template <int NPW, int W>
+__device__ __forceinline__ void linear_dispatch(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob,
+                                                const ClScoreParams& P) {
+    const bool swap = pd.pad & 1u;
+    const uint32_t rows = (pd.pad >> 1) & 7u;
+    if (W == 1 && rows == 2) {
+        if (swap) linear_body<NPW, (W == 1 ? 2 : 1), W, true>(B, pd, prob, P);
+        else linear_body<NPW, (W == 1 ? 2 : 1), W, false>(B, pd, prob, P);
+    } else {
+        if (swap) linear_body<NPW, 1, W, true>(B, pd, prob, P);
+        else linear_body<NPW, 1, W, false>(B, pd, prob, P);
     }
-    return hipGetLastError();
 }
 
-template <int NPW>
-hipError_t launch_r(int R, int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
-                    const ClScoreParams& P, hipStream_t stream) {
-    switch (R) {
-    case 1: return launch_w<NPW, 1>(W, n_blocks, B, plist, P, stream);
-    case 2: return launch_w<NPW, 2>(W, n_blocks, B, plist, P, stream);
-    case 4: return launch_w<NPW, 4>(W, n_blocks, B, plist, P, stream);
-    default: return hipErrorInvalidValue;
+template <int W>
+__global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
+                                                              ClScoreParams P) {
+    const uint32_t prob = plist[blockIdx.x];
+    const ClProbDesc pd = B.desc[prob];
+    switch (pd.npw) {
+    case 1: linear_dispatch<1, W>(B, pd, prob, P); break;
+    case 2: linear_dispatch<2, W>(B, pd, prob, P); break;
+    default: linear_dispatch<3, W>(B, pd, prob, P); break;
     }
 }
 
 }  // namespace
 
-// bytes of workspace a linear problem needs (codes + strip hand-off rows); mirrors the kernel's layout
-size_t cl_linear_workspace_bytes(uint32_t n1, uint32_t n2, int npw, int R) {
-    const size_t S = (n1 + 64 * (size_t)R - 1) / (64 * (size_t)R);
-    const size_t steps = ((n2 + 63 + 63) / 64) * (size_t)64;
+// bytes of workspace a chain problem needs (codes + strip hand-off rows); mirrors the kernel's layout.
+// nr / nc = nodes of the graph laid across lanes / swept
+size_t cl_linear_workspace_bytes(uint32_t nr, uint32_t nc, int npw, int R) {
+    const size_t S = (nr + 64 * (size_t)R - 1) / (64 * (size_t)R);
+    const size_t steps = ((nc + 63 + kChunk - 1) / kChunk) * (size_t)kChunk;
     const size_t csize = npw == 3 ? 2 : 1;
     const size_t code_bytes = (S * steps * 64 * R * csize + 15) & ~(size_t)15;
     const size_t brow_bytes = S * (size_t)(1 + npw) * steps * sizeof(int32_t);
     return code_bytes + brow_bytes;
 }
 
-hipError_t cl_launch_popoa_linear(int npw, int R, int W, uint32_t n_blocks, const ClDeviceBatch& B,
-                                  const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
+hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
+                                  const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    switch (npw) {
-    case 1: return launch_r<1>(R, W, n_blocks, B, plist, P, stream);
-    case 2: return launch_r<2>(R, W, n_blocks, B, plist, P, stream);
-    case 3: return launch_r<3>(R, W, n_blocks, B, plist, P, stream);
+    switch (W) {
+    case 1: hipLaunchKernelGGL((popoa_linear_kernel<1>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P); break;
+    case 4: hipLaunchKernelGGL((popoa_linear_kernel<4>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P); break;
+    case 16: hipLaunchKernelGGL((popoa_linear_kernel<16>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
 }

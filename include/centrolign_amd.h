@@ -155,6 +155,9 @@ int  cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const 
                            const uint8_t* force_num_pw, cl_stitch_plan** plan_out);
 /* Enqueues the DP + traceback kernels for the whole plan on the context's stream; asynchronous. */
 int  cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* plan);
+/* Same work, launched kernel by kernel with HIP events around every launch so that cl_stitch_plan_launch_info can
+ * report per-kernel durations (the unprofiled execute replays a captured hipGraph instead). */
+int  cl_stitch_plan_execute_profiled(cl_context* ctx, cl_stitch_plan* plan);
 /* Waits for the stream; returns the device time of the LAST execute in ms (HIP events on the context's
  * stream) through *ms_out if not NULL. */
 int  cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* plan, float* ms_out);
@@ -181,8 +184,8 @@ typedef struct cl_launch_info {
     uint64_t n_problems;
     uint64_t dp_cells;
     uint64_t dp_bytes;           /* algorithmic bytes: cells * sizeof(cell_t<NumPW>) */
-    float    last_ms;            /* device duration of this launch in the LAST execute (HIP events on its stream);
-                                    valid after cl_stitch_plan_sync */
+    float    last_ms;            /* device duration of this launch in the last cl_stitch_plan_execute_profiled
+                                    (HIP events on its stream); valid after cl_stitch_plan_sync */
 } cl_launch_info;
 int cl_stitch_plan_launch_count(const cl_stitch_plan* plan);
 int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int index, cl_launch_info* info_out);
