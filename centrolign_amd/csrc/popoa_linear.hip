@@ -254,7 +254,7 @@ __device__ __forceinline__ void linear_body(const ClDeviceBatch& B, const ClProb
                     c2 = shift_in(c2, myc2);
                     myc2 = rotate_down(myc2);
                     const uint32_t b = t - lane + 1;  // this lane's column (1-based); wraps when not started
-                    if ((uint32_t)(b - 1) < nc) {
+                    if ((uint32_t)(b - 1) < nc && row0 < nr) {  // lanes below the last row have nothing to do
                         int32_t diag = prevUpM, uM = upM, uV[NPW];
 #pragma unroll
                         for (int k = 0; k < NPW; ++k) uV[k] = upV[k];

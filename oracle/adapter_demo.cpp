@@ -1,0 +1,160 @@
+/*
+ * adapter_demo.cpp — TEST INFRASTRUCTURE ONLY.  Drop-in demonstration on real reference objects: runs the
+ * reference pipeline (match finding, chaining, partitioning, extraction — all the UNMODIFIED reference, linked
+ * from oracle/_ref) on a FASTA pair / small MSA and, for every merge, stitches twice:
+ *   (1) the reference's own Stitcher::subalign loop on the CPU        (include/centrolign/stitcher.hpp:157-203)
+ *   (2) include/centrolign_amd/stitch_adapter.hpp -> C ABI -> MI355X
+ * and compares the two stitched Alignments element by element.  The patch INTEGRATION.md proposes for
+ * Stitcher::stitch is exactly path (2).  Built only where /root/reference exists; the binary travels to the
+ * GPU box inside oracle/_ref/.
+ *
+ * usage: adapter_demo <fasta> [newick-file|-] [max_num_match_pairs]
+ */
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include "centrolign/core.hpp"
+#include "centrolign/parameters.hpp"
+#include "centrolign/stitcher.hpp"
+#include "centrolign/utility.hpp"
+
+#include "../include/centrolign_amd/stitch_adapter.hpp"
+
+using namespace centrolign;
+
+namespace {
+
+struct OpenStitcher : public Stitcher {
+    using Stitcher::subalign;
+    using Extractor::extract_graphs_between;
+};
+
+struct DemoCore : public Core {
+    DemoCore(std::vector<std::pair<std::string, std::string>>&& seqs, Tree&& tree) : Core(std::move(seqs), std::move(tree)) {}
+    centrolign_amd::Device* dev = nullptr;
+    size_t merges = 0, mismatched = 0, problems = 0;
+    double t_cpu = 0, t_gpu = 0;
+
+    template <class XMerge>
+    Alignment align_both(std::vector<match_set_t>& matches, const Subproblem& sp1, const Subproblem& sp2, XMerge& x1, XMerge& x2) {
+        using clk = std::chrono::steady_clock;
+        bool restrain = (sp1.graph.path_size() * sp2.graph.path_size() * anchorer.max_num_match_pairs * log2(anchorer.max_num_match_pairs) > memory_restraint_size);
+        auto anchors = anchorer.anchor_chain(matches, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, restrain);
+        auto segments = partitioner.partition_anchors(anchors, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, false);
+        for (auto& seg : segments) stitcher.despecify_indel_breakpoints(seg);
+        OpenStitcher st;
+        static_cast<Stitcher&>(st) = stitcher;
+        std::vector<std::vector<std::pair<SubGraphInfo, SubGraphInfo>>> within;
+        std::vector<std::pair<SubGraphInfo, SubGraphInfo>> between;
+        std::tie(within, between) = st.extract_graphs_between(segments, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2);
+
+        // (1) reference loop, stitcher.hpp:157-203
+        auto a0 = clk::now();
+        Alignment ref;
+        for (size_t i = 0; i < between.size(); ++i) {
+            if (i != 0) {
+                const auto& seg = segments[i - 1];
+                for (size_t j = 0; j < seg.size(); ++j) {
+                    if (j != 0) st.subalign(within[i - 1][j - 1].first, within[i - 1][j - 1].second, ref, false);
+                    for (size_t k = 0; k < seg[j].walk1.size(); ++k) ref.emplace_back(seg[j].walk1[k], seg[j].walk2[k]);
+                }
+            }
+            st.subalign(between[i].first, between[i].second, ref, true);
+        }
+        t_cpu += std::chrono::duration<double>(clk::now() - a0).count();
+
+        // (2) the same loop with the subalign calls batched onto the GPU
+        auto a1 = clk::now();
+        centrolign_amd::StitchBatchBuilder batch;
+        for (size_t i = 0; i < between.size(); ++i) {
+            if (i != 0)
+                for (size_t j = 1; j < segments[i - 1].size(); ++j) batch.add(within[i - 1][j - 1].first, within[i - 1][j - 1].second, false);
+            batch.add(between[i].first, between[i].second, true);
+        }
+        auto alns = dev->subalign_all<AlignedPair>(batch, centrolign_amd::stitch_params_of(stitcher));
+        Alignment got;
+        size_t k = 0;
+        for (size_t i = 0; i < between.size(); ++i) {
+            if (i != 0) {
+                const auto& seg = segments[i - 1];
+                for (size_t j = 0; j < seg.size(); ++j) {
+                    if (j != 0) { got.insert(got.end(), alns[k].begin(), alns[k].end()); ++k; }
+                    for (size_t w = 0; w < seg[j].walk1.size(); ++w) got.emplace_back(seg[j].walk1[w], seg[j].walk2[w]);
+                }
+            }
+            got.insert(got.end(), alns[k].begin(), alns[k].end());
+            ++k;
+        }
+        t_gpu += std::chrono::duration<double>(clk::now() - a1).count();
+        problems += batch.size();
+        bool same = got.size() == ref.size();
+        for (size_t i = 0; same && i < got.size(); ++i) same = got[i] == ref[i];
+        if (!same) ++mismatched;
+        printf("merge %zu: %zu subproblems, stitched length %zu, GPU path %s the reference\n", merges, batch.size(), ref.size(), same ? "==" : "!=");
+        ++merges;
+        return got;  // continue the MSA on the GPU result: later merges then depend on it
+    }
+
+    void run() {
+        if (!skip_calibration) calibrate_anchor_scores_and_identify_bonds();
+        while (!main_execution.finished()) {
+            auto ptrs = main_execution.next();
+            auto& next_problem = *std::get<0>(ptrs);
+            auto& sp1 = *std::get<1>(ptrs);
+            auto& sp2 = *std::get<2>(ptrs);
+            reassign_sentinels(sp1.graph, sp1.tableau, 5, 6);
+            reassign_sentinels(sp2.graph, sp2.tableau, 7, 8);
+            auto matches = path_match_finder.find_matches(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau);
+            PathMerge<uint32_t, uint8_t> pm1(sp1.graph, sp1.tableau);
+            PathMerge<uint32_t, uint8_t> pm2(sp2.graph, sp2.tableau);
+            next_problem.alignment = align_both(matches, sp1, sp2, pm1, pm2);
+            BaseGraph fused = sp1.graph;
+            fuse(fused, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment);
+            next_problem.graph = std::move(fused);
+            next_problem.tableau = sp1.tableau;
+            next_problem.complete = true;
+        }
+    }
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s <fasta> [newick|-] [max_num_match_pairs]\n", argv[0]); return 2; }
+    try {
+        Parameters params;
+        params.set<std::string>("fasta_name", argv[1]);
+        if (argc > 3) params.set<int64_t>("max_num_match_pairs", atoll(argv[3]));
+        params.validate();
+        logging::level = logging::Silent;
+        std::ifstream fin(argv[1]);
+        auto parsed = parse_fasta(fin);
+        std::vector<std::string> names;
+        for (const auto& p : parsed) names.push_back(p.first);
+        std::string newick;
+        if (argc > 2 && std::string(argv[2]) != "-") {
+            std::ifstream tin(argv[2]);
+            std::stringstream ss;
+            ss << tin.rdbuf();
+            newick = ss.str();
+        } else {
+            newick = in_order_newick_string(names);
+        }
+        Tree tree(newick);
+        DemoCore core(std::move(parsed), std::move(tree));
+        params.apply(core);
+        core.preserve_subproblems = true;
+        centrolign_amd::Device dev(0);
+        core.dev = &dev;
+        core.run();
+        printf("%zu merges, %zu subproblems, subalign loop: reference CPU %.3f s, adapter+GPU %.3f s (incl. flatten, H2D, D2H)\n",
+               core.merges, core.problems, core.t_cpu, core.t_gpu);
+        printf(core.mismatched ? "DROP-IN FAILED\n" : "DROP-IN OK\n");
+        return core.mismatched ? 1 : 0;
+    } catch (std::exception& ex) {
+        fprintf(stderr, "adapter_demo: %s\n", ex.what());
+        return 3;
+    }
+}

@@ -1,0 +1,34 @@
+"""GPU suite: drop-in demonstration on real reference objects.  oracle/_ref/adapter_demo (built in the build
+container from oracle/adapter_demo.cpp + the unmodified reference, shipped prebuilt to the GPU box) runs the
+reference pipeline and stitches every merge twice — reference CPU loop vs include/centrolign_amd/stitch_adapter.hpp
+-> C ABI -> MI355X — and compares the stitched Alignments."""
+import os
+import subprocess
+
+import pytest
+
+from centrolign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "oracle", "_ref", "adapter_demo")
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/adapter_demo not built (needs the reference sources)")
+@pytest.mark.parametrize("seed,length,n,max_pairs", [(21, 60000, 2, 60000), (22, 30000, 4, 40000)])
+def test_reference_stitch_loop_vs_gpu(tmp_path, seed, length, n, max_pairs):
+    seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs)
+    nwk = "-"
+    if n == 4:
+        nwk = str(tmp_path / "tree.nwk")
+        with open(nwk, "w") as f:
+            f.write("((seq0,seq1),(seq2,seq3));")
+    p = subprocess.run([DEMO, fa, nwk, str(max_pairs)], capture_output=True, text=True, timeout=600)
+    print(p.stdout)
+    print(p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DROP-IN OK" in p.stdout
+    assert p.stdout.count("== the reference") == (1 if n == 2 else 3)
