@@ -97,6 +97,97 @@ class PlanStats(C.Structure):
                  "n_launches")]
 
 
+class BaseGraphC(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("label", C.c_void_p), ("next_off", C.c_void_p), ("next_idx", C.c_void_p),
+                ("prev_off", C.c_void_p), ("prev_idx", C.c_void_p), ("n_paths", C.c_uint64), ("path_off", C.c_void_p),
+                ("path_nodes", C.c_void_p), ("src_id", C.c_uint64), ("snk_id", C.c_uint64)]
+
+
+class AnchorSegmentsC(C.Structure):
+    _fields_ = [("n_segments", C.c_uint64), ("seg_off", C.c_void_p), ("walk_off", C.c_void_p), ("walk1", C.c_void_p),
+                ("walk2", C.c_void_p)]
+
+
+class AlignmentC(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("pairs", C.POINTER(C.c_uint64))]
+
+
+class BaseGraph:
+    """numpy holder for a cl_base_graph (BaseGraph + SentinelTableau of one side of a merge)"""
+
+    def __init__(self, label, next_off, next_idx, prev_off, prev_idx, path_off, path_nodes, src_id, snk_id):
+        self.label = np.ascontiguousarray(label, np.uint8)
+        self.next_off = np.ascontiguousarray(next_off, np.uint64)
+        self.next_idx = np.ascontiguousarray(next_idx, np.uint32)
+        self.prev_off = np.ascontiguousarray(prev_off, np.uint64)
+        self.prev_idx = np.ascontiguousarray(prev_idx, np.uint32)
+        self.path_off = np.ascontiguousarray(path_off, np.uint64)
+        self.path_nodes = np.ascontiguousarray(path_nodes, np.uint32)
+        self.src_id, self.snk_id = int(src_id), int(snk_id)
+
+    def as_c(self):
+        g = BaseGraphC()
+        g.n_nodes = len(self.label)
+        g.n_paths = len(self.path_off) - 1
+        for k in ("label", "next_off", "next_idx", "prev_off", "prev_idx", "path_off", "path_nodes"):
+            setattr(g, k, getattr(self, k).ctypes.data)
+        g.src_id, g.snk_id = self.src_id, self.snk_id
+        return g
+
+
+class AnchorSegments:
+    def __init__(self, seg_off, walk_off, walk1, walk2):
+        self.seg_off = np.ascontiguousarray(seg_off, np.uint64)
+        self.walk_off = np.ascontiguousarray(walk_off, np.uint64)
+        self.walk1 = np.ascontiguousarray(walk1, np.uint32)
+        self.walk2 = np.ascontiguousarray(walk2, np.uint32)
+
+    def as_c(self):
+        s = AnchorSegmentsC()
+        s.n_segments = len(self.seg_off) - 1
+        for k in ("seg_off", "walk_off", "walk1", "walk2"):
+            setattr(s, k, getattr(self, k).ctypes.data)
+        return s
+
+
+def _side_from_c(sc, n):
+    """copy a cl_graph_side (C pointers) into a GraphSide"""
+    def arr(ptr, dt, cnt):
+        if not ptr or cnt == 0:
+            return np.zeros(0, dt)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
+    node_off = arr(sc.node_off, np.uint64, n + 1)
+    nn = int(node_off[-1])
+    prev_off = arr(sc.prev_off, np.uint64, nn + 1)
+    next_off = arr(sc.next_off, np.uint64, nn + 1)
+    src_off = arr(sc.src_off, np.uint64, n + 1)
+    snk_off = arr(sc.snk_off, np.uint64, n + 1)
+    return GraphSide(node_off=node_off, label=arr(sc.label, np.uint8, nn), prev_off=prev_off,
+                     prev_idx=arr(sc.prev_idx, np.uint32, int(prev_off[-1])), next_off=next_off,
+                     next_idx=arr(sc.next_idx, np.uint32, int(next_off[-1])), src_off=src_off,
+                     src_idx=arr(sc.src_idx, np.uint32, int(src_off[-1])), snk_off=snk_off,
+                     snk_idx=arr(sc.snk_idx, np.uint32, int(snk_off[-1])),
+                     back_translation=arr(sc.back_translation, np.uint64, nn))
+
+
+def extract_stitch_batch(graph1, graph2, segments):
+    """Extractor::extract_graphs_between in Stitcher::stitch's consumption order (host only, no GPU needed)"""
+    lib = load_library()
+    g1, g2, sg = graph1.as_c(), graph2.as_c(), segments.as_c()
+    h = C.c_void_p()
+    rc = lib.cl_extract_stitch_batch(C.byref(g1), C.byref(g2), C.byref(sg), C.byref(h))
+    if rc != 0:
+        msg = lib.cl_last_error(None)
+        raise ClError(rc, msg.decode() if msg else "")
+    try:
+        v = lib.cl_owned_batch_view(h).contents
+        n = int(v.n_problems)
+        od = np.ctypeslib.as_array(C.cast(v.only_deletion_alns, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+        return StitchBatch(_side_from_c(v.side[0], n), _side_from_c(v.side[1], n), od)
+    finally:
+        lib.cl_owned_batch_free(h)
+
+
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
                 ("dp_bytes", C.c_uint64), ("last_ms", C.c_float)]
@@ -349,6 +440,16 @@ def load_library(path=None):
     lib.cl_stitch_plan_launch_count.argtypes = [C.c_void_p]
     lib.cl_stitch_plan_launch_info.restype = C.c_int
     lib.cl_stitch_plan_launch_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(LaunchInfo)]
+    lib.cl_extract_stitch_batch.restype = C.c_int
+    lib.cl_extract_stitch_batch.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(AnchorSegmentsC),
+                                            C.POINTER(C.c_void_p)]
+    lib.cl_owned_batch_view.restype = C.POINTER(StitchBatchC)
+    lib.cl_owned_batch_view.argtypes = [C.c_void_p]
+    lib.cl_owned_batch_free.argtypes = [C.c_void_p]
+    lib.cl_stitch.restype = C.c_int
+    lib.cl_stitch.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(AnchorSegmentsC),
+                              C.POINTER(StitchParams), C.POINTER(AlignmentC)]
+    lib.cl_alignment_free.argtypes = [C.POINTER(AlignmentC)]
     if path is None:
         _lib = lib
     return lib
@@ -360,6 +461,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
+    "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
 ]
 
 
@@ -449,6 +551,17 @@ class Context:
             return StitchResult.from_c(rc)
         finally:
             self.lib.cl_stitch_result_free(C.byref(rc))
+
+    def stitch(self, graph1, graph2, segments, params=None):
+        """Stitcher::stitch (include/centrolign/stitcher.hpp:104-206): stitched Alignment as an (n, 2) uint64 array"""
+        params = params or default_stitch_params()
+        g1, g2, sg, out = graph1.as_c(), graph2.as_c(), segments.as_c(), AlignmentC()
+        self._check(self.lib.cl_stitch(self.handle, C.byref(g1), C.byref(g2), C.byref(sg), C.byref(params), C.byref(out)))
+        try:
+            n = int(out.n_pairs)
+            return np.ctypeslib.as_array(out.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2)
+        finally:
+            self.lib.cl_alignment_free(C.byref(out))
 
     def plan(self, batch, params=None, force_num_pw=None):
         params = params or default_stitch_params()

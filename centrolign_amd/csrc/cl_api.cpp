@@ -23,6 +23,7 @@
 
 #include "../../include/centrolign_amd.h"
 #include "popoa_device.h"
+#include "stitch_host.hpp"
 
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
@@ -913,6 +914,73 @@ int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t
 int cl_stitch_batch_align(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params, cl_stitch_result* out) {
     if (!ctx || !batch || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     return run_whole(ctx, batch, params, nullptr, out);
+}
+
+
+struct cl_owned_batch {
+    clhost::OwnedBatch b;
+};
+
+int cl_extract_stitch_batch(const cl_base_graph* g1, const cl_base_graph* g2, const cl_anchor_segments* sg, cl_owned_batch** out) {
+    if (!g1 || !g2 || !sg || !out) { set_error(nullptr, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    for (const cl_base_graph* g : {g1, g2})
+        if (g->n_nodes >= (1ull << 32) || g->src_id >= g->n_nodes || g->snk_id >= g->n_nodes) { set_error(nullptr, "bad graph"); return CL_ERR_INVALID_ARGUMENT; }
+    cl_owned_batch* ob = new (std::nothrow) cl_owned_batch();
+    if (!ob) return CL_ERR_OUT_OF_MEMORY;
+    int rc = clhost::extract_stitch_batch(*g1, *g2, *sg, ob->b);
+    if (rc) { set_error(nullptr, rc == CL_ERR_CYCLIC_GRAPH ? "merge graph is not acyclic" : "empty anchor segment"); delete ob; return rc; }
+    *out = ob;
+    return CL_OK;
+}
+
+const cl_stitch_batch* cl_owned_batch_view(cl_owned_batch* b) { return b ? b->b.view() : nullptr; }
+void cl_owned_batch_free(cl_owned_batch* b) { delete b; }
+
+void cl_alignment_free(cl_alignment* a) {
+    if (!a) return;
+    free(a->pairs);
+    a->pairs = nullptr;
+    a->n_pairs = 0;
+}
+
+int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_anchor_segments* sg,
+              const cl_stitch_params* params, cl_alignment* out) {
+    if (!ctx || !g1 || !g2 || !sg || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    out->n_pairs = 0;
+    out->pairs = nullptr;
+    cl_owned_batch* ob = nullptr;
+    int rc = cl_extract_stitch_batch(g1, g2, sg, &ob);
+    if (rc) { if (ctx) ctx->error = g_error; return rc; }
+    cl_stitch_result res;
+    rc = cl_stitch_batch_align(ctx, cl_owned_batch_view(ob), params, &res);
+    cl_owned_batch_free(ob);
+    if (rc) return rc;
+    // stitcher.hpp:157-203: P0 A0 P1 A1 ... every subproblem but the first is preceded by one copied anchor
+    uint64_t n_anchor_pairs = sg->n_segments ? sg->walk_off[sg->seg_off[sg->n_segments]] - sg->walk_off[sg->seg_off[0]] : 0;
+    uint64_t total = res.aln_off[res.n_problems] + n_anchor_pairs;
+    out->pairs = (uint64_t*)malloc((total ? total : 1) * 2 * sizeof(uint64_t));
+    if (!out->pairs) { cl_stitch_result_free(&res); return CL_ERR_OUT_OF_MEMORY; }
+    uint64_t cur = 0, k = 0;
+    auto copy_problem = [&](uint64_t p) {
+        uint64_t n = res.aln_off[p + 1] - res.aln_off[p];
+        memcpy(out->pairs + 2 * cur, res.pairs + 2 * res.aln_off[p], n * 2 * sizeof(uint64_t));
+        cur += n;
+    };
+    copy_problem(k++);
+    for (uint64_t s = 0; s < sg->n_segments; ++s)
+        for (uint64_t a = sg->seg_off[s]; a < sg->seg_off[s + 1]; ++a) {
+            if (a != sg->seg_off[s]) copy_problem(k++);
+            for (uint64_t w = sg->walk_off[a]; w < sg->walk_off[a + 1]; ++w) {
+                out->pairs[2 * cur] = sg->walk1[w];
+                out->pairs[2 * cur + 1] = sg->walk2[w];
+                ++cur;
+            }
+            if (a + 1 == sg->seg_off[s + 1]) copy_problem(k++);
+        }
+    out->n_pairs = cur;
+    cl_stitch_result_free(&res);
+    return CL_OK;
 }
 
 }  // extern "C"

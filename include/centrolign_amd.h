@@ -190,6 +190,51 @@ typedef struct cl_launch_info {
 int cl_stitch_plan_launch_count(const cl_stitch_plan* plan);
 int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int index, cl_launch_info* info_out);
 
+/* --- Stitcher::stitch proper: from a partitioned anchor chain to the stitched base-level alignment ----------------
+ * (include/centrolign/stitcher.hpp:34-38,104-206).  The two merge graphs are passed as flat views of BaseGraph
+ * (include/centrolign/graph.hpp:96-151) + SentinelTableau (include/centrolign/modify_graph.hpp:33-38). */
+typedef struct cl_base_graph {
+    uint64_t        n_nodes;
+    const uint8_t*  label;       /* [n_nodes] */
+    const uint64_t* next_off;    /* [n_nodes+1] CSR of BaseGraph::next, order preserved */
+    const uint32_t* next_idx;
+    const uint64_t* prev_off;    /* [n_nodes+1] CSR of BaseGraph::previous, order preserved */
+    const uint32_t* prev_idx;
+    uint64_t        n_paths;     /* BaseGraph::path_size() */
+    const uint64_t* path_off;    /* [n_paths+1] */
+    const uint32_t* path_nodes;  /* BaseGraph::path(p) concatenated */
+    uint64_t        src_id;      /* SentinelTableau::src_id */
+    uint64_t        snk_id;      /* SentinelTableau::snk_id */
+} cl_base_graph;
+
+/* std::vector<std::vector<anchor_t>>: anchors seg_off[s] .. seg_off[s+1]-1 form segment s; anchor a holds the node
+ * pairs walk1/walk2[walk_off[a] .. walk_off[a+1]) (anchor_t::walk1/walk2, include/centrolign/anchorer.hpp:36-57) */
+typedef struct cl_anchor_segments {
+    uint64_t        n_segments;
+    const uint64_t* seg_off;
+    const uint64_t* walk_off;
+    const uint32_t* walk1;
+    const uint32_t* walk2;
+} cl_anchor_segments;
+
+typedef struct cl_owned_batch cl_owned_batch;
+/* Extractor::extract_graphs_between (include/centrolign/anchorer.hpp:494-585, subgraph_extraction.hpp:52-125) with
+ * PathMerge reachability (path_merge.hpp:96-277), flattened in the order Stitcher::stitch consumes the subgraph pairs.
+ * Host only (no device needed). */
+int  cl_extract_stitch_batch(const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_anchor_segments* segments,
+                             cl_owned_batch** batch_out);
+const cl_stitch_batch* cl_owned_batch_view(cl_owned_batch* batch);
+void cl_owned_batch_free(cl_owned_batch* batch);
+
+typedef struct cl_alignment {
+    uint64_t  n_pairs;
+    uint64_t* pairs;   /* AlignedPair[n_pairs] */
+} cl_alignment;
+/* Stitcher::stitch: extraction + every subalign on the device + anchors copied in between. */
+int  cl_stitch(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_anchor_segments* segments,
+               const cl_stitch_params* params, cl_alignment* out);
+void cl_alignment_free(cl_alignment* a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,29 @@ struct FlatSide {
     }
 };
 
+/* parent graph of a merge: labels, adjacency in BaseGraph order, embedded paths, sentinels */
+void dump_base_graph(Dump& d, const std::string& pre, const BaseGraph& g, const SentinelTableau& t) {
+    std::vector<uint8_t> label;
+    std::vector<uint64_t> next_off{0}, prev_off{0}, path_off{0};
+    std::vector<uint32_t> next_idx, prev_idx, path_nodes;
+    for (uint64_t v = 0; v < g.node_size(); ++v) {
+        label.push_back((uint8_t)g.label(v));
+        for (auto q : g.next(v)) next_idx.push_back((uint32_t)q);
+        next_off.push_back(next_idx.size());
+        for (auto p : g.previous(v)) prev_idx.push_back((uint32_t)p);
+        prev_off.push_back(prev_idx.size());
+    }
+    for (uint64_t p = 0; p < g.path_size(); ++p) {
+        for (auto v : g.path(p)) path_nodes.push_back((uint32_t)v);
+        path_off.push_back(path_nodes.size());
+    }
+    d.u8(pre + "label", label);
+    d.u64(pre + "next_off", next_off); d.u32(pre + "next_idx", next_idx);
+    d.u64(pre + "prev_off", prev_off); d.u32(pre + "prev_idx", prev_idx);
+    d.u64(pre + "path_off", path_off); d.u32(pre + "path_nodes", path_nodes);
+    d.u64(pre + "tableau", std::vector<uint64_t>{t.src_id, t.snk_id});
+}
+
 /* The CLI pipeline with the stitch loop opened up.  Follows Core::do_execution (core.hpp:256-403) and
  * Core::align (core.hpp:182-254) call for call; only Stitcher::stitch (stitcher.hpp:104-206) is unrolled here
  * so that each subalign input/output can be recorded. */
@@ -256,6 +279,22 @@ struct DumpCore : public Core {
         t_subalign += sub_s;
         (void)t4;
         if (dump) {
+            dump_base_graph(*dump, pre + "parent1.", sp1.graph, sp1.tableau);
+            dump_base_graph(*dump, pre + "parent2.", sp2.graph, sp2.tableau);
+            {
+                std::vector<uint64_t> seg_off{0}, walk_off{0};
+                std::vector<uint32_t> w1, w2;
+                for (const auto& seg : segments) {
+                    for (const auto& a : seg) {
+                        for (auto v : a.walk1) w1.push_back((uint32_t)v);
+                        for (auto v : a.walk2) w2.push_back((uint32_t)v);
+                        walk_off.push_back(w1.size());
+                    }
+                    seg_off.push_back(walk_off.size() - 1);
+                }
+                dump->u64(pre + "seg_off", seg_off); dump->u64(pre + "walk_off", walk_off);
+                dump->u32(pre + "walk1", w1); dump->u32(pre + "walk2", w2);
+            }
             dump->put(pre + "n_problems", 2, std::vector<uint64_t>{(uint64_t)only_del.size()}.data(), 1, 8);
             f1.write(*dump, pre + "g1.");
             f2.write(*dump, pre + "g2.");

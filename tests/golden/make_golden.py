@@ -125,6 +125,24 @@ def main():
             d = pack_batch(batch)
             d["subalign.aln_off"], d["subalign.pairs"] = aln_off, pairs
             np.savez_compressed(os.path.join(HERE, "%s_merge%d.npz" % (tag, m)), **d)
+    # 5. Stitcher::stitch level: parent graphs + partitioned anchor chain -> extracted batch -> stitched alignment
+    #    (dump of a 4 x 30 kbp MSA, seed 22, made by ref_msa_dump with max_num_match_pairs=40000)
+    path = "/tmp/c2/t_22_30000_4.fa.dump"
+    if os.path.exists(path):
+        dd = po.read_dump(path)
+        for m in range(int(dd["n_merges"][0])):
+            pre = "m%d." % m
+            batch, aln_off, pairs = po.batch_from_dump(dd, pre)
+            d = pack_batch(batch)
+            d["subalign.aln_off"], d["subalign.pairs"] = aln_off, pairs
+            for side in ("parent1.", "parent2."):
+                for k in ("label", "next_off", "next_idx", "prev_off", "prev_idx", "path_off", "path_nodes", "tableau"):
+                    d[side + k] = dd[pre + side + k]
+            for k in ("seg_off", "walk_off", "walk1", "walk2", "stitched"):
+                d[k] = dd[pre + k]
+            np.savez_compressed(os.path.join(HERE, "stitch4_30k_merge%d.npz" % m), **d)
+    else:
+        print("skip stitch-level fixtures (no dump at %s)" % path)
     print("golden vectors written to", HERE)
 
 
