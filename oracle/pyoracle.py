@@ -31,8 +31,125 @@ def build_ref():
     subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
 
 
+class CloMatchSets(C.Structure):
+    _fields_ = [("n_sets", C.c_uint64)] + [(n, C.c_void_p) for n in
+                ("set_off1", "walk_off1", "nodes1", "set_off2", "walk_off2", "nodes2", "count1", "count2", "full_length")]
+
+
+class CloChainParams(C.Structure):
+    _fields_ = [("gap_open", C.c_double * 3), ("gap_extend", C.c_double * 3), ("anchor_score_function", C.c_int),
+                ("pair_count_power", C.c_double), ("length_intercept", C.c_double), ("length_decay_power", C.c_double)]
+
+
+def default_chain_params():
+    """the CLI's anchoring parameters (src/parameters.cpp:39-59)"""
+    p = CloChainParams()
+    p.gap_open[:] = [1.25, 50.0, 5000.0]
+    p.gap_extend[:] = [2.5, 0.1, 0.0015]
+    p.anchor_score_function = 2  # ConcaveLengthScaleInverseCount
+    p.pair_count_power = 0.5
+    p.length_intercept = 2250.0
+    p.length_decay_power = 2.0
+    return p
+
+
+class MatchSets:
+    """numpy holder for clo_match_sets (std::vector<match_set_t>)"""
+    _DT = dict(set_off1=np.uint64, walk_off1=np.uint64, nodes1=np.uint32, set_off2=np.uint64, walk_off2=np.uint64,
+               nodes2=np.uint32, count1=np.uint64, count2=np.uint64, full_length=np.uint64)
+
+    def __init__(self, **arrays):
+        for k, dt in self._DT.items():
+            setattr(self, k, np.ascontiguousarray(arrays[k], dtype=dt))
+
+    @property
+    def n_sets(self):
+        return len(self.count1)
+
+    def n_pairs(self):
+        return int((np.diff(self.set_off1.astype(np.int64)) * np.diff(self.set_off2.astype(np.int64))).sum())
+
+    def as_c(self):
+        c = CloMatchSets()
+        c.n_sets = self.n_sets
+        for k in self._DT:
+            setattr(c, k, getattr(self, k).ctypes.data)
+        return c
+
+    @staticmethod
+    def from_dump(d, prefix):
+        return MatchSets(**{k: d[prefix + "ms." + k] for k in MatchSets._DT})
+
+
 _oracle = None
 _ref = None
+_chain = None
+CHAIN_LIB = os.path.join(_HERE, "_build", "libcl_chain_oracle.so")
+
+
+def chain_lib():
+    global _chain
+    if _chain is None:
+        if not os.path.exists(CHAIN_LIB):
+            build_oracle()
+        from centrolign_amd.capi import BaseGraphC
+        lib = C.CDLL(CHAIN_LIB)
+        for name in ("clo_sparse_affine_chain", "clo_sparse_chain"):
+            getattr(lib, name).restype = C.c_int
+        lib.clo_sparse_affine_chain.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
+                                                C.POINTER(CloChainParams), C.c_double, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+        lib.clo_sparse_chain.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
+                                         C.POINTER(CloChainParams), C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+        _chain = lib
+    return _chain
+
+
+def oracle_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None, want_dp=False):
+    """algo 'affine' -> sparse_affine_chain_dp, 'sparse' -> sparse_chain_dp; returns chain (n,3) [and dp values]"""
+    lib = chain_lib()
+    params = params or default_chain_params()
+    n = ms.n_sets if num_match_sets is None else num_match_sets
+    c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
+    out = np.zeros((max(ms.n_pairs(), 1), 3), np.uint32)
+    dp = np.zeros(max(ms.n_pairs(), 1), np.float32) if want_dp else None
+    ln = C.c_uint64(0)
+    dpp = dp.ctypes.data if want_dp else None
+    if algo == "affine":
+        rc = lib.clo_sparse_affine_chain(C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale), out.ctypes.data, C.byref(ln), dpp)
+    else:
+        rc = lib.clo_sparse_chain(C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), out.ctypes.data, C.byref(ln), dpp)
+    if rc:
+        raise RuntimeError("chain oracle failed: %d" % rc)
+    chain = out[:int(ln.value)].copy()
+    return (chain, dp) if want_dp else chain
+
+
+def ref_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None):
+    """the compiled reference's DP on the same flat inputs; returns (chain (n,3), seconds)"""
+    lib = ref_lib()
+    from centrolign_amd.capi import BaseGraphC
+    lib.ref_chain_dp.restype = C.c_int
+    lib.ref_chain_dp.argtypes = [C.c_int, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
+                                 C.POINTER(CloChainParams), C.c_double, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    params = params or default_chain_params()
+    n = ms.n_sets if num_match_sets is None else num_match_sets
+    c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
+    out = np.zeros((max(ms.n_pairs(), 1), 3), np.uint32)
+    ln, secs = C.c_uint64(0), C.c_double(0)
+    rc = lib.ref_chain_dp(0 if algo == "affine" else 1, C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale),
+                          out.ctypes.data, C.byref(ln), C.byref(secs))
+    if rc:
+        raise RuntimeError("ref_chain_dp failed: %d" % rc)
+    return out[:int(ln.value)].copy(), secs.value
+
+
+def graphs_from_dump(d, prefix):
+    from centrolign_amd.capi import BaseGraph
+    out = []
+    for side in ("parent1.", "parent2."):
+        t = d[prefix + side + "tableau"]
+        out.append(BaseGraph(*[d[prefix + side + k] for k in ("label", "next_off", "next_idx", "prev_off", "prev_idx", "path_off", "path_nodes")], t[0], t[1]))
+    return out
 
 
 def oracle_lib():
@@ -147,3 +264,37 @@ def ref_msa_dump(fasta_path, newick_path=None, dump_path=None, out_path=None, sk
         raise RuntimeError("ref_msa_dump failed with code %d" % code)
     keys = ("calibration", "match_finding", "chaining", "partition", "extraction", "subalign", "fuse", "total")
     return dict(zip(keys, [float(x) for x in t]))
+
+
+def subset_match_sets(ms, idx):
+    """a MatchSets holding only the sets idx (in that order)"""
+    out = {}
+    for side in ("1", "2"):
+        so = getattr(ms, "set_off" + side).astype(np.int64)
+        wo = getattr(ms, "walk_off" + side).astype(np.int64)
+        nodes = getattr(ms, "nodes" + side)
+        new_so, new_wo, new_nodes = [0], [0], []
+        for s in idx:
+            for w in range(so[s], so[s + 1]):
+                new_nodes.append(nodes[wo[w]:wo[w + 1]])
+                new_wo.append(new_wo[-1] + (wo[w + 1] - wo[w]))
+            new_so.append(len(new_wo) - 1)
+        out["set_off" + side] = np.array(new_so, np.uint64)
+        out["walk_off" + side] = np.array(new_wo, np.uint64)
+        out["nodes" + side] = np.concatenate(new_nodes) if new_nodes else np.zeros(0, np.uint32)
+    idx = np.asarray(idx, np.int64)
+    out["count1"], out["count2"], out["full_length"] = ms.count1[idx], ms.count2[idx], ms.full_length[idx]
+    return MatchSets(**out)
+
+
+def budget_subset(ms, max_pairs, seed=0):
+    """random subset of match sets whose total pair count stays under max_pairs (test-size inputs)"""
+    rng = np.random.default_rng(seed)
+    pairs = np.diff(ms.set_off1.astype(np.int64)) * np.diff(ms.set_off2.astype(np.int64))
+    order = rng.permutation(ms.n_sets)
+    keep, tot = [], 0
+    for s in order:
+        if tot + pairs[s] <= max_pairs:
+            keep.append(int(s)); tot += int(pairs[s])
+    keep.sort()
+    return subset_match_sets(ms, keep)

@@ -329,6 +329,21 @@ struct DumpCore : public Core {
             auto matches = path_match_finder.find_matches(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau);
             t_match += std::chrono::duration<double>(clk::now() - m0).count();
             std::string pre = "m" + std::to_string(merge) + ".";
+            if (dump) {
+                /* the match sets exactly as PathMatchFinder returns them (anchor_chain reorders them later) */
+                std::vector<uint64_t> so1{0}, so2{0}, wo1{0}, wo2{0}, c1, c2, fl;
+                std::vector<uint32_t> n1, n2;
+                for (const auto& ms : matches) {
+                    for (const auto& w : ms.walks1) { for (auto v : w) n1.push_back((uint32_t)v); wo1.push_back(n1.size()); }
+                    for (const auto& w : ms.walks2) { for (auto v : w) n2.push_back((uint32_t)v); wo2.push_back(n2.size()); }
+                    so1.push_back(wo1.size() - 1); so2.push_back(wo2.size() - 1);
+                    c1.push_back(ms.count1); c2.push_back(ms.count2); fl.push_back(ms.full_length);
+                }
+                dump->u64(pre + "ms.set_off1", so1); dump->u64(pre + "ms.walk_off1", wo1); dump->u32(pre + "ms.nodes1", n1);
+                dump->u64(pre + "ms.set_off2", so2); dump->u64(pre + "ms.walk_off2", wo2); dump->u32(pre + "ms.nodes2", n2);
+                dump->u64(pre + "ms.count1", c1); dump->u64(pre + "ms.count2", c2); dump->u64(pre + "ms.full_length", fl);
+                dump->f64(pre + "score_scale", std::vector<double>{score_function.score_scale});
+            }
             /* core.hpp:296-357: this driver covers the default SparseAffine / PathMerge<uint32,uint8> branch */
             PathMerge<uint32_t, uint8_t> pm1(sp1.graph, sp1.tableau);
             PathMerge<uint32_t, uint8_t> pm2(sp2.graph, sp2.tableau);
@@ -348,7 +363,78 @@ struct DumpCore : public Core {
 
 }  // namespace
 
+/* ---- chaining: the reference's DP on flat inputs ------------------------------------------------------------------ */
+BaseGraph build_base_graph(const cl_base_graph* g, SentinelTableau& tableau) {
+    BaseGraph bg;
+    for (uint64_t v = 0; v < g->n_nodes; ++v) bg.add_node((char)g->label[v]);
+    /* edges: honour both list orders with the same greedy merge as build_graph */
+    clo_graph cg;
+    cg.n = g->n_nodes; cg.label = g->label; cg.prev_off = g->prev_off; cg.prev_idx = g->prev_idx;
+    cg.next_off = g->next_off; cg.next_idx = g->next_idx; cg.n_src = cg.n_snk = 0; cg.src = cg.snk = nullptr;
+    BaseGraph with_edges = build_graph(&cg);
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        auto id = with_edges.add_path("p" + std::to_string(p));
+        for (uint64_t i = g->path_off[p]; i < g->path_off[p + 1]; ++i) with_edges.extend_path(id, g->path_nodes[i]);
+    }
+    tableau.src_id = g->src_id;
+    tableau.snk_id = g->snk_id;
+    return with_edges;
+}
+
+struct OpenAnchorer : public Anchorer {
+    explicit OpenAnchorer(const ScoreFunction& sf) : Anchorer(sf) {}
+    using Anchorer::sparse_affine_chain_dp;
+    using Anchorer::sparse_chain_dp;
+};
+
 extern "C" {
+
+/* algo 0: sparse_affine_chain_dp (anchorer.hpp:1812-2471), algo 1: sparse_chain_dp (:1511-1750); local anchoring,
+ * the default (non memory-restrained) integer widths of anchor_chain (:1258-1290) */
+int ref_chain_dp(int algo, const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                 const clo_chain_params* cp, double local_scale, uint32_t* chain_out, uint64_t* chain_len, double* seconds_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    std::vector<match_set_t> sets(ms->n_sets);
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
+            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
+        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
+            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
+        sets[s].count1 = ms->count1[s];
+        sets[s].count2 = ms->count2[s];
+        sets[s].full_length = ms->full_length[s];
+    }
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    OpenAnchorer an(sf);
+    std::array<double, 3> go{{cp->gap_open[0], cp->gap_open[1], cp->gap_open[2]}}, ge{{cp->gap_extend[0], cp->gap_extend[1], cp->gap_extend[2]}};
+    PathMerge<uint32_t, uint8_t> pm1(b1, t1), pm2(b2, t2);
+    using SmallMatchBank = MatchBank<uint32_t, uint16_t, float>;
+    using SmallShiftMatchVector = std::vector<std::pair<int32_t, SmallMatchBank::match_id_t>>;
+    using SmallDistMatchVector = std::vector<std::pair<uint32_t, SmallMatchBank::match_id_t>>;
+    using FwdEdges = ForwardEdges<uint32_t, uint8_t>;
+    std::vector<anchor_t> chain;
+    auto a = std::chrono::steady_clock::now();
+    if (algo == 0)
+        chain = an.sparse_affine_chain_dp<uint32_t, uint16_t, uint32_t, int32_t, uint32_t, float, SmallShiftMatchVector, SmallDistMatchVector,
+                                          std::vector<uint32_t>, std::vector<uint32_t>, SmallMatchBank, FwdEdges>(
+            sets, b1, b2, pm1, pm2, go, ge, local_scale, num_match_sets, true, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else
+        chain = an.sparse_chain_dp<uint32_t, uint32_t, uint16_t, uint32_t, float, SmallDistMatchVector, std::vector<uint32_t>, SmallMatchBank, FwdEdges>(
+            sets, b1, pm1, pm2, num_match_sets, true, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+    *chain_len = chain.size();
+    for (size_t i = 0; i < chain.size(); ++i) {
+        chain_out[3 * i] = (uint32_t)chain[i].match_set;
+        chain_out[3 * i + 1] = (uint32_t)chain[i].idx1;
+        chain_out[3 * i + 2] = (uint32_t)chain[i].idx2;
+    }
+    return 0;
+}
 
 int ref_po_poa(const clo_graph* g1, const clo_graph* g2, int npw, const cl_align_params* prm, uint64_t* pairs_out,
                uint64_t* n_pairs_out, int64_t* score_out) {

@@ -141,6 +141,21 @@ def main():
             for k in ("seg_off", "walk_off", "walk1", "walk2", "stitched"):
                 d[k] = dd[pre + k]
             np.savez_compressed(os.path.join(HERE, "stitch4_30k_merge%d.npz" % m), **d)
+        # 6. chaining DP seam: budgeted subsets of the match sets PathMatchFinder returned for those merges -> the chains
+        #    the reference's sparse_chain_dp / sparse_affine_chain_dp select (graphs are in stitch4_30k_merge*.npz)
+        for m in range(int(dd["n_merges"][0])):
+            pre = "m%d." % m
+            g1, g2 = po.graphs_from_dump(dd, pre)
+            full = po.MatchSets.from_dump(dd, pre)
+            out = {}
+            for tag, budget, seed, scale in (("a", 20000, m, 0.7), ("b", 6000, 10 + m, 0.25)):
+                ms = po.budget_subset(full, budget, seed=seed)
+                for k in po.MatchSets._DT:
+                    out["%s.ms.%s" % (tag, k)] = getattr(ms, k)
+                out[tag + ".scale"] = np.array([scale])
+                out[tag + ".chain_sparse"], _ = po.ref_chain("sparse", g1, g2, ms)
+                out[tag + ".chain_affine"], _ = po.ref_chain("affine", g1, g2, ms, scale=scale)
+            np.savez_compressed(os.path.join(HERE, "chain4_30k_merge%d.npz" % m), **out)
     else:
         print("skip stitch-level fixtures (no dump at %s)" % path)
     print("golden vectors written to", HERE)
