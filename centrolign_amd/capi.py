@@ -188,6 +188,62 @@ def extract_stitch_batch(graph1, graph2, segments):
         lib.cl_owned_batch_free(h)
 
 
+class MatchSetsC(C.Structure):
+    _fields_ = [("n_sets", C.c_uint64)] + [(n, C.c_void_p) for n in
+                ("set_off1", "walk_off1", "nodes1", "set_off2", "walk_off2", "nodes2", "count1", "count2", "full_length")]
+
+
+class ChainParams(C.Structure):
+    """cl_chain_params: Anchorer gap parameters + ScoreFunction fields"""
+    _fields_ = [("gap_open", C.c_double * 3), ("gap_extend", C.c_double * 3), ("anchor_score_function", C.c_int),
+                ("pair_count_power", C.c_double), ("length_intercept", C.c_double), ("length_decay_power", C.c_double)]
+
+
+class ChainResultC(C.Structure):
+    _fields_ = [("n_anchors", C.c_uint64), ("anchors", C.POINTER(C.c_uint32)), ("n_pairs", C.c_uint64),
+                ("dp", C.POINTER(C.c_float)), ("n_ties", C.c_uint64), ("device_ms", C.c_float)]
+
+
+def default_chain_params():
+    """the CLI's anchoring parameters (src/parameters.cpp:39-59)"""
+    p = ChainParams()
+    p.gap_open[:] = [1.25, 50.0, 5000.0]
+    p.gap_extend[:] = [2.5, 0.1, 0.0015]
+    p.anchor_score_function = 2  # ConcaveLengthScaleInverseCount
+    p.pair_count_power = 0.5
+    p.length_intercept = 2250.0
+    p.length_decay_power = 2.0
+    return p
+
+
+class MatchSets:
+    """numpy holder for cl_match_sets (std::vector<match_set_t>)"""
+    _DT = dict(set_off1=np.uint64, walk_off1=np.uint64, nodes1=np.uint32, set_off2=np.uint64, walk_off2=np.uint64,
+               nodes2=np.uint32, count1=np.uint64, count2=np.uint64, full_length=np.uint64)
+
+    def __init__(self, **arrays):
+        for k, dt in self._DT.items():
+            setattr(self, k, np.ascontiguousarray(arrays[k], dtype=dt))
+
+    @property
+    def n_sets(self):
+        return len(self.count1)
+
+    def n_pairs(self):
+        return int((np.diff(self.set_off1.astype(np.int64)) * np.diff(self.set_off2.astype(np.int64))).sum())
+
+    def as_c(self):
+        c = MatchSetsC()
+        c.n_sets = self.n_sets
+        for k in self._DT:
+            setattr(c, k, getattr(self, k).ctypes.data)
+        return c
+
+    @staticmethod
+    def from_dump(d, prefix):
+        return MatchSets(**{k: d[prefix + "ms." + k] for k in MatchSets._DT})
+
+
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
                 ("dp_bytes", C.c_uint64), ("last_ms", C.c_float)]
@@ -450,6 +506,11 @@ def load_library(path=None):
     lib.cl_stitch.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(AnchorSegmentsC),
                               C.POINTER(StitchParams), C.POINTER(AlignmentC)]
     lib.cl_alignment_free.argtypes = [C.POINTER(AlignmentC)]
+    lib.cl_chain_params_default.argtypes = [C.POINTER(ChainParams)]
+    lib.cl_chain_sparse_affine.restype = C.c_int
+    lib.cl_chain_sparse_affine.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
+                                           C.POINTER(ChainParams), C.c_double, C.c_int, C.POINTER(ChainResultC)]
+    lib.cl_chain_result_free.argtypes = [C.POINTER(ChainResultC)]
     if path is None:
         _lib = lib
     return lib
@@ -462,6 +523,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
+    "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_result_free",
 ]
 
 
@@ -562,6 +624,22 @@ class Context:
             return np.ctypeslib.as_array(out.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2)
         finally:
             self.lib.cl_alignment_free(C.byref(out))
+
+    def chain_sparse_affine(self, graph1, graph2, matches, scale=1.0, params=None, num_match_sets=None, want_dp=False):
+        """sparse_affine_chain_dp (include/centrolign/anchorer.hpp:1812-2471) on the GPU.
+        Returns dict(chain=(n,3) uint32 [match_set, idx1, idx2], dp=float32[n_pairs] or None, n_ties, device_ms)"""
+        params = params or default_chain_params()
+        g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), ChainResultC()
+        n = matches.n_sets if num_match_sets is None else num_match_sets
+        self._check(self.lib.cl_chain_sparse_affine(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), n, C.byref(params),
+                                                    float(scale), int(want_dp), C.byref(out)))
+        try:
+            na, npairs = int(out.n_anchors), int(out.n_pairs)
+            chain = np.ctypeslib.as_array(out.anchors, shape=(max(na, 1) * 3,))[:3 * na].copy().reshape(na, 3)
+            dp = np.ctypeslib.as_array(out.dp, shape=(max(npairs, 1),))[:npairs].copy() if want_dp and npairs else None
+            return dict(chain=chain, dp=dp, n_ties=int(out.n_ties), device_ms=float(out.device_ms), n_pairs=npairs)
+        finally:
+            self.lib.cl_chain_result_free(C.byref(out))
 
     def plan(self, batch, params=None, force_num_pw=None):
         params = params or default_stitch_params()

@@ -1,0 +1,52 @@
+// chain_device.h — device-side layout of a packed chaining problem (shared by cl_chain_api.cpp and chain_kernels.hip)
+#ifndef CL_CHAIN_DEVICE_H
+#define CL_CHAIN_DEVICE_H
+
+#include <stdint.h>
+
+#define CL_CHAIN_NEG (-3.402823466e+38f)  // numeric_limits<float>::lowest(), the reference's mininf (anchorer.hpp:1868)
+
+constexpr uint32_t kChainBlock = 1024;    // match pairs per sequential block (one workgroup in the intra kernel)
+constexpr uint32_t kChainTile = 4096;     // predecessor records per workgroup in the inter kernel
+constexpr uint32_t kChainMaxRecs = 32;    // records of one pair broadcast through LDS (more fall back to HBM)
+constexpr uint32_t kChainMaxCand = 16;    // tie candidates listed per query for the traceback
+
+struct ClChainParams {
+    double gap_open[3];
+    double gap_extend[3];
+    double scale;         // local_scale
+};
+
+// one (chain1, chain2) combination = one set of the reference's search trees (anchorer.hpp:2087-2237)
+struct ClChainCombo {
+    uint32_t n_recs;
+    // records: the match pairs that lie on this chain pair, in sorted pair order
+    const uint32_t* rec_s;    // sorted pair index
+    const uint32_t* ins_t;    // index_on(e1, p1)            : insertion time on chain p1
+    const uint32_t* off;      // index_on(e2, p2)            : key offset (anchorer.hpp:1894-1896)
+    const int32_t*  sigma;    // source shift                 (:1875-1880)
+    float*          val;      // [7][n_recs]: dp, then the value stored in tree pw = 0..5 (:2325-2342)
+    const uint32_t* prefix;   // [n_blocks + 1] records whose pair index is < block start
+    // queries: one per sorted pair (dense)
+    const uint32_t* qt;       // predecessor_index(b1, p1), 0xFFFFFFFF = no forward edge on p1
+    const uint32_t* qoff;     // predecessor_index(b2, p2) + 1 (wraps to 0)   (:1898-1901)
+    const int32_t*  q;        // query shift                  (:1886-1892)
+    int*            acc;      // [n_pairs][7] running maxima, order-preserving float encoding
+};
+
+struct ClChainDevice {
+    uint32_t n_pairs, n_combos;
+    const ClChainCombo* combos;
+    const float* weight;        // anchor weight per sorted pair
+    float* dp;                  // final DP value per sorted pair
+    const uint32_t* rec_off;    // [n_pairs + 1] records of each pair
+    const uint32_t* rec_combo;
+    const uint32_t* rec_pos;
+    ClChainParams params;
+};
+
+struct ClChainQuery {
+    uint32_t s, combo, kind;
+};
+
+#endif

@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/centrolign_amd.h"
+#include "cl_internal.hpp"
 #include "popoa_device.h"
 #include "stitch_host.hpp"
 
@@ -40,23 +40,9 @@ const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); re
 // test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
 const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && *e == '1'; }();
 
-constexpr int kNumAuxStreams = 12;
-
 }  // namespace
 
-struct cl_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t aux[kNumAuxStreams] = {};
-    hipEvent_t ev_fork = nullptr;
-    hipEvent_t ev_join[kNumAuxStreams] = {};
-    std::string error;
-    std::string name;
-};
-
-namespace {
-
-void set_error(cl_context* ctx, const char* fmt, ...) {
+void cl_set_error(cl_context* ctx, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -65,15 +51,9 @@ void set_error(cl_context* ctx, const char* fmt, ...) {
     g_error = buf;
     if (ctx) ctx->error = buf;
 }
+#define set_error cl_set_error
 
-#define HIP_TRY(ctx, call)                                                                        \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return e_ == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;                 \
-        }                                                                                         \
-    } while (0)
+namespace {
 
 // ---- one graph of one problem, as a view into the flat batch -------------------------------------------
 struct GraphView {
@@ -293,29 +273,6 @@ int64_t pure_deletion_score(size_t path_len, int npw, const cl_align_params& p) 
     for (int k = 0; k < npw; ++k) s = std::min<int64_t>(s, (int64_t)(uint32_t)(0u - p.gap_open[k] - p.gap_extend[k]));
     return s;
 }
-
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    int alloc(cl_context* ctx, size_t count) {
-        n = count;
-        if (count == 0) count = 1;
-        HIP_TRY(ctx, hipMalloc((void**)&p, count * sizeof(T)));
-        return CL_OK;
-    }
-    int upload(cl_context* ctx, const std::vector<T>& h) {
-        int rc = alloc(ctx, h.size());
-        if (rc) return rc;
-        if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-        return CL_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-};
 
 struct LaunchGroup {
     int kind = 0;

@@ -1,0 +1,547 @@
+// cl_chain_api.cpp — host side of cl_chain_sparse_affine (include/centrolign_amd.h): the Anchorer's sparse affine
+// chaining DP (include/centrolign/anchorer.hpp:1812-2547) with the DP itself on the GPU (chain_kernels.hip).
+//
+// Host work, all O(M) or O(M log M):
+//   * the coordinate system: PathMerge tables (path_merge.hpp:96-277), post-switch distances
+//     (post_switch_distances.hpp:44-81), source/query shifts and offsets per (chain1, chain2) (anchorer.hpp:1875-1904),
+//     forward-edge existence (forward_edges.hpp:40-53 with the masks of anchorer.hpp:1752-1810), anchor weights
+//     (score_function.hpp:51-75);
+//   * ordering the match pairs by the topological position of their first graph-1 node, so that every possible
+//     predecessor of a pair comes before it;
+//   * after the device has produced every DP value: the optimum (anchorer.hpp:2483-2499), and for each pair on the
+//     chain the predecessor the reference would have recorded.  The DP VALUE is a maximum and is order-free, the
+//     BACKPOINTER is whatever the reference's search trees return among equal maxima: first candidate query in its
+//     loop order whose value reaches the maximum (strict '>' in MatchBank::update_dp, match_bank.hpp:177), and inside
+//     that query the tree's traversal rule — first unit met by range_max; inside a cross tree the larger outer index
+//     (values there are (score, index) pairs, orthogonal_max_search_tree.hpp:76); inside a gap-free subtree the
+//     earliest inserted (strict '>' in MaxSearchTree::update, max_search_tree.hpp:318-358).  pick_ortho / pick_gap_free
+//     evaluate that rule directly on the sorted keys; they only run when a maximum is attained more than once.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <vector>
+
+#include "chain_device.h"
+#include "cl_internal.hpp"
+#include "stitch_host.hpp"
+
+hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t max_prefix, hipStream_t stream);
+hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream);
+hipError_t cl_chain_launch_candidates(const ClChainDevice& D, const ClChainQuery* queries, uint32_t n_queries, uint32_t* cand_count,
+                                      uint32_t* cand_list, hipStream_t stream);
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// post_switch_distances.hpp:44-81; 0xFFFFFFFF = none (the reference's size_t(-1), used modulo 2^32)
+struct PostSwitchTable {
+    uint64_t n = 0;
+    std::vector<uint32_t> d;
+    void build(const cl_base_graph& g, const clhost::PathMergeTable& pm) {
+        n = g.n_nodes;
+        d.assign(pm.chain_size() * n, 0);
+        std::vector<uint32_t> order;
+        clhost::topological_order(g, order);
+        for (uint32_t v : order)
+            for (uint64_t p = 0; p < pm.chain_size(); ++p) {
+                uint32_t* row = &d[p * n];
+                const uint32_t pr = pm.predecessor_index(v, p);
+                for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) {
+                    const uint32_t u = g.prev_idx[e];
+                    if (pm.index_on(u, p) == pr) { row[v] = 1; break; }
+                    if (pm.predecessor_index(u, p) == pr) {
+                        const uint64_t thru = (uint64_t)row[u] + 1;
+                        if (row[v] == 0 || row[v] > thru) row[v] = (uint32_t)thru;
+                    }
+                }
+            }
+    }
+    uint32_t distance(uint64_t v, uint64_t p) const { const uint32_t x = d[p * n + v]; return x == 0 ? kNone : x; }
+};
+
+double anchor_weight(const cl_chain_params& cp, uint64_t count1, uint64_t count2, uint64_t length, uint64_t full_length) {
+    const double count = (double)(count1 * count2);
+    const double fraction = double(length) / double(full_length);
+    switch (cp.anchor_score_function) {
+    case 0: return fraction / pow(count, cp.pair_count_power);
+    case 1: return fraction * length / pow(count, cp.pair_count_power);
+    case 2: return fraction * (length / pow(count, cp.pair_count_power) - pow(length / cp.length_intercept, cp.length_decay_power) * cp.length_intercept);
+    default: return fraction * (length - count * pow(length / cp.length_intercept, cp.length_decay_power) * cp.length_intercept);
+    }
+}
+
+inline int enc(float f) { int b; memcpy(&b, &f, 4); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
+inline float dec(int k) { int b = k >= 0 ? k : k ^ 0x7FFFFFFF; float f; memcpy(&f, &b, 4); return f; }
+
+// heap node of the r-th smallest key in a MaxSearchTree / outer OrthogonalMaxSearchTree of n keys
+// (implicit complete binary tree filled by an in-order walk, max_search_tree.hpp:113-150)
+std::vector<uint32_t> heap_of_rank(size_t n) {
+    std::vector<uint32_t> h(n);
+    size_t next = 0;
+    std::vector<std::pair<size_t, bool>> st;
+    if (n) st.emplace_back(0, false);
+    while (!st.empty()) {
+        auto& top = st.back();
+        if (!top.second) {
+            top.second = true;
+            if (2 * top.first + 1 < n) st.emplace_back(2 * top.first + 1, false);
+        } else {
+            const size_t x = top.first;
+            h[next++] = (uint32_t)x;
+            st.pop_back();
+            if (2 * x + 2 < n) st.emplace_back(2 * x + 2, false);
+        }
+    }
+    return h;
+}
+
+inline bool in_subtree(size_t y, size_t x) {
+    while (y > x) y = (y - 1) / 2;
+    return y == x;
+}
+
+// Replays the unit order of range_max over rank interval [rlo, rhi) (max_search_tree.hpp:361-444,
+// orthogonal_max_search_tree.hpp:343-544) on a tree of n keys: calls node(x) for the nodes on the search path that lie
+// in range and subtree(x) for the off-path subtrees, in the order the reference inspects them; stops at the first
+// callback that returns true.
+template <class NodeF, class SubF>
+void replay_units(size_t n, const std::vector<uint32_t>& rank_of_heap, size_t rlo, size_t rhi, NodeF node, SubF subtree) {
+    auto in = [&](size_t x) { return rank_of_heap[x] >= rlo && rank_of_heap[x] < rhi; };
+    size_t c = 0;
+    while (c < n && !in(c)) c = rank_of_heap[c] >= rhi ? 2 * c + 1 : 2 * c + 2;
+    if (c >= n) return;
+    if (node(c)) return;
+    size_t lc = 2 * c + 1, rc = 2 * c + 2;
+    while (lc < n) {
+        if (rank_of_heap[lc] >= rlo) {
+            if (node(lc)) return;
+            if (2 * lc + 2 < n && subtree(2 * lc + 2)) return;
+            lc = 2 * lc + 1;
+        } else lc = 2 * lc + 2;
+    }
+    while (rc < n) {
+        if (rank_of_heap[rc] < rhi) {
+            if (node(rc)) return;
+            if (2 * rc + 1 < n && subtree(2 * rc + 1)) return;
+            rc = 2 * rc + 2;
+        } else rc = 2 * rc + 1;
+    }
+}
+
+struct Combo {
+    uint32_t p1 = 0, p2 = 0;
+    std::vector<uint32_t> rec_s, ins_t, off;
+    std::vector<int32_t> sigma;
+    std::vector<uint32_t> qt, qoff;
+    std::vector<int32_t> q;
+    std::vector<uint32_t> prefix;
+    // device
+    DevBuf<uint32_t> d_rec_s, d_ins_t, d_off, d_prefix, d_qt, d_qoff;
+    DevBuf<int32_t> d_sigma, d_q;
+    DevBuf<float> d_val;
+    DevBuf<int> d_acc;
+    // lazily built for tie resolution
+    std::vector<uint32_t> ortho_order;  // record indices sorted by (sigma, slot)
+    std::vector<uint32_t> ortho_heap, ortho_rank_of_heap;
+    void release() {
+        d_rec_s.release(); d_ins_t.release(); d_off.release(); d_prefix.release(); d_qt.release(); d_qoff.release();
+        d_sigma.release(); d_q.release(); d_val.release(); d_acc.release();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void cl_chain_params_default(cl_chain_params* p) {
+    // src/parameters.cpp:39-59
+    const double go[3] = {1.25, 50.0, 5000.0}, ge[3] = {2.5, 0.1, 0.0015};
+    for (int i = 0; i < 3; ++i) { p->gap_open[i] = go[i]; p->gap_extend[i] = ge[i]; }
+    p->anchor_score_function = 2;
+    p->pair_count_power = 0.5;
+    p->length_intercept = 2250.0;
+    p->length_decay_power = 2.0;
+}
+
+void cl_chain_result_free(cl_chain_result* r) {
+    if (!r) return;
+    free(r->anchors);
+    free(r->dp);
+    memset(r, 0, sizeof(*r));
+}
+
+int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                           uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp,
+                           cl_chain_result* out) {
+    if (!ctx || !g1 || !g2 || !ms || !cp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    if (num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    clhost::PathMergeTable x1, x2;
+    if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    PostSwitchTable sw1, sw2;
+    sw1.build(*g1, x1);
+    sw2.build(*g2, x2);
+    const uint64_t C1 = x1.chain_size(), C2 = x2.chain_size();
+    std::vector<uint32_t> order1;
+    clhost::topological_order(*g1, order1);
+    std::vector<uint32_t> pos1(g1->n_nodes);
+    for (uint32_t i = 0; i < order1.size(); ++i) pos1[order1[i]] = i;
+
+    // match pairs in MatchBank iteration order (match_bank.hpp:252-268): slot = position in that order
+    struct Pair { uint32_t set; uint32_t i1, i2; uint32_t b1, e1, b2, e2; };
+    std::vector<Pair> pairs;
+    std::vector<uint64_t> set_base(num_match_sets + 1, 0);
+    std::vector<char> has_start(g1->n_nodes, 0), after_end(g1->n_nodes, 0);
+    for (uint64_t s = 0; s < num_match_sets; ++s) {
+        const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
+        if (n1 >= 65535 || n2 >= 65535) { cl_set_error(ctx, "match set %llu has too many walks", (unsigned long long)s); return CL_ERR_INVALID_ARGUMENT; }
+        set_base[s + 1] = set_base[s] + n1 * n2;
+        for (uint64_t j = 0; j < n1; ++j) {
+            const uint64_t w1 = ms->set_off1[s] + j;
+            const uint32_t b1 = ms->nodes1[ms->walk_off1[w1]], e1 = ms->nodes1[ms->walk_off1[w1 + 1] - 1];
+            has_start[b1] = 1;
+            after_end[e1] = 1;
+            for (uint64_t k = 0; k < n2; ++k) {
+                const uint64_t w2 = ms->set_off2[s] + k;
+                pairs.push_back(Pair{(uint32_t)s, (uint32_t)j, (uint32_t)k, b1, e1, ms->nodes2[ms->walk_off2[w2]], ms->nodes2[ms->walk_off2[w2 + 1] - 1]});
+            }
+        }
+    }
+    const uint64_t M = pairs.size();
+    if (M >= (1ull << 31)) { cl_set_error(ctx, "too many match pairs"); return CL_ERR_INVALID_ARGUMENT; }
+    out->n_pairs = M;
+    if (M == 0) return CL_OK;
+    {   // nodes that follow the end of some match (anchorer.hpp:1776-1797)
+        std::vector<uint32_t> st;
+        for (uint64_t v = 0; v < g1->n_nodes; ++v)
+            if (after_end[v]) {
+                st.push_back((uint32_t)v);
+                while (!st.empty()) {
+                    const uint32_t h = st.back();
+                    st.pop_back();
+                    for (uint64_t e = g1->next_off[h]; e < g1->next_off[h + 1]; ++e)
+                        if (!after_end[g1->next_idx[e]]) { after_end[g1->next_idx[e]] = 1; st.push_back(g1->next_idx[e]); }
+                }
+            }
+    }
+    // sorted pair order: by topological position of the first graph-1 node (stable in slot order)
+    std::vector<uint32_t> by_s(M);  // sorted index -> slot
+    std::iota(by_s.begin(), by_s.end(), 0u);
+    std::stable_sort(by_s.begin(), by_s.end(), [&](uint32_t a, uint32_t b) { return pos1[pairs[a].b1] < pos1[pairs[b].b1]; });
+    std::vector<uint32_t> s_of_slot(M);
+    for (uint32_t s = 0; s < M; ++s) s_of_slot[by_s[s]] = s;
+
+    std::vector<float> weight(M);
+    for (uint32_t s = 0; s < M; ++s) {
+        const Pair& p = pairs[by_s[s]];
+        const uint64_t w0 = ms->set_off1[p.set];
+        weight[s] = (float)anchor_weight(*cp, ms->count1[p.set], ms->count2[p.set], ms->walk_off1[w0 + 1] - ms->walk_off1[w0], ms->full_length[p.set]);
+    }
+
+    // (chain1, chain2) combinations that hold at least one pair; the most populated one goes first (it is the one the
+    // intra kernel keeps in registers)
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> combo_id;
+    std::vector<Combo> combos;
+    std::vector<uint32_t> rec_off(M + 1, 0), rec_combo, rec_pos;
+    for (uint32_t s = 0; s < M; ++s) {
+        const Pair& p = pairs[by_s[s]];
+        x1.for_each_chain_on(p.e1, [&](uint32_t p1) {
+            x2.for_each_chain_on(p.e2, [&](uint32_t p2) {
+                auto key = std::make_pair(p1, p2);
+                auto it = combo_id.find(key);
+                if (it == combo_id.end()) {
+                    it = combo_id.emplace(key, (uint32_t)combos.size()).first;
+                    combos.emplace_back();
+                    combos.back().p1 = p1;
+                    combos.back().p2 = p2;
+                }
+                Combo& c = combos[it->second];
+                rec_combo.push_back(it->second);
+                rec_pos.push_back((uint32_t)c.rec_s.size());
+                c.rec_s.push_back(s);
+                c.ins_t.push_back(x1.index_on(p.e1, p1));
+                c.off.push_back(x2.index_on(p.e2, p2));
+                c.sigma.push_back((int32_t)(x1.index_on(p.e1, p1) - x2.index_on(p.e2, p2)));
+            });
+        });
+        rec_off[s + 1] = (uint32_t)rec_combo.size();
+    }
+    if (combos.size() > 1) {
+        size_t big = 0;
+        for (size_t c = 1; c < combos.size(); ++c)
+            if (combos[c].rec_s.size() > combos[big].rec_s.size()) big = c;
+        if (big != 0) {
+            std::swap(combos[0], combos[big]);
+            for (auto& rc : rec_combo) rc = rc == 0 ? (uint32_t)big : rc == big ? 0u : rc;
+            for (auto& kv : combo_id) kv.second = kv.second == 0 ? (uint32_t)big : kv.second == big ? 0u : kv.second;
+        }
+    }
+    const uint32_t n_blocks = (uint32_t)((M + kChainBlock - 1) / kChainBlock);
+    for (Combo& c : combos) {
+        c.qt.assign(M, kNone);
+        c.qoff.assign(M, 0);
+        c.q.assign(M, 0);
+        for (uint32_t s = 0; s < M; ++s) {
+            const Pair& p = pairs[by_s[s]];
+            const uint32_t pr = x1.predecessor_index(p.b1, c.p1);
+            // a forward edge exists only from a node that follows some match end (forward_edges.hpp:40-53)
+            if (pr == kNone || !has_start[p.b1] || !after_end[x1.node_at(c.p1, pr)]) continue;
+            c.qt[s] = pr;
+            c.qoff[s] = x2.predecessor_index(p.b2, c.p2) + 1u;
+            c.q[s] = (int32_t)(pr - x2.predecessor_index(p.b2, c.p2) + sw1.distance(p.b1, c.p1) - sw2.distance(p.b2, c.p2));
+        }
+        c.prefix.assign(n_blocks + 1, 0);
+        size_t r = 0;
+        for (uint32_t b = 0; b <= n_blocks; ++b) {
+            const uint64_t first = (uint64_t)b * kChainBlock;
+            while (r < c.rec_s.size() && c.rec_s[r] < first) ++r;
+            c.prefix[b] = (uint32_t)r;
+        }
+    }
+
+    // ---- device ----------------------------------------------------------------------------------------------------
+    int rc = CL_OK;
+    DevBuf<ClChainCombo> d_combos;
+    DevBuf<float> d_weight, d_dp;
+    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos;
+    std::vector<ClChainCombo> hc(combos.size());
+    std::vector<int> acc_init(M * 7, enc(CL_CHAIN_NEG));
+    auto cleanup = [&]() {
+        for (Combo& c : combos) c.release();
+        d_combos.release(); d_weight.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release();
+    };
+#define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
+    for (size_t ci = 0; ci < combos.size(); ++ci) {
+        Combo& c = combos[ci];
+        CH(c.d_rec_s.upload(ctx, c.rec_s)); CH(c.d_ins_t.upload(ctx, c.ins_t)); CH(c.d_off.upload(ctx, c.off));
+        CH(c.d_sigma.upload(ctx, c.sigma)); CH(c.d_prefix.upload(ctx, c.prefix));
+        CH(c.d_qt.upload(ctx, c.qt)); CH(c.d_qoff.upload(ctx, c.qoff)); CH(c.d_q.upload(ctx, c.q));
+        CH(c.d_val.alloc(ctx, 7 * c.rec_s.size()));
+        CH(c.d_acc.upload(ctx, acc_init));
+        hc[ci] = ClChainCombo{(uint32_t)c.rec_s.size(), c.d_rec_s.p, c.d_ins_t.p, c.d_off.p, c.d_sigma.p, c.d_val.p, c.d_prefix.p,
+                              c.d_qt.p, c.d_qoff.p, c.d_q.p, c.d_acc.p};
+    }
+    CH(d_combos.upload(ctx, hc));
+    CH(d_weight.upload(ctx, weight));
+    CH(d_dp.alloc(ctx, M));
+    CH(d_rec_off.upload(ctx, rec_off)); CH(d_rec_combo.upload(ctx, rec_combo)); CH(d_rec_pos.upload(ctx, rec_pos));
+    ClChainDevice D{};
+    D.n_pairs = (uint32_t)M;
+    D.n_combos = (uint32_t)combos.size();
+    D.combos = d_combos.p;
+    D.weight = d_weight.p;
+    D.dp = d_dp.p;
+    D.rec_off = d_rec_off.p;
+    D.rec_combo = d_rec_combo.p;
+    D.rec_pos = d_rec_pos.p;
+    for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
+    D.params.scale = local_scale;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipEventCreate failed"); return CL_ERR_HIP; }
+    auto hip_fail = [&](hipError_t e, const char* what) {
+        cl_set_error(ctx, "%s failed: %s", what, hipGetErrorString(e));
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        cleanup();
+        return e == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;
+    };
+    hipError_t he = hipEventRecord(ev0, ctx->stream);
+    for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {
+        const uint32_t first = b * kChainBlock, count = (uint32_t)std::min<uint64_t>(kChainBlock, M - first);
+        uint32_t max_prefix = 0;
+        for (const Combo& c : combos) max_prefix = std::max(max_prefix, c.prefix[b]);
+        he = cl_chain_launch_inter(D, first, count, max_prefix, ctx->stream);
+        if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, ctx->stream);
+    }
+    if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
+    (void)hipEventElapsedTime(&out->device_ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+
+    std::vector<float> dp_sorted(M);
+    he = hipMemcpy(dp_sorted.data(), d_dp.p, M * sizeof(float), hipMemcpyDeviceToHost);
+    std::vector<std::vector<int>> acc(combos.size());
+    for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
+        acc[ci].resize(M * 7);
+        he = hipMemcpy(acc[ci].data(), combos[ci].d_acc.p, M * 7 * sizeof(int), hipMemcpyDeviceToHost);
+    }
+    if (he != hipSuccess) { cl_set_error(ctx, "download failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
+
+    // ---- optimum and traceback (anchorer.hpp:2483-2531) ----------------------------------------------------------
+    float opt = CL_CHAIN_NEG;
+    uint32_t best_slot = kNone;
+    for (uint32_t slot = 0; slot < M; ++slot) {
+        const float v = dp_sorted[s_of_slot[slot]] + 0.0f;
+        if (v > opt && v > 0.0f) { opt = v; best_slot = slot; }
+    }
+    DevBuf<ClChainQuery> d_query;
+    DevBuf<uint32_t> d_count, d_list;
+    CH(d_query.alloc(ctx, 1)); CH(d_count.alloc(ctx, 1)); CH(d_list.alloc(ctx, kChainMaxCand));
+    auto cleanup2 = [&]() { d_query.release(); d_count.release(); d_list.release(); cleanup(); };
+    std::vector<float> val_host;  // lazily downloaded stored values of one combo (ties only)
+    std::vector<uint32_t> chain_slots;
+    uint64_t n_ties = 0;
+    uint32_t here = best_slot;
+    while (here != kNone) {
+        chain_slots.push_back(here);
+        const uint32_t s = s_of_slot[here];
+        const float dpv = dp_sorted[s], w = weight[s];
+        if (!(dpv > w)) break;  // no candidate was strictly greater than the single-anchor chain: chain start
+        const Pair& p = pairs[here];
+        // the reference's candidate order: forward edges by the topological position of their source node, then chain1;
+        // chain2 ascending; gap-free tree, then trees 0..5 (anchorer.hpp:2352-2413)
+        std::vector<std::pair<uint32_t, uint32_t>> edges;  // (position of from-node, p1)
+        for (uint32_t p1 = 0; p1 < C1; ++p1) {
+            const uint32_t pr = x1.predecessor_index(p.b1, p1);
+            if (pr == kNone) continue;
+            const uint64_t from = x1.node_at(p1, pr);
+            if (has_start[p.b1] && after_end[from]) edges.emplace_back(pos1[from], p1);
+        }
+        std::sort(edges.begin(), edges.end());
+        int win_combo = -1, win_kind = -1;
+        for (size_t e = 0; e < edges.size() && win_combo < 0; ++e)
+            for (uint32_t p2 = 0; p2 < C2 && win_combo < 0; ++p2) {
+                auto it = combo_id.find(std::make_pair(edges[e].second, p2));
+                if (it == combo_id.end()) continue;  // empty trees
+                const Combo& c = combos[it->second];
+                const int* a = &acc[it->second][(size_t)s * 7];
+                for (int kind = 0; kind < 7; ++kind) {
+                    if (a[kind] == enc(CL_CHAIN_NEG)) continue;
+                    const float stored = dec(a[kind]);
+                    float cand;
+                    if (kind == 0) cand = stored + w;
+                    else {
+                        const int pw = kind - 1;
+                        const double pen = (pw % 2 == 1) ? local_scale * (cp->gap_open[pw / 2] + cp->gap_extend[pw / 2] * (double)c.q[s])
+                                                         : local_scale * (cp->gap_open[pw / 2] - cp->gap_extend[pw / 2] * (double)c.q[s]);
+                        cand = (float)((double)(stored + w) - pen);
+                    }
+                    if (cand == dpv) { win_combo = (int)it->second; win_kind = kind; break; }
+                }
+            }
+        if (win_combo < 0) { cl_set_error(ctx, "traceback: no candidate reproduces dp of pair %u", here); cleanup2(); return CL_ERR_HIP; }
+        Combo& c = combos[win_combo];
+        ClChainQuery qh{s, (uint32_t)win_combo, (uint32_t)win_kind};
+        uint32_t zero = 0, count = 0;
+        std::vector<uint32_t> cand(kChainMaxCand);
+        he = hipMemcpyAsync(d_query.p, &qh, sizeof(qh), hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(d_count.p, &zero, 4, hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = cl_chain_launch_candidates(D, d_query.p, 1, d_count.p, d_list.p, ctx->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(&count, d_count.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(cand.data(), d_list.p, kChainMaxCand * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) { cl_set_error(ctx, "candidate kernel failed: %s", hipGetErrorString(he)); cleanup2(); return CL_ERR_HIP; }
+        if (count == 0) { cl_set_error(ctx, "traceback: query of pair %u has no predecessor at its maximum", here); cleanup2(); return CL_ERR_HIP; }
+        uint32_t win_rec;
+        if (count == 1) {
+            win_rec = cand[0];
+        } else {
+            ++n_ties;
+            if (count > kChainMaxCand) { cl_set_error(ctx, "traceback: more than %u tied predecessors", kChainMaxCand); cleanup2(); return CL_ERR_UNSUPPORTED_ROUTE; }
+            cand.resize(count);
+            auto slot_of_rec = [&](uint32_t r) { return by_s[c.rec_s[r]]; };
+            if (win_kind == 0) {
+                // gap-free tree of this diagonal: records with the same shift, keyed (offset, match id);
+                // inside an off-path subtree the earliest inserted wins, insertion order = (position of e1, slot)
+                const int32_t diag = c.q[s];
+                std::vector<uint32_t> members;
+                for (uint32_t r = 0; r < c.rec_s.size(); ++r) if (c.sigma[r] == diag) members.push_back(r);
+                std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) {
+                    return c.off[a] != c.off[b] ? c.off[a] < c.off[b] : slot_of_rec(a) < slot_of_rec(b);
+                });
+                const size_t n = members.size();
+                auto h = heap_of_rank(n);
+                std::vector<uint32_t> rank_of_heap(n);
+                for (size_t r = 0; r < n; ++r) rank_of_heap[h[r]] = (uint32_t)r;
+                size_t rhi = 0;
+                while (rhi < n && c.off[members[rhi]] < c.qoff[s]) ++rhi;
+                std::vector<std::pair<size_t, uint32_t>> ch;  // (heap node, record)
+                for (uint32_t r : cand) {
+                    const size_t rk = std::find(members.begin(), members.end(), r) - members.begin();
+                    ch.emplace_back(h[rk], r);
+                }
+                auto earlier = [&](uint32_t a, uint32_t b) {
+                    const uint32_t pa = pos1[pairs[slot_of_rec(a)].e1], pb = pos1[pairs[slot_of_rec(b)].e1];
+                    return pa != pb ? pa < pb : slot_of_rec(a) < slot_of_rec(b);
+                };
+                win_rec = kNone;
+                replay_units(n, rank_of_heap, 0, rhi,
+                             [&](size_t x) { for (auto& e : ch) if (e.first == x) { win_rec = e.second; return true; } return false; },
+                             [&](size_t x) {
+                                 for (auto& e : ch) if (in_subtree(e.first, x) && (win_rec == kNone || earlier(e.second, win_rec))) win_rec = e.second;
+                                 return win_rec != kNone;
+                             });
+            } else {
+                // orthogonal tree of this combination: all its records keyed ((shift, match id), offset); inside a
+                // cross tree the values are (score, outer index) pairs, so the larger outer heap index wins
+                if (c.ortho_order.empty()) {
+                    c.ortho_order.resize(c.rec_s.size());
+                    std::iota(c.ortho_order.begin(), c.ortho_order.end(), 0u);
+                    std::sort(c.ortho_order.begin(), c.ortho_order.end(), [&](uint32_t a, uint32_t b) {
+                        return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b);
+                    });
+                    c.ortho_heap = heap_of_rank(c.ortho_order.size());
+                    c.ortho_rank_of_heap.resize(c.ortho_order.size());
+                    for (size_t r = 0; r < c.ortho_order.size(); ++r) c.ortho_rank_of_heap[c.ortho_heap[r]] = (uint32_t)r;
+                }
+                const size_t n = c.ortho_order.size();
+                const int32_t qq = c.q[s];
+                const bool odd = (win_kind - 1) % 2 == 1;
+                // rank interval of the key1 range: shift < query (odd trees) or shift > query (even trees)
+                size_t lo = 0, hi = n;
+                auto first_ge = [&](int64_t v) {
+                    return (size_t)(std::partition_point(c.ortho_order.begin(), c.ortho_order.end(), [&](uint32_t r) { return (int64_t)c.sigma[r] < v; }) - c.ortho_order.begin());
+                };
+                if (odd) hi = first_ge(qq);
+                else lo = first_ge((int64_t)qq + 1);
+                std::vector<std::pair<size_t, uint32_t>> ch;
+                std::vector<uint32_t> rank_of_rec_local;
+                for (uint32_t r : cand) {
+                    const size_t rk = std::lower_bound(c.ortho_order.begin(), c.ortho_order.end(), r, [&](uint32_t a, uint32_t b) {
+                                          return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b);
+                                      }) - c.ortho_order.begin();
+                    ch.emplace_back(c.ortho_heap[rk], r);
+                }
+                win_rec = kNone;
+                size_t win_heap = 0;
+                replay_units(n, c.ortho_rank_of_heap, lo, hi,
+                             [&](size_t x) { for (auto& e : ch) if (e.first == x) { win_rec = e.second; return true; } return false; },
+                             [&](size_t x) {
+                                 for (auto& e : ch) if (in_subtree(e.first, x) && (win_rec == kNone || e.first > win_heap)) { win_rec = e.second; win_heap = e.first; }
+                                 return win_rec != kNone;
+                             });
+            }
+            if (win_rec == kNone) { cl_set_error(ctx, "traceback: tie resolution failed for pair %u", here); cleanup2(); return CL_ERR_HIP; }
+        }
+        here = by_s[c.rec_s[win_rec]];
+        if (chain_slots.size() > M) { cl_set_error(ctx, "traceback loop"); cleanup2(); return CL_ERR_HIP; }
+    }
+    std::reverse(chain_slots.begin(), chain_slots.end());
+
+    out->n_anchors = chain_slots.size();
+    out->n_ties = n_ties;
+    out->anchors = (uint32_t*)malloc((chain_slots.size() ? chain_slots.size() : 1) * 3 * sizeof(uint32_t));
+    if (want_dp) out->dp = (float*)malloc(M * sizeof(float));
+    if (!out->anchors || (want_dp && !out->dp)) { cl_chain_result_free(out); cleanup2(); return CL_ERR_OUT_OF_MEMORY; }
+    for (size_t i = 0; i < chain_slots.size(); ++i) {
+        const Pair& p = pairs[chain_slots[i]];
+        out->anchors[3 * i] = p.set;
+        out->anchors[3 * i + 1] = p.i1;
+        out->anchors[3 * i + 2] = p.i2;
+    }
+    if (want_dp)
+        for (uint32_t slot = 0; slot < M; ++slot) out->dp[slot] = dp_sorted[s_of_slot[slot]];
+    cleanup2();
+    return CL_OK;
+#undef CH
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// cl_internal.hpp — shared by the translation units of libcentrolign_amd.so (not part of the public ABI)
+#ifndef CL_INTERNAL_HPP
+#define CL_INTERNAL_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/centrolign_amd.h"
+
+constexpr int kNumAuxStreams = 12;
+
+struct cl_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t aux[kNumAuxStreams] = {};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[kNumAuxStreams] = {};
+    std::string error;
+    std::string name;
+};
+
+// defined in cl_api.cpp
+void cl_set_error(cl_context* ctx, const char* fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            cl_set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;                 \
+        }                                                                                         \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(cl_context* ctx, size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        HIP_TRY(ctx, hipMalloc((void**)&p, count * sizeof(T)));
+        return CL_OK;
+    }
+    template <class Vec>
+    int upload(cl_context* ctx, const Vec& h) {
+        int rc = alloc(ctx, h.size());
+        if (rc) return rc;
+        if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return CL_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+#endif

@@ -235,6 +235,53 @@ int  cl_stitch(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph
                const cl_stitch_params* params, cl_alignment* out);
 void cl_alignment_free(cl_alignment* a);
 
+/* --- Anchorer chaining DP (include/centrolign/anchorer.hpp:1812-2547) --------------------------------------------------
+ * The seam is sparse_affine_chain_dp itself: (graphs + embedded paths, match sets, gap parameters, local scale) in,
+ * the optimal chain out, as the reference's anchor_chain dispatch calls it (anchorer.hpp:1213-1307) with local
+ * anchoring (no sources/sinks) and no masked matches. */
+/* std::vector<match_set_t> (include/centrolign/match_finder.hpp:21-34), flattened.  Set s owns walks
+ * set_off1[s] .. set_off1[s+1]-1 of graph 1 (walk w = nodes1[walk_off1[w] .. walk_off1[w+1])), likewise for graph 2. */
+typedef struct cl_match_sets {
+    uint64_t        n_sets;
+    const uint64_t* set_off1;
+    const uint64_t* walk_off1;
+    const uint32_t* nodes1;
+    const uint64_t* set_off2;
+    const uint64_t* walk_off2;
+    const uint32_t* nodes2;
+    const uint64_t* count1;       /* match_set_t::count1 */
+    const uint64_t* count2;
+    const uint64_t* full_length;
+} cl_match_sets;
+
+/* Anchorer::gap_open / gap_extend (anchorer.hpp:152-175) and the ScoreFunction fields (score_function.hpp:27-45) */
+typedef struct cl_chain_params {
+    double gap_open[3];
+    double gap_extend[3];
+    int    anchor_score_function;   /* ScoreFunction::AnchorScore */
+    double pair_count_power;
+    double length_intercept;
+    double length_decay_power;
+} cl_chain_params;
+/* the values the CLI runs with (src/parameters.cpp:39-59) */
+void cl_chain_params_default(cl_chain_params* p);
+
+typedef struct cl_chain_result {
+    uint64_t  n_anchors;
+    uint32_t* anchors;     /* [3 * n_anchors]: anchor_t::match_set, idx1, idx2 in chain order */
+    uint64_t  n_pairs;     /* number of match pairs that took part */
+    float*    dp;          /* [n_pairs] final DP value of every pair in (set, idx1, idx2) order, or NULL */
+    uint64_t  n_ties;      /* traceback steps where several predecessors attained the maximum (resolved as the
+                              reference's search trees resolve them) */
+    float     device_ms;   /* HIP-event time of the DP kernels */
+} cl_chain_result;
+
+/* sparse_affine_chain_dp<..., float, ...> over the leading num_match_sets sets. */
+int  cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2,
+                            const cl_match_sets* matches, uint64_t num_match_sets, const cl_chain_params* params,
+                            double local_scale, int want_dp, cl_chain_result* out);
+void cl_chain_result_free(cl_chain_result* r);
+
 #ifdef __cplusplus
 }
 #endif

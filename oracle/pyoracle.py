@@ -31,54 +31,8 @@ def build_ref():
     subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
 
 
-class CloMatchSets(C.Structure):
-    _fields_ = [("n_sets", C.c_uint64)] + [(n, C.c_void_p) for n in
-                ("set_off1", "walk_off1", "nodes1", "set_off2", "walk_off2", "nodes2", "count1", "count2", "full_length")]
-
-
-class CloChainParams(C.Structure):
-    _fields_ = [("gap_open", C.c_double * 3), ("gap_extend", C.c_double * 3), ("anchor_score_function", C.c_int),
-                ("pair_count_power", C.c_double), ("length_intercept", C.c_double), ("length_decay_power", C.c_double)]
-
-
-def default_chain_params():
-    """the CLI's anchoring parameters (src/parameters.cpp:39-59)"""
-    p = CloChainParams()
-    p.gap_open[:] = [1.25, 50.0, 5000.0]
-    p.gap_extend[:] = [2.5, 0.1, 0.0015]
-    p.anchor_score_function = 2  # ConcaveLengthScaleInverseCount
-    p.pair_count_power = 0.5
-    p.length_intercept = 2250.0
-    p.length_decay_power = 2.0
-    return p
-
-
-class MatchSets:
-    """numpy holder for clo_match_sets (std::vector<match_set_t>)"""
-    _DT = dict(set_off1=np.uint64, walk_off1=np.uint64, nodes1=np.uint32, set_off2=np.uint64, walk_off2=np.uint64,
-               nodes2=np.uint32, count1=np.uint64, count2=np.uint64, full_length=np.uint64)
-
-    def __init__(self, **arrays):
-        for k, dt in self._DT.items():
-            setattr(self, k, np.ascontiguousarray(arrays[k], dtype=dt))
-
-    @property
-    def n_sets(self):
-        return len(self.count1)
-
-    def n_pairs(self):
-        return int((np.diff(self.set_off1.astype(np.int64)) * np.diff(self.set_off2.astype(np.int64))).sum())
-
-    def as_c(self):
-        c = CloMatchSets()
-        c.n_sets = self.n_sets
-        for k in self._DT:
-            setattr(c, k, getattr(self, k).ctypes.data)
-        return c
-
-    @staticmethod
-    def from_dump(d, prefix):
-        return MatchSets(**{k: d[prefix + "ms." + k] for k in MatchSets._DT})
+from centrolign_amd.capi import (MatchSetsC as CloMatchSets, ChainParams as CloChainParams, MatchSets,  # noqa: E402,F401
+                                 default_chain_params)
 
 
 _oracle = None
