@@ -8,7 +8,7 @@
 
 constexpr uint32_t kChainBlock = 1024;    // match pairs per sequential block (one workgroup in the intra kernel)
 constexpr uint32_t kChainTile = 4096;     // predecessor records per workgroup in the inter kernel
-constexpr uint32_t kChainMaxRecs = 32;    // records of one pair broadcast through LDS (more fall back to HBM)
+constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
 constexpr uint32_t kChainMaxCand = 16;    // tie candidates listed per query for the traceback
 
 struct ClChainParams {
@@ -42,6 +42,8 @@ struct ClChainDevice {
     const uint32_t* rec_off;    // [n_pairs + 1] records of each pair
     const uint32_t* rec_combo;
     const uint32_t* rec_pos;
+    const uint32_t* group;      // [n_pairs] depth window of the pair's first graph-1 node (non-decreasing); pairs of one
+                                // window cannot precede one another
     ClChainParams params;
 };
 

@@ -34,31 +34,37 @@ __device__ __forceinline__ int enc(float f) {  // order-preserving float -> int
 }
 __device__ __forceinline__ float dec(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-// accumulate one predecessor record into the 7 running maxima of a query
+// accumulate one predecessor record into the 7 running maxima of a query.  v[] holds the record's stored values
+// already in the order-preserving integer encoding; everything is branch-free selects + integer max.
 __device__ __forceinline__ void accumulate(int (&acc)[7], uint32_t qt, uint32_t qoff, int32_t q, uint32_t ins_t, uint32_t off,
-                                           int32_t sigma, const float (&v)[7]) {
-    if (ins_t <= qt && off < qoff) {
-        if (sigma == q) acc[0] = max(acc[0], enc(v[0]));
-        else if (sigma < q) {  // odd trees: d1 > d2, value = dp + scale*extend_k*shift (anchorer.hpp:2328-2331, 2394-2403)
-            acc[2] = max(acc[2], enc(v[2])); acc[4] = max(acc[4], enc(v[4])); acc[6] = max(acc[6], enc(v[6]));
-        } else {               // even trees (:2332-2335, 2404-2412)
-            acc[1] = max(acc[1], enc(v[1])); acc[3] = max(acc[3], enc(v[3])); acc[5] = max(acc[5], enc(v[5]));
-        }
+                                           int32_t sigma, const int (&v)[7]) {
+    const int none = INT32_MIN;
+    const bool ok = ins_t <= qt && off < qoff;
+    const bool eq = ok && sigma == q, lt = ok && sigma < q, gt = ok && sigma > q;
+    acc[0] = max(acc[0], eq ? v[0] : none);
+    // odd trees: shift < query (anchorer.hpp:2328-2331, 2394-2403); even trees: shift > query (:2332-2335, 2404-2412)
+    acc[2] = max(acc[2], lt ? v[2] : none); acc[4] = max(acc[4], lt ? v[4] : none); acc[6] = max(acc[6], lt ? v[6] : none);
+    acc[1] = max(acc[1], gt ? v[1] : none); acc[3] = max(acc[3], gt ? v[3] : none); acc[5] = max(acc[5], gt ? v[5] : none);
+}
+
+// the six gap penalties of a query, scale*(open_k +- extend_k*query) (anchorer.hpp:2400, 2409), evaluated in double
+__device__ __forceinline__ void query_penalties(double (&pen)[6], int32_t q, const ClChainParams& P) {
+#pragma unroll
+    for (int pw = 0; pw < 6; ++pw) {
+        const double go = P.gap_open[pw / 2], ge = P.gap_extend[pw / 2];
+        pen[pw] = (pw % 2 == 1) ? P.scale * (go + ge * (double)q) : P.scale * (go - ge * (double)q);
     }
 }
 
 // the reference's candidate values for one (chain1, chain2) combination and the running dp maximum
 // (anchorer.hpp:2379-2412; update_dp keeps the first strictly greater value, match_bank.hpp:177)
-__device__ __forceinline__ float apply_candidates(float best, const int (&acc)[7], float w, int32_t q, const ClChainParams& P) {
+__device__ __forceinline__ float apply_candidates(float best, const int (&acc)[7], float w, const double (&pen)[6]) {
     const int none = enc(CL_CHAIN_NEG);
     if (acc[0] != none) best = fmaxf(best, dec(acc[0]) + w);
 #pragma unroll
     for (int pw = 0; pw < 6; ++pw) {
         if (acc[1 + pw] == none) continue;
-        const float stored = dec(acc[1 + pw]);
-        const double go = P.gap_open[pw / 2], ge = P.gap_extend[pw / 2];
-        const double pen = (pw % 2 == 1) ? P.scale * (go + ge * (double)q) : P.scale * (go - ge * (double)q);
-        const float cand = (float)((double)(stored + w) - pen);
+        const float cand = (float)((double)(dec(acc[1 + pw]) + w) - pen[pw]);
         best = fmaxf(best, cand);
     }
     return best;
@@ -67,153 +73,203 @@ __device__ __forceinline__ float apply_candidates(float best, const int (&acc)[7
 }  // namespace
 
 // acc index layout: [0] gap-free, [1 + pw] tree pw (pw even: shift > query, pw odd: shift < query)
-__global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count) {
+// predecessors = the records of blocks [src_block_lo, src_block_hi)
+__global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
+                                                          uint32_t src_block_lo, uint32_t src_block_hi) {
     const ClChainCombo cb = D.combos[blockIdx.z];
-    const uint32_t n_prefix = cb.prefix[block_first / kChainBlock];
-    const uint32_t tile0 = blockIdx.x * kChainTile;
-    if (tile0 >= n_prefix) return;
-    const uint32_t tile_end = min(tile0 + kChainTile, n_prefix);
+    const uint32_t rec_lo = cb.prefix[src_block_lo], rec_hi = cb.prefix[src_block_hi];
+    const uint32_t tile0 = rec_lo + blockIdx.x * kChainTile;
+    if (tile0 >= rec_hi) return;
+    const uint32_t tile_end = min(tile0 + kChainTile, rec_hi);
     const uint32_t mi = blockIdx.y * 256 + threadIdx.x;
     const uint32_t s = block_first + mi;
     const bool active = mi < block_count;
-    uint32_t qt = 0xFFFFFFFFu, qoff = 0;
+    uint32_t qt = 0, qoff = 0;   // qoff == 0 can never be exceeded: an inactive lane accumulates nothing
     int32_t q = 0;
-    if (active) { qt = cb.qt[s]; qoff = cb.qoff[s]; q = cb.q[s]; }
-    const bool live = active && qt != 0xFFFFFFFFu;
+    if (active && cb.qt[s] != 0xFFFFFFFFu) { qt = cb.qt[s]; qoff = cb.qoff[s]; q = cb.q[s]; }
     int acc[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) acc[i] = enc(CL_CHAIN_NEG);
+    for (int i = 0; i < 7; ++i) acc[i] = INT32_MIN;
 
-    __shared__ uint32_t s_ins[256], s_off[256];
-    __shared__ int32_t s_sig[256];
-    __shared__ float s_val[7][256];
+    // one record = 10 dwords: ins_t, off, sigma, 7 encoded values; padded to 12 so that it is read as three b128
+    __shared__ __attribute__((aligned(16))) int s_rec[256][12];
     for (uint32_t base = tile0; base < tile_end; base += 256) {
         const uint32_t r = base + threadIdx.x;
         __syncthreads();
         if (r < tile_end) {
-            s_ins[threadIdx.x] = cb.ins_t[r];
-            s_off[threadIdx.x] = cb.off[r];
-            s_sig[threadIdx.x] = cb.sigma[r];
+            s_rec[threadIdx.x][0] = (int)cb.ins_t[r];
+            s_rec[threadIdx.x][1] = (int)cb.off[r];
+            s_rec[threadIdx.x][2] = cb.sigma[r];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) s_val[i][threadIdx.x] = cb.val[(size_t)i * cb.n_recs + r];
+            for (int i = 0; i < 7; ++i) s_rec[threadIdx.x][3 + i] = enc(cb.val[(size_t)i * cb.n_recs + r]);
         }
         __syncthreads();
         const uint32_t cnt = min(256u, tile_end - base);
-        if (live) {
-            for (uint32_t j = 0; j < cnt; ++j) {
-                float v[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) v[i] = s_val[i][j];
-                accumulate(acc, qt, qoff, q, s_ins[j], s_off[j], s_sig[j], v);
-            }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const int4 a = *reinterpret_cast<const int4*>(&s_rec[j][0]);
+            const int4 b = *reinterpret_cast<const int4*>(&s_rec[j][4]);
+            const int4 c = *reinterpret_cast<const int4*>(&s_rec[j][8]);
+            const int v[7] = {a.w, b.x, b.y, b.z, b.w, c.x, c.y};
+            accumulate(acc, qt, qoff, q, (uint32_t)a.x, (uint32_t)a.y, a.z, v);
         }
     }
-    if (live) {
+    if (qoff != 0) {
         int* dst = cb.acc + (size_t)s * 7;
 #pragma unroll
         for (int i = 0; i < 7; ++i)
-            if (acc[i] != enc(CL_CHAIN_NEG)) atomicMax(dst + i, acc[i]);
+            if (acc[i] > enc(CL_CHAIN_NEG)) atomicMax(dst + i, acc[i]);
     }
 }
 
-// one workgroup, kChainBlock threads: thread i owns sorted match pair block_first + i
+// one workgroup, kChainBlock threads: thread i owns sorted match pair block_first + i.  Pairs that start on the same
+// graph-1 node cannot precede one another (a predecessor must END before the start), so the block is walked group by
+// group: every pair of a group is finalised at once and the group's records are broadcast through LDS.
 __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count) {
     const uint32_t i = threadIdx.x;
     const uint32_t s = block_first + i;
     const bool active = i < block_count;
     const ClChainCombo* combos = D.combos;
-    // the first combination is kept in registers (the only one in a pairwise problem)
-    const ClChainCombo c0 = combos[0];
-    uint32_t qt0 = 0xFFFFFFFFu, qoff0 = 0;
+    const ClChainCombo c0 = combos[0];  // the first combination lives in registers (the only one in a pairwise problem)
+    uint32_t qt0 = 0, qoff0 = 0;
     int32_t q0 = 0;
     int acc0[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) acc0[k] = enc(CL_CHAIN_NEG);
+    float w = 0.f;
+    uint32_t r0 = 0, r1 = 0, my_combo = 0, my_pos = 0, my_ins = 0, my_off = 0, my_group = 0xFFFFFFFFu;
+    int32_t my_sig = 0;
+    bool has_q0 = false;
     if (active) {
-        qt0 = c0.qt[s]; qoff0 = c0.qoff[s]; q0 = c0.q[s];
+        has_q0 = c0.qt[s] != 0xFFFFFFFFu;
+        if (has_q0) { qt0 = c0.qt[s]; qoff0 = c0.qoff[s]; q0 = c0.q[s]; }
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc0[k] = c0.acc[(size_t)s * 7 + k];
+        w = D.weight[s];
+        my_group = D.group[s];
+        r0 = D.rec_off[s]; r1 = D.rec_off[s + 1];
+        if (r1 > r0) {
+            my_combo = D.rec_combo[r0]; my_pos = D.rec_pos[r0];
+            const ClChainCombo cc = combos[my_combo];
+            my_ins = cc.ins_t[my_pos]; my_off = cc.off[my_pos]; my_sig = cc.sigma[my_pos];
+        }
     }
-    __shared__ uint32_t s_n[2];
-    __shared__ uint32_t s_combo[2][kChainMaxRecs], s_ins[2][kChainMaxRecs], s_off[2][kChainMaxRecs];
-    __shared__ int32_t s_sig[2][kChainMaxRecs];
-    __shared__ float s_val[2][kChainMaxRecs][7];
-
-    for (uint32_t j = 0; j < block_count; ++j) {
-        const uint32_t slot = j & 1u;
-        if (i == j) {
-            // finalise pair j: dp = max(own weight, every candidate) — anchorer.hpp:2041, 2379-2412
-            const float w = D.weight[s];
-            float best = w;
-            best = apply_candidates(best, acc0, w, q0, D.params);
-            for (uint32_t c = 1; c < D.n_combos; ++c) {
-                const ClChainCombo cc = combos[c];
-                if (cc.qt[s] == 0xFFFFFFFFu) continue;
-                int a[7];
+    double pen0[6];
+    query_penalties(pen0, q0, D.params);
+    double my_t[3];  // scale * extend_k * shift of the pair's first record (anchorer.hpp:2330, 2334)
 #pragma unroll
-                for (int k = 0; k < 7; ++k) a[k] = cc.acc[(size_t)s * 7 + k];
-                best = apply_candidates(best, a, w, cc.q[s], D.params);
+    for (int k = 0; k < 3; ++k) my_t[k] = D.params.scale * D.params.gap_extend[k] * (double)my_sig;
+    const bool simple = D.n_combos == 1;
+    // LDS: the records published by the current group (first kChainLdsRecs of them; the rest are re-read from HBM)
+    __shared__ uint32_t s_count, s_next_group;
+    __shared__ __attribute__((aligned(16))) int s_rec[kChainLdsRecs][12];  // ins_t, off, sigma, 7 encoded values, combo, -
+
+    uint32_t group = D.group[block_first];
+    while (true) {
+        if (i == 0) { s_count = 0; s_next_group = 0xFFFFFFFFu; }
+        __syncthreads();
+        if (active && my_group == group) {
+            // finalise: dp = max(own weight, every candidate) — anchorer.hpp:2041, 2379-2412
+            float best = w;
+            if (has_q0) best = apply_candidates(best, acc0, w, pen0);
+            if (!simple) {
+                for (uint32_t c = 1; c < D.n_combos; ++c) {
+                    const ClChainCombo cc = combos[c];
+                    if (cc.qt[s] == 0xFFFFFFFFu) continue;
+                    int a[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) a[k] = cc.acc[(size_t)s * 7 + k];
+                    double pen[6];
+                    query_penalties(pen, cc.q[s], D.params);
+                    best = apply_candidates(best, a, w, pen);
+                }
             }
             D.dp[s] = best;
-            // publish its records: stored values of every tree it sits in (anchorer.hpp:2318-2342)
-            const uint32_t r0 = D.rec_off[s], r1 = D.rec_off[s + 1];
-            s_n[slot] = r1 - r0;
+            // publish the pair's records: the values stored in every tree it sits in (anchorer.hpp:2318-2342)
+            const uint32_t n = r1 - r0;
+            const uint32_t base = n ? atomicAdd(&s_count, n) : 0u;
             for (uint32_t r = r0; r < r1; ++r) {
-                const uint32_t c = D.rec_combo[r], pos = D.rec_pos[r];
-                const ClChainCombo cc = combos[c];
-                const int32_t sg = cc.sigma[pos];
+                uint32_t c = my_combo, pos = my_pos, ins = my_ins, off = my_off;
+                int32_t sg = my_sig;
+                if (r != r0) {
+                    c = D.rec_combo[r]; pos = D.rec_pos[r];
+                    const ClChainCombo cc = combos[c];
+                    ins = cc.ins_t[pos]; off = cc.off[pos]; sg = cc.sigma[pos];
+                }
                 float v[7];
                 v[0] = best;
 #pragma unroll
                 for (int pw = 0; pw < 6; ++pw) {
-                    const double t = D.params.scale * D.params.gap_extend[pw / 2] * (double)sg;
+                    const double t = r == r0 ? my_t[pw / 2] : D.params.scale * D.params.gap_extend[pw / 2] * (double)sg;
                     v[1 + pw] = (pw % 2 == 1) ? (float)((double)best + t) : (float)((double)best - t);
                 }
+                float* vout = (c == 0 ? c0.val : combos[c].val);
+                const uint32_t nrec = (c == 0 ? c0.n_recs : combos[c].n_recs);
 #pragma unroll
-                for (int k = 0; k < 7; ++k) cc.val[(size_t)k * cc.n_recs + pos] = v[k];
-                const uint32_t l = r - r0;
-                if (l < kChainMaxRecs) {
-                    s_combo[slot][l] = c; s_ins[slot][l] = cc.ins_t[pos]; s_off[slot][l] = cc.off[pos]; s_sig[slot][l] = sg;
+                for (int k = 0; k < 7; ++k) vout[(size_t)k * nrec + pos] = v[k];
+                const uint32_t l = base + (r - r0);
+                if (l < kChainLdsRecs) {
+                    s_rec[l][0] = (int)ins; s_rec[l][1] = (int)off; s_rec[l][2] = sg;
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) s_val[slot][l][k] = v[k];
+                    for (int k = 0; k < 7; ++k) s_rec[l][3 + k] = enc(v[k]);
+                    s_rec[l][10] = (int)c;
                 }
             }
+        } else if (active && my_group > group) {
+            atomicMin(&s_next_group, my_group);
         }
         __syncthreads();
-        if (active && i > j) {
-            const uint32_t n = s_n[slot];
-            for (uint32_t l = 0; l < n; ++l) {
-                uint32_t c, ins, off;
-                int32_t sg;
-                float v[7];
-                if (l < kChainMaxRecs) {
-                    c = s_combo[slot][l]; ins = s_ins[slot][l]; off = s_off[slot][l]; sg = s_sig[slot][l];
+        const uint32_t n = s_count, next_group = s_next_group;
+        if (active && my_group > group) {
+            if (n <= kChainLdsRecs) {
+                for (uint32_t l = 0; l < n; ++l) {
+                    const int4 a = *reinterpret_cast<const int4*>(&s_rec[l][0]);
+                    const int4 b = *reinterpret_cast<const int4*>(&s_rec[l][4]);
+                    const int4 cc4 = *reinterpret_cast<const int4*>(&s_rec[l][8]);
+                    const int v[7] = {a.w, b.x, b.y, b.z, b.w, cc4.x, cc4.y};
+                    const uint32_t c = (uint32_t)cc4.z;
+                    if (c == 0) {
+                        if (has_q0) accumulate(acc0, qt0, qoff0, q0, (uint32_t)a.x, (uint32_t)a.y, a.z, v);
+                    } else {
+                        const ClChainCombo cc = combos[c];
+                        const uint32_t qt = cc.qt[s];
+                        if (qt == 0xFFFFFFFFu) continue;
+                        int ac[7];
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) v[k] = s_val[slot][l][k];
-                } else {  // more records than the LDS slot holds: read them back from HBM (visible after the barrier)
-                    const uint32_t r = D.rec_off[block_first + j] + l;
-                    c = D.rec_combo[r];
-                    const uint32_t pos = D.rec_pos[r];
-                    const ClChainCombo cc = combos[c];
-                    ins = cc.ins_t[pos]; off = cc.off[pos]; sg = cc.sigma[pos];
+                        for (int k = 0; k < 7; ++k) ac[k] = cc.acc[(size_t)s * 7 + k];
+                        accumulate(ac, qt, cc.qoff[s], cc.q[s], (uint32_t)a.x, (uint32_t)a.y, a.z, v);
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) v[k] = cc.val[(size_t)k * cc.n_recs + pos];
+                        for (int k = 0; k < 7; ++k) cc.acc[(size_t)s * 7 + k] = ac[k];
+                    }
                 }
-                if (c == 0) {
-                    if (qt0 != 0xFFFFFFFFu) accumulate(acc0, qt0, qoff0, q0, ins, off, sg, v);
-                } else {
-                    const ClChainCombo cc = combos[c];
-                    const uint32_t qt = cc.qt[s];
-                    if (qt == 0xFFFFFFFFu) continue;
-                    int a[7];
+            } else {
+                // a very large group: walk its pairs' records in HBM (written above, visible after the barrier)
+                for (uint32_t sj = block_first; sj < block_first + block_count; ++sj) {
+                    if (D.group[sj] != group) continue;
+                    for (uint32_t r = D.rec_off[sj]; r < D.rec_off[sj + 1]; ++r) {
+                        const uint32_t c = D.rec_combo[r], pos = D.rec_pos[r];
+                        const ClChainCombo cc = combos[c];
+                        const uint32_t qt = cc.qt[s];
+                        if (qt == 0xFFFFFFFFu) continue;
+                        int v[7];
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) a[k] = cc.acc[(size_t)s * 7 + k];
-                    accumulate(a, qt, cc.qoff[s], cc.q[s], ins, off, sg, v);
+                        for (int k = 0; k < 7; ++k) v[k] = enc(cc.val[(size_t)k * cc.n_recs + pos]);
+                        if (c == 0) {
+                            accumulate(acc0, qt0, qoff0, q0, cc.ins_t[pos], cc.off[pos], cc.sigma[pos], v);
+                        } else {
+                            int ac[7];
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) cc.acc[(size_t)s * 7 + k] = a[k];
+                            for (int k = 0; k < 7; ++k) ac[k] = cc.acc[(size_t)s * 7 + k];
+                            accumulate(ac, qt, cc.qoff[s], cc.q[s], cc.ins_t[pos], cc.off[pos], cc.sigma[pos], v);
+#pragma unroll
+                            for (int k = 0; k < 7; ++k) cc.acc[(size_t)s * 7 + k] = ac[k];
+                        }
+                    }
                 }
             }
         }
+        if (next_group == 0xFFFFFFFFu) break;
+        group = next_group;
+        __syncthreads();
     }
     // keep the final maxima: the traceback needs the value every query returned
     if (active) {
@@ -239,18 +295,18 @@ __global__ void __launch_bounds__(256) chain_candidates_kernel(ClChainDevice D, 
         if (cb.rec_s[r] >= Q.s) break;  // records are sorted by pair: later pairs cannot precede
         const int32_t sg = cb.sigma[r];
         const bool kind_ok = Q.kind == 0 ? sg == q : ((Q.kind - 1) % 2 == 1 ? sg < q : sg > q);
-        if (kind_ok && cb.ins_t[r] <= qt && cb.off[r] < qoff && enc(val[r]) == target) {
+        if (kind_ok && qt != 0xFFFFFFFFu && cb.ins_t[r] <= qt && cb.off[r] < qoff && enc(val[r]) == target) {
             const uint32_t k = atomicAdd(cand_count + qi, 1u);
             if (k < kChainMaxCand) cand_list[(size_t)qi * kChainMaxCand + k] = r;
         }
     }
 }
 
-hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t max_prefix,
-                                 hipStream_t stream) {
-    if (max_prefix == 0) return hipSuccess;
-    dim3 grid((max_prefix + kChainTile - 1) / kChainTile, (block_count + 255) / 256, D.n_combos);
-    hipLaunchKernelGGL(chain_inter_kernel, grid, dim3(256), 0, stream, D, block_first, block_count);
+hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
+                                 uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream) {
+    if (max_recs == 0) return hipSuccess;
+    dim3 grid((max_recs + kChainTile - 1) / kChainTile, (block_count + 255) / 256, D.n_combos);
+    hipLaunchKernelGGL(chain_inter_kernel, grid, dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi);
     return hipGetLastError();
 }
 

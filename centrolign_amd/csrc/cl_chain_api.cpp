@@ -28,7 +28,8 @@
 #include "cl_internal.hpp"
 #include "stitch_host.hpp"
 
-hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t max_prefix, hipStream_t stream);
+hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
+                                 uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream);
 hipError_t cl_chain_launch_candidates(const ClChainDevice& D, const ClChainQuery* queries, uint32_t n_queries, uint32_t* cand_count,
                                       uint32_t* cand_list, hipStream_t stream);
@@ -230,10 +231,23 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
                 }
             }
     }
-    // sorted pair order: by topological position of the first graph-1 node (stable in slot order)
+    // Processing order: by the DEPTH (longest path from a source) of the pair's first graph-1 node, stable in slot order.
+    // A predecessor m of m' must end strictly before m' starts, so depth(b1(m')) >= depth(b1(m)) + len(m): pairs whose
+    // start depths fall into the same window of min_len consecutive depths can never precede one another and are
+    // finalised together on the device ("group").
+    std::vector<uint32_t> depth1(g1->n_nodes, 0);
+    for (uint32_t v : order1)
+        for (uint64_t e = g1->next_off[v]; e < g1->next_off[v + 1]; ++e)
+            depth1[g1->next_idx[e]] = std::max(depth1[g1->next_idx[e]], depth1[v] + 1);
+    uint64_t min_len = UINT64_MAX;
+    for (uint64_t s = 0; s < num_match_sets; ++s) {
+        const uint64_t w0 = ms->set_off1[s];
+        if (ms->set_off1[s + 1] > w0 && ms->set_off2[s + 1] > ms->set_off2[s]) min_len = std::min<uint64_t>(min_len, ms->walk_off1[w0 + 1] - ms->walk_off1[w0]);
+    }
+    if (min_len == 0 || min_len == UINT64_MAX) min_len = 1;
     std::vector<uint32_t> by_s(M);  // sorted index -> slot
     std::iota(by_s.begin(), by_s.end(), 0u);
-    std::stable_sort(by_s.begin(), by_s.end(), [&](uint32_t a, uint32_t b) { return pos1[pairs[a].b1] < pos1[pairs[b].b1]; });
+    std::stable_sort(by_s.begin(), by_s.end(), [&](uint32_t a, uint32_t b) { return depth1[pairs[a].b1] < depth1[pairs[b].b1]; });
     std::vector<uint32_t> s_of_slot(M);
     for (uint32_t s = 0; s < M; ++s) s_of_slot[by_s[s]] = s;
 
@@ -309,12 +323,12 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     int rc = CL_OK;
     DevBuf<ClChainCombo> d_combos;
     DevBuf<float> d_weight, d_dp;
-    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos;
+    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group;
     std::vector<ClChainCombo> hc(combos.size());
     std::vector<int> acc_init(M * 7, enc(CL_CHAIN_NEG));
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
-        d_combos.release(); d_weight.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release();
+        d_combos.release(); d_weight.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release();
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
@@ -331,6 +345,11 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     CH(d_weight.upload(ctx, weight));
     CH(d_dp.alloc(ctx, M));
     CH(d_rec_off.upload(ctx, rec_off)); CH(d_rec_combo.upload(ctx, rec_combo)); CH(d_rec_pos.upload(ctx, rec_pos));
+    {
+        std::vector<uint32_t> group(M);
+        for (uint32_t s = 0; s < M; ++s) group[s] = (uint32_t)(depth1[pairs[by_s[s]].b1] / min_len);
+        CH(d_group.upload(ctx, group));
+    }
     ClChainDevice D{};
     D.n_pairs = (uint32_t)M;
     D.n_combos = (uint32_t)combos.size();
@@ -340,6 +359,7 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     D.rec_off = d_rec_off.p;
     D.rec_combo = d_rec_combo.p;
     D.rec_pos = d_rec_pos.p;
+    D.group = d_group.p;
     for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
     D.params.scale = local_scale;
 
@@ -351,17 +371,44 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
         cleanup();
         return e == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;
     };
+    // Two streams: the sequential part of block k (chain_intra_kernel, one workgroup) runs on the context's stream while
+    // the bulk of block k+1's predecessors — every block up to k-1, already final — is evaluated on an auxiliary stream;
+    // only the records of block k itself have to wait for intra(k).
+    std::vector<hipEvent_t> ev_intra(n_blocks, nullptr), ev_far(n_blocks, nullptr);
     hipError_t he = hipEventRecord(ev0, ctx->stream);
+    if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0);
+    auto max_recs = [&](uint32_t lo, uint32_t hi) {
+        uint32_t m = 0;
+        for (const Combo& c : combos) m = std::max(m, c.prefix[hi] - c.prefix[lo]);
+        return m;
+    };
     for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {
         const uint32_t first = b * kChainBlock, count = (uint32_t)std::min<uint64_t>(kChainBlock, M - first);
-        uint32_t max_prefix = 0;
-        for (const Combo& c : combos) max_prefix = std::max(max_prefix, c.prefix[b]);
-        he = cl_chain_launch_inter(D, first, count, max_prefix, ctx->stream);
+        if (b >= 2) {
+            // far predecessors: blocks [0, b-1), final once intra(b-2) is done
+            he = hipStreamWaitEvent(ctx->aux[0], ev_intra[b - 2], 0);
+            if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, b - 1, max_recs(0, b - 1), ctx->aux[0]);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventRecord(ev_far[b], ctx->aux[0]);
+            if (he == hipSuccess) he = hipStreamWaitEvent(ctx->stream, ev_far[b], 0);
+        }
+        // near predecessors: block b-1 (on the main stream, right after intra(b-1))
+        if (he == hipSuccess && b >= 1) he = cl_chain_launch_inter(D, first, count, b - 1, b, max_recs(b - 1, b), ctx->stream);
         if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, ctx->stream);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_intra[b], hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventRecord(ev_intra[b], ctx->stream);
     }
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-    if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->aux[0]);
+    if (he != hipSuccess) {
+        for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
+        return hip_fail(he, "chaining DP kernels");
+    }
+    for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     (void)hipEventElapsedTime(&out->device_ms, ev0, ev1);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
