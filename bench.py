@@ -53,6 +53,39 @@ def cpu_baseline(batch, min_seconds=10.0, max_reps=12):
                       "time inside Stitcher::subalign only" % (cells, reps, total)}
 
 
+def chaining_section(ctx, with_reference):
+    """second half of the hot path: sparse_affine_chain_dp on the match pairs of the same 2 x 1 Mbp pair
+    (bench_data/c2_chain_input.npz: the reference's graphs and budget-selected match sets; built by
+    scripts/chain_bench.py's recipe in the build container, shipped with the repo snapshot, not committed)"""
+    path = os.path.join(HERE, "bench_data", "c2_chain_input.npz")
+    if not os.path.exists(path):
+        return None
+    from centrolign_amd import capi
+    z = np.load(path)
+    graphs = []
+    for side in ("parent1.", "parent2."):
+        t = z[side + "tableau"]
+        graphs.append(capi.BaseGraph(*[z[side + k] for k in ("label", "next_off", "next_idx", "prev_off", "prev_idx", "path_off", "path_nodes")], t[0], t[1]))
+    ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
+    scale = float(z["score_scale"][0])
+    ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale)  # warm-up
+    t0 = time.perf_counter()
+    got = ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale)
+    wall = time.perf_counter() - t0
+    n = got["n_pairs"]
+    out = {"match_pairs": n, "chain_anchors": int(len(got["chain"])), "tie_resolutions": got["n_ties"],
+           "wall_s": wall, "device_dp_ms": got["device_ms"], "host_prep_ms": got["prep_ms"],
+           "value_index_ms": got["index_ms"], "traceback_ms": got["traceback_ms"],
+           "match_pairs_per_s": n / wall, "pair_evaluations_per_s_device": n * n / 2 / (got["device_ms"] * 1e-3)}
+    if with_reference:
+        from oracle import pyoracle as po
+        if po.have_ref():
+            ref, secs = po.ref_chain("affine", graphs[0], graphs[1], ms, scale=scale)
+            out["cpu_reference"] = {"seconds": secs, "match_pairs_per_s": n / secs, "cores": 1, "kind": "reference",
+                                    "identical_chain": bool(np.array_equal(ref, got["chain"]))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +180,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch)
+        if world == 1:
+            ch = chaining_section(ctx, not args.no_cpu_baseline)
+            if ch is not None:
+                out["chaining"] = ch
         print(json.dumps(out))
     barrier()
     plan.destroy()

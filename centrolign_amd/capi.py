@@ -201,7 +201,8 @@ class ChainParams(C.Structure):
 
 class ChainResultC(C.Structure):
     _fields_ = [("n_anchors", C.c_uint64), ("anchors", C.POINTER(C.c_uint32)), ("n_pairs", C.c_uint64),
-                ("dp", C.POINTER(C.c_float)), ("n_ties", C.c_uint64), ("device_ms", C.c_float)]
+                ("dp", C.POINTER(C.c_float)), ("n_ties", C.c_uint64), ("device_ms", C.c_float),
+                ("prep_ms", C.c_float), ("index_ms", C.c_float), ("traceback_ms", C.c_float)]
 
 
 def default_chain_params():
@@ -637,7 +638,8 @@ class Context:
             na, npairs = int(out.n_anchors), int(out.n_pairs)
             chain = np.ctypeslib.as_array(out.anchors, shape=(max(na, 1) * 3,))[:3 * na].copy().reshape(na, 3)
             dp = np.ctypeslib.as_array(out.dp, shape=(max(npairs, 1),))[:npairs].copy() if want_dp and npairs else None
-            return dict(chain=chain, dp=dp, n_ties=int(out.n_ties), device_ms=float(out.device_ms), n_pairs=npairs)
+            return dict(chain=chain, dp=dp, n_ties=int(out.n_ties), device_ms=float(out.device_ms), n_pairs=npairs,
+                        prep_ms=float(out.prep_ms), index_ms=float(out.index_ms), traceback_ms=float(out.traceback_ms))
         finally:
             self.lib.cl_chain_result_free(C.byref(out))
 

@@ -17,11 +17,13 @@
 //     earliest inserted (strict '>' in MaxSearchTree::update, max_search_tree.hpp:318-358).  pick_ortho / pick_gap_free
 //     evaluate that rule directly on the sorted keys; they only run when a maximum is attained more than once.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <unordered_map>
 #include <vector>
 
 #include "chain_device.h"
@@ -31,6 +33,8 @@
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
                                  uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream);
+hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
+                                void* temp, size_t* temp_bytes, hipStream_t stream);
 hipError_t cl_chain_launch_candidates(const ClChainDevice& D, const ClChainQuery* queries, uint32_t n_queries, uint32_t* cand_count,
                                       uint32_t* cand_list, hipStream_t stream);
 
@@ -148,6 +152,7 @@ struct Combo {
     // lazily built for tie resolution
     std::vector<uint32_t> ortho_order;  // record indices sorted by (sigma, slot)
     std::vector<uint32_t> ortho_heap, ortho_rank_of_heap;
+    std::unordered_map<int32_t, std::vector<uint32_t>> by_diag;  // gap-free trees: records of each shift
     void release() {
         d_rec_s.release(); d_ins_t.release(); d_off.release(); d_prefix.release(); d_qt.release(); d_qoff.release();
         d_sigma.release(); d_q.release(); d_val.release(); d_acc.release();
@@ -182,6 +187,8 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     memset(out, 0, sizeof(*out));
     if (num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto T0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 
     clhost::PathMergeTable x1, x2;
     if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
@@ -363,6 +370,7 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
     D.params.scale = local_scale;
 
+    out->prep_ms = ms_since(T0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipEventCreate failed"); return CL_ERR_HIP; }
     auto hip_fail = [&](hipError_t e, const char* what) {
@@ -429,10 +437,37 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
         const float v = dp_sorted[s_of_slot[slot]] + 0.0f;
         if (v > opt && v > 0.0f) { opt = v; best_slot = slot; }
     }
-    DevBuf<ClChainQuery> d_query;
-    DevBuf<uint32_t> d_count, d_list;
-    CH(d_query.alloc(ctx, 1)); CH(d_count.alloc(ctx, 1)); CH(d_list.alloc(ctx, kChainMaxCand));
-    auto cleanup2 = [&]() { d_query.release(); d_count.release(); d_list.release(); cleanup(); };
+    const auto T1 = std::chrono::steady_clock::now();
+    // value index: per combination and tree kind, (encoded stored value, record) sorted by value
+    std::vector<std::vector<std::vector<int>>> vkeys(combos.size(), std::vector<std::vector<int>>(7));
+    std::vector<std::vector<std::vector<uint32_t>>> vrecs(combos.size(), std::vector<std::vector<uint32_t>>(7));
+    {
+        uint32_t nmax = 0;
+        for (const Combo& c : combos) nmax = std::max<uint32_t>(nmax, (uint32_t)c.rec_s.size());
+        DevBuf<int> k_in, k_out;
+        DevBuf<uint32_t> i_in, i_out;
+        DevBuf<char> temp;
+        CH(k_in.alloc(ctx, nmax)); CH(k_out.alloc(ctx, nmax)); CH(i_in.alloc(ctx, nmax)); CH(i_out.alloc(ctx, nmax));
+        size_t temp_bytes = 0;
+        he = cl_chain_sort_values(nullptr, nmax, k_in.p, i_in.p, k_out.p, i_out.p, nullptr, &temp_bytes, ctx->stream);
+        if (he == hipSuccess) { rc = temp.alloc(ctx, temp_bytes); if (rc) he = hipErrorOutOfMemory; }
+        for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
+            const uint32_t n = (uint32_t)combos[ci].rec_s.size();
+            for (int kind = 0; kind < 7 && he == hipSuccess; ++kind) {
+                he = cl_chain_sort_values(combos[ci].d_val.p + (size_t)kind * n, n, k_in.p, i_in.p, k_out.p, i_out.p, temp.p, &temp_bytes, ctx->stream);
+                vkeys[ci][kind].resize(n);
+                vrecs[ci][kind].resize(n);
+                if (he == hipSuccess && n) he = hipMemcpyAsync(vkeys[ci][kind].data(), k_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (he == hipSuccess && n) he = hipMemcpyAsync(vrecs[ci][kind].data(), i_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+            }
+        }
+        k_in.release(); k_out.release(); i_in.release(); i_out.release(); temp.release();
+        if (he != hipSuccess) { cl_set_error(ctx, "value index failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
+    }
+    auto cleanup2 = [&]() { cleanup(); };
+    out->index_ms = ms_since(T1);
+    const auto T2 = std::chrono::steady_clock::now();
     std::vector<float> val_host;  // lazily downloaded stored values of one combo (ties only)
     std::vector<uint32_t> chain_slots;
     uint64_t n_ties = 0;
@@ -476,31 +511,37 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
             }
         if (win_combo < 0) { cl_set_error(ctx, "traceback: no candidate reproduces dp of pair %u", here); cleanup2(); return CL_ERR_HIP; }
         Combo& c = combos[win_combo];
-        ClChainQuery qh{s, (uint32_t)win_combo, (uint32_t)win_kind};
-        uint32_t zero = 0, count = 0;
-        std::vector<uint32_t> cand(kChainMaxCand);
-        he = hipMemcpyAsync(d_query.p, &qh, sizeof(qh), hipMemcpyHostToDevice, ctx->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(d_count.p, &zero, 4, hipMemcpyHostToDevice, ctx->stream);
-        if (he == hipSuccess) he = cl_chain_launch_candidates(D, d_query.p, 1, d_count.p, d_list.p, ctx->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(&count, d_count.p, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(cand.data(), d_list.p, kChainMaxCand * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-        if (he != hipSuccess) { cl_set_error(ctx, "candidate kernel failed: %s", hipGetErrorString(he)); cleanup2(); return CL_ERR_HIP; }
+        // every predecessor whose stored value equals the query's maximum and which lies in the query's range
+        std::vector<uint32_t> cand;
+        {
+            const int target = acc[win_combo][(size_t)s * 7 + win_kind];
+            const auto& keys = vkeys[win_combo][win_kind];
+            const auto& recs = vrecs[win_combo][win_kind];
+            const uint32_t qt = c.qt[s], qoff = c.qoff[s];
+            const int32_t qq = c.q[s];
+            for (size_t k = std::lower_bound(keys.begin(), keys.end(), target) - keys.begin(); k < keys.size() && keys[k] == target; ++k) {
+                const uint32_t r = recs[k];
+                if (c.rec_s[r] >= s) continue;
+                const int32_t sg = c.sigma[r];
+                const bool kind_ok = win_kind == 0 ? sg == qq : ((win_kind - 1) % 2 == 1 ? sg < qq : sg > qq);
+                if (kind_ok && c.ins_t[r] <= qt && c.off[r] < qoff) cand.push_back(r);
+            }
+        }
+        const uint32_t count = (uint32_t)cand.size();
         if (count == 0) { cl_set_error(ctx, "traceback: query of pair %u has no predecessor at its maximum", here); cleanup2(); return CL_ERR_HIP; }
         uint32_t win_rec;
         if (count == 1) {
             win_rec = cand[0];
         } else {
             ++n_ties;
-            if (count > kChainMaxCand) { cl_set_error(ctx, "traceback: more than %u tied predecessors", kChainMaxCand); cleanup2(); return CL_ERR_UNSUPPORTED_ROUTE; }
-            cand.resize(count);
             auto slot_of_rec = [&](uint32_t r) { return by_s[c.rec_s[r]]; };
             if (win_kind == 0) {
                 // gap-free tree of this diagonal: records with the same shift, keyed (offset, match id);
                 // inside an off-path subtree the earliest inserted wins, insertion order = (position of e1, slot)
                 const int32_t diag = c.q[s];
-                std::vector<uint32_t> members;
-                for (uint32_t r = 0; r < c.rec_s.size(); ++r) if (c.sigma[r] == diag) members.push_back(r);
+                if (c.by_diag.empty())  // records bucketed by shift, built once
+                    for (uint32_t r = 0; r < c.rec_s.size(); ++r) c.by_diag[c.sigma[r]].push_back(r);
+                std::vector<uint32_t> members = c.by_diag[diag];
                 std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) {
                     return c.off[a] != c.off[b] ? c.off[a] < c.off[b] : slot_of_rec(a) < slot_of_rec(b);
                 });
@@ -572,6 +613,7 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
         if (chain_slots.size() > M) { cl_set_error(ctx, "traceback loop"); cleanup2(); return CL_ERR_HIP; }
     }
     std::reverse(chain_slots.begin(), chain_slots.end());
+    out->traceback_ms = ms_since(T2);
 
     out->n_anchors = chain_slots.size();
     out->n_ties = n_ties;

@@ -274,6 +274,9 @@ typedef struct cl_chain_result {
     uint64_t  n_ties;      /* traceback steps where several predecessors attained the maximum (resolved as the
                               reference's search trees resolve them) */
     float     device_ms;   /* HIP-event time of the DP kernels */
+    float     prep_ms;     /* host: coordinates, ordering, packing, upload */
+    float     index_ms;    /* value index (device sort + download) */
+    float     traceback_ms;/* host: optimum + traceback with tie resolution */
 } cl_chain_result;
 
 /* sparse_affine_chain_dp<..., float, ...> over the leading num_match_sets sets. */
