@@ -6,8 +6,8 @@
 
 #define CL_CHAIN_NEG (-3.402823466e+38f)  // numeric_limits<float>::lowest(), the reference's mininf (anchorer.hpp:1868)
 
-constexpr uint32_t kChainBlock = 1024;    // match pairs per sequential block (one workgroup in the intra kernel)
-constexpr uint32_t kChainTile = 4096;     // predecessor records per workgroup in the inter kernel
+constexpr uint32_t kChainBlock = 256;     // match pairs per sequential block (one workgroup in the intra kernel)
+constexpr uint32_t kChainTile = 1024;     // predecessor records per workgroup in the inter kernel
 constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
 constexpr uint32_t kChainMaxCand = 16;    // tie candidates listed per query for the traceback
 
