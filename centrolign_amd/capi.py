@@ -511,6 +511,9 @@ def load_library(path=None):
     lib.cl_chain_sparse_affine.restype = C.c_int
     lib.cl_chain_sparse_affine.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
                                            C.POINTER(ChainParams), C.c_double, C.c_int, C.POINTER(ChainResultC)]
+    lib.cl_chain_sparse.restype = C.c_int
+    lib.cl_chain_sparse.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
+                                    C.POINTER(ChainParams), C.c_int, C.POINTER(ChainResultC)]
     lib.cl_chain_result_free.argtypes = [C.POINTER(ChainResultC)]
     if path is None:
         _lib = lib
@@ -524,7 +527,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
-    "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_result_free",
+    "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
 ]
 
 
@@ -626,14 +629,20 @@ class Context:
         finally:
             self.lib.cl_alignment_free(C.byref(out))
 
-    def chain_sparse_affine(self, graph1, graph2, matches, scale=1.0, params=None, num_match_sets=None, want_dp=False):
-        """sparse_affine_chain_dp (include/centrolign/anchorer.hpp:1812-2471) on the GPU.
+    def chain_sparse_affine(self, graph1, graph2, matches, scale=1.0, params=None, num_match_sets=None, want_dp=False,
+                            sparse=False):
+        """sparse_affine_chain_dp (include/centrolign/anchorer.hpp:1812-2471), or with sparse=True sparse_chain_dp
+        (:1511-1750), on the GPU.
         Returns dict(chain=(n,3) uint32 [match_set, idx1, idx2], dp=float32[n_pairs] or None, n_ties, device_ms)"""
         params = params or default_chain_params()
         g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), ChainResultC()
         n = matches.n_sets if num_match_sets is None else num_match_sets
-        self._check(self.lib.cl_chain_sparse_affine(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), n, C.byref(params),
-                                                    float(scale), int(want_dp), C.byref(out)))
+        if sparse:
+            self._check(self.lib.cl_chain_sparse(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), n, C.byref(params),
+                                                 int(want_dp), C.byref(out)))
+        else:
+            self._check(self.lib.cl_chain_sparse_affine(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), n, C.byref(params),
+                                                        float(scale), int(want_dp), C.byref(out)))
         try:
             na, npairs = int(out.n_anchors), int(out.n_pairs)
             chain = np.ctypeslib.as_array(out.anchors, shape=(max(na, 1) * 3,))[:3 * na].copy().reshape(na, 3)

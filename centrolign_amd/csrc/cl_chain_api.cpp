@@ -180,9 +180,14 @@ void cl_chain_result_free(cl_chain_result* r) {
     memset(r, 0, sizeof(*r));
 }
 
-int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
-                           uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp,
-                           cl_chain_result* out) {
+}  // extern "C"
+
+// sparse == false: sparse_affine_chain_dp (anchorer.hpp:1812-2471); sparse == true: sparse_chain_dp (:1511-1750), which is the
+// same sweep with ONE tree per (chain of e1, chain of e2), no shift condition and no gap cost: on the device it is the
+// affine machinery with every shift set to 0, so that only the "same diagonal" maximum is ever fed.
+static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                         uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp, bool sparse,
+                         cl_chain_result* out) {
     if (!ctx || !g1 || !g2 || !ms || !cp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     if (num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
@@ -272,8 +277,16 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     std::vector<uint32_t> rec_off(M + 1, 0), rec_combo, rec_pos;
     for (uint32_t s = 0; s < M; ++s) {
         const Pair& p = pairs[by_s[s]];
+        bool first1 = true;
         x1.for_each_chain_on(p.e1, [&](uint32_t p1) {
+            const bool take1 = !sparse || first1;   // sparse_chain_dp files a match under chain(e1) only (anchorer.hpp:1621-1630)
+            first1 = false;
+            if (!take1) return;
+            bool first2 = true;
             x2.for_each_chain_on(p.e2, [&](uint32_t p2) {
+                const bool take2 = !sparse || first2;
+                first2 = false;
+                if (!take2) return;
                 auto key = std::make_pair(p1, p2);
                 auto it = combo_id.find(key);
                 if (it == combo_id.end()) {
@@ -288,7 +301,7 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
                 c.rec_s.push_back(s);
                 c.ins_t.push_back(x1.index_on(p.e1, p1));
                 c.off.push_back(x2.index_on(p.e2, p2));
-                c.sigma.push_back((int32_t)(x1.index_on(p.e1, p1) - x2.index_on(p.e2, p2)));
+                c.sigma.push_back(sparse ? 0 : (int32_t)(x1.index_on(p.e1, p1) - x2.index_on(p.e2, p2)));
             });
         });
         rec_off[s + 1] = (uint32_t)rec_combo.size();
@@ -315,7 +328,7 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
             if (pr == kNone || !has_start[p.b1] || !after_end[x1.node_at(c.p1, pr)]) continue;
             c.qt[s] = pr;
             c.qoff[s] = x2.predecessor_index(p.b2, c.p2) + 1u;
-            c.q[s] = (int32_t)(pr - x2.predecessor_index(p.b2, c.p2) + sw1.distance(p.b1, c.p1) - sw2.distance(p.b2, c.p2));
+            c.q[s] = sparse ? 0 : (int32_t)(pr - x2.predecessor_index(p.b2, c.p2) + sw1.distance(p.b1, c.p1) - sw2.distance(p.b2, c.p2));
         }
         c.prefix.assign(n_blocks + 1, 0);
         size_t r = 0;
@@ -495,7 +508,7 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
                 if (it == combo_id.end()) continue;  // empty trees
                 const Combo& c = combos[it->second];
                 const int* a = &acc[it->second][(size_t)s * 7];
-                for (int kind = 0; kind < 7; ++kind) {
+                for (int kind = 0; kind < (sparse ? 1 : 7); ++kind) {
                     if (a[kind] == enc(CL_CHAIN_NEG)) continue;
                     const float stored = dec(a[kind]);
                     float cand;
@@ -538,19 +551,31 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
             if (win_kind == 0) {
                 // gap-free tree of this diagonal: records with the same shift, keyed (offset, match id);
                 // inside an off-path subtree the earliest inserted wins, insertion order = (position of e1, slot)
-                const int32_t diag = c.q[s];
-                if (c.by_diag.empty())  // records bucketed by shift, built once
-                    for (uint32_t r = 0; r < c.rec_s.size(); ++r) c.by_diag[c.sigma[r]].push_back(r);
-                std::vector<uint32_t> members = c.by_diag[diag];
-                std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) {
-                    return c.off[a] != c.off[b] ? c.off[a] < c.off[b] : slot_of_rec(a) < slot_of_rec(b);
-                });
+                // members of the tree, as (offset, slot, record-or-none): affine mode -> the records of this combination with
+                // the query's shift; sparse mode -> every pair whose e2 is filed under chain2, whatever its chain1
+                // (search_trees[i][j] is built from search_tree_data[j] for every i, anchorer.hpp:1581-1592)
+                struct Member { uint32_t off, slot, rec; };
+                std::vector<Member> mem;
+                if (!sparse) {
+                    const int32_t diag = c.q[s];
+                    if (c.by_diag.empty())  // records bucketed by shift, built once
+                        for (uint32_t r = 0; r < c.rec_s.size(); ++r) c.by_diag[c.sigma[r]].push_back(r);
+                    for (uint32_t r : c.by_diag[diag]) mem.push_back(Member{c.off[r], slot_of_rec(r), r});
+                } else {
+                    for (const Combo& oc : combos)
+                        if (oc.p2 == c.p2)
+                            for (uint32_t r = 0; r < oc.rec_s.size(); ++r) mem.push_back(Member{oc.off[r], by_s[oc.rec_s[r]], &oc == &c ? r : kNone});
+                }
+                std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; });
+                std::vector<uint32_t> members(mem.size());
+                for (size_t k = 0; k < mem.size(); ++k) members[k] = mem[k].rec;
+                auto off_of_member = [&](size_t k) { return mem[k].off; };
                 const size_t n = members.size();
                 auto h = heap_of_rank(n);
                 std::vector<uint32_t> rank_of_heap(n);
                 for (size_t r = 0; r < n; ++r) rank_of_heap[h[r]] = (uint32_t)r;
                 size_t rhi = 0;
-                while (rhi < n && c.off[members[rhi]] < c.qoff[s]) ++rhi;
+                while (rhi < n && off_of_member(rhi) < c.qoff[s]) ++rhi;
                 std::vector<std::pair<size_t, uint32_t>> ch;  // (heap node, record)
                 for (uint32_t r : cand) {
                     const size_t rk = std::find(members.begin(), members.end(), r) - members.begin();
@@ -631,6 +656,19 @@ int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     cleanup2();
     return CL_OK;
 #undef CH
+}
+
+extern "C" {
+
+int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                           uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp,
+                           cl_chain_result* out) {
+    return chain_dp_impl(ctx, g1, g2, ms, num_match_sets, cp, local_scale, want_dp, false, out);
+}
+
+int cl_chain_sparse(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                    uint64_t num_match_sets, const cl_chain_params* cp, int want_dp, cl_chain_result* out) {
+    return chain_dp_impl(ctx, g1, g2, ms, num_match_sets, cp, 1.0, want_dp, true, out);
 }
 
 }  // extern "C"

@@ -283,6 +283,10 @@ typedef struct cl_chain_result {
 int  cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2,
                             const cl_match_sets* matches, uint64_t num_match_sets, const cl_chain_params* params,
                             double local_scale, int want_dp, cl_chain_result* out);
+/* sparse_chain_dp<..., float, ...> (anchorer.hpp:1511-1750): the chaining without gap costs that
+ * Anchorer::estimate_score_scale (anchorer.hpp:998-1047) and the leaf calibration (src/core.cpp:122-175) run. */
+int  cl_chain_sparse(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+                     uint64_t num_match_sets, const cl_chain_params* params, int want_dp, cl_chain_result* out);
 void cl_chain_result_free(cl_chain_result* r);
 
 #ifdef __cplusplus

@@ -40,3 +40,17 @@ def test_chain_vs_oracle_other_subsets(gpu_ctx, seed, budget, scale):
     want_chain, want_dp = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=scale, want_dp=True)
     assert np.array_equal(got["dp"].view(np.uint32), want_dp[:len(got["dp"])].view(np.uint32))
     assert np.array_equal(got["chain"], want_chain)
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_sparse_chain_matches_reference_golden(gpu_ctx, name):
+    """sparse_chain_dp (the gap-free chaining of estimate_score_scale / leaf calibration) on the GPU"""
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
+    for tag in ("a", "b"):
+        ms = capi.MatchSets(**{k: z["%s.ms.%s" % (tag, k)] for k in capi.MatchSets._DT})
+        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, want_dp=True, sparse=True)
+        want_chain, want_dp = po.oracle_chain("sparse", graphs[0], graphs[1], ms, want_dp=True)
+        assert np.array_equal(got["dp"].view(np.uint32), want_dp[:len(got["dp"])].view(np.uint32)), "DP values differ"
+        assert np.array_equal(got["chain"], z[tag + ".chain_sparse"])
+        assert np.array_equal(got["chain"], want_chain)
