@@ -94,16 +94,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from centrolign_amd import dist as cd
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, dist = cd.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -138,10 +132,7 @@ def main():
         for li in plan.launches():
             e = launch_ms.setdefault(li["kernel"], dict(li, ms=0.0))
             e["ms"] += li["ms"]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = cd.max_over_ranks(elapsed, dist, device="cuda")
 
     if rank == 0:
         cells = stats["dp_cells"]

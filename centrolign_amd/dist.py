@@ -1,0 +1,79 @@
+"""Multi-GPU plumbing for the stitch path: one process per GPU (torch.distributed, RCCL on GPUs, gloo in CPU tests).
+
+The path shards by subproblem with no data exchange, so the only collectives are the barrier that
+brackets a timed region, a MAX over ranks of the elapsed time, and — for callers that split ONE batch over ranks —
+a gather of the per-rank results on rank 0.
+"""
+import os
+
+import numpy as np
+
+
+def init_distributed(backend=None):
+    """returns (rank, world, dist or None); reads RANK / WORLD_SIZE / MASTER_* from the environment"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return rank, world, dist
+
+
+def max_over_ranks(value, dist, device="cpu"):
+    if dist is None:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_problems(batch, world):
+    """Longest-processing-time assignment of the subproblems of ONE batch to `world` ranks by DP cells
+    ((n1+1)(n2+1)); returns a list of index arrays, each in ascending problem order."""
+    n1, n2 = batch.sizes()
+    cells = (n1 + 1) * (n2 + 1)
+    order = np.argsort(-cells, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    bins = [[] for _ in range(world)]
+    for k in order:
+        r = int(np.argmin(load))
+        bins[r].append(int(k))
+        load[r] += int(cells[k])
+    return [np.array(sorted(b), dtype=np.int64) for b in bins]
+
+
+def gather_results(result, idx, n_problems, dist, rank):
+    """rank 0 receives every rank's (problem indices, StitchResult) and reassembles the batch-order result"""
+    from .capi import StitchResult
+    payload = (idx, result.aln_off, result.pairs, result.score, result.route, result.num_pw)
+    if dist is None:
+        parts = [payload]
+    else:
+        parts = [None] * dist.get_world_size() if rank == 0 else None
+        dist.gather_object(payload, parts, dst=0)
+        if rank != 0:
+            return None
+    lens = np.zeros(n_problems, dtype=np.int64)
+    for pidx, aln_off, _, _, _, _ in parts:
+        lens[pidx] = np.diff(aln_off.astype(np.int64))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    pairs = np.zeros((int(off[-1]), 2), dtype=np.uint64)
+    score = np.zeros(n_problems, np.int64)
+    route = np.zeros(n_problems, np.uint8)
+    num_pw = np.zeros(n_problems, np.uint8)
+    for pidx, aln_off, p, sc, ro, pw in parts:
+        for j, k in enumerate(pidx):
+            pairs[int(off[k]):int(off[k + 1])] = p[int(aln_off[j]):int(aln_off[j + 1])]
+        score[pidx], route[pidx], num_pw[pidx] = sc, ro, pw
+    return StitchResult(off, pairs, score, route, num_pw)
