@@ -170,6 +170,28 @@ def _side_from_c(sc, n):
                      back_translation=arr(sc.back_translation, np.uint64, nn))
 
 
+def despecify_indel_breakpoints(score, gap_before, gap_score_before, gap_after, gap_score_after,
+                                min_indel_fuzz_length=50, indel_fuzz_score_proportion=0.001):
+    """Stitcher::despecify_indel_breakpoints on parallel arrays; returns (keep mask, kept gap_before, gap_score_before,
+    gap_after, gap_score_after)"""
+    lib = load_library()
+    n = len(score)
+    sc = np.ascontiguousarray(score, np.float64)
+    gb = np.array(gap_before, np.int64); ga = np.array(gap_after, np.int64)
+    gsb = np.array(gap_score_before, np.float64); gsa = np.array(gap_score_after, np.float64)
+    keep = np.zeros(max(n, 1), np.uint8)
+    kept = C.c_uint64(0)
+    lib.cl_despecify_indel_breakpoints.restype = C.c_int
+    rc = lib.cl_despecify_indel_breakpoints(C.c_uint64(n), sc.ctypes.data_as(C.c_void_p), gb.ctypes.data_as(C.c_void_p),
+                                            gsb.ctypes.data_as(C.c_void_p), ga.ctypes.data_as(C.c_void_p),
+                                            gsa.ctypes.data_as(C.c_void_p), C.c_int64(min_indel_fuzz_length),
+                                            C.c_double(indel_fuzz_score_proportion), keep.ctypes.data_as(C.c_void_p), C.byref(kept))
+    if rc != 0:
+        raise ClError(rc)
+    k = int(kept.value)
+    return keep[:n].astype(bool), gb[:k], gsb[:k], ga[:k], gsa[:k]
+
+
 def extract_stitch_batch(graph1, graph2, segments):
     """Extractor::extract_graphs_between in Stitcher::stitch's consumption order (host only, no GPU needed)"""
     lib = load_library()
@@ -527,7 +549,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
-    "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
+    "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
 ]
 
 

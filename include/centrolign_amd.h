@@ -235,6 +235,16 @@ int  cl_stitch(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph
                const cl_stitch_params* params, cl_alignment* out);
 void cl_alignment_free(cl_alignment* a);
 
+/* --- Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) -------------------------------------------------
+ * Drops the weak anchors that pin the breakpoints of long indels.  Inputs are the anchor_t fields the algorithm reads
+ * (score, gap_before, gap_score_before, gap_after, gap_score_after), as parallel arrays in chain order; Stitcher's
+ * tunables min_indel_fuzz_length / indel_fuzz_score_proportion (stitcher.hpp:68-71).  On return keep_out[i] tells
+ * whether anchor i survives; the gap arrays hold, in their first *n_kept_out entries, the updated values of the kept
+ * anchors in order (exactly what the reference leaves in the resized vector). Host only. */
+int cl_despecify_indel_breakpoints(uint64_t n_anchors, const double* score, int64_t* gap_before, double* gap_score_before,
+                                   int64_t* gap_after, double* gap_score_after, int64_t min_indel_fuzz_length,
+                                   double indel_fuzz_score_proportion, uint8_t* keep_out, uint64_t* n_kept_out);
+
 /* --- Anchorer chaining DP (include/centrolign/anchorer.hpp:1812-2547) --------------------------------------------------
  * The seam is sparse_affine_chain_dp itself: (graphs + embedded paths, match sets, gap parameters, local scale) in,
  * the optimal chain out, as the reference's anchor_chain dispatch calls it (anchorer.hpp:1213-1307) with local

@@ -436,6 +436,35 @@ int ref_chain_dp(int algo, const cl_base_graph* g1, const cl_base_graph* g2, con
     return 0;
 }
 
+/* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as
+ * cl_despecify_indel_breakpoints */
+int ref_despecify(uint64_t n, const double* score, int64_t* gap_before, double* gap_score_before, int64_t* gap_after,
+                  double* gap_score_after, int64_t min_len, double prop, uint8_t* keep_out, uint64_t* n_kept_out) {
+    std::vector<anchor_t> anchors(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        anchors[i].score = score[i];
+        anchors[i].gap_before = gap_before[i];
+        anchors[i].gap_score_before = gap_score_before[i];
+        anchors[i].gap_after = gap_after[i];
+        anchors[i].gap_score_after = gap_score_after[i];
+        anchors[i].idx1 = i;  /* tag to recover which anchors survive */
+    }
+    Stitcher st;
+    st.min_indel_fuzz_length = min_len;
+    st.indel_fuzz_score_proportion = prop;
+    st.despecify_indel_breakpoints(anchors);
+    for (uint64_t i = 0; i < n; ++i) keep_out[i] = 0;
+    for (size_t i = 0; i < anchors.size(); ++i) {
+        keep_out[anchors[i].idx1] = 1;
+        gap_before[i] = anchors[i].gap_before;
+        gap_score_before[i] = anchors[i].gap_score_before;
+        gap_after[i] = anchors[i].gap_after;
+        gap_score_after[i] = anchors[i].gap_score_after;
+    }
+    *n_kept_out = anchors.size();
+    return 0;
+}
+
 int ref_po_poa(const clo_graph* g1, const clo_graph* g2, int npw, const cl_align_params* prm, uint64_t* pairs_out,
                uint64_t* n_pairs_out, int64_t* score_out) {
     BaseGraph b1 = build_graph(g1), b2 = build_graph(g2);

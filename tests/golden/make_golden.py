@@ -158,6 +158,26 @@ def main():
             np.savez_compressed(os.path.join(HERE, "chain4_30k_merge%d.npz" % m), **out)
     else:
         print("skip stitch-level fixtures (no dump at %s)" % path)
+    # 7. despecify_indel_breakpoints: random anchor chains -> the reference's kept set and updated gap fields
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tests.test_despecify import random_case, ref_despecify
+    rng = np.random.default_rng(2026)
+    out = {}
+    n_cases = 60
+    for k in range(n_cases):
+        n = int(rng.integers(1, 80)) if k < 55 else int(rng.integers(300, 1500))
+        case = random_case(rng, n)
+        min_len = int(rng.choice([3, 15, 50, 88]))
+        prop = float(rng.choice([0.001, 0.05, 0.45, 0.77]))
+        res = ref_despecify(*case, min_len, prop)
+        pre = "c%d." % k
+        for name, arr in zip(("score", "gb", "gsb", "ga", "gsa"), case):
+            out[pre + name] = arr
+        out[pre + "min_len"], out[pre + "prop"] = np.array([min_len]), np.array([prop])
+        for name, arr in zip(("keep", "o_gb", "o_gsb", "o_ga", "o_gsa"), res):
+            out[pre + name] = arr
+    out["n_cases"] = np.array([n_cases])
+    np.savez_compressed(os.path.join(HERE, "despecify.npz"), **out)
     print("golden vectors written to", HERE)
 
 
