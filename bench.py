@@ -53,6 +53,28 @@ def cpu_baseline(batch, min_seconds=10.0, max_reps=12):
                       "time inside Stitcher::subalign only" % (cells, reps, total)}
 
 
+def saturated_section(ctx, batch, copies=16, steps=10):
+    """kernel throughput when the device is filled: the same batch replicated `copies` times in one plan (what a
+    guide tree with that many sibling merges in flight on one GPU would submit).  Reported beside the single-batch
+    pass, whose duration is set by the sweep of its few largest matrices rather than by throughput."""
+    from centrolign_amd import capi
+    big = capi.StitchBatch.concat([batch] * copies)
+    plan = ctx.plan(big)
+    st = plan.stats()
+    for _ in range(2):
+        plan.execute()
+        plan.sync()
+    ms = 0.0
+    for _ in range(steps):
+        plan.execute()
+        ms += plan.sync()
+    ms /= steps
+    plan.destroy()
+    return {"copies": copies, "subproblems": st["n_problems"], "dp_cells": st["dp_cells"], "device_ms_per_pass": ms,
+            "cells_per_s": st["dp_cells"] / (ms * 1e-3), "algorithmic_GBps": st["dp_bytes"] / (ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": st["dp_bytes"] / (ms * 1e-3) / 1e9 / 8000.0}
+
+
 def chaining_section(ctx, with_reference):
     """second half of the hot path: sparse_affine_chain_dp on the match pairs of the same 2 x 1 Mbp pair
     (bench_data/c2_chain_input.npz: the reference's graphs and budget-selected match sets; built by
@@ -172,6 +194,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch)
         if world == 1:
+            out["saturated"] = saturated_section(ctx, batch)
             ch = chaining_section(ctx, not args.no_cpu_baseline)
             if ch is not None:
                 out["chaining"] = ch

@@ -9,7 +9,6 @@
 constexpr uint32_t kChainBlock = 256;     // match pairs per sequential block (one workgroup in the intra kernel)
 constexpr uint32_t kChainTile = 1024;     // predecessor records per workgroup in the inter kernel
 constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
-constexpr uint32_t kChainMaxCand = 16;    // tie candidates listed per query for the traceback
 
 struct ClChainParams {
     double gap_open[3];
@@ -45,10 +44,6 @@ struct ClChainDevice {
     const uint32_t* group;      // [n_pairs] depth window of the pair's first graph-1 node (non-decreasing); pairs of one
                                 // window cannot precede one another
     ClChainParams params;
-};
-
-struct ClChainQuery {
-    uint32_t s, combo, kind;
 };
 
 #endif

@@ -18,7 +18,7 @@
 //                        the pairs after it.
 // O(M^2/2) pair evaluations instead of O(M log^2 M) tree steps, but all of them independent: 922 k pairs
 // (the 2 x 1 Mbp config) are 4.3e11 evaluations.  Which predecessor the reference's trees would report among
-// EQUAL maxima is decided afterwards, only for the pairs on the optimal chain (chain_candidates_kernel + host).
+// EQUAL maxima is decided afterwards on the host, only for the pairs on the optimal chain (cl_chain_api.cpp).
 //
 // Compiled with -ffp-contract=off: the candidate values must round exactly like the reference's scalar code.
 #include <hip/hip_runtime.h>
@@ -278,30 +278,6 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
     }
 }
 
-// For the pairs on the optimal chain: list the predecessors that attain the maximum of one query
-// (combination, kind); the host then picks the one the reference's tree traversal would report.
-__global__ void __launch_bounds__(256) chain_candidates_kernel(ClChainDevice D, const ClChainQuery* __restrict__ queries,
-                                                               uint32_t n_queries, uint32_t* __restrict__ cand_count,
-                                                               uint32_t* __restrict__ cand_list) {
-    const uint32_t qi = blockIdx.y;
-    if (qi >= n_queries) return;
-    const ClChainQuery Q = queries[qi];
-    const ClChainCombo cb = D.combos[Q.combo];
-    const uint32_t qt = cb.qt[Q.s], qoff = cb.qoff[Q.s];
-    const int32_t q = cb.q[Q.s];
-    const int target = cb.acc[(size_t)Q.s * 7 + Q.kind];
-    const float* val = cb.val + (size_t)Q.kind * cb.n_recs;
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < cb.n_recs; r += gridDim.x * 256) {
-        if (cb.rec_s[r] >= Q.s) break;  // records are sorted by pair: later pairs cannot precede
-        const int32_t sg = cb.sigma[r];
-        const bool kind_ok = Q.kind == 0 ? sg == q : ((Q.kind - 1) % 2 == 1 ? sg < q : sg > q);
-        if (kind_ok && qt != 0xFFFFFFFFu && cb.ins_t[r] <= qt && cb.off[r] < qoff && enc(val[r]) == target) {
-            const uint32_t k = atomicAdd(cand_count + qi, 1u);
-            if (k < kChainMaxCand) cand_list[(size_t)qi * kChainMaxCand + k] = r;
-        }
-    }
-}
-
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
                                  uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream) {
     if (max_recs == 0) return hipSuccess;
@@ -312,12 +288,5 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
 
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream) {
     hipLaunchKernelGGL(chain_intra_kernel, dim3(1), dim3(kChainBlock), 0, stream, D, block_first, block_count);
-    return hipGetLastError();
-}
-
-hipError_t cl_chain_launch_candidates(const ClChainDevice& D, const ClChainQuery* queries, uint32_t n_queries,
-                                      uint32_t* cand_count, uint32_t* cand_list, hipStream_t stream) {
-    if (!n_queries) return hipSuccess;
-    hipLaunchKernelGGL(chain_candidates_kernel, dim3(64, n_queries), dim3(256), 0, stream, D, queries, n_queries, cand_count, cand_list);
     return hipGetLastError();
 }

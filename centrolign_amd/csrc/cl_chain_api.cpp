@@ -35,8 +35,6 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream);
-hipError_t cl_chain_launch_candidates(const ClChainDevice& D, const ClChainQuery* queries, uint32_t n_queries, uint32_t* cand_count,
-                                      uint32_t* cand_list, hipStream_t stream);
 
 namespace {
 
@@ -481,7 +479,6 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     auto cleanup2 = [&]() { cleanup(); };
     out->index_ms = ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
-    std::vector<float> val_host;  // lazily downloaded stored values of one combo (ties only)
     std::vector<uint32_t> chain_slots;
     uint64_t n_ties = 0;
     uint32_t here = best_slot;
