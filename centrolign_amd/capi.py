@@ -218,18 +218,35 @@ class MatchSetsC(C.Structure):
 class ChainParams(C.Structure):
     """cl_chain_params: Anchorer gap parameters + ScoreFunction fields"""
     _fields_ = [("gap_open", C.c_double * 3), ("gap_extend", C.c_double * 3), ("anchor_score_function", C.c_int),
-                ("pair_count_power", C.c_double), ("length_intercept", C.c_double), ("length_decay_power", C.c_double)]
+                ("pair_count_power", C.c_double), ("length_intercept", C.c_double), ("length_decay_power", C.c_double),
+                ("global_anchoring", C.c_int)]
 
 
 class ChainResultC(C.Structure):
     _fields_ = [("n_anchors", C.c_uint64), ("anchors", C.POINTER(C.c_uint32)), ("n_pairs", C.c_uint64),
                 ("dp", C.POINTER(C.c_float)), ("n_ties", C.c_uint64), ("device_ms", C.c_float),
-                ("prep_ms", C.c_float), ("index_ms", C.c_float), ("traceback_ms", C.c_float)]
+                ("prep_ms", C.c_float), ("index_ms", C.c_float), ("traceback_ms", C.c_float),
+                ("gap_before_first", C.c_int64), ("gap_after_last", C.c_int64),
+                ("gap_score_before_first", C.c_double), ("gap_score_after_last", C.c_double)]
 
 
-def default_chain_params():
-    """the CLI's anchoring parameters (src/parameters.cpp:39-59)"""
+class AnchorParams(C.Structure):
+    """cl_anchor_params"""
+    _fields_ = [("chain", ChainParams), ("max_num_match_pairs", C.c_uint64), ("score_scale", C.c_double),
+                ("autocalibrate_gap_penalties", C.c_int)]
+
+
+class AnchorChainResultC(C.Structure):
+    _fields_ = [("n_anchors", C.c_uint64), ("anchors", C.POINTER(C.c_uint32)), ("gap_before", C.POINTER(C.c_int64)),
+                ("gap_after", C.POINTER(C.c_int64)), ("gap_score_before", C.POINTER(C.c_double)),
+                ("gap_score_after", C.POINTER(C.c_double)), ("score", C.POINTER(C.c_double)), ("n_sets", C.c_uint64),
+                ("set_order", C.POINTER(C.c_uint64)), ("scale", C.c_double), ("n_ties", C.c_uint64)]
+
+
+def default_chain_params(global_anchoring=True):
+    """the CLI's anchoring parameters (src/parameters.cpp:39-60)"""
     p = ChainParams()
+    p.global_anchoring = int(global_anchoring)
     p.gap_open[:] = [1.25, 50.0, 5000.0]
     p.gap_extend[:] = [2.5, 0.1, 0.0015]
     p.anchor_score_function = 2  # ConcaveLengthScaleInverseCount
@@ -537,6 +554,11 @@ def load_library(path=None):
     lib.cl_chain_sparse.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
                                     C.POINTER(ChainParams), C.c_int, C.POINTER(ChainResultC)]
     lib.cl_chain_result_free.argtypes = [C.POINTER(ChainResultC)]
+    lib.cl_anchor_chain.restype = C.c_int
+    lib.cl_anchor_chain.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC),
+                                    C.POINTER(AnchorParams), C.POINTER(AnchorChainResultC)]
+    lib.cl_anchor_chain_result_free.restype = None
+    lib.cl_anchor_chain_result_free.argtypes = [C.POINTER(AnchorChainResultC)]
     if path is None:
         _lib = lib
     return lib
@@ -550,6 +572,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
+    "cl_anchor_chain", "cl_anchor_chain_result_free",
 ]
 
 
@@ -670,9 +693,35 @@ class Context:
             chain = np.ctypeslib.as_array(out.anchors, shape=(max(na, 1) * 3,))[:3 * na].copy().reshape(na, 3)
             dp = np.ctypeslib.as_array(out.dp, shape=(max(npairs, 1),))[:npairs].copy() if want_dp and npairs else None
             return dict(chain=chain, dp=dp, n_ties=int(out.n_ties), device_ms=float(out.device_ms), n_pairs=npairs,
-                        prep_ms=float(out.prep_ms), index_ms=float(out.index_ms), traceback_ms=float(out.traceback_ms))
+                        prep_ms=float(out.prep_ms), index_ms=float(out.index_ms), traceback_ms=float(out.traceback_ms),
+                        end_gaps=(int(out.gap_before_first), int(out.gap_after_last)),
+                        end_gap_scores=(float(out.gap_score_before_first), float(out.gap_score_after_last)))
         finally:
             self.lib.cl_chain_result_free(C.byref(out))
+
+    def anchor_chain(self, graph1, graph2, matches, max_num_match_pairs=1250000, score_scale=1.0, autocalibrate=True,
+                     params=None):
+        """Anchorer::anchor_chain (include/centrolign/anchorer.hpp:958-996) without fill-in re-anchoring and branch
+        splitting.  Returns dict(chain (n,3) [position in the reordered sets, idx1, idx2], gap_before/after,
+        gap_score_before/after, score, set_order, scale, n_ties)"""
+        ap = AnchorParams()
+        ap.chain = params or default_chain_params()
+        ap.max_num_match_pairs = int(max_num_match_pairs)
+        ap.score_scale = float(score_scale)
+        ap.autocalibrate_gap_penalties = int(autocalibrate)
+        g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), AnchorChainResultC()
+        self._check(self.lib.cl_anchor_chain(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), C.byref(out)))
+        try:
+            na, ns = int(out.n_anchors), int(out.n_sets)
+
+            def arr(ptr, n, width=1):
+                return np.ctypeslib.as_array(ptr, shape=(max(n, 1) * width,))[:n * width].copy()
+            return dict(chain=arr(out.anchors, na, 3).reshape(na, 3), gap_before=arr(out.gap_before, na),
+                        gap_after=arr(out.gap_after, na), gap_score_before=arr(out.gap_score_before, na),
+                        gap_score_after=arr(out.gap_score_after, na), score=arr(out.score, na),
+                        set_order=arr(out.set_order, ns), scale=float(out.scale), n_ties=int(out.n_ties))
+        finally:
+            self.lib.cl_anchor_chain_result_free(C.byref(out))
 
     def plan(self, batch, params=None, force_num_pw=None):
         params = params or default_stitch_params()

@@ -37,6 +37,7 @@ struct ClChainDevice {
     uint32_t n_pairs, n_combos;
     const ClChainCombo* combos;
     const float* weight;        // anchor weight per sorted pair
+    const float* init;          // value of the chain that starts at the pair (weight, + lead indel / -inf under global anchoring)
     float* dp;                  // final DP value per sorted pair
     const uint32_t* rec_off;    // [n_pairs + 1] records of each pair
     const uint32_t* rec_combo;

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
     int acc0[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) acc0[k] = enc(CL_CHAIN_NEG);
-    float w = 0.f;
+    float w = 0.f, w_init = 0.f;
     uint32_t r0 = 0, r1 = 0, my_combo = 0, my_pos = 0, my_ins = 0, my_off = 0, my_group = 0xFFFFFFFFu;
     int32_t my_sig = 0;
     bool has_q0 = false;
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc0[k] = c0.acc[(size_t)s * 7 + k];
         w = D.weight[s];
+        w_init = D.init[s];
         my_group = D.group[s];
         r0 = D.rec_off[s]; r1 = D.rec_off[s + 1];
         if (r1 > r0) {
@@ -168,8 +169,8 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
         if (i == 0) { s_count = 0; s_next_group = 0xFFFFFFFFu; }
         __syncthreads();
         if (active && my_group == group) {
-            // finalise: dp = max(own weight, every candidate) — anchorer.hpp:2041, 2379-2412
-            float best = w;
+            // finalise: dp = max(chain starting here, every candidate) — anchorer.hpp:2026-2041, 2379-2412
+            float best = w_init;
             if (has_q0) best = apply_candidates(best, acc0, w, pen0);
             if (!simple) {
                 for (uint32_t c = 1; c < D.n_combos; ++c) {

@@ -169,6 +169,7 @@ void cl_chain_params_default(cl_chain_params* p) {
     p->pair_count_power = 0.5;
     p->length_intercept = 2250.0;
     p->length_decay_power = 2.0;
+    p->global_anchoring = 1;   // src/parameters.cpp:60
 }
 
 void cl_chain_result_free(cl_chain_result* r) {
@@ -268,6 +269,82 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         weight[s] = (float)anchor_weight(*cp, ms->count1[p.set], ms->count2[p.set], ms->walk_off1[w0 + 1] - ms->walk_off1[w0], ms->full_length[p.set]);
     }
 
+    // Global anchoring (anchorer.hpp:1069-1076): sources = the nodes after the source sentinel, sinks = the nodes before the
+    // sink sentinel.  A chain's first anchor pays the lead indel from the sources (affine, :2026-2039) or must be reachable
+    // from them (sparse, :1562-1582); its last anchor pays the final indel to the sinks (:2426-2438 / :1724-1741).
+    const bool global = cp->global_anchoring != 0;
+    std::vector<uint32_t> src1, src2, snk1, snk2;
+    if (global) {
+        for (uint64_t e = g1->next_off[g1->src_id]; e < g1->next_off[g1->src_id + 1]; ++e) src1.push_back(g1->next_idx[e]);
+        for (uint64_t e = g2->next_off[g2->src_id]; e < g2->next_off[g2->src_id + 1]; ++e) src2.push_back(g2->next_idx[e]);
+        for (uint64_t e = g1->prev_off[g1->snk_id]; e < g1->prev_off[g1->snk_id + 1]; ++e) snk1.push_back(g1->prev_idx[e]);
+        for (uint64_t e = g2->prev_off[g2->snk_id]; e < g2->prev_off[g2->snk_id + 1]; ++e) snk2.push_back(g2->prev_idx[e]);
+    }
+    auto score_gap = [&](int32_t gap) -> float {   // anchorer.hpp:1929-1944
+        float score = CL_CHAIN_NEG;
+        if (gap == 0) score = 0.0f;
+        else if (gap != INT32_MAX)
+            for (int pw = 0; pw < 3; ++pw) score = std::max<float>(score, (float)(-local_scale * (cp->gap_open[pw] + cp->gap_extend[pw] * std::abs(gap))));
+        return score;
+    };
+    auto measure_gap = [&](uint32_t a1, uint32_t a2, uint32_t c1, uint32_t c2) -> int32_t {   // anchorer.hpp:1906-1927
+        int32_t gap = INT32_MAX;
+        if ((a1 == c1 || x1.reachable(a1, c1)) && (a2 == c2 || x2.reachable(a2, c2)))
+            x1.for_each_chain_on(a1, [&](uint32_t p1) {
+                x2.for_each_chain_on(a2, [&](uint32_t p2) {
+                    const uint32_t src = x1.index_on(a1, p1) - x2.index_on(a2, p2);
+                    const uint32_t qry = x1.predecessor_index(c1, p1) - x2.predecessor_index(c2, p2) + sw1.distance(c1, p1) - sw2.distance(c2, p2);
+                    const int32_t here_gap = (int32_t)(src - qry);
+                    if (std::abs(here_gap) < std::abs(gap)) gap = here_gap;
+                });
+            });
+        return gap;
+    };
+    // the reference compares |gap| against the SIGNED running value (anchorer.hpp:1954, 1971, 1991)
+    auto gap_from_sources = [&](uint32_t c1, uint32_t c2) {
+        int32_t best = INT32_MAX;
+        for (uint32_t a : src1) for (uint32_t b : src2) { const int32_t h = measure_gap(a, b, c1, c2); if (std::abs(h) < best) best = h; }
+        return best;
+    };
+    auto gap_to_sinks = [&](uint32_t a1, uint32_t a2) {
+        int32_t best = INT32_MAX;
+        for (uint32_t c : snk1) for (uint32_t d : snk2) { const int32_t h = measure_gap(a1, a2, c, d); if (std::abs(h) < best) best = h; }
+        return best;
+    };
+    std::vector<float> init_w(weight);   // the value a chain that STARTS at the pair has
+    std::vector<float> final_term;       // per slot
+    float min_score = 0.0f;
+    if (global) {
+        final_term.resize(M);
+        for (uint32_t s = 0; s < M; ++s) {
+            const Pair& p = pairs[by_s[s]];
+            if (!sparse) {
+                const float lead = score_gap(gap_from_sources(p.b1, p.b2));
+                init_w[s] = lead == CL_CHAIN_NEG ? CL_CHAIN_NEG : weight[s] + lead;
+                final_term[by_s[s]] = score_gap(gap_to_sinks(p.e1, p.e2));
+            } else {
+                bool f1 = false, f2 = false, t = false;
+                for (uint32_t a : src1) if (a == p.b1 || x1.reachable(a, p.b1)) { f1 = true; break; }
+                for (uint32_t b : src2) if (b == p.b2 || x2.reachable(b, p.b2)) { f2 = true; break; }
+                if (!f1 || !f2) init_w[s] = CL_CHAIN_NEG;
+                for (uint32_t c : snk1) {
+                    for (uint32_t d : snk2)
+                        if ((c == p.e1 || x1.reachable(p.e1, c)) && (d == p.e2 || x2.reachable(p.e2, d))) { t = true; break; }
+                    if (t) break;
+                }
+                final_term[by_s[s]] = t ? 0.0f : CL_CHAIN_NEG;
+            }
+        }
+        if (!sparse) {   // the score of aligning nothing: one indel from the sources to the sinks (anchorer.hpp:2419-2424)
+            int32_t best = INT32_MAX;
+            for (uint32_t c : snk1) for (uint32_t d : snk2) for (uint32_t a : src1) for (uint32_t b : src2) {
+                const int32_t h = measure_gap(a, b, c, d);
+                if (std::abs(h) < best) best = h;
+            }
+            min_score = score_gap(best);
+        }
+    }
+
     // (chain1, chain2) combinations that hold at least one pair; the most populated one goes first (it is the one the
     // intra kernel keeps in registers)
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> combo_id;
@@ -340,13 +417,13 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     // ---- device ----------------------------------------------------------------------------------------------------
     int rc = CL_OK;
     DevBuf<ClChainCombo> d_combos;
-    DevBuf<float> d_weight, d_dp;
+    DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group;
     std::vector<ClChainCombo> hc(combos.size());
     std::vector<int> acc_init(M * 7, enc(CL_CHAIN_NEG));
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
-        d_combos.release(); d_weight.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release();
+        d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release();
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
@@ -361,6 +438,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     }
     CH(d_combos.upload(ctx, hc));
     CH(d_weight.upload(ctx, weight));
+    CH(d_init.upload(ctx, init_w));
     CH(d_dp.alloc(ctx, M));
     CH(d_rec_off.upload(ctx, rec_off)); CH(d_rec_combo.upload(ctx, rec_combo)); CH(d_rec_pos.upload(ctx, rec_pos));
     {
@@ -373,6 +451,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     D.n_combos = (uint32_t)combos.size();
     D.combos = d_combos.p;
     D.weight = d_weight.p;
+    D.init = d_init.p;
     D.dp = d_dp.p;
     D.rec_off = d_rec_off.p;
     D.rec_combo = d_rec_combo.p;
@@ -445,8 +524,11 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     float opt = CL_CHAIN_NEG;
     uint32_t best_slot = kNone;
     for (uint32_t slot = 0; slot < M; ++slot) {
-        const float v = dp_sorted[s_of_slot[slot]] + 0.0f;
-        if (v > opt && v > 0.0f) { opt = v; best_slot = slot; }
+        float v = dp_sorted[s_of_slot[slot]];
+        const float f = global ? final_term[slot] : 0.0f;
+        if (f == CL_CHAIN_NEG) v = f;
+        else v += f;
+        if (v > opt && v > min_score) { opt = v; best_slot = slot; }
     }
     const auto T1 = std::chrono::steady_clock::now();
     // value index: per combination and tree kind, (encoded stored value, record) sorted by value
@@ -486,7 +568,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         chain_slots.push_back(here);
         const uint32_t s = s_of_slot[here];
         const float dpv = dp_sorted[s], w = weight[s];
-        if (!(dpv > w)) break;  // no candidate was strictly greater than the single-anchor chain: chain start
+        if (!(dpv > init_w[s])) break;  // no candidate was strictly greater than the chain that starts here: chain start
         const Pair& p = pairs[here];
         // the reference's candidate order: forward edges by the topological position of their source node, then chain1;
         // chain2 ascending; gap-free tree, then trees 0..5 (anchorer.hpp:2352-2413)
@@ -650,6 +732,14 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     }
     if (want_dp)
         for (uint32_t slot = 0; slot < M; ++slot) out->dp[slot] = dp_sorted[s_of_slot[slot]];
+    if (global && !sparse && !chain_slots.empty()) {   // gap annotation of the chain's ends (anchorer.hpp:2445-2451, 2461-2467)
+        const Pair& f = pairs[chain_slots.front()];
+        const Pair& l = pairs[chain_slots.back()];
+        out->gap_before_first = gap_from_sources(f.b1, f.b2);
+        out->gap_score_before_first = score_gap((int32_t)out->gap_before_first);
+        out->gap_after_last = gap_to_sinks(l.e1, l.e2);
+        out->gap_score_after_last = score_gap((int32_t)out->gap_after_last);
+    }
     cleanup2();
     return CL_OK;
 #undef CH
@@ -669,3 +759,268 @@ int cl_chain_sparse(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Anchorer::anchor_chain without fill-in re-anchoring and branch splitting:
+//   budgeted greedy match selection + reorder      include/centrolign/anchorer.hpp:1108-1173
+//   graph swap to save memory                       :1175-1192, 1309-1322
+//   estimate_score_scale                            :998-1047  (sparse_chain_dp + extract_graphs_between + source_sink_minmax)
+//   sparse_affine_chain_dp with the estimated scale :985, 1050-1089
+//   gap / score annotation of the chain             :2443-2468, 1331-1339
+// =====================================================================================================================
+namespace {
+
+struct OwnedMatchSets {
+    std::vector<uint64_t> set_off1{0}, walk_off1{0}, set_off2{0}, walk_off2{0}, count1, count2, full_length;
+    std::vector<uint32_t> nodes1, nodes2;
+    cl_match_sets view() const {
+        return cl_match_sets{count1.size(), set_off1.data(), walk_off1.data(), nodes1.data(), set_off2.data(), walk_off2.data(),
+                             nodes2.data(), count1.data(), count2.data(), full_length.data()};
+    }
+};
+
+// new[k] = old[order[k]]; with swap the two graph sides trade places (anchorer.hpp:1179-1182)
+OwnedMatchSets permute_sets(const cl_match_sets& ms, const std::vector<uint64_t>& order, bool swap) {
+    OwnedMatchSets o;
+    for (uint64_t s : order) {
+        for (int side = 0; side < 2; ++side) {
+            const bool from2 = (side == 1) != swap;
+            const uint64_t* so = from2 ? ms.set_off2 : ms.set_off1;
+            const uint64_t* wo = from2 ? ms.walk_off2 : ms.walk_off1;
+            const uint32_t* nd = from2 ? ms.nodes2 : ms.nodes1;
+            auto& oso = side ? o.set_off2 : o.set_off1;
+            auto& owo = side ? o.walk_off2 : o.walk_off1;
+            auto& ond = side ? o.nodes2 : o.nodes1;
+            for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
+                ond.insert(ond.end(), nd + wo[w], nd + wo[w + 1]);
+                owo.push_back(ond.size());
+            }
+            oso.push_back(owo.size() - 1);
+        }
+        o.count1.push_back(swap ? ms.count2[s] : ms.count1[s]);
+        o.count2.push_back(swap ? ms.count1[s] : ms.count2[s]);
+        o.full_length.push_back(ms.full_length[s]);
+    }
+    return o;
+}
+
+// anchorer.hpp:1108-1173 on a permutation of the original set indices: `cur` is the current order of the caller's
+// vector; returns the number of leading sets that take part
+uint64_t select_matches(const cl_match_sets& ms, const cl_chain_params& cp, std::vector<uint64_t>& cur, uint64_t local_max) {
+    const size_t n = cur.size();
+    auto n_pairs = [&](uint64_t s) { return (ms.set_off1[s + 1] - ms.set_off1[s]) * (ms.set_off2[s + 1] - ms.set_off2[s]); };
+    uint64_t total = 0;
+    for (uint64_t s : cur) total += n_pairs(s);
+    if (total <= local_max) return n;
+    auto wfull = [&](uint64_t s) { return anchor_weight(cp, ms.count1[s], ms.count2[s], ms.full_length[s], ms.full_length[s]); };
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t i, size_t j) { return wfull(cur[i]) > wfull(cur[j]); });
+    size_t removed = 0;
+    uint64_t left = local_max;
+    for (size_t i = 0; i < order.size(); ++i) {
+        const uint64_t s = cur[order[i]];
+        const uint64_t w0 = ms.set_off1[s];
+        const uint64_t len = ms.walk_off1[w0 + 1] - ms.walk_off1[w0];
+        if (anchor_weight(cp, ms.count1[s], ms.count2[s], len, len) < 0.0) { removed += order.size() - i; break; }
+        const uint64_t pc = n_pairs(s);
+        if (left >= pc) { left -= pc; std::swap(order[i - removed], order[i]); }
+        else ++removed;
+    }
+    std::vector<uint64_t> next(n);
+    for (size_t k = 0; k < n; ++k) next[k] = cur[order[k]];  // reorder(matches, invert(order)): new[k] = old[order[k]]
+    cur.swap(next);
+    return n - removed;
+}
+
+// minimum source->sink distance in nodes of one extracted subgraph, as source_sink_minmax(...).first (src/anchorer.cpp:14-23)
+int64_t min_source_sink(const clhost::OwnedBatch::Side& sd, uint64_t k) {
+    const uint64_t b = sd.node_off[k], n = sd.node_off[k + 1] - b;
+    std::vector<int64_t> dist(n, INT64_MAX);
+    std::vector<uint32_t> indeg(n), st, order;
+    for (uint64_t v = 0; v < n; ++v) { indeg[v] = (uint32_t)(sd.prev_off[b + v + 1] - sd.prev_off[b + v]); if (!indeg[v]) st.push_back((uint32_t)v); }
+    while (!st.empty()) {
+        uint32_t v = st.back(); st.pop_back(); order.push_back(v);
+        for (uint64_t e = sd.next_off[b + v]; e < sd.next_off[b + v + 1]; ++e) if (--indeg[sd.next_idx[e]] == 0) st.push_back(sd.next_idx[e]);
+    }
+    for (uint64_t i = sd.src_off[k]; i < sd.src_off[k + 1]; ++i) dist[sd.src_idx[i]] = 0;
+    for (uint32_t v : order)
+        if (dist[v] != INT64_MAX)
+            for (uint64_t e = sd.next_off[b + v]; e < sd.next_off[b + v + 1]; ++e) dist[sd.next_idx[e]] = std::min(dist[sd.next_idx[e]], dist[v] + 1);
+    int64_t mn = INT64_MAX;
+    for (uint64_t i = sd.snk_off[k]; i < sd.snk_off[k + 1]; ++i) mn = std::min(mn, dist[sd.snk_idx[i]]);
+    return mn;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cl_anchor_chain_result_free(cl_anchor_chain_result* r) {
+    if (!r) return;
+    free(r->anchors); free(r->gap_before); free(r->gap_after); free(r->gap_score_before); free(r->gap_score_after);
+    free(r->score); free(r->set_order);
+    memset(r, 0, sizeof(*r));
+}
+
+int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                    const cl_anchor_params* ap, cl_anchor_chain_result* out) {
+    if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    const cl_chain_params& cp = ap->chain;
+    clhost::PathMergeTable x1, x2;
+    if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    // anchorer.hpp:1175: the DP runs with the graphs swapped when that makes its tables smaller
+    const bool swap = g1->n_nodes * x1.chain_size() > g2->n_nodes * x2.chain_size();
+    const cl_base_graph* ga = swap ? g2 : g1;
+    const cl_base_graph* gb = swap ? g1 : g2;
+    std::vector<uint64_t> cur(ms->n_sets);
+    std::iota(cur.begin(), cur.end(), (uint64_t)0);
+
+    struct Chain {   // (set, idx1, idx2) in ORIGINAL graph orientation, set = position in `cur`
+        std::vector<uint32_t> a;
+        int64_t gap_first = 0, gap_last = 0;       // global anchoring: the indels to the graph ends, DP orientation
+        double score_first = 0.0, score_last = 0.0;
+    };
+    auto run = [&](bool sparse, double anchor_scale, Chain& chain) -> int {
+        const uint64_t local_max = std::min<uint64_t>((uint64_t)llround((anchor_scale / ap->score_scale) * (double)ap->max_num_match_pairs),
+                                                     ap->max_num_match_pairs);
+        const uint64_t n_use = select_matches(*ms, cp, cur, local_max);
+        OwnedMatchSets sel = permute_sets(*ms, cur, swap);
+        cl_match_sets v = sel.view();
+        cl_chain_result r;
+        int rc = chain_dp_impl(ctx, ga, gb, &v, n_use, &cp, anchor_scale, 0, sparse, &r);
+        if (rc) return rc;
+        chain.a.assign(r.anchors, r.anchors + 3 * r.n_anchors);
+        if (swap) for (size_t i = 0; i < r.n_anchors; ++i) std::swap(chain.a[3 * i + 1], chain.a[3 * i + 2]);
+        chain.gap_first = r.gap_before_first; chain.gap_last = r.gap_after_last;
+        chain.score_first = r.gap_score_before_first; chain.score_last = r.gap_score_after_last;
+        out->n_ties += r.n_ties;
+        cl_chain_result_free(&r);
+        return CL_OK;
+    };
+    auto walk = [&](int side, uint64_t set_pos, uint32_t idx, const uint32_t*& b, const uint32_t*& e) {
+        const uint64_t s = cur[set_pos];
+        const uint64_t w = (side ? ms->set_off2 : ms->set_off1)[s] + idx;
+        const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
+        const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
+        b = nd + wo[w]; e = nd + wo[w + 1];
+    };
+
+    // ---- estimate_score_scale (anchorer.hpp:998-1047)
+    double scale = 1.0;
+    int rc;
+    if (ap->autocalibrate_gap_penalties) {
+        Chain sc;
+        if ((rc = run(true, 1.0, sc))) return rc;
+        double total_weight = 0.0;
+        uint64_t total_length = 0;
+        const size_t na = sc.a.size() / 3;
+        std::vector<uint64_t> seg_off{0, na}, walk_off{0};
+        std::vector<uint32_t> w1, w2;
+        for (size_t i = 0; i < na; ++i) {
+            const uint32_t *b, *e;
+            walk(0, sc.a[3 * i], sc.a[3 * i + 1], b, e);
+            const uint64_t s = cur[sc.a[3 * i]];
+            total_weight += anchor_weight(cp, ms->count1[s], ms->count2[s], (uint64_t)(e - b), ms->full_length[s]);
+            total_length += (uint64_t)(e - b);
+            w1.insert(w1.end(), b, e);
+            walk(1, sc.a[3 * i], sc.a[3 * i + 2], b, e);
+            w2.insert(w2.end(), b, e);
+            walk_off.push_back(w1.size());
+        }
+        cl_anchor_segments sg{na ? 1u : 0u, seg_off.data(), walk_off.data(), w1.data(), w2.data()};
+        clhost::OwnedBatch ob;
+        if ((rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob))) { cl_set_error(ctx, "extraction failed"); return rc; }
+        for (uint64_t k = 0; k < ob.only_del.size(); ++k) {
+            uint64_t fill = UINT64_MAX;
+            for (int side = 0; side < 2; ++side) {
+                const auto& sd = ob.side[side];
+                if (sd.node_off[k + 1] == sd.node_off[k]) fill = 0;
+                else fill = std::min<uint64_t>(fill, (uint64_t)min_source_sink(sd, k));
+            }
+            total_length += fill;
+        }
+        scale = total_weight / (double)total_length;
+    }
+    out->scale = scale;
+
+    // ---- the affine chain
+    Chain ch;
+    if ((rc = run(false, scale, ch))) return rc;
+    const size_t na = ch.a.size() / 3;
+    out->n_anchors = na;
+    out->n_sets = cur.size();
+    out->anchors = (uint32_t*)malloc((na ? na : 1) * 3 * sizeof(uint32_t));
+    out->gap_before = (int64_t*)calloc(na ? na : 1, sizeof(int64_t));
+    out->gap_after = (int64_t*)calloc(na ? na : 1, sizeof(int64_t));
+    out->gap_score_before = (double*)calloc(na ? na : 1, sizeof(double));
+    out->gap_score_after = (double*)calloc(na ? na : 1, sizeof(double));
+    out->score = (double*)calloc(na ? na : 1, sizeof(double));
+    out->set_order = (uint64_t*)malloc((cur.size() ? cur.size() : 1) * sizeof(uint64_t));
+    if (!out->anchors || !out->gap_before || !out->gap_after || !out->gap_score_before || !out->gap_score_after || !out->score || !out->set_order) {
+        cl_anchor_chain_result_free(out);
+        return CL_ERR_OUT_OF_MEMORY;
+    }
+    memcpy(out->anchors, ch.a.data(), ch.a.size() * sizeof(uint32_t));
+    memcpy(out->set_order, cur.data(), cur.size() * sizeof(uint64_t));
+
+    // ---- annotation (anchorer.hpp:2443-2468 measure_gap_nn, evaluated in the DP's (possibly swapped) orientation, then
+    //      negated back at :1318-1320; score = anchor_weight, :1331-1335)
+    PostSwitchTable swa, swb;
+    const clhost::PathMergeTable& xa = swap ? x2 : x1;
+    const clhost::PathMergeTable& xb = swap ? x1 : x2;
+    swa.build(*ga, xa);
+    swb.build(*gb, xb);
+    auto measure_gap = [&](uint32_t pa, uint32_t pb, uint32_t ca, uint32_t cb) -> int32_t {
+        int32_t gap = INT32_MAX;
+        if ((pa == ca || xa.reachable(pa, ca)) && (pb == cb || xb.reachable(pb, cb))) {
+            xa.for_each_chain_on(pa, [&](uint32_t p1) {
+                xb.for_each_chain_on(pb, [&](uint32_t p2) {
+                    const int32_t src = (int32_t)(xa.index_on(pa, p1) - xb.index_on(pb, p2));
+                    const int32_t qry = (int32_t)(xa.predecessor_index(ca, p1) - xb.predecessor_index(cb, p2) + swa.distance(ca, p1) - swb.distance(cb, p2));
+                    const int32_t here = (int32_t)((uint32_t)src - (uint32_t)qry);
+                    if (std::abs((int64_t)here) < std::abs((int64_t)gap)) gap = here;
+                });
+            });
+        }
+        return gap;
+    };
+    auto score_gap = [&](int32_t gap) -> float {
+        float sc = CL_CHAIN_NEG;
+        if (gap == 0) sc = 0.0f;
+        else if (gap != INT32_MAX)
+            for (int pw = 0; pw < 3; ++pw) sc = std::max<float>(sc, (float)(-scale * (cp.gap_open[pw] + cp.gap_extend[pw] * std::abs(gap))));
+        return sc;
+    };
+    for (size_t i = 0; i < na; ++i) {
+        const uint64_t s = cur[ch.a[3 * i]];
+        const uint32_t *b, *e;
+        walk(0, ch.a[3 * i], ch.a[3 * i + 1], b, e);
+        out->score[i] = anchor_weight(cp, ms->count1[s], ms->count2[s], (uint64_t)(e - b), ms->full_length[s]);
+        if (i == 0) continue;
+        const uint32_t *pb1, *pe1, *pb2, *pe2, *cb1, *ce1, *cb2, *ce2;
+        walk(0, ch.a[3 * (i - 1)], ch.a[3 * (i - 1) + 1], pb1, pe1);
+        walk(1, ch.a[3 * (i - 1)], ch.a[3 * (i - 1) + 2], pb2, pe2);
+        walk(0, ch.a[3 * i], ch.a[3 * i + 1], cb1, ce1);
+        walk(1, ch.a[3 * i], ch.a[3 * i + 2], cb2, ce2);
+        const uint32_t prev1 = pe1[-1], prev2 = pe2[-1], cur1 = cb1[0], cur2 = cb2[0];
+        const int32_t gap = swap ? measure_gap(prev2, prev1, cur2, cur1) : measure_gap(prev1, prev2, cur1, cur2);
+        const double gs = (double)score_gap(gap);
+        const int64_t g = swap ? -(int64_t)gap : (int64_t)gap;
+        out->gap_after[i - 1] = g;
+        out->gap_score_after[i - 1] = gs;
+        out->gap_before[i] = g;
+        out->gap_score_before[i] = gs;
+    }
+    if (cp.global_anchoring && na) {   // anchorer.hpp:2445-2451, 2461-2467; negated with the rest at :1318-1320
+        out->gap_before[0] = swap ? -ch.gap_first : ch.gap_first;
+        out->gap_score_before[0] = ch.score_first;
+        out->gap_after[na - 1] = swap ? -ch.gap_last : ch.gap_last;
+        out->gap_score_after[na - 1] = ch.score_last;
+    }
+    return CL_OK;
+}
+
+}  // extern "C"
+

@@ -272,6 +272,9 @@ typedef struct cl_chain_params {
     double pair_count_power;
     double length_intercept;
     double length_decay_power;
+    int    global_anchoring;        /* Anchorer::global_anchoring (CLI default true, src/parameters.cpp:60): chains start at
+                                       the nodes after graph.src_id and end at the nodes before graph.snk_id
+                                       (anchorer.hpp:1069-1076); 0 = local chaining (sources/sinks == nullptr) */
 } cl_chain_params;
 /* the values the CLI runs with (src/parameters.cpp:39-59) */
 void cl_chain_params_default(cl_chain_params* p);
@@ -287,6 +290,10 @@ typedef struct cl_chain_result {
     float     prep_ms;     /* host: coordinates, ordering, packing, upload */
     float     index_ms;    /* value index (device sort + download) */
     float     traceback_ms;/* host: optimum + traceback with tie resolution */
+    /* global anchoring, affine DP: anchor_t::gap_before / gap_score_before of the first anchor and gap_after /
+       gap_score_after of the last one (anchorer.hpp:2445-2451, 2461-2467); 0 otherwise */
+    int64_t   gap_before_first, gap_after_last;
+    double    gap_score_before_first, gap_score_after_last;
 } cl_chain_result;
 
 /* sparse_affine_chain_dp<..., float, ...> over the leading num_match_sets sets. */
@@ -298,6 +305,35 @@ int  cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* graph1, const 
 int  cl_chain_sparse(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
                      uint64_t num_match_sets, const cl_chain_params* params, int want_dp, cl_chain_result* out);
 void cl_chain_result_free(cl_chain_result* r);
+
+/* --- Anchorer::anchor_chain (include/centrolign/anchorer.hpp:135-145, 958-1329) with do_fill_in_anchoring = false,
+ * split_matches_at_branchpoints = false, no masks: budgeted match selection (which REORDERS the caller's
+ * match sets, :1108-1173), scale estimation (:998-1047), the affine chain, gap and score annotation (:2443-2468).
+ * (Fill-in re-anchoring, :619-699, is the part of the seam that is not built yet.) */
+typedef struct cl_anchor_params {
+    cl_chain_params chain;
+    uint64_t max_num_match_pairs;        /* Anchorer::max_num_match_pairs (CLI: 1250000, src/parameters.cpp:39) */
+    double   score_scale;                /* ScoreFunction::score_scale (calibrated per input, src/core.cpp:193) */
+    int      autocalibrate_gap_penalties;/* Anchorer::autocalibrate_gap_penalties */
+} cl_anchor_params;
+
+typedef struct cl_anchor_chain_result {
+    uint64_t  n_anchors;
+    uint32_t* anchors;           /* [3*n]: anchor_t::match_set (index into the REORDERED sets), idx1, idx2 */
+    int64_t*  gap_before;        /* anchor_t::gap_before ... */
+    int64_t*  gap_after;
+    double*   gap_score_before;
+    double*   gap_score_after;
+    double*   score;             /* anchor_t::score */
+    uint64_t  n_sets;
+    uint64_t* set_order;         /* [n_sets]: the caller's vector after the call holds original set set_order[k] at position k */
+    double    scale;             /* the estimated score scale passed to the affine DP */
+    uint64_t  n_ties;
+} cl_anchor_chain_result;
+
+int  cl_anchor_chain(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+                     const cl_anchor_params* params, cl_anchor_chain_result* out);
+void cl_anchor_chain_result_free(cl_anchor_chain_result* r);
 
 #ifdef __cplusplus
 }

@@ -505,16 +505,39 @@ struct ForwardEdges {
     }
 };
 
+// sources / sinks of global anchoring (anchorer.hpp:1071-1076: next(src sentinel), previous(snk sentinel))
+struct Ends {
+    std::vector<uint32_t> src1, src2, snk1, snk2;
+    bool on = false;
+    Ends(const cl_base_graph& g1, const cl_base_graph& g2, bool global) : on(global) {
+        if (!global) return;
+        for (uint64_t e = g1.next_off[g1.src_id]; e < g1.next_off[g1.src_id + 1]; ++e) src1.push_back(g1.next_idx[e]);
+        for (uint64_t e = g2.next_off[g2.src_id]; e < g2.next_off[g2.src_id + 1]; ++e) src2.push_back(g2.next_idx[e]);
+        for (uint64_t e = g1.prev_off[g1.snk_id]; e < g1.prev_off[g1.snk_id + 1]; ++e) snk1.push_back(g1.prev_idx[e]);
+        for (uint64_t e = g2.prev_off[g2.snk_id]; e < g2.prev_off[g2.snk_id + 1]; ++e) snk2.push_back(g2.prev_idx[e]);
+    }
+};
+
+bool reachable(const PathMerge& x, uint64_t from, uint64_t to) {  // path_merge.hpp:235-248
+    auto ch = x.chain(from);
+    if (ch.first == kNone) return false;
+    uint32_t last = x.pred(to, ch.first);
+    return last != kNone && ch.second <= last;
+}
+
 using ShiftKey = std::pair<int32_t, MatchId>;
 using OffKey = std::pair<uint32_t, MatchId>;
 
-// traceback_sparse_dp (anchorer.hpp:2473-2547) without sinks: first strictly better dp value in iteration order
-std::vector<MatchId> traceback(const MatchBank& bank, float min_score) {
+// traceback_sparse_dp (anchorer.hpp:2473-2547): first strictly better (dp value + final term) in iteration order
+template <class FinalF>
+std::vector<MatchId> traceback(const MatchBank& bank, float min_score, FinalF final_term) {
     float opt = kMinInf;
     MatchId best = kMaxId;
     bank.for_each([&](const MatchId& id) {
         float v = bank.dp(id);
-        v += 0.0f;  // final_function == 0 when there are no sinks
+        const float f = final_term(id);
+        if (f == kMinInf) v = f;
+        else v += f;
         if (v > opt && v > min_score) { opt = v; best = id; }
     });
     std::vector<MatchId> chain;
@@ -528,10 +551,11 @@ std::vector<MatchId> traceback(const MatchBank& bank, float min_score) {
 extern "C" {
 
 // sparse_affine_chain_dp without sources/sinks/masks (local anchoring, the CLI default), NumPW = 3
-int clo_sparse_affine_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
-                            const clo_chain_params* cp, double local_scale, uint32_t* chain_out, uint64_t* chain_len,
-                            float* dp_out) {
+int clo_sparse_affine_chain_ex(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                               const clo_chain_params* cp, double local_scale, int global_anchoring, uint32_t* chain_out,
+                               uint64_t* chain_len, float* dp_out, clo_chain_ends* ends_out) {
     constexpr int NPW = 3;
+    const Ends E(*g1, *g2, global_anchoring != 0);
     Matches M{ms, num_match_sets};
     PathMerge x1(*g1), x2(*g2);
     MatchBank bank(M, g1->n_nodes);
@@ -551,10 +575,61 @@ int clo_sparse_affine_chain(const cl_base_graph* g1, const cl_base_graph* g2, co
         return (float)anchor_weight(*cp, ms->count1[id.set], ms->count2[id.set], M.walk_len(id.set), ms->full_length[id.set]);
     };
 
+    // gap measurement between node pairs and sets (anchorer.hpp:1906-2000)
+    auto basic_source_shift = [&](uint32_t a, uint32_t b, uint64_t p1, uint64_t p2) -> int32_t { return (int32_t)(x1.index_on(a, p1) - x2.index_on(b, p2)); };
+    auto basic_query_shift = [&](uint32_t a, uint32_t b, uint64_t p1, uint64_t p2) -> int32_t {
+        return (int32_t)(x1.pred(a, p1) - x2.pred(b, p2) + sw1.distance(a, p1) - sw2.distance(b, p2));
+    };
+    auto score_gap = [&](int32_t gap) -> float {
+        float score = kMinInf;
+        if (gap == 0) score = 0.0f;
+        else if (gap != std::numeric_limits<int32_t>::max())
+            for (int pw = 0; pw < NPW; ++pw) score = std::max<float>(score, (float)(-local_scale * (cp->gap_open[pw] + cp->gap_extend[pw] * std::abs(gap))));
+        return score;
+    };
+    auto measure_gap = [&](uint32_t p1n, uint32_t p2n, uint32_t c1n, uint32_t c2n) -> int32_t {
+        int32_t gap = std::numeric_limits<int32_t>::max();
+        if ((p1n == c1n || reachable(x1, p1n, c1n)) && (p2n == c2n || reachable(x2, p2n, c2n)))
+            for (uint32_t p1 : x1.chains_on(p1n))
+                for (uint32_t p2 : x2.chains_on(p2n)) {
+                    int32_t here = (int32_t)((uint32_t)basic_source_shift(p1n, p2n, p1, p2) - (uint32_t)basic_query_shift(c1n, c2n, p1, p2));
+                    if (std::abs(here) < std::abs(gap)) gap = here;
+                }
+        return gap;
+    };
+    // note the asymmetric comparison of the reference: |gap_here| against the signed current value (anchorer.hpp:1954,1971,1991)
+    auto measure_gap_sn = [&](const std::vector<uint32_t>& pv1, const std::vector<uint32_t>& pv2, uint32_t c1n, uint32_t c2n) {
+        std::pair<int32_t, float> r(std::numeric_limits<int32_t>::max(), kMinInf);
+        for (uint32_t a : pv1) for (uint32_t b : pv2) { int32_t h = measure_gap(a, b, c1n, c2n); if (std::abs(h) < r.first) r.first = h; }
+        r.second = score_gap(r.first);
+        return r;
+    };
+    auto measure_gap_ns = [&](uint32_t p1n, uint32_t p2n, const std::vector<uint32_t>& cv1, const std::vector<uint32_t>& cv2) {
+        std::pair<int32_t, float> r(std::numeric_limits<int32_t>::max(), kMinInf);
+        for (uint32_t a : cv1) for (uint32_t b : cv2) { int32_t h = measure_gap(p1n, p2n, a, b); if (std::abs(h) < r.first) r.first = h; }
+        r.second = score_gap(r.first);
+        return r;
+    };
+    auto measure_gap_ss = [&]() {
+        std::pair<int32_t, float> r(std::numeric_limits<int32_t>::max(), kMinInf);
+        for (uint32_t c1n : E.snk1) for (uint32_t c2n : E.snk2) for (uint32_t a : E.src1) for (uint32_t b : E.src2) {
+            int32_t h = measure_gap(a, b, c1n, c2n);
+            if (std::abs(h) < r.first) r.first = h;
+        }
+        r.second = score_gap(r.first);
+        return r;
+    };
+
     // bookkeeping (anchorer.hpp:2002-2049)
     std::vector<std::vector<std::tuple<ShiftKey, uint32_t, float>>> ortho_data(C1 * C2);
     bank.for_each([&](const MatchId& id) {
-        bank.update(id, weight_of(id), kMaxId);
+        float init_w = weight_of(id);
+        if (E.on) {
+            float lead = measure_gap_sn(E.src1, E.src2, M.front1(id), M.front2(id)).second;
+            if (lead == kMinInf) init_w = kMinInf;
+            else init_w += lead;
+        }
+        bank.update(id, init_w, kMaxId);
         for (uint32_t p1 : x1.chains_on(M.back1(id)))
             for (uint32_t p2 : x2.chains_on(M.back2(id)))
                 ortho_data[p1 * C2 + p2].emplace_back(ShiftKey(source_shift(id, p1, p2), id), key_offset(id, p2), kMinInf);
@@ -655,7 +730,10 @@ int clo_sparse_affine_chain(const cl_base_graph* g1, const cl_base_graph* g2, co
             });
         }
     }
-    auto chain = traceback(bank, 0.0f);
+    const float min_score = E.on ? measure_gap_ss().second : 0.0f;   // anchorer.hpp:2419-2424
+    auto chain = traceback(bank, min_score, [&](const MatchId& id) -> float {
+        return E.on ? measure_gap_ns(M.back1(id), M.back2(id), E.snk1, E.snk2).second : 0.0f;
+    });
     *chain_len = chain.size();
     for (size_t i = 0; i < chain.size(); ++i) {
         chain_out[3 * i] = chain[i].set;
@@ -663,12 +741,28 @@ int clo_sparse_affine_chain(const cl_base_graph* g1, const cl_base_graph* g2, co
         chain_out[3 * i + 2] = chain[i].i2;
     }
     if (dp_out) bank.for_each([&](const MatchId& id) { dp_out[bank.slot(id)] = bank.dp(id); });
+    if (ends_out) {   // gap annotation of the chain ends (anchorer.hpp:2445-2451, 2461-2467)
+        memset(ends_out, 0, sizeof(*ends_out));
+        if (E.on && !chain.empty()) {
+            auto lead = measure_gap_sn(E.src1, E.src2, M.front1(chain.front()), M.front2(chain.front()));
+            auto tail = measure_gap_ns(M.back1(chain.back()), M.back2(chain.back()), E.snk1, E.snk2);
+            ends_out->gap_before_first = lead.first; ends_out->gap_score_before_first = lead.second;
+            ends_out->gap_after_last = tail.first; ends_out->gap_score_after_last = tail.second;
+        }
+    }
     return 0;
 }
 
+int clo_sparse_affine_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                            const clo_chain_params* cp, double local_scale, uint32_t* chain_out, uint64_t* chain_len,
+                            float* dp_out) {
+    return clo_sparse_affine_chain_ex(g1, g2, ms, num_match_sets, cp, local_scale, 0, chain_out, chain_len, dp_out, nullptr);
+}
+
 // sparse_chain_dp without sources/sinks/masks (anchorer.hpp:1511-1750)
-int clo_sparse_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
-                     const clo_chain_params* cp, uint32_t* chain_out, uint64_t* chain_len, float* dp_out) {
+int clo_sparse_chain_ex(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                        const clo_chain_params* cp, int global_anchoring, uint32_t* chain_out, uint64_t* chain_len, float* dp_out) {
+    const Ends E(*g1, *g2, global_anchoring != 0);
     Matches M{ms, num_match_sets};
     PathMerge x1(*g1), x2(*g2);
     MatchBank bank(M, g1->n_nodes);
@@ -681,7 +775,14 @@ int clo_sparse_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
     bank.for_each([&](const MatchId& id) {
         auto ch = x2.chain(M.back2(id));
         data[ch.first].emplace_back(OffKey(ch.second, id), kMinInf);
-        bank.update(id, weight_of(id), kMaxId);
+        float init_w = weight_of(id);
+        if (E.on) {   // anchorer.hpp:1562-1582: a chain can only start on a match that the sources reach
+            bool f1 = false, f2 = false;
+            for (uint32_t a : E.src1) if (a == M.front1(id) || reachable(x1, a, M.front1(id))) { f1 = true; break; }
+            for (uint32_t b : E.src2) if (b == M.front2(id) || reachable(x2, b, M.front2(id))) { f2 = true; break; }
+            if (!f1 || !f2) init_w = kMinInf;
+        }
+        bank.update(id, init_w, kMaxId);
     });
     for (auto& d : data) std::stable_sort(d.begin(), d.end());
     std::vector<Tree> trees(C1 * C2);
@@ -712,7 +813,13 @@ int clo_sparse_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
             });
         }
     }
-    auto chain = traceback(bank, 0.0f);
+    auto chain = traceback(bank, 0.0f, [&](const MatchId& id) -> float {   // anchorer.hpp:1724-1741
+        if (!E.on) return 0.0f;
+        for (uint32_t a : E.snk1)
+            for (uint32_t b : E.snk2)
+                if ((a == M.back1(id) || reachable(x1, M.back1(id), a)) && (b == M.back2(id) || reachable(x2, M.back2(id), b))) return 0.0f;
+        return kMinInf;
+    });
     *chain_len = chain.size();
     for (size_t i = 0; i < chain.size(); ++i) {
         chain_out[3 * i] = chain[i].set;
@@ -721,6 +828,11 @@ int clo_sparse_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
     }
     if (dp_out) bank.for_each([&](const MatchId& id) { dp_out[bank.slot(id)] = bank.dp(id); });
     return 0;
+}
+
+int clo_sparse_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                     const clo_chain_params* cp, uint32_t* chain_out, uint64_t* chain_len, float* dp_out) {
+    return clo_sparse_chain_ex(g1, g2, ms, num_match_sets, cp, 0, chain_out, chain_len, dp_out);
 }
 
 }  // extern "C"

@@ -58,9 +58,11 @@ def chain_lib():
     return _chain
 
 
-def oracle_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None, want_dp=False):
+def oracle_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None, want_dp=False, global_anchoring=False):
     """algo 'affine' -> sparse_affine_chain_dp, 'sparse' -> sparse_chain_dp; returns chain (n,3) [and dp values]"""
     lib = chain_lib()
+    if global_anchoring:
+        return _oracle_chain_global(lib, algo, g1, g2, ms, scale, params, num_match_sets, want_dp)
     params = params or default_chain_params()
     n = ms.n_sets if num_match_sets is None else num_match_sets
     c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
@@ -78,20 +80,47 @@ def oracle_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None, 
     return (chain, dp) if want_dp else chain
 
 
-def ref_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None):
+def _oracle_chain_global(lib, algo, g1, g2, ms, scale, params, num_match_sets, want_dp):
+    from centrolign_amd.capi import BaseGraphC
+    params = params or default_chain_params()
+    n = ms.n_sets if num_match_sets is None else num_match_sets
+    c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
+    out = np.zeros((max(ms.n_pairs(), 1), 3), np.uint32)
+    dp = np.zeros(max(ms.n_pairs(), 1), np.float32) if want_dp else None
+    ln = C.c_uint64(0)
+    dpp = dp.ctypes.data if want_dp else None
+    if algo == "affine":
+        lib.clo_sparse_affine_chain_ex.restype = C.c_int
+        lib.clo_sparse_affine_chain_ex.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
+                                                   C.POINTER(CloChainParams), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64),
+                                                   C.c_void_p, C.c_void_p]
+        rc = lib.clo_sparse_affine_chain_ex(C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale), 1,
+                                            out.ctypes.data, C.byref(ln), dpp, None)
+    else:
+        lib.clo_sparse_chain_ex.restype = C.c_int
+        lib.clo_sparse_chain_ex.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
+                                            C.POINTER(CloChainParams), C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+        rc = lib.clo_sparse_chain_ex(C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), 1, out.ctypes.data, C.byref(ln), dpp)
+    if rc:
+        raise RuntimeError("chain oracle failed: %d" % rc)
+    chain = out[:int(ln.value)].copy()
+    return (chain, dp) if want_dp else chain
+
+
+def ref_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None, global_anchoring=False):
     """the compiled reference's DP on the same flat inputs; returns (chain (n,3), seconds)"""
     lib = ref_lib()
     from centrolign_amd.capi import BaseGraphC
-    lib.ref_chain_dp.restype = C.c_int
-    lib.ref_chain_dp.argtypes = [C.c_int, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
-                                 C.POINTER(CloChainParams), C.c_double, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.ref_chain_dp_ex.restype = C.c_int
+    lib.ref_chain_dp_ex.argtypes = [C.c_int, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.c_uint64,
+                                    C.POINTER(CloChainParams), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     params = params or default_chain_params()
     n = ms.n_sets if num_match_sets is None else num_match_sets
     c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
     out = np.zeros((max(ms.n_pairs(), 1), 3), np.uint32)
     ln, secs = C.c_uint64(0), C.c_double(0)
-    rc = lib.ref_chain_dp(0 if algo == "affine" else 1, C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale),
-                          out.ctypes.data, C.byref(ln), C.byref(secs))
+    rc = lib.ref_chain_dp_ex(0 if algo == "affine" else 1, C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale),
+                             int(global_anchoring), out.ctypes.data, C.byref(ln), C.byref(secs))
     if rc:
         raise RuntimeError("ref_chain_dp failed: %d" % rc)
     return out[:int(ln.value)].copy(), secs.value
@@ -252,3 +281,32 @@ def budget_subset(ms, max_pairs, seed=0):
             keep.append(int(s)); tot += int(pairs[s])
     keep.sort()
     return subset_match_sets(ms, keep)
+
+
+def ref_anchor_chain(g1, g2, ms, max_num_match_pairs=1250000, score_scale=1.0, autocalibrate=True, params=None,
+                     global_anchoring=True, fill_in=False):
+    """the compiled reference's Anchorer::anchor_chain (anchorer.hpp:958-996) on flat inputs; same dict as
+    capi.Context.anchor_chain"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_anchor_chain.restype = C.c_int
+    lib.ref_anchor_chain.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.POINTER(CloChainParams),
+                                     C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9
+    params = params or default_chain_params()
+    c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
+    cap = max(ms.n_pairs(), 1)
+    anchors = np.zeros((cap, 3), np.uint32)
+    gb, ga = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+    gsb, gsa, sc = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    n = C.c_uint64(0)
+    order = np.zeros(max(ms.n_sets, 1), np.uint64)
+    scale = C.c_double(0)
+    rc = lib.ref_anchor_chain(C.byref(c1), C.byref(c2), C.byref(mc), C.byref(params), int(global_anchoring), int(max_num_match_pairs),
+                              float(score_scale), int(autocalibrate), int(fill_in), 0, anchors.ctypes.data, gb.ctypes.data,
+                              ga.ctypes.data, gsb.ctypes.data, gsa.ctypes.data, sc.ctypes.data, C.addressof(n), order.ctypes.data,
+                              C.addressof(scale))
+    if rc:
+        raise RuntimeError("ref_anchor_chain failed: %d" % rc)
+    k = int(n.value)
+    return dict(chain=anchors[:k].copy(), gap_before=gb[:k].copy(), gap_after=ga[:k].copy(), gap_score_before=gsb[:k].copy(),
+                gap_score_after=gsa[:k].copy(), score=sc[:k].copy(), set_order=order[:ms.n_sets].copy(), scale=float(scale.value))

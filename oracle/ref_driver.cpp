@@ -17,6 +17,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "centrolign/alignment.hpp"
@@ -385,14 +386,25 @@ struct OpenAnchorer : public Anchorer {
     explicit OpenAnchorer(const ScoreFunction& sf) : Anchorer(sf) {}
     using Anchorer::sparse_affine_chain_dp;
     using Anchorer::sparse_chain_dp;
+    using Anchorer::estimate_score_scale;
 };
 
 extern "C" {
 
 /* algo 0: sparse_affine_chain_dp (anchorer.hpp:1812-2471), algo 1: sparse_chain_dp (:1511-1750); local anchoring,
  * the default (non memory-restrained) integer widths of anchor_chain (:1258-1290) */
+int ref_chain_dp_ex(int algo, const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                    const clo_chain_params* cp, double local_scale, int global_anchoring, uint32_t* chain_out, uint64_t* chain_len,
+                    double* seconds_out);
 int ref_chain_dp(int algo, const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
                  const clo_chain_params* cp, double local_scale, uint32_t* chain_out, uint64_t* chain_len, double* seconds_out) {
+    return ref_chain_dp_ex(algo, g1, g2, ms, num_match_sets, cp, local_scale, 0, chain_out, chain_len, seconds_out);
+}
+
+/* global_anchoring != 0: sources = next(src sentinel), sinks = previous(snk sentinel), as anchorer.hpp:1069-1076 */
+int ref_chain_dp_ex(int algo, const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t num_match_sets,
+                    const clo_chain_params* cp, double local_scale, int global_anchoring, uint32_t* chain_out, uint64_t* chain_len,
+                    double* seconds_out) {
     SentinelTableau t1, t2;
     BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
     std::vector<match_set_t> sets(ms->n_sets);
@@ -418,20 +430,85 @@ int ref_chain_dp(int algo, const cl_base_graph* g1, const cl_base_graph* g2, con
     using SmallDistMatchVector = std::vector<std::pair<uint32_t, SmallMatchBank::match_id_t>>;
     using FwdEdges = ForwardEdges<uint32_t, uint8_t>;
     std::vector<anchor_t> chain;
+    const std::vector<uint64_t>* s1 = global_anchoring ? &b1.next(t1.src_id) : nullptr;
+    const std::vector<uint64_t>* s2 = global_anchoring ? &b2.next(t2.src_id) : nullptr;
+    const std::vector<uint64_t>* k1 = global_anchoring ? &b1.previous(t1.snk_id) : nullptr;
+    const std::vector<uint64_t>* k2 = global_anchoring ? &b2.previous(t2.snk_id) : nullptr;
     auto a = std::chrono::steady_clock::now();
     if (algo == 0)
         chain = an.sparse_affine_chain_dp<uint32_t, uint16_t, uint32_t, int32_t, uint32_t, float, SmallShiftMatchVector, SmallDistMatchVector,
                                           std::vector<uint32_t>, std::vector<uint32_t>, SmallMatchBank, FwdEdges>(
-            sets, b1, b2, pm1, pm2, go, ge, local_scale, num_match_sets, true, nullptr, nullptr, nullptr, nullptr, nullptr);
+            sets, b1, b2, pm1, pm2, go, ge, local_scale, num_match_sets, true, s1, s2, k1, k2, nullptr);
     else
         chain = an.sparse_chain_dp<uint32_t, uint32_t, uint16_t, uint32_t, float, SmallDistMatchVector, std::vector<uint32_t>, SmallMatchBank, FwdEdges>(
-            sets, b1, pm1, pm2, num_match_sets, true, nullptr, nullptr, nullptr, nullptr, nullptr);
+            sets, b1, pm1, pm2, num_match_sets, true, s1, s2, k1, k2, nullptr);
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
     *chain_len = chain.size();
     for (size_t i = 0; i < chain.size(); ++i) {
         chain_out[3 * i] = (uint32_t)chain[i].match_set;
         chain_out[3 * i + 1] = (uint32_t)chain[i].idx1;
         chain_out[3 * i + 2] = (uint32_t)chain[i].idx2;
+    }
+    return 0;
+}
+
+/* Anchorer::anchor_chain (the public entry, anchorer.hpp:958-996) on flat inputs.  set_order_out[k] = index (in the
+ * caller's arrays) of the match set that sits at position k of the vector after the call (the call reorders it,
+ * :1108-1173); anchors_out holds (match_set position, idx1, idx2).  Buffers sized for n_pairs anchors / n_sets sets. */
+int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, const clo_chain_params* cp,
+                     int global_anchoring, uint64_t max_num_match_pairs, double score_scale, int autocalibrate, int fill_in,
+                     int split_branching, uint32_t* anchors_out, int64_t* gap_before, int64_t* gap_after, double* gap_score_before,
+                     double* gap_score_after, double* score, uint64_t* n_anchors, uint64_t* set_order_out, double* scale_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    std::vector<match_set_t> sets(ms->n_sets);
+    std::map<std::vector<std::vector<uint64_t>>, uint64_t> identity;
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
+            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
+        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
+            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
+        sets[s].count1 = ms->count1[s];
+        sets[s].count2 = ms->count2[s];
+        sets[s].full_length = ms->full_length[s];
+        if (!identity.emplace(sets[s].walks1, s).second) return -2;   // sets must be told apart by their walks
+    }
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    sf.score_scale = score_scale;
+    OpenAnchorer an(sf);
+    for (int i = 0; i < 3; ++i) { an.gap_open[i] = cp->gap_open[i]; an.gap_extend[i] = cp->gap_extend[i]; }
+    an.global_anchoring = global_anchoring != 0;
+    an.max_num_match_pairs = max_num_match_pairs;
+    an.autocalibrate_gap_penalties = autocalibrate != 0;
+    an.do_fill_in_anchoring = fill_in != 0;
+    an.split_matches_at_branchpoints = split_branching != 0;
+    an.chaining_algorithm = Anchorer::SparseAffine;
+    PathMerge<uint32_t, uint8_t> pm1(b1, t1), pm2(b2, t2);
+    // the two steps of the public entry, run one after the other so that the estimated scale can be reported
+    double scale = 1.0;
+    if (split_branching) return -3;   // (would have to run before the estimate; not exposed here)
+    if (autocalibrate) scale = an.estimate_score_scale(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, nullptr);
+    std::vector<anchor_t> chain = an.anchor_chain(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, &scale);
+    if (scale_out) *scale_out = scale;
+    for (uint64_t k = 0; k < sets.size(); ++k) {
+        auto it = identity.find(sets[k].walks1);
+        if (it == identity.end()) return -4;
+        set_order_out[k] = it->second;
+    }
+    *n_anchors = chain.size();
+    for (size_t i = 0; i < chain.size(); ++i) {
+        anchors_out[3 * i] = (uint32_t)chain[i].match_set;
+        anchors_out[3 * i + 1] = (uint32_t)chain[i].idx1;
+        anchors_out[3 * i + 2] = (uint32_t)chain[i].idx2;
+        gap_before[i] = chain[i].gap_before;
+        gap_after[i] = chain[i].gap_after;
+        gap_score_before[i] = chain[i].gap_score_before;
+        gap_score_after[i] = chain[i].gap_score_after;
+        score[i] = chain[i].score;
     }
     return 0;
 }

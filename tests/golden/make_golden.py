@@ -155,7 +155,25 @@ def main():
                 out[tag + ".scale"] = np.array([scale])
                 out[tag + ".chain_sparse"], _ = po.ref_chain("sparse", g1, g2, ms)
                 out[tag + ".chain_affine"], _ = po.ref_chain("affine", g1, g2, ms, scale=scale)
+                # the same with Anchorer::global_anchoring (the CLI default): sources/sinks = the graph's end nodes
+                out[tag + ".chain_sparse_global"], _ = po.ref_chain("sparse", g1, g2, ms, global_anchoring=True)
+                out[tag + ".chain_affine_global"], _ = po.ref_chain("affine", g1, g2, ms, scale=scale, global_anchoring=True)
             np.savez_compressed(os.path.join(HERE, "chain4_30k_merge%d.npz" % m), **out)
+        # 6b. Anchorer::anchor_chain seam (budgeted selection + reorder, scale estimate, affine chain, annotation) with
+        #     do_fill_in_anchoring = split_matches_at_branchpoints = false; "g" = global anchoring (CLI default), "l" = local
+        for m in range(int(dd["n_merges"][0])):
+            pre = "m%d." % m
+            g1, g2 = po.graphs_from_dump(dd, pre)
+            ms = po.budget_subset(po.MatchSets.from_dump(dd, pre), 60000, seed=20 + m)
+            out = {"score_scale": dd[pre + "score_scale"], "max_num_match_pairs": np.array([20000], np.uint64)}
+            for k in po.MatchSets._DT:
+                out["ms." + k] = getattr(ms, k)
+            for tag, glob, auto in (("g", True, True), ("l", False, True), ("n", True, False)):
+                r = po.ref_anchor_chain(g1, g2, ms, max_num_match_pairs=20000, score_scale=float(dd[pre + "score_scale"][0]),
+                                        autocalibrate=auto, global_anchoring=glob)
+                for k, v in r.items():
+                    out["%s.%s" % (tag, k)] = np.asarray(v)
+            np.savez_compressed(os.path.join(HERE, "anchor4_30k_merge%d.npz" % m), **out)
     else:
         print("skip stitch-level fixtures (no dump at %s)" % path)
     # 7. despecify_indel_breakpoints: random anchor chains -> the reference's kept set and updated gap fields

@@ -25,6 +25,11 @@ def test_chain_oracle_matches_golden(name):
         got = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=float(z[tag + ".scale"][0]))
         assert np.array_equal(got, z[tag + ".chain_affine"])
         assert len(got) > 50
+        # Anchorer::global_anchoring (the CLI default): lead / final indels to the graph's ends are part of the score
+        got = po.oracle_chain("sparse", graphs[0], graphs[1], ms, global_anchoring=True)
+        assert np.array_equal(got, z[tag + ".chain_sparse_global"])
+        got = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=float(z[tag + ".scale"][0]), global_anchoring=True)
+        assert np.array_equal(got, z[tag + ".chain_affine_global"])
 
 
 def test_chain_is_collinear():
@@ -54,5 +59,6 @@ def test_chain_oracle_vs_compiled_reference_live(name):
     for seed, budget, scale in ((1, 3000, 1.0), (2, 8000, 0.1)):
         ms = po.budget_subset(full, budget, seed=seed)
         for algo in ("sparse", "affine"):
-            ref, _ = po.ref_chain(algo, graphs[0], graphs[1], ms, scale=scale)
-            assert np.array_equal(po.oracle_chain(algo, graphs[0], graphs[1], ms, scale=scale), ref)
+            for glob in (False, True):
+                ref, _ = po.ref_chain(algo, graphs[0], graphs[1], ms, scale=scale, global_anchoring=glob)
+                assert np.array_equal(po.oracle_chain(algo, graphs[0], graphs[1], ms, scale=scale, global_anchoring=glob), ref)

@@ -15,42 +15,75 @@ pytestmark = pytest.mark.gpu
 FILES = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("chain4_"))
 
 
+GLOBAL = pytest.mark.parametrize("glob", [False, True], ids=["local", "global"])  # Anchorer::global_anchoring
+
+
+@GLOBAL
 @pytest.mark.parametrize("name", FILES)
-def test_chain_matches_reference_golden(gpu_ctx, name):
+def test_chain_matches_reference_golden(gpu_ctx, name, glob):
     z = np.load(os.path.join(H.GOLDEN, name))
     _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
     for tag in ("a", "b"):
         ms = capi.MatchSets(**{k: z["%s.ms.%s" % (tag, k)] for k in capi.MatchSets._DT})
         scale = float(z[tag + ".scale"][0])
-        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale, want_dp=True)
-        want_chain, want_dp = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=scale, want_dp=True)
+        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale, want_dp=True,
+                                          params=capi.default_chain_params(global_anchoring=glob))
+        want_chain, want_dp = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=scale, want_dp=True, global_anchoring=glob)
         assert np.array_equal(got["dp"].view(np.uint32), want_dp[:len(got["dp"])].view(np.uint32)), "DP values differ"
-        assert np.array_equal(got["chain"], z[tag + ".chain_affine"])
+        assert np.array_equal(got["chain"], z[tag + (".chain_affine_global" if glob else ".chain_affine")])
         assert np.array_equal(got["chain"], want_chain)
 
 
+@GLOBAL
 @pytest.mark.parametrize("seed,budget,scale", [(3, 1500, 1.0), (4, 12000, 0.05), (5, 30000, 0.6)])
-def test_chain_vs_oracle_other_subsets(gpu_ctx, seed, budget, scale):
+def test_chain_vs_oracle_other_subsets(gpu_ctx, seed, budget, scale, glob):
     name = FILES[seed % len(FILES)]
     z = np.load(os.path.join(H.GOLDEN, name))
     _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
     full = capi.MatchSets(**{k: z["a.ms." + k] for k in capi.MatchSets._DT})
     ms = po.budget_subset(full, budget, seed=seed)
-    got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale, want_dp=True)
-    want_chain, want_dp = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=scale, want_dp=True)
+    got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale, want_dp=True,
+                                      params=capi.default_chain_params(global_anchoring=glob))
+    want_chain, want_dp = po.oracle_chain("affine", graphs[0], graphs[1], ms, scale=scale, want_dp=True, global_anchoring=glob)
     assert np.array_equal(got["dp"].view(np.uint32), want_dp[:len(got["dp"])].view(np.uint32))
     assert np.array_equal(got["chain"], want_chain)
 
 
+@GLOBAL
 @pytest.mark.parametrize("name", FILES)
-def test_sparse_chain_matches_reference_golden(gpu_ctx, name):
+def test_sparse_chain_matches_reference_golden(gpu_ctx, name, glob):
     """sparse_chain_dp (the gap-free chaining of estimate_score_scale / leaf calibration) on the GPU"""
     z = np.load(os.path.join(H.GOLDEN, name))
     _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
     for tag in ("a", "b"):
         ms = capi.MatchSets(**{k: z["%s.ms.%s" % (tag, k)] for k in capi.MatchSets._DT})
-        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, want_dp=True, sparse=True)
-        want_chain, want_dp = po.oracle_chain("sparse", graphs[0], graphs[1], ms, want_dp=True)
+        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, want_dp=True, sparse=True,
+                                          params=capi.default_chain_params(global_anchoring=glob))
+        want_chain, want_dp = po.oracle_chain("sparse", graphs[0], graphs[1], ms, want_dp=True, global_anchoring=glob)
         assert np.array_equal(got["dp"].view(np.uint32), want_dp[:len(got["dp"])].view(np.uint32)), "DP values differ"
-        assert np.array_equal(got["chain"], z[tag + ".chain_sparse"])
+        assert np.array_equal(got["chain"], z[tag + (".chain_sparse_global" if glob else ".chain_sparse")])
         assert np.array_equal(got["chain"], want_chain)
+
+
+ANCHOR_FILES = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("anchor4_"))
+
+
+@pytest.mark.parametrize("tag,glob,auto", [("g", True, True), ("l", False, True), ("n", True, False)])
+@pytest.mark.parametrize("name", ANCHOR_FILES)
+def test_anchor_chain_matches_reference_golden(gpu_ctx, name, tag, glob, auto):
+    """cl_anchor_chain == Anchorer::anchor_chain of the compiled reference (fill-in and branch splitting off): the same
+    reordering of the caller's match sets, the same estimated scale, the same chain with the same gap / score annotation"""
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("anchor4_", "stitch4_"))
+    ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
+    got = gpu_ctx.anchor_chain(graphs[0], graphs[1], ms, max_num_match_pairs=int(z["max_num_match_pairs"][0]),
+                               score_scale=float(z["score_scale"][0]), autocalibrate=auto,
+                               params=capi.default_chain_params(global_anchoring=glob))
+    assert got["scale"] == float(z[tag + ".scale"])
+    assert np.array_equal(got["set_order"], z[tag + ".set_order"])
+    assert np.array_equal(got["chain"], z[tag + ".chain"])
+    for k in ("gap_before", "gap_after", "gap_score_before", "gap_score_after"):
+        assert np.array_equal(got[k], z["%s.%s" % (tag, k)]), k
+    # anchor_t::score is a double that the reference evaluates under -ffast-math (its CMakeLists.txt:9): the last bits are
+    # the compiler's choice, so this one field is compared to 1e-12 relative (the float DP weights derived from it are exact)
+    assert np.allclose(got["score"], z[tag + ".score"], rtol=1e-12, atol=0)
