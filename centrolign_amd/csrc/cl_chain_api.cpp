@@ -147,10 +147,16 @@ struct Combo {
     DevBuf<int32_t> d_sigma, d_q;
     DevBuf<float> d_val;
     DevBuf<int> d_acc;
-    // lazily built for tie resolution
-    std::vector<uint32_t> ortho_order;  // record indices sorted by (sigma, slot)
-    std::vector<uint32_t> ortho_heap, ortho_rank_of_heap;
-    std::unordered_map<int32_t, std::vector<uint32_t>> by_diag;  // gap-free trees: records of each shift
+    // lazily built for tie resolution, per chaining instance of the batch
+    struct SubRecs {
+        std::vector<uint32_t> recs;         // the instance's records in this combination
+        std::vector<uint32_t> ortho_order;  // ... sorted by (sigma, slot)
+        std::vector<uint32_t> ortho_heap, ortho_rank_of_heap;
+        std::unordered_map<int32_t, std::vector<uint32_t>> by_diag;  // gap-free trees: records of each shift
+        bool diag_built = false;
+    };
+    std::unordered_map<uint32_t, SubRecs> per_sub;
+    bool split_built = false;
     void release() {
         d_rec_s.release(); d_ins_t.release(); d_off.release(); d_prefix.release(); d_qt.release(); d_qoff.release();
         d_sigma.release(); d_q.release(); d_val.release(); d_acc.release();
@@ -181,105 +187,161 @@ void cl_chain_result_free(cl_chain_result* r) {
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------------------------------------------------
+// chain_dp_batch: K independent chaining instances in ONE device pass.
+//
 // sparse == false: sparse_affine_chain_dp (anchorer.hpp:1812-2471); sparse == true: sparse_chain_dp (:1511-1750), which is the
 // same sweep with ONE tree per (chain of e1, chain of e2), no shift condition and no gap cost: on the device it is the
 // affine machinery with every shift set to 0, so that only the "same diagonal" maximum is ever fed.
-static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
-                         uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp, bool sparse,
-                         cl_chain_result* out) {
-    if (!ctx || !g1 || !g2 || !ms || !cp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
-    memset(out, 0, sizeof(*out));
-    if (num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+//
+// Batching (the fill-in re-anchoring of anchorer.hpp:619-699 runs one small DP per gap of the chain, thousands per merge):
+// the device only ever COMPARES the path coordinates (index of the end node / predecessor index of the start node), the
+// arithmetic uses the shifts, which are stored separately.  Instance k therefore gets its graph-1 coordinates shifted UP by
+// the total size of the instances before it and its graph-2 coordinates shifted up by the total size of the instances AFTER
+// it: a record of another instance then fails one of the two range conditions (index1 <= query1, index2 < query2), and
+// the whole batch is one all-pairs sweep over the concatenated match pairs.
+namespace {
+
+struct ChainSub {
+    const cl_base_graph* g[2] = {nullptr, nullptr};   // DP orientation: g[0] plays graph1
+    bool tableau = true;                               // graphs carry sentinels: PathMerge gets the pseudo-path (path_merge.hpp:148-160)
+    const cl_match_sets* ms = nullptr;                 // DP orientation
+    uint64_t num_match_sets = 0;
+    bool anchored = false;                             // sources / sinks given (global anchoring, fill-in)
+    std::vector<uint32_t> src[2], snk[2];
+    std::vector<uint32_t> tag[2];                      // local chain id -> batch-wide chain tag; empty = identity
+};
+
+struct ChainSubResult {
+    std::vector<uint32_t> chain;     // (set, idx1, idx2) per anchor, DP orientation
+    std::vector<int64_t> gap;        // affine only: [n+1] gap before anchor i; [0] from the sources, [n] to the sinks
+    std::vector<double> gap_score;   // (anchorer.hpp:2443-2468)
+    uint64_t n_ties = 0;
+};
+
+struct ChainTimings { float device_ms = 0, prep_ms = 0, index_ms = 0, traceback_ms = 0; uint64_t n_pairs = 0; };
+
+struct SubCtx {
+    clhost::PathMergeTable x[2];
+    PostSwitchTable sw[2];
+    std::vector<uint32_t> pos1, depth1;
+    std::vector<char> has_start, after_end;
+    uint32_t pair_lo = 0, pair_hi = 0;
+    uint32_t off_a = 0, off_b = 0;
+    float min_score = 0.0f;
+};
+
+struct Pair { uint32_t sub, set, i1, i2, b1, e1, b2, e2; };
+
+}  // namespace
+
+static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
+                          bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto T0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    const size_t K = subs.size();
+    results.assign(K, ChainSubResult());
+    std::vector<SubCtx> sc(K);
 
-    clhost::PathMergeTable x1, x2;
-    if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
-    PostSwitchTable sw1, sw2;
-    sw1.build(*g1, x1);
-    sw2.build(*g2, x2);
-    const uint64_t C1 = x1.chain_size(), C2 = x2.chain_size();
-    std::vector<uint32_t> order1;
-    clhost::topological_order(*g1, order1);
-    std::vector<uint32_t> pos1(g1->n_nodes);
-    for (uint32_t i = 0; i < order1.size(); ++i) pos1[order1[i]] = i;
-
-    // match pairs in MatchBank iteration order (match_bank.hpp:252-268): slot = position in that order
-    struct Pair { uint32_t set; uint32_t i1, i2; uint32_t b1, e1, b2, e2; };
+    // match pairs in MatchBank iteration order (match_bank.hpp:252-268), instance by instance: slot = position in that order
     std::vector<Pair> pairs;
-    std::vector<uint64_t> set_base(num_match_sets + 1, 0);
-    std::vector<char> has_start(g1->n_nodes, 0), after_end(g1->n_nodes, 0);
-    for (uint64_t s = 0; s < num_match_sets; ++s) {
-        const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
-        if (n1 >= 65535 || n2 >= 65535) { cl_set_error(ctx, "match set %llu has too many walks", (unsigned long long)s); return CL_ERR_INVALID_ARGUMENT; }
-        set_base[s + 1] = set_base[s] + n1 * n2;
-        for (uint64_t j = 0; j < n1; ++j) {
-            const uint64_t w1 = ms->set_off1[s] + j;
-            const uint32_t b1 = ms->nodes1[ms->walk_off1[w1]], e1 = ms->nodes1[ms->walk_off1[w1 + 1] - 1];
-            has_start[b1] = 1;
-            after_end[e1] = 1;
-            for (uint64_t k = 0; k < n2; ++k) {
-                const uint64_t w2 = ms->set_off2[s] + k;
-                pairs.push_back(Pair{(uint32_t)s, (uint32_t)j, (uint32_t)k, b1, e1, ms->nodes2[ms->walk_off2[w2]], ms->nodes2[ms->walk_off2[w2 + 1] - 1]});
-            }
-        }
-    }
-    const uint64_t M = pairs.size();
-    if (M >= (1ull << 31)) { cl_set_error(ctx, "too many match pairs"); return CL_ERR_INVALID_ARGUMENT; }
-    out->n_pairs = M;
-    if (M == 0) return CL_OK;
-    {   // nodes that follow the end of some match (anchorer.hpp:1776-1797)
-        std::vector<uint32_t> st;
-        for (uint64_t v = 0; v < g1->n_nodes; ++v)
-            if (after_end[v]) {
-                st.push_back((uint32_t)v);
-                while (!st.empty()) {
-                    const uint32_t h = st.back();
-                    st.pop_back();
-                    for (uint64_t e = g1->next_off[h]; e < g1->next_off[h + 1]; ++e)
-                        if (!after_end[g1->next_idx[e]]) { after_end[g1->next_idx[e]] = 1; st.push_back(g1->next_idx[e]); }
+    uint64_t min_len = UINT64_MAX, span_a = 0, span_b = 0;
+    for (size_t k = 0; k < K; ++k) {
+        const ChainSub& sb = subs[k];
+        const cl_match_sets* ms = sb.ms;
+        sc[k].pair_lo = (uint32_t)pairs.size();
+        if (sb.num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+        for (uint64_t s = 0; s < sb.num_match_sets; ++s) {
+            const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
+            if (n1 >= 65535 || n2 >= 65535) { cl_set_error(ctx, "match set %llu has too many walks", (unsigned long long)s); return CL_ERR_INVALID_ARGUMENT; }
+            if (n1 && n2) min_len = std::min<uint64_t>(min_len, ms->walk_off1[ms->set_off1[s] + 1] - ms->walk_off1[ms->set_off1[s]]);
+            for (uint64_t j = 0; j < n1; ++j) {
+                const uint64_t w1 = ms->set_off1[s] + j;
+                const uint32_t b1 = ms->nodes1[ms->walk_off1[w1]], e1 = ms->nodes1[ms->walk_off1[w1 + 1] - 1];
+                for (uint64_t q = 0; q < n2; ++q) {
+                    const uint64_t w2 = ms->set_off2[s] + q;
+                    pairs.push_back(Pair{(uint32_t)k, (uint32_t)s, (uint32_t)j, (uint32_t)q, b1, e1, ms->nodes2[ms->walk_off2[w2]], ms->nodes2[ms->walk_off2[w2 + 1] - 1]});
                 }
             }
+        }
+        if (pairs.size() >= (1ull << 31)) { cl_set_error(ctx, "too many match pairs"); return CL_ERR_INVALID_ARGUMENT; }
+        sc[k].pair_hi = (uint32_t)pairs.size();
+        if (sc[k].pair_hi > sc[k].pair_lo) { span_a += sb.g[0]->n_nodes + 2; span_b += sb.g[1]->n_nodes + 2; }
     }
-    // Processing order: by the DEPTH (longest path from a source) of the pair's first graph-1 node, stable in slot order.
-    // A predecessor m of m' must end strictly before m' starts, so depth(b1(m')) >= depth(b1(m)) + len(m): pairs whose
-    // start depths fall into the same window of min_len consecutive depths can never precede one another and are
-    // finalised together on the device ("group").
-    std::vector<uint32_t> depth1(g1->n_nodes, 0);
-    for (uint32_t v : order1)
-        for (uint64_t e = g1->next_off[v]; e < g1->next_off[v + 1]; ++e)
-            depth1[g1->next_idx[e]] = std::max(depth1[g1->next_idx[e]], depth1[v] + 1);
-    uint64_t min_len = UINT64_MAX;
-    for (uint64_t s = 0; s < num_match_sets; ++s) {
-        const uint64_t w0 = ms->set_off1[s];
-        if (ms->set_off1[s + 1] > w0 && ms->set_off2[s + 1] > ms->set_off2[s]) min_len = std::min<uint64_t>(min_len, ms->walk_off1[w0 + 1] - ms->walk_off1[w0]);
-    }
+    const uint64_t M = pairs.size();
+    tm.n_pairs = M;
+    if (M == 0) return CL_OK;
+    if (span_a >= 0xFFFFFFFFull || span_b >= 0xFFFFFFFFull) { cl_set_error(ctx, "batch too large for 32-bit path coordinates"); return CL_ERR_INVALID_ARGUMENT; }
     if (min_len == 0 || min_len == UINT64_MAX) min_len = 1;
+
+    // per-instance coordinate systems; chain tags -> dense combination table
+    uint32_t n_tag[2] = {0, 0};
+    {
+        uint64_t run_a = 0, run_b = span_b;
+        for (size_t k = 0; k < K; ++k) {
+            SubCtx& c = sc[k];
+            if (c.pair_hi == c.pair_lo) continue;
+            const ChainSub& sb = subs[k];
+            for (int side = 0; side < 2; ++side) {
+                if (!c.x[side].build(*sb.g[side], sb.tableau)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+                c.sw[side].build(*sb.g[side], c.x[side]);
+                for (uint32_t p = 0; p < c.x[side].chain_size(); ++p)
+                    n_tag[side] = std::max(n_tag[side], (sb.tag[side].empty() ? p : sb.tag[side][p]) + 1);
+            }
+            run_b -= sb.g[1]->n_nodes + 2;
+            c.off_a = (uint32_t)run_a;
+            c.off_b = (uint32_t)run_b;
+            run_a += sb.g[0]->n_nodes + 2;
+            const cl_base_graph& g1 = *sb.g[0];
+            std::vector<uint32_t> order1;
+            clhost::topological_order(g1, order1);
+            c.pos1.resize(g1.n_nodes);
+            for (uint32_t i = 0; i < order1.size(); ++i) c.pos1[order1[i]] = i;
+            // depth = longest path from a source: a predecessor m of m' ends strictly before m' starts, so
+            // depth(b1(m')) >= depth(b1(m)) + len(m); pairs whose start depths fall into one window of min_len consecutive
+            // depths can never precede one another and are finalised together on the device ("group")
+            c.depth1.assign(g1.n_nodes, 0);
+            for (uint32_t v : order1)
+                for (uint64_t e = g1.next_off[v]; e < g1.next_off[v + 1]; ++e)
+                    c.depth1[g1.next_idx[e]] = std::max(c.depth1[g1.next_idx[e]], c.depth1[v] + 1);
+            c.has_start.assign(g1.n_nodes, 0);
+            c.after_end.assign(g1.n_nodes, 0);
+            for (uint32_t s = c.pair_lo; s < c.pair_hi; ++s) { c.has_start[pairs[s].b1] = 1; c.after_end[pairs[s].e1] = 1; }
+            // nodes that follow the end of some match (anchorer.hpp:1776-1797)
+            std::vector<uint32_t> st;
+            for (uint64_t v = 0; v < g1.n_nodes; ++v)
+                if (c.after_end[v]) {
+                    st.push_back((uint32_t)v);
+                    while (!st.empty()) {
+                        const uint32_t h = st.back();
+                        st.pop_back();
+                        for (uint64_t e = g1.next_off[h]; e < g1.next_off[h + 1]; ++e)
+                            if (!c.after_end[g1.next_idx[e]]) { c.after_end[g1.next_idx[e]] = 1; st.push_back(g1.next_idx[e]); }
+                    }
+                }
+        }
+    }
+    auto tag_of = [&](uint32_t k, int side, uint32_t p) { return subs[k].tag[side].empty() ? p : subs[k].tag[side][p]; };
+
+    // processing order: by the depth of the pair's first graph-1 node, stable in slot order
     std::vector<uint32_t> by_s(M);  // sorted index -> slot
     std::iota(by_s.begin(), by_s.end(), 0u);
-    std::stable_sort(by_s.begin(), by_s.end(), [&](uint32_t a, uint32_t b) { return depth1[pairs[a].b1] < depth1[pairs[b].b1]; });
+    std::stable_sort(by_s.begin(), by_s.end(), [&](uint32_t a, uint32_t b) { return sc[pairs[a].sub].depth1[pairs[a].b1] < sc[pairs[b].sub].depth1[pairs[b].b1]; });
     std::vector<uint32_t> s_of_slot(M);
     for (uint32_t s = 0; s < M; ++s) s_of_slot[by_s[s]] = s;
 
     std::vector<float> weight(M);
     for (uint32_t s = 0; s < M; ++s) {
         const Pair& p = pairs[by_s[s]];
+        const cl_match_sets* ms = subs[p.sub].ms;
         const uint64_t w0 = ms->set_off1[p.set];
         weight[s] = (float)anchor_weight(*cp, ms->count1[p.set], ms->count2[p.set], ms->walk_off1[w0 + 1] - ms->walk_off1[w0], ms->full_length[p.set]);
     }
 
-    // Global anchoring (anchorer.hpp:1069-1076): sources = the nodes after the source sentinel, sinks = the nodes before the
-    // sink sentinel.  A chain's first anchor pays the lead indel from the sources (affine, :2026-2039) or must be reachable
-    // from them (sparse, :1562-1582); its last anchor pays the final indel to the sinks (:2426-2438 / :1724-1741).
-    const bool global = cp->global_anchoring != 0;
-    std::vector<uint32_t> src1, src2, snk1, snk2;
-    if (global) {
-        for (uint64_t e = g1->next_off[g1->src_id]; e < g1->next_off[g1->src_id + 1]; ++e) src1.push_back(g1->next_idx[e]);
-        for (uint64_t e = g2->next_off[g2->src_id]; e < g2->next_off[g2->src_id + 1]; ++e) src2.push_back(g2->next_idx[e]);
-        for (uint64_t e = g1->prev_off[g1->snk_id]; e < g1->prev_off[g1->snk_id + 1]; ++e) snk1.push_back(g1->prev_idx[e]);
-        for (uint64_t e = g2->prev_off[g2->snk_id]; e < g2->prev_off[g2->snk_id + 1]; ++e) snk2.push_back(g2->prev_idx[e]);
-    }
+    // Anchored chains (global anchoring, anchorer.hpp:1069-1076; fill-in, :683-693): a chain's first anchor pays the lead
+    // indel from the sources (affine, :2026-2039) or must be reachable from them (sparse, :1562-1582); its last anchor pays
+    // the final indel to the sinks (:2426-2438 / :1724-1741).
     auto score_gap = [&](int32_t gap) -> float {   // anchorer.hpp:1929-1944
         float score = CL_CHAIN_NEG;
         if (gap == 0) score = 0.0f;
@@ -287,13 +349,13 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
             for (int pw = 0; pw < 3; ++pw) score = std::max<float>(score, (float)(-local_scale * (cp->gap_open[pw] + cp->gap_extend[pw] * std::abs(gap))));
         return score;
     };
-    auto measure_gap = [&](uint32_t a1, uint32_t a2, uint32_t c1, uint32_t c2) -> int32_t {   // anchorer.hpp:1906-1927
+    auto measure_gap = [&](const SubCtx& c, uint32_t a1, uint32_t a2, uint32_t c1, uint32_t c2) -> int32_t {   // anchorer.hpp:1906-1927
         int32_t gap = INT32_MAX;
-        if ((a1 == c1 || x1.reachable(a1, c1)) && (a2 == c2 || x2.reachable(a2, c2)))
-            x1.for_each_chain_on(a1, [&](uint32_t p1) {
-                x2.for_each_chain_on(a2, [&](uint32_t p2) {
-                    const uint32_t src = x1.index_on(a1, p1) - x2.index_on(a2, p2);
-                    const uint32_t qry = x1.predecessor_index(c1, p1) - x2.predecessor_index(c2, p2) + sw1.distance(c1, p1) - sw2.distance(c2, p2);
+        if ((a1 == c1 || c.x[0].reachable(a1, c1)) && (a2 == c2 || c.x[1].reachable(a2, c2)))
+            c.x[0].for_each_chain_on(a1, [&](uint32_t p1) {
+                c.x[1].for_each_chain_on(a2, [&](uint32_t p2) {
+                    const uint32_t src = c.x[0].index_on(a1, p1) - c.x[1].index_on(a2, p2);
+                    const uint32_t qry = c.x[0].predecessor_index(c1, p1) - c.x[1].predecessor_index(c2, p2) + c.sw[0].distance(c1, p1) - c.sw[1].distance(c2, p2);
                     const int32_t here_gap = (int32_t)(src - qry);
                     if (std::abs(here_gap) < std::abs(gap)) gap = here_gap;
                 });
@@ -301,82 +363,84 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         return gap;
     };
     // the reference compares |gap| against the SIGNED running value (anchorer.hpp:1954, 1971, 1991)
-    auto gap_from_sources = [&](uint32_t c1, uint32_t c2) {
+    auto gap_from_sources = [&](uint32_t k, uint32_t c1, uint32_t c2) {
         int32_t best = INT32_MAX;
-        for (uint32_t a : src1) for (uint32_t b : src2) { const int32_t h = measure_gap(a, b, c1, c2); if (std::abs(h) < best) best = h; }
+        for (uint32_t a : subs[k].src[0]) for (uint32_t b : subs[k].src[1]) { const int32_t h = measure_gap(sc[k], a, b, c1, c2); if (std::abs(h) < best) best = h; }
         return best;
     };
-    auto gap_to_sinks = [&](uint32_t a1, uint32_t a2) {
+    auto gap_to_sinks = [&](uint32_t k, uint32_t a1, uint32_t a2) {
         int32_t best = INT32_MAX;
-        for (uint32_t c : snk1) for (uint32_t d : snk2) { const int32_t h = measure_gap(a1, a2, c, d); if (std::abs(h) < best) best = h; }
+        for (uint32_t c : subs[k].snk[0]) for (uint32_t d : subs[k].snk[1]) { const int32_t h = measure_gap(sc[k], a1, a2, c, d); if (std::abs(h) < best) best = h; }
         return best;
     };
-    std::vector<float> init_w(weight);   // the value a chain that STARTS at the pair has
-    std::vector<float> final_term;       // per slot
-    float min_score = 0.0f;
-    if (global) {
-        final_term.resize(M);
-        for (uint32_t s = 0; s < M; ++s) {
-            const Pair& p = pairs[by_s[s]];
-            if (!sparse) {
-                const float lead = score_gap(gap_from_sources(p.b1, p.b2));
-                init_w[s] = lead == CL_CHAIN_NEG ? CL_CHAIN_NEG : weight[s] + lead;
-                final_term[by_s[s]] = score_gap(gap_to_sinks(p.e1, p.e2));
-            } else {
-                bool f1 = false, f2 = false, t = false;
-                for (uint32_t a : src1) if (a == p.b1 || x1.reachable(a, p.b1)) { f1 = true; break; }
-                for (uint32_t b : src2) if (b == p.b2 || x2.reachable(b, p.b2)) { f2 = true; break; }
-                if (!f1 || !f2) init_w[s] = CL_CHAIN_NEG;
-                for (uint32_t c : snk1) {
-                    for (uint32_t d : snk2)
-                        if ((c == p.e1 || x1.reachable(p.e1, c)) && (d == p.e2 || x2.reachable(p.e2, d))) { t = true; break; }
-                    if (t) break;
-                }
-                final_term[by_s[s]] = t ? 0.0f : CL_CHAIN_NEG;
+    std::vector<float> init_w(weight);   // the value of a chain that STARTS at the pair
+    std::vector<float> final_term(M, 0.0f);  // per slot
+    for (uint32_t s = 0; s < M; ++s) {
+        const uint32_t slot = by_s[s];
+        const Pair& p = pairs[slot];
+        const ChainSub& sb = subs[p.sub];
+        if (!sb.anchored) continue;
+        const SubCtx& c = sc[p.sub];
+        if (!sparse) {
+            const float lead = score_gap(gap_from_sources(p.sub, p.b1, p.b2));
+            init_w[s] = lead == CL_CHAIN_NEG ? CL_CHAIN_NEG : weight[s] + lead;
+            final_term[slot] = score_gap(gap_to_sinks(p.sub, p.e1, p.e2));
+        } else {
+            bool f1 = false, f2 = false, t = false;
+            for (uint32_t a : sb.src[0]) if (a == p.b1 || c.x[0].reachable(a, p.b1)) { f1 = true; break; }
+            for (uint32_t b : sb.src[1]) if (b == p.b2 || c.x[1].reachable(b, p.b2)) { f2 = true; break; }
+            if (!f1 || !f2) init_w[s] = CL_CHAIN_NEG;
+            for (uint32_t a : sb.snk[0]) {
+                for (uint32_t b : sb.snk[1])
+                    if ((a == p.e1 || c.x[0].reachable(p.e1, a)) && (b == p.e2 || c.x[1].reachable(p.e2, b))) { t = true; break; }
+                if (t) break;
             }
-        }
-        if (!sparse) {   // the score of aligning nothing: one indel from the sources to the sinks (anchorer.hpp:2419-2424)
-            int32_t best = INT32_MAX;
-            for (uint32_t c : snk1) for (uint32_t d : snk2) for (uint32_t a : src1) for (uint32_t b : src2) {
-                const int32_t h = measure_gap(a, b, c, d);
-                if (std::abs(h) < best) best = h;
-            }
-            min_score = score_gap(best);
+            final_term[slot] = t ? 0.0f : CL_CHAIN_NEG;
         }
     }
+    if (!sparse)   // the score of aligning nothing: one indel from the sources to the sinks (anchorer.hpp:2419-2424)
+        for (size_t k = 0; k < K; ++k) {
+            if (!subs[k].anchored || sc[k].pair_hi == sc[k].pair_lo) continue;
+            int32_t best = INT32_MAX;
+            for (uint32_t c : subs[k].snk[0]) for (uint32_t d : subs[k].snk[1]) for (uint32_t a : subs[k].src[0]) for (uint32_t b : subs[k].src[1]) {
+                const int32_t h = measure_gap(sc[k], a, b, c, d);
+                if (std::abs(h) < best) best = h;
+            }
+            sc[k].min_score = score_gap(best);
+        }
 
     // (chain1, chain2) combinations that hold at least one pair; the most populated one goes first (it is the one the
     // intra kernel keeps in registers)
-    std::map<std::pair<uint32_t, uint32_t>, uint32_t> combo_id;
+    std::vector<uint32_t> combo_of((size_t)n_tag[0] * n_tag[1], kNone);
     std::vector<Combo> combos;
     std::vector<uint32_t> rec_off(M + 1, 0), rec_combo, rec_pos;
     for (uint32_t s = 0; s < M; ++s) {
         const Pair& p = pairs[by_s[s]];
+        const SubCtx& c = sc[p.sub];
         bool first1 = true;
-        x1.for_each_chain_on(p.e1, [&](uint32_t p1) {
+        c.x[0].for_each_chain_on(p.e1, [&](uint32_t p1) {
             const bool take1 = !sparse || first1;   // sparse_chain_dp files a match under chain(e1) only (anchorer.hpp:1621-1630)
             first1 = false;
             if (!take1) return;
             bool first2 = true;
-            x2.for_each_chain_on(p.e2, [&](uint32_t p2) {
+            c.x[1].for_each_chain_on(p.e2, [&](uint32_t p2) {
                 const bool take2 = !sparse || first2;
                 first2 = false;
                 if (!take2) return;
-                auto key = std::make_pair(p1, p2);
-                auto it = combo_id.find(key);
-                if (it == combo_id.end()) {
-                    it = combo_id.emplace(key, (uint32_t)combos.size()).first;
+                uint32_t& ci = combo_of[(size_t)tag_of(p.sub, 0, p1) * n_tag[1] + tag_of(p.sub, 1, p2)];
+                if (ci == kNone) {
+                    ci = (uint32_t)combos.size();
                     combos.emplace_back();
-                    combos.back().p1 = p1;
-                    combos.back().p2 = p2;
+                    combos.back().p1 = tag_of(p.sub, 0, p1);
+                    combos.back().p2 = tag_of(p.sub, 1, p2);
                 }
-                Combo& c = combos[it->second];
-                rec_combo.push_back(it->second);
-                rec_pos.push_back((uint32_t)c.rec_s.size());
-                c.rec_s.push_back(s);
-                c.ins_t.push_back(x1.index_on(p.e1, p1));
-                c.off.push_back(x2.index_on(p.e2, p2));
-                c.sigma.push_back(sparse ? 0 : (int32_t)(x1.index_on(p.e1, p1) - x2.index_on(p.e2, p2)));
+                Combo& cb = combos[ci];
+                rec_combo.push_back(ci);
+                rec_pos.push_back((uint32_t)cb.rec_s.size());
+                cb.rec_s.push_back(s);
+                cb.ins_t.push_back(c.x[0].index_on(p.e1, p1) + c.off_a);
+                cb.off.push_back(c.x[1].index_on(p.e2, p2) + c.off_b);
+                cb.sigma.push_back(sparse ? 0 : (int32_t)(c.x[0].index_on(p.e1, p1) - c.x[1].index_on(p.e2, p2)));
             });
         });
         rec_off[s + 1] = (uint32_t)rec_combo.size();
@@ -388,7 +452,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         if (big != 0) {
             std::swap(combos[0], combos[big]);
             for (auto& rc : rec_combo) rc = rc == 0 ? (uint32_t)big : rc == big ? 0u : rc;
-            for (auto& kv : combo_id) kv.second = kv.second == 0 ? (uint32_t)big : kv.second == big ? 0u : kv.second;
+            for (auto& v : combo_of) v = v == 0 ? (uint32_t)big : v == big ? 0u : v;
         }
     }
     const uint32_t n_blocks = (uint32_t)((M + kChainBlock - 1) / kChainBlock);
@@ -396,15 +460,26 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         c.qt.assign(M, kNone);
         c.qoff.assign(M, 0);
         c.q.assign(M, 0);
-        for (uint32_t s = 0; s < M; ++s) {
-            const Pair& p = pairs[by_s[s]];
-            const uint32_t pr = x1.predecessor_index(p.b1, c.p1);
+    }
+    for (uint32_t s = 0; s < M; ++s) {
+        const Pair& p = pairs[by_s[s]];
+        const SubCtx& c = sc[p.sub];
+        if (!c.has_start[p.b1]) continue;
+        for (uint32_t p1 = 0; p1 < c.x[0].chain_size(); ++p1) {
+            const uint32_t pr = c.x[0].predecessor_index(p.b1, p1);
             // a forward edge exists only from a node that follows some match end (forward_edges.hpp:40-53)
-            if (pr == kNone || !has_start[p.b1] || !after_end[x1.node_at(c.p1, pr)]) continue;
-            c.qt[s] = pr;
-            c.qoff[s] = x2.predecessor_index(p.b2, c.p2) + 1u;
-            c.q[s] = sparse ? 0 : (int32_t)(pr - x2.predecessor_index(p.b2, c.p2) + sw1.distance(p.b1, c.p1) - sw2.distance(p.b2, c.p2));
+            if (pr == kNone || !c.after_end[c.x[0].node_at(p1, pr)]) continue;
+            for (uint32_t p2 = 0; p2 < c.x[1].chain_size(); ++p2) {
+                const uint32_t ci = combo_of[(size_t)tag_of(p.sub, 0, p1) * n_tag[1] + tag_of(p.sub, 1, p2)];
+                if (ci == kNone) continue;
+                Combo& cb = combos[ci];
+                cb.qt[s] = pr + c.off_a;
+                cb.qoff[s] = c.x[1].predecessor_index(p.b2, p2) + 1u + c.off_b;
+                cb.q[s] = sparse ? 0 : (int32_t)(pr - c.x[1].predecessor_index(p.b2, p2) + c.sw[0].distance(p.b1, p1) - c.sw[1].distance(p.b2, p2));
+            }
         }
+    }
+    for (Combo& c : combos) {
         c.prefix.assign(n_blocks + 1, 0);
         size_t r = 0;
         for (uint32_t b = 0; b <= n_blocks; ++b) {
@@ -443,7 +518,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     CH(d_rec_off.upload(ctx, rec_off)); CH(d_rec_combo.upload(ctx, rec_combo)); CH(d_rec_pos.upload(ctx, rec_pos));
     {
         std::vector<uint32_t> group(M);
-        for (uint32_t s = 0; s < M; ++s) group[s] = (uint32_t)(depth1[pairs[by_s[s]].b1] / min_len);
+        for (uint32_t s = 0; s < M; ++s) group[s] = (uint32_t)(sc[pairs[by_s[s]].sub].depth1[pairs[by_s[s]].b1] / min_len);
         CH(d_group.upload(ctx, group));
     }
     ClChainDevice D{};
@@ -460,7 +535,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
     D.params.scale = local_scale;
 
-    out->prep_ms = ms_since(T0);
+    tm.prep_ms += ms_since(T0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipEventCreate failed"); return CL_ERR_HIP; }
     auto hip_fail = [&](hipError_t e, const char* what) {
@@ -500,14 +575,14 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->aux[0]);
-    if (he != hipSuccess) {
-        for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
-        for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
-        return hip_fail(he, "chaining DP kernels");
-    }
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
-    (void)hipEventElapsedTime(&out->device_ms, ev0, ev1);
+    if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
+    {
+        float dev_ms = 0;
+        (void)hipEventElapsedTime(&dev_ms, ev0, ev1);
+        tm.device_ms += dev_ms;
+    }
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 
@@ -520,16 +595,6 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
     }
     if (he != hipSuccess) { cl_set_error(ctx, "download failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
 
-    // ---- optimum and traceback (anchorer.hpp:2483-2531) ----------------------------------------------------------
-    float opt = CL_CHAIN_NEG;
-    uint32_t best_slot = kNone;
-    for (uint32_t slot = 0; slot < M; ++slot) {
-        float v = dp_sorted[s_of_slot[slot]];
-        const float f = global ? final_term[slot] : 0.0f;
-        if (f == CL_CHAIN_NEG) v = f;
-        else v += f;
-        if (v > opt && v > min_score) { opt = v; best_slot = slot; }
-    }
     const auto T1 = std::chrono::steady_clock::now();
     // value index: per combination and tree kind, (encoded stored value, record) sorted by value
     std::vector<std::vector<std::vector<int>>> vkeys(combos.size(), std::vector<std::vector<int>>(7));
@@ -546,7 +611,7 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         if (he == hipSuccess) { rc = temp.alloc(ctx, temp_bytes); if (rc) he = hipErrorOutOfMemory; }
         for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
             const uint32_t n = (uint32_t)combos[ci].rec_s.size();
-            for (int kind = 0; kind < 7 && he == hipSuccess; ++kind) {
+            for (int kind = 0; kind < (sparse ? 1 : 7) && he == hipSuccess; ++kind) {
                 he = cl_chain_sort_values(combos[ci].d_val.p + (size_t)kind * n, n, k_in.p, i_in.p, k_out.p, i_out.p, temp.p, &temp_bytes, ctx->stream);
                 vkeys[ci][kind].resize(n);
                 vrecs[ci][kind].resize(n);
@@ -558,191 +623,271 @@ static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base
         k_in.release(); k_out.release(); i_in.release(); i_out.release(); temp.release();
         if (he != hipSuccess) { cl_set_error(ctx, "value index failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
     }
-    auto cleanup2 = [&]() { cleanup(); };
-    out->index_ms = ms_since(T1);
+    tm.index_ms += ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> chain_slots;
-    uint64_t n_ties = 0;
-    uint32_t here = best_slot;
-    while (here != kNone) {
-        chain_slots.push_back(here);
-        const uint32_t s = s_of_slot[here];
-        const float dpv = dp_sorted[s], w = weight[s];
-        if (!(dpv > init_w[s])) break;  // no candidate was strictly greater than the chain that starts here: chain start
-        const Pair& p = pairs[here];
-        // the reference's candidate order: forward edges by the topological position of their source node, then chain1;
-        // chain2 ascending; gap-free tree, then trees 0..5 (anchorer.hpp:2352-2413)
-        std::vector<std::pair<uint32_t, uint32_t>> edges;  // (position of from-node, p1)
-        for (uint32_t p1 = 0; p1 < C1; ++p1) {
-            const uint32_t pr = x1.predecessor_index(p.b1, p1);
-            if (pr == kNone) continue;
-            const uint64_t from = x1.node_at(p1, pr);
-            if (has_start[p.b1] && after_end[from]) edges.emplace_back(pos1[from], p1);
-        }
-        std::sort(edges.begin(), edges.end());
-        int win_combo = -1, win_kind = -1;
-        for (size_t e = 0; e < edges.size() && win_combo < 0; ++e)
-            for (uint32_t p2 = 0; p2 < C2 && win_combo < 0; ++p2) {
-                auto it = combo_id.find(std::make_pair(edges[e].second, p2));
-                if (it == combo_id.end()) continue;  // empty trees
-                const Combo& c = combos[it->second];
-                const int* a = &acc[it->second][(size_t)s * 7];
-                for (int kind = 0; kind < (sparse ? 1 : 7); ++kind) {
-                    if (a[kind] == enc(CL_CHAIN_NEG)) continue;
-                    const float stored = dec(a[kind]);
-                    float cand;
-                    if (kind == 0) cand = stored + w;
-                    else {
-                        const int pw = kind - 1;
-                        const double pen = (pw % 2 == 1) ? local_scale * (cp->gap_open[pw / 2] + cp->gap_extend[pw / 2] * (double)c.q[s])
-                                                         : local_scale * (cp->gap_open[pw / 2] - cp->gap_extend[pw / 2] * (double)c.q[s]);
-                        cand = (float)((double)(stored + w) - pen);
-                    }
-                    if (cand == dpv) { win_combo = (int)it->second; win_kind = kind; break; }
-                }
-            }
-        if (win_combo < 0) { cl_set_error(ctx, "traceback: no candidate reproduces dp of pair %u", here); cleanup2(); return CL_ERR_HIP; }
-        Combo& c = combos[win_combo];
-        // every predecessor whose stored value equals the query's maximum and which lies in the query's range
-        std::vector<uint32_t> cand;
-        {
-            const int target = acc[win_combo][(size_t)s * 7 + win_kind];
-            const auto& keys = vkeys[win_combo][win_kind];
-            const auto& recs = vrecs[win_combo][win_kind];
-            const uint32_t qt = c.qt[s], qoff = c.qoff[s];
-            const int32_t qq = c.q[s];
-            for (size_t k = std::lower_bound(keys.begin(), keys.end(), target) - keys.begin(); k < keys.size() && keys[k] == target; ++k) {
-                const uint32_t r = recs[k];
-                if (c.rec_s[r] >= s) continue;
-                const int32_t sg = c.sigma[r];
-                const bool kind_ok = win_kind == 0 ? sg == qq : ((win_kind - 1) % 2 == 1 ? sg < qq : sg > qq);
-                if (kind_ok && c.ins_t[r] <= qt && c.off[r] < qoff) cand.push_back(r);
-            }
-        }
-        const uint32_t count = (uint32_t)cand.size();
-        if (count == 0) { cl_set_error(ctx, "traceback: query of pair %u has no predecessor at its maximum", here); cleanup2(); return CL_ERR_HIP; }
-        uint32_t win_rec;
-        if (count == 1) {
-            win_rec = cand[0];
-        } else {
-            ++n_ties;
-            auto slot_of_rec = [&](uint32_t r) { return by_s[c.rec_s[r]]; };
-            if (win_kind == 0) {
-                // gap-free tree of this diagonal: records with the same shift, keyed (offset, match id);
-                // inside an off-path subtree the earliest inserted wins, insertion order = (position of e1, slot)
-                // members of the tree, as (offset, slot, record-or-none): affine mode -> the records of this combination with
-                // the query's shift; sparse mode -> every pair whose e2 is filed under chain2, whatever its chain1
-                // (search_trees[i][j] is built from search_tree_data[j] for every i, anchorer.hpp:1581-1592)
-                struct Member { uint32_t off, slot, rec; };
-                std::vector<Member> mem;
-                if (!sparse) {
-                    const int32_t diag = c.q[s];
-                    if (c.by_diag.empty())  // records bucketed by shift, built once
-                        for (uint32_t r = 0; r < c.rec_s.size(); ++r) c.by_diag[c.sigma[r]].push_back(r);
-                    for (uint32_t r : c.by_diag[diag]) mem.push_back(Member{c.off[r], slot_of_rec(r), r});
-                } else {
-                    for (const Combo& oc : combos)
-                        if (oc.p2 == c.p2)
-                            for (uint32_t r = 0; r < oc.rec_s.size(); ++r) mem.push_back(Member{oc.off[r], by_s[oc.rec_s[r]], &oc == &c ? r : kNone});
-                }
-                std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; });
-                std::vector<uint32_t> members(mem.size());
-                for (size_t k = 0; k < mem.size(); ++k) members[k] = mem[k].rec;
-                auto off_of_member = [&](size_t k) { return mem[k].off; };
-                const size_t n = members.size();
-                auto h = heap_of_rank(n);
-                std::vector<uint32_t> rank_of_heap(n);
-                for (size_t r = 0; r < n; ++r) rank_of_heap[h[r]] = (uint32_t)r;
-                size_t rhi = 0;
-                while (rhi < n && off_of_member(rhi) < c.qoff[s]) ++rhi;
-                std::vector<std::pair<size_t, uint32_t>> ch;  // (heap node, record)
-                for (uint32_t r : cand) {
-                    const size_t rk = std::find(members.begin(), members.end(), r) - members.begin();
-                    ch.emplace_back(h[rk], r);
-                }
-                auto earlier = [&](uint32_t a, uint32_t b) {
-                    const uint32_t pa = pos1[pairs[slot_of_rec(a)].e1], pb = pos1[pairs[slot_of_rec(b)].e1];
-                    return pa != pb ? pa < pb : slot_of_rec(a) < slot_of_rec(b);
-                };
-                win_rec = kNone;
-                replay_units(n, rank_of_heap, 0, rhi,
-                             [&](size_t x) { for (auto& e : ch) if (e.first == x) { win_rec = e.second; return true; } return false; },
-                             [&](size_t x) {
-                                 for (auto& e : ch) if (in_subtree(e.first, x) && (win_rec == kNone || earlier(e.second, win_rec))) win_rec = e.second;
-                                 return win_rec != kNone;
-                             });
-            } else {
-                // orthogonal tree of this combination: all its records keyed ((shift, match id), offset); inside a
-                // cross tree the values are (score, outer index) pairs, so the larger outer heap index wins
-                if (c.ortho_order.empty()) {
-                    c.ortho_order.resize(c.rec_s.size());
-                    std::iota(c.ortho_order.begin(), c.ortho_order.end(), 0u);
-                    std::sort(c.ortho_order.begin(), c.ortho_order.end(), [&](uint32_t a, uint32_t b) {
-                        return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b);
-                    });
-                    c.ortho_heap = heap_of_rank(c.ortho_order.size());
-                    c.ortho_rank_of_heap.resize(c.ortho_order.size());
-                    for (size_t r = 0; r < c.ortho_order.size(); ++r) c.ortho_rank_of_heap[c.ortho_heap[r]] = (uint32_t)r;
-                }
-                const size_t n = c.ortho_order.size();
-                const int32_t qq = c.q[s];
-                const bool odd = (win_kind - 1) % 2 == 1;
-                // rank interval of the key1 range: shift < query (odd trees) or shift > query (even trees)
-                size_t lo = 0, hi = n;
-                auto first_ge = [&](int64_t v) {
-                    return (size_t)(std::partition_point(c.ortho_order.begin(), c.ortho_order.end(), [&](uint32_t r) { return (int64_t)c.sigma[r] < v; }) - c.ortho_order.begin());
-                };
-                if (odd) hi = first_ge(qq);
-                else lo = first_ge((int64_t)qq + 1);
-                std::vector<std::pair<size_t, uint32_t>> ch;
-                std::vector<uint32_t> rank_of_rec_local;
-                for (uint32_t r : cand) {
-                    const size_t rk = std::lower_bound(c.ortho_order.begin(), c.ortho_order.end(), r, [&](uint32_t a, uint32_t b) {
-                                          return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b);
-                                      }) - c.ortho_order.begin();
-                    ch.emplace_back(c.ortho_heap[rk], r);
-                }
-                win_rec = kNone;
-                size_t win_heap = 0;
-                replay_units(n, c.ortho_rank_of_heap, lo, hi,
-                             [&](size_t x) { for (auto& e : ch) if (e.first == x) { win_rec = e.second; return true; } return false; },
-                             [&](size_t x) {
-                                 for (auto& e : ch) if (in_subtree(e.first, x) && (win_rec == kNone || e.first > win_heap)) { win_rec = e.second; win_heap = e.first; }
-                                 return win_rec != kNone;
-                             });
-            }
-            if (win_rec == kNone) { cl_set_error(ctx, "traceback: tie resolution failed for pair %u", here); cleanup2(); return CL_ERR_HIP; }
-        }
-        here = by_s[c.rec_s[win_rec]];
-        if (chain_slots.size() > M) { cl_set_error(ctx, "traceback loop"); cleanup2(); return CL_ERR_HIP; }
-    }
-    std::reverse(chain_slots.begin(), chain_slots.end());
-    out->traceback_ms = ms_since(T2);
 
-    out->n_anchors = chain_slots.size();
-    out->n_ties = n_ties;
-    out->anchors = (uint32_t*)malloc((chain_slots.size() ? chain_slots.size() : 1) * 3 * sizeof(uint32_t));
-    if (want_dp) out->dp = (float*)malloc(M * sizeof(float));
-    if (!out->anchors || (want_dp && !out->dp)) { cl_chain_result_free(out); cleanup2(); return CL_ERR_OUT_OF_MEMORY; }
-    for (size_t i = 0; i < chain_slots.size(); ++i) {
-        const Pair& p = pairs[chain_slots[i]];
-        out->anchors[3 * i] = p.set;
-        out->anchors[3 * i + 1] = p.i1;
-        out->anchors[3 * i + 2] = p.i2;
+    // records of one instance inside a combination (the reference's trees belong to ONE chaining call)
+    auto sub_recs = [&](Combo& c, uint32_t k) -> Combo::SubRecs& {
+        if (!c.split_built) {
+            for (uint32_t r = 0; r < c.rec_s.size(); ++r) c.per_sub[pairs[by_s[c.rec_s[r]]].sub].recs.push_back(r);
+            c.split_built = true;
+        }
+        return c.per_sub[k];
+    };
+
+    // ---- optimum and traceback (anchorer.hpp:2483-2531), instance by instance -----------------------------------------
+    for (uint32_t k = 0; k < K; ++k) {
+        const SubCtx& sk = sc[k];
+        if (sk.pair_hi == sk.pair_lo) continue;
+        float opt = CL_CHAIN_NEG;
+        uint32_t best_slot = kNone;
+        for (uint32_t slot = sk.pair_lo; slot < sk.pair_hi; ++slot) {
+            float v = dp_sorted[s_of_slot[slot]];
+            const float f = final_term[slot];
+            if (f == CL_CHAIN_NEG) v = f;
+            else v += f;
+            if (v > opt && v > sk.min_score) { opt = v; best_slot = slot; }
+        }
+        std::vector<uint32_t> chain_slots;
+        uint64_t n_ties = 0;
+        uint32_t here = best_slot;
+        const uint32_t C1 = (uint32_t)sk.x[0].chain_size(), C2 = (uint32_t)sk.x[1].chain_size();
+        while (here != kNone) {
+            chain_slots.push_back(here);
+            const uint32_t s = s_of_slot[here];
+            const float dpv = dp_sorted[s], w = weight[s];
+            if (!(dpv > init_w[s])) break;  // no candidate was strictly greater than the chain that starts here: chain start
+            const Pair& p = pairs[here];
+            // the reference's candidate order: forward edges by the topological position of their source node, then chain1;
+            // chain2 ascending; gap-free tree, then trees 0..5 (anchorer.hpp:2352-2413)
+            std::vector<std::pair<uint32_t, uint32_t>> edges;  // (position of from-node, p1)
+            for (uint32_t p1 = 0; p1 < C1; ++p1) {
+                const uint32_t pr = sk.x[0].predecessor_index(p.b1, p1);
+                if (pr == kNone) continue;
+                const uint64_t from = sk.x[0].node_at(p1, pr);
+                if (sk.has_start[p.b1] && sk.after_end[from]) edges.emplace_back(sk.pos1[from], p1);
+            }
+            std::sort(edges.begin(), edges.end());
+            int win_combo = -1, win_kind = -1;
+            for (size_t e = 0; e < edges.size() && win_combo < 0; ++e)
+                for (uint32_t p2 = 0; p2 < C2 && win_combo < 0; ++p2) {
+                    const uint32_t ci = combo_of[(size_t)tag_of(k, 0, edges[e].second) * n_tag[1] + tag_of(k, 1, p2)];
+                    if (ci == kNone) continue;  // empty trees
+                    const Combo& c = combos[ci];
+                    const int* a = &acc[ci][(size_t)s * 7];
+                    for (int kind = 0; kind < (sparse ? 1 : 7); ++kind) {
+                        if (a[kind] == enc(CL_CHAIN_NEG)) continue;
+                        const float stored = dec(a[kind]);
+                        float cand;
+                        if (kind == 0) cand = stored + w;
+                        else {
+                            const int pw = kind - 1;
+                            const double pen = (pw % 2 == 1) ? local_scale * (cp->gap_open[pw / 2] + cp->gap_extend[pw / 2] * (double)c.q[s])
+                                                             : local_scale * (cp->gap_open[pw / 2] - cp->gap_extend[pw / 2] * (double)c.q[s]);
+                            cand = (float)((double)(stored + w) - pen);
+                        }
+                        if (cand == dpv) { win_combo = (int)ci; win_kind = kind; break; }
+                    }
+                }
+            if (win_combo < 0) { cl_set_error(ctx, "traceback: no candidate reproduces dp of pair %u", here); cleanup(); return CL_ERR_HIP; }
+            Combo& c = combos[win_combo];
+            // every predecessor whose stored value equals the query's maximum and which lies in the query's range
+            std::vector<uint32_t> cand;
+            {
+                const int target = acc[win_combo][(size_t)s * 7 + win_kind];
+                const auto& keys = vkeys[win_combo][win_kind];
+                const auto& recs = vrecs[win_combo][win_kind];
+                const uint32_t qt = c.qt[s], qoff = c.qoff[s];
+                const int32_t qq = c.q[s];
+                for (size_t i = std::lower_bound(keys.begin(), keys.end(), target) - keys.begin(); i < keys.size() && keys[i] == target; ++i) {
+                    const uint32_t r = recs[i];
+                    if (c.rec_s[r] >= s) continue;
+                    const int32_t sg = c.sigma[r];
+                    const bool kind_ok = win_kind == 0 ? sg == qq : ((win_kind - 1) % 2 == 1 ? sg < qq : sg > qq);
+                    if (kind_ok && c.ins_t[r] <= qt && c.off[r] < qoff) cand.push_back(r);
+                }
+            }
+            const uint32_t count = (uint32_t)cand.size();
+            if (count == 0) { cl_set_error(ctx, "traceback: query of pair %u has no predecessor at its maximum", here); cleanup(); return CL_ERR_HIP; }
+            uint32_t win_rec;
+            if (count == 1) {
+                win_rec = cand[0];
+            } else {
+                ++n_ties;
+                auto slot_of_rec = [&](uint32_t r) { return by_s[c.rec_s[r]]; };
+                if (win_kind == 0) {
+                    // gap-free tree of this diagonal: records with the same shift, keyed (offset, match id);
+                    // inside an off-path subtree the earliest inserted wins, insertion order = (position of e1, slot)
+                    // members of the tree, as (offset, slot, record-or-none): affine mode -> the records of this combination with
+                    // the query's shift; sparse mode -> every pair whose e2 is filed under chain2, whatever its chain1
+                    // (search_trees[i][j] is built from search_tree_data[j] for every i, anchorer.hpp:1581-1592)
+                    struct Member { uint32_t off, slot, rec; };
+                    std::vector<Member> mem;
+                    if (!sparse) {
+                        Combo::SubRecs& sr = sub_recs(c, k);
+                        if (!sr.diag_built) {  // records bucketed by shift, built once
+                            for (uint32_t r : sr.recs) sr.by_diag[c.sigma[r]].push_back(r);
+                            sr.diag_built = true;
+                        }
+                        for (uint32_t r : sr.by_diag[c.q[s]]) mem.push_back(Member{c.off[r], slot_of_rec(r), r});
+                    } else {
+                        for (Combo& oc : combos)
+                            if (oc.p2 == c.p2)
+                                for (uint32_t r : sub_recs(oc, k).recs) mem.push_back(Member{oc.off[r], by_s[oc.rec_s[r]], &oc == &c ? r : kNone});
+                    }
+                    std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; });
+                    std::vector<uint32_t> members(mem.size());
+                    for (size_t i = 0; i < mem.size(); ++i) members[i] = mem[i].rec;
+                    const size_t n = members.size();
+                    auto h = heap_of_rank(n);
+                    std::vector<uint32_t> rank_of_heap(n);
+                    for (size_t r = 0; r < n; ++r) rank_of_heap[h[r]] = (uint32_t)r;
+                    size_t rhi = 0;
+                    while (rhi < n && mem[rhi].off < c.qoff[s]) ++rhi;
+                    std::vector<std::pair<size_t, uint32_t>> ch;  // (heap node, record)
+                    for (uint32_t r : cand) {
+                        const size_t rk = std::find(members.begin(), members.end(), r) - members.begin();
+                        ch.emplace_back(h[rk], r);
+                    }
+                    auto earlier = [&](uint32_t a, uint32_t b) {
+                        const uint32_t pa = sk.pos1[pairs[slot_of_rec(a)].e1], pb = sk.pos1[pairs[slot_of_rec(b)].e1];
+                        return pa != pb ? pa < pb : slot_of_rec(a) < slot_of_rec(b);
+                    };
+                    win_rec = kNone;
+                    replay_units(n, rank_of_heap, 0, rhi,
+                                 [&](size_t x) { for (auto& e : ch) if (e.first == x) { win_rec = e.second; return true; } return false; },
+                                 [&](size_t x) {
+                                     for (auto& e : ch) if (in_subtree(e.first, x) && (win_rec == kNone || earlier(e.second, win_rec))) win_rec = e.second;
+                                     return win_rec != kNone;
+                                 });
+                } else {
+                    // orthogonal tree of this combination: all its records keyed ((shift, match id), offset); inside a
+                    // cross tree the values are (score, outer index) pairs, so the larger outer heap index wins
+                    Combo::SubRecs& sr = sub_recs(c, k);
+                    auto key_less = [&](uint32_t a, uint32_t b) { return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b); };
+                    if (sr.ortho_order.empty()) {
+                        sr.ortho_order = sr.recs;
+                        std::sort(sr.ortho_order.begin(), sr.ortho_order.end(), key_less);
+                        sr.ortho_heap = heap_of_rank(sr.ortho_order.size());
+                        sr.ortho_rank_of_heap.resize(sr.ortho_order.size());
+                        for (size_t r = 0; r < sr.ortho_order.size(); ++r) sr.ortho_rank_of_heap[sr.ortho_heap[r]] = (uint32_t)r;
+                    }
+                    const size_t n = sr.ortho_order.size();
+                    const int32_t qq = c.q[s];
+                    const bool odd = (win_kind - 1) % 2 == 1;
+                    // rank interval of the key1 range: shift < query (odd trees) or shift > query (even trees)
+                    size_t lo = 0, hi = n;
+                    auto first_ge = [&](int64_t v) {
+                        return (size_t)(std::partition_point(sr.ortho_order.begin(), sr.ortho_order.end(), [&](uint32_t r) { return (int64_t)c.sigma[r] < v; }) - sr.ortho_order.begin());
+                    };
+                    if (odd) hi = first_ge(qq);
+                    else lo = first_ge((int64_t)qq + 1);
+                    std::vector<std::pair<size_t, uint32_t>> ch;
+                    for (uint32_t r : cand) {
+                        const size_t rk = std::lower_bound(sr.ortho_order.begin(), sr.ortho_order.end(), r, key_less) - sr.ortho_order.begin();
+                        ch.emplace_back(sr.ortho_heap[rk], r);
+                    }
+                    win_rec = kNone;
+                    size_t win_heap = 0;
+                    replay_units(n, sr.ortho_rank_of_heap, lo, hi,
+                                 [&](size_t x) { for (auto& e : ch) if (e.first == x) { win_rec = e.second; return true; } return false; },
+                                 [&](size_t x) {
+                                     for (auto& e : ch) if (in_subtree(e.first, x) && (win_rec == kNone || e.first > win_heap)) { win_rec = e.second; win_heap = e.first; }
+                                     return win_rec != kNone;
+                                 });
+                }
+                if (win_rec == kNone) { cl_set_error(ctx, "traceback: tie resolution failed for pair %u", here); cleanup(); return CL_ERR_HIP; }
+            }
+            here = by_s[c.rec_s[win_rec]];
+            if (chain_slots.size() > M) { cl_set_error(ctx, "traceback loop"); cleanup(); return CL_ERR_HIP; }
+        }
+        std::reverse(chain_slots.begin(), chain_slots.end());
+        ChainSubResult& res = results[k];
+        res.n_ties = n_ties;
+        const size_t na = chain_slots.size();
+        res.chain.resize(3 * na);
+        for (size_t i = 0; i < na; ++i) {
+            const Pair& p = pairs[chain_slots[i]];
+            res.chain[3 * i] = p.set;
+            res.chain[3 * i + 1] = p.i1;
+            res.chain[3 * i + 2] = p.i2;
+        }
+        if (!sparse) {   // gap annotation (anchorer.hpp:2443-2468)
+            res.gap.assign(na + 1, 0);
+            res.gap_score.assign(na + 1, 0.0);
+            for (size_t i = 1; i < na; ++i) {
+                const Pair& a = pairs[chain_slots[i - 1]];
+                const Pair& b = pairs[chain_slots[i]];
+                const int32_t g = measure_gap(sk, a.e1, a.e2, b.b1, b.b2);
+                res.gap[i] = g;
+                res.gap_score[i] = score_gap(g);
+            }
+            if (subs[k].anchored && na) {
+                const Pair& f = pairs[chain_slots.front()];
+                const Pair& l = pairs[chain_slots.back()];
+                res.gap[0] = gap_from_sources(k, f.b1, f.b2);
+                res.gap_score[0] = score_gap((int32_t)res.gap[0]);
+                res.gap[na] = gap_to_sinks(k, l.e1, l.e2);
+                res.gap_score[na] = score_gap((int32_t)res.gap[na]);
+            }
+        }
     }
-    if (want_dp)
-        for (uint32_t slot = 0; slot < M; ++slot) out->dp[slot] = dp_sorted[s_of_slot[slot]];
-    if (global && !sparse && !chain_slots.empty()) {   // gap annotation of the chain's ends (anchorer.hpp:2445-2451, 2461-2467)
-        const Pair& f = pairs[chain_slots.front()];
-        const Pair& l = pairs[chain_slots.back()];
-        out->gap_before_first = gap_from_sources(f.b1, f.b2);
-        out->gap_score_before_first = score_gap((int32_t)out->gap_before_first);
-        out->gap_after_last = gap_to_sinks(l.e1, l.e2);
-        out->gap_score_after_last = score_gap((int32_t)out->gap_after_last);
+    tm.traceback_ms += ms_since(T2);
+    if (dp_out) {
+        dp_out->resize(M);
+        for (uint32_t slot = 0; slot < M; ++slot) (*dp_out)[slot] = dp_sorted[s_of_slot[slot]];
     }
-    cleanup2();
+    cleanup();
     return CL_OK;
 #undef CH
+}
+
+// one instance on the two merge graphs (with their sentinels); global anchoring = chains start at the nodes after the
+// source sentinel and end at the nodes before the sink sentinel (anchorer.hpp:1069-1076)
+static ChainSub whole_graph_instance(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, uint64_t num_match_sets,
+                                     bool global_anchoring) {
+    ChainSub sb;
+    sb.g[0] = g1; sb.g[1] = g2;
+    sb.ms = ms;
+    sb.num_match_sets = num_match_sets;
+    sb.anchored = global_anchoring;
+    if (global_anchoring)
+        for (int side = 0; side < 2; ++side) {
+            const cl_base_graph* g = sb.g[side];
+            sb.src[side].assign(g->next_idx + g->next_off[g->src_id], g->next_idx + g->next_off[g->src_id + 1]);
+            sb.snk[side].assign(g->prev_idx + g->prev_off[g->snk_id], g->prev_idx + g->prev_off[g->snk_id + 1]);
+        }
+    return sb;
+}
+
+static int chain_dp_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                         uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp, bool sparse,
+                         cl_chain_result* out) {
+    if (!ctx || !g1 || !g2 || !ms || !cp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    if (num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+    std::vector<ChainSub> subs(1, whole_graph_instance(g1, g2, ms, num_match_sets, cp->global_anchoring != 0));
+    std::vector<ChainSubResult> res;
+    ChainTimings tm;
+    std::vector<float> dp;
+    const int rc = chain_dp_batch(ctx, subs, cp, local_scale, sparse, res, tm, want_dp ? &dp : nullptr);
+    if (rc) return rc;
+    out->n_pairs = tm.n_pairs;
+    out->device_ms = tm.device_ms; out->prep_ms = tm.prep_ms; out->index_ms = tm.index_ms; out->traceback_ms = tm.traceback_ms;
+    const ChainSubResult& r = res[0];
+    const size_t na = r.chain.size() / 3;
+    out->n_anchors = na;
+    out->n_ties = r.n_ties;
+    out->anchors = (uint32_t*)malloc((na ? na : 1) * 3 * sizeof(uint32_t));
+    if (want_dp) out->dp = (float*)malloc((dp.size() ? dp.size() : 1) * sizeof(float));
+    if (!out->anchors || (want_dp && !out->dp)) { cl_chain_result_free(out); return CL_ERR_OUT_OF_MEMORY; }
+    if (na) memcpy(out->anchors, r.chain.data(), r.chain.size() * sizeof(uint32_t));
+    if (want_dp && !dp.empty()) memcpy(out->dp, dp.data(), dp.size() * sizeof(float));
+    if (!sparse && subs[0].anchored && na) {
+        out->gap_before_first = r.gap[0]; out->gap_score_before_first = r.gap_score[0];
+        out->gap_after_last = r.gap[na]; out->gap_score_after_last = r.gap_score[na];
+    }
+    return CL_OK;
 }
 
 extern "C" {

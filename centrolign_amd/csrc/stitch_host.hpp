@@ -46,11 +46,11 @@ class PathMergeTable {
 public:
     static constexpr uint32_t kNone = std::numeric_limits<uint32_t>::max();
 
-    // path_merge.hpp:96-163 with a tableau (the sentinel pseudo-path is chain number path_size())
-    bool build(const cl_base_graph& g) {
+    // path_merge.hpp:96-163; with a tableau the sentinel pseudo-path is chain number path_size()
+    bool build(const cl_base_graph& g, bool tableau = true) {
         g_ = &g;
         n_ = g.n_nodes;
-        chains_ = g.n_paths + 1;
+        chains_ = g.n_paths + (tableau ? 1 : 0);
         path_head_.assign(n_, kNone);
         index_.assign(chains_ * n_, kNone);
         next_chain_.assign(chains_ * n_, kNone);
@@ -77,6 +77,7 @@ public:
                 }
             }
         }
+        if (!tableau) return true;
         const uint64_t pp = g.n_paths;
         index_[pp * n_ + g.src_id] = 0;
         index_[pp * n_ + g.snk_id] = 1;
