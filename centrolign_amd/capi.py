@@ -233,14 +233,17 @@ class ChainResultC(C.Structure):
 class AnchorParams(C.Structure):
     """cl_anchor_params"""
     _fields_ = [("chain", ChainParams), ("max_num_match_pairs", C.c_uint64), ("score_scale", C.c_double),
-                ("autocalibrate_gap_penalties", C.c_int)]
+                ("autocalibrate_gap_penalties", C.c_int), ("do_fill_in_anchoring", C.c_int)]
 
 
 class AnchorChainResultC(C.Structure):
-    _fields_ = [("n_anchors", C.c_uint64), ("anchors", C.POINTER(C.c_uint32)), ("gap_before", C.POINTER(C.c_int64)),
+    _fields_ = [("n_anchors", C.c_uint64), ("anchors", C.POINTER(C.c_uint64)), ("gap_before", C.POINTER(C.c_int64)),
                 ("gap_after", C.POINTER(C.c_int64)), ("gap_score_before", C.POINTER(C.c_double)),
-                ("gap_score_after", C.POINTER(C.c_double)), ("score", C.POINTER(C.c_double)), ("n_sets", C.c_uint64),
-                ("set_order", C.POINTER(C.c_uint64)), ("scale", C.c_double), ("n_ties", C.c_uint64)]
+                ("gap_score_after", C.POINTER(C.c_double)), ("score", C.POINTER(C.c_double)),
+                ("count1", C.POINTER(C.c_uint64)), ("count2", C.POINTER(C.c_uint64)), ("full_length", C.POINTER(C.c_uint64)),
+                ("walk_off", C.POINTER(C.c_uint64)), ("walk1", C.POINTER(C.c_uint32)), ("walk2", C.POINTER(C.c_uint32)),
+                ("n_sets", C.c_uint64), ("set_order", C.POINTER(C.c_uint64)), ("scale", C.c_double), ("n_ties", C.c_uint64),
+                ("fill_in_pairs", C.c_uint64), ("fill_in_device_ms", C.c_float)]
 
 
 def default_chain_params(global_anchoring=True):
@@ -700,15 +703,16 @@ class Context:
             self.lib.cl_chain_result_free(C.byref(out))
 
     def anchor_chain(self, graph1, graph2, matches, max_num_match_pairs=1250000, score_scale=1.0, autocalibrate=True,
-                     params=None):
-        """Anchorer::anchor_chain (include/centrolign/anchorer.hpp:958-996) without fill-in re-anchoring and branch
-        splitting.  Returns dict(chain (n,3) [position in the reordered sets, idx1, idx2], gap_before/after,
-        gap_score_before/after, score, set_order, scale, n_ties)"""
+                     params=None, fill_in=True):
+        """Anchorer::anchor_chain (include/centrolign/anchorer.hpp:958-996) without branch splitting.
+        Returns dict(chain (n,3) [position in the reordered sets, idx1, idx2], gap_before/after,
+        gap_score_before/after, score, count1, count2, full_length, walk_off, walk1, walk2, set_order, scale, n_ties)"""
         ap = AnchorParams()
         ap.chain = params or default_chain_params()
         ap.max_num_match_pairs = int(max_num_match_pairs)
         ap.score_scale = float(score_scale)
         ap.autocalibrate_gap_penalties = int(autocalibrate)
+        ap.do_fill_in_anchoring = int(fill_in)
         g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), AnchorChainResultC()
         self._check(self.lib.cl_anchor_chain(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), C.byref(out)))
         try:
@@ -716,10 +720,15 @@ class Context:
 
             def arr(ptr, n, width=1):
                 return np.ctypeslib.as_array(ptr, shape=(max(n, 1) * width,))[:n * width].copy()
+            walk_off = np.ctypeslib.as_array(out.walk_off, shape=(na + 1,)).copy()
+            nw = int(walk_off[-1])
             return dict(chain=arr(out.anchors, na, 3).reshape(na, 3), gap_before=arr(out.gap_before, na),
                         gap_after=arr(out.gap_after, na), gap_score_before=arr(out.gap_score_before, na),
                         gap_score_after=arr(out.gap_score_after, na), score=arr(out.score, na),
-                        set_order=arr(out.set_order, ns), scale=float(out.scale), n_ties=int(out.n_ties))
+                        count1=arr(out.count1, na), count2=arr(out.count2, na), full_length=arr(out.full_length, na),
+                        walk_off=walk_off, walk1=arr(out.walk1, nw), walk2=arr(out.walk2, nw),
+                        set_order=arr(out.set_order, ns), scale=float(out.scale), n_ties=int(out.n_ties),
+                        fill_in_pairs=int(out.fill_in_pairs), fill_in_device_ms=float(out.fill_in_device_ms))
         finally:
             self.lib.cl_anchor_chain_result_free(C.byref(out))
 

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <numeric>
 #include <unordered_map>
 #include <vector>
@@ -997,6 +998,65 @@ int64_t min_source_sink(const clhost::OwnedBatch::Side& sd, uint64_t k) {
     return mn;
 }
 
+// anchor_t on the host (include/centrolign/anchorer.hpp:36-57), walks in parent-graph ids
+struct HAnchor {
+    std::vector<uint32_t> w1, w2;
+    uint64_t count1 = 0, count2 = 0, full_length = 0, match_set = 0, idx1 = 0, idx2 = 0;
+    double score = 0.0, gsb = 0.0, gsa = 0.0;
+    int64_t gb = 0, ga = 0;
+};
+
+// node -> ids of the paths through it, ascending (StepIndex, include/centrolign/step_index.hpp:38-46)
+struct PathsOfNode {
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> path;
+    void build(const cl_base_graph& g) {
+        off.assign(g.n_nodes + 1, 0);
+        for (uint64_t i = 0; i < g.path_off[g.n_paths]; ++i) ++off[g.path_nodes[i] + 1];
+        for (uint64_t v = 0; v < g.n_nodes; ++v) off[v + 1] += off[v];
+        path.resize(off[g.n_nodes]);
+        std::vector<uint64_t> fill(off.begin(), off.end() - 1);
+        for (uint64_t p = 0; p < g.n_paths; ++p)
+            for (uint64_t i = g.path_off[p]; i < g.path_off[p + 1]; ++i) path[fill[g.path_nodes[i]]++] = (uint32_t)p;
+    }
+};
+
+// one side of one fill-in subproblem: the extracted subgraph with the parent's paths projected onto it
+// (Extractor::project_paths / do_project, anchorer.hpp:586-615)
+struct FillSide {
+    std::vector<uint64_t> path_off{0};
+    std::vector<uint32_t> path_nodes, tag;
+    cl_base_graph view;
+    void project(const clhost::OwnedBatch::Side& sd, uint64_t k, const PathsOfNode& steps, uint32_t tag_base) {
+        const uint64_t b = sd.node_off[k], n = sd.node_off[k + 1] - b;
+        view = cl_base_graph{n, sd.label.data() + b, sd.next_off.data() + b, sd.next_idx.data(), sd.prev_off.data() + b, sd.prev_idx.data(),
+                             0, nullptr, nullptr, UINT64_MAX, UINT64_MAX};
+        std::vector<uint32_t> order;
+        clhost::topological_order(view, order);
+        std::vector<std::vector<uint32_t>> paths;
+        std::unordered_map<uint32_t, uint32_t> local_of;   // parent path -> projected path, numbered by first encounter
+        for (uint32_t v : order) {
+            const uint64_t parent = sd.back[b + v];
+            for (uint64_t i = steps.off[parent]; i < steps.off[parent + 1]; ++i) {
+                auto it = local_of.find(steps.path[i]);
+                if (it == local_of.end()) {
+                    it = local_of.emplace(steps.path[i], (uint32_t)paths.size()).first;
+                    paths.emplace_back();
+                    tag.push_back(tag_base + steps.path[i]);
+                }
+                paths[it->second].push_back(v);
+            }
+        }
+        for (auto& pth : paths) {
+            path_nodes.insert(path_nodes.end(), pth.begin(), pth.end());
+            path_off.push_back(path_nodes.size());
+        }
+        view.n_paths = paths.size();
+        view.path_off = path_off.data();
+        view.path_nodes = path_nodes.data();
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1004,7 +1064,8 @@ extern "C" {
 void cl_anchor_chain_result_free(cl_anchor_chain_result* r) {
     if (!r) return;
     free(r->anchors); free(r->gap_before); free(r->gap_after); free(r->gap_score_before); free(r->gap_score_after);
-    free(r->score); free(r->set_order);
+    free(r->score); free(r->set_order); free(r->walk_off); free(r->walk1); free(r->walk2); free(r->count1); free(r->count2);
+    free(r->full_length);
     memset(r, 0, sizeof(*r));
 }
 
@@ -1017,33 +1078,12 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
     // anchorer.hpp:1175: the DP runs with the graphs swapped when that makes its tables smaller
     const bool swap = g1->n_nodes * x1.chain_size() > g2->n_nodes * x2.chain_size();
-    const cl_base_graph* ga = swap ? g2 : g1;
-    const cl_base_graph* gb = swap ? g1 : g2;
     std::vector<uint64_t> cur(ms->n_sets);
     std::iota(cur.begin(), cur.end(), (uint64_t)0);
+    PathsOfNode steps1, steps2;
+    if (ap->do_fill_in_anchoring) { steps1.build(*g1); steps2.build(*g2); }
 
-    struct Chain {   // (set, idx1, idx2) in ORIGINAL graph orientation, set = position in `cur`
-        std::vector<uint32_t> a;
-        int64_t gap_first = 0, gap_last = 0;       // global anchoring: the indels to the graph ends, DP orientation
-        double score_first = 0.0, score_last = 0.0;
-    };
-    auto run = [&](bool sparse, double anchor_scale, Chain& chain) -> int {
-        const uint64_t local_max = std::min<uint64_t>((uint64_t)llround((anchor_scale / ap->score_scale) * (double)ap->max_num_match_pairs),
-                                                     ap->max_num_match_pairs);
-        const uint64_t n_use = select_matches(*ms, cp, cur, local_max);
-        OwnedMatchSets sel = permute_sets(*ms, cur, swap);
-        cl_match_sets v = sel.view();
-        cl_chain_result r;
-        int rc = chain_dp_impl(ctx, ga, gb, &v, n_use, &cp, anchor_scale, 0, sparse, &r);
-        if (rc) return rc;
-        chain.a.assign(r.anchors, r.anchors + 3 * r.n_anchors);
-        if (swap) for (size_t i = 0; i < r.n_anchors; ++i) std::swap(chain.a[3 * i + 1], chain.a[3 * i + 2]);
-        chain.gap_first = r.gap_before_first; chain.gap_last = r.gap_after_last;
-        chain.score_first = r.gap_score_before_first; chain.score_last = r.gap_score_after_last;
-        out->n_ties += r.n_ties;
-        cl_chain_result_free(&r);
-        return CL_OK;
-    };
+    // walks of (position in `cur`, idx) on the caller's sets
     auto walk = [&](int side, uint64_t set_pos, uint32_t idx, const uint32_t*& b, const uint32_t*& e) {
         const uint64_t s = cur[set_pos];
         const uint64_t w = (side ? ms->set_off2 : ms->set_off1)[s] + idx;
@@ -1052,26 +1092,235 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         b = nd + wo[w]; e = nd + wo[w + 1];
     };
 
+    // ---- fill_in_anchor_chain (anchorer.hpp:619-699): re-anchor inside every gap of the chain with the matches that lie
+    //      wholly inside it; all the gaps' DPs run as one batched device pass
+    auto fill_in = [&](std::vector<HAnchor>& anchors, bool sparse, double anchor_scale) -> int {
+        if (anchors.empty()) return CL_OK;
+        std::vector<uint64_t> seg_off{0, anchors.size()}, walk_off{0};
+        std::vector<uint32_t> w1, w2;
+        for (const HAnchor& a : anchors) {
+            w1.insert(w1.end(), a.w1.begin(), a.w1.end());
+            w2.insert(w2.end(), a.w2.begin(), a.w2.end());
+            walk_off.push_back(w1.size());
+        }
+        cl_anchor_segments sg{1, seg_off.data(), walk_off.data(), w1.data(), w2.data()};
+        clhost::OwnedBatch ob;
+        int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob);
+        if (rc) { cl_set_error(ctx, "extraction failed"); return rc; }
+        const size_t K = ob.only_del.size();
+        // divvy_matches (anchorer.hpp:701-798): a walk goes to the gap that holds both its ends
+        const uint32_t none = 0xFFFFFFFFu;
+        std::vector<std::pair<uint32_t, uint32_t>> ft[2];
+        for (int side = 0; side < 2; ++side) {
+            ft[side].assign((side ? g2 : g1)->n_nodes, std::make_pair(none, none));
+            const auto& sd = ob.side[side];
+            for (size_t k = 0; k < K; ++k)
+                for (uint64_t v = sd.node_off[k]; v < sd.node_off[k + 1]; ++v) ft[side][sd.back[v]] = std::make_pair((uint32_t)k, (uint32_t)(v - sd.node_off[k]));
+        }
+        struct Divvied {
+            OwnedMatchSets sets;
+            std::vector<uint64_t> origin_set;
+            std::vector<std::vector<uint32_t>> origin_idx1, origin_idx2;
+        };
+        std::vector<Divvied> dv(K);
+        struct Pending { uint32_t k; std::vector<std::vector<uint32_t>> walks1, walks2; std::vector<uint32_t> idx1, idx2; };
+        for (size_t pos = 0; pos < cur.size(); ++pos) {
+            const uint64_t s = cur[pos];
+            std::vector<Pending> pend;
+            for (uint64_t j = 0; j < ms->set_off1[s + 1] - ms->set_off1[s]; ++j) {
+                const uint32_t *b, *e;
+                walk(0, pos, (uint32_t)j, b, e);
+                const uint32_t k = ft[0][b[0]].first;
+                if (k == none || k != ft[0][e[-1]].first) continue;
+                auto it = std::find_if(pend.begin(), pend.end(), [&](const Pending& q) { return q.k == k; });
+                if (it == pend.end()) { pend.emplace_back(); pend.back().k = k; it = pend.end() - 1; }
+                it->idx1.push_back((uint32_t)j);
+                it->walks1.emplace_back();
+                for (const uint32_t* v = b; v != e; ++v) it->walks1.back().push_back(ft[0][*v].second);
+            }
+            if (pend.empty()) continue;
+            for (uint64_t j = 0; j < ms->set_off2[s + 1] - ms->set_off2[s]; ++j) {
+                const uint32_t *b, *e;
+                walk(1, pos, (uint32_t)j, b, e);
+                const uint32_t k = ft[1][b[0]].first;
+                auto it = std::find_if(pend.begin(), pend.end(), [&](const Pending& q) { return q.k == k; });
+                if (it == pend.end() || k != ft[1][e[-1]].first) continue;
+                it->idx2.push_back((uint32_t)j);
+                it->walks2.emplace_back();
+                for (const uint32_t* v = b; v != e; ++v) it->walks2.back().push_back(ft[1][*v].second);
+            }
+            for (Pending& q : pend) {
+                if (q.walks2.empty()) continue;
+                Divvied& d = dv[q.k];
+                for (auto& w : q.walks1) { d.sets.nodes1.insert(d.sets.nodes1.end(), w.begin(), w.end()); d.sets.walk_off1.push_back(d.sets.nodes1.size()); }
+                d.sets.set_off1.push_back(d.sets.walk_off1.size() - 1);
+                for (auto& w : q.walks2) { d.sets.nodes2.insert(d.sets.nodes2.end(), w.begin(), w.end()); d.sets.walk_off2.push_back(d.sets.nodes2.size()); }
+                d.sets.set_off2.push_back(d.sets.walk_off2.size() - 1);
+                d.sets.count1.push_back(ms->count1[s]);
+                d.sets.count2.push_back(ms->count2[s]);
+                d.sets.full_length.push_back(ms->full_length[s]);
+                d.origin_set.push_back(pos);
+                d.origin_idx1.push_back(std::move(q.idx1));
+                d.origin_idx2.push_back(std::move(q.idx2));
+            }
+        }
+        // assign_reanchor_budget (src/anchorer.cpp:136-154)
+        uint64_t total = 0;
+        auto matrix_size = [&](size_t k) { return (ob.side[0].node_off[k + 1] - ob.side[0].node_off[k] + 1) * (ob.side[1].node_off[k + 1] - ob.side[1].node_off[k] + 1); };
+        for (size_t k = 0; k < K; ++k) total += matrix_size(k);
+        // the instances: inner anchor_chain (anchorer.hpp:1091-1329) on the gap's subgraphs with their sources / sinks
+        struct Inst { size_t k; bool swap; std::vector<uint64_t> order; OwnedMatchSets sel; cl_match_sets view, sel_view; FillSide side[2]; };
+        std::vector<std::unique_ptr<Inst>> inst;
+        std::vector<ChainSub> subs;
+        for (size_t k = 0; k < K; ++k) {
+            if (dv[k].origin_set.empty()) continue;
+            inst.emplace_back(new Inst());
+            Inst& in = *inst.back();
+            in.k = k;
+            in.side[0].project(ob.side[0], k, steps1, 0);
+            in.side[1].project(ob.side[1], k, steps2, (uint32_t)g1->n_paths);
+            in.swap = in.side[0].view.n_nodes * in.side[0].view.n_paths > in.side[1].view.n_nodes * in.side[1].view.n_paths;
+            in.view = dv[k].sets.view();
+            in.order.resize(in.view.n_sets);
+            std::iota(in.order.begin(), in.order.end(), (uint64_t)0);
+            const uint64_t budget = (uint64_t)ceil((double)ap->max_num_match_pairs * (double)matrix_size(k) / (double)total);
+            const uint64_t n_use = select_matches(in.view, cp, in.order, budget);
+            in.sel = permute_sets(in.view, in.order, in.swap);
+            in.sel_view = in.sel.view();
+            ChainSub sb;
+            sb.tableau = false;
+            sb.ms = &in.sel_view;
+            sb.num_match_sets = n_use;
+            sb.anchored = true;
+            for (int d = 0; d < 2; ++d) {
+                const int from = in.swap ? 1 - d : d;
+                const auto& sd = ob.side[from];
+                sb.g[d] = &in.side[from].view;
+                sb.tag[d] = in.side[from].tag;
+                sb.src[d].assign(sd.src_idx.begin() + sd.src_off[k], sd.src_idx.begin() + sd.src_off[k + 1]);
+                sb.snk[d].assign(sd.snk_idx.begin() + sd.snk_off[k], sd.snk_idx.begin() + sd.snk_off[k + 1]);
+            }
+            subs.push_back(std::move(sb));
+        }
+        std::vector<ChainSubResult> res;
+        if (!subs.empty()) {
+            ChainTimings tm;
+            rc = chain_dp_batch(ctx, subs, &cp, anchor_scale, sparse, res, tm, nullptr);
+            if (rc) return rc;
+            out->fill_in_pairs += tm.n_pairs;
+            out->fill_in_device_ms += tm.device_ms;
+        }
+        // translate the gap chains back (inner un-swap, anchorer.hpp:1309-1322) and merge (src/anchorer.cpp:157-222)
+        std::vector<std::vector<HAnchor>> fill(K);
+        for (size_t q = 0; q < inst.size(); ++q) {
+            const Inst& in = *inst[q];
+            const ChainSubResult& r = res[q];
+            out->n_ties += r.n_ties;
+            const Divvied& d = dv[in.k];
+            const size_t na = r.chain.size() / 3;
+            for (size_t i = 0; i < na; ++i) {
+                const uint32_t pos = r.chain[3 * i];
+                uint32_t a = r.chain[3 * i + 1], b = r.chain[3 * i + 2];
+                if (in.swap) std::swap(a, b);
+                const uint64_t set = in.order[pos];
+                HAnchor h;
+                for (int side = 0; side < 2; ++side) {
+                    const auto& so = side ? d.sets.set_off2 : d.sets.set_off1;
+                    const auto& wo = side ? d.sets.walk_off2 : d.sets.walk_off1;
+                    const auto& nd = side ? d.sets.nodes2 : d.sets.nodes1;
+                    const uint64_t w = so[set] + (side ? b : a);
+                    auto& dst = side ? h.w2 : h.w1;
+                    for (uint64_t v = wo[w]; v < wo[w + 1]; ++v) dst.push_back((uint32_t)ob.side[side].back[ob.side[side].node_off[in.k] + nd[v]]);
+                }
+                h.count1 = d.sets.count1[set]; h.count2 = d.sets.count2[set]; h.full_length = d.sets.full_length[set];
+                h.score = anchor_weight(cp, h.count1, h.count2, h.w1.size(), h.full_length);
+                // identity: the reference indexes its origin table with the POSITION in the (possibly reordered) gap match
+                // sets (src/anchorer.cpp:207-212), kept as is; out of range -> all ones
+                h.match_set = d.origin_set[pos];
+                h.idx1 = a < d.origin_idx1[pos].size() ? d.origin_idx1[pos][a] : UINT64_MAX;
+                h.idx2 = b < d.origin_idx2[pos].size() ? d.origin_idx2[pos][b] : UINT64_MAX;
+                if (!sparse) {
+                    h.gb = in.swap ? -r.gap[i] : r.gap[i];
+                    h.ga = in.swap ? -r.gap[i + 1] : r.gap[i + 1];
+                    h.gsb = r.gap_score[i];
+                    h.gsa = r.gap_score[i + 1];
+                }
+                fill[in.k].push_back(std::move(h));
+            }
+        }
+        std::vector<HAnchor> merged;
+        for (size_t k = 0; k < K; ++k) {
+            if (k != 0) {
+                HAnchor& a = anchors[k - 1];
+                if (!merged.empty()) { a.gb = merged.back().ga; a.gsb = merged.back().gsa; }
+                merged.push_back(std::move(a));
+            }
+            for (size_t j = 0; j < fill[k].size(); ++j) {
+                if (j == 0 && !merged.empty()) { merged.back().gsa = fill[k][j].gsb; merged.back().ga = fill[k][j].gb; }
+                merged.push_back(std::move(fill[k][j]));
+            }
+        }
+        anchors.swap(merged);
+        return CL_OK;
+    };
+
+    // ---- anchor_chain with a given algorithm and scale (anchorer.hpp:1050-1089)
+    auto run = [&](bool sparse, double anchor_scale, std::vector<HAnchor>& anchors) -> int {
+        const uint64_t local_max = std::min<uint64_t>((uint64_t)llround((anchor_scale / ap->score_scale) * (double)ap->max_num_match_pairs),
+                                                     ap->max_num_match_pairs);
+        const uint64_t n_use = select_matches(*ms, cp, cur, local_max);
+        OwnedMatchSets sel = permute_sets(*ms, cur, swap);
+        cl_match_sets v = sel.view();
+        std::vector<ChainSub> subs(1, whole_graph_instance(swap ? g2 : g1, swap ? g1 : g2, &v, n_use, cp.global_anchoring != 0));
+        std::vector<ChainSubResult> res;
+        ChainTimings tm;
+        int rc = chain_dp_batch(ctx, subs, &cp, anchor_scale, sparse, res, tm, nullptr);
+        if (rc) return rc;
+        out->n_ties += res[0].n_ties;
+        const ChainSubResult& r = res[0];
+        const size_t na = r.chain.size() / 3;
+        anchors.assign(na, HAnchor());
+        for (size_t i = 0; i < na; ++i) {
+            HAnchor& h = anchors[i];
+            h.match_set = r.chain[3 * i];
+            h.idx1 = r.chain[3 * i + 1];
+            h.idx2 = r.chain[3 * i + 2];
+            if (swap) std::swap(h.idx1, h.idx2);
+            const uint32_t *b, *e;
+            walk(0, h.match_set, (uint32_t)h.idx1, b, e);
+            h.w1.assign(b, e);
+            walk(1, h.match_set, (uint32_t)h.idx2, b, e);
+            h.w2.assign(b, e);
+            const uint64_t s = cur[h.match_set];
+            h.count1 = ms->count1[s]; h.count2 = ms->count2[s]; h.full_length = ms->full_length[s];
+            h.score = anchor_weight(cp, h.count1, h.count2, h.w1.size(), h.full_length);
+            if (!sparse) {   // annotation in the DP's orientation, negated back at anchorer.hpp:1318-1320
+                h.gb = swap ? -r.gap[i] : r.gap[i];
+                h.ga = swap ? -r.gap[i + 1] : r.gap[i + 1];
+                h.gsb = r.gap_score[i];
+                h.gsa = r.gap_score[i + 1];
+            }
+        }
+        if (ap->do_fill_in_anchoring) return fill_in(anchors, sparse, anchor_scale);
+        return CL_OK;
+    };
+
     // ---- estimate_score_scale (anchorer.hpp:998-1047)
     double scale = 1.0;
     int rc;
     if (ap->autocalibrate_gap_penalties) {
-        Chain sc;
+        std::vector<HAnchor> sc;
         if ((rc = run(true, 1.0, sc))) return rc;
         double total_weight = 0.0;
         uint64_t total_length = 0;
-        const size_t na = sc.a.size() / 3;
+        const size_t na = sc.size();
         std::vector<uint64_t> seg_off{0, na}, walk_off{0};
         std::vector<uint32_t> w1, w2;
-        for (size_t i = 0; i < na; ++i) {
-            const uint32_t *b, *e;
-            walk(0, sc.a[3 * i], sc.a[3 * i + 1], b, e);
-            const uint64_t s = cur[sc.a[3 * i]];
-            total_weight += anchor_weight(cp, ms->count1[s], ms->count2[s], (uint64_t)(e - b), ms->full_length[s]);
-            total_length += (uint64_t)(e - b);
-            w1.insert(w1.end(), b, e);
-            walk(1, sc.a[3 * i], sc.a[3 * i + 2], b, e);
-            w2.insert(w2.end(), b, e);
+        for (const HAnchor& a : sc) {
+            total_weight += anchor_weight(cp, a.count1, a.count2, a.w1.size(), a.full_length);
+            total_length += a.w1.size();
+            w1.insert(w1.end(), a.w1.begin(), a.w1.end());
+            w2.insert(w2.end(), a.w2.begin(), a.w2.end());
             walk_off.push_back(w1.size());
         }
         cl_anchor_segments sg{na ? 1u : 0u, seg_off.data(), walk_off.data(), w1.data(), w2.data()};
@@ -1091,81 +1340,47 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     out->scale = scale;
 
     // ---- the affine chain
-    Chain ch;
+    std::vector<HAnchor> ch;
     if ((rc = run(false, scale, ch))) return rc;
-    const size_t na = ch.a.size() / 3;
+    const size_t na = ch.size();
+    uint64_t total_walk = 0;
+    for (const HAnchor& a : ch) total_walk += a.w1.size();
     out->n_anchors = na;
     out->n_sets = cur.size();
-    out->anchors = (uint32_t*)malloc((na ? na : 1) * 3 * sizeof(uint32_t));
-    out->gap_before = (int64_t*)calloc(na ? na : 1, sizeof(int64_t));
-    out->gap_after = (int64_t*)calloc(na ? na : 1, sizeof(int64_t));
-    out->gap_score_before = (double*)calloc(na ? na : 1, sizeof(double));
-    out->gap_score_after = (double*)calloc(na ? na : 1, sizeof(double));
-    out->score = (double*)calloc(na ? na : 1, sizeof(double));
+    const size_t na1 = na ? na : 1;
+    out->anchors = (uint64_t*)malloc(na1 * 3 * sizeof(uint64_t));
+    out->gap_before = (int64_t*)calloc(na1, sizeof(int64_t));
+    out->gap_after = (int64_t*)calloc(na1, sizeof(int64_t));
+    out->gap_score_before = (double*)calloc(na1, sizeof(double));
+    out->gap_score_after = (double*)calloc(na1, sizeof(double));
+    out->score = (double*)calloc(na1, sizeof(double));
+    out->count1 = (uint64_t*)calloc(na1, sizeof(uint64_t));
+    out->count2 = (uint64_t*)calloc(na1, sizeof(uint64_t));
+    out->full_length = (uint64_t*)calloc(na1, sizeof(uint64_t));
+    out->walk_off = (uint64_t*)calloc(na + 1, sizeof(uint64_t));
+    out->walk1 = (uint32_t*)malloc((total_walk ? total_walk : 1) * sizeof(uint32_t));
+    out->walk2 = (uint32_t*)malloc((total_walk ? total_walk : 1) * sizeof(uint32_t));
     out->set_order = (uint64_t*)malloc((cur.size() ? cur.size() : 1) * sizeof(uint64_t));
-    if (!out->anchors || !out->gap_before || !out->gap_after || !out->gap_score_before || !out->gap_score_after || !out->score || !out->set_order) {
+    if (!out->anchors || !out->gap_before || !out->gap_after || !out->gap_score_before || !out->gap_score_after || !out->score ||
+        !out->count1 || !out->count2 || !out->full_length || !out->walk_off || !out->walk1 || !out->walk2 || !out->set_order) {
         cl_anchor_chain_result_free(out);
         return CL_ERR_OUT_OF_MEMORY;
     }
-    memcpy(out->anchors, ch.a.data(), ch.a.size() * sizeof(uint32_t));
     memcpy(out->set_order, cur.data(), cur.size() * sizeof(uint64_t));
-
-    // ---- annotation (anchorer.hpp:2443-2468 measure_gap_nn, evaluated in the DP's (possibly swapped) orientation, then
-    //      negated back at :1318-1320; score = anchor_weight, :1331-1335)
-    PostSwitchTable swa, swb;
-    const clhost::PathMergeTable& xa = swap ? x2 : x1;
-    const clhost::PathMergeTable& xb = swap ? x1 : x2;
-    swa.build(*ga, xa);
-    swb.build(*gb, xb);
-    auto measure_gap = [&](uint32_t pa, uint32_t pb, uint32_t ca, uint32_t cb) -> int32_t {
-        int32_t gap = INT32_MAX;
-        if ((pa == ca || xa.reachable(pa, ca)) && (pb == cb || xb.reachable(pb, cb))) {
-            xa.for_each_chain_on(pa, [&](uint32_t p1) {
-                xb.for_each_chain_on(pb, [&](uint32_t p2) {
-                    const int32_t src = (int32_t)(xa.index_on(pa, p1) - xb.index_on(pb, p2));
-                    const int32_t qry = (int32_t)(xa.predecessor_index(ca, p1) - xb.predecessor_index(cb, p2) + swa.distance(ca, p1) - swb.distance(cb, p2));
-                    const int32_t here = (int32_t)((uint32_t)src - (uint32_t)qry);
-                    if (std::abs((int64_t)here) < std::abs((int64_t)gap)) gap = here;
-                });
-            });
-        }
-        return gap;
-    };
-    auto score_gap = [&](int32_t gap) -> float {
-        float sc = CL_CHAIN_NEG;
-        if (gap == 0) sc = 0.0f;
-        else if (gap != INT32_MAX)
-            for (int pw = 0; pw < 3; ++pw) sc = std::max<float>(sc, (float)(-scale * (cp.gap_open[pw] + cp.gap_extend[pw] * std::abs(gap))));
-        return sc;
-    };
+    uint64_t wpos = 0;
     for (size_t i = 0; i < na; ++i) {
-        const uint64_t s = cur[ch.a[3 * i]];
-        const uint32_t *b, *e;
-        walk(0, ch.a[3 * i], ch.a[3 * i + 1], b, e);
-        out->score[i] = anchor_weight(cp, ms->count1[s], ms->count2[s], (uint64_t)(e - b), ms->full_length[s]);
-        if (i == 0) continue;
-        const uint32_t *pb1, *pe1, *pb2, *pe2, *cb1, *ce1, *cb2, *ce2;
-        walk(0, ch.a[3 * (i - 1)], ch.a[3 * (i - 1) + 1], pb1, pe1);
-        walk(1, ch.a[3 * (i - 1)], ch.a[3 * (i - 1) + 2], pb2, pe2);
-        walk(0, ch.a[3 * i], ch.a[3 * i + 1], cb1, ce1);
-        walk(1, ch.a[3 * i], ch.a[3 * i + 2], cb2, ce2);
-        const uint32_t prev1 = pe1[-1], prev2 = pe2[-1], cur1 = cb1[0], cur2 = cb2[0];
-        const int32_t gap = swap ? measure_gap(prev2, prev1, cur2, cur1) : measure_gap(prev1, prev2, cur1, cur2);
-        const double gs = (double)score_gap(gap);
-        const int64_t g = swap ? -(int64_t)gap : (int64_t)gap;
-        out->gap_after[i - 1] = g;
-        out->gap_score_after[i - 1] = gs;
-        out->gap_before[i] = g;
-        out->gap_score_before[i] = gs;
-    }
-    if (cp.global_anchoring && na) {   // anchorer.hpp:2445-2451, 2461-2467; negated with the rest at :1318-1320
-        out->gap_before[0] = swap ? -ch.gap_first : ch.gap_first;
-        out->gap_score_before[0] = ch.score_first;
-        out->gap_after[na - 1] = swap ? -ch.gap_last : ch.gap_last;
-        out->gap_score_after[na - 1] = ch.score_last;
+        const HAnchor& a = ch[i];
+        out->anchors[3 * i] = a.match_set; out->anchors[3 * i + 1] = a.idx1; out->anchors[3 * i + 2] = a.idx2;
+        out->gap_before[i] = a.gb; out->gap_after[i] = a.ga;
+        out->gap_score_before[i] = a.gsb; out->gap_score_after[i] = a.gsa;
+        out->score[i] = a.score;
+        out->count1[i] = a.count1; out->count2[i] = a.count2; out->full_length[i] = a.full_length;
+        memcpy(out->walk1 + wpos, a.w1.data(), a.w1.size() * sizeof(uint32_t));
+        memcpy(out->walk2 + wpos, a.w2.data(), a.w2.size() * sizeof(uint32_t));
+        wpos += a.w1.size();
+        out->walk_off[i + 1] = wpos;
     }
     return CL_OK;
 }
 
 }  // extern "C"
-

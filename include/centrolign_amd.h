@@ -306,29 +306,40 @@ int  cl_chain_sparse(cl_context* ctx, const cl_base_graph* graph1, const cl_base
                      uint64_t num_match_sets, const cl_chain_params* params, int want_dp, cl_chain_result* out);
 void cl_chain_result_free(cl_chain_result* r);
 
-/* --- Anchorer::anchor_chain (include/centrolign/anchorer.hpp:135-145, 958-1329) with do_fill_in_anchoring = false,
- * split_matches_at_branchpoints = false, no masks: budgeted match selection (which REORDERS the caller's
- * match sets, :1108-1173), scale estimation (:998-1047), the affine chain, gap and score annotation (:2443-2468).
- * (Fill-in re-anchoring, :619-699, is the part of the seam that is not built yet.) */
+/* --- Anchorer::anchor_chain (include/centrolign/anchorer.hpp:135-145, 958-1329), no masks,
+ * split_matches_at_branchpoints = false: budgeted match selection (which REORDERS the caller's match sets, :1108-1173),
+ * scale estimation (:998-1047), the affine chain, gap and score annotation (:2443-2468), and — with
+ * do_fill_in_anchoring — fill_in_anchor_chain (:619-699): every gap of the chain is re-anchored with the matches that lie
+ * inside it (divvy_matches :701-798, assign_reanchor_budget / merge_fill_in_chains src/anchorer.cpp:136-222); the DPs of
+ * all gaps run as ONE batched device pass. */
 typedef struct cl_anchor_params {
     cl_chain_params chain;
     uint64_t max_num_match_pairs;        /* Anchorer::max_num_match_pairs (CLI: 1250000, src/parameters.cpp:39) */
     double   score_scale;                /* ScoreFunction::score_scale (calibrated per input, src/core.cpp:193) */
     int      autocalibrate_gap_penalties;/* Anchorer::autocalibrate_gap_penalties */
+    int      do_fill_in_anchoring;       /* Anchorer::do_fill_in_anchoring (CLI default true) */
 } cl_anchor_params;
 
 typedef struct cl_anchor_chain_result {
     uint64_t  n_anchors;
-    uint32_t* anchors;           /* [3*n]: anchor_t::match_set (index into the REORDERED sets), idx1, idx2 */
+    uint64_t* anchors;           /* [3*n]: anchor_t::match_set (index into the REORDERED sets), idx1, idx2 */
     int64_t*  gap_before;        /* anchor_t::gap_before ... */
     int64_t*  gap_after;
     double*   gap_score_before;
     double*   gap_score_after;
     double*   score;             /* anchor_t::score */
+    uint64_t* count1;            /* anchor_t::count1, count2, full_length */
+    uint64_t* count2;
+    uint64_t* full_length;
+    uint64_t* walk_off;          /* [n+1]: anchor a's walk1 / walk2 = walk1/walk2[walk_off[a] .. walk_off[a+1]) (parent node ids) */
+    uint32_t* walk1;
+    uint32_t* walk2;
     uint64_t  n_sets;
     uint64_t* set_order;         /* [n_sets]: the caller's vector after the call holds original set set_order[k] at position k */
     double    scale;             /* the estimated score scale passed to the affine DP */
     uint64_t  n_ties;
+    uint64_t  fill_in_pairs;     /* match pairs chained by the fill-in passes (both the scale estimate's and the final one) */
+    float     fill_in_device_ms;
 } cl_anchor_chain_result;
 
 int  cl_anchor_chain(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,

@@ -291,22 +291,33 @@ def ref_anchor_chain(g1, g2, ms, max_num_match_pairs=1250000, score_scale=1.0, a
     lib = ref_lib()
     lib.ref_anchor_chain.restype = C.c_int
     lib.ref_anchor_chain.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.POINTER(CloChainParams),
-                                     C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9
+                                     C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 13
+    lib.ref_free.argtypes = [C.c_void_p]
     params = params or default_chain_params()
     c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
     cap = max(ms.n_pairs(), 1)
-    anchors = np.zeros((cap, 3), np.uint32)
+    anchors = np.zeros((cap, 3), np.uint64)
+    counts = np.zeros((cap, 3), np.uint64)
+    walk_off = np.zeros(cap + 1, np.uint64)
     gb, ga = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
     gsb, gsa, sc = np.zeros(cap), np.zeros(cap), np.zeros(cap)
     n = C.c_uint64(0)
     order = np.zeros(max(ms.n_sets, 1), np.uint64)
     scale = C.c_double(0)
+    w1p, w2p = C.c_void_p(), C.c_void_p()
     rc = lib.ref_anchor_chain(C.byref(c1), C.byref(c2), C.byref(mc), C.byref(params), int(global_anchoring), int(max_num_match_pairs),
                               float(score_scale), int(autocalibrate), int(fill_in), 0, anchors.ctypes.data, gb.ctypes.data,
                               ga.ctypes.data, gsb.ctypes.data, gsa.ctypes.data, sc.ctypes.data, C.addressof(n), order.ctypes.data,
-                              C.addressof(scale))
+                              C.addressof(scale), counts.ctypes.data, walk_off.ctypes.data, C.addressof(w1p), C.addressof(w2p))
     if rc:
         raise RuntimeError("ref_anchor_chain failed: %d" % rc)
     k = int(n.value)
+    nw = int(walk_off[k])
+    w1 = np.ctypeslib.as_array(C.cast(w1p, C.POINTER(C.c_uint32)), shape=(max(nw, 1),))[:nw].copy()
+    w2 = np.ctypeslib.as_array(C.cast(w2p, C.POINTER(C.c_uint32)), shape=(max(nw, 1),))[:nw].copy()
+    lib.ref_free(w1p)
+    lib.ref_free(w2p)
     return dict(chain=anchors[:k].copy(), gap_before=gb[:k].copy(), gap_after=ga[:k].copy(), gap_score_before=gsb[:k].copy(),
-                gap_score_after=gsa[:k].copy(), score=sc[:k].copy(), set_order=order[:ms.n_sets].copy(), scale=float(scale.value))
+                gap_score_after=gsa[:k].copy(), score=sc[:k].copy(), count1=counts[:k, 0].copy(), count2=counts[:k, 1].copy(),
+                full_length=counts[:k, 2].copy(), walk_off=walk_off[:k + 1].copy(), walk1=w1, walk2=w2,
+                set_order=order[:ms.n_sets].copy(), scale=float(scale.value))

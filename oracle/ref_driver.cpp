@@ -457,8 +457,10 @@ int ref_chain_dp_ex(int algo, const cl_base_graph* g1, const cl_base_graph* g2, 
  * :1108-1173); anchors_out holds (match_set position, idx1, idx2).  Buffers sized for n_pairs anchors / n_sets sets. */
 int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, const clo_chain_params* cp,
                      int global_anchoring, uint64_t max_num_match_pairs, double score_scale, int autocalibrate, int fill_in,
-                     int split_branching, uint32_t* anchors_out, int64_t* gap_before, int64_t* gap_after, double* gap_score_before,
-                     double* gap_score_after, double* score, uint64_t* n_anchors, uint64_t* set_order_out, double* scale_out) {
+                     int split_branching, uint64_t* anchors_out, int64_t* gap_before, int64_t* gap_after, double* gap_score_before,
+                     double* gap_score_after, double* score, uint64_t* n_anchors, uint64_t* set_order_out, double* scale_out,
+                     uint64_t* counts_out /* [3*n]: count1, count2, full_length */, uint64_t* walk_off_out /* [n+1] */,
+                     uint32_t** walk1_out, uint32_t** walk2_out /* malloc'ed, release with ref_free */) {
     SentinelTableau t1, t2;
     BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
     std::vector<match_set_t> sets(ms->n_sets);
@@ -500,10 +502,27 @@ int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
         set_order_out[k] = it->second;
     }
     *n_anchors = chain.size();
+    {
+        uint64_t total = 0;
+        for (const auto& a : chain) total += a.walk1.size();
+        *walk1_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+        *walk2_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+        uint64_t pos = 0;
+        walk_off_out[0] = 0;
+        for (size_t i = 0; i < chain.size(); ++i) {
+            if (chain[i].walk1.size() != chain[i].walk2.size()) return -5;
+            for (size_t j = 0; j < chain[i].walk1.size(); ++j) { (*walk1_out)[pos + j] = (uint32_t)chain[i].walk1[j]; (*walk2_out)[pos + j] = (uint32_t)chain[i].walk2[j]; }
+            pos += chain[i].walk1.size();
+            walk_off_out[i + 1] = pos;
+        }
+    }
     for (size_t i = 0; i < chain.size(); ++i) {
-        anchors_out[3 * i] = (uint32_t)chain[i].match_set;
-        anchors_out[3 * i + 1] = (uint32_t)chain[i].idx1;
-        anchors_out[3 * i + 2] = (uint32_t)chain[i].idx2;
+        anchors_out[3 * i] = chain[i].match_set;
+        anchors_out[3 * i + 1] = chain[i].idx1;
+        anchors_out[3 * i + 2] = chain[i].idx2;
+        counts_out[3 * i] = chain[i].count1;
+        counts_out[3 * i + 1] = chain[i].count2;
+        counts_out[3 * i + 2] = chain[i].full_length;
         gap_before[i] = chain[i].gap_before;
         gap_after[i] = chain[i].gap_after;
         gap_score_before[i] = chain[i].gap_score_before;
@@ -512,6 +531,8 @@ int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
     }
     return 0;
 }
+
+void ref_free(void* p) { free(p); }
 
 /* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as
  * cl_despecify_indel_breakpoints */

@@ -160,7 +160,8 @@ def main():
                 out[tag + ".chain_affine_global"], _ = po.ref_chain("affine", g1, g2, ms, scale=scale, global_anchoring=True)
             np.savez_compressed(os.path.join(HERE, "chain4_30k_merge%d.npz" % m), **out)
         # 6b. Anchorer::anchor_chain seam (budgeted selection + reorder, scale estimate, affine chain, annotation) with
-        #     do_fill_in_anchoring = split_matches_at_branchpoints = false; "g" = global anchoring (CLI default), "l" = local
+        #     split_matches_at_branchpoints = false; "g" = global anchoring (CLI default), "l" = local, "n" = no
+        #     autocalibration, all three without fill-in; "f" / "fl" = with fill-in re-anchoring (global / local)
         for m in range(int(dd["n_merges"][0])):
             pre = "m%d." % m
             g1, g2 = po.graphs_from_dump(dd, pre)
@@ -168,9 +169,10 @@ def main():
             out = {"score_scale": dd[pre + "score_scale"], "max_num_match_pairs": np.array([20000], np.uint64)}
             for k in po.MatchSets._DT:
                 out["ms." + k] = getattr(ms, k)
-            for tag, glob, auto in (("g", True, True), ("l", False, True), ("n", True, False)):
+            for tag, glob, auto, fill in (("g", True, True, False), ("l", False, True, False), ("n", True, False, False),
+                                          ("f", True, True, True), ("fl", False, True, True)):
                 r = po.ref_anchor_chain(g1, g2, ms, max_num_match_pairs=20000, score_scale=float(dd[pre + "score_scale"][0]),
-                                        autocalibrate=auto, global_anchoring=glob)
+                                        autocalibrate=auto, global_anchoring=glob, fill_in=fill)
                 for k, v in r.items():
                     out["%s.%s" % (tag, k)] = np.asarray(v)
             np.savez_compressed(os.path.join(HERE, "anchor4_30k_merge%d.npz" % m), **out)

@@ -68,22 +68,25 @@ def test_sparse_chain_matches_reference_golden(gpu_ctx, name, glob):
 ANCHOR_FILES = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("anchor4_"))
 
 
-@pytest.mark.parametrize("tag,glob,auto", [("g", True, True), ("l", False, True), ("n", True, False)])
+@pytest.mark.parametrize("tag,glob,auto,fill", [("g", True, True, False), ("l", False, True, False), ("n", True, False, False),
+                                                ("f", True, True, True), ("fl", False, True, True)])
 @pytest.mark.parametrize("name", ANCHOR_FILES)
-def test_anchor_chain_matches_reference_golden(gpu_ctx, name, tag, glob, auto):
-    """cl_anchor_chain == Anchorer::anchor_chain of the compiled reference (fill-in and branch splitting off): the same
-    reordering of the caller's match sets, the same estimated scale, the same chain with the same gap / score annotation"""
+def test_anchor_chain_matches_reference_golden(gpu_ctx, name, tag, glob, auto, fill):
+    """cl_anchor_chain == Anchorer::anchor_chain of the compiled reference (branch splitting off; with and without fill-in
+    re-anchoring): the same reordering of the caller's match sets, the same estimated scale, the same chain with the same
+    walks, identities, counts and gap / score annotation"""
     z = np.load(os.path.join(H.GOLDEN, name))
     _, graphs, _ = load_stitch_case(name.replace("anchor4_", "stitch4_"))
     ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
     got = gpu_ctx.anchor_chain(graphs[0], graphs[1], ms, max_num_match_pairs=int(z["max_num_match_pairs"][0]),
-                               score_scale=float(z["score_scale"][0]), autocalibrate=auto,
+                               score_scale=float(z["score_scale"][0]), autocalibrate=auto, fill_in=fill,
                                params=capi.default_chain_params(global_anchoring=glob))
     assert got["scale"] == float(z[tag + ".scale"])
-    assert np.array_equal(got["set_order"], z[tag + ".set_order"])
-    assert np.array_equal(got["chain"], z[tag + ".chain"])
-    for k in ("gap_before", "gap_after", "gap_score_before", "gap_score_after"):
+    for k in ("set_order", "chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "gap_before", "gap_after",
+              "gap_score_before", "gap_score_after"):
         assert np.array_equal(got[k], z["%s.%s" % (tag, k)]), k
     # anchor_t::score is a double that the reference evaluates under -ffast-math (its CMakeLists.txt:9): the last bits are
     # the compiler's choice, so this one field is compared to 1e-12 relative (the float DP weights derived from it are exact)
     assert np.allclose(got["score"], z[tag + ".score"], rtol=1e-12, atol=0)
+    if fill:
+        assert got["fill_in_pairs"] > 0 and len(got["chain"]) > 2 * len(z["g.chain"])
