@@ -192,6 +192,34 @@ def despecify_indel_breakpoints(score, gap_before, gap_score_before, gap_after, 
     return keep[:n].astype(bool), gb[:k], gsb[:k], ga[:k], gsa[:k]
 
 
+def split_branching_matches(graph1, graph2, matches, anchor_split_limit=5, min_split_length=128, min_path_length_spread=50,
+                            max_split_match_set_size=16):
+    """Anchorer::split_branching_matches (include/centrolign/anchorer.hpp:800-956); host only.  Returns the new MatchSets."""
+    lib = load_library()
+    g1, g2, mc = graph1.as_c(), graph2.as_c(), matches.as_c()
+    sp = SplitParams(anchor_split_limit, min_split_length, min_path_length_spread, max_split_match_set_size)
+    h = C.c_void_p()
+    rc = lib.cl_split_branching_matches(C.byref(g1), C.byref(g2), C.byref(mc), C.byref(sp), C.byref(h))
+    if rc != 0:
+        raise ClError(rc)
+    try:
+        v = MatchSetsC()
+        lib.cl_owned_match_sets_view(h, C.byref(v))
+        n = int(v.n_sets)
+
+        def arr(ptr, dt, k):
+            if k == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(k,)).copy()
+        so1, so2 = arr(v.set_off1, np.uint64, n + 1), arr(v.set_off2, np.uint64, n + 1)
+        wo1, wo2 = arr(v.walk_off1, np.uint64, int(so1[-1]) + 1), arr(v.walk_off2, np.uint64, int(so2[-1]) + 1)
+        return MatchSets(set_off1=so1, walk_off1=wo1, nodes1=arr(v.nodes1, np.uint32, int(wo1[-1])), set_off2=so2, walk_off2=wo2,
+                         nodes2=arr(v.nodes2, np.uint32, int(wo2[-1])), count1=arr(v.count1, np.uint64, n),
+                         count2=arr(v.count2, np.uint64, n), full_length=arr(v.full_length, np.uint64, n))
+    finally:
+        lib.cl_owned_match_sets_free(h)
+
+
 def extract_stitch_batch(graph1, graph2, segments):
     """Extractor::extract_graphs_between in Stitcher::stitch's consumption order (host only, no GPU needed)"""
     lib = load_library()
@@ -228,6 +256,12 @@ class ChainResultC(C.Structure):
                 ("prep_ms", C.c_float), ("index_ms", C.c_float), ("traceback_ms", C.c_float),
                 ("gap_before_first", C.c_int64), ("gap_after_last", C.c_int64),
                 ("gap_score_before_first", C.c_double), ("gap_score_after_last", C.c_double)]
+
+
+class SplitParams(C.Structure):
+    """cl_split_params: Anchorer::anchor_split_limit, min_split_length, min_path_length_spread, max_split_match_set_size"""
+    _fields_ = [("anchor_split_limit", C.c_uint64), ("min_split_length", C.c_uint64), ("min_path_length_spread", C.c_uint64),
+                ("max_split_match_set_size", C.c_uint64)]
 
 
 class AnchorParams(C.Structure):
@@ -557,6 +591,15 @@ def load_library(path=None):
     lib.cl_chain_sparse.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
                                     C.POINTER(ChainParams), C.c_int, C.POINTER(ChainResultC)]
     lib.cl_chain_result_free.argtypes = [C.POINTER(ChainResultC)]
+    lib.cl_split_params_default.restype = None
+    lib.cl_split_params_default.argtypes = [C.POINTER(SplitParams)]
+    lib.cl_split_branching_matches.restype = C.c_int
+    lib.cl_split_branching_matches.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.POINTER(SplitParams),
+                                               C.POINTER(C.c_void_p)]
+    lib.cl_owned_match_sets_view.restype = None
+    lib.cl_owned_match_sets_view.argtypes = [C.c_void_p, C.POINTER(MatchSetsC)]
+    lib.cl_owned_match_sets_free.restype = None
+    lib.cl_owned_match_sets_free.argtypes = [C.c_void_p]
     lib.cl_anchor_chain.restype = C.c_int
     lib.cl_anchor_chain.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC),
                                     C.POINTER(AnchorParams), C.POINTER(AnchorChainResultC)]
@@ -576,6 +619,7 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
     "cl_anchor_chain", "cl_anchor_chain_result_free",
+    "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
 ]
 
 

@@ -2,10 +2,12 @@
 //   cl_despecify_indel_breakpoints <-> Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) over
 //                                      identify_despecification_partition (src/stitcher.cpp:115-263) and
 //                                      PartitionClient::traceback (include/centrolign/partition_client.hpp:31-54)
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <tuple>
 #include <vector>
 
@@ -122,6 +124,175 @@ int cl_despecify_indel_breakpoints(uint64_t n_anchors, const double* score, int6
     const size_t kept = n_anchors - removed;
     for (size_t i = 0; i < kept; ++i) { gap_before[i] = gb[i]; gap_after[i] = ga[i]; gap_score_before[i] = gsb[i]; gap_score_after[i] = gsa[i]; }
     *n_kept_out = kept;
+    return CL_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Anchorer::split_branching_matches (include/centrolign/anchorer.hpp:800-956)
+// =====================================================================================================================
+#include "stitch_host.hpp"
+
+struct cl_owned_match_sets {
+    std::vector<uint64_t> set_off1{0}, walk_off1{0}, set_off2{0}, walk_off2{0}, count1, count2, full_length;
+    std::vector<uint32_t> nodes1, nodes2;
+};
+
+namespace {
+
+// SuperbubbleTree(graph, tableau) + SuperbubbleDistances reduced to what the splitter asks: which superbubble begins /
+// ends at a node and the spread between the longest and the shortest path through it.  Superbubbles by the sweep of
+// superbubbles.hpp:63-170 over the reference's topological order; bubbles that touch a sentinel are dropped
+// (structure_tree.hpp:164-169).  On a BaseGraph every label has size 1, so the min / max "distance" of
+// structure_distances.hpp:107-150 is the number of nodes on the shortest / longest path between the two boundaries.
+struct Bubbles {
+    std::vector<uint32_t> begins, ends;   // node -> bubble id or none
+    std::vector<uint64_t> spread;         // max - min path length through the bubble
+    static constexpr uint32_t none = 0xFFFFFFFFu;
+    bool build(const cl_base_graph& g) {
+        const uint64_t n = g.n_nodes;
+        std::vector<uint32_t> order;
+        if (!clhost::topological_order(g, order)) return false;
+        std::vector<int64_t> index(n);
+        for (uint64_t i = 0; i < n; ++i) index[order[i]] = (int64_t)i;
+        begins.assign(n, none);
+        ends.assign(n, none);
+        std::vector<int64_t> stack, backward(n, INT64_MAX);
+        std::vector<std::pair<uint32_t, uint32_t>> found;
+        for (int64_t i = (int64_t)n - 1; i >= 0; --i) {
+            const uint32_t v = order[i];
+            int64_t forward = -1;
+            for (uint64_t e = g.next_off[v]; e < g.next_off[v + 1]; ++e) forward = std::max(forward, index[g.next_idx[e]]);
+            if (forward == i + 1) stack.push_back(i + 1);
+            while (!stack.empty() && forward > stack.back()) {
+                const int64_t bad = stack.back();
+                stack.pop_back();
+                if (!stack.empty()) backward[stack.back()] = std::min(backward[stack.back()], backward[bad]);
+            }
+            if (!stack.empty() && backward[stack.back()] == i) {
+                const int64_t ok = stack.back();
+                found.emplace_back(v, order[ok]);
+                stack.pop_back();
+                if (!stack.empty()) backward[stack.back()] = std::min(backward[stack.back()], backward[ok]);
+            }
+            for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) backward[i] = std::min(backward[i], index[g.prev_idx[e]]);
+            if (!stack.empty()) backward[stack.back()] = std::min(backward[stack.back()], backward[i]);
+        }
+        std::vector<int64_t> dmin(n), dmax(n);
+        for (const auto& b : found) {
+            if (b.first == g.src_id || b.second == g.snk_id || b.first == g.snk_id || b.second == g.src_id) continue;
+            const uint32_t id = (uint32_t)spread.size();
+            begins[b.first] = id;
+            ends[b.second] = id;
+            // the bubble's nodes occupy the positions index[begin] .. index[end] of the order
+            const int64_t lo = index[b.first], hi = index[b.second];
+            for (int64_t i = lo; i <= hi; ++i) { dmin[order[i]] = INT64_MAX; dmax[order[i]] = -1; }
+            dmin[b.first] = dmax[b.first] = 1;
+            for (int64_t i = lo; i < hi; ++i) {
+                const uint32_t v = order[i];
+                if (dmax[v] < 0) continue;
+                for (uint64_t e = g.next_off[v]; e < g.next_off[v + 1]; ++e) {
+                    const uint32_t w = g.next_idx[e];
+                    dmin[w] = std::min(dmin[w], dmin[v] + 1);
+                    dmax[w] = std::max(dmax[w], dmax[v] + 1);
+                }
+            }
+            spread.push_back((uint64_t)(dmax[b.second] - dmin[b.second]));
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void cl_split_params_default(cl_split_params* p) {
+    p->anchor_split_limit = 5;
+    p->min_split_length = 128;
+    p->min_path_length_spread = 50;
+    p->max_split_match_set_size = 16;
+}
+
+void cl_owned_match_sets_view(const cl_owned_match_sets* o, cl_match_sets* v) {
+    *v = cl_match_sets{o->count1.size(), o->set_off1.data(), o->walk_off1.data(), o->nodes1.data(), o->set_off2.data(), o->walk_off2.data(),
+                       o->nodes2.data(), o->count1.data(), o->count2.data(), o->full_length.data()};
+}
+
+void cl_owned_match_sets_free(cl_owned_match_sets* o) { delete o; }
+
+int cl_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp,
+                               cl_owned_match_sets** out) {
+    if (!g1 || !g2 || !ms || !sp || !out) return CL_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<cl_owned_match_sets> o(new cl_owned_match_sets());
+    // a set during the edit: walks as (begin, end) windows into the caller's node arrays
+    struct Set { uint64_t src; uint64_t from, to; };   // piece [from, to) of every walk of original set src
+    std::vector<Set> sets;
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        const uint64_t w0 = ms->set_off1[s];
+        const uint64_t len = ms->set_off1[s + 1] > w0 ? ms->walk_off1[w0 + 1] - ms->walk_off1[w0] : 0;
+        sets.push_back(Set{s, 0, len});
+    }
+    if (sp->anchor_split_limit != 0) {
+        Bubbles b1, b2;
+        if (!b1.build(*g1) || !b2.build(*g2)) return CL_ERR_CYCLIC_GRAPH;
+        const uint64_t n_orig = ms->n_sets;
+        for (uint64_t s = 0; s < n_orig; ++s) {
+            const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
+            if (n1 == 0) return CL_ERR_INVALID_ARGUMENT;   // the reference reads walks1.front()
+            const uint64_t len = sets[s].to;
+            if (n1 * n2 > sp->max_split_match_set_size || len < sp->min_split_length) continue;
+            auto branch = [&](uint64_t j, bool backwards) {
+                for (int side = 0; side < 2; ++side) {
+                    const Bubbles& b = side ? b2 : b1;
+                    const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
+                    const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
+                    const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
+                    for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
+                        const uint32_t id = (backwards ? b.ends : b.begins)[nd[wo[w] + j]];
+                        if (id != Bubbles::none && b.spread[id] >= sp->min_path_length_spread) return true;
+                    }
+                }
+                return false;
+            };
+            std::vector<uint64_t> division;
+            // note: stops early, a branch after the final position is not problematic
+            for (uint64_t j = 0; j < len; ++j) {
+                if (j == sp->anchor_split_limit && j + sp->anchor_split_limit < len) j = len - sp->anchor_split_limit;   // skip to the suffix
+                if (j != 0 && (division.empty() || division.back() != j) && branch(j, true)) division.push_back(j);
+                if (j + 1 != len && branch(j, false)) division.push_back(j + 1);
+            }
+            if (division.empty()) continue;
+            uint64_t end = len;
+            for (size_t q = division.size(); q-- > 0;) {
+                sets.push_back(Set{s, division[q], end});
+                end = division[q];
+            }
+            sets[s].to = division.front();
+        }
+    }
+    for (const Set& st : sets) {
+        const uint64_t s = st.src;
+        for (int side = 0; side < 2; ++side) {
+            const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
+            const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
+            const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
+            auto& oso = side ? o->set_off2 : o->set_off1;
+            auto& owo = side ? o->walk_off2 : o->walk_off1;
+            auto& ond = side ? o->nodes2 : o->nodes1;
+            for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
+                ond.insert(ond.end(), nd + wo[w] + st.from, nd + wo[w] + st.to);
+                owo.push_back(ond.size());
+            }
+            oso.push_back(owo.size() - 1);
+        }
+        o->count1.push_back(ms->count1[s]);
+        o->count2.push_back(ms->count2[s]);
+        o->full_length.push_back(ms->full_length[s]);
+    }
+    *out = o.release();
     return CL_OK;
 }
 

@@ -306,8 +306,25 @@ int  cl_chain_sparse(cl_context* ctx, const cl_base_graph* graph1, const cl_base
                      uint64_t num_match_sets, const cl_chain_params* params, int want_dp, cl_chain_result* out);
 void cl_chain_result_free(cl_chain_result* r);
 
-/* --- Anchorer::anchor_chain (include/centrolign/anchorer.hpp:135-145, 958-1329), no masks,
- * split_matches_at_branchpoints = false: budgeted match selection (which REORDERS the caller's match sets, :1108-1173),
+/* --- Anchorer::split_branching_matches (include/centrolign/anchorer.hpp:800-956), the first step of anchor_chain when
+ * split_matches_at_branchpoints is set (CLI default): match sets whose walks cross the boundary of a superbubble with a
+ * large length spread (superbubbles.hpp:63-170, structure_distances.hpp:55-185) near their ends are cut there; the pieces
+ * are appended to the vector as new sets.  Host only, no masks.  The result owns its arrays. */
+typedef struct cl_split_params {
+    uint64_t anchor_split_limit;        /* Anchorer::anchor_split_limit (5) */
+    uint64_t min_split_length;          /* Anchorer::min_split_length (128) */
+    uint64_t min_path_length_spread;    /* Anchorer::min_path_length_spread (50) */
+    uint64_t max_split_match_set_size;  /* Anchorer::max_split_match_set_size (16) */
+} cl_split_params;
+void cl_split_params_default(cl_split_params* p);
+typedef struct cl_owned_match_sets cl_owned_match_sets;
+int  cl_split_branching_matches(const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+                                const cl_split_params* params, cl_owned_match_sets** out);
+void cl_owned_match_sets_view(const cl_owned_match_sets* sets, cl_match_sets* view_out);
+void cl_owned_match_sets_free(cl_owned_match_sets* sets);
+
+/* --- Anchorer::anchor_chain (include/centrolign/anchorer.hpp:135-145, 958-1329), no masks, after
+ * cl_split_branching_matches (the caller runs it first, as anchor_chain does at :971-973): budgeted match selection (which REORDERS the caller's match sets, :1108-1173),
  * scale estimation (:998-1047), the affine chain, gap and score annotation (:2443-2468), and — with
  * do_fill_in_anchoring — fill_in_anchor_chain (:619-699): every gap of the chain is re-anchored with the matches that lie
  * inside it (divvy_matches :701-798, assign_reanchor_budget / merge_fill_in_chains src/anchorer.cpp:136-222); the DPs of

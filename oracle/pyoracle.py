@@ -321,3 +321,37 @@ def ref_anchor_chain(g1, g2, ms, max_num_match_pairs=1250000, score_scale=1.0, a
                 gap_score_after=gsa[:k].copy(), score=sc[:k].copy(), count1=counts[:k, 0].copy(), count2=counts[:k, 1].copy(),
                 full_length=counts[:k, 2].copy(), walk_off=walk_off[:k + 1].copy(), walk1=w1, walk2=w2,
                 set_order=order[:ms.n_sets].copy(), scale=float(scale.value))
+
+
+def ref_split_branching_matches(g1, g2, ms, anchor_split_limit=5, min_split_length=128, min_path_length_spread=50,
+                                max_split_match_set_size=16):
+    """the compiled reference's Anchorer::split_branching_matches (anchorer.hpp:800-956); returns the new MatchSets"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_split_branching_matches.restype = C.c_int
+    lib.ref_split_branching_matches.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets)] + [C.c_uint64] * 4 + [C.c_void_p] * 4
+    lib.ref_free.argtypes = [C.c_void_p]
+    c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
+    n, nn = C.c_uint64(0), C.c_uint64(0)
+    rows_p, nodes_p = C.c_void_p(), C.c_void_p()
+    rc = lib.ref_split_branching_matches(C.byref(c1), C.byref(c2), C.byref(mc), anchor_split_limit, min_split_length, min_path_length_spread,
+                                         max_split_match_set_size, C.addressof(n), C.addressof(rows_p), C.addressof(nodes_p), C.addressof(nn))
+    if rc:
+        raise RuntimeError("ref_split_branching_matches failed: %d" % rc)
+    k, tot = int(n.value), int(nn.value)
+    rows = np.ctypeslib.as_array(C.cast(rows_p, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 6,))[:6 * k].copy().reshape(k, 6)
+    nodes = np.ctypeslib.as_array(C.cast(nodes_p, C.POINTER(C.c_uint32)), shape=(max(tot, 1),))[:tot].copy()
+    lib.ref_free(rows_p)
+    lib.ref_free(nodes_p)
+    n1, n2, ln = rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64), rows[:, 2].astype(np.int64)
+    so1 = np.concatenate([[0], np.cumsum(n1)]).astype(np.uint64)
+    so2 = np.concatenate([[0], np.cumsum(n2)]).astype(np.uint64)
+    wo1 = np.concatenate([[0], np.cumsum(np.repeat(ln, n1))]).astype(np.uint64)
+    wo2 = np.concatenate([[0], np.cumsum(np.repeat(ln, n2))]).astype(np.uint64)
+    # nodes: per set its graph-1 walks then its graph-2 walks
+    per_set = (n1 + n2) * ln
+    start = np.concatenate([[0], np.cumsum(per_set)])
+    nodes1 = np.concatenate([nodes[start[s]:start[s] + n1[s] * ln[s]] for s in range(k)]) if k else np.zeros(0, np.uint32)
+    nodes2 = np.concatenate([nodes[start[s] + n1[s] * ln[s]:start[s + 1]] for s in range(k)]) if k else np.zeros(0, np.uint32)
+    return MatchSets(set_off1=so1, walk_off1=wo1, nodes1=nodes1, set_off2=so2, walk_off2=wo2, nodes2=nodes2,
+                     count1=rows[:, 3], count2=rows[:, 4], full_length=rows[:, 5])

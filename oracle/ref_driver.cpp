@@ -387,6 +387,7 @@ struct OpenAnchorer : public Anchorer {
     using Anchorer::sparse_affine_chain_dp;
     using Anchorer::sparse_chain_dp;
     using Anchorer::estimate_score_scale;
+    using Anchorer::split_branching_matches;
 };
 
 extern "C" {
@@ -533,6 +534,47 @@ int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
 }
 
 void ref_free(void* p) { free(p); }
+
+/* Anchorer::split_branching_matches (anchorer.hpp:800-956) on flat inputs.  Output: the resulting sets as
+ * (source set, n walks1, n walks2, walk length) rows plus every walk's nodes, graph-1 walks then graph-2 walks per set. */
+int ref_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t anchor_split_limit,
+                                uint64_t min_split_length, uint64_t min_path_length_spread, uint64_t max_split_match_set_size,
+                                uint64_t* n_sets_out, uint64_t** rows_out, uint32_t** nodes_out, uint64_t* n_nodes_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    std::vector<match_set_t> sets(ms->n_sets);
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
+            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
+        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
+            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
+        sets[s].count1 = ms->count1[s];
+        sets[s].count2 = ms->count2[s];
+        sets[s].full_length = ms->full_length[s];
+    }
+    ScoreFunction sf;
+    OpenAnchorer an(sf);
+    an.anchor_split_limit = anchor_split_limit;
+    an.min_split_length = min_split_length;
+    an.min_path_length_spread = min_path_length_spread;
+    an.max_split_match_set_size = max_split_match_set_size;
+    an.split_branching_matches(sets, b1, b2, t1, t2, nullptr);
+    *n_sets_out = sets.size();
+    uint64_t total = 0;
+    for (const auto& st : sets) { for (const auto& w : st.walks1) total += w.size(); for (const auto& w : st.walks2) total += w.size(); }
+    *rows_out = (uint64_t*)malloc((sets.size() ? sets.size() : 1) * 6 * sizeof(uint64_t));
+    *nodes_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+    *n_nodes_out = total;
+    uint64_t pos = 0;
+    for (size_t s = 0; s < sets.size(); ++s) {
+        uint64_t* row = *rows_out + 6 * s;
+        row[0] = sets[s].walks1.size(); row[1] = sets[s].walks2.size(); row[2] = sets[s].walks1.front().size();
+        row[3] = sets[s].count1; row[4] = sets[s].count2; row[5] = sets[s].full_length;
+        for (const auto& w : sets[s].walks1) for (auto v : w) (*nodes_out)[pos++] = (uint32_t)v;
+        for (const auto& w : sets[s].walks2) for (auto v : w) (*nodes_out)[pos++] = (uint32_t)v;
+    }
+    return 0;
+}
 
 /* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as
  * cl_despecify_indel_breakpoints */

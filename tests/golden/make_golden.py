@@ -175,7 +175,26 @@ def main():
                                         autocalibrate=auto, global_anchoring=glob, fill_in=fill)
                 for k, v in r.items():
                     out["%s.%s" % (tag, k)] = np.asarray(v)
+            # "sf": the whole default-configured call — split_branching_matches first (anchorer.hpp:971-973; tunables
+            # (5, 30, 1, 16) so that the small graphs split), then chaining with fill-in on the split sets
+            split = po.ref_split_branching_matches(g1, g2, ms, 5, 30, 1, 16)
+            r = po.ref_anchor_chain(g1, g2, split, max_num_match_pairs=20000, score_scale=float(dd[pre + "score_scale"][0]), fill_in=True)
+            for k, v in r.items():
+                out["sf.%s" % k] = np.asarray(v)
             np.savez_compressed(os.path.join(HERE, "anchor4_30k_merge%d.npz" % m), **out)
+        # 6c. Anchorer::split_branching_matches on the match sets of 6b (inputs: anchor4_30k_merge*.npz "ms.*"); "a" = the CLI
+        #     tunables with a spread threshold the small graphs reach, "b" = aggressive splitting
+        for m in range(int(dd["n_merges"][0])):
+            pre = "m%d." % m
+            g1, g2 = po.graphs_from_dump(dd, pre)
+            ms = po.budget_subset(po.MatchSets.from_dump(dd, pre), 60000, seed=20 + m)
+            out = {}
+            for tag, prm in (("a", (5, 30, 1, 16)), ("b", (3, 10, 0, 64))):
+                r = po.ref_split_branching_matches(g1, g2, ms, *prm)
+                out[tag + ".params"] = np.array(prm, np.uint64)
+                for k in po.MatchSets._DT:
+                    out["%s.%s" % (tag, k)] = getattr(r, k)
+            np.savez_compressed(os.path.join(HERE, "split4_30k_merge%d.npz" % m), **out)
     else:
         print("skip stitch-level fixtures (no dump at %s)" % path)
     # 7. despecify_indel_breakpoints: random anchor chains -> the reference's kept set and updated gap fields

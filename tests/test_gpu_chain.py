@@ -90,3 +90,19 @@ def test_anchor_chain_matches_reference_golden(gpu_ctx, name, tag, glob, auto, f
     assert np.allclose(got["score"], z[tag + ".score"], rtol=1e-12, atol=0)
     if fill:
         assert got["fill_in_pairs"] > 0 and len(got["chain"]) > 2 * len(z["g.chain"])
+
+
+@pytest.mark.parametrize("name", ANCHOR_FILES)
+def test_default_anchor_chain_with_splitting(gpu_ctx, name):
+    """the default-configured Anchorer::anchor_chain: split_branching_matches, then chaining with fill-in, global anchoring"""
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("anchor4_", "stitch4_"))
+    ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
+    split = capi.split_branching_matches(graphs[0], graphs[1], ms, 5, 30, 1, 16)
+    got = gpu_ctx.anchor_chain(graphs[0], graphs[1], split, max_num_match_pairs=int(z["max_num_match_pairs"][0]),
+                               score_scale=float(z["score_scale"][0]))
+    assert got["scale"] == float(z["sf.scale"])
+    for k in ("set_order", "chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "gap_before", "gap_after",
+              "gap_score_before", "gap_score_after"):
+        assert np.array_equal(got[k], z["sf." + k]), k
+    assert np.allclose(got["score"], z["sf.score"], rtol=1e-12, atol=0)
