@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -68,13 +69,25 @@ struct PostSwitchTable {
 };
 
 double anchor_weight(const cl_chain_params& cp, uint64_t count1, uint64_t count2, uint64_t length, uint64_t full_length) {
+    // ScoreFunction::anchor_weight (score_function.hpp:51-75) in the operation order of the reference AS BUILT: its
+    // CMakeLists.txt:9 compiles with -O3 -ffast-math, under which gcc turns "x / pow(c, p)" into "x * pow(c, -p)" and
+    // regroups the products (disassembly of oracle/_ref).  Mathematically tied weights (e.g. lengths symmetric about the
+    // vertex of the concave length term) order match sets in the budget selection (anchorer.hpp:1130-1134), so the
+    // last bit matters.
     const double count = (double)(count1 * count2);
     const double fraction = double(length) / double(full_length);
     switch (cp.anchor_score_function) {
-    case 0: return fraction / pow(count, cp.pair_count_power);
-    case 1: return fraction * length / pow(count, cp.pair_count_power);
-    case 2: return fraction * (length / pow(count, cp.pair_count_power) - pow(length / cp.length_intercept, cp.length_decay_power) * cp.length_intercept);
-    default: return fraction * (length - count * pow(length / cp.length_intercept, cp.length_decay_power) * cp.length_intercept);
+    case 0: return pow(count, -cp.pair_count_power) * fraction;
+    case 1: return (fraction * (double)length) * pow(count, -cp.pair_count_power);
+    case 2: {
+        const double inv = pow(count, -cp.pair_count_power);
+        const double decay = pow((double)length / cp.length_intercept, cp.length_decay_power);
+        return (inv * (double)length - cp.length_intercept * decay) * fraction;
+    }
+    default: {
+        const double decay = pow((double)length / cp.length_intercept, cp.length_decay_power);
+        return ((double)length - (cp.length_intercept * count) * decay) * fraction;
+    }
     }
 }
 
@@ -136,6 +149,14 @@ void replay_units(size_t n, const std::vector<uint32_t>& rank_of_heap, size_t rl
     }
 }
 
+// a gap-free search tree of the reference, as its sorted key list + implicit heap layout (built on first use)
+struct GapFreeTree {
+    struct Member { uint32_t off, slot, rec; };
+    std::vector<Member> mem;
+    std::vector<uint32_t> heap, rank_of_heap;
+    bool built = false;
+};
+
 struct Combo {
     uint32_t p1 = 0, p2 = 0;
     std::vector<uint32_t> rec_s, ins_t, off;
@@ -154,6 +175,7 @@ struct Combo {
         std::vector<uint32_t> ortho_order;  // ... sorted by (sigma, slot)
         std::vector<uint32_t> ortho_heap, ortho_rank_of_heap;
         std::unordered_map<int32_t, std::vector<uint32_t>> by_diag;  // gap-free trees: records of each shift
+        std::unordered_map<int32_t, GapFreeTree> diag_tree;
         bool diag_built = false;
     };
     std::unordered_map<uint32_t, SubRecs> per_sub;
@@ -627,6 +649,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     tm.index_ms += ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
 
+    std::unordered_map<uint64_t, GapFreeTree> sparse_trees;   // sparse mode: (chain2 tag, instance) -> tree
     // records of one instance inside a combination (the reference's trees belong to ONE chaining call)
     auto sub_recs = [&](Combo& c, uint32_t k) -> Combo::SubRecs& {
         if (!c.split_built) {
@@ -722,32 +745,39 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                     // members of the tree, as (offset, slot, record-or-none): affine mode -> the records of this combination with
                     // the query's shift; sparse mode -> every pair whose e2 is filed under chain2, whatever its chain1
                     // (search_trees[i][j] is built from search_tree_data[j] for every i, anchorer.hpp:1581-1592)
-                    struct Member { uint32_t off, slot, rec; };
-                    std::vector<Member> mem;
+                    GapFreeTree* tree;
                     if (!sparse) {
                         Combo::SubRecs& sr = sub_recs(c, k);
                         if (!sr.diag_built) {  // records bucketed by shift, built once
                             for (uint32_t r : sr.recs) sr.by_diag[c.sigma[r]].push_back(r);
                             sr.diag_built = true;
                         }
-                        for (uint32_t r : sr.by_diag[c.q[s]]) mem.push_back(Member{c.off[r], slot_of_rec(r), r});
+                        tree = &sr.diag_tree[c.q[s]];
+                        if (!tree->built)
+                            for (uint32_t r : sr.by_diag[c.q[s]]) tree->mem.push_back(GapFreeTree::Member{c.off[r], slot_of_rec(r), r});
                     } else {
-                        for (Combo& oc : combos)
-                            if (oc.p2 == c.p2)
-                                for (uint32_t r : sub_recs(oc, k).recs) mem.push_back(Member{oc.off[r], by_s[oc.rec_s[r]], &oc == &c ? r : kNone});
+                        tree = &sparse_trees[((uint64_t)c.p2 << 32) | k];
+                        if (!tree->built)
+                            for (Combo& oc : combos)
+                                if (oc.p2 == c.p2)
+                                    for (uint32_t r : sub_recs(oc, k).recs) tree->mem.push_back(GapFreeTree::Member{oc.off[r], by_s[oc.rec_s[r]], r});
                     }
-                    std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; });
-                    std::vector<uint32_t> members(mem.size());
-                    for (size_t i = 0; i < mem.size(); ++i) members[i] = mem[i].rec;
-                    const size_t n = members.size();
-                    auto h = heap_of_rank(n);
-                    std::vector<uint32_t> rank_of_heap(n);
-                    for (size_t r = 0; r < n; ++r) rank_of_heap[h[r]] = (uint32_t)r;
-                    size_t rhi = 0;
-                    while (rhi < n && mem[rhi].off < c.qoff[s]) ++rhi;
+                    if (!tree->built) {
+                        std::sort(tree->mem.begin(), tree->mem.end(), [](const GapFreeTree::Member& a, const GapFreeTree::Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; });
+                        tree->heap = heap_of_rank(tree->mem.size());
+                        tree->rank_of_heap.resize(tree->mem.size());
+                        for (size_t r = 0; r < tree->mem.size(); ++r) tree->rank_of_heap[tree->heap[r]] = (uint32_t)r;
+                        tree->built = true;
+                    }
+                    const auto& mem = tree->mem;
+                    const size_t n = mem.size();
+                    const auto& h = tree->heap;
+                    const auto& rank_of_heap = tree->rank_of_heap;
+                    const size_t rhi = std::partition_point(mem.begin(), mem.end(), [&](const GapFreeTree::Member& m) { return m.off < c.qoff[s]; }) - mem.begin();
                     std::vector<std::pair<size_t, uint32_t>> ch;  // (heap node, record)
                     for (uint32_t r : cand) {
-                        const size_t rk = std::find(members.begin(), members.end(), r) - members.begin();
+                        const GapFreeTree::Member key{c.off[r], slot_of_rec(r), r};
+                        const size_t rk = std::lower_bound(mem.begin(), mem.end(), key, [](const GapFreeTree::Member& a, const GapFreeTree::Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; }) - mem.begin();
                         ch.emplace_back(h[rk], r);
                     }
                     auto earlier = [&](uint32_t a, uint32_t b) {
@@ -1082,6 +1112,13 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     std::iota(cur.begin(), cur.end(), (uint64_t)0);
     PathsOfNode steps1, steps2;
     if (ap->do_fill_in_anchoring) { steps1.build(*g1); steps2.build(*g2); }
+    // CL_CHAIN_TIMING=1: host phase times on stderr
+    const bool timing = getenv("CL_CHAIN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t) {
+        if (timing) fprintf(stderr, "[cl_anchor_chain] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now() - t).count());
+        t = now();
+    };
 
     // walks of (position in `cur`, idx) on the caller's sets
     auto walk = [&](int side, uint64_t set_pos, uint32_t idx, const uint32_t*& b, const uint32_t*& e) {
@@ -1096,6 +1133,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     //      wholly inside it; all the gaps' DPs run as one batched device pass
     auto fill_in = [&](std::vector<HAnchor>& anchors, bool sparse, double anchor_scale) -> int {
         if (anchors.empty()) return CL_OK;
+        auto t = now();
         std::vector<uint64_t> seg_off{0, anchors.size()}, walk_off{0};
         std::vector<uint32_t> w1, w2;
         for (const HAnchor& a : anchors) {
@@ -1107,6 +1145,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         clhost::OwnedBatch ob;
         int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob);
         if (rc) { cl_set_error(ctx, "extraction failed"); return rc; }
+        lap("fill-in: extraction", t);
         const size_t K = ob.only_del.size();
         // divvy_matches (anchorer.hpp:701-798): a walk goes to the gap that holds both its ends
         const uint32_t none = 0xFFFFFFFFu;
@@ -1164,6 +1203,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
                 d.origin_idx2.push_back(std::move(q.idx2));
             }
         }
+        lap("fill-in: divvy", t);
         // assign_reanchor_budget (src/anchorer.cpp:136-154)
         uint64_t total = 0;
         auto matrix_size = [&](size_t k) { return (ob.side[0].node_off[k + 1] - ob.side[0].node_off[k] + 1) * (ob.side[1].node_off[k + 1] - ob.side[1].node_off[k] + 1); };
@@ -1202,6 +1242,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
             }
             subs.push_back(std::move(sb));
         }
+        lap("fill-in: instances", t);
         std::vector<ChainSubResult> res;
         if (!subs.empty()) {
             ChainTimings tm;
@@ -1210,6 +1251,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
             out->fill_in_pairs += tm.n_pairs;
             out->fill_in_device_ms += tm.device_ms;
         }
+        lap("fill-in: batched DP", t);
         // translate the gap chains back (inner un-swap, anchorer.hpp:1309-1322) and merge (src/anchorer.cpp:157-222)
         std::vector<std::vector<HAnchor>> fill(K);
         for (size_t q = 0; q < inst.size(); ++q) {
@@ -1261,6 +1303,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
             }
         }
         anchors.swap(merged);
+        lap("fill-in: merge", t);
         return CL_OK;
     };
 
@@ -1268,14 +1311,18 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     auto run = [&](bool sparse, double anchor_scale, std::vector<HAnchor>& anchors) -> int {
         const uint64_t local_max = std::min<uint64_t>((uint64_t)llround((anchor_scale / ap->score_scale) * (double)ap->max_num_match_pairs),
                                                      ap->max_num_match_pairs);
+        auto t = now();
         const uint64_t n_use = select_matches(*ms, cp, cur, local_max);
         OwnedMatchSets sel = permute_sets(*ms, cur, swap);
         cl_match_sets v = sel.view();
+        lap(sparse ? "sparse: select + permute" : "affine: select + permute", t);
         std::vector<ChainSub> subs(1, whole_graph_instance(swap ? g2 : g1, swap ? g1 : g2, &v, n_use, cp.global_anchoring != 0));
         std::vector<ChainSubResult> res;
         ChainTimings tm;
         int rc = chain_dp_batch(ctx, subs, &cp, anchor_scale, sparse, res, tm, nullptr);
         if (rc) return rc;
+        lap(sparse ? "sparse: chain DP" : "affine: chain DP", t);
+        if (timing) fprintf(stderr, "[cl_anchor_chain]   prep %.1f device %.1f index %.1f traceback %.1f ms, %llu pairs\n", tm.prep_ms, tm.device_ms, tm.index_ms, tm.traceback_ms, (unsigned long long)tm.n_pairs);
         out->n_ties += res[0].n_ties;
         const ChainSubResult& r = res[0];
         const size_t na = r.chain.size() / 3;
@@ -1301,6 +1348,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
                 h.gsa = r.gap_score[i + 1];
             }
         }
+        lap("anchors", t);
         if (ap->do_fill_in_anchoring) return fill_in(anchors, sparse, anchor_scale);
         return CL_OK;
     };
@@ -1311,6 +1359,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     if (ap->autocalibrate_gap_penalties) {
         std::vector<HAnchor> sc;
         if ((rc = run(true, 1.0, sc))) return rc;
+        auto t = now();
         double total_weight = 0.0;
         uint64_t total_length = 0;
         const size_t na = sc.size();
@@ -1336,6 +1385,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
             total_length += fill;
         }
         scale = total_weight / (double)total_length;
+        lap("scale estimate: extraction", t);
     }
     out->scale = scale;
 

@@ -171,13 +171,25 @@ struct Matches {
 
 // score_function.hpp:51-75
 double anchor_weight(const clo_chain_params& cp, uint64_t count1, uint64_t count2, uint64_t length, uint64_t full_length) {
-    double count = (double)(count1 * count2);
-    double fraction = double(length) / double(full_length);
+    // ScoreFunction::anchor_weight (score_function.hpp:51-75) in the operation order of the reference AS BUILT: its
+    // CMakeLists.txt:9 compiles with -O3 -ffast-math, under which gcc turns "x / pow(c, p)" into "x * pow(c, -p)" and
+    // regroups the products (disassembly of oracle/_ref).  Mathematically tied weights (e.g. lengths symmetric about the
+    // vertex of the concave length term) order match sets in the budget selection (anchorer.hpp:1130-1134), so the
+    // last bit matters.
+    const double count = (double)(count1 * count2);
+    const double fraction = double(length) / double(full_length);
     switch (cp.anchor_score_function) {
-    case 0: return fraction / pow(count, cp.pair_count_power);
-    case 1: return fraction * length / pow(count, cp.pair_count_power);
-    case 2: return fraction * (length / pow(count, cp.pair_count_power) - pow(length / cp.length_intercept, cp.length_decay_power) * cp.length_intercept);
-    default: return fraction * (length - count * pow(length / cp.length_intercept, cp.length_decay_power) * cp.length_intercept);
+    case 0: return pow(count, -cp.pair_count_power) * fraction;
+    case 1: return (fraction * (double)length) * pow(count, -cp.pair_count_power);
+    case 2: {
+        const double inv = pow(count, -cp.pair_count_power);
+        const double decay = pow((double)length / cp.length_intercept, cp.length_decay_power);
+        return (inv * (double)length - cp.length_intercept * decay) * fraction;
+    }
+    default: {
+        const double decay = pow((double)length / cp.length_intercept, cp.length_decay_power);
+        return ((double)length - (cp.length_intercept * count) * decay) * fraction;
+    }
     }
 }
 

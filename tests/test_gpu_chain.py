@@ -82,12 +82,10 @@ def test_anchor_chain_matches_reference_golden(gpu_ctx, name, tag, glob, auto, f
                                score_scale=float(z["score_scale"][0]), autocalibrate=auto, fill_in=fill,
                                params=capi.default_chain_params(global_anchoring=glob))
     assert got["scale"] == float(z[tag + ".scale"])
+    # anchor_t::score included: anchor_weight follows the operation order of the reference as built (-ffast-math)
     for k in ("set_order", "chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "gap_before", "gap_after",
-              "gap_score_before", "gap_score_after"):
+              "gap_score_before", "gap_score_after", "score"):
         assert np.array_equal(got[k], z["%s.%s" % (tag, k)]), k
-    # anchor_t::score is a double that the reference evaluates under -ffast-math (its CMakeLists.txt:9): the last bits are
-    # the compiler's choice, so this one field is compared to 1e-12 relative (the float DP weights derived from it are exact)
-    assert np.allclose(got["score"], z[tag + ".score"], rtol=1e-12, atol=0)
     if fill:
         assert got["fill_in_pairs"] > 0 and len(got["chain"]) > 2 * len(z["g.chain"])
 
@@ -103,6 +101,5 @@ def test_default_anchor_chain_with_splitting(gpu_ctx, name):
                                score_scale=float(z["score_scale"][0]))
     assert got["scale"] == float(z["sf.scale"])
     for k in ("set_order", "chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "gap_before", "gap_after",
-              "gap_score_before", "gap_score_after"):
+              "gap_score_before", "gap_score_after", "score"):
         assert np.array_equal(got[k], z["sf." + k]), k
-    assert np.allclose(got["score"], z["sf.score"], rtol=1e-12, atol=0)
