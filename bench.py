@@ -76,8 +76,9 @@ def saturated_section(ctx, batch, copies=16, steps=10):
 
 
 def chaining_section(ctx, with_reference):
-    """second half of the hot path: sparse_affine_chain_dp on the match pairs of the same 2 x 1 Mbp pair
-    (bench_data/c2_chain_input.npz: the reference's graphs and budget-selected match sets; built by
+    """second half of the hot path, at its seam S3: Anchorer::anchor_chain in the CLI's default configuration (branch
+    splitting, scale estimate by sparse_chain_dp, sparse_affine_chain_dp, fill-in re-anchoring, global anchoring) on the
+    match sets of the same 2 x 1 Mbp pair (bench_data/c2_chain_input.npz: the reference's graphs and match sets; built by
     scripts/chain_bench.py's recipe in the build container, shipped with the repo snapshot, not committed)"""
     path = os.path.join(HERE, "bench_data", "c2_chain_input.npz")
     if not os.path.exists(path):
@@ -89,22 +90,35 @@ def chaining_section(ctx, with_reference):
         t = z[side + "tableau"]
         graphs.append(capi.BaseGraph(*[z[side + k] for k in ("label", "next_off", "next_idx", "prev_off", "prev_idx", "path_off", "path_nodes")], t[0], t[1]))
     ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
-    scale = float(z["score_scale"][0])
-    ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale)  # warm-up
-    t0 = time.perf_counter()
-    got = ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=scale)
-    wall = time.perf_counter() - t0
-    n = got["n_pairs"]
-    out = {"match_pairs": n, "chain_anchors": int(len(got["chain"])), "tie_resolutions": got["n_ties"],
-           "wall_s": wall, "device_dp_ms": got["device_ms"], "host_prep_ms": got["prep_ms"],
-           "value_index_ms": got["index_ms"], "traceback_ms": got["traceback_ms"],
-           "match_pairs_per_s": n / wall, "pair_evaluations_per_s_device": n * n / 2 / (got["device_ms"] * 1e-3)}
+    score_scale = float(z["score_scale"][0])
+
+    def run():
+        t0 = time.perf_counter()
+        split = capi.split_branching_matches(graphs[0], graphs[1], ms)
+        got = ctx.anchor_chain(graphs[0], graphs[1], split, score_scale=score_scale)
+        return got, time.perf_counter() - t0
+    run()  # warm-up
+    got, wall = run()
+    n = ms.n_pairs()
+    out = {"seam": "Anchorer::anchor_chain (default configuration)", "match_sets": ms.n_sets, "match_pairs": n,
+           "chain_anchors": int(len(got["chain"])), "estimated_scale": got["scale"], "tie_resolutions": got["n_ties"],
+           "fill_in_pairs": got["fill_in_pairs"], "wall_s": wall, "match_pairs_per_s": n / wall}
+    # the inner DP alone (sparse_affine_chain_dp on every pair), with its device / host split
+    dp = ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=got["scale"])
+    out["affine_dp_only"] = {"match_pairs": dp["n_pairs"], "device_dp_ms": dp["device_ms"], "host_prep_ms": dp["prep_ms"],
+                             "value_index_ms": dp["index_ms"], "traceback_ms": dp["traceback_ms"],
+                             "pair_evaluations_per_s_device": dp["n_pairs"] ** 2 / 2 / (dp["device_ms"] * 1e-3)}
     if with_reference:
         from oracle import pyoracle as po
         if po.have_ref():
-            ref, secs = po.ref_chain("affine", graphs[0], graphs[1], ms, scale=scale)
+            t0 = time.perf_counter()
+            split = po.ref_split_branching_matches(graphs[0], graphs[1], ms)
+            ref = po.ref_anchor_chain(graphs[0], graphs[1], split, score_scale=score_scale, fill_in=True)
+            secs = time.perf_counter() - t0
+            same = all(np.array_equal(ref[k], got[k]) for k in ("set_order", "chain", "walk1", "walk2", "gap_before", "gap_after",
+                                                                 "gap_score_before", "gap_score_after", "score"))
             out["cpu_reference"] = {"seconds": secs, "match_pairs_per_s": n / secs, "cores": 1, "kind": "reference",
-                                    "identical_chain": bool(np.array_equal(ref, got["chain"]))}
+                                    "identical_result": bool(same and ref["scale"] == got["scale"])}
     return out
 
 

@@ -45,6 +45,7 @@ struct ClChainDevice {
     const uint32_t* group;      // [n_pairs] depth window of the pair's first graph-1 node (non-decreasing); pairs of one
                                 // window cannot precede one another
     ClChainParams params;
+    uint32_t sparse;            // sparse_chain_dp: only the gap-free maximum (acc[0], val[0]) is used
 };
 
 #endif

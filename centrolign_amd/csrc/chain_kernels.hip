@@ -121,6 +121,41 @@ __global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint3
     }
 }
 
+// sparse_chain_dp (anchorer.hpp:1511-1750) has one gap-free tree per chain pair and no shift condition: a record is
+// (insertion index, offset, dp) and a query keeps ONE maximum.  Same tiling as chain_inter_kernel, a quarter of the work.
+__global__ void __launch_bounds__(256) chain_inter_sparse_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
+                                                                 uint32_t src_block_lo, uint32_t src_block_hi) {
+    const ClChainCombo cb = D.combos[blockIdx.z];
+    const uint32_t rec_lo = cb.prefix[src_block_lo], rec_hi = cb.prefix[src_block_hi];
+    const uint32_t tile0 = rec_lo + blockIdx.x * kChainTile;
+    if (tile0 >= rec_hi) return;
+    const uint32_t tile_end = min(tile0 + kChainTile, rec_hi);
+    const uint32_t mi = blockIdx.y * 256 + threadIdx.x;
+    const uint32_t s = block_first + mi;
+    const bool active = mi < block_count;
+    uint32_t qt = 0, qoff = 0;   // qoff == 0 can never be exceeded: an inactive lane accumulates nothing
+    if (active && cb.qt[s] != 0xFFFFFFFFu) { qt = cb.qt[s]; qoff = cb.qoff[s]; }
+    int acc = INT32_MIN;
+    __shared__ __attribute__((aligned(16))) int s_rec[256][4];
+    for (uint32_t base = tile0; base < tile_end; base += 256) {
+        const uint32_t r = base + threadIdx.x;
+        __syncthreads();
+        int4 mine = make_int4(-1, -1, INT32_MIN, 0);   // ins_t = 0xFFFFFFFF: never a predecessor
+        if (r < tile_end) mine = make_int4((int)cb.ins_t[r], (int)cb.off[r], enc(cb.val[r]), 0);
+        *reinterpret_cast<int4*>(&s_rec[threadIdx.x][0]) = mine;
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t j = 0; j < 256; j += 2) {
+            const int4 a = *reinterpret_cast<const int4*>(&s_rec[j][0]);
+            const int4 b = *reinterpret_cast<const int4*>(&s_rec[j + 1][0]);
+            const int va = ((uint32_t)a.x <= qt && (uint32_t)a.y < qoff) ? a.z : INT32_MIN;
+            const int vb = ((uint32_t)b.x <= qt && (uint32_t)b.y < qoff) ? b.z : INT32_MIN;
+            acc = max(acc, max(va, vb));
+        }
+    }
+    if (qoff != 0 && acc > enc(CL_CHAIN_NEG)) atomicMax(cb.acc + (size_t)s * 7, acc);
+}
+
 // one workgroup, kChainBlock threads: thread i owns sorted match pair block_first + i.  Pairs that start on the same
 // graph-1 node cannot precede one another (a predecessor must END before the start), so the block is walked group by
 // group: every pair of a group is finalised at once and the group's records are broadcast through LDS.
@@ -283,7 +318,8 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
                                  uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream) {
     if (max_recs == 0) return hipSuccess;
     dim3 grid((max_recs + kChainTile - 1) / kChainTile, (block_count + 255) / 256, D.n_combos);
-    hipLaunchKernelGGL(chain_inter_kernel, grid, dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi);
+    if (D.sparse) hipLaunchKernelGGL(chain_inter_sparse_kernel, grid, dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi);
+    else hipLaunchKernelGGL(chain_inter_kernel, grid, dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi);
     return hipGetLastError();
 }
 

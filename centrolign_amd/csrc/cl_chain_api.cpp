@@ -266,6 +266,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     const size_t K = subs.size();
     results.assign(K, ChainSubResult());
     std::vector<SubCtx> sc(K);
+    const bool timing = getenv("CL_CHAIN_TIMING") != nullptr;
+    auto tlap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[chain_dp_batch]   %-26s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tlap).count());
+        tlap = std::chrono::steady_clock::now();
+    };
 
     // match pairs in MatchBank iteration order (match_bank.hpp:252-268), instance by instance: slot = position in that order
     std::vector<Pair> pairs;
@@ -298,6 +304,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     if (span_a >= 0xFFFFFFFFull || span_b >= 0xFFFFFFFFull) { cl_set_error(ctx, "batch too large for 32-bit path coordinates"); return CL_ERR_INVALID_ARGUMENT; }
     if (min_len == 0 || min_len == UINT64_MAX) min_len = 1;
 
+    lap("pairs");
     // per-instance coordinate systems; chain tags -> dense combination table
     uint32_t n_tag[2] = {0, 0};
     {
@@ -346,22 +353,38 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         }
     }
     auto tag_of = [&](uint32_t k, int side, uint32_t p) { return subs[k].tag[side].empty() ? p : subs[k].tag[side][p]; };
+    lap("tables");
 
     // processing order: by the depth of the pair's first graph-1 node, stable in slot order
     std::vector<uint32_t> by_s(M);  // sorted index -> slot
-    std::iota(by_s.begin(), by_s.end(), 0u);
-    std::stable_sort(by_s.begin(), by_s.end(), [&](uint32_t a, uint32_t b) { return sc[pairs[a].sub].depth1[pairs[a].b1] < sc[pairs[b].sub].depth1[pairs[b].b1]; });
+    {   // counting sort on the depth (stable)
+        std::vector<uint32_t> key(M);
+        uint32_t max_depth = 0;
+        for (uint32_t slot = 0; slot < M; ++slot) { key[slot] = sc[pairs[slot].sub].depth1[pairs[slot].b1]; max_depth = std::max(max_depth, key[slot]); }
+        std::vector<uint32_t> start((size_t)max_depth + 2, 0);
+        for (uint32_t slot = 0; slot < M; ++slot) ++start[key[slot] + 1];
+        for (size_t d = 0; d <= max_depth; ++d) start[d + 1] += start[d];
+        for (uint32_t slot = 0; slot < M; ++slot) by_s[start[key[slot]]++] = slot;
+    }
     std::vector<uint32_t> s_of_slot(M);
     for (uint32_t s = 0; s < M; ++s) s_of_slot[by_s[s]] = s;
 
+    lap("sort by depth");
     std::vector<float> weight(M);
-    for (uint32_t s = 0; s < M; ++s) {
-        const Pair& p = pairs[by_s[s]];
-        const cl_match_sets* ms = subs[p.sub].ms;
-        const uint64_t w0 = ms->set_off1[p.set];
-        weight[s] = (float)anchor_weight(*cp, ms->count1[p.set], ms->count2[p.set], ms->walk_off1[w0 + 1] - ms->walk_off1[w0], ms->full_length[p.set]);
+    {   // the weight depends on the match set only
+        std::vector<std::vector<float>> set_weight(K);
+        for (size_t k = 0; k < K; ++k) {
+            if (sc[k].pair_hi == sc[k].pair_lo) continue;
+            const cl_match_sets* ms = subs[k].ms;
+            set_weight[k].resize(subs[k].num_match_sets);
+            for (uint64_t st = 0; st < subs[k].num_match_sets; ++st) {
+                const uint64_t w0 = ms->set_off1[st];
+                if (ms->set_off1[st + 1] == w0) continue;
+                set_weight[k][st] = (float)anchor_weight(*cp, ms->count1[st], ms->count2[st], ms->walk_off1[w0 + 1] - ms->walk_off1[w0], ms->full_length[st]);
+            }
+        }
+        for (uint32_t s = 0; s < M; ++s) { const Pair& p = pairs[by_s[s]]; weight[s] = set_weight[p.sub][p.set]; }
     }
-
     // Anchored chains (global anchoring, anchorer.hpp:1069-1076; fill-in, :683-693): a chain's first anchor pays the lead
     // indel from the sources (affine, :2026-2039) or must be reachable from them (sparse, :1562-1582); its last anchor pays
     // the final indel to the sinks (:2426-2438 / :1724-1741).
@@ -396,9 +419,11 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         for (uint32_t c : subs[k].snk[0]) for (uint32_t d : subs[k].snk[1]) { const int32_t h = measure_gap(sc[k], a1, a2, c, d); if (std::abs(h) < best) best = h; }
         return best;
     };
+    lap("weights");
     std::vector<float> init_w(weight);   // the value of a chain that STARTS at the pair
     std::vector<float> final_term(M, 0.0f);  // per slot
-    for (uint32_t s = 0; s < M; ++s) {
+    cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
+    for (uint32_t s = (uint32_t)s_begin; s < s_end; ++s) {
         const uint32_t slot = by_s[s];
         const Pair& p = pairs[slot];
         const ChainSub& sb = subs[p.sub];
@@ -421,6 +446,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             final_term[slot] = t ? 0.0f : CL_CHAIN_NEG;
         }
     }
+    });
     if (!sparse)   // the score of aligning nothing: one indel from the sources to the sinks (anchorer.hpp:2419-2424)
         for (size_t k = 0; k < K; ++k) {
             if (!subs[k].anchored || sc[k].pair_hi == sc[k].pair_lo) continue;
@@ -432,6 +458,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             sc[k].min_score = score_gap(best);
         }
 
+    lap("anchoring terms");
     // (chain1, chain2) combinations that hold at least one pair; the most populated one goes first (it is the one the
     // intra kernel keeps in registers)
     std::vector<uint32_t> combo_of((size_t)n_tag[0] * n_tag[1], kNone);
@@ -478,13 +505,15 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             for (auto& v : combo_of) v = v == 0 ? (uint32_t)big : v == big ? 0u : v;
         }
     }
+    lap("records");
     const uint32_t n_blocks = (uint32_t)((M + kChainBlock - 1) / kChainBlock);
     for (Combo& c : combos) {
         c.qt.assign(M, kNone);
         c.qoff.assign(M, 0);
         c.q.assign(M, 0);
     }
-    for (uint32_t s = 0; s < M; ++s) {
+    cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
+    for (uint32_t s = (uint32_t)s_begin; s < s_end; ++s) {
         const Pair& p = pairs[by_s[s]];
         const SubCtx& c = sc[p.sub];
         if (!c.has_start[p.b1]) continue;
@@ -502,6 +531,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             }
         }
     }
+    });
     for (Combo& c : combos) {
         c.prefix.assign(n_blocks + 1, 0);
         size_t r = 0;
@@ -512,6 +542,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         }
     }
 
+    lap("queries");
     // ---- device ----------------------------------------------------------------------------------------------------
     int rc = CL_OK;
     DevBuf<ClChainCombo> d_combos;
@@ -540,8 +571,22 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     CH(d_dp.alloc(ctx, M));
     CH(d_rec_off.upload(ctx, rec_off)); CH(d_rec_combo.upload(ctx, rec_combo)); CH(d_rec_pos.upload(ctx, rec_pos));
     {
+        // groups = maximal runs (in depth order) of pairs none of which can precede another: a predecessor m of m' ends
+        // strictly before m' starts, so depth(b1(m')) >= depth(b1(m)) + len(m); a run is closed as soon as a pair starts at or
+        // beyond the smallest depth(b1) + len of the run.  The device finalises a whole group at once.
         std::vector<uint32_t> group(M);
-        for (uint32_t s = 0; s < M; ++s) group[s] = (uint32_t)(sc[pairs[by_s[s]].sub].depth1[pairs[by_s[s]].b1] / min_len);
+        uint32_t gid = 0;
+        uint64_t min_end = 0;
+        for (uint32_t s = 0; s < M; ++s) {
+            const Pair& p = pairs[by_s[s]];
+            const cl_match_sets* ms = subs[p.sub].ms;
+            const uint64_t w0 = ms->set_off1[p.set];
+            const uint64_t start = sc[p.sub].depth1[p.b1], end = start + (ms->walk_off1[w0 + 1] - ms->walk_off1[w0]);
+            if (s == 0) min_end = end;
+            else if (start >= min_end) { ++gid; min_end = end; }
+            else min_end = std::min(min_end, end);
+            group[s] = gid;
+        }
         CH(d_group.upload(ctx, group));
     }
     ClChainDevice D{};
@@ -557,8 +602,10 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     D.group = d_group.p;
     for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
     D.params.scale = local_scale;
+    D.sparse = sparse ? 1u : 0u;
 
     tm.prep_ms += ms_since(T0);
+    lap("upload");
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipEventCreate failed"); return CL_ERR_HIP; }
     auto hip_fail = [&](hipError_t e, const char* what) {

@@ -59,4 +59,20 @@ struct DevBuf {
     }
 };
 
+
+// host-side parallel loop over [0, n): f(begin, end) on up to 16 threads (the reference is single-threaded; the host glue
+// around the device passes is not part of the compared arithmetic, every iteration writes its own outputs)
+#include <thread>
+template <class F>
+inline void cl_parallel_for(uint64_t n, F f, uint64_t grain = 32768) {
+    unsigned hw = std::thread::hardware_concurrency();
+    uint64_t nt = std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 16), (n + grain - 1) / grain);
+    if (nt <= 1) { f((uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t chunk = (n + nt - 1) / nt;
+    for (uint64_t t = 1; t < nt; ++t) th.emplace_back([=, &f] { f(std::min(n, t * chunk), std::min(n, (t + 1) * chunk)); });
+    f((uint64_t)0, std::min(n, chunk));
+    for (auto& x : th) x.join();
+}
+
 #endif

@@ -54,7 +54,7 @@ def main():
         t0 = time.time(); got = ctx.chain_sparse_affine(g1, g2, ms, scale=scale); t = time.time() - t0
         print("GPU: chain %d anchors, %d ties, device %.1f ms, prep %.0f index %.0f traceback %.0f ms, wall %.2f s" % (len(got["chain"]), got["n_ties"], got["device_ms"], got["prep_ms"], got["index_ms"], got["traceback_ms"], t), flush=True)
     if run_ref:
-        ref, secs = po.ref_chain("affine", g1, g2, ms, scale=scale)
+        ref, secs = po.ref_chain("affine", g1, g2, ms, scale=scale, global_anchoring=True)
         print("reference: chain %d anchors in %.1f s; identical: %s" % (len(ref), secs, np.array_equal(ref, got["chain"])), flush=True)
 
 
