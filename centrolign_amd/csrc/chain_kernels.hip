@@ -70,6 +70,14 @@ __device__ __forceinline__ float apply_candidates(float best, const int (&acc)[7
     return best;
 }
 
+// workgroup barrier that orders LDS traffic only: the walk below communicates through LDS, its global stores (dp, stored
+// values) are consumed by later kernels, so there is no need to drain them (__syncthreads waits for vmcnt) at every group
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 }  // namespace
 
 // acc index layout: [0] gap-free, [1 + pw] tree pw (pw even: shift > query, pw odd: shift < query)
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
     uint32_t group = D.group[block_first];
     while (true) {
         if (i == 0) { s_count = 0; s_next_group = 0xFFFFFFFFu; }
-        __syncthreads();
+        lds_barrier();
         if (active && my_group == group) {
             // finalise: dp = max(chain starting here, every candidate) — anchorer.hpp:2026-2041, 2379-2412
             float best = w_init;
@@ -253,8 +261,9 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
         } else if (active && my_group > group) {
             atomicMin(&s_next_group, my_group);
         }
-        __syncthreads();
+        lds_barrier();
         const uint32_t n = s_count, next_group = s_next_group;
+        if (n > kChainLdsRecs) __syncthreads();   // the overflow path below reads the group's records back from HBM
         if (active && my_group > group) {
             if (n <= kChainLdsRecs) {
                 for (uint32_t l = 0; l < n; ++l) {
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
         }
         if (next_group == 0xFFFFFFFFu) break;
         group = next_group;
-        __syncthreads();
+        lds_barrier();
     }
     // keep the final maxima: the traceback needs the value every query returned
     if (active) {
