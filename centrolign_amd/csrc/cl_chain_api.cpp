@@ -228,8 +228,12 @@ namespace {
 struct ChainSub {
     const cl_base_graph* g[2] = {nullptr, nullptr};   // DP orientation: g[0] plays graph1
     bool tableau = true;                               // graphs carry sentinels: PathMerge gets the pseudo-path (path_merge.hpp:148-160)
-    const cl_match_sets* ms = nullptr;                 // DP orientation
+    const cl_match_sets* ms = nullptr;                 // the sets; DP set s = ms set order[s] (identity if null), and with
+    const uint64_t* order = nullptr;                   // swap_sides the DP's graph-1 walks are the sets' walks2
+    bool swap_sides = false;                           // (anchorer.hpp:1179-1182), without copying anything
     uint64_t num_match_sets = 0;
+    const clhost::PathMergeTable* x[2] = {nullptr, nullptr};   // prebuilt tables of g[0], g[1] (built here if null)
+    const PostSwitchTable* sw[2] = {nullptr, nullptr};
     bool anchored = false;                             // sources / sinks given (global anchoring, fill-in)
     std::vector<uint32_t> src[2], snk[2];
     std::vector<uint32_t> tag[2];                      // local chain id -> batch-wide chain tag; empty = identity
@@ -245,8 +249,10 @@ struct ChainSubResult {
 struct ChainTimings { float device_ms = 0, prep_ms = 0, index_ms = 0, traceback_ms = 0; uint64_t n_pairs = 0; };
 
 struct SubCtx {
-    clhost::PathMergeTable x[2];
-    PostSwitchTable sw[2];
+    clhost::PathMergeTable own_x[2];
+    PostSwitchTable own_sw[2];
+    const clhost::PathMergeTable* x[2] = {nullptr, nullptr};
+    const PostSwitchTable* sw[2] = {nullptr, nullptr};
     std::vector<uint32_t> pos1, depth1;
     std::vector<char> has_start, after_end;
     uint32_t pair_lo = 0, pair_hi = 0;
@@ -255,6 +261,29 @@ struct SubCtx {
 };
 
 struct Pair { uint32_t sub, set, i1, i2, b1, e1, b2, e2; };
+
+// the match sets of an instance as the DP sees them
+struct SetView {
+    const cl_match_sets* ms;
+    const uint64_t* order;
+    const uint64_t *so[2], *wo[2];
+    const uint32_t* nd[2];
+    explicit SetView(const ChainSub& sb) : ms(sb.ms), order(sb.order) {
+        const int a = sb.swap_sides ? 1 : 0;
+        so[a] = ms->set_off1; wo[a] = ms->walk_off1; nd[a] = ms->nodes1;
+        so[1 - a] = ms->set_off2; wo[1 - a] = ms->walk_off2; nd[1 - a] = ms->nodes2;
+    }
+    uint64_t orig(uint64_t s) const { return order ? order[s] : s; }
+    uint64_t n_walks(int side, uint64_t s) const { const uint64_t o = orig(s); return so[side][o + 1] - so[side][o]; }
+    uint64_t walk(int side, uint64_t s, uint64_t j) const { return so[side][orig(s)] + j; }
+    uint32_t front(int side, uint64_t w) const { return nd[side][wo[side][w]]; }
+    uint32_t back(int side, uint64_t w) const { return nd[side][wo[side][w + 1] - 1]; }
+    uint64_t length(uint64_t s) const { const uint64_t w = so[0][orig(s)]; return wo[0][w + 1] - wo[0][w]; }   // walks of a set share their length
+    double weight(const cl_chain_params& cp, uint64_t s) const {
+        const uint64_t o = orig(s);
+        return anchor_weight(cp, ms->count1[o], ms->count2[o], length(s), ms->full_length[o]);
+    }
+};
 
 }  // namespace
 
@@ -278,19 +307,19 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     uint64_t min_len = UINT64_MAX, span_a = 0, span_b = 0;
     for (size_t k = 0; k < K; ++k) {
         const ChainSub& sb = subs[k];
-        const cl_match_sets* ms = sb.ms;
+        const SetView ms(sb);
         sc[k].pair_lo = (uint32_t)pairs.size();
-        if (sb.num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+        if (sb.num_match_sets > sb.ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
         for (uint64_t s = 0; s < sb.num_match_sets; ++s) {
-            const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
+            const uint64_t n1 = ms.n_walks(0, s), n2 = ms.n_walks(1, s);
             if (n1 >= 65535 || n2 >= 65535) { cl_set_error(ctx, "match set %llu has too many walks", (unsigned long long)s); return CL_ERR_INVALID_ARGUMENT; }
-            if (n1 && n2) min_len = std::min<uint64_t>(min_len, ms->walk_off1[ms->set_off1[s] + 1] - ms->walk_off1[ms->set_off1[s]]);
+            if (n1 && n2) min_len = std::min<uint64_t>(min_len, ms.length(s));
             for (uint64_t j = 0; j < n1; ++j) {
-                const uint64_t w1 = ms->set_off1[s] + j;
-                const uint32_t b1 = ms->nodes1[ms->walk_off1[w1]], e1 = ms->nodes1[ms->walk_off1[w1 + 1] - 1];
+                const uint64_t w1 = ms.walk(0, s, j);
+                const uint32_t b1 = ms.front(0, w1), e1 = ms.back(0, w1);
                 for (uint64_t q = 0; q < n2; ++q) {
-                    const uint64_t w2 = ms->set_off2[s] + q;
-                    pairs.push_back(Pair{(uint32_t)k, (uint32_t)s, (uint32_t)j, (uint32_t)q, b1, e1, ms->nodes2[ms->walk_off2[w2]], ms->nodes2[ms->walk_off2[w2 + 1] - 1]});
+                    const uint64_t w2 = ms.walk(1, s, q);
+                    pairs.push_back(Pair{(uint32_t)k, (uint32_t)s, (uint32_t)j, (uint32_t)q, b1, e1, ms.front(1, w2), ms.back(1, w2)});
                 }
             }
         }
@@ -314,9 +343,14 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             if (c.pair_hi == c.pair_lo) continue;
             const ChainSub& sb = subs[k];
             for (int side = 0; side < 2; ++side) {
-                if (!c.x[side].build(*sb.g[side], sb.tableau)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
-                c.sw[side].build(*sb.g[side], c.x[side]);
-                for (uint32_t p = 0; p < c.x[side].chain_size(); ++p)
+                if (sb.x[side] && sb.sw[side]) { c.x[side] = sb.x[side]; c.sw[side] = sb.sw[side]; }
+                else {
+                    if (!c.own_x[side].build(*sb.g[side], sb.tableau)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+                    c.own_sw[side].build(*sb.g[side], c.own_x[side]);
+                    c.x[side] = &c.own_x[side];
+                    c.sw[side] = &c.own_sw[side];
+                }
+                for (uint32_t p = 0; p < c.x[side]->chain_size(); ++p)
                     n_tag[side] = std::max(n_tag[side], (sb.tag[side].empty() ? p : sb.tag[side][p]) + 1);
             }
             run_b -= sb.g[1]->n_nodes + 2;
@@ -375,13 +409,10 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         std::vector<std::vector<float>> set_weight(K);
         for (size_t k = 0; k < K; ++k) {
             if (sc[k].pair_hi == sc[k].pair_lo) continue;
-            const cl_match_sets* ms = subs[k].ms;
+            const SetView ms(subs[k]);
             set_weight[k].resize(subs[k].num_match_sets);
-            for (uint64_t st = 0; st < subs[k].num_match_sets; ++st) {
-                const uint64_t w0 = ms->set_off1[st];
-                if (ms->set_off1[st + 1] == w0) continue;
-                set_weight[k][st] = (float)anchor_weight(*cp, ms->count1[st], ms->count2[st], ms->walk_off1[w0 + 1] - ms->walk_off1[w0], ms->full_length[st]);
-            }
+            for (uint64_t st = 0; st < subs[k].num_match_sets; ++st)
+                if (ms.n_walks(0, st)) set_weight[k][st] = (float)ms.weight(*cp, st);
         }
         for (uint32_t s = 0; s < M; ++s) { const Pair& p = pairs[by_s[s]]; weight[s] = set_weight[p.sub][p.set]; }
     }
@@ -397,11 +428,11 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     };
     auto measure_gap = [&](const SubCtx& c, uint32_t a1, uint32_t a2, uint32_t c1, uint32_t c2) -> int32_t {   // anchorer.hpp:1906-1927
         int32_t gap = INT32_MAX;
-        if ((a1 == c1 || c.x[0].reachable(a1, c1)) && (a2 == c2 || c.x[1].reachable(a2, c2)))
-            c.x[0].for_each_chain_on(a1, [&](uint32_t p1) {
-                c.x[1].for_each_chain_on(a2, [&](uint32_t p2) {
-                    const uint32_t src = c.x[0].index_on(a1, p1) - c.x[1].index_on(a2, p2);
-                    const uint32_t qry = c.x[0].predecessor_index(c1, p1) - c.x[1].predecessor_index(c2, p2) + c.sw[0].distance(c1, p1) - c.sw[1].distance(c2, p2);
+        if ((a1 == c1 || c.x[0]->reachable(a1, c1)) && (a2 == c2 || c.x[1]->reachable(a2, c2)))
+            c.x[0]->for_each_chain_on(a1, [&](uint32_t p1) {
+                c.x[1]->for_each_chain_on(a2, [&](uint32_t p2) {
+                    const uint32_t src = c.x[0]->index_on(a1, p1) - c.x[1]->index_on(a2, p2);
+                    const uint32_t qry = c.x[0]->predecessor_index(c1, p1) - c.x[1]->predecessor_index(c2, p2) + c.sw[0]->distance(c1, p1) - c.sw[1]->distance(c2, p2);
                     const int32_t here_gap = (int32_t)(src - qry);
                     if (std::abs(here_gap) < std::abs(gap)) gap = here_gap;
                 });
@@ -435,12 +466,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             final_term[slot] = score_gap(gap_to_sinks(p.sub, p.e1, p.e2));
         } else {
             bool f1 = false, f2 = false, t = false;
-            for (uint32_t a : sb.src[0]) if (a == p.b1 || c.x[0].reachable(a, p.b1)) { f1 = true; break; }
-            for (uint32_t b : sb.src[1]) if (b == p.b2 || c.x[1].reachable(b, p.b2)) { f2 = true; break; }
+            for (uint32_t a : sb.src[0]) if (a == p.b1 || c.x[0]->reachable(a, p.b1)) { f1 = true; break; }
+            for (uint32_t b : sb.src[1]) if (b == p.b2 || c.x[1]->reachable(b, p.b2)) { f2 = true; break; }
             if (!f1 || !f2) init_w[s] = CL_CHAIN_NEG;
             for (uint32_t a : sb.snk[0]) {
                 for (uint32_t b : sb.snk[1])
-                    if ((a == p.e1 || c.x[0].reachable(p.e1, a)) && (b == p.e2 || c.x[1].reachable(p.e2, b))) { t = true; break; }
+                    if ((a == p.e1 || c.x[0]->reachable(p.e1, a)) && (b == p.e2 || c.x[1]->reachable(p.e2, b))) { t = true; break; }
                 if (t) break;
             }
             final_term[slot] = t ? 0.0f : CL_CHAIN_NEG;
@@ -468,12 +499,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         const Pair& p = pairs[by_s[s]];
         const SubCtx& c = sc[p.sub];
         bool first1 = true;
-        c.x[0].for_each_chain_on(p.e1, [&](uint32_t p1) {
+        c.x[0]->for_each_chain_on(p.e1, [&](uint32_t p1) {
             const bool take1 = !sparse || first1;   // sparse_chain_dp files a match under chain(e1) only (anchorer.hpp:1621-1630)
             first1 = false;
             if (!take1) return;
             bool first2 = true;
-            c.x[1].for_each_chain_on(p.e2, [&](uint32_t p2) {
+            c.x[1]->for_each_chain_on(p.e2, [&](uint32_t p2) {
                 const bool take2 = !sparse || first2;
                 first2 = false;
                 if (!take2) return;
@@ -488,9 +519,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                 rec_combo.push_back(ci);
                 rec_pos.push_back((uint32_t)cb.rec_s.size());
                 cb.rec_s.push_back(s);
-                cb.ins_t.push_back(c.x[0].index_on(p.e1, p1) + c.off_a);
-                cb.off.push_back(c.x[1].index_on(p.e2, p2) + c.off_b);
-                cb.sigma.push_back(sparse ? 0 : (int32_t)(c.x[0].index_on(p.e1, p1) - c.x[1].index_on(p.e2, p2)));
+                cb.ins_t.push_back(c.x[0]->index_on(p.e1, p1) + c.off_a);
+                cb.off.push_back(c.x[1]->index_on(p.e2, p2) + c.off_b);
+                cb.sigma.push_back(sparse ? 0 : (int32_t)(c.x[0]->index_on(p.e1, p1) - c.x[1]->index_on(p.e2, p2)));
             });
         });
         rec_off[s + 1] = (uint32_t)rec_combo.size();
@@ -517,17 +548,17 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         const Pair& p = pairs[by_s[s]];
         const SubCtx& c = sc[p.sub];
         if (!c.has_start[p.b1]) continue;
-        for (uint32_t p1 = 0; p1 < c.x[0].chain_size(); ++p1) {
-            const uint32_t pr = c.x[0].predecessor_index(p.b1, p1);
+        for (uint32_t p1 = 0; p1 < c.x[0]->chain_size(); ++p1) {
+            const uint32_t pr = c.x[0]->predecessor_index(p.b1, p1);
             // a forward edge exists only from a node that follows some match end (forward_edges.hpp:40-53)
-            if (pr == kNone || !c.after_end[c.x[0].node_at(p1, pr)]) continue;
-            for (uint32_t p2 = 0; p2 < c.x[1].chain_size(); ++p2) {
+            if (pr == kNone || !c.after_end[c.x[0]->node_at(p1, pr)]) continue;
+            for (uint32_t p2 = 0; p2 < c.x[1]->chain_size(); ++p2) {
                 const uint32_t ci = combo_of[(size_t)tag_of(p.sub, 0, p1) * n_tag[1] + tag_of(p.sub, 1, p2)];
                 if (ci == kNone) continue;
                 Combo& cb = combos[ci];
                 cb.qt[s] = pr + c.off_a;
-                cb.qoff[s] = c.x[1].predecessor_index(p.b2, p2) + 1u + c.off_b;
-                cb.q[s] = sparse ? 0 : (int32_t)(pr - c.x[1].predecessor_index(p.b2, p2) + c.sw[0].distance(p.b1, p1) - c.sw[1].distance(p.b2, p2));
+                cb.qoff[s] = c.x[1]->predecessor_index(p.b2, p2) + 1u + c.off_b;
+                cb.q[s] = sparse ? 0 : (int32_t)(pr - c.x[1]->predecessor_index(p.b2, p2) + c.sw[0]->distance(p.b1, p1) - c.sw[1]->distance(p.b2, p2));
             }
         }
     }
@@ -575,13 +606,19 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         // strictly before m' starts, so depth(b1(m')) >= depth(b1(m)) + len(m); a run is closed as soon as a pair starts at or
         // beyond the smallest depth(b1) + len of the run.  The device finalises a whole group at once.
         std::vector<uint32_t> group(M);
+        std::vector<std::vector<uint32_t>> set_len(K);
+        for (size_t k = 0; k < K; ++k) {
+            if (sc[k].pair_hi == sc[k].pair_lo) continue;
+            const SetView ms(subs[k]);
+            set_len[k].resize(subs[k].num_match_sets);
+            for (uint64_t st = 0; st < subs[k].num_match_sets; ++st)
+                if (ms.n_walks(0, st)) set_len[k][st] = (uint32_t)ms.length(st);
+        }
         uint32_t gid = 0;
         uint64_t min_end = 0;
         for (uint32_t s = 0; s < M; ++s) {
             const Pair& p = pairs[by_s[s]];
-            const cl_match_sets* ms = subs[p.sub].ms;
-            const uint64_t w0 = ms->set_off1[p.set];
-            const uint64_t start = sc[p.sub].depth1[p.b1], end = start + (ms->walk_off1[w0 + 1] - ms->walk_off1[w0]);
+            const uint64_t start = sc[p.sub].depth1[p.b1], end = start + set_len[p.sub][p.set];
             if (s == 0) min_end = end;
             else if (start >= min_end) { ++gid; min_end = end; }
             else min_end = std::min(min_end, end);
@@ -722,7 +759,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         std::vector<uint32_t> chain_slots;
         uint64_t n_ties = 0;
         uint32_t here = best_slot;
-        const uint32_t C1 = (uint32_t)sk.x[0].chain_size(), C2 = (uint32_t)sk.x[1].chain_size();
+        const uint32_t C1 = (uint32_t)sk.x[0]->chain_size(), C2 = (uint32_t)sk.x[1]->chain_size();
         while (here != kNone) {
             chain_slots.push_back(here);
             const uint32_t s = s_of_slot[here];
@@ -733,9 +770,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             // chain2 ascending; gap-free tree, then trees 0..5 (anchorer.hpp:2352-2413)
             std::vector<std::pair<uint32_t, uint32_t>> edges;  // (position of from-node, p1)
             for (uint32_t p1 = 0; p1 < C1; ++p1) {
-                const uint32_t pr = sk.x[0].predecessor_index(p.b1, p1);
+                const uint32_t pr = sk.x[0]->predecessor_index(p.b1, p1);
                 if (pr == kNone) continue;
-                const uint64_t from = sk.x[0].node_at(p1, pr);
+                const uint64_t from = sk.x[0]->node_at(p1, pr);
                 if (sk.has_start[p.b1] && sk.after_end[from]) edges.emplace_back(sk.pos1[from], p1);
             }
             std::sort(edges.begin(), edges.end());
@@ -1002,31 +1039,6 @@ struct OwnedMatchSets {
     }
 };
 
-// new[k] = old[order[k]]; with swap the two graph sides trade places (anchorer.hpp:1179-1182)
-OwnedMatchSets permute_sets(const cl_match_sets& ms, const std::vector<uint64_t>& order, bool swap) {
-    OwnedMatchSets o;
-    for (uint64_t s : order) {
-        for (int side = 0; side < 2; ++side) {
-            const bool from2 = (side == 1) != swap;
-            const uint64_t* so = from2 ? ms.set_off2 : ms.set_off1;
-            const uint64_t* wo = from2 ? ms.walk_off2 : ms.walk_off1;
-            const uint32_t* nd = from2 ? ms.nodes2 : ms.nodes1;
-            auto& oso = side ? o.set_off2 : o.set_off1;
-            auto& owo = side ? o.walk_off2 : o.walk_off1;
-            auto& ond = side ? o.nodes2 : o.nodes1;
-            for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
-                ond.insert(ond.end(), nd + wo[w], nd + wo[w + 1]);
-                owo.push_back(ond.size());
-            }
-            oso.push_back(owo.size() - 1);
-        }
-        o.count1.push_back(swap ? ms.count2[s] : ms.count1[s]);
-        o.count2.push_back(swap ? ms.count1[s] : ms.count2[s]);
-        o.full_length.push_back(ms.full_length[s]);
-    }
-    return o;
-}
-
 // anchorer.hpp:1108-1173 on a permutation of the original set indices: `cur` is the current order of the caller's
 // vector; returns the number of leading sets that take part
 uint64_t select_matches(const cl_match_sets& ms, const cl_chain_params& cp, std::vector<uint64_t>& cur, uint64_t local_max) {
@@ -1155,6 +1167,9 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
     // anchorer.hpp:1175: the DP runs with the graphs swapped when that makes its tables smaller
     const bool swap = g1->n_nodes * x1.chain_size() > g2->n_nodes * x2.chain_size();
+    PostSwitchTable sw1, sw2;
+    sw1.build(*g1, x1);
+    sw2.build(*g2, x2);
     std::vector<uint64_t> cur(ms->n_sets);
     std::iota(cur.begin(), cur.end(), (uint64_t)0);
     PathsOfNode steps1, steps2;
@@ -1190,7 +1205,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         }
         cl_anchor_segments sg{1, seg_off.data(), walk_off.data(), w1.data(), w2.data()};
         clhost::OwnedBatch ob;
-        int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob);
+        int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob, &x1, &x2);
         if (rc) { cl_set_error(ctx, "extraction failed"); return rc; }
         lap("fill-in: extraction", t);
         const size_t K = ob.only_del.size();
@@ -1256,7 +1271,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         auto matrix_size = [&](size_t k) { return (ob.side[0].node_off[k + 1] - ob.side[0].node_off[k] + 1) * (ob.side[1].node_off[k + 1] - ob.side[1].node_off[k] + 1); };
         for (size_t k = 0; k < K; ++k) total += matrix_size(k);
         // the instances: inner anchor_chain (anchorer.hpp:1091-1329) on the gap's subgraphs with their sources / sinks
-        struct Inst { size_t k; bool swap; std::vector<uint64_t> order; OwnedMatchSets sel; cl_match_sets view, sel_view; FillSide side[2]; };
+        struct Inst { size_t k; bool swap; std::vector<uint64_t> order; cl_match_sets view; FillSide side[2]; };
         std::vector<std::unique_ptr<Inst>> inst;
         std::vector<ChainSub> subs;
         for (size_t k = 0; k < K; ++k) {
@@ -1272,11 +1287,11 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
             std::iota(in.order.begin(), in.order.end(), (uint64_t)0);
             const uint64_t budget = (uint64_t)ceil((double)ap->max_num_match_pairs * (double)matrix_size(k) / (double)total);
             const uint64_t n_use = select_matches(in.view, cp, in.order, budget);
-            in.sel = permute_sets(in.view, in.order, in.swap);
-            in.sel_view = in.sel.view();
             ChainSub sb;
             sb.tableau = false;
-            sb.ms = &in.sel_view;
+            sb.ms = &in.view;
+            sb.order = in.order.data();
+            sb.swap_sides = in.swap;
             sb.num_match_sets = n_use;
             sb.anchored = true;
             for (int d = 0; d < 2; ++d) {
@@ -1360,10 +1375,12 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
                                                      ap->max_num_match_pairs);
         auto t = now();
         const uint64_t n_use = select_matches(*ms, cp, cur, local_max);
-        OwnedMatchSets sel = permute_sets(*ms, cur, swap);
-        cl_match_sets v = sel.view();
-        lap(sparse ? "sparse: select + permute" : "affine: select + permute", t);
-        std::vector<ChainSub> subs(1, whole_graph_instance(swap ? g2 : g1, swap ? g1 : g2, &v, n_use, cp.global_anchoring != 0));
+        lap(sparse ? "sparse: select" : "affine: select", t);
+        std::vector<ChainSub> subs(1, whole_graph_instance(swap ? g2 : g1, swap ? g1 : g2, ms, n_use, cp.global_anchoring != 0));
+        subs[0].order = cur.data();
+        subs[0].swap_sides = swap;
+        subs[0].x[0] = swap ? &x2 : &x1; subs[0].x[1] = swap ? &x1 : &x2;
+        subs[0].sw[0] = swap ? &sw2 : &sw1; subs[0].sw[1] = swap ? &sw1 : &sw2;
         std::vector<ChainSubResult> res;
         ChainTimings tm;
         int rc = chain_dp_batch(ctx, subs, &cp, anchor_scale, sparse, res, tm, nullptr);
@@ -1421,7 +1438,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         }
         cl_anchor_segments sg{na ? 1u : 0u, seg_off.data(), walk_off.data(), w1.data(), w2.data()};
         clhost::OwnedBatch ob;
-        if ((rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob))) { cl_set_error(ctx, "extraction failed"); return rc; }
+        if ((rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob, &x1, &x2))) { cl_set_error(ctx, "extraction failed"); return rc; }
         for (uint64_t k = 0; k < ob.only_del.size(); ++k) {
             uint64_t fill = UINT64_MAX;
             for (int side = 0; side < 2; ++side) {

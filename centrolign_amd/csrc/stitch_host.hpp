@@ -197,9 +197,12 @@ private:
 
 // Extractor::extract_graphs_between(segments, ...) (anchorer.hpp:494-585) in Stitcher::stitch's consumption order:
 // before-first, then per segment its within-segment gaps followed by the gap to the next segment / the sink.
-inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2, const cl_anchor_segments& sg, OwnedBatch& out) {
-    PathMergeTable pm1, pm2;
-    if (!pm1.build(g1) || !pm2.build(g2)) return CL_ERR_CYCLIC_GRAPH;
+inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2, const cl_anchor_segments& sg, OwnedBatch& out,
+                                const PathMergeTable* have1 = nullptr, const PathMergeTable* have2 = nullptr) {
+    PathMergeTable own1, own2;
+    if ((!have1 && !own1.build(g1)) || (!have2 && !own2.build(g2))) return CL_ERR_CYCLIC_GRAPH;
+    const PathMergeTable& pm1 = have1 ? *have1 : own1;
+    const PathMergeTable& pm2 = have2 ? *have2 : own2;
     Extractor ex;
     auto add = [&](uint64_t f1, uint64_t t1, uint64_t f2, uint64_t t2, bool only_del) {
         ex.extract(g1, pm1, f1, t1, out.side[0]);
