@@ -149,6 +149,26 @@ void replay_units(size_t n, const std::vector<uint32_t>& rank_of_heap, size_t rl
     }
 }
 
+// records ordered by (key, slot): slots are unique, so a placement by slot followed by a stable counting sort on the key
+// replaces the comparison sort (the big trees of a 1 Mbp problem hold every match pair)
+template <class KeyF, class SlotF>
+void sort_by_key_then_slot(std::vector<uint32_t>& items, uint64_t n_slots, KeyF key, SlotF slot) {
+    if (items.size() < 4096) {
+        std::sort(items.begin(), items.end(), [&](uint32_t a, uint32_t b) { return key(a) != key(b) ? key(a) < key(b) : slot(a) < slot(b); });
+        return;
+    }
+    std::vector<uint32_t> at(n_slots, 0xFFFFFFFFu), by_slot;
+    for (uint32_t it : items) at[slot(it)] = it;
+    by_slot.reserve(items.size());
+    for (uint64_t sl = 0; sl < n_slots; ++sl) if (at[sl] != 0xFFFFFFFFu) by_slot.push_back(at[sl]);
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (uint32_t it : by_slot) { lo = std::min<int64_t>(lo, key(it)); hi = std::max<int64_t>(hi, key(it)); }
+    std::vector<uint32_t> start((size_t)(hi - lo) + 2, 0);
+    for (uint32_t it : by_slot) ++start[(size_t)(key(it) - lo) + 1];
+    for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+    for (uint32_t it : by_slot) items[start[(size_t)(key(it) - lo)]++] = it;
+}
+
 // a gap-free search tree of the reference, as its sorted key list + implicit heap layout (built on first use)
 struct GapFreeTree {
     struct Member { uint32_t off, slot, rec; };
@@ -847,7 +867,15 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                                     for (uint32_t r : sub_recs(oc, k).recs) tree->mem.push_back(GapFreeTree::Member{oc.off[r], by_s[oc.rec_s[r]], r});
                     }
                     if (!tree->built) {
-                        std::sort(tree->mem.begin(), tree->mem.end(), [](const GapFreeTree::Member& a, const GapFreeTree::Member& b) { return a.off != b.off ? a.off < b.off : a.slot < b.slot; });
+                        {
+                            std::vector<uint32_t> idx(tree->mem.size());
+                            std::iota(idx.begin(), idx.end(), 0u);
+                            const auto& m0 = tree->mem;
+                            sort_by_key_then_slot(idx, M, [&](uint32_t i) { return (int64_t)m0[i].off; }, [&](uint32_t i) { return m0[i].slot; });
+                            std::vector<GapFreeTree::Member> sorted(idx.size());
+                            for (size_t i = 0; i < idx.size(); ++i) sorted[i] = m0[idx[i]];
+                            tree->mem.swap(sorted);
+                        }
                         tree->heap = heap_of_rank(tree->mem.size());
                         tree->rank_of_heap.resize(tree->mem.size());
                         for (size_t r = 0; r < tree->mem.size(); ++r) tree->rank_of_heap[tree->heap[r]] = (uint32_t)r;
@@ -882,7 +910,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                     auto key_less = [&](uint32_t a, uint32_t b) { return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b); };
                     if (sr.ortho_order.empty()) {
                         sr.ortho_order = sr.recs;
-                        std::sort(sr.ortho_order.begin(), sr.ortho_order.end(), key_less);
+                        sort_by_key_then_slot(sr.ortho_order, M, [&](uint32_t r) { return (int64_t)c.sigma[r]; }, [&](uint32_t r) { return slot_of_rec(r); });
                         sr.ortho_heap = heap_of_rank(sr.ortho_order.size());
                         sr.ortho_rank_of_heap.resize(sr.ortho_order.size());
                         for (size_t r = 0; r < sr.ortho_order.size(); ++r) sr.ortho_rank_of_heap[sr.ortho_heap[r]] = (uint32_t)r;
