@@ -75,6 +75,28 @@ def saturated_section(ctx, batch, copies=16, steps=10):
             "frac_of_hbm_peak": st["dp_bytes"] / (ms * 1e-3) / 1e9 / 8000.0}
 
 
+def pipelined_section(batch, local_rank, depth=6, steps=48):
+    """the same pass with `depth` independent passes in flight (one context + plan each, as the sibling merges of a guide
+    tree provide them): fills the CUs that idle while the longest subproblem of a single batch finishes its sweep"""
+    from centrolign_amd import capi
+    ctxs = [capi.Context(local_rank) for _ in range(depth)]
+    plans = [c.plan(batch) for c in ctxs]
+    cells = plans[0].stats()["dp_cells"]
+    for p in plans:
+        p.execute(); p.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        plans[k % depth].execute()
+    for p in plans:
+        p.sync()
+    dt = time.perf_counter() - t0
+    for p in plans:
+        p.destroy()
+    for c in ctxs:
+        c.close()
+    return {"passes_in_flight": depth, "steps": steps, "ms_per_step": dt / steps * 1e3, "cells_per_s": cells * steps / dt}
+
+
 def chaining_section(ctx, with_reference):
     """second half of the hot path, at its seam S3: Anchorer::anchor_chain in the CLI's default configuration (branch
     splitting, scale estimate by sparse_chain_dp, sparse_affine_chain_dp, fill-in re-anchoring, global anchoring) on the
@@ -123,6 +145,7 @@ def chaining_section(ctx, with_reference):
 
 
 def main():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: independent passes overlap on separate queues
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -209,6 +232,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch)
         if world == 1:
             out["saturated"] = saturated_section(ctx, batch)
+            out["pipelined"] = pipelined_section(batch, local_rank)
             ch = chaining_section(ctx, not args.no_cpu_baseline)
             if ch is not None:
                 out["chaining"] = ch

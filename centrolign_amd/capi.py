@@ -192,6 +192,36 @@ def despecify_indel_breakpoints(score, gap_before, gap_score_before, gap_after, 
     return keep[:n].astype(bool), gb[:k], gsb[:k], ga[:k], gsa[:k]
 
 
+def partition_anchors(graph1, graph2, chain, score_scale=1.0, score_boundaries=False, use_annotated_score=False, **overrides):
+    """Partitioner::partition_anchors (include/centrolign/partitioner.hpp:72-213), host only.  `chain` is the dict that
+    Context.anchor_chain returns (walk_off, walk1, walk2, count1, count2, full_length, chain[:,0] = match set, score).
+    Returns an (n_segments, 2) array of (first, past-the-last) anchor indices."""
+    lib = load_library()
+    pp = PartitionParams()
+    lib.cl_partition_params_default(C.byref(pp))
+    pp.score_scale = float(score_scale)
+    pp.score_boundaries = int(score_boundaries)
+    pp.use_annotated_score = int(use_annotated_score)
+    for k, v in overrides.items():
+        setattr(pp, k, v)
+    keep = dict(walk_off=np.ascontiguousarray(chain["walk_off"], np.uint64), walk1=np.ascontiguousarray(chain["walk1"], np.uint32),
+                walk2=np.ascontiguousarray(chain["walk2"], np.uint32), count1=np.ascontiguousarray(chain["count1"], np.uint64),
+                count2=np.ascontiguousarray(chain["count2"], np.uint64), full_length=np.ascontiguousarray(chain["full_length"], np.uint64),
+                match_set=np.ascontiguousarray(np.asarray(chain["chain"])[:, 0] if len(chain["chain"]) else np.zeros(0), np.uint64),
+                score=np.ascontiguousarray(chain["score"], np.float64))
+    n = len(keep["count1"])
+    af = AnchorFieldsC(n, *[keep[k].ctypes.data for k in ("walk_off", "walk1", "walk2", "count1", "count2", "full_length", "match_set", "score")])
+    g1, g2 = graph1.as_c(), graph2.as_c()
+    out, ns = C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_partition_anchors(C.byref(g1), C.byref(g2), C.byref(af), C.byref(pp), C.byref(out), C.byref(ns))
+    if rc != 0:
+        raise ClError(rc)
+    k = int(ns.value)
+    seg = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 2,))[:2 * k].copy().reshape(k, 2)
+    C.CDLL(None).free(out)
+    return seg
+
+
 def split_branching_matches(graph1, graph2, matches, anchor_split_limit=5, min_split_length=128, min_path_length_spread=50,
                             max_split_match_set_size=16):
     """Anchorer::split_branching_matches (include/centrolign/anchorer.hpp:800-956); host only.  Returns the new MatchSets."""
@@ -258,6 +288,19 @@ class ChainResultC(C.Structure):
                 ("gap_score_before_first", C.c_double), ("gap_score_after_last", C.c_double)]
 
 
+class PartitionParams(C.Structure):
+    """cl_partition_params"""
+    _fields_ = [("constraint_method", C.c_int), ("minimum_segment_score", C.c_double), ("minimum_segment_average", C.c_double),
+                ("window_length", C.c_double), ("generalized_length_mean", C.c_double), ("boundary_score_factor", C.c_double),
+                ("score_scale", C.c_double), ("score_boundaries", C.c_int), ("use_annotated_score", C.c_int),
+                ("score_function", ChainParams)]
+
+
+class AnchorFieldsC(C.Structure):
+    _fields_ = [("n_anchors", C.c_uint64)] + [(n, C.c_void_p) for n in
+                ("walk_off", "walk1", "walk2", "count1", "count2", "full_length", "match_set", "score")]
+
+
 class SplitParams(C.Structure):
     """cl_split_params: Anchorer::anchor_split_limit, min_split_length, min_path_length_spread, max_split_match_set_size"""
     _fields_ = [("anchor_split_limit", C.c_uint64), ("min_split_length", C.c_uint64), ("min_path_length_spread", C.c_uint64),
@@ -278,6 +321,20 @@ class AnchorChainResultC(C.Structure):
                 ("walk_off", C.POINTER(C.c_uint64)), ("walk1", C.POINTER(C.c_uint32)), ("walk2", C.POINTER(C.c_uint32)),
                 ("n_sets", C.c_uint64), ("set_order", C.POINTER(C.c_uint64)), ("scale", C.c_double), ("n_ties", C.c_uint64),
                 ("fill_in_pairs", C.c_uint64), ("fill_in_device_ms", C.c_float)]
+
+
+class CoreAlignParams(C.Structure):
+    """cl_core_align_params"""
+    _fields_ = [("split_matches_at_branchpoints", C.c_int), ("split", SplitParams), ("anchor", AnchorParams),
+                ("partition", PartitionParams), ("min_indel_fuzz_length", C.c_int64), ("indel_fuzz_score_proportion", C.c_double),
+                ("stitch", StitchParams)]
+
+
+class CoreAlignResultC(C.Structure):
+    _fields_ = [("alignment", AlignmentC), ("n_segments", C.c_uint64), ("seg_off", C.POINTER(C.c_uint64)),
+                ("walk_off", C.POINTER(C.c_uint64)), ("walk1", C.POINTER(C.c_uint32)), ("walk2", C.POINTER(C.c_uint32)),
+                ("scale", C.c_double), ("n_chain_anchors", C.c_uint64), ("chain_ms", C.c_float), ("partition_ms", C.c_float),
+                ("stitch_ms", C.c_float)]
 
 
 def default_chain_params(global_anchoring=True):
@@ -591,6 +648,18 @@ def load_library(path=None):
     lib.cl_chain_sparse.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
                                     C.POINTER(ChainParams), C.c_int, C.POINTER(ChainResultC)]
     lib.cl_chain_result_free.argtypes = [C.POINTER(ChainResultC)]
+    lib.cl_core_align_params_default.restype = None
+    lib.cl_core_align_params_default.argtypes = [C.POINTER(CoreAlignParams)]
+    lib.cl_core_align.restype = C.c_int
+    lib.cl_core_align.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.POINTER(CoreAlignParams),
+                                  C.POINTER(CoreAlignResultC)]
+    lib.cl_core_align_result_free.restype = None
+    lib.cl_core_align_result_free.argtypes = [C.POINTER(CoreAlignResultC)]
+    lib.cl_partition_params_default.restype = None
+    lib.cl_partition_params_default.argtypes = [C.POINTER(PartitionParams)]
+    lib.cl_partition_anchors.restype = C.c_int
+    lib.cl_partition_anchors.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(AnchorFieldsC), C.POINTER(PartitionParams),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.cl_split_params_default.restype = None
     lib.cl_split_params_default.argtypes = [C.POINTER(SplitParams)]
     lib.cl_split_branching_matches.restype = C.c_int
@@ -619,6 +688,8 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
     "cl_anchor_chain", "cl_anchor_chain_result_free",
+    "cl_partition_params_default", "cl_partition_anchors",
+    "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
 ]
 
@@ -775,6 +846,34 @@ class Context:
                         fill_in_pairs=int(out.fill_in_pairs), fill_in_device_ms=float(out.fill_in_device_ms))
         finally:
             self.lib.cl_anchor_chain_result_free(C.byref(out))
+
+    def core_align(self, graph1, graph2, matches, score_scale=1.0, max_num_match_pairs=1250000, score_boundaries=False, tweak=None):
+        """Core::align (include/centrolign/core.hpp:181-252) with the CLI's default configuration: anchor chain (branch
+        splitting, chaining, fill-in), partition, despecify, stitch.  `tweak(params)` may edit the CoreAlignParams.
+        Returns dict(alignment (n,2) uint64, seg_off, walk_off, walk1, walk2, scale, n_chain_anchors, *_ms)"""
+        ap = CoreAlignParams()
+        self.lib.cl_core_align_params_default(C.byref(ap))
+        ap.anchor.score_scale = float(score_scale)
+        ap.anchor.max_num_match_pairs = int(max_num_match_pairs)
+        ap.partition.score_boundaries = int(score_boundaries)
+        if tweak:
+            tweak(ap)
+        g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), CoreAlignResultC()
+        self._check(self.lib.cl_core_align(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), C.byref(out)))
+        try:
+            n, ns = int(out.alignment.n_pairs), int(out.n_segments)
+            seg_off = np.ctypeslib.as_array(out.seg_off, shape=(ns + 1,)).copy()
+            na = int(seg_off[-1])
+            walk_off = np.ctypeslib.as_array(out.walk_off, shape=(na + 1,)).copy()
+            nw = int(walk_off[-1])
+            return dict(alignment=np.ctypeslib.as_array(out.alignment.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2),
+                        seg_off=seg_off, walk_off=walk_off,
+                        walk1=np.ctypeslib.as_array(out.walk1, shape=(max(nw, 1),))[:nw].copy(),
+                        walk2=np.ctypeslib.as_array(out.walk2, shape=(max(nw, 1),))[:nw].copy(),
+                        scale=float(out.scale), n_chain_anchors=int(out.n_chain_anchors), chain_ms=float(out.chain_ms),
+                        partition_ms=float(out.partition_ms), stitch_ms=float(out.stitch_ms))
+        finally:
+            self.lib.cl_core_align_result_free(C.byref(out))
 
     def plan(self, batch, params=None, force_num_pw=None):
         params = params or default_stitch_params()

@@ -297,3 +297,309 @@ int cl_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2,
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Partitioner::partition_anchors (include/centrolign/partitioner.hpp:72-213)
+// =====================================================================================================================
+namespace {
+
+typedef std::vector<std::pair<size_t, size_t>> Intervals;
+const double kPartMinInf = std::numeric_limits<double>::lowest();
+
+// PartitionClient::traceback (partition_client.hpp:29-53)
+Intervals partition_traceback(const std::vector<std::pair<double, double>>& dp, const std::vector<size_t>& backpointer, size_t tb_idx) {
+    Intervals partition;
+    bool in_interval = true;
+    while (tb_idx > 0) {
+        if (in_interval) {
+            const size_t prev = backpointer[tb_idx];
+            partition.emplace_back(prev, tb_idx);
+            tb_idx = prev;
+            in_interval = false;
+        } else {
+            in_interval = (dp[tb_idx].first == dp[tb_idx - 1].second);
+            --tb_idx;
+        }
+    }
+    std::reverse(partition.begin(), partition.end());
+    return partition;
+}
+
+struct PartCtx {
+    const cl_partition_params* pp;
+    double min_score() const { return pp->minimum_segment_score * pp->score_scale; }
+    double min_average() const { return pp->minimum_segment_average * pp->score_scale; }
+    double adjust(double score, size_t i, size_t n) const {
+        if (pp->score_boundaries) {
+            if (i == 0) score += pp->boundary_score_factor * min_score();
+            if (i + 1 == n) score += pp->boundary_score_factor * min_score();
+        }
+        return score;
+    }
+};
+
+// partitioner.hpp:215-270
+Intervals maximum_weight_partition(const PartCtx& pc, const std::vector<double>& data) {
+    const double min_score = pc.min_score();
+    std::vector<double> prefix_sum(data.size() + 1, 0);
+    for (size_t i = 0; i < data.size(); ++i) prefix_sum[i + 1] = prefix_sum[i] + pc.adjust(data[i], i, data.size());
+    std::vector<std::pair<double, double>> dp(data.size() + 1, std::make_pair(kPartMinInf, kPartMinInf));
+    std::vector<size_t> backpointer(dp.size(), (size_t)-1);
+    dp[0].first = 0;
+    dp[0].second = 0;
+    size_t prefix_argmax = 0, tb_idx = 0;
+    for (size_t i = 1; i < dp.size(); ++i) {
+        dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
+        dp[i].second = dp[prefix_argmax].first + prefix_sum[i] - prefix_sum[prefix_argmax] - min_score;
+        backpointer[i] = prefix_argmax;
+        if (dp[i].first - prefix_sum[i] > dp[prefix_argmax].first - prefix_sum[prefix_argmax]) prefix_argmax = i;
+        if (dp[i].second > dp[tb_idx].second) tb_idx = i;
+    }
+    return partition_traceback(dp, backpointer, tb_idx);
+}
+
+typedef std::pair<double, size_t> PartKey;
+typedef clhost::MaxTree<PartKey, double> PartTree;
+
+// partitioner.hpp:272-351
+Intervals average_constrained_partition(const PartCtx& pc, const std::vector<std::pair<double, double>>& data) {
+    const double min_score = pc.min_score(), min_average = pc.min_average();
+    auto adjusted = [&](size_t i) { return pc.adjust(data[i].first, i, data.size()); };
+    std::vector<double> prefix_sum(data.size()), fractional(data.size());
+    if (!data.empty()) {
+        prefix_sum.front() = data.front().first;
+        fractional.front() = data.front().first - data.front().second * min_average;
+    }
+    for (size_t i = 1; i < data.size(); ++i) {
+        prefix_sum[i] = prefix_sum[i - 1] + adjusted(i);
+        fractional[i] = fractional[i - 1] + adjusted(i) - data[i].second * min_average;
+    }
+    std::vector<std::pair<double, double>> dp(data.size() + 1, std::make_pair(kPartMinInf, kPartMinInf));
+    std::vector<size_t> backpointer(dp.size(), (size_t)-1);
+    std::vector<std::pair<PartKey, double>> tree_data;
+    tree_data.reserve(data.size() + 1);
+    for (size_t i = 0; i < data.size(); ++i) tree_data.emplace_back(PartKey(fractional[i], i + 1), kPartMinInf);
+    tree_data.emplace_back(PartKey(0, 0), 0);
+    dp.front().first = 0;
+    dp.front().second = 0;
+    PartTree tree(tree_data);
+    size_t opt_idx = 0;
+    for (size_t i = 1; i < dp.size(); ++i) {
+        dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
+        const size_t mx = tree.range_max(PartKey(kPartMinInf, 0), PartKey(fractional[i - 1], (size_t)-1));
+        if (mx != tree.end() && tree.val[mx] != kPartMinInf) {
+            dp[i].second = prefix_sum[i - 1] + tree.val[mx] - min_score;
+            backpointer[i] = tree.key[mx].second;
+            if (dp[i].second > dp[opt_idx].second) opt_idx = i;
+        }
+        tree.update(tree.find(PartKey(fractional[i - 1], i)), dp[i].first - prefix_sum[i - 1]);
+    }
+    return partition_traceback(dp, backpointer, opt_idx);
+}
+
+// partitioner.hpp:353-684
+Intervals window_average_constrained_partition(const PartCtx& pc, const std::vector<std::pair<double, double>>& data) {
+    const double min_score = pc.min_score(), min_average = pc.min_average(), window_length = pc.pp->window_length;
+    const int64_t n = (int64_t)data.size();
+    auto adjusted = [&](size_t i) { return pc.adjust(data[i].first, i, data.size()); };
+    std::vector<char> meets_left(data.size()), meets_right(data.size());
+    std::vector<int64_t> leftward_partner(data.size()), rightward_partner(data.size());
+    for (int dir = 0; dir < 2; ++dir) {
+        const bool forward = dir == 0;
+        double window_score = 0.0, window_weight = 0.0;
+        int64_t end = forward ? 0 : n - 1;
+        const int64_t incr = forward ? 1 : -1;
+        auto& meets = forward ? meets_left : meets_right;
+        auto& partner = forward ? rightward_partner : leftward_partner;
+        for (int64_t i = end; i < n && i >= 0; i += incr) {
+            while (end < n && end >= 0 && window_weight < window_length) {
+                window_score += adjusted((size_t)end);
+                window_weight += data[end].second;
+                end += incr;
+            }
+            partner[i] = end;
+            if ((end < 0 || end >= n) && window_weight < window_length) {
+                if (i - incr >= 0 && i - incr < n) meets[i] = meets[i - incr];
+                else meets[i] = (window_score >= min_average * window_weight);
+            } else {
+                const double final_score = data[end - incr].first, final_weight = data[end - incr].second;
+                meets[i] = (final_weight * window_score + (window_length - window_weight) * final_score >= final_weight * min_average * window_length);
+            }
+            window_score -= adjusted((size_t)i);
+            window_weight -= data[i].second;
+        }
+    }
+    std::vector<double> prefix_sum(data.size() + 1), fractional(data.size() + 1);
+    std::vector<int> left_fail(data.size() + 1), right_fail(data.size() + 1);
+    for (size_t i = 0; i < data.size(); ++i) {
+        prefix_sum[i + 1] = prefix_sum[i] + adjusted(i);
+        fractional[i + 1] = fractional[i] + adjusted(i) - data[i].second * min_average;
+        left_fail[i + 1] = left_fail[i] + (int)!meets_left[i];
+        right_fail[i + 1] = right_fail[i] + (int)!meets_right[i];
+    }
+    std::vector<std::pair<PartKey, double>> tree_data;
+    tree_data.reserve(fractional.size() + 1);
+    for (size_t i = 0; i < fractional.size(); ++i) tree_data.emplace_back(PartKey(fractional[i], i), kPartMinInf);
+    tree_data.front().second = 0;
+    PartTree tree(tree_data);
+    std::vector<std::pair<double, double>> dp(data.size() + 1, std::make_pair(kPartMinInf, kPartMinInf));
+    std::vector<size_t> backpointer(dp.size(), (size_t)-1);
+    dp.front().first = 0;
+    dp.front().second = 0;
+    size_t tb_idx = 0, window_begin = 0;
+    double window_weight = 0.0;
+    size_t outside_argmax = (size_t)-1, argmax_partner = (size_t)-1, k = 0, l = 0, final_l = data.size();
+    {
+        double tail_weight = 0.0;
+        while (final_l != 0 && tail_weight + data[final_l - 1].second < window_length) {
+            tail_weight += data[final_l - 1].second;
+            --final_l;
+        }
+    }
+    for (size_t i = 1; i < dp.size(); ++i) {
+        while (l < final_l && rightward_partner[l] <= (int64_t)i) ++l;
+        if (outside_argmax != (size_t)-1 &&
+            (left_fail[outside_argmax] != left_fail[l] || right_fail[argmax_partner] != right_fail[i]))
+            outside_argmax = (size_t)-1;
+        window_weight += data[i - 1].second;
+        while (window_begin < data.size() && window_weight > window_length) {
+            window_weight -= data[window_begin].second;
+            const size_t it = tree.find(PartKey(fractional[window_begin], window_begin));
+            tree.update(it, kPartMinInf);
+            const size_t j = tree.key[it].second;
+            while (k < data.size() && leftward_partner[k] + 1 < (int64_t)j) ++k;
+            if ((left_fail[j] == left_fail[l] && right_fail[k] == right_fail[i]) &&
+                (outside_argmax == (size_t)-1 || dp[j].first - prefix_sum[j] > dp[outside_argmax].first - prefix_sum[outside_argmax])) {
+                outside_argmax = j;
+                argmax_partner = k;
+            }
+            ++window_begin;
+        }
+        dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
+        const size_t mx = tree.range_max(PartKey(kPartMinInf, 0), PartKey(fractional[i], (size_t)-1));
+        if (mx != tree.end() && tree.val[mx] != kPartMinInf) {
+            dp[i].second = prefix_sum[i] + tree.val[mx] - min_score;
+            backpointer[i] = tree.key[mx].second;
+        }
+        if (outside_argmax != (size_t)-1) {
+            const double outside_score = dp[outside_argmax].first + prefix_sum[i] - prefix_sum[outside_argmax] - min_score;
+            if (outside_score > dp[i].second) {
+                dp[i].second = outside_score;
+                backpointer[i] = outside_argmax;
+            }
+        }
+        if (dp[i].second > dp[tb_idx].second) tb_idx = i;
+        tree.update(tree.find(PartKey(fractional[i], i)), dp[i].first - prefix_sum[i]);
+    }
+    return partition_traceback(dp, backpointer, tb_idx);
+}
+
+// utility.hpp:255-285
+double add_log(double log_x, double log_y) {
+    return log_x < log_y ? log_y + log1p(exp(log_x - log_y)) : log_x + log1p(exp(log_y - log_x));
+}
+double generalized_mean(const std::vector<double>& v, double p) {
+    double n = 0.0;
+    if (p == 0.0) {
+        double sum_log = 0.0;
+        for (double x : v) { sum_log += log(x); n += 1.0; }
+        return exp(sum_log / n);
+    }
+    double log_sum = std::numeric_limits<double>::lowest() / 2.0;
+    for (double x : v) { log_sum = add_log(log_sum, p * log(x)); n += 1.0; }
+    return exp((log_sum - log(n)) / p);
+}
+
+}  // namespace
+
+extern "C" {
+
+void cl_partition_params_default(cl_partition_params* p) {
+    p->constraint_method = 3;
+    p->minimum_segment_score = 15000.0;
+    p->minimum_segment_average = 0.1;
+    p->window_length = 10000.0;
+    p->generalized_length_mean = -0.5;
+    p->boundary_score_factor = 0.95;
+    p->score_scale = 1.0;
+    p->score_boundaries = 0;
+    p->use_annotated_score = 0;
+    const double go[3] = {1.25, 50.0, 5000.0}, ge[3] = {2.5, 0.1, 0.0015};
+    for (int i = 0; i < 3; ++i) { p->score_function.gap_open[i] = go[i]; p->score_function.gap_extend[i] = ge[i]; }
+    p->score_function.anchor_score_function = 2;
+    p->score_function.pair_count_power = 0.5;
+    p->score_function.length_intercept = 2250.0;
+    p->score_function.length_decay_power = 2.0;
+    p->score_function.global_anchoring = 1;
+}
+
+int cl_partition_anchors(const cl_base_graph* g1, const cl_base_graph* g2, const cl_anchor_fields* an, const cl_partition_params* pp,
+                         uint64_t** segments_out, uint64_t* n_segments_out) {
+    if (!g1 || !g2 || !an || !pp || !segments_out || !n_segments_out) return CL_ERR_INVALID_ARGUMENT;
+    *segments_out = nullptr;
+    *n_segments_out = 0;
+    const size_t n = an->n_anchors;
+    // partitioner.hpp:81-103: the count penalty is reduced for match sets used several times in this chain
+    std::vector<uint64_t> num_from_set;
+    if (!pp->use_annotated_score)
+        for (size_t i = 0; i < n; ++i) {
+            if (num_from_set.size() <= an->match_set[i]) num_from_set.resize(an->match_set[i] + 1, 0);
+            ++num_from_set[an->match_set[i]];
+        }
+    auto anchor_score = [&](size_t i) -> double {
+        if (pp->use_annotated_score) return an->score[i];
+        const uint64_t used = num_from_set[an->match_set[i]];
+        return clhost::anchor_weight(pp->score_function, an->count1[i] - used + 1, an->count2[i] - used + 1,
+                                     an->walk_off[i + 1] - an->walk_off[i], an->full_length[i]);
+    };
+    const PartCtx pc{pp};
+    Intervals partition;
+    if (pp->constraint_method == 0) {
+        partition.emplace_back(0, n);
+    } else if (pp->constraint_method == 1) {
+        std::vector<double> data(n);
+        for (size_t i = 0; i < n; ++i) data[i] = anchor_score(i);
+        partition = maximum_weight_partition(pc, data);
+    } else if (pp->constraint_method == 2 || pp->constraint_method == 3) {
+        // the gaps between the anchors: extract_graphs_between + minimum distance across either graph (:124-151)
+        std::vector<uint64_t> seg_off{0, n};
+        cl_anchor_segments sg{n ? 1u : 0u, seg_off.data(), an->walk_off, an->walk1, an->walk2};
+        clhost::OwnedBatch ob;
+        const int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob);
+        if (rc) return rc;
+        const size_t n_gaps = ob.only_del.size();
+        std::vector<std::pair<double, double>> data(n + n_gaps);
+        for (size_t i = 0; i < data.size(); ++i) {
+            if (i % 2 == 0) {
+                std::vector<double> sizes;
+                for (int side = 0; side < 2; ++side) {
+                    const auto& sd = ob.side[side];
+                    const size_t kk = i / 2;
+                    if (sd.node_off[kk + 1] == sd.node_off[kk]) sizes.push_back(0.00001);
+                    else sizes.push_back((double)((uint64_t)clhost::min_source_sink(sd, kk) + 1));
+                }
+                data[i].first = 0.0;
+                data[i].second = generalized_mean(sizes, pp->generalized_length_mean);
+            } else {
+                data[i].first = anchor_score(i / 2);
+                data[i].second = (double)(an->walk_off[i / 2 + 1] - an->walk_off[i / 2]);
+            }
+        }
+        partition = pp->constraint_method == 2 ? average_constrained_partition(pc, data) : window_average_constrained_partition(pc, data);
+        for (auto& iv : partition) {
+            iv.first /= 2;
+            iv.second = std::min((iv.second + 1) / 2, n);
+        }
+        if (partition.size() == 1 && partition.front().first == partition.front().second) partition.pop_back();
+    } else {
+        return CL_ERR_INVALID_ARGUMENT;
+    }
+    uint64_t* out = (uint64_t*)malloc((partition.size() ? partition.size() : 1) * 2 * sizeof(uint64_t));
+    if (!out) return CL_ERR_OUT_OF_MEMORY;
+    for (size_t i = 0; i < partition.size(); ++i) { out[2 * i] = partition[i].first; out[2 * i + 1] = partition[i].second; }
+    *segments_out = out;
+    *n_segments_out = partition.size();
+    return CL_OK;
+}
+
+}  // extern "C"

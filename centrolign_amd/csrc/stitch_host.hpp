@@ -13,6 +13,7 @@
 #define CL_STITCH_HOST_HPP
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <limits>
 #include <unordered_map>
@@ -229,6 +230,50 @@ inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2
     }
     return CL_OK;
 }
+
+// minimum source->sink distance in nodes of one extracted subgraph, as source_sink_minmax(...).first (src/anchorer.cpp:14-23)
+inline int64_t min_source_sink(const clhost::OwnedBatch::Side& sd, uint64_t k) {
+    const uint64_t b = sd.node_off[k], n = sd.node_off[k + 1] - b;
+    std::vector<int64_t> dist(n, INT64_MAX);
+    std::vector<uint32_t> indeg(n), st, order;
+    for (uint64_t v = 0; v < n; ++v) { indeg[v] = (uint32_t)(sd.prev_off[b + v + 1] - sd.prev_off[b + v]); if (!indeg[v]) st.push_back((uint32_t)v); }
+    while (!st.empty()) {
+        uint32_t v = st.back(); st.pop_back(); order.push_back(v);
+        for (uint64_t e = sd.next_off[b + v]; e < sd.next_off[b + v + 1]; ++e) if (--indeg[sd.next_idx[e]] == 0) st.push_back(sd.next_idx[e]);
+    }
+    for (uint64_t i = sd.src_off[k]; i < sd.src_off[k + 1]; ++i) dist[sd.src_idx[i]] = 0;
+    for (uint32_t v : order)
+        if (dist[v] != INT64_MAX)
+            for (uint64_t e = sd.next_off[b + v]; e < sd.next_off[b + v + 1]; ++e) dist[sd.next_idx[e]] = std::min(dist[sd.next_idx[e]], dist[v] + 1);
+    int64_t mn = INT64_MAX;
+    for (uint64_t i = sd.snk_off[k]; i < sd.snk_off[k + 1]; ++i) mn = std::min(mn, dist[sd.snk_idx[i]]);
+    return mn;
+}
+
+
+inline double anchor_weight(const cl_chain_params& cp, uint64_t count1, uint64_t count2, uint64_t length, uint64_t full_length) {
+    // ScoreFunction::anchor_weight (score_function.hpp:51-75) in the operation order of the reference AS BUILT: its
+    // CMakeLists.txt:9 compiles with -O3 -ffast-math, under which gcc turns "x / pow(c, p)" into "x * pow(c, -p)" and
+    // regroups the products (disassembly of oracle/_ref).  Mathematically tied weights (e.g. lengths symmetric about the
+    // vertex of the concave length term) order match sets in the budget selection (anchorer.hpp:1130-1134), so the
+    // last bit matters.
+    const double count = (double)(count1 * count2);
+    const double fraction = double(length) / double(full_length);
+    switch (cp.anchor_score_function) {
+    case 0: return pow(count, -cp.pair_count_power) * fraction;
+    case 1: return (fraction * (double)length) * pow(count, -cp.pair_count_power);
+    case 2: {
+        const double inv = pow(count, -cp.pair_count_power);
+        const double decay = pow((double)length / cp.length_intercept, cp.length_decay_power);
+        return (inv * (double)length - cp.length_intercept * decay) * fraction;
+    }
+    default: {
+        const double decay = pow((double)length / cp.length_intercept, cp.length_decay_power);
+        return ((double)length - (cp.length_intercept * count) * decay) * fraction;
+    }
+    }
+}
+
 
 }  // namespace clhost
 

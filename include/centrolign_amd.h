@@ -306,6 +306,40 @@ int  cl_chain_sparse(cl_context* ctx, const cl_base_graph* graph1, const cl_base
                      uint64_t num_match_sets, const cl_chain_params* params, int want_dp, cl_chain_result* out);
 void cl_chain_result_free(cl_chain_result* r);
 
+/* --- Partitioner::partition_anchors (include/centrolign/partitioner.hpp:72-213) -----------------------------------------
+ * Cuts the anchor chain into the well-anchored segments that Stitcher::stitch takes (Core::align, core.hpp:237-249).
+ * Host only: extract_graphs_between + min source-sink distances for the gap lengths, then the partition DP
+ * (window_average_constrained_partition :353-684 by default; also maximum_weight_partition :215-270 and
+ * average_constrained_partition :272-351).  Anchors are passed as the fields the algorithm reads. */
+typedef struct cl_partition_params {
+    int    constraint_method;        /* Partitioner::ConstraintMethod: 0 Null, 1 Unconstrained, 2 MinAverage, 3 MinWindowAverage (default) */
+    double minimum_segment_score;    /* 15000 */
+    double minimum_segment_average;  /* 0.1 */
+    double window_length;            /* 10000 */
+    double generalized_length_mean;  /* -0.5 */
+    double boundary_score_factor;    /* 0.95 */
+    double score_scale;              /* ScoreFunction::score_scale */
+    int    score_boundaries;         /* Core::align passes !is_main_execution */
+    int    use_annotated_score;      /* partition_anchors' last argument (false in Core::align) */
+    cl_chain_params score_function;  /* the ScoreFunction fields (anchor_weight) */
+} cl_partition_params;
+void cl_partition_params_default(cl_partition_params* p);
+typedef struct cl_anchor_fields {
+    uint64_t        n_anchors;
+    const uint64_t* walk_off;     /* [n+1] */
+    const uint32_t* walk1;
+    const uint32_t* walk2;
+    const uint64_t* count1;
+    const uint64_t* count2;
+    const uint64_t* full_length;
+    const uint64_t* match_set;
+    const double*   score;        /* anchor_t::score, read when use_annotated_score */
+} cl_anchor_fields;
+/* segments_out: malloc'ed [2 * *n_segments_out] = (first anchor, past-the-last anchor) of every segment, in order;
+ * anchors outside every interval are dropped, as in the reference.  Release with free(). */
+int cl_partition_anchors(const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_anchor_fields* anchors,
+                         const cl_partition_params* params, uint64_t** segments_out, uint64_t* n_segments_out);
+
 /* --- Anchorer::split_branching_matches (include/centrolign/anchorer.hpp:800-956), the first step of anchor_chain when
  * split_matches_at_branchpoints is set (CLI default): match sets whose walks cross the boundary of a superbubble with a
  * large length spread (superbubbles.hpp:63-170, structure_distances.hpp:55-185) near their ends are cut there; the pieces
@@ -362,6 +396,35 @@ typedef struct cl_anchor_chain_result {
 int  cl_anchor_chain(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
                      const cl_anchor_params* params, cl_anchor_chain_result* out);
 void cl_anchor_chain_result_free(cl_anchor_chain_result* r);
+
+/* --- Core::align (include/centrolign/core.hpp:181-252): matches of one merge -> the merge's base-level alignment ------
+ * anchor_chain (split + chaining + fill-in, device), partition_anchors (host), despecify_indel_breakpoints per
+ * segment (host), Stitcher::stitch (device).  score_boundaries = !is_main_execution goes in partition.score_boundaries;
+ * partition.score_scale and partition.score_function are taken from `anchor`. */
+typedef struct cl_core_align_params {
+    int                 split_matches_at_branchpoints;   /* Anchorer::split_matches_at_branchpoints (CLI default true) */
+    cl_split_params     split;
+    cl_anchor_params    anchor;
+    cl_partition_params partition;
+    int64_t             min_indel_fuzz_length;           /* Stitcher tunables, stitcher.hpp:68-71 */
+    double              indel_fuzz_score_proportion;
+    cl_stitch_params    stitch;
+} cl_core_align_params;
+void cl_core_align_params_default(cl_core_align_params* p);   /* the CLI's values (src/parameters.cpp:36-92) */
+typedef struct cl_core_align_result {
+    cl_alignment alignment;      /* the stitched Alignment (AlignedPair layout) */
+    uint64_t  n_segments;        /* the partitioned, despecified anchor chain that was stitched */
+    uint64_t* seg_off;
+    uint64_t* walk_off;
+    uint32_t* walk1;
+    uint32_t* walk2;
+    double    scale;             /* estimated score scale of the chaining */
+    uint64_t  n_chain_anchors;   /* anchors before partitioning */
+    float     chain_ms, partition_ms, stitch_ms;   /* wall time of the three stages */
+} cl_core_align_result;
+int  cl_core_align(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+              const cl_core_align_params* params, cl_core_align_result* out);
+void cl_core_align_result_free(cl_core_align_result* r);
 
 #ifdef __cplusplus
 }

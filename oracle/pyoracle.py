@@ -355,3 +355,31 @@ def ref_split_branching_matches(g1, g2, ms, anchor_split_limit=5, min_split_leng
     nodes2 = np.concatenate([nodes[start[s] + n1[s] * ln[s]:start[s + 1]] for s in range(k)]) if k else np.zeros(0, np.uint32)
     return MatchSets(set_off1=so1, walk_off1=wo1, nodes1=nodes1, set_off2=so2, walk_off2=wo2, nodes2=nodes2,
                      count1=rows[:, 3], count2=rows[:, 4], full_length=rows[:, 5])
+
+
+def ref_partition_anchors(g1, g2, chain, score_scale=1.0, score_boundaries=False, use_annotated_score=False, params=None,
+                          constraint_method=3, minimum_segment_score=15000.0, minimum_segment_average=0.1, window_length=10000.0,
+                          generalized_length_mean=-0.5, boundary_score_factor=0.95):
+    """the compiled reference's Partitioner::partition_anchors on the anchor dict of ref_anchor_chain; (n_segments, 2)"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_partition_anchors.restype = C.c_int
+    lib.ref_partition_anchors.argtypes = ([C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.c_uint64] + [C.c_void_p] * 8 + [C.POINTER(CloChainParams), C.c_int]
+                                          + [C.c_double] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+    params = params or default_chain_params()
+    c1, c2 = g1.as_c(), g2.as_c()
+    a = dict(walk_off=np.ascontiguousarray(chain["walk_off"], np.uint64), walk1=np.ascontiguousarray(chain["walk1"], np.uint32),
+             walk2=np.ascontiguousarray(chain["walk2"], np.uint32), count1=np.ascontiguousarray(chain["count1"], np.uint64),
+             count2=np.ascontiguousarray(chain["count2"], np.uint64), full_length=np.ascontiguousarray(chain["full_length"], np.uint64),
+             match_set=np.ascontiguousarray(np.asarray(chain["chain"])[:, 0] if len(chain["chain"]) else np.zeros(0), np.uint64),
+             score=np.ascontiguousarray(chain["score"], np.float64))
+    n = len(a["count1"])
+    seg = np.zeros((max(n, 1), 2), np.uint64)
+    ns = C.c_uint64(0)
+    rc = lib.ref_partition_anchors(C.byref(c1), C.byref(c2), n, *[a[k].ctypes.data for k in ("walk_off", "walk1", "walk2", "count1", "count2", "full_length", "match_set", "score")],
+                                   C.byref(params), int(constraint_method), minimum_segment_score, minimum_segment_average, window_length,
+                                   generalized_length_mean, boundary_score_factor, float(score_scale), int(score_boundaries),
+                                   int(use_annotated_score), seg.ctypes.data, C.addressof(ns))
+    if rc:
+        raise RuntimeError("ref_partition_anchors failed: %d" % rc)
+    return seg[:int(ns.value)].copy()

@@ -535,6 +535,53 @@ int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
 
 void ref_free(void* p) { free(p); }
 
+/* Partitioner::partition_anchors (partitioner.hpp:72-213) on flat anchors; segments_out gets (first, past-the-last) anchor
+ * index pairs (buffer for n_anchors pairs) */
+int ref_partition_anchors(const cl_base_graph* g1, const cl_base_graph* g2, uint64_t n_anchors, const uint64_t* walk_off,
+                          const uint32_t* walk1, const uint32_t* walk2, const uint64_t* count1, const uint64_t* count2,
+                          const uint64_t* full_length, const uint64_t* match_set, const double* score, const clo_chain_params* cp,
+                          int constraint_method, double minimum_segment_score, double minimum_segment_average, double window_length,
+                          double generalized_length_mean, double boundary_score_factor, double score_scale, int score_boundaries,
+                          int use_annotated_score, uint64_t* segments_out, uint64_t* n_segments_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    std::vector<anchor_t> anchors(n_anchors);
+    for (uint64_t i = 0; i < n_anchors; ++i) {
+        anchors[i].walk1.assign(walk1 + walk_off[i], walk1 + walk_off[i + 1]);
+        anchors[i].walk2.assign(walk2 + walk_off[i], walk2 + walk_off[i + 1]);
+        anchors[i].count1 = count1[i];
+        anchors[i].count2 = count2[i];
+        anchors[i].full_length = full_length[i];
+        anchors[i].match_set = match_set[i];
+        anchors[i].score = score[i];
+        anchors[i].idx1 = i;   // not read by the partitioner: carries the identity through the move
+    }
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    sf.score_scale = score_scale;
+    Partitioner part(sf);
+    part.constraint_method = (Partitioner::ConstraintMethod)constraint_method;
+    part.minimum_segment_score = minimum_segment_score;
+    part.minimum_segment_average = minimum_segment_average;
+    part.window_length = window_length;
+    part.generalized_length_mean = generalized_length_mean;
+    part.boundary_score_factor = boundary_score_factor;
+    PathMerge<uint32_t, uint8_t> pm1(b1, t1), pm2(b2, t2);
+    auto segments = part.partition_anchors(anchors, b1, b2, t1, t2, pm1, pm2, score_boundaries != 0, use_annotated_score != 0);
+    *n_segments_out = segments.size();
+    for (size_t i = 0; i < segments.size(); ++i) {
+        if (segments[i].empty()) return -2;
+        segments_out[2 * i] = segments[i].front().idx1;
+        segments_out[2 * i + 1] = segments[i].back().idx1 + 1;
+        for (size_t j = 0; j < segments[i].size(); ++j)
+            if (segments[i][j].idx1 != segments[i].front().idx1 + j) return -3;
+    }
+    return 0;
+}
+
 /* Anchorer::split_branching_matches (anchorer.hpp:800-956) on flat inputs.  Output: the resulting sets as
  * (source set, n walks1, n walks2, walk length) rows plus every walk's nodes, graph-1 walks then graph-2 walks per set. */
 int ref_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, uint64_t anchor_split_limit,

@@ -195,6 +195,13 @@ def main():
                 for k in po.MatchSets._DT:
                     out["%s.%s" % (tag, k)] = getattr(r, k)
             np.savez_compressed(os.path.join(HERE, "split4_30k_merge%d.npz" % m), **out)
+        # 6d. Core::align end to end (core.hpp:181-252) on the root merge: ALL the match sets PathMatchFinder returned, the
+        #     calibrated score scale, and what the reference made of them — the partitioned + despecified anchor segments
+        #     and the stitched alignment (graphs are in stitch4_30k_merge2.npz; max_num_match_pairs was 40000)
+        pre = "m2."
+        out = {k[len(pre):]: v for k, v in dd.items() if k.startswith(pre) and (k[len(pre):].startswith("ms.") or
+               k[len(pre):] in ("score_scale", "seg_off", "walk_off", "walk1", "walk2", "stitched"))}
+        np.savez_compressed(os.path.join(HERE, "align4_30k_merge2.npz"), **out)
     else:
         print("skip stitch-level fixtures (no dump at %s)" % path)
     # 7. despecify_indel_breakpoints: random anchor chains -> the reference's kept set and updated gap fields

