@@ -130,6 +130,12 @@ def chaining_section(ctx, with_reference):
     out["affine_dp_only"] = {"match_pairs": dp["n_pairs"], "device_dp_ms": dp["device_ms"], "host_prep_ms": dp["prep_ms"],
                              "value_index_ms": dp["index_ms"], "traceback_ms": dp["traceback_ms"],
                              "pair_evaluations_per_s_device": dp["n_pairs"] ** 2 / 2 / (dp["device_ms"] * 1e-3)}
+    # the whole merge: Core::align = anchor chain + partition + despecify + stitch (cl_core_align), same input
+    t0 = time.perf_counter()
+    al = ctx.core_align(graphs[0], graphs[1], ms, score_scale=score_scale)
+    out["core_align"] = {"wall_s": time.perf_counter() - t0, "chain_ms": al["chain_ms"], "partition_ms": al["partition_ms"],
+                         "stitch_ms": al["stitch_ms"], "segments": int(len(al["seg_off"]) - 1), "anchors": int(len(al["walk_off"]) - 1),
+                         "aligned_pairs": int(len(al["alignment"]))}
     if with_reference:
         from oracle import pyoracle as po
         if po.have_ref():
