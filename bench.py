@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed passes (no saturated / pipelined / chaining sections): the command the rocprofv3 "
+                         "summaries under profiles/ are taken with, so that their per-kernel averages are those of the timed passes")
     args = ap.parse_args()
 
     import torch
@@ -236,7 +239,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch)
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out["saturated"] = saturated_section(ctx, batch)
             out["pipelined"] = pipelined_section(batch, local_rank)
             ch = chaining_section(ctx, not args.no_cpu_baseline)

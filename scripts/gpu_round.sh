@@ -10,5 +10,5 @@ python __graft_entry__.py smoke 2>&1 | tail -3 | tee $OUT/smoke.txt
 python bench.py --steps 50 --warmup 5 2>$OUT/bench.err | tee $OUT/bench.json
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_prof.json 2>$OUT/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_prof.json 2>$OUT/prof.err
 ls -R $OUT/prof | head -30

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o r01 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_$c.json 2>$OUT/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o r01 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_$c.json 2>$OUT/pmc_$c.err
   ls $OUT/pmc_$c | head
 done
 cd $R
