@@ -42,8 +42,10 @@ struct ClChainDevice {
     const uint32_t* rec_off;    // [n_pairs + 1] records of each pair
     const uint32_t* rec_combo;
     const uint32_t* rec_pos;
-    const uint32_t* group;      // [n_pairs] depth window of the pair's first graph-1 node (non-decreasing); pairs of one
-                                // window cannot precede one another
+    const uint32_t* group;      // [n_pairs] group id, consecutive along the sorted pairs; pairs of one group cannot precede
+                                // one another
+    const uint32_t* grp_base;   // [n_pairs] LDS slot of the pair's first record within its (block, group)
+    const uint32_t* grp_total;  // [n_pairs] number of records of the pair's (block, group)
     ClChainParams params;
     uint32_t sparse;            // sparse_chain_dp: only the gap-free maximum (acc[0], val[0]) is used
 };

@@ -204,13 +204,16 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
     for (int k = 0; k < 3; ++k) my_t[k] = D.params.scale * D.params.gap_extend[k] * (double)my_sig;
     const bool simple = D.n_combos == 1;
     // LDS: the records published by the current group (first kChainLdsRecs of them; the rest are re-read from HBM)
-    __shared__ uint32_t s_count, s_next_group;
+    __shared__ uint32_t s_count;
     __shared__ __attribute__((aligned(16))) int s_rec[kChainLdsRecs][12];  // ins_t, off, sigma, 7 encoded values, combo, -
 
+    // group ids are consecutive along the sorted pairs, so the block holds every id from its first pair's to its last pair's;
+    // the LDS slot of a pair's records and the record count of its (block, group) come precomputed from the host: no LDS
+    // atomics in the walk (256 threads hammering one LDS word per group were most of this kernel's time)
+    const uint32_t last_group = D.group[block_first + block_count - 1];
+    const uint32_t my_base = active ? D.grp_base[s] : 0u, my_total = active ? D.grp_total[s] : 0u;
     uint32_t group = D.group[block_first];
     while (true) {
-        if (i == 0) { s_count = 0; s_next_group = 0xFFFFFFFFu; }
-        lds_barrier();
         if (active && my_group == group) {
             // finalise: dp = max(chain starting here, every candidate) — anchorer.hpp:2026-2041, 2379-2412
             float best = w_init;
@@ -229,8 +232,8 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
             }
             D.dp[s] = best;
             // publish the pair's records: the values stored in every tree it sits in (anchorer.hpp:2318-2342)
-            const uint32_t n = r1 - r0;
-            const uint32_t base = n ? atomicAdd(&s_count, n) : 0u;
+            const uint32_t base = my_base;
+            if (my_base == 0) s_count = my_total;   // the group's first pair(s) in this block (all write the same value)
             for (uint32_t r = r0; r < r1; ++r) {
                 uint32_t c = my_combo, pos = my_pos, ins = my_ins, off = my_off;
                 int32_t sg = my_sig;
@@ -258,14 +261,39 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
                     s_rec[l][10] = (int)c;
                 }
             }
-        } else if (active && my_group > group) {
-            atomicMin(&s_next_group, my_group);
         }
         lds_barrier();
-        const uint32_t n = s_count, next_group = s_next_group;
+        const uint32_t n = s_count;
         if (n > kChainLdsRecs) __syncthreads();   // the overflow path below reads the group's records back from HBM
         if (active && my_group > group) {
-            if (n <= kChainLdsRecs) {
+            if (simple && n <= kChainLdsRecs) {
+                // one combination (a pairwise problem): batches of four records, their LDS reads issued together — the loop
+                // is bound by LDS latency, not by the arithmetic
+                if (has_q0) {
+                    uint32_t l = 0;
+                    for (; l + 4 <= n; l += 4) {
+                        int4 ra[4], rb[4], rc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ra[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][0]);
+                            rb[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][4]);
+                            rc[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][8]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int v[7] = {ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w, rc[u].x, rc[u].y};
+                            accumulate(acc0, qt0, qoff0, q0, (uint32_t)ra[u].x, (uint32_t)ra[u].y, ra[u].z, v);
+                        }
+                    }
+                    for (; l < n; ++l) {
+                        const int4 a = *reinterpret_cast<const int4*>(&s_rec[l][0]);
+                        const int4 b = *reinterpret_cast<const int4*>(&s_rec[l][4]);
+                        const int4 cc4 = *reinterpret_cast<const int4*>(&s_rec[l][8]);
+                        const int v[7] = {a.w, b.x, b.y, b.z, b.w, cc4.x, cc4.y};
+                        accumulate(acc0, qt0, qoff0, q0, (uint32_t)a.x, (uint32_t)a.y, a.z, v);
+                    }
+                }
+            } else if (n <= kChainLdsRecs) {
                 for (uint32_t l = 0; l < n; ++l) {
                     const int4 a = *reinterpret_cast<const int4*>(&s_rec[l][0]);
                     const int4 b = *reinterpret_cast<const int4*>(&s_rec[l][4]);
@@ -312,8 +340,8 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
                 }
             }
         }
-        if (next_group == 0xFFFFFFFFu) break;
-        group = next_group;
+        if (group == last_group) break;
+        ++group;
         lds_barrier();
     }
     // keep the final maxima: the traceback needs the value every query returned

@@ -578,12 +578,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     int rc = CL_OK;
     DevBuf<ClChainCombo> d_combos;
     DevBuf<float> d_weight, d_init, d_dp;
-    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group;
+    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total;
     std::vector<ClChainCombo> hc(combos.size());
     std::vector<int> acc_init(M * 7, enc(CL_CHAIN_NEG));
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
-        d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release();
+        d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release(); d_grp_base.release(); d_grp_total.release();
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
@@ -624,7 +624,31 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             else min_end = std::min(min_end, end);
             group[s] = gid;
         }
+        if (timing) {   // groups per block of kChainBlock pairs (each costs the sequential kernel two barriers + one LDS broadcast)
+            std::vector<uint32_t> hist;
+            for (uint64_t b0 = 0; b0 < M; b0 += kChainBlock) {
+                const uint64_t b1 = std::min<uint64_t>(M, b0 + kChainBlock);
+                const uint32_t g = group[b1 - 1] - group[b0] + 1;
+                if (hist.size() <= g) hist.resize(g + 1, 0);
+                ++hist[g];
+            }
+            fprintf(stderr, "[chain_dp_batch]   %u groups; groups per block:", gid + 1);
+            for (size_t g = 0; g < hist.size(); ++g) if (hist[g]) fprintf(stderr, " %zu:%u", g, hist[g]);
+            fprintf(stderr, "\n");
+        }
         CH(d_group.upload(ctx, group));
+        // LDS slots of the sequential kernel: records of a (block, group) are laid out in pair order
+        std::vector<uint32_t> grp_base(M), grp_total(M);
+        for (uint64_t s0 = 0; s0 < M;) {
+            const uint64_t block_end = std::min<uint64_t>(M, (s0 / kChainBlock + 1) * kChainBlock);
+            uint64_t s1 = s0;
+            while (s1 < block_end && group[s1] == group[s0]) ++s1;
+            const uint32_t total = rec_off[s1] - rec_off[s0];
+            for (uint64_t s = s0; s < s1; ++s) { grp_base[s] = rec_off[s] - rec_off[s0]; grp_total[s] = total; }
+            s0 = s1;
+        }
+        CH(d_grp_base.upload(ctx, grp_base));
+        CH(d_grp_total.upload(ctx, grp_total));
     }
     ClChainDevice D{};
     D.n_pairs = (uint32_t)M;
@@ -637,6 +661,8 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     D.rec_combo = d_rec_combo.p;
     D.rec_pos = d_rec_pos.p;
     D.group = d_group.p;
+    D.grp_base = d_grp_base.p;
+    D.grp_total = d_grp_total.p;
     for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
     D.params.scale = local_scale;
     D.sparse = sparse ? 1u : 0u;
