@@ -19,6 +19,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -266,6 +267,171 @@ int pure_deletion(const GraphView& g, std::vector<uint32_t>& path) {
     return CL_OK;
 }
 
+// ---- greedy_partial_alignment (include/centrolign/alignment.hpp:1212-1611): do_alignment's route for gaps that look
+// unalignable (stitcher.hpp:340-357).  Host algorithm in the reference as well: exact-match paths grown greedily (DFS over
+// label-matching node pairs) from the sources and from the sinks, joined by a double deletion along shortest paths;
+// overlapping or mutually unreachable match paths are trimmed by bisection on the total trim.
+struct GreedyGraph {
+    const GraphView* g;
+    NextLists nx;
+    std::vector<uint32_t> order;
+    std::vector<uint64_t> dp;
+    bool init(const GraphView& gv) {
+        g = &gv;
+        nx.build(gv);
+        std::vector<uint32_t> st, indeg;
+        dp.resize(gv.n);
+        return topological_order(gv, nx, order, st, indeg);
+    }
+    // shortest_path between node sets (shortest_path.hpp:32-100), empty if there is none
+    std::vector<uint64_t> shortest(const std::vector<uint64_t>& from, const std::vector<uint64_t>& to) {
+        const uint64_t INF = (uint64_t)std::numeric_limits<int64_t>::max();
+        std::fill(dp.begin(), dp.end(), INF);
+        for (uint64_t v : from) dp[v] = 0;
+        for (uint32_t v : order) {
+            const uint64_t thru = dp[v] + 1;
+            for (uint64_t e = nx.begin(v); e < nx.end(v); ++e) dp[nx.i[e]] = std::min(dp[nx.i[e]], thru);
+        }
+        uint64_t best = UINT64_MAX;
+        for (uint64_t v : to)
+            if (dp[v] != INF && (best == UINT64_MAX || dp[v] < dp[best])) best = v;
+        std::vector<uint64_t> path;
+        if (best == UINT64_MAX) return path;
+        path.push_back(best);
+        while (dp[path.back()] != 0) {
+            const uint64_t cur = path.back();
+            uint64_t nxt = UINT64_MAX;
+            for (uint64_t e = g->prev_off[cur]; e < g->prev_off[cur + 1]; ++e)
+                if (dp[g->prev_idx[e]] + 1 == dp[cur]) { nxt = g->prev_idx[e]; break; }
+            if (nxt == UINT64_MAX) break;
+            path.push_back(nxt);
+        }
+        std::reverse(path.begin(), path.end());
+        return path;
+    }
+    bool reaches(uint64_t from, uint64_t to) { return !shortest(std::vector<uint64_t>(1, from), std::vector<uint64_t>(1, to)).empty(); }
+};
+
+typedef std::vector<std::pair<uint64_t, uint64_t>> HostAlignment;   // local node ids, CL_GAP for a gap
+
+int greedy_partial_alignment(const GraphView& gv1, const GraphView& gv2, HostAlignment& out) {
+    out.clear();
+    GreedyGraph g1, g2;
+    if (!g1.init(gv1) || !g2.init(gv2)) return CL_ERR_CYCLIC_GRAPH;
+    const uint64_t n2 = gv2.n;
+    const std::vector<uint64_t> sources1(gv1.src, gv1.src + gv1.n_src), sources2(gv2.src, gv2.src + gv2.n_src);
+    const std::vector<uint64_t> sinks1(gv1.snk, gv1.snk + gv1.n_snk), sinks2(gv2.snk, gv2.snk + gv2.n_snk);
+    HostAlignment aln_fwd, aln_rev;
+    for (int dir = 0; dir < 2; ++dir) {
+        const bool forward = dir == 0;
+        size_t max_len = 0;
+        uint64_t end_key = UINT64_MAX;
+        std::unordered_map<uint64_t, uint64_t> back;   // pair key -> predecessor key (UINT64_MAX at a start)
+        struct Item { uint64_t a, b; size_t len; };
+        std::vector<Item> stack;
+        for (uint64_t a : (forward ? sources1 : sinks1))
+            for (uint64_t b : (forward ? sources2 : sinks2))
+                if (gv1.label[a] == gv2.label[b]) {
+                    stack.push_back(Item{a, b, 1});
+                    back[a * n2 + b] = UINT64_MAX;
+                }
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.len > max_len) { max_len = it.len; end_key = it.a * n2 + it.b; }
+            const uint64_t b1 = forward ? g1.nx.begin(it.a) : gv1.prev_off[it.a], e1 = forward ? g1.nx.end(it.a) : gv1.prev_off[it.a + 1];
+            const uint64_t b2 = forward ? g2.nx.begin(it.b) : gv2.prev_off[it.b], e2 = forward ? g2.nx.end(it.b) : gv2.prev_off[it.b + 1];
+            const uint32_t* i1 = forward ? g1.nx.i : gv1.prev_idx;
+            const uint32_t* i2 = forward ? g2.nx.i : gv2.prev_idx;
+            for (uint64_t x = b1; x < e1; ++x)
+                for (uint64_t y = b2; y < e2; ++y) {
+                    const uint64_t na = i1[x], nb = i2[y];
+                    if (gv1.label[na] == gv2.label[nb] && !back.count(na * n2 + nb)) {
+                        back[na * n2 + nb] = it.a * n2 + it.b;
+                        stack.push_back(Item{na, nb, it.len + 1});
+                    }
+                }
+        }
+        HostAlignment& aln = forward ? aln_fwd : aln_rev;
+        while (end_key != UINT64_MAX) {
+            aln.emplace_back(end_key / n2, end_key % n2);
+            end_key = back.at(end_key);
+        }
+        if (forward) std::reverse(aln.begin(), aln.end());
+    }
+    size_t left_trim = 0, right_trim = 0;
+    std::vector<uint64_t> path1, path2;
+    bool found = false;
+    if (aln_fwd.empty() || aln_rev.empty() ||
+        (aln_fwd.back().first != aln_rev.front().first && aln_fwd.back().second != aln_rev.front().second)) {
+        const std::vector<uint64_t> start1 = aln_fwd.empty() ? sources1 : std::vector<uint64_t>(1, aln_fwd.back().first);
+        const std::vector<uint64_t> end1 = aln_rev.empty() ? sinks1 : std::vector<uint64_t>(1, aln_rev.front().first);
+        if (!start1.empty() && !end1.empty()) path1 = g1.shortest(start1, end1);
+        if (!path1.empty()) {
+            const std::vector<uint64_t> start2 = aln_fwd.empty() ? sources2 : std::vector<uint64_t>(1, aln_fwd.back().second);
+            const std::vector<uint64_t> end2 = aln_rev.empty() ? sinks2 : std::vector<uint64_t>(1, aln_rev.front().second);
+            if (!start2.empty() && !end2.empty()) path2 = g2.shortest(start2, end2);
+            if (!path2.empty()) {
+                found = true;
+                if (!aln_fwd.empty()) { path1.erase(path1.begin()); path2.erase(path2.begin()); }
+                if (!aln_rev.empty()) { path1.pop_back(); path2.pop_back(); }
+            }
+        }
+    }
+    if (!found) {
+        // the reference answers these questions by direct search for the first 8 and through a distance oracle afterwards
+        // (alignment.hpp:1477-1497); both decide plain reachability
+        auto reachable_after_trim = [&](size_t trim_left, size_t trim_right) {
+            bool allow_equal = false;
+            HostAlignment left, right;
+            if (trim_left == aln_fwd.size()) {
+                for (uint64_t a : sources1) for (uint64_t b : sources2) left.emplace_back(a, b);
+                allow_equal = true;
+            } else left.push_back(aln_fwd[aln_fwd.size() - 1 - trim_left]);
+            if (trim_right == aln_rev.size()) {
+                for (uint64_t a : sinks1) for (uint64_t b : sinks2) right.emplace_back(a, b);
+                allow_equal = true;
+            } else right.push_back(aln_rev[trim_right]);
+            for (const auto& l : left)
+                for (const auto& r : right) {
+                    if (!allow_equal && (l.first == r.first || l.second == r.second)) continue;
+                    if (g1.reaches(l.first, r.first) && g2.reaches(l.second, r.second)) return true;
+                }
+            return false;
+        };
+        int64_t lo = 1, hi = (int64_t)(aln_fwd.size() + aln_rev.size());
+        while (lo <= hi) {
+            const int64_t total = (lo + hi) / 2;
+            bool success = false;
+            const size_t l_min = (size_t)std::max<int64_t>(0, total - (int64_t)aln_rev.size());
+            const size_t l_max = std::min<size_t>((size_t)total, aln_fwd.size());
+            for (size_t l = l_min; l <= l_max; ++l)
+                if (reachable_after_trim(l, (size_t)total - l)) {
+                    left_trim = l;
+                    right_trim = (size_t)total - l;
+                    success = true;
+                    break;
+                }
+            if (success) hi = total - 1;
+            else lo = total + 1;
+        }
+        std::vector<uint64_t> from1, from2, to1, to2;
+        if (left_trim == aln_fwd.size()) { from1 = sources1; from2 = sources2; }
+        else { from1.push_back(aln_fwd[aln_fwd.size() - left_trim - 1].first); from2.push_back(aln_fwd[aln_fwd.size() - left_trim - 1].second); }
+        if (right_trim == aln_rev.size()) { to1 = sinks1; to2 = sinks2; }
+        else { to1.push_back(aln_rev[right_trim].first); to2.push_back(aln_rev[right_trim].second); }
+        path1 = g1.shortest(from1, to1);
+        path2 = g2.shortest(from2, to2);
+        if (left_trim != aln_fwd.size()) { if (!path1.empty()) path1.erase(path1.begin()); if (!path2.empty()) path2.erase(path2.begin()); }
+        if (right_trim != aln_rev.size()) { if (!path1.empty()) path1.pop_back(); if (!path2.empty()) path2.pop_back(); }
+    }
+    for (size_t i = 0; i + left_trim < aln_fwd.size(); ++i) out.push_back(aln_fwd[i]);
+    for (uint64_t v : path1) out.emplace_back(v, CL_GAP);
+    for (uint64_t v : path2) out.emplace_back(CL_GAP, v);
+    for (size_t i = right_trim; i < aln_rev.size(); ++i) out.push_back(aln_rev[i]);
+    return CL_OK;
+}
+
 int64_t pure_deletion_score(size_t path_len, int npw, const cl_align_params& p) {
     if (path_len == 0) return 0;
     // alignment.hpp:1202-1205 evaluates -open - extend in uint32_t before widening; reproduced literally
@@ -296,6 +462,8 @@ struct cl_stitch_plan {
     std::vector<int32_t> po_index;                 // index among PO-POA problems or -1
     std::vector<std::vector<uint32_t>> pd_path;    // pure-deletion paths (local ids), indexed by input problem (sparse)
     std::vector<uint32_t> pd_problem;              // list of problems with a pd path
+    std::vector<HostAlignment> host_aln;           // alignments made on the host (greedy route), indexed by input problem (sparse)
+    std::vector<uint32_t> host_problem;
     // per PO-POA problem
     std::vector<ClProbDesc> desc;
     std::vector<uint8_t> lin_rows, lin_waves, lin_swap;  // chain-kernel geometry per PO-POA problem (0 = general kernel)
@@ -446,6 +614,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     pl->num_pw.assign(n, 0);
     pl->po_index.assign(n, -1);
     pl->pd_path.resize(n);
+    pl->host_aln.resize(n);
     for (int s = 0; s < 2; ++s) {
         pl->node_off[s].assign(batch->side[s].node_off, batch->side[s].node_off + n + 1);
         if (batch->side[s].back_translation) {
@@ -484,8 +653,19 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             pl->pd_problem.push_back((uint32_t)k);
             continue;
         }
+        if (route == CL_ROUTE_GREEDY_PARTIAL) {
+            if (!g[0].next_off || !g[1].next_off) {   // the greedy search visits next() lists in the reference's order
+                set_error(ctx, "problem %llu: the greedy route needs the next lists of the subgraphs", (unsigned long long)k);
+                plan_free(pl);
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+            rc = greedy_partial_alignment(g[0], g[1], pl->host_aln[k]);
+            if (rc) { set_error(ctx, "problem %llu: greedy partial alignment failed", (unsigned long long)k); plan_free(pl); return rc; }
+            pl->host_problem.push_back((uint32_t)k);
+            continue;
+        }
         if (route != CL_ROUTE_PO_POA) {
-            set_error(ctx, "problem %llu (%llu x %llu nodes) is routed to heuristic %d (deletion-WFA / WFA / greedy), which this build does not provide",
+            set_error(ctx, "problem %llu (%llu x %llu nodes) is routed to heuristic %d (deletion-WFA / WFA), which this build does not provide",
                       (unsigned long long)k, (unsigned long long)g[0].n, (unsigned long long)g[1].n, route);
             plan_free(pl);
             return CL_ERR_UNSUPPORTED_ROUTE;
@@ -793,6 +973,7 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
         total += len[i];
     }
     for (uint32_t k : pl->pd_problem) total += pl->pd_path[k].size();
+    for (uint32_t k : pl->host_problem) total += pl->host_aln[k].size();
     out->n_problems = n;
     out->aln_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
     out->pairs = (uint64_t*)malloc((total ? total : 1) * 2 * sizeof(uint64_t));
@@ -825,6 +1006,16 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
                 ++cur;
             }
             out->score[k] = score[i];
+        } else if (pl->route[k] == CL_ROUTE_GREEDY_PARTIAL) {
+            for (const auto& pr : pl->host_aln[k]) {
+                uint64_t a = pr.first, b = pr.second;
+                if (a != CL_GAP && pl->has_back[0]) a = pl->back[0][nb1 + a];
+                if (b != CL_GAP && pl->has_back[1]) b = pl->back[1][nb2 + b];
+                out->pairs[2 * cur] = a;
+                out->pairs[2 * cur + 1] = b;
+                ++cur;
+            }
+            out->score[k] = 0;   // do_alignment does not ask greedy_partial_alignment for a score (stitcher.hpp:343-345)
         } else {
             const std::vector<uint32_t>& path = pl->pd_path[k];
             const bool first = pl->route[k] == CL_ROUTE_PURE_DELETION_1;

@@ -314,6 +314,189 @@ done:
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
+/* greedy_partial_alignment (alignment.hpp:1212-1611): the longest exact-match paths grown from the sources  */
+/* and from the sinks, joined by a double deletion along shortest paths; when the two match paths overlap or */
+/* cannot reach each other they are trimmed (bisection on the total trim) until they can.                    */
+
+/* shortest_path between node sets (shortest_path.hpp:32-100); path_out holds n entries; returns its length */
+static uint64_t sp_sets(const clo_graph* g, const adj_t* nx, const uint32_t* order, const uint64_t* from, uint64_t n_from,
+                        const uint64_t* to, uint64_t n_to, uint64_t* dp, uint64_t* path_out) {
+    const uint64_t INF = (uint64_t)INT64_MAX;
+    for (uint64_t v = 0; v < g->n; ++v) dp[v] = INF;
+    for (uint64_t a = 0; a < n_from; ++a) dp[from[a]] = 0;
+    for (uint64_t t = 0; t < g->n; ++t) {
+        uint32_t v = order[t];
+        uint64_t thru = dp[v] + 1;
+        for (uint64_t e = nx->off[v]; e < nx->off[v + 1]; ++e)
+            if (thru < dp[nx->idx[e]]) dp[nx->idx[e]] = thru;
+    }
+    uint64_t best = UINT64_MAX;
+    for (uint64_t b = 0; b < n_to; ++b)
+        if (dp[to[b]] != INF && (best == UINT64_MAX || dp[to[b]] < dp[best])) best = to[b];
+    if (best == UINT64_MAX) return 0;
+    uint64_t np = 0, cur = best;
+    path_out[np++] = cur;
+    while (dp[cur] != 0) {
+        uint64_t nxt = UINT64_MAX;
+        for (uint64_t e = g->prev_off[cur]; e < g->prev_off[cur + 1]; ++e)
+            if (dp[g->prev_idx[e]] + 1 == dp[cur]) { nxt = g->prev_idx[e]; break; }
+        if (nxt == UINT64_MAX) break;
+        cur = nxt;
+        path_out[np++] = cur;
+    }
+    for (uint64_t a = 0, b = np; a + 1 < b; ++a) { --b; uint64_t t0 = path_out[a]; path_out[a] = path_out[b]; path_out[b] = t0; }
+    return np;
+}
+
+/* one direction of the greedy match search (alignment.hpp:1245-1312): DFS over label-matching node pairs; the deepest
+ * pair met first is the end of the path.  aln_out gets (n1, n2) pairs in the order the reference leaves them. */
+static uint64_t greedy_direction(const clo_graph* g1, const clo_graph* g2, const adj_t* nx1, const adj_t* nx2, int forward,
+                                 int64_t* back /* [n1*n2], -2 = unvisited */, uint64_t* stack /* [3*n1*n2 bound] */, uint64_t* aln_out) {
+    const uint64_t n2 = g2->n;
+    for (uint64_t i = 0; i < g1->n * n2; ++i) back[i] = -2;
+    uint64_t sp = 0, max_len = 0;
+    int64_t path_end = -1;
+    const uint32_t* ends1 = forward ? g1->src : g1->snk;
+    const uint32_t* ends2 = forward ? g2->src : g2->snk;
+    const uint64_t ne1 = forward ? g1->n_src : g1->n_snk, ne2 = forward ? g2->n_src : g2->n_snk;
+    for (uint64_t a = 0; a < ne1; ++a)
+        for (uint64_t b = 0; b < ne2; ++b)
+            if (g1->label[ends1[a]] == g2->label[ends2[b]]) {
+                stack[3 * sp] = ends1[a]; stack[3 * sp + 1] = ends2[b]; stack[3 * sp + 2] = 1; ++sp;
+                back[(uint64_t)ends1[a] * n2 + ends2[b]] = -1;
+            }
+    while (sp) {
+        --sp;
+        const uint64_t v1 = stack[3 * sp], v2 = stack[3 * sp + 1], len = stack[3 * sp + 2];
+        if (len > max_len) { max_len = len; path_end = (int64_t)(v1 * n2 + v2); }
+        const uint64_t* o1 = forward ? nx1->off : g1->prev_off;
+        const uint32_t* i1 = forward ? nx1->idx : g1->prev_idx;
+        const uint64_t* o2 = forward ? nx2->off : g2->prev_off;
+        const uint32_t* i2 = forward ? nx2->idx : g2->prev_idx;
+        for (uint64_t e1 = o1[v1]; e1 < o1[v1 + 1]; ++e1)
+            for (uint64_t e2 = o2[v2]; e2 < o2[v2 + 1]; ++e2) {
+                const uint64_t w1 = i1[e1], w2 = i2[e2];
+                if (g1->label[w1] == g2->label[w2] && back[w1 * n2 + w2] == -2) {
+                    back[w1 * n2 + w2] = (int64_t)(v1 * n2 + v2);
+                    stack[3 * sp] = w1; stack[3 * sp + 1] = w2; stack[3 * sp + 2] = len + 1; ++sp;
+                }
+            }
+    }
+    uint64_t n = 0;
+    while (path_end != -1) {
+        aln_out[2 * n] = (uint64_t)path_end / n2; aln_out[2 * n + 1] = (uint64_t)path_end % n2; ++n;
+        path_end = back[path_end];
+    }
+    if (forward)
+        for (uint64_t a = 0, b = n; a + 1 < b; ++a) {
+            --b;
+            uint64_t t0 = aln_out[2 * a], t1 = aln_out[2 * a + 1];
+            aln_out[2 * a] = aln_out[2 * b]; aln_out[2 * a + 1] = aln_out[2 * b + 1];
+            aln_out[2 * b] = t0; aln_out[2 * b + 1] = t1;
+        }
+    return n;
+}
+
+int clo_greedy_partial_alignment(const clo_graph* g1, const clo_graph* g2, uint64_t* pairs_out, uint64_t* n_pairs_out) {
+    *n_pairs_out = 0;
+    const uint64_t n1 = g1->n, n2 = g2->n;
+    adj_t nx1 = {0, 0, 0}, nx2 = {0, 0, 0};
+    int rc = get_next(g1, &nx1);
+    if (!rc) rc = get_next(g2, &nx2);
+    if (rc) return rc;
+    uint32_t* ord1 = topological_order(g1, &nx1);
+    uint32_t* ord2 = topological_order(g2, &nx2);
+    int64_t* back = (int64_t*)malloc((n1 * n2 ? n1 * n2 : 1) * sizeof(int64_t));
+    uint64_t* stack = (uint64_t*)malloc((n1 * n2 ? n1 * n2 : 1) * 3 * sizeof(uint64_t));
+    uint64_t* fwd = (uint64_t*)malloc((n1 + n2 + 1) * 2 * sizeof(uint64_t));
+    uint64_t* rev = (uint64_t*)malloc((n1 + n2 + 1) * 2 * sizeof(uint64_t));
+    uint64_t* dp = (uint64_t*)malloc(((n1 > n2 ? n1 : n2) + 1) * sizeof(uint64_t));
+    uint64_t* p1 = (uint64_t*)malloc((n1 + 1) * sizeof(uint64_t));
+    uint64_t* p2 = (uint64_t*)malloc((n2 + 1) * sizeof(uint64_t));
+    uint64_t* tmp = (uint64_t*)malloc(((n1 > n2 ? n1 : n2) + 1) * sizeof(uint64_t));
+    uint64_t *s1 = (uint64_t*)malloc((g1->n_src + 1) * 8), *s2 = (uint64_t*)malloc((g2->n_src + 1) * 8);
+    uint64_t *k1 = (uint64_t*)malloc((g1->n_snk + 1) * 8), *k2 = (uint64_t*)malloc((g2->n_snk + 1) * 8);
+    if (!ord1 || !ord2 || !back || !stack || !fwd || !rev || !dp || !p1 || !p2 || !tmp || !s1 || !s2 || !k1 || !k2) { rc = CL_ERR_OUT_OF_MEMORY; goto done; }
+    for (uint64_t a = 0; a < g1->n_src; ++a) s1[a] = g1->src[a];
+    for (uint64_t a = 0; a < g2->n_src; ++a) s2[a] = g2->src[a];
+    for (uint64_t a = 0; a < g1->n_snk; ++a) k1[a] = g1->snk[a];
+    for (uint64_t a = 0; a < g2->n_snk; ++a) k2[a] = g2->snk[a];
+    {
+        const uint64_t nf = greedy_direction(g1, g2, &nx1, &nx2, 1, back, stack, fwd);
+        const uint64_t nr = greedy_direction(g1, g2, &nx1, &nx2, 0, back, stack, rev);
+        uint64_t left_trim = 0, right_trim = 0, np1 = 0, np2 = 0;
+        int found = 0;
+        if (nf == 0 || nr == 0 || (fwd[2 * (nf - 1)] != rev[0] && fwd[2 * (nf - 1) + 1] != rev[1])) {   /* :1335-1337 */
+            uint64_t a1 = nf ? fwd[2 * (nf - 1)] : 0, b1 = nr ? rev[0] : 0;
+            const uint64_t* from1 = nf ? &a1 : s1; const uint64_t nfrom1 = nf ? 1 : g1->n_src;
+            const uint64_t* to1 = nr ? &b1 : k1; const uint64_t nto1 = nr ? 1 : g1->n_snk;
+            if (nfrom1 && nto1) np1 = sp_sets(g1, &nx1, ord1, from1, nfrom1, to1, nto1, dp, p1);
+            if (np1) {
+                uint64_t a2 = nf ? fwd[2 * (nf - 1) + 1] : 0, b2 = nr ? rev[1] : 0;
+                const uint64_t* from2 = nf ? &a2 : s2; const uint64_t nfrom2 = nf ? 1 : g2->n_src;
+                const uint64_t* to2 = nr ? &b2 : k2; const uint64_t nto2 = nr ? 1 : g2->n_snk;
+                if (nfrom2 && nto2) np2 = sp_sets(g2, &nx2, ord2, from2, nfrom2, to2, nto2, dp, p2);
+                if (np2) {
+                    found = 1;
+                    if (nf) { memmove(p1, p1 + 1, (np1 - 1) * 8); --np1; memmove(p2, p2 + 1, (np2 - 1) * 8); --np2; }
+                    if (nr) { --np1; --np2; }
+                }
+            }
+        }
+        if (!found) {
+            /* bisect on the total trim (:1515-1546); reachability == a non-empty shortest path (what both the direct test
+             * and the distance oracle of :1477-1497 decide) */
+            int64_t lo = 1, hi = (int64_t)(nf + nr);
+            while (lo <= hi) {
+                const int64_t total = (lo + hi) / 2;
+                int success = 0;
+                const uint64_t lmin = total > (int64_t)nr ? (uint64_t)(total - (int64_t)nr) : 0;
+                const uint64_t lmax = (uint64_t)total < nf ? (uint64_t)total : nf;
+                for (uint64_t l = lmin; l <= lmax && !success; ++l) {
+                    const uint64_t r = (uint64_t)total - l;
+                    /* test_reachability(l, r), :1435-1511 */
+                    const int left_all = l == nf, right_all = r == nr;
+                    const int allow_equal = left_all || right_all;
+                    const uint64_t nl1 = left_all ? g1->n_src : 1, nl2 = left_all ? g2->n_src : 1;
+                    const uint64_t nr1 = right_all ? g1->n_snk : 1, nr2 = right_all ? g2->n_snk : 1;
+                    for (uint64_t a = 0; a < nl1 && !success; ++a)
+                        for (uint64_t b = 0; b < nl2 && !success; ++b)
+                            for (uint64_t c = 0; c < nr1 && !success; ++c)
+                                for (uint64_t d = 0; d < nr2 && !success; ++d) {
+                                    const uint64_t L1 = left_all ? s1[a] : fwd[2 * (nf - 1 - l)], L2 = left_all ? s2[b] : fwd[2 * (nf - 1 - l) + 1];
+                                    const uint64_t R1 = right_all ? k1[c] : rev[2 * r], R2 = right_all ? k2[d] : rev[2 * r + 1];
+                                    if (!allow_equal && (L1 == R1 || L2 == R2)) continue;
+                                    if (sp_sets(g1, &nx1, ord1, &L1, 1, &R1, 1, dp, tmp) && sp_sets(g2, &nx2, ord2, &L2, 1, &R2, 1, dp, tmp)) success = 1;
+                                }
+                    if (success) { left_trim = l; right_trim = r; }
+                }
+                if (success) hi = total - 1;
+                else lo = total + 1;
+            }
+            uint64_t a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+            const int left_all = left_trim == nf, right_all = right_trim == nr;
+            if (!left_all) { a1 = fwd[2 * (nf - left_trim - 1)]; a2 = fwd[2 * (nf - left_trim - 1) + 1]; }
+            if (!right_all) { b1 = rev[2 * right_trim]; b2 = rev[2 * right_trim + 1]; }
+            np1 = sp_sets(g1, &nx1, ord1, left_all ? s1 : &a1, left_all ? g1->n_src : 1, right_all ? k1 : &b1, right_all ? g1->n_snk : 1, dp, p1);
+            np2 = sp_sets(g2, &nx2, ord2, left_all ? s2 : &a2, left_all ? g2->n_src : 1, right_all ? k2 : &b2, right_all ? g2->n_snk : 1, dp, p2);
+            if (!left_all) { if (np1) { memmove(p1, p1 + 1, (np1 - 1) * 8); --np1; } if (np2) { memmove(p2, p2 + 1, (np2 - 1) * 8); --np2; } }
+            if (!right_all) { if (np1) --np1; if (np2) --np2; }
+        }
+        uint64_t np = 0;
+        for (uint64_t i = 0; i + left_trim < nf; ++i) { pairs_out[2 * np] = fwd[2 * i]; pairs_out[2 * np + 1] = fwd[2 * i + 1]; ++np; }
+        for (uint64_t i = 0; i < np1; ++i) { pairs_out[2 * np] = p1[i]; pairs_out[2 * np + 1] = CL_GAP; ++np; }
+        for (uint64_t i = 0; i < np2; ++i) { pairs_out[2 * np] = CL_GAP; pairs_out[2 * np + 1] = p2[i]; ++np; }
+        for (uint64_t i = right_trim; i < nr; ++i) { pairs_out[2 * np] = rev[2 * i]; pairs_out[2 * np + 1] = rev[2 * i + 1]; ++np; }
+        *n_pairs_out = np;
+    }
+done:
+    free(ord1); free(ord2); free(back); free(stack); free(fwd); free(rev); free(dp); free(p1); free(p2); free(tmp);
+    free(s1); free(s2); free(k1); free(k2);
+    free_adj(&nx1); free_adj(&nx2);
+    return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
 /* pure_deletion_alignment (alignment.hpp:1178-1210) over shortest_path (shortest_path.hpp:32-100)       */
 
 int clo_pure_deletion(const clo_graph* g, int npw, const cl_align_params* prm, uint64_t* pairs_out,
@@ -522,6 +705,9 @@ int clo_stitch_batch(const cl_stitch_batch* batch, const cl_stitch_params* sp, c
             break;
         case CL_ROUTE_PO_POA:
             rc = clo_po_poa(&g1, &g2, npw, &sp->alignment_params, pairs, &np, &out->score[k]);
+            break;
+        case CL_ROUTE_GREEDY_PARTIAL:
+            rc = clo_greedy_partial_alignment(&g1, &g2, pairs, &np);   /* do_alignment does not ask for a score */
             break;
         default:
             rc = CL_ERR_UNSUPPORTED_ROUTE;

@@ -204,6 +204,28 @@ def main():
         np.savez_compressed(os.path.join(HERE, "align4_30k_merge2.npz"), **out)
     else:
         print("skip stitch-level fixtures (no dump at %s)" % path)
+    # 8. greedy_partial_alignment (the route of unalignable gaps above max_trivial_size): stretches of two related sequences
+    #    (identical, mutated, shifted, with an indel, unrelated) and random DAG pairs, all flagged only_deletion_alns
+    rng = np.random.default_rng(5)
+    L = 6000
+    a = rng.integers(0, 4, L).astype(np.uint8)
+    b = a.copy()
+    idx = rng.choice(L, 60, replace=False)
+    b[idx] = (b[idx] + rng.integers(1, 4, 60)) % 4
+    b = np.concatenate([b[:2000], b[2100:4000], rng.integers(0, 4, 150).astype(np.uint8), b[4000:]])
+    rows = np.array([(0, 200, 0, 200), (300, 300, 300, 310), (1000, 400, 1000, 380), (1900, 400, 1900, 300), (3000, 500, 2900, 500),
+                     (3900, 400, 3800, 550), (5000, 400, 5050, 400), (100, 200, 100, 200), (0, 180, 0, 180), (700, 250, 700, 250),
+                     (4500, 1000, 4550, 1000), (50, 300, 3000, 300), (2000, 1, 2000, 400)], np.int64)
+    sb = synth.batch_from_intervals(a, b, rows, np.ones(len(rows), np.uint8))
+    res, _ = po.ref_stitch_batch(sb)
+    out = {"seq1": a, "seq2": b, "rows": rows, "linear.aln_off": res.aln_off, "linear.pairs": res.pairs,
+           "dag_cases": np.array([(11, 300, 40), (13, 400, 30)], np.int64)}
+    for seed, max_n, cnt in out["dag_cases"]:
+        db = synth.random_dag_batch(int(cnt), seed=int(seed), max_n=int(max_n))
+        db.only_deletion_alns[:] = 1
+        res, _ = po.ref_stitch_batch(db)
+        out["dag%d.aln_off" % seed], out["dag%d.pairs" % seed] = res.aln_off, res.pairs
+    np.savez_compressed(os.path.join(HERE, "popoa_greedy.npz"), **out)
     # 7. despecify_indel_breakpoints: random anchor chains -> the reference's kept set and updated gap fields
     sys.path.insert(0, os.path.dirname(HERE))
     from tests.test_despecify import random_case, ref_despecify

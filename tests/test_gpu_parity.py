@@ -78,8 +78,6 @@ def test_known_answers(gpu_ctx):
 @pytest.mark.parametrize("seed,max_n,count", [(1, 8, 500), (2, 40, 400), (3, 100, 120), (4, 330, 40)])
 def test_random_dags_vs_oracle(gpu_ctx, seed, max_n, count):
     b = synth.random_dag_batch(count, seed=seed, max_n=max_n)
-    if max_n > 170:  # between-segment problems above max_trivial_size route to heuristics; not the subject here
-        b.only_deletion_alns[:] = 0
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
     for npw in (1, 2, 3):
         f = np.full(b.n_problems, npw, np.uint8)
@@ -134,8 +132,22 @@ def test_tie_heavy_chains(gpu_ctx):
         assert got.same_as(po.oracle_stitch_batch(b, tp, force_num_pw=f)) is None
 
 
+def test_greedy_route_vs_oracle(gpu_ctx):
+    """gaps that look unalignable (only_deletion_alns and above max_trivial_size) take greedy_partial_alignment on the host
+    (alignment.hpp:1212-1611), next to the device problems of the same batch"""
+    z = np.load(os.path.join(H.GOLDEN, "popoa_greedy.npz"))
+    sb = synth.batch_from_intervals(z["seq1"], z["seq2"], z["rows"], np.ones(len(z["rows"]), np.uint8))
+    got = gpu_ctx.stitch_batch_align(sb)
+    assert (got.route[:-1] == 6).all()
+    assert np.array_equal(got.aln_off, z["linear.aln_off"]) and np.array_equal(got.pairs, z["linear.pairs"])
+    for seed, max_n, cnt in z["dag_cases"]:
+        b = synth.random_dag_batch(int(cnt), seed=int(seed), max_n=int(max_n))
+        b.only_deletion_alns[:] = 1
+        assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+
+
 def test_error_reporting(gpu_ctx):
-    lb = synth.linear_batch([(300, 200)], seed=1)
+    lb = synth.linear_batch([(200, 2100)], seed=1)   # lopsided unalignable gap -> deletion-WFA, not provided
     lb.only_deletion_alns[:] = 1
     with pytest.raises(capi.ClError) as e:
         gpu_ctx.stitch_batch_align(lb)

@@ -101,10 +101,31 @@ def test_empty_and_degenerate_problems():
 
 
 def test_unsupported_route_is_reported():
-    lb = synth.linear_batch([(300, 200)], seed=1)
-    lb.only_deletion_alns[:] = 1  # 60k cells > max_trivial_size between segments -> heuristic route
+    lb = synth.linear_batch([(200, 2100)], seed=1)
+    lb.only_deletion_alns[:] = 1  # 422k cells > max_trivial_size and 8x lopsided -> deletion-WFA, which is not restated
     with pytest.raises(RuntimeError):
         po.oracle_stitch_batch(lb)
+
+
+def _greedy_case():
+    """between-segment gaps above max_trivial_size: stretches of two related sequences (exact, mutated, shifted, unrelated)"""
+    z = np.load(os.path.join(H.GOLDEN, "popoa_greedy.npz"))
+    sb = synth.batch_from_intervals(z["seq1"], z["seq2"], z["rows"], np.ones(len(z["rows"]), np.uint8))
+    return z, sb
+
+
+def test_greedy_partial_alignment_matches_golden():
+    """greedy_partial_alignment (alignment.hpp:1212-1611), the route of unalignable gaps: chains and random DAG pairs"""
+    z, sb = _greedy_case()
+    got = po.oracle_stitch_batch(sb)
+    assert (got.route[:-1] == 6).all()
+    assert np.array_equal(got.aln_off, z["linear.aln_off"]) and np.array_equal(got.pairs, z["linear.pairs"])
+    for seed, max_n, cnt in z["dag_cases"]:
+        b = synth.random_dag_batch(int(cnt), seed=int(seed), max_n=int(max_n))
+        b.only_deletion_alns[:] = 1
+        got = po.oracle_stitch_batch(b)
+        assert (got.route == 6).sum() >= 5
+        assert np.array_equal(got.aln_off, z["dag%d.aln_off" % seed]) and np.array_equal(got.pairs, z["dag%d.pairs" % seed])
 
 
 @pytest.mark.ref
