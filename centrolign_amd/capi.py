@@ -192,6 +192,25 @@ def despecify_indel_breakpoints(score, gap_before, gap_score_before, gap_after, 
     return keep[:n].astype(bool), gb[:k], gsb[:k], ga[:k], gsa[:k]
 
 
+def host_route_align(batch, k, params=None):
+    """cl_host_route_align: one subproblem by the host route Stitcher::do_alignment takes for it (pure deletion, greedy,
+    deletion-WFA, pruned WFA); no device needed.  Returns (route, (n, 2) uint64 pairs)"""
+    lib = load_library()
+    params = params or default_stitch_params()
+    bc = batch.as_c()
+    route, out, n = C.c_int(-100), C.c_void_p(), C.c_uint64(0)
+    lib.cl_host_route_align.restype = C.c_int
+    lib.cl_host_route_align.argtypes = [C.POINTER(StitchBatchC), C.c_uint64, C.POINTER(StitchParams), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    rc = lib.cl_host_route_align(C.byref(bc), int(k), C.byref(params), C.byref(route), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise ClError(rc, "route %d" % route.value)
+    cnt = int(n.value)
+    pairs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(cnt, 1) * 2,))[:2 * cnt].copy().reshape(cnt, 2)
+    C.CDLL(None).free(out)
+    return int(route.value), pairs
+
+
 def partition_anchors(graph1, graph2, chain, score_scale=1.0, score_boundaries=False, use_annotated_score=False, **overrides):
     """Partitioner::partition_anchors (include/centrolign/partitioner.hpp:72-213), host only.  `chain` is the dict that
     Context.anchor_chain returns (walk_off, walk1, walk2, count1, count2, full_length, chain[:,0] = match set, score).
@@ -688,7 +707,7 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
     "cl_anchor_chain", "cl_anchor_chain_result_free",
-    "cl_partition_params_default", "cl_partition_anchors",
+    "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
 ]

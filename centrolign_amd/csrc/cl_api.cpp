@@ -25,6 +25,7 @@
 #include "cl_internal.hpp"
 #include "popoa_device.h"
 #include "stitch_host.hpp"
+#include "wfa_host.hpp"
 
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
@@ -432,6 +433,57 @@ int greedy_partial_alignment(const GraphView& gv1, const GraphView& gv2, HostAli
     return CL_OK;
 }
 
+// ---- the wavefront heuristics of do_alignment (stitcher.hpp:304-339), wfa_host.hpp
+bool wfa_side(const GraphView& g, clwfa::Side& out) {
+    if (!g.next_off) return false;   // the wavefronts expand next() lists in the reference's order
+    out.n = g.n;
+    out.label = g.label;
+    out.next.assign(g.n, {});
+    out.prev.assign(g.n, {});
+    for (uint64_t v = 0; v < g.n; ++v) {
+        out.next[v].assign(g.next_idx + g.next_off[v], g.next_idx + g.next_off[v + 1]);
+        out.prev[v].assign(g.prev_idx + g.prev_off[v], g.prev_idx + g.prev_off[v + 1]);
+    }
+    out.sources.assign(g.src, g.src + g.n_src);
+    out.sinks.assign(g.snk, g.snk + g.n_snk);
+    NextLists nx;
+    nx.build(g);
+    std::vector<uint32_t> order, st, indeg;
+    if (!topological_order(g, nx, order, st, indeg)) return false;
+    out.order.assign(order.begin(), order.end());
+    return true;
+}
+
+// every route of do_alignment that the reference runs on the host: pure deletion, greedy, deletion-WFA, pruned WFA
+int host_route_alignment(int route, const GraphView& g1, const GraphView& g2, int npw, const cl_stitch_params& sp, HostAlignment& out) {
+    out.clear();
+    if (route == CL_ROUTE_PURE_DELETION_1 || route == CL_ROUTE_PURE_DELETION_2) {
+        std::vector<uint32_t> path;
+        const int rc = pure_deletion(route == CL_ROUTE_PURE_DELETION_1 ? g1 : g2, path);
+        if (rc) return rc;
+        for (uint32_t v : path) out.push_back(route == CL_ROUTE_PURE_DELETION_1 ? std::make_pair((uint64_t)v, (uint64_t)CL_GAP) : std::make_pair((uint64_t)CL_GAP, (uint64_t)v));
+        return CL_OK;
+    }
+    if (route == CL_ROUTE_GREEDY_PARTIAL) {
+        if (!g1.next_off || !g2.next_off) return CL_ERR_INVALID_ARGUMENT;
+        return greedy_partial_alignment(g1, g2, out);
+    }
+    if (route != CL_ROUTE_DELETION_WFA_1 && route != CL_ROUTE_DELETION_WFA_2 && route != CL_ROUTE_PWFA) return CL_ERR_UNSUPPORTED_ROUTE;
+    clwfa::Side s1, s2;
+    if (!wfa_side(g1, s1) || !wfa_side(g2, s2)) return (g1.next_off && g2.next_off) ? CL_ERR_CYCLIC_GRAPH : CL_ERR_INVALID_ARGUMENT;
+    const cl_align_params& ap = sp.alignment_params;
+    const clwfa::WfaParams wp = clwfa::to_wfa_params(ap.match, ap.mismatch, ap.gap_open, ap.gap_extend, npw);   // the truncated parameters of subalign
+    clwfa::Alignment aln;
+    if (route == CL_ROUTE_PWFA) aln = clwfa::pwfa_po_poa(s1, s2, wp, (int64_t)(2 * sp.wfa_pruning_dist));
+    else if (route == CL_ROUTE_DELETION_WFA_1) aln = clwfa::deletion_wfa_po_poa(s1, s2, wp);
+    else {
+        aln = clwfa::deletion_wfa_po_poa(s2, s1, wp);
+        for (auto& pr : aln) std::swap(pr.first, pr.second);   // swap_graphs, src/alignment.cpp:41-45
+    }
+    out.assign(aln.begin(), aln.end());
+    return CL_OK;
+}
+
 int64_t pure_deletion_score(size_t path_len, int npw, const cl_align_params& p) {
     if (path_len == 0) return 0;
     // alignment.hpp:1202-1205 evaluates -open - extend in uint32_t before widening; reproduced literally
@@ -653,22 +705,16 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             pl->pd_problem.push_back((uint32_t)k);
             continue;
         }
-        if (route == CL_ROUTE_GREEDY_PARTIAL) {
-            if (!g[0].next_off || !g[1].next_off) {   // the greedy search visits next() lists in the reference's order
-                set_error(ctx, "problem %llu: the greedy route needs the next lists of the subgraphs", (unsigned long long)k);
+        if (route != CL_ROUTE_PO_POA) {   // greedy / deletion-WFA / pruned WFA: host algorithms (in the reference too)
+            rc = host_route_alignment(route, g[0], g[1], npw, *params, pl->host_aln[k]);
+            if (rc) {
+                set_error(ctx, rc == CL_ERR_INVALID_ARGUMENT ? "problem %llu: route %d needs the next lists of the subgraphs" : "problem %llu: host route %d failed",
+                          (unsigned long long)k, route);
                 plan_free(pl);
-                return CL_ERR_INVALID_ARGUMENT;
+                return rc;
             }
-            rc = greedy_partial_alignment(g[0], g[1], pl->host_aln[k]);
-            if (rc) { set_error(ctx, "problem %llu: greedy partial alignment failed", (unsigned long long)k); plan_free(pl); return rc; }
             pl->host_problem.push_back((uint32_t)k);
             continue;
-        }
-        if (route != CL_ROUTE_PO_POA) {
-            set_error(ctx, "problem %llu (%llu x %llu nodes) is routed to heuristic %d (deletion-WFA / WFA), which this build does not provide",
-                      (unsigned long long)k, (unsigned long long)g[0].n, (unsigned long long)g[1].n, route);
-            plan_free(pl);
-            return CL_ERR_UNSUPPORTED_ROUTE;
         }
         uint64_t cells = (g[0].n + 1) * (g[1].n + 1);
         if (cells >= (1ull << 31) || g[0].n_src == 0 || g[1].n_src == 0 || g[0].n_snk == 0 || g[1].n_snk == 0) {
@@ -1006,7 +1052,7 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
                 ++cur;
             }
             out->score[k] = score[i];
-        } else if (pl->route[k] == CL_ROUTE_GREEDY_PARTIAL) {
+        } else if (pl->route[k] != CL_ROUTE_PURE_DELETION_1 && pl->route[k] != CL_ROUTE_PURE_DELETION_2) {
             for (const auto& pr : pl->host_aln[k]) {
                 uint64_t a = pr.first, b = pr.second;
                 if (a != CL_GAP && pl->has_back[0]) a = pl->back[0][nb1 + a];
@@ -1015,7 +1061,7 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
                 out->pairs[2 * cur + 1] = b;
                 ++cur;
             }
-            out->score[k] = 0;   // do_alignment does not ask greedy_partial_alignment for a score (stitcher.hpp:343-345)
+            out->score[k] = 0;   // do_alignment does not ask the heuristics for a score (stitcher.hpp:304-345)
         } else {
             const std::vector<uint32_t>& path = pl->pd_path[k];
             const bool first = pl->route[k] == CL_ROUTE_PURE_DELETION_1;
@@ -1048,6 +1094,37 @@ static int run_whole(cl_context* ctx, const cl_stitch_batch* batch, const cl_sti
     if (!rc) rc = cl_stitch_plan_collect(ctx, pl, out);
     cl_stitch_plan_destroy(ctx, pl);
     return rc;
+}
+
+// host-only: the alignment of ONE subproblem by the route do_alignment takes for it, when that route is a host algorithm
+int cl_host_route_align(const cl_stitch_batch* batch, uint64_t k, const cl_stitch_params* sp, int* route_out, uint64_t** pairs_out,
+                        uint64_t* n_pairs_out) {
+    if (!batch || !sp || !pairs_out || !n_pairs_out || k >= batch->n_problems) return CL_ERR_INVALID_ARGUMENT;
+    *pairs_out = nullptr;
+    *n_pairs_out = 0;
+    const GraphView g1 = view(batch->side[0], k), g2 = view(batch->side[1], k);
+    const int npw = choose_num_pw(g1.n, g2.n, sp->alignment_params);
+    if (npw < 1 || npw > 3) return npw < 0 ? npw : CL_ERR_INVALID_ARGUMENT;
+    const int route = route_problem(g1, g2, batch->only_deletion_alns && batch->only_deletion_alns[k], *sp);
+    if (route_out) *route_out = route;
+    if (route < 0) return route;
+    if (route == CL_ROUTE_PO_POA) return CL_ERR_UNSUPPORTED_ROUTE;   // the device's
+    HostAlignment aln;
+    const int rc = host_route_alignment(route, g1, g2, npw, *sp, aln);
+    if (rc) return rc;
+    uint64_t* out = (uint64_t*)malloc((aln.size() ? aln.size() : 1) * 2 * sizeof(uint64_t));
+    if (!out) return CL_ERR_OUT_OF_MEMORY;
+    const uint64_t nb1 = batch->side[0].node_off[k], nb2 = batch->side[1].node_off[k];
+    for (size_t i = 0; i < aln.size(); ++i) {   // translate, src/alignment.cpp:26-39
+        uint64_t a = aln[i].first, b = aln[i].second;
+        if (a != CL_GAP && batch->side[0].back_translation) a = batch->side[0].back_translation[nb1 + a];
+        if (b != CL_GAP && batch->side[1].back_translation) b = batch->side[1].back_translation[nb2 + b];
+        out[2 * i] = a;
+        out[2 * i + 1] = b;
+    }
+    *pairs_out = out;
+    *n_pairs_out = aln.size();
+    return CL_OK;
 }
 
 int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw, const cl_align_params* params,

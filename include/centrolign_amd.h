@@ -46,7 +46,7 @@ enum {
     CL_ERR_NO_DEVICE = -3,          /* no HIP device / HIP runtime failure at context creation */
     CL_ERR_HIP = -4,                /* a HIP call failed; see cl_last_error */
     CL_ERR_OUT_OF_MEMORY = -5,
-    CL_ERR_UNSUPPORTED_ROUTE = -6,  /* subproblem routed to a heuristic this build does not provide */
+    CL_ERR_UNSUPPORTED_ROUTE = -6,  /* the requested route is not available through this entry point */
     CL_ERR_CYCLIC_GRAPH = -7,       /* a subgraph is not a DAG (topological_order.hpp:56 asserts) */
     CL_ERR_UNREACHABLE_SINK = -8    /* no (source..sink) connection; the reference has UB here (alignment.hpp:76-77) */
 };
@@ -189,6 +189,14 @@ typedef struct cl_launch_info {
 } cl_launch_info;
 int cl_stitch_plan_launch_count(const cl_stitch_plan* plan);
 int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int index, cl_launch_info* info_out);
+
+/* The routes of Stitcher::do_alignment (stitcher.hpp:268-360) that are host algorithms in the reference are host algorithms
+ * here: pure deletion, greedy_partial_alignment (alignment.hpp:1212-1611), deletion_wfa_po_poa (:2036-2282), pwfa_po_poa
+ * (:2299-2338); cl_stitch_batch_align / the plan API run them at plan creation next to the device problems.  This entry runs
+ * ONE subproblem of a batch by its route without a device (CL_ERR_UNSUPPORTED_ROUTE if the route is PO-POA, the device's):
+ * pairs_out is malloc'ed, AlignedPair layout, translated through back_translation; release with free(). */
+int cl_host_route_align(const cl_stitch_batch* batch, uint64_t problem, const cl_stitch_params* params, int* route_out,
+                        uint64_t** pairs_out, uint64_t* n_pairs_out);
 
 /* --- Stitcher::stitch proper: from a partitioned anchor chain to the stitched base-level alignment ----------------
  * (include/centrolign/stitcher.hpp:34-38,104-206).  The two merge graphs are passed as flat views of BaseGraph

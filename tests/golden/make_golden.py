@@ -48,6 +48,13 @@ def result_digest(aln_off, pairs):
     return h.hexdigest()
 
 
+def host_route_cases():
+    """inputs of fixture 9 (also used by the tests to rebuild the batches): name -> (batch, StitchParams)"""
+    from tests.helpers import host_route_batches
+    seqs = host_route_batches.make_sequences()
+    return {"seq1": seqs[0], "seq2": seqs[1], "_batches": host_route_batches.build(seqs[0], seqs[1])}
+
+
 def ref_results(batch, params, with_forced=True):
     out = {}
     res, _ = po.ref_stitch_batch(batch, params)
@@ -226,6 +233,14 @@ def main():
         res, _ = po.ref_stitch_batch(db)
         out["dag%d.aln_off" % seed], out["dag%d.pairs" % seed] = res.aln_off, res.pairs
     np.savez_compressed(os.path.join(HERE, "popoa_greedy.npz"), **out)
+    # 9. the host routes of Stitcher::do_alignment (deletion-WFA "ad1/ad2", pruned WFA "w", greedy "u", pure deletion) on
+    #    stretches of two related sequences and on random DAG batches with shrunken thresholds: whole-batch reference results
+    out = host_route_cases()
+    for tag, (batch, params) in list(out["_batches"].items()):
+        res, _ = po.ref_stitch_batch(batch, params)
+        out[tag + ".aln_off"], out[tag + ".pairs"] = res.aln_off, res.pairs
+    del out["_batches"]
+    np.savez_compressed(os.path.join(HERE, "host_routes.npz"), **out)
     # 7. despecify_indel_breakpoints: random anchor chains -> the reference's kept set and updated gap fields
     sys.path.insert(0, os.path.dirname(HERE))
     from tests.test_despecify import random_case, ref_despecify

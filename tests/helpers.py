@@ -120,3 +120,43 @@ def batch_from_graphs(pairs_of_graphs, only_del=None):
 
 def as_signed_pairs(pairs):
     return [(-1 if a == capi.CL_GAP else int(a), -1 if b == capi.CL_GAP else int(b)) for a, b in pairs]
+
+
+class host_route_batches:
+    """the batches of tests/golden/host_routes.npz: every host route of Stitcher::do_alignment (stitcher.hpp:268-360)"""
+
+    @staticmethod
+    def make_sequences():
+        rng = np.random.default_rng(9)
+        a = rng.integers(0, 4, 12000).astype(np.uint8)
+        b = a.copy()
+        idx = rng.choice(len(a), 150, replace=False)
+        b[idx] = (b[idx] + rng.integers(1, 4, 150)) % 4
+        return a, b
+
+    @staticmethod
+    def build(a, b):
+        from centrolign_amd import capi, synth
+        out = {}
+        # "ad1/ad2": lopsided unalignable gaps (short side <= 1500, long side >= 2000 and >= 8x), CLI thresholds
+        rows = np.array([(100, 250, 100, 2100), (3000, 2400, 3000, 200), (500, 100, 400, 2500), (6000, 2200, 6100, 150)], np.int64)
+        out["ad_linear"] = (synth.batch_from_intervals(a, b, rows, np.ones(len(rows), np.uint8)), capi.default_stitch_params())
+        # "w": near-diagonal gaps above min_wfa_size (shrunk so that small problems take the route)
+        sp = capi.default_stitch_params()
+        sp.min_wfa_size, sp.max_wfa_size = 1000, 10 ** 9
+        rows = np.array([(100, 300, 100, 300), (1000, 500, 1000, 510), (2000, 800, 2000, 790), (4000, 200, 4000, 205),
+                         (7000, 1500, 7000, 1500), (9000, 400, 3000, 400)], np.int64)
+        out["w_linear"] = (synth.batch_from_intervals(a, b, rows, np.zeros(len(rows), np.uint8)), sp)
+        sp = capi.default_stitch_params()
+        sp.min_wfa_size, sp.max_wfa_size, sp.max_wfa_ratio = 50, 10 ** 9, 100.0
+        db = synth.random_dag_batch(60, seed=21, max_n=60)
+        db.only_deletion_alns[:] = 0
+        out["w_dags"] = (db, sp)
+        # a mixed batch: random DAG pairs flagged unalignable, thresholds shrunk so that every route occurs
+        sp = capi.default_stitch_params()
+        sp.max_trivial_size, sp.deletion_alignment_ratio = 10, 3
+        sp.deletion_alignment_short_max_size, sp.deletion_alignment_long_min_size = 100, 30
+        db = synth.random_dag_batch(300, seed=23, max_n=150)
+        db.only_deletion_alns[:] = 1
+        out["mixed_dags"] = (db, sp)
+        return out

@@ -146,12 +146,18 @@ def test_greedy_route_vs_oracle(gpu_ctx):
         assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
 
 
+def test_every_route_in_one_batch(gpu_ctx):
+    """a batch in which every route of Stitcher::do_alignment occurs (device PO-POA next to the host heuristics), against the
+    compiled reference's results for the whole batch"""
+    z = np.load(os.path.join(H.GOLDEN, "host_routes.npz"))
+    for tag, (batch, params) in H.host_route_batches.build(z["seq1"], z["seq2"]).items():
+        got = gpu_ctx.stitch_batch_align(batch, params)
+        assert np.array_equal(got.aln_off, z[tag + ".aln_off"]) and np.array_equal(got.pairs, z[tag + ".pairs"]), tag
+        if tag == "mixed_dags":
+            assert {1, 2, 3, 4, 6} <= set(np.unique(got.route).tolist())
+
+
 def test_error_reporting(gpu_ctx):
-    lb = synth.linear_batch([(200, 2100)], seed=1)   # lopsided unalignable gap -> deletion-WFA, not provided
-    lb.only_deletion_alns[:] = 1
-    with pytest.raises(capi.ClError) as e:
-        gpu_ctx.stitch_batch_align(lb)
-    assert e.value.code == -6
     bad = capi.default_stitch_params()
     bad.alignment_params.gap_open[:] = [60, 50, 2500]
     with pytest.raises(capi.ClError) as e:
