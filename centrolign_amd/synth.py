@@ -286,3 +286,48 @@ def batch_from_intervals(seq1, seq2, intervals, only_del=None):
             back_translation=pos.astype(np.uint64)))
     od = np.zeros(len(iv), np.uint8) if only_del is None else np.asarray(only_del, np.uint8)
     return StitchBatch(sides[0], sides[1], od)
+
+
+def base_graph_from_sequence(seq):
+    """capi.BaseGraph of one sequence as the reference builds a leaf subproblem: one node per base in a chain, one path over
+    them, plus the two sentinel nodes of add_sentinels (source before the first base, sink after the last; labels 5 and 6)"""
+    from . import capi
+    e = encode(seq) if isinstance(seq, str) else np.asarray(seq, np.uint8)
+    n = len(e)
+    src, snk = n, n + 1
+    label = np.concatenate([e, [5, 6]]).astype(np.uint8)
+    nxt = [[i + 1] for i in range(n - 1)] + ([[snk]] if n else []) + [[0] if n else [snk], []]
+    prv = ([[src]] if n else []) + [[i - 1] for i in range(1, n)] + [[], [n - 1] if n else [src]]
+    def csr(lists):
+        off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+        idx = np.array([v for x in lists for v in x], np.uint32)
+        return off, idx
+    no, ni = csr(nxt)
+    po_, pi = csr(prv)
+    return capi.BaseGraph(label, no, ni, po_, pi, np.array([0, n], np.uint64), np.arange(n, dtype=np.uint32), src, snk)
+
+
+def exact_matches(seq1, seq2, k=12, max_sets=None):
+    """capi.MatchSets of the shared k-mers of two sequences (one set per k-mer, every occurrence a walk): a simple stand-in
+    for the match finder, enough to drive the chaining seam in small tests"""
+    from . import capi
+    e1 = encode(seq1) if isinstance(seq1, str) else np.asarray(seq1, np.uint8)
+    e2 = encode(seq2) if isinstance(seq2, str) else np.asarray(seq2, np.uint8)
+    def index(e):
+        d = {}
+        for i in range(len(e) - k + 1):
+            d.setdefault(e[i:i + k].tobytes(), []).append(i)
+        return d
+    d1, d2 = index(e1), index(e2)
+    so1, wo1, n1, so2, wo2, n2, c1, c2, fl = [0], [0], [], [0], [0], [], [], [], []
+    for key in sorted(set(d1) & set(d2)):
+        if max_sets is not None and len(c1) >= max_sets:
+            break
+        for occ, so, wo, nd in ((d1[key], so1, wo1, n1), (d2[key], so2, wo2, n2)):
+            for i in occ:
+                nd.extend(range(i, i + k))
+                wo.append(len(nd))
+            so.append(len(wo) - 1)
+        c1.append(len(d1[key])); c2.append(len(d2[key])); fl.append(k)
+    return capi.MatchSets(set_off1=so1, walk_off1=wo1, nodes1=n1, set_off2=so2, walk_off2=wo2, nodes2=n2, count1=c1, count2=c2,
+                          full_length=fl)

@@ -116,3 +116,27 @@ def test_core_align_end_to_end_matches_reference(gpu_ctx):
         assert np.array_equal(got[k], z[k]), k
     assert np.array_equal(got["alignment"].reshape(-1), z["stitched"])
     assert len(got["walk_off"]) > 1000
+
+
+def test_core_align_small_and_degenerate_inputs(gpu_ctx):
+    """cl_core_align on tiny leaf graphs: no matches at all, a handful of matches, a chain below the segment threshold"""
+    from centrolign_amd import synth
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 4, 400).astype(np.uint8)
+    b = a.copy()
+    b[rng.choice(400, 12, replace=False)] ^= 1
+    g1, g2 = synth.base_graph_from_sequence(a), synth.base_graph_from_sequence(b[:380])
+    empty = capi.MatchSets(set_off1=[0], walk_off1=[0], nodes1=[], set_off2=[0], walk_off2=[0], nodes2=[], count1=[], count2=[], full_length=[])
+    # permissive partition thresholds so that the short chain survives
+    def tweak(ap):
+        ap.partition.minimum_segment_score = 1.0
+        ap.partition.window_length = 50.0
+    for ms in (empty, synth.exact_matches(a, b[:380], k=10)):
+        for tw in (None, tweak):
+            got = gpu_ctx.core_align(g1, g2, ms, tweak=tw)
+            aln = got["alignment"]
+            gap = np.uint64(2 ** 64 - 1)
+            # a global alignment: every base of both sequences exactly once, in order
+            assert np.array_equal(aln[aln[:, 0] != gap, 0], np.arange(400, dtype=np.uint64))
+            assert np.array_equal(aln[aln[:, 1] != gap, 1], np.arange(380, dtype=np.uint64))
+    assert len(got["walk_off"]) > 5   # the last run (matches + permissive thresholds) did anchor
