@@ -7,7 +7,10 @@
 #define CL_CHAIN_NEG (-3.402823466e+38f)  // numeric_limits<float>::lowest(), the reference's mininf (anchorer.hpp:1868)
 
 constexpr uint32_t kChainBlock = 256;     // match pairs per sequential block (one workgroup in the intra kernel)
-constexpr uint32_t kChainTile = 1024;     // predecessor records per workgroup in the inter kernel
+constexpr uint32_t kChainFarTile = 1024;  // predecessor records per workgroup of a far launch
+constexpr uint32_t kChainNearTile = 256;  // ... of a near launch, and of a far launch whose grid would not fill the chip
+constexpr uint32_t kChainFullGrid = 1024; // workgroups that fill the chip (4 per CU)
+constexpr uint32_t kChainLag = 1;         // blocks the near pass covers: far(b) reads blocks < b - kChainLag (measured: no gain from more)
 constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
 
 struct ClChainParams {

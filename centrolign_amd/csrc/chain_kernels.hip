@@ -23,6 +23,7 @@
 // Compiled with -ffp-contract=off: the candidate values must round exactly like the reference's scalar code.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "chain_device.h"
 
@@ -83,12 +84,12 @@ __device__ __forceinline__ void lds_barrier() {
 // acc index layout: [0] gap-free, [1 + pw] tree pw (pw even: shift > query, pw odd: shift < query)
 // predecessors = the records of blocks [src_block_lo, src_block_hi)
 __global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
-                                                          uint32_t src_block_lo, uint32_t src_block_hi) {
+                                                          uint32_t src_block_lo, uint32_t src_block_hi, uint32_t tile_recs) {
     const ClChainCombo cb = D.combos[blockIdx.z];
     const uint32_t rec_lo = cb.prefix[src_block_lo], rec_hi = cb.prefix[src_block_hi];
-    const uint32_t tile0 = rec_lo + blockIdx.x * kChainTile;
+    const uint32_t tile0 = rec_lo + blockIdx.x * tile_recs;
     if (tile0 >= rec_hi) return;
-    const uint32_t tile_end = min(tile0 + kChainTile, rec_hi);
+    const uint32_t tile_end = min(tile0 + tile_recs, rec_hi);
     const uint32_t mi = blockIdx.y * 256 + threadIdx.x;
     const uint32_t s = block_first + mi;
     const bool active = mi < block_count;
@@ -132,12 +133,12 @@ __global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint3
 // sparse_chain_dp (anchorer.hpp:1511-1750) has one gap-free tree per chain pair and no shift condition: a record is
 // (insertion index, offset, dp) and a query keeps ONE maximum.  Same tiling as chain_inter_kernel, a quarter of the work.
 __global__ void __launch_bounds__(256) chain_inter_sparse_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
-                                                                 uint32_t src_block_lo, uint32_t src_block_hi) {
+                                                                 uint32_t src_block_lo, uint32_t src_block_hi, uint32_t tile_recs) {
     const ClChainCombo cb = D.combos[blockIdx.z];
     const uint32_t rec_lo = cb.prefix[src_block_lo], rec_hi = cb.prefix[src_block_hi];
-    const uint32_t tile0 = rec_lo + blockIdx.x * kChainTile;
+    const uint32_t tile0 = rec_lo + blockIdx.x * tile_recs;
     if (tile0 >= rec_hi) return;
-    const uint32_t tile_end = min(tile0 + kChainTile, rec_hi);
+    const uint32_t tile_end = min(tile0 + tile_recs, rec_hi);
     const uint32_t mi = blockIdx.y * 256 + threadIdx.x;
     const uint32_t s = block_first + mi;
     const bool active = mi < block_count;
@@ -167,7 +168,11 @@ __global__ void __launch_bounds__(256) chain_inter_sparse_kernel(ClChainDevice D
 // one workgroup, kChainBlock threads: thread i owns sorted match pair block_first + i.  Pairs that start on the same
 // graph-1 node cannot precede one another (a predecessor must END before the start), so the block is walked group by
 // group: every pair of a group is finalised at once and the group's records are broadcast through LDS.
-__global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count) {
+// near_blocks > 0 (single-combination problems): the kernel first evaluates the records of the near_blocks blocks before this
+// one against its queries itself — that is the "near" launch folded into the walk, one launch per block less on the
+// sequential stream.
+__global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
+                                                                  uint32_t near_blocks) {
     const uint32_t i = threadIdx.x;
     const uint32_t s = block_first + i;
     const bool active = i < block_count;
@@ -206,6 +211,42 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
     // LDS: the records published by the current group (first kChainLdsRecs of them; the rest are re-read from HBM)
     __shared__ uint32_t s_count;
     __shared__ __attribute__((aligned(16))) int s_rec[kChainLdsRecs][12];  // ins_t, off, sigma, 7 encoded values, combo, -
+
+    if (near_blocks) {   // simple == true
+        const uint32_t bcur = block_first / kChainBlock;
+        const uint32_t rec_lo = c0.prefix[bcur - near_blocks], rec_hi = c0.prefix[bcur];
+        for (uint32_t base = rec_lo; base < rec_hi; base += kChainBlock) {
+            const uint32_t r = base + i;
+            __syncthreads();
+            if (r < rec_hi) {
+                s_rec[i][0] = (int)c0.ins_t[r];
+                s_rec[i][1] = (int)c0.off[r];
+                s_rec[i][2] = c0.sigma[r];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) s_rec[i][3 + k] = enc(c0.val[(size_t)k * c0.n_recs + r]);
+            } else {
+                s_rec[i][0] = -1;   // insertion index 0xFFFFFFFF: never a predecessor
+                s_rec[i][1] = -1;
+            }
+            __syncthreads();
+            if (has_q0)
+                for (uint32_t l = 0; l < kChainBlock; l += 4) {
+                    int4 ra[4], rb[4], rc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ra[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][0]);
+                        rb[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][4]);
+                        rc[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][8]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int v[7] = {ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w, rc[u].x, rc[u].y};
+                        accumulate(acc0, qt0, qoff0, q0, (uint32_t)ra[u].x, (uint32_t)ra[u].y, ra[u].z, v);
+                    }
+                }
+        }
+        __syncthreads();
+    }
 
     // group ids are consecutive along the sorted pairs, so the block holds every id from its first pair's to its last pair's;
     // the LDS slot of a pair's records and the record count of its (block, group) come precomputed from the host: no LDS
@@ -351,16 +392,106 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_kernel(ClChainDevice 
     }
 }
 
+// the same walk for sparse_chain_dp on a single chain pair (every pairwise merge): a pair has at most one record, a query one
+// running maximum, a record is 4 dwords
+__global__ void __launch_bounds__(kChainBlock) chain_intra_sparse_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
+                                                                         uint32_t near_blocks) {
+    const uint32_t i = threadIdx.x;
+    const uint32_t s = block_first + i;
+    const bool active = i < block_count;
+    const ClChainCombo c0 = D.combos[0];
+    uint32_t qt0 = 0, qoff0 = 0, my_group = 0xFFFFFFFFu, my_base = 0, my_total = 0, my_pos = 0, my_ins = 0, my_off = 0;
+    int acc = enc(CL_CHAIN_NEG);
+    float w = 0.f, w_init = 0.f;
+    bool has_q0 = false, has_rec = false;
+    if (active) {
+        has_q0 = c0.qt[s] != 0xFFFFFFFFu;
+        if (has_q0) { qt0 = c0.qt[s]; qoff0 = c0.qoff[s]; }
+        acc = c0.acc[(size_t)s * 7];
+        w = D.weight[s];
+        w_init = D.init[s];
+        my_group = D.group[s];
+        my_base = D.grp_base[s];
+        my_total = D.grp_total[s];
+        const uint32_t r0 = D.rec_off[s];
+        has_rec = D.rec_off[s + 1] > r0;
+        if (has_rec) { my_pos = D.rec_pos[r0]; my_ins = c0.ins_t[my_pos]; my_off = c0.off[my_pos]; }
+    }
+    __shared__ uint32_t s_count;
+    __shared__ __attribute__((aligned(16))) int s_rec[kChainBlock][4];
+    if (near_blocks) {   // the "near" launch folded in: the records of the blocks just before this one
+        const uint32_t bcur = block_first / kChainBlock;
+        const uint32_t rec_lo = c0.prefix[bcur - near_blocks], rec_hi = c0.prefix[bcur];
+        for (uint32_t base = rec_lo; base < rec_hi; base += kChainBlock) {
+            const uint32_t r = base + i;
+            __syncthreads();
+            int4 mine = make_int4(-1, -1, INT32_MIN, 0);
+            if (r < rec_hi) mine = make_int4((int)c0.ins_t[r], (int)c0.off[r], enc(c0.val[r]), 0);
+            *reinterpret_cast<int4*>(&s_rec[i][0]) = mine;
+            __syncthreads();
+            if (has_q0)
+                for (uint32_t l = 0; l < kChainBlock; l += 4) {
+                    int4 r4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r4[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][0]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = max(acc, ((uint32_t)r4[u].x <= qt0 && (uint32_t)r4[u].y < qoff0) ? r4[u].z : INT32_MIN);
+                }
+        }
+        __syncthreads();
+    }
+    const uint32_t last_group = D.group[block_first + block_count - 1];
+    uint32_t group = D.group[block_first];
+    while (true) {
+        if (active && my_group == group) {
+            // dp = max(chain starting here, best predecessor + weight) — anchorer.hpp:1640-1700
+            float best = w_init;
+            if (has_q0 && acc != enc(CL_CHAIN_NEG)) best = fmaxf(best, dec(acc) + w);
+            D.dp[s] = best;
+            if (has_rec) {
+                c0.val[my_pos] = best;
+                *reinterpret_cast<int4*>(&s_rec[my_base][0]) = make_int4((int)my_ins, (int)my_off, enc(best), 0);
+            }
+            if (my_base == 0) s_count = my_total;
+        }
+        lds_barrier();
+        const uint32_t n = s_count;
+        if (active && has_q0 && my_group > group) {
+            uint32_t l = 0;
+            for (; l + 4 <= n; l += 4) {
+                int4 r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][0]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = max(acc, ((uint32_t)r[u].x <= qt0 && (uint32_t)r[u].y < qoff0) ? r[u].z : INT32_MIN);
+            }
+            for (; l < n; ++l) {
+                const int4 r = *reinterpret_cast<const int4*>(&s_rec[l][0]);
+                acc = max(acc, ((uint32_t)r.x <= qt0 && (uint32_t)r.y < qoff0) ? r.z : INT32_MIN);
+            }
+        }
+        if (group == last_group) break;
+        ++group;
+        lds_barrier();
+    }
+    if (active) c0.acc[(size_t)s * 7] = acc;   // the traceback needs the value the query returned
+}
+
+// tile_recs (a multiple of 256): predecessor records per workgroup.  A launch lasts at least one tile, and every workgroup
+// ends with one atomic merge per query and kind: large tiles for the bulk ("far") launches, small ones for the short
+// "near" launches that sit on the sequential stream.
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
-                                 uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream) {
+                                 uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream) {
     if (max_recs == 0) return hipSuccess;
-    dim3 grid((max_recs + kChainTile - 1) / kChainTile, (block_count + 255) / 256, D.n_combos);
-    if (D.sparse) hipLaunchKernelGGL(chain_inter_sparse_kernel, grid, dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi);
-    else hipLaunchKernelGGL(chain_inter_kernel, grid, dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi);
+    const uint32_t tiles = (max_recs + tile_recs - 1) / tile_recs;
+    if (D.sparse) hipLaunchKernelGGL(chain_inter_sparse_kernel, dim3(tiles, (block_count + 255) / 256, D.n_combos), dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi, tile_recs);
+    else hipLaunchKernelGGL(chain_inter_kernel, dim3(tiles, (block_count + 255) / 256, D.n_combos), dim3(256), 0, stream, D, block_first, block_count, src_block_lo, src_block_hi, tile_recs);
     return hipGetLastError();
 }
 
-hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream) {
-    hipLaunchKernelGGL(chain_intra_kernel, dim3(1), dim3(kChainBlock), 0, stream, D, block_first, block_count);
+hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream) {
+    static const bool no_sparse_intra = getenv("CL_CHAIN_NO_SPARSE_INTRA") != nullptr;   // A/B switch for measurements
+    if (D.sparse && D.n_combos == 1 && !no_sparse_intra) hipLaunchKernelGGL(chain_intra_sparse_kernel, dim3(1), dim3(kChainBlock), 0, stream, D, block_first, block_count, near_blocks);
+    else hipLaunchKernelGGL(chain_intra_kernel, dim3(1), dim3(kChainBlock), 0, stream, D, block_first, block_count, near_blocks);
     return hipGetLastError();
 }

@@ -33,8 +33,8 @@
 #include "stitch_host.hpp"
 
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
-                                 uint32_t src_block_hi, uint32_t max_recs, hipStream_t stream);
-hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, hipStream_t stream);
+                                 uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream);
+hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream);
 
@@ -677,9 +677,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         cleanup();
         return e == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;
     };
-    // Two streams: the sequential part of block k (chain_intra_kernel, one workgroup) runs on the context's stream while
-    // the bulk of block k+1's predecessors — every block up to k-1, already final — is evaluated on an auxiliary stream;
-    // only the records of block k itself have to wait for intra(k).
+    // Two streams.  The context's stream is the sequential one: per block b a "near" launch (the records of the last kChainLag
+    // blocks, small tiles) and the one-workgroup walk of the block itself.  The bulk — every block before b - kChainLag, final
+    // once walk(b - kChainLag - 1) is done — is evaluated on an auxiliary stream ("far").  The lag gives a far launch kChainLag
+    // block times to finish before walk(b) needs it: with a lag of one the two streams handed each other a dependency every
+    // other block, and that round trip (two cross-queue event waits) set the pace.
+    static const uint32_t lag = getenv("CL_CHAIN_LAG") ? std::max(1, atoi(getenv("CL_CHAIN_LAG"))) : kChainLag;
     std::vector<hipEvent_t> ev_intra(n_blocks, nullptr), ev_far(n_blocks, nullptr);
     hipError_t he = hipEventRecord(ev0, ctx->stream);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
@@ -691,21 +694,33 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     };
     for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {
         const uint32_t first = b * kChainBlock, count = (uint32_t)std::min<uint64_t>(kChainBlock, M - first);
-        if (b >= 2) {
-            // far predecessors: blocks [0, b-1), final once intra(b-2) is done
-            he = hipStreamWaitEvent(ctx->aux[0], ev_intra[b - 2], 0);
-            if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, b - 1, max_recs(0, b - 1), ctx->aux[0]);
+        const uint32_t near_lo = b > lag ? b - lag : 0;
+        if (near_lo > 0) {
+            // far predecessors: blocks [0, near_lo), final once walk(near_lo - 1) is done
+            he = hipStreamWaitEvent(ctx->aux[0], ev_intra[near_lo - 1], 0);
+            // a launch lasts at least one tile and ends with one atomic merge per query and workgroup: small tiles while
+            // the grid does not fill the chip (latency), large ones afterwards (fewer merges)
+            const uint32_t recs = max_recs(0, near_lo);
+            uint32_t tile = kChainFarTile;   // affine: 7 atomics per query and workgroup — large tiles (measured: smaller ones lose)
+            if (sparse) {                   // sparse: one atomic per query, so small tiles are cheap
+                tile = kChainNearTile;
+                while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
+            }
+            if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, ctx->aux[0]);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
             if (he == hipSuccess) he = hipEventRecord(ev_far[b], ctx->aux[0]);
-            if (he == hipSuccess) he = hipStreamWaitEvent(ctx->stream, ev_far[b], 0);
         }
-        // near predecessors: block b-1 (on the main stream, right after intra(b-1))
-        if (he == hipSuccess && b >= 1) he = cl_chain_launch_inter(D, first, count, b - 1, b, max_recs(b - 1, b), ctx->stream);
-        if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, ctx->stream);
+        // near predecessors: blocks [near_lo, b), on the sequential stream right after walk(b - 1); with a single
+        // combination the walk kernel does it itself
+        const bool fuse_near = combos.size() == 1;
+        if (he == hipSuccess && b >= 1 && !fuse_near) he = cl_chain_launch_inter(D, first, count, near_lo, b, max_recs(near_lo, b), kChainNearTile, ctx->stream);
+        if (he == hipSuccess && ev_far[b]) he = hipStreamWaitEvent(ctx->stream, ev_far[b], 0);
+        if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, fuse_near ? b - near_lo : 0u, ctx->stream);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_intra[b], hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventRecord(ev_intra[b], ctx->stream);
     }
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
+    lap("enqueue (host)");
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->aux[0]);
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
