@@ -27,7 +27,7 @@
 #include "stitch_host.hpp"
 #include "wfa_host.hpp"
 
-hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
+hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
                                   const ClScoreParams& P, hipStream_t stream);
@@ -39,6 +39,8 @@ thread_local std::string g_error;
 
 // test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
+const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
+constexpr uint64_t kRingLdsBytes = 64 * 1024;   // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU)
 // test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
 const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && *e == '1'; }();
 
@@ -501,6 +503,7 @@ struct LaunchGroup {
     uint32_t first = 0;  // into plist
     uint32_t count = 0;
     uint64_t cells = 0, bytes = 0;
+    uint32_t ring_bytes = 0;  // general kernel: dynamic LDS of the ring variant (0 = planes read from HBM)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -727,6 +730,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         d.n2 = (uint32_t)g[1].n;
         d.npw = (uint8_t)npw;
         bool linear = true;
+        uint64_t span[2] = {0, 0};   // how many rows (columns) back the cells of a row (column) read: predecessors, boundary for a source
         for (int s = 0; s < 2; ++s) {
             NextLists nx;
             nx.build(g[s]);
@@ -748,12 +752,18 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 uint32_t v = order[r];
                 lab[s].push_back(g[s].label[v] & 0x7f);
                 uint64_t deg = g[s].prev_off[v + 1] - g[s].prev_off[v];
-                for (uint64_t e = g[s].prev_off[v]; e < g[s].prev_off[v + 1]; ++e) pidx[s].push_back(rank[g[s].prev_idx[e]] + 1);
+                for (uint64_t e = g[s].prev_off[v]; e < g[s].prev_off[v + 1]; ++e) {
+                    pidx[s].push_back(rank[g[s].prev_idx[e]] + 1);
+                    span[s] = std::max<uint64_t>(span[s], r - rank[g[s].prev_idx[e]]);
+                }
                 poff[s].push_back((uint32_t)pidx[s].size());
                 if (r == 0 ? deg != 0 : (deg != 1 || rank[g[s].prev_idx[g[s].prev_off[v]]] != r - 1)) linear = false;
                 if (g[s].label[v] & 0x80) { set_error(ctx, "labels must be < 128"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
             }
-            for (uint64_t i = 0; i < g[s].n_src; ++i) lab[s][lab0 + rank[g[s].src[i]]] |= 0x80;
+            for (uint64_t i = 0; i < g[s].n_src; ++i) {
+                lab[s][lab0 + rank[g[s].src[i]]] |= 0x80;
+                span[s] = std::max<uint64_t>(span[s], (uint64_t)rank[g[s].src[i]] + 1);   // a source reads the boundary index 0
+            }
             if (g[s].n_src != 1 || rank[g[s].src[0]] != 0) linear = false;
             if (g[s].n_snk != 1 || rank[g[s].snk[0]] != g[s].n - 1) linear = false;
             d.snk_base[s] = (uint32_t)snk[s].size();
@@ -776,6 +786,9 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
         } else {
             plane_cursor += (cells * (uint64_t)(1 + 2 * npw) + 3) / 4 * 4;
+            // LDS ring of the last span1+span2+1 anti-diagonals when it fits (popoa_kernels.hip): every read then stays in LDS
+            const uint64_t depth = span[0] + span[1] + 1, width = std::min(d.n1, d.n2) + 1;
+            if (!g_no_ring && depth <= 65535 && depth * width * (uint64_t)(1 + 2 * npw) * 4 <= kRingLdsBytes) d.pad = (uint16_t)depth;
         }
         pl->lin_rows.push_back(lr);
         pl->lin_waves.push_back(lw);
@@ -831,18 +844,22 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     }
     const int blocks[3] = {64, 256, 1024};
     for (int bi = 2; bi >= 0; --bi)
-        for (int npw = 3; npw >= 1; --npw) {
-            LaunchGroup grp;
-            grp.kind = CL_KIND_GENERAL; grp.npw = npw; grp.block = blocks[bi];
-            grp.first = (uint32_t)plist.size();
-            for (uint32_t i = 0; i < pl->desc.size(); ++i) {
-                const ClProbDesc& d = pl->desc[i];
-                uint32_t width = std::min(d.n1, d.n2) + 1;
-                int b = width <= 64 ? 0 : width <= 256 ? 1 : 2;
-                if (d.kind == CL_KIND_GENERAL && d.npw == npw && b == bi) plist.push_back(i);
+        for (int npw = 3; npw >= 1; --npw)
+            for (int ring = 1; ring >= 0; --ring) {
+                LaunchGroup grp;
+                grp.kind = CL_KIND_GENERAL; grp.npw = npw; grp.block = blocks[bi];
+                grp.first = (uint32_t)plist.size();
+                for (uint32_t i = 0; i < pl->desc.size(); ++i) {
+                    const ClProbDesc& d = pl->desc[i];
+                    uint32_t width = std::min(d.n1, d.n2) + 1;
+                    int b = width <= 64 ? 0 : width <= 256 ? 1 : 2;
+                    if (d.kind == CL_KIND_GENERAL && d.npw == npw && b == bi && (d.pad != 0) == (ring != 0)) {
+                        plist.push_back(i);
+                        if (ring) grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, (uint32_t)((uint64_t)d.pad * width * (1 + 2 * npw) * 4));
+                    }
+                }
+                close_group(grp);
             }
-            close_group(grp);
-        }
     // longest-running launch first: a group's duration is set by its longest anti-diagonal sweep
     {
         auto crit = [&](const LaunchGroup& g) {
@@ -899,7 +916,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
         if (g.kind == CL_KIND_LINEAR)
             HIP_TRY(ctx, cl_launch_popoa_linear(g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
         else
-            HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
+            HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
         if (timed && g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->aux[si]));
     }
     for (int si = 0; si < kNumAuxStreams; ++si)

@@ -56,10 +56,28 @@ struct Planes {
 //                            M   = s(a,b) + max_{p,q} Mf(p,q), with Mf(corner) == 0       (:929-936, :814-818, :854-861, :886-893)
 //   Mf = max(M, I_k, D_k)                                                                 (:837, :869, :903-905)
 // p ranges over previous1(a) plus the boundary index when a is a source; q likewise.
+// The last `depth` anti-diagonals of the matrix in LDS, [diagonal mod depth][position on the diagonal][plane].  The host
+// only picks this variant when every cell a cell reads (predecessor rows / columns, the boundary row / column for a source)
+// lies at most depth-1 anti-diagonals back (ClProbDesc::pad), so reads never leave the ring; the HBM planes are still
+// written, for the traceback.
 template <int NPW>
+struct Ring {
+    int32_t* lds;
+    uint32_t depth, width;
+    static constexpr int PL = 1 + 2 * NPW;
+    __device__ __forceinline__ int32_t* cell(const DiagGeom& G, uint32_t a, uint32_t b) const {
+        const uint32_t d = a + b;
+        return lds + ((size_t)(d % depth) * width + (a - G.lo(d))) * PL;
+    }
+};
+
+template <int NPW, bool RING>
 __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClProbDesc& pd, const DiagGeom& G,
-                                             const Planes<NPW>& pl, const ClScoreParams& P, uint32_t a, uint32_t b,
-                                             uint32_t self_idx) {
+                                             const Planes<NPW>& pl, const Ring<NPW>& ring, const ClScoreParams& P, uint32_t a,
+                                             uint32_t b, uint32_t self_idx) {
+    auto rdM = [&](uint32_t x, uint32_t y) -> int32_t { return RING ? ring.cell(G, x, y)[0] : pl.M()[G.idx(x, y)]; };
+    auto rdI = [&](int k, uint32_t x, uint32_t y) -> int32_t { return RING ? ring.cell(G, x, y)[1 + k] : pl.I(k)[G.idx(x, y)]; };
+    auto rdD = [&](int k, uint32_t x, uint32_t y) -> int32_t { return RING ? ring.cell(G, x, y)[1 + NPW + k] : pl.D(k)[G.idx(x, y)]; };
     const uint8_t* lab1 = B.lab[0] + pd.node_base[0];
     const uint8_t* lab2 = B.lab[1] + pd.node_base[1];
     const uint32_t* poff1 = B.poff[0] + pd.node_base[0];
@@ -77,9 +95,9 @@ __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClPro
     if (a) {
         if (b == 0) {
             for (uint32_t e = e1b; e < e1e; ++e) {
-                uint32_t c = G.idx(B.pidx[0][e], 0);
+                const uint32_t pa = B.pidx[0][e];
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], pl.I(k)[c] - P.ext[k]);
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], rdI(k, pa, 0) - P.ext[k]);
             }
             if (src1) {
 #pragma unroll
@@ -87,13 +105,13 @@ __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClPro
             }
         } else {
             for (uint32_t e = e1b; e < e1e; ++e) {
-                uint32_t c = G.idx(B.pidx[0][e], b);
-                int32_t m = pl.M()[c];
+                const uint32_t pa = B.pidx[0][e];
+                int32_t m = rdM(pa, b);
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], pl.I(k)[c] - P.ext[k]));
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], rdI(k, pa, b) - P.ext[k]));
             }
             if (src1) {
-                int32_t m = pl.M()[G.idx(0, b)];
+                int32_t m = rdM(0, b);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], m - P.oe[k]);
             }
@@ -102,9 +120,9 @@ __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClPro
     if (b) {
         if (a == 0) {
             for (uint32_t f = e2b; f < e2e; ++f) {
-                uint32_t c = G.idx(0, B.pidx[1][f]);
+                const uint32_t pb = B.pidx[1][f];
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], pl.D(k)[c] - P.ext[k]);
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], rdD(k, 0, pb) - P.ext[k]);
             }
             if (src2) {
 #pragma unroll
@@ -112,13 +130,13 @@ __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClPro
             }
         } else {
             for (uint32_t f = e2b; f < e2e; ++f) {
-                uint32_t c = G.idx(a, B.pidx[1][f]);
-                int32_t m = pl.M()[c];
+                const uint32_t pb = B.pidx[1][f];
+                int32_t m = rdM(a, pb);
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], pl.D(k)[c] - P.ext[k]));
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], rdD(k, a, pb) - P.ext[k]));
             }
             if (src2) {
-                int32_t m = pl.M()[G.idx(a, 0)];
+                int32_t m = rdM(a, 0);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], m - P.oe[k]);
             }
@@ -131,7 +149,7 @@ __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClPro
             uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
             for (uint32_t f = e2b; f < e2x; ++f) {
                 uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
-                int32_t v = (pa | pb) ? pl.M()[G.idx(pa, pb)] : 0;
+                int32_t v = (pa | pb) ? rdM(pa, pb) : 0;
                 M = imax(M, v + s);
             }
         }
@@ -143,6 +161,12 @@ __device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClPro
         pl.D(k)[self_idx] = D[k];
     }
     pl.M()[self_idx] = M;
+    if (RING) {
+        int32_t* c = ring.cell(G, a, b);
+        c[0] = M;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) { c[1 + k] = I[k]; c[1 + NPW + k] = D[k]; }
+    }
 }
 
 // best sink pair + traceback by one lane; alignment.hpp:979-1138, rule for rule
@@ -232,57 +256,86 @@ __device__ void traceback(const ClDeviceBatch& B, const ClProbDesc& pd, const Di
     B.out_status[prob] = status;
 }
 
-template <int NPW, int BLOCK>
+template <int NPW, int BLOCK, bool RING>
 __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
+    extern __shared__ int32_t ring_lds[];
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
     Planes<NPW> pl;
     pl.base = B.planes + pd.plane_base;
     pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
+    Ring<NPW> ring;
+    ring.lds = ring_lds;
+    ring.depth = pd.pad;
+    ring.width = (pd.n1 < pd.n2 ? pd.n1 : pd.n2) + 1;
     const uint32_t tid = threadIdx.x;
 
     if (tid == 0) {  // the corner stays -inf in memory; the diagonal term treats it as 0 (alignment.hpp:814-818)
         pl.M()[0] = CL_NEG_INF;
 #pragma unroll
         for (int k = 0; k < NPW; ++k) { pl.I(k)[0] = CL_NEG_INF; pl.D(k)[0] = CL_NEG_INF; }
+        if (RING) {
+            int32_t* c = ring.cell(G, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 1 + 2 * NPW; ++k) c[k] = CL_NEG_INF;
+        }
     }
+    if (RING) __syncthreads();
     const uint32_t last = pd.n1 + pd.n2;
     uint32_t off = 1;  // G.off(1)
     for (uint32_t d = 1; d <= last; ++d) {
         const uint32_t lo = G.lo(d), cnt = G.hi(d) - lo + 1;
         for (uint32_t t = tid; t < cnt; t += BLOCK) {
             const uint32_t a = lo + t;
-            compute_cell<NPW>(B, pd, G, pl, P, a, d - a, off + t);
+            compute_cell<NPW, RING>(B, pd, G, pl, ring, P, a, d - a, off + t);
         }
         off += cnt;
-        __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
+        if (RING) {
+            // the next anti-diagonal reads this one from LDS: order LDS traffic only, the HBM stores drain in the background
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        } else {
+            __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
+        }
     }
+    if (RING) __syncthreads();   // the traceback reads the HBM planes
     if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
 }
 
 template <int NPW>
-void launch_general_npw(int block, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
+void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                         const ClScoreParams& P, hipStream_t stream) {
+    if (ring_bytes) {
+        if (block <= 64)
+            hipLaunchKernelGGL((popoa_general_kernel<NPW, 64, true>), dim3(n_blocks), dim3(64), ring_bytes, stream, B, plist, P);
+        else if (block <= 256)
+            hipLaunchKernelGGL((popoa_general_kernel<NPW, 256, true>), dim3(n_blocks), dim3(256), ring_bytes, stream, B, plist, P);
+        else
+            hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024, true>), dim3(n_blocks), dim3(1024), ring_bytes, stream, B, plist, P);
+        return;
+    }
     if (block <= 64)
-        hipLaunchKernelGGL((popoa_general_kernel<NPW, 64>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P);
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 64, false>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P);
     else if (block <= 256)
-        hipLaunchKernelGGL((popoa_general_kernel<NPW, 256>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P);
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 256, false>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P);
     else
-        hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P);
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024, false>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P);
 }
 
 }  // namespace
 
 // host-callable launcher (C++ linkage, used by cl_api.cpp only)
-hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, const ClDeviceBatch& B,
+// ring_bytes > 0: the LDS-ring variant (every problem of the launch has its ring depth in ClProbDesc::pad and fits ring_bytes)
+hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     switch (npw) {
-    case 1: launch_general_npw<1>(block, n_blocks, B, plist, P, stream); break;
-    case 2: launch_general_npw<2>(block, n_blocks, B, plist, P, stream); break;
-    case 3: launch_general_npw<3>(block, n_blocks, B, plist, P, stream); break;
+    case 1: launch_general_npw<1>(block, n_blocks, ring_bytes, B, plist, P, stream); break;
+    case 2: launch_general_npw<2>(block, n_blocks, ring_bytes, B, plist, P, stream); break;
+    case 3: launch_general_npw<3>(block, n_blocks, ring_bytes, B, plist, P, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
