@@ -677,12 +677,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         cleanup();
         return e == hipErrorOutOfMemory ? CL_ERR_OUT_OF_MEMORY : CL_ERR_HIP;
     };
-    // Two streams.  The context's stream is the sequential one: per block b a "near" launch (the records of the last kChainLag
-    // blocks, small tiles) and the one-workgroup walk of the block itself.  The bulk — every block before b - kChainLag, final
-    // once walk(b - kChainLag - 1) is done — is evaluated on an auxiliary stream ("far").  The lag gives a far launch kChainLag
-    // block times to finish before walk(b) needs it: with a lag of one the two streams handed each other a dependency every
-    // other block, and that round trip (two cross-queue event waits) set the pace.
-    static const uint32_t lag = getenv("CL_CHAIN_LAG") ? std::max(1, atoi(getenv("CL_CHAIN_LAG"))) : kChainLag;
+    // Two streams.  The context's stream is the sequential one: per block b the one-workgroup walk of the block, preceded by
+    // the "near" pass over the blocks the far launch could not see yet (folded into the walk kernel when there is a single
+    // combination).  The bulk is evaluated on an auxiliary stream ("far"): one launch serves a GROUP of kChainFarGroup
+    // consecutive blocks (a far launch lasts at least one tile, ~70 us, however few predecessors there are, and the far
+    // stream sets the pace: fewer, fatter launches) and reads the blocks before g0 - 1, final once walk(g0 - 2) is done.
+    static const uint32_t far_group = getenv("CL_CHAIN_FAR_GROUP") ? std::max(1, atoi(getenv("CL_CHAIN_FAR_GROUP"))) : kChainFarGroup;
     std::vector<hipEvent_t> ev_intra(n_blocks, nullptr), ev_far(n_blocks, nullptr);
     hipError_t he = hipEventRecord(ev0, ctx->stream);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
@@ -692,28 +692,31 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         for (const Combo& c : combos) m = std::max(m, c.prefix[hi] - c.prefix[lo]);
         return m;
     };
+    uint32_t near_lo = 0;   // first block the current group's far launch did not cover
     for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {
         const uint32_t first = b * kChainBlock, count = (uint32_t)std::min<uint64_t>(kChainBlock, M - first);
-        const uint32_t near_lo = b > lag ? b - lag : 0;
-        if (near_lo > 0) {
-            // far predecessors: blocks [0, near_lo), final once walk(near_lo - 1) is done
-            he = hipStreamWaitEvent(ctx->aux[0], ev_intra[near_lo - 1], 0);
-            // a launch lasts at least one tile and ends with one atomic merge per query and workgroup: small tiles while
-            // the grid does not fill the chip (latency), large ones afterwards (fewer merges)
-            const uint32_t recs = max_recs(0, near_lo);
-            uint32_t tile = kChainFarTile;   // affine: 7 atomics per query and workgroup — large tiles (measured: smaller ones lose)
-            if (sparse) {                   // sparse: one atomic per query, so small tiles are cheap
-                tile = kChainNearTile;
-                while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
+        if (b % far_group == 0) {
+            near_lo = b > 1 ? b - 1 : 0;
+            if (near_lo > 0) {
+                // far predecessors of the whole group: blocks [0, near_lo), final once walk(near_lo - 1) is done
+                he = hipStreamWaitEvent(ctx->aux[0], ev_intra[near_lo - 1], 0);
+                // a launch ends with one atomic merge per query and workgroup: small tiles (low latency) only where that is
+                // cheap — sparse mode has one maximum per query — and while the grid does not fill the chip
+                const uint32_t recs = max_recs(0, near_lo);
+                uint32_t tile = kChainFarTile;
+                if (sparse) {
+                    tile = kChainNearTile;
+                    while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
+                }
+                const uint32_t group_count = (uint32_t)std::min<uint64_t>((uint64_t)far_group * kChainBlock, M - first);
+                if (he == hipSuccess) he = cl_chain_launch_inter(D, first, group_count, 0, near_lo, recs, tile, ctx->aux[0]);
+                if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
+                if (he == hipSuccess) he = hipEventRecord(ev_far[b], ctx->aux[0]);
             }
-            if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, ctx->aux[0]);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventRecord(ev_far[b], ctx->aux[0]);
         }
-        // near predecessors: blocks [near_lo, b), on the sequential stream right after walk(b - 1); with a single
-        // combination the walk kernel does it itself
+        // near predecessors: blocks [near_lo, b), on the sequential stream right after walk(b - 1)
         const bool fuse_near = combos.size() == 1;
-        if (he == hipSuccess && b >= 1 && !fuse_near) he = cl_chain_launch_inter(D, first, count, near_lo, b, max_recs(near_lo, b), kChainNearTile, ctx->stream);
+        if (he == hipSuccess && b > near_lo && !fuse_near) he = cl_chain_launch_inter(D, first, count, near_lo, b, max_recs(near_lo, b), kChainNearTile, ctx->stream);
         if (he == hipSuccess && ev_far[b]) he = hipStreamWaitEvent(ctx->stream, ev_far[b], 0);
         if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, fuse_near ? b - near_lo : 0u, ctx->stream);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_intra[b], hipEventDisableTiming);
