@@ -787,6 +787,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         return c.per_sub[k];
     };
 
+    uint64_t n_scanned = 0, n_steps = 0;
     // ---- optimum and traceback (anchorer.hpp:2483-2531), instance by instance -----------------------------------------
     for (uint32_t k = 0; k < K; ++k) {
         const SubCtx& sk = sc[k];
@@ -805,6 +806,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         uint32_t here = best_slot;
         const uint32_t C1 = (uint32_t)sk.x[0]->chain_size(), C2 = (uint32_t)sk.x[1]->chain_size();
         while (here != kNone) {
+            ++n_steps;
             chain_slots.push_back(here);
             const uint32_t s = s_of_slot[here];
             const float dpv = dp_sorted[s], w = weight[s];
@@ -852,6 +854,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                 const uint32_t qt = c.qt[s], qoff = c.qoff[s];
                 const int32_t qq = c.q[s];
                 for (size_t i = std::lower_bound(keys.begin(), keys.end(), target) - keys.begin(); i < keys.size() && keys[i] == target; ++i) {
+                    ++n_scanned;
                     const uint32_t r = recs[i];
                     if (c.rec_s[r] >= s) continue;
                     const int32_t sg = c.sigma[r];
@@ -1000,6 +1003,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         }
     }
     tm.traceback_ms += ms_since(T2);
+    if (timing) fprintf(stderr, "[chain_dp_batch]   traceback: %llu steps, %llu equal-valued records scanned\n", (unsigned long long)n_steps, (unsigned long long)n_scanned);
     if (dp_out) {
         dp_out->resize(M);
         for (uint32_t slot = 0; slot < M; ++slot) (*dp_out)[slot] = dp_sorted[s_of_slot[slot]];

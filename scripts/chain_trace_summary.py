@@ -16,6 +16,9 @@ intr = [r for r in run2 if 'intra' in r['Kernel_Name']]
 dur = lambda rs: np.array([int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rs]) / 1e3
 for name, rs in (('far', far), ('near', near), ('intra', intr)):
     d = dur(rs)
+    if len(d) == 0:
+        print('%-6s n=    0' % name)
+        continue
     print('%-6s n=%5d total %.1f ms mean %.1f us p10 %.1f p50 %.1f p90 %.1f' % (name, len(rs), d.sum() / 1e3, d.mean(), np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
 d = dur(far); g = np.array([int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']) for r in far])
 for i in (10, 100, 500, 1000, 2000, 3000, 4000, 4800):
