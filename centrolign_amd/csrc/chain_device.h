@@ -10,7 +10,8 @@ constexpr uint32_t kChainBlock = 256;     // match pairs per sequential block (o
 constexpr uint32_t kChainFarTile = 1024;  // predecessor records per workgroup of a far launch
 constexpr uint32_t kChainNearTile = 256;  // ... of a near launch, and of a far launch whose grid would not fill the chip
 constexpr uint32_t kChainFullGrid = 1024; // workgroups that fill the chip (4 per CU)
-constexpr uint32_t kChainFarGroup = 2;    // consecutive blocks served by one far launch
+constexpr uint32_t kChainFarGroup = 1;    // consecutive blocks served by one far launch
+constexpr uint32_t kChainFarStreams = 2;  // auxiliary streams the far launches alternate between
 constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
 
 struct ClChainParams {

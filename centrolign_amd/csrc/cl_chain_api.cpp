@@ -683,10 +683,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     // consecutive blocks (a far launch lasts at least one tile, ~70 us, however few predecessors there are, and the far
     // stream sets the pace: fewer, fatter launches) and reads the blocks before g0 - 1, final once walk(g0 - 2) is done.
     static const uint32_t far_group = getenv("CL_CHAIN_FAR_GROUP") ? std::max(1, atoi(getenv("CL_CHAIN_FAR_GROUP"))) : kChainFarGroup;
+    // consecutive far launches alternate between auxiliary streams: while their grids are small their latency floors overlap
+    static const uint32_t far_streams = getenv("CL_CHAIN_FAR_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CL_CHAIN_FAR_STREAMS")))) : kChainFarStreams;
     std::vector<hipEvent_t> ev_intra(n_blocks, nullptr), ev_far(n_blocks, nullptr);
     hipError_t he = hipEventRecord(ev0, ctx->stream);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
-    if (he == hipSuccess) he = hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0);
+    for (uint32_t f = 0; f < far_streams && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
     auto max_recs = [&](uint32_t lo, uint32_t hi) {
         uint32_t m = 0;
         for (const Combo& c : combos) m = std::max(m, c.prefix[hi] - c.prefix[lo]);
@@ -699,7 +701,8 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             near_lo = b > 1 ? b - 1 : 0;
             if (near_lo > 0) {
                 // far predecessors of the whole group: blocks [0, near_lo), final once walk(near_lo - 1) is done
-                he = hipStreamWaitEvent(ctx->aux[0], ev_intra[near_lo - 1], 0);
+                hipStream_t far_stream = ctx->aux[(b / far_group) % far_streams];
+                he = hipStreamWaitEvent(far_stream, ev_intra[near_lo - 1], 0);
                 // a launch ends with one atomic merge per query and workgroup: small tiles (low latency) only where that is
                 // cheap — sparse mode has one maximum per query — and while the grid does not fill the chip
                 const uint32_t recs = max_recs(0, near_lo);
@@ -709,9 +712,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                     while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
                 }
                 const uint32_t group_count = (uint32_t)std::min<uint64_t>((uint64_t)far_group * kChainBlock, M - first);
-                if (he == hipSuccess) he = cl_chain_launch_inter(D, first, group_count, 0, near_lo, recs, tile, ctx->aux[0]);
+                if (he == hipSuccess) he = cl_chain_launch_inter(D, first, group_count, 0, near_lo, recs, tile, far_stream);
                 if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
-                if (he == hipSuccess) he = hipEventRecord(ev_far[b], ctx->aux[0]);
+                if (he == hipSuccess) he = hipEventRecord(ev_far[b], far_stream);
             }
         }
         // near predecessors: blocks [near_lo, b), on the sequential stream right after walk(b - 1)
@@ -725,7 +728,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     lap("enqueue (host)");
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(ctx->aux[0]);
+    for (uint32_t f = 0; f < far_streams && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
