@@ -1,7 +1,8 @@
-// cl_chain_api.cpp — host side of cl_chain_sparse_affine (include/centrolign_amd.h): the Anchorer's sparse affine
-// chaining DP (include/centrolign/anchorer.hpp:1812-2547) with the DP itself on the GPU (chain_kernels.hip).
+// cl_chain_api.cpp — host side of the chaining seams (include/centrolign_amd.h): cl_chain_sparse_affine / cl_chain_sparse
+// (the Anchorer's chaining DPs, include/centrolign/anchorer.hpp:1511-2547, with the DP itself on the GPU,
+// chain_kernels.hip) and cl_anchor_chain (Anchorer::anchor_chain, :958-1329, with fill-in re-anchoring :619-956).
 //
-// Host work, all O(M) or O(M log M):
+// chain_dp_batch runs K independent chaining instances in one device pass; its host work is O(M) or O(M log M):
 //   * the coordinate system: PathMerge tables (path_merge.hpp:96-277), post-switch distances
 //     (post_switch_distances.hpp:44-81), source/query shifts and offsets per (chain1, chain2) (anchorer.hpp:1875-1904),
 //     forward-edge existence (forward_edges.hpp:40-53 with the masks of anchorer.hpp:1752-1810), anchor weights
@@ -14,8 +15,8 @@
 //     loop order whose value reaches the maximum (strict '>' in MatchBank::update_dp, match_bank.hpp:177), and inside
 //     that query the tree's traversal rule — first unit met by range_max; inside a cross tree the larger outer index
 //     (values there are (score, index) pairs, orthogonal_max_search_tree.hpp:76); inside a gap-free subtree the
-//     earliest inserted (strict '>' in MaxSearchTree::update, max_search_tree.hpp:318-358).  pick_ortho / pick_gap_free
-//     evaluate that rule directly on the sorted keys; they only run when a maximum is attained more than once.
+//     earliest inserted (strict '>' in MaxSearchTree::update, max_search_tree.hpp:318-358).  replay_units evaluates that
+//     rule directly on the sorted keys; it only runs when a maximum is attained more than once.
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -255,8 +255,8 @@ int cl_despecify_indel_breakpoints(uint64_t n_anchors, const double* score, int6
 
 /* --- Anchorer chaining DP (include/centrolign/anchorer.hpp:1812-2547) --------------------------------------------------
  * The seam is sparse_affine_chain_dp itself: (graphs + embedded paths, match sets, gap parameters, local scale) in,
- * the optimal chain out, as the reference's anchor_chain dispatch calls it (anchorer.hpp:1213-1307) with local
- * anchoring (no sources/sinks) and no masked matches. */
+ * the optimal chain out, as the reference's anchor_chain dispatch calls it (anchorer.hpp:1213-1307): sources / sinks are
+ * the graph ends (cl_chain_params.global_anchoring, the CLI default) or absent (local chaining); no masked matches. */
 /* std::vector<match_set_t> (include/centrolign/match_finder.hpp:21-34), flattened.  Set s owns walks
  * set_off1[s] .. set_off1[s+1]-1 of graph 1 (walk w = nodes1[walk_off1[w] .. walk_off1[w+1])), likewise for graph 2. */
 typedef struct cl_match_sets {
