@@ -684,6 +684,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     poff[0].push_back(0);
     poff[1].push_back(0);
     std::vector<uint32_t> order, st, indeg, rank;
+    std::vector<uint32_t> ring_need;   // per PO-POA problem: dynamic LDS of the ring variant of the general kernel (0 = not taken)
     uint64_t plane_cursor = 0, out_cursor = 0;
 
     for (uint64_t k = 0; k < n; ++k) {
@@ -784,11 +785,21 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             else { lr = 1; lw = 16; }
             d.pad = (uint16_t)(ls | (lr << 1));  // read by linear_dispatch
             plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
+            ring_need.push_back(0);
         } else {
             plane_cursor += (cells * (uint64_t)(1 + 2 * npw) + 3) / 4 * 4;
-            // LDS ring of the last span1+span2+1 anti-diagonals when it fits (popoa_kernels.hip): every read then stays in LDS
-            const uint64_t depth = span[0] + span[1] + 1, width = std::min(d.n1, d.n2) + 1;
-            if (!g_no_ring && depth <= 65535 && depth * width * (uint64_t)(1 + 2 * npw) * 4 <= kRingLdsBytes) d.pad = (uint16_t)depth;
+            // LDS ring of the most recent anti-diagonals (popoa_kernels.hip): span1+span2+1 of them serve every read; when that
+            // does not fit, as many as do (at least 8) — the rare reads that reach further back go to HBM
+            const uint64_t width = std::min(d.n1, d.n2) + 1, per_diag = width * (uint64_t)(1 + 2 * npw) * 4;
+            // the ring variant also stages the subproblem's topology in LDS: offsets, predecessor ranks, labels
+            const uint64_t n_pred = (poff[0].back() - poff[0][d.node_base[0]]) + (poff[1].back() - poff[1][d.node_base[1]]);
+            const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2 + 2 + n_pred) * 4 + d.n1 + d.n2 + 8;
+            uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
+            while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 32768) depth *= 2;
+            if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && depth >= 8) {
+                d.pad = (uint16_t)depth;
+                ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
+            } else ring_need.push_back(0);
         }
         pl->lin_rows.push_back(lr);
         pl->lin_waves.push_back(lw);
@@ -855,7 +866,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     int b = width <= 64 ? 0 : width <= 256 ? 1 : 2;
                     if (d.kind == CL_KIND_GENERAL && d.npw == npw && b == bi && (d.pad != 0) == (ring != 0)) {
                         plist.push_back(i);
-                        if (ring) grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, (uint32_t)((uint64_t)d.pad * width * (1 + 2 * npw) * 4));
+                        if (ring) grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
                     }
                 }
                 close_group(grp);
