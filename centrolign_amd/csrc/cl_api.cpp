@@ -796,7 +796,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2 + 2 + n_pred) * 4 + d.n1 + d.n2 + 8;
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 32768) depth *= 2;
-            if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && depth >= 8) {
+            if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
                 d.pad = (uint16_t)depth;
                 ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
             } else ring_need.push_back(0);
