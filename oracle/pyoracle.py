@@ -119,7 +119,7 @@ def ref_chain(algo, g1, g2, ms, scale=1.0, params=None, num_match_sets=None, glo
     c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
     out = np.zeros((max(ms.n_pairs(), 1), 3), np.uint32)
     ln, secs = C.c_uint64(0), C.c_double(0)
-    rc = lib.ref_chain_dp_ex(0 if algo == "affine" else 1, C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale),
+    rc = lib.ref_chain_dp_ex({"affine": 0, "sparse": 1, "exhaustive": 2}[algo], C.byref(c1), C.byref(c2), C.byref(mc), n, C.byref(params), float(scale),
                              int(global_anchoring), out.ctypes.data, C.byref(ln), C.byref(secs))
     if rc:
         raise RuntimeError("ref_chain_dp failed: %d" % rc)

@@ -388,6 +388,7 @@ struct OpenAnchorer : public Anchorer {
     using Anchorer::sparse_chain_dp;
     using Anchorer::estimate_score_scale;
     using Anchorer::split_branching_matches;
+    using Anchorer::exhaustive_chain_dp;
 };
 
 extern "C" {
@@ -436,7 +437,9 @@ int ref_chain_dp_ex(int algo, const cl_base_graph* g1, const cl_base_graph* g2, 
     const std::vector<uint64_t>* k1 = global_anchoring ? &b1.previous(t1.snk_id) : nullptr;
     const std::vector<uint64_t>* k2 = global_anchoring ? &b2.previous(t2.snk_id) : nullptr;
     auto a = std::chrono::steady_clock::now();
-    if (algo == 0)
+    if (algo == 2)   // exhaustive_chain_dp (anchorer.hpp:1342-1509), the O(M^2) algorithm behind "-g 0": no gap costs here
+        chain = an.exhaustive_chain_dp<uint64_t, uint32_t>(sets, b1, b2, pm1, pm2, false, local_scale, num_match_sets, s1, s2, k1, k2, nullptr);
+    else if (algo == 0)
         chain = an.sparse_affine_chain_dp<uint32_t, uint16_t, uint32_t, int32_t, uint32_t, float, SmallShiftMatchVector, SmallDistMatchVector,
                                           std::vector<uint32_t>, std::vector<uint32_t>, SmallMatchBank, FwdEdges>(
             sets, b1, b2, pm1, pm2, go, ge, local_scale, num_match_sets, true, s1, s2, k1, k2, nullptr);

@@ -55,6 +55,17 @@ def host_route_cases():
     return {"seq1": seqs[0], "seq2": seqs[1], "_batches": host_route_batches.build(seqs[0], seqs[1])}
 
 
+def chain_weight(ms, chain):
+    """sum of ScoreFunction::anchor_weight (score_function.hpp:51-75, CLI parameters) over a chain's anchors"""
+    tot = 0.0
+    for s in chain[:, 0]:
+        c = float(ms.count1[s] * ms.count2[s])
+        w0 = int(ms.set_off1[s])
+        ln, fl = float(ms.walk_off1[w0 + 1] - ms.walk_off1[w0]), float(ms.full_length[s])
+        tot += (ln / fl) * (ln / c ** 0.5 - (ln / 2250.0) ** 2 * 2250.0)
+    return tot
+
+
 def ref_results(batch, params, with_forced=True):
     out = {}
     res, _ = po.ref_stitch_batch(batch, params)
@@ -165,6 +176,13 @@ def main():
                 # the same with Anchorer::global_anchoring (the CLI default): sources/sinks = the graph's end nodes
                 out[tag + ".chain_sparse_global"], _ = po.ref_chain("sparse", g1, g2, ms, global_anchoring=True)
                 out[tag + ".chain_affine_global"], _ = po.ref_chain("affine", g1, g2, ms, scale=scale, global_anchoring=True)
+            # optimality: the total anchor weight of the chain exhaustive_chain_dp (anchorer.hpp:1342-1509, the O(M^2) "-g 0"
+            # algorithm) finds on two small subsets of "a" — what any gap-free chaining of those matches must reach
+            full_a = po.MatchSets(**{k: out["a.ms." + k] for k in po.MatchSets._DT})
+            for seed, budget in ((1, 1500), (2, 3000)):
+                sub = po.budget_subset(full_a, budget, seed=seed)
+                ex, _ = po.ref_chain("exhaustive", g1, g2, sub, global_anchoring=True)
+                out["exhaustive.%d.%d" % (seed, budget)] = np.array([chain_weight(sub, ex)])
             np.savez_compressed(os.path.join(HERE, "chain4_30k_merge%d.npz" % m), **out)
         # 6b. Anchorer::anchor_chain seam (budgeted selection + reorder, scale estimate, affine chain, annotation) with
         #     split_matches_at_branchpoints = false; "g" = global anchoring (CLI default), "l" = local, "n" = no

@@ -62,3 +62,26 @@ def test_chain_oracle_vs_compiled_reference_live(name):
             for glob in (False, True):
                 ref, _ = po.ref_chain(algo, graphs[0], graphs[1], ms, scale=scale, global_anchoring=glob)
                 assert np.array_equal(po.oracle_chain(algo, graphs[0], graphs[1], ms, scale=scale, global_anchoring=glob), ref)
+
+
+def chain_weight(ms, chain):
+    tot = 0.0
+    for s in chain[:, 0]:
+        c = float(ms.count1[s] * ms.count2[s])
+        w0 = int(ms.set_off1[s])
+        ln, fl = float(ms.walk_off1[w0 + 1] - ms.walk_off1[w0]), float(ms.full_length[s])
+        tot += (ln / fl) * (ln / c ** 0.5 - (ln / 2250.0) ** 2 * 2250.0)
+    return tot
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_sparse_chain_is_optimal(name):
+    """independent check: the gap-free chain reaches the total weight that the reference's exhaustive_chain_dp
+    (anchorer.hpp:1342-1509, O(M^2), the "-g 0" algorithm) finds on the same matches"""
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
+    full = po.MatchSets(**{k: z["a.ms." + k] for k in po.MatchSets._DT})
+    for seed, budget in ((1, 1500), (2, 3000)):
+        ms = po.budget_subset(full, budget, seed=seed)
+        chain = po.oracle_chain("sparse", graphs[0], graphs[1], ms, global_anchoring=True)
+        assert abs(chain_weight(ms, chain) - float(z["exhaustive.%d.%d" % (seed, budget)][0])) < 1e-6

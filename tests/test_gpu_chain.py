@@ -140,3 +140,18 @@ def test_core_align_small_and_degenerate_inputs(gpu_ctx):
             assert np.array_equal(aln[aln[:, 0] != gap, 0], np.arange(400, dtype=np.uint64))
             assert np.array_equal(aln[aln[:, 1] != gap, 1], np.arange(380, dtype=np.uint64))
     assert len(got["walk_off"]) > 5   # the last run (matches + permissive thresholds) did anchor
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_gpu_sparse_chain_is_optimal(gpu_ctx, name):
+    """the device's gap-free chain reaches the total weight of the reference's exhaustive O(M^2) chaining (row a23)"""
+    from tests.test_chain_oracle import chain_weight
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
+    full = capi.MatchSets(**{k: z["a.ms." + k] for k in capi.MatchSets._DT})
+    for seed, budget in ((1, 1500), (2, 3000)):
+        ms = po.budget_subset(full, budget, seed=seed)
+        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, sparse=True, want_dp=True)
+        want = float(z["exhaustive.%d.%d" % (seed, budget)][0])
+        assert abs(chain_weight(ms, got["chain"]) - want) < 1e-6
+        assert abs(float(got["dp"].max()) - want) < 1e-3 * max(1.0, want)   # the float DP value of the chain's last anchor
