@@ -8,7 +8,11 @@
  * Stitcher::stitch is exactly path (2).  Built only where /root/reference exists; the binary travels to the
  * GPU box inside oracle/_ref/.
  *
- * usage: adapter_demo <fasta> [newick-file|-] [max_num_match_pairs]
+ * With a fourth argument "core" the comparison is made one level up, at Core::align (include/centrolign/core.hpp:181-252):
+ *   (1) the reference's anchor_chain -> partition_anchors -> despecify_indel_breakpoints -> stitch on the CPU
+ *   (2) include/centrolign_amd/core_adapter.hpp -> cl_core_align -> MI355X, from the same match sets
+ *
+ * usage: adapter_demo <fasta> [newick-file|-] [max_num_match_pairs] [core]
  */
 #include <chrono>
 #include <cstdio>
@@ -21,6 +25,7 @@
 #include "centrolign/utility.hpp"
 
 #include "../include/centrolign_amd/stitch_adapter.hpp"
+#include "../include/centrolign_amd/core_adapter.hpp"
 
 using namespace centrolign;
 
@@ -97,6 +102,28 @@ struct DemoCore : public Core {
         return got;  // continue the MSA on the GPU result: later merges then depend on it
     }
 
+    bool whole_align = false;
+
+    // Core::align both ways from the same matches (anchor_chain reorders and extends its argument, so each side gets a copy)
+    template <class XMerge>
+    Alignment align_core_both(std::vector<match_set_t>& matches, const Subproblem& sp1, const Subproblem& sp2, XMerge& x1, XMerge& x2) {
+        using clk = std::chrono::steady_clock;
+        auto a1 = clk::now();
+        const cl_core_align_params prm = centrolign_amd::core_align_params_of(*this, true);
+        Alignment got = centrolign_amd::core_align<AlignedPair>(*dev, sp1.graph, sp1.tableau, sp2.graph, sp2.tableau, matches, prm);
+        t_gpu += std::chrono::duration<double>(clk::now() - a1).count();
+        auto a0 = clk::now();
+        std::vector<match_set_t> copy = matches;
+        Alignment ref = align(copy, sp1, sp2, x1, x2, true);   // the reference's Core::align (the merge structures are consumed)
+        t_cpu += std::chrono::duration<double>(clk::now() - a0).count();
+        bool same = got.size() == ref.size();
+        for (size_t i = 0; same && i < got.size(); ++i) same = got[i] == ref[i];
+        if (!same) ++mismatched;
+        printf("merge %zu: %zu match sets, alignment length %zu, GPU Core::align %s the reference\n", merges, matches.size(), ref.size(), same ? "==" : "!=");
+        ++merges;
+        return got;
+    }
+
     void run() {
         if (!skip_calibration) calibrate_anchor_scores_and_identify_bonds();
         while (!main_execution.finished()) {
@@ -109,7 +136,7 @@ struct DemoCore : public Core {
             auto matches = path_match_finder.find_matches(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau);
             PathMerge<uint32_t, uint8_t> pm1(sp1.graph, sp1.tableau);
             PathMerge<uint32_t, uint8_t> pm2(sp2.graph, sp2.tableau);
-            next_problem.alignment = align_both(matches, sp1, sp2, pm1, pm2);
+            next_problem.alignment = whole_align ? align_core_both(matches, sp1, sp2, pm1, pm2) : align_both(matches, sp1, sp2, pm1, pm2);
             BaseGraph fused = sp1.graph;
             fuse(fused, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment);
             next_problem.graph = std::move(fused);
@@ -148,9 +175,13 @@ int main(int argc, char** argv) {
         core.preserve_subproblems = true;
         centrolign_amd::Device dev(0);
         core.dev = &dev;
+        core.whole_align = argc > 4 && std::string(argv[4]) == "core";
         core.run();
-        printf("%zu merges, %zu subproblems, subalign loop: reference CPU %.3f s, adapter+GPU %.3f s (incl. flatten, H2D, D2H)\n",
-               core.merges, core.problems, core.t_cpu, core.t_gpu);
+        if (core.whole_align)
+            printf("%zu merges, Core::align: reference CPU %.3f s, adapter+GPU %.3f s (incl. flattening)\n", core.merges, core.t_cpu, core.t_gpu);
+        else
+            printf("%zu merges, %zu subproblems, subalign loop: reference CPU %.3f s, adapter+GPU %.3f s (incl. flatten, H2D, D2H)\n",
+                   core.merges, core.problems, core.t_cpu, core.t_gpu);
         printf(core.mismatched ? "DROP-IN FAILED\n" : "DROP-IN OK\n");
         return core.mismatched ? 1 : 0;
     } catch (std::exception& ex) {

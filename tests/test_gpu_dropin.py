@@ -32,3 +32,25 @@ def test_reference_stitch_loop_vs_gpu(tmp_path, seed, length, n, max_pairs):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DROP-IN OK" in p.stdout
     assert p.stdout.count("== the reference") == (1 if n == 2 else 3)
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/adapter_demo not built (needs the reference sources)")
+@pytest.mark.parametrize("seed,length,n,max_pairs", [(23, 60000, 2, 60000), (24, 30000, 4, 40000), (25, 40000, 4, 200000)])
+def test_reference_core_align_vs_gpu(tmp_path, seed, length, n, max_pairs):
+    """the same one level up: Core::align (anchor chain -> partition -> despecify -> stitch) of the unmodified reference
+    against include/centrolign_amd/core_adapter.hpp -> cl_core_align, from the reference's own match sets, merge after
+    merge of a fresh FASTA (later merges depend on the earlier GPU results)"""
+    seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs)
+    nwk = "-"
+    if n == 4:
+        nwk = str(tmp_path / "tree.nwk")
+        with open(nwk, "w") as f:
+            f.write("((seq0,seq1),(seq2,seq3));")
+    p = subprocess.run([DEMO, fa, nwk, str(max_pairs), "core"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    print(p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DROP-IN OK" in p.stdout
+    assert p.stdout.count("GPU Core::align == the reference") == (1 if n == 2 else 3)
