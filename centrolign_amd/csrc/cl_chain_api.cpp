@@ -1107,10 +1107,11 @@ uint64_t select_matches(const cl_match_sets& ms, const cl_chain_params& cp, std:
     uint64_t total = 0;
     for (uint64_t s : cur) total += n_pairs(s);
     if (total <= local_max) return n;
-    auto wfull = [&](uint64_t s) { return anchor_weight(cp, ms.count1[s], ms.count2[s], ms.full_length[s], ms.full_length[s]); };
+    std::vector<double> wfull(n);   // the sort key, evaluated once per set instead of twice per comparison
+    for (size_t i = 0; i < n; ++i) { const uint64_t s = cur[i]; wfull[i] = anchor_weight(cp, ms.count1[s], ms.count2[s], ms.full_length[s], ms.full_length[s]); }
     std::vector<size_t> order(n);
     std::iota(order.begin(), order.end(), (size_t)0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t i, size_t j) { return wfull(cur[i]) > wfull(cur[j]); });
+    std::stable_sort(order.begin(), order.end(), [&](size_t i, size_t j) { return wfull[i] > wfull[j]; });
     size_t removed = 0;
     uint64_t left = local_max;
     for (size_t i = 0; i < order.size(); ++i) {
