@@ -793,11 +793,11 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const uint64_t width = std::min(d.n1, d.n2) + 1, per_diag = width * (uint64_t)(1 + 2 * npw) * 4;
             // the ring variant also stages the subproblem's topology in LDS: offsets, predecessor ranks, labels
             const uint64_t n_pred = (poff[0].back() - poff[0][d.node_base[0]]) + (poff[1].back() - poff[1][d.node_base[1]]);
-            const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2 + 2 + n_pred) * 4 + d.n1 + d.n2 + 8;
+            const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2) * 8 + n_pred * 4 + ((uint64_t)d.n1 + d.n2 + 2) * (1 + npw) * 4 + 16;   // node records, lists, boundaries
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
-            while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 32768) depth *= 2;
+            while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
             if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
-                d.pad = (uint16_t)depth;
+                d.pad = (uint16_t)(depth | (depth >= span[0] + span[1] + 1 ? 0x8000u : 0u));   // bit 15: the ring serves every read
                 ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
             } else ring_need.push_back(0);
         }

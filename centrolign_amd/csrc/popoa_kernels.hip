@@ -363,16 +363,213 @@ __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, c
     if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// popoa_ring_kernel: the same sweep for subproblems whose working set fits LDS.  In LDS: a ring of the most recent anti-
+// diagonals ([diagonal & (depth-1)][position][plane], depth a power of two, ClProbDesc::pad), one packed record per node
+// ({first predecessor or list start, degree | label << 16 | source << 31}), the predecessor lists, and the boundary column
+// and row.  The boundary (a == 0 or b == 0: chains of gap extensions only, alignment.hpp:832-894) is a 1-D recurrence per
+// graph and is done up front by two lanes, so the sweep only meets interior cells — one code path, no per-diagonal
+// divergence — whose reads are LDS reads; a read that reaches further back than the ring goes to the HBM planes, which are
+// written as before (the traceback reads them) and drained every depth/2 anti-diagonals.
+template <int NPW, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
+    extern __shared__ int32_t lds[];
+    constexpr int PL = 1 + 2 * NPW, BP = 1 + NPW;
+    const uint32_t prob = plist[blockIdx.x];
+    const ClProbDesc pd = B.desc[prob];
+    const DiagGeom G(pd.n1, pd.n2);
+    Planes<NPW> pl;
+    pl.base = B.planes + pd.plane_base;
+    pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
+    const uint32_t tid = threadIdx.x, n1 = pd.n1, n2 = pd.n2;
+    // ClProbDesc::pad: ring depth (a power of two, <= 2^14) | 0x8000 when the ring serves every read of the subproblem
+    const uint32_t depth = pd.pad & 0x7FFFu, width = (n1 < n2 ? n1 : n2) + 1, mask = depth - 1;
+    const bool full_cover = pd.pad & 0x8000u;
+
+    // LDS layout (int32 units): ring | node records 1 | node records 2 | predecessor lists 1 | 2 | boundary column | boundary row
+    int32_t* ring = lds;
+    uint2* rec1 = reinterpret_cast<uint2*>(lds + (((size_t)depth * width * PL + 1) & ~(size_t)1));   // 8-byte aligned
+    uint2* rec2 = rec1 + n1;
+    uint32_t* pl1 = reinterpret_cast<uint32_t*>(rec2 + n2);
+    const uint32_t* gp1 = B.poff[0] + pd.node_base[0];
+    const uint32_t* gp2 = B.poff[1] + pd.node_base[1];
+    const uint32_t e10 = gp1[0], e11 = gp1[n1], e20 = gp2[0], e21 = gp2[n2];
+    uint32_t* pl2 = pl1 + (e11 - e10);
+    int32_t* bcol = reinterpret_cast<int32_t*>(pl2 + (e21 - e20));   // [(n1+1)][BP]: M, I_k of cell (a, 0)
+    int32_t* brow = bcol + (size_t)(n1 + 1) * BP;                    // [(n2+1)][BP]: M, D_k of cell (0, b)
+    for (uint32_t i = tid; i < e11 - e10; i += BLOCK) pl1[i] = B.pidx[0][e10 + i];
+    for (uint32_t i = tid; i < e21 - e20; i += BLOCK) pl2[i] = B.pidx[1][e20 + i];
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t n = s ? n2 : n1, e0 = s ? e20 : e10;
+        const uint32_t* gp = s ? gp2 : gp1;
+        const uint8_t* gl = B.lab[s] + pd.node_base[s];
+        uint2* rec = s ? rec2 : rec1;
+        for (uint32_t i = tid; i < n; i += BLOCK) {
+            const uint32_t b0 = gp[i] - e0, deg = gp[i + 1] - gp[i], l = gl[i];
+            rec[i] = make_uint2(deg == 1 ? B.pidx[s][gp[i]] : b0, (deg & 0xFFFFu) | ((l & 0x7Fu) << 16) | ((l >> 7) << 31));
+        }
+    }
+    __syncthreads();
+    // boundary column (lane 0) and row (lane 1): I_k(a,0) = max(source ? -(o_k+e_k) : -inf, max_p I_k(p,0) - e_k), M = max_k;
+    // the corner stays -inf (the diagonal term treats it as 0, alignment.hpp:814-818)
+    if (tid < 2) {
+        const uint32_t n = tid ? n2 : n1;
+        const uint2* rec = tid ? rec2 : rec1;
+        const uint32_t* lst = tid ? pl2 : pl1;
+        int32_t* bnd = tid ? brow : bcol;
+        int32_t prev[NPW];   // the values of node v-1: a chain step (the usual case) needs nothing else
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) prev[k] = CL_NEG_INF;
+#pragma unroll
+        for (int k = 0; k < BP; ++k) bnd[k] = CL_NEG_INF;
+        uint2 r = n ? rec[0] : make_uint2(0u, 0u);
+        for (uint32_t v = 1; v <= n; ++v) {
+            const uint2 r_next = v < n ? rec[v] : make_uint2(0u, 0u);   // fetched while this node is worked on
+            const uint32_t deg = r.y & 0xFFFFu;
+            int32_t g[NPW], m = CL_NEG_INF;
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) g[k] = (r.y >> 31) ? -P.oe[k] : CL_NEG_INF;
+            if (deg == 1 && r.x == v - 1) {
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) g[k] = imax(g[k], prev[k] - P.ext[k]);
+            } else {
+                for (uint32_t e = 0; e < deg; ++e) {
+                    const uint32_t p = deg == 1 ? r.x : lst[r.x + e];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) g[k] = imax(g[k], bnd[(size_t)p * BP + 1 + k] - P.ext[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) { bnd[(size_t)v * BP + 1 + k] = g[k]; m = imax(m, g[k]); prev[k] = g[k]; }
+            bnd[(size_t)v * BP] = m;
+            r = r_next;
+        }
+    }
+    __syncthreads();
+    // the boundary cells also go to the HBM planes (the traceback reads them), all lanes at once
+    for (uint32_t i = tid; i <= n1 + n2; i += BLOCK) {
+        const bool row = i > n1;                       // i in [0, n1]: cell (i, 0); i in (n1, n1+n2]: cell (0, i - n1)
+        const uint32_t v = row ? i - n1 : i;
+        const int32_t* bnd = (row ? brow : bcol) + (size_t)v * BP;
+        const uint32_t c = row ? G.idx(0, v) : G.idx(v, 0);
+        pl.M()[c] = bnd[0];
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            pl.I(k)[c] = row ? CL_NEG_INF : bnd[1 + k];
+            pl.D(k)[c] = row ? bnd[1 + k] : CL_NEG_INF;
+        }
+    }
+
+    auto ring_cell = [&](uint32_t x, uint32_t y) -> int32_t* {
+        const uint32_t d = x + y;
+        return ring + ((size_t)(d & mask) * width + (x - G.lo(d))) * PL;
+    };
+    const uint32_t last = n1 + n2, drain_every = depth >= 2 ? depth / 2 : 1u;
+    uint32_t off = 3;   // G.off(2): cells on anti-diagonals 0 and 1
+    for (uint32_t d = 2; d <= last; ++d) {
+        const uint32_t lo_full = G.lo(d), cnt_full = G.hi(d) - lo_full + 1;
+        const uint32_t lo = lo_full ? lo_full : 1u, hi = (d - 1 < n1) ? d - 1 : n1;   // interior cells: a >= 1, b >= 1
+        for (uint32_t a = lo + tid; a <= hi; a += BLOCK) {
+            const uint32_t b = d - a;
+            const uint2 r1 = rec1[a - 1], r2 = rec2[b - 1];
+            const uint32_t deg1 = r1.y & 0xFFFFu, deg2 = r2.y & 0xFFFFu;
+            const bool src1 = r1.y >> 31, src2 = r2.y >> 31;
+            auto cellM = [&](uint32_t x, uint32_t y) -> int32_t { if (d - (x + y) < depth) return ring_cell(x, y)[0]; return pl.M()[G.idx(x, y)]; };
+            int32_t M = CL_NEG_INF, I[NPW], D[NPW];
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) { I[k] = CL_NEG_INF; D[k] = CL_NEG_INF; }
+            for (uint32_t e = 0; e < deg1; ++e) {   // insertions: from (p, b)
+                const uint32_t pa = deg1 == 1 ? r1.x : pl1[r1.x + e];
+                if (d - (pa + b) < depth) {
+                    const int32_t* c = ring_cell(pa, b);
+                    const int32_t m = c[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], c[1 + k] - P.ext[k]));
+                } else {
+                    const uint32_t c = G.idx(pa, b);
+                    const int32_t m = pl.M()[c];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], pl.I(k)[c] - P.ext[k]));
+                }
+            }
+            if (src1) {
+                const int32_t m = brow[(size_t)b * BP];
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], m - P.oe[k]);
+            }
+            for (uint32_t f = 0; f < deg2; ++f) {   // deletions: from (a, q)
+                const uint32_t pb = deg2 == 1 ? r2.x : pl2[r2.x + f];
+                if (d - (a + pb) < depth) {
+                    const int32_t* c = ring_cell(a, pb);
+                    const int32_t m = c[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], c[1 + NPW + k] - P.ext[k]));
+                } else {
+                    const uint32_t c = G.idx(a, pb);
+                    const int32_t m = pl.M()[c];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], pl.D(k)[c] - P.ext[k]));
+                }
+            }
+            if (src2) {
+                const int32_t m = bcol[(size_t)a * BP];
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], m - P.oe[k]);
+            }
+            {   // diagonal: max over predecessor pairs, the boundary index standing in for a source
+                const int32_t s = (((r1.y >> 16) & 0x7Fu) == ((r2.y >> 16) & 0x7Fu)) ? P.match : -P.mismatch;
+                for (uint32_t e = 0; e < deg1; ++e) {
+                    const uint32_t pa = deg1 == 1 ? r1.x : pl1[r1.x + e];
+                    for (uint32_t f = 0; f < deg2; ++f) {
+                        const uint32_t pb = deg2 == 1 ? r2.x : pl2[r2.x + f];
+                        M = imax(M, cellM(pa, pb) + s);
+                    }
+                    if (src2) M = imax(M, bcol[(size_t)pa * BP] + s);
+                }
+                if (src1) {
+                    for (uint32_t f = 0; f < deg2; ++f) {
+                        const uint32_t pb = deg2 == 1 ? r2.x : pl2[r2.x + f];
+                        M = imax(M, brow[(size_t)pb * BP] + s);
+                    }
+                    if (src2) M = imax(M, s);   // the corner counts as 0
+                }
+            }
+            const uint32_t self_idx = off + (a - lo_full);
+            int32_t* rc = ring + ((size_t)(d & mask) * width + (a - lo_full)) * PL;
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) {
+                M = imax(M, imax(I[k], D[k]));
+                pl.I(k)[self_idx] = I[k];
+                pl.D(k)[self_idx] = D[k];
+                rc[1 + k] = I[k];
+                rc[1 + NPW + k] = D[k];
+            }
+            pl.M()[self_idx] = M;
+            rc[0] = M;
+        }
+        off += cnt_full;
+        if (full_cover || (d & (drain_every - 1)) != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        } else {
+            __syncthreads();   // vmcnt(0): cells written depth/2 or more diagonals ago are in memory for the far reads
+        }
+    }
+    __syncthreads();
+    if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
+}
+
 template <int NPW>
 void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                         const ClScoreParams& P, hipStream_t stream) {
     if (ring_bytes) {
         if (block <= 64)
-            hipLaunchKernelGGL((popoa_general_kernel<NPW, 64, true>), dim3(n_blocks), dim3(64), ring_bytes, stream, B, plist, P);
+            hipLaunchKernelGGL((popoa_ring_kernel<NPW, 64>), dim3(n_blocks), dim3(64), ring_bytes, stream, B, plist, P);
         else if (block <= 256)
-            hipLaunchKernelGGL((popoa_general_kernel<NPW, 256, true>), dim3(n_blocks), dim3(256), ring_bytes, stream, B, plist, P);
+            hipLaunchKernelGGL((popoa_ring_kernel<NPW, 256>), dim3(n_blocks), dim3(256), ring_bytes, stream, B, plist, P);
         else
-            hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024, true>), dim3(n_blocks), dim3(1024), ring_bytes, stream, B, plist, P);
+            hipLaunchKernelGGL((popoa_ring_kernel<NPW, 1024>), dim3(n_blocks), dim3(1024), ring_bytes, stream, B, plist, P);
         return;
     }
     if (block <= 64)
