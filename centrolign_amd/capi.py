@@ -251,6 +251,11 @@ def split_branching_matches(graph1, graph2, matches, anchor_split_limit=5, min_s
     rc = lib.cl_split_branching_matches(C.byref(g1), C.byref(g2), C.byref(mc), C.byref(sp), C.byref(h))
     if rc != 0:
         raise ClError(rc)
+    return _take_owned_match_sets(lib, h)
+
+
+def _take_owned_match_sets(lib, h):
+    """copies a cl_owned_match_sets into a MatchSets and frees it"""
     try:
         v = MatchSetsC()
         lib.cl_owned_match_sets_view(h, C.byref(v))
@@ -267,6 +272,47 @@ def split_branching_matches(graph1, graph2, matches, anchor_split_limit=5, min_s
                          count2=arr(v.count2, np.uint64, n), full_length=arr(v.full_length, np.uint64, n))
     finally:
         lib.cl_owned_match_sets_free(h)
+
+
+def match_params(max_count=3000, use_color_set_size=True, params=None):
+    mp = MatchParams()
+    mp.max_count = int(max_count)
+    mp.use_color_set_size = int(use_color_set_size)
+    mp.score = params or default_chain_params()
+    return mp
+
+
+def match_joined_text(graph1, graph2):
+    """PathESA's joined path text (include/centrolign/path_esa.hpp:92-118) as a uint8 array; host only"""
+    lib = load_library()
+    g1, g2 = graph1.as_c(), graph2.as_c()
+    p, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_match_joined_text(C.byref(g1), C.byref(g2), C.byref(p), C.byref(n))
+    if rc != 0:
+        raise ClError(rc)
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(n.value),)).copy()
+    finally:
+        _libc_free(p)
+
+
+def _libc_free(p):
+    C.CDLL(None).free.argtypes = [C.c_void_p]
+    C.CDLL(None).free(p)
+
+
+def matches_from_suffix_array(graph1, graph2, sa, lcp, max_count=3000, params=None, want_stats=False):
+    """the host half of cl_find_matches (LCP-interval tree, counts, query, walk-out) on a caller-supplied suffix array + LCP
+    array of match_joined_text(graph1, graph2); host only"""
+    lib = load_library()
+    g1, g2, mp, st = graph1.as_c(), graph2.as_c(), match_params(max_count, True, params), MatchStats()
+    sa, lcp = np.ascontiguousarray(sa, np.uint32), np.ascontiguousarray(lcp, np.uint32)
+    h = C.c_void_p()
+    rc = lib.cl_matches_from_suffix_array(C.byref(g1), C.byref(g2), C.byref(mp), sa.ctypes.data, lcp.ctypes.data, len(sa), C.byref(h), C.byref(st))
+    if rc != 0:
+        raise ClError(rc)
+    ms = _take_owned_match_sets(lib, h)
+    return (ms, st.as_dict()) if want_stats else ms
 
 
 def extract_stitch_batch(graph1, graph2, segments):
@@ -324,6 +370,20 @@ class SplitParams(C.Structure):
     """cl_split_params: Anchorer::anchor_split_limit, min_split_length, min_path_length_spread, max_split_match_set_size"""
     _fields_ = [("anchor_split_limit", C.c_uint64), ("min_split_length", C.c_uint64), ("min_path_length_spread", C.c_uint64),
                 ("max_split_match_set_size", C.c_uint64)]
+
+
+class MatchParams(C.Structure):
+    """cl_match_params: BaseMatchFinder::max_count, use_color_set_size + the ScoreFunction of the positive-weight filter"""
+    _fields_ = [("max_count", C.c_uint64), ("use_color_set_size", C.c_int), ("score", ChainParams)]
+
+
+class MatchStats(C.Structure):
+    """cl_match_stats"""
+    _fields_ = [("text_length", C.c_uint64), ("doubling_rounds", C.c_uint32), ("n_internal_nodes", C.c_uint64), ("n_candidates", C.c_uint64),
+                ("sa_ms", C.c_float), ("lcp_ms", C.c_float), ("tree_ms", C.c_double), ("query_ms", C.c_double), ("walk_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class AnchorParams(C.Structure):
@@ -688,6 +748,18 @@ def load_library(path=None):
     lib.cl_owned_match_sets_view.argtypes = [C.c_void_p, C.POINTER(MatchSetsC)]
     lib.cl_owned_match_sets_free.restype = None
     lib.cl_owned_match_sets_free.argtypes = [C.c_void_p]
+    lib.cl_match_params_default.restype = None
+    lib.cl_match_params_default.argtypes = [C.POINTER(MatchParams)]
+    lib.cl_find_matches.restype = C.c_int
+    lib.cl_find_matches.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchParams), C.POINTER(C.c_void_p),
+                                    C.POINTER(MatchStats)]
+    lib.cl_match_joined_text.restype = C.c_int
+    lib.cl_match_joined_text.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cl_suffix_array_lcp.restype = C.c_int
+    lib.cl_suffix_array_lcp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.cl_matches_from_suffix_array.restype = C.c_int
+    lib.cl_matches_from_suffix_array.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchParams), C.c_void_p, C.c_void_p,
+                                                 C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(MatchStats)]
     lib.cl_anchor_chain.restype = C.c_int
     lib.cl_anchor_chain.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC),
                                     C.POINTER(AnchorParams), C.POINTER(AnchorChainResultC)]
@@ -710,6 +782,7 @@ EXPORTED_SYMBOLS = [
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
+    "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
 ]
 
 
@@ -835,6 +908,25 @@ class Context:
                         end_gap_scores=(float(out.gap_score_before_first), float(out.gap_score_after_last)))
         finally:
             self.lib.cl_chain_result_free(C.byref(out))
+
+    def find_matches(self, graph1, graph2, max_count=3000, use_color_set_size=True, params=None, want_stats=False):
+        """PathMatchFinder::find_matches (include/centrolign/match_finder.hpp:120-212): suffix array + LCP on the device, the
+        minimal-rare-match query on the host.  Returns MatchSets (and the cl_match_stats dict)."""
+        g1, g2, mp, st = graph1.as_c(), graph2.as_c(), match_params(max_count, use_color_set_size, params), MatchStats()
+        h = C.c_void_p()
+        self._check(self.lib.cl_find_matches(self.handle, C.byref(g1), C.byref(g2), C.byref(mp), C.byref(h), C.byref(st)))
+        ms = _take_owned_match_sets(self.lib, h)
+        return (ms, st.as_dict()) if want_stats else ms
+
+    def suffix_array_lcp(self, text):
+        """device suffix array / LCP array / inverse suffix array of a uint8 text ending in a unique smallest character;
+        returns (sa, lcp, isa, rounds)"""
+        text = np.ascontiguousarray(text, np.uint8)
+        n = len(text)
+        sa, lcp, isa = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        rounds = C.c_uint32(0)
+        self._check(self.lib.cl_suffix_array_lcp(self.handle, text.ctypes.data, n, sa.ctypes.data, lcp.ctypes.data, isa.ctypes.data, C.byref(rounds)))
+        return sa, lcp, isa, int(rounds.value)
 
     def anchor_chain(self, graph1, graph2, matches, max_num_match_pairs=1250000, score_scale=1.0, autocalibrate=True,
                      params=None, fill_in=True):

@@ -134,10 +134,6 @@ int cl_despecify_indel_breakpoints(uint64_t n_anchors, const double* score, int6
 // =====================================================================================================================
 #include "stitch_host.hpp"
 
-struct cl_owned_match_sets {
-    std::vector<uint64_t> set_off1{0}, walk_off1{0}, set_off2{0}, walk_off2{0}, count1, count2, full_length;
-    std::vector<uint32_t> nodes1, nodes2;
-};
 
 namespace {
 

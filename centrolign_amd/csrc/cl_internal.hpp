@@ -60,6 +60,13 @@ struct DevBuf {
 };
 
 
+// std::vector<match_set_t> owned by the library (cl_split_branching_matches, cl_find_matches); layout of cl_match_sets
+#include <vector>
+struct cl_owned_match_sets {
+    std::vector<uint64_t> set_off1{0}, walk_off1{0}, set_off2{0}, walk_off2{0}, count1, count2, full_length;
+    std::vector<uint32_t> nodes1, nodes2;
+};
+
 // host-side parallel loop over [0, n): f(begin, end) on up to 16 threads (the reference is single-threaded; the host glue
 // around the device passes is not part of the compared arithmetic, every iteration writes its own outputs)
 #include <thread>

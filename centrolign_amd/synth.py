@@ -288,14 +288,15 @@ def batch_from_intervals(seq1, seq2, intervals, only_del=None):
     return StitchBatch(sides[0], sides[1], od)
 
 
-def base_graph_from_sequence(seq):
+def base_graph_from_sequence(seq, sentinels=(5, 6)):
     """capi.BaseGraph of one sequence as the reference builds a leaf subproblem: one node per base in a chain, one path over
-    them, plus the two sentinel nodes of add_sentinels (source before the first base, sink after the last; labels 5 and 6)"""
+    them, plus the two sentinel nodes of add_sentinels (source before the first base, sink after the last; labels 5 and 6,
+    or 7 and 8 for the second graph of a merge)"""
     from . import capi
     e = encode(seq) if isinstance(seq, str) else np.asarray(seq, np.uint8)
     n = len(e)
     src, snk = n, n + 1
-    label = np.concatenate([e, [5, 6]]).astype(np.uint8)
+    label = np.concatenate([e, list(sentinels)]).astype(np.uint8)
     nxt = [[i + 1] for i in range(n - 1)] + ([[snk]] if n else []) + [[0] if n else [snk], []]
     prv = ([[src]] if n else []) + [[i - 1] for i in range(1, n)] + [[], [n - 1] if n else [src]]
     def csr(lists):
@@ -305,6 +306,66 @@ def base_graph_from_sequence(seq):
     no, ni = csr(nxt)
     po_, pi = csr(prv)
     return capi.BaseGraph(label, no, ni, po_, pi, np.array([0, n], np.uint64), np.arange(n, dtype=np.uint32), src, snk)
+
+
+def bubble_graph(ancestor, n_paths, seed=0, alt_p=0.05, skip_p=0.02, sentinels=(5, 6)):
+    """capi.BaseGraph shaped like a merged subproblem: n_paths embedded paths over a DAG made of the ancestor's chain plus
+    bubbles.  Each path follows the ancestor, at some positions stepping through an alternative node (one per position and
+    base, shared by the paths that take it) or skipping the position; edges are the path adjacencies, the sentinels hang
+    before / after the path ends."""
+    from . import capi
+    rng = np.random.default_rng(seed)
+    anc = encode(ancestor) if isinstance(ancestor, str) else np.asarray(ancestor, np.uint8)
+    n = len(anc)
+    labels = list(anc)
+    alt = {}
+    paths = []
+    for _ in range(n_paths):
+        p = []
+        for i in range(n):
+            r = rng.random()
+            if r < skip_p and 0 < i < n - 1:
+                continue
+            if r < skip_p + alt_p:
+                b = int((anc[i] + 1 + rng.integers(0, 3)) % 4)
+                if (i, b) not in alt:
+                    alt[(i, b)] = len(labels)
+                    labels.append(b)
+                p.append(alt[(i, b)])
+            else:
+                p.append(i)
+        paths.append(p)
+    # keep node ids topologically ordered: ancestor position first, alternatives after the position they shadow
+    key = {v: (v, 0) for v in range(n)}
+    for (i, b), v in alt.items():
+        key[v] = (i, 1 + b)
+    used = sorted({v for p in paths for v in p}, key=lambda v: key[v])
+    remap = {v: k for k, v in enumerate(used)}
+    m = len(used)
+    src, snk = m, m + 1
+    label = np.array([labels[v] for v in used] + list(sentinels), np.uint8)
+    nxt = [[] for _ in range(m + 2)]
+    prv = [[] for _ in range(m + 2)]
+    def edge(a, b):
+        if b not in nxt[a]:
+            nxt[a].append(b)
+            prv[b].append(a)
+    path_nodes, path_off = [], [0]
+    for p in paths:
+        q = [remap[v] for v in p]
+        edge(src, q[0])
+        for a, b in zip(q[:-1], q[1:]):
+            edge(a, b)
+        edge(q[-1], snk)
+        path_nodes.extend(q)
+        path_off.append(len(path_nodes))
+    def csr(lists):
+        off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+        idx = np.array([v for x in lists for v in x], np.uint32)
+        return off, idx
+    no, ni = csr(nxt)
+    po_, pi = csr(prv)
+    return capi.BaseGraph(label, no, ni, po_, pi, np.array(path_off, np.uint64), np.array(path_nodes, np.uint32), src, snk)
 
 
 def exact_matches(seq1, seq2, k=12, max_sets=None):

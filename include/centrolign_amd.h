@@ -365,6 +365,41 @@ int  cl_split_branching_matches(const cl_base_graph* graph1, const cl_base_graph
 void cl_owned_match_sets_view(const cl_owned_match_sets* sets, cl_match_sets* view_out);
 void cl_owned_match_sets_free(cl_owned_match_sets* sets);
 
+/* --- PathMatchFinder::find_matches (include/centrolign/match_finder.hpp:73-85,120-212) ----------------
+ * The minimal rare matches between the embedded paths of two merge graphs, as Core calls it for every merge
+ * (include/centrolign/core.hpp:289): the index the reference builds with PathESA (path_esa.hpp:81-170: SA-IS suffix array,
+ * Kasai LCP) comes from the device (suffix array by prefix doubling on radix sorts, LCP by a descent over the kept rank
+ * levels); the LCP-interval tree, Hui's distinct-start-node counts (src/esa.cpp:149-300), the query
+ * (esa.hpp:284-494) and the walk-out (esa.hpp:610-665) are one linear host pass each.  The sentinel characters are the labels
+ * of graph.src_id / graph.snk_id (SentinelTableau::src_sentinel / snk_sentinel); labels must be < 255.  The result holds
+ * the match sets in the reference's order, count1 / count2 / full_length set as match_finder.hpp:199-203 does. */
+typedef struct cl_match_params {
+    uint64_t        max_count;            /* BaseMatchFinder::max_count: count1 * count2 bound (CLI 3000, src/parameters.cpp:36) */
+    int             use_color_set_size;   /* BaseMatchFinder::use_color_set_size: the reference's two counting structures
+                                             (esa.hpp:208-279) return the same counts; accepted for interface parity */
+    cl_chain_params score;                /* ScoreFunction of the positive-weight filter (match_finder.hpp:162); only the four
+                                             ScoreFunction fields are read */
+} cl_match_params;
+void cl_match_params_default(cl_match_params* p);
+typedef struct cl_match_stats {
+    uint64_t text_length;        /* joined path text incl. sentinels */
+    uint32_t doubling_rounds;    /* device suffix-sort rounds */
+    uint64_t n_internal_nodes;   /* LCP intervals */
+    uint64_t n_candidates;       /* (parent, internal child) pairs examined */
+    float    sa_ms, lcp_ms;      /* device time */
+    double   tree_ms, query_ms, walk_ms;   /* host passes */
+} cl_match_stats;
+int cl_find_matches(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_params* params,
+                    cl_owned_match_sets** out, cl_match_stats* stats /* may be NULL */);
+/* The two halves separately.  cl_match_joined_text: PathESA's joined_seq (path_esa.hpp:92-118; malloc'ed, release with free()).
+ * cl_suffix_array_lcp: the device half on any text that ends in a unique smallest character (sa / lcp / isa: n entries
+ * each, lcp[0] = 0).  cl_matches_from_suffix_array: the host half for a caller that already holds the suffix array and LCP
+ * array of cl_match_joined_text's text (no device needed). */
+int cl_match_joined_text(const cl_base_graph* graph1, const cl_base_graph* graph2, uint8_t** text_out, uint64_t* n_out);
+int cl_suffix_array_lcp(cl_context* ctx, const uint8_t* text, uint64_t n, uint32_t* sa, uint32_t* lcp, uint32_t* isa, uint32_t* rounds_out);
+int cl_matches_from_suffix_array(const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_params* params, const uint32_t* sa,
+                                 const uint32_t* lcp, uint64_t n, cl_owned_match_sets** out, cl_match_stats* stats /* may be NULL */);
+
 /* --- Anchorer::anchor_chain (include/centrolign/anchorer.hpp:135-145, 958-1329), no masks, after
  * cl_split_branching_matches (the caller runs it first, as anchor_chain does at :971-973): budgeted match selection (which REORDERS the caller's match sets, :1108-1173),
  * scale estimation (:998-1047), the affine chain, gap and score annotation (:2443-2468), and — with

@@ -338,6 +338,11 @@ def ref_split_branching_matches(g1, g2, ms, anchor_split_limit=5, min_split_leng
                                          max_split_match_set_size, C.addressof(n), C.addressof(rows_p), C.addressof(nodes_p), C.addressof(nn))
     if rc:
         raise RuntimeError("ref_split_branching_matches failed: %d" % rc)
+    return _match_sets_from_rows(lib, n, nn, rows_p, nodes_p)
+
+
+def _match_sets_from_rows(lib, n, nn, rows_p, nodes_p):
+    """(rows, nodes) as the ref_* functions return them -> MatchSets; frees the two buffers"""
     k, tot = int(n.value), int(nn.value)
     rows = np.ctypeslib.as_array(C.cast(rows_p, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 6,))[:6 * k].copy().reshape(k, 6)
     nodes = np.ctypeslib.as_array(C.cast(nodes_p, C.POINTER(C.c_uint32)), shape=(max(tot, 1),))[:tot].copy()
@@ -351,10 +356,30 @@ def ref_split_branching_matches(g1, g2, ms, anchor_split_limit=5, min_split_leng
     # nodes: per set its graph-1 walks then its graph-2 walks
     per_set = (n1 + n2) * ln
     start = np.concatenate([[0], np.cumsum(per_set)])
-    nodes1 = np.concatenate([nodes[start[s]:start[s] + n1[s] * ln[s]] for s in range(k)]) if k else np.zeros(0, np.uint32)
-    nodes2 = np.concatenate([nodes[start[s] + n1[s] * ln[s]:start[s + 1]] for s in range(k)]) if k else np.zeros(0, np.uint32)
+    # nodes of set s: [start[s], start[s] + n1*ln) belong to graph 1, the rest to graph 2
+    owner = np.repeat(np.arange(k), per_set) if k else np.zeros(0, np.int64)
+    in1 = (np.arange(len(nodes)) - start[owner]) < (n1 * ln)[owner] if k else np.zeros(0, bool)
+    nodes1, nodes2 = nodes[in1], nodes[~in1]
     return MatchSets(set_off1=so1, walk_off1=wo1, nodes1=nodes1, set_off2=so2, walk_off2=wo2, nodes2=nodes2,
                      count1=rows[:, 3], count2=rows[:, 4], full_length=rows[:, 5])
+
+
+def ref_find_matches(g1, g2, max_count=50, use_color_set_size=True, params=None):
+    """the compiled reference's PathMatchFinder::find_matches (match_finder.hpp:120-212); returns MatchSets"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_find_matches.restype = C.c_int
+    lib.ref_find_matches.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloChainParams), C.c_uint64, C.c_int] + [C.c_void_p] * 4
+    lib.ref_free.argtypes = [C.c_void_p]
+    params = params or default_chain_params()
+    c1, c2 = g1.as_c(), g2.as_c()
+    n, nn = C.c_uint64(0), C.c_uint64(0)
+    rows_p, nodes_p = C.c_void_p(), C.c_void_p()
+    rc = lib.ref_find_matches(C.byref(c1), C.byref(c2), C.byref(params), int(max_count), int(bool(use_color_set_size)),
+                              C.addressof(n), C.addressof(rows_p), C.addressof(nodes_p), C.addressof(nn))
+    if rc:
+        raise RuntimeError("ref_find_matches failed: %d" % rc)
+    return _match_sets_from_rows(lib, n, nn, rows_p, nodes_p)
 
 
 def ref_partition_anchors(g1, g2, chain, score_scale=1.0, score_boundaries=False, use_annotated_score=False, params=None,
@@ -383,3 +408,49 @@ def ref_partition_anchors(g1, g2, chain, score_scale=1.0, score_boundaries=False
     if rc:
         raise RuntimeError("ref_partition_anchors failed: %d" % rc)
     return seg[:int(ns.value)].copy()
+
+
+_match = None
+MATCH_LIB = os.path.join(_HERE, "_build", "libcl_match_oracle.so")
+
+
+def match_lib():
+    global _match
+    if _match is None:
+        if not os.path.exists(MATCH_LIB):
+            build_oracle()
+        from centrolign_amd.capi import BaseGraphC
+        lib = C.CDLL(MATCH_LIB)
+        lib.clo_find_matches.restype = C.c_int
+        lib.clo_find_matches.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloChainParams), C.c_uint64] + [C.c_void_p] * 4
+        lib.clo_suffix_array_lcp.restype = C.c_int
+        lib.clo_suffix_array_lcp.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        lib.clo_free.argtypes = [C.c_void_p]
+        lib.ref_free = lib.clo_free
+        _match = lib
+    return _match
+
+
+def oracle_find_matches(g1, g2, max_count=3000, params=None):
+    """match_oracle.cpp's restatement of PathMatchFinder::find_matches; returns MatchSets"""
+    lib = match_lib()
+    params = params or default_chain_params()
+    c1, c2 = g1.as_c(), g2.as_c()
+    n, nn = C.c_uint64(0), C.c_uint64(0)
+    rows_p, nodes_p = C.c_void_p(), C.c_void_p()
+    rc = lib.clo_find_matches(C.byref(c1), C.byref(c2), C.byref(params), int(max_count), C.addressof(n), C.addressof(rows_p),
+                              C.addressof(nodes_p), C.addressof(nn))
+    if rc:
+        raise RuntimeError("clo_find_matches failed: %d" % rc)
+    return _match_sets_from_rows(lib, n, nn, rows_p, nodes_p)
+
+
+def oracle_suffix_array_lcp(text):
+    """(suffix array, LCP array) of a uint8 text that ends in a unique smallest character (path_esa.hpp:174-200)"""
+    lib = match_lib()
+    text = np.ascontiguousarray(text, np.uint8)
+    sa, lcp = np.zeros(len(text), np.uint32), np.zeros(len(text), np.uint32)
+    rc = lib.clo_suffix_array_lcp(text.ctypes.data, len(text), sa.ctypes.data, lcp.ctypes.data)
+    if rc:
+        raise RuntimeError("clo_suffix_array_lcp failed: %d" % rc)
+    return sa, lcp

@@ -626,6 +626,40 @@ int ref_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2
     return 0;
 }
 
+/* PathMatchFinder::find_matches (match_finder.hpp:120-131 -> query_index :133-212 -> PathESA) on flat inputs; the sentinel
+ * characters are the labels of the tableau nodes.  Output rows/nodes as ref_split_branching_matches. */
+int ref_find_matches(const cl_base_graph* g1, const cl_base_graph* g2, const clo_chain_params* cp, uint64_t max_count, int use_css,
+                     uint64_t* n_sets_out, uint64_t** rows_out, uint32_t** nodes_out, uint64_t* n_nodes_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    t1.src_sentinel = (char)g1->label[g1->src_id]; t1.snk_sentinel = (char)g1->label[g1->snk_id];
+    t2.src_sentinel = (char)g2->label[g2->src_id]; t2.snk_sentinel = (char)g2->label[g2->snk_id];
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    PathMatchFinder mf(sf);
+    mf.max_count = max_count;
+    mf.use_color_set_size = use_css != 0;
+    std::vector<match_set_t> sets = mf.find_matches(b1, b2, t1, t2);
+    *n_sets_out = sets.size();
+    uint64_t total = 0;
+    for (const auto& st : sets) { for (const auto& w : st.walks1) total += w.size(); for (const auto& w : st.walks2) total += w.size(); }
+    *rows_out = (uint64_t*)malloc((sets.size() ? sets.size() : 1) * 6 * sizeof(uint64_t));
+    *nodes_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+    *n_nodes_out = total;
+    uint64_t pos = 0;
+    for (size_t s = 0; s < sets.size(); ++s) {
+        uint64_t* row = *rows_out + 6 * s;
+        row[0] = sets[s].walks1.size(); row[1] = sets[s].walks2.size(); row[2] = sets[s].walks1.front().size();
+        row[3] = sets[s].count1; row[4] = sets[s].count2; row[5] = sets[s].full_length;
+        for (const auto& w : sets[s].walks1) for (auto v : w) (*nodes_out)[pos++] = (uint32_t)v;
+        for (const auto& w : sets[s].walks2) for (auto v : w) (*nodes_out)[pos++] = (uint32_t)v;
+    }
+    return 0;
+}
+
 /* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as
  * cl_despecify_indel_breakpoints */
 int ref_despecify(uint64_t n, const double* score, int64_t* gap_before, double* gap_score_before, int64_t* gap_after,

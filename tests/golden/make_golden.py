@@ -85,7 +85,43 @@ def ref_results(batch, params, with_forced=True):
     return out
 
 
+def match_finding_goldens():
+    # 10. PathMatchFinder::find_matches (match_finder.hpp:120-212): the seeded inputs of tests/helpers.match_cases() -> the
+    #     reference's match sets in full; the leaf-pair merges of the 4 x 30 kbp MSA (graphs in stitch4_30k_merge*.npz) -> per-set
+    #     counts/lengths and a digest (the root merge's sets are align4_30k_merge2.npz "ms.*" in full)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests import helpers as H
+    from tests.test_extraction import load_stitch_case
+    out = {}
+    names = []
+    for name, g1, g2, mc in H.match_cases():
+        r = po.ref_find_matches(g1, g2, max_count=mc)
+        names.append(name)
+        for k in po.MatchSets._DT:
+            out["%s.%s" % (name, k)] = getattr(r, k)
+        print(name, "max_count", mc, "->", r.n_sets, "sets")
+    for m in (0, 1, 2):
+        _, graphs, _ = load_stitch_case("stitch4_30k_merge%d.npz" % m)
+        r = po.ref_find_matches(graphs[0], graphs[1], max_count=3000)
+        pre = "merge%d." % m
+        for k in ("count1", "count2", "full_length"):
+            out[pre + k] = getattr(r, k)
+        out[pre + "digest"] = np.array([H.match_sets_digest(r)])
+        print("merge", m, "->", r.n_sets, "sets")
+    # the BASELINE pair (2 x 1 Mbp, seed 7): digest only
+    from centrolign_amd import synth
+    seqs = synth.hor_sequences(7, 1000000, 2)
+    r = po.ref_find_matches(synth.base_graph_from_sequence(seqs[0]), synth.base_graph_from_sequence(seqs[1], sentinels=(7, 8)), max_count=3000)
+    out["c2.n_sets"] = np.array([r.n_sets])
+    out["c2.digest"] = np.array([H.match_sets_digest(r)])
+    print("c2 ->", r.n_sets, "sets")
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "match_finder.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "match":
+        return match_finding_goldens()
     sp = capi.default_stitch_params()
     # 1. random DAG pairs, CLI scoring
     b = synth.random_dag_batch(400, seed=20261002, max_n=36)
@@ -279,6 +315,7 @@ def main():
             out[pre + name] = arr
     out["n_cases"] = np.array([n_cases])
     np.savez_compressed(os.path.join(HERE, "despecify.npz"), **out)
+    match_finding_goldens()
     print("golden vectors written to", HERE)
 
 

@@ -160,3 +160,45 @@ class host_route_batches:
         db.only_deletion_alns[:] = 1
         out["mixed_dags"] = (db, sp)
         return out
+
+
+def match_cases():
+    """seeded inputs of the match-finding parity tests: (name, graph1, graph2, max_count).  Tandem-repeat ancestors at
+    several divergences; leaf pairs (one chain, one path each) and merged-subproblem-like graphs (several paths over a DAG
+    with bubbles); the second graph usually carries its own sentinel characters (7, 8) as in a real merge."""
+    cases = []
+    for seed in range(24):
+        rng = np.random.default_rng(1000 + seed)
+        L = int(rng.integers(20, 3000))
+        unit = rng.integers(0, 4, int(rng.integers(3, 60))).astype(np.uint8)
+        anc = np.tile(unit, L // len(unit) + 1)[:L].copy()
+        mut = rng.random(L) < rng.choice([0.0, 0.01, 0.05, 0.3])
+        anc[mut] = rng.integers(0, 4, int(mut.sum()))
+        if seed % 3 == 0:
+            a2 = anc.copy()
+            m2 = rng.random(L) < 0.02
+            a2[m2] = rng.integers(0, 4, int(m2.sum()))
+            g1 = synth.base_graph_from_sequence(anc)
+            g2 = synth.base_graph_from_sequence(a2[: L - int(rng.integers(0, 10))], sentinels=(7, 8))
+        else:
+            g1 = synth.bubble_graph(anc, int(rng.integers(1, 5)), seed=seed)
+            g2 = synth.bubble_graph(anc, int(rng.integers(1, 5)), seed=seed + 1000, sentinels=(7, 8) if seed % 2 else (5, 6))
+        cases.append(("rand%02d" % seed, g1, g2, int((1, 4, 50, 3000)[seed % 4])))
+    # degenerate: a one-base pair, identical sequences, a homopolymer against itself, nothing in common
+    one = np.array([2], np.uint8)
+    same = np.random.default_rng(7).integers(0, 4, 500).astype(np.uint8)
+    cases.append(("one_base", synth.base_graph_from_sequence(one), synth.base_graph_from_sequence(one, sentinels=(7, 8)), 3000))
+    cases.append(("identical", synth.base_graph_from_sequence(same), synth.base_graph_from_sequence(same, sentinels=(7, 8)), 3000))
+    cases.append(("homopolymer", synth.base_graph_from_sequence(np.zeros(300, np.uint8)),
+                  synth.base_graph_from_sequence(np.zeros(280, np.uint8), sentinels=(7, 8)), 3000))
+    cases.append(("disjoint", synth.base_graph_from_sequence(np.zeros(50, np.uint8)),
+                  synth.base_graph_from_sequence(np.ones(50, np.uint8), sentinels=(7, 8)), 3000))
+    return cases
+
+
+def match_sets_digest(ms):
+    """sha256 over every array of a MatchSets (for fixtures too large to commit in full)"""
+    h = hashlib.sha256()
+    for k in capi.MatchSets._DT:
+        h.update(np.ascontiguousarray(getattr(ms, k)).tobytes())
+    return h.hexdigest()
