@@ -7,6 +7,7 @@
 //   TableauT    : .src_id, .snk_id                                                           (include/centrolign/modify_graph.hpp:33-38)
 //   MatchSetT   : .walks1, .walks2 (vector<vector<uint64_t>>), .count1, .count2, .full_length (include/centrolign/match_finder.hpp:21-34)
 //   CoreT       : .anchorer, .partitioner, .stitcher, .score_function with their public tunables (include/centrolign/core.hpp:70-103)
+//   MatchFinderT: .max_count, .use_color_set_size                                             (include/centrolign/match_finder.hpp:52-54)
 #ifndef CENTROLIGN_AMD_CORE_ADAPTER_HPP
 #define CENTROLIGN_AMD_CORE_ADAPTER_HPP
 
@@ -130,6 +131,47 @@ std::vector<AlignedPairT> core_align(Device& dev, const BaseGraphT& graph1, cons
     out.reserve(r.alignment.n_pairs);
     for (uint64_t i = 0; i < r.alignment.n_pairs; ++i) out.emplace_back(r.alignment.pairs[2 * i], r.alignment.pairs[2 * i + 1]);
     cl_core_align_result_free(&r);
+    return out;
+}
+
+// the tunables PathMatchFinder::find_matches reads (match_finder.hpp:52-54) + the ScoreFunction of its weight filter
+template <class MatchFinderT, class ScoreFunctionT>
+cl_match_params match_params_of(const MatchFinderT& finder, const ScoreFunctionT& score_function) {
+    cl_match_params p;
+    cl_match_params_default(&p);
+    p.max_count = finder.max_count;
+    p.use_color_set_size = finder.use_color_set_size ? 1 : 0;
+    p.score.anchor_score_function = (int)score_function.anchor_score_function;
+    p.score.pair_count_power = score_function.pair_count_power;
+    p.score.length_intercept = score_function.length_intercept;
+    p.score.length_decay_power = score_function.length_decay_power;
+    return p;
+}
+
+// PathMatchFinder::find_matches (match_finder.hpp:120-131) through the library: same arguments, same std::vector<match_set_t>
+template <class MatchSetT, class BaseGraphT, class TableauT>
+std::vector<MatchSetT> find_matches(Device& dev, const BaseGraphT& graph1, const BaseGraphT& graph2, const TableauT& tableau1,
+                                    const TableauT& tableau2, const cl_match_params& params) {
+    FlatBaseGraph g1(graph1, tableau1), g2(graph2, tableau2);
+    // the sentinel characters travel as the labels of the sentinel nodes (Core::do_execution reassigns them before every
+    // merge, core.hpp:283-286)
+    if (g1.view.n_nodes) { g1.label[tableau1.src_id] = (uint8_t)tableau1.src_sentinel; g1.label[tableau1.snk_id] = (uint8_t)tableau1.snk_sentinel; }
+    if (g2.view.n_nodes) { g2.label[tableau2.src_id] = (uint8_t)tableau2.src_sentinel; g2.label[tableau2.snk_id] = (uint8_t)tableau2.snk_sentinel; }
+    cl_owned_match_sets* owned = nullptr;
+    if (int rc = cl_find_matches(dev.get(), &g1.view, &g2.view, &params, &owned, nullptr))
+        throw std::runtime_error(std::string("cl_find_matches failed (") + std::to_string(rc) + "): " + cl_last_error(dev.get()));
+    cl_match_sets v;
+    cl_owned_match_sets_view(owned, &v);
+    std::vector<MatchSetT> out(v.n_sets);
+    for (uint64_t s = 0; s < v.n_sets; ++s) {
+        MatchSetT& m = out[s];
+        for (uint64_t w = v.set_off1[s]; w < v.set_off1[s + 1]; ++w) m.walks1.emplace_back(v.nodes1 + v.walk_off1[w], v.nodes1 + v.walk_off1[w + 1]);
+        for (uint64_t w = v.set_off2[s]; w < v.set_off2[s + 1]; ++w) m.walks2.emplace_back(v.nodes2 + v.walk_off2[w], v.nodes2 + v.walk_off2[w + 1]);
+        m.count1 = v.count1[s];
+        m.count2 = v.count2[s];
+        m.full_length = v.full_length[s];
+    }
+    cl_owned_match_sets_free(owned);
     return out;
 }
 

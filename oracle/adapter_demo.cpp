@@ -103,6 +103,7 @@ struct DemoCore : public Core {
     }
 
     bool whole_align = false;
+    double t_match_cpu = 0, t_match_gpu = 0;
 
     // Core::align both ways from the same matches (anchor_chain reorders and extends its argument, so each side gets a copy)
     template <class XMerge>
@@ -133,7 +134,23 @@ struct DemoCore : public Core {
             auto& sp2 = *std::get<2>(ptrs);
             reassign_sentinels(sp1.graph, sp1.tableau, 5, 6);
             reassign_sentinels(sp2.graph, sp2.tableau, 7, 8);
+            using clk = std::chrono::steady_clock;
+            auto m0 = clk::now();
             auto matches = path_match_finder.find_matches(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau);
+            t_match_cpu += std::chrono::duration<double>(clk::now() - m0).count();
+            if (whole_align) {   // PathMatchFinder::find_matches through the library, from the same reference objects
+                auto m1 = clk::now();
+                auto ours = centrolign_amd::find_matches<match_set_t>(*dev, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau,
+                                                                      centrolign_amd::match_params_of(path_match_finder, score_function));
+                t_match_gpu += std::chrono::duration<double>(clk::now() - m1).count();
+                bool same = ours.size() == matches.size();
+                for (size_t i = 0; same && i < ours.size(); ++i)
+                    same = ours[i].walks1 == matches[i].walks1 && ours[i].walks2 == matches[i].walks2 && ours[i].count1 == matches[i].count1 &&
+                           ours[i].count2 == matches[i].count2 && ours[i].full_length == matches[i].full_length;
+                if (!same) ++mismatched;
+                printf("merge %zu: %zu match sets, GPU find_matches %s the reference\n", merges, matches.size(), same ? "==" : "!=");
+                matches = std::move(ours);
+            }
             PathMerge<uint32_t, uint8_t> pm1(sp1.graph, sp1.tableau);
             PathMerge<uint32_t, uint8_t> pm2(sp2.graph, sp2.tableau);
             next_problem.alignment = whole_align ? align_core_both(matches, sp1, sp2, pm1, pm2) : align_both(matches, sp1, sp2, pm1, pm2);
@@ -178,7 +195,11 @@ int main(int argc, char** argv) {
         core.whole_align = argc > 4 && std::string(argv[4]) == "core";
         core.run();
         if (core.whole_align)
+        {
+            printf("%zu merges, find_matches: reference CPU %.3f s, adapter+GPU %.3f s (incl. flattening and rebuilding the vectors)\n", core.merges,
+                   core.t_match_cpu, core.t_match_gpu);
             printf("%zu merges, Core::align: reference CPU %.3f s, adapter+GPU %.3f s (incl. flattening)\n", core.merges, core.t_cpu, core.t_gpu);
+        }
         else
             printf("%zu merges, %zu subproblems, subalign loop: reference CPU %.3f s, adapter+GPU %.3f s (incl. flatten, H2D, D2H)\n",
                    core.merges, core.problems, core.t_cpu, core.t_gpu);
