@@ -150,6 +150,35 @@ def chaining_section(ctx, with_reference):
     return out
 
 
+def match_section(ctx, with_reference):
+    """the row before the hot path: PathMatchFinder::find_matches on the same 2 x 1 Mbp pair — suffix
+    array + LCP on the device, the minimal-rare-match query on the host — checked against the digest of the compiled
+    reference's output (tests/golden/match_finder.npz "c2.*") and timed beside the reference where oracle/_ref exists"""
+    from centrolign_amd import capi, synth
+    from tests import helpers as H
+    seqs = synth.hor_sequences(7, 1000000, 2)
+    g1 = synth.base_graph_from_sequence(seqs[0])
+    g2 = synth.base_graph_from_sequence(seqs[1], sentinels=(7, 8))
+    ctx.find_matches(g1, g2)   # warm-up
+    t0 = time.perf_counter()
+    ms, st = ctx.find_matches(g1, g2, want_stats=True)
+    wall = time.perf_counter() - t0
+    z = np.load(os.path.join(H.GOLDEN, "match_finder.npz"))
+    out = {"seam": "PathMatchFinder::find_matches", "text_length": st["text_length"], "match_sets": ms.n_sets, "wall_s": wall,
+           "device_suffix_array_ms": st["sa_ms"], "device_lcp_ms": st["lcp_ms"], "doubling_rounds": st["doubling_rounds"],
+           "host_tree_ms": st["tree_ms"], "host_query_ms": st["query_ms"], "host_walk_out_ms": st["walk_ms"],
+           "lcp_intervals": st["n_internal_nodes"],
+           "identical_to_reference_digest": bool(ms.n_sets == int(z["c2.n_sets"][0]) and H.match_sets_digest(ms) == str(z["c2.digest"][0]))}
+    if with_reference:
+        from oracle import pyoracle as po
+        if po.have_ref():
+            t0 = time.perf_counter()
+            po.ref_find_matches(g1, g2, max_count=3000)
+            out["cpu_reference"] = {"seconds": time.perf_counter() - t0, "cores": 1, "kind": "reference",
+                                    "note": "includes flattening the reference's vectors into numpy"}
+    return out
+
+
 def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: independent passes overlap on separate queues
     ap = argparse.ArgumentParser()
@@ -245,6 +274,7 @@ def main():
             ch = chaining_section(ctx, not args.no_cpu_baseline)
             if ch is not None:
                 out["chaining"] = ch
+            out["match_finding"] = match_section(ctx, not args.no_cpu_baseline)
         print(json.dumps(out))
     barrier()
     plan.destroy()
