@@ -274,6 +274,44 @@ def _take_owned_match_sets(lib, h):
         lib.cl_owned_match_sets_free(h)
 
 
+GRAPH_KEYS = ("label", "next_off", "next_idx", "prev_off", "prev_idx", "path_off", "path_nodes")
+
+
+def _take_owned_base_graph(lib, h):
+    """copies a cl_owned_base_graph into a BaseGraph and frees it"""
+    try:
+        v = BaseGraphC()
+        lib.cl_owned_base_graph_view(h, C.byref(v))
+        n, p = int(v.n_nodes), int(v.n_paths)
+
+        def arr(ptr, dt, k):
+            if k == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(k,)).copy()
+        no, po, pao = arr(v.next_off, np.uint64, n + 1), arr(v.prev_off, np.uint64, n + 1), arr(v.path_off, np.uint64, p + 1)
+        return BaseGraph(arr(v.label, np.uint8, n), no, arr(v.next_idx, np.uint32, int(no[-1])), po, arr(v.prev_idx, np.uint32, int(po[-1])),
+                         pao, arr(v.path_nodes, np.uint32, int(pao[-1])), int(v.src_id), int(v.snk_id))
+    finally:
+        lib.cl_owned_base_graph_free(h)
+
+
+def fuse(dest, source, pairs):
+    """fuse (include/centrolign/fuse.hpp:46-152): `source` merged into `dest` along the alignment ((n, 2) uint64 AlignedPairs,
+    gap = 2^64 - 1); host only.  Returns the fused BaseGraph."""
+    lib = load_library()
+    g1, g2 = dest.as_c(), source.as_c()
+    pairs = np.ascontiguousarray(pairs, np.uint64).reshape(-1, 2)
+    h = C.c_void_p()
+    rc = lib.cl_fuse(C.byref(g1), C.byref(g2), pairs.ctypes.data, len(pairs), C.byref(h))
+    if rc != 0:
+        raise ClError(rc)
+    return _take_owned_base_graph(lib, h)
+
+
+def graphs_equal(a, b):
+    return a.src_id == b.src_id and a.snk_id == b.snk_id and all(np.array_equal(getattr(a, k), getattr(b, k)) for k in GRAPH_KEYS)
+
+
 def match_params(max_count=3000, use_color_set_size=True, params=None):
     mp = MatchParams()
     mp.max_count = int(max_count)
@@ -386,6 +424,12 @@ class MatchStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class MergeResultC(C.Structure):
+    """cl_merge_result"""
+    _fields_ = [("alignment", AlignmentC), ("fused", C.c_void_p), ("n_match_sets", C.c_uint64), ("match_ms", C.c_float), ("align_ms", C.c_float),
+                ("fuse_ms", C.c_float)]
+
+
 class AnchorParams(C.Structure):
     """cl_anchor_params"""
     _fields_ = [("chain", ChainParams), ("max_num_match_pairs", C.c_uint64), ("score_scale", C.c_double),
@@ -407,6 +451,11 @@ class CoreAlignParams(C.Structure):
     _fields_ = [("split_matches_at_branchpoints", C.c_int), ("split", SplitParams), ("anchor", AnchorParams),
                 ("partition", PartitionParams), ("min_indel_fuzz_length", C.c_int64), ("indel_fuzz_score_proportion", C.c_double),
                 ("stitch", StitchParams)]
+
+
+class MergeParams(C.Structure):
+    """cl_merge_params"""
+    _fields_ = [("match", MatchParams), ("align", CoreAlignParams)]
 
 
 class CoreAlignResultC(C.Structure):
@@ -748,6 +797,18 @@ def load_library(path=None):
     lib.cl_owned_match_sets_view.argtypes = [C.c_void_p, C.POINTER(MatchSetsC)]
     lib.cl_owned_match_sets_free.restype = None
     lib.cl_owned_match_sets_free.argtypes = [C.c_void_p]
+    lib.cl_fuse.restype = C.c_int
+    lib.cl_fuse.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.cl_owned_base_graph_view.restype = None
+    lib.cl_owned_base_graph_view.argtypes = [C.c_void_p, C.POINTER(BaseGraphC)]
+    lib.cl_owned_base_graph_free.restype = None
+    lib.cl_owned_base_graph_free.argtypes = [C.c_void_p]
+    lib.cl_merge_params_default.restype = None
+    lib.cl_merge_params_default.argtypes = [C.POINTER(MergeParams)]
+    lib.cl_merge.restype = C.c_int
+    lib.cl_merge.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MergeParams), C.POINTER(MergeResultC)]
+    lib.cl_merge_result_free.restype = None
+    lib.cl_merge_result_free.argtypes = [C.POINTER(MergeResultC)]
     lib.cl_match_params_default.restype = None
     lib.cl_match_params_default.argtypes = [C.POINTER(MatchParams)]
     lib.cl_find_matches.restype = C.c_int
@@ -782,6 +843,7 @@ EXPORTED_SYMBOLS = [
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
+    "cl_fuse", "cl_owned_base_graph_view", "cl_owned_base_graph_free", "cl_merge_params_default", "cl_merge", "cl_merge_result_free",
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
 ]
 
@@ -985,6 +1047,27 @@ class Context:
                         partition_ms=float(out.partition_ms), stitch_ms=float(out.stitch_ms))
         finally:
             self.lib.cl_core_align_result_free(C.byref(out))
+
+    def merge(self, graph1, graph2, score_scale=1.0, max_num_match_pairs=1250000, max_count=3000, tweak=None):
+        """one merge of the progressive MSA (the loop body of Core::do_execution, include/centrolign/core.hpp:268-392):
+        reassign_sentinels, find_matches, Core::align, fuse.  Returns dict(alignment (n,2), fused BaseGraph, n_match_sets, *_ms)"""
+        mp = MergeParams()
+        self.lib.cl_merge_params_default(C.byref(mp))
+        mp.match.max_count = int(max_count)
+        mp.align.anchor.score_scale = float(score_scale)
+        mp.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
+        if tweak:
+            tweak(mp)
+        g1, g2, out = graph1.as_c(), graph2.as_c(), MergeResultC()
+        self._check(self.lib.cl_merge(self.handle, C.byref(g1), C.byref(g2), C.byref(mp), C.byref(out)))
+        try:
+            n = int(out.alignment.n_pairs)
+            aln = np.ctypeslib.as_array(out.alignment.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2)
+            fused, out.fused = _take_owned_base_graph(self.lib, out.fused), None
+            return dict(alignment=aln, fused=fused, n_match_sets=int(out.n_match_sets), match_ms=float(out.match_ms),
+                        align_ms=float(out.align_ms), fuse_ms=float(out.fuse_ms))
+        finally:
+            self.lib.cl_merge_result_free(C.byref(out))
 
     def plan(self, batch, params=None, force_num_pw=None):
         params = params or default_stitch_params()

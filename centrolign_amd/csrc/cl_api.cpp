@@ -1009,7 +1009,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
     if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
-    else snprintf(out->kernel, sizeof(out->kernel), "popoa_general_kernel<%d, %d>", g.npw, g.block);
+    else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);
     out->n_problems = g.count;
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;

@@ -1,0 +1,183 @@
+// cl_fuse_api.cpp — fuse (include/centrolign/fuse.hpp:46-152): merge the second graph of a merge into the first along their
+// alignment, what Core::do_execution does with the result of Core::align (include/centrolign/core.hpp:366-388), and
+// cl_merge, the whole loop body of do_execution for one merge: find_matches -> align -> fuse.
+//
+// Host code, linear in the graphs and the alignment.  BaseGraph::add_node / add_edge append (src/graph.cpp:221-229), so the
+// fused graph's node ids and the ORDER of every adjacency list follow from the order of the reference's calls; that order
+// is kept, because the next merge's reachability tables, topological orders and predecessor tie-breaks read the lists in
+// order.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <unordered_set>
+#include <vector>
+
+#include "cl_internal.hpp"
+
+struct cl_owned_base_graph {
+    std::vector<uint8_t> label;
+    std::vector<uint64_t> next_off, prev_off, path_off;
+    std::vector<uint32_t> next_idx, prev_idx, path_nodes;
+    uint64_t src_id = 0, snk_id = 0;
+};
+
+extern "C" {
+
+void cl_owned_base_graph_view(const cl_owned_base_graph* g, cl_base_graph* v) {
+    v->n_nodes = g->label.size();
+    v->label = g->label.data();
+    v->next_off = g->next_off.data(); v->next_idx = g->next_idx.data();
+    v->prev_off = g->prev_off.data(); v->prev_idx = g->prev_idx.data();
+    v->n_paths = g->path_off.size() - 1;
+    v->path_off = g->path_off.data(); v->path_nodes = g->path_nodes.data();
+    v->src_id = g->src_id; v->snk_id = g->snk_id;
+}
+
+void cl_owned_base_graph_free(cl_owned_base_graph* g) { delete g; }
+
+int cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64_t* pairs, uint64_t n_pairs, cl_owned_base_graph** out) {
+    if (!dest || !source || (n_pairs && !pairs) || !out) return CL_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    const uint64_t n1 = dest->n_nodes, n2 = source->n_nodes;
+    const uint64_t gap = ~(uint64_t)0;
+    if (n1 == 0 || n2 == 0 || dest->src_id >= n1 || dest->snk_id >= n1 || source->src_id >= n2 || source->snk_id >= n2) return CL_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < n_pairs; ++i)
+        if ((pairs[2 * i] != gap && pairs[2 * i] >= n1) || (pairs[2 * i + 1] != gap && pairs[2 * i + 1] >= n2)) return CL_ERR_INVALID_ARGUMENT;
+    // adjacency as growable lists: the destination's own, then whatever the fuse appends
+    std::vector<uint8_t> label(dest->label, dest->label + n1);
+    std::vector<std::vector<uint32_t>> next(n1), prev(n1);
+    for (uint64_t v = 0; v < n1; ++v) {
+        next[v].assign(dest->next_idx + dest->next_off[v], dest->next_idx + dest->next_off[v + 1]);
+        prev[v].assign(dest->prev_idx + dest->prev_off[v], dest->prev_idx + dest->prev_off[v + 1]);
+    }
+    auto add_edge = [&](uint64_t from, uint64_t to) { next[from].push_back((uint32_t)to); prev[to].push_back((uint32_t)from); };
+    // record match nodes (fuse.hpp:58-66), join the sentinels (:68-70), add the unmatched nodes (:72-77)
+    std::vector<uint64_t> trans(n2, gap);
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        if (a != gap && b != gap && dest->label[a] == source->label[b]) trans[b] = a;
+    }
+    trans[source->src_id] = dest->src_id;
+    trans[source->snk_id] = dest->snk_id;
+    for (uint64_t b = 0; b < n2; ++b) {
+        if (trans[b] != gap) continue;
+        trans[b] = label.size();
+        label.push_back(source->label[b]);
+        next.emplace_back();
+        prev.emplace_back();
+    }
+    if (label.size() >= 0xFFFFFFFFull) return CL_ERR_INVALID_ARGUMENT;
+    // substitution edges from the destination graph (:83-108): a mismatched pair hangs between the nearest aligned destination
+    // nodes to its right and to its left
+    std::vector<uint64_t> left_of(n_pairs), right_of(n_pairs);   // nearest index with node_id1 != gap, exclusive
+    {
+        uint64_t last = gap;
+        for (uint64_t i = 0; i < n_pairs; ++i) { left_of[i] = last; if (pairs[2 * i] != gap) last = i; }
+        last = gap;
+        for (uint64_t i = n_pairs; i-- > 0;) { right_of[i] = last; if (pairs[2 * i] != gap) last = i; }
+    }
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        if (a == gap || b == gap || dest->label[a] == source->label[b]) continue;
+        if (right_of[i] != gap) add_edge(trans[b], pairs[2 * right_of[i]]);
+        if (left_of[i] != gap) add_edge(pairs[2 * left_of[i]], trans[b]);
+    }
+    // the source's edges that are not there yet (:114-129); the membership set is taken once per node, before its additions
+    std::unordered_set<uint64_t> have;
+    for (uint64_t b = 0; b < n2; ++b) {
+        const uint64_t v = trans[b];
+        have.clear();
+        for (auto w : next[v]) have.insert(w);
+        for (uint64_t e = source->next_off[b]; e < source->next_off[b + 1]; ++e) {
+            const uint64_t w = trans[source->next_idx[e]];
+            if (!have.count(w)) add_edge(v, w);
+        }
+    }
+    std::unique_ptr<cl_owned_base_graph> g(new cl_owned_base_graph());
+    const uint64_t n = label.size();
+    g->label = std::move(label);
+    g->next_off.assign(1, 0);
+    g->prev_off.assign(1, 0);
+    for (uint64_t v = 0; v < n; ++v) {
+        g->next_idx.insert(g->next_idx.end(), next[v].begin(), next[v].end());
+        g->next_off.push_back(g->next_idx.size());
+        g->prev_idx.insert(g->prev_idx.end(), prev[v].begin(), prev[v].end());
+        g->prev_off.push_back(g->prev_idx.size());
+    }
+    // the paths: the destination's, then the source's translated (:137-143)
+    g->path_off.assign(1, 0);
+    for (uint64_t p = 0; p < dest->n_paths; ++p) {
+        g->path_nodes.insert(g->path_nodes.end(), dest->path_nodes + dest->path_off[p], dest->path_nodes + dest->path_off[p + 1]);
+        g->path_off.push_back(g->path_nodes.size());
+    }
+    for (uint64_t p = 0; p < source->n_paths; ++p) {
+        for (uint64_t i = source->path_off[p]; i < source->path_off[p + 1]; ++i) {
+            if (source->path_nodes[i] >= n2) return CL_ERR_INVALID_ARGUMENT;
+            g->path_nodes.push_back((uint32_t)trans[source->path_nodes[i]]);
+        }
+        g->path_off.push_back(g->path_nodes.size());
+    }
+    g->src_id = dest->src_id;   // next_problem.tableau = subproblem1.tableau (core.hpp:388)
+    g->snk_id = dest->snk_id;
+    *out = g.release();
+    return CL_OK;
+}
+
+void cl_merge_params_default(cl_merge_params* p) {
+    if (!p) return;
+    cl_match_params_default(&p->match);
+    cl_core_align_params_default(&p->align);
+}
+
+void cl_merge_result_free(cl_merge_result* r) {
+    if (!r) return;
+    cl_alignment_free(&r->alignment);
+    cl_owned_base_graph_free(r->fused);
+    memset(r, 0, sizeof(*r));
+}
+
+int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_merge_params* prm, cl_merge_result* out) {
+    if (!ctx || !g1 || !g2 || !prm || !out) return CL_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    if (g1->n_nodes == 0 || g2->n_nodes == 0 || g1->src_id >= g1->n_nodes || g1->snk_id >= g1->n_nodes || g2->src_id >= g2->n_nodes ||
+        g2->snk_id >= g2->n_nodes) {
+        cl_set_error(ctx, "cl_merge: sentinel ids out of range");
+        return CL_ERR_INVALID_ARGUMENT;
+    }
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(now() - t).count(); };
+    // reassign_sentinels(…, 5, 6) / (…, 7, 8) (core.hpp:283-284): on private copies of the label arrays
+    std::vector<uint8_t> lab1(g1->label, g1->label + g1->n_nodes), lab2(g2->label, g2->label + g2->n_nodes);
+    lab1[g1->src_id] = 5; lab1[g1->snk_id] = 6;
+    lab2[g2->src_id] = 7; lab2[g2->snk_id] = 8;
+    cl_base_graph a = *g1, b = *g2;
+    a.label = lab1.data();
+    b.label = lab2.data();
+    auto t0 = now();
+    cl_owned_match_sets* ms = nullptr;
+    cl_match_stats mst;
+    int rc = cl_find_matches(ctx, &a, &b, &prm->match, &ms, &mst);
+    if (rc) return rc;
+    out->match_ms = ms_since(t0);
+    cl_match_sets view;
+    cl_owned_match_sets_view(ms, &view);
+    out->n_match_sets = view.n_sets;
+    t0 = now();
+    cl_core_align_result ar;
+    rc = cl_core_align(ctx, &a, &b, &view, &prm->align, &ar);
+    cl_owned_match_sets_free(ms);
+    if (rc) return rc;
+    out->align_ms = ms_since(t0);
+    out->alignment = ar.alignment;
+    ar.alignment.pairs = nullptr;
+    ar.alignment.n_pairs = 0;
+    cl_core_align_result_free(&ar);
+    t0 = now();
+    rc = cl_fuse(&a, &b, out->alignment.pairs, out->alignment.n_pairs, &out->fused);
+    out->fuse_ms = ms_since(t0);
+    if (rc) { cl_set_error(ctx, "cl_fuse failed"); cl_merge_result_free(out); return rc; }
+    return CL_OK;
+}
+
+}  // extern "C"

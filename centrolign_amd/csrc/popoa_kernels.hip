@@ -7,6 +7,8 @@
 // order, so the lanes of a wave write one contiguous run per plane and, for chain-like graphs, read three
 // contiguous runs (coalesced).  Lane 0 then picks the best sink pair and walks the traceback with exactly
 // the reference's equality tests and tie-break order (alignment.hpp:979-1138).
+//
+// popoa_ring_kernel: the same sweep for subproblems whose topology and a ring of recent anti-diagonals fit LDS (below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,69 +58,30 @@ struct Planes {
 //                            M   = s(a,b) + max_{p,q} Mf(p,q), with Mf(corner) == 0       (:929-936, :814-818, :854-861, :886-893)
 //   Mf = max(M, I_k, D_k)                                                                 (:837, :869, :903-905)
 // p ranges over previous1(a) plus the boundary index when a is a source; q likewise.
-// The last `depth` anti-diagonals of the matrix in LDS, [diagonal mod depth][position on the diagonal][plane]
-// (ClProbDesc::pad = depth).  A read that reaches at most depth-1 anti-diagonals back is served from the ring; the per-
-// diagonal barrier then only has to order LDS.  A read that reaches further back (the far end of a bubble whose branches
-// differ by thousands of nodes) goes to the HBM planes, which are always written (the traceback needs them): the kernel drains
-// its stores (vmcnt(0) + barrier) every depth/2 anti-diagonals, so a cell written depth or more diagonals ago is in memory.
 template <int NPW>
-struct Ring {
-    int32_t* lds;
-    uint32_t depth, width;
-    static constexpr int PL = 1 + 2 * NPW;
-    __device__ __forceinline__ int32_t* cell(const DiagGeom& G, uint32_t a, uint32_t b) const {
-        const uint32_t d = a + b;
-        return lds + ((size_t)(d & (depth - 1)) * width + (a - G.lo(d))) * PL;   // depth is a power of two
-    }
-};
-
-// the subproblem's topology as the cell update reads it: labels, predecessor offsets (relative to the subproblem's first
-// predecessor entry) and predecessor ranks of both graphs — in HBM, or staged into LDS by the ring variant (every cell
-// walks poff -> pidx -> plane, and with the planes in LDS those dependent HBM loads were what an anti-diagonal cost)
-template <bool RING>
-struct Topo {
-    // HBM (RING == false)
-    const uint8_t* lab[2];
-    const uint32_t* poff[2];   // [n+1], poff[a-1]..poff[a] = predecessor entries of node a (1-based)
-    const uint32_t* pidx[2];
-    // LDS (RING == true): the same arrays staged behind the ring, as offsets into the workgroup's dynamic LDS
-    const uint32_t* lds_u32;
-    const uint8_t* lds_u8;
-    uint32_t poff_at[2], pidx_at[2], lab_at[2];
-    uint32_t base[2];          // subtracted from poff entries before indexing pidx
-    __device__ __forceinline__ uint32_t Lab(int s, uint32_t i) const { if (RING) return lds_u8[lab_at[s] + i]; return lab[s][i]; }
-    __device__ __forceinline__ uint32_t Poff(int s, uint32_t i) const { if (RING) return lds_u32[poff_at[s] + i]; return poff[s][i]; }
-    __device__ __forceinline__ uint32_t Pidx(int s, uint32_t e) const { if (RING) return lds_u32[pidx_at[s] + e]; return pidx[s][e]; }
-};
-
-template <int NPW, bool RING>
-__device__ __forceinline__ void compute_cell(const Topo<RING>& T, const DiagGeom& G,
-                                             const Planes<NPW>& pl, const Ring<NPW>& ring, const ClScoreParams& P, uint32_t a,
-                                             uint32_t b, uint32_t self_idx) {
-    const uint32_t d_here = a + b;
-    auto near = [&](uint32_t x, uint32_t y) { return RING && d_here - (x + y) < ring.depth; };
-    // value-level branches, never a select between an LDS and an HBM POINTER: that would turn every access into a flat one
-    auto rdM = [&](uint32_t x, uint32_t y) -> int32_t { if (near(x, y)) return ring.cell(G, x, y)[0]; return pl.M()[G.idx(x, y)]; };
-    auto rdI = [&](int k, uint32_t x, uint32_t y) -> int32_t { if (near(x, y)) return ring.cell(G, x, y)[1 + k]; return pl.I(k)[G.idx(x, y)]; };
-    auto rdD = [&](int k, uint32_t x, uint32_t y) -> int32_t { if (near(x, y)) return ring.cell(G, x, y)[1 + NPW + k]; return pl.D(k)[G.idx(x, y)]; };
+__device__ __forceinline__ void compute_cell(const ClDeviceBatch& B, const ClProbDesc& pd, const DiagGeom& G,
+                                             const Planes<NPW>& pl, const ClScoreParams& P, uint32_t a, uint32_t b,
+                                             uint32_t self_idx) {
+    const uint8_t* lab1 = B.lab[0] + pd.node_base[0];
+    const uint8_t* lab2 = B.lab[1] + pd.node_base[1];
+    const uint32_t* poff1 = B.poff[0] + pd.node_base[0];
+    const uint32_t* poff2 = B.poff[1] + pd.node_base[1];
     int32_t M = CL_NEG_INF, I[NPW], D[NPW];
 #pragma unroll
     for (int k = 0; k < NPW; ++k) { I[k] = CL_NEG_INF; D[k] = CL_NEG_INF; }
 
     uint32_t e1b = 0, e1e = 0, e2b = 0, e2e = 0;
     uint32_t l1 = 0, l2 = 0;
-    if (a) { e1b = T.Poff(0, a - 1) - T.base[0]; e1e = T.Poff(0, a) - T.base[0]; l1 = T.Lab(0, a - 1); }
-    if (b) { e2b = T.Poff(1, b - 1) - T.base[1]; e2e = T.Poff(1, b) - T.base[1]; l2 = T.Lab(1, b - 1); }
+    if (a) { e1b = poff1[a - 1]; e1e = poff1[a]; l1 = lab1[a - 1]; }
+    if (b) { e2b = poff2[b - 1]; e2e = poff2[b]; l2 = lab2[b - 1]; }
     const bool src1 = l1 & 0x80, src2 = l2 & 0x80;
-    auto pred1 = [&](uint32_t e) -> uint32_t { return T.Pidx(0, e); };
-    auto pred2 = [&](uint32_t f) -> uint32_t { return T.Pidx(1, f); };
 
     if (a) {
         if (b == 0) {
             for (uint32_t e = e1b; e < e1e; ++e) {
-                const uint32_t pa = pred1(e);
+                uint32_t c = G.idx(B.pidx[0][e], 0);
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], rdI(k, pa, 0) - P.ext[k]);
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], pl.I(k)[c] - P.ext[k]);
             }
             if (src1) {
 #pragma unroll
@@ -126,13 +89,13 @@ __device__ __forceinline__ void compute_cell(const Topo<RING>& T, const DiagGeom
             }
         } else {
             for (uint32_t e = e1b; e < e1e; ++e) {
-                const uint32_t pa = pred1(e);
-                int32_t m = rdM(pa, b);
+                uint32_t c = G.idx(B.pidx[0][e], b);
+                int32_t m = pl.M()[c];
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], rdI(k, pa, b) - P.ext[k]));
+                for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], imax(m - P.oe[k], pl.I(k)[c] - P.ext[k]));
             }
             if (src1) {
-                int32_t m = rdM(0, b);
+                int32_t m = pl.M()[G.idx(0, b)];
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) I[k] = imax(I[k], m - P.oe[k]);
             }
@@ -141,9 +104,9 @@ __device__ __forceinline__ void compute_cell(const Topo<RING>& T, const DiagGeom
     if (b) {
         if (a == 0) {
             for (uint32_t f = e2b; f < e2e; ++f) {
-                const uint32_t pb = pred2(f);
+                uint32_t c = G.idx(0, B.pidx[1][f]);
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], rdD(k, 0, pb) - P.ext[k]);
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], pl.D(k)[c] - P.ext[k]);
             }
             if (src2) {
 #pragma unroll
@@ -151,13 +114,13 @@ __device__ __forceinline__ void compute_cell(const Topo<RING>& T, const DiagGeom
             }
         } else {
             for (uint32_t f = e2b; f < e2e; ++f) {
-                const uint32_t pb = pred2(f);
-                int32_t m = rdM(a, pb);
+                uint32_t c = G.idx(a, B.pidx[1][f]);
+                int32_t m = pl.M()[c];
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], rdD(k, a, pb) - P.ext[k]));
+                for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], imax(m - P.oe[k], pl.D(k)[c] - P.ext[k]));
             }
             if (src2) {
-                int32_t m = rdM(a, 0);
+                int32_t m = pl.M()[G.idx(a, 0)];
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) D[k] = imax(D[k], m - P.oe[k]);
             }
@@ -167,10 +130,10 @@ __device__ __forceinline__ void compute_cell(const Topo<RING>& T, const DiagGeom
         const int32_t s = ((l1 & 0x7f) == (l2 & 0x7f)) ? P.match : -P.mismatch;
         const uint32_t e1x = e1e + (src1 ? 1u : 0u), e2x = e2e + (src2 ? 1u : 0u);
         for (uint32_t e = e1b; e < e1x; ++e) {
-            uint32_t pa = e < e1e ? pred1(e) : 0u;
+            uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
             for (uint32_t f = e2b; f < e2x; ++f) {
-                uint32_t pb = f < e2e ? pred2(f) : 0u;
-                int32_t v = (pa | pb) ? rdM(pa, pb) : 0;
+                uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
+                int32_t v = (pa | pb) ? pl.M()[G.idx(pa, pb)] : 0;
                 M = imax(M, v + s);
             }
         }
@@ -182,12 +145,6 @@ __device__ __forceinline__ void compute_cell(const Topo<RING>& T, const DiagGeom
         pl.D(k)[self_idx] = D[k];
     }
     pl.M()[self_idx] = M;
-    if (RING) {
-        int32_t* c = ring.cell(G, a, b);
-        c[0] = M;
-#pragma unroll
-        for (int k = 0; k < NPW; ++k) { c[1 + k] = I[k]; c[1 + NPW + k] = D[k]; }
-    }
 }
 
 // best sink pair + traceback by one lane; alignment.hpp:979-1138, rule for rule
@@ -277,89 +234,33 @@ __device__ void traceback(const ClDeviceBatch& B, const ClProbDesc& pd, const Di
     B.out_status[prob] = status;
 }
 
-template <int NPW, int BLOCK, bool RING>
+template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
-    extern __shared__ int32_t ring_lds[];
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
     Planes<NPW> pl;
     pl.base = B.planes + pd.plane_base;
     pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
-    Ring<NPW> ring;
-    ring.lds = ring_lds;
-    ring.depth = pd.pad;
-    ring.width = (pd.n1 < pd.n2 ? pd.n1 : pd.n2) + 1;
     const uint32_t tid = threadIdx.x;
-    Topo<RING> T;
-    const uint32_t nn[2] = {pd.n1, pd.n2};
-    for (int s = 0; s < 2; ++s) {
-        T.lab[s] = B.lab[s] + pd.node_base[s];
-        T.poff[s] = B.poff[s] + pd.node_base[s];
-        T.pidx[s] = B.pidx[s];
-        T.base[s] = 0;
-    }
-    if (RING) {
-        // behind the ring: poff1 | poff2 | pidx1 | pidx2 | lab1 | lab2 (the host sized the launch's LDS for it)
-        uint32_t* lds_w = reinterpret_cast<uint32_t*>(ring_lds);
-        uint32_t at = ring.depth * ring.width * Ring<NPW>::PL;
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t* gp = B.poff[s] + pd.node_base[s];
-            for (uint32_t i = tid; i <= nn[s]; i += BLOCK) lds_w[at + i] = gp[i];
-            T.poff_at[s] = at;
-            at += nn[s] + 1;
-        }
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t* gp = B.poff[s] + pd.node_base[s];
-            const uint32_t e0 = gp[0], e1 = gp[nn[s]];
-            for (uint32_t i = tid; i < e1 - e0; i += BLOCK) lds_w[at + i] = B.pidx[s][e0 + i];
-            T.pidx_at[s] = at;
-            T.base[s] = e0;
-            at += e1 - e0;
-        }
-        uint8_t* lds_b = reinterpret_cast<uint8_t*>(ring_lds);
-        uint32_t bat = at * 4;
-        for (int s = 0; s < 2; ++s) {
-            const uint8_t* gl = B.lab[s] + pd.node_base[s];
-            for (uint32_t i = tid; i < nn[s]; i += BLOCK) lds_b[bat + i] = gl[i];
-            T.lab_at[s] = bat;
-            bat += nn[s];
-        }
-        T.lds_u32 = lds_w;
-        T.lds_u8 = lds_b;
-    }
+
     if (tid == 0) {  // the corner stays -inf in memory; the diagonal term treats it as 0 (alignment.hpp:814-818)
         pl.M()[0] = CL_NEG_INF;
 #pragma unroll
         for (int k = 0; k < NPW; ++k) { pl.I(k)[0] = CL_NEG_INF; pl.D(k)[0] = CL_NEG_INF; }
-        if (RING) {
-            int32_t* c = ring.cell(G, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 1 + 2 * NPW; ++k) c[k] = CL_NEG_INF;
-        }
     }
-    if (RING) __syncthreads();
     const uint32_t last = pd.n1 + pd.n2;
-    const uint32_t drain_every = RING ? (ring.depth >= 2 ? ring.depth / 2 : 1u) : 1u;
     uint32_t off = 1;  // G.off(1)
     for (uint32_t d = 1; d <= last; ++d) {
         const uint32_t lo = G.lo(d), cnt = G.hi(d) - lo + 1;
         for (uint32_t t = tid; t < cnt; t += BLOCK) {
             const uint32_t a = lo + t;
-            compute_cell<NPW, RING>(T, G, pl, ring, P, a, d - a, off + t);
+            compute_cell<NPW>(B, pd, G, pl, P, a, d - a, off + t);
         }
         off += cnt;
-        if (RING && (d & (drain_every - 1)) != 0) {
-            // the next anti-diagonal reads this one from LDS: order LDS traffic only, the HBM stores drain in the background
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        } else {
-            __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
-        }
+        __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
     }
-    if (RING) __syncthreads();   // the traceback reads the HBM planes
     if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
 }
 
@@ -573,11 +474,11 @@ void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const
         return;
     }
     if (block <= 64)
-        hipLaunchKernelGGL((popoa_general_kernel<NPW, 64, false>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P);
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 64>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P);
     else if (block <= 256)
-        hipLaunchKernelGGL((popoa_general_kernel<NPW, 256, false>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P);
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 256>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P);
     else
-        hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024, false>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P);
+        hipLaunchKernelGGL((popoa_general_kernel<NPW, 1024>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P);
 }
 
 }  // namespace

@@ -469,6 +469,33 @@ int  cl_core_align(cl_context* ctx, const cl_base_graph* graph1, const cl_base_g
               const cl_core_align_params* params, cl_core_align_result* out);
 void cl_core_align_result_free(cl_core_align_result* r);
 
+/* --- fuse (include/centrolign/fuse.hpp:46-152) and the whole loop body of Core::do_execution (core.hpp:268-392) --------------
+ * cl_fuse merges `source` into `dest` along their alignment (AlignedPair[n_pairs], graph-1 ids = dest) exactly as the
+ * reference does in place: matched nodes with equal labels are identified, the sentinels joined, the other source nodes
+ * appended in id order; then the substitution edges, the source edges that are missing, and the source paths after the
+ * destination's.  Node ids and the order of every adjacency list are the reference's.  The result's sentinel ids are dest's
+ * (core.hpp:388).  Host only. */
+typedef struct cl_owned_base_graph cl_owned_base_graph;
+int  cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64_t* pairs, uint64_t n_pairs, cl_owned_base_graph** out);
+void cl_owned_base_graph_view(const cl_owned_base_graph* graph, cl_base_graph* view_out);
+void cl_owned_base_graph_free(cl_owned_base_graph* graph);
+
+/* One merge of the progressive MSA from nothing but the two subproblem graphs: reassign_sentinels (5,6 / 7,8),
+ * PathMatchFinder::find_matches, Core::align, fuse.  `fused` is the next subproblem's graph. */
+typedef struct cl_merge_params {
+    cl_match_params      match;
+    cl_core_align_params align;
+} cl_merge_params;
+void cl_merge_params_default(cl_merge_params* p);
+typedef struct cl_merge_result {
+    cl_alignment         alignment;   /* next_problem.alignment */
+    cl_owned_base_graph* fused;       /* next_problem.graph (+ tableau ids) */
+    uint64_t             n_match_sets;
+    float                match_ms, align_ms, fuse_ms;
+} cl_merge_result;
+int  cl_merge(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_merge_params* params, cl_merge_result* out);
+void cl_merge_result_free(cl_merge_result* r);
+
 #ifdef __cplusplus
 }
 #endif

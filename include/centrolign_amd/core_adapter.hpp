@@ -12,6 +12,7 @@
 #define CENTROLIGN_AMD_CORE_ADAPTER_HPP
 
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -173,6 +174,29 @@ std::vector<MatchSetT> find_matches(Device& dev, const BaseGraphT& graph1, const
     }
     cl_owned_match_sets_free(owned);
     return out;
+}
+
+// fuse (fuse.hpp:46-152) through the library, checked against an already fused reference graph: true when cl_fuse of
+// (dest, source, alignment) is node for node, list for list and path for path the graph `fused_by_reference`
+template <class BaseGraphT, class TableauT, class AlignmentT>
+bool fuse_equals(const BaseGraphT& dest, const BaseGraphT& source, const TableauT& dest_table, const TableauT& source_table,
+                 const AlignmentT& alignment, const BaseGraphT& fused_by_reference) {
+    FlatBaseGraph g1(dest, dest_table), g2(source, source_table), want(fused_by_reference, dest_table);
+    std::vector<uint64_t> pairs;
+    pairs.reserve(2 * alignment.size());
+    for (const auto& ap : alignment) { pairs.push_back(ap.node_id1); pairs.push_back(ap.node_id2); }
+    cl_owned_base_graph* owned = nullptr;
+    if (int rc = cl_fuse(&g1.view, &g2.view, pairs.data(), alignment.size(), &owned))
+        throw std::runtime_error("cl_fuse failed (" + std::to_string(rc) + ")");
+    cl_base_graph v;
+    cl_owned_base_graph_view(owned, &v);
+    auto same = [](const void* a, const void* b, size_t bytes) { return bytes == 0 || std::memcmp(a, b, bytes) == 0; };
+    bool ok = v.n_nodes == want.view.n_nodes && v.n_paths == want.view.n_paths && same(v.label, want.view.label, v.n_nodes) &&
+              same(v.next_off, want.view.next_off, (v.n_nodes + 1) * 8) && same(v.prev_off, want.view.prev_off, (v.n_nodes + 1) * 8) &&
+              same(v.next_idx, want.view.next_idx, v.next_off[v.n_nodes] * 4) && same(v.prev_idx, want.view.prev_idx, v.prev_off[v.n_nodes] * 4) &&
+              same(v.path_off, want.view.path_off, (v.n_paths + 1) * 8) && same(v.path_nodes, want.view.path_nodes, v.path_off[v.n_paths] * 4);
+    cl_owned_base_graph_free(owned);
+    return ok;
 }
 
 }  // namespace centrolign_amd

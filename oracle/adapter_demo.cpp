@@ -156,6 +156,11 @@ struct DemoCore : public Core {
             next_problem.alignment = whole_align ? align_core_both(matches, sp1, sp2, pm1, pm2) : align_both(matches, sp1, sp2, pm1, pm2);
             BaseGraph fused = sp1.graph;
             fuse(fused, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment);
+            if (whole_align) {   // fuse through the library, against the graph the reference has just fused
+                const bool same = centrolign_amd::fuse_equals(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment, fused);
+                if (!same) ++mismatched;
+                printf("merge %zu: fused graph %zu nodes, cl_fuse %s the reference\n", merges - 1, (size_t)fused.node_size(), same ? "==" : "!=");
+            }
             next_problem.graph = std::move(fused);
             next_problem.tableau = sp1.tableau;
             next_problem.complete = true;

@@ -410,6 +410,29 @@ def ref_partition_anchors(g1, g2, chain, score_scale=1.0, score_boundaries=False
     return seg[:int(ns.value)].copy()
 
 
+def ref_fuse(g1, g2, pairs):
+    """the compiled reference's fuse (fuse.hpp:46-152): graph 2 merged into graph 1 along the alignment; returns capi.BaseGraph"""
+    from centrolign_amd.capi import BaseGraphC, BaseGraph
+    lib = ref_lib()
+    lib.ref_fuse.restype = C.c_int
+    lib.ref_fuse.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c1, c2 = g1.as_c(), g2.as_c()
+    pairs = np.ascontiguousarray(pairs, np.uint64).reshape(-1, 2)
+    out = (C.c_void_p * 7)()
+    sizes = (C.c_uint64 * 4)()
+    rc = lib.ref_fuse(C.byref(c1), C.byref(c2), pairs.ctypes.data, len(pairs), out, sizes)
+    if rc:
+        raise RuntimeError("ref_fuse failed: %d" % rc)
+    n, e, p, pn = [int(x) for x in sizes]
+    def arr(i, dt, k):
+        a = np.ctypeslib.as_array(C.cast(out[i], C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(max(k, 1),))[:k].copy()
+        lib.ref_free(out[i])
+        return a
+    return BaseGraph(arr(0, np.uint8, n), arr(1, np.uint64, n + 1), arr(2, np.uint32, e), arr(3, np.uint64, n + 1), arr(4, np.uint32, e),
+                     arr(5, np.uint64, p + 1), arr(6, np.uint32, pn), g1.src_id, g1.snk_id)
+
+
 _match = None
 MATCH_LIB = os.path.join(_HERE, "_build", "libcl_match_oracle.so")
 

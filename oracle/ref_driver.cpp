@@ -22,6 +22,7 @@
 
 #include "centrolign/alignment.hpp"
 #include "centrolign/core.hpp"
+#include "centrolign/fuse.hpp"
 #include "centrolign/gfa.hpp"
 #include "centrolign/parameters.hpp"
 #include "centrolign/stitcher.hpp"
@@ -658,6 +659,43 @@ int ref_find_matches(const cl_base_graph* g1, const cl_base_graph* g2, const clo
         for (const auto& w : sets[s].walks2) for (auto v : w) (*nodes_out)[pos++] = (uint32_t)v;
     }
     return 0;
+}
+
+/* fuse (fuse.hpp:46-152) on flat inputs: graph 2 merged into graph 1 along the alignment; the fused graph flattened with its
+ * adjacency lists in BaseGraph order.  out[]: label (u8), next_off, next_idx (u32), prev_off, prev_idx (u32), path_off,
+ * path_nodes (u32) — malloc'ed, release with ref_free; sizes[]: nodes, edges, paths, path nodes. */
+int ref_fuse(const cl_base_graph* g1, const cl_base_graph* g2, const uint64_t* pairs, uint64_t n_pairs, void** out, uint64_t* sizes) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    Alignment aln;
+    for (uint64_t i = 0; i < n_pairs; ++i) aln.emplace_back(pairs[2 * i], pairs[2 * i + 1]);
+    fuse(b1, b2, t1, t2, aln);
+    const uint64_t n = b1.node_size();
+    uint64_t edges = 0, pn = 0;
+    for (uint64_t v = 0; v < n; ++v) edges += b1.next_size(v);
+    for (uint64_t p = 0; p < b1.path_size(); ++p) pn += b1.path(p).size();
+    uint8_t* label = (uint8_t*)malloc(n ? n : 1);
+    uint64_t* next_off = (uint64_t*)malloc((n + 1) * 8); uint32_t* next_idx = (uint32_t*)malloc((edges ? edges : 1) * 4);
+    uint64_t* prev_off = (uint64_t*)malloc((n + 1) * 8); uint32_t* prev_idx = (uint32_t*)malloc((edges ? edges : 1) * 4);
+    uint64_t* path_off = (uint64_t*)malloc((b1.path_size() + 1) * 8); uint32_t* path_nodes = (uint32_t*)malloc((pn ? pn : 1) * 4);
+    uint64_t a = 0, b = 0;
+    next_off[0] = prev_off[0] = 0;
+    for (uint64_t v = 0; v < n; ++v) {
+        label[v] = (uint8_t)b1.label(v);
+        for (auto w : b1.next(v)) next_idx[a++] = (uint32_t)w;
+        next_off[v + 1] = a;
+        for (auto w : b1.previous(v)) prev_idx[b++] = (uint32_t)w;
+        prev_off[v + 1] = b;
+    }
+    uint64_t c = 0;
+    path_off[0] = 0;
+    for (uint64_t p = 0; p < b1.path_size(); ++p) {
+        for (auto v : b1.path(p)) path_nodes[c++] = (uint32_t)v;
+        path_off[p + 1] = c;
+    }
+    out[0] = label; out[1] = next_off; out[2] = next_idx; out[3] = prev_off; out[4] = prev_idx; out[5] = path_off; out[6] = path_nodes;
+    sizes[0] = n; sizes[1] = edges; sizes[2] = b1.path_size(); sizes[3] = pn;
+    return b == edges ? 0 : -1;
 }
 
 /* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as

@@ -12,3 +12,6 @@ export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_prof.json 2>$OUT/prof.err
 ls -R $OUT/prof | head -30
+# match finding on the same pair: per-kernel times of the device suffix sort / LCP
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_match -o r01 -- python3 $R/scripts/match_bench.py > $OUT/match_prof.txt 2>$OUT/match_prof.err
+tail -5 $OUT/match_prof.txt

@@ -119,9 +119,35 @@ def match_finding_goldens():
     np.savez_compressed(os.path.join(HERE, "match_finder.npz"), **out)
 
 
+def fuse_goldens():
+    # 11. fuse (fuse.hpp:46-152): the seeded inputs of tests/helpers.fuse_cases() -> the reference's fused graph in full; the three
+    #     merges of the 4 x 30 kbp MSA (parents + stitched alignment in stitch4_30k_merge*.npz) -> digest of the fused graph
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests import helpers as H
+    from tests.test_extraction import load_stitch_case
+    from centrolign_amd import capi
+    out = {}
+    names = []
+    for name, g1, g2, pairs in H.fuse_cases():
+        r = po.ref_fuse(g1, g2, pairs)
+        names.append(name)
+        for k in capi.GRAPH_KEYS:
+            out["%s.%s" % (name, k)] = getattr(r, k)
+    for m in (0, 1, 2):
+        z, graphs, _ = load_stitch_case("stitch4_30k_merge%d.npz" % m)
+        r = po.ref_fuse(graphs[0], graphs[1], z["stitched"].reshape(-1, 2))
+        out["merge%d.digest" % m] = np.array([H.graph_digest(r)])
+        out["merge%d.sizes" % m] = np.array([len(r.label), len(r.next_idx), len(r.path_off) - 1])
+        print("merge", m, "fused:", out["merge%d.sizes" % m])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "fuse.npz"), **out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "match":
         return match_finding_goldens()
+    if len(sys.argv) > 1 and sys.argv[1] == "fuse":
+        return fuse_goldens()
     sp = capi.default_stitch_params()
     # 1. random DAG pairs, CLI scoring
     b = synth.random_dag_batch(400, seed=20261002, max_n=36)
@@ -316,6 +342,7 @@ def main():
     out["n_cases"] = np.array([n_cases])
     np.savez_compressed(os.path.join(HERE, "despecify.npz"), **out)
     match_finding_goldens()
+    fuse_goldens()
     print("golden vectors written to", HERE)
 
 

@@ -202,3 +202,44 @@ def match_sets_digest(ms):
     for k in capi.MatchSets._DT:
         h.update(np.ascontiguousarray(getattr(ms, k)).tobytes())
     return h.hexdigest()
+
+
+GAP = np.uint64(2 ** 64 - 1)
+
+
+def fuse_cases():
+    """seeded inputs of the fuse parity tests: (name, dest graph, source graph, alignment): bubble graphs over related
+    ancestors with an alignment that walks their first paths in lockstep with random gaps (matches, mismatches ->
+    substitution edges, insertions, deletions; leading / trailing gaps)"""
+    cases = []
+    for seed in range(24):
+        rng = np.random.default_rng(300 + seed)
+        L = int(rng.integers(1, 400))
+        anc = rng.integers(0, 4, L).astype(np.uint8)
+        a2 = anc.copy()
+        mm = rng.random(L) < 0.1
+        a2[mm] = rng.integers(0, 4, int(mm.sum()))
+        g1 = synth.bubble_graph(anc, int(rng.integers(1, 4)), seed=seed)
+        g2 = synth.bubble_graph(a2, int(rng.integers(1, 4)), seed=seed + 500, sentinels=(7, 8))
+        p1 = g1.path_nodes[int(g1.path_off[0]):int(g1.path_off[1])]
+        p2 = g2.path_nodes[int(g2.path_off[0]):int(g2.path_off[1])]
+        i = j = 0
+        out = []
+        while i < len(p1) or j < len(p2):
+            r = rng.random()
+            if i < len(p1) and j < len(p2) and r < 0.8:
+                out.append((p1[i], p2[j])); i += 1; j += 1
+            elif i < len(p1) and (r < 0.9 or j >= len(p2)):
+                out.append((p1[i], GAP)); i += 1
+            else:
+                out.append((GAP, p2[j])); j += 1
+        cases.append(("fuse%02d" % seed, g1, g2, np.array(out, np.uint64).reshape(-1, 2)))
+    return cases
+
+
+def graph_digest(g):
+    h = hashlib.sha256()
+    for k in capi.GRAPH_KEYS:
+        h.update(np.ascontiguousarray(getattr(g, k)).tobytes())
+    h.update(np.array([g.src_id, g.snk_id], np.uint64).tobytes())
+    return h.hexdigest()
