@@ -803,6 +803,11 @@ def load_library(path=None):
     lib.cl_owned_base_graph_view.argtypes = [C.c_void_p, C.POINTER(BaseGraphC)]
     lib.cl_owned_base_graph_free.restype = None
     lib.cl_owned_base_graph_free.argtypes = [C.c_void_p]
+    lib.cl_estimate_score_scale.restype = C.c_int
+    lib.cl_estimate_score_scale.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.POINTER(AnchorParams),
+                                            C.POINTER(C.c_double)]
+    lib.cl_leaf_intrinsic_scale.restype = C.c_int
+    lib.cl_leaf_intrinsic_scale.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(MatchParams), C.POINTER(AnchorParams), C.POINTER(C.c_double)]
     lib.cl_merge_params_default.restype = None
     lib.cl_merge_params_default.argtypes = [C.POINTER(MergeParams)]
     lib.cl_merge.restype = C.c_int
@@ -843,6 +848,7 @@ EXPORTED_SYMBOLS = [
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
+    "cl_estimate_score_scale", "cl_leaf_intrinsic_scale",
     "cl_fuse", "cl_owned_base_graph_view", "cl_owned_base_graph_free", "cl_merge_params_default", "cl_merge", "cl_merge_result_free",
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
 ]
@@ -1047,6 +1053,19 @@ class Context:
                         partition_ms=float(out.partition_ms), stitch_ms=float(out.stitch_ms))
         finally:
             self.lib.cl_core_align_result_free(C.byref(out))
+
+    def leaf_intrinsic_scale(self, leaf, max_count=3000, max_num_match_pairs=1250000, params=None, fill_in=True):
+        """the per-leaf step of Core's calibration (src/core.cpp:122-166): self matches, main-diagonal subset,
+        Anchorer::estimate_score_scale.  ScoreFunction::score_scale = the mean over the leaves."""
+        ap = AnchorParams()
+        ap.chain = params or default_chain_params()
+        ap.max_num_match_pairs = int(max_num_match_pairs)
+        ap.score_scale = 1.0
+        ap.autocalibrate_gap_penalties = 1
+        ap.do_fill_in_anchoring = int(fill_in)
+        g, mp, scale = leaf.as_c(), match_params(max_count, True, params), C.c_double(0)
+        self._check(self.lib.cl_leaf_intrinsic_scale(self.handle, C.byref(g), C.byref(mp), C.byref(ap), C.byref(scale)))
+        return float(scale.value)
 
     def merge(self, graph1, graph2, score_scale=1.0, max_num_match_pairs=1250000, max_count=3000, tweak=None):
         """one merge of the progressive MSA (the loop body of Core::do_execution, include/centrolign/core.hpp:268-392):

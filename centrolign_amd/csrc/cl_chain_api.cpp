@@ -1200,8 +1200,11 @@ void cl_anchor_chain_result_free(cl_anchor_chain_result* r) {
     memset(r, 0, sizeof(*r));
 }
 
-int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
-                    const cl_anchor_params* ap, cl_anchor_chain_result* out) {
+}  // extern "C"
+
+// scale_only: stop after estimate_score_scale (out->scale is the only field set)
+static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                             const cl_anchor_params* ap, cl_anchor_chain_result* out, bool scale_only) {
     if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     const cl_chain_params& cp = ap->chain;
@@ -1494,6 +1497,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         lap("scale estimate: extraction", t);
     }
     out->scale = scale;
+    if (scale_only) return CL_OK;
 
     // ---- the affine chain
     std::vector<HAnchor> ch;
@@ -1536,6 +1540,25 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
         wpos += a.w1.size();
         out->walk_off[i + 1] = wpos;
     }
+    return CL_OK;
+}
+
+extern "C" {
+
+int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                    const cl_anchor_params* ap, cl_anchor_chain_result* out) {
+    return anchor_chain_impl(ctx, g1, g2, ms, ap, out, false);
+}
+
+int cl_estimate_score_scale(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                            const cl_anchor_params* ap, double* scale_out) {
+    if (!ap || !scale_out) return CL_ERR_INVALID_ARGUMENT;
+    cl_anchor_params p = *ap;
+    p.autocalibrate_gap_penalties = 1;
+    cl_anchor_chain_result r;
+    const int rc = anchor_chain_impl(ctx, g1, g2, ms, &p, &r, true);
+    if (rc) return rc;
+    *scale_out = r.scale;
     return CL_OK;
 }
 

@@ -124,6 +124,34 @@ int cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64
     return CL_OK;
 }
 
+int cl_leaf_intrinsic_scale(cl_context* ctx, const cl_base_graph* leaf, const cl_match_params* mp, const cl_anchor_params* ap, double* scale_out) {
+    if (!ctx || !leaf || !mp || !ap || !scale_out) return CL_ERR_INVALID_ARGUMENT;
+    if (leaf->n_nodes == 0 || leaf->src_id >= leaf->n_nodes || leaf->snk_id >= leaf->n_nodes) return CL_ERR_INVALID_ARGUMENT;
+    // the leaf against itself, the second copy under its own sentinel characters (src/core.cpp:128-133)
+    std::vector<uint8_t> lab1(leaf->label, leaf->label + leaf->n_nodes), lab2(lab1);
+    lab1[leaf->src_id] = 5; lab1[leaf->snk_id] = 6;
+    lab2[leaf->src_id] = 7; lab2[leaf->snk_id] = 8;
+    cl_base_graph a = *leaf, b = *leaf;
+    a.label = lab1.data();
+    b.label = lab2.data();
+    cl_owned_match_sets* ms = nullptr;
+    int rc = cl_find_matches(ctx, &a, &b, mp, &ms, nullptr);
+    if (rc) return rc;
+    cl_match_sets v;
+    cl_owned_match_sets_view(ms, &v);
+    // the main-diagonal subset (:135-148): one set per graph-1 walk, matched to itself, counts and full length retained
+    const uint64_t n_walks = v.set_off1[v.n_sets];
+    std::vector<uint64_t> set_off(n_walks + 1), count1(n_walks), count2(n_walks), full_length(n_walks);
+    for (uint64_t w = 0; w <= n_walks; ++w) set_off[w] = w;
+    for (uint64_t s = 0; s < v.n_sets; ++s)
+        for (uint64_t w = v.set_off1[s]; w < v.set_off1[s + 1]; ++w) { count1[w] = v.count1[s]; count2[w] = v.count2[s]; full_length[w] = v.full_length[s]; }
+    cl_match_sets diag{n_walks, set_off.data(), v.walk_off1, v.nodes1, set_off.data(), v.walk_off1, v.nodes1, count1.data(), count2.data(), full_length.data()};
+    // Anchorer::estimate_score_scale on (graph, graph) (:150-156; a leaf has one path, its ChainMerge is that path)
+    rc = cl_estimate_score_scale(ctx, &a, &a, &diag, ap, scale_out);
+    cl_owned_match_sets_free(ms);
+    return rc;
+}
+
 void cl_merge_params_default(cl_merge_params* p) {
     if (!p) return;
     cl_match_params_default(&p->match);

@@ -480,6 +480,16 @@ int  cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint6
 void cl_owned_base_graph_view(const cl_owned_base_graph* graph, cl_base_graph* view_out);
 void cl_owned_base_graph_free(cl_owned_base_graph* graph);
 
+/* Calibration (Core::calibrate_anchor_scores_and_identify_bonds without cyclisation, src/core.cpp:98-191).
+ * cl_estimate_score_scale: Anchorer::estimate_score_scale (include/centrolign/anchorer.hpp:998-1047): the sparse anchor chain,
+ * its weight over its length plus the shortest fill-in between its anchors.  cl_leaf_intrinsic_scale: the per-leaf step
+ * (src/core.cpp:122-166): the leaf's matches against itself (second copy under sentinels 7 / 8), the main-diagonal
+ * subset, estimate_score_scale; ScoreFunction::score_scale is the mean of the leaves' values (:168-184). */
+int cl_estimate_score_scale(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+                            const cl_anchor_params* params, double* scale_out);
+int cl_leaf_intrinsic_scale(cl_context* ctx, const cl_base_graph* leaf, const cl_match_params* match_params,
+                            const cl_anchor_params* anchor_params, double* scale_out);
+
 /* One merge of the progressive MSA from nothing but the two subproblem graphs: reassign_sentinels (5,6 / 7,8),
  * PathMatchFinder::find_matches, Core::align, fuse.  `fused` is the next subproblem's graph. */
 typedef struct cl_merge_params {

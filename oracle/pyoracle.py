@@ -410,6 +410,23 @@ def ref_partition_anchors(g1, g2, chain, score_scale=1.0, score_boundaries=False
     return seg[:int(ns.value)].copy()
 
 
+def ref_leaf_intrinsic_scale(g, max_count=3000, max_num_match_pairs=1250000, params=None, global_anchoring=True, fill_in=True):
+    """the per-leaf step of the compiled reference's calibration (src/core.cpp:122-166): the leaf's intrinsic score scale"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_leaf_intrinsic_scale.restype = C.c_int
+    lib.ref_leaf_intrinsic_scale.argtypes = [C.POINTER(BaseGraphC), C.POINTER(CloChainParams), C.c_uint64, C.c_int, C.c_uint64, C.c_int,
+                                             C.POINTER(C.c_double)]
+    params = params or default_chain_params()
+    c = g.as_c()
+    scale = C.c_double(0)
+    rc = lib.ref_leaf_intrinsic_scale(C.byref(c), C.byref(params), int(max_count), int(global_anchoring), int(max_num_match_pairs), int(fill_in),
+                                      C.byref(scale))
+    if rc:
+        raise RuntimeError("ref_leaf_intrinsic_scale failed: %d" % rc)
+    return float(scale.value)
+
+
 def ref_fuse(g1, g2, pairs):
     """the compiled reference's fuse (fuse.hpp:46-152): graph 2 merged into graph 1 along the alignment; returns capi.BaseGraph"""
     from centrolign_amd.capi import BaseGraphC, BaseGraph

@@ -661,6 +661,46 @@ int ref_find_matches(const cl_base_graph* g1, const cl_base_graph* g2, const clo
     return 0;
 }
 
+/* the per-leaf step of Core::calibrate_anchor_scores_and_identify_bonds (src/core.cpp:122-166) with the reference's own
+ * classes: self matches, the main-diagonal subset, Anchorer::estimate_score_scale over a ChainMerge */
+int ref_leaf_intrinsic_scale(const cl_base_graph* g, const clo_chain_params* cp, uint64_t max_count, int global_anchoring,
+                             uint64_t max_num_match_pairs, int fill_in, double* scale_out) {
+    SentinelTableau t;
+    BaseGraph b = build_base_graph(g, t);
+    reassign_sentinels(b, t, 5, 6);
+    SentinelTableau dummy = t;
+    dummy.src_sentinel = 7;
+    dummy.snk_sentinel = 8;
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    PathMatchFinder mf(sf);
+    mf.max_count = max_count;
+    std::vector<match_set_t> matches = mf.find_matches(b, b, t, dummy);
+    std::vector<match_set_t> diagonal;
+    for (const auto& ms : matches)
+        for (const auto& walk : ms.walks1) {
+            diagonal.emplace_back();
+            auto& m = diagonal.back();
+            m.walks1.emplace_back(walk);
+            m.walks2.emplace_back(walk);
+            m.count1 = ms.count1;
+            m.count2 = ms.count2;
+            m.full_length = ms.full_length;
+        }
+    OpenAnchorer an(sf);
+    for (int i = 0; i < 3; ++i) { an.gap_open[i] = cp->gap_open[i]; an.gap_extend[i] = cp->gap_extend[i]; }
+    an.global_anchoring = global_anchoring != 0;
+    an.max_num_match_pairs = max_num_match_pairs;
+    an.do_fill_in_anchoring = fill_in != 0;
+    an.chaining_algorithm = Anchorer::SparseAffine;
+    ChainMerge cm(b, t);
+    *scale_out = an.estimate_score_scale(diagonal, b, b, t, t, cm, cm, false, nullptr, nullptr);
+    return 0;
+}
+
 /* fuse (fuse.hpp:46-152) on flat inputs: graph 2 merged into graph 1 along the alignment; the fused graph flattened with its
  * adjacency lists in BaseGraph order.  out[]: label (u8), next_off, next_idx (u32), prev_off, prev_idx (u32), path_off,
  * path_nodes (u32) — malloc'ed, release with ref_free; sizes[]: nodes, edges, paths, path nodes. */

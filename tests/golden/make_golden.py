@@ -143,7 +143,33 @@ def fuse_goldens():
     np.savez_compressed(os.path.join(HERE, "fuse.npz"), **out)
 
 
+def calibration_goldens():
+    # 12. the per-leaf step of Core::calibrate_anchor_scores_and_identify_bonds (src/core.cpp:122-166) with the reference's own
+    #     classes: the four leaves of the 4 x 30 kbp MSA (their mean IS the score_scale that run used, align4_30k_merge2.npz)
+    #     and seeded leaves of other shapes (tests/helpers.calibration_leaves())
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests import helpers as H
+    from tests.test_extraction import load_stitch_case
+    out = {}
+    msa = []
+    for m in (0, 1):
+        _, graphs, _ = load_stitch_case("stitch4_30k_merge%d.npz" % m)
+        msa += [po.ref_leaf_intrinsic_scale(g, max_num_match_pairs=40000) for g in graphs]
+    out["msa4_30k.scales"] = np.array(msa)
+    out["msa4_30k.mean"] = np.array([sum(msa) / len(msa)])   # src/core.cpp:169-173: summed in leaf order
+    print("4 x 30 kbp leaves:", msa, "mean", out["msa4_30k.mean"][0])
+    names = []
+    for name, g, budget in H.calibration_leaves():
+        out[name] = np.array([po.ref_leaf_intrinsic_scale(g, max_num_match_pairs=budget)])
+        names.append(name)
+        print(name, out[name][0])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "calibration.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "calibration":
+        return calibration_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "match":
         return match_finding_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "fuse":
@@ -343,6 +369,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "despecify.npz"), **out)
     match_finding_goldens()
     fuse_goldens()
+    calibration_goldens()
     print("golden vectors written to", HERE)
 
 

@@ -243,3 +243,15 @@ def graph_digest(g):
         h.update(np.ascontiguousarray(getattr(g, k)).tobytes())
     h.update(np.array([g.src_id, g.snk_id], np.uint64).tobytes())
     return h.hexdigest()
+
+
+def calibration_leaves():
+    """seeded leaf graphs of the calibration parity tests: (name, graph, max_num_match_pairs)"""
+    out = []
+    for k, (length, budget, kw) in enumerate([(8000, 1250000, {}), (20000, 5000, {}), (12000, 1250000, dict(hor_div=0.1)),
+                                             (3000, 1250000, dict(mono_len=31, hor_n=4)), (40000, 30000, dict(seq_div=0.02))]):
+        seq = synth.hor_sequences(40 + k, length, 1, **kw)[0]
+        out.append(("leaf%d" % k, synth.base_graph_from_sequence(seq), budget))
+    rng = np.random.default_rng(9)
+    out.append(("random", synth.base_graph_from_sequence(rng.integers(0, 4, 5000).astype(np.uint8)), 1250000))
+    return out
