@@ -308,6 +308,47 @@ def fuse(dest, source, pairs):
     return _take_owned_base_graph(lib, h)
 
 
+def leaf_graph(sequence):
+    """make_base_graph + add_sentinels (src/modify_graph.cpp:30-77) of one sequence (str of ACGTN); host only"""
+    lib = load_library()
+    raw = sequence.encode() if isinstance(sequence, str) else bytes(sequence)
+    h = C.c_void_p()
+    rc = lib.cl_leaf_graph(raw, len(raw), C.byref(h))
+    if rc != 0:
+        raise ClError(rc)
+    return _take_owned_base_graph(lib, h)
+
+
+def explicit_cigar(graph1, graph2, pairs):
+    """explicit_cigar(alignment, graph1, graph2) (include/centrolign/alignment.hpp:2804-2843); returns bytes"""
+    lib = load_library()
+    g1, g2 = graph1.as_c(), graph2.as_c()
+    pairs = np.ascontiguousarray(pairs, np.uint64).reshape(-1, 2)
+    p, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_explicit_cigar(C.byref(g1), C.byref(g2), pairs.ctypes.data, len(pairs), C.byref(p), C.byref(n))
+    if rc != 0:
+        raise ClError(rc)
+    try:
+        return C.string_at(p, int(n.value))
+    finally:
+        _libc_free(p)
+
+
+def write_gfa(graph, path_names, decode=True):
+    """write_gfa (include/centrolign/gfa.hpp:46-157); returns the GFA text as bytes"""
+    lib = load_library()
+    g = graph.as_c()
+    names = (C.c_char_p * max(len(path_names), 1))(*[s.encode() for s in path_names])
+    p, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_write_gfa(C.byref(g), names, int(decode), C.byref(p), C.byref(n))
+    if rc != 0:
+        raise ClError(rc)
+    try:
+        return C.string_at(p, int(n.value))
+    finally:
+        _libc_free(p)
+
+
 def graphs_equal(a, b):
     return a.src_id == b.src_id and a.snk_id == b.snk_id and all(np.array_equal(getattr(a, k), getattr(b, k)) for k in GRAPH_KEYS)
 
@@ -803,6 +844,12 @@ def load_library(path=None):
     lib.cl_owned_base_graph_view.argtypes = [C.c_void_p, C.POINTER(BaseGraphC)]
     lib.cl_owned_base_graph_free.restype = None
     lib.cl_owned_base_graph_free.argtypes = [C.c_void_p]
+    lib.cl_leaf_graph.restype = C.c_int
+    lib.cl_leaf_graph.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.cl_explicit_cigar.restype = C.c_int
+    lib.cl_explicit_cigar.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cl_write_gfa.restype = C.c_int
+    lib.cl_write_gfa.argtypes = [C.POINTER(BaseGraphC), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.cl_estimate_score_scale.restype = C.c_int
     lib.cl_estimate_score_scale.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.POINTER(AnchorParams),
                                             C.POINTER(C.c_double)]
@@ -848,7 +895,7 @@ EXPORTED_SYMBOLS = [
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
-    "cl_estimate_score_scale", "cl_leaf_intrinsic_scale",
+    "cl_estimate_score_scale", "cl_leaf_intrinsic_scale", "cl_leaf_graph", "cl_explicit_cigar", "cl_write_gfa",
     "cl_fuse", "cl_owned_base_graph_view", "cl_owned_base_graph_free", "cl_merge_params_default", "cl_merge", "cl_merge_result_free",
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
 ]

@@ -15,12 +15,6 @@
 
 #include "cl_internal.hpp"
 
-struct cl_owned_base_graph {
-    std::vector<uint8_t> label;
-    std::vector<uint64_t> next_off, prev_off, path_off;
-    std::vector<uint32_t> next_idx, prev_idx, path_nodes;
-    uint64_t src_id = 0, snk_id = 0;
-};
 
 extern "C" {
 

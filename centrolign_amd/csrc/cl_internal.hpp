@@ -67,6 +67,14 @@ struct cl_owned_match_sets {
     std::vector<uint32_t> nodes1, nodes2;
 };
 
+// a BaseGraph + SentinelTableau owned by the library (cl_fuse, cl_merge, cl_leaf_graph); layout of cl_base_graph
+struct cl_owned_base_graph {
+    std::vector<uint8_t> label;
+    std::vector<uint64_t> next_off, prev_off, path_off;
+    std::vector<uint32_t> next_idx, prev_idx, path_nodes;
+    uint64_t src_id = 0, snk_id = 0;
+};
+
 // host-side parallel loop over [0, n): f(begin, end) on up to 16 threads (the reference is single-threaded; the host glue
 // around the device passes is not part of the compared arithmetic, every iteration writes its own outputs)
 #include <thread>

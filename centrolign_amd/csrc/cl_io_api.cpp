@@ -1,0 +1,169 @@
+// cl_io_api.cpp — the data formats either side of a merge: the leaf graph of a sequence (make_base_graph + add_sentinels,
+// src/modify_graph.cpp:30-77), the explicit CIGAR of a pairwise alignment (include/centrolign/alignment.hpp:2804-2843) and the
+// GFA of a subproblem graph (include/centrolign/gfa.hpp:46-157).  Host code; byte-identical text.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cl_internal.hpp"
+
+namespace {
+
+// encode_base (src/utility.cpp:324-345): A C G T N in either case -> 0..4, anything else -> 5
+uint8_t encode_base(char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    case 'N': case 'n': return 4;
+    default: return 5;
+    }
+}
+
+char* to_c_string(const std::string& s, uint64_t* len_out) {
+    char* p = (char*)malloc(s.size() + 1);
+    if (!p) return nullptr;
+    memcpy(p, s.data(), s.size());
+    p[s.size()] = '\0';
+    if (len_out) *len_out = s.size();
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cl_leaf_graph(const char* sequence, uint64_t n, cl_owned_base_graph** out) {
+    if (!sequence || n == 0 || n >= 0xFFFFFFF0ull || !out) return CL_ERR_INVALID_ARGUMENT;   // make_base_graph asserts !sequence.empty()
+    std::unique_ptr<cl_owned_base_graph> g(new cl_owned_base_graph());
+    const uint32_t src = (uint32_t)n, snk = (uint32_t)n + 1;
+    g->label.resize(n + 2);
+    for (uint64_t i = 0; i < n; ++i) g->label[i] = encode_base(sequence[i]);
+    g->label[src] = 5;   // add_sentinels(graph, 5, 6) (src/execution.cpp:70)
+    g->label[snk] = 6;
+    g->next_off.resize(n + 3);
+    g->prev_off.resize(n + 3);
+    g->next_idx.resize(n + 1);
+    g->prev_idx.resize(n + 1);
+    for (uint64_t i = 0; i < n; ++i) {
+        g->next_off[i] = i;
+        g->next_idx[i] = i + 1 < n ? (uint32_t)(i + 1) : snk;
+        g->prev_off[i] = i;
+        g->prev_idx[i] = i ? (uint32_t)(i - 1) : src;
+    }
+    g->next_off[src] = n; g->next_idx[n] = 0;          // source -> first base
+    g->next_off[snk] = n + 1; g->next_off[n + 2] = n + 1;
+    g->prev_off[src] = n; g->prev_off[snk] = n;        // the source has no predecessor
+    g->prev_idx[n] = (uint32_t)(n - 1);                // last base -> sink
+    g->prev_off[n + 2] = n + 1;
+    g->path_off = {0, n};
+    g->path_nodes.resize(n);
+    for (uint64_t i = 0; i < n; ++i) g->path_nodes[i] = (uint32_t)i;
+    g->src_id = src;
+    g->snk_id = snk;
+    *out = g.release();
+    return CL_OK;
+}
+
+int cl_explicit_cigar(const cl_base_graph* g1, const cl_base_graph* g2, const uint64_t* pairs, uint64_t n_pairs, char** text_out, uint64_t* len_out) {
+    if (!g1 || !g2 || (n_pairs && !pairs) || !text_out) return CL_ERR_INVALID_ARGUMENT;
+    const uint64_t gap = ~(uint64_t)0;
+    std::string out;
+    int curr_len = 0;   // an int in the reference too
+    char curr_op = '\0';
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        if ((a != gap && a >= g1->n_nodes) || (b != gap && b >= g2->n_nodes)) return CL_ERR_INVALID_ARGUMENT;
+        const char op = a == gap ? 'I' : b == gap ? 'D' : g1->label[a] == g2->label[b] ? '=' : 'X';
+        if (op == curr_op) { ++curr_len; continue; }
+        if (curr_len != 0) { out += std::to_string(curr_len); out += curr_op; }
+        curr_len = 1;
+        curr_op = op;
+    }
+    if (curr_len != 0) { out += std::to_string(curr_len); out += curr_op; }
+    *text_out = to_c_string(out, len_out);
+    return *text_out ? CL_OK : CL_ERR_OUT_OF_MEMORY;
+}
+
+int cl_write_gfa(const cl_base_graph* g, const char* const* path_names, int decode, char** text_out, uint64_t* len_out) {
+    if (!g || !text_out || (g->n_paths && !path_names)) return CL_ERR_INVALID_ARGUMENT;
+    const uint64_t n = g->n_nodes;
+    auto sentinel = [&](uint64_t v) { return v == g->src_id || v == g->snk_id; };
+    auto next_size = [&](uint64_t v) { return g->next_off[v + 1] - g->next_off[v]; };
+    auto prev_size = [&](uint64_t v) { return g->prev_off[v + 1] - g->prev_off[v]; };
+    auto first_next = [&](uint64_t v) { return (uint64_t)g->next_idx[g->next_off[v]]; };
+    auto first_prev = [&](uint64_t v) { return (uint64_t)g->prev_idx[g->prev_off[v]]; };
+    std::vector<uint8_t> path_begin(n, 0), path_end(n, 0), compacted_end(n, 0);
+    std::vector<uint64_t> compacted_id(n, ~(uint64_t)0);
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        if (g->path_off[p + 1] == g->path_off[p]) return CL_ERR_INVALID_ARGUMENT;   // the reference reads front() / back()
+        path_begin[g->path_nodes[g->path_off[p]]] = 1;
+        path_end[g->path_nodes[g->path_off[p + 1] - 1]] = 1;
+    }
+    static const char dec[] = {'A', 'C', 'G', 'T', 'N', '\0'};   // src/utility.cpp:355
+    std::string out = "H\tVN:Z:1.0\n";
+    // segments: maximal non-branching runs that no path begins or ends inside (gfa.hpp:66-121)
+    uint64_t next_compacted_id = 1;
+    std::vector<uint64_t> run;
+    for (uint64_t v = 0; v < n; ++v) {
+        if (compacted_id[v] != ~(uint64_t)0 || sentinel(v)) continue;
+        run.assign(1, v);
+        while (!path_begin[run.back()] && prev_size(run.back()) == 1 && !path_end[first_prev(run.back())] &&
+               next_size(first_prev(run.back())) == 1 && !sentinel(first_prev(run.back())))
+            run.push_back(first_prev(run.back()));
+        std::reverse(run.begin(), run.end());
+        while (!path_end[run.back()] && next_size(run.back()) == 1 && !path_begin[first_next(run.back())] &&
+               prev_size(first_next(run.back())) == 1 && !sentinel(first_next(run.back())))
+            run.push_back(first_next(run.back()));
+        out += "S\t";
+        out += std::to_string(next_compacted_id);
+        out += '\t';
+        for (uint64_t u : run) {
+            compacted_id[u] = next_compacted_id;
+            out += decode ? dec[g->label[u] < 5 ? g->label[u] : 5] : (char)g->label[u];
+        }
+        out += '\n';
+        ++next_compacted_id;
+        compacted_end[run.back()] = 1;
+    }
+    // links (:123-136)
+    for (uint64_t v = 0; v < n; ++v) {
+        if (!compacted_end[v] || sentinel(v)) continue;
+        for (uint64_t e = g->next_off[v]; e < g->next_off[v + 1]; ++e) {
+            const uint64_t w = g->next_idx[e];
+            if (sentinel(w)) continue;
+            out += "L\t";
+            out += std::to_string(compacted_id[v]);
+            out += "\t+\t";
+            out += std::to_string(compacted_id[w]);
+            out += "\t+\t*\n";
+        }
+    }
+    // paths (:138-156)
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        out += "P\t";
+        out += path_names[p];
+        out += '\t';
+        bool write_next = true, first = true;
+        for (uint64_t i = g->path_off[p]; i < g->path_off[p + 1]; ++i) {
+            const uint64_t v = g->path_nodes[i];
+            if (sentinel(v)) continue;
+            if (write_next) {
+                if (!first) out += ',';
+                out += std::to_string(compacted_id[v]);
+                out += '+';
+                first = false;
+            }
+            write_next = compacted_end[v];
+        }
+        out += "\t*\n";
+    }
+    *text_out = to_c_string(out, len_out);
+    return *text_out ? CL_OK : CL_ERR_OUT_OF_MEMORY;
+}
+
+}  // extern "C"

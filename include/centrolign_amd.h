@@ -480,6 +480,17 @@ int  cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint6
 void cl_owned_base_graph_view(const cl_owned_base_graph* graph, cl_base_graph* view_out);
 void cl_owned_base_graph_free(cl_owned_base_graph* graph);
 
+/* The data formats either side of a merge (host only; text is malloc'ed and NUL-terminated, release with free()).
+ * cl_leaf_graph: make_base_graph + add_sentinels(graph, 5, 6) (src/modify_graph.cpp:30-77, src/execution.cpp:66-73) of one sequence
+ * (ACGTN in either case -> 0..4, anything else -> 5, src/utility.cpp:324-345): nodes 0..n-1 in a chain, the source sentinel
+ * n, the sink n+1, one path.  cl_explicit_cigar: explicit_cigar(alignment, graph1, graph2)
+ * (include/centrolign/alignment.hpp:2804-2843), the pairwise output of the CLI.  cl_write_gfa: write_gfa(graph, tableau, out,
+ * decode) (include/centrolign/gfa.hpp:46-157), the MSA output; path_names[p] = BaseGraph::path_name(p). */
+int cl_leaf_graph(const char* sequence, uint64_t n, cl_owned_base_graph** out);
+int cl_explicit_cigar(const cl_base_graph* graph1, const cl_base_graph* graph2, const uint64_t* pairs, uint64_t n_pairs, char** text_out,
+                      uint64_t* len_out /* may be NULL */);
+int cl_write_gfa(const cl_base_graph* graph, const char* const* path_names, int decode, char** text_out, uint64_t* len_out /* may be NULL */);
+
 /* Calibration (Core::calibrate_anchor_scores_and_identify_bonds without cyclisation, src/core.cpp:98-191).
  * cl_estimate_score_scale: Anchorer::estimate_score_scale (include/centrolign/anchorer.hpp:998-1047): the sparse anchor chain,
  * its weight over its length plus the shortest fill-in between its anchors.  cl_leaf_intrinsic_scale: the per-leaf step

@@ -427,6 +427,64 @@ def ref_leaf_intrinsic_scale(g, max_count=3000, max_num_match_pairs=1250000, par
     return float(scale.value)
 
 
+def _graph_from_out(lib, out, sizes, src_id, snk_id):
+    from centrolign_amd.capi import BaseGraph
+    n, e, p, pn = [int(x) for x in sizes]
+    def arr(i, dt, k):
+        a = np.ctypeslib.as_array(C.cast(out[i], C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(max(k, 1),))[:k].copy()
+        lib.ref_free(out[i])
+        return a
+    return BaseGraph(arr(0, np.uint8, n), arr(1, np.uint64, n + 1), arr(2, np.uint32, e), arr(3, np.uint64, n + 1), arr(4, np.uint32, e),
+                     arr(5, np.uint64, p + 1), arr(6, np.uint32, pn), src_id, snk_id)
+
+
+def ref_leaf_graph(sequence):
+    """make_base_graph + add_sentinels(5, 6) of the compiled reference for one sequence (str); returns capi.BaseGraph"""
+    lib = ref_lib()
+    lib.ref_leaf_graph.restype = C.c_int
+    lib.ref_leaf_graph.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    out, sizes, ids = (C.c_void_p * 7)(), (C.c_uint64 * 4)(), (C.c_uint64 * 2)()
+    raw = sequence.encode()
+    if lib.ref_leaf_graph(raw, len(raw), out, sizes, ids):
+        raise RuntimeError("ref_leaf_graph failed")
+    return _graph_from_out(lib, out, sizes, int(ids[0]), int(ids[1]))
+
+
+def ref_write_gfa(g, names, decode=True):
+    """write_gfa (gfa.hpp:46-157) of the compiled reference; returns the text (bytes)"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_write_gfa.restype = C.c_int
+    lib.ref_write_gfa.argtypes = [C.POINTER(BaseGraphC), C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c = g.as_c()
+    arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+    p, n = C.c_void_p(), C.c_uint64(0)
+    if lib.ref_write_gfa(C.byref(c), arr, int(decode), C.byref(p), C.byref(n)):
+        raise RuntimeError("ref_write_gfa failed")
+    text = C.string_at(p, int(n.value))
+    lib.ref_free(p)
+    return text
+
+
+def ref_explicit_cigar(g1, g2, pairs):
+    """explicit_cigar(alignment, graph1, graph2) (alignment.hpp:2804-2843) of the compiled reference; returns bytes"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_explicit_cigar.restype = C.c_int
+    lib.ref_explicit_cigar.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c1, c2 = g1.as_c(), g2.as_c()
+    pairs = np.ascontiguousarray(pairs, np.uint64).reshape(-1, 2)
+    p = C.c_void_p()
+    if lib.ref_explicit_cigar(C.byref(c1), C.byref(c2), pairs.ctypes.data, len(pairs), C.byref(p)):
+        raise RuntimeError("ref_explicit_cigar failed")
+    text = C.string_at(p)
+    lib.ref_free(p)
+    return text
+
+
 def ref_fuse(g1, g2, pairs):
     """the compiled reference's fuse (fuse.hpp:46-152): graph 2 merged into graph 1 along the alignment; returns capi.BaseGraph"""
     from centrolign_amd.capi import BaseGraphC, BaseGraph

@@ -701,6 +701,80 @@ int ref_leaf_intrinsic_scale(const cl_base_graph* g, const clo_chain_params* cp,
     return 0;
 }
 
+/* flatten a BaseGraph the way ref_fuse documents */
+static void flatten_graph(const BaseGraph& b1, void** out, uint64_t* sizes) {
+    const uint64_t n = b1.node_size();
+    uint64_t edges = 0, pn = 0;
+    for (uint64_t v = 0; v < n; ++v) edges += b1.next_size(v);
+    for (uint64_t p = 0; p < b1.path_size(); ++p) pn += b1.path(p).size();
+    uint8_t* label = (uint8_t*)malloc(n ? n : 1);
+    uint64_t* next_off = (uint64_t*)malloc((n + 1) * 8); uint32_t* next_idx = (uint32_t*)malloc((edges ? edges : 1) * 4);
+    uint64_t* prev_off = (uint64_t*)malloc((n + 1) * 8); uint32_t* prev_idx = (uint32_t*)malloc((edges ? edges : 1) * 4);
+    uint64_t* path_off = (uint64_t*)malloc((b1.path_size() + 1) * 8); uint32_t* path_nodes = (uint32_t*)malloc((pn ? pn : 1) * 4);
+    uint64_t a = 0, b = 0, c = 0;
+    next_off[0] = prev_off[0] = path_off[0] = 0;
+    for (uint64_t v = 0; v < n; ++v) {
+        label[v] = (uint8_t)b1.label(v);
+        for (auto w : b1.next(v)) next_idx[a++] = (uint32_t)w;
+        next_off[v + 1] = a;
+        for (auto w : b1.previous(v)) prev_idx[b++] = (uint32_t)w;
+        prev_off[v + 1] = b;
+    }
+    for (uint64_t p = 0; p < b1.path_size(); ++p) {
+        for (auto v : b1.path(p)) path_nodes[c++] = (uint32_t)v;
+        path_off[p + 1] = c;
+    }
+    out[0] = label; out[1] = next_off; out[2] = next_idx; out[3] = prev_off; out[4] = prev_idx; out[5] = path_off; out[6] = path_nodes;
+    sizes[0] = n; sizes[1] = edges; sizes[2] = b1.path_size(); sizes[3] = pn;
+}
+
+/* make_base_graph + add_sentinels(graph, 5, 6) as Execution builds a leaf subproblem (src/execution.cpp:66-73); ids_out = src, snk */
+int ref_leaf_graph(const char* sequence, uint64_t n, void** out, uint64_t* sizes, uint64_t* ids_out) {
+    BaseGraph g = make_base_graph("leaf", std::string(sequence, sequence + n));
+    SentinelTableau t = add_sentinels(g, 5, 6);
+    flatten_graph(g, out, sizes);
+    ids_out[0] = t.src_id; ids_out[1] = t.snk_id;
+    return 0;
+}
+
+static char* dup_text(const std::string& s) {
+    char* p = (char*)malloc(s.size() + 1);
+    memcpy(p, s.data(), s.size());
+    p[s.size()] = '\0';
+    return p;
+}
+
+/* write_gfa (gfa.hpp:46-157) of a flat graph whose paths get the given names */
+int ref_write_gfa(const cl_base_graph* g, const char* const* names, int decode, char** text_out, uint64_t* len_out) {
+    BaseGraph bg;
+    for (uint64_t v = 0; v < g->n_nodes; ++v) bg.add_node((char)g->label[v]);
+    clo_graph cg;
+    cg.n = g->n_nodes; cg.label = g->label; cg.prev_off = g->prev_off; cg.prev_idx = g->prev_idx;
+    cg.next_off = g->next_off; cg.next_idx = g->next_idx; cg.n_src = cg.n_snk = 0; cg.src = cg.snk = nullptr;
+    BaseGraph b = build_graph(&cg);
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        auto id = b.add_path(names[p]);
+        for (uint64_t i = g->path_off[p]; i < g->path_off[p + 1]; ++i) b.extend_path(id, g->path_nodes[i]);
+    }
+    SentinelTableau t;
+    t.src_id = g->src_id; t.snk_id = g->snk_id;
+    std::stringstream ss;
+    write_gfa(b, t, ss, decode != 0);
+    *text_out = dup_text(ss.str());
+    *len_out = ss.str().size();
+    return 0;
+}
+
+/* explicit_cigar(alignment, graph1, graph2) (alignment.hpp:2804-2843) */
+int ref_explicit_cigar(const cl_base_graph* g1, const cl_base_graph* g2, const uint64_t* pairs, uint64_t n_pairs, char** text_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    Alignment aln;
+    for (uint64_t i = 0; i < n_pairs; ++i) aln.emplace_back(pairs[2 * i], pairs[2 * i + 1]);
+    *text_out = dup_text(explicit_cigar(aln, b1, b2));
+    return 0;
+}
+
 /* fuse (fuse.hpp:46-152) on flat inputs: graph 2 merged into graph 1 along the alignment; the fused graph flattened with its
  * adjacency lists in BaseGraph order.  out[]: label (u8), next_off, next_idx (u32), prev_off, prev_idx (u32), path_off,
  * path_nodes (u32) — malloc'ed, release with ref_free; sizes[]: nodes, edges, paths, path nodes. */
@@ -710,32 +784,8 @@ int ref_fuse(const cl_base_graph* g1, const cl_base_graph* g2, const uint64_t* p
     Alignment aln;
     for (uint64_t i = 0; i < n_pairs; ++i) aln.emplace_back(pairs[2 * i], pairs[2 * i + 1]);
     fuse(b1, b2, t1, t2, aln);
-    const uint64_t n = b1.node_size();
-    uint64_t edges = 0, pn = 0;
-    for (uint64_t v = 0; v < n; ++v) edges += b1.next_size(v);
-    for (uint64_t p = 0; p < b1.path_size(); ++p) pn += b1.path(p).size();
-    uint8_t* label = (uint8_t*)malloc(n ? n : 1);
-    uint64_t* next_off = (uint64_t*)malloc((n + 1) * 8); uint32_t* next_idx = (uint32_t*)malloc((edges ? edges : 1) * 4);
-    uint64_t* prev_off = (uint64_t*)malloc((n + 1) * 8); uint32_t* prev_idx = (uint32_t*)malloc((edges ? edges : 1) * 4);
-    uint64_t* path_off = (uint64_t*)malloc((b1.path_size() + 1) * 8); uint32_t* path_nodes = (uint32_t*)malloc((pn ? pn : 1) * 4);
-    uint64_t a = 0, b = 0;
-    next_off[0] = prev_off[0] = 0;
-    for (uint64_t v = 0; v < n; ++v) {
-        label[v] = (uint8_t)b1.label(v);
-        for (auto w : b1.next(v)) next_idx[a++] = (uint32_t)w;
-        next_off[v + 1] = a;
-        for (auto w : b1.previous(v)) prev_idx[b++] = (uint32_t)w;
-        prev_off[v + 1] = b;
-    }
-    uint64_t c = 0;
-    path_off[0] = 0;
-    for (uint64_t p = 0; p < b1.path_size(); ++p) {
-        for (auto v : b1.path(p)) path_nodes[c++] = (uint32_t)v;
-        path_off[p + 1] = c;
-    }
-    out[0] = label; out[1] = next_off; out[2] = next_idx; out[3] = prev_off; out[4] = prev_idx; out[5] = path_off; out[6] = path_nodes;
-    sizes[0] = n; sizes[1] = edges; sizes[2] = b1.path_size(); sizes[3] = pn;
-    return b == edges ? 0 : -1;
+    flatten_graph(b1, out, sizes);
+    return 0;
 }
 
 /* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as

@@ -167,7 +167,42 @@ def calibration_goldens():
     np.savez_compressed(os.path.join(HERE, "calibration.npz"), **out)
 
 
+def io_goldens():
+    # 13. leaf graphs, explicit CIGAR, GFA: sha256 of the REFERENCE's text for the cases of tests/test_io.io_texts() (one GFA in full),
+    #     the reference's leaf graphs of tests/test_io.SEQS in full
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import hashlib
+    from tests import helpers as H
+    from tests import test_io as T
+    from tests.test_extraction import load_stitch_case
+    from centrolign_amd import capi
+    out = {}
+    sha = lambda b: np.array([hashlib.sha256(b).hexdigest()])
+    for m in range(3):
+        z, graphs, _ = load_stitch_case("stitch4_30k_merge%d.npz" % m)
+        pairs = z["stitched"].reshape(-1, 2)
+        fused = po.ref_fuse(graphs[0], graphs[1], pairs)
+        names = ["seq%d" % i for i in range(len(fused.path_off) - 1)]
+        out["gfa.merge%d" % m] = sha(po.ref_write_gfa(fused, names))
+        out["gfa_raw.merge%d" % m] = sha(po.ref_write_gfa(fused, names, False))
+        out["cigar.merge%d" % m] = sha(po.ref_explicit_cigar(graphs[0], graphs[1], pairs))
+    for name, g1, g2, pairs in H.fuse_cases()[:10]:
+        fused = po.ref_fuse(g1, g2, pairs)
+        names = ["p%d" % i for i in range(len(fused.path_off) - 1)]
+        out["gfa." + name] = sha(po.ref_write_gfa(fused, names))
+        out["cigar." + name] = sha(po.ref_explicit_cigar(g1, g2, pairs))
+        if name == "fuse02":
+            out["gfa_text.fuse02"] = np.frombuffer(po.ref_write_gfa(fused, ["a", "b", "c", "d", "e", "f"][:len(names)]), np.uint8)
+    for i, seq in enumerate(T.SEQS):
+        g = po.ref_leaf_graph(seq)
+        for k in capi.GRAPH_KEYS:
+            out["leaf%d.%s" % (i, k)] = getattr(g, k)
+    np.savez_compressed(os.path.join(HERE, "io.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "io":
+        return io_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "calibration":
         return calibration_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "match":
@@ -370,6 +405,7 @@ def main():
     match_finding_goldens()
     fuse_goldens()
     calibration_goldens()
+    io_goldens()
     print("golden vectors written to", HERE)
 
 
