@@ -200,7 +200,31 @@ def io_goldens():
     np.savez_compressed(os.path.join(HERE, "io.npz"), **out)
 
 
+def msa_goldens():
+    # 14. the reference's whole pipeline (Core::execute + write_gfa / explicit_cigar, through ref_msa_dump) on small inputs: the
+    #     text a native run must reproduce byte for byte (tests/test_msa.py)
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests import helpers as H
+    from centrolign_amd import msa, synth
+    out = {}
+    for name, n, length, seed, budget in H.msa_cases():
+        seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+        names = ["seq%d" % i for i in range(n)]
+        with tempfile.TemporaryDirectory() as d:
+            fa, nwk, o = os.path.join(d, "in.fa"), os.path.join(d, "t.nwk"), os.path.join(d, "out.txt")
+            synth.write_fasta(fa, seqs, names)
+            open(nwk, "w").write(msa.newick(msa.balanced_tree(names)) + ";")
+            po.ref_msa_dump(fa, newick_path=nwk, out_path=o, max_num_match_pairs=budget)
+            text = open(o, "rb").read()
+        out[name] = np.frombuffer(text, np.uint8)
+        print(name, len(text), "bytes")
+    np.savez_compressed(os.path.join(HERE, "msa_text.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "msa":
+        return msa_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "io":
         return io_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "calibration":
@@ -406,6 +430,7 @@ def main():
     fuse_goldens()
     calibration_goldens()
     io_goldens()
+    msa_goldens()
     print("golden vectors written to", HERE)
 
 

@@ -255,3 +255,9 @@ def calibration_leaves():
     rng = np.random.default_rng(9)
     out.append(("random", synth.base_graph_from_sequence(rng.integers(0, 4, 5000).astype(np.uint8)), 1250000))
     return out
+
+
+def msa_cases():
+    """(name, n sequences, length, seed, max_num_match_pairs) of the end-to-end fixtures (balanced guide tree over seq0..)"""
+    return [("pair_10k", 2, 10000, 21, 1250000), ("pair_60k", 2, 60000, 3, 100000), ("msa4_8k", 4, 8000, 13, 20000), ("msa3_6k", 3, 6000, 5, 1250000),
+            ("msa5_5k", 5, 5000, 8, 8000)]
