@@ -179,6 +179,37 @@ def match_section(ctx, with_reference):
     return out
 
 
+def end_to_end_section(ctx, with_reference):
+    """BASELINE configs[1] as the CLI runs it, without the reference in the loop: FASTA-level sequences -> leaf graphs ->
+    calibration -> match finding -> Core::align -> fuse -> explicit CIGAR (centrolign_amd/msa.py over the C ABI), wall-clock;
+    beside it the compiled reference's whole pipeline on the same sequences (ref_msa_dump = Core::execute + explicit_cigar) and a
+    byte comparison of the two outputs"""
+    import hashlib
+    import tempfile
+    from centrolign_amd import msa, synth
+    seqs = synth.hor_sequences(7, 1000000, 2)
+    names = ["seq0", "seq1"]
+    t0 = time.perf_counter()
+    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), msa.balanced_tree(names))
+    text = msa.output_text(r)
+    wall = time.perf_counter() - t0
+    out = {"pipeline": "leaf graphs + calibration + find_matches + Core::align + fuse + explicit_cigar", "wall_s": wall,
+           "score_scale": r["scale"], "match_ms": r["stats"]["match_ms"], "align_ms": r["stats"]["align_ms"], "fuse_ms": r["stats"]["fuse_ms"],
+           "cigar_bytes": len(text), "cigar_sha256": hashlib.sha256(text).hexdigest()}
+    if with_reference:
+        from oracle import pyoracle as po
+        if po.have_ref():
+            with tempfile.TemporaryDirectory() as d:
+                fa, o = os.path.join(d, "in.fa"), os.path.join(d, "out.txt")
+                synth.write_fasta(fa, seqs, names)
+                t0 = time.perf_counter()
+                tm = po.ref_msa_dump(fa, out_path=o)
+                secs = time.perf_counter() - t0
+                want = open(o, "rb").read().rstrip(b"\n")
+            out["cpu_reference"] = {"seconds": secs, "cores": 1, "kind": "reference", "phases_s": tm, "identical_output": bool(want == text)}
+    return out
+
+
 def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: independent passes overlap on separate queues
     ap = argparse.ArgumentParser()
@@ -275,6 +306,7 @@ def main():
             if ch is not None:
                 out["chaining"] = ch
             out["match_finding"] = match_section(ctx, not args.no_cpu_baseline)
+            out["end_to_end"] = end_to_end_section(ctx, not args.no_cpu_baseline)
         print(json.dumps(out))
     barrier()
     plan.destroy()

@@ -15,52 +15,32 @@ sys.path.insert(0, HERE)
 from centrolign_amd import capi, synth  # noqa: E402
 
 
-def balanced(items):
-    if len(items) == 1:
-        return items[0]
-    h = len(items) // 2
-    return (balanced(items[:h]), balanced(items[h:]))
-
-
-def newick(t):
-    return t if isinstance(t, str) else "(" + newick(t[0]) + "," + newick(t[1]) + ")"
+from centrolign_amd import msa  # noqa: E402
 
 
 def main():
     n, length, budget, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
     names = ["seq%d" % i for i in range(n)]
-    tree = balanced(names)
+    tree = msa.balanced_tree(names)
     ctx = capi.Context(0)
     ctx.find_matches(capi.leaf_graph("ACGTACGTAC"), capi.leaf_graph("ACGTTCGTAC"))   # first-use initialisation outside the timed region
     t0 = time.perf_counter()
-    leaves = {nm: capi.leaf_graph(s) for nm, s in zip(names, seqs)}
-    scales = [ctx.leaf_intrinsic_scale(leaves[nm], max_num_match_pairs=budget) for nm in names]
-    scale = sum(scales) / len(scales)
-    t1 = time.perf_counter()
-    stats = dict(match=0.0, align=0.0, fuse=0.0, merges=0)
-
-    def solve(t):
-        if isinstance(t, str):
-            return leaves[t], [t]
-        (g1, p1), (g2, p2) = solve(t[0]), solve(t[1])
-        r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=budget)
-        stats["match"] += r["match_ms"]; stats["align"] += r["align_ms"]; stats["fuse"] += r["fuse_ms"]; stats["merges"] += 1
-        return r["fused"], p1 + p2
-    root, paths = solve(tree)
-    t2 = time.perf_counter()
+    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), tree, max_num_match_pairs=budget)
+    root, paths, scale, stats = r["root"], r["paths"], r["scale"], r["stats"]
+    t1 = t2 = time.perf_counter()
     gfa = capi.write_gfa(root, paths)
     t3 = time.perf_counter()
-    print("native: calibration %.2f s (scale %.17g), %d merges %.2f s (matches %.2f, align %.2f, fuse %.2f s), GFA %.2f s; total %.2f s; "
-          "root graph %d nodes, GFA %d bytes sha256 %s" % (t1 - t0, scale, stats["merges"], t2 - t1, stats["match"] / 1e3, stats["align"] / 1e3,
-                                                           stats["fuse"] / 1e3, t3 - t2, t3 - t0, len(root.label), len(gfa),
-                                                           hashlib.sha256(gfa).hexdigest()[:16]), flush=True)
+    print("native: leaf graphs + calibration + %d merges %.2f s (scale %.17g; in the merges: matches %.2f, align %.2f, fuse %.2f s), GFA %.2f s; "
+          "total %.2f s; root graph %d nodes, GFA %d bytes sha256 %s" % (stats["merges"], t1 - t0, scale, stats["match_ms"] / 1e3, stats["align_ms"] / 1e3,
+                                                                         stats["fuse_ms"] / 1e3, t3 - t2, t3 - t0, len(root.label), len(gfa),
+                                                                         hashlib.sha256(gfa).hexdigest()[:16]), flush=True)
     from oracle import pyoracle as po
     if po.have_ref() and "--no-ref" not in sys.argv:
         with tempfile.TemporaryDirectory() as d:
             fa, nwk, out = os.path.join(d, "in.fa"), os.path.join(d, "t.nwk"), os.path.join(d, "out.gfa")
             synth.write_fasta(fa, seqs, names)
-            open(nwk, "w").write(newick(tree) + ";")
+            open(nwk, "w").write(msa.newick(tree) + ";")
             t = time.perf_counter()
             tm = po.ref_msa_dump(fa, newick_path=nwk, out_path=out, max_num_match_pairs=budget)
             wall = time.perf_counter() - t
