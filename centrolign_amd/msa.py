@@ -52,3 +52,106 @@ def output_text(result):
         g1, g2 = result["root_inputs"]
         return capi.explicit_cigar(g1, g2, result["alignment"])
     return capi.write_gfa(result["root"], result["paths"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same MSA over several ranks (one process per GPU).  The path shards at two levels with no collective inside the
+# work: the leaf calibrations are independent, and so are sibling merges of the guide tree.  What does cross
+# ranks is the one real exchange step of a progressive MSA: a merge needs the fused graphs of its two children, so the
+# owner of the right child sends its graph to the owner of the left child.  Graphs are host arrays at the C-ABI boundary, so
+# the transport is a host-side point-to-point (a gloo group), not a device collective.
+
+def _count_leaves(tree):
+    return 1 if isinstance(tree, str) else _count_leaves(tree[0]) + _count_leaves(tree[1])
+
+
+def split_ranks(tree, ranks):
+    """ranks of the left / right child of an internal node: proportional to leaf counts, at least one each"""
+    nl, nr = _count_leaves(tree[0]), _count_leaves(tree[1])
+    k = max(1, min(len(ranks) - 1, round(len(ranks) * nl / (nl + nr))))
+    return ranks[:k], ranks[k:]
+
+
+def _pack_graph(g):
+    import numpy as np
+    head = np.array([len(getattr(g, k)) for k in capi.GRAPH_KEYS] + [g.src_id, g.snk_id], np.int64)
+    body = b"".join(np.ascontiguousarray(getattr(g, k)).tobytes() for k in capi.GRAPH_KEYS)
+    return head, np.frombuffer(body, np.uint8)
+
+
+def _unpack_graph(head, body):
+    import numpy as np
+    dts = (np.uint8, np.uint64, np.uint32, np.uint64, np.uint32, np.uint64, np.uint32)
+    arrays, at = [], 0
+    for n, dt in zip(head[:7], dts):
+        nbytes = int(n) * np.dtype(dt).itemsize
+        arrays.append(np.frombuffer(body[at:at + nbytes].tobytes(), dt).copy())
+        at += nbytes
+    return capi.BaseGraph(*arrays, int(head[7]), int(head[8]))
+
+
+def send_graph(g, dst, dist, group=None):
+    import torch
+    head, body = _pack_graph(g)
+    dist.send(torch.from_numpy(head.copy()), dst, group=group)
+    dist.send(torch.from_numpy(body.copy()), dst, group=group)
+
+
+def recv_graph(src, dist, group=None):
+    import numpy as np
+    import torch
+    head = torch.zeros(9, dtype=torch.int64)
+    dist.recv(head, src, group=group)
+    sizes = (1, 8, 4, 8, 4, 8, 4)
+    body = torch.zeros(int(sum(int(n) * s for n, s in zip(head[:7].tolist(), sizes))), dtype=torch.uint8)
+    dist.recv(body, src, group=group)
+    return _unpack_graph(head.numpy(), body.numpy())
+
+
+def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000):
+    """progressive_msa over `world` ranks; every rank calls it with the same arguments (its own ctx).  `group` must be a
+    host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None."""
+    import torch
+    order = leaves_of(tree)
+    # level 1: leaf calibrations, round-robin; the scales meet by a SUM all-reduce of a vector that is zero except at the
+    # rank's own leaves (x + 0.0 is exact), and every rank takes the mean in leaf order like the reference (src/core.cpp:169-173)
+    leaves = {}
+    mine = torch.zeros(len(order), dtype=torch.float64)
+    for i, nm in enumerate(order):
+        if i % world == rank:
+            leaves[nm] = capi.leaf_graph(sequences[nm])
+            mine[i] = ctx.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
+    dist.all_reduce(mine, group=group)
+    scales = mine.tolist()
+    scale = sum(scales) / len(scales)
+    stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0, graphs_received=0)
+
+    def merge(g1, g2):
+        r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
+        for k in ("match_ms", "align_ms", "fuse_ms"):
+            stats[k] += r[k]
+        stats["merges"] += 1
+        return r["fused"]
+
+    def solve(t, ranks):
+        """the subtree's graph on ranks[0], None elsewhere"""
+        if rank not in ranks:
+            return None
+        if isinstance(t, str):
+            return leaves[t] if t in leaves else capi.leaf_graph(sequences[t])
+        if len(ranks) == 1:
+            return merge(solve(t[0], ranks), solve(t[1], ranks))
+        left, right = split_ranks(t, ranks)
+        g1, g2 = solve(t[0], left), solve(t[1], right)
+        if rank == right[0]:
+            send_graph(g2, left[0], dist, group)
+        if rank != left[0]:
+            return None
+        g2 = recv_graph(right[0], dist, group)
+        stats["graphs_received"] += 1
+        return merge(g1, g2)
+
+    root = solve(tree, list(range(world)))
+    if rank != 0:
+        return None
+    return dict(root=root, paths=order, scale=scale, scales=scales, stats=stats)
