@@ -956,6 +956,7 @@ class Context:
 
     def __init__(self, device=0):
         self.lib = load_library()
+        self.device = int(device)
         self.handle = self.lib.cl_context_create(device)
         if not self.handle:
             msg = self.lib.cl_last_error(None)

@@ -1031,10 +1031,10 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
     std::vector<int32_t> score(npo);
     std::vector<uint2> pairs(pl->d_out_pairs.n);
     if (npo) {
-        HIP_TRY(ctx, hipMemcpy(len.data(), pl->d_out_len.p, npo * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(status.data(), pl->d_out_status.p, npo * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(score.data(), pl->d_out_score.p, npo * 4, hipMemcpyDeviceToHost));
-        if (!pairs.empty()) HIP_TRY(ctx, hipMemcpy(pairs.data(), pl->d_out_pairs.p, pairs.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, cl_copy_sync(ctx, len.data(), pl->d_out_len.p, npo * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, cl_copy_sync(ctx, status.data(), pl->d_out_status.p, npo * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, cl_copy_sync(ctx, score.data(), pl->d_out_score.p, npo * 4, hipMemcpyDeviceToHost));
+        if (!pairs.empty()) HIP_TRY(ctx, cl_copy_sync(ctx, pairs.data(), pl->d_out_pairs.p, pairs.size() * sizeof(uint2), hipMemcpyDeviceToHost));
     }
     const uint64_t n = pl->n_problems;
     uint64_t total = 0;

@@ -742,11 +742,11 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     (void)hipEventDestroy(ev1);
 
     std::vector<float> dp_sorted(M);
-    he = hipMemcpy(dp_sorted.data(), d_dp.p, M * sizeof(float), hipMemcpyDeviceToHost);
+    he = cl_copy_sync(ctx, dp_sorted.data(), d_dp.p, M * sizeof(float), hipMemcpyDeviceToHost);
     std::vector<std::vector<int>> acc(combos.size());
     for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
         acc[ci].resize(M * 7);
-        he = hipMemcpy(acc[ci].data(), combos[ci].d_acc.p, M * 7 * sizeof(int), hipMemcpyDeviceToHost);
+        he = cl_copy_sync(ctx, acc[ci].data(), combos[ci].d_acc.p, M * 7 * sizeof(int), hipMemcpyDeviceToHost);
     }
     if (he != hipSuccess) { cl_set_error(ctx, "download failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
 

@@ -34,6 +34,15 @@ void cl_set_error(cl_context* ctx, const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+// Blocking copy WITHOUT the legacy default stream: a hipMemcpy on the legacy stream fails ("operation would make the legacy
+// stream depend on a capturing blocking stream") while ANOTHER thread of the process captures its stitch plan into a hipGraph, so
+// every copy of this library goes through the context's own (non-blocking) stream and waits for it.
+inline hipError_t cl_copy_sync(cl_context* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -49,7 +58,7 @@ struct DevBuf {
     int upload(cl_context* ctx, const Vec& h) {
         int rc = alloc(ctx, h.size());
         if (rc) return rc;
-        if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (!h.empty()) HIP_TRY(ctx, cl_copy_sync(ctx, p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
         return CL_OK;
     }
     void release() {

@@ -21,27 +21,66 @@ def leaves_of(tree):
     return [tree] if isinstance(tree, str) else leaves_of(tree[0]) + leaves_of(tree[1])
 
 
-def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000):
+def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
-    scales, stats)"""
+    scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
+    side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
+    anchor chain leaves much of the device idle between its host phases, a second one fills the gaps."""
     order = leaves_of(tree)
     leaves = {nm: capi.leaf_graph(sequences[nm]) for nm in order}
-    scales = [ctx.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs) for nm in order]
-    scale = sum(scales) / len(scales)                    # ScoreFunction::score_scale (src/core.cpp:169-184)
+    contexts = [ctx] + [capi.Context(getattr(ctx, "device", 0)) for _ in range(max(1, int(workers)) - 1)]
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0)
     last = {}
 
-    def solve(t):
-        if isinstance(t, str):
-            return leaves[t], [t]
-        (g1, p1), (g2, p2) = solve(t[0]), solve(t[1])
-        r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
-        for k in ("match_ms", "align_ms", "fuse_ms"):
-            stats[k] += r[k]
-        stats["merges"] += 1
-        last["alignment"], last["graphs"] = r["alignment"], (g1, g2)
-        return r["fused"], p1 + p2
-    root, paths = solve(tree)
+    def in_parallel(jobs):
+        """jobs: list of callables taking a context; results in order"""
+        if len(contexts) == 1 or len(jobs) <= 1:
+            return [job(contexts[0]) for job in jobs]
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        free = queue.Queue()
+        for c in contexts:
+            free.put(c)
+
+        def run(job):
+            c = free.get()
+            try:
+                return job(c)
+            finally:
+                free.put(c)
+        with ThreadPoolExecutor(len(contexts)) as pool:
+            return list(pool.map(run, jobs))
+
+    try:
+        scales = in_parallel([lambda c, nm=nm: c.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
+                              for nm in order])
+        scale = sum(scales) / len(scales)                    # ScoreFunction::score_scale (src/core.cpp:169-184)
+
+        # the guide tree in waves: every merge whose two children are there runs in the same wave
+        done = {nm: (leaves[nm], [nm]) for nm in order}       # subtree (as its newick text) -> (graph, path names)
+        pending = []
+
+        def collect(t):
+            if not isinstance(t, str):
+                collect(t[0]); collect(t[1]); pending.append(t)
+        collect(tree)
+        while pending:
+            ready = [t for t in pending if newick(t[0]) in done and newick(t[1]) in done]
+            pending = [t for t in pending if not (newick(t[0]) in done and newick(t[1]) in done)]
+
+            def job(c, t):
+                (g1, p1), (g2, p2) = done[newick(t[0])], done[newick(t[1])]
+                return c.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count), g1, g2, p1 + p2
+            for t, (r, g1, g2, paths) in zip(ready, in_parallel([lambda c, t=t: job(c, t) for t in ready])):
+                for k in ("match_ms", "align_ms", "fuse_ms"):
+                    stats[k] += r[k]
+                stats["merges"] += 1
+                done[newick(t)] = (r["fused"], paths)
+                last["alignment"], last["graphs"] = r["alignment"], (g1, g2)
+        root, paths = done[newick(tree)]
+    finally:
+        for c in contexts[1:]:
+            c.close()
     return dict(root=root, paths=paths, alignment=last.get("alignment"), root_inputs=last.get("graphs"), scale=scale, scales=scales,
                 stats=stats, leaves=leaves)
 

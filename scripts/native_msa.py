@@ -26,13 +26,14 @@ def main():
     ctx = capi.Context(0)
     ctx.find_matches(capi.leaf_graph("ACGTACGTAC"), capi.leaf_graph("ACGTTCGTAC"))   # first-use initialisation outside the timed region
     t0 = time.perf_counter()
-    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), tree, max_num_match_pairs=budget)
+    workers = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5].isdigit() else 1
+    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), tree, max_num_match_pairs=budget, workers=workers)
     root, paths, scale, stats = r["root"], r["paths"], r["scale"], r["stats"]
     t1 = t2 = time.perf_counter()
     gfa = capi.write_gfa(root, paths)
     t3 = time.perf_counter()
-    print("native: leaf graphs + calibration + %d merges %.2f s (scale %.17g; in the merges: matches %.2f, align %.2f, fuse %.2f s), GFA %.2f s; "
-          "total %.2f s; root graph %d nodes, GFA %d bytes sha256 %s" % (stats["merges"], t1 - t0, scale, stats["match_ms"] / 1e3, stats["align_ms"] / 1e3,
+    print("native (%d worker context%s): leaf graphs + calibration + %d merges %.2f s (scale %.17g; in the merges: matches %.2f, align %.2f, fuse %.2f s), GFA %.2f s; "
+          "total %.2f s; root graph %d nodes, GFA %d bytes sha256 %s" % (workers, "" if workers == 1 else "s", stats["merges"], t1 - t0, scale, stats["match_ms"] / 1e3, stats["align_ms"] / 1e3,
                                                                          stats["fuse_ms"] / 1e3, t3 - t2, t3 - t0, len(root.label), len(gfa),
                                                                          hashlib.sha256(gfa).hexdigest()[:16]), flush=True)
     from oracle import pyoracle as po

@@ -28,7 +28,14 @@ def main():
     t0 = time.perf_counter()
     leaves = [capi.leaf_graph(s) for s in seqs]
     t1 = time.perf_counter()
-    scales = [ctx.leaf_intrinsic_scale(g) for g in leaves]
+    if "--workers2" in sys.argv:   # the two leaf calibrations side by side, each on its own cl_context
+        from concurrent.futures import ThreadPoolExecutor
+        ctx2 = capi.Context(0)
+        with ThreadPoolExecutor(2) as pool:
+            scales = list(pool.map(lambda a: a[0].leaf_intrinsic_scale(a[1]), zip((ctx, ctx2), leaves)))
+        ctx2.close()
+    else:
+        scales = [ctx.leaf_intrinsic_scale(g) for g in leaves]
     scale = sum(scales) / len(scales)                      # src/core.cpp:169-184
     t2 = time.perf_counter()
     r = ctx.merge(leaves[0], leaves[1], score_scale=scale)

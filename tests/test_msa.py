@@ -18,12 +18,14 @@ def test_tree_helpers():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 3])
 @pytest.mark.parametrize("case", H.msa_cases(), ids=lambda c: c[0])
-def test_gpu_native_run_prints_the_references_text(gpu_ctx, case):
+def test_gpu_native_run_prints_the_references_text(gpu_ctx, case, workers):
+    """workers = 3: leaf calibrations and sibling merges side by side on one device, one cl_context per worker thread"""
     name, n, length, seed, budget = case
     seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
     names = ["seq%d" % i for i in range(n)]
-    r = msa.progressive_msa(gpu_ctx, dict(zip(names, seqs)), msa.balanced_tree(names), max_num_match_pairs=budget)
+    r = msa.progressive_msa(gpu_ctx, dict(zip(names, seqs)), msa.balanced_tree(names), max_num_match_pairs=budget, workers=workers)
     want = bytes(Z[name])
     got = msa.output_text(r)
     assert got == (want.rstrip(b"\n") if n == 2 else want)   # the CIGAR line ends in a newline in the dump
