@@ -201,10 +201,10 @@ def end_to_end_section(ctx, with_reference):
     seqs = synth.hor_sequences(7, 1000000, 2)
     names = ["seq0", "seq1"]
     t0 = time.perf_counter()
-    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), msa.balanced_tree(names))
+    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), msa.balanced_tree(names), workers=2)   # the two leaf calibrations side by side
     text = msa.output_text(r)
     wall = time.perf_counter() - t0
-    out = {"pipeline": "leaf graphs + calibration + find_matches + Core::align + fuse + explicit_cigar", "wall_s": wall,
+    out = {"pipeline": "leaf graphs + calibration (2 worker contexts) + find_matches + Core::align + fuse + explicit_cigar", "wall_s": wall,
            "score_scale": r["scale"], "match_ms": r["stats"]["match_ms"], "align_ms": r["stats"]["align_ms"], "fuse_ms": r["stats"]["fuse_ms"],
            "cigar_bytes": len(text), "cigar_sha256": hashlib.sha256(text).hexdigest()}
     if with_reference:

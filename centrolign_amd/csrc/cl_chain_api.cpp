@@ -412,10 +412,14 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             if (sc[k].pair_hi == sc[k].pair_lo) continue;
             const SetView ms(subs[k]);
             set_weight[k].resize(subs[k].num_match_sets);
-            for (uint64_t st = 0; st < subs[k].num_match_sets; ++st)
-                if (ms.n_walks(0, st)) set_weight[k][st] = (float)ms.weight(*cp, st);
+            cl_parallel_for(subs[k].num_match_sets, [&](uint64_t b, uint64_t e) {
+                for (uint64_t st = b; st < e; ++st)
+                    if (ms.n_walks(0, st)) set_weight[k][st] = (float)ms.weight(*cp, st);
+            }, 4096);
         }
-        for (uint32_t s = 0; s < M; ++s) { const Pair& p = pairs[by_s[s]]; weight[s] = set_weight[p.sub][p.set]; }
+        cl_parallel_for(M, [&](uint64_t b, uint64_t e) {
+            for (uint64_t s = b; s < e; ++s) { const Pair& p = pairs[by_s[s]]; weight[s] = set_weight[p.sub][p.set]; }
+        });
     }
     // Anchored chains (global anchoring, anchorer.hpp:1069-1076; fill-in, :683-693): a chain's first anchor pays the lead
     // indel from the sources (affine, :2026-2039) or must be reachable from them (sparse, :1562-1582); its last anchor pays
@@ -496,36 +500,82 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     std::vector<uint32_t> combo_of((size_t)n_tag[0] * n_tag[1], kNone);
     std::vector<Combo> combos;
     std::vector<uint32_t> rec_off(M + 1, 0), rec_combo, rec_pos;
-    for (uint32_t s = 0; s < M; ++s) {
-        const Pair& p = pairs[by_s[s]];
-        const SubCtx& c = sc[p.sub];
-        bool first1 = true;
-        c.x[0]->for_each_chain_on(p.e1, [&](uint32_t p1) {
-            const bool take1 = !sparse || first1;   // sparse_chain_dp files a match under chain(e1) only (anchorer.hpp:1621-1630)
-            first1 = false;
-            if (!take1) return;
-            bool first2 = true;
-            c.x[1]->for_each_chain_on(p.e2, [&](uint32_t p2) {
-                const bool take2 = !sparse || first2;
-                first2 = false;
-                if (!take2) return;
-                uint32_t& ci = combo_of[(size_t)tag_of(p.sub, 0, p1) * n_tag[1] + tag_of(p.sub, 1, p2)];
-                if (ci == kNone) {
-                    ci = (uint32_t)combos.size();
-                    combos.emplace_back();
-                    combos.back().p1 = tag_of(p.sub, 0, p1);
-                    combos.back().p2 = tag_of(p.sub, 1, p2);
-                }
-                Combo& cb = combos[ci];
-                rec_combo.push_back(ci);
-                rec_pos.push_back((uint32_t)cb.rec_s.size());
-                cb.rec_s.push_back(s);
-                cb.ins_t.push_back(c.x[0]->index_on(p.e1, p1) + c.off_a);
-                cb.off.push_back(c.x[1]->index_on(p.e2, p2) + c.off_b);
-                cb.sigma.push_back(sparse ? 0 : (int32_t)(c.x[0]->index_on(p.e1, p1) - c.x[1]->index_on(p.e2, p2)));
-            });
+    {
+        // records per pair: one per (chain through e1, chain through e2); sparse_chain_dp files a match under the first chain
+        // of each end only (anchorer.hpp:1621-1630).  Counted and filled in parallel over the pairs, numbered serially: a
+        // combination's id is its order of first appearance, a record's position the number of earlier records of its combination
+        cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
+            for (uint64_t s = s_begin; s < s_end; ++s) {
+                if (sparse) { rec_off[s + 1] = 1; continue; }
+                const Pair& p = pairs[by_s[s]];
+                const SubCtx& c = sc[p.sub];
+                uint32_t k1 = 0, k2 = 0;
+                c.x[0]->for_each_chain_on(p.e1, [&](uint32_t) { ++k1; });
+                c.x[1]->for_each_chain_on(p.e2, [&](uint32_t) { ++k2; });
+                rec_off[s + 1] = k1 * k2;
+            }
         });
-        rec_off[s + 1] = (uint32_t)rec_combo.size();
+        for (uint64_t s = 0; s < M; ++s) rec_off[s + 1] += rec_off[s];
+        const uint64_t R = rec_off[M];
+        std::vector<uint32_t> r_tag(R), r_ins(R), r_off(R);
+        std::vector<int32_t> r_sig(R);
+        cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
+            for (uint64_t s = s_begin; s < s_end; ++s) {
+                const Pair& p = pairs[by_s[s]];
+                const SubCtx& c = sc[p.sub];
+                uint64_t r = rec_off[s];
+                bool first1 = true;
+                c.x[0]->for_each_chain_on(p.e1, [&](uint32_t p1) {
+                    const bool take1 = !sparse || first1;
+                    first1 = false;
+                    if (!take1) return;
+                    bool first2 = true;
+                    c.x[1]->for_each_chain_on(p.e2, [&](uint32_t p2) {
+                        const bool take2 = !sparse || first2;
+                        first2 = false;
+                        if (!take2) return;
+                        const uint32_t i1 = c.x[0]->index_on(p.e1, p1), i2 = c.x[1]->index_on(p.e2, p2);
+                        r_tag[r] = tag_of(p.sub, 0, p1) * n_tag[1] + tag_of(p.sub, 1, p2);
+                        r_ins[r] = i1 + c.off_a;
+                        r_off[r] = i2 + c.off_b;
+                        r_sig[r] = sparse ? 0 : (int32_t)(i1 - i2);
+                        ++r;
+                    });
+                });
+            }
+        });
+        rec_combo.resize(R);
+        rec_pos.resize(R);
+        std::vector<uint32_t> combo_size;
+        for (uint64_t r = 0; r < R; ++r) {
+            uint32_t& ci = combo_of[r_tag[r]];
+            if (ci == kNone) {
+                ci = (uint32_t)combos.size();
+                combos.emplace_back();
+                combos.back().p1 = r_tag[r] / n_tag[1];
+                combos.back().p2 = r_tag[r] % n_tag[1];
+                combo_size.push_back(0);
+            }
+            rec_combo[r] = ci;
+            rec_pos[r] = combo_size[ci]++;
+        }
+        for (size_t ci = 0; ci < combos.size(); ++ci) {
+            combos[ci].rec_s.resize(combo_size[ci]);
+            combos[ci].ins_t.resize(combo_size[ci]);
+            combos[ci].off.resize(combo_size[ci]);
+            combos[ci].sigma.resize(combo_size[ci]);
+        }
+        cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
+            for (uint64_t s = s_begin; s < s_end; ++s)
+                for (uint64_t r = rec_off[s]; r < rec_off[s + 1]; ++r) {
+                    Combo& cb = combos[rec_combo[r]];
+                    const uint32_t at = rec_pos[r];
+                    cb.rec_s[at] = (uint32_t)s;
+                    cb.ins_t[at] = r_ins[r];
+                    cb.off[at] = r_off[r];
+                    cb.sigma[at] = r_sig[r];
+                }
+        });
     }
     if (combos.size() > 1) {
         size_t big = 0;

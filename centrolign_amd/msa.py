@@ -21,14 +21,15 @@ def leaves_of(tree):
     return [tree] if isinstance(tree, str) else leaves_of(tree[0]) + leaves_of(tree[1])
 
 
-def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1):
+def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
     anchor chain leaves much of the device idle between its host phases, a second one fills the gaps."""
     order = leaves_of(tree)
     leaves = {nm: capi.leaf_graph(sequences[nm]) for nm in order}
-    contexts = [ctx] + [capi.Context(getattr(ctx, "device", 0)) for _ in range(max(1, int(workers)) - 1)]
+    make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
+    contexts = [ctx] + [make_context() for _ in range(max(1, int(workers)) - 1)]
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0)
     last = {}
 
@@ -80,7 +81,8 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
         root, paths = done[newick(tree)]
     finally:
         for c in contexts[1:]:
-            c.close()
+            if hasattr(c, "close"):
+                c.close()
     return dict(root=root, paths=paths, alignment=last.get("alignment"), root_inputs=last.get("graphs"), scale=scale, scales=scales,
                 stats=stats, leaves=leaves)
 

@@ -17,6 +17,35 @@ def test_tree_helpers():
     assert msa.newick(t) == "((a,b),(c,(d,e)))" and msa.leaves_of(t) == ["a", "b", "c", "d", "e"]
 
 
+class _StubCtx:
+    """host-only stand-in for a device context: the scale is a function of the leaf, merge = cl_fuse along the first bases"""
+    def leaf_intrinsic_scale(self, g, **kw):
+        return float(int(g.label.astype(np.int64).sum()) % 9973) / 7.0
+
+    def merge(self, g1, g2, score_scale=1.0, **kw):
+        from centrolign_amd import capi
+        k = min(5, len(g1.label) - 2, len(g2.label) - 2)
+        p1 = g1.path_nodes[int(g1.path_off[0]):int(g1.path_off[0]) + k].astype(np.uint64)
+        p2 = g2.path_nodes[int(g2.path_off[0]):int(g2.path_off[0]) + k].astype(np.uint64)
+        pairs = np.stack([p1, p2], 1)
+        return dict(fused=capi.fuse(g1, g2, pairs), alignment=pairs, match_ms=0.0, align_ms=0.0, fuse_ms=0.0, n_match_sets=0)
+
+
+def test_worker_threads_schedule_the_same_msa():
+    """the wave scheduler with several worker contexts (host-only stub contexts): same root graph, paths and scale as one worker"""
+    from centrolign_amd import capi
+    rng = np.random.default_rng(2)
+    names = ["s%d" % i for i in range(9)]
+    seqs = {nm: "".join("ACGT"[b] for b in rng.integers(0, 4, int(rng.integers(20, 80)))) for nm in names}
+    for tree in (msa.balanced_tree(names), ((("s0", "s1"), "s2"), ("s3", ("s4", ("s5", ("s6", ("s7", "s8"))))))):
+        want = msa.progressive_msa(_StubCtx(), seqs, tree)
+        for workers in (2, 5):
+            got = msa.progressive_msa(_StubCtx(), seqs, tree, workers=workers, make_context=_StubCtx)
+            assert capi.graphs_equal(got["root"], want["root"]) and got["paths"] == want["paths"] and got["scales"] == want["scales"]
+            assert got["stats"]["merges"] == len(names) - 1
+        assert msa.output_text(want).startswith(b"H\tVN:Z:1.0\n")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("workers", [1, 3])
 @pytest.mark.parametrize("case", H.msa_cases(), ids=lambda c: c[0])
