@@ -10,7 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
-#include <unordered_set>
+#include <algorithm>
+#include <unordered_map>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -38,15 +39,8 @@ int cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64
     if (n1 == 0 || n2 == 0 || dest->src_id >= n1 || dest->snk_id >= n1 || source->src_id >= n2 || source->snk_id >= n2) return CL_ERR_INVALID_ARGUMENT;
     for (uint64_t i = 0; i < n_pairs; ++i)
         if ((pairs[2 * i] != gap && pairs[2 * i] >= n1) || (pairs[2 * i + 1] != gap && pairs[2 * i + 1] >= n2)) return CL_ERR_INVALID_ARGUMENT;
-    // adjacency as growable lists: the destination's own, then whatever the fuse appends
-    std::vector<uint8_t> label(dest->label, dest->label + n1);
-    std::vector<std::vector<uint32_t>> next(n1), prev(n1);
-    for (uint64_t v = 0; v < n1; ++v) {
-        next[v].assign(dest->next_idx + dest->next_off[v], dest->next_idx + dest->next_off[v + 1]);
-        prev[v].assign(dest->prev_idx + dest->prev_off[v], dest->prev_idx + dest->prev_off[v + 1]);
-    }
-    auto add_edge = [&](uint64_t from, uint64_t to) { next[from].push_back((uint32_t)to); prev[to].push_back((uint32_t)from); };
     // record match nodes (fuse.hpp:58-66), join the sentinels (:68-70), add the unmatched nodes (:72-77)
+    std::vector<uint8_t> label(dest->label, dest->label + n1);
     std::vector<uint64_t> trans(n2, gap);
     for (uint64_t i = 0; i < n_pairs; ++i) {
         const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
@@ -58,46 +52,77 @@ int cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64
         if (trans[b] != gap) continue;
         trans[b] = label.size();
         label.push_back(source->label[b]);
-        next.emplace_back();
-        prev.emplace_back();
     }
-    if (label.size() >= 0xFFFFFFFFull) return CL_ERR_INVALID_ARGUMENT;
-    // substitution edges from the destination graph (:83-108): a mismatched pair hangs between the nearest aligned destination
-    // nodes to its right and to its left
-    std::vector<uint64_t> left_of(n_pairs), right_of(n_pairs);   // nearest index with node_id1 != gap, exclusive
+    const uint64_t n = label.size();
+    if (n >= 0xFFFFFFFFull) return CL_ERR_INVALID_ARGUMENT;
+    // The reference appends edges to per-node lists (BaseGraph::add_edge, src/graph.cpp:226-229) in two phases; here the appended
+    // edges are kept as one list in call order and the lists are put together at the end: next(v) = dest's next(v), then the
+    // appended edges out of v in call order; previous(w) likewise.
+    std::vector<std::pair<uint32_t, uint32_t>> added;
+    // phase 1 — substitution edges from the destination graph (:83-108): a mismatched pair hangs between the nearest aligned
+    // destination nodes to its right and to its left
     {
+        std::vector<uint64_t> left_of(n_pairs), right_of(n_pairs);   // nearest index with node_id1 != gap, exclusive
         uint64_t last = gap;
         for (uint64_t i = 0; i < n_pairs; ++i) { left_of[i] = last; if (pairs[2 * i] != gap) last = i; }
         last = gap;
         for (uint64_t i = n_pairs; i-- > 0;) { right_of[i] = last; if (pairs[2 * i] != gap) last = i; }
+        for (uint64_t i = 0; i < n_pairs; ++i) {
+            const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+            if (a == gap || b == gap || dest->label[a] == source->label[b]) continue;
+            if (right_of[i] != gap) added.emplace_back((uint32_t)trans[b], (uint32_t)pairs[2 * right_of[i]]);
+            if (left_of[i] != gap) added.emplace_back((uint32_t)pairs[2 * left_of[i]], (uint32_t)trans[b]);
+        }
     }
-    for (uint64_t i = 0; i < n_pairs; ++i) {
-        const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
-        if (a == gap || b == gap || dest->label[a] == source->label[b]) continue;
-        if (right_of[i] != gap) add_edge(trans[b], pairs[2 * right_of[i]]);
-        if (left_of[i] != gap) add_edge(pairs[2 * left_of[i]], trans[b]);
+    // the phase-1 edges grouped by their tail (stable): what next(v) holds beyond dest's list when phase 2 looks at v
+    const uint64_t n_sub = added.size();
+    std::vector<uint64_t> sub_off(n + 1, 0);
+    for (uint64_t e = 0; e < n_sub; ++e) ++sub_off[added[e].first + 1];
+    for (uint64_t v = 0; v < n; ++v) sub_off[v + 1] += sub_off[v];
+    std::vector<uint32_t> sub_to(n_sub);
+    {
+        std::vector<uint64_t> fill(sub_off.begin(), sub_off.end() - 1);
+        for (uint64_t e = 0; e < n_sub; ++e) sub_to[fill[added[e].first]++] = added[e].second;
     }
-    // the source's edges that are not there yet (:114-129); the membership set is taken once per node, before its additions
-    std::unordered_set<uint64_t> have;
+    // phase 2 — the source's edges that are not there yet (:114-129).  The reference tests membership in next(new_id) as it stood
+    // BEFORE this source node's own additions: dest's list, the phase-1 edges out of it, and what phase 2 appended for EARLIER
+    // source nodes that map to the same node (in a valid alignment only the two sentinels collect several source nodes)
+    std::vector<uint8_t> hits(n, 0);   // source nodes per fused node, saturating at 2
+    for (uint64_t b = 0; b < n2; ++b) if (hits[trans[b]] < 2) ++hits[trans[b]];
+    std::unordered_map<uint64_t, std::vector<uint32_t>> earlier;   // phase-2 heads appended so far out of a node several source nodes map to
     for (uint64_t b = 0; b < n2; ++b) {
         const uint64_t v = trans[b];
-        have.clear();
-        for (auto w : next[v]) have.insert(w);
+        const uint32_t* d0 = v < n1 ? dest->next_idx + dest->next_off[v] : nullptr;
+        const uint32_t* d1 = v < n1 ? dest->next_idx + dest->next_off[v + 1] : nullptr;
+        const uint32_t* s0 = sub_to.data() + sub_off[v];
+        const uint32_t* s1 = sub_to.data() + sub_off[v + 1];
+        std::vector<uint32_t>* shared = hits[v] > 1 ? &earlier[v] : nullptr;
+        const size_t seen = shared ? shared->size() : 0;
         for (uint64_t e = source->next_off[b]; e < source->next_off[b + 1]; ++e) {
-            const uint64_t w = trans[source->next_idx[e]];
-            if (!have.count(w)) add_edge(v, w);
+            const uint32_t w = (uint32_t)trans[source->next_idx[e]];
+            bool have = std::find(d0, d1, w) != d1 || std::find(s0, s1, w) != s1;
+            if (!have && shared) have = std::find(shared->begin(), shared->begin() + seen, w) != shared->begin() + seen;
+            if (have) continue;
+            added.emplace_back((uint32_t)v, w);
+            if (shared) shared->push_back(w);
         }
     }
     std::unique_ptr<cl_owned_base_graph> g(new cl_owned_base_graph());
-    const uint64_t n = label.size();
     g->label = std::move(label);
-    g->next_off.assign(1, 0);
-    g->prev_off.assign(1, 0);
-    for (uint64_t v = 0; v < n; ++v) {
-        g->next_idx.insert(g->next_idx.end(), next[v].begin(), next[v].end());
-        g->next_off.push_back(g->next_idx.size());
-        g->prev_idx.insert(g->prev_idx.end(), prev[v].begin(), prev[v].end());
-        g->prev_off.push_back(g->prev_idx.size());
+    for (int dir = 0; dir < 2; ++dir) {
+        const uint64_t* doff = dir ? dest->prev_off : dest->next_off;
+        const uint32_t* didx = dir ? dest->prev_idx : dest->next_idx;
+        std::vector<uint64_t>& off = dir ? g->prev_off : g->next_off;
+        std::vector<uint32_t>& idx = dir ? g->prev_idx : g->next_idx;
+        off.assign(n + 1, 0);
+        for (uint64_t v = 0; v < n1; ++v) off[v + 1] = doff[v + 1] - doff[v];
+        for (const auto& e : added) ++off[(dir ? e.second : e.first) + 1];
+        for (uint64_t v = 0; v < n; ++v) off[v + 1] += off[v];
+        idx.resize(off[n]);
+        std::vector<uint64_t> fill(off.begin(), off.end() - 1);
+        for (uint64_t v = 0; v < n1; ++v)
+            for (uint64_t e = doff[v]; e < doff[v + 1]; ++e) idx[fill[v]++] = didx[e];
+        for (const auto& e : added) idx[fill[dir ? e.second : e.first]++] = dir ? e.first : e.second;
     }
     // the paths: the destination's, then the source's translated (:137-143)
     g->path_off.assign(1, 0);

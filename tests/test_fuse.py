@@ -84,6 +84,13 @@ def test_fuse_live_reference_agreement():
         keep = rng.random(len(pairs)) < 0.7                      # a different alignment than the committed one
         sub = pairs[keep]
         assert capi.graphs_equal(capi.fuse(g1, g2, sub), po.ref_fuse(g1, g2, sub)), name
+        # not an alignment at all: arbitrary pairs, nodes aligned several times — fuse is defined for any pair list
+        n1, n2, k = len(g1.label) - 2, len(g2.label) - 2, 2 * len(pairs)
+        a, b = rng.integers(0, n1, k).astype(np.uint64), rng.integers(0, n2, k).astype(np.uint64)
+        a[rng.random(k) < 0.15] = H.GAP
+        b[rng.random(k) < 0.15] = H.GAP
+        wild = np.stack([a, b], 1)
+        assert capi.graphs_equal(capi.fuse(g1, g2, wild), po.ref_fuse(g1, g2, wild)), name
 
 
 @pytest.mark.gpu
