@@ -346,7 +346,8 @@ Intervals maximum_weight_partition(const PartCtx& pc, const std::vector<double>&
     size_t prefix_argmax = 0, tb_idx = 0;
     for (size_t i = 1; i < dp.size(); ++i) {
         dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
-        dp[i].second = dp[prefix_argmax].first + prefix_sum[i] - prefix_sum[prefix_argmax] - min_score;
+        // as built (see window_average_constrained_partition below): (prefix - min) + (dp - prefix)
+        dp[i].second = (prefix_sum[i] - min_score) + (dp[prefix_argmax].first - prefix_sum[prefix_argmax]);
         backpointer[i] = prefix_argmax;
         if (dp[i].first - prefix_sum[i] > dp[prefix_argmax].first - prefix_sum[prefix_argmax]) prefix_argmax = i;
         if (dp[i].second > dp[tb_idx].second) tb_idx = i;
@@ -384,7 +385,7 @@ Intervals average_constrained_partition(const PartCtx& pc, const std::vector<std
         dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
         const size_t mx = tree.range_max(PartKey(kPartMinInf, 0), PartKey(fractional[i - 1], (size_t)-1));
         if (mx != tree.end() && tree.val[mx] != kPartMinInf) {
-            dp[i].second = prefix_sum[i - 1] + tree.val[mx] - min_score;
+            dp[i].second = (tree.val[mx] - min_score) + prefix_sum[i - 1];   // as built
             backpointer[i] = tree.key[mx].second;
             if (dp[i].second > dp[opt_idx].second) opt_idx = i;
         }
@@ -474,11 +475,14 @@ Intervals window_average_constrained_partition(const PartCtx& pc, const std::vec
         dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
         const size_t mx = tree.range_max(PartKey(kPartMinInf, 0), PartKey(fractional[i], (size_t)-1));
         if (mx != tree.end() && tree.val[mx] != kPartMinInf) {
-            dp[i].second = prefix_sum[i] + tree.val[mx] - min_score;
+            // operation order of the reference AS BUILT (-O3 -ffast-math regroups partitioner.hpp's "prefix_sum[i] + max - min_score"
+            // and "dp[a].first + prefix_sum[i] - prefix_sum[a] - min_score"; disassembly of oracle/_ref): exact ties between
+            // candidate segments — a boundary on either side of a zero-score item — are decided by the last bit
+            dp[i].second = (tree.val[mx] - min_score) + prefix_sum[i];
             backpointer[i] = tree.key[mx].second;
         }
         if (outside_argmax != (size_t)-1) {
-            const double outside_score = dp[outside_argmax].first + prefix_sum[i] - prefix_sum[outside_argmax] - min_score;
+            const double outside_score = (dp[outside_argmax].first - prefix_sum[outside_argmax]) + (prefix_sum[i] - min_score);
             if (outside_score > dp[i].second) {
                 dp[i].second = outside_score;
                 backpointer[i] = outside_argmax;
