@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/centrolign_amd.h"
@@ -89,8 +90,9 @@ struct cl_owned_base_graph {
 #include <thread>
 template <class F>
 inline void cl_parallel_for(uint64_t n, F f, uint64_t grain = 32768) {
+    static const unsigned cap = [] { const char* e = getenv("CL_HOST_THREADS"); int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 32u; }();
     unsigned hw = std::thread::hardware_concurrency();
-    uint64_t nt = std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 16), (n + grain - 1) / grain);
+    uint64_t nt = std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, cap), (n + grain - 1) / grain);
     if (nt <= 1) { f((uint64_t)0, n); return; }
     std::vector<std::thread> th;
     const uint64_t chunk = (n + nt - 1) / nt;

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -204,12 +205,55 @@ inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2
     if ((!have1 && !own1.build(g1)) || (!have2 && !own2.build(g2))) return CL_ERR_CYCLIC_GRAPH;
     const PathMergeTable& pm1 = have1 ? *have1 : own1;
     const PathMergeTable& pm2 = have2 ? *have2 : own2;
-    Extractor ex;
-    auto add = [&](uint64_t f1, uint64_t t1, uint64_t f2, uint64_t t2, bool only_del) {
-        ex.extract(g1, pm1, f1, t1, out.side[0]);
-        ex.extract(g2, pm2, f2, t2, out.side[1]);
-        out.only_del.push_back(only_del ? 1 : 0);
-    };
+    // the gaps are independent: list them in consumption order, extract chunks of the list side by side, append the chunks in order
+    struct Gap { uint64_t f1, t1, f2, t2; bool only_del; };
+    std::vector<Gap> gaps;
+    auto add = [&](uint64_t f1, uint64_t t1, uint64_t f2, uint64_t t2, bool only_del) { gaps.push_back(Gap{f1, t1, f2, t2, only_del}); };
+    struct Finish {   // runs when the function returns: every path below only fills `gaps`
+        const cl_base_graph& g1; const cl_base_graph& g2; const PathMergeTable& pm1; const PathMergeTable& pm2;
+        std::vector<Gap>& gaps; OwnedBatch& out;
+        ~Finish() {
+            const uint64_t n = gaps.size();
+            unsigned hw = std::thread::hardware_concurrency();
+            const uint64_t nt = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 16), n / 512));
+            std::vector<OwnedBatch> part(nt);
+            auto work = [&](uint64_t t) {
+                Extractor ex;
+                OwnedBatch& o = nt == 1 ? out : part[t];
+                for (uint64_t k = n * t / nt; k < n * (t + 1) / nt; ++k) {
+                    ex.extract(g1, pm1, gaps[k].f1, gaps[k].t1, o.side[0]);
+                    ex.extract(g2, pm2, gaps[k].f2, gaps[k].t2, o.side[1]);
+                    o.only_del.push_back(gaps[k].only_del ? 1 : 0);
+                }
+            };
+            if (nt == 1) { work(0); return; }
+            std::vector<std::thread> th;
+            for (uint64_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto& x : th) x.join();
+            for (uint64_t t = 0; t < nt; ++t) {
+                out.only_del.insert(out.only_del.end(), part[t].only_del.begin(), part[t].only_del.end());
+                for (int sd = 0; sd < 2; ++sd) {
+                    OwnedBatch::Side& d = out.side[sd];
+                    const OwnedBatch::Side& p = part[t].side[sd];
+                    auto append_off = [](std::vector<uint64_t>& dst, const std::vector<uint64_t>& src, uint64_t base) {
+                        for (size_t i = 1; i < src.size(); ++i) dst.push_back(src[i] + base);   // both start with a leading 0
+                    };
+                    append_off(d.node_off, p.node_off, d.label.size());
+                    append_off(d.next_off, p.next_off, d.next_idx.size());
+                    append_off(d.prev_off, p.prev_off, d.prev_idx.size());
+                    append_off(d.src_off, p.src_off, d.src_idx.size());
+                    append_off(d.snk_off, p.snk_off, d.snk_idx.size());
+                    d.label.insert(d.label.end(), p.label.begin(), p.label.end());
+                    d.back.insert(d.back.end(), p.back.begin(), p.back.end());
+                    d.next_idx.insert(d.next_idx.end(), p.next_idx.begin(), p.next_idx.end());
+                    d.prev_idx.insert(d.prev_idx.end(), p.prev_idx.begin(), p.prev_idx.end());
+                    d.src_idx.insert(d.src_idx.end(), p.src_idx.begin(), p.src_idx.end());
+                    d.snk_idx.insert(d.snk_idx.end(), p.snk_idx.begin(), p.snk_idx.end());
+                }
+            }
+        }
+    } finish{g1, g2, pm1, pm2, gaps, out};
     auto first1 = [&](uint64_t a) { return (uint64_t)sg.walk1[sg.walk_off[a]]; };
     auto last1 = [&](uint64_t a) { return (uint64_t)sg.walk1[sg.walk_off[a + 1] - 1]; };
     auto first2 = [&](uint64_t a) { return (uint64_t)sg.walk2[sg.walk_off[a]]; };
