@@ -1320,9 +1320,12 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         };
         std::vector<Divvied> dv(K);
         struct Pending { uint32_t k; std::vector<std::vector<uint32_t>> walks1, walks2; std::vector<uint32_t> idx1, idx2; };
-        for (size_t pos = 0; pos < cur.size(); ++pos) {
+        // the sets are independent: gather each set's walks per gap in parallel, then append to the gaps in set order
+        std::vector<std::vector<Pending>> pend_of(cur.size());
+        cl_parallel_for(cur.size(), [&](uint64_t pos_begin, uint64_t pos_end) {
+        for (size_t pos = pos_begin; pos < pos_end; ++pos) {
             const uint64_t s = cur[pos];
-            std::vector<Pending> pend;
+            std::vector<Pending>& pend = pend_of[pos];
             for (uint64_t j = 0; j < ms->set_off1[s + 1] - ms->set_off1[s]; ++j) {
                 const uint32_t *b, *e;
                 walk(0, pos, (uint32_t)j, b, e);
@@ -1345,7 +1348,11 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
                 it->walks2.emplace_back();
                 for (const uint32_t* v = b; v != e; ++v) it->walks2.back().push_back(ft[1][*v].second);
             }
-            for (Pending& q : pend) {
+        }
+        }, 2048);
+        for (size_t pos = 0; pos < cur.size(); ++pos) {
+            const uint64_t s = cur[pos];
+            for (Pending& q : pend_of[pos]) {
                 if (q.walks2.empty()) continue;
                 Divvied& d = dv[q.k];
                 for (auto& w : q.walks1) { d.sets.nodes1.insert(d.sets.nodes1.end(), w.begin(), w.end()); d.sets.walk_off1.push_back(d.sets.nodes1.size()); }
