@@ -46,7 +46,7 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
     // anchor chain (core.hpp:194-197)
     cl_owned_match_sets* split = nullptr;
     cl_match_sets view = *matches;
-    if (ap->split_matches_at_branchpoints) {
+    if (ap->split_matches_at_branchpoints && !cl_split_is_identity(g1, g2, &ap->split)) {
         if ((rc = cl_split_branching_matches(g1, g2, matches, &ap->split, &split))) { cl_set_error(ctx, "split_branching_matches failed"); return rc; }
         cl_owned_match_sets_view(split, &view);
     }

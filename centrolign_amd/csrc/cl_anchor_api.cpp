@@ -218,6 +218,22 @@ void cl_owned_match_sets_view(const cl_owned_match_sets* o, cl_match_sets* v) {
 
 void cl_owned_match_sets_free(cl_owned_match_sets* o) { delete o; }
 
+}  // extern "C"
+
+// no superbubble of either graph is wide enough to cut a match at: cl_split_branching_matches would hand back a copy of its input
+// (always the case for the leaf graphs of a pairwise merge) — callers inside the library skip the 100-MB copy
+bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp) {
+    if (sp->anchor_split_limit == 0) return true;
+    Bubbles b1, b2;
+    if (!b1.build(*g1) || !b2.build(*g2)) return false;   // let the real call report the cycle
+    for (const Bubbles* b : {&b1, &b2})
+        for (uint64_t spread : b->spread)
+            if (spread >= sp->min_path_length_spread) return false;
+    return true;
+}
+
+extern "C" {
+
 int cl_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp,
                                cl_owned_match_sets** out) {
     if (!g1 || !g2 || !ms || !sp || !out) return CL_ERR_INVALID_ARGUMENT;

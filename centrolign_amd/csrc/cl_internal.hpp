@@ -85,6 +85,9 @@ struct cl_owned_base_graph {
     uint64_t src_id = 0, snk_id = 0;
 };
 
+// defined in cl_anchor_api.cpp
+bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp);
+
 // host-side parallel loop over [0, n): f(begin, end) on up to 16 threads (the reference is single-threaded; the host glue
 // around the device passes is not part of the compared arithmetic, every iteration writes its own outputs)
 #include <thread>
