@@ -21,7 +21,7 @@ def leaves_of(tree):
     return [tree] if isinstance(tree, str) else leaves_of(tree[0]) + leaves_of(tree[1])
 
 
-def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None):
+def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None, verbose=False):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
@@ -76,6 +76,12 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
                 for k in ("match_ms", "align_ms", "fuse_ms"):
                     stats[k] += r[k]
                 stats["merges"] += 1
+                stats.setdefault("per_merge", []).append(dict(merge=newick(t), paths1=len(done[newick(t[0])][1]), paths2=len(done[newick(t[1])][1]),
+                                                              match_sets=r["n_match_sets"], match_ms=r["match_ms"], align_ms=r["align_ms"],
+                                                              fuse_ms=r["fuse_ms"], nodes=len(r["fused"].label)))
+                if verbose:
+                    import sys
+                    print("merge %s: %s" % (newick(t), stats["per_merge"][-1]), file=sys.stderr, flush=True)
                 done[newick(t)] = (r["fused"], paths)
                 last["alignment"], last["graphs"] = r["alignment"], (g1, g2)
         root, paths = done[newick(tree)]
