@@ -13,6 +13,8 @@ constexpr uint32_t kChainFullGrid = 1024; // workgroups that fill the chip (4 pe
 constexpr uint32_t kChainFarGroup = 1;    // consecutive blocks served by one far launch
 constexpr uint32_t kChainFarStreams = 2;  // auxiliary streams the far launches alternate between
 constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
+constexpr uint32_t kChainMacro = 1024;    // match pairs per launch of the walk kernel (one workgroup per chain combination)
+constexpr uint32_t kChainWalkMaxCombos = 96;  // the walk's workgroups wait for one another: all of them must be resident
 
 struct ClChainParams {
     double gap_open[3];
@@ -35,6 +37,7 @@ struct ClChainCombo {
     const uint32_t* qoff;     // predecessor_index(b2, p2) + 1 (wraps to 0)   (:1898-1901)
     const int32_t*  q;        // query shift                  (:1886-1892)
     int*            acc;      // [n_pairs][7] running maxima, order-preserving float encoding
+    uint32_t*       own_rec;  // [n_pairs] position of the pair's record in this combination, 0xFFFFFFFF = none
 };
 
 struct ClChainDevice {
@@ -52,6 +55,10 @@ struct ClChainDevice {
     const uint32_t* grp_total;  // [n_pairs] number of records of the pair's (block, group)
     ClChainParams params;
     uint32_t sparse;            // sparse_chain_dp: only the gap-free maximum (acc[0], val[0]) is used
+    const uint32_t* group_end;  // [n_pairs] sorted index one past the last pair of the pair's group
+    unsigned long long* xch;    // [n_combos][kChainMacro] {tag, value} granules: the walk's workgroups exchange their
+                                // combination's best candidate per pair (zeroed before every DP)
+    uint32_t* status;           // [1] set non-zero by a walk that gave up waiting for a sibling workgroup
 };
 
 #endif

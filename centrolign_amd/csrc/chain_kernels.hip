@@ -29,8 +29,9 @@
 
 namespace {
 
-__device__ __forceinline__ int enc(float f) {  // order-preserving float -> int
-    int b = __float_as_int(f);
+__device__ __forceinline__ int enc(float f) {  // order-preserving float -> int; -0.0f and +0.0f map to the same key (the
+    int b = __float_as_int(f);                  // reference's search-tree maxima and traceback '==' treat them as equal)
+    if (b == (int)0x80000000) b = 0;
     return b >= 0 ? b : b ^ 0x7FFFFFFF;
 }
 __device__ __forceinline__ float dec(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
@@ -475,6 +476,185 @@ __global__ void __launch_bounds__(kChainBlock) chain_intra_sparse_kernel(ClChain
         lds_barrier();
     }
     if (active) c0.acc[(size_t)s * 7] = acc;   // the traceback needs the value the query returned
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chain_walk_kernel — the sequential part of the DP for kChainMacro consecutive match pairs, ONE WORKGROUP PER CHAIN
+// COMBINATION.  Thread t of workgroup c owns the query of sorted pair first + t in combination c: its 7 running maxima live in
+// registers for the whole walk, and only the records of combination c pass through the workgroup's LDS.  The pairs are walked
+// group by group (pairs of a group cannot precede one another).  Finalising a pair needs the best candidate of EVERY
+// combination (anchorer.hpp:2352-2416 loops over forward edges x chains of graph 2): each workgroup stores its combination's
+// candidate as an 8-byte {tag, value} granule (write-through, agent scope) and the group's threads of every workgroup sweep the
+// n_combos granules of their pair until all carry the pair's tag — the data is the flag, no fence and no counter
+// (cdna_hip_programming.md §6 Guideline 16, recipe R2).  Every workgroup derives the same dp value from the same granules, so
+// the stored values it publishes for its own combination are the reference's (anchorer.hpp:2318-2342).
+// The workgroups wait for one another, so all n_combos of them must be resident: the host uses this kernel only up to
+// kChainWalkMaxCombos combinations; every spin is bounded and reports through D.status.
+template <bool SPARSE>
+__global__ void __launch_bounds__(kChainMacro) chain_walk_kernel(ClChainDevice D, uint32_t first, uint32_t count) {
+    constexpr int NK = SPARSE ? 1 : 7;
+    constexpr int RW = SPARSE ? 4 : 12;
+    const uint32_t c = blockIdx.x;
+    const ClChainCombo cb = D.combos[c];
+    const uint32_t t = threadIdx.x, s = first + t;
+    const bool active = t < count;
+    const int none = enc(CL_CHAIN_NEG);
+    bool has_q = false, has_rec = false;
+    uint32_t qt = 0, qoff = 0, pos = 0, ins = 0, off = 0;
+    int32_t q = 0, sig = 0;
+    int acc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = none;
+    float w = 0.f, w_init = CL_CHAIN_NEG;
+    if (active) {
+        qt = cb.qt[s];
+        has_q = qt != 0xFFFFFFFFu;
+        if (has_q) { qoff = cb.qoff[s]; q = cb.q[s]; }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) acc[k] = cb.acc[(size_t)s * 7 + k];
+        w = D.weight[s];
+        w_init = D.init[s];
+        pos = cb.own_rec[s];
+        has_rec = pos != 0xFFFFFFFFu;
+        if (has_rec) { ins = cb.ins_t[pos]; off = cb.off[pos]; sig = cb.sigma[pos]; }
+    }
+    if (!has_q) qoff = 0;   // a record's offset is never below 0: such a lane accumulates nothing
+    __shared__ __attribute__((aligned(16))) int s_rec[kChainMacro][RW];   // slot t = the record of pair first + t in this combination
+    __shared__ int s_abort;
+    if (t == 0) s_abort = 0;
+    __syncthreads();
+    const uint32_t end = first + count;
+    const uint32_t n_combos = D.n_combos;
+    uint32_t cur = first;
+    while (cur < end) {
+        const uint32_t gend = min(D.group_end[cur], end);
+        if (active && s >= cur && s < gend) {
+            // this combination's best candidate for the pair (anchorer.hpp:2379-2412)
+            float cand = CL_CHAIN_NEG;
+            if (has_q) {
+                if (SPARSE) {
+                    if (acc[0] != none) cand = dec(acc[0]) + w;
+                } else {
+                    double pen[6];
+                    query_penalties(pen, q, D.params);
+                    cand = apply_candidates(CL_CHAIN_NEG, acc, w, pen);
+                }
+            }
+            float best = fmaxf(w_init, cand);
+            if (n_combos > 1) {
+                const unsigned long long tag = (unsigned long long)(s + 1u) << 32;
+                __hip_atomic_store(&D.xch[(size_t)c * kChainMacro + t], tag | (unsigned)__float_as_int(cand), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (true) {
+                    bool ok = true;
+                    float m = w_init;
+                    for (uint32_t cc = 0; cc < n_combos; cc += 4) {
+                        unsigned long long x[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            x[u] = cc + u < n_combos ? __hip_atomic_load(&D.xch[(size_t)(cc + u) * kChainMacro + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag | (unsigned)__float_as_int(CL_CHAIN_NEG);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ok = ok && (x[u] >> 32) == (tag >> 32);
+                            m = fmaxf(m, __int_as_float((int)(unsigned)x[u]));
+                        }
+                    }
+                    if (ok) { best = m; break; }
+                    // a sibling workgroup never arrived (not resident), or another one has already given up
+                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(D.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        atomicExch(D.status, 1u);
+                        s_abort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (c == 0) D.dp[s] = best;
+            // publish the pair's record of this combination: the values stored in its trees (anchorer.hpp:2318-2342)
+            if (has_rec) {
+                float v[7];
+                v[0] = best;
+                if (!SPARSE) {
+#pragma unroll
+                    for (int pw = 0; pw < 6; ++pw) {
+                        const double tt = D.params.scale * D.params.gap_extend[pw / 2] * (double)sig;
+                        v[1 + pw] = (pw % 2 == 1) ? (float)((double)best + tt) : (float)((double)best - tt);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NK; ++k) cb.val[(size_t)k * cb.n_recs + pos] = v[k];
+                if (SPARSE) {
+                    *reinterpret_cast<int4*>(&s_rec[t][0]) = make_int4((int)ins, (int)off, enc(best), 0);
+                } else {
+                    *reinterpret_cast<int4*>(&s_rec[t][0]) = make_int4((int)ins, (int)off, sig, enc(v[0]));
+                    *reinterpret_cast<int4*>(&s_rec[t][4]) = make_int4(enc(v[1]), enc(v[2]), enc(v[3]), enc(v[4]));
+                    *reinterpret_cast<int4*>(&s_rec[t][8]) = make_int4(enc(v[5]), enc(v[6]), 0, 0);
+                }
+            } else {
+                *reinterpret_cast<int4*>(&s_rec[t][0]) = make_int4(-1, -1, 0, INT32_MIN);   // insertion index 0xFFFFFFFF: never a predecessor
+            }
+        }
+        lds_barrier();
+        if (s_abort) break;
+        if (active && s >= gend && has_q) {
+            const uint32_t l0 = cur - first, l1 = gend - first;
+            if (SPARSE) {
+                for (uint32_t l = l0; l < l1; ++l) {
+                    const int4 r = *reinterpret_cast<const int4*>(&s_rec[l][0]);
+                    acc[0] = max(acc[0], ((uint32_t)r.x <= qt && (uint32_t)r.y < qoff) ? r.z : INT32_MIN);
+                }
+            } else {
+                uint32_t l = l0;
+                for (; l + 2 <= l1; l += 2) {
+                    int4 ra[2], rb[2], rc[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ra[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][0]);
+                        rb[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][4]);
+                        rc[u] = *reinterpret_cast<const int4*>(&s_rec[l + u][8]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int v[7] = {ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w, rc[u].x, rc[u].y};
+                        accumulate(acc, qt, qoff, q, (uint32_t)ra[u].x, (uint32_t)ra[u].y, ra[u].z, v);
+                    }
+                }
+                for (; l < l1; ++l) {
+                    const int4 a = *reinterpret_cast<const int4*>(&s_rec[l][0]);
+                    const int4 b = *reinterpret_cast<const int4*>(&s_rec[l][4]);
+                    const int4 cc4 = *reinterpret_cast<const int4*>(&s_rec[l][8]);
+                    const int v[7] = {a.w, b.x, b.y, b.z, b.w, cc4.x, cc4.y};
+                    accumulate(acc, qt, qoff, q, (uint32_t)a.x, (uint32_t)a.y, a.z, v);
+                }
+            }
+        }
+        cur = gend;
+    }
+    // keep the final maxima: the traceback needs the value every query returned
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) cb.acc[(size_t)s * 7 + k] = acc[k];
+    }
+}
+
+// own_rec[c][s] = position of pair s's record in combination c (a pair has at most one record per combination)
+__global__ void __launch_bounds__(256) chain_own_rec_kernel(const ClChainCombo* combos) {
+    const ClChainCombo cb = combos[blockIdx.y];
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < cb.n_recs) cb.own_rec[cb.rec_s[r]] = r;
+}
+
+hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream) {
+    if (max_recs == 0) return hipSuccess;
+    hipLaunchKernelGGL(chain_own_rec_kernel, dim3((max_recs + 255) / 256, D.n_combos), dim3(256), 0, stream, D.combos);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream) {
+    if (D.sparse) hipLaunchKernelGGL(chain_walk_kernel<true>, dim3(D.n_combos), dim3(kChainMacro), 0, stream, D, first, count);
+    else hipLaunchKernelGGL(chain_walk_kernel<false>, dim3(D.n_combos), dim3(kChainMacro), 0, stream, D, first, count);
+    return hipGetLastError();
 }
 
 // tile_recs (a multiple of 256): predecessor records per workgroup.  A launch lasts at least one tile, and every workgroup

@@ -36,6 +36,8 @@
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
                                  uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
+hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream);
+hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream);
 
@@ -72,7 +74,7 @@ struct PostSwitchTable {
 using clhost::anchor_weight;
 using clhost::min_source_sink;
 
-inline int enc(float f) { int b; memcpy(&b, &f, 4); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
+inline int enc(float f) { int b; memcpy(&b, &f, 4); if (b == (int)0x80000000) b = 0; return b >= 0 ? b : b ^ 0x7FFFFFFF; }   // -0.0f == +0.0f, as on the device
 inline float dec(int k) { int b = k >= 0 ? k : k ^ 0x7FFFFFFF; float f; memcpy(&f, &b, 4); return f; }
 
 // heap node of the r-th smallest key in a MaxSearchTree / outer OrthogonalMaxSearchTree of n keys
@@ -166,7 +168,7 @@ struct Combo {
     std::vector<int32_t> q;
     std::vector<uint32_t> prefix;
     // device
-    DevBuf<uint32_t> d_rec_s, d_ins_t, d_off, d_prefix, d_qt, d_qoff;
+    DevBuf<uint32_t> d_rec_s, d_ins_t, d_off, d_prefix, d_qt, d_qoff, d_own_rec;
     DevBuf<int32_t> d_sigma, d_q;
     DevBuf<float> d_val;
     DevBuf<int> d_acc;
@@ -183,7 +185,7 @@ struct Combo {
     bool split_built = false;
     void release() {
         d_rec_s.release(); d_ins_t.release(); d_off.release(); d_prefix.release(); d_qt.release(); d_qoff.release();
-        d_sigma.release(); d_q.release(); d_val.release(); d_acc.release();
+        d_sigma.release(); d_q.release(); d_val.release(); d_acc.release(); d_own_rec.release();
     }
 };
 
@@ -629,12 +631,18 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     int rc = CL_OK;
     DevBuf<ClChainCombo> d_combos;
     DevBuf<float> d_weight, d_init, d_dp;
-    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total;
+    DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
+    DevBuf<unsigned long long> d_xch;
+    // the walk kernel (one workgroup per combination, all resident) replaces the per-block intra launches up to
+    // kChainWalkMaxCombos combinations; CL_CHAIN_OLD_WALK=1 forces the per-block path (A/B measurements)
+    static const bool old_walk_env = getenv("CL_CHAIN_OLD_WALK") != nullptr;
+    const bool use_walk = combos.size() <= kChainWalkMaxCombos && !old_walk_env;
     std::vector<ClChainCombo> hc(combos.size());
     std::vector<int> acc_init(M * 7, enc(CL_CHAIN_NEG));
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
         d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release(); d_grp_base.release(); d_grp_total.release();
+        d_group_end.release(); d_status.release(); d_xch.release();
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
@@ -644,8 +652,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         CH(c.d_qt.upload(ctx, c.qt)); CH(c.d_qoff.upload(ctx, c.qoff)); CH(c.d_q.upload(ctx, c.q));
         CH(c.d_val.alloc(ctx, 7 * c.rec_s.size()));
         CH(c.d_acc.upload(ctx, acc_init));
+        if (use_walk) {
+            CH(c.d_own_rec.alloc(ctx, M));
+            if (hipMemsetAsync(c.d_own_rec.p, 0xFF, M * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+        }
         hc[ci] = ClChainCombo{(uint32_t)c.rec_s.size(), c.d_rec_s.p, c.d_ins_t.p, c.d_off.p, c.d_sigma.p, c.d_val.p, c.d_prefix.p,
-                              c.d_qt.p, c.d_qoff.p, c.d_q.p, c.d_acc.p};
+                              c.d_qt.p, c.d_qoff.p, c.d_q.p, c.d_acc.p, c.d_own_rec.p};
     }
     CH(d_combos.upload(ctx, hc));
     CH(d_weight.upload(ctx, weight));
@@ -688,6 +700,20 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             fprintf(stderr, "\n");
         }
         CH(d_group.upload(ctx, group));
+        if (use_walk) {
+            std::vector<uint32_t> group_end(M);
+            for (uint64_t s1 = M; s1 > 0;) {
+                uint64_t s0 = s1 - 1;
+                while (s0 > 0 && group[s0 - 1] == group[s1 - 1]) --s0;
+                for (uint64_t s = s0; s < s1; ++s) group_end[s] = (uint32_t)s1;
+                s1 = s0;
+            }
+            CH(d_group_end.upload(ctx, group_end));
+            CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
+            CH(d_status.alloc(ctx, 4));
+            if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
+                hipMemsetAsync(d_status.p, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+        }
         // LDS slots of the sequential kernel: records of a (block, group) are laid out in pair order
         std::vector<uint32_t> grp_base(M), grp_total(M);
         for (uint64_t s0 = 0; s0 < M;) {
@@ -717,6 +743,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     for (int i = 0; i < 3; ++i) { D.params.gap_open[i] = cp->gap_open[i]; D.params.gap_extend[i] = cp->gap_extend[i]; }
     D.params.scale = local_scale;
     D.sparse = sparse ? 1u : 0u;
+    D.group_end = d_group_end.p;
+    D.xch = d_xch.p;
+    D.status = d_status.p;
 
     tm.prep_ms += ms_since(T0);
     lap("upload");
@@ -745,36 +774,72 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         for (const Combo& c : combos) m = std::max(m, c.prefix[hi] - c.prefix[lo]);
         return m;
     };
-    uint32_t near_lo = 0;   // first block the current group's far launch did not cover
-    for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {
-        const uint32_t first = b * kChainBlock, count = (uint32_t)std::min<uint64_t>(kChainBlock, M - first);
-        if (b % far_group == 0) {
-            near_lo = b > 1 ? b - 1 : 0;
+    if (use_walk) {
+        // macro-blocks of kChainMacro pairs: walk(k) on the context's stream is one launch of n_combos workgroups; the records of
+        // macro-block k - 1 reach k's queries by a brute-force "near" launch in front of it; everything older by a "far" launch on
+        // an auxiliary stream that may start as soon as walk(k - 2) is done
+        uint32_t max_n = 0;
+        for (const Combo& c : combos) max_n = std::max<uint32_t>(max_n, (uint32_t)c.rec_s.size());
+        if (he == hipSuccess) he = cl_chain_launch_own_rec(D, max_n, ctx->stream);
+        const uint32_t n_macro = (uint32_t)((M + kChainMacro - 1) / kChainMacro), bpm = kChainMacro / kChainBlock;
+        std::vector<hipEvent_t> ev_walk(n_macro, nullptr);
+        ev_far.assign(n_macro, nullptr);
+        for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
+            const uint32_t first = k * kChainMacro, count = (uint32_t)std::min<uint64_t>(kChainMacro, M - first);
+            const uint32_t b0 = k * bpm, near_lo = k >= 1 ? (k - 1) * bpm : 0;
             if (near_lo > 0) {
-                // far predecessors of the whole group: blocks [0, near_lo), final once walk(near_lo - 1) is done
-                hipStream_t far_stream = ctx->aux[(b / far_group) % far_streams];
-                he = hipStreamWaitEvent(far_stream, ev_intra[near_lo - 1], 0);
-                // a launch ends with one atomic merge per query and workgroup: small tiles (low latency) only where that is
-                // cheap — sparse mode has one maximum per query — and while the grid does not fill the chip
+                hipStream_t far_stream = ctx->aux[k % far_streams];
+                he = hipStreamWaitEvent(far_stream, ev_walk[k - 2], 0);
                 const uint32_t recs = max_recs(0, near_lo);
                 uint32_t tile = kChainFarTile;
                 if (sparse) {
                     tile = kChainNearTile;
                     while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
                 }
-                const uint32_t group_count = (uint32_t)std::min<uint64_t>((uint64_t)far_group * kChainBlock, M - first);
-                if (he == hipSuccess) he = cl_chain_launch_inter(D, first, group_count, 0, near_lo, recs, tile, far_stream);
-                if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
-                if (he == hipSuccess) he = hipEventRecord(ev_far[b], far_stream);
+                if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, far_stream);
+                if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[k], hipEventDisableTiming);
+                if (he == hipSuccess) he = hipEventRecord(ev_far[k], far_stream);
             }
+            if (he == hipSuccess && b0 > near_lo) he = cl_chain_launch_inter(D, first, count, near_lo, b0, max_recs(near_lo, b0), kChainNearTile, ctx->stream);
+            if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
+            if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_walk[k], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
         }
-        // near predecessors: blocks [near_lo, b), on the sequential stream right after walk(b - 1)
-        const bool fuse_near = combos.size() == 1;
-        if (he == hipSuccess && b > near_lo && !fuse_near) he = cl_chain_launch_inter(D, first, count, near_lo, b, max_recs(near_lo, b), kChainNearTile, ctx->stream);
-        if (he == hipSuccess && ev_far[b]) he = hipStreamWaitEvent(ctx->stream, ev_far[b], 0);
-        if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, fuse_near ? b - near_lo : 0u, ctx->stream);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_intra[b], hipEventDisableTiming);
-        if (he == hipSuccess) he = hipEventRecord(ev_intra[b], ctx->stream);
+        ev_intra.swap(ev_walk);   // destroyed below
+        for (auto e : ev_walk) if (e) (void)hipEventDestroy(e);
+    } else {
+        uint32_t near_lo = 0;   // first block the current group's far launch did not cover
+        for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {
+            const uint32_t first = b * kChainBlock, count = (uint32_t)std::min<uint64_t>(kChainBlock, M - first);
+            if (b % far_group == 0) {
+                near_lo = b > 1 ? b - 1 : 0;
+                if (near_lo > 0) {
+                    // far predecessors of the whole group: blocks [0, near_lo), final once walk(near_lo - 1) is done
+                    hipStream_t far_stream = ctx->aux[(b / far_group) % far_streams];
+                    he = hipStreamWaitEvent(far_stream, ev_intra[near_lo - 1], 0);
+                    // a launch ends with one atomic merge per query and workgroup: small tiles (low latency) only where that is
+                    // cheap — sparse mode has one maximum per query — and while the grid does not fill the chip
+                    const uint32_t recs = max_recs(0, near_lo);
+                    uint32_t tile = kChainFarTile;
+                    if (sparse) {
+                        tile = kChainNearTile;
+                        while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
+                    }
+                    const uint32_t group_count = (uint32_t)std::min<uint64_t>((uint64_t)far_group * kChainBlock, M - first);
+                    if (he == hipSuccess) he = cl_chain_launch_inter(D, first, group_count, 0, near_lo, recs, tile, far_stream);
+                    if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[b], hipEventDisableTiming);
+                    if (he == hipSuccess) he = hipEventRecord(ev_far[b], far_stream);
+                }
+            }
+            // near predecessors: blocks [near_lo, b), on the sequential stream right after walk(b - 1)
+            const bool fuse_near = combos.size() == 1;
+            if (he == hipSuccess && b > near_lo && !fuse_near) he = cl_chain_launch_inter(D, first, count, near_lo, b, max_recs(near_lo, b), kChainNearTile, ctx->stream);
+            if (he == hipSuccess && ev_far[b]) he = hipStreamWaitEvent(ctx->stream, ev_far[b], 0);
+            if (he == hipSuccess) he = cl_chain_launch_intra(D, first, count, fuse_near ? b - near_lo : 0u, ctx->stream);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_intra[b], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventRecord(ev_intra[b], ctx->stream);
+        }
     }
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     lap("enqueue (host)");
@@ -783,6 +848,17 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
+    if (use_walk) {
+        uint32_t status = 0;
+        he = cl_copy_sync(ctx, &status, d_status.p, sizeof(status), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) return hip_fail(he, "chaining DP status");
+        if (status != 0) {
+            cl_set_error(ctx, "chaining DP: a workgroup of the walk kernel gave up waiting for its siblings (%zu combinations not all resident?)", combos.size());
+            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+            cleanup();
+            return CL_ERR_HIP;
+        }
+    }
     {
         float dev_ms = 0;
         (void)hipEventElapsedTime(&dev_ms, ev0, ev1);
