@@ -465,12 +465,6 @@ class MatchStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-class MergeResultC(C.Structure):
-    """cl_merge_result"""
-    _fields_ = [("alignment", AlignmentC), ("fused", C.c_void_p), ("n_match_sets", C.c_uint64), ("match_ms", C.c_float), ("align_ms", C.c_float),
-                ("fuse_ms", C.c_float)]
-
-
 class AnchorParams(C.Structure):
     """cl_anchor_params"""
     _fields_ = [("chain", ChainParams), ("max_num_match_pairs", C.c_uint64), ("score_scale", C.c_double),
@@ -484,7 +478,8 @@ class AnchorChainResultC(C.Structure):
                 ("count1", C.POINTER(C.c_uint64)), ("count2", C.POINTER(C.c_uint64)), ("full_length", C.POINTER(C.c_uint64)),
                 ("walk_off", C.POINTER(C.c_uint64)), ("walk1", C.POINTER(C.c_uint32)), ("walk2", C.POINTER(C.c_uint32)),
                 ("n_sets", C.c_uint64), ("set_order", C.POINTER(C.c_uint64)), ("scale", C.c_double), ("n_ties", C.c_uint64),
-                ("fill_in_pairs", C.c_uint64), ("fill_in_device_ms", C.c_float)]
+                ("fill_in_pairs", C.c_uint64), ("fill_in_device_ms", C.c_float), ("dp_device_ms", C.c_float), ("dp_pair_evals", C.c_double),
+                ("dp_match_pairs", C.c_uint64), ("dp_combinations", C.c_uint32)]
 
 
 class CoreAlignParams(C.Structure):
@@ -503,7 +498,31 @@ class CoreAlignResultC(C.Structure):
     _fields_ = [("alignment", AlignmentC), ("n_segments", C.c_uint64), ("seg_off", C.POINTER(C.c_uint64)),
                 ("walk_off", C.POINTER(C.c_uint64)), ("walk1", C.POINTER(C.c_uint32)), ("walk2", C.POINTER(C.c_uint32)),
                 ("scale", C.c_double), ("n_chain_anchors", C.c_uint64), ("chain_ms", C.c_float), ("partition_ms", C.c_float),
-                ("stitch_ms", C.c_float)]
+                ("stitch_ms", C.c_float), ("chain_device_ms", C.c_float), ("chain_pair_evals", C.c_double), ("chain_match_pairs", C.c_uint64),
+                ("chain_combinations", C.c_uint32)]
+
+
+class MergeResultC(C.Structure):
+    """cl_merge_result"""
+    _fields_ = [("align", CoreAlignResultC), ("fused", C.c_void_p), ("n_match_sets", C.c_uint64), ("match_ms", C.c_float), ("align_ms", C.c_float),
+                ("fuse_ms", C.c_float)]
+
+
+def _core_align_dict(out):
+    """CoreAlignResultC -> dict of numpy copies"""
+    n, ns = int(out.alignment.n_pairs), int(out.n_segments)
+    seg_off = np.ctypeslib.as_array(out.seg_off, shape=(ns + 1,)).copy()
+    na = int(seg_off[-1])
+    walk_off = np.ctypeslib.as_array(out.walk_off, shape=(na + 1,)).copy()
+    nw = int(walk_off[-1])
+    return dict(alignment=np.ctypeslib.as_array(out.alignment.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2),
+                seg_off=seg_off, walk_off=walk_off,
+                walk1=np.ctypeslib.as_array(out.walk1, shape=(max(nw, 1),))[:nw].copy(),
+                walk2=np.ctypeslib.as_array(out.walk2, shape=(max(nw, 1),))[:nw].copy(),
+                scale=float(out.scale), n_chain_anchors=int(out.n_chain_anchors), chain_ms=float(out.chain_ms),
+                partition_ms=float(out.partition_ms), stitch_ms=float(out.stitch_ms), chain_device_ms=float(out.chain_device_ms),
+                chain_pair_evals=float(out.chain_pair_evals), chain_match_pairs=int(out.chain_match_pairs),
+                chain_combinations=int(out.chain_combinations))
 
 
 def default_chain_params(global_anchoring=True):
@@ -1088,17 +1107,7 @@ class Context:
         g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), CoreAlignResultC()
         self._check(self.lib.cl_core_align(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), C.byref(out)))
         try:
-            n, ns = int(out.alignment.n_pairs), int(out.n_segments)
-            seg_off = np.ctypeslib.as_array(out.seg_off, shape=(ns + 1,)).copy()
-            na = int(seg_off[-1])
-            walk_off = np.ctypeslib.as_array(out.walk_off, shape=(na + 1,)).copy()
-            nw = int(walk_off[-1])
-            return dict(alignment=np.ctypeslib.as_array(out.alignment.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2),
-                        seg_off=seg_off, walk_off=walk_off,
-                        walk1=np.ctypeslib.as_array(out.walk1, shape=(max(nw, 1),))[:nw].copy(),
-                        walk2=np.ctypeslib.as_array(out.walk2, shape=(max(nw, 1),))[:nw].copy(),
-                        scale=float(out.scale), n_chain_anchors=int(out.n_chain_anchors), chain_ms=float(out.chain_ms),
-                        partition_ms=float(out.partition_ms), stitch_ms=float(out.stitch_ms))
+            return _core_align_dict(out)
         finally:
             self.lib.cl_core_align_result_free(C.byref(out))
 
@@ -1128,11 +1137,10 @@ class Context:
         g1, g2, out = graph1.as_c(), graph2.as_c(), MergeResultC()
         self._check(self.lib.cl_merge(self.handle, C.byref(g1), C.byref(g2), C.byref(mp), C.byref(out)))
         try:
-            n = int(out.alignment.n_pairs)
-            aln = np.ctypeslib.as_array(out.alignment.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2)
+            al = _core_align_dict(out.align)
             fused, out.fused = _take_owned_base_graph(self.lib, out.fused), None
-            return dict(alignment=aln, fused=fused, n_match_sets=int(out.n_match_sets), match_ms=float(out.match_ms),
-                        align_ms=float(out.align_ms), fuse_ms=float(out.fuse_ms))
+            return dict(alignment=al["alignment"], fused=fused, n_match_sets=int(out.n_match_sets), match_ms=float(out.match_ms),
+                        align_ms=float(out.align_ms), fuse_ms=float(out.fuse_ms), align=al)
         finally:
             self.lib.cl_merge_result_free(C.byref(out))
 

@@ -59,6 +59,41 @@ struct ClChainDevice {
     unsigned long long* xch;    // [n_combos][kChainMacro] {tag, value} granules: the walk's workgroups exchange their
                                 // combination's best candidate per pair (zeroed before every DP)
     uint32_t* status;           // [1] set non-zero by a walk that gave up waiting for a sibling workgroup
+    // branch-and-bound far pass (chain_far.hip); null / 0 when it is not in use
+    int* far_rec;               // [r_pad][12] the records of every combination as the kernels consume them: insertion index, offset,
+                                // shift, 7 encoded stored values (written by the walk), 2 pad words; combination c starts at far_base[c]
+    const uint32_t* far_base;
+    uint32_t lo_mask;           // the first source record of an inter launch is rounded down to a multiple of lo_mask + 1
+};
+
+// ---- branch-and-bound far pass ---------------------------------------------------------------------------------------
+// The records of a combination, in sorted-pair order, are cut into aligned nodes of 64 * 8^l records (l = 0 .. n_levels-1).
+// Once every record of a node is final the node is SEALED: in two static orders of its records (by offset; by shift bucket,
+// then offset) the running maximum of the DP value is written down.  A query can then bound, by a few binary searches, the
+// best candidate the node could give it, and skip the node when that is below what it already has.
+constexpr int kFarLeafShift = 6;
+constexpr int kFarFanShift = 3;
+constexpr int kFarMaxLevels = 4;     // up to 32768 records: one wave seals a node in about a millisecond
+constexpr uint32_t kFarLag = 8;       // the far pass of macro-block k reads the records final kFarLag macro-blocks earlier:
+                                      // that many far launches run side by side, their binary searches hide one another's latency
+constexpr int kFarBandShift = 16;   // shift buckets of 65536: beyond that the gap cost is on its last, nearly flat piece
+
+struct ClFarLevel {
+    uint32_t* key_o;             // [r_pad] offset, ascending within a node
+    int*      pm_o;              // [r_pad] running maximum of the encoded DP value in that order (valid for sealed nodes)
+    unsigned long long* key_b;   // [r_pad] (shift bucket << 32 | offset), ascending within a node
+    int*      pm_b;              // [r_pad] running maximum within (node, bucket)
+    uint32_t* perm_o;            // [r_pad] which record sits at each position of the two orders
+    uint32_t* perm_b;
+};
+
+struct ClFarDevice {
+    uint32_t n_levels, r_pad;
+    ClFarLevel lv[kFarMaxLevels];
+    int32_t sig_bias;            // added to a shift before bucketing (buckets are non-negative)
+    double band_pen;             // least gap cost of a shift difference of one bucket width or more
+    double slack_t0;             // rounding allowance of a bound: 2^-21 (|dp| + slack_t0 + slack_e0 |query shift| + |weight|)
+    double slack_e0;
 };
 
 #endif

@@ -1,0 +1,449 @@
+// chain_far.hip — the "far" pass of the chaining DP (chain_kernels.hip) as a branch-and-bound instead of an all-pairs sweep.
+//
+// What a query needs from the records that were final long before it is ONE number per tree kind: the maximum stored value
+// over the records in range (include/centrolign/anchorer.hpp:2379-2412).  The all-pairs sweep evaluates every such record; almost
+// all of them lose by a wide margin, because DP values grow along the graphs and a gap costs at least its opening penalty.
+// This pass proves that for whole blocks of records at once and looks only at the blocks it cannot rule out.
+//
+// Records of a combination lie in sorted-pair order and are cut into aligned nodes of 64 * 8^l records.  When the walk has
+// finalised every record of a node, far_seal_kernel writes, in two static orders of the node's records — by offset, and by
+// (shift bucket of 65536, offset) — the running maximum of the DP value.  For a query (offset bound qoff, shift q, weight w)
+// and a node, with  A = max dp over the node's records with offset < qoff  and  B = the same over the three shift buckets
+// around q, every candidate the node can give is, in exact arithmetic, at most
+//        max( B , A - P ) + w          P = least gap cost of a shift difference >= one bucket width,
+// because a candidate is dp - cost(shift difference) + w with cost >= 0, and >= P outside the three buckets (the cost of
+// anchorer.hpp:1906-1918 grows with the difference).  The kernels round (float stores of double sums, :2318-2342, 2394-2412);
+// three roundings of magnitudes below |dp| + scale * extend_0 * (|shift| + |q|) + scale * open_max + |w| are covered by the
+// allowance  2^-21 x that magnitude  added to the bound.  A node whose bound is STRICTLY below the query's best candidate so
+// far cannot hold a record that attains the query's final DP value in any tree kind, so skipping it changes neither the DP
+// value nor any running maximum the traceback will read for an attaining kind (cl_chain_api.cpp); nodes that survive are
+// opened level by level, and surviving leaves are evaluated record by record with the exact arithmetic of the sweep.
+//
+// Eight lanes work on one query: a round tests eight sibling nodes (one per lane), surviving leaves are scanned by the lane
+// that tested them, surviving inner nodes go on a small per-query stack in LDS (nearest on top); the eight lanes share their
+// best candidate after every round.
+//
+// Compiled with -ffp-contract=off like chain_kernels.hip: the leaf evaluation must round like the reference's scalar code.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "chain_device.h"
+
+namespace {
+
+__device__ __forceinline__ int enc(float f) {
+    int b = __float_as_int(f);
+    if (b == (int)0x80000000) b = 0;
+    return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float dec(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+__device__ __forceinline__ void accumulate(int (&acc)[7], uint32_t qt, uint32_t qoff, int32_t q, uint32_t ins_t, uint32_t off,
+                                           int32_t sigma, const int (&v)[7]) {
+    const int none = INT32_MIN;
+    const bool ok = ins_t <= qt && off < qoff;
+    const bool eq = ok && sigma == q, lt = ok && sigma < q, gt = ok && sigma > q;
+    acc[0] = max(acc[0], eq ? v[0] : none);
+    acc[2] = max(acc[2], lt ? v[2] : none); acc[4] = max(acc[4], lt ? v[4] : none); acc[6] = max(acc[6], lt ? v[6] : none);
+    acc[1] = max(acc[1], gt ? v[1] : none); acc[3] = max(acc[3], gt ? v[3] : none); acc[5] = max(acc[5], gt ? v[5] : none);
+}
+
+__device__ __forceinline__ float best_candidate(float best, const int (&acc)[7], float w, const double (&pen)[6]) {
+    const int none = enc(CL_CHAIN_NEG);
+    if (acc[0] > none) best = fmaxf(best, dec(acc[0]) + w);
+#pragma unroll
+    for (int pw = 0; pw < 6; ++pw) {
+        if (acc[1 + pw] <= none) continue;
+        const float cand = (float)((double)(dec(acc[1 + pw]) + w) - pen[pw]);
+        best = fmaxf(best, cand);
+    }
+    return best;
+}
+
+// number of keys < x among the n ascending keys at k (n a power of two >= 64)
+template <class K>
+__device__ __forceinline__ uint32_t count_below(const K* __restrict__ k, uint32_t n, K x) {
+    uint32_t lo = 0;
+    for (uint32_t step = n >> 1; step > 0; step >>= 1)
+        if (k[lo + step - 1] < x) lo += step;
+    return lo + (k[lo] < x ? 1u : 0u);
+}
+
+// ---- setup: the record image and the sort keys -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) far_init_kernel(const ClChainCombo* combos, const uint32_t* base, uint32_t n_combos, uint32_t r_pad,
+                                                       int32_t sig_bias, int* rec, uint32_t* key_off, unsigned long long* key_band, uint32_t* idx) {
+    const uint32_t c = blockIdx.y;
+    const ClChainCombo cb = combos[c];
+    const uint32_t b0 = base[c], b1 = c + 1 < n_combos ? base[c + 1] : r_pad;
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    if (b0 + pos >= b1) return;
+    const uint32_t g = b0 + pos;
+    const int none = enc(CL_CHAIN_NEG);
+    uint32_t ins = 0xFFFFFFFFu, off = 0xFFFFFFFFu;
+    int32_t sg = 0;
+    unsigned long long bucket = 0xFFFFull;   // padding: beyond every real bucket (< 0x8000), keys stay below 2^48
+    if (pos < cb.n_recs) {
+        ins = cb.ins_t[pos]; off = cb.off[pos]; sg = cb.sigma[pos];
+        bucket = (unsigned long long)((uint32_t)(sg + sig_bias) >> kFarBandShift);
+    }
+    int4* r = reinterpret_cast<int4*>(rec + (size_t)g * 12);
+    r[0] = make_int4((int)ins, (int)off, sg, none);
+    r[1] = make_int4(none, none, none, none);
+    r[2] = make_int4(none, none, 0, 0);
+    key_off[g] = off;
+    key_band[g] = (bucket << 32) | off;
+    idx[g] = g;
+}
+
+__global__ void __launch_bounds__(256) far_node_key_kernel(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) node_key[i] = order[i] >> shift;
+}
+
+template <class K>
+__global__ void __launch_bounds__(256) far_gather_kernel(const uint32_t* perm, const K* src, uint32_t n, K* dst) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+// ---- sealing: running maxima of the DP value in the node's two orders ----------------------------------------------------
+// one wave per node
+__global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* __restrict__ rec, const uint32_t* __restrict__ items, uint32_t item0) {
+    const uint32_t it = items[item0 + blockIdx.x];
+    const uint32_t l = it >> 28, node = it & 0x0FFFFFFFu;
+    const ClFarLevel L = F.lv[l];
+    const uint32_t shift = kFarLeafShift + kFarFanShift * l;
+    const uint32_t g0 = node << shift, n = 1u << shift;
+    const uint32_t lane = threadIdx.x;
+    int carry_o = INT32_MIN, carry_b = INT32_MIN;
+    uint32_t carry_bucket = 0xFFFFFFFEu;
+    for (uint32_t at = 0; at < n; at += 64) {
+        const uint32_t i = g0 + at + lane;
+        // by offset: plain inclusive maximum
+        int x = rec[(size_t)L.perm_o[i] * 12 + 3];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(x, d);
+            if ((int)lane >= d) x = max(x, o);
+        }
+        x = max(x, carry_o);
+        L.pm_o[i] = x;
+        carry_o = __shfl(x, 63);
+        if (!L.key_b) continue;   // sparse_chain_dp: one order only
+        // by (bucket, offset): maximum within the bucket
+        int y = rec[(size_t)L.perm_b[i] * 12 + 3];
+        const uint32_t bk = (uint32_t)(L.key_b[i] >> 32);
+        const uint32_t prev = __shfl_up(bk, 1);
+        int head = (lane == 0 ? bk != carry_bucket : bk != prev) ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int oy = __shfl_up(y, d);
+            const int oh = __shfl_up(head, d);
+            if ((int)lane >= d) {
+                if (!head) y = max(y, oy);
+                head |= oh;
+            }
+        }
+        if (!head) y = max(y, carry_b);   // the bucket began in an earlier chunk
+        L.pm_b[i] = y;
+        carry_b = __shfl(y, 63);
+        carry_bucket = __shfl(bk, 63);
+    }
+}
+
+// ---- the pass -------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFarStack = 80;
+
+struct FarQuery {
+    uint32_t qt, qoff, bq;
+    int32_t q;
+    float w;
+    double slack_q;
+};
+
+// upper bound of every candidate the node (level lvl, first record g0 of the global image) can give the query; -inf if no
+// record of the node lies below the query's offset
+template <bool SPARSE>
+__device__ __forceinline__ double node_bound(const ClFarDevice& F, uint32_t lvl, uint32_t g0, const FarQuery& Q) {
+    const ClFarLevel L = F.lv[lvl];
+    const uint32_t n = 1u << (kFarLeafShift + kFarFanShift * lvl);
+    if (SPARSE) {
+        const uint32_t cnt = count_below<uint32_t>(L.key_o + g0, n, Q.qoff);
+        if (cnt == 0) return -HUGE_VAL;
+        const double da = (double)dec(L.pm_o[g0 + cnt - 1]);
+        return da + (double)Q.w + 0x1p-21 * (fabs(da) + fabs((double)Q.w));
+    }
+    // four binary searches in lockstep (their loads overlap): offset < qoff in the offset order; (bucket, offset) < (b, qoff)
+    // for the three buckets around the query's in the bucket order.  A bucket no record can have searches for key 0.
+    const uint32_t* __restrict__ ko = L.key_o + g0;
+    const unsigned long long* __restrict__ kb = L.key_b + g0;
+    unsigned long long key[3];
+    uint32_t bk[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        bk[j] = Q.bq + (uint32_t)(j - 1);
+        key[j] = bk[j] >= 0x8000u ? 0ull : (((unsigned long long)bk[j] << 32) | Q.qoff);
+    }
+    uint32_t lo = 0, l0 = 0, l1 = 0, l2 = 0;
+    for (uint32_t step = n >> 1; step > 0; step >>= 1) {
+        const uint32_t vo = ko[lo + step - 1];
+        const unsigned long long v0 = kb[l0 + step - 1], v1 = kb[l1 + step - 1], v2 = kb[l2 + step - 1];
+        lo += vo < Q.qoff ? step : 0u;
+        l0 += v0 < key[0] ? step : 0u;
+        l1 += v1 < key[1] ? step : 0u;
+        l2 += v2 < key[2] ? step : 0u;
+    }
+    {
+        const uint32_t vo = ko[lo];
+        const unsigned long long v0 = kb[l0], v1 = kb[l1], v2 = kb[l2];
+        lo += vo < Q.qoff ? 1u : 0u;
+        l0 += v0 < key[0] ? 1u : 0u;
+        l1 += v1 < key[1] ? 1u : 0u;
+        l2 += v2 < key[2] ? 1u : 0u;
+    }
+    if (lo == 0) return -HUGE_VAL;
+    const uint32_t ix[3] = {l0, l1, l2};
+    const int pa = L.pm_o[g0 + lo - 1];
+    int dband = INT32_MIN;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t at = ix[j] ? ix[j] - 1 : 0;
+        const unsigned long long kk = kb[at];
+        const int pv = L.pm_b[g0 + at];
+        if (ix[j] != 0 && bk[j] < 0x8000u && (uint32_t)(kk >> 32) == bk[j]) dband = max(dband, pv);
+    }
+    const double da = (double)dec(pa);
+    double m = da - F.band_pen;
+    if (dband != INT32_MIN) m = fmax(m, (double)dec(dband));
+    return m + (double)Q.w + 0x1p-21 * (fabs(da) + Q.slack_q);
+}
+
+// the exact evaluation of the sweep over the 64 records of a leaf
+template <bool SPARSE>
+__device__ __forceinline__ float scan_leaf(const int* __restrict__ rec, uint32_t g0, const FarQuery& Q, int (&acc)[7], float best, const double (&pen)[6]) {
+    const int none = enc(CL_CHAIN_NEG);
+    const int4* r4 = reinterpret_cast<const int4*>(rec + (size_t)g0 * 12);
+    if (SPARSE) {
+        for (uint32_t i = 0; i < 64; i += 4) {
+            int4 ra[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ra[u] = r4[(i + u) * 3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[0] = max(acc[0], ((uint32_t)ra[u].x <= Q.qt && (uint32_t)ra[u].y < Q.qoff) ? ra[u].w : INT32_MIN);
+        }
+        if (acc[0] > none) best = fmaxf(best, dec(acc[0]) + Q.w);
+    } else {
+        for (uint32_t i = 0; i < 64; i += 2) {
+            int4 ra[2], rb[2], rc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { ra[u] = r4[(i + u) * 3]; rb[u] = r4[(i + u) * 3 + 1]; rc[u] = r4[(i + u) * 3 + 2]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int v[7] = {ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w, rc[u].x, rc[u].y};
+                accumulate(acc, Q.qt, Q.qoff, Q.q, (uint32_t)ra[u].x, (uint32_t)ra[u].y, ra[u].z, v);
+            }
+        }
+        best = best_candidate(best, acc, Q.w, pen);
+    }
+    return best;
+}
+
+// this lane's share of the next eight cover nodes of [0, p): aligned nodes, the nearest (smallest) first
+__device__ __forceinline__ void next_cover(uint32_t& p, uint32_t sub, uint32_t top, uint32_t& lvl, uint32_t& a) {
+    uint32_t pp = p;
+    lvl = 0xFFu;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        if (pp == 0) break;
+        uint32_t l = (uint32_t)(__builtin_ctz(pp >> kFarLeafShift)) / kFarFanShift;
+        if (l > top) l = top;
+        const uint32_t nn = 1u << (kFarLeafShift + kFarFanShift * l);
+        if (j == sub) { lvl = l; a = pp - nn; }
+        pp -= nn;
+    }
+    p = pp;
+}
+
+// the node with the largest bound among the eight lanes of the group (ties: the smaller code), the same answer in every lane
+__device__ __forceinline__ void group_argmax(double& b, uint32_t& code) {
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        const double ob = __shfl_xor(b, m);
+        const uint32_t oc = __shfl_xor(code, m);
+        if (ob > b || (ob == b && oc < code)) { b = ob; code = oc; }
+    }
+}
+
+template <bool SPARSE>
+__global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDevice F, uint32_t first, uint32_t count, uint32_t end_block) {
+    const uint32_t c = blockIdx.y;
+    const ClChainCombo cb = D.combos[c];
+    const uint32_t sub = threadIdx.x & 7u;                       // lane within the query's group of eight
+    const uint32_t grp = threadIdx.x >> 3;                       // group within the workgroup
+    const uint32_t qi = blockIdx.x * 32 + grp;
+    const uint32_t s = first + qi;
+    const uint32_t E = cb.prefix[end_block] & ~63u;              // records [0, E) are final, every node inside is sealed
+    const int none = enc(CL_CHAIN_NEG);
+    bool live = qi < count && E != 0;
+    FarQuery Q{};
+    if (live) {
+        Q.qt = cb.qt[s];
+        live = Q.qt != 0xFFFFFFFFu;
+        if (live) { Q.qoff = cb.qoff[s]; Q.q = cb.q[s]; live = Q.qoff != 0; }
+    }
+    if (!live) return;                                           // uniform over the group of eight
+    Q.w = D.weight[s];
+    float best = D.init[s];
+    int acc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = INT32_MIN;
+    double pen[6];
+#pragma unroll
+    for (int pw = 0; pw < 6; ++pw) {
+        const double go = D.params.gap_open[pw / 2], ge = D.params.gap_extend[pw / 2];
+        pen[pw] = (pw % 2 == 1) ? D.params.scale * (go + ge * (double)Q.q) : D.params.scale * (go - ge * (double)Q.q);
+    }
+    const uint32_t base = D.far_base[c];
+    const int* __restrict__ rec = D.far_rec;
+    Q.slack_q = F.slack_t0 + F.slack_e0 * fabs((double)Q.q) + fabs((double)Q.w);
+    // shift bucket of the query; the host picks sig_bias so that every record's bucket lies in [1, 0x8000): a query whose biased
+    // shift is negative is more than a bucket width away from every record
+    const long long qb = (long long)Q.q + (long long)F.sig_bias;
+    Q.bq = qb < 0 ? 0xFFFF0000u : (uint32_t)(qb >> kFarBandShift);
+    const uint32_t top = F.n_levels - 1;
+
+    // ---- probe: follow the largest bound down to one leaf.  A query whose best predecessor lies far back (a pair on a distant
+    //      diagonal chains from wherever the main chain passed its graph-2 position) would otherwise open every node between
+    //      itself and that place before it knows what it is looking for.
+    {
+        double pb = -HUGE_VAL;
+        uint32_t pcode = 0xFFFFFFFFu;
+        uint32_t p = E;
+        while (p > 0) {
+            uint32_t lvl, a = 0;
+            next_cover(p, sub, top, lvl, a);
+            if (lvl != 0xFFu) {
+                const double b = node_bound<SPARSE>(F, lvl, base + a, Q);
+                const uint32_t code = (lvl << 28) | (a >> kFarLeafShift);
+                if (b > pb || (b == pb && code < pcode)) { pb = b; pcode = code; }
+            }
+        }
+        group_argmax(pb, pcode);
+        while (pcode != 0xFFFFFFFFu && (pcode >> 28) != 0 && pb > -HUGE_VAL) {
+            const uint32_t lvl = (pcode >> 28) - 1;
+            const uint32_t a = ((pcode & 0x0FFFFFFFu) << kFarLeafShift) + (sub << (kFarLeafShift + kFarFanShift * lvl));
+            pb = node_bound<SPARSE>(F, lvl, base + a, Q);
+            pcode = (lvl << 28) | (a >> kFarLeafShift);
+            group_argmax(pb, pcode);
+        }
+        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL && sub == 0)
+            best = scan_leaf<SPARSE>(rec, base + ((pcode & 0x0FFFFFFFu) << kFarLeafShift), Q, acc, best, pen);
+        best = fmaxf(best, __shfl_xor(best, 1));
+        best = fmaxf(best, __shfl_xor(best, 2));
+        best = fmaxf(best, __shfl_xor(best, 4));
+    }
+
+    // ---- the branch-and-bound proper, nearest nodes first
+    __shared__ uint32_t s_stack[32][kFarStack];
+    volatile uint32_t* st = s_stack[grp];
+    uint32_t sp = 0;
+    uint32_t p = E;                                              // cover nodes still to hand out lie in [0, p)
+    while (true) {
+        // this round's node for this lane: (level, first record), level 0xFF = none
+        uint32_t lvl = 0xFFu, a = 0;
+        if (sp > 0) {
+            const uint32_t e = st[sp - 1];
+            --sp;
+            lvl = (e >> 28) - 1;
+            a = ((e & 0x0FFFFFFFu) << kFarLeafShift) + ((7u - sub) << (kFarLeafShift + kFarFanShift * lvl));   // lane 0 takes the nearest child
+        } else if (p > 0) {
+            next_cover(p, sub, top, lvl, a);
+        } else {
+            break;
+        }
+        bool hit = false;
+        if (lvl != 0xFFu) hit = node_bound<SPARSE>(F, lvl, base + a, Q) >= (double)best;
+        if (hit && lvl == 0) best = scan_leaf<SPARSE>(rec, base + a, Q, acc, best, pen);
+        // surviving inner nodes go on the stack, nearest (lane 0) on top
+        const bool push = hit && lvl != 0 && lvl != 0xFFu;
+        const unsigned long long bal = __ballot(push);
+        const uint32_t mask = (uint32_t)(bal >> ((threadIdx.x & 63u) & ~7u)) & 0xFFu;
+        if (push) {
+            const uint32_t above = __popc(mask >> (sub + 1));    // surviving lanes farther than this one go below it
+            st[sp + above] = (lvl << 28) | (a >> kFarLeafShift);
+        }
+        sp += __popc(mask);
+        // the eight lanes share the best candidate found so far
+        best = fmaxf(best, __shfl_xor(best, 1));
+        best = fmaxf(best, __shfl_xor(best, 2));
+        best = fmaxf(best, __shfl_xor(best, 4));
+    }
+    // merge the eight lanes' maxima and hand them to the walk
+    constexpr int NK = SPARSE ? 1 : 7;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        int v = acc[k];
+        v = max(v, __shfl_xor(v, 1));
+        v = max(v, __shfl_xor(v, 2));
+        v = max(v, __shfl_xor(v, 4));
+        if (sub == 0 && v > none) atomicMax(cb.acc + (size_t)s * 7 + k, v);
+    }
+}
+
+}  // namespace
+
+// ---- host entry points ---------------------------------------------------------------------------------------------------
+hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias,
+                             uint32_t* key_off, unsigned long long* key_band, uint32_t* idx, hipStream_t stream) {
+    hipLaunchKernelGGL(far_init_kernel, dim3((max_padded + 255) / 256, D.n_combos), dim3(256), 0, stream, D.combos, d_base, D.n_combos, r_pad,
+                       sig_bias, D.far_rec, key_off, key_band, idx);
+    return hipGetLastError();
+}
+
+size_t cl_chain_far_sort_temp_bytes(uint32_t n) {
+    size_t a = 0, b = 0, c = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    c = a > b ? a : b;
+    return c + 256;
+}
+
+// order_out = idx sorted by key (32-bit keys, bits [0, end_bit))
+hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                               uint32_t n, int end_bit, hipStream_t stream) {
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream);
+}
+
+hipError_t cl_chain_far_sort64(void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
+                               uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t stream) {
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream);
+}
+
+hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream) {
+    hipLaunchKernelGGL(far_node_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, order, n, shift, node_key);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_far_gather32(const uint32_t* perm, const uint32_t* src, uint32_t n, uint32_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(far_gather_kernel<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, stream, perm, src, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_far_gather64(const uint32_t* perm, const unsigned long long* src, uint32_t n, unsigned long long* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(far_gather_kernel<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, stream, perm, src, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, hipStream_t stream) {
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(far_seal_kernel, dim3(n_items), dim3(64), 0, stream, F, D.far_rec, items, item0);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream) {
+    const dim3 grid((count + 31) / 32, D.n_combos);
+    if (D.sparse) hipLaunchKernelGGL(far_prune_kernel<true>, grid, dim3(256), 0, stream, D, F, first, count, end_block);
+    else hipLaunchKernelGGL(far_prune_kernel<false>, grid, dim3(256), 0, stream, D, F, first, count, end_block);
+    return hipGetLastError();
+}

@@ -87,7 +87,7 @@ __device__ __forceinline__ void lds_barrier() {
 __global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
                                                           uint32_t src_block_lo, uint32_t src_block_hi, uint32_t tile_recs) {
     const ClChainCombo cb = D.combos[blockIdx.z];
-    const uint32_t rec_lo = cb.prefix[src_block_lo], rec_hi = cb.prefix[src_block_hi];
+    const uint32_t rec_lo = cb.prefix[src_block_lo] & ~D.lo_mask, rec_hi = cb.prefix[src_block_hi];
     const uint32_t tile0 = rec_lo + blockIdx.x * tile_recs;
     if (tile0 >= rec_hi) return;
     const uint32_t tile_end = min(tile0 + tile_recs, rec_hi);
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) chain_inter_kernel(ClChainDevice D, uint3
 __global__ void __launch_bounds__(256) chain_inter_sparse_kernel(ClChainDevice D, uint32_t block_first, uint32_t block_count,
                                                                  uint32_t src_block_lo, uint32_t src_block_hi, uint32_t tile_recs) {
     const ClChainCombo cb = D.combos[blockIdx.z];
-    const uint32_t rec_lo = cb.prefix[src_block_lo], rec_hi = cb.prefix[src_block_hi];
+    const uint32_t rec_lo = cb.prefix[src_block_lo] & ~D.lo_mask, rec_hi = cb.prefix[src_block_hi];
     const uint32_t tile0 = rec_lo + blockIdx.x * tile_recs;
     if (tile0 >= rec_hi) return;
     const uint32_t tile_end = min(tile0 + tile_recs, rec_hi);
@@ -584,6 +584,14 @@ __global__ void __launch_bounds__(kChainMacro) chain_walk_kernel(ClChainDevice D
                 }
 #pragma unroll
                 for (int k = 0; k < NK; ++k) cb.val[(size_t)k * cb.n_recs + pos] = v[k];
+                if (D.far_rec) {   // the image the branch-and-bound far pass reads (chain_far.hip)
+                    int4* fr = reinterpret_cast<int4*>(D.far_rec + (size_t)(D.far_base[c] + pos) * 12);
+                    fr[0] = make_int4((int)ins, (int)off, sig, enc(v[0]));
+                    if (!SPARSE) {
+                        fr[1] = make_int4(enc(v[1]), enc(v[2]), enc(v[3]), enc(v[4]));
+                        fr[2] = make_int4(enc(v[5]), enc(v[6]), 0, 0);
+                    }
+                }
                 if (SPARSE) {
                     *reinterpret_cast<int4*>(&s_rec[t][0]) = make_int4((int)ins, (int)off, enc(best), 0);
                 } else {

@@ -56,6 +56,10 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
     if (rc) return rc;
     out->scale = ch.scale;
     out->n_chain_anchors = ch.n_anchors;
+    out->chain_device_ms = ch.dp_device_ms;
+    out->chain_pair_evals = ch.dp_pair_evals;
+    out->chain_match_pairs = ch.dp_match_pairs;
+    out->chain_combinations = ch.dp_combinations;
     out->chain_ms = ms_since(t0);
     t0 = now();
     // partition (core.hpp:237-241)

@@ -38,6 +38,19 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
 hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream);
 hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
+// chain_far.hip
+hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias,
+                             uint32_t* key_off, unsigned long long* key_band, uint32_t* idx, hipStream_t stream);
+size_t cl_chain_far_sort_temp_bytes(uint32_t n);
+hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                               uint32_t n, int end_bit, hipStream_t stream);
+hipError_t cl_chain_far_sort64(void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
+                               uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t stream);
+hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream);
+hipError_t cl_chain_far_gather32(const uint32_t* perm, const uint32_t* src, uint32_t n, uint32_t* dst, hipStream_t stream);
+hipError_t cl_chain_far_gather64(const uint32_t* perm, const unsigned long long* src, uint32_t n, unsigned long long* dst, hipStream_t stream);
+hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, hipStream_t stream);
+hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream);
 
@@ -249,7 +262,7 @@ struct ChainSubResult {
     uint64_t n_ties = 0;
 };
 
-struct ChainTimings { float device_ms = 0, prep_ms = 0, index_ms = 0, traceback_ms = 0; uint64_t n_pairs = 0; };
+struct ChainTimings { float device_ms = 0, prep_ms = 0, index_ms = 0, traceback_ms = 0; uint64_t n_pairs = 0; double pair_evals = 0; uint32_t n_combos = 0; };
 
 struct SubCtx {
     clhost::PathMergeTable own_x[2];
@@ -590,6 +603,8 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         }
     }
     lap("records");
+    tm.n_combos = (uint32_t)combos.size();
+    for (const Combo& c : combos) tm.pair_evals += 0.5 * (double)c.rec_s.size() * (double)M;
     const uint32_t n_blocks = (uint32_t)((M + kChainBlock - 1) / kChainBlock);
     for (Combo& c : combos) {
         c.qt.assign(M, kNone);
@@ -633,6 +648,13 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
     DevBuf<unsigned long long> d_xch;
+    // branch-and-bound far pass (chain_far.hip)
+    DevBuf<int> d_far_rec, d_far_pm[2 * kFarMaxLevels];
+    DevBuf<uint32_t> d_far_base, d_far_u32[6 + 3 * kFarMaxLevels], d_seal_items;
+    DevBuf<unsigned long long> d_far_u64[2 + kFarMaxLevels];
+    DevBuf<char> d_far_temp;
+    ClFarDevice F{};
+    std::vector<uint32_t> seal_off;   // [n_macro + 1] into d_seal_items
     // the walk kernel (one workgroup per combination, all resident) replaces the per-block intra launches up to
     // kChainWalkMaxCombos combinations; CL_CHAIN_OLD_WALK=1 forces the per-block path (A/B measurements)
     static const bool old_walk_env = getenv("CL_CHAIN_OLD_WALK") != nullptr;
@@ -643,6 +665,10 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         for (Combo& c : combos) c.release();
         d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release(); d_grp_base.release(); d_grp_total.release();
         d_group_end.release(); d_status.release(); d_xch.release();
+        d_far_rec.release(); d_far_base.release(); d_seal_items.release(); d_far_temp.release();
+        for (auto& b : d_far_pm) b.release();
+        for (auto& b : d_far_u32) b.release();
+        for (auto& b : d_far_u64) b.release();
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
@@ -747,6 +773,106 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     D.xch = d_xch.p;
     D.status = d_status.p;
 
+
+    // ---- branch-and-bound far pass: record image, the two static orders per level, the sealing schedule -------------------
+    static const bool no_far_env = getenv("CL_CHAIN_NO_FAR_PRUNE") != nullptr;
+    const uint32_t n_macro_all = (uint32_t)((M + kChainMacro - 1) / kChainMacro);
+    bool use_far = use_walk && !no_far_env && n_macro_all >= kFarLag + 3;
+    if (use_far) {
+        uint32_t max_n = 0;
+        int64_t smin = INT64_MAX, smax = INT64_MIN;
+        for (const Combo& c : combos) {
+            max_n = std::max<uint32_t>(max_n, (uint32_t)c.rec_s.size());
+            for (int32_t sg : c.sigma) { smin = std::min<int64_t>(smin, sg); smax = std::max<int64_t>(smax, sg); }
+        }
+        uint32_t n_levels = 1;
+        while (n_levels < (uint32_t)kFarMaxLevels && (64ull << (kFarFanShift * n_levels)) <= max_n) ++n_levels;
+        const uint64_t n_top = 64ull << (kFarFanShift * (n_levels - 1));
+        std::vector<uint32_t> base(combos.size());
+        uint64_t r_pad = 0, max_padded = 0;
+        for (size_t ci = 0; ci < combos.size(); ++ci) {
+            base[ci] = (uint32_t)r_pad;
+            const uint64_t padded = (combos[ci].rec_s.size() + n_top - 1) / n_top * n_top;
+            max_padded = std::max(max_padded, padded);
+            r_pad += padded;
+        }
+        const int64_t bias = 65536 - smin;
+        if (r_pad == 0 || r_pad >= (1ull << 31) || smin == INT64_MAX || smax + bias >= (1ll << 31) || bias >= (1ll << 31)) use_far = false;
+        if (use_far) {
+            const uint32_t R = (uint32_t)r_pad;
+            F.n_levels = n_levels;
+            F.r_pad = R;
+            F.sig_bias = (int32_t)bias;
+            double pw = 1e300, omax = 0, emax = 0;
+            for (int k = 0; k < 3; ++k) {
+                pw = std::min(pw, local_scale * (cp->gap_open[k] + cp->gap_extend[k] * 65536.0));
+                omax = std::max(omax, cp->gap_open[k]);
+                emax = std::max(emax, cp->gap_extend[k]);
+            }
+            F.band_pen = sparse ? 0.0 : pw;
+            F.slack_t0 = local_scale * emax * (double)std::max<int64_t>(std::llabs(smin), std::llabs(smax)) + local_scale * omax;
+            F.slack_e0 = local_scale * emax;
+            CH(d_far_rec.alloc(ctx, (size_t)R * 12));
+            CH(d_far_base.upload(ctx, base));
+            D.far_rec = d_far_rec.p;
+            D.far_base = d_far_base.p;
+            // scratch: 0 key_off, 1 idx, 2 order_off, 3 order_band, 4 node keys in, 5 node keys out / sorted-key sink; u64: 0 key_band, 1 sorted sink
+            for (int i = 0; i < 6; ++i) CH(d_far_u32[i].alloc(ctx, R));
+            for (int i = 0; i < 2; ++i) CH(d_far_u64[i].alloc(ctx, R));
+            const size_t temp_bytes = cl_chain_far_sort_temp_bytes(R);
+            CH(d_far_temp.alloc(ctx, temp_bytes));
+            hipError_t fe = cl_chain_far_init(D, d_far_base.p, (uint32_t)max_padded, R, F.sig_bias, d_far_u32[0].p, d_far_u64[0].p, d_far_u32[1].p, ctx->stream);
+            if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[0].p, d_far_u32[5].p, d_far_u32[1].p, d_far_u32[2].p, R, 32, ctx->stream);
+            if (fe == hipSuccess && !sparse) fe = cl_chain_far_sort64(d_far_temp.p, temp_bytes, d_far_u64[0].p, d_far_u64[1].p, d_far_u32[1].p, d_far_u32[3].p, R, 48, ctx->stream);
+            for (uint32_t l = 0; l < n_levels && fe == hipSuccess; ++l) {
+                const uint32_t shift = kFarLeafShift + kFarFanShift * l;
+                int bits = 1;
+                while (((uint64_t)R >> shift) >> bits) ++bits;
+                DevBuf<uint32_t>& perm_o = d_far_u32[6 + 3 * l];
+                DevBuf<uint32_t>& perm_b = d_far_u32[6 + 3 * l + 1];
+                DevBuf<uint32_t>& key_o = d_far_u32[6 + 3 * l + 2];
+                CH(perm_o.alloc(ctx, R)); CH(key_o.alloc(ctx, R)); CH(d_far_pm[2 * l].alloc(ctx, R));
+                fe = cl_chain_far_node_keys(d_far_u32[2].p, R, shift, d_far_u32[4].p, ctx->stream);
+                if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[4].p, d_far_u32[5].p, d_far_u32[2].p, perm_o.p, R, bits, ctx->stream);
+                if (fe == hipSuccess) fe = cl_chain_far_gather32(perm_o.p, d_far_u32[0].p, R, key_o.p, ctx->stream);
+                F.lv[l].key_o = key_o.p; F.lv[l].pm_o = d_far_pm[2 * l].p; F.lv[l].perm_o = perm_o.p;
+                if (!sparse) {
+                    CH(perm_b.alloc(ctx, R)); CH(d_far_u64[2 + l].alloc(ctx, R)); CH(d_far_pm[2 * l + 1].alloc(ctx, R));
+                    if (fe == hipSuccess) fe = cl_chain_far_node_keys(d_far_u32[3].p, R, shift, d_far_u32[4].p, ctx->stream);
+                    if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[4].p, d_far_u32[5].p, d_far_u32[3].p, perm_b.p, R, bits, ctx->stream);
+                    if (fe == hipSuccess) fe = cl_chain_far_gather64(perm_b.p, d_far_u64[0].p, R, d_far_u64[2 + l].p, ctx->stream);
+                    F.lv[l].key_b = d_far_u64[2 + l].p; F.lv[l].pm_b = d_far_pm[2 * l + 1].p; F.lv[l].perm_b = perm_b.p;
+                } else {   // sparse_chain_dp has no shifts: the bucket order is the offset order
+                    F.lv[l].key_b = nullptr; F.lv[l].pm_b = d_far_pm[2 * l].p; F.lv[l].perm_b = perm_o.p;
+                }
+            }
+            if (fe != hipSuccess) { cl_set_error(ctx, "far pass setup failed: %s", hipGetErrorString(fe)); cleanup(); return CL_ERR_HIP; }
+            // sealing schedule: a node is sealed right after the walk of the macro-block that finalises its last record
+            std::vector<std::vector<uint32_t>> by_macro(n_macro_all);
+            for (size_t ci = 0; ci < combos.size(); ++ci) {
+                const Combo& c = combos[ci];
+                const uint64_t nc = c.rec_s.size();
+                for (uint32_t l = 0; l < n_levels; ++l) {
+                    const uint32_t shift = kFarLeafShift + kFarFanShift * l;
+                    const uint64_t nn = 1ull << shift;
+                    for (uint64_t a = 0; a < nc; a += nn) {
+                        const uint64_t last = std::min(a + nn, nc) - 1;
+                        by_macro[c.rec_s[last] / kChainMacro].push_back((l << 28) | (uint32_t)((base[ci] + a) >> shift));
+                    }
+                }
+            }
+            std::vector<uint32_t> items;
+            seal_off.assign(n_macro_all + 1, 0);
+            for (uint32_t k = 0; k < n_macro_all; ++k) {
+                items.insert(items.end(), by_macro[k].begin(), by_macro[k].end());
+                seal_off[k + 1] = (uint32_t)items.size();
+            }
+            CH(d_seal_items.upload(ctx, items));
+            for (int i = 1; i < 6; ++i) d_far_u32[i].release();   // scratch (key_off stays: nothing reads it again, but it is small)
+            d_far_u64[1].release();
+        }
+    }
+    lap("far pass setup");
     tm.prep_ms += ms_since(T0);
     lap("upload");
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -782,30 +908,56 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         for (const Combo& c : combos) max_n = std::max<uint32_t>(max_n, (uint32_t)c.rec_s.size());
         if (he == hipSuccess) he = cl_chain_launch_own_rec(D, max_n, ctx->stream);
         const uint32_t n_macro = (uint32_t)((M + kChainMacro - 1) / kChainMacro), bpm = kChainMacro / kChainBlock;
-        std::vector<hipEvent_t> ev_walk(n_macro, nullptr);
+        std::vector<hipEvent_t> ev_walk(n_macro, nullptr), ev_seal(n_macro, nullptr);
         ev_far.assign(n_macro, nullptr);
+        static_assert(kFarLag + 1 <= (uint32_t)kNumAuxStreams, "one auxiliary stream per far launch in flight plus the sealing stream");
+        hipStream_t seal_stream = ctx->aux[kFarLag];
+        if (use_far) {
+            if (he == hipSuccess) he = hipStreamWaitEvent(seal_stream, ctx->ev_fork, 0);
+            for (uint32_t f = far_streams; f < kFarLag && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
+        }
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
             const uint32_t first = k * kChainMacro, count = (uint32_t)std::min<uint64_t>(kChainMacro, M - first);
-            const uint32_t b0 = k * bpm, near_lo = k >= 1 ? (k - 1) * bpm : 0;
+            const uint32_t lag = use_far ? kFarLag : 1u;
+            const uint32_t b0 = k * bpm, near_lo = k >= lag ? (k - lag) * bpm : 0;
             if (near_lo > 0) {
-                hipStream_t far_stream = ctx->aux[k % far_streams];
-                he = hipStreamWaitEvent(far_stream, ev_walk[k - 2], 0);
-                const uint32_t recs = max_recs(0, near_lo);
-                uint32_t tile = kChainFarTile;
-                if (sparse) {
-                    tile = kChainNearTile;
-                    while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
+                hipStream_t far_stream = ctx->aux[k % (use_far ? kFarLag : far_streams)];
+                if (use_far) {
+                    // every node inside the records [0, prefix[near_lo]) was sealed by seal(k - lag - 1) or earlier
+                    he = hipStreamWaitEvent(far_stream, ev_seal[k - lag - 1], 0);
+                    if (he == hipSuccess) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream);
+                } else {
+                    he = hipStreamWaitEvent(far_stream, ev_walk[k - 2], 0);
+                    const uint32_t recs = max_recs(0, near_lo);
+                    uint32_t tile = kChainFarTile;
+                    if (sparse) {
+                        tile = kChainNearTile;
+                        while (tile < kChainFarTile && (recs + tile - 1) / tile > kChainFullGrid) tile *= 2;
+                    }
+                    if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, far_stream);
                 }
-                if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, far_stream);
                 if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[k], hipEventDisableTiming);
                 if (he == hipSuccess) he = hipEventRecord(ev_far[k], far_stream);
             }
-            if (he == hipSuccess && b0 > near_lo) he = cl_chain_launch_inter(D, first, count, near_lo, b0, max_recs(near_lo, b0), kChainNearTile, ctx->stream);
+            if (he == hipSuccess && b0 > near_lo) {
+                // the far pass stops at a leaf boundary: the near launch starts there
+                ClChainDevice Dn = D;
+                if (use_far && near_lo > 0) Dn.lo_mask = 63u;
+                he = cl_chain_launch_inter(Dn, first, count, near_lo, b0, max_recs(near_lo, b0) + Dn.lo_mask, kChainNearTile, ctx->stream);
+            }
             if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
             if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_walk[k], hipEventDisableTiming);
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
+            if (use_far && he == hipSuccess && k + kFarLag + 1 < n_macro) {
+                he = hipStreamWaitEvent(seal_stream, ev_walk[k], 0);
+                if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_stream);
+                if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_seal[k], hipEventDisableTiming);
+                if (he == hipSuccess) he = hipEventRecord(ev_seal[k], seal_stream);
+            }
         }
+        if (use_far && he == hipSuccess) he = hipStreamSynchronize(seal_stream);
+        for (auto e : ev_seal) if (e) (void)hipEventDestroy(e);
         ev_intra.swap(ev_walk);   // destroyed below
         for (auto e : ev_walk) if (e) (void)hipEventDestroy(e);
     } else {
@@ -844,7 +996,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     lap("enqueue (host)");
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-    for (uint32_t f = 0; f < far_streams && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
+    for (uint32_t f = 0; f < std::max<uint32_t>(far_streams, kFarLag) && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
@@ -1564,7 +1716,10 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         int rc = chain_dp_batch(ctx, subs, &cp, anchor_scale, sparse, res, tm, nullptr);
         if (rc) return rc;
         lap(sparse ? "sparse: chain DP" : "affine: chain DP", t);
-        if (timing) fprintf(stderr, "[cl_anchor_chain]   prep %.1f device %.1f index %.1f traceback %.1f ms, %llu pairs\n", tm.prep_ms, tm.device_ms, tm.index_ms, tm.traceback_ms, (unsigned long long)tm.n_pairs);
+        if (timing) fprintf(stderr, "[cl_anchor_chain]   prep %.1f device %.1f index %.1f traceback %.1f ms, %llu pairs, %u combinations\n", tm.prep_ms, tm.device_ms, tm.index_ms, tm.traceback_ms, (unsigned long long)tm.n_pairs, tm.n_combos);
+        out->dp_device_ms += tm.device_ms;
+        out->dp_pair_evals += tm.pair_evals;
+        if (!sparse) { out->dp_match_pairs = tm.n_pairs; out->dp_combinations = tm.n_combos; }
         out->n_ties += res[0].n_ties;
         const ChainSubResult& r = res[0];
         const size_t na = r.chain.size() / 3;

@@ -179,7 +179,7 @@ void cl_merge_params_default(cl_merge_params* p) {
 
 void cl_merge_result_free(cl_merge_result* r) {
     if (!r) return;
-    cl_alignment_free(&r->alignment);
+    cl_core_align_result_free(&r->align);
     cl_owned_base_graph_free(r->fused);
     memset(r, 0, sizeof(*r));
 }
@@ -211,17 +211,12 @@ int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, 
     cl_owned_match_sets_view(ms, &view);
     out->n_match_sets = view.n_sets;
     t0 = now();
-    cl_core_align_result ar;
-    rc = cl_core_align(ctx, &a, &b, &view, &prm->align, &ar);
+    rc = cl_core_align(ctx, &a, &b, &view, &prm->align, &out->align);
     cl_owned_match_sets_free(ms);
     if (rc) return rc;
     out->align_ms = ms_since(t0);
-    out->alignment = ar.alignment;
-    ar.alignment.pairs = nullptr;
-    ar.alignment.n_pairs = 0;
-    cl_core_align_result_free(&ar);
     t0 = now();
-    rc = cl_fuse(&a, &b, out->alignment.pairs, out->alignment.n_pairs, &out->fused);
+    rc = cl_fuse(&a, &b, out->align.alignment.pairs, out->align.alignment.n_pairs, &out->fused);
     out->fuse_ms = ms_since(t0);
     if (rc) { cl_set_error(ctx, "cl_fuse failed"); cl_merge_result_free(out); return rc; }
     return CL_OK;

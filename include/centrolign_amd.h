@@ -434,6 +434,11 @@ typedef struct cl_anchor_chain_result {
     uint64_t  n_ties;
     uint64_t  fill_in_pairs;     /* match pairs chained by the fill-in passes (both the scale estimate's and the final one) */
     float     fill_in_device_ms;
+    float     dp_device_ms;      /* device time of the two whole-graph DPs (sparse_chain_dp for the scale, sparse_affine_chain_dp) */
+    double    dp_pair_evals;     /* (predecessor record, query) evaluations an all-pairs sweep of those two DPs amounts to:
+                                    sum over chain combinations of records x match pairs / 2 */
+    uint64_t  dp_match_pairs;    /* match pairs of the affine DP */
+    uint32_t  dp_combinations;   /* (chain of graph 1, chain of graph 2) combinations that hold records in the affine DP */
 } cl_anchor_chain_result;
 
 int  cl_anchor_chain(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
@@ -464,6 +469,10 @@ typedef struct cl_core_align_result {
     double    scale;             /* estimated score scale of the chaining */
     uint64_t  n_chain_anchors;   /* anchors before partitioning */
     float     chain_ms, partition_ms, stitch_ms;   /* wall time of the three stages */
+    float     chain_device_ms;   /* cl_anchor_chain_result.dp_device_ms / dp_pair_evals / dp_match_pairs / dp_combinations */
+    double    chain_pair_evals;
+    uint64_t  chain_match_pairs;
+    uint32_t  chain_combinations;
 } cl_core_align_result;
 int  cl_core_align(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
               const cl_core_align_params* params, cl_core_align_result* out);
@@ -509,7 +518,7 @@ typedef struct cl_merge_params {
 } cl_merge_params;
 void cl_merge_params_default(cl_merge_params* p);
 typedef struct cl_merge_result {
-    cl_alignment         alignment;   /* next_problem.alignment */
+    cl_core_align_result align;       /* align.alignment = next_problem.alignment; the stitched anchor segments and stage times */
     cl_owned_base_graph* fused;       /* next_problem.graph (+ tableau ids) */
     uint64_t             n_match_sets;
     float                match_ms, align_ms, fuse_ms;
