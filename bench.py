@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — stitch-path throughput on MI355X (driver contract: see the task statement / DESIGN.md §Measurement).
+"""bench.py — the anchor-and-stitch hot path on MI355X, on BASELINE.json configs[2]: the progressive MSA of 10 synthetic 1 Mbp HOR
+arrays (seed 7) over the guide tree of SURVEY.md §8(d) (driver contract: see the task statement / DESIGN.md §Measurement).
 
-One "step" = one pass of the hot path (batched PO-POA fill + traceback of every between-anchor
-subproblem) over the stitch batch of BASELINE.json configs[1]: the pairwise 2 x 1 Mbp synthetic HOR
-centromere, seed 7 — exactly the 13 245 subproblems / 42 416 142 DP cells the reference extracts for that pair
-(tests/golden/c2_pair_seed7_intervals.npz holds the subproblem intervals dumped from the reference; the two
-sequences are regenerated from the seed).  Inputs are resident in HBM before the timed region starts.
+What runs:
+  1. the whole MSA once, natively through the C ABI (cl_leaf_graph, cl_leaf_intrinsic_scale, nine cl_merge calls = match finding +
+     Core::align + fuse), timed as `msa_wall_s`; its nine merges leave behind the nine stitch batches the reference's
+     Stitcher::stitch would have aligned (every between-anchor subproblem of every merge);
+  2. those batches are packed into nine resident stitch plans (inputs in HBM), and one "step" = one pass of the stitcher's
+     PO-POA DP (fill + traceback of every subproblem) over all nine.  W warm-up steps, then exactly K timed steps bracketed by
+     barrier + synchronize; `value` = DP cells of all steps / elapsed.
 
-N > 1: one process per GPU (torchrun), every rank stitches one such pairwise batch (independent sibling merges
-of a guide tree shard with no data-path exchange) => weak scaling, no collective in the timed region except
-the bracketing barriers.
+N > 1 (torchrun, one process per GPU): ONE MSA over the N ranks (centrolign_amd.msa.progressive_msa_distributed: leaf calibrations and
+sibling subtrees of the guide tree on different ranks, fused graphs travel between owners) => `"scaling": "strong"`.  The stitch
+batches stay on the rank that made them; a step is every rank's pass over its own batches, `value` = all ranks' cells / the slowest
+rank's time, `msa_wall_s` = the slowest rank's wall-clock of the distributed MSA.  No data-path collective in the timed steps.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,84 +29,99 @@ sys.path.insert(0, HERE)
 
 import numpy as np  # noqa: E402
 
-
-def build_workload():
-    from centrolign_amd import synth
-    z = np.load(os.path.join(HERE, "tests", "golden", "c2_pair_seed7_intervals.npz"))
-    seqs = synth.hor_sequences(7, 1000000, 2)
-    return synth.batch_from_intervals(seqs[0], seqs[1], z["intervals"], z["only_del"])
+WORKLOAD = "BASELINE configs[2]: 10 x 1 Mbp synthetic HOR arrays (seed 7), guide tree ((((s0,s1),(s2,s3)),s4),(((s5,s6),(s7,s8)),s9)), " \
+           "full progressive MSA; step = stitcher PO-POA DP over the stitch batches of all nine merges"
+VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9   # int32 VALU lane-operations per second (256 CUs x 128 lanes x 2.4 GHz), MI355X_MICROARCH.md
+EVAL_VALU_OPS = 19                       # VALU operations of one (record, query) evaluation of the all-pairs sweep (chain_kernels.hip)
 
 
-def cpu_baseline(batch, min_seconds=10.0, max_reps=12):
-    """single-thread CPU time of the same stitch batch: the compiled reference when oracle/_ref travelled
-    with the repo ("reference"), else our C restatement ("port")"""
+def relabelled(g, src_label, snk_label):
+    """reassign_sentinels (core.hpp:287-288) on a copy: what cl_merge does to its inputs before anything else"""
+    from centrolign_amd import capi
+    lab = g.label.copy()
+    lab[g.src_id], lab[g.snk_id] = src_label, snk_label
+    return capi.BaseGraph(lab, g.next_off, g.next_idx, g.prev_off, g.prev_idx, g.path_off, g.path_nodes, g.src_id, g.snk_id)
+
+
+def stitch_batches(kept):
+    """the stitch batch of every kept merge: Extractor::extract_graphs_between on the anchor segments the merge stitched"""
+    from centrolign_amd import capi
+    out = []
+    for m in kept:
+        g1, g2 = relabelled(m["graphs"][0], 5, 6), relabelled(m["graphs"][1], 7, 8)
+        al = m["align"]
+        seg = capi.AnchorSegments(al["seg_off"], al["walk_off"], al["walk1"], al["walk2"])
+        out.append((m["merge"], capi.extract_stitch_batch(g1, g2, seg)))
+    return out
+
+
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "cpu_cores": os.cpu_count()}
+
+
+def cpu_baseline(batches, min_seconds=8.0, max_reps=6):
+    """single-thread CPU time of the same DP: the compiled reference's Stitcher::subalign where oracle/_ref travelled with the repo
+    ("reference"), else our C restatement ("port"), on a bounded sample: the first leaf merge's batch and the first graph x graph
+    (multi-path) merge's batch"""
     from oracle import pyoracle as po
-    cells = batch.dp_cells()
     kind = "reference" if po.have_ref() else "port"
-    total, reps = 0.0, 0
+    sample = [batches[0]]
+    multi = [b for b in batches if "((" in b[0] or b[0].count(",") > 1]
+    if multi:
+        sample.append(multi[0])
+    cells = total = 0.0
+    reps = 0
     while total < min_seconds and reps < max_reps:
-        if kind == "reference":
-            _, secs = po.ref_stitch_batch(batch)
-        else:
-            t0 = time.perf_counter()
-            po.oracle_stitch_batch(batch)
-            secs = time.perf_counter() - t0
-        total += secs
+        for _, b in sample:
+            if kind == "reference":
+                _, secs = po.ref_stitch_batch(b)
+            else:
+                t0 = time.perf_counter()
+                po.oracle_stitch_batch(b)
+                secs = time.perf_counter() - t0
+            total += secs
+            cells += b.dp_cells()
         reps += 1
-    return {"value": cells * reps / total, "unit": "DP cells/s", "cores": 1, "kind": kind,
-            "sample": "the whole 2x1Mbp stitch batch (13245 subproblems, %d cells) x %d passes, %.1f s of CPU, "
-                      "time inside Stitcher::subalign only" % (cells, reps, total)}
+    out = {"value": cells / total, "unit": "DP cells/s", "cores": 1, "kind": kind,
+           "sample": "stitch batches of merges %s (%d subproblems, %d cells) x %d passes, %.1f s of CPU inside Stitcher::subalign; "
+                     "the other merges' batches are the same kind of work" %
+                     (" and ".join(m for m, _ in sample), sum(b.n_problems for _, b in sample), sum(b.dp_cells() for _, b in sample), reps, total)}
+    out.update(host_info())
+    if kind != "reference":
+        out["skipped"] = "oracle/_ref (the compiled reference) is not on this box: the C restatement of the path was timed instead"
+    return out
 
 
-def saturated_section(ctx, batch, copies=16, steps=10):
-    """kernel throughput when the device is filled: the same batch replicated `copies` times in one plan (what a
-    guide tree with that many sibling merges in flight on one GPU would submit).  Reported beside the single-batch
-    pass, whose duration is set by the sweep of its few largest matrices rather than by throughput."""
-    from centrolign_amd import capi
-    big = capi.StitchBatch.concat([batch] * copies)
-    plan = ctx.plan(big)
-    st = plan.stats()
-    for _ in range(2):
-        plan.execute()
-        plan.sync()
-    ms = 0.0
-    for _ in range(steps):
-        plan.execute()
-        ms += plan.sync()
-    ms /= steps
-    plan.destroy()
-    return {"copies": copies, "subproblems": st["n_problems"], "dp_cells": st["dp_cells"], "device_ms_per_pass": ms,
-            "cells_per_s": st["dp_cells"] / (ms * 1e-3), "algorithmic_GBps": st["dp_bytes"] / (ms * 1e-3) / 1e9,
-            "frac_of_hbm_peak": st["dp_bytes"] / (ms * 1e-3) / 1e9 / 8000.0}
-
-
-def pipelined_section(batch, local_rank, depth=6, steps=48):
-    """the same pass with `depth` independent passes in flight (one context + plan each, as the sibling merges of a guide
-    tree provide them): fills the CUs that idle while the longest subproblem of a single batch finishes its sweep"""
-    from centrolign_amd import capi
-    ctxs = [capi.Context(local_rank) for _ in range(depth)]
-    plans = [c.plan(batch) for c in ctxs]
-    cells = plans[0].stats()["dp_cells"]
-    for p in plans:
-        p.execute(); p.sync()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        plans[k % depth].execute()
-    for p in plans:
-        p.sync()
-    dt = time.perf_counter() - t0
-    for p in plans:
-        p.destroy()
-    for c in ctxs:
-        c.close()
-    return {"passes_in_flight": depth, "steps": steps, "ms_per_step": dt / steps * 1e3, "cells_per_s": cells * steps / dt}
+def reference_leaf_merge(seqs, names):
+    """the reference's whole pipeline (Core::execute + explicit_cigar) on the first leaf pair of the guide tree, wall-clock: the one
+    piece of configs[2] the single-threaded reference finishes within the bench's time budget"""
+    import tempfile
+    from centrolign_amd import synth
+    from oracle import pyoracle as po
+    if not po.have_ref():
+        return {"skipped": "oracle/_ref is not on this box"}
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "in.fa")
+        synth.write_fasta(fa, [seqs[n] for n in names[:2]], names[:2])
+        t0 = time.perf_counter()
+        tm = po.ref_msa_dump(fa, out_path=os.path.join(d, "o.txt"))
+        secs = time.perf_counter() - t0
+    return {"merge": "(%s,%s) incl. the two leaf calibrations" % (names[0], names[1]), "seconds": secs, "cores": 1, "kind": "reference", "phases_s": tm}
 
 
 def chaining_section(ctx, with_reference):
-    """second half of the hot path, at its seam S3: Anchorer::anchor_chain in the CLI's default configuration (branch
-    splitting, scale estimate by sparse_chain_dp, sparse_affine_chain_dp, fill-in re-anchoring, global anchoring) on the
-    match sets of the same 2 x 1 Mbp pair (bench_data/c2_chain_input.npz: the reference's graphs and match sets; built by
-    scripts/chain_bench.py's recipe in the build container, shipped with the repo snapshot, not committed)"""
+    """seam S3 at BASELINE configs[1] scale: Anchorer::anchor_chain in the CLI's default configuration on the match sets of the
+    2 x 1 Mbp pair (bench_data/c2_chain_input.npz where it travelled with the repo, else made in place), the inner affine DP alone,
+    the whole Core::align, and — with oracle/_ref — the compiled reference on the same input with a field-by-field comparison"""
     from centrolign_amd import capi, synth
     path = os.path.join(HERE, "bench_data", "c2_chain_input.npz")
     if os.path.exists(path):
@@ -114,39 +134,31 @@ def chaining_section(ctx, with_reference):
         score_scale = float(z["score_scale"][0])
         source = "bench_data/c2_chain_input.npz (graphs, match sets and calibrated scale dumped from the reference's run)"
     else:
-        # no fixture on this box: the same inputs made here — the pair's leaf graphs, its match sets by cl_find_matches (identical
-        # to the reference's, see match_finding) and the calibrated scale by cl_leaf_intrinsic_scale
         seqs = synth.hor_sequences(7, 1000000, 2)
         graphs = [synth.base_graph_from_sequence(seqs[0]), synth.base_graph_from_sequence(seqs[1], sentinels=(7, 8))]
         ms = ctx.find_matches(graphs[0], graphs[1])
         scales = [ctx.leaf_intrinsic_scale(g) for g in graphs]
         score_scale = sum(scales) / len(scales)
-        source = "made in place: cl_find_matches + cl_leaf_intrinsic_scale on the synthetic pair"
+        source = "made in place (bench_data/ did not travel): cl_find_matches + cl_leaf_intrinsic_scale on the synthetic pair"
 
     def run():
         t0 = time.perf_counter()
         split = capi.split_branching_matches(graphs[0], graphs[1], ms)
         got = ctx.anchor_chain(graphs[0], graphs[1], split, score_scale=score_scale)
         return got, time.perf_counter() - t0
-    run()  # warm-up
+    run()
     got, wall = run()
     n = ms.n_pairs()
-    out = {"seam": "Anchorer::anchor_chain (default configuration)", "input": source, "match_sets": ms.n_sets, "match_pairs": n,
-           "chain_anchors": int(len(got["chain"])), "estimated_scale": got["scale"], "tie_resolutions": got["n_ties"],
-           "fill_in_pairs": got["fill_in_pairs"], "max_num_match_pairs": 1250000, "wall_s": wall,
-           "match_pairs_per_s": min(n, 1250000) / wall}
-    # the inner DP alone (sparse_affine_chain_dp on every pair), with its device / host split
-    if n <= 1300000:   # the fixture is already cut to the CLI's budget of 1.25 M pairs; the unbudgeted sets are several times that
+    out = {"seam": "Anchorer::anchor_chain (default configuration), 2 x 1 Mbp pair", "input": source, "match_sets": ms.n_sets, "match_pairs": n,
+           "chain_anchors": int(len(got["chain"])), "estimated_scale": got["scale"], "tie_resolutions": got["n_ties"], "wall_s": wall}
+    if n <= 1300000:
         dp = ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=got["scale"])
         out["affine_dp_only"] = {"match_pairs": dp["n_pairs"], "device_dp_ms": dp["device_ms"], "host_prep_ms": dp["prep_ms"],
-                                 "value_index_ms": dp["index_ms"], "traceback_ms": dp["traceback_ms"],
-                                 "pair_evaluations_per_s_device": dp["n_pairs"] ** 2 / 2 / (dp["device_ms"] * 1e-3)}
-    # the whole merge: Core::align = anchor chain + partition + despecify + stitch (cl_core_align), same input
+                                 "value_index_ms": dp["index_ms"], "traceback_ms": dp["traceback_ms"]}
     t0 = time.perf_counter()
     al = ctx.core_align(graphs[0], graphs[1], ms, score_scale=score_scale)
     out["core_align"] = {"wall_s": time.perf_counter() - t0, "chain_ms": al["chain_ms"], "partition_ms": al["partition_ms"],
-                         "stitch_ms": al["stitch_ms"], "segments": int(len(al["seg_off"]) - 1), "anchors": int(len(al["walk_off"]) - 1),
-                         "aligned_pairs": int(len(al["alignment"]))}
+                         "stitch_ms": al["stitch_ms"], "aligned_pairs": int(len(al["alignment"]))}
     if with_reference:
         from oracle import pyoracle as po
         if po.have_ref():
@@ -156,57 +168,25 @@ def chaining_section(ctx, with_reference):
             secs = time.perf_counter() - t0
             same = all(np.array_equal(ref[k], got[k]) for k in ("set_order", "chain", "walk1", "walk2", "gap_before", "gap_after",
                                                                  "gap_score_before", "gap_score_after", "score"))
-            out["cpu_reference"] = {"seconds": secs, "match_pairs_per_s": min(n, 1250000) / secs, "cores": 1, "kind": "reference",
-                                    "identical_result": bool(same and ref["scale"] == got["scale"])}
+            out["cpu_reference"] = {"seconds": secs, "cores": 1, "kind": "reference", "identical_result": bool(same and ref["scale"] == got["scale"])}
+        else:
+            out["cpu_reference"] = {"skipped": "oracle/_ref is not on this box"}
     return out
 
 
-def match_section(ctx, with_reference):
-    """the row before the hot path: PathMatchFinder::find_matches on the same 2 x 1 Mbp pair — suffix
-    array + LCP on the device, the minimal-rare-match query on the host — checked against the digest of the compiled
-    reference's output (tests/golden/match_finder.npz "c2.*") and timed beside the reference where oracle/_ref exists"""
-    from centrolign_amd import capi, synth
-    from tests import helpers as H
-    seqs = synth.hor_sequences(7, 1000000, 2)
-    g1 = synth.base_graph_from_sequence(seqs[0])
-    g2 = synth.base_graph_from_sequence(seqs[1], sentinels=(7, 8))
-    ctx.find_matches(g1, g2)   # warm-up
-    t0 = time.perf_counter()
-    ms, st = ctx.find_matches(g1, g2, want_stats=True)
-    wall = time.perf_counter() - t0
-    z = np.load(os.path.join(H.GOLDEN, "match_finder.npz"))
-    out = {"seam": "PathMatchFinder::find_matches", "text_length": st["text_length"], "match_sets": ms.n_sets, "wall_s": wall,
-           "device_suffix_array_ms": st["sa_ms"], "device_lcp_ms": st["lcp_ms"], "doubling_rounds": st["doubling_rounds"],
-           "host_tree_ms": st["tree_ms"], "host_query_ms": st["query_ms"], "host_walk_out_ms": st["walk_ms"],
-           "lcp_intervals": st["n_internal_nodes"],
-           "identical_to_reference_digest": bool(ms.n_sets == int(z["c2.n_sets"][0]) and H.match_sets_digest(ms) == str(z["c2.digest"][0]))}
-    if with_reference:
-        from oracle import pyoracle as po
-        if po.have_ref():
-            t0 = time.perf_counter()
-            po.ref_find_matches(g1, g2, max_count=3000)
-            out["cpu_reference"] = {"seconds": time.perf_counter() - t0, "cores": 1, "kind": "reference",
-                                    "note": "includes flattening the reference's vectors into numpy"}
-    return out
-
-
-def end_to_end_section(ctx, with_reference):
-    """BASELINE configs[1] as the CLI runs it, without the reference in the loop: FASTA-level sequences -> leaf graphs ->
-    calibration -> match finding -> Core::align -> fuse -> explicit CIGAR (centrolign_amd/msa.py over the C ABI), wall-clock;
-    beside it the compiled reference's whole pipeline on the same sequences (ref_msa_dump = Core::execute + explicit_cigar) and a
-    byte comparison of the two outputs"""
-    import hashlib
+def pairwise_section(ctx, with_reference):
+    """BASELINE configs[1] end to end without the reference in the loop: sequences -> leaf graphs -> calibration -> match finding ->
+    Core::align -> fuse -> explicit CIGAR, wall-clock; beside it the compiled reference's whole pipeline and a byte comparison"""
     import tempfile
     from centrolign_amd import msa, synth
     seqs = synth.hor_sequences(7, 1000000, 2)
     names = ["seq0", "seq1"]
     t0 = time.perf_counter()
-    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), msa.balanced_tree(names), workers=2)   # the two leaf calibrations side by side
+    r = msa.progressive_msa(ctx, dict(zip(names, seqs)), msa.balanced_tree(names), workers=2)
     text = msa.output_text(r)
     wall = time.perf_counter() - t0
-    out = {"pipeline": "leaf graphs + calibration (2 worker contexts) + find_matches + Core::align + fuse + explicit_cigar", "wall_s": wall,
-           "score_scale": r["scale"], "match_ms": r["stats"]["match_ms"], "align_ms": r["stats"]["align_ms"], "fuse_ms": r["stats"]["fuse_ms"],
-           "cigar_bytes": len(text), "cigar_sha256": hashlib.sha256(text).hexdigest()}
+    out = {"pipeline": "BASELINE configs[1] (2 x 1 Mbp): leaf graphs + calibration + find_matches + Core::align + fuse + explicit_cigar", "wall_s": wall,
+           "match_ms": r["stats"]["match_ms"], "align_ms": r["stats"]["align_ms"], "cigar_bytes": len(text), "cigar_sha256": hashlib.sha256(text).hexdigest()}
     if with_reference:
         from oracle import pyoracle as po
         if po.have_ref():
@@ -217,110 +197,175 @@ def end_to_end_section(ctx, with_reference):
                 tm = po.ref_msa_dump(fa, out_path=o)
                 secs = time.perf_counter() - t0
                 want = open(o, "rb").read().rstrip(b"\n")
-            out["cpu_reference"] = {"seconds": secs, "cores": 1, "kind": "reference", "phases_s": tm, "identical_output": bool(want == text)}
+            out["cpu_reference"] = {"seconds": secs, "cores": 1, "kind": "reference", "phases_s": tm, "identical_output": bool(want == text),
+                                    "speedup": secs / wall}
+        else:
+            out["cpu_reference"] = {"skipped": "oracle/_ref is not on this box"}
     return out
 
 
 def main():
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: independent passes overlap on separate queues
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: independent launches overlap on separate queues
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workers", type=int, default=4, help="worker contexts of the single-GPU MSA (sibling merges side by side)")
+    ap.add_argument("--length", type=int, default=1000000, help="sequence length (the headline is 1 000 000; smaller only for dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="only the timed passes (no saturated / pipelined / chaining sections): the command the rocprofv3 "
-                         "summaries under profiles/ are taken with, so that their per-kernel averages are those of the timed passes")
+                    help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
     args = ap.parse_args()
 
     import torch
     from centrolign_amd import dist as cd
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    rank, world, dist = cd.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    share = world_env > 1 and n_dev < world_env          # dry run of the multi-rank path on fewer devices: ranks share them, gloo collectives
+    rank, world, dist = cd.init_distributed(None if world_env == 1 else ("gloo" if share else "nccl"))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    device = local_rank % max(1, n_dev)
+    torch.cuda.set_device(device)
 
-    from centrolign_amd import capi
-    ctx = capi.Context(local_rank)          # raises without a GPU / without the HIP library: no fallback
-    batch = build_workload()
-    plan = ctx.plan(batch)
-    stats = plan.stats()
+    from centrolign_amd import capi, msa, synth
+    ctx = capi.Context(device)          # raises without a GPU / without the HIP library: no fallback
+    names, seqs, tree = synth.c3_workload(args.length)
+    ctx.find_matches(capi.leaf_graph("ACGTACGTAC"), capi.leaf_graph("ACGTTCGTAC"))   # first-use initialisation outside the timed regions
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- 1. the MSA ------------------------------------------------------------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    if world == 1:
+        res = msa.progressive_msa(ctx, seqs, tree, workers=args.workers, keep_merges=True)
+        host_group = None
+    else:
+        host_group = dist.new_group(backend="gloo") if not share else None
+        res = msa.progressive_msa_distributed(ctx, seqs, tree, dist, rank, world, group=host_group, keep_merges=True, all_ranks=True)
+    msa_wall = time.perf_counter() - t0
+    msa_wall = cd.max_over_ranks(msa_wall, dist, device="cpu" if share else "cuda")
+    kept = res["stats"].get("kept", []) if res is not None and "stats" in res else []
+    gfa_sha = gfa_bytes = None
+    if rank == 0:
+        gfa = capi.write_gfa(res["root"], res["paths"])
+        gfa_sha, gfa_bytes = hashlib.sha256(gfa).hexdigest(), len(gfa)
+
+    # ---- 2. the stitch batches of this rank's merges, resident in HBM ----------------------------------------------------------
+    batches = stitch_batches(kept)
+    # one context (= one HIP stream set) per batch: the nine merges are independent, their passes run side by side on the device
+    # exactly as the worker contexts of the MSA above run sibling merges side by side
+    plan_ctx = [capi.Context(device) for _ in batches]
+    plans = [(m, c.plan(b)) for (m, b), c in zip(batches, plan_ctx)]
+    stats = [p.stats() for _, p in plans]
+    my_cells = sum(st["dp_cells"] for st in stats)
+
+    def one_pass():
+        for _, p in plans:
+            p.execute()           # replays the captured hipGraph of the plan's kernel launches on its context's stream
+        return max([p.sync() for _, p in plans] or [0.0])   # HIP events around each plan's pass; the passes overlap
+
     for _ in range(args.warmup):
-        plan.execute()
-        plan.sync()
+        one_pass()
     barrier()
     t0 = time.perf_counter()
     dev_ms = 0.0
     for _ in range(args.steps):
-        plan.execute()            # replays the captured hipGraph of all kernel launches of the pass
-        dev_ms += plan.sync()     # HIP events around the pass on the context's stream
+        dev_ms += one_pass()
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel durations: the same pass launched kernel by kernel with HIP events on each launch's stream
-    launch_ms = {}
-    prof_steps = max(5, min(20, args.steps))
-    for _ in range(prof_steps):
-        plan.execute_profiled()
-        plan.sync()
-        for li in plan.launches():
-            e = launch_ms.setdefault(li["kernel"], dict(li, ms=0.0))
-            e["ms"] += li["ms"]
-    elapsed = cd.max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = cd.max_over_ranks(elapsed, dist, device="cpu" if share else "cuda")
+    total_cells = my_cells
+    if dist is not None:
+        t = torch.tensor([float(my_cells)], dtype=torch.float64, device="cpu" if share else "cuda")
+        dist.all_reduce(t)
+        total_cells = int(t.item())
+
+    # per-kernel durations: the same passes launched kernel by kernel with HIP events on each launch's stream
+    launches = []
+    prof_steps = max(3, min(10, args.steps))
+    for (m, p), st in zip(plans, stats):
+        acc = {}
+        for _ in range(prof_steps):
+            p.execute_profiled()
+            p.sync()
+            for li in p.launches():
+                e = acc.setdefault(li["kernel"], dict(li, ms=0.0, merge=m))
+                e["ms"] += li["ms"]
+        for e in acc.values():
+            e["ms"] /= prof_steps
+            launches.append(e)
 
     if rank == 0:
-        cells = stats["dp_cells"]
-        value = cells * args.steps * world / elapsed
-        for e in launch_ms.values():
-            e["ms"] /= prof_steps
-        dom = max(launch_ms.values(), key=lambda e: e["ms"])
-        peak = 8000.0
-        achieved = dom["dp_bytes"] / (dom["ms"] * 1e-3) / 1e9
-        traffic = None
+        value = total_cells * args.steps / elapsed
+        dom = max(launches, key=lambda e: e["ms"]) if launches else None
+        traffic = limiter = None
         tp = os.path.join(HERE, "profiles", "hbm_traffic_latest.json")
-        if os.path.exists(tp):
+        if dom is not None and os.path.exists(tp):
             try:
                 with open(tp) as f:
-                    traffic = json.load(f).get(dom["kernel"])
+                    tj = json.load(f)
+                traffic = tj.get(dom["kernel"])
+                limiter = tj.get("_limiter", {}).get(dom["kernel"])
             except Exception:
                 traffic = None
+        per_merge = res["stats"].get("per_merge", [])
+        chain_ms = sum(m["chain_device_ms"] for m in per_merge)
+        chain_evals = sum(m["chain_pair_evals"] for m in per_merge)
         out = {
-            "metric": "stitcher PO-POA DP cells/s (2x1Mbp synthetic HOR pair, all between-anchor subproblems, fill + traceback)",
+            "metric": "stitcher PO-POA DP cells/s (10 x 1 Mbp synthetic HOR MSA, every between-anchor subproblem of all nine merges, fill + traceback)",
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: pairwise 1 Mbp x 1 Mbp synthetic centromere (seed 7), "
-                                   "stitch batch = %d subproblems / %d DP cells per GPU" % (stats["n_problems"], cells),
-                       "subproblems": stats["n_problems"], "dp_cells": cells, "chain_problems": stats["n_linear"],
-                       "parallelism": "1 stitch batch per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": dom["kernel"], "kernel_ms": dom["ms"],
-                         "kernel_cells": dom["dp_cells"], "kernel_problems": dom["n_problems"],
-                         "note": "achieved = sizeof(cell_t<NumPW>) x cells of this launch / its HIP-event duration; "
-                                 "scores stay in registers and only 1-2 B/cell traceback codes reach HBM, so traffic << algorithmic bytes"},
-            "device_ms_per_step": dev_ms / args.steps,
-            "whole_pass": {"algorithmic_GBps": stats["dp_bytes"] / (dev_ms / args.steps * 1e-3) / 1e9,
-                           "cells_per_s_device": cells / (dev_ms / args.steps * 1e-3)},
-            "launches": sorted(launch_ms.values(), key=lambda e: -e["ms"]),
+            "config": {"workload": WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
+                       "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
+                       "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
+                       "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
+                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank), stitch batches on the rank that made them, no data-path collective" % world},
+            "msa_wall_s": msa_wall,
+            "msa": {"pipeline": "leaf graphs + 10 calibrations + 9 x (find_matches + Core::align + fuse) + write_gfa, no reference in the loop",
+                    "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "score_scale": res["scale"],
+                    "match_s": res["stats"]["match_ms"] / 1e3, "align_s_summed_over_contexts": res["stats"]["align_ms"] / 1e3,
+                    "per_merge": [{k: m[k] for k in ("merge", "paths1", "paths2", "match_sets", "chain_match_pairs", "chain_combinations", "match_ms",
+                                                     "align_ms", "chain_ms", "chain_device_ms", "partition_ms", "stitch_ms", "fuse_ms")} for m in per_merge]},
+            "device_ms_per_step_longest_plan": dev_ms / args.steps,
+            "launches": sorted(launches, key=lambda e: -e["ms"])[:12],
         }
+        if dom is not None:
+            achieved = dom["dp_bytes"] / (dom["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                               "kernel": dom["kernel"], "merge": dom["merge"], "kernel_ms": dom["ms"], "kernel_cells": dom["dp_cells"],
+                               "kernel_problems": dom["n_problems"],
+                               "hbm_measured_GBps": None if not traffic else traffic / (dom["ms"] * 1e-3) / 1e9,
+                               "limiter": limiter or "dependent anti-diagonal chain of the largest matrix (VALU issue latency), not HBM",
+                               "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells of the launch, SURVEY.md §8d) / its HIP-event duration; "
+                                       "`traffic` / `hbm_measured_GBps` = PMC bytes per launch (profiles/): scores stay in registers or LDS, so the "
+                                       "measured traffic is far below the algorithmic figure and the HBM roofline is not what limits this kernel"}
+        if chain_ms > 0:
+            evals_per_s = chain_evals / (chain_ms * 1e-3)
+            out["roofline_chain"] = {"bound": "valu", "unit": "pair evaluations/s", "achieved": evals_per_s, "peak": VALU_PEAK_LANE_OPS / EVAL_VALU_OPS,
+                                     "frac": evals_per_s / (VALU_PEAK_LANE_OPS / EVAL_VALU_OPS), "device_ms": chain_ms, "pair_evaluations": chain_evals,
+                                     "kernels": "chain_walk_kernel + far_prune_kernel + chain_inter_kernel (both whole-graph DPs of all nine merges)",
+                                     "note": "pair evaluations = what an all-pairs sweep of the same DPs evaluates (sum over chain combinations of records x "
+                                             "match pairs / 2); the branch-and-bound far pass proves most of them unnecessary, so `achieved` is the "
+                                             "all-pairs-equivalent rate and may exceed the VALU peak of a sweep that really evaluates them"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch)
+            out["cpu_baseline"] = cpu_baseline(batches)
+            out["cpu_reference_wall"] = reference_leaf_merge(seqs, names)
         if world == 1 and not args.no_extras:
-            out["saturated"] = saturated_section(ctx, batch)
-            out["pipelined"] = pipelined_section(batch, local_rank)
-            ch = chaining_section(ctx, not args.no_cpu_baseline)
-            if ch is not None:
-                out["chaining"] = ch
-            out["match_finding"] = match_section(ctx, not args.no_cpu_baseline)
-            out["end_to_end"] = end_to_end_section(ctx, not args.no_cpu_baseline)
+            out["chaining_c2"] = chaining_section(ctx, not args.no_cpu_baseline)
+            out["pairwise_c2"] = pairwise_section(ctx, not args.no_cpu_baseline)
         print(json.dumps(out))
     barrier()
-    plan.destroy()
+    for _, p in plans:
+        p.destroy()
+    for c in plan_ctx:
+        c.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -64,6 +64,7 @@ struct ClChainDevice {
                                 // shift, 7 encoded stored values (written by the walk), 2 pad words; combination c starts at far_base[c]
     const uint32_t* far_base;
     uint32_t lo_mask;           // the first source record of an inter launch is rounded down to a multiple of lo_mask + 1
+    // status[2..3], status[4..5]: 64-bit counts of leaves the branch-and-bound far pass scanned / had in range
 };
 
 // ---- branch-and-bound far pass ---------------------------------------------------------------------------------------

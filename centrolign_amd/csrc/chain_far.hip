@@ -313,6 +313,7 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     Q.bq = qb < 0 ? 0xFFFF0000u : (uint32_t)(qb >> kFarBandShift);
     const uint32_t top = F.n_levels - 1;
 
+    uint32_t n_scanned = 0;
     // ---- probe: follow the largest bound down to one leaf.  A query whose best predecessor lies far back (a pair on a distant
     //      diagonal chains from wherever the main chain passed its graph-2 position) would otherwise open every node between
     //      itself and that place before it knows what it is looking for.
@@ -337,8 +338,10 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
             pcode = (lvl << 28) | (a >> kFarLeafShift);
             group_argmax(pb, pcode);
         }
-        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL && sub == 0)
+        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL && sub == 0) {
             best = scan_leaf<SPARSE>(rec, base + ((pcode & 0x0FFFFFFFu) << kFarLeafShift), Q, acc, best, pen);
+            ++n_scanned;
+        }
         best = fmaxf(best, __shfl_xor(best, 1));
         best = fmaxf(best, __shfl_xor(best, 2));
         best = fmaxf(best, __shfl_xor(best, 4));
@@ -364,7 +367,7 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         }
         bool hit = false;
         if (lvl != 0xFFu) hit = node_bound<SPARSE>(F, lvl, base + a, Q) >= (double)best;
-        if (hit && lvl == 0) best = scan_leaf<SPARSE>(rec, base + a, Q, acc, best, pen);
+        if (hit && lvl == 0) { best = scan_leaf<SPARSE>(rec, base + a, Q, acc, best, pen); ++n_scanned; }
         // surviving inner nodes go on the stack, nearest (lane 0) on top
         const bool push = hit && lvl != 0 && lvl != 0xFFu;
         const unsigned long long bal = __ballot(push);
@@ -378,6 +381,18 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         best = fmaxf(best, __shfl_xor(best, 1));
         best = fmaxf(best, __shfl_xor(best, 2));
         best = fmaxf(best, __shfl_xor(best, 4));
+    }
+    // bookkeeping for the host's choice between this pass and the all-pairs sweep (cl_chain_api.cpp): leaves this query scanned
+    // against the leaves it had in range.  A scanned leaf costs a lane about what sixteen leaves cost the sweep (divergent loads
+    // instead of LDS broadcasts, plus the tests that led to it).
+    n_scanned += __shfl_xor(n_scanned, 1);
+    n_scanned += __shfl_xor(n_scanned, 2);
+    n_scanned += __shfl_xor(n_scanned, 4);
+    if (sub == 0) {
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(D.status + 2);
+        // only queries with a long history say anything about the trend (early ones open their few leaves whatever happens)
+        const unsigned long long add_sc = E >= (1u << 16) ? n_scanned : 0u, add_in = E >= (1u << 16) ? (E >> kFarLeafShift) : 0u;
+        if (add_in) { atomicAdd(cnt, add_sc); atomicAdd(cnt + 1, add_in); }
     }
     // merge the eight lanes' maxima and hand them to the walk
     constexpr int NK = SPARSE ? 1 : 7;

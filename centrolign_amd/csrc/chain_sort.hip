@@ -10,7 +10,8 @@ namespace {
 __global__ void chain_keys_kernel(const float* __restrict__ val, uint32_t n, int* __restrict__ keys, uint32_t* __restrict__ idx) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    const int b = __float_as_int(val[r]);
+    int b = __float_as_int(val[r]);
+    if (b == (int)0x80000000) b = 0;   // -0.0f == +0.0f, as in the DP kernels' encoding
     keys[r] = b >= 0 ? b : b ^ 0x7FFFFFFF;
     idx[r] = r;
 }

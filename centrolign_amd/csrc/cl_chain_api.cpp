@@ -736,9 +736,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             }
             CH(d_group_end.upload(ctx, group_end));
             CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
-            CH(d_status.alloc(ctx, 4));
+            CH(d_status.alloc(ctx, 8));
             if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
-                hipMemsetAsync(d_status.p, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+                hipMemsetAsync(d_status.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
         }
         // LDS slots of the sequential kernel: records of a (block, group) are laid out in pair order
         std::vector<uint32_t> grp_base(M), grp_total(M);
@@ -916,16 +916,39 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             if (he == hipSuccess) he = hipStreamWaitEvent(seal_stream, ctx->ev_fork, 0);
             for (uint32_t f = far_streams; f < kFarLag && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
         }
+        // Branch-and-bound or sweep?  The far kernels count the leaves they had to open against the leaves in range (status[2..5]).
+        // At a few checkpoints the host waits for the launches so far and reads the counts: once they cover enough queries with a
+        // long history, more than one leaf in sixteen opened means the sweep is the faster far pass for this input (repeats so
+        // dense that every pair is near every other) and it takes over for the rest of the DP.  One decision per DP, taken between
+        // launches: nothing is in flight when the mode changes.
+        bool far_bb = use_far, far_decided = !use_far;
+        static const char* far_mode_env = getenv("CL_CHAIN_FAR_MODE");   // A/B switch: "sweep" / "bb" pin the mode
+        if (use_far && far_mode_env) { far_decided = true; far_bb = far_mode_env[0] != 's'; }
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
+            if (!far_decided && k >= 96 && (k & (k - 1)) == 0) {   // k = 128, 256, 512, ...
+                he = hipStreamSynchronize(ctx->stream);
+                for (uint32_t f = 0; f < kFarLag && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
+                unsigned long long cnt[2] = {0, 0};
+                if (he == hipSuccess) he = cl_copy_sync(ctx, cnt, d_status.p + 2, sizeof(cnt), hipMemcpyDeviceToHost);
+                if (he == hipSuccess && cnt[1] >= (1ull << 22)) {
+                    far_decided = true;
+                    far_bb = cnt[0] * 16 <= cnt[1];
+                    if (timing) fprintf(stderr, "[chain_dp_batch]   far pass after %u macro-blocks: %llu of %llu leaves opened -> %s\n", k, cnt[0], cnt[1], far_bb ? "branch-and-bound" : "all-pairs sweep");
+                }
+            }
             const uint32_t first = k * kChainMacro, count = (uint32_t)std::min<uint64_t>(kChainMacro, M - first);
             const uint32_t lag = use_far ? kFarLag : 1u;
             const uint32_t b0 = k * bpm, near_lo = k >= lag ? (k - lag) * bpm : 0;
             if (near_lo > 0) {
                 hipStream_t far_stream = ctx->aux[k % (use_far ? kFarLag : far_streams)];
-                if (use_far) {
+                if (use_far && far_bb) {
                     // every node inside the records [0, prefix[near_lo]) was sealed by seal(k - lag - 1) or earlier
                     he = hipStreamWaitEvent(far_stream, ev_seal[k - lag - 1], 0);
                     if (he == hipSuccess) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream);
+                } else if (use_far) {
+                    // the all-pairs sweep has taken over (see the checkpoints below); same lag, so that sweeps run side by side
+                    he = hipStreamWaitEvent(far_stream, ev_walk[k - lag - 1], 0);
+                    if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, max_recs(0, near_lo), kChainFarTile, far_stream);
                 } else {
                     he = hipStreamWaitEvent(far_stream, ev_walk[k - 2], 0);
                     const uint32_t recs = max_recs(0, near_lo);
@@ -949,7 +972,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_walk[k], hipEventDisableTiming);
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
-            if (use_far && he == hipSuccess && k + kFarLag + 1 < n_macro) {
+            if (use_far && far_bb && he == hipSuccess && k + kFarLag + 1 < n_macro) {
                 he = hipStreamWaitEvent(seal_stream, ev_walk[k], 0);
                 if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_stream);
                 if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_seal[k], hipEventDisableTiming);

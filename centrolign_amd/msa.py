@@ -21,7 +21,8 @@ def leaves_of(tree):
     return [tree] if isinstance(tree, str) else leaves_of(tree[0]) + leaves_of(tree[1])
 
 
-def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None, verbose=False):
+def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None, verbose=False,
+                    keep_merges=False):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
@@ -76,9 +77,14 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
                 for k in ("match_ms", "align_ms", "fuse_ms"):
                     stats[k] += r[k]
                 stats["merges"] += 1
+                al = r.get("align") or {}
+                if keep_merges:   # what the bench replays: the merge's two graphs and the anchor segments that were stitched
+                    stats.setdefault("kept", []).append(dict(merge=newick(t), graphs=(g1, g2), align=al, fused=r["fused"], paths=paths))
                 stats.setdefault("per_merge", []).append(dict(merge=newick(t), paths1=len(done[newick(t[0])][1]), paths2=len(done[newick(t[1])][1]),
                                                               match_sets=r["n_match_sets"], match_ms=r["match_ms"], align_ms=r["align_ms"],
-                                                              fuse_ms=r["fuse_ms"], nodes=len(r["fused"].label)))
+                                                              fuse_ms=r["fuse_ms"], nodes=len(r["fused"].label),
+                                                              **{k: al.get(k, 0) for k in ("chain_ms", "partition_ms", "stitch_ms", "chain_device_ms",
+                                                                                          "chain_pair_evals", "chain_match_pairs", "chain_combinations")}))
                 if verbose:
                     import sys
                     print("merge %s: %s" % (newick(t), stats["per_merge"][-1]), file=sys.stderr, flush=True)
@@ -112,10 +118,26 @@ def _count_leaves(tree):
     return 1 if isinstance(tree, str) else _count_leaves(tree[0]) + _count_leaves(tree[1])
 
 
-def split_ranks(tree, ranks):
-    """ranks of the left / right child of an internal node: proportional to leaf counts, at least one each"""
+def subtree_work(tree):
+    """relative cost of building a subtree's graph: a merge's chaining DP grows with the number of (chain of graph 1, chain of
+    graph 2) combinations, (paths1 + 1)(paths2 + 1); leaves cost nothing"""
+    if isinstance(tree, str):
+        return 0
     nl, nr = _count_leaves(tree[0]), _count_leaves(tree[1])
-    k = max(1, min(len(ranks) - 1, round(len(ranks) * nl / (nl + nr))))
+    return (nl + 1) * (nr + 1) + subtree_work(tree[0]) + subtree_work(tree[1])
+
+
+def split_ranks(tree, ranks):
+    """ranks of the left / right child of an internal node (len(ranks) >= 2): in proportion to the work under each child, at least
+    one each, and a leaf never more than one (a leaf has nothing to share; surplus ranks go to its sibling)"""
+    wl, wr = subtree_work(tree[0]), subtree_work(tree[1])
+    n = len(ranks)
+    if isinstance(tree[0], str):
+        k = 1
+    elif isinstance(tree[1], str):
+        k = n - 1
+    else:
+        k = max(1, min(n - 1, round(n * wl / (wl + wr))))
     return ranks[:k], ranks[k:]
 
 
@@ -155,9 +177,11 @@ def recv_graph(src, dist, group=None):
     return _unpack_graph(head.numpy(), body.numpy())
 
 
-def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000):
+def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000,
+                                keep_merges=False, all_ranks=False):
     """progressive_msa over `world` ranks; every rank calls it with the same arguments (its own ctx).  `group` must be a
-    host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None."""
+    host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None — or, with
+    all_ranks, their own dict (root None, stats of the merges they ran)."""
     import torch
     order = leaves_of(tree)
     # level 1: leaf calibrations, round-robin; the scales meet by a SUM all-reduce of a vector that is zero except at the
@@ -173,11 +197,19 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
     scale = sum(scales) / len(scales)
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0, graphs_received=0)
 
-    def merge(g1, g2):
+    def merge(g1, g2, t):
         r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
         for k in ("match_ms", "align_ms", "fuse_ms"):
             stats[k] += r[k]
         stats["merges"] += 1
+        al = r.get("align")
+        if al is not None:
+            stats.setdefault("per_merge", []).append(dict(merge=newick(t), paths1=_count_leaves(t[0]), paths2=_count_leaves(t[1]),
+                                                          match_sets=r["n_match_sets"], match_ms=r["match_ms"], align_ms=r["align_ms"], fuse_ms=r["fuse_ms"],
+                                                          **{k: al[k] for k in ("chain_ms", "partition_ms", "stitch_ms", "chain_device_ms", "chain_pair_evals",
+                                                                                "chain_match_pairs", "chain_combinations")}))
+            if keep_merges:
+                stats.setdefault("kept", []).append(dict(merge=newick(t), graphs=(g1, g2), align=al, fused=r["fused"], paths=leaves_of(t)))
         return r["fused"]
 
     def solve(t, ranks):
@@ -185,9 +217,11 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
         if rank not in ranks:
             return None
         if isinstance(t, str):
+            if rank != ranks[0]:
+                return None   # only the owner needs the leaf's graph
             return leaves[t] if t in leaves else capi.leaf_graph(sequences[t])
         if len(ranks) == 1:
-            return merge(solve(t[0], ranks), solve(t[1], ranks))
+            return merge(solve(t[0], ranks), solve(t[1], ranks), t)
         left, right = split_ranks(t, ranks)
         g1, g2 = solve(t[0], left), solve(t[1], right)
         if rank == right[0]:
@@ -196,9 +230,9 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
             return None
         g2 = recv_graph(right[0], dist, group)
         stats["graphs_received"] += 1
-        return merge(g1, g2)
+        return merge(g1, g2, t)
 
     root = solve(tree, list(range(world)))
     if rank != 0:
-        return None
+        return dict(root=None, paths=order, scale=scale, scales=scales, stats=stats) if all_ranks else None
     return dict(root=root, paths=order, scale=scale, scales=scales, stats=stats)

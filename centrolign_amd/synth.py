@@ -392,3 +392,21 @@ def exact_matches(seq1, seq2, k=12, max_sets=None):
         c1.append(len(d1[key])); c2.append(len(d2[key])); fl.append(k)
     return capi.MatchSets(set_off1=so1, walk_off1=wo1, nodes1=n1, set_off2=so2, walk_off2=wo2, nodes2=n2, count1=c1, count2=c2,
                           full_length=fl)
+
+
+# BASELINE configs[2] / [3]: 10 sequences x 1 Mbp (seed 7, the generator above with its defaults), guide tree of SURVEY.md §8(d)
+C3_NEWICK = "((((s0,s1),(s2,s3)),s4),(((s5,s6),(s7,s8)),s9));"
+C3_TREE = (((("s0", "s1"), ("s2", "s3")), "s4"), ((("s5", "s6"), ("s7", "s8")), "s9"))
+
+
+def c3_workload(length=1000000, n_seq=10, seed=7):
+    """(names, {name: sequence}, guide tree as nested 2-tuples) of BASELINE configs[2]; other n_seq get a balanced tree"""
+    seqs = hor_sequences(seed, length, n_seq)
+    names = ["s%d" % i for i in range(n_seq)]
+    if n_seq == 10:
+        tree = C3_TREE
+    else:
+        def bal(nm):
+            return nm[0] if len(nm) == 1 else (bal(nm[:len(nm) // 2]), bal(nm[len(nm) // 2:]))
+        tree = bal(names)
+    return names, dict(zip(names, seqs)), tree
