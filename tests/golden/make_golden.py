@@ -222,7 +222,44 @@ def msa_goldens():
     np.savez_compressed(os.path.join(HERE, "msa_text.npz"), **out)
 
 
+def msa_big_goldens():
+    # 15. two larger end-to-end fixtures from the reference's own CLI flow (oracle/_ref/ref_cli, -S for the subproblems):
+    #     BASELINE configs[0] — the pairwise 2 x 20 kbp pair, seed 1, default budget (the reference's CPU-runnable case, ~2 min) —
+    #     and a 10-sequence MSA over the guide tree of configs[2] at 30 kbp per sequence with a 200 000 pair budget (~7 min), so
+    #     that merges of 2+2, 4+1 and 5+5 paths are pinned by the driver-run suite (tests/test_msa.py)
+    import hashlib
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from centrolign_amd import synth
+    cli = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "ref_cli")
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        seqs = synth.hor_sequences(1, 20000, 2)
+        synth.write_fasta(os.path.join(d, "c1.fa"), seqs, ["seq0", "seq1"])
+        subprocess.check_call([cli, os.path.join(d, "c1.fa"), "-", "-", os.path.join(d, "c1.out"), "0", "0"])
+        out["c1_pair_20k.cigar"] = np.frombuffer(open(os.path.join(d, "c1.out"), "rb").read(), np.uint8)
+        names, sq, _ = synth.c3_workload(30000)
+        synth.write_fasta(os.path.join(d, "m10.fa"), [sq[n] for n in names], names)
+        open(os.path.join(d, "t.nwk"), "w").write(synth.C3_NEWICK + "\n")
+        subprocess.check_call([cli, os.path.join(d, "m10.fa"), os.path.join(d, "t.nwk"), os.path.join(d, "sub"), os.path.join(d, "m10.gfa"), "200000", "0"])
+        out["msa10_30k.gfa"] = np.frombuffer(open(os.path.join(d, "m10.gfa"), "rb").read(), np.uint8)
+        keys, shas = [], []
+        with open(os.path.join(d, "sub_info.txt")) as f:
+            next(f)
+            for ln in f:
+                path, leaves = ln.rstrip("\n").split("\t")
+                keys.append(leaves)
+                shas.append(hashlib.sha256(open(path, "rb").read()).hexdigest())
+        out["msa10_30k.sub_leaves"] = np.array(keys)
+        out["msa10_30k.sub_sha256"] = np.array(shas)
+    np.savez_compressed(os.path.join(HERE, "msa_text_big.npz"), **out)
+    print({k: len(v) for k, v in out.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "msa_big":
+        return msa_big_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "msa":
         return msa_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "io":

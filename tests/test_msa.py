@@ -59,3 +59,31 @@ def test_gpu_native_run_prints_the_references_text(gpu_ctx, case, workers):
     got = msa.output_text(r)
     assert got == (want.rstrip(b"\n") if n == 2 else want)   # the CIGAR line ends in a newline in the dump
     assert r["stats"]["merges"] == n - 1 and len(r["root"].path_off) - 1 == n
+
+
+ZB = np.load(os.path.join(H.GOLDEN, "msa_text_big.npz"))
+
+
+@pytest.mark.gpu
+def test_gpu_baseline_configs0_pairwise_20k(gpu_ctx):
+    """BASELINE configs[0]: the pairwise 2 x 20 kbp HOR pair (seed 1, default budget: 1.14 M match pairs), explicit CIGAR byte for byte
+    as the reference's CLI flow printed it (tests/golden/make_golden.py msa_big)"""
+    seqs = synth.hor_sequences(1, 20000, 2)
+    names = ["seq0", "seq1"]
+    r = msa.progressive_msa(gpu_ctx, dict(zip(names, seqs)), msa.balanced_tree(names), workers=2)
+    assert msa.output_text(r) == bytes(ZB["c1_pair_20k.cigar"]).rstrip(b"\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 4])
+def test_gpu_ten_sequence_msa_30k(gpu_ctx, workers):
+    """ten sequences over the guide tree of BASELINE configs[2] (30 kbp each, 200 000 pair budget): merges of 1+1, 2+2, 4+1 and 5+5
+    paths; the root GFA byte for byte and every subproblem GFA (-S of the reference) by digest"""
+    import hashlib
+    from centrolign_amd import capi
+    names, seqs, tree = synth.c3_workload(30000)
+    r = msa.progressive_msa(gpu_ctx, seqs, tree, max_num_match_pairs=200000, workers=workers, keep_merges=True)
+    assert msa.output_text(r) == bytes(ZB["msa10_30k.gfa"])
+    want = dict(zip(ZB["msa10_30k.sub_leaves"].tolist(), ZB["msa10_30k.sub_sha256"].tolist()))
+    got = {",".join(sorted(m["paths"])): hashlib.sha256(capi.write_gfa(m["fused"], m["paths"])).hexdigest() for m in r["stats"]["kept"]}
+    assert got == want and len(got) == 9
