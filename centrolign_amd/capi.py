@@ -525,6 +525,23 @@ def _core_align_dict(out):
                 chain_combinations=int(out.chain_combinations))
 
 
+def chain_exhaustive(graph1, graph2, matches, params=None, num_match_sets=None):
+    """exhaustive_chain_dp + heaviest_weight_path (include/centrolign/anchorer.hpp:1342-1509, src/anchorer.cpp:68-133), the O(M^2)
+    "-g 0" chaining; host only.  Returns the chain (n, 3) uint32 [match_set, idx1, idx2]"""
+    lib = load_library()
+    params = params or default_chain_params()
+    g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), ChainResultC()
+    n = matches.n_sets if num_match_sets is None else num_match_sets
+    rc = lib.cl_chain_exhaustive(None, C.byref(g1), C.byref(g2), C.byref(mc), n, C.byref(params), C.byref(out))
+    if rc != 0:
+        raise ClError(rc)
+    try:
+        na = int(out.n_anchors)
+        return np.ctypeslib.as_array(out.anchors, shape=(max(na, 1) * 3,))[:3 * na].copy().reshape(na, 3)
+    finally:
+        lib.cl_chain_result_free(C.byref(out))
+
+
 def default_chain_params(global_anchoring=True):
     """the CLI's anchoring parameters (src/parameters.cpp:39-60)"""
     p = ChainParams()
@@ -832,6 +849,9 @@ def load_library(path=None):
     lib.cl_chain_sparse_affine.restype = C.c_int
     lib.cl_chain_sparse_affine.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
                                            C.POINTER(ChainParams), C.c_double, C.c_int, C.POINTER(ChainResultC)]
+    lib.cl_chain_exhaustive.restype = C.c_int
+    lib.cl_chain_exhaustive.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
+                                        C.POINTER(ChainParams), C.POINTER(ChainResultC)]
     lib.cl_chain_sparse.restype = C.c_int
     lib.cl_chain_sparse.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.c_uint64,
                                     C.POINTER(ChainParams), C.c_int, C.POINTER(ChainResultC)]
@@ -909,7 +929,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
-    "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_result_free",
+    "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_exhaustive", "cl_chain_result_free",
     "cl_anchor_chain", "cl_anchor_chain_result_free",
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",

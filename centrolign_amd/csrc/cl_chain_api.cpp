@@ -648,6 +648,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
     DevBuf<unsigned long long> d_xch;
+    DevBuf<int> k_in, k_out;          // value index of the traceback (built on demand)
+    DevBuf<uint32_t> i_in, i_out;
+    DevBuf<char> vtemp;
     // branch-and-bound far pass (chain_far.hip)
     DevBuf<int> d_far_rec, d_far_pm[2 * kFarMaxLevels];
     DevBuf<uint32_t> d_far_base, d_far_u32[6 + 3 * kFarMaxLevels], d_seal_items;
@@ -660,11 +663,11 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     static const bool old_walk_env = getenv("CL_CHAIN_OLD_WALK") != nullptr;
     const bool use_walk = combos.size() <= kChainWalkMaxCombos && !old_walk_env;
     std::vector<ClChainCombo> hc(combos.size());
-    std::vector<int> acc_init(M * 7, enc(CL_CHAIN_NEG));
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
         d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release(); d_grp_base.release(); d_grp_total.release();
         d_group_end.release(); d_status.release(); d_xch.release();
+        k_in.release(); k_out.release(); i_in.release(); i_out.release(); vtemp.release();
         d_far_rec.release(); d_far_base.release(); d_seal_items.release(); d_far_temp.release();
         for (auto& b : d_far_pm) b.release();
         for (auto& b : d_far_u32) b.release();
@@ -677,7 +680,8 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         CH(c.d_sigma.upload(ctx, c.sigma)); CH(c.d_prefix.upload(ctx, c.prefix));
         CH(c.d_qt.upload(ctx, c.qt)); CH(c.d_qoff.upload(ctx, c.qoff)); CH(c.d_q.upload(ctx, c.q));
         CH(c.d_val.alloc(ctx, 7 * c.rec_s.size()));
-        CH(c.d_acc.upload(ctx, acc_init));
+        CH(c.d_acc.alloc(ctx, M * 7));
+        if (hipMemsetD32Async((hipDeviceptr_t)c.d_acc.p, enc(CL_CHAIN_NEG), M * 7, ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetD32Async failed"); return CL_ERR_HIP; }
         if (use_walk) {
             CH(c.d_own_rec.alloc(ctx, M));
             if (hipMemsetAsync(c.d_own_rec.p, 0xFF, M * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
@@ -1052,33 +1056,37 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     if (he != hipSuccess) { cl_set_error(ctx, "download failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
 
     const auto T1 = std::chrono::steady_clock::now();
-    // value index: per combination and tree kind, (encoded stored value, record) sorted by value
+    // value index: per combination and tree kind, (encoded stored value, record) sorted by value — built on first use: the
+    // traceback touches only the (combination, kind) pairs that win a step of the chain
     std::vector<std::vector<std::vector<int>>> vkeys(combos.size(), std::vector<std::vector<int>>(7));
     std::vector<std::vector<std::vector<uint32_t>>> vrecs(combos.size(), std::vector<std::vector<uint32_t>>(7));
+    std::vector<std::vector<char>> vbuilt(combos.size(), std::vector<char>(7, 0));
+    size_t vtemp_bytes = 0;
+    float index_ms = 0;
+    auto release_index = [&]() { k_in.release(); k_out.release(); i_in.release(); i_out.release(); vtemp.release(); };
     {
         uint32_t nmax = 0;
         for (const Combo& c : combos) nmax = std::max<uint32_t>(nmax, (uint32_t)c.rec_s.size());
-        DevBuf<int> k_in, k_out;
-        DevBuf<uint32_t> i_in, i_out;
-        DevBuf<char> temp;
         CH(k_in.alloc(ctx, nmax)); CH(k_out.alloc(ctx, nmax)); CH(i_in.alloc(ctx, nmax)); CH(i_out.alloc(ctx, nmax));
-        size_t temp_bytes = 0;
-        he = cl_chain_sort_values(nullptr, nmax, k_in.p, i_in.p, k_out.p, i_out.p, nullptr, &temp_bytes, ctx->stream);
-        if (he == hipSuccess) { rc = temp.alloc(ctx, temp_bytes); if (rc) he = hipErrorOutOfMemory; }
-        for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
-            const uint32_t n = (uint32_t)combos[ci].rec_s.size();
-            for (int kind = 0; kind < (sparse ? 1 : 7) && he == hipSuccess; ++kind) {
-                he = cl_chain_sort_values(combos[ci].d_val.p + (size_t)kind * n, n, k_in.p, i_in.p, k_out.p, i_out.p, temp.p, &temp_bytes, ctx->stream);
-                vkeys[ci][kind].resize(n);
-                vrecs[ci][kind].resize(n);
-                if (he == hipSuccess && n) he = hipMemcpyAsync(vkeys[ci][kind].data(), k_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (he == hipSuccess && n) he = hipMemcpyAsync(vrecs[ci][kind].data(), i_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-            }
-        }
-        k_in.release(); k_out.release(); i_in.release(); i_out.release(); temp.release();
-        if (he != hipSuccess) { cl_set_error(ctx, "value index failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
+        he = cl_chain_sort_values(nullptr, nmax, k_in.p, i_in.p, k_out.p, i_out.p, nullptr, &vtemp_bytes, ctx->stream);
+        if (he == hipSuccess) { rc = vtemp.alloc(ctx, vtemp_bytes); if (rc) he = hipErrorOutOfMemory; }
+        if (he != hipSuccess) { cl_set_error(ctx, "value index failed: %s", hipGetErrorString(he)); release_index(); cleanup(); return CL_ERR_HIP; }
     }
+    auto value_index = [&](size_t ci, int kind) -> bool {
+        if (vbuilt[ci][kind]) return true;
+        const auto t = std::chrono::steady_clock::now();
+        const uint32_t n = (uint32_t)combos[ci].rec_s.size();
+        hipError_t e = cl_chain_sort_values(combos[ci].d_val.p + (size_t)kind * n, n, k_in.p, i_in.p, k_out.p, i_out.p, vtemp.p, &vtemp_bytes, ctx->stream);
+        vkeys[ci][kind].resize(n);
+        vrecs[ci][kind].resize(n);
+        if (e == hipSuccess && n) e = hipMemcpyAsync(vkeys[ci][kind].data(), k_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n) e = hipMemcpyAsync(vrecs[ci][kind].data(), i_out.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        index_ms += ms_since(t);
+        if (e != hipSuccess) { cl_set_error(ctx, "value index failed: %s", hipGetErrorString(e)); return false; }
+        vbuilt[ci][kind] = 1;
+        return true;
+    };
     tm.index_ms += ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
 
@@ -1154,6 +1162,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             std::vector<uint32_t> cand;
             {
                 const int target = acc[win_combo][(size_t)s * 7 + win_kind];
+                if (!value_index((size_t)win_combo, win_kind)) { release_index(); cleanup(); return CL_ERR_HIP; }
                 const auto& keys = vkeys[win_combo][win_kind];
                 const auto& recs = vrecs[win_combo][win_kind];
                 const uint32_t qt = c.qt[s], qoff = c.qoff[s];
@@ -1307,7 +1316,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             }
         }
     }
-    tm.traceback_ms += ms_since(T2);
+    release_index();
+    tm.index_ms += index_ms;
+    tm.traceback_ms += ms_since(T2) - index_ms;
     if (timing) fprintf(stderr, "[chain_dp_batch]   traceback: %llu steps, %llu equal-valued records scanned\n", (unsigned long long)n_steps, (unsigned long long)n_scanned);
     if (dp_out) {
         dp_out->resize(M);
@@ -1380,6 +1391,87 @@ int cl_chain_sparse(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
 }
 
 }  // extern "C"
+
+// exhaustive_chain_dp with score_edges == false (anchorer.hpp:1342-1509 as dispatched at :1229-1232) and
+// AnchorGraph::heaviest_weight_path (src/anchorer.cpp:68-133).  The reference materialises every edge; here an edge is the
+// reachability test itself, evaluated twice per ordered pair (once for the in-degrees of Kahn's algorithm, once when the
+// source node is popped), so a few tens of thousands of match pairs stay within memory.  Node order, edge order (ascending
+// target id), the LIFO stack of topological_order.hpp:12-60 and the strict '>' updates decide ties exactly as there.
+extern "C" int cl_chain_exhaustive(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                                   uint64_t num_match_sets, const cl_chain_params* cp, cl_chain_result* out) {
+    if (!g1 || !g2 || !ms || !cp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    if (num_match_sets > ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+    clhost::PathMergeTable x1, x2;
+    if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    const ChainSub sb = whole_graph_instance(g1, g2, ms, num_match_sets, cp->global_anchoring != 0);
+    const double lowest = std::numeric_limits<double>::lowest();
+    struct Node { uint32_t set, i1, i2, b1, e1, b2, e2; double weight, initial, final_w; };
+    std::vector<Node> nodes;
+    for (uint64_t s = 0; s < num_match_sets; ++s) {
+        const uint64_t a0 = ms->set_off1[s], a1 = ms->set_off1[s + 1], c0 = ms->set_off2[s], c1 = ms->set_off2[s + 1];
+        if (a0 == a1) continue;
+        const double w = anchor_weight(*cp, ms->count1[s], ms->count2[s], ms->walk_off1[a0 + 1] - ms->walk_off1[a0], ms->full_length[s]);
+        for (uint64_t j = a0; j < a1; ++j)
+            for (uint64_t q = c0; q < c1; ++q) {
+                Node nd{(uint32_t)s, (uint32_t)(j - a0), (uint32_t)(q - c0), ms->nodes1[ms->walk_off1[j]], ms->nodes1[ms->walk_off1[j + 1] - 1],
+                        ms->nodes2[ms->walk_off2[q]], ms->nodes2[ms->walk_off2[q + 1] - 1], w, 0.0, 0.0};
+                if (sb.anchored) {
+                    nd.initial = lowest;
+                    for (uint32_t a : sb.src[0]) for (uint32_t b : sb.src[1])
+                        if ((a == nd.b1 || x1.reachable(a, nd.b1)) && (b == nd.b2 || x2.reachable(b, nd.b2))) nd.initial = 0.0;
+                    nd.final_w = lowest;
+                    for (uint32_t a : sb.snk[0]) for (uint32_t b : sb.snk[1])
+                        if ((a == nd.e1 || x1.reachable(nd.e1, a)) && (b == nd.e2 || x2.reachable(nd.e2, b))) nd.final_w = 0.0;
+                }
+                nodes.push_back(nd);
+            }
+    }
+    const size_t N = nodes.size();
+    out->n_pairs = N;
+    auto edge = [&](size_t i, size_t j) { return x1.reachable(nodes[i].e1, nodes[j].b1) && x2.reachable(nodes[i].e2, nodes[j].b2); };
+    std::vector<uint32_t> indeg(N, 0);
+    cl_parallel_for(N, [&](uint64_t jb, uint64_t je) {
+        for (size_t j = jb; j < je; ++j) {
+            uint32_t d = 0;
+            for (size_t i = 0; i < N; ++i) d += edge(i, j) ? 1u : 0u;
+            indeg[j] = d;
+        }
+    }, 64);
+    std::vector<double> dp(N);
+    std::vector<size_t> back(N, SIZE_MAX), stack;
+    for (size_t i = 0; i < N; ++i) { dp[i] = nodes[i].initial; if (!indeg[i]) stack.push_back(i); }
+    size_t max_id = SIZE_MAX, seen = 0;
+    double max_weight = 0.0;   // min_score: edges are not scored
+    while (!stack.empty()) {
+        const size_t v = stack.back();
+        stack.pop_back();
+        ++seen;
+        const bool live = dp[v] != lowest;
+        if (live) {
+            dp[v] += nodes[v].weight;
+            if (nodes[v].final_w != lowest && dp[v] + nodes[v].final_w > max_weight) { max_id = v; max_weight = dp[v] + nodes[v].final_w; }
+        }
+        for (size_t j = 0; j < N; ++j) {
+            if (!edge(v, j)) continue;
+            if (live && dp[v] + 0.0 > dp[j]) { dp[j] = dp[v] + 0.0; back[j] = v; }
+            if (--indeg[j] == 0) stack.push_back(j);
+        }
+    }
+    if (seen != N) { cl_set_error(ctx, "anchor graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    std::vector<size_t> path;
+    for (size_t v = max_id; v != SIZE_MAX; v = back[v]) path.push_back(v);
+    std::reverse(path.begin(), path.end());
+    out->n_anchors = path.size();
+    out->anchors = (uint32_t*)malloc((path.empty() ? 1 : path.size()) * 3 * sizeof(uint32_t));
+    if (!out->anchors) return CL_ERR_OUT_OF_MEMORY;
+    for (size_t i = 0; i < path.size(); ++i) {
+        out->anchors[3 * i] = nodes[path[i]].set;
+        out->anchors[3 * i + 1] = nodes[path[i]].i1;
+        out->anchors[3 * i + 2] = nodes[path[i]].i2;
+    }
+    return CL_OK;
+}
 
 // =====================================================================================================================
 // Anchorer::anchor_chain without fill-in re-anchoring and branch splitting:

@@ -312,6 +312,11 @@ int  cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* graph1, const 
  * Anchorer::estimate_score_scale (anchorer.hpp:998-1047) and the leaf calibration (src/core.cpp:122-175) run. */
 int  cl_chain_sparse(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
                      uint64_t num_match_sets, const cl_chain_params* params, int want_dp, cl_chain_result* out);
+/* exhaustive_chain_dp (anchorer.hpp:1342-1509) + AnchorGraph::heaviest_weight_path (src/anchorer.cpp:68-133): the O(M^2) chaining behind
+ * the CLI's "-g 0" and the reference's test oracle, as Anchorer::anchor_chain dispatches it (:1229-1232: no edge scores).  Host only
+ * (ctx may be NULL); the anchor graph is never materialised, so memory stays O(M).  cl_chain_params.global_anchoring as above. */
+int  cl_chain_exhaustive(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+                         uint64_t num_match_sets, const cl_chain_params* params, cl_chain_result* out);
 void cl_chain_result_free(cl_chain_result* r);
 
 /* --- Partitioner::partition_anchors (include/centrolign/partitioner.hpp:72-213) -----------------------------------------

@@ -257,7 +257,28 @@ def msa_big_goldens():
     print({k: len(v) for k, v in out.items()})
 
 
+def exhaustive_goldens():
+    # 16. exhaustive_chain_dp (anchorer.hpp:1342-1509, the "-g 0" algorithm) by the compiled reference: the CHAINS (not only their
+    #     weights) on budgeted subsets of the match sets of the three merges of the 4 x 30 kbp MSA, global and local anchoring
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.test_extraction import load_stitch_case
+    out = {}
+    for m in range(3):
+        z = np.load(os.path.join(HERE, "chain4_30k_merge%d.npz" % m))
+        _, graphs, _ = load_stitch_case("stitch4_30k_merge%d.npz" % m)
+        full = po.MatchSets(**{k: z["a.ms." + k] for k in po.MatchSets._DT})
+        for seed, budget in ((1, 1500), (2, 3000), (3, 600)):
+            sub = po.budget_subset(full, budget, seed=seed)
+            for glob in (True, False):
+                ex, _ = po.ref_chain("exhaustive", graphs[0], graphs[1], sub, global_anchoring=glob)
+                out["m%d.%d.%d.%s" % (m, seed, budget, "g" if glob else "l")] = ex
+                print(m, seed, budget, glob, len(ex))
+    np.savez_compressed(os.path.join(HERE, "exhaustive_chains.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "exhaustive":
+        return exhaustive_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "msa_big":
         return msa_big_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "msa":
