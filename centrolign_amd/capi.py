@@ -542,6 +542,63 @@ def chain_exhaustive(graph1, graph2, matches, params=None, num_match_sets=None):
         lib.cl_chain_result_free(C.byref(out))
 
 
+class FastaC(C.Structure):
+    """cl_fasta"""
+    _fields_ = [("n_sequences", C.c_uint64), ("names", C.POINTER(C.c_char_p)), ("sequences", C.POINTER(C.c_char_p)),
+                ("lengths", C.POINTER(C.c_uint64)), ("owner", C.c_void_p)]
+
+
+class MsaPlanC(C.Structure):
+    """cl_msa_plan"""
+    _fields_ = [("n_leaves", C.c_uint64), ("leaf_sequence", C.POINTER(C.c_uint64)), ("n_merges", C.c_uint64),
+                ("merge_children", C.POINTER(C.c_uint64))]
+
+
+class MsaParams(C.Structure):
+    """cl_msa_params"""
+    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int)]
+
+
+class MsaStats(C.Structure):
+    """cl_msa_stats"""
+    _fields_ = [("n_merges", C.c_uint64), ("root_nodes", C.c_uint64), ("score_scale", C.c_double), ("calibration_s", C.c_double),
+                ("match_s", C.c_double), ("align_s", C.c_double), ("fuse_s", C.c_double), ("total_s", C.c_double)]
+
+
+def parse_fasta(text):
+    """parse_fasta (src/utility.cpp:19-65); host only.  Returns [(name, sequence)]"""
+    lib = load_library()
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    f = FastaC()
+    rc = lib.cl_parse_fasta(None, raw, len(raw), C.byref(f))
+    if rc != 0:
+        msg = lib.cl_last_error(None)
+        raise ClError(rc, msg.decode() if msg else "")
+    try:
+        return [(f.names[i].decode(), C.string_at(f.sequences[i], int(f.lengths[i])).decode()) for i in range(int(f.n_sequences))]
+    finally:
+        lib.cl_fasta_free(C.byref(f))
+
+
+def msa_plan(newick, names):
+    """Tree(newick) + Execution's normalisation and order (src/tree.cpp, src/execution.cpp:12-92); host only.  Returns
+    (leaf_sequence: index into names per leaf in calibration order, merges: [(slot of graph 1, slot of graph 2)] in execution order);
+    slot i < len(leaf_sequence) is leaf i, slot len(leaf_sequence) + k the result of merge k"""
+    lib = load_library()
+    arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+    p = MsaPlanC()
+    rc = lib.cl_msa_plan_create(None, (newick or "").encode(), arr, len(names), C.byref(p))
+    if rc != 0:
+        msg = lib.cl_last_error(None)
+        raise ClError(rc, msg.decode() if msg else "")
+    try:
+        leaves = [int(p.leaf_sequence[i]) for i in range(int(p.n_leaves))]
+        merges = [(int(p.merge_children[2 * k]), int(p.merge_children[2 * k + 1])) for k in range(int(p.n_merges))]
+        return leaves, merges
+    finally:
+        lib.cl_msa_plan_free(C.byref(p))
+
+
 def default_chain_params(global_anchoring=True):
     """the CLI's anchoring parameters (src/parameters.cpp:39-60)"""
     p = ChainParams()
@@ -930,6 +987,7 @@ EXPORTED_SYMBOLS = [
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_exhaustive", "cl_chain_result_free",
+    "cl_parse_fasta", "cl_fasta_free", "cl_msa_plan_create", "cl_msa_plan_free", "cl_msa_params_default", "cl_msa",
     "cl_anchor_chain", "cl_anchor_chain_result_free",
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
@@ -1163,6 +1221,22 @@ class Context:
                         align_ms=float(out.align_ms), fuse_ms=float(out.fuse_ms), align=al)
         finally:
             self.lib.cl_merge_result_free(C.byref(out))
+
+    def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False):
+        """the whole CLI flow in the library (cl_msa): FASTA text (+ Newick text) -> explicit CIGAR (two sequences) or GFA; returns
+        (text bytes, stats dict)"""
+        raw = fasta_text.encode() if isinstance(fasta_text, str) else bytes(fasta_text)
+        mp = MsaParams()
+        self.lib.cl_msa_params_default(C.byref(mp))
+        mp.merge.match.max_count = int(max_count)
+        mp.merge.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
+        mp.skip_calibration = int(skip_calibration)
+        p, n, st = C.c_void_p(), C.c_uint64(0), MsaStats()
+        self._check(self.lib.cl_msa(self.handle, raw, len(raw), None if not newick else newick.encode(), C.byref(mp), C.byref(p), C.byref(n), C.byref(st)))
+        try:
+            return C.string_at(p, int(n.value)), {k: getattr(st, k) for k, _ in MsaStats._fields_}
+        finally:
+            _libc_free(p)
 
     def plan(self, batch, params=None, force_num_pw=None):
         params = params or default_stitch_params()

@@ -1,0 +1,498 @@
+// cl_plan_api.cpp — the front of the reference's driver, behind the C ABI (include/centrolign_amd.h):
+//   cl_parse_fasta        parse_fasta                          src/utility.cpp:19-65
+//   cl_msa_plan_create    Tree(newick) + Execution's setup     src/tree.cpp:39-160, src/execution.cpp:12-92
+//                         (prune to the FASTA's names, compact, binarize, small_first_postorder) -> leaf order + merge order
+//   cl_msa                main() -> Core::execute -> output    src/main.cpp:239-301, src/core.cpp:63-94
+// Host code.  What must be reproduced is the ORDER the reference works in: leaves are calibrated in tree-id order (the mean of the
+// intrinsic scales is a floating-point sum, src/core.cpp:169-173), merges run in small_first_postorder order, and the first child of a
+// tree node is graph 1 of its merge (src/execution.cpp:98-124).  Tree ids follow the Newick text (a node is numbered when its '('
+// is met, a leaf when the ',' or ')' behind it is), survive prune / compact as a stable renumbering, and binarize appends its new
+// nodes; the tree is kept here as flat arrays (parent, ordered child lists) with those ids.
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cl_internal.hpp"
+
+namespace {
+
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+struct GuideTree {
+    std::vector<uint32_t> parent;
+    std::vector<std::vector<uint32_t>> kids;
+    std::vector<std::string> label;
+    uint32_t root = kNoNode;
+    std::string error;
+
+    uint32_t add(uint32_t par) {
+        const uint32_t id = (uint32_t)parent.size();
+        parent.push_back(par);
+        kids.emplace_back();
+        label.emplace_back();
+        if (par != kNoNode) kids[par].push_back(id);
+        return id;
+    }
+
+    // label text between two structural characters: up to an unquoted ':', trimmed, one pair of quotes removed (src/tree.cpp:198-245)
+    bool set_label(uint32_t v, const std::string& s, size_t b, size_t e) {
+        bool q = false;
+        size_t colon = e;
+        for (size_t i = b; i < e; ++i) {
+            if (s[i] == '"') q = !q;
+            else if (!q && s[i] == ':') { colon = i; break; }
+        }
+        if (colon != e) {
+            size_t d = colon + 1;
+            while (d < e && isspace((unsigned char)s[d])) ++d;
+            if (d == e) { error = "Newick string has ':' without a distance following it"; return false; }
+        }
+        size_t lo = b, hi = colon;
+        while (lo < hi && isspace((unsigned char)s[lo])) ++lo;
+        while (hi > lo + 1 && isspace((unsigned char)s[hi - 1])) --hi;
+        for (size_t i = lo + 1; i + 1 < hi; ++i)
+            if (s[i] == '"') { error = "Newick string label has internal quotation mark: " + s.substr(lo, hi - lo); return false; }
+        if (lo < hi && s[lo] == '"') {
+            if (lo + 1 == hi) { error = "Newick string label consists of only one quotation mark"; return false; }
+            if (s[hi - 1] != '"') { error = "Newick string label has unmatched quotation mark: " + s.substr(lo, hi - lo); return false; }
+            ++lo; --hi;
+        }
+        label[v] = s.substr(lo, hi - lo);
+        return true;
+    }
+
+    bool parse(const std::string& s) {
+        // the checks of src/tree.cpp:41-60
+        size_t semi = std::string::npos;
+        {
+            bool q = false;
+            for (size_t i = 0; i < s.size(); ++i) {
+                if (s[i] == '"') q = !q;
+                else if (!q && s[i] == ';') { semi = i; break; }
+            }
+        }
+        if (semi == std::string::npos) { error = "Newick string is missing a terminating ';'"; return false; }
+        for (size_t i = semi + 1; i < s.size(); ++i)
+            if (!isspace((unsigned char)s[i])) { error = "Newick string includes characters after the terminating ';'"; return false; }
+        if (std::count(s.begin(), s.end(), '"') % 2 == 1) { error = "Newick string has an odd number of quotation marks"; return false; }
+        if (s.find('\'') != std::string::npos) { error = "Newick string parser does not support single quotes (')"; return false; }
+        // structural characters outside quotes, in text order
+        std::vector<size_t> marks;
+        {
+            bool q = false;
+            for (size_t i = 0; i <= semi; ++i) {
+                if (s[i] == '"') q = !q;
+                else if (!q && (s[i] == '(' || s[i] == ')' || s[i] == ',' || s[i] == ';')) marks.push_back(i);
+            }
+        }
+        if (marks.size() == 1) {   // no parentheses, no commas: one node
+            root = add(kNoNode);
+            return set_label(root, s, 0, semi) && index_labels();
+        }
+        std::vector<uint32_t> open;     // nodes whose child list is being read
+        uint32_t closed = kNoNode;      // the node whose ')' was the previous mark: the text up to the next mark is ITS label
+        size_t from = 0;
+        for (size_t m : marks) {
+            const char c = s[m];
+            if (c == ';') {
+                if (closed != kNoNode && !set_label(closed, s, from, m)) return false;
+                break;
+            }
+            if (c == '(') {
+                if (open.empty()) {
+                    if (!parent.empty()) { error = "Newick string encodes a disconnected tree"; return false; }
+                    root = add(kNoNode);
+                    open.push_back(root);
+                } else {
+                    open.push_back(add(open.back()));
+                }
+                closed = kNoNode;
+            } else {   // ',' or ')': ends a leaf's text, or the label of the node that has just been closed
+                if (open.empty()) { error = "Newick string is not a tree"; return false; }
+                const uint32_t v = closed != kNoNode ? closed : add(open.back());
+                if (!set_label(v, s, from, m)) return false;
+                closed = kNoNode;
+                if (c == ')') { closed = open.back(); open.pop_back(); }
+            }
+            from = m + 1;
+        }
+        return index_labels();
+    }
+
+    std::unordered_map<std::string, uint32_t> by_label;
+    bool index_labels() {
+        for (uint32_t v = 0; v < label.size(); ++v) {
+            if (label[v].find('#') != std::string::npos) { error = "Tree labels may not include '#': " + label[v]; return false; }
+            if (label[v].empty()) continue;
+            if (!by_label.emplace(label[v], v).second) { error = "Duplicate label " + label[v] + " in guide tree"; return false; }
+        }
+        return true;
+    }
+
+    // drop the nodes not kept; ids close up in order, child lists keep their order (Tree::filter, src/tree.cpp:469-525)
+    void keep_only(const std::vector<char>& keep) {
+        std::vector<uint32_t> new_id(parent.size(), kNoNode);
+        uint32_t n = 0;
+        for (uint32_t v = 0; v < parent.size(); ++v) if (keep[v]) new_id[v] = n++;
+        if (n == parent.size()) return;
+        std::vector<std::vector<uint32_t>> k2(n);
+        std::vector<std::string> l2(n);
+        for (uint32_t v = 0; v < parent.size(); ++v) {
+            if (!keep[v]) continue;
+            for (uint32_t c : kids[v]) if (keep[c]) k2[new_id[v]].push_back(new_id[c]);
+            l2[new_id[v]] = std::move(label[v]);
+        }
+        kids.swap(k2);
+        label.swap(l2);
+        parent.assign(n, kNoNode);
+        for (uint32_t v = 0; v < n; ++v) for (uint32_t c : kids[v]) parent[c] = v;
+        root = kNoNode;
+        for (uint32_t v = 0; v < n; ++v) if (parent[v] == kNoNode) { root = v; break; }
+        by_label.clear();
+        for (uint32_t v = 0; v < n; ++v) if (!label[v].empty()) by_label[label[v]] = v;
+    }
+
+    // Tree::prune (src/tree.cpp:385-425): the kept leaves, their ancestors, minus the unary stem above their last common ancestor
+    void prune_to(const std::vector<uint32_t>& leaves) {
+        std::vector<char> keep(parent.size(), 0);
+        for (uint32_t v : leaves)
+            for (uint32_t h = v; h != kNoNode && !keep[h]; h = parent[h]) keep[h] = 1;
+        uint32_t h = root;
+        while (h != kNoNode && keep[h]) {
+            uint32_t only = kNoNode, cnt = 0;
+            for (uint32_t c : kids[h]) if (keep[c]) { only = c; ++cnt; }
+            if (cnt != 1) break;
+            keep[h] = 0;
+            h = only;
+        }
+        if (!leaves.empty()) keep[leaves.front()] = 1;
+        keep_only(keep);
+    }
+
+    // Tree::compact (src/tree.cpp:427-467): a node with one child hands that child to its own parent — APPENDED to the parent's list
+    void compact() {
+        std::vector<char> keep(parent.size(), 1);
+        for (uint32_t v = 0; v < parent.size(); ++v) {
+            if (kids[v].size() != 1) continue;
+            keep[v] = 0;
+            const uint32_t c = kids[v].front();
+            if (v == root) { root = c; parent[c] = kNoNode; }
+            else { kids[parent[v]].push_back(c); parent[c] = parent[v]; }
+        }
+        keep_only(keep);
+    }
+
+    // Tree::binarize (src/tree.cpp:281-329): a node with k > 2 children keeps the first; k - 2 new nodes (appended ids) hang off
+    // one another to the right, each with the next child on its left, the last one with the final two
+    void binarize() {
+        const uint32_t n0 = (uint32_t)parent.size();
+        for (uint32_t v = 0; v < n0; ++v) {
+            if (kids[v].size() <= 2) continue;
+            const std::vector<uint32_t> ch = kids[v];
+            kids[v].assign(1, ch.front());
+            uint32_t prev = v;
+            for (size_t i = 2; i < ch.size(); ++i) {
+                const uint32_t nn = add(prev);
+                kids[nn].push_back(ch[i - 1]);
+                parent[ch[i - 1]] = nn;
+                prev = nn;
+            }
+            kids[prev].push_back(ch.back());
+            parent[ch.back()] = prev;
+        }
+    }
+
+    // Tree::postorder (src/tree.cpp:527-556) visits the LAST child's subtree first (children are pushed in order and popped from the back)
+    std::vector<uint32_t> postorder() const {
+        std::vector<uint32_t> order;
+        std::vector<std::pair<uint32_t, bool>> st;
+        if (root != kNoNode) st.emplace_back(root, false);
+        while (!st.empty()) {
+            if (st.back().second) { order.push_back(st.back().first); st.pop_back(); continue; }
+            st.back().second = true;
+            const uint32_t v = st.back().first;
+            for (uint32_t c : kids[v]) st.emplace_back(c, false);
+        }
+        return order;
+    }
+
+    // Tree::small_first_postorder (src/tree.cpp:558-586): ids stably sorted by (leaves below, position in postorder)
+    std::vector<uint32_t> small_first_postorder() const {
+        const size_t n = parent.size();
+        std::vector<std::pair<uint64_t, uint64_t>> pri(n, {0, 0});
+        uint64_t p = 0;
+        for (uint32_t v : postorder()) {
+            if (kids[v].empty()) pri[v].first = 1;
+            else for (uint32_t c : kids[v]) pri[v].first += pri[c].first;
+            pri[v].second = p++;
+        }
+        std::vector<uint32_t> order(n);
+        for (uint32_t v = 0; v < n; ++v) order[v] = v;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pri[a] < pri[b]; });
+        return order;
+    }
+};
+
+// in_order_newick_string (src/tree.cpp:17-37): the left-deep tree over the sequences in file order
+bool in_order_newick(const std::vector<std::string>& names, std::string& out, std::string& error) {
+    for (const auto& n : names)
+        if (n.find('"') != std::string::npos) { error = "Sequence names cannot have internal quotation marks: " + n; return false; }
+    out.assign(names.size() > 1 ? names.size() - 1 : 0, '(');
+    if (!names.empty()) {
+        out += '"' + names.front() + '"';
+        for (size_t i = 1; i < names.size(); ++i) out += ",\"" + names[i] + "\")";
+    }
+    out += ';';
+    return true;
+}
+
+}  // namespace
+
+struct cl_fasta_owned {
+    std::vector<std::string> names, seqs;
+    std::vector<const char*> name_ptr, seq_ptr;
+    std::vector<uint64_t> seq_len;
+};
+
+extern "C" {
+
+void cl_fasta_free(cl_fasta* f) {
+    if (!f) return;
+    delete (cl_fasta_owned*)f->owner;
+    memset(f, 0, sizeof(*f));
+}
+
+int cl_parse_fasta(cl_context* ctx, const char* text, uint64_t len, cl_fasta* out) {
+    if (!text || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    std::unique_ptr<cl_fasta_owned> own(new cl_fasta_owned());
+    // line by line like std::getline in a `while (in)` loop (src/utility.cpp:27-62): after the last line one more, empty, line is seen
+    uint64_t at = 0, line_num = 0;
+    size_t prev = SIZE_MAX, prev_prev = SIZE_MAX;
+    bool more = true;
+    while (more) {
+        uint64_t end = at;
+        while (end < len && text[end] != '\n') ++end;
+        const std::string line(text + at, text + end);
+        if (end >= len) more = false;
+        at = end + 1;
+        ++line_num;
+        if (!line.empty() && line.front() == '>') {
+            const size_t sp = line.find(' ');
+            own->names.push_back(line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1));
+            own->seqs.emplace_back();
+            if (own->names.back().empty()) { cl_set_error(ctx, "FASTA input is missing sequence name at line %llu", (unsigned long long)line_num); return CL_ERR_INVALID_ARGUMENT; }
+            prev = prev_prev = SIZE_MAX;
+        } else {
+            if (own->names.empty()) {
+                if (line.empty() && !more) break;
+                cl_set_error(ctx, "FASTA input does not have sequence name line");
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+            if (prev_prev != SIZE_MAX && prev != prev_prev && !line.empty()) {
+                cl_set_error(ctx, "Encountered sequence lines of unequal lengths that were not followed by a sequence name at line %llu of FASTA input", (unsigned long long)line_num);
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+            if (prev != SIZE_MAX && line.size() > prev) {
+                cl_set_error(ctx, "Encountered adjacent sequence lines of increasing lengths at line %llu of FASTA input", (unsigned long long)line_num);
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+            own->seqs.back() += line;
+            prev_prev = prev;
+            prev = line.size();
+        }
+    }
+    if (own->names.empty()) { cl_set_error(ctx, "FASTA file is empty"); return CL_ERR_INVALID_ARGUMENT; }
+    for (size_t i = 0; i < own->names.size(); ++i) {
+        own->name_ptr.push_back(own->names[i].c_str());
+        own->seq_ptr.push_back(own->seqs[i].c_str());
+        own->seq_len.push_back(own->seqs[i].size());
+    }
+    out->n_sequences = own->names.size();
+    out->names = own->name_ptr.data();
+    out->sequences = own->seq_ptr.data();
+    out->lengths = own->seq_len.data();
+    out->owner = own.release();
+    return CL_OK;
+}
+
+void cl_msa_plan_free(cl_msa_plan* p) {
+    if (!p) return;
+    free(p->leaf_sequence);
+    free(p->merge_children);
+    memset(p, 0, sizeof(*p));
+}
+
+int cl_msa_plan_create(cl_context* ctx, const char* newick, const char* const* names, uint64_t n_names, cl_msa_plan* out) {
+    if (!names || !out || n_names == 0) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    memset(out, 0, sizeof(*out));
+    std::vector<std::string> nm(names, names + n_names);
+    std::unordered_map<std::string, uint64_t> seq_of;
+    for (uint64_t i = 0; i < n_names; ++i)
+        if (!seq_of.emplace(nm[i], i).second) { cl_set_error(ctx, "FASTA contains duplicate name %s", nm[i].c_str()); return CL_ERR_INVALID_ARGUMENT; }
+    std::string text;
+    GuideTree t;
+    if (newick && *newick) text = newick;
+    else if (!in_order_newick(nm, text, t.error)) { cl_set_error(ctx, "%s", t.error.c_str()); return CL_ERR_INVALID_ARGUMENT; }
+    if (!t.parse(text)) { cl_set_error(ctx, "%s", t.error.c_str()); return CL_ERR_INVALID_ARGUMENT; }
+    // the match between the FASTA and the tree (src/execution.cpp:31-47)
+    std::vector<uint32_t> leaf_ids;
+    for (const auto& n : nm) {
+        auto it = t.by_label.find(n);
+        if (it == t.by_label.end()) { cl_set_error(ctx, "Guide tree does not include sequence %s", n.c_str()); return CL_ERR_INVALID_ARGUMENT; }
+        if (!t.kids[it->second].empty()) { cl_set_error(ctx, "Sequence %s is not a leaf in the guide tree", n.c_str()); return CL_ERR_INVALID_ARGUMENT; }
+        leaf_ids.push_back(it->second);
+    }
+    t.prune_to(leaf_ids);
+    t.compact();
+    t.binarize();
+    // slots: leaves in tree-id order (Execution::leaf_subproblems, src/execution.cpp:141-153), then one per merge in execution order
+    const size_t n = t.parent.size();
+    std::vector<uint64_t> slot(n, UINT64_MAX);
+    std::vector<uint64_t> leaf_seq;
+    for (uint32_t v = 0; v < n; ++v)
+        if (t.kids[v].empty()) {
+            auto it = seq_of.find(t.label[v]);
+            if (it == seq_of.end()) { cl_set_error(ctx, "guide tree leaf %s has no sequence", t.label[v].c_str()); return CL_ERR_INVALID_ARGUMENT; }
+            slot[v] = leaf_seq.size();
+            leaf_seq.push_back(it->second);
+        }
+    std::vector<uint64_t> merges;
+    uint64_t next = leaf_seq.size();
+    for (uint32_t v : t.small_first_postorder()) {
+        if (t.kids[v].empty()) continue;
+        if (t.kids[v].size() != 2 || slot[t.kids[v][0]] == UINT64_MAX || slot[t.kids[v][1]] == UINT64_MAX) {
+            cl_set_error(ctx, "Attempting execution with a tree that is not binary");
+            return CL_ERR_INVALID_ARGUMENT;
+        }
+        merges.push_back(slot[t.kids[v].front()]);
+        merges.push_back(slot[t.kids[v].back()]);
+        slot[v] = next++;
+    }
+    out->n_leaves = leaf_seq.size();
+    out->n_merges = merges.size() / 2;
+    out->leaf_sequence = (uint64_t*)malloc((leaf_seq.size() ? leaf_seq.size() : 1) * sizeof(uint64_t));
+    out->merge_children = (uint64_t*)malloc((merges.size() ? merges.size() : 1) * sizeof(uint64_t));
+    if (!out->leaf_sequence || !out->merge_children) { cl_msa_plan_free(out); return CL_ERR_OUT_OF_MEMORY; }
+    memcpy(out->leaf_sequence, leaf_seq.data(), leaf_seq.size() * sizeof(uint64_t));
+    if (!merges.empty()) memcpy(out->merge_children, merges.data(), merges.size() * sizeof(uint64_t));
+    return CL_OK;
+}
+
+void cl_msa_params_default(cl_msa_params* p) {
+    memset(p, 0, sizeof(*p));
+    cl_merge_params_default(&p->merge);
+    p->skip_calibration = 0;
+}
+
+// main() of the reference from the parsed inputs on (src/main.cpp:239-301): plan, leaf graphs, calibration (src/core.cpp:98-191 without
+// cyclisation: score_scale = mean of the leaves' intrinsic scales in leaf order), one cl_merge per tree node in execution order, then
+// explicit_cigar for two sequences, write_gfa otherwise.  Everything numerical happens behind the seams this function calls.
+int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const char* newick, const cl_msa_params* params, char** text_out,
+           uint64_t* len_out, cl_msa_stats* stats) {
+    if (!ctx || !fasta_text || !params || !text_out || !len_out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    *text_out = nullptr;
+    *len_out = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+    const auto t_all = now();
+    cl_fasta fa;
+    int rc = cl_parse_fasta(ctx, fasta_text, fasta_len, &fa);
+    if (rc) return rc;
+    if (fa.n_sequences < 2) { cl_fasta_free(&fa); cl_set_error(ctx, "FASTA input contains %llu sequence(s), cannot form an alignment", (unsigned long long)fa.n_sequences); return CL_ERR_INVALID_ARGUMENT; }
+    cl_msa_plan plan;
+    rc = cl_msa_plan_create(ctx, newick, fa.names, fa.n_sequences, &plan);
+    if (rc) { cl_fasta_free(&fa); return rc; }
+    const uint64_t n_slots = plan.n_leaves + plan.n_merges;
+    std::vector<cl_owned_base_graph*> graph(n_slots, nullptr);
+    std::vector<std::vector<uint64_t>> paths(n_slots);   // sequence indices of a slot's paths, in path order
+    cl_alignment root_aln{};
+    uint64_t root_children[2] = {0, 0};
+    cl_msa_stats st{};
+    auto fail = [&](int code) {
+        for (auto* g : graph) cl_owned_base_graph_free(g);
+        cl_alignment_free(&root_aln);
+        cl_msa_plan_free(&plan);
+        cl_fasta_free(&fa);
+        return code;
+    };
+    for (uint64_t i = 0; i < plan.n_leaves; ++i) {
+        const uint64_t s = plan.leaf_sequence[i];
+        if ((rc = cl_leaf_graph(fa.sequences[s], fa.lengths[s], &graph[i]))) { cl_set_error(ctx, "sequence %s cannot be made into a graph", fa.names[s]); return fail(rc); }
+        paths[i].assign(1, s);
+    }
+    cl_merge_params mp = params->merge;
+    if (!params->skip_calibration) {
+        const auto t = now();
+        double mean = 0.0;
+        for (uint64_t i = 0; i < plan.n_leaves; ++i) {
+            cl_base_graph v;
+            cl_owned_base_graph_view(graph[i], &v);
+            double scale = 0.0;
+            if ((rc = cl_leaf_intrinsic_scale(ctx, &v, &mp.match, &mp.align.anchor, &scale))) return fail(rc);
+            mean += scale;
+        }
+        mean /= (double)plan.n_leaves;
+        mp.align.anchor.score_scale = mean;
+        st.calibration_s = secs(t);
+    }
+    st.score_scale = mp.align.anchor.score_scale;
+    for (uint64_t k = 0; k < plan.n_merges; ++k) {
+        const uint64_t a = plan.merge_children[2 * k], b = plan.merge_children[2 * k + 1];
+        cl_base_graph g1, g2;
+        cl_owned_base_graph_view(graph[a], &g1);
+        cl_owned_base_graph_view(graph[b], &g2);
+        cl_merge_result r;
+        if ((rc = cl_merge(ctx, &g1, &g2, &mp, &r))) return fail(rc);
+        st.match_s += r.match_ms * 1e-3;
+        st.align_s += r.align_ms * 1e-3;
+        st.fuse_s += r.fuse_ms * 1e-3;
+        const uint64_t slot = plan.n_leaves + k;
+        graph[slot] = r.fused;
+        r.fused = nullptr;
+        paths[slot] = paths[a];
+        paths[slot].insert(paths[slot].end(), paths[b].begin(), paths[b].end());
+        if (k + 1 == plan.n_merges) {
+            root_aln = r.align.alignment;
+            r.align.alignment.pairs = nullptr;
+            r.align.alignment.n_pairs = 0;
+            root_children[0] = a; root_children[1] = b;
+        } else if (fa.n_sequences > 2) {   // a child is not needed again (two sequences: the CIGAR needs the leaves)
+            cl_owned_base_graph_free(graph[a]); graph[a] = nullptr;
+            cl_owned_base_graph_free(graph[b]); graph[b] = nullptr;
+        }
+        cl_merge_result_free(&r);
+    }
+    st.n_merges = plan.n_merges;
+    const uint64_t root = n_slots - 1;
+    if (fa.n_sequences == 2) {
+        // explicit_cigar(root.alignment, leaf of the FIRST sequence, leaf of the LAST one) (src/main.cpp:292-296)
+        uint64_t first = 0, last = 0;
+        for (uint64_t i = 0; i < plan.n_leaves; ++i) { if (plan.leaf_sequence[i] == 0) first = i; if (plan.leaf_sequence[i] == 1) last = i; }
+        cl_base_graph g1, g2;
+        cl_owned_base_graph_view(graph[first], &g1);
+        cl_owned_base_graph_view(graph[last], &g2);
+        (void)root_children;
+        rc = cl_explicit_cigar(&g1, &g2, root_aln.pairs, root_aln.n_pairs, text_out, len_out);
+    } else {
+        std::vector<const char*> names;
+        for (uint64_t s : paths[root]) names.push_back(fa.names[s]);
+        cl_base_graph g;
+        cl_owned_base_graph_view(graph[root], &g);
+        st.root_nodes = g.n_nodes;
+        rc = cl_write_gfa(&g, names.data(), 1, text_out, len_out);
+    }
+    if (rc) { cl_set_error(ctx, "writing the output failed"); return fail(rc); }
+    st.total_s = secs(t_all);
+    if (stats) *stats = st;
+    fail(CL_OK);
+    return CL_OK;
+}
+
+}  // extern "C"

@@ -531,6 +531,47 @@ typedef struct cl_merge_result {
 int  cl_merge(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_merge_params* params, cl_merge_result* out);
 void cl_merge_result_free(cl_merge_result* r);
 
+/* --- the front of the driver: FASTA, guide tree, the whole MSA (the rest of it) -------------------------------
+ * cl_parse_fasta: parse_fasta (src/utility.cpp:19-65): a name is the header line up to the first space; sequence lines are joined;
+ *   the same complaints (no name line, unequal or growing line lengths, empty input).
+ * cl_msa_plan_create: Tree(newick) (src/tree.cpp:39-160; NULL or "" = in_order_newick_string of the names, :17-37) followed by what
+ *   Execution's constructor does with it (src/execution.cpp:12-92): prune to the given sequence names, compact, binarize,
+ *   small_first_postorder.  Out: the leaves in the order the reference calibrates them (Execution::leaf_subproblems: tree-id order)
+ *   as indices into `names`, and the merges in execution order.  A merge's operands are SLOTS: slot i < n_leaves is leaf i of that
+ *   order, slot n_leaves + k is the result of merge k; merge_children[2k] is graph 1 of merge k (the node's first child).
+ * cl_msa: main() from the parsed inputs on (src/main.cpp:239-301): plan, leaf graphs, calibration (score_scale = mean intrinsic
+ *   scale in leaf order), cl_merge per node, then explicit_cigar for two sequences / write_gfa otherwise.  text_out is malloc'ed. */
+typedef struct cl_fasta {
+    uint64_t            n_sequences;
+    const char* const*  names;       /* NUL-terminated */
+    const char* const*  sequences;
+    const uint64_t*     lengths;
+    void*               owner;
+} cl_fasta;
+int  cl_parse_fasta(cl_context* ctx /* may be NULL */, const char* text, uint64_t len, cl_fasta* out);
+void cl_fasta_free(cl_fasta* f);
+
+typedef struct cl_msa_plan {
+    uint64_t  n_leaves;
+    uint64_t* leaf_sequence;     /* [n_leaves] index into the names given */
+    uint64_t  n_merges;
+    uint64_t* merge_children;    /* [2 * n_merges] slots of graph 1 and graph 2 */
+} cl_msa_plan;
+int  cl_msa_plan_create(cl_context* ctx /* may be NULL */, const char* newick, const char* const* names, uint64_t n_names, cl_msa_plan* out);
+void cl_msa_plan_free(cl_msa_plan* p);
+
+typedef struct cl_msa_params {
+    cl_merge_params merge;            /* merge.align.anchor.score_scale is overwritten by the calibration unless it is skipped */
+    int             skip_calibration; /* --skip-calibration of the CLI */
+} cl_msa_params;
+void cl_msa_params_default(cl_msa_params* p);
+typedef struct cl_msa_stats {
+    uint64_t n_merges, root_nodes;
+    double   score_scale, calibration_s, match_s, align_s, fuse_s, total_s;
+} cl_msa_stats;
+int  cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const char* newick /* NULL: in-order tree */,
+            const cl_msa_params* params, char** text_out, uint64_t* len_out, cl_msa_stats* stats /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
  *   ref_msa_dump      -> the CLI pipeline (src/main.cpp:239-301, include/centrolign/core.hpp:182-403) with the
  *                        stitch subproblems of every merge written out as flat arrays
  */
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +23,8 @@
 
 #include "centrolign/alignment.hpp"
 #include "centrolign/core.hpp"
+#include "centrolign/execution.hpp"
+#include "centrolign/tree.hpp"
 #include "centrolign/fuse.hpp"
 #include "centrolign/gfa.hpp"
 #include "centrolign/parameters.hpp"
@@ -885,6 +888,40 @@ void ref_result_free(cl_stitch_result* r) {
  * (Parameters defaults, src/parameters.cpp:22-108; src/main.cpp:239-301).  dump_path may be NULL.
  * skip_calibration mirrors --skip-calibration; max_num_match_pairs <= 0 keeps the default.
  * timings_out[8] = calibration, match finding, chaining, partition, extraction, subalign, fuse, total */
+/* The plan of a progressive MSA as the reference derives it: Tree(newick) (in_order_newick_string when newick is empty), then
+ * Execution's constructor (prune to the FASTA's names, compact, binarize, small_first_postorder; src/execution.cpp:12-92).  Text out:
+ * one "L <name>" line per leaf in Execution::leaf_subproblems order (the calibration order), then one "M <child1 leaves>;<child2
+ * leaves>" line per merge in execution order, leaves sorted and comma separated.  An exception's message comes back as "E <what>". */
+int ref_msa_plan(const char* newick, const char* const* names, uint64_t n_names, char** text_out) {
+    std::stringstream ss;
+    try {
+        std::vector<std::pair<std::string, std::string>> seqs;
+        std::vector<std::string> nm;
+        for (uint64_t i = 0; i < n_names; ++i) { seqs.emplace_back(names[i], "ACGT"); nm.push_back(names[i]); }
+        Tree tree(newick && *newick ? std::string(newick) : in_order_newick_string(nm));
+        Execution ex(std::move(seqs), std::move(tree), true);
+        for (auto* leaf : ex.leaf_subproblems()) ss << "L " << leaf->name << "\n";
+        auto leaves = [&](const Subproblem& sp) {
+            auto v = ex.leaf_descendents(sp);
+            std::sort(v.begin(), v.end());
+            std::string r;
+            for (size_t i = 0; i < v.size(); ++i) r += (i ? "," : "") + v[i];
+            return r;
+        };
+        while (!ex.finished()) {
+            auto t = ex.next();
+            ss << "M " << leaves(*std::get<1>(t)) << ";" << leaves(*std::get<2>(t)) << "\n";
+        }
+    } catch (std::exception& e) {
+        ss.str("");
+        ss << "E " << e.what() << "\n";
+    }
+    const std::string text = ss.str();
+    *text_out = (char*)malloc(text.size() + 1);
+    memcpy(*text_out, text.c_str(), text.size() + 1);
+    return 0;
+}
+
 int ref_msa_dump(const char* fasta_path, const char* newick_path, const char* dump_path, const char* out_path,
                  int skip_calibration, long long max_num_match_pairs, int verbosity, double* timings_out) {
     try {

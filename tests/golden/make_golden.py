@@ -276,7 +276,49 @@ def exhaustive_goldens():
     np.savez_compressed(os.path.join(HERE, "exhaustive_chains.npz"), **out)
 
 
+PLAN_CASES = [
+    # (newick or "" for the in-order tree, sequence names in FASTA order)
+    ("((((s0,s1),(s2,s3)),s4),(((s5,s6),(s7,s8)),s9));", ["s%d" % i for i in range(10)]),
+    ("", ["a", "b", "c", "d"]),
+    ("((a,b),(c,(d,e)),f);", list("abcdef")),                       # a polytomy at the root
+    ("((a,b,c,d,e)x,(f,g)y)z;", list("abcdefg")),                   # a five-way polytomy, internal labels
+    ("((a,b)x,(c)y);", ["a", "c"]),                                 # leaves of the tree without a sequence, unary nodes
+    ("(((((a)))),((b,(c))));", ["c", "a", "b"]),                    # chains of unary nodes; FASTA order differs from the tree's
+    ('( "seq one" : 0.5 , ( "s,2" :1e-3, s3:2 ) "in(ner" : 0.1 ) ;', ["seq one", "s,2", "s3"]),   # quotes, distances, blanks
+    ("(a:1,(b:2,(c:3,(d:4,(e:5,f:6)))));", list("fedcba")),         # a caterpillar
+    ("((a,b),(c,d),(e,f),(g,h));", list("abcdefgh")),               # four cherries under one node
+    ("((a,b),((c,d),(e,(f,(g,h)))),i,j);", list("acegij")),         # pruning changes subtree sizes
+    ("(a,b,c);", ["a", "b"]),
+    ("a;", ["a"]),
+    ("((a,b),(c,d))", list("abcd")),                                # no terminating ';'
+    ("((a,b),(a,d));", list("abd")),                                # duplicate label
+    ("((a,b),(c,d));", list("abce")),                               # a sequence the tree does not have
+    ("((a,b)c,d);", list("acd")),                                   # a sequence that is not a leaf
+    ("((a,b),(c,d)); x", list("abcd")),                             # text after the ';'
+]
+
+
+def plan_goldens():
+    # 17. the order of work: Tree(newick) + Execution (prune / compact / binarize / small_first_postorder) on odd guide trees, as text
+    #     (oracle/ref_driver.cpp ref_msa_plan); and parse_fasta on a few inputs
+    import ctypes as C
+    import json
+    lib = po.ref_lib()
+    lib.ref_msa_plan.restype = C.c_int
+    lib.ref_msa_plan.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint64, C.POINTER(C.c_char_p)]
+    out = []
+    for nwk, names in PLAN_CASES:
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        txt = C.c_char_p()
+        lib.ref_msa_plan(nwk.encode(), arr, len(names), C.byref(txt))
+        out.append({"newick": nwk, "names": names, "plan": txt.value.decode()})
+        print(repr(nwk), "->", txt.value.decode().replace("\n", " | "))
+    json.dump(out, open(os.path.join(HERE, "msa_plans.json"), "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "plans":
+        return plan_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "exhaustive":
         return exhaustive_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "msa_big":

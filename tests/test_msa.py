@@ -87,3 +87,25 @@ def test_gpu_ten_sequence_msa_30k(gpu_ctx, workers):
     want = dict(zip(ZB["msa10_30k.sub_leaves"].tolist(), ZB["msa10_30k.sub_sha256"].tolist()))
     got = {",".join(sorted(m["paths"])): hashlib.sha256(capi.write_gfa(m["fused"], m["paths"])).hexdigest() for m in r["stats"]["kept"]}
     assert got == want and len(got) == 9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", H.msa_cases()[:4], ids=lambda c: c[0])
+def test_gpu_cl_msa_is_the_cli_flow(gpu_ctx, case):
+    """cl_msa: FASTA text + Newick text in, the reference's output text out — parse_fasta, Tree / Execution order, calibration, merges
+    and writer all inside the library, no Python driver"""
+    name, n, length, seed, budget = case
+    seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+    names = ["seq%d" % i for i in range(n)]
+    fasta = "".join(">%s\n%s\n" % (nm, "\n".join(s[i:i + 80] for i in range(0, len(s), 80))) for nm, s in zip(names, seqs))
+    text, st = gpu_ctx.msa(fasta, msa.newick(msa.balanced_tree(names)) + ";", max_num_match_pairs=budget)
+    want = bytes(Z[name])
+    assert text == (want.rstrip(b"\n") if n == 2 else want) and st["n_merges"] == n - 1
+
+
+@pytest.mark.gpu
+def test_gpu_cl_msa_ten_sequences(gpu_ctx):
+    names, seqs, _ = synth.c3_workload(30000)
+    fasta = "".join(">%s some description\n%s\n" % (nm, seqs[nm]) for nm in names)
+    text, st = gpu_ctx.msa(fasta, synth.C3_NEWICK, max_num_match_pairs=200000)
+    assert text == bytes(ZB["msa10_30k.gfa"])
