@@ -957,6 +957,19 @@ def load_library(path=None):
     lib.cl_merge.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MergeParams), C.POINTER(MergeResultC)]
     lib.cl_merge_result_free.restype = None
     lib.cl_merge_result_free.argtypes = [C.POINTER(MergeResultC)]
+    lib.cl_parse_fasta.restype = C.c_int
+    lib.cl_parse_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(FastaC)]
+    lib.cl_fasta_free.restype = None
+    lib.cl_fasta_free.argtypes = [C.POINTER(FastaC)]
+    lib.cl_msa_plan_create.restype = C.c_int
+    lib.cl_msa_plan_create.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint64, C.POINTER(MsaPlanC)]
+    lib.cl_msa_plan_free.restype = None
+    lib.cl_msa_plan_free.argtypes = [C.POINTER(MsaPlanC)]
+    lib.cl_msa_params_default.restype = None
+    lib.cl_msa_params_default.argtypes = [C.POINTER(MsaParams)]
+    lib.cl_msa.restype = C.c_int
+    lib.cl_msa.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.POINTER(MsaParams), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                           C.POINTER(MsaStats)]
     lib.cl_match_params_default.restype = None
     lib.cl_match_params_default.argtypes = [C.POINTER(MatchParams)]
     lib.cl_find_matches.restype = C.c_int

@@ -27,6 +27,12 @@
 
 #include "popoa_device.h"
 
+// The systolic moves below are the whole-wave DPP controls wave_shr:1 / wave_shl:1, which exist on the GFX9 family with 64-wide waves
+// only; built for anything else the kernel would be rejected by the backend or, worse, compute wrong DP values without a diagnostic.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "popoa_linear.hip is written for gfx950 (MI355X): build with --offload-arch=gfx950"
+#endif
+
 namespace {
 
 __device__ __forceinline__ int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-2 evidence for profiles/: (1) rocprofv3 kernel stats of the bench command, (2) HBM bytes per kernel launch from the PMC
+# counters, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; MI355X_MICROARCH.md "rocprofv3 PMC slots"),
+# (3) the VALU / LDS issue counters of the same kernels.  PMC passes carry --kernel-trace only (no other trace domain).
+# Run via gpurun from the repo root; the program itself follows "--" (no wrapper).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16
+cd /tmp
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --workers 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o r02 -- python3 $R/bench.py $ARGS > $OUT/prof_bench.json 2>$OUT/prof_bench.err
+rm -f $OUT/prof_bench/r02_kernel_trace.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_$c.json 2>$OUT/pmc_$c.err
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_SQ.json 2>$OUT/pmc_SQ.err
+cd $R
+python3 scripts/pmc_summary.py $OUT | tee $OUT/pmc_summary.txt | head -60
+for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do rm -f $OUT/$d/*kernel_trace.csv; ls -la $OUT/$d | head -5; done
