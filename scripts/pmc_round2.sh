@@ -19,4 +19,6 @@ done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_SQ.json 2>$OUT/pmc_SQ.err
 cd $R
 python3 scripts/pmc_summary.py $OUT | tee $OUT/pmc_summary.txt | head -60
-for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do rm -f $OUT/$d/*kernel_trace.csv; ls -la $OUT/$d | head -5; done
+# the per-dispatch CSVs are hundreds of MB (gpurun copies back at most 64 MiB): only the summaries travel
+for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do rm -f $OUT/$d/*kernel_trace.csv $OUT/$d/*counter_collection.csv; done
+du -sh $OUT
