@@ -27,6 +27,8 @@
 #include "stitch_host.hpp"
 #include "wfa_host.hpp"
 
+hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
+                               const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
@@ -39,6 +41,8 @@ thread_local std::string g_error;
 
 // test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
+const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
+constexpr uint64_t kSysLdsBytes = 120 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
 constexpr uint64_t kRingLdsBytes = 64 * 1024;   // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU)
 // test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
@@ -794,9 +798,25 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // the ring variant also stages the subproblem's topology in LDS: offsets, predecessor ranks, labels
             const uint64_t n_pred = (poff[0].back() - poff[0][d.node_base[0]]) + (poff[1].back() - poff[1][d.node_base[1]]);
             const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2) * 8 + n_pred * 4 + ((uint64_t)d.n1 + d.n2 + 2) * (1 + npw) * 4 + 16;   // node records, lists, boundaries
+            // the systolic kernel (popoa_sys_kernel): the shorter graph's rows on the threads, a ring of H columns per row in LDS,
+            // H a power of two above the sum of the two predecessor spans (then every read is an LDS read)
+            const uint64_t n_rows = std::min(d.n1, d.n2) + 1, n_cols = std::max(d.n1, d.n2);
+            // ... or, when that does not fit (or exceeds 256 columns), as many as do (at least 8): the rare reads that reach further
+            // back go to the HBM planes
+            uint32_t sys_log = 0;
+            while ((1ull << sys_log) < span[0] + span[1] + 1 && sys_log < 8) ++sys_log;
+            auto sys_need = [&](uint32_t lg) { return ((n_rows * (1ull << lg) * (uint64_t)(1 + 2 * npw) + 1) & ~1ull) * 4 + n_cols * 8 + n_pred * 4 + 16; };
+            while (sys_log > 3 && sys_need(sys_log) > kSysLdsBytes) --sys_log;
+            const uint64_t sys_h = 1ull << sys_log, sys_bytes = sys_need(sys_log);
+            const bool sys_full = sys_h >= span[0] + span[1] + 1;
+            const bool take_sys = !g_no_sys && n_rows <= 1024 && (sys_log >= 3 || sys_full) && sys_bytes <= kSysLdsBytes;
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
-            if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
+            if (take_sys) {
+                d.kind = CL_KIND_SYS;
+                d.pad = (uint16_t)(sys_log | (sys_full ? 0x4000u : 0u) | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | ring serves every read | rows = graph 2
+                ring_need.push_back((uint32_t)sys_bytes);
+            } else if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
                 d.pad = (uint16_t)(depth | (depth >= span[0] + span[1] + 1 ? 0x8000u : 0u));   // bit 15: the ring serves every read
                 ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
             } else ring_need.push_back(0);
@@ -871,13 +891,29 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 }
                 close_group(grp);
             }
+    for (int bi = 2; bi >= 0; --bi)
+        for (int npw = 3; npw >= 1; --npw) {
+            LaunchGroup grp;
+            grp.kind = CL_KIND_SYS; grp.npw = npw; grp.block = blocks[bi];
+            grp.first = (uint32_t)plist.size();
+            for (uint32_t i = 0; i < pl->desc.size(); ++i) {
+                const ClProbDesc& d = pl->desc[i];
+                const uint32_t rows = std::min(d.n1, d.n2) + 1;
+                const int b = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
+                if (d.kind == CL_KIND_SYS && d.npw == npw && b == bi) {
+                    plist.push_back(i);
+                    grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
+                }
+            }
+            close_group(grp);
+        }
     // longest-running launch first: a group's duration is set by its longest anti-diagonal sweep
     {
         auto crit = [&](const LaunchGroup& g) {
             uint64_t c = 0;
             for (uint32_t i = g.first; i < g.first + g.count; ++i)
                 c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
-            return c * (g.kind == CL_KIND_GENERAL ? 8 : 1);
+            return c * (g.kind == CL_KIND_GENERAL ? 8 : g.kind == CL_KIND_SYS ? 2 : 1);
         };
         std::stable_sort(pl->groups.begin(), pl->groups.end(), [&](const LaunchGroup& x, const LaunchGroup& y) { return crit(x) > crit(y); });
     }
@@ -926,6 +962,8 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
         if (timed && g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
         if (g.kind == CL_KIND_LINEAR)
             HIP_TRY(ctx, cl_launch_popoa_linear(g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
+        else if (g.kind == CL_KIND_SYS)
+            HIP_TRY(ctx, cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
         else
             HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
         if (timed && g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->aux[si]));
@@ -1009,6 +1047,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
     if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
+    else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
     else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);
     out->n_problems = g.count;
     out->dp_cells = g.cells;

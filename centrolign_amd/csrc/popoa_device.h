@@ -13,7 +13,7 @@
 #define CL_NEG_INF (INT32_MIN / 2)  // cell_t::mininf, alignment.hpp:740
 
 // kernel families
-enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1 };
+enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1, CL_KIND_SYS = 2 };   // SYS: the systolic DAG kernel (popoa_sys_kernel)
 
 struct ClProbDesc {
     uint32_t n1, n2;          // node counts (both > 0)

@@ -234,6 +234,208 @@ __device__ void traceback(const ClDeviceBatch& B, const ClProbDesc& pd, const Di
     B.out_status[prob] = status;
 }
 
+// The same traceback walked by the first WAVE of the workgroup.  Rule for rule it is the function above (one lane executes exactly that
+// code for a step that needs it); what the other 63 lanes add is look-ahead over the stretches where the walk has no choice to make:
+//   * diagonal run (state "match"): lane i looks at cell (a - i, b - i).  While both nodes have exactly one predecessor, the node of
+//     rank one less, and are not sources, the only candidate pair is (a - i - 1, b - i - 1); and while the cell's M equals none of its
+//     I_k / D_k the walk stays in the match state and takes that pair (M = s + M(pair) then holds by construction).  The lanes test
+//     this for 64 cells at once, a ballot finds the end of the run, the run is emitted in one go;
+//   * gap run (state I_k or D_k): lane i looks at the cell i steps up (left); with a single predecessor the step either re-opens
+//     (I_k == M(pred) - open - extend, tested first, alignment.hpp:1105-1118) — the run ends there, back in the match state — or extends.
+// A whole-repeat deletion between two MSA graphs is a gap run of two thousand cells: thirty-odd round trips instead of two thousand
+// dependent loads.
+template <int NPW>
+__device__ void traceback_wave(const ClDeviceBatch& B, const ClProbDesc& pd, const DiagGeom& G, const Planes<NPW>& pl,
+                               const ClScoreParams& P, uint32_t prob) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint8_t* lab1 = B.lab[0] + pd.node_base[0];
+    const uint8_t* lab2 = B.lab[1] + pd.node_base[1];
+    const uint32_t* poff1 = B.poff[0] + pd.node_base[0];
+    const uint32_t* poff2 = B.poff[1] + pd.node_base[1];
+    const uint32_t* snk1 = B.snk[0] + pd.snk_base[0];
+    const uint32_t* snk2 = B.snk[1] + pd.snk_base[1];
+    const int32_t* Mp = pl.M();
+    uint32_t a = 0, b = 0, status = 0, len = 0;
+    int32_t best = 0;
+    int have_i = 0;
+    if (lane == 0) {   // first strictly better in the given sink order (:982-989)
+        bool have = false;
+        for (uint32_t i = 0; i < pd.snk_cnt[0]; ++i)
+            for (uint32_t j = 0; j < pd.snk_cnt[1]; ++j) {
+                int32_t v = Mp[G.idx(snk1[i], snk2[j])];
+                if (!have || v > best) { have = true; best = v; a = snk1[i]; b = snk2[j]; }
+            }
+        B.out_score[prob] = have ? best : 0;
+        have_i = have ? 1 : 0;
+    }
+    a = __shfl(a, 0); b = __shfl(b, 0); have_i = __shfl(have_i, 0);
+    const uint32_t cap = pd.n1 + pd.n2;
+    uint2* out = B.out_pairs + pd.out_base;
+    int comp = 0;
+    // a node (1-based rank r >= 1) of graph g is "plain" when its only predecessor is rank r - 1 >= 1 ... or, for r == 1, when it
+    // has no predecessor and is a source (its only predecessor is then the boundary index 0 = r - 1)
+    auto plain1 = [&](uint32_t r) -> bool {
+        const uint32_t e0 = poff1[r - 1], e1 = poff1[r];
+        const bool src = lab1[r - 1] >> 7;
+        if (r == 1) return e1 == e0 && src;
+        return e1 - e0 == 1 && !src && B.pidx[0][e0] == r - 1;
+    };
+    auto plain2 = [&](uint32_t r) -> bool {
+        const uint32_t e0 = poff2[r - 1], e1 = poff2[r];
+        const bool src = lab2[r - 1] >> 7;
+        if (r == 1) return e1 == e0 && src;
+        return e1 - e0 == 1 && !src && B.pidx[1][e0] == r - 1;
+    };
+    while (have_i) {
+        if (len >= cap) { status = 2; break; }
+        // ---- look-ahead ------------------------------------------------------------------------------------------------
+        uint32_t run = 0;
+        bool run_opens = false;
+        if (comp == 0) {
+            bool ok = false;
+            if (lane < a && lane < b) {
+                const uint32_t ai = a - lane, bi = b - lane;
+                const uint32_t c = G.idx(ai, bi);
+                const int32_t Mv = Mp[c];
+                bool closes = false;
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) closes = closes || Mv == pl.I(k)[c] || Mv == pl.D(k)[c];
+                // the step whose only candidate is the corner (0, 0) ends the walk (the corner's M is -inf in memory): not part of a run
+                ok = !closes && !(ai == 1 && bi == 1) && plain1(ai) && plain2(bi);
+            }
+            const unsigned long long m = __ballot(ok);
+            run = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+            run = min(run, cap - len);
+            if (run) {
+                if (lane < run) out[cap - 1 - (len + lane)] = make_uint2(a - lane, b - lane);
+                len += run; a -= run; b -= run;
+                // the pair reached is (a, b) with the boundary index 0 standing for "nothing left"; the walk ends when the state has no
+                // predecessor, which the single step below finds out
+                continue;
+            }
+        } else if (comp > 0) {
+            const int k = comp - 1;
+            bool ok = false, opens = false;
+            if (lane < a && b) {   // gap runs along the boundary column (b == 0) are left to the single step
+                const uint32_t ai = a - lane;
+                if (plain1(ai)) {
+                    const uint32_t c = G.idx(ai, b), pc = G.idx(ai - 1, b);
+                    const int32_t Iv = pl.I(k)[c];
+                    opens = Iv == Mp[pc] - P.oe[k];
+                    ok = opens || Iv == pl.I(k)[pc] - P.ext[k];
+                }
+            }
+            const unsigned long long m = __ballot(ok), mo = __ballot(opens);
+            run = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+            const unsigned long long first_open = mo & (run >= 64 ? ~0ull : ((1ull << run) - 1));
+            if (first_open) { run = (uint32_t)__builtin_ctzll(first_open) + 1; run_opens = true; }
+            run = min(run, cap - len);
+            if (run) {
+                if (lane < run) out[cap - 1 - (len + lane)] = make_uint2(a - lane, 0u);
+                len += run; a -= run;
+                if (run_opens) comp = 0;
+                continue;
+            }
+        } else {
+            const int k = -comp - 1;
+            bool ok = false, opens = false;
+            if (lane < b && a) {
+                const uint32_t bi = b - lane;
+                if (plain2(bi)) {
+                    const uint32_t c = G.idx(a, bi), pc = G.idx(a, bi - 1);
+                    const int32_t Dv = pl.D(k)[c];
+                    opens = Dv == Mp[pc] - P.oe[k];
+                    ok = opens || Dv == pl.D(k)[pc] - P.ext[k];
+                }
+            }
+            const unsigned long long m = __ballot(ok), mo = __ballot(opens);
+            run = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+            const unsigned long long first_open = mo & (run >= 64 ? ~0ull : ((1ull << run) - 1));
+            if (first_open) { run = (uint32_t)__builtin_ctzll(first_open) + 1; run_opens = true; }
+            run = min(run, cap - len);
+            if (run) {
+                if (lane < run) out[cap - 1 - (len + lane)] = make_uint2(0u, b - lane);
+                len += run; b -= run;
+                if (run_opens) comp = 0;
+                continue;
+            }
+        }
+        // ---- one step by the rules of the reference, on lane 0 ----------------------------------------------------------
+        uint32_t na = 0xFFFFFFFFu, nb = 0xFFFFFFFFu;
+        int ncomp = comp;
+        uint32_t st = 0, emitted = 0;
+        if (lane == 0) {
+            const uint32_t c = G.idx(a, b);
+            const int32_t Mv = Mp[c];
+            if (ncomp == 0) {  // gap close test order I_0, D_0, I_1, D_1, ... (:1048-1066)
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) {
+                    if (Mv == pl.I(k)[c]) { ncomp = k + 1; break; }
+                    if (Mv == pl.D(k)[c]) { ncomp = -k - 1; break; }
+                }
+            }
+            uint32_t e1b = 0, e1e = 0, e2b = 0, e2e = 0, x1 = 0, x2 = 0, l1 = 0, l2 = 0;
+            if (a) { e1b = poff1[a - 1]; e1e = poff1[a]; l1 = lab1[a - 1]; x1 = l1 >> 7; }
+            if (b) { e2b = poff2[b - 1]; e2e = poff2[b]; l2 = lab2[b - 1]; x2 = l2 >> 7; }
+            if (ncomp == 0) {
+                if (!a || !b) st = 3;
+                else {
+                    out[cap - 1 - len] = make_uint2(a, b);
+                    emitted = 1;
+                    const int32_t s = ((l1 & 0x7f) == (l2 & 0x7f)) ? P.match : -P.mismatch;
+                    // the inner break leaves only the inner loop: LAST prev1 with a hit, its FIRST prev2 (:1091-1099)
+                    for (uint32_t e = e1b; e < e1e + x1; ++e) {
+                        uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
+                        for (uint32_t f = e2b; f < e2e + x2; ++f) {
+                            uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
+                            if (Mp[G.idx(pa, pb)] + s == Mv) { na = pa; nb = pb; break; }
+                        }
+                    }
+                }
+            } else if (ncomp > 0) {
+                if (!a) st = 3;
+                else {
+                    out[cap - 1 - len] = make_uint2(a, 0u);
+                    emitted = 1;
+                    const int k = ncomp - 1;
+                    const int32_t Iv = pl.I(k)[c];
+                    for (uint32_t e = e1b; e < e1e + x1; ++e) {  // open before extend, first predecessor wins (:1105-1118)
+                        uint32_t pa = e < e1e ? B.pidx[0][e] : 0u;
+                        uint32_t pc = G.idx(pa, b);
+                        if (Iv == Mp[pc] - P.oe[k]) { ncomp = 0; na = pa; nb = b; break; }
+                        if (Iv == pl.I(k)[pc] - P.ext[k]) { na = pa; nb = b; break; }
+                    }
+                }
+            } else {
+                if (!b) st = 3;
+                else {
+                    out[cap - 1 - len] = make_uint2(0u, b);
+                    emitted = 1;
+                    const int k = -ncomp - 1;
+                    const int32_t Dv = pl.D(k)[c];
+                    for (uint32_t f = e2b; f < e2e + x2; ++f) {  // (:1123-1136)
+                        uint32_t pb = f < e2e ? B.pidx[1][f] : 0u;
+                        uint32_t pc = G.idx(a, pb);
+                        if (Dv == Mp[pc] - P.oe[k]) { ncomp = 0; na = a; nb = pb; break; }
+                        if (Dv == pl.D(k)[pc] - P.ext[k]) { na = a; nb = pb; break; }
+                    }
+                }
+            }
+        }
+        na = __shfl(na, 0); nb = __shfl(nb, 0); ncomp = __shfl(ncomp, 0); st = __shfl(st, 0); emitted = __shfl(emitted, 0);
+        len += emitted;
+        comp = ncomp;
+        if (st) { status = st; break; }
+        if (na == 0xFFFFFFFFu) break;
+        a = na;
+        b = nb;
+    }
+    if (lane == 0) {
+        B.out_len[prob] = len;
+        B.out_status[prob] = status;
+    }
+}
+
 template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
@@ -261,7 +463,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, c
         off += cnt;
         __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
     }
-    if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
+    if (tid < 64) traceback_wave<NPW>(B, pd, G, pl, P, prob);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -458,7 +660,196 @@ __global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, cons
         }
     }
     __syncthreads();
-    if (tid == 0) traceback<NPW>(B, pd, G, pl, P, prob);
+    if (tid < 64) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// popoa_sys_kernel: any DAG pair whose SHORTER graph has at most BLOCK - 1 nodes, swept as a systolic array like the chain kernel
+// (popoa_linear.hip) instead of anti-diagonal by anti-diagonal.  Thread r owns ROW r (rank r of the shorter graph, row 0 = the
+// boundary "nothing consumed yet") for the whole sweep and at step t works on column t - r, so the three cells a cell needs —
+// (p, c), (r, q), (p, q) for predecessors p of its row and q of its column — were finished (r - p), (c - q) and (r - p) + (c - q) steps
+// earlier.  Every row keeps its last H columns in an LDS ring ([row][column & (H - 1)][plane], H a power of two above the sum of
+// the two graphs' predecessor spans), so every read is an LDS read of a few consecutive words, the address arithmetic is a
+// shift and a mask, the row's own topology sits in registers and the column's arrives as one 8-byte LDS record.  One step costs a
+// wave two dependent LDS round trips; a whole-repeat indel between two MSA graphs (83 x 4 398, 7 x 2 051: thousands of anti-
+// diagonals of a few cells) is swept at that pace instead of a barrier and a round of global loads per anti-diagonal.
+// The int32 planes still go to HBM (fire and forget, anti-diagonal-major as before): the traceback below reads them.
+// A predecessor further back than the ring reaches (the end of a bubble whose branches differ by thousands of nodes) is read from the
+// HBM planes, which are then drained every H / 2 steps (ClProbDesc::pad bit 14 says the ring serves every read and nothing is waited for).
+// ClProbDesc::pad bit 15: graph 2 is the shorter one (rows = graph 2: the roles of I and D swap).
+template <int NPW, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
+    extern __shared__ int32_t lds[];
+    constexpr int PL = 1 + 2 * NPW;
+    const uint32_t prob = plist[blockIdx.x];
+    const ClProbDesc pd = B.desc[prob];
+    const DiagGeom G(pd.n1, pd.n2);
+    Planes<NPW> pl;
+    pl.base = B.planes + pd.plane_base;
+    pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
+    const uint32_t tid = threadIdx.x;
+    // ClProbDesc::pad: bits 0-4 log2 of the ring length H, bit 14: the ring serves every read, bit 15: rows = graph 2
+    const bool swap = pd.pad & 0x8000u, full = pd.pad & 0x4000u;
+    const uint32_t H = 1u << (pd.pad & 31u), hm = H - 1;
+    const int sR = swap ? 1 : 0, sC = 1 - sR;
+    const uint32_t nR = swap ? pd.n2 : pd.n1, nC = swap ? pd.n1 : pd.n2;
+    // LDS (int32 units): ring [nR + 1][H][PL] | column records [nC] (uint2) | row predecessor lists | column predecessor lists
+    int32_t* ring = lds;
+    uint2* recC = reinterpret_cast<uint2*>(lds + (((size_t)(nR + 1) * H * PL + 1) & ~(size_t)1));
+    const uint32_t* gpR = B.poff[sR] + pd.node_base[sR];
+    const uint32_t* gpC = B.poff[sC] + pd.node_base[sC];
+    const uint32_t eR0 = gpR[0], eR1 = gpR[nR], eC0 = gpC[0], eC1 = gpC[nC];
+    uint32_t* plR = reinterpret_cast<uint32_t*>(recC + nC);
+    uint32_t* plC = plR + (eR1 - eR0);
+    for (uint32_t i = tid; i < eR1 - eR0; i += BLOCK) plR[i] = B.pidx[sR][eR0 + i];
+    for (uint32_t i = tid; i < eC1 - eC0; i += BLOCK) plC[i] = B.pidx[sC][eC0 + i];
+    {
+        const uint8_t* gl = B.lab[sC] + pd.node_base[sC];
+        for (uint32_t i = tid; i < nC; i += BLOCK) {
+            const uint32_t b0 = gpC[i] - eC0, deg = gpC[i + 1] - gpC[i], l = gl[i];
+            recC[i] = make_uint2(deg == 1 ? B.pidx[sC][gpC[i]] : b0, (deg & 0xFFFFu) | ((l & 0x7Fu) << 16) | ((l >> 7) << 31));
+        }
+    }
+    // this thread's row (rows beyond nR idle)
+    const uint32_t r = tid;
+    uint32_t degR = 0, firstR = 0, labR = 0;
+    bool srcR = false;
+    if (r >= 1 && r <= nR) {
+        const uint32_t l = (B.lab[sR] + pd.node_base[sR])[r - 1];
+        degR = gpR[r] - gpR[r - 1];
+        firstR = degR == 1 ? B.pidx[sR][gpR[r - 1]] : gpR[r - 1] - eR0;
+        labR = l & 0x7Fu;
+        srcR = l >> 7;
+    }
+    __syncthreads();
+    int32_t* my_row = ring + (size_t)r * H * PL;
+    const uint32_t last = nR + nC;
+    uint32_t off = 0;   // G.off(t): cells on the anti-diagonals before t
+    uint32_t t = 0;
+    // cell (row, col) as {M, V_k, H_k}: from the row's ring while the row has not moved H columns past col (at step t it is at column
+    // t - row), else from the HBM planes (written at least H steps ago and drained since)
+    int32_t far_buf[PL];
+    auto cell = [&](uint32_t row, uint32_t col) -> const int32_t* {
+        if (full || t - row - col < H) return ring + ((size_t)row * H + (col & hm)) * PL;
+        const uint32_t idx = swap ? G.idx(col, row) : G.idx(row, col);
+        // L1-bypassing loads: the line may sit in this CU's L1 from before the cell was written
+        far_buf[0] = __hip_atomic_load(pl.M() + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int32_t iv = __hip_atomic_load(pl.I(k) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t dv = __hip_atomic_load(pl.D(k) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            far_buf[1 + k] = swap ? dv : iv;
+            far_buf[1 + NPW + k] = swap ? iv : dv;
+        }
+        return far_buf;
+    };
+    for (; t <= last; ++t) {
+        const uint32_t lo_d = G.lo(t), cnt_d = G.hi(t) - lo_d + 1;
+        if (r <= nR && t >= r && t - r <= nC) {
+            const uint32_t c = t - r;
+            int32_t M = CL_NEG_INF, V[NPW], Hh[NPW];
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; Hh[k] = CL_NEG_INF; }
+            uint32_t degC = 0, firstC = 0, labC = 0;
+            bool srcC = false;
+            if (c) {
+                const uint2 rc = recC[c - 1];
+                degC = rc.y & 0xFFFFu; firstC = rc.x; labC = (rc.y >> 16) & 0x7Fu; srcC = rc.y >> 31;
+            }
+            if (r && !c) {          // boundary column: gap extensions down the row graph (alignment.hpp:832-845)
+                for (uint32_t e = 0; e < degR; ++e) {
+                    const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                    const int32_t* x = cell(p, 0);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], x[1 + k] - P.ext[k]);
+                }
+                if (srcR) {
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], -P.oe[k]);
+                }
+            } else if (!r && c) {   // boundary row (:864-877)
+                for (uint32_t f = 0; f < degC; ++f) {
+                    const uint32_t q = degC == 1 ? firstC : plC[firstC + f];
+                    const int32_t* x = cell(0, q);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], x[1 + NPW + k] - P.ext[k]);
+                }
+                if (srcC) {
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], -P.oe[k]);
+                }
+            } else if (r && c) {    // interior (:897-938 in pull form, see compute_cell)
+                for (uint32_t e = 0; e < degR; ++e) {
+                    const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                    const int32_t* x = cell(p, c);
+                    const int32_t m = x[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m - P.oe[k], x[1 + k] - P.ext[k]));
+                }
+                if (srcR) {
+                    const int32_t m = cell(0, c)[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], m - P.oe[k]);
+                }
+                const int32_t s = (labR == labC) ? P.match : -P.mismatch;
+                for (uint32_t f = 0; f < degC; ++f) {
+                    const uint32_t q = degC == 1 ? firstC : plC[firstC + f];
+                    const int32_t* x = cell(r, q);
+                    const int32_t m = x[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], x[1 + NPW + k] - P.ext[k]));
+                    for (uint32_t e = 0; e < degR; ++e) {
+                        const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                        M = imax(M, cell(p, q)[0] + s);
+                    }
+                    if (srcR) M = imax(M, cell(0, q)[0] + s);
+                }
+                if (srcC) {
+                    const int32_t m = cell(r, 0)[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], m - P.oe[k]);
+                    for (uint32_t e = 0; e < degR; ++e) {
+                        const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                        M = imax(M, cell(p, 0)[0] + s);
+                    }
+                    if (srcR) M = imax(M, s);   // the corner counts as 0 (:814-818)
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) M = imax(M, imax(V[k], Hh[k]));
+            int32_t* w = my_row + (size_t)(c & hm) * PL;
+            w[0] = M;
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) { w[1 + k] = V[k]; w[1 + NPW + k] = Hh[k]; }
+            // the planes in graph-1 / graph-2 terms: I consumes a graph-1 node, D a graph-2 node
+            const uint32_t a = swap ? c : r;
+            const uint32_t self_idx = off + (a - lo_d);
+            pl.M()[self_idx] = M;
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) {
+                pl.I(k)[self_idx] = swap ? Hh[k] : V[k];
+                pl.D(k)[self_idx] = swap ? V[k] : Hh[k];
+            }
+        }
+        off += cnt_d;
+        if (!full && (t & ((H >> 1) - 1)) == 0) {
+            __syncthreads();   // vmcnt(0): cells written H / 2 or more steps ago are in memory for the far reads
+        } else if (BLOCK > 64) {   // LDS traffic only
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    }
+    __syncthreads();   // vmcnt(0): every plane value is in memory
+    if (tid < 64) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+}
+
+template <int NPW>
+void launch_sys_npw(int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P,
+                    hipStream_t stream) {
+    if (block <= 64) hipLaunchKernelGGL((popoa_sys_kernel<NPW, 64>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P);
+    else if (block <= 256) hipLaunchKernelGGL((popoa_sys_kernel<NPW, 256>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P);
+    else hipLaunchKernelGGL((popoa_sys_kernel<NPW, 1024>), dim3(n_blocks), dim3(1024), lds_bytes, stream, B, plist, P);
 }
 
 template <int NPW>
@@ -485,6 +876,32 @@ void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const
 
 // host-callable launcher (C++ linkage, used by cl_api.cpp only)
 // ring_bytes > 0: the LDS-ring variant (every problem of the launch has its ring depth in ClProbDesc::pad and fits ring_bytes)
+hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
+                               const ClScoreParams& P, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    static bool attr_set = false;   // more than 64 KB of dynamic LDS needs the opt-in once per function
+    if (!attr_set) {
+        attr_set = true;
+        const int cap = 128 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    }
+    switch (npw) {
+    case 1: launch_sys_npw<1>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
+    case 2: launch_sys_npw<2>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
+    case 3: launch_sys_npw<3>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;

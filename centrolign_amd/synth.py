@@ -214,6 +214,17 @@ def random_dag_batch(n_problems, seed=0, max_n=40, extra_edge_p=0.3, skip_max=4,
     return StitchBatch(b1.finish(), b2.finish(), (rng.random(n_problems) < 0.2).astype(np.uint8))
 
 
+def sized_dag_batch(sizes, seed=0, extra_edge_p=0.15, skip_max=4, alphabet=4, n_alt=2):
+    """graph pairs with bubbles of the given (n1, n2) sizes — lopsided and large matrices for the graph x graph kernels"""
+    rng = np.random.default_rng(seed)
+    b1, b2 = _SideBuilder(), _SideBuilder()
+    for n1, n2 in sizes:
+        for bld, n in ((b1, n1), (b2, n2)):
+            lab, edges, src, snk = _random_dag(rng, n, extra_edge_p, skip_max, int(rng.integers(0, n_alt + 1)), int(rng.integers(0, n_alt + 1)), alphabet)
+            bld.add_graph(lab, edges, src, snk, rng.integers(0, 1 << 40, size=n, dtype=np.uint64))
+    return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
+
+
 def hor_stitch_batch(seed, total_len, min_anchor=20, seq_div=0.005, hor_div=0.02, indel_hor=2, max_cells=40000000):
     """between-anchor subproblems of a simulated HOR pair (see module docstring).  Returns (batch, info)."""
     (s1, s2), (a1, a2) = hor_sequences(seed, total_len, 2, seq_div=seq_div, hor_div=hor_div, indel_hor=indel_hor,

@@ -170,3 +170,20 @@ def test_error_reporting(gpu_ctx):
     with pytest.raises(capi.ClError) as e:
         gpu_ctx.stitch_batch_align(capi.StitchBatch(b1.finish(), b2.finish(), np.zeros(1, np.uint8)))
     assert e.value.code == -7
+
+
+def test_lopsided_and_large_dag_pairs(gpu_ctx):
+    """graph x graph matrices far from square (a whole-repeat indel between two MSA graphs: 7 x 2 051, 83 x 4 398) in both orientations,
+    mid-size squares, a 2 000 x 2 000 pair and a 10 M-cell pair, against the oracle: the systolic kernel (shorter side on the threads,
+    either graph), the LDS-ring and the HBM-plane kernels all take part"""
+    sizes = [(7, 2051), (2051, 7), (83, 4398), (4398, 83), (60, 3000), (200, 2500), (2500, 200), (1, 900), (900, 1), (63, 64), (64, 63),
+             (255, 256), (256, 255), (500, 500), (1000, 1200), (1023, 1500), (1024, 1500), (2000, 2000), (1000, 10000)]
+    b = synth.sized_dag_batch(sizes, seed=5)
+    got = gpu_ctx.stitch_batch_align(b)
+    want = po.oracle_stitch_batch(b)
+    assert got.same_as(want) is None
+    for npw in (1, 2, 3):
+        small = synth.sized_dag_batch(sizes[:12], seed=40 + npw, extra_edge_p=0.4, skip_max=6, alphabet=2)
+        f = np.full(small.n_problems, npw, np.uint8)
+        got = gpu_ctx.po_poa_batch(small, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(small, force_num_pw=f)) is None
