@@ -75,8 +75,8 @@ struct ClChainDevice {
 constexpr int kFarLeafShift = 6;
 constexpr int kFarFanShift = 3;
 constexpr int kFarMaxLevels = 4;     // up to 32768 records: one wave seals a node in about a millisecond
-constexpr uint32_t kFarLag = 8;       // the far pass of macro-block k reads the records final kFarLag macro-blocks earlier:
-                                      // that many far launches run side by side, their binary searches hide one another's latency
+constexpr uint32_t kFarLag = 8;       // upper limit of the far pass's lag: the far pass of macro-block k reads the records final `lag`
+                                      // macro-blocks earlier, so that many far launches run side by side (cl_chain_api.cpp picks the lag)
 constexpr int kFarBandShift = 16;   // shift buckets of 65536: beyond that the gap cost is on its last, nearly flat piece
 
 struct ClFarLevel {

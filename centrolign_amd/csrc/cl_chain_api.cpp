@@ -781,7 +781,10 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     // ---- branch-and-bound far pass: record image, the two static orders per level, the sealing schedule -------------------
     static const bool no_far_env = getenv("CL_CHAIN_NO_FAR_PRUNE") != nullptr;
     const uint32_t n_macro_all = (uint32_t)((M + kChainMacro - 1) / kChainMacro);
-    bool use_far = use_walk && !no_far_env && n_macro_all >= kFarLag + 3;
+    // far launches in flight: 2 by default (measured on 10 x 1 Mbp: 2, 4 and 8 within 5 % of one another on one context, 2 best with four
+    // worker contexts, whose streams share the hardware queues); CL_CHAIN_FAR_LAG=1..8 for measurements
+    static const uint32_t far_lag = [] { const char* e = getenv("CL_CHAIN_FAR_LAG"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= (int)kFarLag ? v : 2); }();
+    bool use_far = use_walk && !no_far_env && n_macro_all >= far_lag + 3;
     if (use_far) {
         uint32_t max_n = 0;
         int64_t smin = INT64_MAX, smax = INT64_MIN;
@@ -915,10 +918,10 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         std::vector<hipEvent_t> ev_walk(n_macro, nullptr), ev_seal(n_macro, nullptr);
         ev_far.assign(n_macro, nullptr);
         static_assert(kFarLag + 1 <= (uint32_t)kNumAuxStreams, "one auxiliary stream per far launch in flight plus the sealing stream");
-        hipStream_t seal_stream = ctx->aux[kFarLag];
+        hipStream_t seal_stream = ctx->aux[kFarLag];   // (fixed slot, whatever far_lag is)
         if (use_far) {
             if (he == hipSuccess) he = hipStreamWaitEvent(seal_stream, ctx->ev_fork, 0);
-            for (uint32_t f = far_streams; f < kFarLag && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
+            for (uint32_t f = far_streams; f < far_lag && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
         }
         // Branch-and-bound or sweep?  The far kernels count the leaves they had to open against the leaves in range (status[2..5]).
         // At a few checkpoints the host waits for the launches so far and reads the counts: once they cover enough queries with a
@@ -931,7 +934,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
             if (!far_decided && k >= 96 && (k & (k - 1)) == 0) {   // k = 128, 256, 512, ...
                 he = hipStreamSynchronize(ctx->stream);
-                for (uint32_t f = 0; f < kFarLag && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
+                for (uint32_t f = 0; f < far_lag && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
                 unsigned long long cnt[2] = {0, 0};
                 if (he == hipSuccess) he = cl_copy_sync(ctx, cnt, d_status.p + 2, sizeof(cnt), hipMemcpyDeviceToHost);
                 if (he == hipSuccess && cnt[1] >= (1ull << 22)) {
@@ -941,10 +944,10 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                 }
             }
             const uint32_t first = k * kChainMacro, count = (uint32_t)std::min<uint64_t>(kChainMacro, M - first);
-            const uint32_t lag = use_far ? kFarLag : 1u;
+            const uint32_t lag = use_far ? far_lag : 1u;
             const uint32_t b0 = k * bpm, near_lo = k >= lag ? (k - lag) * bpm : 0;
             if (near_lo > 0) {
-                hipStream_t far_stream = ctx->aux[k % (use_far ? kFarLag : far_streams)];
+                hipStream_t far_stream = ctx->aux[k % (use_far ? far_lag : far_streams)];
                 if (use_far && far_bb) {
                     // every node inside the records [0, prefix[near_lo]) was sealed by seal(k - lag - 1) or earlier
                     he = hipStreamWaitEvent(far_stream, ev_seal[k - lag - 1], 0);
@@ -976,7 +979,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_walk[k], hipEventDisableTiming);
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
-            if (use_far && far_bb && he == hipSuccess && k + kFarLag + 1 < n_macro) {
+            if (use_far && far_bb && he == hipSuccess && k + far_lag + 1 < n_macro) {
                 he = hipStreamWaitEvent(seal_stream, ev_walk[k], 0);
                 if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_stream);
                 if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_seal[k], hipEventDisableTiming);
@@ -1023,7 +1026,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     lap("enqueue (host)");
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-    for (uint32_t f = 0; f < std::max<uint32_t>(far_streams, kFarLag) && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
+    for (uint32_t f = 0; f < std::max<uint32_t>(far_streams, far_lag) && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");

@@ -27,6 +27,8 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
     anchor chain leaves much of the device idle between its host phases, a second one fills the gaps."""
+    import time as _time
+    _t0 = _time.perf_counter()
     order = leaves_of(tree)
     leaves = {nm: capi.leaf_graph(sequences[nm]) for nm in order}
     make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
@@ -53,10 +55,12 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
         with ThreadPoolExecutor(len(contexts)) as pool:
             return list(pool.map(run, jobs))
 
+    stats["timeline_s"] = [("leaf graphs done", _time.perf_counter() - _t0)]
     try:
         scales = in_parallel([lambda c, nm=nm: c.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
                               for nm in order])
         scale = sum(scales) / len(scales)                    # ScoreFunction::score_scale (src/core.cpp:169-184)
+        stats["timeline_s"].append(("calibrations done", _time.perf_counter() - _t0))
 
         # the guide tree in waves: every merge whose two children are there runs in the same wave
         done = {nm: (leaves[nm], [nm]) for nm in order}       # subtree (as its newick text) -> (graph, path names)
@@ -90,6 +94,7 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
                     print("merge %s: %s" % (newick(t), stats["per_merge"][-1]), file=sys.stderr, flush=True)
                 done[newick(t)] = (r["fused"], paths)
                 last["alignment"], last["graphs"] = r["alignment"], (g1, g2)
+            stats["timeline_s"].append(("wave of %d merge(s) done" % len(ready), _time.perf_counter() - _t0))
         root, paths = done[newick(tree)]
     finally:
         for c in contexts[1:]:
