@@ -534,6 +534,7 @@ struct cl_stitch_plan {
     bool has_back[2] = {false, false};
     // device
     DevBuf<ClProbDesc> d_desc;
+    DevBuf<uint32_t> d_aux;
     DevBuf<uint8_t> d_lab[2];
     DevBuf<uint32_t> d_poff[2], d_pidx[2], d_snk[2];
     DevBuf<int32_t> d_planes;
@@ -560,7 +561,7 @@ void plan_free(cl_stitch_plan* pl) {
         pl->d_lab[s].release(); pl->d_poff[s].release(); pl->d_pidx[s].release(); pl->d_snk[s].release();
     }
     pl->d_planes.release(); pl->d_out_pairs.release(); pl->d_out_len.release(); pl->d_out_status.release();
-    pl->d_plist.release(); pl->d_out_score.release();
+    pl->d_plist.release(); pl->d_out_score.release(); pl->d_aux.release();
     for (auto& g : pl->groups) {
         if (g.ev0) (void)hipEventDestroy(g.ev0);
         if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -689,6 +690,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     poff[1].push_back(0);
     std::vector<uint32_t> order, st, indeg, rank;
     std::vector<uint32_t> ring_need;   // per PO-POA problem: dynamic LDS of the ring variant of the general kernel (0 = not taken)
+    std::vector<uint32_t> sys_aux;     // saved-column lists of the systolic kernel's problems, concatenated
     uint64_t plane_cursor = 0, out_cursor = 0;
 
     for (uint64_t k = 0; k < n; ++k) {
@@ -798,23 +800,47 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // the ring variant also stages the subproblem's topology in LDS: offsets, predecessor ranks, labels
             const uint64_t n_pred = (poff[0].back() - poff[0][d.node_base[0]]) + (poff[1].back() - poff[1][d.node_base[1]]);
             const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2) * 8 + n_pred * 4 + ((uint64_t)d.n1 + d.n2 + 2) * (1 + npw) * 4 + 16;   // node records, lists, boundaries
-            // the systolic kernel (popoa_sys_kernel): the shorter graph's rows on the threads, a ring of H columns per row in LDS,
-            // H a power of two above the sum of the two predecessor spans (then every read is an LDS read)
+            // the systolic kernel (popoa_sys_kernel): the shorter graph's rows on the threads, a ring of H columns per row in LDS.  H must
+            // exceed the row graph's predecessor span plus the column graph's NEAR predecessor distances; columns that are read from
+            // further away (the fork in front of a long bubble; column 0 for a late source) are SAVED columns with LDS of their own
+            const int sRow = d.n2 < d.n1 ? 1 : 0, sCol = 1 - sRow;
             const uint64_t n_rows = std::min(d.n1, d.n2) + 1, n_cols = std::max(d.n1, d.n2);
-            // ... or, when that does not fit (or exceeds 256 columns), as many as do (at least 8): the rare reads that reach further
-            // back go to the HBM planes
+            bool take_sys = !g_no_sys && n_rows <= 1024;
             uint32_t sys_log = 0;
-            while ((1ull << sys_log) < span[0] + span[1] + 1 && sys_log < 8) ++sys_log;
-            auto sys_need = [&](uint32_t lg) { return ((n_rows * (1ull << lg) * (uint64_t)(1 + 2 * npw) + 1) & ~1ull) * 4 + n_cols * 8 + n_pred * 4 + 16; };
-            while (sys_log > 3 && sys_need(sys_log) > kSysLdsBytes) --sys_log;
-            const uint64_t sys_h = 1ull << sys_log, sys_bytes = sys_need(sys_log);
-            const bool sys_full = sys_h >= span[0] + span[1] + 1;
-            const bool take_sys = !g_no_sys && n_rows <= 1024 && (sys_log >= 3 || sys_full) && sys_bytes <= kSysLdsBytes;
+            uint64_t sys_bytes = 0;
+            std::vector<uint32_t> far_cols;
+            if (take_sys) {
+                const uint32_t* cp = poff[sCol].data() + d.node_base[sCol];   // node j (1-based rank): predecessors pidx[cp[j - 1] .. cp[j])
+                const uint8_t* cl = lab[sCol].data() + d.node_base[sCol];
+                uint64_t near_limit = 8, near_max = 0;
+                while (true) {
+                    far_cols.clear();
+                    near_max = 0;
+                    for (uint64_t j = 1; j <= n_cols; ++j) {
+                        for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
+                            const uint64_t dist = j - pidx[sCol][e];
+                            if (dist > near_limit) far_cols.push_back(pidx[sCol][e]); else near_max = std::max(near_max, dist);
+                        }
+                        if (cl[j - 1] & 0x80) { if (j > near_limit) far_cols.push_back(0); else near_max = std::max(near_max, j); }
+                    }
+                    std::sort(far_cols.begin(), far_cols.end());
+                    far_cols.erase(std::unique(far_cols.begin(), far_cols.end()), far_cols.end());
+                    if (far_cols.size() <= 32 || near_limit >= 4096) break;
+                    near_limit *= 4;
+                }
+                while ((1ull << sys_log) < span[sRow] + near_max + 1 && sys_log < 14) ++sys_log;
+                const uint64_t cw = npw == 1 ? 4 : 8, hw = (1ull << sys_log) * cw, stride = hw + ((cw + 4 + 64 - (hw & 63)) & 63);
+                sys_bytes = n_rows * stride * 4 + far_cols.size() * n_rows * cw * 4 + n_cols * 8 + n_pred * 4 + far_cols.size() * 4 + 16;
+                take_sys = far_cols.size() <= 32 && (1ull << sys_log) >= span[sRow] + near_max + 1 && sys_bytes <= kSysLdsBytes;
+            }
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
             if (take_sys) {
                 d.kind = CL_KIND_SYS;
-                d.pad = (uint16_t)(sys_log | (sys_full ? 0x4000u : 0u) | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | ring serves every read | rows = graph 2
+                d.pad = (uint16_t)(sys_log | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | rows = graph 2
+                d.aux_base = (uint32_t)sys_aux.size();
+                d.aux_cnt = (uint32_t)far_cols.size();
+                sys_aux.insert(sys_aux.end(), far_cols.begin(), far_cols.end());
                 ring_need.push_back((uint32_t)sys_bytes);
             } else if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
                 d.pad = (uint16_t)(depth | (depth >= span[0] + span[1] + 1 ? 0x8000u : 0u));   // bit 15: the ring serves every read
@@ -891,22 +917,28 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 }
                 close_group(grp);
             }
+    // systolic DAG kernel: (NumPW, workgroup size, LDS class) — a launch's dynamic LDS is that of its hungriest problem, and LDS decides
+    // how many workgroups share a CU, so the many small problems must not ride with the few large ones
+    const uint32_t lds_class[4] = {12 * 1024, 32 * 1024, 64 * 1024, (uint32_t)kSysLdsBytes};
     for (int bi = 2; bi >= 0; --bi)
-        for (int npw = 3; npw >= 1; --npw) {
-            LaunchGroup grp;
-            grp.kind = CL_KIND_SYS; grp.npw = npw; grp.block = blocks[bi];
-            grp.first = (uint32_t)plist.size();
-            for (uint32_t i = 0; i < pl->desc.size(); ++i) {
-                const ClProbDesc& d = pl->desc[i];
-                const uint32_t rows = std::min(d.n1, d.n2) + 1;
-                const int b = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
-                if (d.kind == CL_KIND_SYS && d.npw == npw && b == bi) {
+        for (int npw = 3; npw >= 1; --npw)
+            for (int lc = 3; lc >= 0; --lc) {
+                LaunchGroup grp;
+                grp.kind = CL_KIND_SYS; grp.npw = npw; grp.block = blocks[bi];
+                grp.first = (uint32_t)plist.size();
+                for (uint32_t i = 0; i < pl->desc.size(); ++i) {
+                    const ClProbDesc& d = pl->desc[i];
+                    const uint32_t rows = std::min(d.n1, d.n2) + 1;
+                    const int b = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
+                    if (d.kind != CL_KIND_SYS || d.npw != npw || b != bi) continue;
+                    int c = 0;
+                    while (c < 3 && ring_need[i] > lds_class[c]) ++c;
+                    if (c != lc) continue;
                     plist.push_back(i);
                     grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
                 }
+                close_group(grp);
             }
-            close_group(grp);
-        }
     // longest-running launch first: a group's duration is set by its longest anti-diagonal sweep
     {
         auto crit = [&](const LaunchGroup& g) {
@@ -920,7 +952,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     pl->stats.n_launches = pl->groups.size();
 
     // HBM
-    if ((rc = pl->d_desc.upload(ctx, pl->desc)) || (rc = pl->d_plist.upload(ctx, plist))) { plan_free(pl); return rc; }
+    if ((rc = pl->d_desc.upload(ctx, pl->desc)) || (rc = pl->d_plist.upload(ctx, plist)) || (rc = pl->d_aux.upload(ctx, sys_aux))) { plan_free(pl); return rc; }
     for (int s = 0; s < 2; ++s)
         if ((rc = pl->d_lab[s].upload(ctx, lab[s])) || (rc = pl->d_poff[s].upload(ctx, poff[s])) ||
             (rc = pl->d_pidx[s].upload(ctx, pidx[s])) || (rc = pl->d_snk[s].upload(ctx, snk[s]))) { plan_free(pl); return rc; }
@@ -933,11 +965,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     for (int s = 0; s < 2; ++s) {
         pl->dev.lab[s] = pl->d_lab[s].p; pl->dev.poff[s] = pl->d_poff[s].p; pl->dev.pidx[s] = pl->d_pidx[s].p; pl->dev.snk[s] = pl->d_snk[s].p;
     }
+    pl->dev.aux = pl->d_aux.p;
     pl->dev.planes = pl->d_planes.p;
     pl->dev.out_pairs = pl->d_out_pairs.p;
     pl->dev.out_len = pl->d_out_len.p;
     pl->dev.out_score = pl->d_out_score.p;
     pl->dev.out_status = pl->d_out_status.p;
+    { const char* e = getenv("CL_DEBUG_SKIP_TRACEBACK"); pl->dev.skip_traceback = e && *e == '1'; }   // measurement hook
     pl->sparams.match = (int32_t)ap.match;
     pl->sparams.mismatch = (int32_t)ap.mismatch;
     for (int k = 0; k < 3; ++k) { pl->sparams.oe[k] = (int32_t)(ap.gap_open[k] + ap.gap_extend[k]); pl->sparams.ext[k] = (int32_t)ap.gap_extend[k]; }

@@ -25,6 +25,8 @@ struct ClProbDesc {
     uint8_t  npw;             // 1..3
     uint8_t  kind;            // CL_KIND_*
     uint16_t pad;
+    uint32_t aux_base;        // systolic kernel: first entry of the problem's saved-column list in ClDeviceBatch::aux
+    uint32_t aux_cnt;         // ... and its length
 };
 
 struct ClScoreParams {
@@ -41,11 +43,13 @@ struct ClDeviceBatch {
     const uint32_t* poff[2];  // CSR offsets (global) of predecessor lists, rank order, node_count+1 entries per side
     const uint32_t* pidx[2];  // predecessor rank+1, in BaseGraph::previous() order
     const uint32_t* snk[2];   // sink rank+1, in SubGraphInfo::sinks order
+    const uint32_t* aux;      // systolic kernel: per problem, the columns (0-based matrix columns, ascending) whose cells are kept for good
     int32_t*  planes;         // DP workspace
     uint2*    out_pairs;      // (a, b) with 0 = gap, rank+1 otherwise; each problem fills its slot range from the END
     uint32_t* out_len;        // pairs emitted per problem
     int32_t*  out_score;      // best sink-pair score per problem
     uint32_t* out_status;     // 0 = ok
+    int       skip_traceback; // measurement hook (CL_DEBUG_SKIP_TRACEBACK=1, scripts/stitch_dag_bench.py): the graph x graph kernels fill only
 };
 
 #endif

@@ -316,7 +316,7 @@ __device__ void traceback_wave(const ClDeviceBatch& B, const ClProbDesc& pd, con
         } else if (comp > 0) {
             const int k = comp - 1;
             bool ok = false, opens = false;
-            if (lane < a && b) {   // gap runs along the boundary column (b == 0) are left to the single step
+            if (lane < a) {   // (also along the boundary column b == 0: the same equalities decide there)
                 const uint32_t ai = a - lane;
                 if (plain1(ai)) {
                     const uint32_t c = G.idx(ai, b), pc = G.idx(ai - 1, b);
@@ -339,7 +339,7 @@ __device__ void traceback_wave(const ClDeviceBatch& B, const ClProbDesc& pd, con
         } else {
             const int k = -comp - 1;
             bool ok = false, opens = false;
-            if (lane < b && a) {
+            if (lane < b) {
                 const uint32_t bi = b - lane;
                 if (plain2(bi)) {
                     const uint32_t c = G.idx(a, bi), pc = G.idx(a, bi - 1);
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, c
         off += cnt;
         __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
     }
-    if (tid < 64) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -660,27 +660,31 @@ __global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, cons
         }
     }
     __syncthreads();
-    if (tid < 64) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // popoa_sys_kernel: any DAG pair whose SHORTER graph has at most BLOCK - 1 nodes, swept as a systolic array like the chain kernel
 // (popoa_linear.hip) instead of anti-diagonal by anti-diagonal.  Thread r owns ROW r (rank r of the shorter graph, row 0 = the
-// boundary "nothing consumed yet") for the whole sweep and at step t works on column t - r, so the three cells a cell needs —
-// (p, c), (r, q), (p, q) for predecessors p of its row and q of its column — were finished (r - p), (c - q) and (r - p) + (c - q) steps
-// earlier.  Every row keeps its last H columns in an LDS ring ([row][column & (H - 1)][plane], H a power of two above the sum of
-// the two graphs' predecessor spans), so every read is an LDS read of a few consecutive words, the address arithmetic is a
-// shift and a mask, the row's own topology sits in registers and the column's arrives as one 8-byte LDS record.  One step costs a
-// wave two dependent LDS round trips; a whole-repeat indel between two MSA graphs (83 x 4 398, 7 x 2 051: thousands of anti-
-// diagonals of a few cells) is swept at that pace instead of a barrier and a round of global loads per anti-diagonal.
-// The int32 planes still go to HBM (fire and forget, anti-diagonal-major as before): the traceback below reads them.
-// A predecessor further back than the ring reaches (the end of a bubble whose branches differ by thousands of nodes) is read from the
-// HBM planes, which are then drained every H / 2 steps (ClProbDesc::pad bit 14 says the ring serves every read and nothing is waited for).
-// ClProbDesc::pad bit 15: graph 2 is the shorter one (rows = graph 2: the roles of I and D swap).
+// boundary "nothing consumed yet") for the whole sweep and at step t works on column t - r, so the cells a cell needs — (p, c), (r, q),
+// (p, q) for predecessors p of its row and q of its column — were finished (r - p), (c - q) and (r - p) + (c - q) steps earlier.  Every
+// row keeps its last H columns in an LDS ring, H a power of two above the row graph's predecessor span plus the column graph's NEAR
+// predecessor distances; a column that some later column reaches from further away (the fork in front of a bubble whose branches
+// differ by a whole repeat unit: one or two per subproblem) is a SAVED column: its cells are also written to a small LDS area of their
+// own ([slot][row]) and read from there.  So every read of the sweep is an LDS read, and — this is the point — the loop contains no
+// global load at all: on gfx9 loads and stores share one counter, a single load in the loop makes every step wait for the previous
+// step's plane stores (≈1 µs); without one the stores are fire-and-forget.  The row's own topology sits in registers, the column's
+// arrives as one 8-byte LDS record; up to two predecessors per side (a source's boundary index counted as one) take a straight-line
+// path of eight independent LDS reads, more go through loops.
+// The int32 planes go to HBM anti-diagonal-major as before: the traceback reads them.
+// ClProbDesc::pad: bits 0-4 log2 H, bit 15: graph 2 is the shorter one (rows = graph 2: the roles of I and D swap);
+// ClProbDesc::aux_base / aux_cnt: the saved columns.
 template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
-    extern __shared__ int32_t lds[];
-    constexpr int PL = 1 + 2 * NPW;
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    // one cell: NumPW 1: {M, V0, H0, -}; NumPW 2, 3: {M, V0, V1, V2 | M, H0, H1, H2} — what a vertical or a horizontal read needs is one
+    // aligned 16-byte LDS read
+    constexpr int CW = NPW == 1 ? 4 : 8;
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -688,61 +692,92 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     pl.base = B.planes + pd.plane_base;
     pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
     const uint32_t tid = threadIdx.x;
-    // ClProbDesc::pad: bits 0-4 log2 of the ring length H, bit 14: the ring serves every read, bit 15: rows = graph 2
-    const bool swap = pd.pad & 0x8000u, full = pd.pad & 0x4000u;
-    const uint32_t H = 1u << (pd.pad & 31u), hm = H - 1;
-    const int sR = swap ? 1 : 0, sC = 1 - sR;
+    const bool swap = pd.pad & 0x8000u;
+    const uint32_t logH = pd.pad & 31u, H = 1u << logH, hm = H - 1;
     const uint32_t nR = swap ? pd.n2 : pd.n1, nC = swap ? pd.n1 : pd.n2;
-    // LDS (int32 units): ring [nR + 1][H][PL] | column records [nC] (uint2) | row predecessor lists | column predecessor lists
-    int32_t* ring = lds;
-    uint2* recC = reinterpret_cast<uint2*>(lds + (((size_t)(nR + 1) * H * PL + 1) & ~(size_t)1));
-    const uint32_t* gpR = B.poff[sR] + pd.node_base[sR];
-    const uint32_t* gpC = B.poff[sC] + pd.node_base[sC];
-    const uint32_t eR0 = gpR[0], eR1 = gpR[nR], eC0 = gpC[0], eC1 = gpC[nC];
-    uint32_t* plR = reinterpret_cast<uint32_t*>(recC + nC);
-    uint32_t* plC = plR + (eR1 - eR0);
-    for (uint32_t i = tid; i < eR1 - eR0; i += BLOCK) plR[i] = B.pidx[sR][eR0 + i];
-    for (uint32_t i = tid; i < eC1 - eC0; i += BLOCK) plC[i] = B.pidx[sC][eC0 + i];
-    {
-        const uint8_t* gl = B.lab[sC] + pd.node_base[sC];
-        for (uint32_t i = tid; i < nC; i += BLOCK) {
-            const uint32_t b0 = gpC[i] - eC0, deg = gpC[i + 1] - gpC[i], l = gl[i];
-            recC[i] = make_uint2(deg == 1 ? B.pidx[sC][gpC[i]] : b0, (deg & 0xFFFFu) | ((l & 0x7Fu) << 16) | ((l >> 7) << 31));
-        }
+    const uint32_t K = pd.aux_cnt;
+    const uint32_t baseR = swap ? pd.node_base[1] : pd.node_base[0], baseC = swap ? pd.node_base[0] : pd.node_base[1];
+    const uint32_t* const poffR = (swap ? B.poff[1] : B.poff[0]) + baseR;
+    const uint32_t* const poffC = (swap ? B.poff[0] : B.poff[1]) + baseC;
+    const uint32_t* const pidxR = swap ? B.pidx[1] : B.pidx[0];
+    const uint32_t* const pidxC = swap ? B.pidx[0] : B.pidx[1];
+    const uint8_t* const labRp = (swap ? B.lab[1] : B.lab[0]) + baseR;
+    const uint8_t* const labCp = (swap ? B.lab[0] : B.lab[1]) + baseC;
+    // LDS (int32 units): ring [nR + 1][row stride] | saved columns [K][nR + 1][CW] | column records [nC] (uint2) | row predecessor lists |
+    // column predecessor lists | saved column numbers [K].
+    // Lane r works on row r at column t - r, so neighbouring lanes' ring addresses differ by (row stride - CW) words: the stride is padded
+    // to make that 4 (mod 64) — the sixteen lanes of a 16-byte LDS access then fall on sixteen different 4-bank groups
+    const uint32_t row_stride = (H * CW) + ((CW + 4u + 64u - ((H * CW) & 63u)) & 63u);
+    int32_t* const ring = lds;
+    int32_t* const saved = ring + (nR + 1) * row_stride;
+    uint2* const recC = reinterpret_cast<uint2*>(saved + K * (nR + 1) * CW);
+    const uint32_t eR0 = poffR[0], eR1 = poffR[nR], eC0 = poffC[0], eC1 = poffC[nC];
+    uint32_t* const plR = reinterpret_cast<uint32_t*>(recC + nC);
+    uint32_t* const plC = plR + (eR1 - eR0);
+    uint32_t* const saved_col = plC + (eC1 - eC0);
+    for (uint32_t i = tid; i < eR1 - eR0; i += BLOCK) plR[i] = pidxR[eR0 + i];
+    for (uint32_t i = tid; i < eC1 - eC0; i += BLOCK) plC[i] = pidxC[eC0 + i];
+    for (uint32_t i = tid; i < K; i += BLOCK) saved_col[i] = B.aux[pd.aux_base + i];
+    __syncthreads();
+    // column record: {first predecessor (degree 1) or list start, degree | label << 16 | is saved << 30 | is a source << 31}
+    for (uint32_t i = tid; i < nC; i += BLOCK) {
+        const uint32_t b0 = poffC[i] - eC0, deg = poffC[i + 1] - poffC[i], l = labCp[i];
+        uint32_t is_saved = 0;
+        for (uint32_t k = 0; k < K; ++k) is_saved |= saved_col[k] == i + 1 ? 1u : 0u;
+        recC[i] = make_uint2(deg == 1 ? pidxC[poffC[i]] : b0, (deg & 0xFFFFu) | ((l & 0x7Fu) << 16) | (is_saved << 30) | ((l >> 7) << 31));
     }
+    const bool save_col0 = K && saved_col[0] == 0;   // the list is ascending
     // this thread's row (rows beyond nR idle)
     const uint32_t r = tid;
     uint32_t degR = 0, firstR = 0, labR = 0;
     bool srcR = false;
     if (r >= 1 && r <= nR) {
-        const uint32_t l = (B.lab[sR] + pd.node_base[sR])[r - 1];
-        degR = gpR[r] - gpR[r - 1];
-        firstR = degR == 1 ? B.pidx[sR][gpR[r - 1]] : gpR[r - 1] - eR0;
+        const uint32_t l = labRp[r - 1];
+        degR = poffR[r] - poffR[r - 1];
+        firstR = degR == 1 ? pidxR[poffR[r - 1]] : poffR[r - 1] - eR0;
         labR = l & 0x7Fu;
         srcR = l >> 7;
     }
+    // up to two predecessors per side, a source's boundary index (row / column 0) counted as one: the straight-line cell below covers them
+    // with no data-dependent loop (a missing second predecessor repeats the first: the maxima do not care)
+    const bool fastR = r >= 1 && r <= nR && degR + (srcR ? 1u : 0u) <= 2 && degR + (srcR ? 1u : 0u) >= 1;
+    uint32_t rp0 = 0, rp1 = 0;
+    if (fastR) {
+        if (degR == 0) rp0 = rp1 = 0;
+        else if (degR == 1) { rp0 = firstR; rp1 = srcR ? 0u : rp0; }
+        else { rp0 = plR[firstR]; rp1 = plR[firstR + 1]; }
+    }
     __syncthreads();
-    int32_t* my_row = ring + (size_t)r * H * PL;
     const uint32_t last = nR + nC;
     uint32_t off = 0;   // G.off(t): cells on the anti-diagonals before t
     uint32_t t = 0;
-    // cell (row, col) as {M, V_k, H_k}: from the row's ring while the row has not moved H columns past col (at step t it is at column
-    // t - row), else from the HBM planes (written at least H steps ago and drained since)
-    int32_t far_buf[PL];
-    auto cell = [&](uint32_t row, uint32_t col) -> const int32_t* {
-        if (full || t - row - col < H) return ring + ((size_t)row * H + (col & hm)) * PL;
-        const uint32_t idx = swap ? G.idx(col, row) : G.idx(row, col);
-        // L1-bypassing loads: the line may sit in this CU's L1 from before the cell was written
-        far_buf[0] = __hip_atomic_load(pl.M() + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < NPW; ++k) {
-            const int32_t iv = __hip_atomic_load(pl.I(k) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int32_t dv = __hip_atomic_load(pl.D(k) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            far_buf[1 + k] = swap ? dv : iv;
-            far_buf[1 + NPW + k] = swap ? iv : dv;
-        }
-        return far_buf;
+    // where cell (row, col) lives: in the row's ring while the row has not moved H columns past col (at step t it is at column t - row),
+    // else in the saved area (the host saved every column that is read from further away)
+    auto where = [&](uint32_t row, uint32_t col) -> const int32_t* {
+        if (t - row - col < H) return ring + (row * row_stride + (col & hm) * CW);
+        uint32_t slot = 0;
+        while (slot + 1 < K && saved_col[slot] != col) ++slot;
+        return saved + (slot * (nR + 1) + row) * CW;
     };
+    auto get_mv = [&](uint32_t row, uint32_t col, int32_t& m, int32_t (&v)[NPW]) {   // M and the vertical gap values of a cell
+        const int4 x = reinterpret_cast<const int4*>(where(row, col))[0];
+        m = x.x; v[0] = x.y;
+        if (NPW > 1) v[1] = x.z;
+        if (NPW > 2) v[2] = x.w;
+    };
+    auto get_mh = [&](uint32_t row, uint32_t col, int32_t& m, int32_t (&h)[NPW]) {   // M and the horizontal gap values
+        if (NPW == 1) { const int4 x = reinterpret_cast<const int4*>(where(row, col))[0]; m = x.x; h[0] = x.z; }
+        else {
+            const int4 x = reinterpret_cast<const int4*>(where(row, col))[1];
+            m = x.x; h[0] = x.y;
+            if (NPW > 1) h[1] = x.z;
+            if (NPW > 2) h[2] = x.w;
+        }
+    };
+    auto get_m = [&](uint32_t row, uint32_t col) -> int32_t { return where(row, col)[0]; };
+    int32_t* const my_row = ring + r * row_stride;
+    int32_t* const plane0 = pl.M();
+    const size_t plane_stride = pl.cells;
     for (; t <= last; ++t) {
         const uint32_t lo_d = G.lo(t), cnt_d = G.hi(t) - lo_d + 1;
         if (r <= nR && t >= r && t - r <= nC) {
@@ -751,17 +786,40 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
 #pragma unroll
             for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; Hh[k] = CL_NEG_INF; }
             uint32_t degC = 0, firstC = 0, labC = 0;
-            bool srcC = false;
+            bool srcC = false, keep = !c && save_col0;
             if (c) {
                 const uint2 rc = recC[c - 1];
-                degC = rc.y & 0xFFFFu; firstC = rc.x; labC = (rc.y >> 16) & 0x7Fu; srcC = rc.y >> 31;
+                degC = rc.y & 0xFFFFu; firstC = rc.x; labC = (rc.y >> 16) & 0x7Fu; srcC = rc.y >> 31; keep = (rc.y >> 30) & 1u;
             }
-            if (r && !c) {          // boundary column: gap extensions down the row graph (alignment.hpp:832-845)
+            const uint32_t nqC = degC + (srcC ? 1u : 0u);
+            if (r && c && fastR && nqC >= 1 && nqC <= 2) {
+                // the usual cell, straight-line: two predecessors per side (the second may repeat the first), eight independent LDS reads.
+                // The boundary row / column as a predecessor needs no special case: its V (H) values are -inf in LDS, so "extend from
+                // the boundary" never wins, and only the corner's M counts as 0 (alignment.hpp:814-818)
+                uint32_t q0, q1;
+                if (degC == 0) q0 = q1 = 0;
+                else if (degC == 1) { q0 = firstC; q1 = srcC ? 0u : q0; }
+                else { q0 = plC[firstC]; q1 = plC[firstC + 1]; }
+                int32_t mv0, mv1, mh0, mh1, vv0[NPW], vv1[NPW], hh0[NPW], hh1[NPW];
+                get_mv(rp0, c, mv0, vv0);
+                get_mv(rp1, c, mv1, vv1);
+                get_mh(r, q0, mh0, hh0);
+                get_mh(r, q1, mh1, hh1);
+                const int32_t d00 = (rp0 | q0) ? get_m(rp0, q0) : 0, d01 = (rp0 | q1) ? get_m(rp0, q1) : 0;
+                const int32_t d10 = (rp1 | q0) ? get_m(rp1, q0) : 0, d11 = (rp1 | q1) ? get_m(rp1, q1) : 0;
+                M = imax(imax(d00, d01), imax(d10, d11)) + ((labR == labC) ? P.match : -P.mismatch);
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) {
+                    V[k] = imax(imax(mv0 - P.oe[k], vv0[k] - P.ext[k]), imax(mv1 - P.oe[k], vv1[k] - P.ext[k]));
+                    Hh[k] = imax(imax(mh0 - P.oe[k], hh0[k] - P.ext[k]), imax(mh1 - P.oe[k], hh1[k] - P.ext[k]));
+                }
+            } else if (r && !c) {          // boundary column: gap extensions down the row graph (alignment.hpp:832-845)
                 for (uint32_t e = 0; e < degR; ++e) {
                     const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
-                    const int32_t* x = cell(p, 0);
+                    int32_t m, vv[NPW];
+                    get_mv(p, 0, m, vv);
 #pragma unroll
-                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], x[1 + k] - P.ext[k]);
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], vv[k] - P.ext[k]);
                 }
                 if (srcR) {
 #pragma unroll
@@ -770,78 +828,84 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
             } else if (!r && c) {   // boundary row (:864-877)
                 for (uint32_t f = 0; f < degC; ++f) {
                     const uint32_t q = degC == 1 ? firstC : plC[firstC + f];
-                    const int32_t* x = cell(0, q);
+                    int32_t m, hh[NPW];
+                    get_mh(0, q, m, hh);
 #pragma unroll
-                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], x[1 + NPW + k] - P.ext[k]);
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], hh[k] - P.ext[k]);
                 }
                 if (srcC) {
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], -P.oe[k]);
                 }
-            } else if (r && c) {    // interior (:897-938 in pull form, see compute_cell)
+            } else if (r && c) {    // interior, any degrees (:897-938 in pull form, see compute_cell)
                 for (uint32_t e = 0; e < degR; ++e) {
                     const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
-                    const int32_t* x = cell(p, c);
-                    const int32_t m = x[0];
+                    int32_t m, vv[NPW];
+                    get_mv(p, c, m, vv);
 #pragma unroll
-                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m - P.oe[k], x[1 + k] - P.ext[k]));
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m - P.oe[k], vv[k] - P.ext[k]));
                 }
                 if (srcR) {
-                    const int32_t m = cell(0, c)[0];
+                    const int32_t m = get_m(0, c);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], m - P.oe[k]);
                 }
                 const int32_t s = (labR == labC) ? P.match : -P.mismatch;
                 for (uint32_t f = 0; f < degC; ++f) {
                     const uint32_t q = degC == 1 ? firstC : plC[firstC + f];
-                    const int32_t* x = cell(r, q);
-                    const int32_t m = x[0];
+                    int32_t m, hh[NPW];
+                    get_mh(r, q, m, hh);
 #pragma unroll
-                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], x[1 + NPW + k] - P.ext[k]));
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], hh[k] - P.ext[k]));
                     for (uint32_t e = 0; e < degR; ++e) {
                         const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
-                        M = imax(M, cell(p, q)[0] + s);
+                        M = imax(M, get_m(p, q) + s);
                     }
-                    if (srcR) M = imax(M, cell(0, q)[0] + s);
+                    if (srcR) M = imax(M, get_m(0, q) + s);
                 }
                 if (srcC) {
-                    const int32_t m = cell(r, 0)[0];
+                    const int32_t m = get_m(r, 0);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], m - P.oe[k]);
                     for (uint32_t e = 0; e < degR; ++e) {
                         const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
-                        M = imax(M, cell(p, 0)[0] + s);
+                        M = imax(M, get_m(p, 0) + s);
                     }
                     if (srcR) M = imax(M, s);   // the corner counts as 0 (:814-818)
                 }
             }
 #pragma unroll
             for (int k = 0; k < NPW; ++k) M = imax(M, imax(V[k], Hh[k]));
-            int32_t* w = my_row + (size_t)(c & hm) * PL;
-            w[0] = M;
-#pragma unroll
-            for (int k = 0; k < NPW; ++k) { w[1 + k] = V[k]; w[1 + NPW + k] = Hh[k]; }
+            const int4 w0 = NPW == 1 ? make_int4(M, V[0], Hh[0], 0) : make_int4(M, V[0], V[NPW > 1 ? 1 : 0], V[NPW > 2 ? 2 : 0]);
+            const int4 w1 = make_int4(M, Hh[0], Hh[NPW > 1 ? 1 : 0], Hh[NPW > 2 ? 2 : 0]);
+            int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
+            w[0] = w0;
+            if (NPW > 1) w[1] = w1;
+            if (keep) {   // a saved column: its cells stay available for the far reads
+                uint32_t slot = 0;
+                while (slot + 1 < K && saved_col[slot] != c) ++slot;
+                int4* sw = reinterpret_cast<int4*>(saved + (slot * (nR + 1) + r) * CW);
+                sw[0] = w0;
+                if (NPW > 1) sw[1] = w1;
+            }
             // the planes in graph-1 / graph-2 terms: I consumes a graph-1 node, D a graph-2 node
-            const uint32_t a = swap ? c : r;
-            const uint32_t self_idx = off + (a - lo_d);
-            pl.M()[self_idx] = M;
+            int32_t* dst = plane0 + (off + ((swap ? c : r) - lo_d));
+            dst[0] = M;
 #pragma unroll
             for (int k = 0; k < NPW; ++k) {
-                pl.I(k)[self_idx] = swap ? Hh[k] : V[k];
-                pl.D(k)[self_idx] = swap ? V[k] : Hh[k];
+                dst[(size_t)(1 + k) * plane_stride] = swap ? Hh[k] : V[k];
+                dst[(size_t)(1 + NPW + k) * plane_stride] = swap ? V[k] : Hh[k];
             }
         }
         off += cnt_d;
-        if (!full && (t & ((H >> 1) - 1)) == 0) {
-            __syncthreads();   // vmcnt(0): cells written H / 2 or more steps ago are in memory for the far reads
-        } else if (BLOCK > 64) {   // LDS traffic only
+        if (BLOCK > 64) {   // LDS traffic only: nothing in the sweep reads the planes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
     }
     __syncthreads();   // vmcnt(0): every plane value is in memory
-    if (tid < 64) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
 }
 
 template <int NPW>
