@@ -808,15 +808,18 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             bool take_sys = !g_no_sys && n_rows <= 1024;
             uint32_t sys_log = 0;
             uint64_t sys_bytes = 0;
+            uint64_t near_limit = 8;
             std::vector<uint32_t> far_cols;
             if (take_sys) {
                 const uint32_t* cp = poff[sCol].data() + d.node_base[sCol];   // node j (1-based rank): predecessors pidx[cp[j - 1] .. cp[j])
                 const uint8_t* cl = lab[sCol].data() + d.node_base[sCol];
-                uint64_t near_limit = 8, near_max = 0;
+                uint64_t near_max = 0, max_deg = 0;
+                near_limit = 8;
                 while (true) {
                     far_cols.clear();
                     near_max = 0;
                     for (uint64_t j = 1; j <= n_cols; ++j) {
+                        max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
                         for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
                             const uint64_t dist = j - pidx[sCol][e];
                             if (dist > near_limit) far_cols.push_back(pidx[sCol][e]); else near_max = std::max(near_max, dist);
@@ -825,21 +828,23 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     }
                     std::sort(far_cols.begin(), far_cols.end());
                     far_cols.erase(std::unique(far_cols.begin(), far_cols.end()), far_cols.end());
-                    if (far_cols.size() <= 32 || near_limit >= 4096) break;
-                    near_limit *= 4;
+                    if (far_cols.size() <= 32 || near_limit >= 2047) break;
+                    near_limit = std::min<uint64_t>(near_limit * 4, 2047);   // the kernel's column records hold a near distance in 11 bits
                 }
                 while ((1ull << sys_log) < span[sRow] + near_max + 1 && sys_log < 14) ++sys_log;
                 const uint64_t cw = npw == 1 ? 4 : 8, hw = (1ull << sys_log) * cw, stride = hw + ((cw + 4 + 64 - (hw & 63)) & 63);
                 sys_bytes = n_rows * stride * 4 + far_cols.size() * n_rows * cw * 4 + n_cols * 8 + n_pred * 4 + far_cols.size() * 4 + 16;
-                take_sys = far_cols.size() <= 32 && (1ull << sys_log) >= span[sRow] + near_max + 1 && sys_bytes <= kSysLdsBytes;
+                take_sys = far_cols.size() <= 32 && (1ull << sys_log) >= span[sRow] + near_max + 1 && sys_bytes <= kSysLdsBytes &&
+                           max_deg <= 63 && cp[n_cols] - cp[0] < (1u << 17);   // field widths of the column records
             }
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
             if (take_sys) {
                 d.kind = CL_KIND_SYS;
                 d.pad = (uint16_t)(sys_log | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | rows = graph 2
-                d.aux_base = (uint32_t)sys_aux.size();
+                d.aux_base = (uint32_t)sys_aux.size();   // {near limit, the saved columns ascending}
                 d.aux_cnt = (uint32_t)far_cols.size();
+                sys_aux.push_back((uint32_t)near_limit);
                 sys_aux.insert(sys_aux.end(), far_cols.begin(), far_cols.end());
                 ring_need.push_back((uint32_t)sys_bytes);
             } else if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {

@@ -717,14 +717,26 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     uint32_t* const saved_col = plC + (eC1 - eC0);
     for (uint32_t i = tid; i < eR1 - eR0; i += BLOCK) plR[i] = pidxR[eR0 + i];
     for (uint32_t i = tid; i < eC1 - eC0; i += BLOCK) plC[i] = pidxC[eC0 + i];
-    for (uint32_t i = tid; i < K; i += BLOCK) saved_col[i] = B.aux[pd.aux_base + i];
+    const uint32_t near_limit = B.aux[pd.aux_base];
+    for (uint32_t i = tid; i < K; i += BLOCK) saved_col[i] = B.aux[pd.aux_base + 1 + i];
     __syncthreads();
-    // column record: {first predecessor (degree 1) or list start, degree | label << 16 | is saved << 30 | is a source << 31}
+    // column record, 8 bytes.  x: the straight-line cell's two predecessor columns, 12 bits each — bit 11 clear: the column is that many
+    // columns back, in the ring; set: it is saved column number (low bits) — a source's boundary column 0 counted as a predecessor, a
+    // missing second one repeating the first | bit 26: this column is itself saved, bits 27-31: in that slot.
+    // y: list start (17 bits) | in-degree (6 bits) | bit 23: the straight-line cell applies (1 or 2 predecessors) | label (7 bits) | source
+    auto slot_of = [&](uint32_t col) { uint32_t k = 0; while (k + 1 < K && saved_col[k] != col) ++k; return k; };
+    auto pred_code = [&](uint32_t c, uint32_t q) { return c - q > near_limit ? 0x800u | slot_of(q) : c - q; };
     for (uint32_t i = tid; i < nC; i += BLOCK) {
-        const uint32_t b0 = poffC[i] - eC0, deg = poffC[i + 1] - poffC[i], l = labCp[i];
-        uint32_t is_saved = 0;
-        for (uint32_t k = 0; k < K; ++k) is_saved |= saved_col[k] == i + 1 ? 1u : 0u;
-        recC[i] = make_uint2(deg == 1 ? pidxC[poffC[i]] : b0, (deg & 0xFFFFu) | ((l & 0x7Fu) << 16) | (is_saved << 30) | ((l >> 7) << 31));
+        const uint32_t c = i + 1, b0 = poffC[i] - eC0, deg = poffC[i + 1] - poffC[i], l = labCp[i], src = l >> 7, nq = deg + src;
+        uint32_t x = 0;
+        if (nq >= 1 && nq <= 2) {
+            const uint32_t q0 = deg ? plC[b0] : 0u, q1 = deg == 2 ? plC[b0 + 1] : (src ? 0u : q0);
+            x = pred_code(c, q0) | (pred_code(c, q1) << 12);
+        }
+        bool is_saved = false;
+        for (uint32_t k = 0; k < K; ++k) is_saved |= saved_col[k] == c;
+        if (is_saved) x |= (1u << 26) | (slot_of(c) << 27);
+        recC[i] = make_uint2(x, b0 | (deg << 17) | ((nq >= 1 && nq <= 2) ? 1u << 23 : 0u) | ((l & 0x7Fu) << 24) | (src << 31));
     }
     const bool save_col0 = K && saved_col[0] == 0;   // the list is ascending
     // this thread's row (rows beyond nR idle)
@@ -734,18 +746,18 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     if (r >= 1 && r <= nR) {
         const uint32_t l = labRp[r - 1];
         degR = poffR[r] - poffR[r - 1];
-        firstR = degR == 1 ? pidxR[poffR[r - 1]] : poffR[r - 1] - eR0;
+        firstR = poffR[r - 1] - eR0;
         labR = l & 0x7Fu;
         srcR = l >> 7;
     }
     // up to two predecessors per side, a source's boundary index (row / column 0) counted as one: the straight-line cell below covers them
-    // with no data-dependent loop (a missing second predecessor repeats the first: the maxima do not care)
-    const bool fastR = r >= 1 && r <= nR && degR + (srcR ? 1u : 0u) <= 2 && degR + (srcR ? 1u : 0u) >= 1;
+    // with no data-dependent branch (a missing second predecessor repeats the first: the maxima do not care).  The boundary row 0 takes
+    // the same path with "predecessor rows" 0, its M and V forced to -inf afterwards
+    const bool fastR = r == 0 || (r <= nR && degR + (srcR ? 1u : 0u) <= 2 && degR + (srcR ? 1u : 0u) >= 1);
     uint32_t rp0 = 0, rp1 = 0;
-    if (fastR) {
-        if (degR == 0) rp0 = rp1 = 0;
-        else if (degR == 1) { rp0 = firstR; rp1 = srcR ? 0u : rp0; }
-        else { rp0 = plR[firstR]; rp1 = plR[firstR + 1]; }
+    if (r && fastR && degR) {
+        rp0 = plR[firstR];
+        rp1 = degR == 2 ? plR[firstR + 1] : (srcR ? 0u : rp0);
     }
     __syncthreads();
     const uint32_t last = nR + nC;
@@ -755,26 +767,28 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     // else in the saved area (the host saved every column that is read from further away)
     auto where = [&](uint32_t row, uint32_t col) -> const int32_t* {
         if (t - row - col < H) return ring + (row * row_stride + (col & hm) * CW);
-        uint32_t slot = 0;
-        while (slot + 1 < K && saved_col[slot] != col) ++slot;
-        return saved + (slot * (nR + 1) + row) * CW;
+        return saved + (slot_of(col) * (nR + 1) + row) * CW;
     };
-    auto get_mv = [&](uint32_t row, uint32_t col, int32_t& m, int32_t (&v)[NPW]) {   // M and the vertical gap values of a cell
-        const int4 x = reinterpret_cast<const int4*>(where(row, col))[0];
+    // one cell: NumPW 1: {M, V0, H0, M'}; NumPW 2, 3: {M, V0, V1, V2 | M', H0, H1, H2}.  M' is what a HORIZONTAL step reads as the cell's M:
+    // M itself, except on the boundary row, where it is -inf (the row only extends its gap: alignment.hpp:864-877) and 0 at the corner
+    // (where a source column opens it); the corner's M reads 0 as well (:814-818)
+    auto get_mv = [&](const int32_t* cell, int32_t& m, int32_t (&v)[NPW]) {   // M and the vertical gap values of a cell
+        const int4 x = reinterpret_cast<const int4*>(cell)[0];
         m = x.x; v[0] = x.y;
         if (NPW > 1) v[1] = x.z;
         if (NPW > 2) v[2] = x.w;
     };
-    auto get_mh = [&](uint32_t row, uint32_t col, int32_t& m, int32_t (&h)[NPW]) {   // M and the horizontal gap values
-        if (NPW == 1) { const int4 x = reinterpret_cast<const int4*>(where(row, col))[0]; m = x.x; h[0] = x.z; }
+    auto get_mh = [&](const int32_t* cell, int32_t& m, int32_t (&h)[NPW]) {   // M' and the horizontal gap values
+        if (NPW == 1) { const int4 x = reinterpret_cast<const int4*>(cell)[0]; m = x.w; h[0] = x.z; }
         else {
-            const int4 x = reinterpret_cast<const int4*>(where(row, col))[1];
+            const int4 x = reinterpret_cast<const int4*>(cell)[1];
             m = x.x; h[0] = x.y;
             if (NPW > 1) h[1] = x.z;
             if (NPW > 2) h[2] = x.w;
         }
     };
     auto get_m = [&](uint32_t row, uint32_t col) -> int32_t { return where(row, col)[0]; };
+    const uint32_t saved_off = (uint32_t)(saved - ring), slot_stride = (nR + 1) * CW;
     int32_t* const my_row = ring + r * row_stride;
     int32_t* const plane0 = pl.M();
     const size_t plane_stride = pl.cells;
@@ -785,39 +799,46 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
             int32_t M = CL_NEG_INF, V[NPW], Hh[NPW];
 #pragma unroll
             for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; Hh[k] = CL_NEG_INF; }
-            uint32_t degC = 0, firstC = 0, labC = 0;
-            bool srcC = false, keep = !c && save_col0;
+            uint32_t degC = 0, firstC = 0, labC = 0, keep_slot = 0;
+            bool srcC = false, keep = !c && save_col0, fastC = false;
+            uint2 rc = make_uint2(0, 0);
             if (c) {
-                const uint2 rc = recC[c - 1];
-                degC = rc.y & 0xFFFFu; firstC = rc.x; labC = (rc.y >> 16) & 0x7Fu; srcC = rc.y >> 31; keep = (rc.y >> 30) & 1u;
+                rc = recC[c - 1];
+                firstC = rc.y & 0x1FFFFu; degC = (rc.y >> 17) & 63u; fastC = (rc.y >> 23) & 1u; labC = (rc.y >> 24) & 0x7Fu; srcC = rc.y >> 31;
+                keep = (rc.x >> 26) & 1u; keep_slot = rc.x >> 27;
             }
-            const uint32_t nqC = degC + (srcC ? 1u : 0u);
-            if (r && c && fastR && nqC >= 1 && nqC <= 2) {
-                // the usual cell, straight-line: two predecessors per side (the second may repeat the first), eight independent LDS reads.
-                // The boundary row / column as a predecessor needs no special case: its V (H) values are -inf in LDS, so "extend from
-                // the boundary" never wins, and only the corner's M counts as 0 (alignment.hpp:814-818)
-                uint32_t q0, q1;
-                if (degC == 0) q0 = q1 = 0;
-                else if (degC == 1) { q0 = firstC; q1 = srcC ? 0u : q0; }
-                else { q0 = plC[firstC]; q1 = plC[firstC + 1]; }
+            if (c && fastC && fastR) {
+                // the usual cell, straight-line: two predecessors per side (the second may repeat the first), eight independent LDS reads
+                // at addresses that are selects and multiply-adds of the column record
+                const uint32_t e0 = rc.x & 0xFFFu, e1 = (rc.x >> 12) & 0xFFFu;
+                const bool f0 = e0 & 0x800u, f1 = e1 & 0x800u;
+                const uint32_t o0 = f0 ? saved_off + (e0 & 0x7FFu) * slot_stride : ((c - e0) & hm) * CW;
+                const uint32_t o1 = f1 ? saved_off + (e1 & 0x7FFu) * slot_stride : ((c - e1) & hm) * CW;
+                const uint32_t s0 = f0 ? (uint32_t)CW : row_stride, s1 = f1 ? (uint32_t)CW : row_stride;
+                const uint32_t oc = (c & hm) * CW;
                 int32_t mv0, mv1, mh0, mh1, vv0[NPW], vv1[NPW], hh0[NPW], hh1[NPW];
-                get_mv(rp0, c, mv0, vv0);
-                get_mv(rp1, c, mv1, vv1);
-                get_mh(r, q0, mh0, hh0);
-                get_mh(r, q1, mh1, hh1);
-                const int32_t d00 = (rp0 | q0) ? get_m(rp0, q0) : 0, d01 = (rp0 | q1) ? get_m(rp0, q1) : 0;
-                const int32_t d10 = (rp1 | q0) ? get_m(rp1, q0) : 0, d11 = (rp1 | q1) ? get_m(rp1, q1) : 0;
+                get_mv(ring + (rp0 * row_stride + oc), mv0, vv0);
+                get_mv(ring + (rp1 * row_stride + oc), mv1, vv1);
+                get_mh(ring + (o0 + r * s0), mh0, hh0);
+                get_mh(ring + (o1 + r * s1), mh1, hh1);
+                const int32_t d00 = ring[o0 + rp0 * s0], d01 = ring[o1 + rp0 * s1];
+                const int32_t d10 = ring[o0 + rp1 * s0], d11 = ring[o1 + rp1 * s1];
                 M = imax(imax(d00, d01), imax(d10, d11)) + ((labR == labC) ? P.match : -P.mismatch);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) {
                     V[k] = imax(imax(mv0 - P.oe[k], vv0[k] - P.ext[k]), imax(mv1 - P.oe[k], vv1[k] - P.ext[k]));
                     Hh[k] = imax(imax(mh0 - P.oe[k], hh0[k] - P.ext[k]), imax(mh1 - P.oe[k], hh1[k] - P.ext[k]));
                 }
+                if (!r) {   // the boundary row has no M and no vertical gap (what was read for them is its own unwritten cell)
+                    M = CL_NEG_INF;
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = CL_NEG_INF;
+                }
             } else if (r && !c) {          // boundary column: gap extensions down the row graph (alignment.hpp:832-845)
                 for (uint32_t e = 0; e < degR; ++e) {
-                    const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                    const uint32_t p = plR[firstR + e];
                     int32_t m, vv[NPW];
-                    get_mv(p, 0, m, vv);
+                    get_mv(where(p, 0), m, vv);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], vv[k] - P.ext[k]);
                 }
@@ -827,9 +848,9 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
                 }
             } else if (!r && c) {   // boundary row (:864-877)
                 for (uint32_t f = 0; f < degC; ++f) {
-                    const uint32_t q = degC == 1 ? firstC : plC[firstC + f];
+                    const uint32_t q = plC[firstC + f];
                     int32_t m, hh[NPW];
-                    get_mh(0, q, m, hh);
+                    get_mh(where(0, q), m, hh);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], hh[k] - P.ext[k]);
                 }
@@ -839,9 +860,9 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
                 }
             } else if (r && c) {    // interior, any degrees (:897-938 in pull form, see compute_cell)
                 for (uint32_t e = 0; e < degR; ++e) {
-                    const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                    const uint32_t p = plR[firstR + e];
                     int32_t m, vv[NPW];
-                    get_mv(p, c, m, vv);
+                    get_mv(where(p, c), m, vv);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m - P.oe[k], vv[k] - P.ext[k]));
                 }
@@ -852,13 +873,13 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
                 }
                 const int32_t s = (labR == labC) ? P.match : -P.mismatch;
                 for (uint32_t f = 0; f < degC; ++f) {
-                    const uint32_t q = degC == 1 ? firstC : plC[firstC + f];
+                    const uint32_t q = plC[firstC + f];
                     int32_t m, hh[NPW];
-                    get_mh(r, q, m, hh);
+                    get_mh(where(r, q), m, hh);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], hh[k] - P.ext[k]));
                     for (uint32_t e = 0; e < degR; ++e) {
-                        const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                        const uint32_t p = plR[firstR + e];
                         M = imax(M, get_m(p, q) + s);
                     }
                     if (srcR) M = imax(M, get_m(0, q) + s);
@@ -868,7 +889,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], m - P.oe[k]);
                     for (uint32_t e = 0; e < degR; ++e) {
-                        const uint32_t p = degR == 1 ? firstR : plR[firstR + e];
+                        const uint32_t p = plR[firstR + e];
                         M = imax(M, get_m(p, 0) + s);
                     }
                     if (srcR) M = imax(M, s);   // the corner counts as 0 (:814-818)
@@ -876,15 +897,15 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
             }
 #pragma unroll
             for (int k = 0; k < NPW; ++k) M = imax(M, imax(V[k], Hh[k]));
-            const int4 w0 = NPW == 1 ? make_int4(M, V[0], Hh[0], 0) : make_int4(M, V[0], V[NPW > 1 ? 1 : 0], V[NPW > 2 ? 2 : 0]);
-            const int4 w1 = make_int4(M, Hh[0], Hh[NPW > 1 ? 1 : 0], Hh[NPW > 2 ? 2 : 0]);
+            // the LDS copy: the corner's M reads 0, the boundary row's M' -inf (see get_mh)
+            const int32_t Ml = (r | c) ? M : 0, Mh = r ? M : (c ? CL_NEG_INF : 0);
+            const int4 w0 = NPW == 1 ? make_int4(Ml, V[0], Hh[0], Mh) : make_int4(Ml, V[0], V[NPW > 1 ? 1 : 0], V[NPW > 2 ? 2 : 0]);
+            const int4 w1 = make_int4(Mh, Hh[0], Hh[NPW > 1 ? 1 : 0], Hh[NPW > 2 ? 2 : 0]);
             int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
             w[0] = w0;
             if (NPW > 1) w[1] = w1;
             if (keep) {   // a saved column: its cells stay available for the far reads
-                uint32_t slot = 0;
-                while (slot + 1 < K && saved_col[slot] != c) ++slot;
-                int4* sw = reinterpret_cast<int4*>(saved + (slot * (nR + 1) + r) * CW);
+                int4* sw = reinterpret_cast<int4*>(saved + ((c ? keep_slot : 0u) * (nR + 1) + r) * CW);
                 sw[0] = w0;
                 if (NPW > 1) sw[1] = w1;
             }
