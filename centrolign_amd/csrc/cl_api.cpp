@@ -644,6 +644,7 @@ void cl_context_destroy(cl_context* ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 

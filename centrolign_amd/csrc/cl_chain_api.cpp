@@ -190,9 +190,7 @@ struct Combo {
         std::vector<uint32_t> recs;         // the instance's records in this combination
         std::vector<uint32_t> ortho_order;  // ... sorted by (sigma, slot)
         std::vector<uint32_t> ortho_heap, ortho_rank_of_heap;
-        std::unordered_map<int32_t, std::vector<uint32_t>> by_diag;  // gap-free trees: records of each shift
         std::unordered_map<int32_t, GapFreeTree> diag_tree;
-        bool diag_built = false;
     };
     std::unordered_map<uint32_t, SubRecs> per_sub;
     bool split_built = false;
@@ -781,9 +779,12 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     // ---- branch-and-bound far pass: record image, the two static orders per level, the sealing schedule -------------------
     static const bool no_far_env = getenv("CL_CHAIN_NO_FAR_PRUNE") != nullptr;
     const uint32_t n_macro_all = (uint32_t)((M + kChainMacro - 1) / kChainMacro);
-    // far launches in flight: 2 by default (measured on 10 x 1 Mbp: 2, 4 and 8 within 5 % of one another on one context, 2 best with four
-    // worker contexts, whose streams share the hardware queues); CL_CHAIN_FAR_LAG=1..8 for measurements
-    static const uint32_t far_lag = [] { const char* e = getenv("CL_CHAIN_FAR_LAG"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= (int)kFarLag ? v : 2); }();
+    // far launches in flight: 4 by default in the affine DP.  Measured: the 2 x 1 Mbp affine DP's device time is 1045 / 540 / 393 / 372 / 340 ms at 1 / 2 / 3 /
+    // 4 / 6 in flight (a far launch is 1024 queries, too few to fill the chip alone); the 10 x 1 Mbp MSA with four worker contexts is
+    // within 3 % for 2, 3 and 4 and 5 % slower at 6 (the near pass grows with the lag).  CL_CHAIN_FAR_LAG=1..8 for measurements
+    // The gap-free DP's far pass opens a tenth of the leaves, so its near pass is what grows: 175 ms at 2 in flight, 253 ms at 4 — it keeps 2
+    static const uint32_t far_lag_env = [] { const char* e = getenv("CL_CHAIN_FAR_LAG"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= (int)kFarLag ? v : 0); }();
+    const uint32_t far_lag = far_lag_env ? far_lag_env : sparse ? 2u : 4u;
     bool use_far = use_walk && !no_far_env && n_macro_all >= far_lag + 3;
     if (use_far) {
         uint32_t max_n = 0;
@@ -1049,14 +1050,36 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 
+    lap("sync");
     std::vector<float> dp_sorted(M);
     he = cl_copy_sync(ctx, dp_sorted.data(), d_dp.p, M * sizeof(float), hipMemcpyDeviceToHost);
-    std::vector<std::vector<int>> acc(combos.size());
-    for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
-        acc[ci].resize(M * 7);
-        he = cl_copy_sync(ctx, acc[ci].data(), combos[ci].d_acc.p, M * 7 * sizeof(int), hipMemcpyDeviceToHost);
+    // the stored query results of every combination (7 per pair): into the context's page-locked area when it can be had — 35 MB per
+    // combination at 1.25 M pairs, 25 combinations at the root of a 10-sequence tree
+    std::vector<std::vector<int>> acc_own;
+    std::vector<const int*> acc(combos.size(), nullptr);
+    if (he == hipSuccess) {
+        const size_t per = (size_t)M * 7;
+        int* pin = (int*)cl_pinned(ctx, combos.size() * per * sizeof(int));
+        if (pin) {
+            for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
+                acc[ci] = pin + ci * per;
+                he = hipMemcpyAsync(pin + ci * per, combos[ci].d_acc.p, per * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        } else {
+            acc_own.resize(combos.size());
+            for (size_t ci = 0; ci < combos.size() && he == hipSuccess; ++ci) {
+                acc_own[ci].resize(per);
+                acc[ci] = acc_own[ci].data();
+                he = cl_copy_sync(ctx, acc_own[ci].data(), combos[ci].d_acc.p, per * sizeof(int), hipMemcpyDeviceToHost);
+            }
+        }
     }
     if (he != hipSuccess) { cl_set_error(ctx, "download failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
+    lap("download");
+    double t_split = 0, t_ortho = 0, t_diag = 0, t_gapfree = 0, t_cand = 0;   // CL_CHAIN_TIMING: where the traceback's time goes
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tadd = [&](double& acc_ms, std::chrono::steady_clock::time_point t0) { acc_ms += std::chrono::duration<double, std::milli>(tnow() - t0).count(); };
 
     const auto T1 = std::chrono::steady_clock::now();
     // value index: per combination and tree kind, (encoded stored value, record) sorted by value — built on first use: the
@@ -1097,12 +1120,36 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     // records of one instance inside a combination (the reference's trees belong to ONE chaining call)
     auto sub_recs = [&](Combo& c, uint32_t k) -> Combo::SubRecs& {
         if (!c.split_built) {
-            for (uint32_t r = 0; r < c.rec_s.size(); ++r) c.per_sub[pairs[by_s[c.rec_s[r]]].sub].recs.push_back(r);
+            const auto t0 = tnow();
+            if (K == 1) {
+                auto& recs = c.per_sub[0].recs;
+                recs.resize(c.rec_s.size());
+                std::iota(recs.begin(), recs.end(), 0u);
+            } else {
+                std::vector<Combo::SubRecs*> of_sub(K, nullptr);
+                for (uint32_t r = 0; r < c.rec_s.size(); ++r) {
+                    const uint32_t sub = pairs[by_s[c.rec_s[r]]].sub;
+                    if (!of_sub[sub]) of_sub[sub] = &c.per_sub[sub];   // unordered_map: references stay valid across insertions
+                    of_sub[sub]->recs.push_back(r);
+                }
+            }
             c.split_built = true;
+            tadd(t_split, t0);
         }
         return c.per_sub[k];
     };
 
+    // an instance's records of one combination in (shift, slot) order with the implicit-heap layout of the reference's outer tree
+    auto ortho_of = [&](Combo::SubRecs& sr, const Combo& c) {
+        if (!sr.ortho_order.empty()) return;
+        const auto t0 = tnow();
+        sr.ortho_order = sr.recs;
+        sort_by_key_then_slot(sr.ortho_order, M, [&](uint32_t r) { return (int64_t)c.sigma[r]; }, [&](uint32_t r) { return by_s[c.rec_s[r]]; });
+        sr.ortho_heap = heap_of_rank(sr.ortho_order.size());
+        sr.ortho_rank_of_heap.resize(sr.ortho_order.size());
+        for (size_t r = 0; r < sr.ortho_order.size(); ++r) sr.ortho_rank_of_heap[sr.ortho_heap[r]] = (uint32_t)r;
+        tadd(t_ortho, t0);
+    };
     uint64_t n_scanned = 0, n_steps = 0;
     // ---- optimum and traceback (anchorer.hpp:2483-2531), instance by instance -----------------------------------------
     for (uint32_t k = 0; k < K; ++k) {
@@ -1164,6 +1211,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             // every predecessor whose stored value equals the query's maximum and which lies in the query's range
             std::vector<uint32_t> cand;
             {
+                const auto t0 = tnow();
                 const int target = acc[win_combo][(size_t)s * 7 + win_kind];
                 if (!value_index((size_t)win_combo, win_kind)) { release_index(); cleanup(); return CL_ERR_HIP; }
                 const auto& keys = vkeys[win_combo][win_kind];
@@ -1178,6 +1226,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                     const bool kind_ok = win_kind == 0 ? sg == qq : ((win_kind - 1) % 2 == 1 ? sg < qq : sg > qq);
                     if (kind_ok && c.ins_t[r] <= qt && c.off[r] < qoff) cand.push_back(r);
                 }
+                tadd(t_cand, t0);
             }
             const uint32_t count = (uint32_t)cand.size();
             if (count == 0) { cl_set_error(ctx, "traceback: query of pair %u has no predecessor at its maximum", here); cleanup(); return CL_ERR_HIP; }
@@ -1196,13 +1245,15 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                     GapFreeTree* tree;
                     if (!sparse) {
                         Combo::SubRecs& sr = sub_recs(c, k);
-                        if (!sr.diag_built) {  // records bucketed by shift, built once
-                            for (uint32_t r : sr.recs) sr.by_diag[c.sigma[r]].push_back(r);
-                            sr.diag_built = true;
-                        }
                         tree = &sr.diag_tree[c.q[s]];
-                        if (!tree->built)
-                            for (uint32_t r : sr.by_diag[c.q[s]]) tree->mem.push_back(GapFreeTree::Member{c.off[r], slot_of_rec(r), r});
+                        if (!tree->built) {   // the records of this shift are one run of the (shift, slot) order
+                            const auto t0 = tnow();
+                            ortho_of(sr, c);
+                            const int32_t qq = c.q[s];
+                            auto it = std::partition_point(sr.ortho_order.begin(), sr.ortho_order.end(), [&](uint32_t r) { return c.sigma[r] < qq; });
+                            for (; it != sr.ortho_order.end() && c.sigma[*it] == qq; ++it) tree->mem.push_back(GapFreeTree::Member{c.off[*it], slot_of_rec(*it), *it});
+                            tadd(t_diag, t0);
+                        }
                     } else {
                         tree = &sparse_trees[((uint64_t)c.p2 << 32) | k];
                         if (!tree->built)
@@ -1211,6 +1262,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                                     for (uint32_t r : sub_recs(oc, k).recs) tree->mem.push_back(GapFreeTree::Member{oc.off[r], by_s[oc.rec_s[r]], r});
                     }
                     if (!tree->built) {
+                        const auto t0 = tnow();
                         {
                             std::vector<uint32_t> idx(tree->mem.size());
                             std::iota(idx.begin(), idx.end(), 0u);
@@ -1224,6 +1276,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                         tree->rank_of_heap.resize(tree->mem.size());
                         for (size_t r = 0; r < tree->mem.size(); ++r) tree->rank_of_heap[tree->heap[r]] = (uint32_t)r;
                         tree->built = true;
+                        tadd(t_gapfree, t0);
                     }
                     const auto& mem = tree->mem;
                     const size_t n = mem.size();
@@ -1252,13 +1305,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
                     // cross tree the values are (score, outer index) pairs, so the larger outer heap index wins
                     Combo::SubRecs& sr = sub_recs(c, k);
                     auto key_less = [&](uint32_t a, uint32_t b) { return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b); };
-                    if (sr.ortho_order.empty()) {
-                        sr.ortho_order = sr.recs;
-                        sort_by_key_then_slot(sr.ortho_order, M, [&](uint32_t r) { return (int64_t)c.sigma[r]; }, [&](uint32_t r) { return slot_of_rec(r); });
-                        sr.ortho_heap = heap_of_rank(sr.ortho_order.size());
-                        sr.ortho_rank_of_heap.resize(sr.ortho_order.size());
-                        for (size_t r = 0; r < sr.ortho_order.size(); ++r) sr.ortho_rank_of_heap[sr.ortho_heap[r]] = (uint32_t)r;
-                    }
+                    ortho_of(sr, c);
                     const size_t n = sr.ortho_order.size();
                     const int32_t qq = c.q[s];
                     const bool odd = (win_kind - 1) % 2 == 1;
@@ -1322,7 +1369,9 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     release_index();
     tm.index_ms += index_ms;
     tm.traceback_ms += ms_since(T2) - index_ms;
-    if (timing) fprintf(stderr, "[chain_dp_batch]   traceback: %llu steps, %llu equal-valued records scanned\n", (unsigned long long)n_steps, (unsigned long long)n_scanned);
+    if (timing) fprintf(stderr, "[chain_dp_batch]   traceback: %llu steps, %llu equal-valued records scanned; split %.1f ortho %.1f by-shift %.1f gap-free trees %.1f candidates (incl. value index) %.1f ms\n",
+                        (unsigned long long)n_steps, (unsigned long long)n_scanned, t_split, t_ortho, t_diag, t_gapfree, t_cand);
+    lap("traceback");
     if (dp_out) {
         dp_out->resize(M);
         for (uint32_t slot = 0; slot < M; ++slot) (*dp_out)[slot] = dp_sorted[s_of_slot[slot]];

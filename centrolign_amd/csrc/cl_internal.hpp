@@ -21,7 +21,23 @@ struct cl_context {
     hipEvent_t ev_join[kNumAuxStreams] = {};
     std::string error;
     std::string name;
+    // page-locked host staging area, grown on demand and kept for the context's lifetime (cl_pinned): device-to-host copies into it run
+    // at the link's rate, copies into pageable memory at a tenth of it, and locking pages is too slow to do per call
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
 };
+
+// at least `bytes` of page-locked host memory owned by the context (contents undefined; one user at a time); nullptr when it cannot be had
+inline void* cl_pinned(cl_context* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) return ctx->pinned;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    const size_t want = bytes + bytes / 8;
+    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; (void)hipGetLastError(); return nullptr; }
+    ctx->pinned_bytes = want;
+    return ctx->pinned;
+}
 
 // defined in cl_api.cpp
 void cl_set_error(cl_context* ctx, const char* fmt, ...);

@@ -1,5 +1,5 @@
 """per-launch times of the stitch pass on REAL graph x graph batches: the merges of a 10-sequence MSA (200 kbp per sequence by default),
-replayed from resident plans; CL_DEBUG_SKIP_TRACEBACK=1 times the fill alone, CL_NO_SYS=1 the older kernels"""
+replayed from resident plans; a second argument "fill" times the fill alone, CL_NO_SYS=1 the older kernels"""
 import os
 import sys
 
@@ -13,6 +13,8 @@ def main():
     names, seqs, tree = synth.c3_workload(length)
     ctx = capi.Context(0)
     r = msa.progressive_msa(ctx, seqs, tree, max_num_match_pairs=400000, workers=4, keep_merges=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "fill":   # read when a plan is made: the MSA above needed its tracebacks
+        os.environ["CL_DEBUG_SKIP_TRACEBACK"] = "1"
     for m, b in stitch_batches(r["stats"]["kept"])[4:]:
         plan = ctx.plan(b)
         for _ in range(2):
