@@ -77,7 +77,9 @@ constexpr int kFarFanShift = 3;
 constexpr int kFarMaxLevels = 4;     // up to 32768 records: one wave seals a node in about a millisecond
 constexpr uint32_t kFarLag = 8;       // upper limit of the far pass's lag: the far pass of macro-block k reads the records final `lag`
                                       // macro-blocks earlier, so that many far launches run side by side (cl_chain_api.cpp picks the lag)
-constexpr int kFarBandShift = 16;   // shift buckets of 65536: beyond that the gap cost is on its last, nearly flat piece
+constexpr int kFarBandShift = 16;   // shift buckets of 65536 by default (ClFarDevice::band_shift; wider when the shifts span more than 2^15 buckets): beyond
+                                    // that the gap cost is on its last, nearly flat piece.  Measured on 2 x 1 Mbp: buckets of 4096 / 1024 / 256 open 3.4x /
+                                    // 3.6x / 3.7x the leaves (the "everything else pays one bucket width" term gets weak), 572 / 751 / 812 ms against 366
 
 struct ClFarLevel {
     uint32_t* key_o;             // [r_pad] offset, ascending within a node
@@ -92,6 +94,7 @@ struct ClFarDevice {
     uint32_t n_levels, r_pad;
     ClFarLevel lv[kFarMaxLevels];
     int32_t sig_bias;            // added to a shift before bucketing (buckets are non-negative)
+    uint32_t band_shift;         // log2 of the bucket width
     double band_pen;             // least gap cost of a shift difference of one bucket width or more
     double slack_t0;             // rounding allowance of a bound: 2^-21 (|dp| + slack_t0 + slack_e0 |query shift| + |weight|)
     double slack_e0;

@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t count_below(const K* __restrict__ k, uint32_
 
 // ---- setup: the record image and the sort keys -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) far_init_kernel(const ClChainCombo* combos, const uint32_t* base, uint32_t n_combos, uint32_t r_pad,
-                                                       int32_t sig_bias, int* rec, uint32_t* key_off, unsigned long long* key_band, uint32_t* idx) {
+                                                       int32_t sig_bias, uint32_t band_shift, int* rec, uint32_t* key_off, unsigned long long* key_band, uint32_t* idx) {
     const uint32_t c = blockIdx.y;
     const ClChainCombo cb = combos[c];
     const uint32_t b0 = base[c], b1 = c + 1 < n_combos ? base[c + 1] : r_pad;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) far_init_kernel(const ClChainCombo* combo
     unsigned long long bucket = 0xFFFFull;   // padding: beyond every real bucket (< 0x8000), keys stay below 2^48
     if (pos < cb.n_recs) {
         ins = cb.ins_t[pos]; off = cb.off[pos]; sg = cb.sigma[pos];
-        bucket = (unsigned long long)((uint32_t)(sg + sig_bias) >> kFarBandShift);
+        bucket = (unsigned long long)((uint32_t)(sg + sig_bias) >> band_shift);
     }
     int4* r = reinterpret_cast<int4*>(rec + (size_t)g * 12);
     r[0] = make_int4((int)ins, (int)off, sg, none);
@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
 
 // ---- the pass -------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kFarStack = 80;
+constexpr uint32_t kFarCoverCache = 12;   // rounds of eight cover nodes whose bounds the probe leaves in LDS for the pass proper (96 nodes: 2.7 M records)
 
 struct FarQuery {
     uint32_t qt, qoff, bq;
@@ -310,9 +311,11 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     // shift bucket of the query; the host picks sig_bias so that every record's bucket lies in [1, 0x8000): a query whose biased
     // shift is negative is more than a bucket width away from every record
     const long long qb = (long long)Q.q + (long long)F.sig_bias;
-    Q.bq = qb < 0 ? 0xFFFF0000u : (uint32_t)(qb >> kFarBandShift);
+    Q.bq = qb < 0 ? 0xFFFF0000u : (uint32_t)(qb >> F.band_shift);
     const uint32_t top = F.n_levels - 1;
 
+    // bounds of the cover nodes, computed once by the probe: they depend on the query alone, only what they are compared with changes
+    __shared__ double s_cover[32][kFarCoverCache][8];
     uint32_t n_scanned = 0;
     // ---- probe: follow the largest bound down to one leaf.  A query whose best predecessor lies far back (a pair on a distant
     //      diagonal chains from wherever the main chain passed its graph-2 position) would otherwise open every node between
@@ -321,11 +324,12 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         double pb = -HUGE_VAL;
         uint32_t pcode = 0xFFFFFFFFu;
         uint32_t p = E;
-        while (p > 0) {
+        for (uint32_t round = 0; p > 0; ++round) {
             uint32_t lvl, a = 0;
             next_cover(p, sub, top, lvl, a);
             if (lvl != 0xFFu) {
                 const double b = node_bound<SPARSE>(F, lvl, base + a, Q);
+                if (round < kFarCoverCache) s_cover[grp][round][sub] = b;
                 const uint32_t code = (lvl << 28) | (a >> kFarLeafShift);
                 if (b > pb || (b == pb && code < pcode)) { pb = b; pcode = code; }
             }
@@ -352,9 +356,11 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     volatile uint32_t* st = s_stack[grp];
     uint32_t sp = 0;
     uint32_t p = E;                                              // cover nodes still to hand out lie in [0, p)
+    uint32_t cover_round = 0;
     while (true) {
         // this round's node for this lane: (level, first record), level 0xFF = none
         uint32_t lvl = 0xFFu, a = 0;
+        bool cached = false;
         if (sp > 0) {
             const uint32_t e = st[sp - 1];
             --sp;
@@ -362,11 +368,13 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
             a = ((e & 0x0FFFFFFFu) << kFarLeafShift) + ((7u - sub) << (kFarLeafShift + kFarFanShift * lvl));   // lane 0 takes the nearest child
         } else if (p > 0) {
             next_cover(p, sub, top, lvl, a);
+            cached = cover_round < kFarCoverCache;
+            ++cover_round;
         } else {
             break;
         }
         bool hit = false;
-        if (lvl != 0xFFu) hit = node_bound<SPARSE>(F, lvl, base + a, Q) >= (double)best;
+        if (lvl != 0xFFu) hit = (cached ? s_cover[grp][cover_round - 1][sub] : node_bound<SPARSE>(F, lvl, base + a, Q)) >= (double)best;
         if (hit && lvl == 0) { best = scan_leaf<SPARSE>(rec, base + a, Q, acc, best, pen); ++n_scanned; }
         // surviving inner nodes go on the stack, nearest (lane 0) on top
         const bool push = hit && lvl != 0 && lvl != 0xFFu;
@@ -409,10 +417,10 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
 }  // namespace
 
 // ---- host entry points ---------------------------------------------------------------------------------------------------
-hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias,
+hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias, uint32_t band_shift,
                              uint32_t* key_off, unsigned long long* key_band, uint32_t* idx, hipStream_t stream) {
     hipLaunchKernelGGL(far_init_kernel, dim3((max_padded + 255) / 256, D.n_combos), dim3(256), 0, stream, D.combos, d_base, D.n_combos, r_pad,
-                       sig_bias, D.far_rec, key_off, key_band, idx);
+                       sig_bias, band_shift, D.far_rec, key_off, key_band, idx);
     return hipGetLastError();
 }
 

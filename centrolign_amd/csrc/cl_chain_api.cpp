@@ -39,7 +39,7 @@ hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, u
 hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream);
 hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
 // chain_far.hip
-hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias,
+hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias, uint32_t band_shift,
                              uint32_t* key_off, unsigned long long* key_band, uint32_t* idx, hipStream_t stream);
 size_t cl_chain_far_sort_temp_bytes(uint32_t n);
 hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
@@ -804,16 +804,21 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             max_padded = std::max(max_padded, padded);
             r_pad += padded;
         }
-        const int64_t bias = 65536 - smin;
+        // shift buckets: kFarBandShift wide unless the shifts then span more than the 15 bits a bucket number has (CL_CHAIN_FAR_BAND for measurements)
+        static const int band_env = [] { const char* e = getenv("CL_CHAIN_FAR_BAND"); int v = e ? atoi(e) : 0; return v >= 4 && v <= 24 ? v : kFarBandShift; }();
+        uint32_t band_shift = (uint32_t)band_env;
+        while (smin != INT64_MAX && band_shift < 30 && (((smax - smin) >> band_shift) + 3) >= 0x7FFF) ++band_shift;
+        const int64_t bias = (1ll << band_shift) - smin;
         if (r_pad == 0 || r_pad >= (1ull << 31) || smin == INT64_MAX || smax + bias >= (1ll << 31) || bias >= (1ll << 31)) use_far = false;
         if (use_far) {
             const uint32_t R = (uint32_t)r_pad;
             F.n_levels = n_levels;
             F.r_pad = R;
             F.sig_bias = (int32_t)bias;
+            F.band_shift = band_shift;
             double pw = 1e300, omax = 0, emax = 0;
             for (int k = 0; k < 3; ++k) {
-                pw = std::min(pw, local_scale * (cp->gap_open[k] + cp->gap_extend[k] * 65536.0));
+                pw = std::min(pw, local_scale * (cp->gap_open[k] + cp->gap_extend[k] * (double)(1ull << band_shift)));
                 omax = std::max(omax, cp->gap_open[k]);
                 emax = std::max(emax, cp->gap_extend[k]);
             }
@@ -829,7 +834,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             for (int i = 0; i < 2; ++i) CH(d_far_u64[i].alloc(ctx, R));
             const size_t temp_bytes = cl_chain_far_sort_temp_bytes(R);
             CH(d_far_temp.alloc(ctx, temp_bytes));
-            hipError_t fe = cl_chain_far_init(D, d_far_base.p, (uint32_t)max_padded, R, F.sig_bias, d_far_u32[0].p, d_far_u64[0].p, d_far_u32[1].p, ctx->stream);
+            hipError_t fe = cl_chain_far_init(D, d_far_base.p, (uint32_t)max_padded, R, F.sig_bias, F.band_shift, d_far_u32[0].p, d_far_u64[0].p, d_far_u32[1].p, ctx->stream);
             if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[0].p, d_far_u32[5].p, d_far_u32[1].p, d_far_u32[2].p, R, 32, ctx->stream);
             if (fe == hipSuccess && !sparse) fe = cl_chain_far_sort64(d_far_temp.p, temp_bytes, d_far_u64[0].p, d_far_u64[1].p, d_far_u32[1].p, d_far_u32[3].p, R, 48, ctx->stream);
             for (uint32_t l = 0; l < n_levels && fe == hipSuccess; ++l) {
