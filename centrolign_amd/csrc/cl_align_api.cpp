@@ -9,7 +9,12 @@
 #include <cstring>
 #include <vector>
 
+#include <thread>
+
 #include "cl_internal.hpp"
+#include "stitch_host.hpp"
+
+thread_local ClSharedTables cl_tls_tables;
 
 extern "C" {
 
@@ -39,6 +44,22 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
              cl_core_align_result* out) {
     if (!ctx || !g1 || !g2 || !matches || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
+    // the two PathMerge tables, built side by side and shared by every stage below (cl_internal.hpp: cl_shared_table)
+    clhost::PathMergeTable x1, x2;
+    {
+        bool ok2 = false;
+        std::thread other([&] { ok2 = x2.build(*g2); });
+        const bool ok1 = x1.build(*g1);
+        other.join();
+        if (!ok1 || !ok2) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    }
+    struct Registered {
+        ClSharedTables saved;
+        Registered(const cl_base_graph* a, const clhost::PathMergeTable* xa, const cl_base_graph* b, const clhost::PathMergeTable* xb) : saved(cl_tls_tables) {
+            cl_tls_tables.g[0] = a; cl_tls_tables.x[0] = xa; cl_tls_tables.g[1] = b; cl_tls_tables.x[1] = xb;
+        }
+        ~Registered() { cl_tls_tables = saved; }
+    } registered(g1, &x1, g2, &x2);
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(now() - t).count(); };
     int rc;

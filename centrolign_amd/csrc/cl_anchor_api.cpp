@@ -581,7 +581,7 @@ int cl_partition_anchors(const cl_base_graph* g1, const cl_base_graph* g2, const
         std::vector<uint64_t> seg_off{0, n};
         cl_anchor_segments sg{n ? 1u : 0u, seg_off.data(), an->walk_off, an->walk1, an->walk2};
         clhost::OwnedBatch ob;
-        const int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob);
+        const int rc = clhost::extract_stitch_batch(*g1, *g2, sg, ob, cl_shared_table(g1), cl_shared_table(g2));
         if (rc) return rc;
         const size_t n_gaps = ob.only_del.size();
         std::vector<std::pair<double, double>> data(n + n_gaps);

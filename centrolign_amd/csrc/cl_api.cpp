@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <chrono>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -44,7 +45,7 @@ const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); re
 const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
 constexpr uint64_t kSysLdsBytes = 120 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
-constexpr uint64_t kRingLdsBytes = 64 * 1024;   // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU)
+constexpr uint64_t kRingLdsBytes = 128 * 1024;  // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU); launches are split at 64 KB
 // test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
 const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && *e == '1'; }();
 
@@ -667,6 +668,12 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     for (int k = 0; k < 3; ++k)
         if (ap.gap_open[k] > (1u << 24) || ap.gap_extend[k] > (1u << 24)) { set_error(ctx, "gap penalties too large"); return CL_ERR_INVALID_ARGUMENT; }
 
+    static const bool timing = getenv("CL_STITCH_TIMING") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[cl_stitch]     %-20s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
+        tp = std::chrono::steady_clock::now();
+    };
     cl_stitch_plan* pl = new (std::nothrow) cl_stitch_plan();
     if (!pl) return CL_ERR_OUT_OF_MEMORY;
     pl->n_problems = n;
@@ -684,55 +691,61 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
     }
 
-    // host-side packing into rank space
-    std::vector<uint8_t> lab[2];
-    std::vector<uint32_t> poff[2], pidx[2], snk[2];
-    poff[0].push_back(0);
-    poff[1].push_back(0);
-    std::vector<uint32_t> order, st, indeg, rank;
-    std::vector<uint32_t> ring_need;   // per PO-POA problem: dynamic LDS of the ring variant of the general kernel (0 = not taken)
-    std::vector<uint32_t> sys_aux;     // saved-column lists of the systolic kernel's problems, concatenated
-    uint64_t plane_cursor = 0, out_cursor = 0;
-
-    for (uint64_t k = 0; k < n; ++k) {
+    // host-side packing into rank space.  The subproblems are independent: chunks of them are packed side by side into parts of their own
+    // (offsets relative to the part) and the parts are appended in order, which gives exactly the arrays of a serial pass
+    struct PackPart {
+        std::vector<uint8_t> lab[2];
+        std::vector<uint32_t> poff[2], pidx[2], snk[2], order[2];
+        std::vector<uint32_t> ring_need;   // per PO-POA problem: dynamic LDS of the ring / systolic variant (0 = not taken)
+        std::vector<uint32_t> sys_aux;     // saved-column lists of the systolic kernel's problems, concatenated
+        std::vector<ClProbDesc> desc;
+        std::vector<uint64_t> po_problem;
+        std::vector<uint32_t> pd_problem, host_problem;
+        std::vector<uint8_t> lin_rows, lin_waves, lin_swap;
+        uint64_t plane_cursor = 0, out_cursor = 0, dp_cells = 0, dp_bytes = 0, max_cells = 0, n_linear = 0;
+        int rc = CL_OK;
+        std::string err;
+        PackPart() { poff[0].push_back(0); poff[1].push_back(0); }
+        void fail(int code, const char* fmt, ...) {
+            if (rc) return;
+            rc = code;
+            char buf[512];
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, sizeof(buf), fmt, ap);
+            va_end(ap);
+            err = buf;
+        }
+    };
+    struct Scratch { std::vector<uint32_t> order, st, indeg, rank; };
+    auto pack_one = [&](uint64_t k, PackPart& P, Scratch& S) {
+        std::vector<uint32_t>& order = S.order; std::vector<uint32_t>& st = S.st; std::vector<uint32_t>& indeg = S.indeg; std::vector<uint32_t>& rank = S.rank;
         GraphView g[2] = {view(batch->side[0], k), view(batch->side[1], k)};
         int npw = force_num_pw ? force_num_pw[k] : choose_num_pw(g[0].n, g[1].n, ap);
-        if (npw < 1 || npw > 3) {
-            set_error(ctx, npw == CL_ERR_BAD_GAP_PARAMS ? "Affine gap parameters must be increasing in gap open penalty and decreasing in gap extend penalty"
-                                                        : "num_pw must be 1, 2 or 3 (problem %llu)", (unsigned long long)k);
-            plan_free(pl);
-            return npw < 0 ? npw : CL_ERR_INVALID_ARGUMENT;
-        }
+        if (npw < 1 || npw > 3) { P.fail(npw < 0 ? npw : CL_ERR_INVALID_ARGUMENT, npw == CL_ERR_BAD_GAP_PARAMS ? "Affine gap parameters must be increasing in gap open penalty and decreasing in gap extend penalty"
+                                                        : "num_pw must be 1, 2 or 3 (problem %llu)", (unsigned long long)k); return; }
         bool only_del = batch->only_deletion_alns && batch->only_deletion_alns[k];
         int route;
         if (force_num_pw) route = g[1].n == 0 ? CL_ROUTE_PURE_DELETION_1 : g[0].n == 0 ? CL_ROUTE_PURE_DELETION_2 : CL_ROUTE_PO_POA;
         else route = route_problem(g[0], g[1], only_del, *params);
-        if (route < 0) { set_error(ctx, "problem %llu: subgraph is not acyclic", (unsigned long long)k); plan_free(pl); return route; }
+        if (route < 0) { P.fail(route, "problem %llu: subgraph is not acyclic", (unsigned long long)k); return; }
         pl->route[k] = (uint8_t)route;
         pl->num_pw[k] = (uint8_t)npw;
         if (route == CL_ROUTE_PURE_DELETION_1 || route == CL_ROUTE_PURE_DELETION_2) {
-            rc = pure_deletion(route == CL_ROUTE_PURE_DELETION_1 ? g[0] : g[1], pl->pd_path[k]);
-            if (rc) { set_error(ctx, "problem %llu: pure deletion failed", (unsigned long long)k); plan_free(pl); return rc; }
-            pl->pd_problem.push_back((uint32_t)k);
-            continue;
+            const int rc = pure_deletion(route == CL_ROUTE_PURE_DELETION_1 ? g[0] : g[1], pl->pd_path[k]);
+            if (rc) { P.fail(rc, "problem %llu: pure deletion failed", (unsigned long long)k); return; }
+            P.pd_problem.push_back((uint32_t)k);
+            return;
         }
         if (route != CL_ROUTE_PO_POA) {   // greedy / deletion-WFA / pruned WFA: host algorithms (in the reference too)
-            rc = host_route_alignment(route, g[0], g[1], npw, *params, pl->host_aln[k]);
-            if (rc) {
-                set_error(ctx, rc == CL_ERR_INVALID_ARGUMENT ? "problem %llu: route %d needs the next lists of the subgraphs" : "problem %llu: host route %d failed",
-                          (unsigned long long)k, route);
-                plan_free(pl);
-                return rc;
-            }
-            pl->host_problem.push_back((uint32_t)k);
-            continue;
+            const int rc = host_route_alignment(route, g[0], g[1], npw, *params, pl->host_aln[k]);
+            if (rc) { P.fail(rc, rc == CL_ERR_INVALID_ARGUMENT ? "problem %llu: route %d needs the next lists of the subgraphs" : "problem %llu: host route %d failed",
+                          (unsigned long long)k, route); return; }
+            P.host_problem.push_back((uint32_t)k);
+            return;
         }
         uint64_t cells = (g[0].n + 1) * (g[1].n + 1);
-        if (cells >= (1ull << 31) || g[0].n_src == 0 || g[1].n_src == 0 || g[0].n_snk == 0 || g[1].n_snk == 0) {
-            set_error(ctx, "problem %llu: matrix too large for the device path or no sources/sinks", (unsigned long long)k);
-            plan_free(pl);
-            return cells >= (1ull << 31) ? CL_ERR_INVALID_ARGUMENT : CL_ERR_UNREACHABLE_SINK;
-        }
+        if (cells >= (1ull << 31) || g[0].n_src == 0 || g[1].n_src == 0 || g[0].n_snk == 0 || g[1].n_snk == 0) { P.fail(cells >= (1ull << 31) ? CL_ERR_INVALID_ARGUMENT : CL_ERR_UNREACHABLE_SINK, "problem %llu: matrix too large for the device path or no sources/sinks", (unsigned long long)k); return; }
         ClProbDesc d{};
         d.n1 = (uint32_t)g[0].n;
         d.n2 = (uint32_t)g[1].n;
@@ -742,45 +755,37 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         for (int s = 0; s < 2; ++s) {
             NextLists nx;
             nx.build(g[s]);
-            if (!topological_order(g[s], nx, order, st, indeg)) {
-                set_error(ctx, "problem %llu: graph %d is not acyclic", (unsigned long long)k, s + 1);
-                plan_free(pl);
-                return CL_ERR_CYCLIC_GRAPH;
-            }
+            if (!topological_order(g[s], nx, order, st, indeg)) { P.fail(CL_ERR_CYCLIC_GRAPH, "problem %llu: graph %d is not acyclic", (unsigned long long)k, s + 1); return; }
             rank.resize(g[s].n);
             for (uint32_t r = 0; r < g[s].n; ++r) rank[order[r]] = r;
-            if (lab[s].size() + g[s].n >= (1ull << 32) || pidx[s].size() + (g[s].prev_off[g[s].n] - g[s].prev_off[0]) >= (1ull << 32)) {
-                set_error(ctx, "batch too large for 32-bit device offsets");
-                plan_free(pl);
-                return CL_ERR_INVALID_ARGUMENT;
-            }
-            d.node_base[s] = (uint32_t)lab[s].size();
-            size_t lab0 = lab[s].size();
+            if (P.lab[s].size() + g[s].n >= (1ull << 32) || P.pidx[s].size() + (g[s].prev_off[g[s].n] - g[s].prev_off[0]) >= (1ull << 32)) { P.fail(CL_ERR_INVALID_ARGUMENT, "batch too large for 32-bit device offsets"); return; }
+            d.node_base[s] = (uint32_t)P.lab[s].size();
+            size_t lab0 = P.lab[s].size();
             for (uint32_t r = 0; r < g[s].n; ++r) {
                 uint32_t v = order[r];
-                lab[s].push_back(g[s].label[v] & 0x7f);
+                P.lab[s].push_back(g[s].label[v] & 0x7f);
                 uint64_t deg = g[s].prev_off[v + 1] - g[s].prev_off[v];
                 for (uint64_t e = g[s].prev_off[v]; e < g[s].prev_off[v + 1]; ++e) {
-                    pidx[s].push_back(rank[g[s].prev_idx[e]] + 1);
+                    P.pidx[s].push_back(rank[g[s].prev_idx[e]] + 1);
                     span[s] = std::max<uint64_t>(span[s], r - rank[g[s].prev_idx[e]]);
                 }
-                poff[s].push_back((uint32_t)pidx[s].size());
+                P.poff[s].push_back((uint32_t)P.pidx[s].size());
                 if (r == 0 ? deg != 0 : (deg != 1 || rank[g[s].prev_idx[g[s].prev_off[v]]] != r - 1)) linear = false;
-                if (g[s].label[v] & 0x80) { set_error(ctx, "labels must be < 128"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
+                if (g[s].label[v] & 0x80) { P.fail(CL_ERR_INVALID_ARGUMENT, "labels must be < 128"); return; }
             }
             for (uint64_t i = 0; i < g[s].n_src; ++i) {
-                lab[s][lab0 + rank[g[s].src[i]]] |= 0x80;
+                P.lab[s][lab0 + rank[g[s].src[i]]] |= 0x80;
                 span[s] = std::max<uint64_t>(span[s], (uint64_t)rank[g[s].src[i]] + 1);   // a source reads the boundary index 0
             }
             if (g[s].n_src != 1 || rank[g[s].src[0]] != 0) linear = false;
             if (g[s].n_snk != 1 || rank[g[s].snk[0]] != g[s].n - 1) linear = false;
-            d.snk_base[s] = (uint32_t)snk[s].size();
+            d.snk_base[s] = (uint32_t)P.snk[s].size();
             d.snk_cnt[s] = (uint32_t)g[s].n_snk;
-            for (uint64_t i = 0; i < g[s].n_snk; ++i) snk[s].push_back(rank[g[s].snk[i]] + 1);
-            pl->order[s].insert(pl->order[s].end(), order.begin(), order.end());
+            for (uint64_t i = 0; i < g[s].n_snk; ++i) P.snk[s].push_back(rank[g[s].snk[i]] + 1);
+            P.order[s].insert(P.order[s].end(), order.begin(), order.end());
         }
         d.kind = (linear && !g_force_general) ? CL_KIND_LINEAR : CL_KIND_GENERAL;
-        d.plane_base = plane_cursor;
+        d.plane_base = P.plane_cursor;
         uint8_t lr = 0, lw = 0, ls = 0;
         if (d.kind == CL_KIND_LINEAR) {
             // the shorter graph goes across the lanes; strips of 64 rows are pipelined over the waves
@@ -791,15 +796,15 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             else if (nshort <= 256) { lr = 1; lw = 4; }
             else { lr = 1; lw = 16; }
             d.pad = (uint16_t)(ls | (lr << 1));  // read by linear_dispatch
-            plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
-            ring_need.push_back(0);
+            P.plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
+            P.ring_need.push_back(0);
         } else {
-            plane_cursor += (cells * (uint64_t)(1 + 2 * npw) + 3) / 4 * 4;
+            P.plane_cursor += (cells * (uint64_t)(1 + 2 * npw) + 3) / 4 * 4;
             // LDS ring of the most recent anti-diagonals (popoa_kernels.hip): span1+span2+1 of them serve every read; when that
             // does not fit, as many as do (at least 8) — the rare reads that reach further back go to HBM
             const uint64_t width = std::min(d.n1, d.n2) + 1, per_diag = width * (uint64_t)(1 + 2 * npw) * 4;
             // the ring variant also stages the subproblem's topology in LDS: offsets, predecessor ranks, labels
-            const uint64_t n_pred = (poff[0].back() - poff[0][d.node_base[0]]) + (poff[1].back() - poff[1][d.node_base[1]]);
+            const uint64_t n_pred = (P.poff[0].back() - P.poff[0][d.node_base[0]]) + (P.poff[1].back() - P.poff[1][d.node_base[1]]);
             const uint64_t topo_bytes = ((uint64_t)d.n1 + d.n2) * 8 + n_pred * 4 + ((uint64_t)d.n1 + d.n2 + 2) * (1 + npw) * 4 + 16;   // node records, lists, boundaries
             // the systolic kernel (popoa_sys_kernel): the shorter graph's rows on the threads, a ring of H columns per row in LDS.  H must
             // exceed the row graph's predecessor span plus the column graph's NEAR predecessor distances; columns that are read from
@@ -812,8 +817,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             uint64_t near_limit = 8;
             std::vector<uint32_t> far_cols;
             if (take_sys) {
-                const uint32_t* cp = poff[sCol].data() + d.node_base[sCol];   // node j (1-based rank): predecessors pidx[cp[j - 1] .. cp[j])
-                const uint8_t* cl = lab[sCol].data() + d.node_base[sCol];
+                const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];   // node j (1-based rank): predecessors P.pidx[cp[j - 1] .. cp[j])
+                const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
                 uint64_t near_max = 0, max_deg = 0;
                 near_limit = 8;
                 while (true) {
@@ -822,8 +827,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     for (uint64_t j = 1; j <= n_cols; ++j) {
                         max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
                         for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
-                            const uint64_t dist = j - pidx[sCol][e];
-                            if (dist > near_limit) far_cols.push_back(pidx[sCol][e]); else near_max = std::max(near_max, dist);
+                            const uint64_t dist = j - P.pidx[sCol][e];
+                            if (dist > near_limit) far_cols.push_back(P.pidx[sCol][e]); else near_max = std::max(near_max, dist);
                         }
                         if (cl[j - 1] & 0x80) { if (j > near_limit) far_cols.push_back(0); else near_max = std::max(near_max, j); }
                     }
@@ -843,29 +848,90 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             if (take_sys) {
                 d.kind = CL_KIND_SYS;
                 d.pad = (uint16_t)(sys_log | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | rows = graph 2
-                d.aux_base = (uint32_t)sys_aux.size();   // {near limit, the saved columns ascending}
+                d.aux_base = (uint32_t)P.sys_aux.size();   // {near limit, the saved columns ascending}
                 d.aux_cnt = (uint32_t)far_cols.size();
-                sys_aux.push_back((uint32_t)near_limit);
-                sys_aux.insert(sys_aux.end(), far_cols.begin(), far_cols.end());
-                ring_need.push_back((uint32_t)sys_bytes);
+                P.sys_aux.push_back((uint32_t)near_limit);
+                P.sys_aux.insert(P.sys_aux.end(), far_cols.begin(), far_cols.end());
+                P.ring_need.push_back((uint32_t)sys_bytes);
             } else if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
                 d.pad = (uint16_t)(depth | (depth >= span[0] + span[1] + 1 ? 0x8000u : 0u));   // bit 15: the ring serves every read
-                ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
-            } else ring_need.push_back(0);
+                P.ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
+            } else P.ring_need.push_back(0);
         }
-        pl->lin_rows.push_back(lr);
-        pl->lin_waves.push_back(lw);
-        pl->lin_swap.push_back(ls);
-        if (out_cursor + d.n1 + d.n2 >= (1ull << 32)) { set_error(ctx, "batch too large for 32-bit output offsets"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
-        d.out_base = (uint32_t)out_cursor;
-        out_cursor += d.n1 + d.n2;
-        pl->po_index[k] = (int32_t)pl->desc.size();
-        pl->desc.push_back(d);
-        pl->po_problem.push_back(k);
-        pl->stats.dp_cells += cells;
-        pl->stats.dp_bytes += cells * 4ull * (1 + 2 * npw);
-        pl->stats.max_cells = std::max<uint64_t>(pl->stats.max_cells, cells);
-        if (d.kind == CL_KIND_LINEAR) pl->stats.n_linear++;
+        P.lin_rows.push_back(lr);
+        P.lin_waves.push_back(lw);
+        P.lin_swap.push_back(ls);
+        if (P.out_cursor + d.n1 + d.n2 >= (1ull << 32)) { P.fail(CL_ERR_INVALID_ARGUMENT, "batch too large for 32-bit output offsets"); return; }
+        d.out_base = (uint32_t)P.out_cursor;
+        P.out_cursor += d.n1 + d.n2;
+        P.desc.push_back(d);
+        P.po_problem.push_back(k);
+        P.dp_cells += cells;
+        P.dp_bytes += cells * 4ull * (1 + 2 * npw);
+        P.max_cells = std::max<uint64_t>(P.max_cells, cells);
+        if (d.kind == CL_KIND_LINEAR) P.n_linear++;
+    };
+    unsigned hw_threads = std::thread::hardware_concurrency();
+    const uint64_t n_parts = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw_threads ? hw_threads : 1, 16), n / 256));
+    std::vector<PackPart> parts(n_parts);
+    {
+        auto work = [&](uint64_t t) {
+            Scratch S;
+            for (uint64_t k = n * t / n_parts; k < n * (t + 1) / n_parts && !parts[t].rc; ++k) pack_one(k, parts[t], S);
+        };
+        std::vector<std::thread> th;
+        for (uint64_t t = 1; t < n_parts; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    std::vector<uint8_t> lab[2];
+    std::vector<uint32_t> poff[2], pidx[2], snk[2];
+    poff[0].push_back(0);
+    poff[1].push_back(0);
+    std::vector<uint32_t> ring_need, sys_aux;
+    uint64_t plane_cursor = 0, out_cursor = 0;
+    for (PackPart& P : parts) {   // in order: the first failure is the one a serial pass would have met
+        if (P.rc) { set_error(ctx, "%s", P.err.c_str()); plan_free(pl); return P.rc; }
+        for (int s = 0; s < 2; ++s)
+            if (lab[s].size() + P.lab[s].size() >= (1ull << 32) || pidx[s].size() + P.pidx[s].size() >= (1ull << 32)) {
+                set_error(ctx, "batch too large for 32-bit device offsets");
+                plan_free(pl);
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+        if (out_cursor + P.out_cursor >= (1ull << 32)) { set_error(ctx, "batch too large for 32-bit output offsets"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
+        const uint32_t lab_base[2] = {(uint32_t)lab[0].size(), (uint32_t)lab[1].size()}, pidx_base[2] = {(uint32_t)pidx[0].size(), (uint32_t)pidx[1].size()};
+        const uint32_t snk_base[2] = {(uint32_t)snk[0].size(), (uint32_t)snk[1].size()}, aux_base = (uint32_t)sys_aux.size();
+        for (size_t i = 0; i < P.desc.size(); ++i) {
+            ClProbDesc d = P.desc[i];
+            for (int s = 0; s < 2; ++s) { d.node_base[s] += lab_base[s]; d.snk_base[s] += snk_base[s]; }
+            d.plane_base += plane_cursor;
+            d.out_base += (uint32_t)out_cursor;
+            if (d.kind == CL_KIND_SYS) d.aux_base += aux_base;
+            pl->po_index[P.po_problem[i]] = (int32_t)pl->desc.size();
+            pl->desc.push_back(d);
+            pl->po_problem.push_back(P.po_problem[i]);
+        }
+        for (int s = 0; s < 2; ++s) {
+            lab[s].insert(lab[s].end(), P.lab[s].begin(), P.lab[s].end());
+            for (size_t i = 1; i < P.poff[s].size(); ++i) poff[s].push_back(P.poff[s][i] + pidx_base[s]);
+            pidx[s].insert(pidx[s].end(), P.pidx[s].begin(), P.pidx[s].end());
+            snk[s].insert(snk[s].end(), P.snk[s].begin(), P.snk[s].end());
+            pl->order[s].insert(pl->order[s].end(), P.order[s].begin(), P.order[s].end());
+        }
+        ring_need.insert(ring_need.end(), P.ring_need.begin(), P.ring_need.end());
+        sys_aux.insert(sys_aux.end(), P.sys_aux.begin(), P.sys_aux.end());
+        pl->pd_problem.insert(pl->pd_problem.end(), P.pd_problem.begin(), P.pd_problem.end());
+        pl->host_problem.insert(pl->host_problem.end(), P.host_problem.begin(), P.host_problem.end());
+        pl->lin_rows.insert(pl->lin_rows.end(), P.lin_rows.begin(), P.lin_rows.end());
+        pl->lin_waves.insert(pl->lin_waves.end(), P.lin_waves.begin(), P.lin_waves.end());
+        pl->lin_swap.insert(pl->lin_swap.end(), P.lin_swap.begin(), P.lin_swap.end());
+        plane_cursor += P.plane_cursor;
+        out_cursor += P.out_cursor;
+        pl->stats.dp_cells += P.dp_cells;
+        pl->stats.dp_bytes += P.dp_bytes;
+        pl->stats.max_cells = std::max<uint64_t>(pl->stats.max_cells, P.max_cells);
+        pl->stats.n_linear += P.n_linear;
+        P = PackPart();
     }
     pl->stats.n_problems = n;
     pl->stats.n_po_poa = pl->desc.size();
@@ -882,7 +948,6 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             grp.cells += cells_of(plist[i]);
             grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * grp.npw);
         }
-        if (hipEventCreate(&grp.ev0) != hipSuccess || hipEventCreate(&grp.ev1) != hipSuccess) grp.ev0 = grp.ev1 = nullptr;
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
         pl->groups.push_back(grp);
     };
@@ -902,13 +967,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
         auto sweep = [&](uint32_t x) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 + (pl->desc[x].npw == 3 ? 64 : 0); };
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return sweep(x) > sweep(y); });
-        if (hipEventCreate(&grp.ev0) != hipSuccess || hipEventCreate(&grp.ev1) != hipSuccess) grp.ev0 = grp.ev1 = nullptr;
         pl->groups.push_back(grp);
     }
+    lap("pack + route");
     const int blocks[3] = {64, 256, 1024};
     for (int bi = 2; bi >= 0; --bi)
         for (int npw = 3; npw >= 1; --npw)
-            for (int ring = 1; ring >= 0; --ring) {
+            for (int ring = 2; ring >= 0; --ring) {   // 2: ring above 64 KB of LDS (one workgroup per CU), 1: ring up to 64 KB, 0: planes in HBM
                 LaunchGroup grp;
                 grp.kind = CL_KIND_GENERAL; grp.npw = npw; grp.block = blocks[bi];
                 grp.first = (uint32_t)plist.size();
@@ -916,7 +981,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     const ClProbDesc& d = pl->desc[i];
                     uint32_t width = std::min(d.n1, d.n2) + 1;
                     int b = width <= 64 ? 0 : width <= 256 ? 1 : 2;
-                    if (d.kind == CL_KIND_GENERAL && d.npw == npw && b == bi && (d.pad != 0) == (ring != 0)) {
+                    const int cls = d.pad == 0 ? 0 : ring_need[i] > 64 * 1024 ? 2 : 1;
+                    if (d.kind == CL_KIND_GENERAL && d.npw == npw && b == bi && cls == ring) {
                         plist.push_back(i);
                         if (ring) grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
                     }
@@ -951,11 +1017,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             uint64_t c = 0;
             for (uint32_t i = g.first; i < g.first + g.count; ++i)
                 c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
-            return c * (g.kind == CL_KIND_GENERAL ? 8 : g.kind == CL_KIND_SYS ? 2 : 1);
+            // microseconds per anti-diagonal step, roughly: planes in HBM 4-8, LDS ring 1.6-2.5, systolic DAG 0.45, chain 0.2-0.6
+            return c * (g.kind == CL_KIND_GENERAL ? (g.ring_bytes ? 5 : 16) : 1);
         };
         std::stable_sort(pl->groups.begin(), pl->groups.end(), [&](const LaunchGroup& x, const LaunchGroup& y) { return crit(x) > crit(y); });
     }
     pl->stats.n_launches = pl->groups.size();
+    lap("launch groups");
 
     // HBM
     if ((rc = pl->d_desc.upload(ctx, pl->desc)) || (rc = pl->d_plist.upload(ctx, plist)) || (rc = pl->d_aux.upload(ctx, sys_aux))) { plan_free(pl); return rc; }
@@ -986,6 +1054,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         plan_free(pl);
         return CL_ERR_HIP;
     }
+    lap("allocate + upload");
     *plan_out = pl;
     return CL_OK;
 }
@@ -993,6 +1062,9 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
 static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
+    if (timed)   // the per-launch events exist only for plans that are profiled
+        for (LaunchGroup& g : pl->groups)
+            if (!g.ev0 && (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess)) g.ev0 = g.ev1 = nullptr;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     bool used[kNumAuxStreams] = {};
     for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
@@ -1194,12 +1266,24 @@ void cl_stitch_plan_destroy(cl_context* ctx, cl_stitch_plan* pl) {
 
 static int run_whole(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* sp, const uint8_t* force,
                      cl_stitch_result* out) {
+    // CL_STITCH_TIMING=1: host phase times on stderr
+    static const bool timing = getenv("CL_STITCH_TIMING") != nullptr;
+    auto t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[cl_stitch]   %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count());
+        t = std::chrono::steady_clock::now();
+    };
     cl_stitch_plan* pl = nullptr;
     int rc = cl_stitch_plan_create(ctx, batch, sp, force, &pl);
     if (rc) return rc;
+    pl->graph_tried = true;   // executed once: capturing and instantiating a hipGraph costs more than the launches it would save
+    lap("plan (host + upload)");
     rc = cl_stitch_plan_execute(ctx, pl);
+    if (!rc && timing) { (void)hipStreamSynchronize(ctx->stream); lap("execute (device)"); }
     if (!rc) rc = cl_stitch_plan_collect(ctx, pl, out);
+    lap("collect");
     cl_stitch_plan_destroy(ctx, pl);
+    lap("free");
     return rc;
 }
 
@@ -1260,7 +1344,7 @@ int cl_extract_stitch_batch(const cl_base_graph* g1, const cl_base_graph* g2, co
         if (g->n_nodes >= (1ull << 32) || g->src_id >= g->n_nodes || g->snk_id >= g->n_nodes) { set_error(nullptr, "bad graph"); return CL_ERR_INVALID_ARGUMENT; }
     cl_owned_batch* ob = new (std::nothrow) cl_owned_batch();
     if (!ob) return CL_ERR_OUT_OF_MEMORY;
-    int rc = clhost::extract_stitch_batch(*g1, *g2, *sg, ob->b);
+    int rc = clhost::extract_stitch_batch(*g1, *g2, *sg, ob->b, cl_shared_table(g1), cl_shared_table(g2));
     if (rc) { set_error(nullptr, rc == CL_ERR_CYCLIC_GRAPH ? "merge graph is not acyclic" : "empty anchor segment"); delete ob; return rc; }
     *out = ob;
     return CL_OK;
@@ -1281,11 +1365,19 @@ int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2,
     if (!ctx || !g1 || !g2 || !sg || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     out->n_pairs = 0;
     out->pairs = nullptr;
+    static const bool timing = getenv("CL_STITCH_TIMING") != nullptr;
+    auto t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[cl_stitch] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count());
+        t = std::chrono::steady_clock::now();
+    };
     cl_owned_batch* ob = nullptr;
     int rc = cl_extract_stitch_batch(g1, g2, sg, &ob);
     if (rc) { if (ctx) ctx->error = g_error; return rc; }
+    lap("extraction");
     cl_stitch_result res;
     rc = cl_stitch_batch_align(ctx, cl_owned_batch_view(ob), params, &res);
+    lap("batch align");
     cl_owned_batch_free(ob);
     if (rc) return rc;
     // stitcher.hpp:157-203: P0 A0 P1 A1 ... every subproblem but the first is preceded by one copied anchor
@@ -1312,6 +1404,7 @@ int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2,
         }
     out->n_pairs = cur;
     cl_stitch_result_free(&res);
+    lap("interleave anchors");
     return CL_OK;
 }
 

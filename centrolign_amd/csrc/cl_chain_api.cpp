@@ -1658,8 +1658,11 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     const cl_chain_params& cp = ap->chain;
-    clhost::PathMergeTable x1, x2;
-    if (!x1.build(*g1) || !x2.build(*g2)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    clhost::PathMergeTable own_x1, own_x2;
+    const clhost::PathMergeTable* const sx1 = cl_shared_table(g1), * const sx2 = cl_shared_table(g2);   // cl_core_align's, when it is the caller
+    if ((!sx1 && !own_x1.build(*g1)) || (!sx2 && !own_x2.build(*g2))) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    const clhost::PathMergeTable& x1 = sx1 ? *sx1 : own_x1;
+    const clhost::PathMergeTable& x2 = sx2 ? *sx2 : own_x2;
     // anchorer.hpp:1175: the DP runs with the graphs swapped when that makes its tables smaller
     const bool swap = g1->n_nodes * x1.chain_size() > g2->n_nodes * x2.chain_size();
     PostSwitchTable sw1, sw2;

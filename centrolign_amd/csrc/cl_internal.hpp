@@ -104,6 +104,17 @@ struct cl_owned_base_graph {
 // defined in cl_anchor_api.cpp
 bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp);
 
+// The PathMerge tables of the two graphs of a merge are needed by the chaining, the partitioner's gap measurement and the stitcher's
+// extraction (the reference builds them once in Core::align, core.hpp:186-193, and hands them down).  cl_core_align builds them once and
+// registers them for the duration of the call, per thread; the stages look them up by graph pointer and build their own when called alone.
+namespace clhost { class PathMergeTable; }
+struct ClSharedTables { const cl_base_graph* g[2] = {nullptr, nullptr}; const clhost::PathMergeTable* x[2] = {nullptr, nullptr}; };
+extern thread_local ClSharedTables cl_tls_tables;   // cl_align_api.cpp
+inline const clhost::PathMergeTable* cl_shared_table(const cl_base_graph* g) {
+    for (int i = 0; i < 2; ++i) if (g && cl_tls_tables.g[i] == g) return cl_tls_tables.x[i];
+    return nullptr;
+}
+
 // host-side parallel loop over [0, n): f(begin, end) on up to 16 threads (the reference is single-threaded; the host glue
 // around the device passes is not part of the compared arithmetic, every iteration writes its own outputs)
 #include <thread>

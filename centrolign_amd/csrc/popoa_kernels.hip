@@ -10,6 +10,7 @@
 //
 // popoa_ring_kernel: the same sweep for subproblems whose topology and a ring of recent anti-diagonals fit LDS (below).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include "popoa_device.h"
@@ -964,9 +965,8 @@ void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const
 hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                                const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    static bool attr_set = false;   // more than 64 KB of dynamic LDS needs the opt-in once per function
-    if (!attr_set) {
-        attr_set = true;
+    static std::once_flag attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function (worker threads launch concurrently)
+    std::call_once(attr_once, [] {
         const int cap = 128 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -977,7 +977,7 @@ hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    }
+    });
     switch (npw) {
     case 1: launch_sys_npw<1>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
     case 2: launch_sys_npw<2>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
@@ -990,6 +990,19 @@ hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t l
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
+    static std::once_flag attr_once;
+    if (ring_bytes > 64 * 1024) std::call_once(attr_once, [] {
+        const int cap = 160 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<2, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<3, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    });
     switch (npw) {
     case 1: launch_general_npw<1>(block, n_blocks, ring_bytes, B, plist, P, stream); break;
     case 2: launch_general_npw<2>(block, n_blocks, ring_bytes, B, plist, P, stream); break;
