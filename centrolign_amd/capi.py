@@ -639,6 +639,25 @@ class MatchSets:
     def from_dump(d, prefix):
         return MatchSets(**{k: d[prefix + "ms." + k] for k in MatchSets._DT})
 
+    def reordered(self, set_order):
+        """the sets in the order anchor_chain left the caller's vector in (set_order of its result): position k holds original set
+        set_order[k].  The reference reorders in place (anchorer.hpp:1108-1173); here the caller does it when it needs the next call to
+        start from that order (the tandem-duplication rounds of cyclisation)."""
+        order = np.asarray(set_order, np.int64)
+        out = {}
+        for side in ("1", "2"):
+            so, wo, nd = getattr(self, "set_off" + side).astype(np.int64), getattr(self, "walk_off" + side).astype(np.int64), getattr(self, "nodes" + side)
+            n_walks = so[order + 1] - so[order]
+            new_so = np.concatenate([[0], np.cumsum(n_walks)])
+            walk_ids = np.concatenate([np.arange(so[s], so[s + 1]) for s in order]) if len(order) else np.zeros(0, np.int64)
+            lens = wo[walk_ids + 1] - wo[walk_ids]
+            new_wo = np.concatenate([[0], np.cumsum(lens)])
+            node_ids = np.concatenate([np.arange(wo[w], wo[w + 1]) for w in walk_ids]) if len(walk_ids) else np.zeros(0, np.int64)
+            out["set_off" + side], out["walk_off" + side], out["nodes" + side] = new_so, new_wo, nd[node_ids]
+        for k in ("count1", "count2", "full_length"):
+            out[k] = getattr(self, k)[order]
+        return MatchSets(**out)
+
 
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
@@ -987,6 +1006,17 @@ def load_library(path=None):
                                     C.POINTER(AnchorParams), C.POINTER(AnchorChainResultC)]
     lib.cl_anchor_chain_result_free.restype = None
     lib.cl_anchor_chain_result_free.argtypes = [C.POINTER(AnchorChainResultC)]
+    lib.cl_anchor_chain_masked.restype = C.c_int
+    lib.cl_anchor_chain_masked.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(MatchSetsC), C.POINTER(AnchorParams),
+                                           C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(AnchorChainResultC)]
+    lib.cl_generate_diagonal_mask.restype = C.c_int
+    lib.cl_generate_diagonal_mask.argtypes = [C.POINTER(MatchSetsC), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cl_update_mask.restype = C.c_int
+    lib.cl_update_mask.argtypes = [C.POINTER(MatchSetsC), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.cl_internal_stitch.restype = C.c_int
+    lib.cl_internal_stitch.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StitchParams),
+                                       C.POINTER(AlignmentC)]
     if path is None:
         _lib = lib
     return lib
@@ -1001,7 +1031,7 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_exhaustive", "cl_chain_result_free",
     "cl_parse_fasta", "cl_fasta_free", "cl_msa_plan_create", "cl_msa_plan_free", "cl_msa_params_default", "cl_msa",
-    "cl_anchor_chain", "cl_anchor_chain_result_free",
+    "cl_anchor_chain", "cl_anchor_chain_result_free", "cl_anchor_chain_masked", "cl_generate_diagonal_mask", "cl_update_mask", "cl_internal_stitch",
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
@@ -1009,6 +1039,35 @@ EXPORTED_SYMBOLS = [
     "cl_fuse", "cl_owned_base_graph_view", "cl_owned_base_graph_free", "cl_merge_params_default", "cl_merge", "cl_merge_result_free",
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
 ]
+
+
+def _take_mask(lib, ptr, n):
+    k = int(n.value)
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 3,))[:3 * k].copy().reshape(k, 3)
+    _libc_free(ptr)
+    return a
+
+
+def generate_diagonal_mask(matches):
+    """Core::generate_diagonal_mask (src/core.cpp:301-321): (n, 3) [set, idx1, idx2], sorted"""
+    lib = load_library()
+    mc, ptr, n = matches.as_c(), C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_generate_diagonal_mask(C.byref(mc), C.byref(ptr), C.byref(n))
+    if rc:
+        raise ClError(rc, "cl_generate_diagonal_mask")
+    return _take_mask(lib, ptr, n)
+
+
+def update_mask(matches, chain_walk1, chain_walk2, mask, mask_reciprocal=False):
+    """Core::update_mask (src/core.cpp:323-372): the mask grown by every pair that shares an aligned node pair with the chain"""
+    lib = load_library()
+    w1, w2 = np.ascontiguousarray(chain_walk1, np.uint32), np.ascontiguousarray(chain_walk2, np.uint32)
+    m = np.ascontiguousarray(mask, np.uint64).reshape(-1, 3)
+    mc, ptr, n = matches.as_c(), C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_update_mask(C.byref(mc), len(w1), w1.ctypes.data, w2.ctypes.data, int(mask_reciprocal), m.ctypes.data, len(m), C.byref(ptr), C.byref(n))
+    if rc:
+        raise ClError(rc, "cl_update_mask")
+    return _take_mask(lib, ptr, n)
 
 
 class Plan:
@@ -1167,6 +1226,9 @@ class Context:
         ap.do_fill_in_anchoring = int(fill_in)
         g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), AnchorChainResultC()
         self._check(self.lib.cl_anchor_chain(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), C.byref(out)))
+        return self._anchor_chain_dict(out)
+
+    def _anchor_chain_dict(self, out):
         try:
             na, ns = int(out.n_anchors), int(out.n_sets)
 
@@ -1183,6 +1245,36 @@ class Context:
                         fill_in_pairs=int(out.fill_in_pairs), fill_in_device_ms=float(out.fill_in_device_ms))
         finally:
             self.lib.cl_anchor_chain_result_free(C.byref(out))
+
+    def anchor_chain_masked(self, graph1, graph2, matches, mask, override_scale=None, max_num_match_pairs=1250000, score_scale=1.0,
+                            autocalibrate=True, params=None, fill_in=True):
+        """Anchorer::anchor_chain with masked matches and an overriding scale (include/centrolign/anchorer.hpp:135-145; the cyclisation
+        rounds, src/core.cpp:221-227).  mask: (n, 3) [set, idx1, idx2] in the indexing of `matches`.  Same dict as anchor_chain."""
+        ap = AnchorParams()
+        ap.chain = params or default_chain_params()
+        ap.max_num_match_pairs = int(max_num_match_pairs)
+        ap.score_scale = float(score_scale)
+        ap.autocalibrate_gap_penalties = int(autocalibrate)
+        ap.do_fill_in_anchoring = int(fill_in)
+        m = np.ascontiguousarray(mask, np.uint64).reshape(-1, 3)
+        sc = C.c_double(float(override_scale)) if override_scale is not None else None
+        g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), AnchorChainResultC()
+        self._check(self.lib.cl_anchor_chain_masked(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), m.ctypes.data, len(m),
+                                                    C.byref(sc) if sc is not None else None, C.byref(out)))
+        return self._anchor_chain_dict(out)
+
+    def internal_stitch(self, graph, walk_off, walk1, walk2, params=None):
+        """Stitcher::internal_stitch (include/centrolign/stitcher.hpp:209-234): a chain of anchors inside ONE graph -> (n, 2) uint64"""
+        params = params or default_stitch_params()
+        wo, w1, w2 = np.ascontiguousarray(walk_off, np.uint64), np.ascontiguousarray(walk1, np.uint32), np.ascontiguousarray(walk2, np.uint32)
+        g, out = graph.as_c(), AlignmentC()
+        self._check(self.lib.cl_internal_stitch(self.handle, C.byref(g), len(wo) - 1 if len(wo) else 0, wo.ctypes.data, w1.ctypes.data, w2.ctypes.data,
+                                                C.byref(params), C.byref(out)))
+        try:
+            n = int(out.n_pairs)
+            return np.ctypeslib.as_array(out.pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2)
+        finally:
+            self.lib.cl_alignment_free(C.byref(out))
 
     def core_align(self, graph1, graph2, matches, score_scale=1.0, max_num_match_pairs=1250000, score_boundaries=False, tweak=None):
         """Core::align (include/centrolign/core.hpp:181-252) with the CLI's default configuration: anchor chain (branch

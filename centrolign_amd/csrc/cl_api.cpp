@@ -1408,4 +1408,46 @@ int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2,
     return CL_OK;
 }
 
+// Stitcher::internal_stitch (stitcher.hpp:209-234): a chain of anchors between two places of ONE graph (a tandem duplication found by the
+// cyclisation rounds, src/core.cpp:268-269).  The gaps between consecutive anchors are extracted from the graph against itself and aligned
+// like any other gap (subalign with only_deletion_alns = false); the output order is the reference's: anchor 0, then for every later anchor
+// its own pairs FOLLOWED by the alignment of the gap in front of it (:216-231).
+int cl_internal_stitch(cl_context* ctx, const cl_base_graph* g, uint64_t n_anchors, const uint64_t* walk_off, const uint32_t* walk1,
+                       const uint32_t* walk2, const cl_stitch_params* params, cl_alignment* out) {
+    if (!ctx || !g || !params || !out || (n_anchors && (!walk_off || !walk1 || !walk2))) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    out->n_pairs = 0;
+    out->pairs = nullptr;
+    if (g->n_nodes >= (1ull << 32) || g->src_id >= g->n_nodes || g->snk_id >= g->n_nodes) { set_error(ctx, "bad graph"); return CL_ERR_INVALID_ARGUMENT; }
+    cl_stitch_result res;
+    memset(&res, 0, sizeof(res));
+    if (n_anchors > 1) {
+        clhost::PathMergeTable own;
+        const clhost::PathMergeTable* pm = cl_shared_table(g);
+        if (!pm) { if (!own.build(*g)) { set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; } pm = &own; }
+        const uint64_t seg_off[2] = {0, n_anchors};
+        const cl_anchor_segments sg{1, seg_off, walk_off, walk1, walk2};
+        for (uint64_t a = 0; a < n_anchors; ++a) if (walk_off[a + 1] <= walk_off[a]) { set_error(ctx, "empty anchor"); return CL_ERR_INVALID_ARGUMENT; }
+        cl_owned_batch ob;
+        int rc = clhost::extract_stitch_batch(*g, *g, sg, ob.b, pm, pm, false);
+        if (rc) { set_error(ctx, "extraction failed"); return rc; }
+        if ((rc = cl_stitch_batch_align(ctx, ob.b.view(), params, &res))) return rc;
+        if (res.n_problems != n_anchors - 1) { cl_stitch_result_free(&res); set_error(ctx, "internal_stitch: gap count"); return CL_ERR_INVALID_ARGUMENT; }
+    }
+    const uint64_t total = (n_anchors ? walk_off[n_anchors] - walk_off[0] : 0) + (res.aln_off ? res.aln_off[res.n_problems] : 0);
+    out->pairs = (uint64_t*)malloc((total ? total : 1) * 2 * sizeof(uint64_t));
+    if (!out->pairs) { cl_stitch_result_free(&res); return CL_ERR_OUT_OF_MEMORY; }
+    uint64_t cur = 0;
+    for (uint64_t a = 0; a < n_anchors; ++a) {
+        for (uint64_t w = walk_off[a]; w < walk_off[a + 1]; ++w) { out->pairs[2 * cur] = walk1[w]; out->pairs[2 * cur + 1] = walk2[w]; ++cur; }
+        if (a) {
+            const uint64_t n = res.aln_off[a] - res.aln_off[a - 1];
+            memcpy(out->pairs + 2 * cur, res.pairs + 2 * res.aln_off[a - 1], n * 2 * sizeof(uint64_t));
+            cur += n;
+        }
+    }
+    out->n_pairs = cur;
+    cl_stitch_result_free(&res);
+    return CL_OK;
+}
+
 }  // extern "C"

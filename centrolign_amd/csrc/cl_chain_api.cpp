@@ -18,7 +18,9 @@
 //     earliest inserted (strict '>' in MaxSearchTree::update, max_search_tree.hpp:318-358).  replay_units evaluates that
 //     rule directly on the sorted keys; it only runs when a maximum is attained more than once.
 #include <algorithm>
+#include <array>
 #include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -251,6 +253,9 @@ struct ChainSub {
     bool anchored = false;                             // sources / sinks given (global anchoring, fill-in)
     std::vector<uint32_t> src[2], snk[2];
     std::vector<uint32_t> tag[2];                      // local chain id -> batch-wide chain tag; empty = identity
+    // masked matches (anchorer.hpp:144; MatchBank skips them, match_bank.hpp:187-215,252-268): (set of `ms`, idx1, idx2) in the sets' own
+    // sides -> true if the pair does not take part in the DP.  Empty = no mask
+    std::function<bool(uint64_t, uint32_t, uint32_t)> masked;
 };
 
 struct ChainSubResult {
@@ -269,6 +274,7 @@ struct SubCtx {
     const PostSwitchTable* sw[2] = {nullptr, nullptr};
     std::vector<uint32_t> pos1, depth1;
     std::vector<char> has_start, after_end;
+    std::vector<std::pair<uint32_t, uint32_t>> walk_marks;   // (first, last node) of every graph-1 walk when some pairs are masked
     uint32_t pair_lo = 0, pair_hi = 0;
     uint32_t off_a = 0, off_b = 0;
     float min_score = 0.0f;
@@ -328,10 +334,13 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             const uint64_t n1 = ms.n_walks(0, s), n2 = ms.n_walks(1, s);
             if (n1 >= 65535 || n2 >= 65535) { cl_set_error(ctx, "match set %llu has too many walks", (unsigned long long)s); return CL_ERR_INVALID_ARGUMENT; }
             if (n1 && n2) min_len = std::min<uint64_t>(min_len, ms.length(s));
+            const uint64_t ms_set = sb.order ? sb.order[s] : s;
             for (uint64_t j = 0; j < n1; ++j) {
                 const uint64_t w1 = ms.walk(0, s, j);
                 const uint32_t b1 = ms.front(0, w1), e1 = ms.back(0, w1);
+                if (sb.masked) sc[k].walk_marks.emplace_back(b1, e1);   // the forward-edge masks see every walk, masked or not
                 for (uint64_t q = 0; q < n2; ++q) {
+                    if (sb.masked && (sb.swap_sides ? sb.masked(ms_set, (uint32_t)q, (uint32_t)j) : sb.masked(ms_set, (uint32_t)j, (uint32_t)q))) continue;
                     const uint64_t w2 = ms.walk(1, s, q);
                     pairs.push_back(Pair{(uint32_t)k, (uint32_t)s, (uint32_t)j, (uint32_t)q, b1, e1, ms.front(1, w2), ms.back(1, w2)});
                 }
@@ -386,6 +395,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
             c.has_start.assign(g1.n_nodes, 0);
             c.after_end.assign(g1.n_nodes, 0);
             for (uint32_t s = c.pair_lo; s < c.pair_hi; ++s) { c.has_start[pairs[s].b1] = 1; c.after_end[pairs[s].e1] = 1; }
+            for (const auto& m : c.walk_marks) { c.has_start[m.first] = 1; c.after_end[m.second] = 1; }
             // nodes that follow the end of some match (anchorer.hpp:1776-1797)
             std::vector<uint32_t> st;
             for (uint64_t v = 0; v < g1.n_nodes; ++v)
@@ -1653,8 +1663,15 @@ void cl_anchor_chain_result_free(cl_anchor_chain_result* r) {
 }  // extern "C"
 
 // scale_only: stop after estimate_score_scale (out->scale is the only field set)
+// masked matches: sorted (set, idx1, idx2) triples in the indexing of the caller's sets (anchorer.hpp:144)
+struct MaskSet {
+    std::vector<std::array<uint64_t, 3>> v;
+    bool has(uint64_t s, uint64_t a, uint64_t b) const { return std::binary_search(v.begin(), v.end(), std::array<uint64_t, 3>{s, a, b}); }
+};
+
 static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
-                             const cl_anchor_params* ap, cl_anchor_chain_result* out, bool scale_only) {
+                             const cl_anchor_params* ap, cl_anchor_chain_result* out, bool scale_only, const MaskSet* mask = nullptr,
+                             const double* override_scale = nullptr) {
     if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     const cl_chain_params& cp = ap->chain;
@@ -1799,6 +1816,13 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
             sb.swap_sides = in.swap;
             sb.num_match_sets = n_use;
             sb.anchored = true;
+            if (mask) {   // a divvied pair is masked if the pair it came from is (anchorer.hpp:662-680)
+                const Divvied* dk = &dv[k];
+                const std::vector<uint64_t>* order_now = &cur;
+                sb.masked = [mask, dk, order_now](uint64_t set, uint32_t i1, uint32_t i2) {
+                    return mask->has((*order_now)[dk->origin_set[set]], dk->origin_idx1[set][i1], dk->origin_idx2[set][i2]);
+                };
+            }
             for (int d = 0; d < 2; ++d) {
                 const int from = in.swap ? 1 - d : d;
                 const auto& sd = ob.side[from];
@@ -1884,6 +1908,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         std::vector<ChainSub> subs(1, whole_graph_instance(swap ? g2 : g1, swap ? g1 : g2, ms, n_use, cp.global_anchoring != 0));
         subs[0].order = cur.data();
         subs[0].swap_sides = swap;
+        if (mask) subs[0].masked = [mask](uint64_t set, uint32_t i1, uint32_t i2) { return mask->has(set, i1, i2); };
         subs[0].x[0] = swap ? &x2 : &x1; subs[0].x[1] = swap ? &x1 : &x2;
         subs[0].sw[0] = swap ? &sw2 : &sw1; subs[0].sw[1] = swap ? &sw1 : &sw2;
         std::vector<ChainSubResult> res;
@@ -1928,7 +1953,8 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     // ---- estimate_score_scale (anchorer.hpp:998-1047)
     double scale = 1.0;
     int rc;
-    if (ap->autocalibrate_gap_penalties) {
+    if (override_scale && !scale_only) scale = *override_scale;   // anchorer.hpp:975-978
+    else if (ap->autocalibrate_gap_penalties) {
         std::vector<HAnchor> sc;
         if ((rc = run(true, 1.0, sc))) return rc;
         auto t = now();
@@ -2011,6 +2037,77 @@ extern "C" {
 int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
                     const cl_anchor_params* ap, cl_anchor_chain_result* out) {
     return anchor_chain_impl(ctx, g1, g2, ms, ap, out, false);
+}
+
+int cl_anchor_chain_masked(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_anchor_params* ap,
+                           const uint64_t* masked, uint64_t n_masked, const double* override_scale, cl_anchor_chain_result* out) {
+    if (n_masked && !masked) { cl_set_error(ctx, "null mask"); return CL_ERR_INVALID_ARGUMENT; }
+    MaskSet mask;
+    mask.v.resize(n_masked);
+    for (uint64_t i = 0; i < n_masked; ++i) mask.v[i] = {masked[3 * i], masked[3 * i + 1], masked[3 * i + 2]};
+    std::sort(mask.v.begin(), mask.v.end());
+    mask.v.erase(std::unique(mask.v.begin(), mask.v.end()), mask.v.end());
+    return anchor_chain_impl(ctx, g1, g2, ms, ap, out, false, n_masked ? &mask : nullptr, override_scale);
+}
+
+// Core::generate_diagonal_mask (src/core.cpp:301-321): in a self-comparison, the pairs of a set whose two walks start at the same node
+int cl_generate_diagonal_mask(const cl_match_sets* ms, uint64_t** masked_out, uint64_t* n_masked_out) {
+    if (!ms || !masked_out || !n_masked_out) return CL_ERR_INVALID_ARGUMENT;
+    std::vector<uint64_t> m;
+    std::unordered_map<uint32_t, uint64_t> start_to_idx;
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        start_to_idx.clear();
+        for (uint64_t j = ms->set_off1[s]; j < ms->set_off1[s + 1]; ++j) start_to_idx[ms->nodes1[ms->walk_off1[j]]] = j - ms->set_off1[s];   // the last walk wins (:309-311)
+        for (uint64_t k = ms->set_off2[s]; k < ms->set_off2[s + 1]; ++k) {
+            auto it = start_to_idx.find(ms->nodes2[ms->walk_off2[k]]);
+            if (it != start_to_idx.end()) { m.push_back(s); m.push_back(it->second); m.push_back(k - ms->set_off2[s]); }
+        }
+    }
+    *n_masked_out = m.size() / 3;
+    *masked_out = (uint64_t*)malloc((m.size() ? m.size() : 1) * sizeof(uint64_t));
+    if (!*masked_out) return CL_ERR_OUT_OF_MEMORY;
+    if (!m.empty()) memcpy(*masked_out, m.data(), m.size() * sizeof(uint64_t));
+    return CL_OK;
+}
+
+// Core::update_mask (src/core.cpp:323-372): every pair (set, j, k) in which some position of walk1 j and the same position of walk2 k are a
+// node pair of the chain (or its mirror image) is added to the mask.  The result is the union, sorted, without duplicates.
+int cl_update_mask(const cl_match_sets* ms, uint64_t n_chain_pairs, const uint32_t* chain_walk1, const uint32_t* chain_walk2, int mask_reciprocal,
+                   const uint64_t* masked, uint64_t n_masked, uint64_t** masked_out, uint64_t* n_masked_out) {
+    if (!ms || !masked_out || !n_masked_out || (n_chain_pairs && (!chain_walk1 || !chain_walk2)) || (n_masked && !masked)) return CL_ERR_INVALID_ARGUMENT;
+    std::unordered_map<uint32_t, uint32_t> paired;   // later pairs overwrite earlier ones (:330-337)
+    for (uint64_t i = 0; i < n_chain_pairs; ++i) {
+        paired[chain_walk1[i]] = chain_walk2[i];
+        if (mask_reciprocal) paired[chain_walk2[i]] = chain_walk1[i];
+    }
+    std::vector<std::array<uint64_t, 3>> m(n_masked);
+    for (uint64_t i = 0; i < n_masked; ++i) m[i] = {masked[3 * i], masked[3 * i + 1], masked[3 * i + 2]};
+    std::unordered_map<uint64_t, std::vector<uint32_t>> walk2_node;   // (position << 32 | node) -> walk2 indexes
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        walk2_node.clear();
+        const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
+        for (uint64_t k = 0; k < n2; ++k) {
+            const uint64_t w = ms->set_off2[s] + k;
+            for (uint64_t l = ms->walk_off2[w]; l < ms->walk_off2[w + 1]; ++l) walk2_node[((l - ms->walk_off2[w]) << 32) | ms->nodes2[l]].push_back((uint32_t)k);
+        }
+        for (uint64_t j = 0; j < n1; ++j) {
+            const uint64_t w = ms->set_off1[s] + j;
+            for (uint64_t l = ms->walk_off1[w]; l < ms->walk_off1[w + 1]; ++l) {
+                auto it = paired.find(ms->nodes1[l]);
+                if (it == paired.end()) continue;
+                auto it2 = walk2_node.find(((l - ms->walk_off1[w]) << 32) | it->second);
+                if (it2 == walk2_node.end()) continue;
+                for (uint32_t k : it2->second) m.push_back({s, j, (uint64_t)k});
+            }
+        }
+    }
+    std::sort(m.begin(), m.end());
+    m.erase(std::unique(m.begin(), m.end()), m.end());
+    *n_masked_out = m.size();
+    *masked_out = (uint64_t*)malloc((m.size() ? m.size() : 1) * 3 * sizeof(uint64_t));
+    if (!*masked_out) return CL_ERR_OUT_OF_MEMORY;
+    for (size_t i = 0; i < m.size(); ++i) { (*masked_out)[3 * i] = m[i][0]; (*masked_out)[3 * i + 1] = m[i][1]; (*masked_out)[3 * i + 2] = m[i][2]; }
+    return CL_OK;
 }
 
 int cl_estimate_score_scale(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,

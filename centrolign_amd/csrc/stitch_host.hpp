@@ -199,8 +199,10 @@ private:
 
 // Extractor::extract_graphs_between(segments, ...) (anchorer.hpp:494-585) in Stitcher::stitch's consumption order:
 // before-first, then per segment its within-segment gaps followed by the gap to the next segment / the sink.
+// with_ends = false: only the gaps between consecutive anchors, the overload without tableaus that Stitcher::internal_stitch uses
+// (anchorer.hpp:423-431; no gap in front of the first anchor or behind the last one)
 inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2, const cl_anchor_segments& sg, OwnedBatch& out,
-                                const PathMergeTable* have1 = nullptr, const PathMergeTable* have2 = nullptr) {
+                                const PathMergeTable* have1 = nullptr, const PathMergeTable* have2 = nullptr, bool with_ends = true) {
     PathMergeTable own1, own2;
     if ((!have1 && !own1.build(g1)) || (!have2 && !own2.build(g2))) return CL_ERR_CYCLIC_GRAPH;
     const PathMergeTable& pm1 = have1 ? *have1 : own1;
@@ -259,18 +261,18 @@ inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2
     auto first2 = [&](uint64_t a) { return (uint64_t)sg.walk2[sg.walk_off[a]]; };
     auto last2 = [&](uint64_t a) { return (uint64_t)sg.walk2[sg.walk_off[a + 1] - 1]; };
     if (sg.n_segments == 0) {
-        add(g1.src_id, g1.snk_id, g2.src_id, g2.snk_id, true);
+        if (with_ends) add(g1.src_id, g1.snk_id, g2.src_id, g2.snk_id, true);
         return CL_OK;
     }
     for (uint64_t s = 0; s < sg.n_segments; ++s)
         if (sg.seg_off[s + 1] <= sg.seg_off[s]) return CL_ERR_INVALID_ARGUMENT;  // the reference assumes non-empty segments
     const uint64_t a0 = sg.seg_off[0];
-    add(g1.src_id, first1(a0), g2.src_id, first2(a0), true);
+    if (with_ends) add(g1.src_id, first1(a0), g2.src_id, first2(a0), true);
     for (uint64_t s = 0; s < sg.n_segments; ++s) {
         for (uint64_t a = sg.seg_off[s] + 1; a < sg.seg_off[s + 1]; ++a) add(last1(a - 1), first1(a), last2(a - 1), first2(a), false);
         const uint64_t al = sg.seg_off[s + 1] - 1;
         if (s + 1 < sg.n_segments) add(last1(al), first1(sg.seg_off[s + 1]), last2(al), first2(sg.seg_off[s + 1]), true);
-        else add(last1(al), g1.snk_id, last2(al), g2.snk_id, true);
+        else if (with_ends) add(last1(al), g1.snk_id, last2(al), g2.snk_id, true);
     }
     return CL_OK;
 }

@@ -241,6 +241,12 @@ typedef struct cl_alignment {
 /* Stitcher::stitch: extraction + every subalign on the device + anchors copied in between. */
 int  cl_stitch(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_anchor_segments* segments,
                const cl_stitch_params* params, cl_alignment* out);
+/* Stitcher::internal_stitch (include/centrolign/stitcher.hpp:41-43,209-234), the second entry of seam S2: the alignment of a graph with
+ * ITSELF along a chain of anchors (anchor a = walk1/walk2[walk_off[a] .. walk_off[a + 1]), node ids of `graph`), the gaps between consecutive
+ * anchors aligned as in cl_stitch; nothing in front of the first anchor or behind the last.  Output order as in the reference: anchor 0,
+ * then every later anchor's pairs followed by the gap in front of it. */
+int cl_internal_stitch(cl_context* ctx, const cl_base_graph* graph, uint64_t n_anchors, const uint64_t* walk_off, const uint32_t* walk1,
+                       const uint32_t* walk2, const cl_stitch_params* params, cl_alignment* out);
 void cl_alignment_free(cl_alignment* a);
 
 /* --- Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) -------------------------------------------------
@@ -449,6 +455,23 @@ typedef struct cl_anchor_chain_result {
 int  cl_anchor_chain(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
                      const cl_anchor_params* params, cl_anchor_chain_result* out);
 void cl_anchor_chain_result_free(cl_anchor_chain_result* r);
+
+/* --- anchor_chain with masked matches and a given scale: the last two arguments of Anchorer::anchor_chain
+ * (include/centrolign/anchorer.hpp:143-145), as the tandem-duplication rounds of cyclisation call it (src/core.cpp:221-227).
+ * masked: [3 * n_masked] (set, idx1, idx2) in the indexing of `matches`; a masked pair takes no part in any DP (MatchBank skips it,
+ * match_bank.hpp:187-215,252-268; fill-in translates the mask to the divvied sets, anchorer.hpp:662-680) while the forward-edge masks
+ * still see every walk (:1753-1774).  override_scale != NULL: the affine DP's scale, no estimate (:975-978).
+ * The sets are not moved here (set_order in the result): the mask stays in the caller's indexing, where the reference re-indexes it
+ * in place (:1159-1166).  Branch splitting with a mask (:816-820,911-918) is not part of this entry: the leaf graphs it is called on
+ * in the reference have no branches. */
+int  cl_anchor_chain_masked(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
+                            const cl_anchor_params* params, const uint64_t* masked, uint64_t n_masked, const double* override_scale,
+                            cl_anchor_chain_result* out);
+/* Core::generate_diagonal_mask (src/core.cpp:301-321) and Core::update_mask (:323-372) on flat sets; *masked_out is malloc'ed
+ * [3 * *n_masked_out] (release with free()), sorted, without duplicates.  chain_walk1/2: the node pairs of the chain's anchors, concatenated. */
+int  cl_generate_diagonal_mask(const cl_match_sets* matches, uint64_t** masked_out, uint64_t* n_masked_out);
+int  cl_update_mask(const cl_match_sets* matches, uint64_t n_chain_pairs, const uint32_t* chain_walk1, const uint32_t* chain_walk2,
+                    int mask_reciprocal, const uint64_t* masked, uint64_t n_masked, uint64_t** masked_out, uint64_t* n_masked_out);
 
 /* --- Core::align (include/centrolign/core.hpp:181-252): matches of one merge -> the merge's base-level alignment ------
  * anchor_chain (split + chaining + fill-in, device), partition_anchors (host), despecify_indel_breakpoints per

@@ -552,3 +552,85 @@ def oracle_suffix_array_lcp(text):
     if rc:
         raise RuntimeError("clo_suffix_array_lcp failed: %d" % rc)
     return sa, lcp
+
+
+def ref_anchor_chain_masked(g1, g2, ms, mask, override_scale=None, max_num_match_pairs=1250000, score_scale=1.0, params=None,
+                            global_anchoring=True, fill_in=True):
+    """the compiled reference's Anchorer::anchor_chain with masked matches and an overriding scale (anchorer.hpp:135-145).
+    Returns dict(chain (n,3) in the REORDERED indexing, score, walk_off, walk1, walk2, set_order, mask (the mask after the call, reordered indexing))"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_anchor_chain_masked.restype = C.c_int
+    lib.ref_anchor_chain_masked.argtypes = ([C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.POINTER(CloChainParams),
+                                            C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)] + [C.c_void_p] * 9)
+    lib.ref_free.argtypes = [C.c_void_p]
+    params = params or default_chain_params()
+    c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
+    cap = max(ms.n_pairs(), 1)
+    anchors = np.zeros((cap, 3), np.uint64)
+    walk_off = np.zeros(cap + 1, np.uint64)
+    sc = np.zeros(cap)
+    n, nm = C.c_uint64(0), C.c_uint64(0)
+    order = np.zeros(max(ms.n_sets, 1), np.uint64)
+    w1p, w2p, mp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    m = np.ascontiguousarray(mask, np.uint64).reshape(-1, 3)
+    osc = C.c_double(float(override_scale)) if override_scale is not None else None
+    rc = lib.ref_anchor_chain_masked(C.byref(c1), C.byref(c2), C.byref(mc), C.byref(params), int(global_anchoring), int(max_num_match_pairs),
+                                     float(score_scale), int(fill_in), m.ctypes.data, len(m), C.byref(osc) if osc is not None else None,
+                                     anchors.ctypes.data, sc.ctypes.data, C.addressof(n), order.ctypes.data, walk_off.ctypes.data,
+                                     C.addressof(w1p), C.addressof(w2p), C.addressof(mp), C.addressof(nm))
+    if rc:
+        raise RuntimeError("ref_anchor_chain_masked failed: %d" % rc)
+    k = int(n.value)
+    nw = int(walk_off[k])
+    w1 = np.ctypeslib.as_array(C.cast(w1p, C.POINTER(C.c_uint32)), shape=(max(nw, 1),))[:nw].copy()
+    w2 = np.ctypeslib.as_array(C.cast(w2p, C.POINTER(C.c_uint32)), shape=(max(nw, 1),))[:nw].copy()
+    km = int(nm.value)
+    mo = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint64)), shape=(max(km, 1) * 3,))[:3 * km].copy().reshape(km, 3)
+    for ptr in (w1p, w2p, mp):
+        lib.ref_free(ptr)
+    return dict(chain=anchors[:k].copy(), score=sc[:k].copy(), walk_off=walk_off[:k + 1].copy(), walk1=w1, walk2=w2,
+                set_order=order[:ms.n_sets].copy(), mask=mo)
+
+
+def ref_masks(ms, mode, chain=None, mask=None, mask_reciprocal=False):
+    """Core::generate_diagonal_mask (mode 0) / Core::update_mask (mode 1; chain = dict with walk_off, walk1, walk2) of the compiled
+    reference (src/core.cpp:301-372): the resulting mask, sorted (n, 3)"""
+    lib = ref_lib()
+    lib.ref_masks.restype = C.c_int
+    lib.ref_masks.argtypes = [C.c_int, C.POINTER(CloMatchSets), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64,
+                              C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    mc = ms.as_c()
+    wo = np.ascontiguousarray(chain["walk_off"], np.uint64) if chain else np.zeros(1, np.uint64)
+    w1 = np.ascontiguousarray(chain["walk1"], np.uint32) if chain else np.zeros(1, np.uint32)
+    w2 = np.ascontiguousarray(chain["walk2"], np.uint32) if chain else np.zeros(1, np.uint32)
+    m = np.ascontiguousarray(mask if mask is not None else np.zeros((0, 3)), np.uint64).reshape(-1, 3)
+    mp, nm = C.c_void_p(), C.c_uint64(0)
+    rc = lib.ref_masks(int(mode), C.byref(mc), len(wo) - 1, wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, int(mask_reciprocal), m.ctypes.data, len(m),
+                       C.addressof(mp), C.addressof(nm))
+    if rc:
+        raise RuntimeError("ref_masks failed: %d" % rc)
+    km = int(nm.value)
+    out = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint64)), shape=(max(km, 1) * 3,))[:3 * km].copy().reshape(km, 3)
+    lib.ref_free(mp)
+    return out
+
+
+def ref_internal_stitch(g, walk_off, walk1, walk2, params=None):
+    """the compiled reference's Stitcher::internal_stitch (stitcher.hpp:209-234): (n, 2) uint64"""
+    from centrolign_amd.capi import BaseGraphC, StitchParams, default_stitch_params
+    lib = ref_lib()
+    lib.ref_internal_stitch.restype = C.c_int
+    lib.ref_internal_stitch.argtypes = [C.POINTER(BaseGraphC), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StitchParams), C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    params = params or default_stitch_params()
+    wo, w1, w2 = np.ascontiguousarray(walk_off, np.uint64), np.ascontiguousarray(walk1, np.uint32), np.ascontiguousarray(walk2, np.uint32)
+    c, pp, n = g.as_c(), C.c_void_p(), C.c_uint64(0)
+    rc = lib.ref_internal_stitch(C.byref(c), len(wo) - 1, wo.ctypes.data, w1.ctypes.data, w2.ctypes.data, C.byref(params), C.addressof(pp), C.addressof(n))
+    if rc:
+        raise RuntimeError("ref_internal_stitch failed: %d" % rc)
+    k = int(n.value)
+    out = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 2,))[:2 * k].copy().reshape(k, 2)
+    lib.ref_free(pp)
+    return out

@@ -542,6 +542,117 @@ int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
 
 void ref_free(void* p) { free(p); }
 
+/* Anchorer::anchor_chain WITH masked matches and an overriding scale (anchorer.hpp:135-145), as the tandem-duplication rounds of
+ * Core::calibrate_anchor_scores_and_identify_bonds call it (src/core.cpp:221-227).  mask_in: [3*n_mask] (set, idx1, idx2) in the indexing of
+ * `ms`; the call reorders the sets and re-indexes the mask in place: set_order_out as in ref_anchor_chain, *mask_out (malloc'ed, [3 * *n_mask_out])
+ * is the mask AFTER the call in the reordered indexing.  Only the chain's identities, walks and scores are returned. */
+int ref_anchor_chain_masked(const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, const clo_chain_params* cp,
+                            int global_anchoring, uint64_t max_num_match_pairs, double score_scale, int fill_in,
+                            const uint64_t* mask_in, uint64_t n_mask, const double* override_scale,
+                            uint64_t* anchors_out, double* score, uint64_t* n_anchors, uint64_t* set_order_out,
+                            uint64_t* walk_off_out, uint32_t** walk1_out, uint32_t** walk2_out, uint64_t** mask_out, uint64_t* n_mask_out) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    std::vector<match_set_t> sets(ms->n_sets);
+    std::map<std::pair<std::vector<std::vector<uint64_t>>, std::vector<std::vector<uint64_t>>>, uint64_t> identity;
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
+            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
+        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
+            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
+        sets[s].count1 = ms->count1[s];
+        sets[s].count2 = ms->count2[s];
+        sets[s].full_length = ms->full_length[s];
+        if (!identity.emplace(std::make_pair(sets[s].walks1, sets[s].walks2), s).second) return -2;
+    }
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    sf.score_scale = score_scale;
+    OpenAnchorer an(sf);
+    for (int i = 0; i < 3; ++i) { an.gap_open[i] = cp->gap_open[i]; an.gap_extend[i] = cp->gap_extend[i]; }
+    an.global_anchoring = global_anchoring != 0;
+    an.max_num_match_pairs = max_num_match_pairs;
+    an.autocalibrate_gap_penalties = true;
+    an.do_fill_in_anchoring = fill_in != 0;
+    an.split_matches_at_branchpoints = false;
+    an.chaining_algorithm = Anchorer::SparseAffine;
+    PathMerge<> pm1(b1, t1), pm2(b2, t2);
+    std::unordered_set<std::tuple<size_t, size_t, size_t>> mask;
+    for (uint64_t i = 0; i < n_mask; ++i) mask.emplace(mask_in[3 * i], mask_in[3 * i + 1], mask_in[3 * i + 2]);
+    double scale = override_scale ? *override_scale : 1.0;
+    std::vector<anchor_t> chain = an.anchor_chain(sets, b1, b2, t1, t2, pm1, pm2, false, &mask, override_scale ? &scale : nullptr);
+    for (uint64_t k = 0; k < sets.size(); ++k) {
+        auto it = identity.find(std::make_pair(sets[k].walks1, sets[k].walks2));
+        if (it == identity.end()) return -4;
+        set_order_out[k] = it->second;
+    }
+    *n_anchors = chain.size();
+    uint64_t total = 0;
+    for (const auto& a : chain) total += a.walk1.size();
+    *walk1_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+    *walk2_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+    uint64_t pos = 0;
+    walk_off_out[0] = 0;
+    for (size_t i = 0; i < chain.size(); ++i) {
+        for (size_t j = 0; j < chain[i].walk1.size(); ++j) { (*walk1_out)[pos + j] = (uint32_t)chain[i].walk1[j]; (*walk2_out)[pos + j] = (uint32_t)chain[i].walk2[j]; }
+        pos += chain[i].walk1.size();
+        walk_off_out[i + 1] = pos;
+        anchors_out[3 * i] = chain[i].match_set;
+        anchors_out[3 * i + 1] = chain[i].idx1;
+        anchors_out[3 * i + 2] = chain[i].idx2;
+        score[i] = chain[i].score;
+    }
+    std::vector<std::tuple<size_t, size_t, size_t>> sorted(mask.begin(), mask.end());
+    std::sort(sorted.begin(), sorted.end());
+    *n_mask_out = sorted.size();
+    *mask_out = (uint64_t*)malloc((sorted.size() ? sorted.size() : 1) * 3 * sizeof(uint64_t));
+    for (size_t i = 0; i < sorted.size(); ++i) {
+        (*mask_out)[3 * i] = std::get<0>(sorted[i]); (*mask_out)[3 * i + 1] = std::get<1>(sorted[i]); (*mask_out)[3 * i + 2] = std::get<2>(sorted[i]);
+    }
+    return 0;
+}
+
+/* Core::generate_diagonal_mask (mode 0) and Core::update_mask (mode 1, mask_reciprocal as given) on flat sets (src/core.cpp:301-372). */
+struct MaskCore : public Core {
+    MaskCore(std::vector<std::pair<std::string, std::string>>&& seqs, Tree&& tree) : Core(std::move(seqs), std::move(tree)) {}
+    using Core::generate_diagonal_mask;
+    using Core::update_mask;
+};
+int ref_masks(int mode, const clo_match_sets* ms, uint64_t n_chain, const uint64_t* chain_walk_off, const uint32_t* chain_walk1, const uint32_t* chain_walk2,
+              int mask_reciprocal, const uint64_t* mask_in, uint64_t n_mask, uint64_t** mask_out, uint64_t* n_mask_out) {
+    std::vector<match_set_t> sets(ms->n_sets);
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
+            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
+        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
+            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
+    }
+    std::vector<std::pair<std::string, std::string>> seqs{{"a", "ACGT"}, {"b", "ACGT"}};
+    MaskCore core(std::move(seqs), Tree("(a,b);"));
+    std::unordered_set<std::tuple<size_t, size_t, size_t>> mask;
+    if (mode == 0) mask = core.generate_diagonal_mask(sets);
+    else {
+        for (uint64_t i = 0; i < n_mask; ++i) mask.emplace(mask_in[3 * i], mask_in[3 * i + 1], mask_in[3 * i + 2]);
+        std::vector<anchor_t> chain(n_chain);
+        for (uint64_t a = 0; a < n_chain; ++a) {
+            chain[a].walk1.assign(chain_walk1 + chain_walk_off[a], chain_walk1 + chain_walk_off[a + 1]);
+            chain[a].walk2.assign(chain_walk2 + chain_walk_off[a], chain_walk2 + chain_walk_off[a + 1]);
+        }
+        core.update_mask(sets, chain, mask, mask_reciprocal != 0);
+    }
+    std::vector<std::tuple<size_t, size_t, size_t>> sorted(mask.begin(), mask.end());
+    std::sort(sorted.begin(), sorted.end());
+    *n_mask_out = sorted.size();
+    *mask_out = (uint64_t*)malloc((sorted.size() ? sorted.size() : 1) * 3 * sizeof(uint64_t));
+    for (size_t i = 0; i < sorted.size(); ++i) {
+        (*mask_out)[3 * i] = std::get<0>(sorted[i]); (*mask_out)[3 * i + 1] = std::get<1>(sorted[i]); (*mask_out)[3 * i + 2] = std::get<2>(sorted[i]);
+    }
+    return 0;
+}
+
 /* Partitioner::partition_anchors (partitioner.hpp:72-213) on flat anchors; segments_out gets (first, past-the-last) anchor
  * index pairs (buffer for n_anchors pairs) */
 int ref_partition_anchors(const cl_base_graph* g1, const cl_base_graph* g2, uint64_t n_anchors, const uint64_t* walk_off,
@@ -875,6 +986,26 @@ int ref_stitch_batch(const cl_stitch_batch* batch, const cl_stitch_params* sp, c
     out->pairs = (uint64_t*)malloc((pairs.size() ? pairs.size() : 1) * sizeof(uint64_t));
     if (!pairs.empty()) memcpy(out->pairs, pairs.data(), pairs.size() * sizeof(uint64_t));
     if (seconds_out) *seconds_out = secs;
+    return 0;
+}
+
+/* Stitcher::internal_stitch (stitcher.hpp:209-234) on a flat anchor chain inside one graph. */
+int ref_internal_stitch(const cl_base_graph* g, uint64_t n_anchors, const uint64_t* walk_off, const uint32_t* walk1, const uint32_t* walk2,
+                        const cl_stitch_params* sp, uint64_t** pairs_out, uint64_t* n_pairs_out) {
+    SentinelTableau t;
+    BaseGraph b = build_base_graph(g, t);
+    PathMerge<> pm(b, t);
+    DumpStitcher st;
+    set_stitcher(st, sp);
+    std::vector<anchor_t> chain(n_anchors);
+    for (uint64_t a = 0; a < n_anchors; ++a) {
+        chain[a].walk1.assign(walk1 + walk_off[a], walk1 + walk_off[a + 1]);
+        chain[a].walk2.assign(walk2 + walk_off[a], walk2 + walk_off[a + 1]);
+    }
+    Alignment aln = st.internal_stitch(chain, b, pm);
+    *n_pairs_out = aln.size();
+    *pairs_out = (uint64_t*)malloc((aln.size() ? aln.size() : 1) * 2 * sizeof(uint64_t));
+    for (size_t i = 0; i < aln.size(); ++i) { (*pairs_out)[2 * i] = aln[i].node_id1; (*pairs_out)[2 * i + 1] = aln[i].node_id2; }
     return 0;
 }
 

@@ -317,6 +317,8 @@ def plan_goldens():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cyclize":
+        return cyclize_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "plans":
         return plan_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "exhaustive":
@@ -532,6 +534,49 @@ def main():
     io_goldens()
     msa_goldens()
     print("golden vectors written to", HERE)
+
+
+
+def cyclize_goldens():
+    # 16. the tandem-duplication rounds of cyclisation (src/core.cpp:196-296), the parts on the hot path: a leaf's
+    #     self-matches, Core::generate_diagonal_mask, Anchorer::anchor_chain with masked matches and the leaf's intrinsic scale as the
+    #     overriding scale, Core::update_mask, a second round on the reordered sets, and Stitcher::internal_stitch of the secondary chain
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    out = {}
+    names = []
+    for k, (length, budget, kw) in enumerate([(6000, 1250000, {}), (9000, 4000, dict(hor_div=0.05)), (3000, 1250000, dict(mono_len=31, hor_n=4))]):
+        name = "leaf%d" % k
+        names.append(name)
+        seq = synth.hor_sequences(60 + k, length, 1, **kw)[0]
+        g = g5 = synth.base_graph_from_sequence(seq, (5, 6))
+        g7 = synth.base_graph_from_sequence(seq, (7, 8))                  # the second copy under its own sentinels, src/core.cpp:128-133
+        ms = po.ref_find_matches(g5, g7, max_count=3000)
+        scale = po.ref_leaf_intrinsic_scale(g, max_num_match_pairs=budget)
+        mask0 = po.ref_masks(ms, 0)
+        d = {"seq": np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), np.uint8), "budget": np.array([budget]), "scale": np.array([scale]), "mask0": mask0}
+        d.update({"ms." + f: getattr(ms, f) for f in capi.MatchSets._DT})
+        cur, mask = ms, mask0
+        for rnd in (1, 2):
+            r = po.ref_anchor_chain_masked(g5, g5, cur, mask, override_scale=scale, max_num_match_pairs=budget, score_scale=scale)
+            pre = "r%d." % rnd
+            for f in ("chain", "score", "walk_off", "walk1", "walk2", "set_order"):
+                d[pre + f] = r[f]
+            # what Core does next: the sets are now reordered and the mask re-indexed (r["mask"]); update_mask on them (src/core.cpp:288-291)
+            cur = cur.reordered(r["set_order"])
+            mask = po.ref_masks(cur, 1, chain=r, mask=r["mask"], mask_reciprocal=True)
+            d[pre + "mask_after_chain"] = r["mask"]
+            d[pre + "mask_after_update"] = mask
+            print(name, "round", rnd, "anchors", len(r["chain"]), "mask", len(r["mask"]), "->", len(mask))
+            if rnd == 1:
+                n = min(len(r["chain"]), 60)
+                wo = r["walk_off"][:n + 1]
+                d["stitch.pairs"] = po.ref_internal_stitch(g5, wo, r["walk1"][:int(wo[-1])], r["walk2"][:int(wo[-1])])
+                d["stitch.n_anchors"] = np.array([n])
+                print(name, "internal_stitch of", n, "anchors:", len(d["stitch.pairs"]), "pairs")
+        for f, v in d.items():
+            out[name + "." + f] = v
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "cyclize_rounds.npz"), **out)
 
 
 if __name__ == "__main__":
