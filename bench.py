@@ -205,7 +205,10 @@ def pairwise_section(ctx, with_reference):
 
 
 def main():
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: independent launches overlap on separate queues
+    # before HIP initialises: independent launches overlap on separate hardware queues.  Measured on the nine concurrent stitch plans
+    # (ms per step): 4 queues 8.9, 8: 8.2, 12: 5.6, 16: 4.9, 20: 3.8, 22: 4.9, 24: 11.5, 32: 28.5 — beyond ~23 the queues are
+    # oversubscribed and time-sliced; the MSA's wall-clock does not depend on it (15.2-16.3 s for 8..23)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

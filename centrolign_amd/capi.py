@@ -661,7 +661,8 @@ class MatchSets:
 
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("dp_bytes", C.c_uint64), ("last_ms", C.c_float)]
+                ("dp_bytes", C.c_uint64), ("last_ms", C.c_float), ("lds_bytes", C.c_uint32), ("max_sweep", C.c_uint32),
+                ("max_n1", C.c_uint32), ("max_n2", C.c_uint32)]
 
 
 _SIDE_DTYPES = dict(node_off=np.uint64, label=np.uint8, prev_off=np.uint64, prev_idx=np.uint32,
@@ -1105,7 +1106,8 @@ class Plan:
             li = LaunchInfo()
             self.ctx._check(self.ctx.lib.cl_stitch_plan_launch_info(self.ctx.handle, self.handle, i, C.byref(li)))
             out.append(dict(kernel=li.kernel.decode(), n_problems=int(li.n_problems), dp_cells=int(li.dp_cells),
-                            dp_bytes=int(li.dp_bytes), ms=float(li.last_ms)))
+                            dp_bytes=int(li.dp_bytes), ms=float(li.last_ms), lds_bytes=int(li.lds_bytes), max_sweep=int(li.max_sweep),
+                            longest=(int(li.max_n1), int(li.max_n2))))
         return out
 
     def destroy(self):

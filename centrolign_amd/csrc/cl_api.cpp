@@ -43,7 +43,7 @@ thread_local std::string g_error;
 // test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
 const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
-constexpr uint64_t kSysLdsBytes = 120 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
+constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
 constexpr uint64_t kRingLdsBytes = 128 * 1024;  // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU); launches are split at 64 KB
 // test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
@@ -550,6 +550,7 @@ struct cl_stitch_plan {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_tried = false;
+    std::vector<uint32_t> plist_host;   // the launch groups' subproblem lists (cl_stitch_plan_launch_info)
     bool executed = false, profiled = false;
 };
 
@@ -820,27 +821,35 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];   // node j (1-based rank): predecessors P.pidx[cp[j - 1] .. cp[j])
                 const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
                 uint64_t near_max = 0, max_deg = 0;
-                near_limit = 8;
-                while (true) {
-                    far_cols.clear();
-                    near_max = 0;
+                for (uint64_t j = 1; j <= n_cols; ++j) max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
+                // the near limit decides the ring depth H (LDS per row) against the number of saved columns (LDS per column): the candidate
+                // with the smallest footprint wins — LDS is what bounds how many subproblems a CU holds at once
+                const uint64_t cw = npw == 1 ? 4 : 8;
+                const uint64_t candidates[7] = {2, 4, 8, 32, 128, 512, 2047};   // the kernel's column records hold a near distance in 11 bits
+                uint64_t best_bytes = UINT64_MAX;
+                std::vector<uint32_t> cand_cols;
+                for (uint64_t limit : candidates) {
+                    cand_cols.clear();
+                    uint64_t nm = 0;
                     for (uint64_t j = 1; j <= n_cols; ++j) {
-                        max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
                         for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
                             const uint64_t dist = j - P.pidx[sCol][e];
-                            if (dist > near_limit) far_cols.push_back(P.pidx[sCol][e]); else near_max = std::max(near_max, dist);
+                            if (dist > limit) cand_cols.push_back(P.pidx[sCol][e]); else nm = std::max(nm, dist);
                         }
-                        if (cl[j - 1] & 0x80) { if (j > near_limit) far_cols.push_back(0); else near_max = std::max(near_max, j); }
+                        if (cl[j - 1] & 0x80) { if (j > limit) cand_cols.push_back(0); else nm = std::max(nm, j); }
                     }
-                    std::sort(far_cols.begin(), far_cols.end());
-                    far_cols.erase(std::unique(far_cols.begin(), far_cols.end()), far_cols.end());
-                    if (far_cols.size() <= 32 || near_limit >= 2047) break;
-                    near_limit = std::min<uint64_t>(near_limit * 4, 2047);   // the kernel's column records hold a near distance in 11 bits
+                    std::sort(cand_cols.begin(), cand_cols.end());
+                    cand_cols.erase(std::unique(cand_cols.begin(), cand_cols.end()), cand_cols.end());
+                    if (cand_cols.size() > 32) continue;
+                    uint32_t lg = 0;
+                    while ((1ull << lg) < span[sRow] + nm + 1 && lg < 14) ++lg;
+                    const uint64_t hw = (1ull << lg) * cw, stride = hw + ((cw + 4 + 64 - (hw & 63)) & 63);
+                    const uint64_t bytes = n_rows * stride * 4 + cand_cols.size() * n_rows * cw * 4 + n_cols * 8 + n_pred * 4 + cand_cols.size() * 4 + 16;
+                    if (bytes < best_bytes) { best_bytes = bytes; near_limit = limit; near_max = nm; sys_log = lg; far_cols = cand_cols; }
+                    if (cand_cols.empty()) break;   // a larger limit only deepens the ring
                 }
-                while ((1ull << sys_log) < span[sRow] + near_max + 1 && sys_log < 14) ++sys_log;
-                const uint64_t cw = npw == 1 ? 4 : 8, hw = (1ull << sys_log) * cw, stride = hw + ((cw + 4 + 64 - (hw & 63)) & 63);
-                sys_bytes = n_rows * stride * 4 + far_cols.size() * n_rows * cw * 4 + n_cols * 8 + n_pred * 4 + far_cols.size() * 4 + 16;
-                take_sys = far_cols.size() <= 32 && (1ull << sys_log) >= span[sRow] + near_max + 1 && sys_bytes <= kSysLdsBytes &&
+                sys_bytes = best_bytes;
+                take_sys = best_bytes != UINT64_MAX && far_cols.size() <= 32 && (1ull << sys_log) >= span[sRow] + near_max + 1 && sys_bytes <= kSysLdsBytes &&
                            max_deg <= 63 && cp[n_cols] - cp[0] < (1u << 17);   // field widths of the column records
             }
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
@@ -991,10 +1000,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             }
     // systolic DAG kernel: (NumPW, workgroup size, LDS class) — a launch's dynamic LDS is that of its hungriest problem, and LDS decides
     // how many workgroups share a CU, so the many small problems must not ride with the few large ones
-    const uint32_t lds_class[4] = {12 * 1024, 32 * 1024, 64 * 1024, (uint32_t)kSysLdsBytes};
+    const uint32_t lds_class[5] = {12 * 1024, 32 * 1024, 64 * 1024, 100 * 1024, (uint32_t)kSysLdsBytes};
     for (int bi = 2; bi >= 0; --bi)
         for (int npw = 3; npw >= 1; --npw)
-            for (int lc = 3; lc >= 0; --lc) {
+            for (int lc = 4; lc >= 0; --lc) {
                 LaunchGroup grp;
                 grp.kind = CL_KIND_SYS; grp.npw = npw; grp.block = blocks[bi];
                 grp.first = (uint32_t)plist.size();
@@ -1004,7 +1013,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     const int b = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
                     if (d.kind != CL_KIND_SYS || d.npw != npw || b != bi) continue;
                     int c = 0;
-                    while (c < 3 && ring_need[i] > lds_class[c]) ++c;
+                    while (c < 4 && ring_need[i] > lds_class[c]) ++c;
                     if (c != lc) continue;
                     plist.push_back(i);
                     grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
@@ -1026,6 +1035,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     lap("launch groups");
 
     // HBM
+    pl->plist_host = plist;
     if ((rc = pl->d_desc.upload(ctx, pl->desc)) || (rc = pl->d_plist.upload(ctx, plist)) || (rc = pl->d_aux.upload(ctx, sys_aux))) { plan_free(pl); return rc; }
     for (int s = 0; s < 2; ++s)
         if ((rc = pl->d_lab[s].upload(ctx, lab[s])) || (rc = pl->d_poff[s].upload(ctx, poff[s])) ||
@@ -1059,6 +1069,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     return CL_OK;
 }
 
+// auxiliary streams a plan spreads its launches over (CL_STITCH_STREAMS, 1..kNumAuxStreams): many contexts at once share the process's
+// hardware queues, and launches of different streams that land on one queue run one after the other
+static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kNumAuxStreams ? v : kNumAuxStreams; }();
+
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
 static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
@@ -1069,7 +1083,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
     bool used[kNumAuxStreams] = {};
     for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
         const LaunchGroup& g = pl->groups[gi];
-        int si = (int)(gi % kNumAuxStreams);
+        int si = (int)(gi % (size_t)g_plan_streams);
         if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
         if (timed && g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
         if (g.kind == CL_KIND_LINEAR)
@@ -1164,6 +1178,11 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     out->n_problems = g.count;
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;
+    out->lds_bytes = g.kind == CL_KIND_LINEAR ? 0u : g.ring_bytes;
+    for (uint32_t i = g.first; i < g.first + g.count; ++i) {
+        const ClProbDesc& d = pl->desc[pl->plist_host[i]];
+        if (d.n1 + d.n2 > out->max_sweep) { out->max_sweep = d.n1 + d.n2; out->max_n1 = d.n1; out->max_n2 = d.n2; }
+    }
     if (pl->profiled && g.ev0 && g.ev1) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (hipEventElapsedTime(&out->last_ms, g.ev0, g.ev1) != hipSuccess) out->last_ms = 0.f;

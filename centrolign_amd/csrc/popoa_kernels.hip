@@ -967,7 +967,7 @@ hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t l
     if (n_blocks == 0) return hipSuccess;
     static std::once_flag attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function (worker threads launch concurrently)
     std::call_once(attr_once, [] {
-        const int cap = 128 * 1024;
+        const int cap = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);

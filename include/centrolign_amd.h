@@ -186,6 +186,9 @@ typedef struct cl_launch_info {
     uint64_t dp_bytes;           /* algorithmic bytes: cells * sizeof(cell_t<NumPW>) */
     float    last_ms;            /* device duration of this launch in the last cl_stitch_plan_execute_profiled
                                     (HIP events on its stream); valid after cl_stitch_plan_sync */
+    uint32_t lds_bytes;          /* dynamic LDS per workgroup (0: static only) */
+    uint32_t max_sweep;          /* the longest dependent chain of the launch: max n1 + n2 over its subproblems */
+    uint32_t max_n1, max_n2;     /* the subproblem that has it */
 } cl_launch_info;
 int cl_stitch_plan_launch_count(const cl_stitch_plan* plan);
 int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int index, cl_launch_info* info_out);

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=20
 cd /tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --workers 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o r02 -- python3 $R/bench.py $ARGS > $OUT/prof_bench.json 2>$OUT/prof_bench.err

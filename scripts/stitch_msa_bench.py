@@ -23,13 +23,14 @@ def main():
         for _ in range(4):
             plan.execute_profiled(); plan.sync()
             for li in plan.launches():
-                k = (li["kernel"], li["n_problems"], li["dp_cells"])
+                k = (li["kernel"], li["n_problems"], li["dp_cells"], li["lds_bytes"], li["longest"])
                 best[k] = min(best.get(k, 1e9), li["ms"])
         n1, n2 = b.sizes()
         big = sorted(zip((n1 + 1) * (n2 + 1), n1, n2), reverse=True)[:3]
         print(m[:40], "problems", b.n_problems, "largest", [(int(x[1]), int(x[2])) for x in big])
-        for (kern, npb, cells), ms in sorted(best.items(), key=lambda kv: -kv[1])[:6]:
-            print("    %-30s %5d problems %10d cells %8.3f ms" % (kern, npb, cells, ms))
+        for (kern, npb, cells, lds, longest), ms in sorted(best.items(), key=lambda kv: -kv[1])[:8]:
+            print("    %-30s %5d problems %10d cells %8.3f ms   LDS %6d B, longest sweep %d x %d = %.2f us per step" %
+                  (kern, npb, cells, ms, lds, longest[0], longest[1], 1e3 * ms / max(1, sum(longest))))
         plan.destroy()
 
 
