@@ -843,7 +843,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     if (cand_cols.size() > 32) continue;
                     uint32_t lg = 0;
                     while ((1ull << lg) < span[sRow] + nm + 1 && lg < 14) ++lg;
-                    const uint64_t hw = (1ull << lg) * cw, stride = hw + ((cw + 4 + 64 - (hw & 63)) & 63);
+                    const uint64_t hw = (1ull << lg) * cw, stride = hw + (cw == 8 ? 4 : 8);   // popoa_sys_kernel's row stride
                     const uint64_t bytes = n_rows * stride * 4 + cand_cols.size() * n_rows * cw * 4 + n_cols * 8 + n_pred * 4 + cand_cols.size() * 4 + 16;
                     if (bytes < best_bytes) { best_bytes = bytes; near_limit = limit; near_max = nm; sys_log = lg; far_cols = cand_cols; }
                     if (cand_cols.empty()) break;   // a larger limit only deepens the ring

@@ -706,9 +706,10 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     const uint8_t* const labCp = (swap ? B.lab[0] : B.lab[1]) + baseC;
     // LDS (int32 units): ring [nR + 1][row stride] | saved columns [K][nR + 1][CW] | column records [nC] (uint2) | row predecessor lists |
     // column predecessor lists | saved column numbers [K].
-    // Lane r works on row r at column t - r, so neighbouring lanes' ring addresses differ by (row stride - CW) words: the stride is padded
-    // to make that 4 (mod 64) — the sixteen lanes of a 16-byte LDS access then fall on sixteen different 4-bank groups
-    const uint32_t row_stride = (H * CW) + ((CW + 4u + 64u - ((H * CW) & 63u)) & 63u);
+    // Lane r works on row r at column t - r, so neighbouring lanes' ring addresses differ by (row stride - CW) words: with a pad of 4 (8)
+    // words for 8-word (4-word) cells that difference is an ODD multiple of four words — 4(2H - 1), 4(H + 1) — so the sixteen lanes of a
+    // 16-byte LDS access fall on sixteen different 4-bank groups
+    const uint32_t row_stride = H * CW + (CW == 8 ? 4u : 8u);
     int32_t* const ring = lds;
     int32_t* const saved = ring + (nR + 1) * row_stride;
     uint2* const recC = reinterpret_cast<uint2*>(saved + K * (nR + 1) * CW);

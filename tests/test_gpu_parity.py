@@ -187,3 +187,19 @@ def test_lopsided_and_large_dag_pairs(gpu_ctx):
         f = np.full(small.n_problems, npw, np.uint8)
         got = gpu_ctx.po_poa_batch(small, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(small, force_num_pw=f)) is None
+
+
+def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
+    """branching pairs whose per-row column rings fill the systolic kernel's LDS budget (launches with 98-160 KB of dynamic LDS), next to
+    ones that overflow it and take the LDS-ring or the HBM-plane kernel: all against the oracle"""
+    sizes = [(480, 500), (510, 300), (300, 509), (440, 2000), (1000, 620), (255, 3000), (64, 5000)]
+    seen = set()
+    for kw in (dict(extra_edge_p=0.02, skip_max=2), dict(extra_edge_p=0.05, skip_max=3), dict(extra_edge_p=0.15, skip_max=2)):
+        b = synth.sized_dag_batch(sizes, seed=11, **kw)
+        plan = gpu_ctx.plan(b)
+        for li in plan.launches():
+            seen.add((li["kernel"].split("<")[0], li["lds_bytes"] > 128 * 1024))
+        plan.destroy()
+        got = gpu_ctx.stitch_batch_align(b)
+        assert got.same_as(po.oracle_stitch_batch(b)) is None, kw
+    assert ("popoa_sys_kernel", True) in seen and ("popoa_ring_kernel", False) in seen and ("popoa_general_kernel", False) in seen, seen
