@@ -205,10 +205,6 @@ def pairwise_section(ctx, with_reference):
 
 
 def main():
-    # before HIP initialises: independent launches overlap on separate hardware queues.  Measured on the nine concurrent stitch plans
-    # (ms per step): 4 queues 8.9, 8: 8.2, 12: 5.6, 16: 4.9, 20: 3.8, 22: 4.9, 24: 11.5, 32: 28.5 — beyond ~23 the queues are
-    # oversubscribed and time-sliced; the MSA's wall-clock does not depend on it (15.2-16.3 s for 8..23)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -226,6 +222,12 @@ def main():
     n_dev = torch.cuda.device_count()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     share = world_env > 1 and n_dev < world_env          # dry run of the multi-rank path on fewer devices: ranks share them, gloo collectives
+    # before HIP initialises (device_count above does not): independent launches overlap on separate hardware queues.  Measured on the
+    # nine concurrent stitch plans (ms per step): 4 queues 8.9, 8: 8.2, 12: 5.6, 16: 4.9, 20: 3.8, 22: 4.9, 24: 11.5, 32: 28.5 — beyond
+    # ~23 PER DEVICE the queues are oversubscribed and time-sliced, so ranks that share a device share the 20; the MSA's wall-clock does
+    # not depend on it (15.2-16.3 s for 8..23)
+    per_device = max(1, -(-world_env // max(1, n_dev)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 20 // per_device)))
     rank, world, dist = cd.init_distributed(None if world_env == 1 else ("gloo" if share else "nccl"))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
