@@ -307,8 +307,27 @@ struct SetView {
 
 }  // namespace
 
+constexpr int kWalkStalled = -1000;   // internal: the walk kernel's workgroups were not all resident (chain_dp_batch retries without it)
+
+static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
+                               bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out, bool allow_walk);
+
+// The walk kernel's workgroups (one per chain combination) wait for one another and must all be resident at once.  That holds whenever the
+// device is not packed with OTHER contexts' workgroups; if a bounded wait ever expires, nothing has been decided yet (the status word is
+// read before any result is used) and the DP is simply run again on the per-block kernels, which need no co-residency.
 static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
                           bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out) {
+    const ChainTimings before = tm;
+    int rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, true);
+    if (rc != kWalkStalled) return rc;
+    if (getenv("CL_CHAIN_TIMING")) fprintf(stderr, "[chain_dp_batch]   walk kernel stalled: repeating the DP on the per-block kernels\n");
+    tm = before;
+    rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, false);
+    return rc == kWalkStalled ? CL_ERR_HIP : rc;
+}
+
+static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
+                               bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out, bool allow_walk) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto T0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
@@ -669,7 +688,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     // the walk kernel (one workgroup per combination, all resident) replaces the per-block intra launches up to
     // kChainWalkMaxCombos combinations; CL_CHAIN_OLD_WALK=1 forces the per-block path (A/B measurements)
     static const bool old_walk_env = getenv("CL_CHAIN_OLD_WALK") != nullptr;
-    const bool use_walk = combos.size() <= kChainWalkMaxCombos && !old_walk_env;
+    const bool use_walk = allow_walk && combos.size() <= kChainWalkMaxCombos && !old_walk_env;
     std::vector<ClChainCombo> hc(combos.size());
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
@@ -1050,11 +1069,13 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
         uint32_t status = 0;
         he = cl_copy_sync(ctx, &status, d_status.p, sizeof(status), hipMemcpyDeviceToHost);
         if (he != hipSuccess) return hip_fail(he, "chaining DP status");
+        static const bool debug_stall = getenv("CL_CHAIN_DEBUG_STALL") != nullptr;   // test hook: behave as if a wait had expired
+        if (debug_stall) status = 1;
         if (status != 0) {
             cl_set_error(ctx, "chaining DP: a workgroup of the walk kernel gave up waiting for its siblings (%zu combinations not all resident?)", combos.size());
             (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
             cleanup();
-            return CL_ERR_HIP;
+            return kWalkStalled;
         }
     }
     {

@@ -155,3 +155,30 @@ def test_gpu_sparse_chain_is_optimal(gpu_ctx, name):
         want = float(z["exhaustive.%d.%d" % (seed, budget)][0])
         assert abs(chain_weight(ms, got["chain"]) - want) < 1e-6
         assert abs(float(got["dp"].max()) - want) < 1e-3 * max(1.0, want)   # the float DP value of the chain's last anchor
+
+
+def test_walk_stall_falls_back_to_the_per_block_kernels():
+    """the walk kernel needs all its workgroups resident; if one of its bounded waits ever expires, the DP is repeated on the per-block
+    kernels.  CL_CHAIN_DEBUG_STALL=1 makes every walk attempt report a stall (the variable is read once, hence the child process): the
+    multi-path golden chains must still come out"""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from centrolign_amd import capi\n"
+        "from tests import helpers as H\n"
+        "from tests.test_extraction import load_stitch_case\n"
+        "name = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith('chain4_'))[-1]\n"
+        "z = np.load(os.path.join(H.GOLDEN, name))\n"
+        "_, graphs, _ = load_stitch_case(name.replace('chain4_', 'stitch4_'))\n"
+        "ctx = capi.Context(0)\n"
+        "for tag in ('a', 'b'):\n"
+        "    ms = capi.MatchSets(**{k: z['%%s.ms.%%s' %% (tag, k)] for k in capi.MatchSets._DT})\n"
+        "    got = ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z[tag + '.scale'][0]), params=capi.default_chain_params(global_anchoring=True))\n"
+        "    assert np.array_equal(got['chain'], z[tag + '.chain_affine_global']), tag\n"
+        "print('fallback ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, CL_CHAIN_DEBUG_STALL="1", CL_CHAIN_TIMING="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "walk kernel stalled" in r.stderr
