@@ -252,7 +252,8 @@ def main():
         host_group = None
     else:
         host_group = dist.new_group(backend="gloo") if not share else None
-        res = msa.progressive_msa_distributed(ctx, seqs, tree, dist, rank, world, group=host_group, keep_merges=True, all_ranks=True)
+        res = msa.progressive_msa_distributed(ctx, seqs, tree, dist, rank, world, group=host_group, keep_merges=True, all_ranks=True,
+                                              workers=args.workers)
     msa_wall = time.perf_counter() - t0
     msa_wall = cd.max_over_ranks(msa_wall, dist, device="cpu" if share else "cuda")
     kept = res["stats"].get("kept", []) if res is not None and "stats" in res else []
@@ -331,7 +332,7 @@ def main():
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
                        "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
-                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank), stitch batches on the rank that made them, no data-path collective" % world},
+                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank), stitch batches on the rank that made them, no data-path collective" % (world, args.workers)},
             "msa_wall_s": msa_wall,
             "msa": {"pipeline": "leaf graphs + 10 calibrations + 9 x (find_matches + Core::align + fuse) + write_gfa, no reference in the loop",
                     "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "score_scale": res["scale"],

@@ -182,28 +182,57 @@ def recv_graph(src, dist, group=None):
     return _unpack_graph(head.numpy(), body.numpy())
 
 
+def _in_parallel(contexts, jobs):
+    """jobs: callables taking a context, run side by side on the contexts (one thread per context; the ABI calls release the GIL);
+    results in order"""
+    if len(contexts) == 1 or len(jobs) <= 1:
+        return [job(contexts[0]) for job in jobs]
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    free = queue.Queue()
+    for c in contexts:
+        free.put(c)
+
+    def run(job):
+        c = free.get()
+        try:
+            return job(c)
+        finally:
+            free.put(c)
+    with ThreadPoolExecutor(len(contexts)) as pool:
+        return list(pool.map(run, jobs))
+
+
 def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000,
-                                keep_merges=False, all_ranks=False):
+                                keep_merges=False, all_ranks=False, workers=1, make_context=None):
     """progressive_msa over `world` ranks; every rank calls it with the same arguments (its own ctx).  `group` must be a
     host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None — or, with
-    all_ranks, their own dict (root None, stats of the merges they ran)."""
+    all_ranks, their own dict (root None, stats of the merges they ran).  workers > 1: a rank that owns a whole subtree runs its
+    independent merges (and its share of the calibrations) side by side on that many contexts of its device, as progressive_msa does."""
     import torch
     order = leaves_of(tree)
+    make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
+    contexts = [ctx] + [make_context() for _ in range(max(1, int(workers)) - 1)]
     # level 1: leaf calibrations, round-robin; the scales meet by a SUM all-reduce of a vector that is zero except at the
     # rank's own leaves (x + 0.0 is exact), and every rank takes the mean in leaf order like the reference (src/core.cpp:169-173)
     leaves = {}
     mine = torch.zeros(len(order), dtype=torch.float64)
-    for i, nm in enumerate(order):
-        if i % world == rank:
-            leaves[nm] = capi.leaf_graph(sequences[nm])
-            mine[i] = ctx.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
+    own = [(i, nm) for i, nm in enumerate(order) if i % world == rank]
+    for i, nm in own:
+        leaves[nm] = capi.leaf_graph(sequences[nm])
+    for (i, nm), sc in zip(own, _in_parallel(contexts, [lambda c, nm=nm: c.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
+                                                        for i, nm in own])):
+        mine[i] = sc
     dist.all_reduce(mine, group=group)
     scales = mine.tolist()
     scale = sum(scales) / len(scales)
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0, graphs_received=0)
 
-    def merge(g1, g2, t):
-        r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
+    def merge(g1, g2, t, c=None):
+        r = (c or ctx).merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
+        return record(r, g1, g2, t)
+
+    def record(r, g1, g2, t):
         for k in ("match_ms", "align_ms", "fuse_ms"):
             stats[k] += r[k]
         stats["merges"] += 1
@@ -217,6 +246,25 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
                 stats.setdefault("kept", []).append(dict(merge=newick(t), graphs=(g1, g2), align=al, fused=r["fused"], paths=leaves_of(t)))
         return r["fused"]
 
+    def solve_local(t):
+        """a whole subtree on this rank: its merges in waves, every merge whose two children are there side by side on the contexts"""
+        done, pending = {}, []
+
+        def collect(u):
+            if isinstance(u, str):
+                done[u] = leaves[u] if u in leaves else capi.leaf_graph(sequences[u])
+            else:
+                collect(u[0]); collect(u[1]); pending.append(u)
+        collect(t)
+        while pending:
+            ready = [u for u in pending if newick(u[0]) in done and newick(u[1]) in done]
+            pending = [u for u in pending if not (newick(u[0]) in done and newick(u[1]) in done)]
+            jobs = [lambda c, u=u: c.merge(done[newick(u[0])], done[newick(u[1])], score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
+                    for u in ready]
+            for u, r in zip(ready, _in_parallel(contexts, jobs)):
+                done[newick(u)] = record(r, done[newick(u[0])], done[newick(u[1])], u)   # (stats in tree order of the wave)
+        return done[newick(t)]
+
     def solve(t, ranks):
         """the subtree's graph on ranks[0], None elsewhere"""
         if rank not in ranks:
@@ -226,7 +274,9 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
                 return None   # only the owner needs the leaf's graph
             return leaves[t] if t in leaves else capi.leaf_graph(sequences[t])
         if len(ranks) == 1:
-            return merge(solve(t[0], ranks), solve(t[1], ranks), t)
+            if len(contexts) == 1:
+                return merge(solve(t[0], ranks), solve(t[1], ranks), t)
+            return solve_local(t)
         left, right = split_ranks(t, ranks)
         g1, g2 = solve(t[0], left), solve(t[1], right)
         if rank == right[0]:
@@ -237,7 +287,12 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
         stats["graphs_received"] += 1
         return merge(g1, g2, t)
 
-    root = solve(tree, list(range(world)))
+    try:
+        root = solve(tree, list(range(world)))
+    finally:
+        for c in contexts[1:]:
+            if hasattr(c, "close"):
+                c.close()
     if rank != 0:
         return dict(root=None, paths=order, scale=scale, scales=scales, stats=stats) if all_ranks else None
     return dict(root=root, paths=order, scale=scale, scales=scales, stats=stats)

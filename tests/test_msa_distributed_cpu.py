@@ -34,7 +34,10 @@ names = ["s%%d" %% i for i in range(7)]
 seqs = {nm: "".join("ACGT"[b] for b in rng.integers(0, 4, int(rng.integers(20, 60)))) for nm in names}
 for tree in (msa.balanced_tree(names), msa.balanced_tree(names[:2]), ((("s0", "s1"), "s2"), ("s3", ("s4", ("s5", "s6"))))):
     got = msa.progressive_msa_distributed(StubCtx(), seqs, tree, dist, rank, world)
+    # three worker contexts inside every rank: a rank's independent merges and calibrations side by side, same result
+    par = msa.progressive_msa_distributed(StubCtx(), seqs, tree, dist, rank, world, workers=3, make_context=StubCtx)
     if rank == 0:
+        assert capi.graphs_equal(got["root"], par["root"]) and got["scales"] == par["scales"] and got["stats"]["merges"] == par["stats"]["merges"]
         want = msa.progressive_msa(StubCtx(), seqs, tree)
         assert capi.graphs_equal(got["root"], want["root"]) and got["paths"] == want["paths"]
         assert got["scale"] == want["scale"] and got["scales"] == want["scales"]
