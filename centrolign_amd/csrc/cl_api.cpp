@@ -577,6 +577,15 @@ void plan_free(cl_stitch_plan* pl) {
 
 }  // namespace
 
+namespace {
+std::mutex g_live_mutex;
+std::vector<const cl_context*> g_live_contexts;
+}
+bool cl_context_live(const cl_context* ctx) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    return std::find(g_live_contexts.begin(), g_live_contexts.end(), ctx) != g_live_contexts.end();
+}
+
 extern "C" {
 
 int cl_abi_version(void) { return CL_ABI_VERSION; }
@@ -634,11 +643,19 @@ cl_context* cl_context_create(int device_ordinal) {
         return nullptr;
     }
     ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live_contexts.push_back(ctx);
+    }
     return ctx;
 }
 
 void cl_context_destroy(cl_context* ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live_contexts.erase(std::remove(g_live_contexts.begin(), g_live_contexts.end(), ctx), g_live_contexts.end());
+    }
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < kNumAuxStreams; ++i) {
         if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
@@ -647,6 +664,10 @@ void cl_context_destroy(cl_context* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        cl_pool_trim(ctx);
+    }
     delete ctx;
 }
 

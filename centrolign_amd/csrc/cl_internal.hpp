@@ -7,7 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/centrolign_amd.h"
 
@@ -25,7 +28,61 @@ struct cl_context {
     // at the link's rate, copies into pageable memory at a tenth of it, and locking pages is too slow to do per call
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // device memory pool (cl_dev_alloc / cl_dev_free).  hipFree waits for the WHOLE device and hipMalloc takes a process-wide lock: with
+    // several contexts at work (the worker threads of an MSA) every release in one of them stalled on the others' kernels.  Released
+    // blocks are kept here and handed out again, largest-fit within 2x; they go back to the driver when the context is destroyed or the
+    // pool holds more than kPoolCap bytes.
+    std::mutex pool_mutex;
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_size;
+    size_t pool_free_bytes = 0;
 };
+constexpr size_t kPoolCap = 24ull << 30;
+
+inline void cl_pool_trim(cl_context* ctx) {   // under pool_mutex
+    for (auto& b : ctx->pool_free) { ctx->pool_size.erase(b.second); (void)hipFree(b.second); }
+    ctx->pool_free.clear();
+    ctx->pool_free_bytes = 0;
+}
+
+inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
+    static const bool no_pool = getenv("CL_NO_POOL") != nullptr;
+    if (no_pool) return hipMalloc(out, bytes);
+    bytes = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    auto it = ctx->pool_free.lower_bound(bytes);
+    if (it != ctx->pool_free.end() && it->first <= 2 * bytes + (1u << 20)) {
+        *out = it->second;
+        ctx->pool_free_bytes -= it->first;
+        ctx->pool_free.erase(it);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        cl_pool_trim(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) ctx->pool_size[*out] = bytes;
+    return e;
+}
+
+bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not yet destroyed
+
+inline void cl_dev_free(cl_context* ctx, void* p) {
+    if (!p) return;
+    static const bool no_pool = getenv("CL_NO_POOL") != nullptr;
+    if (no_pool || !ctx || !cl_context_live(ctx)) { (void)hipFree(p); return; }   // (a plan may outlive the context it was made on)
+    // the block may be handed out again at once: wait for THIS context's streams (hipFree used to wait for the whole device)
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < kNumAuxStreams; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    auto it = ctx->pool_size.find(p);
+    if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
+    if (ctx->pool_free_bytes + it->second > kPoolCap) { ctx->pool_size.erase(it); (void)hipFree(p); return; }
+    ctx->pool_free.emplace(it->second, p);
+    ctx->pool_free_bytes += it->second;
+}
 
 // at least `bytes` of page-locked host memory owned by the context (contents undefined; one user at a time); nullptr when it cannot be had
 inline void* cl_pinned(cl_context* ctx, size_t bytes) {
@@ -64,11 +121,13 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    cl_context* owner = nullptr;
     int alloc(cl_context* ctx, size_t count) {
         release();
         n = count;
         if (count == 0) count = 1;
-        HIP_TRY(ctx, hipMalloc((void**)&p, count * sizeof(T)));
+        HIP_TRY(ctx, cl_dev_alloc(ctx, count * sizeof(T), (void**)&p));
+        owner = ctx;
         return CL_OK;
     }
     template <class Vec>
@@ -79,7 +138,7 @@ struct DevBuf {
         return CL_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) cl_dev_free(owner, p);
         p = nullptr;
         n = 0;
     }
