@@ -1001,7 +1001,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     }
                     if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, far_stream);
                 }
-                if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_far[k], hipEventDisableTiming);
+                if (he == hipSuccess) he = cl_ring_event(ctx, 1, k, &ev_far[k]);
                 if (he == hipSuccess) he = hipEventRecord(ev_far[k], far_stream);
             }
             if (he == hipSuccess && b0 > near_lo) {
@@ -1012,19 +1012,18 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
             if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
             if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_walk[k], hipEventDisableTiming);
+            if (he == hipSuccess) he = cl_ring_event(ctx, 0, k, &ev_walk[k]);
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
             if (use_far && far_bb && he == hipSuccess && k + far_lag + 1 < n_macro) {
                 he = hipStreamWaitEvent(seal_stream, ev_walk[k], 0);
                 if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_stream);
-                if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_seal[k], hipEventDisableTiming);
+                if (he == hipSuccess) he = cl_ring_event(ctx, 2, k, &ev_seal[k]);
                 if (he == hipSuccess) he = hipEventRecord(ev_seal[k], seal_stream);
             }
         }
         if (use_far && he == hipSuccess) he = hipStreamSynchronize(seal_stream);
-        for (auto e : ev_seal) if (e) (void)hipEventDestroy(e);
-        ev_intra.swap(ev_walk);   // destroyed below
-        for (auto e : ev_walk) if (e) (void)hipEventDestroy(e);
+        // (the walk path's events are the context's ring events: nothing to destroy)
+        ev_far.assign(ev_far.size(), nullptr);
     } else {
         uint32_t near_lo = 0;   // first block the current group's far launch did not cover
         for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {

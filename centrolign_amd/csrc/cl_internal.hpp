@@ -32,6 +32,9 @@ struct cl_context {
     // several contexts at work (the worker threads of an MSA) every release in one of them stalled on the others' kernels.  Released
     // blocks are kept here and handed out again, largest-fit within 2x; they go back to the driver when the context is destroyed or the
     // pool holds more than kPoolCap bytes.
+    // events the chaining DP records once per macro-block (walk done / far done / sealed): three rings, made once and reused — an event wait
+    // refers to the record that precedes it, so a slot can be recorded again as soon as its waits have been enqueued (a few blocks later)
+    hipEvent_t ev_ring[3][32] = {};
     std::mutex pool_mutex;
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_size;
@@ -65,6 +68,13 @@ inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
     }
     if (e == hipSuccess) ctx->pool_size[*out] = bytes;
     return e;
+}
+
+inline hipError_t cl_ring_event(cl_context* ctx, int kind, uint32_t k, hipEvent_t* out) {
+    hipEvent_t& e = ctx->ev_ring[kind][k & 31u];
+    if (!e) { hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (rc != hipSuccess) return rc; }
+    *out = e;
+    return hipSuccess;
 }
 
 bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not yet destroyed
