@@ -12,7 +12,12 @@
  *   (1) the reference's anchor_chain -> partition_anchors -> despecify_indel_breakpoints -> stitch on the CPU
  *   (2) include/centrolign_amd/core_adapter.hpp -> cl_core_align -> MI355X, from the same match sets
  *
- * usage: adapter_demo <fasta> [newick-file|-] [max_num_match_pairs] [core]
+ * With "seams" the wrappers of include/centrolign_amd/seam_wrappers.hpp — the reference's own signatures at S1 / S3 / internal_stitch — are
+ * called next to the reference's functions on the same objects: anchor_chain per merge (chain, annotation, the order it leaves the match
+ * sets in), po_poa<1|2|3> on extracted subgraph pairs (alignment + score), and on every leaf the masked anchor_chain of the cyclisation
+ * rounds (src/core.cpp:221-227) + Stitcher::internal_stitch of its chain.
+ *
+ * usage: adapter_demo <fasta> [newick-file|-] [max_num_match_pairs] [core|seams]
  */
 #include <chrono>
 #include <cstdio>
@@ -26,6 +31,7 @@
 
 #include "../include/centrolign_amd/stitch_adapter.hpp"
 #include "../include/centrolign_amd/core_adapter.hpp"
+#include "../include/centrolign_amd/seam_wrappers.hpp"
 
 using namespace centrolign;
 
@@ -102,6 +108,87 @@ struct DemoCore : public Core {
         return got;  // continue the MSA on the GPU result: later merges then depend on it
     }
 
+    bool seams = false;
+
+    static bool same_chain(const std::vector<anchor_t>& a, const std::vector<anchor_t>& b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (a[i].walk1 != b[i].walk1 || a[i].walk2 != b[i].walk2 || a[i].count1 != b[i].count1 || a[i].count2 != b[i].count2 ||
+                a[i].full_length != b[i].full_length || a[i].score != b[i].score || a[i].gap_before != b[i].gap_before ||
+                a[i].gap_after != b[i].gap_after || a[i].gap_score_before != b[i].gap_score_before || a[i].gap_score_after != b[i].gap_score_after ||
+                a[i].match_set != b[i].match_set || a[i].idx1 != b[i].idx1 || a[i].idx2 != b[i].idx2)
+                return false;
+        return true;
+    }
+    static bool same_sets(const std::vector<match_set_t>& a, const std::vector<match_set_t>& b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (a[i].walks1 != b[i].walks1 || a[i].walks2 != b[i].walks2 || a[i].count1 != b[i].count1 || a[i].count2 != b[i].count2) return false;
+        return true;
+    }
+    template <int NumPW>
+    bool po_poa_both(const SubGraphInfo& i1, const SubGraphInfo& i2) {
+        AlignmentParameters<NumPW> p;
+        p.match = stitcher.alignment_params.match;
+        p.mismatch = stitcher.alignment_params.mismatch;
+        for (int k = 0; k < NumPW; ++k) { p.gap_open[k] = stitcher.alignment_params.gap_open[k]; p.gap_extend[k] = stitcher.alignment_params.gap_extend[k]; }
+        int64_t s_ref = 0, s_got = 0;
+        Alignment ref = po_poa(i1.subgraph, i2.subgraph, i1.sources, i2.sources, i1.sinks, i2.sinks, p, &s_ref);
+        Alignment got = centrolign_amd::po_poa<NumPW, Alignment>(*dev, i1.subgraph, i2.subgraph, i1.sources, i2.sources, i1.sinks, i2.sinks, p, &s_got);
+        return ref == got && s_ref == s_got;
+    }
+
+    // seam S3 (+ S1 on the gaps of its chain) on the objects of one merge
+    template <class XMerge>
+    void seams_of_merge(const std::vector<match_set_t>& matches, const Subproblem& sp1, const Subproblem& sp2, XMerge& x1, XMerge& x2) {
+        std::vector<match_set_t> m_ref = matches, m_got = matches;
+        auto ref = anchorer.anchor_chain(m_ref, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, false);
+        auto got = centrolign_amd::anchor_chain<anchor_t>(*dev, anchorer, score_function, m_got, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, false);
+        const bool ok3 = same_chain(ref, got) && same_sets(m_ref, m_got);
+        if (!ok3) ++mismatched;
+        OpenStitcher st;
+        static_cast<Stitcher&>(st) = stitcher;
+        auto gaps = st.extract_graphs_between(ref, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2);
+        size_t tried = 0, bad = 0;
+        for (size_t i = 0; i < gaps.size() && tried < 60; ++i) {
+            if (gaps[i].first.subgraph.node_size() == 0 || gaps[i].second.subgraph.node_size() == 0) continue;
+            const int npw = 1 + (int)(tried % 3);
+            const bool ok = npw == 1 ? po_poa_both<1>(gaps[i].first, gaps[i].second) : npw == 2 ? po_poa_both<2>(gaps[i].first, gaps[i].second) : po_poa_both<3>(gaps[i].first, gaps[i].second);
+            ++tried;
+            if (!ok) ++bad;
+        }
+        if (bad) ++mismatched;
+        printf("merge %zu: anchor_chain wrapper %s the reference (%zu anchors, %zu sets after the call); po_poa<1|2|3> wrapper %s on %zu gap pairs\n", merges,
+               ok3 ? "==" : "!=", ref.size(), m_ref.size(), bad ? "!=" : "==", tried);
+    }
+
+    // the cyclisation round of one leaf (src/core.cpp:204-269): masked anchor_chain with the given scale, internal_stitch of its chain
+    void seams_of_leaf(const Subproblem& leaf) {
+        Subproblem sp = leaf;
+        reassign_sentinels(sp.graph, sp.tableau, 5, 6);
+        SentinelTableau dummy = sp.tableau;
+        dummy.src_sentinel = 7;
+        dummy.snk_sentinel = 8;
+        auto matches = path_match_finder.find_matches(sp.graph, sp.graph, sp.tableau, dummy);
+        PathMerge<> pm(sp.graph, sp.tableau);
+        auto mask_ref = generate_diagonal_mask(matches);
+        auto mask_got = mask_ref;
+        double scale_ref = score_function.score_scale, scale_got = scale_ref;
+        std::vector<match_set_t> m_ref = matches, m_got = matches;
+        auto ref = anchorer.anchor_chain(m_ref, sp.graph, sp.graph, sp.tableau, sp.tableau, pm, pm, false, &mask_ref, &scale_ref);
+        auto got = centrolign_amd::anchor_chain<anchor_t>(*dev, anchorer, score_function, m_got, sp.graph, sp.graph, sp.tableau, sp.tableau, pm, pm, false,
+                                                          &mask_got, &scale_got);
+        const bool ok3 = same_chain(ref, got) && same_sets(m_ref, m_got) && mask_ref == mask_got;
+        if (!ok3) ++mismatched;
+        std::vector<anchor_t> head(ref.begin(), ref.begin() + std::min<size_t>(ref.size(), 50));
+        Alignment s_ref = stitcher.internal_stitch(head, sp.graph, pm);
+        Alignment s_got = centrolign_amd::internal_stitch<Alignment>(*dev, stitcher, head, sp.graph, sp.tableau, pm);
+        const bool ok2 = s_ref == s_got;
+        if (!ok2) ++mismatched;
+        printf("leaf %s: masked anchor_chain wrapper %s the reference (%zu anchors, mask %zu); internal_stitch wrapper %s (%zu anchors, %zu pairs)\n",
+               sp.name.c_str(), ok3 ? "==" : "!=", ref.size(), mask_ref.size(), ok2 ? "==" : "!=", head.size(), s_ref.size());
+    }
+
     bool whole_align = false;
     double t_match_cpu = 0, t_match_gpu = 0;
 
@@ -123,6 +210,12 @@ struct DemoCore : public Core {
         printf("merge %zu: %zu match sets, alignment length %zu, GPU Core::align %s the reference\n", merges, matches.size(), ref.size(), same ? "==" : "!=");
         ++merges;
         return got;
+    }
+
+    void leaves_first() {
+        if (!skip_calibration) calibrate_anchor_scores_and_identify_bonds();
+        skip_calibration = true;
+        for (auto* leaf : main_execution.leaf_subproblems()) seams_of_leaf(*leaf);
     }
 
     void run() {
@@ -153,6 +246,7 @@ struct DemoCore : public Core {
             }
             PathMerge<uint32_t, uint8_t> pm1(sp1.graph, sp1.tableau);
             PathMerge<uint32_t, uint8_t> pm2(sp2.graph, sp2.tableau);
+            if (seams) seams_of_merge(matches, sp1, sp2, pm1, pm2);
             next_problem.alignment = whole_align ? align_core_both(matches, sp1, sp2, pm1, pm2) : align_both(matches, sp1, sp2, pm1, pm2);
             BaseGraph fused = sp1.graph;
             fuse(fused, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment);
@@ -198,6 +292,8 @@ int main(int argc, char** argv) {
         centrolign_amd::Device dev(0);
         core.dev = &dev;
         core.whole_align = argc > 4 && std::string(argv[4]) == "core";
+        core.seams = argc > 4 && std::string(argv[4]) == "seams";
+        if (core.seams) core.leaves_first();
         core.run();
         if (core.whole_align)
         {

@@ -54,3 +54,27 @@ def test_reference_core_align_vs_gpu(tmp_path, seed, length, n, max_pairs):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DROP-IN OK" in p.stdout
     assert p.stdout.count("GPU Core::align == the reference") == (1 if n == 2 else 3)
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/adapter_demo not built (needs the reference sources)")
+@pytest.mark.parametrize("seed,length,n,max_pairs", [(26, 30000, 2, 50000), (27, 12000, 4, 30000)])
+def test_reference_signatures_at_the_seams(tmp_path, seed, length, n, max_pairs):
+    """include/centrolign_amd/seam_wrappers.hpp: the reference's own signatures — Anchorer::anchor_chain (with and without masked matches
+    and an overriding scale), po_poa<NumPW>, Stitcher::internal_stitch — called next to the reference's functions on the same objects"""
+    seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs)
+    nwk = "-"
+    if n == 4:
+        nwk = str(tmp_path / "tree.nwk")
+        with open(nwk, "w") as f:
+            f.write("((seq0,seq1),(seq2,seq3));")
+    p = subprocess.run([DEMO, fa, nwk, str(max_pairs), "seams"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    print(p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DROP-IN OK" in p.stdout and "!=" not in p.stdout
+    assert p.stdout.count("masked anchor_chain wrapper == the reference") == n
+    assert p.stdout.count("internal_stitch wrapper ==") == n
+    assert p.stdout.count("anchor_chain wrapper == the reference (") >= (1 if n == 2 else 3)
+    assert p.stdout.count("po_poa<1|2|3> wrapper == on") == (1 if n == 2 else 3)
