@@ -349,6 +349,36 @@ def write_gfa(graph, path_names, decode=True):
         _libc_free(p)
 
 
+def read_gfa(text, add_sentinels=True):
+    """read_gfa + add_sentinels(graph, 5, 6) (src/gfa.cpp:9-96, src/modify_graph.cpp:47-77), as a -R restart loads a subproblem file:
+    returns (BaseGraph, path names)"""
+    lib = load_library()
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    h, names, n = C.c_void_p(), C.POINTER(C.c_char_p)(), C.c_uint64(0)
+    lib.cl_read_gfa.restype = C.c_int
+    lib.cl_read_gfa.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_uint64)]
+    rc = lib.cl_read_gfa(raw, len(raw), int(add_sentinels), C.byref(h), C.byref(names), C.byref(n))
+    if rc != 0:
+        raise ClError(rc, "cl_read_gfa")
+    out = [names[i].decode() for i in range(int(n.value))]
+    for i in range(int(n.value)):
+        _libc_free(C.c_void_p(C.cast(names, C.POINTER(C.c_void_p))[i]))
+    _libc_free(C.cast(names, C.c_void_p))
+    return _take_owned_base_graph(lib, h), out
+
+
+def subproblem_hash_hex(sequence_names):
+    """Execution::subproblem_hash through to_hex (src/execution.cpp:190-203): the <hash> of PREFIX_<hash>.gfa under -S / -R"""
+    lib = load_library()
+    arr = (C.c_char_p * max(len(sequence_names), 1))(*[s.encode() for s in sequence_names])
+    buf = C.create_string_buffer(17)
+    lib.cl_subproblem_hash_hex.restype = C.c_int
+    rc = lib.cl_subproblem_hash_hex(arr, C.c_uint64(len(sequence_names)), buf)
+    if rc != 0:
+        raise ClError(rc, "cl_subproblem_hash_hex")
+    return buf.value.decode()
+
+
 def graphs_equal(a, b):
     return a.src_id == b.src_id and a.snk_id == b.snk_id and all(np.array_equal(getattr(a, k), getattr(b, k)) for k in GRAPH_KEYS)
 
@@ -1032,6 +1062,7 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_exhaustive", "cl_chain_result_free",
     "cl_parse_fasta", "cl_fasta_free", "cl_msa_plan_create", "cl_msa_plan_free", "cl_msa_params_default", "cl_msa",
+    "cl_read_gfa", "cl_subproblem_hash_hex",
     "cl_anchor_chain", "cl_anchor_chain_result_free", "cl_anchor_chain_masked", "cl_generate_diagonal_mask", "cl_update_mask", "cl_internal_stitch",
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",

@@ -166,4 +166,135 @@ int cl_write_gfa(const cl_base_graph* g, const char* const* path_names, int deco
     return *text_out ? CL_OK : CL_ERR_OUT_OF_MEMORY;
 }
 
+// read_gfa(in, encode = true) + add_sentinels(graph, 5, 6) (src/gfa.cpp:9-96, src/modify_graph.cpp:47-77): how Execution::restart loads a
+// subproblem written by -S (src/execution.cpp:240-251).  Node ids follow the S lines (a compacted node becomes a chain), adjacency lists the
+// order of insertion: chain edges as the S lines are read, L lines in file order, then per node the sink edge before the source edge.
+int cl_read_gfa(const char* text, uint64_t len, int add_sentinels, cl_owned_base_graph** out, char*** path_names_out, uint64_t* n_paths_out) {
+    if (!text || !out) return CL_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (path_names_out) *path_names_out = nullptr;
+    if (n_paths_out) *n_paths_out = 0;
+    std::vector<uint8_t> label;
+    std::vector<std::vector<uint32_t>> next, prev;
+    std::vector<std::pair<int64_t, int64_t>> span;   // GFA id -> (first node, last node)
+    std::vector<std::string> names;
+    std::vector<std::vector<uint32_t>> paths;
+    auto add_node = [&](uint8_t l) { label.push_back(l); next.emplace_back(); prev.emplace_back(); return (uint32_t)(label.size() - 1); };
+    auto add_edge = [&](uint32_t a, uint32_t b) { next[a].push_back(b); prev[b].push_back(a); };
+    auto tokens_of = [](const std::string& line, char delim) {
+        std::vector<std::string> t;
+        size_t at = 0;
+        while (true) {
+            const size_t e = line.find(delim, at);
+            if (e == std::string::npos) { t.push_back(line.substr(at)); break; }
+            t.push_back(line.substr(at, e - at));
+            at = e + 1;
+        }
+        return t;
+    };
+    auto parse_id = [](const std::string& s, int64_t& v) {
+        if (s.empty()) return false;
+        char* end = nullptr;
+        v = strtoll(s.c_str(), &end, 10);
+        return end && *end == '\0' && v >= 0;
+    };
+    uint64_t at = 0;
+    while (at < len) {
+        const char* nl = (const char*)memchr(text + at, '\n', len - at);
+        const uint64_t e = nl ? (uint64_t)(nl - text) : len;
+        const std::string line(text + at, text + e);
+        at = e + 1;
+        if (line.empty()) continue;
+        const std::vector<std::string> tk = tokens_of(line, '\t');
+        if (tk[0] == "S") {
+            int64_t id;
+            if (tk.size() != 3 || tk[2].empty() || !parse_id(tk[1], id)) return CL_ERR_INVALID_ARGUMENT;
+            while ((int64_t)span.size() <= id) span.emplace_back(-1, -1);
+            uint32_t node = add_node(encode_base(tk[2][0]));
+            span[id] = {node, node};
+            for (size_t i = 1; i < tk[2].size(); ++i) {
+                const uint32_t nx = add_node(encode_base(tk[2][i]));
+                span[id].second = nx;
+                add_edge(node, nx);
+                node = nx;
+            }
+        } else if (tk[0] == "L") {
+            if (tk.size() != 6 || (tk[5] != "*" && tk[5] != "0M") || tk[2] != tk[4]) return CL_ERR_INVALID_ARGUMENT;
+            int64_t a, b;
+            if (!parse_id(tk[1], a) || !parse_id(tk[3], b)) return CL_ERR_INVALID_ARGUMENT;
+            if (tk[2] == "-") std::swap(a, b);
+            if (a >= (int64_t)span.size() || b >= (int64_t)span.size() || span[a].first < 0 || span[b].first < 0) return CL_ERR_INVALID_ARGUMENT;
+            add_edge((uint32_t)span[a].second, (uint32_t)span[b].first);
+        } else if (tk[0] == "P") {
+            if (tk.size() != 4 || tk[3] != "*") return CL_ERR_INVALID_ARGUMENT;
+            names.push_back(tk[1]);
+            paths.emplace_back();
+            for (const std::string& step : tokens_of(tk[2], ',')) {
+                int64_t id;
+                if (step.empty() || step.back() != '+' || !parse_id(step.substr(0, step.size() - 1), id) || id >= (int64_t)span.size() || span[id].first < 0)
+                    return CL_ERR_INVALID_ARGUMENT;
+                uint32_t node = (uint32_t)span[id].first;
+                paths.back().push_back(node);
+                while (node != (uint32_t)span[id].second) { node = next[node].front(); paths.back().push_back(node); }
+            }
+        }
+    }
+    uint64_t src = 0, snk = 0;
+    if (add_sentinels) {
+        std::vector<char> begins(label.size(), 0), ends(label.size(), 0);
+        for (const auto& pth : paths) if (!pth.empty()) { begins[pth.front()] = 1; ends[pth.back()] = 1; }
+        const uint32_t n0 = (uint32_t)label.size();
+        src = add_node(5);
+        snk = add_node(6);
+        if (n0 == 0) add_edge((uint32_t)src, (uint32_t)snk);
+        else
+            for (uint32_t v = 0; v < n0; ++v) {
+                const bool no_next = next[v].empty(), no_prev = prev[v].empty();   // (as they were before this node's own sentinel edges)
+                if (no_next || ends[v]) add_edge(v, (uint32_t)snk);
+                if (no_prev || begins[v]) add_edge((uint32_t)src, v);
+            }
+    }
+    std::unique_ptr<cl_owned_base_graph> g(new cl_owned_base_graph());
+    g->label = label;
+    g->next_off.assign(1, 0);
+    g->prev_off.assign(1, 0);
+    for (size_t v = 0; v < label.size(); ++v) {
+        g->next_idx.insert(g->next_idx.end(), next[v].begin(), next[v].end());
+        g->next_off.push_back(g->next_idx.size());
+        g->prev_idx.insert(g->prev_idx.end(), prev[v].begin(), prev[v].end());
+        g->prev_off.push_back(g->prev_idx.size());
+    }
+    g->path_off.assign(1, 0);
+    for (const auto& pth : paths) { g->path_nodes.insert(g->path_nodes.end(), pth.begin(), pth.end()); g->path_off.push_back(g->path_nodes.size()); }
+    g->src_id = src;
+    g->snk_id = snk;
+    if (path_names_out) {
+        char** arr = (char**)calloc(names.size() ? names.size() : 1, sizeof(char*));
+        if (!arr) return CL_ERR_OUT_OF_MEMORY;
+        for (size_t i = 0; i < names.size(); ++i) arr[i] = to_c_string(names[i], nullptr);
+        *path_names_out = arr;
+    }
+    if (n_paths_out) *n_paths_out = names.size();
+    *out = g.release();
+    return CL_OK;
+}
+
+// Execution::subproblem_hash (src/execution.cpp:190-203) as to_hex prints it (include/centrolign/utility.hpp:310-328): the name of a
+// subproblem's file under -S / -R is PREFIX + "_" + this + ".gfa" (src/core.cpp:378-380).  hex_out: 17 bytes.
+int cl_subproblem_hash_hex(const char* const* sequence_names, uint64_t n, char* hex_out) {
+    if ((n && !sequence_names) || !hex_out) return CL_ERR_INVALID_ARGUMENT;
+    std::vector<std::string> names(sequence_names, sequence_names + n);
+    std::sort(names.begin(), names.end());
+    auto combine = [](uint64_t& seed, uint64_t v) { seed ^= v + 0x9e3779b9ull + (seed << 6) + (seed >> 2); };   // hash_combine with libstdc++'s identity std::hash
+    uint64_t h = 660422875706093811ull;
+    for (const std::string& nm : names) {
+        combine(h, 2110260111091729000ull);
+        for (char c : nm) combine(h, (uint64_t)(size_t)c);
+    }
+    static const char digits[] = "0123456789ABCDEF";
+    for (int i = 0; i < 16; ++i) hex_out[i] = digits[(h >> (60 - 4 * i)) & 0xF];
+    hex_out[16] = '\0';
+    return CL_OK;
+}
+
 }  // extern "C"

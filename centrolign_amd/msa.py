@@ -21,8 +21,37 @@ def leaves_of(tree):
     return [tree] if isinstance(tree, str) else leaves_of(tree[0]) + leaves_of(tree[1])
 
 
+def tree_of_plan(newick_text, names):
+    """the guide tree as the nested tuple the drivers here take, in the reference's orientation: Tree(newick) with Execution's pruning,
+    binarisation and child order (capi.msa_plan): every merge is (graph 1, graph 2) as Execution::next hands them out"""
+    leaves, merges = capi.msa_plan(newick_text, list(names))
+    slots = [names[i] for i in leaves]
+    for a, b in merges:
+        slots.append((slots[a], slots[b]))
+    return slots[-1]
+
+
+def subproblem_file_name(prefix, names):
+    """Core::subproblem_file_name (src/core.cpp:378-380): PREFIX_<hash of the sorted leaf names>.gfa"""
+    return "%s_%s.gfa" % (prefix, capi.subproblem_hash_hex(list(names)))
+
+
+def emit_subproblem(prefix, graph, paths):
+    """Core::emit_subproblem (src/core.cpp:397-422): the subproblem's GFA under its hashed name, one line in PREFIX_info.txt"""
+    import os
+    name = subproblem_file_name(prefix, paths)
+    info = prefix + "_info.txt"
+    header = not os.path.exists(info)
+    with open(info, "a") as f:
+        if header:
+            f.write("filename\tsequences\n")
+        f.write("%s\t%s\n" % (name, ",".join(sorted(paths))))
+    with open(name, "wb") as f:
+        f.write(capi.write_gfa(graph, paths))
+
+
 def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None, verbose=False,
-                    keep_merges=False):
+                    keep_merges=False, subproblems_prefix=None, restart=False):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
@@ -70,6 +99,34 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
             if not isinstance(t, str):
                 collect(t[0]); collect(t[1]); pending.append(t)
         collect(tree)
+        if restart and subproblems_prefix:
+            # Execution::restart (src/execution.cpp:222-277): top-down, the first finished subproblem on every branch is loaded from its
+            # file — read_gfa + add_sentinels, i.e. NOT the node numbering the interrupted run had in memory — and everything below it
+            # is skipped
+            import os
+
+            def load(t):
+                if isinstance(t, str):
+                    return
+                name = subproblem_file_name(subproblems_prefix, leaves_of(t))
+                if os.path.exists(name):
+                    with open(name, "rb") as f:
+                        done[newick(t)] = capi.read_gfa(f.read())
+                    stats["restarted"] = stats.get("restarted", 0) + 1
+                else:
+                    load(t[0]); load(t[1])
+            load(tree)
+
+            def below_loaded(t, under=False):
+                out = set()
+                if not isinstance(t, str):
+                    here = under or newick(t) in done
+                    if under or newick(t) in done:
+                        out.add(newick(t))
+                    out |= below_loaded(t[0], here) | below_loaded(t[1], here)
+                return out
+            skip = below_loaded(tree)
+            pending = [t for t in pending if newick(t) not in skip]
         while pending:
             ready = [t for t in pending if newick(t[0]) in done and newick(t[1]) in done]
             pending = [t for t in pending if not (newick(t[0]) in done and newick(t[1]) in done)]
@@ -93,6 +150,8 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
                     import sys
                     print("merge %s: %s" % (newick(t), stats["per_merge"][-1]), file=sys.stderr, flush=True)
                 done[newick(t)] = (r["fused"], paths)
+                if subproblems_prefix:
+                    emit_subproblem(subproblems_prefix, r["fused"], paths)
                 last["alignment"], last["graphs"] = r["alignment"], (g1, g2)
             stats["timeline_s"].append(("wave of %d merge(s) done" % len(ready), _time.perf_counter() - _t0))
         root, paths = done[newick(tree)]

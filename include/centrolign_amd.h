@@ -530,6 +530,14 @@ int cl_leaf_graph(const char* sequence, uint64_t n, cl_owned_base_graph** out);
 int cl_explicit_cigar(const cl_base_graph* graph1, const cl_base_graph* graph2, const uint64_t* pairs, uint64_t n_pairs, char** text_out,
                       uint64_t* len_out /* may be NULL */);
 int cl_write_gfa(const cl_base_graph* graph, const char* const* path_names, int decode, char** text_out, uint64_t* len_out /* may be NULL */);
+/* -S / -R (src/core.cpp:370-422, src/execution.cpp:222-277): a finished subproblem is written as PREFIX_<hash>.gfa with cl_write_gfa, a
+ * restart loads it back with read_gfa(in) + add_sentinels(graph, 5, 6) — NOT the graph that was written: node ids follow the S lines and the
+ * sentinels come last, and the run continues on that graph.  cl_read_gfa builds exactly that graph (add_sentinels = 0: read_gfa alone);
+ * *path_names_out is a malloc'ed array of malloc'ed strings.  cl_subproblem_hash_hex: Execution::subproblem_hash of the subproblem's leaf
+ * names, printed as to_hex does (16 upper-case digits + NUL). */
+int cl_read_gfa(const char* text, uint64_t len, int add_sentinels, cl_owned_base_graph** out, char*** path_names_out /* may be NULL */,
+                uint64_t* n_paths_out /* may be NULL */);
+int cl_subproblem_hash_hex(const char* const* sequence_names, uint64_t n, char* hex_out /* [17] */);
 
 /* Calibration (Core::calibrate_anchor_scores_and_identify_bonds without cyclisation, src/core.cpp:98-191).
  * cl_estimate_score_scale: Anchorer::estimate_score_scale (include/centrolign/anchorer.hpp:998-1047): the sparse anchor chain,

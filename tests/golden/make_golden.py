@@ -317,6 +317,8 @@ def plan_goldens():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "restart":
+        return restart_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "cyclize":
         return cyclize_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "plans":
@@ -577,6 +579,49 @@ def cyclize_goldens():
             out[name + "." + f] = v
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "cyclize_rounds.npz"), **out)
+
+
+def restart_goldens():
+    # 17. -S / -R of the CLI (src/core.cpp:370-422,1071-1081; src/execution.cpp:222-277) with the compiled reference (oracle/_ref/ref_cli):
+    #     a 5-sequence MSA with every finished subproblem written out; then the root's and one inner subproblem's files are removed and
+    #     the run restarted — the restarted run continues on read_gfa + add_sentinels graphs, so its output is pinned separately
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    cli = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "ref_cli")
+    seqs = synth.hor_sequences(8, 5000, 5)
+    names = ["seq%d" % i for i in range(5)]
+    newick = "(((seq0,seq1),seq2),(seq3,seq4));"
+    budget = 8000
+    tmp = tempfile.mkdtemp()
+    try:
+        fa, nwk = os.path.join(tmp, "in.fa"), os.path.join(tmp, "tree.nwk")
+        synth.write_fasta(fa, seqs)
+        with open(nwk, "w") as f:
+            f.write(newick)
+        prefix = os.path.join(tmp, "sub")
+        subprocess.run([cli, fa, nwk, prefix, os.path.join(tmp, "full.gfa"), str(budget), "0"], check=True)
+        files = sorted(glob.glob(prefix + "_*.gfa"))
+        out = {"newick": np.array([newick]), "budget": np.array([budget]), "names": np.array(names),
+               "fasta": np.frombuffer(open(fa, "rb").read(), np.uint8), "full": np.frombuffer(open(os.path.join(tmp, "full.gfa"), "rb").read(), np.uint8),
+               "info": np.frombuffer(open(prefix + "_info.txt", "rb").read().replace(tmp.encode() + b"/", b""), np.uint8),
+               "files": np.array([os.path.basename(f) for f in files])}
+        for f in files:
+            out["file." + os.path.basename(f)] = np.frombuffer(open(f, "rb").read(), np.uint8)
+        # which file is which: the root's lists all five names in the info file; drop it and the ((seq0,seq1),seq2) one
+        info = open(prefix + "_info.txt").read().splitlines()[1:]
+        by_names = {line.split("\t")[1]: line.split("\t")[0] for line in info}
+        removed = [by_names["seq0,seq1,seq2,seq3,seq4"], by_names["seq0,seq1,seq2"]]
+        for f in removed:
+            os.remove(f)
+        out["removed"] = np.array([os.path.basename(f) for f in removed])
+        subprocess.run([cli, fa, nwk, prefix, os.path.join(tmp, "restart.gfa"), str(budget), "0", "1"], check=True)
+        out["restart"] = np.frombuffer(open(os.path.join(tmp, "restart.gfa"), "rb").read(), np.uint8)
+        print("full == restart:", out["full"].tobytes() == out["restart"].tobytes(), "files", [os.path.basename(f) for f in files])
+        np.savez_compressed(os.path.join(HERE, "restart_case.npz"), **out)
+    finally:
+        shutil.rmtree(tmp)
 
 
 if __name__ == "__main__":
