@@ -489,7 +489,8 @@ class MatchParams(C.Structure):
 class MatchStats(C.Structure):
     """cl_match_stats"""
     _fields_ = [("text_length", C.c_uint64), ("doubling_rounds", C.c_uint32), ("n_internal_nodes", C.c_uint64), ("n_candidates", C.c_uint64),
-                ("sa_ms", C.c_float), ("lcp_ms", C.c_float), ("tree_ms", C.c_double), ("query_ms", C.c_double), ("walk_ms", C.c_double)]
+                ("sa_ms", C.c_float), ("lcp_ms", C.c_float), ("tree_ms", C.c_double), ("query_ms", C.c_double), ("walk_ms", C.c_double),
+                ("text_ms", C.c_double), ("suffix_wall_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -130,7 +131,11 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
     before[0][0] = before[1][0] = 0;
     leaf_parent[0] = stack[0];
     visit_leaf(0);
+    // the pass is a chain of cache misses — id[sa[i]], then prev_occ[...][that id] — on addresses known far ahead: fetch them early
+    constexpr uint32_t kAheadId = 48, kAheadOcc = 24;
     for (uint32_t i = 1; i < n; ++i) {
+        if (i + kAheadId < n) __builtin_prefetch(&T.id[sa[i + kAheadId]]);
+        if (i + kAheadOcc < n) { const uint32_t pa = sa[i + kAheadOcc]; __builtin_prefetch(&prev_occ[T.comp(pa)][T.id[pa]], 1); }
         uint32_t last = kNone, left = i - 1;
         bool fresh = true;
         while (nodes[stack.back()].depth > lcp[i]) {
@@ -162,37 +167,38 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
     // subtree totals of the duplicates (src/esa.cpp:235-300), then distinct start nodes = leaves - duplicates
     std::vector<uint32_t>& dup0 = own_dup[0];
     std::vector<uint32_t>& dup1 = own_dup[1];
-    for (uint32_t v : closed)
+    for (size_t k = 0; k < closed.size(); ++k) {
+        if (k + 32 < closed.size()) __builtin_prefetch(&nodes[closed[k + 32]]);
+        if (k + 16 < closed.size()) {
+            const uint32_t pa = nodes[closed[k + 16]].parent;
+            if (pa != kNone) { __builtin_prefetch(&dup0[pa], 1); __builtin_prefetch(&dup1[pa], 1); }
+        }
+        const uint32_t v = closed[k];
         if (nodes[v].parent != kNone) { dup0[nodes[v].parent] += dup0[v]; dup1[nodes[v].parent] += dup1[v]; }
+    }
     auto distinct = [&](uint32_t v, int c) -> uint64_t {
         return (uint64_t)(before[c][nodes[v].r + 1] - before[c][nodes[v].l]) - (c ? dup1[v] : dup0[v]);
     };
     if (st) { st->n_internal_nodes = nodes.size(); st->tree_ms = ms_since(t0); }
 
-    // ---- the query (esa.hpp:290-431), children grouped under their parents in closing order
+    // ---- the query (esa.hpp:290-431): every (parent, child) pair is independent.  The reference meets the children grouped under their
+    //      parents, parents in closing order, children in closing order: evaluate them all side by side in closing order of the child and
+    //      sort the few that pass by (closing rank of the parent, closing rank of the child)
     t0 = clk::now();
     const uint32_t n_nodes = (uint32_t)nodes.size();
-    std::vector<uint32_t> closed_rank(n_nodes);
-    for (uint32_t k = 0; k < n_nodes; ++k) closed_rank[closed[k]] = k;
-    std::vector<uint32_t> child_off(n_nodes + 1, 0);   // indexed by the parent's closing rank
-    for (uint32_t v : closed)
-        if (nodes[v].parent != kNone) ++child_off[closed_rank[nodes[v].parent] + 1];
-    for (uint32_t k = 0; k < n_nodes; ++k) child_off[k + 1] += child_off[k];
-    std::vector<uint32_t> child(child_off[n_nodes]);
-    {
-        std::vector<uint32_t> fill(child_off.begin(), child_off.end() - 1);
-        for (uint32_t v : closed)
-            if (nodes[v].parent != kNone) child[fill[closed_rank[nodes[v].parent]]++] = v;
+    std::vector<uint32_t> close_rank(n_nodes);
+    for (uint32_t k = 0; k < n_nodes; ++k) {
+        if (k + 32 < n_nodes) __builtin_prefetch(&close_rank[closed[k + 32]], 1);
+        close_rank[closed[k]] = k;
     }
-    // every (parent, child) is independent: evaluate in parallel into a flag + record, then compact in order
-    std::vector<Found> found(child.size());
-    std::vector<uint8_t> keep(child.size(), 0);
-    std::vector<uint32_t> child_parent_rank(child.size());
-    for (uint32_t k = 0; k < n_nodes; ++k)
-        for (uint32_t e = child_off[k]; e < child_off[k + 1]; ++e) child_parent_rank[e] = k;
-    cl_parallel_for(child.size(), [&](uint64_t b, uint64_t e) {
+    struct Kept { uint64_t key; Found f; };
+    std::vector<std::vector<Kept>> kept_parts;
+    std::mutex kept_mutex;
+    cl_parallel_for(n_nodes, [&](uint64_t b, uint64_t e) {
+        std::vector<Kept> mine;
         for (uint64_t x = b; x < e; ++x) {
-            const uint32_t C = child[x], P = closed[child_parent_rank[x]];
+            const uint32_t C = closed[x], P = nodes[C].parent;
+            if (P == kNone) continue;
             const uint64_t c0 = distinct(C, 0);
             if (c0 == 0) continue;                   // esa.hpp:391-393: counts stay 0, total 0
             const uint64_t c1 = distinct(C, 1);
@@ -210,14 +216,17 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
                 if (!(c0 < distinct(L, 0) || c1 < distinct(L, 1))) continue;            // link_more_frequent (:396)
             }
             if (!(clhost::anchor_weight(prm.score, c0, c1, (uint64_t)d + 1, (uint64_t)d + 1) > 0.0)) continue;   // match_finder.hpp:162
-            found[x] = Found{C, d + 1, {c0, c1}};
-            keep[x] = 1;
+            mine.push_back(Kept{((uint64_t)close_rank[P] << 32) | x, Found{C, d + 1, {c0, c1}}});
         }
+        std::lock_guard<std::mutex> lock(kept_mutex);
+        kept_parts.push_back(std::move(mine));
     }, 4096);
-    std::vector<Found> matches;
-    for (size_t x = 0; x < child.size(); ++x)
-        if (keep[x]) matches.push_back(found[x]);
-    if (st) { st->n_candidates = child.size(); st->query_ms = ms_since(t0); }
+    std::vector<Kept> kept;
+    for (auto& part : kept_parts) kept.insert(kept.end(), part.begin(), part.end());
+    std::sort(kept.begin(), kept.end(), [](const Kept& x, const Kept& y) { return x.key < y.key; });
+    std::vector<Found> matches(kept.size());
+    for (size_t i = 0; i < kept.size(); ++i) matches[i] = kept[i].f;
+    if (st) { st->n_candidates = n_nodes ? n_nodes - 1 : 0; st->query_ms = ms_since(t0); }
 
     // ---- walk the matches out (esa.hpp:610-665, match_finder.hpp:186-205)
     t0 = clk::now();
@@ -300,16 +309,21 @@ int cl_find_matches(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     if (!ctx || !g1 || !g2 || !prm || !out) return CL_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (stats) *stats = cl_match_stats{};
+    auto t0 = clk::now();
     JoinedText T;
     int rc = T.build(*g1, *g2);
     if (rc) { cl_set_error(ctx, "cl_find_matches: malformed graph (path node or sentinel id out of range, or joined text >= 2^31)"); return rc; }
     const uint32_t n = (uint32_t)T.text.size();
+    const double text_ms = ms_since(t0);
+    t0 = clk::now();
     std::vector<uint32_t> sa(n), lcp(n), isa(n);
     ClSuffixStats ss;
     if ((rc = cl_match_suffix_array(ctx, T.text.data(), n, sa.data(), lcp.data(), isa.data(), &ss))) return rc;
+    const double suffix_wall_ms = ms_since(t0);
     if (stats) { stats->text_length = n; stats->doubling_rounds = ss.rounds; stats->sa_ms = ss.sort_ms; stats->lcp_ms = ss.lcp_ms; }
     std::unique_ptr<cl_owned_match_sets> o(new cl_owned_match_sets());
     if ((rc = matches_from_esa(*g1, *g2, *prm, T, sa.data(), lcp.data(), isa.data(), *o, stats))) return rc;
+    if (stats) { stats->text_ms = text_ms; stats->suffix_wall_ms = suffix_wall_ms; }
     *out = o.release();
     return CL_OK;
 }

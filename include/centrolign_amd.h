@@ -402,6 +402,7 @@ typedef struct cl_match_stats {
     uint64_t n_candidates;       /* (parent, internal child) pairs examined */
     float    sa_ms, lcp_ms;      /* device time */
     double   tree_ms, query_ms, walk_ms;   /* host passes */
+    double   text_ms, suffix_wall_ms;      /* joining the path text; the device half as the host sees it (transfers included) */
 } cl_match_stats;
 int cl_find_matches(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_params* params,
                     cl_owned_match_sets** out, cl_match_stats* stats /* may be NULL */);
