@@ -589,6 +589,52 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         rec_combo.resize(R);
         rec_pos.resize(R);
         std::vector<uint32_t> combo_size;
+        const size_t n_tags = combo_of.size();
+        static const uint64_t par_min = [] { const char* e = getenv("CL_CHAIN_PAR_RECORDS_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)(1u << 20); }();   // (0 in tests: every size)
+        if (R >= par_min && R > 0 && n_tags <= 4096) {
+            // the same numbering in parallel: chunks of records count their tags, a combination's id is the order of first appearance of
+            // its tag (smallest first record), a record's position the records of its combination in earlier chunks plus those before
+            // it in its own
+            const uint64_t n_chunks = std::min<uint64_t>(64, (R + (1u << 18) - 1) >> 18), chunk = (R + n_chunks - 1) / n_chunks;
+            std::vector<std::vector<uint32_t>> hist(n_chunks, std::vector<uint32_t>(n_tags, 0));
+            std::vector<std::vector<uint64_t>> first(n_chunks, std::vector<uint64_t>(n_tags, UINT64_MAX));
+            cl_parallel_for(n_chunks, [&](uint64_t cb, uint64_t ce) {
+                for (uint64_t c = cb; c < ce; ++c)
+                    for (uint64_t r = c * chunk; r < std::min<uint64_t>(R, (c + 1) * chunk); ++r) {
+                        const uint32_t t = r_tag[r];
+                        if (hist[c][t]++ == 0) first[c][t] = r;
+                    }
+            }, 1);
+            std::vector<std::pair<uint64_t, uint32_t>> order;   // (first record, tag)
+            for (uint32_t t = 0; t < n_tags; ++t) {
+                uint64_t f = UINT64_MAX;
+                for (uint64_t c = 0; c < n_chunks; ++c) f = std::min(f, first[c][t]);
+                if (f != UINT64_MAX) order.emplace_back(f, t);
+            }
+            std::sort(order.begin(), order.end());
+            for (const auto& o : order) {
+                combo_of[o.second] = (uint32_t)combos.size();
+                combos.emplace_back();
+                combos.back().p1 = o.second / n_tag[1];
+                combos.back().p2 = o.second % n_tag[1];
+                combo_size.push_back(0);
+            }
+            std::vector<std::vector<uint32_t>> base(n_chunks, std::vector<uint32_t>(n_tags, 0));
+            for (uint32_t t = 0; t < n_tags; ++t) {
+                uint32_t run = 0;
+                for (uint64_t c = 0; c < n_chunks; ++c) { base[c][t] = run; run += hist[c][t]; }
+                if (combo_of[t] != kNone) combo_size[combo_of[t]] = run;
+            }
+            cl_parallel_for(n_chunks, [&](uint64_t cb, uint64_t ce) {
+                for (uint64_t c = cb; c < ce; ++c) {
+                    std::vector<uint32_t>& next = base[c];
+                    for (uint64_t r = c * chunk; r < std::min<uint64_t>(R, (c + 1) * chunk); ++r) {
+                        rec_combo[r] = combo_of[r_tag[r]];
+                        rec_pos[r] = next[r_tag[r]]++;
+                    }
+                }
+            }, 1);
+        } else
         for (uint64_t r = 0; r < R; ++r) {
             uint32_t& ci = combo_of[r_tag[r]];
             if (ci == kNone) {
@@ -633,11 +679,13 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     tm.n_combos = (uint32_t)combos.size();
     for (const Combo& c : combos) tm.pair_evals += 0.5 * (double)c.rec_s.size() * (double)M;
     const uint32_t n_blocks = (uint32_t)((M + kChainBlock - 1) / kChainBlock);
-    for (Combo& c : combos) {
-        c.qt.assign(M, kNone);
-        c.qoff.assign(M, 0);
-        c.q.assign(M, 0);
-    }
+    cl_parallel_for(combos.size(), [&](uint64_t c_begin, uint64_t c_end) {   // 15 MB per combination at 1.25 M pairs, 25 combinations at the root
+        for (uint64_t ci = c_begin; ci < c_end; ++ci) {
+            combos[ci].qt.assign(M, kNone);
+            combos[ci].qoff.assign(M, 0);
+            combos[ci].q.assign(M, 0);
+        }
+    }, 1);
     cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
     for (uint32_t s = (uint32_t)s_begin; s < s_end; ++s) {
         const Pair& p = pairs[by_s[s]];
