@@ -47,10 +47,8 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
     // the two PathMerge tables, built side by side and shared by every stage below (cl_internal.hpp: cl_shared_table)
     clhost::PathMergeTable x1, x2;
     {
-        bool ok2 = false;
-        std::thread other([&] { ok2 = x2.build(*g2); });
-        const bool ok1 = x1.build(*g1);
-        other.join();
+        bool ok1 = false, ok2 = false;
+        cl_pool_run(2, [&](unsigned t) { if (t) ok2 = x2.build(*g2); else ok1 = x1.build(*g1); });
         if (!ok1 || !ok2) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
     }
     struct Registered {

@@ -20,6 +20,11 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <thread>
 #include <chrono>
 #include <vector>
 
@@ -577,6 +582,94 @@ void plan_free(cl_stitch_plan* pl) {
 
 }  // namespace
 
+// ---- the process's host thread pool (cl_parallel_for, cl_internal.hpp) ---------------------------------------------------------------
+namespace {
+struct HostPool {
+    struct Batch {
+        const std::function<void(unsigned)>* task;
+        unsigned n_tasks;
+        std::atomic<unsigned> next{1};       // task 0 belongs to the caller
+        std::atomic<unsigned> done{0};
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Batch>> open;   // batches that still have unclaimed tasks
+    std::vector<std::thread> threads;
+    unsigned width = 1;
+    bool stop = false;
+    static thread_local bool is_worker;
+
+    HostPool() {
+        const char* e = getenv("CL_HOST_THREADS");
+        const int v = e ? atoi(e) : 0;
+        const unsigned hw = std::thread::hardware_concurrency();
+        width = v > 0 ? (unsigned)v : std::min(hw ? hw : 1u, 32u);
+        // more threads than one loop uses: several contexts (MSA workers) run loops at the same time
+        const unsigned n_threads = width <= 1 ? 0 : std::min(hw ? hw : 1u, 4 * width) - 1;
+        for (unsigned i = 0; i < n_threads; ++i) threads.emplace_back([this] { work(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lock(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    static void run_one(Batch& b, unsigned t) {
+        (*b.task)(t);
+        if (b.done.fetch_add(1) + 1 == b.n_tasks) { std::lock_guard<std::mutex> lock(b.m); b.cv.notify_all(); }
+    }
+    void work() {
+        is_worker = true;
+        while (true) {
+            std::shared_ptr<Batch> b;
+            unsigned t = 0;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return stop || !open.empty(); });
+                if (stop) return;
+                b = open.front();
+                t = b->next.fetch_add(1);
+                if (t + 1 >= b->n_tasks) open.pop_front();   // this was the last unclaimed task
+                if (t >= b->n_tasks) continue;
+            }
+            run_one(*b, t);
+        }
+    }
+    void run(unsigned n_tasks, const std::function<void(unsigned)>& task) {
+        if (n_tasks <= 1 || threads.empty() || is_worker) {   // (a loop inside a pool task runs in place)
+            for (unsigned t = 0; t < n_tasks; ++t) task(t);
+            return;
+        }
+        auto b = std::make_shared<Batch>();
+        b->task = &task;
+        b->n_tasks = n_tasks;
+        { std::lock_guard<std::mutex> lock(m); open.push_back(b); }
+        cv.notify_all();
+        run_one(*b, 0);
+        // help with this batch's remaining tasks instead of sleeping, then wait for the ones other threads took
+        while (true) {
+            unsigned t;
+            {
+                std::lock_guard<std::mutex> lock(m);
+                t = b->next.load();
+                if (t >= b->n_tasks) break;
+                t = b->next.fetch_add(1);
+                if (t + 1 >= b->n_tasks) { auto it = std::find(open.begin(), open.end(), b); if (it != open.end()) open.erase(it); }
+                if (t >= b->n_tasks) break;
+            }
+            run_one(*b, t);
+        }
+        std::unique_lock<std::mutex> lock(b->m);
+        b->cv.wait(lock, [&] { return b->done.load() == b->n_tasks; });
+    }
+};
+thread_local bool HostPool::is_worker = false;
+HostPool& host_pool() { static HostPool pool; return pool; }
+}  // namespace
+void cl_pool_run(unsigned n_tasks, const std::function<void(unsigned)>& task) { host_pool().run(n_tasks, task); }
+unsigned cl_pool_width() { return host_pool().width; }
+
 namespace {
 std::mutex g_live_mutex;
 std::vector<const cl_context*> g_live_contexts;
@@ -634,9 +727,16 @@ cl_context* cl_context_create(int device_ordinal) {
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; ok && i < kNumAuxStreams; ++i)
-        ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    // streams of their own: CL_CTX_STREAMS (default 6: what one chaining DP keeps busy — four far launches in flight, the sealing stream and
+    // a spare).  Every stream takes a share of the process's hardware queues (GPU_MAX_HW_QUEUES); streams that share a queue run their
+    // launches one after the other, whichever context they belong to, so contexts that work side by side should not hold idle streams
+    static const int n_own = [] { const char* e = getenv("CL_CTX_STREAMS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kNumAuxStreams ? v : 6; }();
+    ctx->n_aux = n_own;
+    for (int i = 0; ok && i < kNumAuxStreams; ++i) {
+        if (i < n_own) ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess;
+        else ctx->aux[i] = ctx->aux[i % n_own];
+        ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) {
         set_error(nullptr, "HIP context setup failed on device %d: %s", device_ordinal, hipGetErrorString(hipGetLastError()));
         cl_context_destroy(ctx);
@@ -658,7 +758,7 @@ void cl_context_destroy(cl_context* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < kNumAuxStreams; ++i) {
-        if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+        if (ctx->aux[i] && i < ctx->n_aux) (void)hipStreamDestroy(ctx->aux[i]);
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -910,10 +1010,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             Scratch S;
             for (uint64_t k = n * t / n_parts; k < n * (t + 1) / n_parts && !parts[t].rc; ++k) pack_one(k, parts[t], S);
         };
-        std::vector<std::thread> th;
-        for (uint64_t t = 1; t < n_parts; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
+        cl_pool_run((unsigned)n_parts, [&](unsigned t) { work(t); });
     }
     std::vector<uint8_t> lab[2];
     std::vector<uint32_t> poff[2], pidx[2], snk[2];
@@ -1105,7 +1202,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
     bool used[kNumAuxStreams] = {};
     for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
         const LaunchGroup& g = pl->groups[gi];
-        int si = (int)(gi % (size_t)g_plan_streams);
+        int si = (int)(gi % (size_t)std::min(g_plan_streams, ctx->n_aux));
         if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
         if (timed && g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
         if (g.kind == CL_KIND_LINEAR)

@@ -1001,7 +1001,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         std::vector<hipEvent_t> ev_walk(n_macro, nullptr), ev_seal(n_macro, nullptr);
         ev_far.assign(n_macro, nullptr);
         static_assert(kFarLag + 1 <= (uint32_t)kNumAuxStreams, "one auxiliary stream per far launch in flight plus the sealing stream");
-        hipStream_t seal_stream = ctx->aux[kFarLag];   // (fixed slot, whatever far_lag is)
+        hipStream_t seal_stream = ctx->aux[far_lag];   // right behind the far streams: the context's own streams are few (cl_context_create)
         if (use_far) {
             if (he == hipSuccess) he = hipStreamWaitEvent(seal_stream, ctx->ev_fork, 0);
             for (uint32_t f = far_streams; f < far_lag && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);

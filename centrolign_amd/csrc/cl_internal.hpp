@@ -19,7 +19,8 @@ constexpr int kNumAuxStreams = 12;
 struct cl_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux[kNumAuxStreams] = {};
+    hipStream_t aux[kNumAuxStreams] = {};   // the first n_aux are streams of their own, the rest aliases of them (aux[i] = aux[i % n_aux])
+    int n_aux = kNumAuxStreams;
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[kNumAuxStreams] = {};
     std::string error;
@@ -85,7 +86,7 @@ inline void cl_dev_free(cl_context* ctx, void* p) {
     if (no_pool || !ctx || !cl_context_live(ctx)) { (void)hipFree(p); return; }   // (a plan may outlive the context it was made on)
     // the block may be handed out again at once: wait for THIS context's streams (hipFree used to wait for the whole device)
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < kNumAuxStreams; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
+    for (int i = 0; i < ctx->n_aux; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     auto it = ctx->pool_size.find(p);
     if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
@@ -184,20 +185,21 @@ inline const clhost::PathMergeTable* cl_shared_table(const cl_base_graph* g) {
     return nullptr;
 }
 
-// host-side parallel loop over [0, n): f(begin, end) on up to 16 threads (the reference is single-threaded; the host glue
-// around the device passes is not part of the compared arithmetic, every iteration writes its own outputs)
+// host-side parallel loop over [0, n): f(begin, end) on up to 32 threads (the reference is single-threaded; the host glue around the device
+// passes is not part of the compared arithmetic, every iteration writes its own outputs).  The threads come from ONE pool per process
+// (cl_api.cpp), made on first use: creating and destroying threads per loop costs an mmap / munmap of every stack, and those take the
+// process's address-space lock in write mode — with four MSA workers doing it dozens of times per merge, every page fault of every
+// other worker waited (a leaf merge took 2.5 s next to three others, 1.1 s alone).
+#include <functional>
 #include <thread>
+void cl_pool_run(unsigned n_tasks, const std::function<void(unsigned)>& task);   // task(0 .. n_tasks-1), task 0 on the caller; returns when all are done
+unsigned cl_pool_width();                                                       // threads a loop may use (CL_HOST_THREADS, default min(cores, 32))
 template <class F>
 inline void cl_parallel_for(uint64_t n, F f, uint64_t grain = 32768) {
-    static const unsigned cap = [] { const char* e = getenv("CL_HOST_THREADS"); int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 32u; }();
-    unsigned hw = std::thread::hardware_concurrency();
-    uint64_t nt = std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, cap), (n + grain - 1) / grain);
+    uint64_t nt = std::min<uint64_t>(cl_pool_width(), (n + grain - 1) / grain);
     if (nt <= 1) { f((uint64_t)0, n); return; }
-    std::vector<std::thread> th;
     const uint64_t chunk = (n + nt - 1) / nt;
-    for (uint64_t t = 1; t < nt; ++t) th.emplace_back([=, &f] { f(std::min(n, t * chunk), std::min(n, (t + 1) * chunk)); });
-    f((uint64_t)0, std::min(n, chunk));
-    for (auto& x : th) x.join();
+    cl_pool_run((unsigned)nt, [&](unsigned t) { f(std::min(n, (uint64_t)t * chunk), std::min(n, ((uint64_t)t + 1) * chunk)); });
 }
 
 #endif

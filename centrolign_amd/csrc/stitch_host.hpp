@@ -22,6 +22,9 @@
 
 #include "../../include/centrolign_amd.h"
 
+#include <functional>
+void cl_pool_run(unsigned n_tasks, const std::function<void(unsigned)>& task);   // cl_api.cpp
+
 namespace clhost {
 
 // Kahn's algorithm with a LIFO stack seeded in ascending id order (topological_order.hpp:12-60)
@@ -229,10 +232,7 @@ inline int extract_stitch_batch(const cl_base_graph& g1, const cl_base_graph& g2
                 }
             };
             if (nt == 1) { work(0); return; }
-            std::vector<std::thread> th;
-            for (uint64_t t = 1; t < nt; ++t) th.emplace_back(work, t);
-            work(0);
-            for (auto& x : th) x.join();
+            cl_pool_run((unsigned)nt, [&](unsigned t) { work(t); });   // the process's thread pool (cl_internal.hpp)
             for (uint64_t t = 0; t < nt; ++t) {
                 out.only_del.insert(out.only_del.end(), part[t].only_del.begin(), part[t].only_del.end());
                 for (int sd = 0; sd < 2; ++sd) {
