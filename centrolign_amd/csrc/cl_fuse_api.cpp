@@ -12,6 +12,7 @@
 #include <memory>
 #include <algorithm>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -202,9 +203,19 @@ int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, 
     a.label = lab1.data();
     b.label = lab2.data();
     auto t0 = now();
+    // the chaining DPs bring their per-pair query results back through the context's page-locked area: up to 28 bytes per match pair and
+    // (chain of graph 1, chain of graph 2) combination — 0.9 GB at the root of a 10-sequence tree.  Locking that many pages takes ≈ 0.25 s
+    // the first time a context needs them: do it beside the match finding instead of in front of the first traceback
+    const uint64_t want_pinned = (uint64_t)prm->align.anchor.max_num_match_pairs * 28ull * std::max<uint64_t>(1, g1->n_paths) * std::max<uint64_t>(1, g2->n_paths);
+    std::thread pin;
+    if (want_pinned > ctx->pinned_bytes && want_pinned <= (8ull << 30)) {
+        const int device = ctx->device;
+        pin = std::thread([ctx, want_pinned, device] { (void)hipSetDevice(device); (void)cl_pinned(ctx, want_pinned); });
+    }
     cl_owned_match_sets* ms = nullptr;
     cl_match_stats mst;
     int rc = cl_find_matches(ctx, &a, &b, &prm->match, &ms, &mst);
+    if (pin.joinable()) pin.join();
     if (rc) return rc;
     out->match_ms = ms_since(t0);
     cl_match_sets view;
