@@ -379,6 +379,22 @@ def subproblem_hash_hex(sequence_names):
     return buf.value.decode()
 
 
+def internal_fuse(graph, pairs):
+    """internal_fuse (include/centrolign/fuse.hpp:144-247): the graph merged with itself along the alignment(s) (n, 2); host only.
+    Returns (fused BaseGraph — possibly cyclic, trans [old node -> new node])"""
+    lib = load_library()
+    g = graph.as_c()
+    pairs = np.ascontiguousarray(pairs, np.uint64).reshape(-1, 2)
+    h = C.c_void_p()
+    trans = np.zeros(len(graph.label), np.uint64)
+    lib.cl_internal_fuse.restype = C.c_int
+    lib.cl_internal_fuse.argtypes = [C.POINTER(BaseGraphC), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p]
+    rc = lib.cl_internal_fuse(C.byref(g), pairs.ctypes.data, len(pairs), C.byref(h), trans.ctypes.data)
+    if rc != 0:
+        raise ClError(rc, "cl_internal_fuse")
+    return _take_owned_base_graph(lib, h), trans
+
+
 def graphs_equal(a, b):
     return a.src_id == b.src_id and a.snk_id == b.snk_id and all(np.array_equal(getattr(a, k), getattr(b, k)) for k in GRAPH_KEYS)
 
@@ -1063,7 +1079,7 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_exhaustive", "cl_chain_result_free",
     "cl_parse_fasta", "cl_fasta_free", "cl_msa_plan_create", "cl_msa_plan_free", "cl_msa_params_default", "cl_msa",
-    "cl_read_gfa", "cl_subproblem_hash_hex",
+    "cl_read_gfa", "cl_subproblem_hash_hex", "cl_internal_fuse",
     "cl_anchor_chain", "cl_anchor_chain_result_free", "cl_anchor_chain_masked", "cl_generate_diagonal_mask", "cl_update_mask", "cl_internal_stitch",
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",

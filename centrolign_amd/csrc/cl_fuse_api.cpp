@@ -12,6 +12,7 @@
 #include <memory>
 #include <algorithm>
 #include <unordered_map>
+#include <unordered_set>
 #include <thread>
 #include <vector>
 
@@ -183,6 +184,81 @@ void cl_merge_result_free(cl_merge_result* r) {
     cl_core_align_result_free(&r->align);
     cl_owned_base_graph_free(r->fused);
     memset(r, 0, sizeof(*r));
+}
+
+// internal_fuse (include/centrolign/fuse.hpp:144-247): the nodes of ONE graph that the alignments pair up — transitively — become one node
+// per label; the graph that comes out may have cycles (Core::apply_bonds, src/core.cpp:631-636: the tandem duplications of a cyclised
+// alignment).  Node numbering: UnionFind groups in ascending order of their final head (union by rank as union_find.hpp:55-72 does it, the
+// pairs in the given order), inside a group one node per label in ascending label order; edges in the order a walk over the old nodes and
+// their next lists first meets them; paths translated node by node.
+int cl_internal_fuse(const cl_base_graph* g, const uint64_t* pairs, uint64_t n_pairs, cl_owned_base_graph** out, uint64_t* trans_out) {
+    if (!g || (n_pairs && !pairs) || !out) return CL_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    const uint64_t n = g->n_nodes, gap = ~(uint64_t)0;
+    if (n == 0 || g->src_id >= n || g->snk_id >= n) return CL_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < 2 * n_pairs; ++i) if (pairs[i] != gap && pairs[i] >= n) return CL_ERR_INVALID_ARGUMENT;
+    std::vector<uint64_t> head(n), rank(n, 0);
+    for (uint64_t v = 0; v < n; ++v) head[v] = v;
+    auto find = [&](uint64_t i) {   // union_find.hpp:42-53: the path is pointed at the root, except its last element
+        std::vector<uint64_t> path;
+        while (head[i] != i) { path.push_back(i); i = head[i]; }
+        for (size_t p = 1; p < path.size(); ++p) head[path[p - 1]] = i;
+        return i;
+    };
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        const uint64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        if (a == gap || b == gap) continue;
+        const uint64_t ha = find(a), hb = find(b);
+        if (ha == hb) continue;
+        if (rank[ha] > rank[hb]) head[hb] = ha;
+        else { head[ha] = hb; if (rank[hb] == rank[ha]) ++rank[hb]; }
+    }
+    std::vector<std::vector<uint64_t>> groups(n);
+    for (uint64_t v = 0; v < n; ++v) groups[find(v)].push_back(v);
+    std::unique_ptr<cl_owned_base_graph> f(new cl_owned_base_graph());
+    std::vector<uint64_t> trans(n, gap);
+    for (uint64_t hd = 0; hd < n; ++hd) {
+        const auto& grp = groups[hd];
+        if (grp.empty()) continue;
+        // std::map<char, ...> (fuse.hpp:176): ascending (signed) label
+        std::vector<std::pair<int, uint64_t>> by_label;
+        for (uint64_t v : grp) by_label.emplace_back((int)(signed char)g->label[v], v);
+        std::stable_sort(by_label.begin(), by_label.end(), [](const std::pair<int, uint64_t>& x, const std::pair<int, uint64_t>& y) { return x.first < y.first; });
+        for (size_t i = 0; i < by_label.size(); ++i) {
+            if (i == 0 || by_label[i].first != by_label[i - 1].first) f->label.push_back((uint8_t)by_label[i].first);
+            trans[by_label[i].second] = f->label.size() - 1;
+        }
+    }
+    const uint64_t m = f->label.size();
+    std::vector<std::vector<uint32_t>> next(m), prev(m);
+    {
+        std::vector<std::unordered_set<uint64_t>> seen(m);
+        for (uint64_t v = 0; v < n; ++v) {
+            const uint64_t fv = trans[v];
+            for (uint64_t e = g->next_off[v]; e < g->next_off[v + 1]; ++e) {
+                const uint64_t fw = trans[g->next_idx[e]];
+                if (seen[fv].insert(fw).second) { next[fv].push_back((uint32_t)fw); prev[fw].push_back((uint32_t)fv); }
+            }
+        }
+    }
+    f->next_off.assign(1, 0);
+    f->prev_off.assign(1, 0);
+    for (uint64_t v = 0; v < m; ++v) {
+        f->next_idx.insert(f->next_idx.end(), next[v].begin(), next[v].end());
+        f->next_off.push_back(f->next_idx.size());
+        f->prev_idx.insert(f->prev_idx.end(), prev[v].begin(), prev[v].end());
+        f->prev_off.push_back(f->prev_idx.size());
+    }
+    f->path_off.assign(1, 0);
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        for (uint64_t i = g->path_off[p]; i < g->path_off[p + 1]; ++i) f->path_nodes.push_back((uint32_t)trans[g->path_nodes[i]]);
+        f->path_off.push_back(f->path_nodes.size());
+    }
+    f->src_id = trans[g->src_id];
+    f->snk_id = trans[g->snk_id];
+    if (trans_out) memcpy(trans_out, trans.data(), n * sizeof(uint64_t));
+    *out = f.release();
+    return CL_OK;
 }
 
 int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_merge_params* prm, cl_merge_result* out) {

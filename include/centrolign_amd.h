@@ -518,6 +518,11 @@ void cl_core_align_result_free(cl_core_align_result* r);
  * (core.hpp:388).  Host only. */
 typedef struct cl_owned_base_graph cl_owned_base_graph;
 int  cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64_t* pairs, uint64_t n_pairs, cl_owned_base_graph** out);
+/* internal_fuse(graph, alignments, …) (include/centrolign/fuse.hpp:144-247), the merge Core::apply_bonds makes along the tandem-duplication
+ * alignments of a cyclised run (src/core.cpp:631-636): nodes of ONE graph paired by the alignments (pairs: the alignments concatenated,
+ * AlignedPair layout; node ids of `graph`) are merged transitively, one new node per label of a group.  The result may contain cycles.
+ * trans_out (may be NULL): [graph->n_nodes] old node -> new node, which also translates an alignment (fuse.hpp:229-243) and the sentinels. */
+int  cl_internal_fuse(const cl_base_graph* graph, const uint64_t* pairs, uint64_t n_pairs, cl_owned_base_graph** out, uint64_t* trans_out);
 void cl_owned_base_graph_view(const cl_owned_base_graph* graph, cl_base_graph* view_out);
 void cl_owned_base_graph_free(cl_owned_base_graph* graph);
 

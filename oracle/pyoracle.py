@@ -634,3 +634,22 @@ def ref_internal_stitch(g, walk_off, walk1, walk2, params=None):
     out = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 2,))[:2 * k].copy().reshape(k, 2)
     lib.ref_free(pp)
     return out
+
+
+def ref_internal_fuse(g, pairs):
+    """the compiled reference's internal_fuse (fuse.hpp:144-247) of one graph along one alignment: (fused BaseGraph, trans [old node -> new node])"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_internal_fuse.restype = C.c_int
+    lib.ref_internal_fuse.argtypes = [C.POINTER(BaseGraphC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c = g.as_c()
+    pairs = np.ascontiguousarray(pairs, np.uint64).reshape(-1, 2)
+    out = (C.c_void_p * 7)()
+    sizes = (C.c_uint64 * 4)()
+    ids = (C.c_uint64 * 2)()
+    trans = np.zeros(len(g.label), np.uint64)
+    rc = lib.ref_internal_fuse(C.byref(c), pairs.ctypes.data, len(pairs), out, sizes, ids, trans.ctypes.data)
+    if rc:
+        raise RuntimeError("ref_internal_fuse failed: %d" % rc)
+    return _graph_from_out(lib, out, sizes, int(ids[0]), int(ids[1])), trans

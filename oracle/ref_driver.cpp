@@ -904,6 +904,23 @@ int ref_fuse(const cl_base_graph* g1, const cl_base_graph* g2, const uint64_t* p
 
 /* Stitcher::despecify_indel_breakpoints (src/stitcher.cpp:265-310) on parallel arrays; same contract as
  * cl_despecify_indel_breakpoints */
+/* internal_fuse (fuse.hpp:144-247) of one graph along one alignment; trans_out[old node] = new node */
+int ref_internal_fuse(const cl_base_graph* g, const uint64_t* pairs, uint64_t n_pairs, void** out, uint64_t* sizes, uint64_t* ids_out, uint64_t* trans_out) {
+    SentinelTableau t, t_out;
+    BaseGraph b = build_base_graph(g, t);
+    std::vector<Alignment> alns(1);
+    for (uint64_t i = 0; i < n_pairs; ++i) alns[0].emplace_back(pairs[2 * i], pairs[2 * i + 1]);
+    // an identity "alignment" over all nodes reports the translation
+    Alignment ident, ident_out;
+    for (uint64_t v = 0; v < b.node_size(); ++v) ident.emplace_back(v, v);
+    BaseGraph fused = internal_fuse(b, alns, &t, &t_out, &ident, &ident_out);
+    for (uint64_t v = 0; v < b.node_size(); ++v) trans_out[v] = ident_out[v].node_id1;
+    flatten_graph(fused, out, sizes);
+    ids_out[0] = t_out.src_id;
+    ids_out[1] = t_out.snk_id;
+    return 0;
+}
+
 int ref_despecify(uint64_t n, const double* score, int64_t* gap_before, double* gap_score_before, int64_t* gap_after,
                   double* gap_score_after, int64_t min_len, double prop, uint8_t* keep_out, uint64_t* n_kept_out) {
     std::vector<anchor_t> anchors(n);

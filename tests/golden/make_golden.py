@@ -317,6 +317,8 @@ def plan_goldens():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ifuse":
+        return internal_fuse_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "restart":
         return restart_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "cyclize":
@@ -622,6 +624,41 @@ def restart_goldens():
         np.savez_compressed(os.path.join(HERE, "restart_case.npz"), **out)
     finally:
         shutil.rmtree(tmp)
+
+
+def internal_fuse_goldens():
+    # 18. internal_fuse (fuse.hpp:144-247; Core::apply_bonds, src/core.cpp:631-636): a graph merged with itself along an alignment — the
+    #     tandem-duplication alignments of the cyclisation goldens (leaf graphs, Stitcher::internal_stitch output) and random node pairs on
+    #     multi-path bubble graphs (transitive merges, groups with several labels, cycles)
+    z = np.load(os.path.join(HERE, "cyclize_rounds.npz"))
+    out = {}
+    names = []
+
+    def put(name, g, pairs):
+        fused, trans = po.ref_internal_fuse(g, pairs)
+        names.append(name)
+        out[name + ".pairs"] = np.asarray(pairs, np.uint64).reshape(-1, 2)
+        out[name + ".trans"] = trans
+        for k in capi.GRAPH_KEYS:
+            out[name + ".g." + k] = getattr(g, k)
+            out[name + ".f." + k] = getattr(fused, k)
+        out[name + ".g.ids"] = np.array([g.src_id, g.snk_id], np.uint64)
+        out[name + ".f.ids"] = np.array([fused.src_id, fused.snk_id], np.uint64)
+        print(name, len(g.label), "->", len(fused.label), "nodes")
+    for leaf in z["names"]:
+        seq = bytes(z[str(leaf) + ".seq"]).decode()
+        put(str(leaf), synth.base_graph_from_sequence(seq, (5, 6)), z[str(leaf) + ".stitch.pairs"])
+    rng = np.random.default_rng(12)
+    for k in range(6):
+        anc = "".join("ACGT"[b] for b in rng.integers(0, 4, int(rng.integers(30, 200))))
+        g = synth.bubble_graph(anc, int(rng.integers(1, 5)), seed=k)
+        n = len(g.label)
+        m = int(rng.integers(1, 3 * n))
+        pairs = np.stack([rng.integers(0, n, m), rng.integers(0, n, m)], 1).astype(np.uint64)
+        pairs[::5, int(k % 2)] = np.uint64(2 ** 64 - 1)   # gaps are skipped
+        put("random%d" % k, g, pairs)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "internal_fuse.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -109,3 +109,40 @@ def test_internal_stitch_matches_the_reference(gpu_ctx):
             one = gpu_ctx.internal_stitch(g, wo[:2], w1[:int(wo[1])], w2[:int(wo[1])])
             assert np.array_equal(one, np.stack([w1[:int(wo[1])], w2[:int(wo[1])]], 1).astype(np.uint64)), name
     assert len(gpu_ctx.internal_stitch(g, np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint32))) == 0
+
+
+def _graph(z, pre):
+    ids = z[pre + "ids"]
+    return capi.BaseGraph(*[z[pre + k] for k in capi.GRAPH_KEYS], int(ids[0]), int(ids[1]))
+
+
+def test_internal_fuse_matches_the_reference():
+    """host only: internal_fuse (fuse.hpp:144-247) — node numbering by union-find group and label, adjacency lists in first-met order,
+    translated paths and sentinels, and the old -> new translation — on the tandem-duplication alignments of the leaves and on random
+    pairs over multi-path graphs (transitive merges, mixed labels, cycles); live against the compiled reference where it is built"""
+    z = np.load(os.path.join(HERE, "golden", "internal_fuse.npz"))
+    for name in z["names"]:
+        g, want = _graph(z, "%s.g." % name), _graph(z, "%s.f." % name)
+        got, trans = capi.internal_fuse(g, z["%s.pairs" % name])
+        assert capi.graphs_equal(got, want), name
+        assert np.array_equal(trans, z["%s.trans" % name]), name
+        assert (got.src_id, got.snk_id) == (int(trans[g.src_id]), int(trans[g.snk_id]))
+        # merged nodes share their label; an alignment with nothing but gaps changes nothing but (possibly) the numbering
+        assert np.array_equal(got.label[trans.astype(np.int64)], g.label)
+    name = str(z["names"][0])
+    g = _graph(z, "%s.g." % name)
+    same, trans = capi.internal_fuse(g, np.zeros((0, 2), np.uint64))
+    assert len(same.label) == len(g.label) and np.array_equal(trans, np.arange(len(g.label), dtype=np.uint64)) and capi.graphs_equal(same, g)
+    try:
+        from oracle import pyoracle as po
+        po.ref_lib()
+    except Exception:
+        return
+    rng = np.random.default_rng(77)
+    for k in range(4):
+        g = synth.bubble_graph("".join("ACGT"[b] for b in rng.integers(0, 4, 120)), 3, seed=50 + k)
+        n = len(g.label)
+        pairs = np.stack([rng.integers(0, n, 2 * n), rng.integers(0, n, 2 * n)], 1).astype(np.uint64)
+        got, tg = capi.internal_fuse(g, pairs)
+        want, tw = po.ref_internal_fuse(g, pairs)
+        assert capi.graphs_equal(got, want) and np.array_equal(tg, tw), k
