@@ -395,6 +395,22 @@ def internal_fuse(graph, pairs):
     return _take_owned_base_graph(lib, h), trans
 
 
+def induced_pairwise_cigar(graph, path1, path2):
+    """explicit_cigar(induced_pairwise_alignment(graph, path1, path2), …) (src/alignment.cpp:84-229): the CLI's -A output for two of the
+    sequences of an acyclic MSA graph; bytes"""
+    lib = load_library()
+    g, p, n = graph.as_c(), C.c_void_p(), C.c_uint64(0)
+    lib.cl_induced_pairwise_cigar.restype = C.c_int
+    lib.cl_induced_pairwise_cigar.argtypes = [C.POINTER(BaseGraphC), C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    rc = lib.cl_induced_pairwise_cigar(C.byref(g), int(path1), int(path2), C.byref(p), C.byref(n))
+    if rc != 0:
+        raise ClError(rc, "cl_induced_pairwise_cigar")
+    try:
+        return C.string_at(p, int(n.value))
+    finally:
+        _libc_free(p)
+
+
 def graphs_equal(a, b):
     return a.src_id == b.src_id and a.snk_id == b.snk_id and all(np.array_equal(getattr(a, k), getattr(b, k)) for k in GRAPH_KEYS)
 
@@ -1079,7 +1095,7 @@ EXPORTED_SYMBOLS = [
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
     "cl_despecify_indel_breakpoints", "cl_chain_params_default", "cl_chain_sparse_affine", "cl_chain_sparse", "cl_chain_exhaustive", "cl_chain_result_free",
     "cl_parse_fasta", "cl_fasta_free", "cl_msa_plan_create", "cl_msa_plan_free", "cl_msa_params_default", "cl_msa",
-    "cl_read_gfa", "cl_subproblem_hash_hex", "cl_internal_fuse",
+    "cl_read_gfa", "cl_subproblem_hash_hex", "cl_internal_fuse", "cl_induced_pairwise_cigar",
     "cl_anchor_chain", "cl_anchor_chain_result_free", "cl_anchor_chain_masked", "cl_generate_diagonal_mask", "cl_update_mask", "cl_internal_stitch",
     "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",

@@ -297,4 +297,65 @@ int cl_subproblem_hash_hex(const char* const* sequence_names, uint64_t n, char* 
     return CL_OK;
 }
 
+// induced_pairwise_alignment(graph, path1, path2) (src/alignment.cpp:130-229) printed with explicit_cigar(alignment, seq1, seq2) (:84-123):
+// the -A output of the CLI for an acyclic graph (src/core.cpp:546-550) — the alignment of two input sequences that the MSA graph implies.
+// Positions on the two paths, not node ids; equal-length gap runs of at most 4 on both sides are read as mismatches, other mixed runs as
+// one deletion followed by one insertion.
+int cl_induced_pairwise_cigar(const cl_base_graph* g, uint64_t path1, uint64_t path2, char** text_out, uint64_t* len_out) {
+    if (!g || !text_out || path1 >= g->n_paths || path2 >= g->n_paths) return CL_ERR_INVALID_ARGUMENT;
+    const uint64_t gap = ~(uint64_t)0;
+    const uint32_t* p1 = g->path_nodes + g->path_off[path1];
+    const uint32_t* p2 = g->path_nodes + g->path_off[path2];
+    const uint64_t n1 = g->path_off[path1 + 1] - g->path_off[path1], n2 = g->path_off[path2 + 1] - g->path_off[path2];
+    std::vector<uint64_t> index_in_path1(g->n_nodes, gap);
+    for (uint64_t i = 0; i < n1; ++i) {
+        if (p1[i] >= g->n_nodes || index_in_path1[p1[i]] != gap) return CL_ERR_CYCLIC_GRAPH;   // "follows cycles in the graph" (:138-140)
+        index_in_path1[p1[i]] = i;
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> aln;
+    uint64_t j = 0;
+    for (uint64_t i = 0; i < n2; ++i) {
+        if (p2[i] >= g->n_nodes) return CL_ERR_INVALID_ARGUMENT;
+        const uint64_t at = index_in_path1[p2[i]];
+        if (at == gap) aln.emplace_back(gap, i);
+        else {
+            while (j < at) aln.emplace_back(j++, gap);
+            aln.emplace_back(j++, i);
+        }
+    }
+    while (j < n1) aln.emplace_back(j++, gap);
+    // consolidate the gap runs (:170-224)
+    const size_t max_mismatch_size = 4;
+    size_t removed = 0;
+    for (size_t i = 0; i < aln.size();) {
+        if (aln[i].first != gap && aln[i].second != gap) { aln[i - removed] = aln[i]; ++i; continue; }
+        size_t e = i, gaps1 = 0, gaps2 = 0;
+        while (e < aln.size() && (aln[e].first == gap || aln[e].second == gap)) { gaps1 += aln[e].first == gap; gaps2 += aln[e].second == gap; ++e; }
+        uint64_t last1 = gap, last2 = gap;   // -1: the run starts the alignment
+        if (i != 0) { last1 = aln[i - removed - 1].first; last2 = aln[i - removed - 1].second; }
+        if (gaps1 == gaps2 && gaps1 <= max_mismatch_size) {
+            for (uint64_t k = 0; k < gaps1; ++k) aln[i - removed + k] = {last1 + k + 1, last2 + k + 1};
+            removed += gaps1;
+        } else {
+            for (uint64_t k = 0; k < gaps2; ++k) aln[i - removed + k] = {last1 + k + 1, gap};
+            for (uint64_t k = 0; k < gaps1; ++k) aln[i - removed + k + gaps2] = {gap, last2 + k + 1};
+        }
+        i = e;
+    }
+    aln.resize(aln.size() - removed);
+    std::string out;
+    int curr_len = 0;
+    char curr_op = '\0';
+    for (const auto& ap : aln) {
+        const char op = ap.first == gap ? 'I' : ap.second == gap ? 'D' : g->label[p1[ap.first]] == g->label[p2[ap.second]] ? '=' : 'X';
+        if (op == curr_op) { ++curr_len; continue; }
+        if (curr_len != 0) { out += std::to_string(curr_len); out += curr_op; }
+        curr_len = 1;
+        curr_op = op;
+    }
+    if (curr_len != 0) { out += std::to_string(curr_len); out += curr_op; }
+    *text_out = to_c_string(out, len_out);
+    return *text_out ? CL_OK : CL_ERR_OUT_OF_MEMORY;
+}
+
 }  // extern "C"

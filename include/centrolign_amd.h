@@ -536,6 +536,10 @@ int cl_leaf_graph(const char* sequence, uint64_t n, cl_owned_base_graph** out);
 int cl_explicit_cigar(const cl_base_graph* graph1, const cl_base_graph* graph2, const uint64_t* pairs, uint64_t n_pairs, char** text_out,
                       uint64_t* len_out /* may be NULL */);
 int cl_write_gfa(const cl_base_graph* graph, const char* const* path_names, int decode, char** text_out, uint64_t* len_out /* may be NULL */);
+/* The -A output of the CLI on an acyclic result (src/core.cpp:546-550): explicit_cigar(induced_pairwise_alignment(graph, path1, path2), seq1, seq2)
+ * (src/alignment.cpp:84-229) — the pairwise alignment of two of the input sequences that the MSA graph implies.  CL_ERR_CYCLIC_GRAPH when path1
+ * visits a node twice (the reference throws). */
+int cl_induced_pairwise_cigar(const cl_base_graph* graph, uint64_t path1, uint64_t path2, char** text_out, uint64_t* len_out /* may be NULL */);
 /* -S / -R (src/core.cpp:370-422, src/execution.cpp:222-277): a finished subproblem is written as PREFIX_<hash>.gfa with cl_write_gfa, a
  * restart loads it back with read_gfa(in) + add_sentinels(graph, 5, 6) — NOT the graph that was written: node ids follow the S lines and the
  * sentinels come last, and the run continues on that graph.  cl_read_gfa builds exactly that graph (add_sentinels = 0: read_gfa alone);

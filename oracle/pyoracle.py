@@ -653,3 +653,19 @@ def ref_internal_fuse(g, pairs):
     if rc:
         raise RuntimeError("ref_internal_fuse failed: %d" % rc)
     return _graph_from_out(lib, out, sizes, int(ids[0]), int(ids[1])), trans
+
+
+def ref_induced_pairwise_cigar(g, p1, p2):
+    """the compiled reference's -A output for two paths of an acyclic graph (src/core.cpp:546-550): bytes"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_induced_pairwise_cigar.restype = C.c_int
+    lib.ref_induced_pairwise_cigar.argtypes = [C.POINTER(BaseGraphC), C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c, p = g.as_c(), C.c_void_p()
+    rc = lib.ref_induced_pairwise_cigar(C.byref(c), int(p1), int(p2), C.byref(p))
+    if rc:
+        raise RuntimeError("ref_induced_pairwise_cigar failed: %d" % rc)
+    out = C.string_at(p)
+    lib.ref_free(p)
+    return out

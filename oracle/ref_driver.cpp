@@ -921,6 +921,16 @@ int ref_internal_fuse(const cl_base_graph* g, const uint64_t* pairs, uint64_t n_
     return 0;
 }
 
+/* explicit_cigar(induced_pairwise_alignment(graph, p1, p2), seq1, seq2): the -A output (src/core.cpp:546-550) */
+int ref_induced_pairwise_cigar(const cl_base_graph* g, uint64_t p1, uint64_t p2, char** text_out) {
+    SentinelTableau t;
+    BaseGraph b = build_base_graph(g, t);
+    std::string text = explicit_cigar(induced_pairwise_alignment(b, p1, p2), path_to_string(b, b.path(p1)), path_to_string(b, b.path(p2)));
+    *text_out = (char*)malloc(text.size() + 1);
+    memcpy(*text_out, text.c_str(), text.size() + 1);
+    return 0;
+}
+
 int ref_despecify(uint64_t n, const double* score, int64_t* gap_before, double* gap_score_before, int64_t* gap_after,
                   double* gap_score_after, int64_t min_len, double prop, uint8_t* keep_out, uint64_t* n_kept_out) {
     std::vector<anchor_t> anchors(n);

@@ -317,6 +317,8 @@ def plan_goldens():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "induced":
+        return induced_cigar_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "ifuse":
         return internal_fuse_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "restart":
@@ -659,6 +661,26 @@ def internal_fuse_goldens():
         put("random%d" % k, g, pairs)
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "internal_fuse.npz"), **out)
+
+
+def induced_cigar_goldens():
+    # 19. the -A output (src/core.cpp:546-550): explicit_cigar(induced_pairwise_alignment(graph, p1, p2), ...) of the compiled reference for
+    #     every ordered path pair of the restart fixture's subproblem graphs (as read_gfa + add_sentinels loads them)
+    z = np.load(os.path.join(HERE, "restart_case.npz"))
+    out, keys = {}, []
+    for f in z["files"]:
+        f = str(f)
+        text = bytes(z["file." + f])
+        g, names = capi.read_gfa(text)
+        out["gfa." + f] = np.frombuffer(text, np.uint8)
+        for a in range(len(names)):
+            for b in range(len(names)):
+                if a != b:
+                    k = "%s|%d|%d" % (f, a, b)
+                    keys.append(k)
+                    out["cigar." + k] = np.frombuffer(po.ref_induced_pairwise_cigar(g, a, b), np.uint8)
+    out["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(HERE, "induced_cigars.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -79,3 +79,33 @@ def test_live_reference_agreement():
             assert capi.write_gfa(fused, names, dec) == po.ref_write_gfa(fused, names, dec), name
         assert capi.write_gfa(g2, names[:len(g2.path_off) - 1]) == po.ref_write_gfa(g2, names[:len(g2.path_off) - 1])
         assert capi.explicit_cigar(g1, g2, pairs) == po.ref_explicit_cigar(g1, g2, pairs)
+
+
+def test_induced_pairwise_cigar_matches_the_reference():
+    """the -A output of the CLI (src/core.cpp:546-550): explicit_cigar of the pairwise alignment an acyclic MSA graph induces on two of its
+    paths — on the subproblem graphs of the restart fixture (committed expectations from the compiled reference) and, where the reference
+    is built, live on random bubble graphs"""
+    import os
+    import numpy as np
+    from centrolign_amd import synth
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", "induced_cigars.npz"))
+    for key in z["keys"]:
+        f, a, b = str(key).split("|")
+        g, names = capi.read_gfa(bytes(z["gfa." + f]))
+        assert capi.induced_pairwise_cigar(g, int(a), int(b)) == bytes(z["cigar." + str(key)]), key
+    g, names = capi.read_gfa(bytes(z["gfa." + str(z["keys"][0]).split("|")[0]]))
+    assert capi.induced_pairwise_cigar(g, 0, 0) == b"%d=" % int(g.path_off[1] - g.path_off[0])
+    with pytest.raises(capi.ClError):
+        capi.induced_pairwise_cigar(g, 0, len(names))
+    try:
+        from oracle import pyoracle as po
+        po.ref_lib()
+    except Exception:
+        return
+    rng = np.random.default_rng(15)
+    for k in range(4):
+        g = synth.bubble_graph("".join("ACGT"[b] for b in rng.integers(0, 4, 250)), 3, seed=30 + k, alt_p=0.12, skip_p=0.06)
+        for a in range(3):
+            for b in range(3):
+                assert capi.induced_pairwise_cigar(g, a, b) == po.ref_induced_pairwise_cigar(g, a, b), (k, a, b)
