@@ -619,13 +619,14 @@ class MsaPlanC(C.Structure):
 
 class MsaParams(C.Structure):
     """cl_msa_params"""
-    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int)]
+    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int), ("subproblems_prefix", C.c_char_p), ("restart", C.c_int),
+                ("induced_pairwise_prefix", C.c_char_p)]
 
 
 class MsaStats(C.Structure):
     """cl_msa_stats"""
     _fields_ = [("n_merges", C.c_uint64), ("root_nodes", C.c_uint64), ("score_scale", C.c_double), ("calibration_s", C.c_double),
-                ("match_s", C.c_double), ("align_s", C.c_double), ("fuse_s", C.c_double), ("total_s", C.c_double)]
+                ("match_s", C.c_double), ("align_s", C.c_double), ("fuse_s", C.c_double), ("total_s", C.c_double), ("n_restarted", C.c_uint64)]
 
 
 def parse_fasta(text):
@@ -1393,7 +1394,8 @@ class Context:
         finally:
             self.lib.cl_merge_result_free(C.byref(out))
 
-    def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False):
+    def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False, subproblems_prefix=None,
+            restart=False, induced_pairwise_prefix=None):
         """the whole CLI flow in the library (cl_msa): FASTA text (+ Newick text) -> explicit CIGAR (two sequences) or GFA; returns
         (text bytes, stats dict)"""
         raw = fasta_text.encode() if isinstance(fasta_text, str) else bytes(fasta_text)
@@ -1402,6 +1404,9 @@ class Context:
         mp.merge.match.max_count = int(max_count)
         mp.merge.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
         mp.skip_calibration = int(skip_calibration)
+        mp.subproblems_prefix = subproblems_prefix.encode() if subproblems_prefix else None   # -S
+        mp.restart = int(restart)                                                             # -R
+        mp.induced_pairwise_prefix = induced_pairwise_prefix.encode() if induced_pairwise_prefix else None   # -A
         p, n, st = C.c_void_p(), C.c_uint64(0), MsaStats()
         self._check(self.lib.cl_msa(self.handle, raw, len(raw), None if not newick else newick.encode(), C.byref(mp), C.byref(p), C.byref(n), C.byref(st)))
         try:

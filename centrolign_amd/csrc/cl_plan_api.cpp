@@ -16,6 +16,8 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <fstream>
+#include <iterator>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -443,8 +445,56 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         st.calibration_s = secs(t);
     }
     st.score_scale = mp.align.anchor.score_scale;
+    // -S / -R (src/core.cpp:370-422, src/execution.cpp:190-203, 222-277)
+    const std::string prefix = params->subproblems_prefix ? params->subproblems_prefix : "";
+    std::vector<std::vector<uint64_t>> leaf_set(n_slots);   // the sequences under every slot
+    for (uint64_t i = 0; i < plan.n_leaves; ++i) leaf_set[i].assign(1, plan.leaf_sequence[i]);
+    for (uint64_t k = 0; k < plan.n_merges; ++k) {
+        auto& dst = leaf_set[plan.n_leaves + k];
+        dst = leaf_set[plan.merge_children[2 * k]];
+        dst.insert(dst.end(), leaf_set[plan.merge_children[2 * k + 1]].begin(), leaf_set[plan.merge_children[2 * k + 1]].end());
+    }
+    auto file_of = [&](uint64_t slot) {
+        std::vector<const char*> nm;
+        for (uint64_t s : leaf_set[slot]) nm.push_back(fa.names[s]);
+        char hex[17];
+        (void)cl_subproblem_hash_hex(nm.data(), nm.size(), hex);
+        return prefix + "_" + hex + ".gfa";
+    };
+    std::vector<char> done(n_slots, 0);   // loaded, or below something loaded
+    if (params->restart && !prefix.empty()) {
+        for (uint64_t k = plan.n_merges; k-- > 0;) {   // the root first: what is loaded makes everything below it unnecessary
+            const uint64_t slot = plan.n_leaves + k;
+            if (!done[slot]) {
+                std::ifstream in(file_of(slot), std::ios::binary);
+                if (in) {
+                    const std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+                    char** nm = nullptr;
+                    uint64_t np = 0;
+                    if ((rc = cl_read_gfa(text.data(), text.size(), 1, &graph[slot], &nm, &np))) { cl_set_error(ctx, "cannot read %s", file_of(slot).c_str()); return fail(rc); }
+                    for (uint64_t p = 0; p < np; ++p) {
+                        uint64_t s = 0;
+                        while (s < fa.n_sequences && strcmp(fa.names[s], nm[p]) != 0) ++s;
+                        if (s < fa.n_sequences) paths[slot].push_back(s);
+                        free(nm[p]);
+                    }
+                    free(nm);
+                    if (paths[slot].size() != np) { cl_set_error(ctx, "%s names a path that is not an input sequence", file_of(slot).c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+                    done[slot] = 1;
+                    ++st.n_restarted;
+                }
+            }
+            if (done[slot]) {   // (loaded here or under a loaded ancestor): its children are not needed
+                for (int c = 0; c < 2; ++c) {
+                    const uint64_t ch = plan.merge_children[2 * k + c];
+                    if (ch >= plan.n_leaves) done[ch] = done[ch] ? done[ch] : 2;
+                }
+            }
+        }
+    }
     for (uint64_t k = 0; k < plan.n_merges; ++k) {
         const uint64_t a = plan.merge_children[2 * k], b = plan.merge_children[2 * k + 1];
+        if (done[plan.n_leaves + k]) continue;
         cl_base_graph g1, g2;
         cl_owned_base_graph_view(graph[a], &g1);
         cl_owned_base_graph_view(graph[b], &g2);
@@ -468,8 +518,30 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
             cl_owned_base_graph_free(graph[b]); graph[b] = nullptr;
         }
         cl_merge_result_free(&r);
+        ++st.n_merges;
+        if (!prefix.empty()) {   // Core::emit_subproblem
+            const std::string info_name = prefix + "_info.txt", gfa_name = file_of(slot);
+            const bool header = !std::ifstream(info_name);
+            std::ofstream info(info_name, std::ios::app), gfa(gfa_name, std::ios::binary);
+            if (!info || !gfa) { cl_set_error(ctx, "Failed to write to subproblem file %s", gfa_name.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+            if (header) info << "filename\tsequences\n";
+            std::vector<std::string> sorted;
+            for (uint64_t s : leaf_set[slot]) sorted.push_back(fa.names[s]);
+            std::sort(sorted.begin(), sorted.end());
+            info << gfa_name << '\t';
+            for (size_t i = 0; i < sorted.size(); ++i) info << (i ? "," : "") << sorted[i];
+            info << '\n';
+            std::vector<const char*> nm;
+            for (uint64_t s : paths[slot]) nm.push_back(fa.names[s]);
+            cl_base_graph g;
+            cl_owned_base_graph_view(graph[slot], &g);
+            char* text = nullptr;
+            uint64_t len = 0;
+            if ((rc = cl_write_gfa(&g, nm.data(), 1, &text, &len))) return fail(rc);
+            gfa.write(text, (std::streamsize)len);
+            free(text);
+        }
     }
-    st.n_merges = plan.n_merges;
     const uint64_t root = n_slots - 1;
     if (fa.n_sequences == 2) {
         // explicit_cigar(root.alignment, leaf of the FIRST sequence, leaf of the LAST one) (src/main.cpp:292-296)
@@ -489,6 +561,23 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         rc = cl_write_gfa(&g, names.data(), 1, text_out, len_out);
     }
     if (rc) { cl_set_error(ctx, "writing the output failed"); return fail(rc); }
+    if (params->induced_pairwise_prefix && *params->induced_pairwise_prefix) {   // Core::output_pairwise_alignments(false)
+        cl_base_graph g;
+        cl_owned_base_graph_view(graph[root], &g);
+        for (uint64_t p1 = 0; p1 < g.n_paths; ++p1)
+            for (uint64_t p2 = p1 + 1; p2 < g.n_paths; ++p2) {
+                std::string n1 = fa.names[paths[root][p1]], n2 = fa.names[paths[root][p2]];
+                std::replace(n1.begin(), n1.end(), '/', '_');
+                std::replace(n2.begin(), n2.end(), '/', '_');
+                const std::string name = std::string(params->induced_pairwise_prefix) + "_" + n1 + "_" + n2 + ".txt";
+                char* text = nullptr;
+                if ((rc = cl_induced_pairwise_cigar(&g, p1, p2, &text, nullptr))) { cl_set_error(ctx, "induced pairwise alignment of %s and %s failed", n1.c_str(), n2.c_str()); return fail(rc); }
+                std::ofstream out(name);
+                if (!out) { free(text); cl_set_error(ctx, "could not write to induced pairwise alignment file %s", name.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+                out << text << '\n';
+                free(text);
+            }
+    }
     st.total_s = secs(t_all);
     if (stats) *stats = st;
     fail(CL_OK);

@@ -607,11 +607,18 @@ void cl_msa_plan_free(cl_msa_plan* p);
 typedef struct cl_msa_params {
     cl_merge_params merge;            /* merge.align.anchor.score_scale is overwritten by the calibration unless it is skipped */
     int             skip_calibration; /* --skip-calibration of the CLI */
+    const char*     subproblems_prefix;      /* -S: every finished subproblem is written as PREFIX_<hash>.gfa, one line each in PREFIX_info.txt
+                                                (Core::emit_subproblem, src/core.cpp:397-422); NULL: off */
+    int             restart;                 /* -R: subproblems whose files exist are loaded instead of computed (Execution::restart,
+                                                src/execution.cpp:222-277); needs subproblems_prefix */
+    const char*     induced_pairwise_prefix; /* -A: PREFIX_<name1>_<name2>.txt with the induced pairwise CIGAR of every pair of sequences
+                                                (Core::output_pairwise_alignments, src/core.cpp:523-575); NULL: off */
 } cl_msa_params;
 void cl_msa_params_default(cl_msa_params* p);
 typedef struct cl_msa_stats {
     uint64_t n_merges, root_nodes;
     double   score_scale, calibration_s, match_s, align_s, fuse_s, total_s;
+    uint64_t n_restarted;        /* subproblems loaded from files (-R) */
 } cl_msa_stats;
 int  cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const char* newick /* NULL: in-order tree */,
             const cl_msa_params* params, char** text_out, uint64_t* len_out, cl_msa_stats* stats /* may be NULL */);

@@ -83,3 +83,31 @@ def test_gpu_subproblem_files_and_restart_match_the_reference(gpu_ctx, tmp_path)
     # everything there: nothing to do but load the root
     r3 = msa.progressive_msa(gpu_ctx, seqs, tree, max_num_match_pairs=budget, subproblems_prefix=prefix, restart=True)
     assert r3["stats"]["merges"] == 0 and msa.output_text(r3) == bytes(d["restart"])
+
+
+@pytest.mark.gpu
+def test_gpu_cl_msa_writes_restarts_and_prints_induced_alignments(gpu_ctx, tmp_path):
+    """the same through the library's own driver (cl_msa with -S, -R and -A): files, restart output, and one induced pairwise CIGAR per
+    pair of sequences, each equal to the compiled reference's where it is built"""
+    d = case()
+    fasta, newick, budget = bytes(d["fasta"]), str(d["newick"][0]), int(d["budget"][0])
+    prefix, aprefix = str(tmp_path / "sub"), str(tmp_path / "ind")
+    text, st = gpu_ctx.msa(fasta, newick, max_num_match_pairs=budget, subproblems_prefix=prefix, induced_pairwise_prefix=aprefix)
+    assert text == bytes(d["full"]) and st["n_merges"] == 4 and st["n_restarted"] == 0
+    for f in d["files"]:
+        assert open(os.path.join(tmp_path, f), "rb").read() == bytes(d["file." + f]), f
+    want_info = bytes(d["info"]).decode()
+    assert open(prefix + "_info.txt").read().replace(str(tmp_path) + "/", "") == want_info   # one context, the reference's order
+    root, names = capi.read_gfa(text, add_sentinels=True)
+    written = sorted(f for f in os.listdir(tmp_path) if f.startswith("ind_"))
+    assert len(written) == len(names) * (len(names) - 1) // 2
+    for a in range(len(names)):
+        for b in range(a + 1, len(names)):
+            got = open(os.path.join(tmp_path, "ind_%s_%s.txt" % (names[a], names[b])), "rb").read()
+            assert got == capi.induced_pairwise_cigar(root, a, b) + b"\n"
+    for f in d["removed"]:
+        os.remove(os.path.join(tmp_path, f))
+    text2, st2 = gpu_ctx.msa(fasta, newick, max_num_match_pairs=budget, subproblems_prefix=prefix, restart=True)
+    assert text2 == bytes(d["restart"]) and st2["n_restarted"] == 2 and st2["n_merges"] == 2
+    text3, st3 = gpu_ctx.msa(fasta, newick, max_num_match_pairs=budget, subproblems_prefix=prefix, restart=True)
+    assert text3 == bytes(d["restart"]) and st3["n_restarted"] == 1 and st3["n_merges"] == 0
