@@ -619,7 +619,7 @@ class MsaPlanC(C.Structure):
 
 class MsaParams(C.Structure):
     """cl_msa_params"""
-    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int), ("subproblems_prefix", C.c_char_p), ("restart", C.c_int),
+    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int), ("n_workers", C.c_int), ("subproblems_prefix", C.c_char_p), ("restart", C.c_int),
                 ("induced_pairwise_prefix", C.c_char_p)]
 
 
@@ -1395,7 +1395,7 @@ class Context:
             self.lib.cl_merge_result_free(C.byref(out))
 
     def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False, subproblems_prefix=None,
-            restart=False, induced_pairwise_prefix=None):
+            restart=False, induced_pairwise_prefix=None, workers=1):
         """the whole CLI flow in the library (cl_msa): FASTA text (+ Newick text) -> explicit CIGAR (two sequences) or GFA; returns
         (text bytes, stats dict)"""
         raw = fasta_text.encode() if isinstance(fasta_text, str) else bytes(fasta_text)
@@ -1404,6 +1404,7 @@ class Context:
         mp.merge.match.max_count = int(max_count)
         mp.merge.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
         mp.skip_calibration = int(skip_calibration)
+        mp.n_workers = int(workers)
         mp.subproblems_prefix = subproblems_prefix.encode() if subproblems_prefix else None   # -S
         mp.restart = int(restart)                                                             # -R
         mp.induced_pairwise_prefix = induced_pairwise_prefix.encode() if induced_pairwise_prefix else None   # -A

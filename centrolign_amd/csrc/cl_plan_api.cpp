@@ -18,6 +18,12 @@
 #include <unordered_map>
 #include <fstream>
 #include <iterator>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "cl_internal.hpp"
@@ -430,16 +436,40 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         paths[i].assign(1, s);
     }
     cl_merge_params mp = params->merge;
+    // worker contexts (n_workers > 1): the leaf calibrations, and every merge whose two children are there, run side by side, one thread per
+    // context — the merges of a guide tree that do not depend on one another (src/execution.cpp:98-124 hands them out one at a time)
+    const int n_workers = std::max(1, std::min(params->n_workers, 16));
+    std::vector<cl_context*> workers(1, ctx);
+    for (int w = 1; w < n_workers; ++w) {
+        cl_context* c = cl_context_create(ctx->device);
+        if (!c) break;
+        workers.push_back(c);
+    }
+    struct WorkersGuard { std::vector<cl_context*>& w; ~WorkersGuard() { for (size_t i = 1; i < w.size(); ++i) cl_context_destroy(w[i]); } } workers_guard{workers};
+    auto run_workers = [&](const std::function<void(cl_context*)>& body) {
+        std::vector<std::thread> th;
+        for (size_t w = 1; w < workers.size(); ++w) th.emplace_back(body, workers[w]);
+        body(workers[0]);
+        for (auto& t : th) t.join();
+    };
     if (!params->skip_calibration) {
         const auto t = now();
-        double mean = 0.0;
-        for (uint64_t i = 0; i < plan.n_leaves; ++i) {
-            cl_base_graph v;
-            cl_owned_base_graph_view(graph[i], &v);
-            double scale = 0.0;
-            if ((rc = cl_leaf_intrinsic_scale(ctx, &v, &mp.match, &mp.align.anchor, &scale))) return fail(rc);
-            mean += scale;
+        std::vector<double> scales(plan.n_leaves, 0.0);
+        {
+            std::atomic<uint64_t> next{0};
+            std::atomic<int> first_rc{CL_OK};
+            run_workers([&](cl_context* c) {
+                for (uint64_t i = next.fetch_add(1); i < plan.n_leaves && first_rc.load() == CL_OK; i = next.fetch_add(1)) {
+                    cl_base_graph v;
+                    cl_owned_base_graph_view(graph[i], &v);
+                    const int r = cl_leaf_intrinsic_scale(c, &v, &mp.match, &mp.align.anchor, &scales[i]);
+                    if (r) { int expected = CL_OK; if (first_rc.compare_exchange_strong(expected, r) && c != ctx) cl_set_error(ctx, "%s", cl_last_error(c)); }
+                }
+            });
+            if ((rc = first_rc.load())) return fail(rc);
         }
+        double mean = 0.0;
+        for (double sc : scales) mean += sc;   // summed in leaf order (src/core.cpp:169-173)
         mean /= (double)plan.n_leaves;
         mp.align.anchor.score_scale = mean;
         st.calibration_s = secs(t);
@@ -492,14 +522,16 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
             }
         }
     }
-    for (uint64_t k = 0; k < plan.n_merges; ++k) {
+    std::mutex state_mutex;
+    auto do_merge = [&](uint64_t k, cl_context* c) -> int {
         const uint64_t a = plan.merge_children[2 * k], b = plan.merge_children[2 * k + 1];
-        if (done[plan.n_leaves + k]) continue;
         cl_base_graph g1, g2;
         cl_owned_base_graph_view(graph[a], &g1);
         cl_owned_base_graph_view(graph[b], &g2);
         cl_merge_result r;
-        if ((rc = cl_merge(ctx, &g1, &g2, &mp, &r))) return fail(rc);
+        int rc = cl_merge(c, &g1, &g2, &mp, &r);
+        if (rc) { if (c != ctx) cl_set_error(ctx, "%s", cl_last_error(c)); return rc; }
+        std::lock_guard<std::mutex> lock(state_mutex);
         st.match_s += r.match_ms * 1e-3;
         st.align_s += r.align_ms * 1e-3;
         st.fuse_s += r.fuse_ms * 1e-3;
@@ -523,7 +555,7 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
             const std::string info_name = prefix + "_info.txt", gfa_name = file_of(slot);
             const bool header = !std::ifstream(info_name);
             std::ofstream info(info_name, std::ios::app), gfa(gfa_name, std::ios::binary);
-            if (!info || !gfa) { cl_set_error(ctx, "Failed to write to subproblem file %s", gfa_name.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+            if (!info || !gfa) { cl_set_error(ctx, "Failed to write to subproblem file %s", gfa_name.c_str()); return (int)CL_ERR_INVALID_ARGUMENT; }
             if (header) info << "filename\tsequences\n";
             std::vector<std::string> sorted;
             for (uint64_t s : leaf_set[slot]) sorted.push_back(fa.names[s]);
@@ -537,10 +569,49 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
             cl_owned_base_graph_view(graph[slot], &g);
             char* text = nullptr;
             uint64_t len = 0;
-            if ((rc = cl_write_gfa(&g, nm.data(), 1, &text, &len))) return fail(rc);
+            if ((rc = cl_write_gfa(&g, nm.data(), 1, &text, &len))) return rc;
             gfa.write(text, (std::streamsize)len);
             free(text);
         }
+            return CL_OK;
+    };
+    {
+        // ready queue: a merge is ready when both children are there (leaves, loaded subproblems, finished merges)
+        std::mutex qm;
+        std::condition_variable qcv;
+        std::vector<char> have(n_slots, 0), queued(plan.n_merges, 0);
+        std::deque<uint64_t> ready;
+        uint64_t remaining = 0;
+        int first_rc = CL_OK;
+        for (uint64_t i = 0; i < plan.n_leaves; ++i) have[i] = 1;
+        for (uint64_t k = 0; k < plan.n_merges; ++k) { if (done[plan.n_leaves + k] == 1) have[plan.n_leaves + k] = 1; if (!done[plan.n_leaves + k]) ++remaining; }
+        auto enqueue_ready = [&]() {   // under qm
+            for (uint64_t k = 0; k < plan.n_merges; ++k)
+                if (!queued[k] && !done[plan.n_leaves + k] && have[plan.merge_children[2 * k]] && have[plan.merge_children[2 * k + 1]]) { queued[k] = 1; ready.push_back(k); }
+        };
+        enqueue_ready();
+        run_workers([&](cl_context* c) {
+            while (true) {
+                uint64_t k;
+                {
+                    std::unique_lock<std::mutex> lock(qm);
+                    qcv.wait(lock, [&] { return !ready.empty() || remaining == 0 || first_rc != CL_OK; });
+                    if (ready.empty()) return;
+                    k = ready.front();
+                    ready.pop_front();
+                }
+                const int r = do_merge(k, c);
+                {
+                    std::lock_guard<std::mutex> lock(qm);
+                    if (r && first_rc == CL_OK) first_rc = r;
+                    have[plan.n_leaves + k] = 1;
+                    --remaining;
+                    if (first_rc == CL_OK) enqueue_ready(); else { ready.clear(); remaining = 0; }
+                }
+                qcv.notify_all();
+            }
+        });
+        if (first_rc) return fail(first_rc);
     }
     const uint64_t root = n_slots - 1;
     if (fa.n_sequences == 2) {

@@ -607,6 +607,7 @@ void cl_msa_plan_free(cl_msa_plan* p);
 typedef struct cl_msa_params {
     cl_merge_params merge;            /* merge.align.anchor.score_scale is overwritten by the calibration unless it is skipped */
     int             skip_calibration; /* --skip-calibration of the CLI */
+    int             n_workers;        /* contexts (threads) that run leaf calibrations and independent merges side by side on ctx's device; <= 1: one */
     const char*     subproblems_prefix;      /* -S: every finished subproblem is written as PREFIX_<hash>.gfa, one line each in PREFIX_info.txt
                                                 (Core::emit_subproblem, src/core.cpp:397-422); NULL: off */
     int             restart;                 /* -R: subproblems whose files exist are loaded instead of computed (Execution::restart,

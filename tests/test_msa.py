@@ -101,6 +101,9 @@ def test_gpu_cl_msa_is_the_cli_flow(gpu_ctx, case):
     text, st = gpu_ctx.msa(fasta, msa.newick(msa.balanced_tree(names)) + ";", max_num_match_pairs=budget)
     want = bytes(Z[name])
     assert text == (want.rstrip(b"\n") if n == 2 else want) and st["n_merges"] == n - 1
+    # three worker contexts inside the library: calibrations and independent merges side by side, the same text
+    text_w, st_w = gpu_ctx.msa(fasta, msa.newick(msa.balanced_tree(names)) + ";", max_num_match_pairs=budget, workers=3)
+    assert text_w == text and st_w["n_merges"] == n - 1 and st_w["score_scale"] == st["score_scale"]
 
 
 @pytest.mark.gpu
@@ -109,3 +112,5 @@ def test_gpu_cl_msa_ten_sequences(gpu_ctx):
     fasta = "".join(">%s some description\n%s\n" % (nm, seqs[nm]) for nm in names)
     text, st = gpu_ctx.msa(fasta, synth.C3_NEWICK, max_num_match_pairs=200000)
     assert text == bytes(ZB["msa10_30k.gfa"])
+    text4, st4 = gpu_ctx.msa(fasta, synth.C3_NEWICK, max_num_match_pairs=200000, workers=4)
+    assert text4 == text and st4["n_merges"] == 9
