@@ -118,37 +118,57 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
     const uint32_t lane = threadIdx.x;
     int carry_o = INT32_MIN, carry_b = INT32_MIN;
     uint32_t carry_bucket = 0xFFFFFFFEu;
-    for (uint32_t at = 0; at < n; at += 64) {
-        const uint32_t i = g0 + at + lane;
-        // by offset: plain inclusive maximum
-        int x = rec[(size_t)L.perm_o[i] * 12 + 3];
+    // the values come through two dependent gathers (order -> record -> dp): U chunks of 64 are fetched together so that a large node pays
+    // one such round trip per U chunks, not per chunk (a node of 32 768 records: 512 chunks, 1-2.5 ms before, on the path of the far pass)
+    constexpr uint32_t U = 8;
+    const bool banded = L.key_b != nullptr;   // sparse_chain_dp: one order only
+    for (uint32_t at0 = 0; at0 < n; at0 += 64 * U) {
+        int xs[U], ys[U];
+        uint32_t bks[U];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(x, d);
-            if ((int)lane >= d) x = max(x, o);
-        }
-        x = max(x, carry_o);
-        L.pm_o[i] = x;
-        carry_o = __shfl(x, 63);
-        if (!L.key_b) continue;   // sparse_chain_dp: one order only
-        // by (bucket, offset): maximum within the bucket
-        int y = rec[(size_t)L.perm_b[i] * 12 + 3];
-        const uint32_t bk = (uint32_t)(L.key_b[i] >> 32);
-        const uint32_t prev = __shfl_up(bk, 1);
-        int head = (lane == 0 ? bk != carry_bucket : bk != prev) ? 1 : 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int oy = __shfl_up(y, d);
-            const int oh = __shfl_up(head, d);
-            if ((int)lane >= d) {
-                if (!head) y = max(y, oy);
-                head |= oh;
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t at = at0 + 64 * u;
+            if (at < n) {
+                const uint32_t i = g0 + at + lane;
+                xs[u] = rec[(size_t)L.perm_o[i] * 12 + 3];
+                if (banded) { ys[u] = rec[(size_t)L.perm_b[i] * 12 + 3]; bks[u] = (uint32_t)(L.key_b[i] >> 32); }
             }
         }
-        if (!head) y = max(y, carry_b);   // the bucket began in an earlier chunk
-        L.pm_b[i] = y;
-        carry_b = __shfl(y, 63);
-        carry_bucket = __shfl(bk, 63);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t at = at0 + 64 * u;
+            if (at >= n) break;
+            const uint32_t i = g0 + at + lane;
+            // by offset: plain inclusive maximum
+            int x = xs[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(x, d);
+                if ((int)lane >= d) x = max(x, o);
+            }
+            x = max(x, carry_o);
+            L.pm_o[i] = x;
+            carry_o = __shfl(x, 63);
+            if (!banded) continue;
+            // by (bucket, offset): maximum within the bucket
+            int y = ys[u];
+            const uint32_t bk = bks[u];
+            const uint32_t prev = __shfl_up(bk, 1);
+            int head = (lane == 0 ? bk != carry_bucket : bk != prev) ? 1 : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int oy = __shfl_up(y, d);
+                const int oh = __shfl_up(head, d);
+                if ((int)lane >= d) {
+                    if (!head) y = max(y, oy);
+                    head |= oh;
+                }
+            }
+            if (!head) y = max(y, carry_b);   // the bucket began in an earlier chunk
+            L.pm_b[i] = y;
+            carry_b = __shfl(y, 63);
+            carry_bucket = __shfl(bk, 63);
+        }
     }
 }
 
