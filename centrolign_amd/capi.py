@@ -929,6 +929,7 @@ class StitchResult:
 
 
 _lib = None
+ABI_VERSION = 3     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -942,6 +943,9 @@ def load_library(path=None):
                           "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C centrolign_amd/csrc`)" % p)
     lib = C.CDLL(p)
     lib.cl_abi_version.restype = C.c_int
+    if lib.cl_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, these bindings are written for %d (include/centrolign_amd.h: CL_ABI_VERSION): rebuild the library"
+                          % (p, lib.cl_abi_version(), ABI_VERSION))
     lib.cl_device_count.restype = C.c_int
     lib.cl_context_create.restype = C.c_void_p
     lib.cl_context_create.argtypes = [C.c_int]

@@ -81,20 +81,27 @@ constexpr int kFarBandShift = 16;   // shift buckets of 65536 by default (ClFarD
                                     // that the gap cost is on its last, nearly flat piece.  Measured on 2 x 1 Mbp: buckets of 4096 / 1024 / 256 open 3.4x /
                                     // 3.6x / 3.7x the leaves (the "everything else pays one bucket width" term gets weak), 572 / 751 / 812 ms against 366
 
-struct ClFarLevel {
-    uint32_t* key_o;             // [r_pad] offset, ascending within a node
-    int*      pm_o;              // [r_pad] running maximum of the encoded DP value in that order (valid for sealed nodes)
-    unsigned long long* key_b;   // [r_pad] (shift bucket << 32 | offset), ascending within a node
-    int*      pm_b;              // [r_pad] running maximum within (node, bucket)
-    uint32_t* perm_o;            // [r_pad] which record sits at each position of the two orders
-    uint32_t* perm_b;
-};
+// Every level keeps its records' keys in two static orders per node (by offset; by shift bucket, then offset), each as a static
+// 8-ary search tree (an "S+ tree"): the ascending keys lie in blocks of eight, every block followed by the eight RUNNING MAXIMA of the DP
+// value at its positions (written when the node is sealed), and index arrays hold every 8th, 64th, ... key.  A search reads one 32-byte
+// index block per tree level and ends on one 64-byte block that holds both the last key below the bound and the running maximum there:
+// level + 2 dependent loads per node instead of the 6 .. 15 + 2 of a binary search.  All arrays live in ONE arena; the kernels keep the
+// table of their offsets in LDS (a lane picks its node's level at run time).
+constexpr int kFarTabWidth = 2 + 2 * kFarMaxLevels;   // words per level in ClFarDevice::tab
 
 struct ClFarDevice {
     uint32_t n_levels, r_pad;
-    ClFarLevel lv[kFarMaxLevels];
-    int32_t sig_bias;            // added to a shift before bucketing (buckets are non-negative)
+    uint32_t* arena;             // all search structures of all levels
+    // per level, in words from `arena`: [0] the blocked offset order (2 * r_pad words: 8 keys | 8 running maxima per block), [1] the blocked
+    // (bucket << off_bits | offset) order (0xFFFFFFFF: sparse_chain_dp has none), [2 + j] every 8^(j+1)-th key of the offset order,
+    // [2 + kFarMaxLevels + j] the same for the bucket order  (j = 0 .. level)
+    uint32_t tab[kFarMaxLevels][kFarTabWidth];
+    const uint32_t* tab_dev;     // the same table in device memory (the far kernel copies it to LDS)
+    uint32_t* perm_o[kFarMaxLevels];   // [r_pad] which record sits at each position of the two orders (the sealing kernel's gather)
+    uint32_t* perm_b[kFarMaxLevels];
+    int32_t sig_bias;            // added to a shift before bucketing (buckets are positive)
     uint32_t band_shift;         // log2 of the bucket width
+    uint32_t off_bits;           // bucket keys are bucket << off_bits | offset
     double band_pen;             // least gap cost of a shift difference of one bucket width or more
     double slack_t0;             // rounding allowance of a bound: 2^-21 (|dp| + slack_t0 + slack_e0 |query shift| + |weight|)
     double slack_e0;

@@ -19,9 +19,14 @@
 // value nor any running maximum the traceback will read for an attaining kind (cl_chain_api.cpp); nodes that survive are
 // opened level by level, and surviving leaves are evaluated record by record with the exact arithmetic of the sweep.
 //
-// Eight lanes work on one query: a round tests eight sibling nodes (one per lane), surviving leaves are scanned by the lane
-// that tested them, surviving inner nodes go on a small per-query stack in LDS (nearest on top); the eight lanes share their
-// best candidate after every round.
+// Eight lanes work on one query: a round tests eight sibling nodes (one per lane), surviving leaves are scanned by the eight
+// lanes TOGETHER (eight records each, coalesced, nearest leaf first, re-tested against the best candidate the leaves before it
+// gave), surviving inner nodes go on a small per-query stack in LDS (nearest on top); the eight lanes share their best
+// candidate after every leaf and every round.
+//
+// A node's two static orders are kept as 8-ary search trees (chain_device.h): the bound of a node costs level + 2 dependent
+// loads (one 32-byte index block per tree level, then one 64-byte block with the keys AND the running maxima) — the binary
+// searches of round 2 cost 8 .. 17, and a far launch lasts as long as the dependent loads of its slowest query.
 //
 // Compiled with -ffp-contract=off like chain_kernels.hip: the leaf evaluation must round like the reference's scalar code.
 #include <hip/hip_runtime.h>
@@ -61,18 +66,9 @@ __device__ __forceinline__ float best_candidate(float best, const int (&acc)[7],
     return best;
 }
 
-// number of keys < x among the n ascending keys at k (n a power of two >= 64)
-template <class K>
-__device__ __forceinline__ uint32_t count_below(const K* __restrict__ k, uint32_t n, K x) {
-    uint32_t lo = 0;
-    for (uint32_t step = n >> 1; step > 0; step >>= 1)
-        if (k[lo + step - 1] < x) lo += step;
-    return lo + (k[lo] < x ? 1u : 0u);
-}
-
 // ---- setup: the record image and the sort keys -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) far_init_kernel(const ClChainCombo* combos, const uint32_t* base, uint32_t n_combos, uint32_t r_pad,
-                                                       int32_t sig_bias, uint32_t band_shift, int* rec, uint32_t* key_off, unsigned long long* key_band, uint32_t* idx) {
+                                                       int32_t sig_bias, uint32_t band_shift, uint32_t off_bits, int* rec, uint32_t* key_off, uint32_t* key_band, uint32_t* idx) {
     const uint32_t c = blockIdx.y;
     const ClChainCombo cb = combos[c];
     const uint32_t b0 = base[c], b1 = c + 1 < n_combos ? base[c + 1] : r_pad;
@@ -80,19 +76,18 @@ __global__ void __launch_bounds__(256) far_init_kernel(const ClChainCombo* combo
     if (b0 + pos >= b1) return;
     const uint32_t g = b0 + pos;
     const int none = enc(CL_CHAIN_NEG);
-    uint32_t ins = 0xFFFFFFFFu, off = 0xFFFFFFFFu;
+    uint32_t ins = 0xFFFFFFFFu, off = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;   // padding: beyond every real key
     int32_t sg = 0;
-    unsigned long long bucket = 0xFFFFull;   // padding: beyond every real bucket (< 0x8000), keys stay below 2^48
     if (pos < cb.n_recs) {
         ins = cb.ins_t[pos]; off = cb.off[pos]; sg = cb.sigma[pos];
-        bucket = (unsigned long long)((uint32_t)(sg + sig_bias) >> band_shift);
+        kb = (((uint32_t)(sg + sig_bias) >> band_shift) << off_bits) | off;
     }
     int4* r = reinterpret_cast<int4*>(rec + (size_t)g * 12);
     r[0] = make_int4((int)ins, (int)off, sg, none);
     r[1] = make_int4(none, none, none, none);
     r[2] = make_int4(none, none, 0, 0);
     key_off[g] = off;
-    key_band[g] = (bucket << 32) | off;
+    key_band[g] = kb;
     idx[g] = g;
 }
 
@@ -101,10 +96,18 @@ __global__ void __launch_bounds__(256) far_node_key_kernel(const uint32_t* order
     if (i < n) node_key[i] = order[i] >> shift;
 }
 
-template <class K>
-__global__ void __launch_bounds__(256) far_gather_kernel(const uint32_t* perm, const K* src, uint32_t n, K* dst) {
+// the keys of one order of one level into their search tree: position i of the node-wise ascending order holds record perm[i]; its key
+// goes to the blocked array (8 keys | 8 running maxima per block) and, when i is a multiple of 8^j, to index array j
+__global__ void __launch_bounds__(256) far_layout_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key, uint32_t n, uint32_t* arena, uint32_t ord_off,
+                                                         uint32_t ix0, uint32_t ix1, uint32_t ix2, uint32_t ix3, uint32_t n_ix) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[perm[i]];
+    if (i >= n) return;
+    const uint32_t k = key[perm[i]];
+    arena[ord_off + ((i >> 3) << 4) + (i & 7u)] = k;
+    const uint32_t ix[4] = {ix0, ix1, ix2, ix3};
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if (j < n_ix && (i & ((8u << (3 * j)) - 1u)) == 0) arena[ix[j] + (i >> (3 * (j + 1)))] = k;
 }
 
 // ---- sealing: running maxima of the DP value in the node's two orders ----------------------------------------------------
@@ -112,16 +115,19 @@ __global__ void __launch_bounds__(256) far_gather_kernel(const uint32_t* perm, c
 __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* __restrict__ rec, const uint32_t* __restrict__ items, uint32_t item0) {
     const uint32_t it = items[item0 + blockIdx.x];
     const uint32_t l = it >> 28, node = it & 0x0FFFFFFFu;
-    const ClFarLevel L = F.lv[l];
     const uint32_t shift = kFarLeafShift + kFarFanShift * l;
     const uint32_t g0 = node << shift, n = 1u << shift;
     const uint32_t lane = threadIdx.x;
+    const uint32_t* __restrict__ perm_o = F.perm_o[l];
+    const uint32_t* __restrict__ perm_b = F.perm_b[l];
+    uint32_t* ord_o = F.arena + F.tab[l][0];
+    const bool banded = F.tab[l][1] != 0xFFFFFFFFu;   // sparse_chain_dp: one order only
+    uint32_t* ord_b = F.arena + (banded ? F.tab[l][1] : 0u);
     int carry_o = INT32_MIN, carry_b = INT32_MIN;
     uint32_t carry_bucket = 0xFFFFFFFEu;
     // the values come through two dependent gathers (order -> record -> dp): U chunks of 64 are fetched together so that a large node pays
     // one such round trip per U chunks, not per chunk (a node of 32 768 records: 512 chunks, 1-2.5 ms before, on the path of the far pass)
     constexpr uint32_t U = 8;
-    const bool banded = L.key_b != nullptr;   // sparse_chain_dp: one order only
     for (uint32_t at0 = 0; at0 < n; at0 += 64 * U) {
         int xs[U], ys[U];
         uint32_t bks[U];
@@ -130,8 +136,8 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
             const uint32_t at = at0 + 64 * u;
             if (at < n) {
                 const uint32_t i = g0 + at + lane;
-                xs[u] = rec[(size_t)L.perm_o[i] * 12 + 3];
-                if (banded) { ys[u] = rec[(size_t)L.perm_b[i] * 12 + 3]; bks[u] = (uint32_t)(L.key_b[i] >> 32); }
+                xs[u] = rec[(size_t)perm_o[i] * 12 + 3];
+                if (banded) { ys[u] = rec[(size_t)perm_b[i] * 12 + 3]; bks[u] = ord_b[((i >> 3) << 4) + (i & 7u)] >> F.off_bits; }
             }
         }
 #pragma unroll
@@ -139,6 +145,7 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
             const uint32_t at = at0 + 64 * u;
             if (at >= n) break;
             const uint32_t i = g0 + at + lane;
+            const uint32_t slot = ((i >> 3) << 4) + 8u + (i & 7u);
             // by offset: plain inclusive maximum
             int x = xs[u];
 #pragma unroll
@@ -147,7 +154,7 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
                 if ((int)lane >= d) x = max(x, o);
             }
             x = max(x, carry_o);
-            L.pm_o[i] = x;
+            ord_o[slot] = (uint32_t)x;
             carry_o = __shfl(x, 63);
             if (!banded) continue;
             // by (bucket, offset): maximum within the bucket
@@ -165,7 +172,7 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
                 }
             }
             if (!head) y = max(y, carry_b);   // the bucket began in an earlier chunk
-            L.pm_b[i] = y;
+            ord_b[slot] = (uint32_t)y;
             carry_b = __shfl(y, 63);
             carry_bucket = __shfl(bk, 63);
         }
@@ -183,90 +190,118 @@ struct FarQuery {
     double slack_q;
 };
 
+struct Blk8 { uint4 a, b; };
+__device__ __forceinline__ Blk8 load8(const uint32_t* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    return Blk8{q[0], q[1]};
+}
+__device__ __forceinline__ uint32_t count_lt(const Blk8& k, uint32_t x) {
+    return (k.a.x < x ? 1u : 0u) + (k.a.y < x ? 1u : 0u) + (k.a.z < x ? 1u : 0u) + (k.a.w < x ? 1u : 0u) +
+           (k.b.x < x ? 1u : 0u) + (k.b.y < x ? 1u : 0u) + (k.b.z < x ? 1u : 0u) + (k.b.w < x ? 1u : 0u);
+}
+// the largest running maximum among the block's positions whose key k satisfies lo <= k < hi (as k - lo < hi - lo, unsigned); the running
+// maxima do not decrease along such a run, so this is the running maximum at the LAST such position; INT32_MIN when there is none
+__device__ __forceinline__ int max_in(const Blk8& k, const Blk8& m, uint32_t lo, uint32_t span) {
+    int r = INT32_MIN;
+    r = max(r, k.a.x - lo < span ? (int)m.a.x : INT32_MIN); r = max(r, k.a.y - lo < span ? (int)m.a.y : INT32_MIN);
+    r = max(r, k.a.z - lo < span ? (int)m.a.z : INT32_MIN); r = max(r, k.a.w - lo < span ? (int)m.a.w : INT32_MIN);
+    r = max(r, k.b.x - lo < span ? (int)m.b.x : INT32_MIN); r = max(r, k.b.y - lo < span ? (int)m.b.y : INT32_MIN);
+    r = max(r, k.b.z - lo < span ? (int)m.b.z : INT32_MIN); r = max(r, k.b.w - lo < span ? (int)m.b.w : INT32_MIN);
+    return r;
+}
+
 // upper bound of every candidate the node (level lvl, first record g0 of the global image) can give the query; -inf if no
-// record of the node lies below the query's offset
+// record of the node lies below the query's offset.  `tab` = ClFarDevice::tab in LDS.
 template <bool SPARSE>
-__device__ __forceinline__ double node_bound(const ClFarDevice& F, uint32_t lvl, uint32_t g0, const FarQuery& Q) {
-    const ClFarLevel L = F.lv[lvl];
-    const uint32_t n = 1u << (kFarLeafShift + kFarFanShift * lvl);
-    if (SPARSE) {
-        const uint32_t cnt = count_below<uint32_t>(L.key_o + g0, n, Q.qoff);
-        if (cnt == 0) return -HUGE_VAL;
-        const double da = (double)dec(L.pm_o[g0 + cnt - 1]);
-        return da + (double)Q.w + 0x1p-21 * (fabs(da) + fabs((double)Q.w));
-    }
-    // four binary searches in lockstep (their loads overlap): offset < qoff in the offset order; (bucket, offset) < (b, qoff)
-    // for the three buckets around the query's in the bucket order.  A bucket no record can have searches for key 0.
-    const uint32_t* __restrict__ ko = L.key_o + g0;
-    const unsigned long long* __restrict__ kb = L.key_b + g0;
-    unsigned long long key[3];
-    uint32_t bk[3];
+__device__ __forceinline__ double node_bound(const ClFarDevice& F, const uint32_t* tab, uint32_t lvl, uint32_t g0, const FarQuery& Q) {
+    const uint32_t* __restrict__ A = F.arena;
+    const uint32_t* t = tab + lvl * kFarTabWidth;
+    // the searches run in lockstep (their loads overlap): offset < qoff in the offset order; key < (b << off_bits | qoff) for the three
+    // buckets b around the query's in the bucket order.  A bucket no record can have searches for key 0.
+    uint32_t xb[3], xlo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        bk[j] = Q.bq + (uint32_t)(j - 1);
-        key[j] = bk[j] >= 0x8000u ? 0ull : (((unsigned long long)bk[j] << 32) | Q.qoff);
+        const uint32_t bk = Q.bq + (uint32_t)(j - 1);
+        const bool real = !SPARSE && bk < (1u << (32 - F.off_bits)) - 1u && bk != 0;
+        xlo[j] = real ? bk << F.off_bits : 0u;
+        xb[j] = real ? xlo[j] + Q.qoff : 0u;   // qoff <= largest offset + 1 < 2^off_bits
     }
-    uint32_t lo = 0, l0 = 0, l1 = 0, l2 = 0;
-    for (uint32_t step = n >> 1; step > 0; step >>= 1) {
-        const uint32_t vo = ko[lo + step - 1];
-        const unsigned long long v0 = kb[l0 + step - 1], v1 = kb[l1 + step - 1], v2 = kb[l2 + step - 1];
-        lo += vo < Q.qoff ? step : 0u;
-        l0 += v0 < key[0] ? step : 0u;
-        l1 += v1 < key[1] ? step : 0u;
-        l2 += v2 < key[2] ? step : 0u;
+    uint32_t po = g0 >> (3 * (lvl + 1)), p0 = po, p1 = po, p2 = po;   // entry numbers in the current index array: the node's top block
+    bool none = false;
+    for (uint32_t j = lvl + 1; j >= 1; --j) {
+        const uint32_t* io = A + t[2 + (j - 1)];
+        const Blk8 eo = load8(io + po);
+        uint32_t co, c0 = 1, c1 = 1, c2 = 1;
+        if (!SPARSE) {
+            const uint32_t* ib = A + t[2 + kFarMaxLevels + (j - 1)];
+            const Blk8 e0 = load8(ib + p0), e1 = load8(ib + p1), e2 = load8(ib + p2);
+            c0 = count_lt(e0, xb[0]); c1 = count_lt(e1, xb[1]); c2 = count_lt(e2, xb[2]);
+        }
+        co = count_lt(eo, Q.qoff);
+        if (j == lvl + 1) none = co == 0;      // below the top block a followed entry is itself below the bound
+        po = (po + (co ? co - 1 : 0u)) << 3;
+        p0 = (p0 + (c0 ? c0 - 1 : 0u)) << 3; p1 = (p1 + (c1 ? c1 - 1 : 0u)) << 3; p2 = (p2 + (c2 ? c2 - 1 : 0u)) << 3;
     }
-    {
-        const uint32_t vo = ko[lo];
-        const unsigned long long v0 = kb[l0], v1 = kb[l1], v2 = kb[l2];
-        lo += vo < Q.qoff ? 1u : 0u;
-        l0 += v0 < key[0] ? 1u : 0u;
-        l1 += v1 < key[1] ? 1u : 0u;
-        l2 += v2 < key[2] ? 1u : 0u;
-    }
-    if (lo == 0) return -HUGE_VAL;
-    const uint32_t ix[3] = {l0, l1, l2};
-    const int pa = L.pm_o[g0 + lo - 1];
+    if (none) return -HUGE_VAL;
+    // po .. p2 are positions (multiples of 8) in the ascending orders: blocks of 16 words
+    const uint32_t* oo = A + t[0] + 2 * (size_t)po;
+    const Blk8 ko = load8(oo), mo = load8(oo + 8);
     int dband = INT32_MIN;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const uint32_t at = ix[j] ? ix[j] - 1 : 0;
-        const unsigned long long kk = kb[at];
-        const int pv = L.pm_b[g0 + at];
-        if (ix[j] != 0 && bk[j] < 0x8000u && (uint32_t)(kk >> 32) == bk[j]) dband = max(dband, pv);
+    if (!SPARSE) {
+        const uint32_t* ob = A + t[1];
+        const Blk8 k0 = load8(ob + 2 * (size_t)p0), m0 = load8(ob + 2 * (size_t)p0 + 8);
+        const Blk8 k1 = load8(ob + 2 * (size_t)p1), m1 = load8(ob + 2 * (size_t)p1 + 8);
+        const Blk8 k2 = load8(ob + 2 * (size_t)p2), m2 = load8(ob + 2 * (size_t)p2 + 8);
+        dband = max(max_in(k0, m0, xlo[0], xb[0] - xlo[0]), max(max_in(k1, m1, xlo[1], xb[1] - xlo[1]), max_in(k2, m2, xlo[2], xb[2] - xlo[2])));
     }
+    const int pa = max_in(ko, mo, 0u, Q.qoff);
+    if (pa == INT32_MIN) return -HUGE_VAL;
     const double da = (double)dec(pa);
+    if (SPARSE) return da + (double)Q.w + 0x1p-21 * (fabs(da) + fabs((double)Q.w));
     double m = da - F.band_pen;
     if (dband != INT32_MIN) m = fmax(m, (double)dec(dband));
     return m + (double)Q.w + 0x1p-21 * (fabs(da) + Q.slack_q);
 }
 
-// the exact evaluation of the sweep over the 64 records of a leaf
+// the exact evaluation of the sweep over the 64 records of a leaf, by the eight lanes of the query's group: lane `sub` takes records sub, sub + 8, ...
 template <bool SPARSE>
-__device__ __forceinline__ float scan_leaf(const int* __restrict__ rec, uint32_t g0, const FarQuery& Q, int (&acc)[7], float best, const double (&pen)[6]) {
-    const int none = enc(CL_CHAIN_NEG);
+__device__ __forceinline__ void scan_leaf(const int* __restrict__ rec, uint32_t g0, uint32_t sub, const FarQuery& Q, int (&acc)[7]) {
     const int4* r4 = reinterpret_cast<const int4*>(rec + (size_t)g0 * 12);
     if (SPARSE) {
-        for (uint32_t i = 0; i < 64; i += 4) {
-            int4 ra[4];
+        int4 ra[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ra[u] = r4[(i + u) * 3];
+        for (int u = 0; u < 8; ++u) ra[u] = r4[(sub + 8 * u) * 3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[0] = max(acc[0], ((uint32_t)ra[u].x <= Q.qt && (uint32_t)ra[u].y < Q.qoff) ? ra[u].w : INT32_MIN);
-        }
-        if (acc[0] > none) best = fmaxf(best, dec(acc[0]) + Q.w);
+        for (int u = 0; u < 8; ++u) acc[0] = max(acc[0], ((uint32_t)ra[u].x <= Q.qt && (uint32_t)ra[u].y < Q.qoff) ? ra[u].w : INT32_MIN);
     } else {
-        for (uint32_t i = 0; i < 64; i += 2) {
-            int4 ra[2], rb[2], rc[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { ra[u] = r4[(i + u) * 3]; rb[u] = r4[(i + u) * 3 + 1]; rc[u] = r4[(i + u) * 3 + 2]; }
+        for (int h = 0; h < 2; ++h) {
+            int4 ra[4], rb[4];
+            int2 rc[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = sub + 8 * (4 * h + u);
+                ra[u] = r4[i * 3]; rb[u] = r4[i * 3 + 1]; rc[u] = reinterpret_cast<const int2*>(r4 + i * 3 + 2)[0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 const int v[7] = {ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w, rc[u].x, rc[u].y};
                 accumulate(acc, Q.qt, Q.qoff, Q.q, (uint32_t)ra[u].x, (uint32_t)ra[u].y, ra[u].z, v);
             }
         }
+    }
+}
+
+template <bool SPARSE>
+__device__ __forceinline__ float best_of(float best, const int (&acc)[7], const FarQuery& Q, const double (&pen)[6]) {
+    if (SPARSE) {
+        if (acc[0] > enc(CL_CHAIN_NEG)) best = fmaxf(best, dec(acc[0]) + Q.w);
+    } else {
         best = best_candidate(best, acc, Q.w, pen);
     }
+    best = fmaxf(best, __shfl_xor(best, 1));
+    best = fmaxf(best, __shfl_xor(best, 2));
+    best = fmaxf(best, __shfl_xor(best, 4));
     return best;
 }
 
@@ -298,6 +333,9 @@ __device__ __forceinline__ void group_argmax(double& b, uint32_t& code) {
 
 template <bool SPARSE>
 __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDevice F, uint32_t first, uint32_t count, uint32_t end_block) {
+    __shared__ uint32_t s_tab[kFarMaxLevels * kFarTabWidth];
+    if (threadIdx.x < kFarMaxLevels * kFarTabWidth) s_tab[threadIdx.x] = F.tab_dev[threadIdx.x];
+    __syncthreads();
     const uint32_t c = blockIdx.y;
     const ClChainCombo cb = D.combos[c];
     const uint32_t sub = threadIdx.x & 7u;                       // lane within the query's group of eight
@@ -328,11 +366,12 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     const uint32_t base = D.far_base[c];
     const int* __restrict__ rec = D.far_rec;
     Q.slack_q = F.slack_t0 + F.slack_e0 * fabs((double)Q.q) + fabs((double)Q.w);
-    // shift bucket of the query; the host picks sig_bias so that every record's bucket lies in [1, 0x8000): a query whose biased
-    // shift is negative is more than a bucket width away from every record
+    // shift bucket of the query; the host picks sig_bias so that every record's bucket is >= 1: a query whose biased shift is negative is
+    // more than a bucket width away from every record
     const long long qb = (long long)Q.q + (long long)F.sig_bias;
     Q.bq = qb < 0 ? 0xFFFF0000u : (uint32_t)(qb >> F.band_shift);
     const uint32_t top = F.n_levels - 1;
+    const uint32_t gsh = (threadIdx.x & 63u) & ~7u;             // where the group's eight lanes sit in a ballot
 
     // bounds of the cover nodes, computed once by the probe: they depend on the query alone, only what they are compared with changes
     __shared__ double s_cover[32][kFarCoverCache][8];
@@ -348,7 +387,7 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
             uint32_t lvl, a = 0;
             next_cover(p, sub, top, lvl, a);
             if (lvl != 0xFFu) {
-                const double b = node_bound<SPARSE>(F, lvl, base + a, Q);
+                const double b = node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
                 if (round < kFarCoverCache) s_cover[grp][round][sub] = b;
                 const uint32_t code = (lvl << 28) | (a >> kFarLeafShift);
                 if (b > pb || (b == pb && code < pcode)) { pb = b; pcode = code; }
@@ -358,17 +397,15 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         while (pcode != 0xFFFFFFFFu && (pcode >> 28) != 0 && pb > -HUGE_VAL) {
             const uint32_t lvl = (pcode >> 28) - 1;
             const uint32_t a = ((pcode & 0x0FFFFFFFu) << kFarLeafShift) + (sub << (kFarLeafShift + kFarFanShift * lvl));
-            pb = node_bound<SPARSE>(F, lvl, base + a, Q);
+            pb = node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
             pcode = (lvl << 28) | (a >> kFarLeafShift);
             group_argmax(pb, pcode);
         }
-        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL && sub == 0) {
-            best = scan_leaf<SPARSE>(rec, base + ((pcode & 0x0FFFFFFFu) << kFarLeafShift), Q, acc, best, pen);
+        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL) {   // (uniform over the group)
+            scan_leaf<SPARSE>(rec, base + ((pcode & 0x0FFFFFFFu) << kFarLeafShift), sub, Q, acc);
+            best = best_of<SPARSE>(best, acc, Q, pen);
             ++n_scanned;
         }
-        best = fmaxf(best, __shfl_xor(best, 1));
-        best = fmaxf(best, __shfl_xor(best, 2));
-        best = fmaxf(best, __shfl_xor(best, 4));
     }
 
     // ---- the branch-and-bound proper, nearest nodes first
@@ -393,29 +430,34 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         } else {
             break;
         }
-        bool hit = false;
-        if (lvl != 0xFFu) hit = (cached ? s_cover[grp][cover_round - 1][sub] : node_bound<SPARSE>(F, lvl, base + a, Q)) >= (double)best;
-        if (hit && lvl == 0) { best = scan_leaf<SPARSE>(rec, base + a, Q, acc, best, pen); ++n_scanned; }
+        double bnd = -HUGE_VAL;
+        if (lvl != 0xFFu) bnd = cached ? s_cover[grp][cover_round - 1][sub] : node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
+        bool hit = lvl != 0xFFu && bnd >= (double)best;
+        // surviving leaves, nearest (lane 0) first, by the eight lanes together; each is tested again against what the ones before it gave
+        uint32_t leaves = (uint32_t)(__ballot(hit && lvl == 0) >> gsh) & 0xFFu;
+        while (leaves) {
+            const uint32_t j = (uint32_t)__builtin_ctz(leaves);
+            leaves &= leaves - 1;
+            const double bj = __shfl(bnd, (int)j, 8);
+            const uint32_t aj = __shfl(a, (int)j, 8);
+            if (bj >= (double)best) {
+                scan_leaf<SPARSE>(rec, base + aj, sub, Q, acc);
+                best = best_of<SPARSE>(best, acc, Q, pen);
+                ++n_scanned;
+            }
+        }
         // surviving inner nodes go on the stack, nearest (lane 0) on top
-        const bool push = hit && lvl != 0 && lvl != 0xFFu;
-        const unsigned long long bal = __ballot(push);
-        const uint32_t mask = (uint32_t)(bal >> ((threadIdx.x & 63u) & ~7u)) & 0xFFu;
+        const bool push = hit && lvl != 0 && bnd >= (double)best;
+        const uint32_t mask = (uint32_t)(__ballot(push) >> gsh) & 0xFFu;
         if (push) {
             const uint32_t above = __popc(mask >> (sub + 1));    // surviving lanes farther than this one go below it
             st[sp + above] = (lvl << 28) | (a >> kFarLeafShift);
         }
         sp += __popc(mask);
-        // the eight lanes share the best candidate found so far
-        best = fmaxf(best, __shfl_xor(best, 1));
-        best = fmaxf(best, __shfl_xor(best, 2));
-        best = fmaxf(best, __shfl_xor(best, 4));
     }
     // bookkeeping for the host's choice between this pass and the all-pairs sweep (cl_chain_api.cpp): leaves this query scanned
-    // against the leaves it had in range.  A scanned leaf costs a lane about what sixteen leaves cost the sweep (divergent loads
+    // against the leaves it had in range.  A scanned leaf costs about what sixteen leaves cost the sweep (divergent loads
     // instead of LDS broadcasts, plus the tests that led to it).
-    n_scanned += __shfl_xor(n_scanned, 1);
-    n_scanned += __shfl_xor(n_scanned, 2);
-    n_scanned += __shfl_xor(n_scanned, 4);
     if (sub == 0) {
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(D.status + 2);
         // only queries with a long history say anything about the trend (early ones open their few leaves whatever happens)
@@ -438,18 +480,16 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
 
 // ---- host entry points ---------------------------------------------------------------------------------------------------
 hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias, uint32_t band_shift,
-                             uint32_t* key_off, unsigned long long* key_band, uint32_t* idx, hipStream_t stream) {
+                             uint32_t off_bits, uint32_t* key_off, uint32_t* key_band, uint32_t* idx, hipStream_t stream) {
     hipLaunchKernelGGL(far_init_kernel, dim3((max_padded + 255) / 256, D.n_combos), dim3(256), 0, stream, D.combos, d_base, D.n_combos, r_pad,
-                       sig_bias, band_shift, D.far_rec, key_off, key_band, idx);
+                       sig_bias, band_shift, off_bits, D.far_rec, key_off, key_band, idx);
     return hipGetLastError();
 }
 
 size_t cl_chain_far_sort_temp_bytes(uint32_t n) {
-    size_t a = 0, b = 0, c = 0;
+    size_t a = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    c = a > b ? a : b;
-    return c + 256;
+    return a + 256;
 }
 
 // order_out = idx sorted by key (32-bit keys, bits [0, end_bit))
@@ -458,23 +498,15 @@ hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* ke
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream);
 }
 
-hipError_t cl_chain_far_sort64(void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
-                               uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t stream) {
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream);
-}
-
 hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream) {
     hipLaunchKernelGGL(far_node_key_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, order, n, shift, node_key);
     return hipGetLastError();
 }
 
-hipError_t cl_chain_far_gather32(const uint32_t* perm, const uint32_t* src, uint32_t n, uint32_t* dst, hipStream_t stream) {
-    hipLaunchKernelGGL(far_gather_kernel<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, stream, perm, src, n, dst);
-    return hipGetLastError();
-}
-
-hipError_t cl_chain_far_gather64(const uint32_t* perm, const unsigned long long* src, uint32_t n, unsigned long long* dst, hipStream_t stream) {
-    hipLaunchKernelGGL(far_gather_kernel<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, stream, perm, src, n, dst);
+// the search tree of one order of level `lvl`: arena[ord_off ...] blocked keys, arena[ix[j] ...] every 8^(j+1)-th key (j = 0 .. lvl)
+hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32_t n, uint32_t* arena, uint32_t ord_off, const uint32_t* ix, uint32_t n_ix,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(far_layout_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, perm, key, n, arena, ord_off, ix[0], ix[1], ix[2], ix[3], n_ix);
     return hipGetLastError();
 }
 

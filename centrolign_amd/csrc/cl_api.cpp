@@ -56,6 +56,8 @@ const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && 
 
 }  // namespace
 
+std::atomic<size_t> cl_pinned_total{0};
+
 void cl_set_error(cl_context* ctx, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -63,7 +65,11 @@ void cl_set_error(cl_context* ctx, const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_error = buf;
-    if (ctx) ctx->error = buf;
+    if (ctx) {   // worker threads of cl_msa report into the caller's context: one writer at a time
+        static std::mutex error_mutex;
+        std::lock_guard<std::mutex> lock(error_mutex);
+        ctx->error = buf;
+    }
 }
 #define set_error cl_set_error
 
@@ -763,7 +769,7 @@ void cl_context_destroy(cl_context* ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    cl_pinned_release(ctx);
     for (auto& ring : ctx->ev_ring) for (hipEvent_t e : ring) if (e) (void)hipEventDestroy(e);
     {
         std::lock_guard<std::mutex> lock(ctx->pool_mutex);

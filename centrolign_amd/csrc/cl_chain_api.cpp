@@ -42,15 +42,13 @@ hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t
 hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
 // chain_far.hip
 hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias, uint32_t band_shift,
-                             uint32_t* key_off, unsigned long long* key_band, uint32_t* idx, hipStream_t stream);
+                             uint32_t off_bits, uint32_t* key_off, uint32_t* key_band, uint32_t* idx, hipStream_t stream);
 size_t cl_chain_far_sort_temp_bytes(uint32_t n);
 hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                                uint32_t n, int end_bit, hipStream_t stream);
-hipError_t cl_chain_far_sort64(void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
-                               uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t stream);
 hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream);
-hipError_t cl_chain_far_gather32(const uint32_t* perm, const uint32_t* src, uint32_t n, uint32_t* dst, hipStream_t stream);
-hipError_t cl_chain_far_gather64(const uint32_t* perm, const unsigned long long* src, uint32_t n, unsigned long long* dst, hipStream_t stream);
+hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32_t n, uint32_t* arena, uint32_t ord_off, const uint32_t* ix, uint32_t n_ix,
+                               hipStream_t stream);
 hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, hipStream_t stream);
 hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
@@ -727,9 +725,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<uint32_t> i_in, i_out;
     DevBuf<char> vtemp;
     // branch-and-bound far pass (chain_far.hip)
-    DevBuf<int> d_far_rec, d_far_pm[2 * kFarMaxLevels];
-    DevBuf<uint32_t> d_far_base, d_far_u32[6 + 3 * kFarMaxLevels], d_seal_items;
-    DevBuf<unsigned long long> d_far_u64[2 + kFarMaxLevels];
+    DevBuf<int> d_far_rec;
+    DevBuf<uint32_t> d_far_base, d_far_u32[7], d_far_perm[2 * kFarMaxLevels], d_far_arena, d_far_tab, d_seal_items;
     DevBuf<char> d_far_temp;
     ClFarDevice F{};
     std::vector<uint32_t> seal_off;   // [n_macro + 1] into d_seal_items
@@ -744,9 +741,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         d_group_end.release(); d_status.release(); d_xch.release();
         k_in.release(); k_out.release(); i_in.release(); i_out.release(); vtemp.release();
         d_far_rec.release(); d_far_base.release(); d_seal_items.release(); d_far_temp.release();
-        for (auto& b : d_far_pm) b.release();
+        for (auto& b : d_far_perm) b.release();
         for (auto& b : d_far_u32) b.release();
-        for (auto& b : d_far_u64) b.release();
+        d_far_arena.release(); d_far_tab.release();
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
@@ -881,18 +878,26 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             max_padded = std::max(max_padded, padded);
             r_pad += padded;
         }
-        // shift buckets: kFarBandShift wide unless the shifts then span more than the 15 bits a bucket number has (CL_CHAIN_FAR_BAND for measurements)
+        // shift buckets: kFarBandShift wide (CL_CHAIN_FAR_BAND for measurements) unless bucket number and offset then do not fit the 32 bits of a
+        // bucket key: bucket << off_bits | offset, off_bits enough for the largest offset + 1 (what a query's offset bound can be)
         static const int band_env = [] { const char* e = getenv("CL_CHAIN_FAR_BAND"); int v = e ? atoi(e) : 0; return v >= 4 && v <= 24 ? v : kFarBandShift; }();
         uint32_t band_shift = (uint32_t)band_env;
-        while (smin != INT64_MAX && band_shift < 30 && (((smax - smin) >> band_shift) + 3) >= 0x7FFF) ++band_shift;
+        uint32_t max_off = 0;
+        for (const Combo& c : combos) for (uint32_t o : c.off) max_off = std::max(max_off, o);
+        uint32_t off_bits = 1;
+        while (off_bits < 31 && ((uint64_t)max_off + 1) >> off_bits) ++off_bits;
+        // buckets are numbered from 1; bucket + 2 must stay below 2^(32 - off_bits) - 1 (the query's upper neighbour bucket, and the padding key above all)
+        while (smin != INT64_MAX && band_shift < 30 && (((smax - smin) >> band_shift) + 4) >= (int64_t)((1ull << (32 - off_bits)) - 1)) ++band_shift;
         const int64_t bias = (1ll << band_shift) - smin;
-        if (r_pad == 0 || r_pad >= (1ull << 31) || smin == INT64_MAX || smax + bias >= (1ll << 31) || bias >= (1ll << 31)) use_far = false;
+        if (r_pad == 0 || r_pad >= (1ull << 31) || smin == INT64_MAX || smax + bias >= (1ll << 31) || bias >= (1ll << 31) || off_bits >= 28 ||
+            (((smax - smin) >> band_shift) + 4) >= (int64_t)((1ull << (32 - off_bits)) - 1)) use_far = false;
         if (use_far) {
             const uint32_t R = (uint32_t)r_pad;
             F.n_levels = n_levels;
             F.r_pad = R;
             F.sig_bias = (int32_t)bias;
             F.band_shift = band_shift;
+            F.off_bits = off_bits;
             double pw = 1e300, omax = 0, emax = 0;
             for (int k = 0; k < 3; ++k) {
                 pw = std::min(pw, local_scale * (cp->gap_open[k] + cp->gap_extend[k] * (double)(1ull << band_shift)));
@@ -906,34 +911,53 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             CH(d_far_base.upload(ctx, base));
             D.far_rec = d_far_rec.p;
             D.far_base = d_far_base.p;
-            // scratch: 0 key_off, 1 idx, 2 order_off, 3 order_band, 4 node keys in, 5 node keys out / sorted-key sink; u64: 0 key_band, 1 sorted sink
-            for (int i = 0; i < 6; ++i) CH(d_far_u32[i].alloc(ctx, R));
-            for (int i = 0; i < 2; ++i) CH(d_far_u64[i].alloc(ctx, R));
+            // the arena: per level the two blocked orders (2 R words each) and their index arrays (R / 8, R / 64, ...)
+            uint64_t words = 0;
+            std::vector<uint32_t> tab((size_t)kFarMaxLevels * kFarTabWidth, 0xFFFFFFFFu);
+            for (uint32_t l = 0; l < n_levels; ++l) {
+                for (int side = 0; side < (sparse ? 1 : 2); ++side) {
+                    tab[l * kFarTabWidth + side] = (uint32_t)words;
+                    words += 2ull * R;
+                    for (uint32_t j = 0; j <= l; ++j) {
+                        tab[l * kFarTabWidth + 2 + side * kFarMaxLevels + j] = (uint32_t)words;
+                        words += ((uint64_t)R >> (3 * (j + 1))) + 8;
+                        words = (words + 7) & ~7ull;    // 32-byte blocks stay aligned
+                    }
+                }
+            }
+            if (words >= (1ull << 32)) use_far = false;
+            if (use_far) {
+            CH(d_far_arena.alloc(ctx, words));
+            CH(d_far_tab.upload(ctx, tab));
+            F.arena = d_far_arena.p;
+            F.tab_dev = d_far_tab.p;
+            for (uint32_t l = 0; l < (uint32_t)kFarMaxLevels; ++l) for (int w = 0; w < kFarTabWidth; ++w) F.tab[l][w] = tab[l * kFarTabWidth + w];
+            // scratch: 0 key_off, 1 idx, 2 order_off, 3 order_band, 4 node keys in, 5 node keys out / sorted-key sink, 6 key_band
+            for (int i = 0; i < 7; ++i) CH(d_far_u32[i].alloc(ctx, R));
             const size_t temp_bytes = cl_chain_far_sort_temp_bytes(R);
             CH(d_far_temp.alloc(ctx, temp_bytes));
-            hipError_t fe = cl_chain_far_init(D, d_far_base.p, (uint32_t)max_padded, R, F.sig_bias, F.band_shift, d_far_u32[0].p, d_far_u64[0].p, d_far_u32[1].p, ctx->stream);
+            hipError_t fe = cl_chain_far_init(D, d_far_base.p, (uint32_t)max_padded, R, F.sig_bias, F.band_shift, F.off_bits, d_far_u32[0].p, d_far_u32[6].p, d_far_u32[1].p, ctx->stream);
             if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[0].p, d_far_u32[5].p, d_far_u32[1].p, d_far_u32[2].p, R, 32, ctx->stream);
-            if (fe == hipSuccess && !sparse) fe = cl_chain_far_sort64(d_far_temp.p, temp_bytes, d_far_u64[0].p, d_far_u64[1].p, d_far_u32[1].p, d_far_u32[3].p, R, 48, ctx->stream);
+            if (fe == hipSuccess && !sparse) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[6].p, d_far_u32[5].p, d_far_u32[1].p, d_far_u32[3].p, R, 32, ctx->stream);
             for (uint32_t l = 0; l < n_levels && fe == hipSuccess; ++l) {
                 const uint32_t shift = kFarLeafShift + kFarFanShift * l;
                 int bits = 1;
                 while (((uint64_t)R >> shift) >> bits) ++bits;
-                DevBuf<uint32_t>& perm_o = d_far_u32[6 + 3 * l];
-                DevBuf<uint32_t>& perm_b = d_far_u32[6 + 3 * l + 1];
-                DevBuf<uint32_t>& key_o = d_far_u32[6 + 3 * l + 2];
-                CH(perm_o.alloc(ctx, R)); CH(key_o.alloc(ctx, R)); CH(d_far_pm[2 * l].alloc(ctx, R));
+                DevBuf<uint32_t>& perm_o = d_far_perm[2 * l];
+                DevBuf<uint32_t>& perm_b = d_far_perm[2 * l + 1];
+                CH(perm_o.alloc(ctx, R));
                 fe = cl_chain_far_node_keys(d_far_u32[2].p, R, shift, d_far_u32[4].p, ctx->stream);
                 if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[4].p, d_far_u32[5].p, d_far_u32[2].p, perm_o.p, R, bits, ctx->stream);
-                if (fe == hipSuccess) fe = cl_chain_far_gather32(perm_o.p, d_far_u32[0].p, R, key_o.p, ctx->stream);
-                F.lv[l].key_o = key_o.p; F.lv[l].pm_o = d_far_pm[2 * l].p; F.lv[l].perm_o = perm_o.p;
+                if (fe == hipSuccess) fe = cl_chain_far_layout(perm_o.p, d_far_u32[0].p, R, F.arena, F.tab[l][0], &F.tab[l][2], l + 1, ctx->stream);
+                F.perm_o[l] = perm_o.p;
                 if (!sparse) {
-                    CH(perm_b.alloc(ctx, R)); CH(d_far_u64[2 + l].alloc(ctx, R)); CH(d_far_pm[2 * l + 1].alloc(ctx, R));
+                    CH(perm_b.alloc(ctx, R));
                     if (fe == hipSuccess) fe = cl_chain_far_node_keys(d_far_u32[3].p, R, shift, d_far_u32[4].p, ctx->stream);
                     if (fe == hipSuccess) fe = cl_chain_far_sort32(d_far_temp.p, temp_bytes, d_far_u32[4].p, d_far_u32[5].p, d_far_u32[3].p, perm_b.p, R, bits, ctx->stream);
-                    if (fe == hipSuccess) fe = cl_chain_far_gather64(perm_b.p, d_far_u64[0].p, R, d_far_u64[2 + l].p, ctx->stream);
-                    F.lv[l].key_b = d_far_u64[2 + l].p; F.lv[l].pm_b = d_far_pm[2 * l + 1].p; F.lv[l].perm_b = perm_b.p;
-                } else {   // sparse_chain_dp has no shifts: the bucket order is the offset order
-                    F.lv[l].key_b = nullptr; F.lv[l].pm_b = d_far_pm[2 * l].p; F.lv[l].perm_b = perm_o.p;
+                    if (fe == hipSuccess) fe = cl_chain_far_layout(perm_b.p, d_far_u32[6].p, R, F.arena, F.tab[l][1], &F.tab[l][2 + kFarMaxLevels], l + 1, ctx->stream);
+                    F.perm_b[l] = perm_b.p;
+                } else {   // sparse_chain_dp has no shifts: one order
+                    F.perm_b[l] = perm_o.p;
                 }
             }
             if (fe != hipSuccess) { cl_set_error(ctx, "far pass setup failed: %s", hipGetErrorString(fe)); cleanup(); return CL_ERR_HIP; }
@@ -958,8 +982,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 seal_off[k + 1] = (uint32_t)items.size();
             }
             CH(d_seal_items.upload(ctx, items));
-            for (int i = 1; i < 6; ++i) d_far_u32[i].release();   // scratch (key_off stays: nothing reads it again, but it is small)
-            d_far_u64[1].release();
+            for (int i = 0; i < 7; ++i) d_far_u32[i].release();   // scratch
+            }
         }
     }
     lap("far pass setup");

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,7 @@ struct cl_context {
     // at the link's rate, copies into pageable memory at a tenth of it, and locking pages is too slow to do per call
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    std::mutex pinned_mutex;   // cl_merge grows the area on a helper thread beside the match finding: every access goes through cl_pinned
     // device memory pool (cl_dev_alloc / cl_dev_free).  hipFree waits for the WHOLE device and hipMalloc takes a process-wide lock: with
     // several contexts at work (the worker threads of an MSA) every release in one of them stalled on the others' kernels.  Released
     // blocks are kept here and handed out again, largest-fit within 2x; they go back to the driver when the context is destroyed or the
@@ -95,16 +97,34 @@ inline void cl_dev_free(cl_context* ctx, void* p) {
     ctx->pool_free_bytes += it->second;
 }
 
-// at least `bytes` of page-locked host memory owned by the context (contents undefined; one user at a time); nullptr when it cannot be had
-inline void* cl_pinned(cl_context* ctx, size_t bytes) {
-    if (bytes <= ctx->pinned_bytes) return ctx->pinned;
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+// at least `bytes` of page-locked host memory owned by the context (contents undefined; one user at a time); nullptr when it cannot be had.
+// Serialised per context (cl_merge pre-pins on a helper thread), and capped over the whole process: page-locked memory is taken from
+// every other process of the host, and an MSA may run up to sixteen worker contexts (CL_PINNED_CAP_GB, default 16; callers fall back
+// to pageable copies when the cap is reached).
+extern std::atomic<size_t> cl_pinned_total;   // cl_api.cpp
+inline size_t cl_pinned_cap() {
+    static const size_t cap = [] { const char* e = getenv("CL_PINNED_CAP_GB"); const long v = e ? atol(e) : 16; return (size_t)(v < 0 ? 0 : v) << 30; }();
+    return cap;
+}
+inline void cl_pinned_release_locked(cl_context* ctx) {
+    if (ctx->pinned) { (void)hipHostFree(ctx->pinned); cl_pinned_total -= ctx->pinned_bytes; }
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
+}
+inline void* cl_pinned(cl_context* ctx, size_t bytes) {
+    std::lock_guard<std::mutex> lock(ctx->pinned_mutex);
+    if (bytes <= ctx->pinned_bytes) return ctx->pinned;
+    cl_pinned_release_locked(ctx);
     const size_t want = bytes + bytes / 8;
-    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (cl_pinned_total.fetch_add(want) + want > cl_pinned_cap()) { cl_pinned_total -= want; return nullptr; }
+    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; cl_pinned_total -= want; (void)hipGetLastError(); return nullptr; }
     ctx->pinned_bytes = want;
     return ctx->pinned;
+}
+// give the area back (after the largest merge of a run; the next user locks what it needs)
+inline void cl_pinned_release(cl_context* ctx) {
+    std::lock_guard<std::mutex> lock(ctx->pinned_mutex);
+    cl_pinned_release_locked(ctx);
 }
 
 // defined in cl_api.cpp

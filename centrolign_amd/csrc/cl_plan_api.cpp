@@ -99,7 +99,9 @@ struct GuideTree {
                 else if (!q && (s[i] == '(' || s[i] == ')' || s[i] == ',' || s[i] == ';')) marks.push_back(i);
             }
         }
-        if (marks.size() == 1) {   // no parentheses, no commas: one node
+        bool any_paren = false;
+        for (size_t m : marks) any_paren |= s[m] == '(' || s[m] == ')';
+        if (!any_paren) {   // no parentheses (src/tree.cpp:62-70): one node whose label is everything up to the ';', commas included
             root = add(kNoNode);
             return set_label(root, s, 0, semi) && index_labels();
         }

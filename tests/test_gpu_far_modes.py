@@ -1,0 +1,72 @@
+"""GPU suite: the far pass of the chaining DP (chain_far.hip) skips work on the strength of a floating-point bound and may hand the rest
+of a DP to the all-pairs sweep at a checkpoint.  Whatever path is taken, every DP value and the chain must be bit-identical: the same
+multi-combination DP (2 + 2 paths, several hundred macro-blocks, repeats dense enough that the automatic choice switches to the sweep
+in mid-DP) is run with the automatic choice, with the branch-and-bound pinned, with the sweep pinned, without the far pass, and on the
+round-1 per-block kernels — each in a process of its own, because the switches are read once."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from centrolign_amd import capi, synth
+from oracle import pyoracle as po
+from tests import far_ab_child
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = [
+    ("auto", {}),
+    ("bb", {"CL_CHAIN_FAR_MODE": "bb"}),
+    ("sweep", {"CL_CHAIN_FAR_MODE": "sweep"}),
+    ("no_far", {"CL_CHAIN_NO_FAR_PRUNE": "1"}),
+    ("per_block", {"CL_CHAIN_NO_FAR_PRUNE": "1", "CL_CHAIN_OLD_WALK": "1"}),
+]
+
+
+@pytest.fixture(scope="module")
+def dense_input(gpu_ctx, tmp_path_factory):
+    """root merge of a 4 x 100 kbp MSA: 2 + 2 paths; ~350 k match pairs out of the millions the 100 kbp arrays have"""
+    seqs = synth.hor_sequences(11, 100000, 4)
+    leaves = [capi.leaf_graph(s) for s in seqs]
+    scale = sum(gpu_ctx.leaf_intrinsic_scale(g) for g in leaves) / 4
+    left = gpu_ctx.merge(leaves[0], leaves[1], score_scale=scale)["fused"]
+    right = gpu_ctx.merge(leaves[2], leaves[3], score_scale=scale)["fused"]
+    from bench import relabelled
+    g1, g2 = relabelled(left, 5, 6), relabelled(right, 7, 8)
+    ms = po.budget_subset(gpu_ctx.find_matches(g1, g2), 350000, seed=5)
+    assert ms.n_pairs() > 300000
+    path = str(tmp_path_factory.mktemp("far_ab") / "dense.npz")
+    far_ab_child.save_input(path, g1, g2, ms, 0.7)
+    return path
+
+
+def run_variant(path, kind, env_extra):
+    env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
+    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK"):
+        if k not in env_extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    m = re.search(r"RESULT pairs=(\d+) anchors=(\d+) dp=(\w+) chain=(\w+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    return m.groups(), r.stderr
+
+
+@pytest.mark.parametrize("kind", ["affine", "sparse"])
+def test_every_far_mode_gives_the_same_dp_values_and_chain(dense_input, kind):
+    results = {}
+    for name, env in VARIANTS:
+        results[name], err = run_variant(dense_input, kind, env)
+        if name == "auto" and kind == "affine":
+            # the automatic choice took its decision at a checkpoint in mid-DP, and on this input it is the sweep
+            assert "far pass after" in err and "all-pairs sweep" in err, err[-3000:]
+        if name == "bb":
+            assert "all-pairs sweep" not in err
+    want = results["per_block"]
+    assert int(want[0]) > 300000 and int(want[1]) > 10
+    for name, got in results.items():
+        assert got == want, "%s differs from the per-block all-pairs path: %s vs %s" % (name, got, want)

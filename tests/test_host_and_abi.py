@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), "libcentrolign_amd.so does not export %s" % sym
     assert set(capi.EXPORTED_SYMBOLS) == declared
-    assert lib.cl_abi_version() == 1
+    assert lib.cl_abi_version() == capi.ABI_VERSION
 
 
 def test_default_params_match_cli_values():
