@@ -858,7 +858,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // within 3 % for 2, 3 and 4 and 5 % slower at 6 (the near pass grows with the lag).  CL_CHAIN_FAR_LAG=1..8 for measurements
     // The gap-free DP's far pass opens a tenth of the leaves, so its near pass is what grows: 175 ms at 2 in flight, 253 ms at 4 — it keeps 2
     static const uint32_t far_lag_env = [] { const char* e = getenv("CL_CHAIN_FAR_LAG"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= (int)kFarLag ? v : 0); }();
-    const uint32_t far_lag = far_lag_env ? far_lag_env : sparse ? 2u : 4u;
+    const uint32_t far_lag = far_lag_env ? far_lag_env : 2u;   // round 3 (8-ary search trees, leaves scanned by eight lanes): 2 x 1 Mbp affine 313 / 396 / 341 / 393 ms at 2 / 3 / 4 / 6; root of 10 x 1 Mbp 1.22 s at 2, 1.39 s at 4
     bool use_far = use_walk && !no_far_env && n_macro_all >= far_lag + 3;
     if (use_far) {
         uint32_t max_n = 0;
