@@ -1108,7 +1108,106 @@ EXPORTED_SYMBOLS = [
     "cl_estimate_score_scale", "cl_leaf_intrinsic_scale", "cl_leaf_graph", "cl_explicit_cigar", "cl_write_gfa",
     "cl_fuse", "cl_owned_base_graph_view", "cl_owned_base_graph_free", "cl_merge_params_default", "cl_merge", "cl_merge_result_free",
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
+    "cl_bond_params_default", "cl_identify_bonds", "cl_bonds_free", "cl_leaf_calibrate", "cl_leaf_calibration_free", "cl_alignment_list_free",
+    "cl_leaf_bond_alignments", "cl_simplify_bubbles", "cl_apply_bonds",
 ]
+
+
+class BondParams(C.Structure):
+    """cl_bond_params: Bonder's tunables as the CLI sets them (src/parameters.cpp:91-97)"""
+    _fields_ = [("min_opt_proportion", C.c_double), ("include_gap_scores", C.c_int), ("min_length", C.c_double),
+                ("deviation_drift_factor", C.c_double), ("separation_drift_factor", C.c_double),
+                ("deduplication_slosh_proportion", C.c_double), ("trim_window_proportion", C.c_double)]
+
+
+class ChainAnchorsC(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("walk_off", C.c_void_p), ("walk1", C.c_void_p), ("walk2", C.c_void_p), ("score", C.c_void_p),
+                ("gap_after", C.c_void_p), ("gap_score_after", C.c_void_p)]
+
+
+class BondsC(C.Structure):
+    _fields_ = [("n_intervals", C.c_uint64), ("interval_off", C.POINTER(C.c_uint64)), ("offset1", C.POINTER(C.c_uint64)),
+                ("offset2", C.POINTER(C.c_uint64)), ("length", C.POINTER(C.c_uint64)), ("score", C.POINTER(C.c_double))]
+
+
+class AlignmentListC(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("alignments", C.POINTER(AlignmentC))]
+
+
+def bond_params(min_length=None, **kw):
+    lib = load_library()
+    bp = BondParams()
+    lib.cl_bond_params_default(C.byref(bp))
+    if min_length is not None:
+        bp.min_length = float(min_length)
+    for k, v in kw.items():
+        setattr(bp, k, v)
+    return bp
+
+
+def _chain_anchors(chain):
+    """dict(walk_off, walk1, walk2, score, gap_after, gap_score_after) -> (ChainAnchorsC, keep-alive arrays)"""
+    keep = [np.ascontiguousarray(chain["walk_off"], np.uint64), np.ascontiguousarray(chain["walk1"], np.uint32),
+            np.ascontiguousarray(chain["walk2"], np.uint32), np.ascontiguousarray(chain["score"], np.float64),
+            np.ascontiguousarray(chain["gap_after"], np.int64), np.ascontiguousarray(chain["gap_score_after"], np.float64)]
+    c = ChainAnchorsC(max(len(keep[0]) - 1, 0), *[a.ctypes.data for a in keep])
+    return c, keep
+
+
+def identify_bonds(leaf, opt_chain, secondary_chain, params=None, deduplicate=True):
+    """Bonder::identify_bonds (+ deduplicate_self_bonds) on a leaf against itself (include/centrolign/bonder.hpp:116-452, src/bonder.cpp:473-551);
+    host only.  Chains: dicts of walk_off, walk1, walk2, score, gap_after, gap_score_after.  Returns dict(interval_off, offset1, offset2, length, score)"""
+    lib = load_library()
+    lib.cl_identify_bonds.restype = C.c_int
+    lib.cl_identify_bonds.argtypes = [C.POINTER(BaseGraphC), C.POINTER(ChainAnchorsC), C.POINTER(ChainAnchorsC), C.POINTER(BondParams), C.c_int, C.POINTER(BondsC)]
+    params = params or bond_params()
+    g = leaf.as_c()
+    oc, k1 = _chain_anchors(opt_chain)
+    sc, k2 = _chain_anchors(secondary_chain)
+    out = BondsC()
+    rc = lib.cl_identify_bonds(C.byref(g), C.byref(oc), C.byref(sc), C.byref(params), int(deduplicate), C.byref(out))
+    if rc:
+        raise ClError(rc, "cl_identify_bonds")
+    try:
+        n = int(out.n_intervals)
+        off = np.ctypeslib.as_array(out.interval_off, shape=(n + 1,)).copy()
+        t = int(off[-1])
+
+        def arr(ptr):
+            return np.ctypeslib.as_array(ptr, shape=(max(t, 1),))[:t].copy()
+        return dict(interval_off=off, offset1=arr(out.offset1), offset2=arr(out.offset2), length=arr(out.length), score=arr(out.score))
+    finally:
+        lib.cl_bonds_free(C.byref(out))
+
+
+def simplify_bubbles(graph):
+    """simplify_bubbles + purge_uncovered_nodes (src/modify_graph.cpp:89-382); host only"""
+    lib = load_library()
+    lib.cl_simplify_bubbles.restype = C.c_int
+    lib.cl_simplify_bubbles.argtypes = [C.POINTER(BaseGraphC), C.POINTER(C.c_void_p)]
+    g, h = graph.as_c(), C.c_void_p()
+    rc = lib.cl_simplify_bubbles(C.byref(g), C.byref(h))
+    if rc:
+        raise ClError(rc, "cl_simplify_bubbles")
+    return _take_owned_base_graph(lib, h)
+
+
+def apply_bonds(root, path_of_alignment, alignments):
+    """Core::apply_bonds up to the polishing step (src/core.cpp:613-645): bond alignments in path positions -> fused and simplified graph; host only"""
+    lib = load_library()
+    lib.cl_apply_bonds.restype = C.c_int
+    lib.cl_apply_bonds.argtypes = [C.POINTER(BaseGraphC), C.c_uint64, C.c_void_p, C.POINTER(AlignmentC), C.POINTER(C.c_void_p)]
+    g, h = root.as_c(), C.c_void_p()
+    keep = [np.ascontiguousarray(a, np.uint64).reshape(-1, 2) for a in alignments]
+    arr = (AlignmentC * max(len(keep), 1))()
+    for i, a in enumerate(keep):
+        arr[i].n_pairs = len(a)
+        arr[i].pairs = a.ctypes.data_as(C.POINTER(C.c_uint64))
+    pa = np.ascontiguousarray(path_of_alignment, np.uint64)
+    rc = lib.cl_apply_bonds(C.byref(g), len(keep), pa.ctypes.data, arr, C.byref(h))
+    if rc:
+        raise ClError(rc, "cl_apply_bonds")
+    return _take_owned_base_graph(lib, h)
 
 
 def _take_mask(lib, ptr, n):
@@ -1377,6 +1476,51 @@ class Context:
         g, mp, scale = leaf.as_c(), match_params(max_count, True, params), C.c_double(0)
         self._check(self.lib.cl_leaf_intrinsic_scale(self.handle, C.byref(g), C.byref(mp), C.byref(ap), C.byref(scale)))
         return float(scale.value)
+
+    def leaf_calibrate(self, leaf, max_count=3000, max_num_match_pairs=1250000, params=None, fill_in=True):
+        """cl_leaf_calibrate: the leaf's intrinsic scale plus an opaque handle on what the tandem-duplication rounds read (the self matches,
+        the main-diagonal chain); returns (scale, handle) — release with free_leaf_calibration"""
+        ap = AnchorParams()
+        ap.chain = params or default_chain_params()
+        ap.max_num_match_pairs = int(max_num_match_pairs)
+        ap.score_scale = 1.0
+        ap.autocalibrate_gap_penalties = 1
+        ap.do_fill_in_anchoring = int(fill_in)
+        g, mp, scale, h = leaf.as_c(), match_params(max_count, True, params), C.c_double(0), C.c_void_p()
+        self.lib.cl_leaf_calibrate.restype = C.c_int
+        self.lib.cl_leaf_calibrate.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.c_void_p, C.POINTER(AnchorParams), C.POINTER(C.c_double), C.POINTER(C.c_void_p)]
+        self._check(self.lib.cl_leaf_calibrate(self.handle, C.byref(g), C.byref(mp), C.byref(ap), C.byref(scale), C.byref(h)))
+        return float(scale.value), h
+
+    def free_leaf_calibration(self, h):
+        self.lib.cl_leaf_calibration_free.argtypes = [C.c_void_p]
+        self.lib.cl_leaf_calibration_free(h)
+
+    def leaf_bond_alignments(self, leaf, memo, score_scale, max_num_match_pairs=1250000, params=None, fill_in=True, stitch_params=None,
+                             bonds=None, max_rounds=3):
+        """cl_leaf_bond_alignments: the tandem-duplication rounds of one leaf (src/core.cpp:199-296); list of (n, 2) uint64 alignments in
+        path positions"""
+        ap = AnchorParams()
+        ap.chain = params or default_chain_params()
+        ap.max_num_match_pairs = int(max_num_match_pairs)
+        ap.score_scale = float(score_scale)
+        ap.autocalibrate_gap_penalties = 1
+        ap.do_fill_in_anchoring = int(fill_in)
+        sp = stitch_params or default_stitch_params()
+        bp = bonds or bond_params()
+        g, out = leaf.as_c(), AlignmentListC()
+        self.lib.cl_leaf_bond_alignments.restype = C.c_int
+        self.lib.cl_leaf_bond_alignments.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.c_void_p, C.POINTER(AnchorParams), C.POINTER(StitchParams),
+                                                     C.POINTER(BondParams), C.c_uint64, C.POINTER(AlignmentListC)]
+        self._check(self.lib.cl_leaf_bond_alignments(self.handle, C.byref(g), memo, C.byref(ap), C.byref(sp), C.byref(bp), int(max_rounds), C.byref(out)))
+        try:
+            res = []
+            for i in range(int(out.n)):
+                n = int(out.alignments[i].n_pairs)
+                res.append(np.ctypeslib.as_array(out.alignments[i].pairs, shape=(max(n, 1) * 2,))[:2 * n].copy().reshape(n, 2))
+            return res
+        finally:
+            self.lib.cl_alignment_list_free(C.byref(out))
 
     def merge(self, graph1, graph2, score_scale=1.0, max_num_match_pairs=1250000, max_count=3000, tweak=None):
         """one merge of the progressive MSA (the loop body of Core::do_execution, include/centrolign/core.hpp:268-392):

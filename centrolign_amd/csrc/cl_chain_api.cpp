@@ -1763,7 +1763,7 @@ struct MaskSet {
 
 static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
                              const cl_anchor_params* ap, cl_anchor_chain_result* out, bool scale_only, const MaskSet* mask = nullptr,
-                             const double* override_scale = nullptr) {
+                             const double* override_scale = nullptr, bool keep_scale_chain = false) {
     if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     const cl_chain_params& cp = ap->chain;
@@ -2045,9 +2045,9 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     // ---- estimate_score_scale (anchorer.hpp:998-1047)
     double scale = 1.0;
     int rc;
+    std::vector<HAnchor> sc;   // the chain of the estimate: estimate_score_scale's chain_out (anchorer.hpp:1042-1044)
     if (override_scale && !scale_only) scale = *override_scale;   // anchorer.hpp:975-978
     else if (ap->autocalibrate_gap_penalties) {
-        std::vector<HAnchor> sc;
         if ((rc = run(true, 1.0, sc))) return rc;
         auto t = now();
         double total_weight = 0.0;
@@ -2078,11 +2078,12 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         lap("scale estimate: extraction", t);
     }
     out->scale = scale;
-    if (scale_only) return CL_OK;
+    if (scale_only && !keep_scale_chain) return CL_OK;
 
-    // ---- the affine chain
+    // ---- the affine chain (or, for cl_leaf_calibrate, the estimate's own chain)
     std::vector<HAnchor> ch;
-    if ((rc = run(false, scale, ch))) return rc;
+    if (scale_only) ch.swap(sc);
+    else if ((rc = run(false, scale, ch))) return rc;
     const size_t na = ch.size();
     uint64_t total_walk = 0;
     for (const HAnchor& a : ch) total_walk += a.w1.size();
@@ -2200,6 +2201,15 @@ int cl_update_mask(const cl_match_sets* ms, uint64_t n_chain_pairs, const uint32
     if (!*masked_out) return CL_ERR_OUT_OF_MEMORY;
     for (size_t i = 0; i < m.size(); ++i) { (*masked_out)[3 * i] = m[i][0]; (*masked_out)[3 * i + 1] = m[i][1]; (*masked_out)[3 * i + 2] = m[i][2]; }
     return CL_OK;
+}
+
+// Anchorer::estimate_score_scale with its chain_out (anchorer.hpp:998-1047): out->scale and the chain the estimate was made on
+int cl_estimate_score_scale_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
+                                  const cl_anchor_params* ap, cl_anchor_chain_result* out) {
+    if (!ap || !out) return CL_ERR_INVALID_ARGUMENT;
+    cl_anchor_params p = *ap;
+    p.autocalibrate_gap_penalties = 1;
+    return anchor_chain_impl(ctx, g1, g2, ms, &p, out, true, nullptr, nullptr, true);
 }
 
 int cl_estimate_score_scale(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,

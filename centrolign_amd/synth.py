@@ -76,6 +76,22 @@ def hor_sequences(seed, total_len, n_seq, mono_len=171, hor_n=12, mono_div=0.25,
     return (seqs, srcs) if track else seqs
 
 
+def tandem_dup_sequences(seed, total_len, n_seq, dup_len, dup_at=None, dup_div=0.003, carriers=None, **kw):
+    """hor_sequences in which some sequences carry a recent tandem duplication: a copy of [dup_at, dup_at + dup_len), mutated at rate
+    dup_div, inserted right behind the original (inputs for the cyclisation path, the CLI's -c)"""
+    seqs = hor_sequences(seed, total_len, n_seq, **kw)
+    rng = random.Random(seed * 7919 + 13)
+    carriers = range(n_seq) if carriers is None else carriers
+    out = list(seqs)
+    for i in carriers:
+        s = out[i]
+        a = (len(s) // 3 if dup_at is None else dup_at)
+        a = max(0, min(a, len(s) - dup_len))
+        copy = "".join(_mut_track(rng, list(s[a:a + dup_len]), dup_div)[0])
+        out[i] = s[:a + dup_len] + copy + s[a + dup_len:]
+    return out
+
+
 def write_fasta(path, seqs, names=None):
     with open(path, "w") as f:
         for i, s in enumerate(seqs):

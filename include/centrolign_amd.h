@@ -575,6 +575,72 @@ typedef struct cl_merge_result {
 int  cl_merge(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_merge_params* params, cl_merge_result* out);
 void cl_merge_result_free(cl_merge_result* r);
 
+/* --- Cyclisation (the CLI's -c): the steps around the hot path's calls -----------------------------------------------
+ * Bonder (include/centrolign/bonder.hpp:47-108) as Core::calibrate_anchor_scores_and_identify_bonds uses it (src/core.cpp:229-234): on a
+ * leaf against itself, bond algorithm LongestNearOptDevConstrained (the class default; the CLI has no switch for the other two). */
+typedef struct cl_bond_params {          /* src/parameters.cpp:91-97 -> :174-180 */
+    double min_opt_proportion;           /* tandem_dup_score_proportion, 0.2 */
+    int    include_gap_scores;           /* include_tandem_dup_gap_scores, true */
+    double min_length;                   /* min_cyclizing_length, 100000 */
+    double deviation_drift_factor;       /* 150 */
+    double separation_drift_factor;      /* 50 */
+    double deduplication_slosh_proportion; /* 0.1 */
+    double trim_window_proportion;       /* 0.1 */
+} cl_bond_params;
+void cl_bond_params_default(cl_bond_params* p);
+/* a chain of anchors as Bonder reads it: anchor a = walk1/walk2[walk_off[a] .. walk_off[a+1]) (node ids), anchor_t::score, gap_after, gap_score_after */
+typedef struct cl_chain_anchors {
+    uint64_t n;
+    const uint64_t* walk_off;
+    const uint32_t* walk1;
+    const uint32_t* walk2;
+    const double*   score;
+    const int64_t*  gap_after;
+    const double*   gap_score_after;
+} cl_chain_anchors;
+/* std::vector<bond_interval_t> (bonder.hpp:22-42) of one leaf: interval i = bonds [interval_off[i], interval_off[i+1]); a bond pairs
+ * path positions [offset1, offset1 + length) with [offset2, offset2 + length) */
+typedef struct cl_bonds {
+    uint64_t  n_intervals;
+    uint64_t* interval_off;
+    uint64_t* offset1;
+    uint64_t* offset2;
+    uint64_t* length;
+    double*   score;
+} cl_bonds;
+/* Bonder::identify_bonds (bonder.hpp:116-452; the optimal chain = the leaf's main-diagonal chain of the calibration, the secondary chain =
+ * the next-best chain with the diagonal masked) and, with deduplicate != 0, Bonder::deduplicate_self_bonds (src/bonder.cpp:473-551). Host only. */
+int  cl_identify_bonds(const cl_base_graph* leaf, const cl_chain_anchors* opt_chain, const cl_chain_anchors* secondary_chain,
+                       const cl_bond_params* params, int deduplicate, cl_bonds* out);
+void cl_bonds_free(cl_bonds* b);
+
+/* The per-leaf step of the calibration (src/core.cpp:122-175) that also keeps what the tandem-duplication rounds read: the leaf's matches
+ * against itself and the main-diagonal chain the scale was estimated on (:168-172).  *memo_out (may be NULL: then this is
+ * cl_leaf_intrinsic_scale) is released with cl_leaf_calibration_free. */
+typedef struct cl_leaf_calibration cl_leaf_calibration;
+int  cl_leaf_calibrate(cl_context* ctx, const cl_base_graph* leaf, const cl_match_params* match_params, const cl_anchor_params* anchor_params,
+                       double* scale_out, cl_leaf_calibration** memo_out);
+void cl_leaf_calibration_free(cl_leaf_calibration* c);
+typedef struct cl_alignment_list {
+    uint64_t      n;
+    cl_alignment* alignments;
+} cl_alignment_list;
+void cl_alignment_list_free(cl_alignment_list* l);
+/* The tandem-duplication rounds of one leaf (src/core.cpp:199-296) after every leaf has been calibrated (anchor_params->score_scale = the mean
+ * of the intrinsic scales, :193): per round Anchorer::anchor_chain with the mask and the leaf's own scale, Bonder::identify_bonds +
+ * deduplicate_self_bonds, Core::bonds_to_chain + Stitcher::internal_stitch per bond, Core::update_mask; at most max_rounds
+ * (max_tandem_duplication_search_rounds, 3), ending with the first round without bonds.  Alignments in PATH POSITIONS of the leaf (:275-283),
+ * in the order the reference appends them. */
+int  cl_leaf_bond_alignments(cl_context* ctx, const cl_base_graph* leaf, const cl_leaf_calibration* memo, const cl_anchor_params* anchor_params,
+                             const cl_stitch_params* stitch_params, const cl_bond_params* bond_params, uint64_t max_rounds, cl_alignment_list* out);
+/* simplify_bubbles (src/modify_graph.cpp:165-382) with purge_uncovered_nodes (:89-163): bubbles whose alleles are plain runs of nodes get their
+ * identical alleles merged (every path moves to the first of them), nodes no path visits any more are dropped. Host only; cyclic graphs welcome. */
+int  cl_simplify_bubbles(const cl_base_graph* graph, cl_owned_base_graph** out);
+/* Core::apply_bonds up to the polishing step (src/core.cpp:613-645): alignment a pairs path positions of path path_of_alignment[a] of `root`;
+ * positions -> node ids, internal_fuse along all alignments, simplify_bubbles. */
+int  cl_apply_bonds(const cl_base_graph* root, uint64_t n_alignments, const uint64_t* path_of_alignment, const cl_alignment* alignments,
+                    cl_owned_base_graph** out);
+
 /* --- the front of the driver: FASTA, guide tree, the whole MSA (the rest of it) -------------------------------
  * cl_parse_fasta: parse_fasta (src/utility.cpp:19-65): a name is the header line up to the first space; sequence lines are joined;
  *   the same complaints (no name line, unequal or growing line lengths, empty input).

@@ -237,6 +237,18 @@ def batch_from_dump(d, prefix):
     return batch, d[prefix + "aln_off"], d[prefix + "pairs"].reshape(-1, 2)
 
 
+def ref_cyclize_dump(fasta_path, newick_path=None, dump_path=None, out_path=None, overrides="", verbosity=0):
+    """the reference's -c flow with the cyclisation steps recorded (oracle/ref_driver.cpp: ref_cyclize_dump); overrides as for ref_cli:
+    "i:min_cyclizing_length=3000;i:max_num_match_pairs=100000" """
+    lib = ref_lib()
+    lib.ref_cyclize_dump.restype = C.c_int
+    lib.ref_cyclize_dump.argtypes = [C.c_char_p] * 5 + [C.c_int]
+    code = lib.ref_cyclize_dump(fasta_path.encode(), (newick_path or "").encode(), (dump_path or "").encode(), (out_path or "").encode(),
+                                overrides.encode(), int(verbosity))
+    if code != 0:
+        raise RuntimeError("ref_cyclize_dump failed with %d" % code)
+
+
 def ref_msa_dump(fasta_path, newick_path=None, dump_path=None, out_path=None, skip_calibration=False,
                  max_num_match_pairs=0, verbosity=0):
     lib = ref_lib()

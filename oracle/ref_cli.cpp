@@ -4,7 +4,8 @@
  * process under a memory limit, writing every finished subproblem as a GFA file (-S of the CLI: Core::subproblems_prefix,
  * src/core.cpp:370-422); tests/golden/make_c3_digests.py turns those files into the digests the -m gpu suite reproduces.
  *
- *   ref_cli FASTA NEWICK|- PREFIX|- OUT|- [max_num_match_pairs] [verbosity] [restart 0|1]
+ *   ref_cli FASTA NEWICK|- PREFIX|- OUT|- [max_num_match_pairs] [verbosity] [restart 0|1] [overrides]
+ *   overrides: typed settings of the reference's Parameters, "b:cyclize_tandem_duplications=1;i:min_cyclizing_length=5000;d:name=0.2"
  */
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,19 @@ int main(int argc, char** argv) {
         if (prefix != "-") params.set<std::string>("subproblems_prefix", prefix);
         if (budget > 0) params.set<int64_t>("max_num_match_pairs", (int64_t)budget);
         if (restart) params.set<bool>("restart", true);
+        if (argc > 8) {
+            std::stringstream ss(argv[8]);
+            std::string item;
+            while (std::getline(ss, item, ';')) {
+                const size_t eq = item.find('=');
+                if (item.size() < 4 || item[1] != ':' || eq == std::string::npos) continue;
+                const std::string name = item.substr(2, eq - 2), val = item.substr(eq + 1);
+                if (item[0] == 'b') params.set<bool>(name, val != "0");
+                else if (item[0] == 'i') params.set<int64_t>(name, (int64_t)atoll(val.c_str()));
+                else if (item[0] == 'd') params.set<double>(name, atof(val.c_str()));
+                else params.set<std::string>(name, val);
+            }
+        }
         params.validate();
         logging::level = (logging::LoggingLevel)verbosity;
         std::ifstream fin(fasta);

@@ -615,6 +615,219 @@ int ref_anchor_chain_masked(const cl_base_graph* g1, const cl_base_graph* g2, co
     return 0;
 }
 
+/* typed overrides of the reference's Parameters, "b:name=1;i:name=5000;d:name=0.2;s:name=text" (what the CLI's options and config file set) */
+static void apply_overrides(Parameters& params, const char* overrides) {
+    if (!overrides) return;
+    std::stringstream ss(overrides);
+    std::string item;
+    while (std::getline(ss, item, ';')) {
+        if (item.size() < 4 || item[1] != ':') continue;
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string name = item.substr(2, eq - 2), val = item.substr(eq + 1);
+        switch (item[0]) {
+            case 'b': params.set<bool>(name, val != "0"); break;
+            case 'i': params.set<int64_t>(name, (int64_t)atoll(val.c_str())); break;
+            case 'd': params.set<double>(name, atof(val.c_str())); break;
+            default: params.set<std::string>(name, val); break;
+        }
+    }
+}
+
+/* The CLI's -c flow (src/core.cpp:63-94) with the cyclisation steps opened up so that every intermediate result can be recorded:
+ * per leaf the calibration chain, per tandem-duplication round the secondary chain, the bonds and the bond alignments (:196-297);
+ * after the MSA the graph Core::apply_bonds fuses (:613-637), what simplify_bubbles makes of it, the inconsistencies, and the polished graph.
+ * The steps are the reference's own functions called in the reference's order; tests/golden/make_golden.py checks that the text that comes
+ * out equals the unmodified flow's (oracle/_ref/ref_cli with the same parameters). */
+static void dump_chain(Dump& d, const std::string& pre, const std::vector<anchor_t>& chain) {
+    std::vector<uint64_t> walk_off{0};
+    std::vector<uint32_t> w1, w2;
+    std::vector<double> score, gsa;
+    std::vector<int64_t> ga;
+    for (const auto& a : chain) {
+        for (auto v : a.walk1) w1.push_back((uint32_t)v);
+        for (auto v : a.walk2) w2.push_back((uint32_t)v);
+        walk_off.push_back(w1.size());
+        score.push_back(a.score); ga.push_back(a.gap_after); gsa.push_back(a.gap_score_after);
+    }
+    d.u64(pre + "walk_off", walk_off); d.u32(pre + "walk1", w1); d.u32(pre + "walk2", w2);
+    d.f64(pre + "score", score); d.i64(pre + "gap_after", ga); d.f64(pre + "gap_score_after", gsa);
+}
+static void dump_bonds(Dump& d, const std::string& pre, const std::vector<bond_interval_t>& bonds) {
+    std::vector<uint64_t> off{0}, o1, o2, len;
+    std::vector<double> sc;
+    for (const auto& iv : bonds) {
+        for (const auto& b : iv) { o1.push_back(b.offset1); o2.push_back(b.offset2); len.push_back(b.length); sc.push_back(b.score); }
+        off.push_back(o1.size());
+    }
+    d.u64(pre + "interval_off", off); d.u64(pre + "offset1", o1); d.u64(pre + "offset2", o2); d.u64(pre + "length", len); d.f64(pre + "score", sc);
+}
+static void dump_alignment(Dump& d, const std::string& name, const Alignment& aln) {
+    std::vector<uint64_t> flat;
+    for (const auto& ap : aln) { flat.push_back(ap.node_id1); flat.push_back(ap.node_id2); }
+    d.u64(name, flat);
+}
+struct CycCore : public Core {
+    CycCore(std::vector<std::pair<std::string, std::string>>&& seqs, Tree&& tree) : Core(std::move(seqs), std::move(tree)) {}
+
+    std::vector<std::pair<std::string, Alignment>> calibrate_and_bond(Dump* dump) {   /* src/core.cpp:96-299, cyclising, no restart */
+        std::vector<double> intrinsic_scales;
+        std::vector<std::pair<std::string, Alignment>> bond_alns;
+        auto leaves = main_execution.leaf_subproblems();
+        std::vector<std::pair<std::vector<match_set_t>, std::vector<anchor_t>>> memo(leaves.size());
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            auto& sp = *leaves[i];
+            reassign_sentinels(sp.graph, sp.tableau, 5, 6);
+            SentinelTableau dummy = sp.tableau;
+            dummy.src_sentinel = 7; dummy.snk_sentinel = 8;
+            std::vector<match_set_t> matches = path_match_finder.find_matches(sp.graph, sp.graph, sp.tableau, dummy);
+            std::vector<match_set_t> diagonal;
+            diagonal.reserve(matches.size());
+            for (const auto& ms : matches) {
+                for (const auto& walk : ms.walks1) {
+                    diagonal.emplace_back();
+                    auto& m = diagonal.back();
+                    m.walks1.emplace_back(walk); m.walks2.emplace_back(walk);
+                    m.count1 = ms.count1; m.count2 = ms.count2; m.full_length = ms.full_length;
+                }
+            }
+            ChainMerge chain_merge(sp.graph, sp.tableau);
+            std::vector<anchor_t> chain;
+            bool restrain = anchorer.max_num_match_pairs > memory_restraint_size;
+            double scale = anchorer.estimate_score_scale(diagonal, sp.graph, sp.graph, sp.tableau, sp.tableau, chain_merge, chain_merge, restrain, &chain);
+            intrinsic_scales.push_back(scale);
+            memo[i].first = std::move(matches);
+            memo[i].second = std::move(chain);
+        }
+        if (!skip_calibration) {
+            double mean = 0.0;
+            for (auto sc : intrinsic_scales) mean += sc;
+            mean /= intrinsic_scales.size();
+            score_function.score_scale = mean;
+        }
+        if (dump) { dump->f64("intrinsic_scales", intrinsic_scales); dump->f64("score_scale", std::vector<double>{score_function.score_scale}); }
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            auto& sp = *leaves[i];
+            const std::string lp = "leaf" + std::to_string(i) + ".";
+            PathMerge<> path_merge(sp.graph, sp.tableau);
+            auto matches = std::move(memo[i].first);
+            auto chain = std::move(memo[i].second);
+            if (dump) dump_chain(*dump, lp + "opt.", chain);
+            auto mask = generate_diagonal_mask(matches);
+            StepIndex step_index;
+            size_t bonds_identified = 0, rounds = 0;
+            for (size_t iter = 0; iter < max_tandem_duplication_search_rounds; ++iter) {
+                auto secondary = anchorer.anchor_chain(matches, sp.graph, sp.graph, sp.tableau, sp.tableau, path_merge, path_merge,
+                                                       anchorer.max_num_match_pairs * log2(anchorer.max_num_match_pairs) > memory_restraint_size,
+                                                       &mask, &intrinsic_scales[i]);
+                auto bonds = bonder.identify_bonds(sp.graph, sp.graph, sp.tableau, sp.tableau, path_merge, path_merge, chain, secondary);
+                const std::string rp = lp + "r" + std::to_string(iter) + ".";
+                if (dump) { dump_chain(*dump, rp + "sec.", secondary); dump_bonds(*dump, rp + "raw_bonds.", bonds); }
+                bonder.deduplicate_self_bonds(bonds);
+                if (dump) dump_bonds(*dump, rp + "bonds.", bonds);
+                ++rounds;
+                if (bonds.empty()) break;
+                if (iter == 0) step_index = std::move(StepIndex(sp.graph));
+                for (auto& bond : bonds) {
+                    auto bond_chain = bonds_to_chain(sp.graph, bond);
+                    bond_alns.emplace_back(sp.graph.path_name(0), stitcher.internal_stitch(bond_chain, sp.graph, path_merge));
+                    for (auto& ap : bond_alns.back().second) {
+                        if (ap.node_id1 != AlignedPair::gap) ap.node_id1 = step_index.path_steps(ap.node_id1).front().second;
+                        if (ap.node_id2 != AlignedPair::gap) ap.node_id2 = step_index.path_steps(ap.node_id2).front().second;
+                    }
+                    if (dump) dump_alignment(*dump, lp + "bond_aln" + std::to_string(bonds_identified), bond_alns.back().second);
+                    ++bonds_identified;
+                }
+                update_mask(matches, secondary, mask, true);
+            }
+            if (dump) dump->u64(lp + "counts", std::vector<uint64_t>{(uint64_t)rounds, (uint64_t)bonds_identified});
+        }
+        return bond_alns;
+    }
+
+    void run(Dump* dump) {   /* src/core.cpp:63-94 + apply_bonds (:594-648) */
+        auto bond_alignments = calibrate_and_bond(dump);
+        do_execution(main_execution, this->path_match_finder, true);
+        auto& root = main_execution.final_subproblem();
+        if (dump) dump_base_graph(*dump, "msa.", root.graph, root.tableau);
+        if (bond_alignments.empty()) return;
+        std::vector<Alignment> to_fuse;
+        for (auto& ba : bond_alignments) {
+            uint64_t path_id = root.graph.path_id(ba.first);
+            for (auto& ap : ba.second) {
+                if (ap.node_id1 != AlignedPair::gap) ap.node_id1 = root.graph.path(path_id)[ap.node_id1];
+                if (ap.node_id2 != AlignedPair::gap) ap.node_id2 = root.graph.path(path_id)[ap.node_id2];
+            }
+            to_fuse.emplace_back(std::move(ba.second));
+        }
+        SentinelTableau ct;
+        Alignment ca;
+        BaseGraph cyclized = internal_fuse(root.graph, to_fuse, &root.tableau, &ct, &root.alignment, &ca);
+        if (dump) dump_base_graph(*dump, "fused.", cyclized, ct);
+        simplify_bubbles(cyclized, ct);
+        if (dump) dump_base_graph(*dump, "simplified.", cyclized, ct);
+        root.graph = std::move(cyclized);
+        root.tableau = ct;
+        root.alignment.clear();
+        if (dump) {
+            auto inc = inconsistency_identifier.identify_inconsistencies(root.graph, root.tableau);
+            std::vector<uint64_t> flat;
+            for (const auto& b : inc) { flat.push_back(b.first); flat.push_back(b.second); }
+            dump->u64("inconsistencies", flat);
+        }
+        polish_cyclized_graph(root);
+        if (dump) dump_base_graph(*dump, "polished.", root.graph, root.tableau);
+    }
+};
+
+int ref_cyclize_dump(const char* fasta_path, const char* newick_path, const char* dump_path, const char* out_path, const char* overrides, int verbosity) {
+    try {
+        Parameters params;
+        params.set<std::string>("fasta_name", fasta_path);
+        params.set<bool>("cyclize_tandem_duplications", true);
+        apply_overrides(params, overrides);
+        params.validate();
+        logging::level = (logging::LoggingLevel)verbosity;
+        std::ifstream fin(fasta_path);
+        if (!fin) return -100;
+        auto parsed = parse_fasta(fin);
+        std::vector<std::string> names;
+        for (const auto& p : parsed) names.push_back(p.first);
+        std::string newick;
+        if (newick_path && *newick_path) {
+            std::ifstream tin(newick_path);
+            std::stringstream ss;
+            ss << tin.rdbuf();
+            newick = ss.str();
+        } else {
+            newick = in_order_newick_string(names);
+        }
+        Tree tree(newick);
+        CycCore core(std::move(parsed), std::move(tree));
+        if (names.size() == 2) params.set<bool>("preserve_subproblems", true);
+        params.apply(core);
+        Dump dump;
+        Dump* dp = nullptr;
+        if (dump_path && *dump_path) {
+            if (!dump.open(dump_path)) return -101;
+            dp = &dump;
+        }
+        core.run(dp);
+        std::stringstream ss;
+        const auto& root = core.root_subproblem();
+        write_gfa(root.graph, root.tableau, ss);
+        if (dp) { dump.str("output", ss.str()); dump.close(); }
+        if (out_path && *out_path) {
+            std::ofstream fo(out_path);
+            fo << ss.str();
+        }
+        return 0;
+    } catch (std::exception& ex) {
+        fprintf(stderr, "ref_cyclize_dump: %s\n", ex.what());
+        return -102;
+    }
+}
+
 /* Core::generate_diagonal_mask (mode 0) and Core::update_mask (mode 1, mask_reciprocal as given) on flat sets (src/core.cpp:301-372). */
 struct MaskCore : public Core {
     MaskCore(std::vector<std::pair<std::string, std::string>>&& seqs, Tree&& tree) : Core(std::move(seqs), std::move(tree)) {}
