@@ -1058,7 +1058,10 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (use_far && far_bb) {
                     // every node inside the records [0, prefix[near_lo]) was sealed by seal(k - lag - 1) or earlier
                     he = hipStreamWaitEvent(far_stream, ev_seal[k - lag - 1], 0);
-                    if (he == hipSuccess) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream);
+                    // CL_CHAIN_DEBUG_SKIP_FAR=1 (measurements only, WRONG RESULTS): the DP without its far launches = the serial walk / near chain alone,
+                    // i.e. what a merge would cost its leader if other devices took the far pass off it
+                    static const bool skip_far = getenv("CL_CHAIN_DEBUG_SKIP_FAR") != nullptr;
+                    if (he == hipSuccess && !skip_far) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream);
                 } else if (use_far) {
                     // the all-pairs sweep has taken over (see the checkpoints below); same lag, so that sweeps run side by side
                     he = hipStreamWaitEvent(far_stream, ev_walk[k - lag - 1], 0);

@@ -325,6 +325,8 @@ def main():
         return restart_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "cyclize":
         return cyclize_goldens()
+    if len(sys.argv) > 1 and sys.argv[1] == "cyclize_flow":
+        return cyclize_flow_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "plans":
         return plan_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "exhaustive":
@@ -583,6 +585,44 @@ def cyclize_goldens():
             out[name + "." + f] = v
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "cyclize_rounds.npz"), **out)
+
+
+CYCLIZE_FLOW_CASES = [
+    # name, seed, length, sequences, duplicated bases, hor_div, carriers of the duplication, min_cyclizing_length, max_num_match_pairs
+    ("tri16k", 33, 16000, 3, 5000, 0.10, [0], 3000, 40000),   # (two sequences would print a CIGAR, src/main.cpp:290-296)
+    ("three24k", 32, 24000, 3, 8000, 0.05, [0, 1, 2], 6000, 60000),
+]
+
+
+def cyclize_flow_goldens():
+    # 18. the CLI's -c flow end to end (src/core.cpp:63-94, 196-297, 594-767) on inputs with real tandem duplications, from the compiled
+    #     reference with the cyclisation steps opened up (oracle/ref_driver.cpp: ref_cyclize_dump): per leaf the calibration chain, per
+    #     tandem-duplication round the secondary chain, the bonds before and after deduplication and the bond alignments; the MSA graph,
+    #     what internal_fuse and simplify_bubbles make of it, the inconsistencies, the polished graph and the GFA text.  The text is
+    #     checked against the UNMODIFIED flow (oracle/_ref/ref_cli with the same parameters) before anything is written.
+    import subprocess
+    import tempfile
+    cli = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "ref_cli")
+    out = {"names": np.array([c[0] for c in CYCLIZE_FLOW_CASES])}
+    for name, seed, length, n, dup, hor_div, carriers, min_len, budget in CYCLIZE_FLOW_CASES:
+        seqs = synth.tandem_dup_sequences(seed, length, n, dup, carriers=carriers, hor_div=hor_div)
+        names = ["s%d" % i for i in range(n)]
+        overrides = "i:min_cyclizing_length=%d;i:max_num_match_pairs=%d" % (min_len, budget)
+        with tempfile.TemporaryDirectory() as tmp:
+            fa = os.path.join(tmp, "in.fa")
+            synth.write_fasta(fa, seqs, names)
+            po.ref_cyclize_dump(fa, None, os.path.join(tmp, "d.bin"), os.path.join(tmp, "dump.gfa"), overrides)
+            subprocess.run([cli, fa, "-", "-", os.path.join(tmp, "cli.gfa"), "0", "0", "0", "b:cyclize_tandem_duplications=1;" + overrides], check=True)
+            assert open(os.path.join(tmp, "cli.gfa"), "rb").read() == open(os.path.join(tmp, "dump.gfa"), "rb").read(), name
+            d = po.read_dump(os.path.join(tmp, "d.bin"))
+        for k, v in d.items():
+            out[name + "." + k] = v
+        out[name + ".params"] = np.array([seed, length, n, dup, min_len, budget], np.int64)
+        out[name + ".hor_div"] = np.array([hor_div])
+        out[name + ".carriers"] = np.array(carriers, np.int64)
+        print(name, "bonds per leaf:", [int(d["leaf%d.counts" % i][1]) for i in range(n)], "inconsistencies:", len(d["inconsistencies"]) // 2,
+              "nodes:", [len(d[k + "label"]) for k in ("msa.", "fused.", "simplified.", "polished.")])
+    np.savez_compressed(os.path.join(HERE, "cyclize_flow.npz"), **out)
 
 
 def restart_goldens():

@@ -2,9 +2,12 @@
 the C ABI.  The single-threaded reference finishes eight of the nine merges of this input in the build container before it runs out of
 memory at the root (tests/golden/make_c3_digests.py, 37 minutes); the GFA text of each of those eight subproblems, as the reference's -S
 option writes it (Core::emit_subproblem, src/core.cpp:392-422), is pinned here by sha256 and must be reproduced byte for byte.  The
-root merge has no reference output: it is pinned by what can be checked without one — every path of the root graph spells its input
-sequence, the graph is the fuse of the two pinned children along an alignment that covers both of them completely, and the text is the
-same from one worker context and from four.  Also the distributed driver over two ranks' worth of contexts on the one device."""
+root merge at the default budget has no reference output: there it is pinned by what can be checked without one — every path of the root
+graph spells its input sequence, the graph is the fuse of the two pinned children along an alignment that covers both of them completely,
+and the text is the same from one worker context and from four.  The reference DOES finish the root merge when it is restarted (-R) from
+its own two subproblem files with a budget of 500 000 match pairs (25 minutes, 28 GB): that GFA is pinned by digest and reproduced here the
+same way — the two pinned children written as GFA, read back as a restart reads them, merged with that budget (5 + 5 paths, 36 chain
+combinations, full-size graphs: the walk kernel's exchange between workgroups and the far pass at scale, against the reference)."""
 import hashlib
 import json
 import os
@@ -75,3 +78,21 @@ def test_one_worker_prints_the_same_gfa(gpu_ctx, c3_run):
     names, seqs, tree, r = c3_run
     r1 = msa.progressive_msa(gpu_ctx, seqs, tree, workers=1)
     assert capi.write_gfa(r1["root"], r1["paths"]) == capi.write_gfa(r["root"], r["paths"])
+
+
+@pytest.mark.gpu
+def test_root_merge_restarted_with_a_smaller_budget_matches_the_reference(gpu_ctx, c3_run):
+    names, seqs, tree, r = c3_run
+    gold = GOLD["root_restart_500k"]
+    kept = {",".join(sorted(m["paths"])): m for m in r["stats"]["kept"]}
+    children = []
+    for key in ("s0,s1,s2,s3,s4", "s5,s6,s7,s8,s9"):
+        m = kept[key]
+        text = capi.write_gfa(m["fused"], m["paths"])
+        assert hashlib.sha256(text).hexdigest() == GOLD["subproblems"][key]["sha256"]      # the very file the reference restarted from
+        children.append(capi.read_gfa(text))                                                 # read_gfa + add_sentinels, as Core::restart does
+    (g1, p1), (g2, p2) = children
+    got = gpu_ctx.merge(g1, g2, score_scale=r["scale"], max_num_match_pairs=gold["max_num_match_pairs"])
+    gfa = capi.write_gfa(got["fused"], p1 + p2)
+    assert len(gfa) == gold["bytes"]
+    assert hashlib.sha256(gfa).hexdigest() == gold["sha256"]

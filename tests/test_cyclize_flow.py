@@ -1,0 +1,127 @@
+"""Cyclisation (the CLI's -c) beyond the hot path's own calls: Bonder::identify_bonds / deduplicate_self_bonds, the
+per-leaf tandem-duplication rounds (src/core.cpp:196-297), Core::apply_bonds up to the polishing step (internal_fuse + simplify_bubbles,
+:594-645).  Expected values: the compiled reference's -c flow with its steps recorded (tests/golden/make_golden.py cyclize_flow ->
+cyclize_flow.npz; the recorded flow's GFA was checked against the unmodified CLI flow when the file was made) on inputs with real tandem
+duplications."""
+import os
+
+import numpy as np
+import pytest
+
+from centrolign_amd import capi, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CHAIN_KEYS = ("walk_off", "walk1", "walk2", "score", "gap_after", "gap_score_after")
+BOND_KEYS = ("interval_off", "offset1", "offset2", "length")
+
+
+def cases():
+    z = np.load(os.path.join(HERE, "golden", "cyclize_flow.npz"))
+    for name in z["names"]:
+        name = str(name)
+        d = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + ".")}
+        seed, length, n, dup, min_len, budget = [int(x) for x in d["params"]]
+        seqs = synth.tandem_dup_sequences(seed, length, n, dup, carriers=[int(c) for c in d["carriers"]], hor_div=float(d["hor_div"][0]))
+        yield name, d, seqs, min_len, budget
+
+
+def graph_of(d, pre):
+    t = d[pre + "tableau"]
+    return capi.BaseGraph(*[d[pre + k] for k in capi.GRAPH_KEYS], int(t[0]), int(t[1]))
+
+
+def bond_alignments(d, n_leaves):
+    alns, owner = [], []
+    for i in range(n_leaves):
+        for b in range(int(d["leaf%d.counts" % i][1])):
+            alns.append(d["leaf%d.bond_aln%d" % (i, b)].reshape(-1, 2))
+            owner.append(i)
+    return alns, owner
+
+
+def test_identify_bonds_matches_the_reference():
+    """host only: every round of every leaf, before and after deduplication; offsets, lengths and — to the last bit — scores"""
+    n_rounds = n_bonds = 0
+    for name, d, seqs, min_len, budget in cases():
+        bp = capi.bond_params(min_length=min_len)
+        for i, seq in enumerate(seqs):
+            leaf = synth.base_graph_from_sequence(seq, (5, 6))
+            opt = {k: d["leaf%d.opt.%s" % (i, k)] for k in CHAIN_KEYS}
+            for r in range(int(d["leaf%d.counts" % i][0])):
+                sec = {k: d["leaf%d.r%d.sec.%s" % (i, r, k)] for k in CHAIN_KEYS}
+                for dedup, key in ((False, "raw_bonds."), (True, "bonds.")):
+                    got = capi.identify_bonds(leaf, opt, sec, bp, deduplicate=dedup)
+                    pre = "leaf%d.r%d.%s" % (i, r, key)
+                    for k in BOND_KEYS:
+                        assert np.array_equal(got[k], d[pre + k]), (name, pre, k)
+                    assert np.array_equal(got["score"].view(np.uint64), d[pre + "score"].view(np.uint64)), (name, pre)
+                    n_bonds += len(got["interval_off"]) - 1
+                n_rounds += 1
+    assert n_rounds >= 8 and n_bonds >= 10
+
+
+def test_apply_bonds_and_simplify_bubbles_match_the_reference():
+    """host only: the MSA graph and the bond alignments (path positions) -> the graph the polishing step starts from; and simplify_bubbles
+    alone on what internal_fuse made"""
+    import re
+    for name, d, seqs, min_len, budget in cases():
+        alns, owner = bond_alignments(d, len(seqs))
+        assert alns
+        path_names = re.findall(r"^P\t(\S+)", d["output"].tobytes().decode(), re.M)
+        path_of = [path_names.index("s%d" % i) for i in owner]
+        want = graph_of(d, "simplified.")
+        got = capi.apply_bonds(graph_of(d, "msa."), path_of, alns)
+        assert capi.graphs_equal(got, want), name
+        fused = graph_of(d, "fused.")
+        assert capi.graphs_equal(capi.simplify_bubbles(fused), want), name
+        assert len(want.label) < len(fused.label) < len(d["msa.label"])          # the bonds merged something, the bubbles went, cycles exist
+        # simplifying again changes nothing
+        assert capi.graphs_equal(capi.simplify_bubbles(want), want), name
+
+
+def test_simplify_bubbles_small_cases():
+    """hand-made graphs: identical alleles merge onto the first, different ones stay, a bubble at a sentinel is left alone"""
+    def g(labels, edges, paths, src, snk):
+        n = len(labels)
+        nxt, prv = [[] for _ in range(n)], [[] for _ in range(n)]
+        for a, b in edges:
+            nxt[a].append(b); prv[b].append(a)
+        off = lambda ls: np.cumsum([0] + [len(x) for x in ls]).astype(np.uint64)
+        flat = lambda ls: np.array([v for x in ls for v in x], np.uint32)
+        return capi.BaseGraph(np.array(labels, np.uint8), off(nxt), flat(nxt), off(prv), flat(prv), off(paths), flat(paths), src, snk)
+    # 0:src 1:A 2:C 3:C 4:G 5:T 6:snk   bubble 1 -> {2, 3, 4} -> 5, alleles C, C, G
+    graph = g([5, 0, 1, 1, 2, 3, 6], [(0, 1), (1, 2), (1, 3), (1, 4), (2, 5), (3, 5), (4, 5), (5, 6)], [[1, 2, 5], [1, 3, 5], [1, 4, 5]], 0, 6)
+    out = capi.simplify_bubbles(graph)
+    assert len(out.label) == 6 and out.label.tolist() == [5, 0, 1, 2, 3, 6]
+    assert out.path_nodes.tolist() == [1, 2, 4, 1, 2, 4, 1, 3, 4]
+    # the same bubble hanging off the source sentinel stays
+    graph = g([5, 1, 1, 3, 6], [(0, 1), (0, 2), (1, 3), (2, 3), (3, 4)], [[1, 3], [2, 3]], 0, 4)
+    assert capi.graphs_equal(capi.simplify_bubbles(graph), graph)
+    # an allele with a second way in is not a plain run: nothing happens
+    graph = g([5, 0, 1, 1, 2, 3, 6], [(0, 1), (1, 2), (1, 3), (2, 3), (2, 5), (3, 5), (5, 6), (1, 4), (4, 5)], [[1, 2, 5], [1, 3, 5], [1, 2, 3, 5], [1, 4, 5]], 0, 6)
+    assert capi.graphs_equal(capi.simplify_bubbles(graph), graph)
+
+
+@pytest.mark.gpu
+def test_leaf_calibration_and_bond_rounds_match_the_reference(gpu_ctx):
+    """device: per leaf cl_leaf_calibrate (self matches + main-diagonal chain + intrinsic scale), then the tandem-duplication rounds with the
+    mean scale — masked anchor chains, bonds, internal_stitch — give the reference's bond alignments, in its order, in path positions"""
+    for name, d, seqs, min_len, budget in cases():
+        leaves = [capi.leaf_graph(s) for s in seqs]
+        memos, scales = [], []
+        try:
+            for leaf in leaves:
+                sc, h = gpu_ctx.leaf_calibrate(leaf, max_num_match_pairs=budget)
+                scales.append(sc); memos.append(h)
+            assert np.array_equal(np.array(scales).view(np.uint64), d["intrinsic_scales"].view(np.uint64)), name
+            mean = sum(scales) / len(scales)
+            assert mean == float(d["score_scale"][0])
+            bp = capi.bond_params(min_length=min_len)
+            for i, leaf in enumerate(leaves):
+                got = gpu_ctx.leaf_bond_alignments(leaf, memos[i], mean, max_num_match_pairs=budget, bonds=bp)
+                assert len(got) == int(d["leaf%d.counts" % i][1]), (name, i)
+                for b, aln in enumerate(got):
+                    assert np.array_equal(aln, d["leaf%d.bond_aln%d" % (i, b)].reshape(-1, 2)), (name, i, b)
+        finally:
+            for h in memos:
+                gpu_ctx.free_leaf_calibration(h)
