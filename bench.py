@@ -11,7 +11,8 @@ What runs:
      barrier + synchronize; `value` = DP cells of all steps / elapsed.
 
 N > 1 (torchrun, one process per GPU): ONE MSA over the N ranks (centrolign_amd.msa.progressive_msa_distributed: leaf calibrations and
-sibling subtrees of the guide tree on different ranks, fused graphs travel between owners) => `"scaling": "strong"`.  The stitch
+sibling subtrees of the guide tree on different ranks, fused graphs travel between owners) => `"scaling": "strong"` (at every N, 1 included:
+the N = 1 line is the anchor of that curve).  The stitch
 batches stay on the rank that made them; a step is every rank's pass over its own batches, `value` = all ranks' cells / the slowest
 rank's time, `msa_wall_s` = the slowest rank's wall-clock of the distributed MSA.  No data-path collective in the timed steps.
 
@@ -31,8 +32,6 @@ import numpy as np  # noqa: E402
 
 WORKLOAD = "BASELINE configs[2]: 10 x 1 Mbp synthetic HOR arrays (seed 7), guide tree ((((s0,s1),(s2,s3)),s4),(((s5,s6),(s7,s8)),s9)), " \
            "full progressive MSA; step = stitcher PO-POA DP over the stitch batches of all nine merges"
-VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9   # int32 VALU lane-operations per second (256 CUs x 128 lanes x 2.4 GHz), MI355X_MICROARCH.md
-EVAL_VALU_OPS = 19                       # VALU operations of one (record, query) evaluation of the all-pairs sweep (chain_kernels.hip)
 
 
 def relabelled(g, src_label, snk_label):
@@ -226,8 +225,10 @@ def main():
     # nine concurrent stitch plans (ms per step): 4 queues 8.9, 8: 8.2, 12: 5.6, 16: 4.9, 20: 3.8, 22: 4.9, 24: 11.5, 32: 28.5 — beyond
     # ~23 PER DEVICE the queues are oversubscribed and time-sliced, so ranks that share a device share the 20; the MSA's wall-clock does
     # not depend on it (15.2-16.3 s for 8..23)
+    # (a single rank per device leaves it to the library, which asks for 20 when it is loaded: cl_api.cpp, cl_library_loaded)
     per_device = max(1, -(-world_env // max(1, n_dev)))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 20 // per_device)))
+    if per_device > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 20 // per_device)))
     rank, world, dist = cd.init_distributed(None if world_env == 1 else ("gloo" if share else "nccl"))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -310,29 +311,35 @@ def main():
     if rank == 0:
         value = total_cells * args.steps / elapsed
         dom = max(launches, key=lambda e: e["ms"]) if launches else None
-        traffic = limiter = None
+        # PMC traffic cannot be collected inside this run (rocprofv3 --pmc is its own pass): what profiles/ holds is quoted with its
+        # provenance and never divided by this run's times
+        traffic_profile = None
         tp = os.path.join(HERE, "profiles", "hbm_traffic_latest.json")
         if dom is not None and os.path.exists(tp):
             try:
                 with open(tp) as f:
                     tj = json.load(f)
-                traffic = tj.get(dom["kernel"])
-                limiter = tj.get("_limiter", {}).get(dom["kernel"])
+                if tj.get(dom["kernel"]) is not None:
+                    traffic_profile = {"file": "profiles/hbm_traffic_latest.json", "kernel": dom["kernel"],
+                                       "hbm_bytes_per_launch_mean_over_all_launches_of_that_kernel": tj.get(dom["kernel"]),
+                                       "collected_with": tj.get("_command", "scripts/pmc_round2.sh (separate --pmc passes, FETCH_SIZE x 2 + WRITE_SIZE corrections of MI355X_MICROARCH.md)"),
+                                       "tree": tj.get("_commit", "round 2"), "limiter": tj.get("_limiter", {}).get(dom["kernel"])}
             except Exception:
-                traffic = None
+                traffic_profile = None
         per_merge = res["stats"].get("per_merge", [])
         chain_ms = sum(m["chain_device_ms"] for m in per_merge)
-        chain_evals = sum(m["chain_pair_evals"] for m in per_merge)
+        chain_pairs = sum(m["chain_match_pairs"] for m in per_merge)
         out = {
             "metric": "stitcher PO-POA DP cells/s (10 x 1 Mbp synthetic HOR MSA, every between-anchor subproblem of all nine merges, fill + traceback)",
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
+                       "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes,
                        "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
-                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank), stitch batches on the rank that made them, no data-path collective" % (world, args.workers)},
+                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank), stitch batches on the rank that made them, no data-path collective; one merge still runs on one GPU, so msa_wall_s is bounded by the spine of the guide tree (DESIGN.md §5); no multi-GPU hardware curve has been measured by the builder" % (world, args.workers)},
             "msa_wall_s": msa_wall,
             "msa": {"pipeline": "leaf graphs + 10 calibrations + 9 x (find_matches + Core::align + fuse) + write_gfa, no reference in the loop",
                     "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "score_scale": res["scale"],
@@ -344,14 +351,24 @@ def main():
         }
         if dom is not None:
             achieved = dom["dp_bytes"] / (dom["ms"] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            # latency model of the same launch: its duration is the dependent sweep of its longest subproblem (rows on lanes, one column per
+            # step), so what can be acted on is the time per step against what ONE wave can issue: ~195 instructions per step in the systolic
+            # DAG kernel, 4 cycles per 64-wide VALU instruction, 2.4 GHz
+            steps = int(dom.get("max_sweep") or 0)
+            issue_floor_ns = 195 * 4 / 2.4
+            latency = None
+            if steps:
+                ns_per_step = dom["ms"] * 1e6 / steps
+                latency = {"model": "latency", "dependent_steps": steps, "ns_per_step": ns_per_step, "single_wave_issue_floor_ns_per_step": issue_floor_ns,
+                           "floor_over_measured": issue_floor_ns / ns_per_step, "longest_subproblem": dom.get("longest"),
+                           "note": "measured while the other eight plans run beside it; alone the same launch is faster (DESIGN.md §4.4)"}
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                                "kernel": dom["kernel"], "merge": dom["merge"], "kernel_ms": dom["ms"], "kernel_cells": dom["dp_cells"],
-                               "kernel_problems": dom["n_problems"],
-                               "hbm_measured_GBps": None if not traffic else traffic / (dom["ms"] * 1e-3) / 1e9,
-                               "limiter": limiter or "dependent anti-diagonal chain of the largest matrix (VALU issue latency), not HBM",
-                               "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells of the launch, SURVEY.md §8d) / its HIP-event duration; "
-                                       "`traffic` / `hbm_measured_GBps` = PMC bytes per launch (profiles/): scores stay in registers or LDS, so the "
-                                       "measured traffic is far below the algorithmic figure and the HBM roofline is not what limits this kernel"}
+                               "kernel_problems": dom["n_problems"], "latency_model": latency, "traffic_profile": traffic_profile,
+                               "limiter": "dependent chain of the largest matrix (n1 + n2 steps of one workgroup), not HBM: see latency_model",
+                               "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells of the launch, SURVEY.md §8d) / its HIP-event duration in THIS run; "
+                                       "traffic (PMC HBM bytes of this very launch) cannot be collected in the same run and is null; traffic_profile quotes the "
+                                       "committed rocprofv3 summary with its provenance"}
         if elapsed > 0:
             # the whole step against the same roofline: what the nine plans together stream per second if every cell's state moved once
             step_bytes = float(sum(st["dp_bytes"] for st in stats))
@@ -362,13 +379,14 @@ def main():
                                     "note": "ALGORITHMIC bytes of all launches of a step / the step's wall-clock: the nine plans' launches overlap, so the "
                                             "pass as a whole sits much closer to the roofline than its longest (latency-bound) launch, which `roofline` reports"}
         if chain_ms > 0:
-            evals_per_s = chain_evals / (chain_ms * 1e-3)
-            out["roofline_chain"] = {"bound": "valu", "unit": "pair evaluations/s", "achieved": evals_per_s, "peak": VALU_PEAK_LANE_OPS / EVAL_VALU_OPS,
-                                     "frac": evals_per_s / (VALU_PEAK_LANE_OPS / EVAL_VALU_OPS), "device_ms": chain_ms, "pair_evaluations": chain_evals,
-                                     "kernels": "chain_walk_kernel + far_prune_kernel + chain_inter_kernel (both whole-graph DPs of all nine merges)",
-                                     "note": "pair evaluations = what an all-pairs sweep of the same DPs evaluates (sum over chain combinations of records x "
-                                             "match pairs / 2); the branch-and-bound far pass proves most of them unnecessary, so `achieved` is the "
-                                             "all-pairs-equivalent rate and may exceed the VALU peak of a sweep that really evaluates them"}
+            n_macro = sum(2 * -(-int(m["chain_match_pairs"]) // 1024) for m in per_merge)     # two whole-graph DPs per merge, 1024 pairs per macro-block
+            out["chain_dp"] = {"model": "latency", "not_a_roofline": True, "device_ms": chain_ms, "match_pairs": int(chain_pairs), "macro_blocks": n_macro,
+                               "us_per_macro_block": chain_ms * 1e3 / max(1, n_macro),
+                               "kernels": "chain_walk_kernel -> chain_inter_kernel (near) -> far_prune_kernel / far_seal_kernel, both whole-graph DPs of all nine merges",
+                               "note": "the chaining DP is a chain of ~1 200 dependent macro-blocks per DP (walk + near pass on the serial stream, far pass two blocks "
+                                       "behind on side streams); its kernels are priced per kernel against HBM bytes/s and VALU issue in profiles/r03_pmc_summary.json "
+                                       "(rocprofv3 --pmc passes; command recorded in the file), not here: the far pass skips >98 % of the pair evaluations an "
+                                       "all-pairs sweep would make, so an evaluations/s figure says nothing about the hardware"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)
             out["cpu_reference_wall"] = reference_leaf_merge(seqs, names)
