@@ -1109,7 +1109,7 @@ EXPORTED_SYMBOLS = [
     "cl_fuse", "cl_owned_base_graph_view", "cl_owned_base_graph_free", "cl_merge_params_default", "cl_merge", "cl_merge_result_free",
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
     "cl_bond_params_default", "cl_identify_bonds", "cl_bonds_free", "cl_leaf_calibrate", "cl_leaf_calibration_free", "cl_alignment_list_free",
-    "cl_leaf_bond_alignments", "cl_simplify_bubbles", "cl_apply_bonds",
+    "cl_leaf_bond_alignments", "cl_simplify_bubbles", "cl_apply_bonds", "cl_polish_params_default", "cl_identify_inconsistencies",
 ]
 
 
@@ -1208,6 +1208,36 @@ def apply_bonds(root, path_of_alignment, alignments):
     if rc:
         raise ClError(rc, "cl_apply_bonds")
     return _take_owned_base_graph(lib, h)
+
+
+class PolishParams(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("max_tight_cycle_size", "max_bond_inconsistency_window", "min_inconsistency_disjoint_length",
+                                          "min_inconsistency_total_length", "padding_target_min_length", "padding_max_length_limit")]
+
+
+def polish_params(**kw):
+    lib = load_library()
+    pp = PolishParams()
+    lib.cl_polish_params_default(C.byref(pp))
+    for k, v in kw.items():
+        setattr(pp, k, int(v))
+    return pp
+
+
+def identify_inconsistencies(graph, params=None):
+    """InconsistencyIdentifier::identify_inconsistencies (include/centrolign/inconsistency_identifier.hpp:66-187); host only; (n, 2) node pairs"""
+    lib = load_library()
+    lib.cl_identify_inconsistencies.restype = C.c_int
+    lib.cl_identify_inconsistencies.argtypes = [C.POINTER(BaseGraphC), C.POINTER(PolishParams), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    params = params or polish_params()
+    g, ptr, n = graph.as_c(), C.c_void_p(), C.c_uint64(0)
+    rc = lib.cl_identify_inconsistencies(C.byref(g), C.byref(params), C.byref(ptr), C.byref(n))
+    if rc:
+        raise ClError(rc, "cl_identify_inconsistencies")
+    k = int(n.value)
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 2,))[:2 * k].copy().reshape(k, 2)
+    _libc_free(ptr)
+    return a
 
 
 def _take_mask(lib, ptr, n):

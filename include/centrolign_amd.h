@@ -614,6 +614,20 @@ int  cl_identify_bonds(const cl_base_graph* leaf, const cl_chain_anchors* opt_ch
                        const cl_bond_params* params, int deduplicate, cl_bonds* out);
 void cl_bonds_free(cl_bonds* b);
 
+/* InconsistencyIdentifier (include/centrolign/inconsistency_identifier.hpp:17-57) as the CLI configures it (src/parameters.cpp:98-103 -> :182-187) */
+typedef struct cl_polish_params {
+    uint64_t max_tight_cycle_size;               /* max_realignment_cycle_size, 10000 */
+    uint64_t max_bond_inconsistency_window;      /* inconsistent_indel_window, 100 */
+    uint64_t min_inconsistency_disjoint_length;  /* 8 */
+    uint64_t min_inconsistency_total_length;     /* 50 */
+    uint64_t padding_target_min_length;          /* realignment_min_padding, 1000 */
+    uint64_t padding_max_length_limit;           /* realignment_max_padding, 10000 */
+} cl_polish_params;
+void cl_polish_params_default(cl_polish_params* p);
+/* InconsistencyIdentifier::identify_inconsistencies (inconsistency_identifier.hpp:66-187) on a cyclised graph: *bounds_out = malloc'ed
+ * [2 * *n_out] (first node, last node) of the mutually disjoint regions to realign, in the reference's order. Host only. */
+int  cl_identify_inconsistencies(const cl_base_graph* graph, const cl_polish_params* params, uint64_t** bounds_out, uint64_t* n_out);
+
 /* The per-leaf step of the calibration (src/core.cpp:122-175) that also keeps what the tandem-duplication rounds read: the leaf's matches
  * against itself and the main-diagonal chain the scale was estimated on (:168-172).  *memo_out (may be NULL: then this is
  * cl_leaf_intrinsic_scale) is released with cl_leaf_calibration_free. */
