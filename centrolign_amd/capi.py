@@ -1110,6 +1110,7 @@ EXPORTED_SYMBOLS = [
     "cl_match_params_default", "cl_find_matches", "cl_match_joined_text", "cl_suffix_array_lcp", "cl_matches_from_suffix_array",
     "cl_bond_params_default", "cl_identify_bonds", "cl_bonds_free", "cl_leaf_calibrate", "cl_leaf_calibration_free", "cl_alignment_list_free",
     "cl_leaf_bond_alignments", "cl_simplify_bubbles", "cl_apply_bonds", "cl_polish_params_default", "cl_identify_inconsistencies",
+    "cl_polish_cyclized_graph",
 ]
 
 
@@ -1551,6 +1552,28 @@ class Context:
             return res
         finally:
             self.lib.cl_alignment_list_free(C.byref(out))
+
+    def polish_cyclized_graph(self, graph, path_names, sequence_names, score_scale, newick=None, max_num_match_pairs=1250000, max_count=3000,
+                              polish=None, tweak=None):
+        """Core::polish_cyclized_graph (src/core.cpp:650-767): realigns the regions cl_identify_inconsistencies reports; returns
+        (polished BaseGraph, number of regions)"""
+        mp = MergeParams()
+        self.lib.cl_merge_params_default(C.byref(mp))
+        mp.match.max_count = int(max_count)
+        mp.align.anchor.score_scale = float(score_scale)
+        mp.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
+        if tweak:
+            tweak(mp)
+        pp = polish or polish_params()
+        g, h, n = graph.as_c(), C.c_void_p(), C.c_uint64(0)
+        pn = (C.c_char_p * max(len(path_names), 1))(*[x.encode() for x in path_names])
+        sn = (C.c_char_p * max(len(sequence_names), 1))(*[x.encode() for x in sequence_names])
+        self.lib.cl_polish_cyclized_graph.restype = C.c_int
+        self.lib.cl_polish_cyclized_graph.argtypes = [C.c_void_p, C.POINTER(BaseGraphC), C.POINTER(C.c_char_p), C.c_char_p, C.POINTER(C.c_char_p), C.c_uint64,
+                                                      C.POINTER(MergeParams), C.POINTER(PolishParams), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        self._check(self.lib.cl_polish_cyclized_graph(self.handle, C.byref(g), pn, newick.encode() if newick else None, sn, len(sequence_names),
+                                                      C.byref(mp), C.byref(pp), C.byref(h), C.byref(n)))
+        return _take_owned_base_graph(self.lib, h), int(n.value)
 
     def merge(self, graph1, graph2, score_scale=1.0, max_num_match_pairs=1250000, max_count=3000, tweak=None):
         """one merge of the progressive MSA (the loop body of Core::do_execution, include/centrolign/core.hpp:268-392):

@@ -354,7 +354,7 @@ std::unique_ptr<cl_owned_match_sets> reordered_sets(const cl_match_sets& v, cons
 }
 
 // purge_uncovered_nodes (src/modify_graph.cpp:89-163): nodes no path visits (the sentinels excepted) are dropped, the others keep their order
-bool purge_uncovered(cl_owned_base_graph& g) {
+bool purge_uncovered_impl(cl_owned_base_graph& g) {
     const uint64_t n = g.label.size();
     std::vector<char> covered(n, 0);
     covered[g.src_id] = covered[g.snk_id] = 1;
@@ -450,7 +450,7 @@ bool simplify_bubbles_impl(cl_owned_base_graph& g, std::string& error) {
             }
         }
     }
-    if (did) purge_uncovered(g);
+    if (did) purge_uncovered_impl(g);
     return true;
 }
 
@@ -468,6 +468,8 @@ cl_owned_base_graph owned_copy(const cl_base_graph* g) {
 }
 
 }  // namespace
+
+bool cl_purge_uncovered(cl_owned_base_graph& g) { return purge_uncovered_impl(g); }
 
 extern "C" {
 

@@ -191,6 +191,19 @@ struct cl_owned_base_graph {
     uint64_t src_id = 0, snk_id = 0;
 };
 
+// The guide tree as Execution keeps it (src/execution.cpp:12-92: pruned to the sequences, compacted, binarised), for Core::make_copy_expanded_tree
+// (cl_polish_api.cpp); defined in cl_plan_api.cpp next to the parser
+#include <string>
+struct ClGuideTreeView {
+    std::vector<std::vector<uint32_t>> kids;   // Tree::get_children, in order
+    std::vector<std::string> label;
+    uint32_t root = 0;
+    std::vector<uint32_t> postorder;           // Tree::postorder
+};
+int cl_processed_guide_tree(const char* newick, const char* const* names, uint64_t n_names, ClGuideTreeView& out, std::string& error);
+// purge_uncovered_nodes (src/modify_graph.cpp:89-163), cl_cyclize_api.cpp
+bool cl_purge_uncovered(cl_owned_base_graph& g);
+
 // defined in cl_anchor_api.cpp
 bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp);
 

@@ -264,6 +264,29 @@ bool in_order_newick(const std::vector<std::string>& names, std::string& out, st
 
 }  // namespace
 
+int cl_processed_guide_tree(const char* newick, const char* const* names, uint64_t n_names, ClGuideTreeView& out, std::string& error) {
+    std::vector<std::string> nm(names, names + n_names);
+    std::string text;
+    GuideTree t;
+    if (newick && *newick) text = newick;
+    else if (!in_order_newick(nm, text, t.error)) { error = t.error; return CL_ERR_INVALID_ARGUMENT; }
+    if (!t.parse(text)) { error = t.error; return CL_ERR_INVALID_ARGUMENT; }
+    std::vector<uint32_t> leaf_ids;
+    for (const auto& n : nm) {
+        auto it = t.by_label.find(n);
+        if (it == t.by_label.end() || !t.kids[it->second].empty()) { error = "Guide tree does not include sequence " + n + " as a leaf"; return CL_ERR_INVALID_ARGUMENT; }
+        leaf_ids.push_back(it->second);
+    }
+    t.prune_to(leaf_ids);
+    t.compact();
+    t.binarize();
+    out.kids = t.kids;
+    out.label = t.label;
+    out.root = t.root;
+    out.postorder = t.postorder();
+    return CL_OK;
+}
+
 struct cl_fasta_owned {
     std::vector<std::string> names, seqs;
     std::vector<const char*> name_ptr, seq_ptr;

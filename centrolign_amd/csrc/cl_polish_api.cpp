@@ -6,10 +6,13 @@
 //
 // Host code (graph bookkeeping, as in the reference); the realignments themselves re-enter the hot path through cl_core_align.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <tuple>
 #include <deque>
 #include <list>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -312,6 +315,329 @@ std::vector<std::pair<uint64_t, uint64_t>> identify_inconsistencies(const cl_bas
     return merged;
 }
 
+
+// ---- InducedMatchFinder (include/centrolign/induced_match_finder.hpp, src/induced_match_finder.cpp): the full graph's matches against
+//      itself, localised to the regions that are realigned: per region the match sets that touch it, per set where its walks lie on every
+//      path and how often it occurs in the whole graph
+struct PathHitSet {
+    std::map<uint64_t, std::vector<std::pair<uint64_t, uint64_t>>> hit_locations;   // path -> (offset, index of the walk in its set), ascending
+    uint64_t length = 0, deduplicated_count = 0;
+};
+
+std::vector<std::vector<PathHitSet>> induce_matches(const cl_base_graph& g, const cl_match_sets& ms, const std::vector<std::pair<uint64_t, uint64_t>>& regions,
+                                                    const Steps& st) {
+    std::vector<std::vector<PathHitSet>> hits(regions.size());
+    std::vector<uint64_t> region_of(g.n_nodes, kNone);
+    for (size_t i = 0; i < regions.size(); ++i) {
+        std::vector<uint64_t> stack(1, regions[i].first);
+        region_of[regions[i].first] = i;
+        region_of[regions[i].second] = i;
+        while (!stack.empty()) {
+            const uint64_t v = stack.back();
+            stack.pop_back();
+            for (uint64_t e = g.next_off[v]; e < g.next_off[v + 1]; ++e) {
+                const uint64_t w = g.next_idx[e];
+                if (region_of[w] == kNone) { region_of[w] = i; stack.push_back(w); }
+            }
+        }
+    }
+    for (uint64_t s = 0; s < ms.n_sets; ++s) {
+        std::vector<uint64_t> started;   // regions whose hit set for this match set exists
+        const uint64_t n_walks = ms.set_off1[s + 1] - ms.set_off1[s];
+        for (uint64_t j = 0; j < n_walks; ++j) {
+            const uint64_t w = ms.set_off1[s] + j;
+            const uint32_t* walk = ms.nodes1 + ms.walk_off1[w];
+            const uint64_t len = ms.walk_off1[w + 1] - ms.walk_off1[w];
+            std::vector<uint64_t> touched;
+            for (uint64_t k = 0; k < len; ++k) if (region_of[walk[k]] != kNone) touched.push_back(region_of[walk[k]]);
+            std::sort(touched.begin(), touched.end());
+            touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+            if (touched.empty()) continue;
+            for (uint64_t r : touched)
+                if (std::find(started.begin(), started.end(), r) == started.end()) {
+                    started.push_back(r);
+                    hits[r].emplace_back();
+                    hits[r].back().length = len;
+                    hits[r].back().deduplicated_count = n_walks;
+                }
+            // the paths that spell the whole walk: (path, step) pairs extended node by node
+            std::vector<std::pair<uint64_t, uint64_t>> ext(st.begin(walk[0]), st.end(walk[0]));
+            for (uint64_t k = 1; k < len && !ext.empty(); ++k) {
+                std::vector<std::pair<uint64_t, uint64_t>> next;
+                for (auto it = st.begin(walk[k]); it != st.end(walk[k]); ++it)
+                    if (it->second > 0 && std::binary_search(ext.begin(), ext.end(), std::make_pair(it->first, it->second - 1))) next.push_back(*it);
+                ext.swap(next);   // ((path, step) lists of a node are ascending, so every list stays sorted)
+            }
+            for (const auto& e : ext)
+                for (uint64_t r : touched) hits[r].back().hit_locations[e.first].emplace_back(e.second + 1 - len, j);
+        }
+        for (uint64_t r : started) {
+            auto& loc = hits[r].back().hit_locations;
+            if (loc.empty() || (loc.size() == 1 && loc.begin()->second.size() == 1)) hits[r].pop_back();
+            else for (auto& kv : loc) std::sort(kv.second.begin(), kv.second.end());
+        }
+    }
+    return hits;
+}
+
+// a subproblem graph of a realignment: its paths are stretches [begin, end] of the full graph's paths
+struct SubPaths { std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> of; };   // per path (full-graph path, begin, end)
+
+// InducedMatchFinderComponentView::find_matches (induced_match_finder.hpp:100-372) as owned match sets
+std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& full, const std::vector<PathHitSet>& path_hits, const cl_base_graph& g1,
+                                                          const SubPaths& sp1, const cl_base_graph& g2, const SubPaths& sp2) {
+    std::unique_ptr<cl_owned_match_sets> out(new cl_owned_match_sets());
+    std::unordered_set<uint64_t> parent_seen;
+    uint64_t len1 = 0, len2 = 0;
+    for (int side = 0; side < 2; ++side) {
+        const SubPaths& sp = side ? sp2 : sp1;
+        uint64_t& len = side ? len2 : len1;
+        for (const auto& t : sp.of)
+            if (parent_seen.insert(std::get<0>(t)).second) len += full.path_off[std::get<0>(t) + 1] - full.path_off[std::get<0>(t)];
+    }
+    const double ratio = double(len1) / double(len2);
+    // double -> size_t as the reference's build converts it (x86-64, gcc: cvttsd2si below 2^63, else of x - 2^63 with the top bit flipped): when
+    // both graphs hold stretches of the SAME paths only, the second graph's path length is 0 (a parent path is counted once, for the graph that
+    // shows it first), the ratio is infinite, and infinity — not representable — converts to 0; the counts then fall back to what was observed
+    auto to_size = [](double x) -> uint64_t {
+        const double two63 = 9223372036854775808.0;
+        if (x < two63) return x >= -two63 ? (uint64_t)(int64_t)x : 0x8000000000000000ull;
+        const double y = x - two63;
+        return (y < two63 ? (uint64_t)(int64_t)y : 0x8000000000000000ull) ^ 0x8000000000000000ull;
+    };
+    auto assign_count = [&to_size](uint64_t observed1, uint64_t observed2, uint64_t target, double ratio12) {
+        uint64_t count2 = to_size(round(sqrt(target / ratio12)));
+        uint64_t count1 = to_size(round(sqrt(target * ratio12)));
+        if (count1 >= observed1 && count2 < observed2) { count2 = observed2; count1 = to_size(round(target / double(count2))); }
+        else if (count2 >= observed2 && count1 < observed1) { count1 = observed1; count2 = to_size(round(target / double(count1))); }
+        return std::make_pair(std::max(count1, observed1), std::max(count2, observed2));
+    };
+    for (const PathHitSet& hs : path_hits) {
+        std::unordered_set<uint64_t> origin_walks;
+        std::vector<std::tuple<uint64_t, uint64_t, bool, uint64_t, uint64_t>> iv;   // (match begin, match end, on graph 1, path, offset on the path)
+        uint64_t observed1 = 0, observed2 = 0;
+        for (int side = 0; side < 2; ++side) {
+            const bool do1 = side == 0;
+            const cl_base_graph& g = do1 ? g1 : g2;
+            const SubPaths& sp = do1 ? sp1 : sp2;
+            uint64_t& observed = do1 ? observed1 : observed2;
+            std::set<std::pair<uint64_t, uint64_t>> initial;
+            for (uint64_t p = 0; p < g.n_paths; ++p) {
+                const uint64_t parent = std::get<0>(sp.of[p]), pb = std::get<1>(sp.of[p]), pe = std::get<2>(sp.of[p]);
+                auto it = hs.hit_locations.find(parent);
+                if (it == hs.hit_locations.end()) continue;
+                auto lo = std::lower_bound(it->second.begin(), it->second.end(), std::make_pair(pb >= hs.length ? pb - hs.length : (uint64_t)0, (uint64_t)0));
+                auto hi = std::upper_bound(it->second.begin(), it->second.end(), std::make_pair(pe + 1, (uint64_t)0));
+                for (auto l = lo; l != hi; ++l) {
+                    const uint64_t mb = l->first, me = mb + hs.length;
+                    origin_walks.insert(l->second);
+                    const uint64_t begin = mb < pb ? pb - mb : 0, end = me > pe ? pe - mb : hs.length;
+                    const uint64_t offset = mb < pb ? 0 : mb - pb;
+                    const uint64_t node = g.path_nodes[g.path_off[p] + offset];
+                    if (initial.emplace(node, begin).second) iv.emplace_back(begin, end, do1, p, offset);
+                    ++observed;
+                }
+            }
+        }
+        const uint64_t total = observed1 * observed2 + hs.deduplicated_count - origin_walks.size();
+        const auto counts = assign_count(observed1, observed2, total, ratio);
+        std::sort(iv.begin(), iv.end());
+        std::vector<size_t> active;   // a heap by interval end (std::push_heap / pop_heap: the order of the walks of a set is the heap's)
+        auto cmp = [&](size_t a, size_t b) { return std::get<1>(iv[a]) > std::get<1>(iv[b]); };
+        uint64_t last = 0, n1 = 0, n2 = 0;
+        size_t i = 0;
+        while (i < iv.size() || !active.empty()) {
+            bool is_start;
+            uint64_t next;
+            if (active.empty() || (i < iv.size() && std::get<0>(iv[i]) < std::get<1>(iv[active.front()]))) { is_start = true; next = std::get<0>(iv[i]); }
+            else { is_start = false; next = std::get<1>(iv[active.front()]); }
+            if (n1 != 0 && n2 != 0 && next != last) {
+                for (int side = 0; side < 2; ++side) {
+                    auto& set_off = side ? out->set_off2 : out->set_off1;
+                    auto& walk_off = side ? out->walk_off2 : out->walk_off1;
+                    auto& nodes = side ? out->nodes2 : out->nodes1;
+                    const cl_base_graph& g = side ? g2 : g1;
+                    for (size_t idx : active) {
+                        if (std::get<2>(iv[idx]) != (side == 0)) continue;
+                        const uint64_t b = std::get<4>(iv[idx]) + (last - std::get<0>(iv[idx])), e = b + (next - last);
+                        const uint32_t* path = g.path_nodes + g.path_off[std::get<3>(iv[idx])];
+                        nodes.insert(nodes.end(), path + b, path + e);
+                        walk_off.push_back(nodes.size());
+                    }
+                    set_off.push_back(walk_off.size() - 1);
+                }
+                out->full_length.push_back(hs.length);
+                out->count1.push_back(counts.first);
+                out->count2.push_back(counts.second);
+            }
+            last = next;
+            if (is_start) {
+                size_t j = i + 1;
+                while (j < iv.size() && std::get<0>(iv[j]) == std::get<0>(iv[i])) ++j;
+                for (size_t k = i; k < j; ++k) {
+                    active.push_back(k);
+                    if (std::get<2>(iv[k])) ++n1; else ++n2;
+                    std::push_heap(active.begin(), active.end(), cmp);
+                }
+                i = j;
+            } else {
+                auto heap_end = active.end();
+                std::pop_heap(active.begin(), heap_end--, cmp);
+                while (heap_end != active.begin() && std::get<1>(iv[active.front()]) == std::get<1>(iv[active.back()])) std::pop_heap(active.begin(), heap_end--, cmp);
+                for (auto it = heap_end; it != active.end(); ++it) { if (std::get<2>(iv[*it])) --n1; else --n2; }
+                active.resize(heap_end - active.begin());
+            }
+        }
+    }
+    return out;
+}
+
+
+// Core::make_copy_expanded_tree (src/core.cpp:769-976) up to the Newick text it builds (distances left out: nothing downstream reads them):
+// the guide tree with every leaf replaced by its copies in this region; the highest subtrees whose observed leaves all have the same number
+// of copies are repeated once per copy under a node of their own, so that corresponding copies are aligned with one another first
+bool expanded_newick(const ClGuideTreeView& tree, const std::vector<std::tuple<uint64_t, uint64_t, uint64_t>>& intervals,
+                     const std::vector<std::string>& subpath_names, const std::vector<std::string>& subpath_parent, std::string& out, std::string& error) {
+    const uint64_t U2 = ~(uint64_t)0 - 1, U1 = ~(uint64_t)0;   // the reference's -2 "unobserved" and -1 "inconsistent"
+    std::unordered_map<std::string, std::vector<std::string>> copies;
+    {
+        std::vector<size_t> idx(intervals.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return intervals[a] < intervals[b]; });
+        for (size_t i : idx) copies[subpath_parent[i]].push_back(subpath_names[i]);
+    }
+    std::unordered_map<std::string, uint32_t> id_of;
+    for (uint32_t v = 0; v < tree.label.size(); ++v) if (!tree.label[v].empty()) id_of[tree.label[v]] = v;
+    std::vector<uint64_t> count(tree.kids.size(), 0);
+    for (const auto& c : copies) {
+        auto it = id_of.find(c.first);
+        if (it == id_of.end()) { error = "path " + c.first + " is not in the guide tree"; return false; }
+        count[it->second] = c.second.size();
+    }
+    for (uint32_t v : tree.postorder) {
+        if (tree.kids[v].empty()) continue;
+        uint64_t last = U2;
+        for (uint32_t c : tree.kids[v]) {
+            if (count[c] == U1 || (last != U2 && count[c] != last)) { last = U1; break; }
+            if (count[c] != 0) last = count[c];
+        }
+        if (last != U2) count[v] = last;
+    }
+    if (count[tree.root] == 0) { error = "Root is not included in induced subpath tree"; return false; }
+    struct Rec { uint64_t node, copy; std::vector<std::pair<uint64_t, uint64_t>> edges; size_t next = 0; };
+    std::vector<Rec> stack(1);
+    if (count[tree.root] == U1) {
+        stack.back().node = tree.root; stack.back().copy = U1;
+        for (uint32_t c : tree.kids[tree.root]) if (count[c] != 0) stack.back().edges.emplace_back(c, U1);
+    } else {
+        stack.back().node = U1; stack.back().copy = U1;
+        for (uint64_t i = 0; i < count[tree.root]; ++i) stack.back().edges.emplace_back(tree.root, i);
+    }
+    while (!stack.empty()) {
+        if (stack.back().next == stack.back().edges.size()) {
+            const Rec& top = stack.back();
+            if (!top.edges.empty()) out += ')';
+            if (top.node != U1 && tree.kids[top.node].empty()) {
+                if (top.copy == U1) { error = "Leaf of induced subpath tree was not marked as having consistent count"; return false; }
+                out += '"' + copies.at(tree.label[top.node])[top.copy] + '"';
+            }
+            stack.pop_back();
+            continue;
+        }
+        out += stack.back().next == 0 ? '(' : ',';
+        const auto edge = stack.back().edges[stack.back().next++];
+        Rec rec;
+        if (edge.second == U1 && count[edge.first] != U1) {   // the first subtree with a consistent count on the way down: a node to house its copies
+            rec.node = U1; rec.copy = U1;
+            for (uint64_t i = 0; i < count[edge.first]; ++i) rec.edges.emplace_back(edge.first, i);
+        } else {
+            rec.node = edge.first; rec.copy = edge.second;
+            for (uint32_t c : tree.kids[edge.first]) if (count[c] != 0) rec.edges.emplace_back(c, edge.second);
+        }
+        stack.push_back(std::move(rec));
+    }
+    out += ';';
+    return true;
+}
+
+// CL_POLISH_DEBUG=<file>: what every realignment was given and what it made, in the container format of oracle/ref_driver.cpp's dumps
+// (name, type, count, data), for comparisons against the reference's recorded flow; development aid only
+struct DebugDump {
+    FILE* f = nullptr;
+    DebugDump() { const char* p = getenv("CL_POLISH_DEBUG"); if (p && *p) { f = fopen(p, "wb"); if (f) fwrite("CLDUMP1\n", 1, 8, f); } }
+    ~DebugDump() { if (f) fclose(f); }
+    void put(const std::string& name, uint8_t dtype, const void* data, uint64_t count, size_t esz) {
+        if (!f) return;
+        const uint32_t nl = (uint32_t)name.size();
+        fwrite(&nl, 4, 1, f); fwrite(name.data(), 1, nl, f); fwrite(&dtype, 1, 1, f); fwrite(&count, 8, 1, f);
+        if (count) fwrite(data, esz, count, f);
+    }
+    void str(const std::string& n, const std::string& v) { put(n, 0, v.data(), v.size(), 1); }
+    void u64(const std::string& n, const std::vector<uint64_t>& v) { put(n, 2, v.data(), v.size(), 8); }
+};
+
+struct MutableGraph {   // BaseGraph with add_node / add_edge appending (src/graph.cpp:214-229)
+    std::vector<uint8_t> label;
+    std::vector<std::vector<uint32_t>> next, prev;
+    std::vector<uint64_t> path_off;
+    std::vector<uint32_t> path_nodes;
+    uint64_t src = 0, snk = 0;
+    explicit MutableGraph(const cl_base_graph& g) : label(g.label, g.label + g.n_nodes), next(g.n_nodes), prev(g.n_nodes),
+        path_off(g.path_off, g.path_off + g.n_paths + 1), path_nodes(g.path_nodes, g.path_nodes + g.path_off[g.n_paths]), src(g.src_id), snk(g.snk_id) {
+        for (uint64_t v = 0; v < g.n_nodes; ++v) {
+            next[v].assign(g.next_idx + g.next_off[v], g.next_idx + g.next_off[v + 1]);
+            prev[v].assign(g.prev_idx + g.prev_off[v], g.prev_idx + g.prev_off[v + 1]);
+        }
+    }
+    uint32_t add_node(uint8_t l) { label.push_back(l); next.emplace_back(); prev.emplace_back(); return (uint32_t)label.size() - 1; }
+    void add_edge(uint32_t a, uint32_t b) { next[a].push_back(b); prev[b].push_back(a); }
+    cl_owned_base_graph* owned() const {
+        std::unique_ptr<cl_owned_base_graph> o(new cl_owned_base_graph());
+        o->label = label;
+        o->next_off.assign(1, 0); o->prev_off.assign(1, 0);
+        for (size_t v = 0; v < label.size(); ++v) {
+            o->next_idx.insert(o->next_idx.end(), next[v].begin(), next[v].end()); o->next_off.push_back(o->next_idx.size());
+            o->prev_idx.insert(o->prev_idx.end(), prev[v].begin(), prev[v].end()); o->prev_off.push_back(o->prev_idx.size());
+        }
+        o->path_off = path_off;
+        o->path_nodes = path_nodes;
+        o->src_id = src; o->snk_id = snk;
+        return o.release();
+    }
+};
+
+struct Realigned { cl_owned_base_graph* graph = nullptr; SubPaths paths; };
+
+// Core::integrate_polished_subgraphs (src/core.cpp:978-1069) without the final purge
+void integrate(MutableGraph& root, const std::vector<Realigned>& realigned) {
+    for (const Realigned& r : realigned) {
+        cl_base_graph g;
+        cl_owned_base_graph_view(r.graph, &g);
+        std::vector<uint32_t> trans(g.n_nodes, ~0u);
+        for (uint64_t v = 0; v < g.n_nodes; ++v) if (v != g.src_id && v != g.snk_id) trans[v] = root.add_node(g.label[v]);
+        for (uint64_t v = 0; v < g.n_nodes; ++v) {
+            if (v == g.src_id || v == g.snk_id) continue;
+            for (uint64_t e = g.next_off[v]; e < g.next_off[v + 1]; ++e) {
+                const uint64_t w = g.next_idx[e];
+                if (w != g.src_id && w != g.snk_id) root.add_edge(trans[v], trans[w]);
+            }
+        }
+        std::set<std::pair<uint32_t, uint32_t>> adjacencies;
+        for (uint64_t p = 0; p < g.n_paths; ++p) {
+            const uint64_t parent = std::get<0>(r.paths.of[p]), begin = std::get<1>(r.paths.of[p]), end = std::get<2>(r.paths.of[p]);
+            if (begin == end) continue;
+            uint32_t* rp = root.path_nodes.data() + root.path_off[parent];
+            const uint64_t len = root.path_off[parent + 1] - root.path_off[parent];
+            const uint32_t before = begin == 0 ? (uint32_t)root.src : rp[begin - 1], after = end + 1 == len ? (uint32_t)root.snk : rp[end + 1];
+            const uint32_t* sub = g.path_nodes + g.path_off[p];
+            const uint64_t sub_len = g.path_off[p + 1] - g.path_off[p];
+            if (adjacencies.emplace(before, trans[sub[0]]).second) root.add_edge(before, trans[sub[0]]);
+            if (adjacencies.emplace(trans[sub[sub_len - 1]], after).second) root.add_edge(trans[sub[sub_len - 1]], after);
+            for (uint64_t i = 0; i < sub_len; ++i) rp[begin + i] = trans[sub[i]];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -338,6 +664,141 @@ int cl_identify_inconsistencies(const cl_base_graph* graph, const cl_polish_para
     if (!*bounds_out) return CL_ERR_OUT_OF_MEMORY;
     for (size_t i = 0; i < inc.size(); ++i) { (*bounds_out)[2 * i] = inc[i].first; (*bounds_out)[2 * i + 1] = inc[i].second; }
     *n_out = inc.size();
+    return CL_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// Core::polish_cyclized_graph (src/core.cpp:650-767): the regions InconsistencyIdentifier reports are cut out path by path, every stretch a
+// sequence of its own, realigned from scratch over the guide tree expanded by their copies — match sets induced from the whole graph's
+// matches against itself, Core::align with score_boundaries (core.hpp:235-238) and fuse per tree node: the hot path again — and the
+// realigned subgraphs put back in place of the old nodes (integrate_polished_subgraphs + purge_uncovered_nodes)
+int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const char* const* path_names, const char* newick, const char* const* sequence_names,
+                             uint64_t n_sequences, const cl_merge_params* mp, const cl_polish_params* pp, cl_owned_base_graph** out, uint64_t* n_regions_out) {
+    if (!ctx || !graph || !path_names || !sequence_names || !mp || !pp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (n_regions_out) *n_regions_out = 0;
+    bool ok = true;
+    const auto regions = identify_inconsistencies(*graph, *pp, ok);
+    if (!ok) { cl_set_error(ctx, "cl_polish_cyclized_graph: no snarl decomposition of the graph"); return CL_ERR_INVALID_ARGUMENT; }
+    if (n_regions_out) *n_regions_out = regions.size();
+    MutableGraph root(*graph);
+    if (regions.empty()) { *out = root.owned(); return CL_OK; }
+    Steps st;
+    st.build(*graph);
+    // the whole graph's matches against itself give the counts (reassign_sentinels 5, 6; second copy under 7, 8: src/core.cpp:683-696)
+    std::vector<uint8_t> lab1(graph->label, graph->label + graph->n_nodes), lab2(lab1);
+    lab1[graph->src_id] = 5; lab1[graph->snk_id] = 6;
+    lab2[graph->src_id] = 7; lab2[graph->snk_id] = 8;
+    cl_base_graph a = *graph, b = *graph;
+    a.label = lab1.data();
+    b.label = lab2.data();
+    root.label[graph->src_id] = 5; root.label[graph->snk_id] = 6;
+    cl_owned_match_sets* full = nullptr;
+    int rc = cl_find_matches(ctx, &a, &b, &mp->match, &full, nullptr);
+    if (rc) return rc;
+    cl_match_sets fv;
+    cl_owned_match_sets_view(full, &fv);
+    const auto hits = induce_matches(a, fv, regions, st);
+    cl_owned_match_sets_free(full);
+    ClGuideTreeView tree;
+    std::string error;
+    if ((rc = cl_processed_guide_tree(newick, sequence_names, n_sequences, tree, error))) { cl_set_error(ctx, "%s", error.c_str()); return rc; }
+    std::vector<Realigned> realigned;
+    auto fail = [&](int code) { for (auto& r : realigned) cl_owned_base_graph_free(r.graph); return code; };
+    cl_core_align_params ap = mp->align;
+    ap.partition.score_boundaries = 1;
+    static const char kDecode[] = "ACGTN";
+    DebugDump dbg;
+    for (size_t ri = 0; ri < regions.size(); ++ri) {
+        const std::string rp = "region" + std::to_string(ri) + ".";
+        std::map<uint64_t, std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> loc;
+        for (auto it = st.begin(regions[ri].first); it != st.end(regions[ri].first); ++it) loc[it->first].first.push_back(it->second);
+        for (auto it = st.begin(regions[ri].second); it != st.end(regions[ri].second); ++it) loc[it->first].second.push_back(it->second);
+        std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> intervals;
+        std::vector<std::string> names, parents, seqs;
+        for (auto& kv : loc) {
+            if (kv.second.first.size() != kv.second.second.size()) { cl_set_error(ctx, "Path starts or ends in the middle of a cycle realignment interval"); return fail(CL_ERR_INVALID_ARGUMENT); }
+            for (size_t k = 0; k < kv.second.first.size(); ++k) {
+                const uint64_t bg = kv.second.first[k], en = kv.second.second[k];
+                intervals.emplace_back(kv.first, bg, en);
+                parents.push_back(path_names[kv.first]);
+                names.push_back(parents.back() + ":" + std::to_string(bg) + "-" + std::to_string(en));
+                std::string sq;
+                for (uint64_t j = bg; j <= en; ++j) {
+                    const uint8_t l = graph->label[graph->path_nodes[graph->path_off[kv.first] + j]];
+                    sq.push_back(l < 5 ? kDecode[l] : 'N');
+                }
+                seqs.push_back(std::move(sq));
+            }
+        }
+        std::string text;
+        if (!expanded_newick(tree, intervals, names, parents, text, error)) { cl_set_error(ctx, "%s", error.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+        if (dbg.f) { std::string all; for (const auto& nm : names) all += nm + "\n"; dbg.str(rp + "names", all); dbg.str(rp + "tree", text); }
+        std::vector<const char*> name_ptr;
+        for (const auto& nm : names) name_ptr.push_back(nm.c_str());
+        cl_msa_plan plan;
+        if ((rc = cl_msa_plan_create(ctx, text.c_str(), name_ptr.data(), name_ptr.size(), &plan))) return fail(rc);
+        const uint64_t n_slots = plan.n_leaves + plan.n_merges;
+        std::vector<cl_owned_base_graph*> slot_graph(n_slots, nullptr);
+        std::vector<SubPaths> slot_paths(n_slots);
+        auto drop = [&]() { for (auto* g : slot_graph) cl_owned_base_graph_free(g); cl_msa_plan_free(&plan); };
+        for (uint64_t i = 0; i < plan.n_leaves && !rc; ++i) {
+            const uint64_t sq = plan.leaf_sequence[i];
+            rc = cl_leaf_graph(seqs[sq].c_str(), seqs[sq].size(), &slot_graph[i]);
+            slot_paths[i].of.assign(1, intervals[sq]);
+        }
+        for (uint64_t k = 0; k < plan.n_merges && !rc; ++k) {
+            const uint64_t ia = plan.merge_children[2 * k], ib = plan.merge_children[2 * k + 1];
+            cl_base_graph g1, g2;
+            cl_owned_base_graph_view(slot_graph[ia], &g1);
+            cl_owned_base_graph_view(slot_graph[ib], &g2);
+            std::vector<uint8_t> l1(g1.label, g1.label + g1.n_nodes), l2(g2.label, g2.label + g2.n_nodes);
+            l1[g1.src_id] = 5; l1[g1.snk_id] = 6;
+            l2[g2.src_id] = 7; l2[g2.snk_id] = 8;
+            g1.label = l1.data();
+            g2.label = l2.data();
+            auto ms = induced_find_matches(a, hits[ri], g1, slot_paths[ia], g2, slot_paths[ib]);
+            cl_match_sets view;
+            cl_owned_match_sets_view(ms.get(), &view);
+            if (dbg.f) {
+                std::vector<uint64_t> flat;
+                for (uint64_t st_ = 0; st_ < view.n_sets; ++st_) {
+                    const uint64_t w1 = view.set_off1[st_ + 1] - view.set_off1[st_], w2 = view.set_off2[st_ + 1] - view.set_off2[st_];
+                    flat.push_back(w1); flat.push_back(w2); flat.push_back(w1 ? view.walk_off1[view.set_off1[st_] + 1] - view.walk_off1[view.set_off1[st_]] : 0);
+                    flat.push_back(view.count1[st_]); flat.push_back(view.count2[st_]); flat.push_back(view.full_length[st_]);
+                    for (uint64_t w = view.set_off1[st_]; w < view.set_off1[st_ + 1]; ++w) flat.push_back(view.nodes1[view.walk_off1[w]]);
+                    for (uint64_t w = view.set_off2[st_]; w < view.set_off2[st_ + 1]; ++w) flat.push_back(view.nodes2[view.walk_off2[w]]);
+                }
+                dbg.u64(rp + "m" + std::to_string(k) + ".matches", flat);
+            }
+            cl_core_align_result al;
+            if ((rc = cl_core_align(ctx, &g1, &g2, &view, &ap, &al))) break;
+            const uint64_t slot = plan.n_leaves + k;
+            if (dbg.f) dbg.put(rp + "m" + std::to_string(k) + ".alignment", 2, al.alignment.pairs, 2 * al.alignment.n_pairs, 8);
+            rc = cl_fuse(&g1, &g2, al.alignment.pairs, al.alignment.n_pairs, &slot_graph[slot]);
+            cl_core_align_result_free(&al);
+            if (rc) break;
+            slot_paths[slot].of = slot_paths[ia].of;
+            slot_paths[slot].of.insert(slot_paths[slot].of.end(), slot_paths[ib].of.begin(), slot_paths[ib].of.end());
+            cl_owned_base_graph_free(slot_graph[ia]); slot_graph[ia] = nullptr;
+            cl_owned_base_graph_free(slot_graph[ib]); slot_graph[ib] = nullptr;
+        }
+        if (rc) { drop(); return fail(rc); }
+        Realigned r;
+        r.graph = slot_graph[n_slots - 1];
+        slot_graph[n_slots - 1] = nullptr;
+        r.paths = slot_paths[n_slots - 1];
+        realigned.push_back(std::move(r));
+        drop();
+    }
+    integrate(root, realigned);
+    for (auto& r : realigned) cl_owned_base_graph_free(r.graph);
+    cl_owned_base_graph* result = root.owned();
+    cl_purge_uncovered(*result);
+    *out = result;
     return CL_OK;
 }
 

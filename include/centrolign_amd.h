@@ -628,6 +628,15 @@ void cl_polish_params_default(cl_polish_params* p);
  * [2 * *n_out] (first node, last node) of the mutually disjoint regions to realign, in the reference's order. Host only. */
 int  cl_identify_inconsistencies(const cl_base_graph* graph, const cl_polish_params* params, uint64_t** bounds_out, uint64_t* n_out);
 
+/* Core::polish_cyclized_graph (src/core.cpp:650-767): every region cl_identify_inconsistencies reports is realigned from scratch — the stretches
+ * of the paths through it as sequences of their own, the guide tree (newick, NULL = in order; sequence_names = the FASTA's names) expanded by
+ * their copies (make_copy_expanded_tree, :769-976), match sets induced from the whole graph's matches against itself (InducedMatchFinder),
+ * Core::align + fuse per tree node on the device — and put back in place (integrate_polished_subgraphs, :978-1069).  path_names: the names of
+ * graph's paths; params->align.anchor.score_scale = the calibrated scale.  *n_regions_out (may be NULL): regions realigned. */
+int  cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const char* const* path_names, const char* newick,
+                              const char* const* sequence_names, uint64_t n_sequences, const cl_merge_params* params, const cl_polish_params* polish,
+                              cl_owned_base_graph** out, uint64_t* n_regions_out);
+
 /* The per-leaf step of the calibration (src/core.cpp:122-175) that also keeps what the tandem-duplication rounds read: the leaf's matches
  * against itself and the main-diagonal chain the scale was estimated on (:168-172).  *memo_out (may be NULL: then this is
  * cl_leaf_intrinsic_scale) is released with cl_leaf_calibration_free. */

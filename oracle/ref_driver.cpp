@@ -27,6 +27,7 @@
 #include "centrolign/tree.hpp"
 #include "centrolign/fuse.hpp"
 #include "centrolign/gfa.hpp"
+#include "centrolign/induced_match_finder.hpp"
 #include "centrolign/parameters.hpp"
 #include "centrolign/stitcher.hpp"
 #include "centrolign/utility.hpp"
@@ -745,6 +746,85 @@ struct CycCore : public Core {
         return bond_alns;
     }
 
+    /* Core::polish_cyclized_graph (src/core.cpp:650-767) call for call, with the loop of do_execution (core.hpp:256-403) opened up so that every
+     * realignment's subpaths, induced match sets and result can be recorded */
+    void polish_dump(Subproblem& subproblem, Dump& dump) {
+        auto inconsistencies = inconsistency_identifier.identify_inconsistencies(subproblem.graph, subproblem.tableau);
+        if (inconsistencies.empty()) return;
+        StepIndex step_index(subproblem.graph);
+        reassign_sentinels(subproblem.graph, subproblem.tableau, 5, 6);
+        SentinelTableau dummy = subproblem.tableau;
+        dummy.src_sentinel = 7; dummy.snk_sentinel = 8;
+        std::vector<match_set_t> full = path_match_finder.find_matches(subproblem.graph, subproblem.graph, subproblem.tableau, dummy);
+        dump.u64("polish.full_match_sets", std::vector<uint64_t>{(uint64_t)full.size()});
+        InducedMatchFinder induced(subproblem.graph, full, inconsistencies, step_index);
+        std::vector<Subproblem> realigned;
+        for (size_t i = 0; i < inconsistencies.size(); ++i) {
+            auto inc = inconsistencies[i];
+            std::unordered_map<uint64_t, std::pair<std::vector<size_t>, std::vector<size_t>>> loc;
+            for (auto step : step_index.path_steps(inc.first)) loc[step.first].first.push_back(step.second);
+            for (auto step : step_index.path_steps(inc.second)) loc[step.first].second.push_back(step.second);
+            std::vector<uint64_t> path_ids;
+            for (auto& kv : loc) path_ids.push_back(kv.first);
+            std::sort(path_ids.begin(), path_ids.end());
+            std::vector<std::tuple<uint64_t, size_t, size_t>> intervals;
+            std::vector<std::pair<std::string, std::string>> subpaths;
+            for (auto pid : path_ids) {
+                const auto& l = loc[pid];
+                for (size_t k = 0; k < l.first.size(); ++k) {
+                    intervals.emplace_back(pid, l.first[k], l.second[k]);
+                    subpaths.emplace_back();
+                    subpaths.back().first = get_subpath_name(subproblem.graph.path_name(pid), l.first[k], l.second[k]);
+                    for (size_t j = l.first[k]; j <= l.second[k]; ++j) subpaths.back().second.push_back(decode_base(subproblem.graph.label(subproblem.graph.path(pid)[j])));
+                }
+            }
+            const std::string rp = "region" + std::to_string(i) + ".";
+            {
+                std::string names;
+                for (const auto& sp : subpaths) names += sp.first + "\n";
+                dump.str(rp + "names", names);
+            }
+            auto expanded = make_copy_expanded_tree(intervals, subpaths);
+            dump.str(rp + "tree", expanded.to_newick());
+            Execution realignment(std::move(subpaths), std::move(expanded));
+            auto view = induced.component_view(i);
+            size_t merge = 0;
+            auto saved = logging::level;
+            while (!realignment.finished()) {
+                auto ptrs = realignment.next();
+                auto& next_problem = *std::get<0>(ptrs);
+                auto& sp1 = *std::get<1>(ptrs);
+                auto& sp2 = *std::get<2>(ptrs);
+                reassign_sentinels(sp1.graph, sp1.tableau, 5, 6);
+                reassign_sentinels(sp2.graph, sp2.tableau, 7, 8);
+                auto matches = view.find_matches(sp1.graph, sp2.graph, sp1.tableau, sp2.tableau);
+                {
+                    std::vector<uint64_t> flat;   /* per set: n walks1, n walks2, length, count1, count2, full_length, then the walks' first nodes */
+                    for (const auto& ms : matches) {
+                        flat.push_back(ms.walks1.size()); flat.push_back(ms.walks2.size()); flat.push_back(ms.walks1.empty() ? 0 : ms.walks1.front().size());
+                        flat.push_back(ms.count1); flat.push_back(ms.count2); flat.push_back(ms.full_length);
+                        for (const auto& w : ms.walks1) flat.push_back(w.front());
+                        for (const auto& w : ms.walks2) flat.push_back(w.front());
+                    }
+                    dump.u64(rp + "m" + std::to_string(merge) + ".matches", flat);
+                }
+                PathMerge<> pm1(sp1.graph, sp1.tableau), pm2(sp2.graph, sp2.tableau);
+                next_problem.alignment = align(matches, sp1, sp2, pm1, pm2, false);
+                dump_alignment(dump, rp + "m" + std::to_string(merge) + ".alignment", next_problem.alignment);
+                BaseGraph fused = std::move(sp1.graph);
+                fuse(fused, sp2.graph, sp1.tableau, sp2.tableau, next_problem.alignment);
+                next_problem.graph = std::move(fused);
+                next_problem.tableau = sp1.tableau;
+                next_problem.complete = true;
+                ++merge;
+            }
+            logging::level = saved;
+            dump_base_graph(dump, rp + "graph.", realignment.final_subproblem().graph, realignment.final_subproblem().tableau);
+            realigned.emplace_back(std::move(realignment.final_subproblem()));
+        }
+        integrate_polished_subgraphs(subproblem, realigned);
+    }
+
     void run(Dump* dump) {   /* src/core.cpp:63-94 + apply_bonds (:594-648) */
         auto bond_alignments = calibrate_and_bond(dump);
         do_execution(main_execution, this->path_match_finder, true);
@@ -775,7 +855,8 @@ struct CycCore : public Core {
             for (const auto& b : inc) { flat.push_back(b.first); flat.push_back(b.second); }
             dump->u64("inconsistencies", flat);
         }
-        polish_cyclized_graph(root);
+        if (dump) polish_dump(root, *dump);
+        else polish_cyclized_graph(root);
         if (dump) dump_base_graph(*dump, "polished.", root.graph, root.tableau);
     }
 };

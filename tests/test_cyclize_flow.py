@@ -125,3 +125,29 @@ def test_leaf_calibration_and_bond_rounds_match_the_reference(gpu_ctx):
         finally:
             for h in memos:
                 gpu_ctx.free_leaf_calibration(h)
+
+
+def test_inconsistencies_match_the_reference():
+    """host only: InconsistencyIdentifier::identify_inconsistencies on the cyclised graphs — snarl tree of a cyclic graph, tight cycles,
+    indels placed inconsistently across a bond, merging along chains, padding: the same regions in the same order"""
+    n = 0
+    for name, d, seqs, min_len, budget in cases():
+        got = capi.identify_inconsistencies(graph_of(d, "simplified."))
+        assert np.array_equal(got, d["inconsistencies"].reshape(-1, 2)), name
+        n += len(got)
+    assert n >= 20
+
+
+@pytest.mark.gpu
+def test_polishing_matches_the_reference(gpu_ctx):
+    """device: Core::polish_cyclized_graph — every region realigned through the hot path with induced matches — gives the reference's polished
+    graph, and its GFA is the text the reference's -c run printed"""
+    import re
+    for name, d, seqs, min_len, budget in cases():
+        text = d["output"].tobytes()
+        path_names = re.findall(r"^P\t(\S+)", text.decode(), re.M)
+        seq_names = ["s%d" % i for i in range(len(seqs))]
+        got, n_regions = gpu_ctx.polish_cyclized_graph(graph_of(d, "simplified."), path_names, seq_names, float(d["score_scale"][0]), max_num_match_pairs=budget)
+        assert n_regions == len(d["inconsistencies"]) // 2
+        assert capi.graphs_equal(got, graph_of(d, "polished.")), name
+        assert capi.write_gfa(got, path_names) == text, name
