@@ -617,16 +617,30 @@ class MsaPlanC(C.Structure):
                 ("merge_children", C.POINTER(C.c_uint64))]
 
 
+class BondParams(C.Structure):
+    """cl_bond_params: Bonder's tunables as the CLI sets them (src/parameters.cpp:91-97)"""
+    _fields_ = [("min_opt_proportion", C.c_double), ("include_gap_scores", C.c_int), ("min_length", C.c_double),
+                ("deviation_drift_factor", C.c_double), ("separation_drift_factor", C.c_double),
+                ("deduplication_slosh_proportion", C.c_double), ("trim_window_proportion", C.c_double)]
+
+
+class PolishParams(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("max_tight_cycle_size", "max_bond_inconsistency_window", "min_inconsistency_disjoint_length",
+                                          "min_inconsistency_total_length", "padding_target_min_length", "padding_max_length_limit")]
+
+
 class MsaParams(C.Structure):
     """cl_msa_params"""
     _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int), ("n_workers", C.c_int), ("subproblems_prefix", C.c_char_p), ("restart", C.c_int),
-                ("induced_pairwise_prefix", C.c_char_p)]
+                ("induced_pairwise_prefix", C.c_char_p), ("cyclize", C.c_int), ("max_tandem_duplication_search_rounds", C.c_uint64),
+                ("bonds", BondParams), ("polish", PolishParams)]
 
 
 class MsaStats(C.Structure):
     """cl_msa_stats"""
     _fields_ = [("n_merges", C.c_uint64), ("root_nodes", C.c_uint64), ("score_scale", C.c_double), ("calibration_s", C.c_double),
-                ("match_s", C.c_double), ("align_s", C.c_double), ("fuse_s", C.c_double), ("total_s", C.c_double), ("n_restarted", C.c_uint64)]
+                ("match_s", C.c_double), ("align_s", C.c_double), ("fuse_s", C.c_double), ("total_s", C.c_double), ("n_restarted", C.c_uint64),
+                ("n_bonds", C.c_uint64), ("n_polished_regions", C.c_uint64), ("bonds_s", C.c_double), ("cyclize_s", C.c_double)]
 
 
 def parse_fasta(text):
@@ -929,7 +943,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 3     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 4     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1114,13 +1128,6 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-class BondParams(C.Structure):
-    """cl_bond_params: Bonder's tunables as the CLI sets them (src/parameters.cpp:91-97)"""
-    _fields_ = [("min_opt_proportion", C.c_double), ("include_gap_scores", C.c_int), ("min_length", C.c_double),
-                ("deviation_drift_factor", C.c_double), ("separation_drift_factor", C.c_double),
-                ("deduplication_slosh_proportion", C.c_double), ("trim_window_proportion", C.c_double)]
-
-
 class ChainAnchorsC(C.Structure):
     _fields_ = [("n", C.c_uint64), ("walk_off", C.c_void_p), ("walk1", C.c_void_p), ("walk2", C.c_void_p), ("score", C.c_void_p),
                 ("gap_after", C.c_void_p), ("gap_score_after", C.c_void_p)]
@@ -1209,11 +1216,6 @@ def apply_bonds(root, path_of_alignment, alignments):
     if rc:
         raise ClError(rc, "cl_apply_bonds")
     return _take_owned_base_graph(lib, h)
-
-
-class PolishParams(C.Structure):
-    _fields_ = [(k, C.c_uint64) for k in ("max_tight_cycle_size", "max_bond_inconsistency_window", "min_inconsistency_disjoint_length",
-                                          "min_inconsistency_total_length", "padding_target_min_length", "padding_max_length_limit")]
 
 
 def polish_params(**kw):
@@ -1596,9 +1598,9 @@ class Context:
             self.lib.cl_merge_result_free(C.byref(out))
 
     def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False, subproblems_prefix=None,
-            restart=False, induced_pairwise_prefix=None, workers=1):
+            restart=False, induced_pairwise_prefix=None, workers=1, cyclize=False, min_cyclizing_length=None):
         """the whole CLI flow in the library (cl_msa): FASTA text (+ Newick text) -> explicit CIGAR (two sequences) or GFA; returns
-        (text bytes, stats dict)"""
+        (text bytes, stats dict).  cyclize = the CLI's -c, min_cyclizing_length its -y"""
         raw = fasta_text.encode() if isinstance(fasta_text, str) else bytes(fasta_text)
         mp = MsaParams()
         self.lib.cl_msa_params_default(C.byref(mp))
@@ -1609,6 +1611,9 @@ class Context:
         mp.subproblems_prefix = subproblems_prefix.encode() if subproblems_prefix else None   # -S
         mp.restart = int(restart)                                                             # -R
         mp.induced_pairwise_prefix = induced_pairwise_prefix.encode() if induced_pairwise_prefix else None   # -A
+        mp.cyclize = int(cyclize)                                                             # -c
+        if min_cyclizing_length is not None:
+            mp.bonds.min_length = float(min_cyclizing_length)                                 # -y
         p, n, st = C.c_void_p(), C.c_uint64(0), MsaStats()
         self._check(self.lib.cl_msa(self.handle, raw, len(raw), None if not newick else newick.encode(), C.byref(mp), C.byref(p), C.byref(n), C.byref(st)))
         try:

@@ -422,6 +422,10 @@ void cl_msa_params_default(cl_msa_params* p) {
     memset(p, 0, sizeof(*p));
     cl_merge_params_default(&p->merge);
     p->skip_calibration = 0;
+    p->cyclize = 0;
+    p->max_tandem_duplication_search_rounds = 3;   // src/parameters.cpp:90
+    cl_bond_params_default(&p->bonds);
+    cl_polish_params_default(&p->polish);
 }
 
 // main() of the reference from the parsed inputs on (src/main.cpp:239-301): plan, leaf graphs, calibration (src/core.cpp:98-191 without
@@ -448,7 +452,10 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
     cl_alignment root_aln{};
     uint64_t root_children[2] = {0, 0};
     cl_msa_stats st{};
+    std::vector<std::pair<uint64_t, cl_alignment>> bond_alns;   // -c: (sequence, bond alignment in path positions), in the reference's order
+    auto free_bonds = [&]() { for (auto& b : bond_alns) free(b.second.pairs); bond_alns.clear(); };
     auto fail = [&](int code) {
+        free_bonds();
         for (auto* g : graph) cl_owned_base_graph_free(g);
         cl_alignment_free(&root_aln);
         cl_msa_plan_free(&plan);
@@ -477,9 +484,46 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         body(workers[0]);
         for (auto& t : th) t.join();
     };
-    if (!params->skip_calibration) {
+    // -c (src/core.cpp:63-75): the tandem-duplication bonds come from the calibration pass, or — on a restart — from PREFIX_bonds.txt
+    const bool cyclize = params->cyclize != 0;
+    const std::string bonds_file = (params->subproblems_prefix ? std::string(params->subproblems_prefix) : std::string()) + "_bonds.txt";
+    bool bonds_restarted = false;
+    if (cyclize && params->restart && params->subproblems_prefix && *params->subproblems_prefix) {   // Core::restart_bonds (:491-521)
+        std::ifstream in(bonds_file);
+        if (!in) { cl_set_error(ctx, "Couldn't open tandem duplication bonds to restart from file %s.", bonds_file.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+        std::string line;
+        std::vector<uint64_t> cur;
+        auto close_current = [&]() {
+            if (bond_alns.empty()) return;
+            cl_alignment& a = bond_alns.back().second;
+            a.n_pairs = cur.size() / 2;
+            a.pairs = (uint64_t*)malloc((cur.size() ? cur.size() : 1) * sizeof(uint64_t));
+            if (!cur.empty()) memcpy(a.pairs, cur.data(), cur.size() * sizeof(uint64_t));
+            cur.clear();
+        };
+        while (std::getline(in, line)) {
+            if (line.empty()) continue;
+            if (line.front() == '#') {
+                close_current();
+                const std::string name = line.substr(1);
+                uint64_t sq = 0;
+                while (sq < fa.n_sequences && name != fa.names[sq]) ++sq;
+                if (sq == fa.n_sequences) { free_bonds(); cl_set_error(ctx, "%s names a sequence that is not in the input: %s", bonds_file.c_str(), name.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+                bond_alns.emplace_back(sq, cl_alignment{});
+            } else if (!bond_alns.empty()) {
+                long long x = 0, y = 0;
+                if (sscanf(line.c_str(), "%lld\t%lld", &x, &y) == 2) { cur.push_back((uint64_t)(int64_t)x); cur.push_back((uint64_t)(int64_t)y); }
+            }
+        }
+        close_current();
+        bonds_restarted = true;
+    }
+    if (!params->skip_calibration || (cyclize && !bonds_restarted)) {
         const auto t = now();
+        const bool search_bonds = cyclize && !bonds_restarted;
         std::vector<double> scales(plan.n_leaves, 0.0);
+        std::vector<cl_leaf_calibration*> memo(plan.n_leaves, nullptr);
+        auto free_memo = [&]() { for (auto*& m : memo) { cl_leaf_calibration_free(m); m = nullptr; } };
         {
             std::atomic<uint64_t> next{0};
             std::atomic<int> first_rc{CL_OK};
@@ -487,18 +531,52 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
                 for (uint64_t i = next.fetch_add(1); i < plan.n_leaves && first_rc.load() == CL_OK; i = next.fetch_add(1)) {
                     cl_base_graph v;
                     cl_owned_base_graph_view(graph[i], &v);
-                    const int r = cl_leaf_intrinsic_scale(c, &v, &mp.match, &mp.align.anchor, &scales[i]);
+                    const int r = search_bonds ? cl_leaf_calibrate(c, &v, &mp.match, &mp.align.anchor, &scales[i], &memo[i])
+                                               : cl_leaf_intrinsic_scale(c, &v, &mp.match, &mp.align.anchor, &scales[i]);
                     if (r) { int expected = CL_OK; if (first_rc.compare_exchange_strong(expected, r) && c != ctx) cl_set_error(ctx, "%s", cl_last_error(c)); }
                 }
             });
-            if ((rc = first_rc.load())) return fail(rc);
+            if ((rc = first_rc.load())) { free_memo(); return fail(rc); }
         }
-        double mean = 0.0;
-        for (double sc : scales) mean += sc;   // summed in leaf order (src/core.cpp:169-173)
-        mean /= (double)plan.n_leaves;
-        mp.align.anchor.score_scale = mean;
+        if (!params->skip_calibration) {
+            double mean = 0.0;
+            for (double sc : scales) mean += sc;   // summed in leaf order (src/core.cpp:169-173)
+            mean /= (double)plan.n_leaves;
+            mp.align.anchor.score_scale = mean;
+        }
         st.calibration_s = secs(t);
+        if (search_bonds) {   // the tandem-duplication rounds (:196-297), leaf by leaf in the reference, leaves side by side here
+            const auto tb = now();
+            std::vector<cl_alignment_list> found(plan.n_leaves);
+            for (auto& f : found) memset(&f, 0, sizeof(f));
+            std::atomic<uint64_t> next{0};
+            std::atomic<int> first_rc{CL_OK};
+            run_workers([&](cl_context* c) {
+                for (uint64_t i = next.fetch_add(1); i < plan.n_leaves && first_rc.load() == CL_OK; i = next.fetch_add(1)) {
+                    cl_base_graph v;
+                    cl_owned_base_graph_view(graph[i], &v);
+                    const int r = cl_leaf_bond_alignments(c, &v, memo[i], &mp.align.anchor, &mp.align.stitch, &params->bonds, params->max_tandem_duplication_search_rounds, &found[i]);
+                    if (r) { int expected = CL_OK; if (first_rc.compare_exchange_strong(expected, r) && c != ctx) cl_set_error(ctx, "%s", cl_last_error(c)); }
+                }
+            });
+            free_memo();
+            for (uint64_t i = 0; i < plan.n_leaves; ++i) {
+                for (uint64_t b = 0; b < found[i].n; ++b) { bond_alns.emplace_back(plan.leaf_sequence[i], found[i].alignments[b]); found[i].alignments[b].pairs = nullptr; }
+                cl_alignment_list_free(&found[i]);
+            }
+            if ((rc = first_rc.load())) { free_bonds(); return fail(rc); }
+            st.bonds_s = secs(tb);
+        }
     }
+    if (cyclize && !bonds_restarted && params->subproblems_prefix && *params->subproblems_prefix) {   // Core::emit_restart_bonds (:476-489)
+        std::ofstream bo(bonds_file);
+        if (!bo) { free_bonds(); cl_set_error(ctx, "Couldn't write subproblem bonds to file '%s'.", bonds_file.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+        for (const auto& b : bond_alns) {
+            bo << '#' << fa.names[b.first] << '\n';
+            for (uint64_t i = 0; i < b.second.n_pairs; ++i) bo << (long long)(int64_t)b.second.pairs[2 * i] << '\t' << (long long)(int64_t)b.second.pairs[2 * i + 1] << '\n';
+        }
+    }
+    st.n_bonds = bond_alns.size();
     st.score_scale = mp.align.anchor.score_scale;
     // -S / -R (src/core.cpp:370-422, src/execution.cpp:190-203, 222-277)
     const std::string prefix = params->subproblems_prefix ? params->subproblems_prefix : "";
@@ -639,6 +717,39 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         if (first_rc) return fail(first_rc);
     }
     const uint64_t root = n_slots - 1;
+    if (cyclize && !bond_alns.empty()) {   // Core::apply_bonds (src/core.cpp:594-648)
+        const auto tc = now();
+        cl_base_graph g;
+        cl_owned_base_graph_view(graph[root], &g);
+        std::vector<uint64_t> path_of;
+        std::vector<cl_alignment> alns;
+        for (const auto& b : bond_alns) {
+            uint64_t p = 0;
+            while (p < paths[root].size() && paths[root][p] != b.first) ++p;
+            path_of.push_back(p);
+            alns.push_back(b.second);
+        }
+        cl_owned_base_graph* cyc = nullptr;
+        rc = cl_apply_bonds(&g, alns.size(), path_of.data(), alns.data(), &cyc);
+        free_bonds();
+        if (rc) { cl_set_error(ctx, "merging the tandem duplications failed"); return fail(rc); }
+        cl_owned_base_graph_free(graph[root]);
+        graph[root] = cyc;
+        cl_alignment_free(&root_aln);   // (root_subproblem.alignment.clear(), :645)
+        cl_owned_base_graph_view(graph[root], &g);
+        std::vector<const char*> pn, sn;
+        for (uint64_t sq : paths[root]) pn.push_back(fa.names[sq]);
+        for (uint64_t sq = 0; sq < fa.n_sequences; ++sq) sn.push_back(fa.names[sq]);
+        cl_owned_base_graph* polished = nullptr;
+        uint64_t n_regions = 0;
+        rc = cl_polish_cyclized_graph(ctx, &g, pn.data(), newick, sn.data(), sn.size(), &mp, &params->polish, &polished, &n_regions);
+        if (rc) return fail(rc);
+        cl_owned_base_graph_free(graph[root]);
+        graph[root] = polished;
+        st.n_polished_regions = n_regions;
+        st.cyclize_s = secs(tc);
+    }
+    free_bonds();
     if (fa.n_sequences == 2) {
         // explicit_cigar(root.alignment, leaf of the FIRST sequence, leaf of the LAST one) (src/main.cpp:292-296)
         uint64_t first = 0, last = 0;

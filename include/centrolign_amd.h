@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 3   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 4   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -703,12 +703,22 @@ typedef struct cl_msa_params {
                                                 src/execution.cpp:222-277); needs subproblems_prefix */
     const char*     induced_pairwise_prefix; /* -A: PREFIX_<name1>_<name2>.txt with the induced pairwise CIGAR of every pair of sequences
                                                 (Core::output_pairwise_alignments, src/core.cpp:523-575); NULL: off */
+    int             cyclize;                 /* -c: tandem duplications found in every sequence (cl_leaf_bond_alignments) are merged into cycles of
+                                                the final graph (cl_apply_bonds) and the graph is polished (cl_polish_cyclized_graph): src/core.cpp:63-94.
+                                                With subproblems_prefix the bond alignments go to PREFIX_bonds.txt (Core::emit_restart_bonds, :476-489)
+                                                and a restart reads them back instead of searching again (Core::restart_bonds, :491-521) */
+    uint64_t        max_tandem_duplication_search_rounds;   /* 3 */
+    cl_bond_params   bonds;
+    cl_polish_params polish;
 } cl_msa_params;
 void cl_msa_params_default(cl_msa_params* p);
 typedef struct cl_msa_stats {
     uint64_t n_merges, root_nodes;
     double   score_scale, calibration_s, match_s, align_s, fuse_s, total_s;
     uint64_t n_restarted;        /* subproblems loaded from files (-R) */
+    uint64_t n_bonds;            /* tandem duplications merged (-c) */
+    uint64_t n_polished_regions; /* regions realigned by the polishing step (-c) */
+    double   bonds_s, cyclize_s; /* time in the tandem-duplication rounds; in apply_bonds + polishing */
 } cl_msa_stats;
 int  cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const char* newick /* NULL: in-order tree */,
             const cl_msa_params* params, char** text_out, uint64_t* len_out, cl_msa_stats* stats /* may be NULL */);

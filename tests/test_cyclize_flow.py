@@ -151,3 +151,26 @@ def test_polishing_matches_the_reference(gpu_ctx):
         assert n_regions == len(d["inconsistencies"]) // 2
         assert capi.graphs_equal(got, graph_of(d, "polished.")), name
         assert capi.write_gfa(got, path_names) == text, name
+
+
+@pytest.mark.gpu
+def test_cl_msa_with_cyclisation_prints_the_reference_gfa(gpu_ctx, tmp_path):
+    """device: the CLI's -c flow inside the library — cl_msa(cyclize) from FASTA text: calibration with bond search, the MSA, apply_bonds,
+    polishing — byte for byte the GFA of the compiled reference (oracle/_ref/ref_cli -c, checked when the golden was made); with worker
+    contexts; and a -S run followed by a -R restart that reads the bond alignments back from PREFIX_bonds.txt"""
+    for name, d, seqs, min_len, budget in cases():
+        want = d["output"].tobytes()
+        fasta = "".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+        got, st = gpu_ctx.msa(fasta, max_num_match_pairs=budget, cyclize=True, min_cyclizing_length=min_len)
+        assert got == want, name
+        assert st["n_bonds"] == sum(int(d["leaf%d.counts" % i][1]) for i in range(len(seqs))) and st["n_polished_regions"] == len(d["inconsistencies"]) // 2
+        got4, _ = gpu_ctx.msa(fasta, max_num_match_pairs=budget, cyclize=True, min_cyclizing_length=min_len, workers=3)
+        assert got4 == want, name
+        prefix = str(tmp_path / (name + "_sub"))
+        got_s, _ = gpu_ctx.msa(fasta, max_num_match_pairs=budget, cyclize=True, min_cyclizing_length=min_len, subproblems_prefix=prefix)
+        assert got_s == want and os.path.exists(prefix + "_bonds.txt")
+        lines = open(prefix + "_bonds.txt").read().splitlines()
+        assert sum(1 for ln in lines if ln.startswith("#")) == st["n_bonds"]
+        got_r, st_r = gpu_ctx.msa(fasta, max_num_match_pairs=budget, cyclize=True, min_cyclizing_length=min_len, subproblems_prefix=prefix, restart=True)
+        assert got_r == want and st_r["n_restarted"] >= 1 and st_r["n_bonds"] == st["n_bonds"]
+        break   # (the second golden is covered step by step above; one end-to-end flow keeps the suite short)
