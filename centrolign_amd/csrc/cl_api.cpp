@@ -58,6 +58,42 @@ const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && 
 
 std::atomic<size_t> cl_pinned_total{0};
 
+// ClRawVec's storage (cl_internal.hpp): blocks of a megabyte and more come from, and go back to, a per-thread cache (at most kBigCacheCap bytes
+// per thread, best fit within 2x); a 64-byte header in front of every block says how large it is
+namespace {
+constexpr size_t kBigMin = 1u << 20, kBigCacheCap = 6ull << 30;
+struct BigCache {
+    std::multimap<size_t, void*> free_blocks;   // capacity -> header
+    size_t bytes = 0;
+    ~BigCache() { for (auto& b : free_blocks) free(b.second); }
+};
+thread_local BigCache t_big_cache;
+}
+void* cl_big_alloc(size_t bytes) {
+    if (bytes >= kBigMin) {
+        auto it = t_big_cache.free_blocks.lower_bound(bytes);
+        if (it != t_big_cache.free_blocks.end() && it->first <= 2 * bytes) {
+            void* h = it->second;
+            t_big_cache.bytes -= it->first;
+            t_big_cache.free_blocks.erase(it);
+            return static_cast<char*>(h) + 64;
+        }
+    }
+    void* h = malloc(bytes + 64);
+    if (!h) throw std::bad_alloc();
+    *static_cast<size_t*>(h) = bytes;
+    return static_cast<char*>(h) + 64;
+}
+void cl_big_free(void* p) noexcept {
+    if (!p) return;
+    void* h = static_cast<char*>(p) - 64;
+    const size_t cap = *static_cast<size_t*>(h);
+    if (cap >= kBigMin && t_big_cache.bytes + cap <= kBigCacheCap) {
+        try { t_big_cache.free_blocks.emplace(cap, h); t_big_cache.bytes += cap; return; } catch (...) {}
+    }
+    free(h);
+}
+
 // A context keeps up to seven streams busy (the chaining DP: walk, two far launches, the sealing stream, copies) and an MSA runs several worker
 // contexts; HIP's default of 4 hardware queues per process makes their launches queue up behind one another.  Measured on the nine concurrent
 // stitch plans of 10 x 1 Mbp (ms per pass): 4 queues 8.9, 16: 4.9, 20: 3.8, 24: 11.5 (beyond ~23 the queues are time-sliced).  The runtime reads the

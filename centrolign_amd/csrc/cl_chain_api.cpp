@@ -175,10 +175,10 @@ struct GapFreeTree {
 
 struct Combo {
     uint32_t p1 = 0, p2 = 0;
-    std::vector<uint32_t> rec_s, ins_t, off;
-    std::vector<int32_t> sigma;
-    std::vector<uint32_t> qt, qoff;
-    std::vector<int32_t> q;
+    ClRawVec<uint32_t> rec_s, ins_t, off;   // (filled completely by the record / query passes)
+    ClRawVec<int32_t> sigma;
+    ClRawVec<uint32_t> qt, qoff;
+    ClRawVec<int32_t> q;
     std::vector<uint32_t> prefix;
     // device
     DevBuf<uint32_t> d_rec_s, d_ins_t, d_off, d_prefix, d_qt, d_qoff, d_own_rec;
@@ -539,7 +539,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // intra kernel keeps in registers)
     std::vector<uint32_t> combo_of((size_t)n_tag[0] * n_tag[1], kNone);
     std::vector<Combo> combos;
-    std::vector<uint32_t> rec_off(M + 1, 0), rec_combo, rec_pos;
+    std::vector<uint32_t> rec_off(M + 1, 0);
+    ClRawVec<uint32_t> rec_combo, rec_pos;
     {
         // records per pair: one per (chain through e1, chain through e2); sparse_chain_dp files a match under the first chain
         // of each end only (anchorer.hpp:1621-1630).  Counted and filled in parallel over the pairs, numbered serially: a
@@ -557,8 +558,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         });
         for (uint64_t s = 0; s < M; ++s) rec_off[s + 1] += rec_off[s];
         const uint64_t R = rec_off[M];
-        std::vector<uint32_t> r_tag(R), r_ins(R), r_off(R);
-        std::vector<int32_t> r_sig(R);
+        ClRawVec<uint32_t> r_tag(R), r_ins(R), r_off(R);
+        ClRawVec<int32_t> r_sig(R);
         cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
             for (uint64_t s = s_begin; s < s_end; ++s) {
                 const Pair& p = pairs[by_s[s]];

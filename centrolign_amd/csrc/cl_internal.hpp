@@ -176,6 +176,26 @@ struct DevBuf {
 };
 
 
+// Host arrays of tens to hundreds of megabytes that are filled completely right after they are made (the record and query tables of a
+// chaining DP: 1.2 GB at the root of a ten-sequence tree): std::vector would zero them first, single-threaded, and malloc hands such blocks
+// out as fresh mappings whose every page faults on first touch — and takes the process's address-space lock, under which the other MSA
+// workers' faults wait.  ClRawVec leaves new elements uninitialised and keeps large blocks in a per-thread cache for the next DP.
+void* cl_big_alloc(size_t bytes);            // cl_api.cpp
+void  cl_big_free(void* p) noexcept;
+template <class T>
+struct ClRawAlloc {
+    using value_type = T;
+    ClRawAlloc() = default;
+    template <class U> ClRawAlloc(const ClRawAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(cl_big_alloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t) noexcept { cl_big_free(p); }
+    template <class U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }   // default-, not value-initialised
+    template <class U, class A0, class... A> void construct(U* p, A0&& a0, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+    template <class U> bool operator==(const ClRawAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const ClRawAlloc<U>&) const { return false; }
+};
+template <class T> using ClRawVec = std::vector<T, ClRawAlloc<T>>;
+
 // std::vector<match_set_t> owned by the library (cl_split_branching_matches, cl_find_matches); layout of cl_match_sets
 #include <vector>
 struct cl_owned_match_sets {
