@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--workers", type=int, default=4, help="worker contexts of the single-GPU MSA (sibling merges side by side)")
     ap.add_argument("--length", type=int, default=1000000, help="sequence length (the headline is 1 000 000; smaller only for dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-skip", type=int, default=0, help="measurements only: CL_DEBUG_SKIP_TRACEBACK for the timed plans (1 no traceback, 3 no plane stores either); the line is then NOT a result")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
     args = ap.parse_args()
@@ -225,10 +226,10 @@ def main():
     # nine concurrent stitch plans (ms per step): 4 queues 8.9, 8: 8.2, 12: 5.6, 16: 4.9, 20: 3.8, 22: 4.9, 24: 11.5, 32: 28.5 — beyond
     # ~23 PER DEVICE the queues are oversubscribed and time-sliced, so ranks that share a device share the 20; the MSA's wall-clock does
     # not depend on it (15.2-16.3 s for 8..23)
-    # (a single rank per device leaves it to the library, which asks for 20 when it is loaded: cl_api.cpp, cl_library_loaded)
+    # (the library asks for 20 itself when it is loaded — cl_api.cpp, cl_library_loaded — but in this process torch has loaded the HIP runtime
+    # first, and the runtime has read its settings by then: measured 9.3 ms per step without the line below, 4.1 ms with it)
     per_device = max(1, -(-world_env // max(1, n_dev)))
-    if per_device > 1:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 20 // per_device)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 20 // per_device)))
     rank, world, dist = cd.init_distributed(None if world_env == 1 else ("gloo" if share else "nccl"))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -265,6 +266,8 @@ def main():
 
     # ---- 2. the stitch batches of this rank's merges, resident in HBM ----------------------------------------------------------
     batches = stitch_batches(kept)
+    if args.debug_skip:
+        os.environ["CL_DEBUG_SKIP_TRACEBACK"] = str(args.debug_skip)
     # one context (= one HIP stream set) per batch: the nine merges are independent, their passes run side by side on the device
     # exactly as the worker contexts of the MSA above run sibling merges side by side
     plan_ctx = [capi.Context(device) for _ in batches]
@@ -334,7 +337,7 @@ def main():
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
+            "config": {"workload": ("INVALID (--debug-skip %d): " % args.debug_skip if args.debug_skip else "") + WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
                        "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes,

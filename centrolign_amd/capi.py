@@ -562,7 +562,8 @@ class CoreAlignResultC(C.Structure):
                 ("walk_off", C.POINTER(C.c_uint64)), ("walk1", C.POINTER(C.c_uint32)), ("walk2", C.POINTER(C.c_uint32)),
                 ("scale", C.c_double), ("n_chain_anchors", C.c_uint64), ("chain_ms", C.c_float), ("partition_ms", C.c_float),
                 ("stitch_ms", C.c_float), ("chain_device_ms", C.c_float), ("chain_pair_evals", C.c_double), ("chain_match_pairs", C.c_uint64),
-                ("chain_combinations", C.c_uint32)]
+                ("chain_combinations", C.c_uint32), ("ref_restrain_memory", C.c_uint32), ("ref_packed_path_merge", C.c_uint32),
+                ("ref_path_merge_widths", C.c_uint32)]
 
 
 class MergeResultC(C.Structure):
@@ -585,7 +586,8 @@ def _core_align_dict(out):
                 scale=float(out.scale), n_chain_anchors=int(out.n_chain_anchors), chain_ms=float(out.chain_ms),
                 partition_ms=float(out.partition_ms), stitch_ms=float(out.stitch_ms), chain_device_ms=float(out.chain_device_ms),
                 chain_pair_evals=float(out.chain_pair_evals), chain_match_pairs=int(out.chain_match_pairs),
-                chain_combinations=int(out.chain_combinations))
+                chain_combinations=int(out.chain_combinations), ref_restrain_memory=bool(out.ref_restrain_memory),
+                ref_packed_path_merge=bool(out.ref_packed_path_merge), ref_path_merge_widths=int(out.ref_path_merge_widths))
 
 
 def chain_exhaustive(graph1, graph2, matches, params=None, num_match_sets=None):

@@ -11,6 +11,7 @@
 
 #include <thread>
 
+#include <cmath>
 #include "cl_internal.hpp"
 #include "stitch_host.hpp"
 
@@ -79,6 +80,17 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
     out->chain_pair_evals = ch.dp_pair_evals;
     out->chain_match_pairs = ch.dp_match_pairs;
     out->chain_combinations = ch.dp_combinations;
+    {   // what the reference would dispatch to (core.hpp:194, 303-343); see the header
+        const double restraint = (double)(1u << 30);
+        const double mp = (double)ap->anchor.max_num_match_pairs;
+        out->ref_restrain_memory = (double)g1->n_paths * (double)g2->n_paths * mp * log2(mp) > restraint ? 1u : 0u;
+        out->ref_packed_path_merge = (double)g1->n_nodes * (double)g1->n_paths + (double)g2->n_nodes + (double)g2->n_paths > restraint ? 1u : 0u;
+        const uint64_t max_nodes = std::max(g1->n_nodes, g2->n_nodes), max_paths = std::max(g1->n_paths, g2->n_paths);
+        const bool small_nodes = max_nodes < 0xFFFFFFFFull;
+        if (small_nodes && max_paths < 0xFF) out->ref_path_merge_widths = 0x0401;
+        else if (small_nodes && (out->ref_packed_path_merge ? max_paths < 0xFFFF : true)) out->ref_path_merge_widths = 0x0402;
+        else out->ref_path_merge_widths = 0x0802;
+    }
     out->chain_ms = ms_since(t0);
     t0 = now();
     // partition (core.hpp:237-241)

@@ -1223,7 +1223,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     pl->dev.out_len = pl->d_out_len.p;
     pl->dev.out_score = pl->d_out_score.p;
     pl->dev.out_status = pl->d_out_status.p;
-    { const char* e = getenv("CL_DEBUG_SKIP_TRACEBACK"); pl->dev.skip_traceback = e && *e == '1'; }   // measurement hook
+    { const char* e = getenv("CL_DEBUG_SKIP_TRACEBACK"); pl->dev.skip_traceback = e ? atoi(e) : 0; }   // measurement hook: 1 no traceback, 3 also no plane stores in the systolic kernel
     pl->sparams.match = (int32_t)ap.match;
     pl->sparams.mismatch = (int32_t)ap.mismatch;
     for (int k = 0; k < 3; ++k) { pl->sparams.oe[k] = (int32_t)(ap.gap_open[k] + ap.gap_extend[k]); pl->sparams.ext[k] = (int32_t)ap.gap_extend[k]; }

@@ -913,11 +913,13 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
             }
             // the planes in graph-1 / graph-2 terms: I consumes a graph-1 node, D a graph-2 node
             int32_t* dst = plane0 + (off + ((swap ? c : r) - lo_d));
+            if (!(B.skip_traceback & 2)) {
             dst[0] = M;
 #pragma unroll
             for (int k = 0; k < NPW; ++k) {
                 dst[(size_t)(1 + k) * plane_stride] = swap ? Hh[k] : V[k];
                 dst[(size_t)(1 + NPW + k) * plane_stride] = swap ? V[k] : Hh[k];
+            }
             }
         }
         off += cnt_d;

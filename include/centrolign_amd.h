@@ -505,6 +505,12 @@ typedef struct cl_core_align_result {
     double    chain_pair_evals;
     uint64_t  chain_match_pairs;
     uint32_t  chain_combinations;
+    /* The reference's memory-restrained dispatch for this merge (memory_restraint_size = 2^30, src/parameters.cpp:40). Informational: the
+     * restrained variants (PackedMatchBank / PackedForwardEdges, PackedPathMerge) hold the same tables in fewer bits and select the same chain
+     * (packed_match_bank.hpp:150-165,236-249), and the device formulation has no search trees to restrain, so nothing here switches on them. */
+    uint32_t  ref_restrain_memory;     /* paths1 * paths2 * max_num_match_pairs * log2(max_num_match_pairs) > 2^30 (core.hpp:194) */
+    uint32_t  ref_packed_path_merge;   /* nodes1 * paths1 + nodes2 + paths2 > 2^30 (core.hpp:306-310, as written there) */
+    uint32_t  ref_path_merge_widths;   /* bytes of (UIntSize, UIntChain) the reference instantiates: 0x0401, 0x0402 or 0x0802 (core.hpp:318-340) */
 } cl_core_align_result;
 int  cl_core_align(cl_context* ctx, const cl_base_graph* graph1, const cl_base_graph* graph2, const cl_match_sets* matches,
               const cl_core_align_params* params, cl_core_align_result* out);

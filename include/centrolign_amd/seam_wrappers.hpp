@@ -21,6 +21,7 @@
 #include <tuple>
 #include <unordered_set>
 #include <utility>
+#include <unordered_map>
 #include <vector>
 
 #include "../centrolign_amd.h"
@@ -116,10 +117,25 @@ std::vector<AnchorT> anchor_chain(Device& dev, const AnchorerT& anchorer, const 
             m.full_length = v.full_length[s];
         }
         cl_owned_match_sets_free(owned);
-        // the mask would have to follow the new sets (anchorer.hpp:816-820, 911-918): only splits that cut nothing are covered — the leaf
-        // graphs the masked overload is called on (src/core.cpp:221-227) have no branch points
-        if (masked_matches && !masked_matches->empty() && split.size() != matches.size())
-            throw std::runtime_error("anchor_chain: branch splitting that cuts match sets is not supported together with masked matches");
+        // the mask follows the new sets (anchorer.hpp:816-820, 911-918): every piece cut off set i is appended behind the original sets and
+        // inherits set i's masked (idx1, idx2) pairs; set i itself keeps only its first piece.  The pieces are appended in the order of the
+        // sets they come from, and the pieces of one set add up to what it lost, which identifies every appended set's origin.
+        if (masked_matches && !masked_matches->empty() && split.size() != matches.size()) {
+            std::unordered_map<size_t, std::vector<std::pair<size_t, size_t>>> by_set;
+            for (const auto& m : *masked_matches) by_set[std::get<0>(m)].emplace_back(std::get<1>(m), std::get<2>(m));
+            size_t next = matches.size();
+            for (size_t i = 0; i < matches.size(); ++i) {
+                if (matches[i].walks1.empty()) continue;
+                size_t lost = matches[i].walks1.front().size() - split[i].walks1.front().size();
+                while (lost > 0 && next < split.size()) {
+                    auto it = by_set.find(i);
+                    if (it != by_set.end())
+                        for (const auto& ab : it->second) masked_matches->emplace(next, ab.first, ab.second);
+                    lost -= split[next].walks1.front().size();
+                    ++next;
+                }
+            }
+        }
         matches.swap(split);
     }
     FlatMatchSets ms(matches);

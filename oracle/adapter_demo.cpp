@@ -160,6 +160,24 @@ struct DemoCore : public Core {
         if (bad) ++mismatched;
         printf("merge %zu: anchor_chain wrapper %s the reference (%zu anchors, %zu sets after the call); po_poa<1|2|3> wrapper %s on %zu gap pairs\n", merges,
                ok3 ? "==" : "!=", ref.size(), m_ref.size(), bad ? "!=" : "==", tried);
+        // the same call with masked matches and an overriding scale on graphs WITH branch points: where the splitting cuts match sets, the
+        // mask has to follow the pieces (anchorer.hpp:816-820, 911-918)
+        {
+            std::unordered_set<std::tuple<size_t, size_t, size_t>> k_ref, k_got;
+            for (size_t s = 0; s < matches.size(); s += 7) k_ref.emplace(s, 0, 0);
+            k_got = k_ref;
+            double sc_ref = 0.6, sc_got = 0.6;
+            std::vector<match_set_t> m2r = matches, m2g = matches;
+            Anchorer eager = anchorer;            // (thresholds under which the small bubbles of these test graphs already count as branch points)
+            eager.min_path_length_spread = 1;
+            eager.min_split_length = 2;
+            auto r2 = eager.anchor_chain(m2r, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, false, &k_ref, &sc_ref);
+            auto g2 = centrolign_amd::anchor_chain<anchor_t>(*dev, eager, score_function, m2g, sp1.graph, sp2.graph, sp1.tableau, sp2.tableau, x1, x2, false, &k_got, &sc_got);
+            const bool ok = same_chain(r2, g2) && same_sets(m2r, m2g) && k_ref == k_got;
+            if (!ok) ++mismatched;
+            printf("merge %zu: masked + split anchor_chain wrapper %s the reference (%zu anchors, %zu -> %zu sets, mask %zu)\n", merges, ok ? "==" : "!=", r2.size(),
+                   matches.size(), m2r.size(), k_ref.size());
+        }
     }
 
     // the cyclisation round of one leaf (src/core.cpp:204-269): masked anchor_chain with the given scale, internal_stitch of its chain

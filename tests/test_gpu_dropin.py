@@ -78,3 +78,4 @@ def test_reference_signatures_at_the_seams(tmp_path, seed, length, n, max_pairs)
     assert p.stdout.count("internal_stitch wrapper ==") == n
     assert p.stdout.count("anchor_chain wrapper == the reference (") >= (1 if n == 2 else 3)
     assert p.stdout.count("po_poa<1|2|3> wrapper == on") == (1 if n == 2 else 3)
+    assert p.stdout.count("masked + split anchor_chain wrapper == the reference") == (1 if n == 2 else 3)
