@@ -8,7 +8,13 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+command = sys.argv[2] if len(sys.argv) > 2 else None
 res = defaultdict(dict)
+# average duration per kernel from the --stats pass of the same command (prof_bench/*kernel_stats.csv)
+duration_ns = {}
+for f in glob.glob(os.path.join(out, "prof_bench", "*kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        duration_ns[r["Name"]] = (float(r["AverageNs"]), int(r["Calls"]), float(r["Percentage"]))
 for d, counters in (("pmc_FETCH_SIZE", ("FETCH_SIZE",)), ("pmc_WRITE_SIZE", ("WRITE_SIZE",)),
                     ("pmc_SQ", ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"))):
     files = glob.glob(os.path.join(out, d, "*counter_collection.csv"))
@@ -40,9 +46,25 @@ for k, v in res.items():
             limiter[short] = ("%.3f VALU and %.3f LDS wave-instructions per resident wave-cycle (a wave issuing back to back would show 0.25 "
                               "VALU: one 64-wide VALU instruction per 4 cycles): the waves wait on their own dependent chain, not on HBM"
                               % (e["valu_insts_per_wave_cycle"], e["lds_insts_per_wave_cycle"]))
+    if k in duration_ns:
+        avg_ns, calls, pct = duration_ns[k]
+        e.update({"avg_duration_us": avg_ns / 1e3, "calls_in_stats_pass": calls, "share_of_kernel_time_pct": pct,
+                  "hbm_GBps": (fetch + write) / avg_ns if avg_ns else None, "hbm_frac_of_8TBps": (fetch + write) / avg_ns / 8000.0 if avg_ns else None})
+        if "valu_insts_per_wave_cycle" in e:
+            e["valu_frac_of_single_wave_issue"] = e["valu_insts_per_wave_cycle"] / 0.25
     summary[short] = e
     traffic[short] = fetch + write
 print(json.dumps(summary, indent=1))
 traffic["_limiter"] = limiter
+if command:
+    traffic["_command"] = command
+    summary["_command"] = command
+try:
+    import subprocess
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+except Exception:
+    head = ""
+traffic["_commit"] = head or os.environ.get("CL_TREE", "round 3 working tree (no .git on the GPU box)")
+summary["_commit"] = traffic["_commit"]
 json.dump(traffic, open(os.path.join(out, "hbm_traffic_latest.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
