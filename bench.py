@@ -341,6 +341,7 @@ def main():
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
                        "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes,
+                       "workspace_bytes": int(sum(st.get("workspace_bytes", 0) for st in stats)),
                        "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
                                       "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank), stitch batches on the rank that made them, no data-path collective; one merge still runs on one GPU, so msa_wall_s is bounded by the spine of the guide tree (DESIGN.md §5); no multi-GPU hardware curve has been measured by the builder" % (world, args.workers)},
             "msa_wall_s": msa_wall,

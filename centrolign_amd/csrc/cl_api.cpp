@@ -152,10 +152,7 @@ int validate_side(cl_context* ctx, const cl_graph_side& s, uint64_t n, int which
         set_error(ctx, "graph side %d: missing offset array", which);
         return CL_ERR_INVALID_ARGUMENT;
     }
-    if (s.node_off[0] != 0 || s.src_off[0] != 0 || s.snk_off[0] != 0) {
-        set_error(ctx, "graph side %d: offsets must start at 0", which);
-        return CL_ERR_INVALID_ARGUMENT;
-    }
+    // (the offsets are absolute positions in the side's arrays; they need not start at 0: run_whole hands chunks of a batch on as views)
     for (uint64_t k = 0; k < n; ++k) {
         if (s.node_off[k + 1] < s.node_off[k] || s.src_off[k + 1] < s.src_off[k] || s.snk_off[k + 1] < s.snk_off[k]) {
             set_error(ctx, "graph side %d: offsets not monotone at problem %llu", which, (unsigned long long)k);
@@ -1451,7 +1448,69 @@ void cl_stitch_plan_destroy(cl_context* ctx, cl_stitch_plan* pl) {
     plan_free(pl);
 }
 
+static int run_chunk(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* sp, const uint8_t* force, cl_stitch_result* out);
+
+// A plan holds one workspace for its whole batch: full score planes for every graph x graph subproblem that is not swept from LDS, addressed
+// with 32-bit word offsets.  A merge whose gaps add up to more than that (several graph x graph gaps near the 40 M-cell ceiling of
+// min_wfa_size, src/parameters.cpp:79; configs[4]-sized merges) is run as consecutive chunks of subproblems, each a plan of its own on the
+// same context, the results appended in order.  CL_STITCH_WORKSPACE_WORDS (default 3 * 2^30 int32 words = 12 GB) for tests.
 static int run_whole(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* sp, const uint8_t* force,
+                     cl_stitch_result* out) {
+    const char* cap_env = getenv("CL_STITCH_WORKSPACE_WORDS");
+    const uint64_t cap = cap_env && atoll(cap_env) > 0 ? (uint64_t)atoll(cap_env) : (3ull << 30);
+    const uint64_t n = batch->n_problems;
+    std::vector<uint64_t> cuts(1, 0);
+    uint64_t acc = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t n1 = batch->side[0].node_off[k + 1] - batch->side[0].node_off[k], n2 = batch->side[1].node_off[k + 1] - batch->side[1].node_off[k];
+        const uint64_t words = (n1 + 1) * (n2 + 1) * 7;   // the planes of a NumPW = 3 matrix: an upper bound whatever kernel takes it
+        if (acc && acc + words > cap) { cuts.push_back(k); acc = 0; }
+        acc += words;
+    }
+    cuts.push_back(n);
+    if (cuts.size() == 2) return run_chunk(ctx, batch, sp, force, out);
+    memset(out, 0, sizeof(*out));
+    std::vector<cl_stitch_result> parts(cuts.size() - 1);
+    int rc = CL_OK;
+    size_t done = 0;
+    for (; done + 1 < cuts.size() && !rc; ++done) {
+        cl_stitch_batch sub = *batch;
+        const uint64_t a = cuts[done];
+        sub.n_problems = cuts[done + 1] - a;
+        for (int s = 0; s < 2; ++s) { sub.side[s].node_off += a; sub.side[s].src_off += a; sub.side[s].snk_off += a; }
+        if (sub.only_deletion_alns) sub.only_deletion_alns += a;
+        rc = run_chunk(ctx, &sub, sp, force ? force + a : nullptr, &parts[done]);
+    }
+    if (!rc) {
+        uint64_t total_pairs = 0;
+        for (size_t i = 0; i < done; ++i) total_pairs += parts[i].aln_off[parts[i].n_problems];
+        out->n_problems = n;
+        out->aln_off = (uint64_t*)malloc((n + 1) * sizeof(uint64_t));
+        out->pairs = (uint64_t*)malloc((total_pairs ? total_pairs : 1) * 2 * sizeof(uint64_t));
+        out->score = (int64_t*)malloc((n ? n : 1) * sizeof(int64_t));
+        out->route = (uint8_t*)malloc(n ? n : 1);
+        out->num_pw = (uint8_t*)malloc(n ? n : 1);
+        if (!out->aln_off || !out->pairs || !out->score || !out->route || !out->num_pw) { cl_stitch_result_free(out); rc = CL_ERR_OUT_OF_MEMORY; }
+        else {
+            uint64_t pair_at = 0;
+            for (size_t i = 0; i < done; ++i) {
+                const cl_stitch_result& p = parts[i];
+                const uint64_t a = cuts[i];
+                for (uint64_t k = 0; k < p.n_problems; ++k) out->aln_off[a + k] = pair_at + p.aln_off[k];
+                memcpy(out->pairs + 2 * pair_at, p.pairs, p.aln_off[p.n_problems] * 2 * sizeof(uint64_t));
+                memcpy(out->score + a, p.score, p.n_problems * sizeof(int64_t));
+                memcpy(out->route + a, p.route, p.n_problems);
+                memcpy(out->num_pw + a, p.num_pw, p.n_problems);
+                pair_at += p.aln_off[p.n_problems];
+            }
+            out->aln_off[n] = pair_at;
+        }
+    }
+    for (size_t i = 0; i < done; ++i) cl_stitch_result_free(&parts[i]);
+    return rc;
+}
+
+static int run_chunk(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* sp, const uint8_t* force,
                      cl_stitch_result* out) {
     // CL_STITCH_TIMING=1: host phase times on stderr
     static const bool timing = getenv("CL_STITCH_TIMING") != nullptr;

@@ -157,6 +157,28 @@ def test_every_route_in_one_batch(gpu_ctx):
             assert {1, 2, 3, 4, 6} <= set(np.unique(got.route).tolist())
 
 
+def test_a_batch_larger_than_one_workspace_runs_in_chunks(gpu_ctx, monkeypatch):
+    """one plan holds one workspace for its whole batch; a batch that would exceed it (CL_STITCH_WORKSPACE_WORDS, 12 GB by default) is run as
+    consecutive chunks of subproblems on the same context and gives the same result — here with the limit set so low that the 700-problem
+    batches fall into dozens of chunks, and with three 30 M-cell graph x graph pairs under a limit that puts each into a chunk of its own"""
+    z = np.load(os.path.join(H.GOLDEN, "popoa_random_dags.npz"))
+    batch = H.load_batch(z)
+    want = gpu_ctx.stitch_batch_align(batch)
+    monkeypatch.setenv("CL_STITCH_WORKSPACE_WORDS", "60000")
+    got = gpu_ctx.stitch_batch_align(batch)
+    assert got.same_as(want) is None and np.array_equal(got.route, want.route) and np.array_equal(got.num_pw, want.num_pw)
+    assert got.same_as(H.load_result(z, "subalign.")) is None          # the compiled reference's results for this batch
+    big = synth.sized_dag_batch([(5400, 5500)] * 3, seed=77)
+    assert big.dp_cells() > 85000000
+    monkeypatch.setenv("CL_STITCH_WORKSPACE_WORDS", str(5401 * 5501 * 7 + 1000))
+    got = gpu_ctx.stitch_batch_align(big)
+    monkeypatch.delenv("CL_STITCH_WORKSPACE_WORDS")
+    want = gpu_ctx.stitch_batch_align(big)
+    assert got.same_as(want) is None
+    for k in range(3):
+        H.check_alignment_valid(big, got, k)
+
+
 def test_error_reporting(gpu_ctx):
     bad = capi.default_stitch_params()
     bad.alignment_params.gap_open[:] = [60, 50, 2500]
