@@ -667,6 +667,42 @@ def ref_internal_fuse(g, pairs):
     return _graph_from_out(lib, out, sizes, int(ids[0]), int(ids[1])), trans
 
 
+def ref_simplify_bubbles(g):
+    """the compiled reference's simplify_bubbles (src/modify_graph.cpp:165-382): BaseGraph"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_simplify_bubbles.restype = C.c_int
+    lib.ref_simplify_bubbles.argtypes = [C.POINTER(BaseGraphC), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c = g.as_c()
+    out = (C.c_void_p * 7)()
+    sizes = (C.c_uint64 * 4)()
+    ids = (C.c_uint64 * 2)()
+    rc = lib.ref_simplify_bubbles(C.byref(c), out, sizes, ids)
+    if rc:
+        raise RuntimeError("ref_simplify_bubbles failed: %d" % rc)
+    return _graph_from_out(lib, out, sizes, int(ids[0]), int(ids[1]))
+
+
+def ref_inconsistencies(g, settings=(10000, 100, 8, 50, 1000, 10000)):
+    """the compiled reference's InconsistencyIdentifier::identify_inconsistencies: (n, 2) node pairs"""
+    from centrolign_amd.capi import BaseGraphC
+    lib = ref_lib()
+    lib.ref_inconsistencies.restype = C.c_int
+    lib.ref_inconsistencies.argtypes = [C.POINTER(BaseGraphC), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.ref_free.argtypes = [C.c_void_p]
+    c = g.as_c()
+    st = np.array(settings, np.uint64)
+    ptr, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.ref_inconsistencies(C.byref(c), st.ctypes.data, C.byref(ptr), C.byref(n))
+    if rc:
+        raise RuntimeError("ref_inconsistencies failed: %d" % rc)
+    k = int(n.value)
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(max(k, 1) * 2,))[:2 * k].copy().reshape(k, 2)
+    lib.ref_free(ptr)
+    return a
+
+
 def ref_induced_pairwise_cigar(g, p1, p2):
     """the compiled reference's -A output for two paths of an acyclic graph (src/core.cpp:546-550): bytes"""
     from centrolign_amd.capi import BaseGraphC

@@ -28,6 +28,8 @@
 #include "centrolign/fuse.hpp"
 #include "centrolign/gfa.hpp"
 #include "centrolign/induced_match_finder.hpp"
+#include "centrolign/inconsistency_identifier.hpp"
+#include "centrolign/modify_graph.hpp"
 #include "centrolign/parameters.hpp"
 #include "centrolign/stitcher.hpp"
 #include "centrolign/utility.hpp"
@@ -1213,6 +1215,45 @@ int ref_internal_fuse(const cl_base_graph* g, const uint64_t* pairs, uint64_t n_
     ids_out[0] = t_out.src_id;
     ids_out[1] = t_out.snk_id;
     return 0;
+}
+
+/* simplify_bubbles (src/modify_graph.cpp:165-382) on a flat graph with sentinels (cyclic graphs welcome) */
+int ref_simplify_bubbles(const cl_base_graph* g, void** out, uint64_t* sizes, uint64_t* ids_out) {
+    try {
+        SentinelTableau t;
+        BaseGraph b = build_base_graph(g, t);
+        simplify_bubbles(b, t);
+        flatten_graph(b, out, sizes);
+        ids_out[0] = t.src_id;
+        ids_out[1] = t.snk_id;
+        return 0;
+    } catch (std::exception& ex) {
+        fprintf(stderr, "ref_simplify_bubbles: %s\n", ex.what());
+        return -1;
+    }
+}
+
+/* InconsistencyIdentifier::identify_inconsistencies with the CLI's settings (src/parameters.cpp:98-103); *bounds_out malloc'ed [2 * *n_out] */
+int ref_inconsistencies(const cl_base_graph* g, const uint64_t* settings /* [6] as cl_polish_params */, uint64_t** bounds_out, uint64_t* n_out) {
+    try {
+        SentinelTableau t;
+        BaseGraph b = build_base_graph(g, t);
+        InconsistencyIdentifier ii;
+        ii.max_tight_cycle_size = settings[0];
+        ii.max_bond_inconsistency_window = settings[1];
+        ii.min_inconsistency_disjoint_length = settings[2];
+        ii.min_inconsistency_total_length = settings[3];
+        ii.padding_target_min_length = settings[4];
+        ii.padding_max_length_limit = settings[5];
+        auto inc = ii.identify_inconsistencies(b, t);
+        *n_out = inc.size();
+        *bounds_out = (uint64_t*)malloc((inc.size() ? inc.size() : 1) * 2 * sizeof(uint64_t));
+        for (size_t i = 0; i < inc.size(); ++i) { (*bounds_out)[2 * i] = inc[i].first; (*bounds_out)[2 * i + 1] = inc[i].second; }
+        return 0;
+    } catch (std::exception& ex) {
+        fprintf(stderr, "ref_inconsistencies: %s\n", ex.what());
+        return -1;
+    }
 }
 
 /* explicit_cigar(induced_pairwise_alignment(graph, p1, p2), seq1, seq2): the -A output (src/core.cpp:546-550) */
