@@ -114,3 +114,23 @@ def test_gpu_cl_msa_ten_sequences(gpu_ctx):
     assert text == bytes(ZB["msa10_30k.gfa"])
     text4, st4 = gpu_ctx.msa(fasta, synth.C3_NEWICK, max_num_match_pairs=200000, workers=4)
     assert text4 == text and st4["n_merges"] == 9
+
+
+@pytest.mark.gpu
+def test_gpu_wide_merge_24_sequences(gpu_ctx):
+    """24 sequences of 7 kbp over a balanced tree: the root merge pairs 12 + 12 paths = 144 chain combinations, more than one walk launch
+    of the chaining DP takes (96; the rest go through the per-block path, cl_chain_api.cpp).  The GFA is the one the unmodified reference
+    printed (tests/golden/make_wide_merge.py, 26 CPU-minutes there), byte for byte, with one worker and with four"""
+    import gzip
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(H.GOLDEN, "wide_merge_24x7k.json")))
+    names, seqs = ["q%02d" % i for i in range(24)], synth.hor_sequences(91, 7000, 24, indel_hor=1)
+    assert hashlib.sha256("".join(seqs).encode()).hexdigest() == gold["input_sha256"]
+    fasta = "".join(">%s\n%s\n" % (n, s) for n, s in zip(names, seqs))
+    want = gzip.open(os.path.join(H.GOLDEN, "wide_merge_24x7k.gfa.gz")).read()
+    assert hashlib.sha256(want).hexdigest() == gold["gfa"]["sha256"] and len(want) == gold["gfa"]["bytes"]
+    for workers in (1, 4):
+        got, st = gpu_ctx.msa(fasta, newick=gold["newick"], workers=workers)
+        assert got == want, workers
+        assert st["n_merges"] == 23
