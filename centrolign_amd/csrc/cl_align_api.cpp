@@ -43,15 +43,32 @@ void cl_core_align_result_free(cl_core_align_result* r) {
 
 int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* matches, const cl_core_align_params* ap,
              cl_core_align_result* out) {
+    return cl_core_align_prepared(ctx, g1, g2, matches, ap, out, nullptr);
+}
+
+}  // extern "C"
+
+ClPathMergeTables::ClPathMergeTables() : x1(new clhost::PathMergeTable()), x2(new clhost::PathMergeTable()) {}
+ClPathMergeTables::~ClPathMergeTables() { wait(); delete x1; delete x2; }
+void ClPathMergeTables::start(const cl_base_graph* g1, const cl_base_graph* g2) {
+    builder = std::thread([this, g1, g2] { cl_pool_run(2, [&](unsigned t) { if (t) ok2 = x2->build(*g2); else ok1 = x1->build(*g1); }); });
+}
+void ClPathMergeTables::wait() { if (builder.joinable()) builder.join(); }
+
+// cl_core_align; `ready`: the two PathMerge tables a caller started building earlier (cl_merge: beside the match finding)
+int cl_core_align_prepared(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* matches, const cl_core_align_params* ap,
+                           cl_core_align_result* out, ClPathMergeTables* ready) {
     if (!ctx || !g1 || !g2 || !matches || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     // the two PathMerge tables, built side by side and shared by every stage below (cl_internal.hpp: cl_shared_table)
-    clhost::PathMergeTable x1, x2;
-    {
-        bool ok1 = false, ok2 = false;
-        cl_pool_run(2, [&](unsigned t) { if (t) ok2 = x2.build(*g2); else ok1 = x1.build(*g1); });
-        if (!ok1 || !ok2) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
-    }
+    ClPathMergeTables own;
+    ClPathMergeTables& tabs = ready ? *ready : own;
+    const bool timing = getenv("CL_CHAIN_TIMING") != nullptr;
+    const auto t_tab = std::chrono::steady_clock::now();
+    if (!ready) own.start(g1, g2);
+    tabs.wait();
+    if (!tabs.ok1 || !tabs.ok2) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    const clhost::PathMergeTable &x1 = *tabs.x1, &x2 = *tabs.x2;
     struct Registered {
         ClSharedTables saved;
         Registered(const cl_base_graph* a, const clhost::PathMergeTable* xa, const cl_base_graph* b, const clhost::PathMergeTable* xb) : saved(cl_tls_tables) {
@@ -63,13 +80,15 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(now() - t).count(); };
     int rc;
     auto t0 = now();
+    if (timing) fprintf(stderr, "[cl_core_align] path-merge tables          %8.1f ms\n", ms_since(t_tab));
     // anchor chain (core.hpp:194-197)
     cl_owned_match_sets* split = nullptr;
     cl_match_sets view = *matches;
-    if (ap->split_matches_at_branchpoints && !cl_split_is_identity(g1, g2, &ap->split)) {
-        if ((rc = cl_split_branching_matches(g1, g2, matches, &ap->split, &split))) { cl_set_error(ctx, "split_branching_matches failed"); return rc; }
-        cl_owned_match_sets_view(split, &view);
+    if (ap->split_matches_at_branchpoints) {
+        if ((rc = cl_split_branching_matches_unless_identity(g1, g2, matches, &ap->split, &split))) { cl_set_error(ctx, "split_branching_matches failed"); return rc; }
+        if (split) cl_owned_match_sets_view(split, &view);
     }
+    if (timing) fprintf(stderr, "[cl_core_align] branch split               %8.1f ms\n", ms_since(t0));
     cl_anchor_chain_result ch;
     rc = cl_anchor_chain(ctx, g1, g2, &view, &ap->anchor, &ch);
     cl_owned_match_sets_free(split);
@@ -143,5 +162,3 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
     if (!w1.empty()) { memcpy(out->walk1, w1.data(), w1.size() * sizeof(uint32_t)); memcpy(out->walk2, w2.data(), w2.size() * sizeof(uint32_t)); }
     return CL_OK;
 }
-
-}  // extern "C"

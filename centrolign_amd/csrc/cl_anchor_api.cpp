@@ -220,64 +220,74 @@ void cl_owned_match_sets_free(cl_owned_match_sets* o) { delete o; }
 
 }  // extern "C"
 
-// no superbubble of either graph is wide enough to cut a match at: cl_split_branching_matches would hand back a copy of its input
-// (always the case for the leaf graphs of a pairwise merge) — callers inside the library skip the 100-MB copy
-bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp) {
-    if (sp->anchor_split_limit == 0) return true;
-    Bubbles b1, b2;
-    if (!b1.build(*g1) || !b2.build(*g2)) return false;   // let the real call report the cycle
+namespace {
+
+bool build_bubbles(const cl_base_graph& g1, const cl_base_graph& g2, Bubbles& b1, Bubbles& b2) {
+    bool ok1 = false, ok2 = false;
+    cl_pool_run(2, [&](unsigned t) { if (t) ok2 = b2.build(g2); else ok1 = b1.build(g1); });
+    return ok1 && ok2;
+}
+
+bool no_wide_bubble(const Bubbles& b1, const Bubbles& b2, const cl_split_params& sp) {
     for (const Bubbles* b : {&b1, &b2})
         for (uint64_t spread : b->spread)
-            if (spread >= sp->min_path_length_spread) return false;
+            if (spread >= sp.min_path_length_spread) return false;
     return true;
 }
 
-extern "C" {
-
-int cl_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp,
-                               cl_owned_match_sets** out) {
-    if (!g1 || !g2 || !ms || !sp || !out) return CL_ERR_INVALID_ARGUMENT;
+// the body of cl_split_branching_matches; with skip_identity, *out stays null when no match can be cut (no superbubble of either graph is
+// wide enough: always the case for the leaf graphs of a pairwise merge) and the caller goes on with its own sets, without the 100-MB copy
+int split_matches(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp, bool skip_identity,
+                  cl_owned_match_sets** out) {
     *out = nullptr;
-    std::unique_ptr<cl_owned_match_sets> o(new cl_owned_match_sets());
     // a set during the edit: walks as (begin, end) windows into the caller's node arrays
     struct Set { uint64_t src; uint64_t from, to; };   // piece [from, to) of every walk of original set src
-    std::vector<Set> sets;
-    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+    const uint64_t n_orig = ms->n_sets;
+    std::vector<Set> sets(n_orig);
+    for (uint64_t s = 0; s < n_orig; ++s) {
         const uint64_t w0 = ms->set_off1[s];
         const uint64_t len = ms->set_off1[s + 1] > w0 ? ms->walk_off1[w0 + 1] - ms->walk_off1[w0] : 0;
-        sets.push_back(Set{s, 0, len});
+        sets[s] = Set{s, 0, len};
     }
     if (sp->anchor_split_limit != 0) {
         Bubbles b1, b2;
-        if (!b1.build(*g1) || !b2.build(*g2)) return CL_ERR_CYCLIC_GRAPH;
-        const uint64_t n_orig = ms->n_sets;
-        for (uint64_t s = 0; s < n_orig; ++s) {
-            const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
-            if (n1 == 0) return CL_ERR_INVALID_ARGUMENT;   // the reference reads walks1.front()
-            const uint64_t len = sets[s].to;
-            if (n1 * n2 > sp->max_split_match_set_size || len < sp->min_split_length) continue;
-            auto branch = [&](uint64_t j, bool backwards) {
-                for (int side = 0; side < 2; ++side) {
-                    const Bubbles& b = side ? b2 : b1;
-                    const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
-                    const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
-                    const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
-                    for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
-                        const uint32_t id = (backwards ? b.ends : b.begins)[nd[wo[w] + j]];
-                        if (id != Bubbles::none && b.spread[id] >= sp->min_path_length_spread) return true;
+        if (!build_bubbles(*g1, *g2, b1, b2)) return CL_ERR_CYCLIC_GRAPH;
+        if (skip_identity && no_wide_bubble(b1, b2, *sp)) return CL_OK;
+        for (uint64_t s = 0; s < n_orig; ++s)
+            if (ms->set_off1[s + 1] == ms->set_off1[s]) return CL_ERR_INVALID_ARGUMENT;   // the reference reads walks1.front()
+        // the cuts of every set, side by side; the pieces are appended in the order of the sets afterwards
+        std::vector<std::vector<uint64_t>> cuts(n_orig);
+        cl_parallel_for(n_orig, [&](uint64_t sb, uint64_t se) {
+            for (uint64_t s = sb; s < se; ++s) {
+                const uint64_t n1 = ms->set_off1[s + 1] - ms->set_off1[s], n2 = ms->set_off2[s + 1] - ms->set_off2[s];
+                const uint64_t len = sets[s].to;
+                if (n1 * n2 > sp->max_split_match_set_size || len < sp->min_split_length) continue;
+                auto branch = [&](uint64_t j, bool backwards) {
+                    for (int side = 0; side < 2; ++side) {
+                        const Bubbles& b = side ? b2 : b1;
+                        const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
+                        const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
+                        const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
+                        for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
+                            const uint32_t id = (backwards ? b.ends : b.begins)[nd[wo[w] + j]];
+                            if (id != Bubbles::none && b.spread[id] >= sp->min_path_length_spread) return true;
+                        }
                     }
+                    return false;
+                };
+                std::vector<uint64_t>& division = cuts[s];
+                // note: stops early, a branch after the final position is not problematic
+                for (uint64_t j = 0; j < len; ++j) {
+                    if (j == sp->anchor_split_limit && j + sp->anchor_split_limit < len) j = len - sp->anchor_split_limit;   // skip to the suffix
+                    if (j != 0 && (division.empty() || division.back() != j) && branch(j, true)) division.push_back(j);
+                    if (j + 1 != len && branch(j, false)) division.push_back(j + 1);
                 }
-                return false;
-            };
-            std::vector<uint64_t> division;
-            // note: stops early, a branch after the final position is not problematic
-            for (uint64_t j = 0; j < len; ++j) {
-                if (j == sp->anchor_split_limit && j + sp->anchor_split_limit < len) j = len - sp->anchor_split_limit;   // skip to the suffix
-                if (j != 0 && (division.empty() || division.back() != j) && branch(j, true)) division.push_back(j);
-                if (j + 1 != len && branch(j, false)) division.push_back(j + 1);
             }
+        }, 2048);
+        for (uint64_t s = 0; s < n_orig; ++s) {
+            const std::vector<uint64_t>& division = cuts[s];
             if (division.empty()) continue;
-            uint64_t end = len;
+            uint64_t end = sets[s].to;
             for (size_t q = division.size(); q-- > 0;) {
                 sets.push_back(Set{s, division[q], end});
                 end = division[q];
@@ -285,27 +295,75 @@ int cl_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2,
             sets[s].to = division.front();
         }
     }
-    for (const Set& st : sets) {
-        const uint64_t s = st.src;
-        for (int side = 0; side < 2; ++side) {
-            const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
-            const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
-            const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
-            auto& oso = side ? o->set_off2 : o->set_off1;
-            auto& owo = side ? o->walk_off2 : o->walk_off1;
-            auto& ond = side ? o->nodes2 : o->nodes1;
-            for (uint64_t w = so[s]; w < so[s + 1]; ++w) {
-                ond.insert(ond.end(), nd + wo[w] + st.from, nd + wo[w] + st.to);
-                owo.push_back(ond.size());
-            }
-            oso.push_back(owo.size() - 1);
+    // lay the pieces out: sizes, offsets, then the copy side by side
+    std::unique_ptr<cl_owned_match_sets> o(new cl_owned_match_sets());
+    const uint64_t m = sets.size();
+    o->count1.resize(m); o->count2.resize(m); o->full_length.resize(m);
+    std::vector<uint64_t> node_base[2];
+    for (int side = 0; side < 2; ++side) {
+        const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
+        auto& oso = side ? o->set_off2 : o->set_off1;
+        oso.resize(m + 1);
+        node_base[side].resize(m + 1);
+        oso[0] = 0; node_base[side][0] = 0;
+        for (uint64_t k = 0; k < m; ++k) {
+            const uint64_t nw = so[sets[k].src + 1] - so[sets[k].src];
+            oso[k + 1] = oso[k] + nw;
+            node_base[side][k + 1] = node_base[side][k] + nw * (sets[k].to - sets[k].from);
         }
-        o->count1.push_back(ms->count1[s]);
-        o->count2.push_back(ms->count2[s]);
-        o->full_length.push_back(ms->full_length[s]);
+        (side ? o->walk_off2 : o->walk_off1).resize(oso[m] + 1);
+        (side ? o->nodes2 : o->nodes1).resize(node_base[side][m]);
+        (side ? o->walk_off2 : o->walk_off1)[0] = 0;
     }
+    cl_parallel_for(m, [&](uint64_t kb, uint64_t ke) {
+        for (uint64_t k = kb; k < ke; ++k) {
+            const Set& st = sets[k];
+            const uint64_t s = st.src, len = st.to - st.from;
+            for (int side = 0; side < 2; ++side) {
+                const uint64_t* so = side ? ms->set_off2 : ms->set_off1;
+                const uint64_t* wo = side ? ms->walk_off2 : ms->walk_off1;
+                const uint32_t* nd = side ? ms->nodes2 : ms->nodes1;
+                uint64_t* owo = (side ? o->walk_off2 : o->walk_off1).data() + (side ? o->set_off2 : o->set_off1)[k];
+                uint32_t* ond = (side ? o->nodes2 : o->nodes1).data();
+                uint64_t at = node_base[side][k];
+                for (uint64_t w = so[s], i = 0; w < so[s + 1]; ++w, ++i) {
+                    if (len) std::memcpy(ond + at, nd + wo[w] + st.from, len * sizeof(uint32_t));
+                    at += len;
+                    owo[i + 1] = at;
+                }
+            }
+            o->count1[k] = ms->count1[s];
+            o->count2[k] = ms->count2[s];
+            o->full_length[k] = ms->full_length[s];
+        }
+    }, 4096);
     *out = o.release();
     return CL_OK;
+}
+
+}  // namespace
+
+// no superbubble of either graph is wide enough to cut a match at: cl_split_branching_matches would hand back a copy of its input
+bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp) {
+    if (sp->anchor_split_limit == 0) return true;
+    Bubbles b1, b2;
+    if (!build_bubbles(*g1, *g2, b1, b2)) return false;   // let the real call report the cycle
+    return no_wide_bubble(b1, b2, *sp);
+}
+
+// cl_split_branching_matches for callers inside the library: *out stays null when the split changes nothing
+int cl_split_branching_matches_unless_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp,
+                                               cl_owned_match_sets** out) {
+    if (sp->anchor_split_limit == 0) { *out = nullptr; return CL_OK; }
+    return split_matches(g1, g2, ms, sp, true, out);
+}
+
+extern "C" {
+
+int cl_split_branching_matches(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp,
+                               cl_owned_match_sets** out) {
+    if (!g1 || !g2 || !ms || !sp || !out) return CL_ERR_INVALID_ARGUMENT;
+    return split_matches(g1, g2, ms, sp, false, out);
 }
 
 }  // extern "C"

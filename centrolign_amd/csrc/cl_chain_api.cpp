@@ -1778,13 +1778,6 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     const clhost::PathMergeTable& x2 = sx2 ? *sx2 : own_x2;
     // anchorer.hpp:1175: the DP runs with the graphs swapped when that makes its tables smaller
     const bool swap = g1->n_nodes * x1.chain_size() > g2->n_nodes * x2.chain_size();
-    PostSwitchTable sw1, sw2;
-    sw1.build(*g1, x1);
-    sw2.build(*g2, x2);
-    std::vector<uint64_t> cur(ms->n_sets);
-    std::iota(cur.begin(), cur.end(), (uint64_t)0);
-    PathsOfNode steps1, steps2;
-    if (ap->do_fill_in_anchoring) { steps1.build(*g1); steps2.build(*g2); }
     // CL_CHAIN_TIMING=1: host phase times on stderr
     const bool timing = getenv("CL_CHAIN_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1792,6 +1785,19 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         if (timing) fprintf(stderr, "[cl_anchor_chain] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now() - t).count());
         t = now();
     };
+    auto t_pre = now();
+    PostSwitchTable sw1, sw2;
+    PathsOfNode steps1, steps2;
+    cl_pool_run(4, [&](unsigned t) {
+        if (t == 0) sw1.build(*g1, x1);
+        else if (t == 1) sw2.build(*g2, x2);
+        else if (!ap->do_fill_in_anchoring) return;
+        else if (t == 2) steps1.build(*g1);
+        else steps2.build(*g2);
+    });
+    lap("post-switch tables, paths of nodes", t_pre);
+    std::vector<uint64_t> cur(ms->n_sets);
+    std::iota(cur.begin(), cur.end(), (uint64_t)0);
 
     // walks of (position in `cur`, idx) on the caller's sets
     auto walk = [&](int side, uint64_t set_pos, uint32_t idx, const uint32_t*& b, const uint32_t*& e) {

@@ -283,22 +283,32 @@ int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, 
     // (chain of graph 1, chain of graph 2) combination — 0.9 GB at the root of a 10-sequence tree.  Locking that many pages takes ≈ 0.25 s
     // the first time a context needs them: do it beside the match finding instead of in front of the first traceback
     const uint64_t want_pinned = (uint64_t)prm->align.anchor.max_num_match_pairs * 28ull * std::max<uint64_t>(1, g1->n_paths) * std::max<uint64_t>(1, g2->n_paths);
+    // — and beside the HOST half of it: while pages are being locked every HIP call of the process stalls (the suffix sort of the root took
+    // 226 ms instead of 20 when the two ran side by side)
     std::thread pin;
-    if (want_pinned > ctx->pinned_bytes && want_pinned <= (8ull << 30)) {
-        const int device = ctx->device;
-        pin = std::thread([ctx, want_pinned, device] { (void)hipSetDevice(device); (void)cl_pinned(ctx, want_pinned); });
-    }
+    const std::function<void()> start_pin = [&] {
+        if (want_pinned > ctx->pinned_bytes && want_pinned <= (8ull << 30)) {
+            const int device = ctx->device;
+            pin = std::thread([ctx, want_pinned, device] { (void)hipSetDevice(device); (void)cl_pinned(ctx, want_pinned); });
+        }
+    };
+    // the PathMerge tables of the alignment need the graphs only: built beside the match finding
+    ClPathMergeTables tables;
+    tables.start(&a, &b);
     cl_owned_match_sets* ms = nullptr;
     cl_match_stats mst;
-    int rc = cl_find_matches(ctx, &a, &b, &prm->match, &ms, &mst);
+    int rc = cl_find_matches_hooked(ctx, &a, &b, &prm->match, &ms, &mst, &start_pin);
     if (pin.joinable()) pin.join();
     if (rc) return rc;
     out->match_ms = ms_since(t0);
+    if (getenv("CL_CHAIN_TIMING"))
+        fprintf(stderr, "[cl_merge] find_matches %.1f ms: text %.1f, device half %.1f (suffix sort %.1f, lcp %.1f), interval tree %.1f, queries %.1f, walks %.1f\n",
+                out->match_ms, mst.text_ms, mst.suffix_wall_ms, mst.sa_ms, mst.lcp_ms, mst.tree_ms, mst.query_ms, mst.walk_ms);
     cl_match_sets view;
     cl_owned_match_sets_view(ms, &view);
     out->n_match_sets = view.n_sets;
     t0 = now();
-    rc = cl_core_align(ctx, &a, &b, &view, &prm->align, &out->align);
+    rc = cl_core_align_prepared(ctx, &a, &b, &view, &prm->align, &out->align, &tables);
     cl_owned_match_sets_free(ms);
     if (rc) return rc;
     out->align_ms = ms_since(t0);

@@ -2,6 +2,8 @@
 #ifndef CL_INTERNAL_HPP
 #define CL_INTERNAL_HPP
 
+#include <thread>
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -225,7 +227,11 @@ int cl_processed_guide_tree(const char* newick, const char* const* names, uint64
 bool cl_purge_uncovered(cl_owned_base_graph& g);
 
 // defined in cl_anchor_api.cpp
+int cl_find_matches_hooked(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_params* prm, cl_owned_match_sets** out,
+                           cl_match_stats* stats, const std::function<void()>* after_device_half);   // cl_match_api.cpp
 bool cl_split_is_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_split_params* sp);
+int cl_split_branching_matches_unless_identity(const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_split_params* sp,
+                                               cl_owned_match_sets** out);   // *out stays null when the split changes nothing
 
 // The PathMerge tables of the two graphs of a merge are needed by the chaining, the partitioner's gap measurement and the stitcher's
 // extraction (the reference builds them once in Core::align, core.hpp:186-193, and hands them down).  cl_core_align builds them once and
@@ -238,13 +244,25 @@ inline const clhost::PathMergeTable* cl_shared_table(const cl_base_graph* g) {
     return nullptr;
 }
 
+// the two PathMerge tables of a merge, built on a thread of their own (cl_align_api.cpp)
+struct ClPathMergeTables {
+    clhost::PathMergeTable *x1, *x2;
+    bool ok1 = false, ok2 = false;
+    std::thread builder;
+    ClPathMergeTables();
+    ~ClPathMergeTables();
+    ClPathMergeTables(const ClPathMergeTables&) = delete;
+    void start(const cl_base_graph* g1, const cl_base_graph* g2);
+    void wait();
+};
+int cl_core_align_prepared(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* matches, const cl_core_align_params* ap,
+                           cl_core_align_result* out, ClPathMergeTables* ready /* may be null */);
+
 // host-side parallel loop over [0, n): f(begin, end) on up to 32 threads (the reference is single-threaded; the host glue around the device
 // passes is not part of the compared arithmetic, every iteration writes its own outputs).  The threads come from ONE pool per process
 // (cl_api.cpp), made on first use: creating and destroying threads per loop costs an mmap / munmap of every stack, and those take the
 // process's address-space lock in write mode — with four MSA workers doing it dozens of times per merge, every page fault of every
 // other worker waited (a leaf merge took 2.5 s next to three others, 1.1 s alone).
-#include <functional>
-#include <thread>
 void cl_pool_run(unsigned n_tasks, const std::function<void(unsigned)>& task);   // task(0 .. n_tasks-1), task 0 on the caller; returns when all are done
 unsigned cl_pool_width();                                                       // threads a loop may use (CL_HOST_THREADS, default min(cores, 32))
 template <class F>

@@ -306,6 +306,15 @@ void cl_match_params_default(cl_match_params* p) {
 
 int cl_find_matches(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_params* prm, cl_owned_match_sets** out,
                     cl_match_stats* stats) {
+    return cl_find_matches_hooked(ctx, g1, g2, prm, out, stats, nullptr);
+}
+
+}  // extern "C"
+
+// cl_find_matches with a callback between its device half (suffix array, LCP) and its host half (interval tree, queries, walks): cl_merge
+// starts work there that would get in the device half's way (page-locking the traceback's download area stalls every HIP call of the process)
+int cl_find_matches_hooked(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_params* prm, cl_owned_match_sets** out,
+                           cl_match_stats* stats, const std::function<void()>* after_device_half) {
     if (!ctx || !g1 || !g2 || !prm || !out) return CL_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (stats) *stats = cl_match_stats{};
@@ -320,6 +329,7 @@ int cl_find_matches(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     ClSuffixStats ss;
     if ((rc = cl_match_suffix_array(ctx, T.text.data(), n, sa.data(), lcp.data(), isa.data(), &ss))) return rc;
     const double suffix_wall_ms = ms_since(t0);
+    if (after_device_half) (*after_device_half)();
     if (stats) { stats->text_length = n; stats->doubling_rounds = ss.rounds; stats->sa_ms = ss.sort_ms; stats->lcp_ms = ss.lcp_ms; }
     std::unique_ptr<cl_owned_match_sets> o(new cl_owned_match_sets());
     if ((rc = matches_from_esa(*g1, *g2, *prm, T, sa.data(), lcp.data(), isa.data(), *o, stats))) return rc;
@@ -327,6 +337,8 @@ int cl_find_matches(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
     *out = o.release();
     return CL_OK;
 }
+
+extern "C" {
 
 int cl_match_joined_text(const cl_base_graph* g1, const cl_base_graph* g2, uint8_t** text_out, uint64_t* n_out) {
     if (!g1 || !g2 || !text_out || !n_out) return CL_ERR_INVALID_ARGUMENT;

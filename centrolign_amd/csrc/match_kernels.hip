@@ -103,9 +103,16 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
     } release{level, text, key_in, key_out, idx_in, idx_out, flag, dense, lcp, isa, temp, level_ptr};
 
     int rc;
+    const bool timing = getenv("CL_CHAIN_TIMING") != nullptr;
+    auto t_host = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[cl_match_suffix_array] %-20s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count());
+        t_host = std::chrono::steady_clock::now();
+    };
     if ((rc = text.alloc(ctx, n)) || (rc = key_in.alloc(ctx, n)) || (rc = key_out.alloc(ctx, n)) || (rc = idx_in.alloc(ctx, n)) ||
         (rc = idx_out.alloc(ctx, n)) || (rc = flag.alloc(ctx, n)) || (rc = dense.alloc(ctx, n)) || (rc = lcp.alloc(ctx, n)) || (rc = isa.alloc(ctx, n)))
         return rc;
+    lap("allocations");
     HIP_TRY(ctx, hipMemcpyAsync(text.p, h_text, n, hipMemcpyHostToDevice, s));
     size_t sort_bytes = 0, scan_bytes = 0;
     HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (int)n, 0, 64, s));
@@ -145,6 +152,7 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
         if (h >= n) { cl_set_error(ctx, "suffix ranks did not separate: the text must end in a unique smallest character"); return CL_ERR_INVALID_ARGUMENT; }
     }
     HIP_TRY(ctx, hipEventRecord(e1, s));
+    lap("doubling rounds");
     // idx_out now holds the suffix array (every key distinct)
     std::vector<const uint32_t*> ptrs;
     for (auto& l : level) ptrs.push_back(l.p);
@@ -152,10 +160,12 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
     hipLaunchKernelGGL(lcp_kernel, grid, block, 0, s, text.p, n, idx_out.p, level_ptr.p, (int)level.size(), lcp.p, isa.p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e2, s));
+    if (timing) { HIP_TRY(ctx, hipStreamSynchronize(s)); lap("lcp"); }
     HIP_TRY(ctx, hipMemcpyAsync(h_sa, idx_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(h_lcp, lcp.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(h_isa, isa.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    lap("download");
     if (st) {
         st->rounds = rounds;
         (void)hipEventElapsedTime(&st->sort_ms, e0, e1);
