@@ -62,10 +62,16 @@ std::atomic<size_t> cl_pinned_total{0};
 // per thread, best fit within 2x); a 64-byte header in front of every block says how large it is
 namespace {
 constexpr size_t kBigMin = 1u << 20, kBigCacheCap = 6ull << 30;
+struct BigHeader { size_t capacity; void* map; size_t map_bytes; };   // map: the block's own mapping (null: malloc'ed)
+static_assert(sizeof(BigHeader) <= 64, "header");
+void big_release(void* h) noexcept {
+    BigHeader* hd = static_cast<BigHeader*>(h);
+    if (hd->map) (void)munmap(hd->map, hd->map_bytes); else free(h);
+}
 struct BigCache {
     std::multimap<size_t, void*> free_blocks;   // capacity -> header
     size_t bytes = 0;
-    ~BigCache() { for (auto& b : free_blocks) free(b.second); }
+    ~BigCache() { for (auto& b : free_blocks) big_release(b.second); }
 };
 thread_local BigCache t_big_cache;
 }
@@ -79,19 +85,33 @@ void* cl_big_alloc(size_t bytes) {
             return static_cast<char*>(h) + 64;
         }
     }
+    if (bytes >= kBigMin) {
+        // a mapping of its own, advised to use huge pages: first touch then costs a fault per 2 MB instead of per 4 KB (34 ms instead of
+        // 120 ms per 900 MB on the MI355X host, scripts/dev/pin_bench.cpp) — and faults take the address-space lock the other workers need
+        constexpr size_t kHuge = 2u << 20;
+        const size_t len = ((bytes + 64 + kHuge - 1) & ~(kHuge - 1)) + kHuge;
+        void* map = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (map == MAP_FAILED) throw std::bad_alloc();
+        char* h = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(map) + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+        (void)madvise(h, len - kHuge, MADV_HUGEPAGE);
+        BigHeader* hd = reinterpret_cast<BigHeader*>(h);
+        hd->capacity = bytes; hd->map = map; hd->map_bytes = len;
+        return h + 64;
+    }
     void* h = malloc(bytes + 64);
     if (!h) throw std::bad_alloc();
-    *static_cast<size_t*>(h) = bytes;
+    BigHeader* hd = static_cast<BigHeader*>(h);
+    hd->capacity = bytes; hd->map = nullptr; hd->map_bytes = 0;
     return static_cast<char*>(h) + 64;
 }
 void cl_big_free(void* p) noexcept {
     if (!p) return;
     void* h = static_cast<char*>(p) - 64;
-    const size_t cap = *static_cast<size_t*>(h);
+    const size_t cap = static_cast<BigHeader*>(h)->capacity;
     if (cap >= kBigMin && t_big_cache.bytes + cap <= kBigCacheCap) {
         try { t_big_cache.free_blocks.emplace(cap, h); t_big_cache.bytes += cap; return; } catch (...) {}
     }
-    free(h);
+    big_release(h);
 }
 
 // A context keeps up to seven streams busy (the chaining DP: walk, two far launches, the sealing stream, copies) and an MSA runs several worker

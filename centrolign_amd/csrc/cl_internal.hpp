@@ -4,6 +4,7 @@
 
 #include <thread>
 #include <functional>
+#include <sys/mman.h>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -32,6 +33,8 @@ struct cl_context {
     // at the link's rate, copies into pageable memory at a tenth of it, and locking pages is too slow to do per call
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    void* pinned_map = nullptr;      // the mapping `pinned` lies in (cl_pinned)
+    size_t pinned_map_bytes = 0;
     std::mutex pinned_mutex;   // cl_merge grows the area on a helper thread beside the match finding: every access goes through cl_pinned
     // device memory pool (cl_dev_alloc / cl_dev_free).  hipFree waits for the WHOLE device and hipMalloc takes a process-wide lock: with
     // several contexts at work (the worker threads of an MSA) every release in one of them stalled on the others' kernels.  Released
@@ -108,18 +111,41 @@ inline size_t cl_pinned_cap() {
     static const size_t cap = [] { const char* e = getenv("CL_PINNED_CAP_GB"); const long v = e ? atol(e) : 16; return (size_t)(v < 0 ? 0 : v) << 30; }();
     return cap;
 }
+// The area is an anonymous mapping advised to use huge pages, touched and then registered with the runtime: locking 900 MB that way takes
+// 36 ms on the MI355X host (touch 34 + hipHostRegister 2.4) against 170-190 ms for hipHostMalloc of the same size, releasing it 33 ms
+// against 80-100 — and while pages are being locked every HIP call and every page fault of the process waits (scripts/dev/pin_bench.cpp).
+// Device-to-host copies into it run at the same 54 GB/s.
 inline void cl_pinned_release_locked(cl_context* ctx) {
-    if (ctx->pinned) { (void)hipHostFree(ctx->pinned); cl_pinned_total -= ctx->pinned_bytes; }
+    if (ctx->pinned) {
+        (void)hipHostUnregister(ctx->pinned);
+        (void)munmap(ctx->pinned_map, ctx->pinned_map_bytes);
+        cl_pinned_total -= ctx->pinned_bytes;
+    }
     ctx->pinned = nullptr;
-    ctx->pinned_bytes = 0;
+    ctx->pinned_map = nullptr;
+    ctx->pinned_bytes = ctx->pinned_map_bytes = 0;
 }
 inline void* cl_pinned(cl_context* ctx, size_t bytes) {
     std::lock_guard<std::mutex> lock(ctx->pinned_mutex);
     if (bytes <= ctx->pinned_bytes) return ctx->pinned;
     cl_pinned_release_locked(ctx);
-    const size_t want = bytes + bytes / 8;
+    constexpr size_t kHuge = 2u << 20;
+    const size_t want = (bytes + bytes / 8 + kHuge - 1) & ~(kHuge - 1);
     if (cl_pinned_total.fetch_add(want) + want > cl_pinned_cap()) { cl_pinned_total -= want; return nullptr; }
-    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; cl_pinned_total -= want; (void)hipGetLastError(); return nullptr; }
+    void* map = mmap(nullptr, want + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (map == MAP_FAILED) { cl_pinned_total -= want; return nullptr; }
+    char* area = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(map) + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+    (void)madvise(area, want, MADV_HUGEPAGE);
+    for (size_t i = 0; i < want; i += 4096) area[i] = 0;
+    if (hipHostRegister(area, want, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)munmap(map, want + kHuge);
+        cl_pinned_total -= want;
+        return nullptr;
+    }
+    ctx->pinned = area;
+    ctx->pinned_map = map;
+    ctx->pinned_map_bytes = want + kHuge;
     ctx->pinned_bytes = want;
     return ctx->pinned;
 }

@@ -78,9 +78,6 @@ struct JoinedText {
     int comp(uint32_t pos) const { return pos >= first2 ? 1 : 0; }
 };
 
-struct Node {
-    uint32_t l, r, depth, parent;
-};
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct Found {
@@ -92,112 +89,198 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
                      const uint32_t* lcp, const uint32_t* isa, cl_owned_match_sets& out, cl_match_stats* st) {
     const uint32_t n = (uint32_t)T.text.size();
     auto t0 = clk::now();
-    // ---- the LCP-interval tree, bottom-up (the stack pass of esa.hpp:436-494), with Hui's duplicate counts
-    std::vector<Node> nodes;
-    std::vector<uint32_t> closed;            // node ids in the order the pass closes them (children before parents)
-    std::vector<uint32_t> own_dup[2];        // duplicates whose LCA is the node
-    std::vector<uint32_t> leaf_parent(n);    // deepest internal node above every leaf
-    std::vector<uint32_t> stack;
-    std::vector<uint32_t> prev_occ[2];
-    for (int c = 0; c < 2; ++c) prev_occ[c].assign(T.n_ids[c], kNone);
-    std::vector<uint32_t> before[2];         // leaves of graph c at suffix-array positions < p
-    for (int c = 0; c < 2; ++c) before[c].resize((size_t)n + 1);
-    nodes.reserve(n);
-    closed.reserve(n);
-    auto new_node = [&](uint32_t l, uint32_t depth) {
-        nodes.push_back(Node{l, 0, depth, kNone});
-        own_dup[0].push_back(0);
-        own_dup[1].push_back(0);
-        return (uint32_t)(nodes.size() - 1);
-    };
-    auto visit_leaf = [&](uint32_t i) {
-        const uint32_t pos = sa[i];
-        const int c = T.comp(pos);
-        before[0][i + 1] = before[0][i] + (c == 0);
-        before[1][i + 1] = before[1][i] + (c == 1);
-        uint32_t& prev = prev_occ[c][T.id[pos]];
-        if (prev != kNone) {
-            // deepest open interval that also holds the previous occurrence: interval starts grow along the stack
-            size_t lo = 0, hi = stack.size() - 1;
-            while (lo < hi) {
-                const size_t mid = (lo + hi + 1) / 2;
-                if (nodes[stack[mid]].l <= prev) lo = mid; else hi = mid - 1;
+    // ---- the LCP-interval tree, bottom-up (the stack pass of esa.hpp:436-494), with Hui's duplicate counts — cut into ranges of suffix-array
+    //      positions that run side by side.  A node is NAMED by the position at which the pass opens it (0 = the root; at most one node opens
+    //      per position), so every range names the nodes alike without talking to the others:
+    //        * the intervals still open in front of a range are the strict minima of the LCP values met going left from it (depth = the
+    //          minimum, left end = the position of the next smaller value, opened at the leftmost position that holds the minimum);
+    //        * the earlier occurrence of a leaf's start node (Hui's "previous leaf of the same colour") is tabulated beforehand from the
+    //          inverse suffix array instead of carried along the pass;
+    //        * the nodes below a node are exactly those opened at positions (l, r] of its interval, so the subtree totals of the
+    //          duplicates (src/esa.cpp:235-300) are differences of one prefix sum over positions.
+    //      Closing order (children before parents, the order the reference meets the nodes in) = the ranges' closing lists one after another.
+    //      (ClRawVec: the big arrays come uninitialised from the thread's block cache — fresh zeroed vectors cost a page fault per 4 KB, and
+    //      those wait while another thread of the process locks pages)
+    uint32_t grain = 1u << 16;
+    uint64_t max_ranges = cl_pool_width();
+    if (const char* e = getenv("CL_MATCH_TREE_GRAIN")) { grain = (uint32_t)std::max(1, atoi(e)); max_ranges = 4096; }   // test hook: many small ranges
+    const unsigned n_ranges = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(max_ranges, n / grain));
+    std::vector<uint32_t> cut(n_ranges + 1);
+    for (unsigned t = 0; t <= n_ranges; ++t) cut[t] = (uint32_t)((uint64_t)n * t / n_ranges);
+    auto comp_of = [&](uint32_t i) { return T.comp(sa[i]); };
+    // leaves of graph 0 at suffix-array positions < p (graph 1: p minus that)
+    ClRawVec<uint32_t> before0((size_t)n + 1);
+    {
+        std::vector<uint32_t> part(n_ranges + 1, 0);
+        cl_pool_run(n_ranges, [&](unsigned t) {
+            uint32_t k = 0;
+            for (uint32_t i = cut[t]; i < cut[t + 1]; ++i) k += comp_of(i) == 0;
+            part[t + 1] = k;
+        });
+        for (unsigned t = 0; t < n_ranges; ++t) part[t + 1] += part[t];
+        cl_pool_run(n_ranges, [&](unsigned t) {
+            uint32_t k = part[t];
+            for (uint32_t i = cut[t]; i < cut[t + 1]; ++i) { before0[i] = k; k += comp_of(i) == 0; }
+            if (t + 1 == n_ranges) before0[n] = k;
+        });
+    }
+    auto before = [&](int c, uint32_t p) { return c ? p - before0[p] : before0[p]; };
+    // prev_of[i]: the largest suffix-array position < i whose suffix starts at the same node of the same graph
+    ClRawVec<uint32_t> prev_of(n);
+    {
+        const uint64_t n_keys = T.n_ids[0] + T.n_ids[1];
+        auto key_of = [&](uint32_t pos) { return (uint64_t)(T.comp(pos) ? T.n_ids[0] + T.id[pos] : T.id[pos]); };
+        ClRawVec<uint32_t> key_off(n_keys + 1), fill(n_keys), occ(n);
+        cl_parallel_for(n_keys, [&](uint64_t b, uint64_t e) { std::memset(fill.data() + b, 0, (e - b) * sizeof(uint32_t)); });
+        cl_parallel_for(n, [&](uint64_t b, uint64_t e) { for (uint64_t pos = b; pos < e; ++pos) __atomic_fetch_add(&fill[key_of((uint32_t)pos)], 1u, __ATOMIC_RELAXED); });
+        {   // exclusive prefix sum of the counts
+            const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(cl_pool_width(), n_keys / 65536));
+            std::vector<uint64_t> kc(nt + 1), sum(nt + 1, 0);
+            for (unsigned t = 0; t <= nt; ++t) kc[t] = n_keys * t / nt;
+            cl_pool_run(nt, [&](unsigned t) { uint64_t a = 0; for (uint64_t k = kc[t]; k < kc[t + 1]; ++k) a += fill[k]; sum[t + 1] = a; });
+            for (unsigned t = 0; t < nt; ++t) sum[t + 1] += sum[t];
+            cl_pool_run(nt, [&](unsigned t) { uint32_t a = (uint32_t)sum[t]; for (uint64_t k = kc[t]; k < kc[t + 1]; ++k) { key_off[k] = a; a += fill[k]; } });
+            key_off[n_keys] = n;
+        }
+        cl_parallel_for(n, [&](uint64_t b, uint64_t e) {
+            for (uint64_t pos = b; pos < e; ++pos) {
+                const uint64_t k = key_of((uint32_t)pos);
+                occ[key_off[k] + __atomic_sub_fetch(&fill[k], 1u, __ATOMIC_RELAXED)] = isa[pos];
             }
-            ++own_dup[c][stack[lo]];
-        }
-        prev = i;
-    };
-    stack.push_back(new_node(0, 0));
-    before[0][0] = before[1][0] = 0;
-    leaf_parent[0] = stack[0];
-    visit_leaf(0);
-    // the pass is a chain of cache misses — id[sa[i]], then prev_occ[...][that id] — on addresses known far ahead: fetch them early
-    constexpr uint32_t kAheadId = 48, kAheadOcc = 24;
-    for (uint32_t i = 1; i < n; ++i) {
-        if (i + kAheadId < n) __builtin_prefetch(&T.id[sa[i + kAheadId]]);
-        if (i + kAheadOcc < n) { const uint32_t pa = sa[i + kAheadOcc]; __builtin_prefetch(&prev_occ[T.comp(pa)][T.id[pa]], 1); }
-        uint32_t last = kNone, left = i - 1;
-        bool fresh = true;
-        while (nodes[stack.back()].depth > lcp[i]) {
-            const uint32_t v = stack.back();
-            stack.pop_back();
-            nodes[v].r = i - 1;
-            closed.push_back(v);
-            left = nodes[v].l;
-            fresh = false;
-            if (nodes[stack.back()].depth >= lcp[i]) { nodes[v].parent = stack.back(); last = kNone; }
-            else last = v;
-        }
-        if (nodes[stack.back()].depth < lcp[i]) {
-            const uint32_t u = new_node(left, lcp[i]);
-            stack.push_back(u);
-            if (last != kNone) nodes[last].parent = u;
-            if (fresh) leaf_parent[i - 1] = u;   // the interval opens at leaf i-1
-        }
-        leaf_parent[i] = stack.back();
-        visit_leaf(i);
+        });
+        cl_parallel_for(n_keys, [&](uint64_t b, uint64_t e) {
+            for (uint64_t k = b; k < e; ++k) {
+                uint32_t* lo = occ.data() + key_off[k];
+                uint32_t* hi = occ.data() + key_off[k + 1];
+                if (lo == hi) continue;
+                if (hi - lo > 1) std::sort(lo, hi);
+                prev_of[*lo] = kNone;
+                for (uint32_t* q = lo + 1; q < hi; ++q) prev_of[*q] = q[-1];
+            }
+        });
     }
-    while (!stack.empty()) {
-        const uint32_t v = stack.back();
-        stack.pop_back();
-        nodes[v].r = n - 1;
-        closed.push_back(v);
-        if (!stack.empty()) nodes[v].parent = stack.back();
+    ClRawVec<uint32_t> node_l(n), node_r(n), node_parent(n);   // by node = opening position
+    ClRawVec<uint32_t> leaf_parent(n);                          // deepest internal node above every leaf
+    ClRawVec<uint32_t> dup[2];                                   // duplicates whose LCA is the node; prefix sums over positions afterwards
+    for (int c = 0; c < 2; ++c) {
+        dup[c].resize(n);
+        cl_parallel_for(n, [&](uint64_t b, uint64_t e) { std::memset(dup[c].data() + b, 0, (e - b) * sizeof(uint32_t)); });
     }
-    // subtree totals of the duplicates (src/esa.cpp:235-300), then distinct start nodes = leaves - duplicates
-    std::vector<uint32_t>& dup0 = own_dup[0];
-    std::vector<uint32_t>& dup1 = own_dup[1];
-    for (size_t k = 0; k < closed.size(); ++k) {
-        if (k + 32 < closed.size()) __builtin_prefetch(&nodes[closed[k + 32]]);
-        if (k + 16 < closed.size()) {
-            const uint32_t pa = nodes[closed[k + 16]].parent;
-            if (pa != kNone) { __builtin_prefetch(&dup0[pa], 1); __builtin_prefetch(&dup1[pa], 1); }
+    auto depth_of = [&](uint32_t v) -> uint32_t { return v ? lcp[v] : 0; };
+    node_l[0] = 0; node_parent[0] = kNone;
+    struct Open { uint32_t node, l, depth; };
+    std::vector<ClRawVec<uint32_t>> closed_part(n_ranges);     // node ids in the order the pass closes them (children before parents)
+    std::vector<uint32_t> late_leaf_parent(n_ranges, kNone);   // a node that opens at a range's first position sits above the leaf in front of it
+    cl_pool_run(n_ranges, [&](unsigned t) {
+        const uint32_t a = cut[t], b = cut[t + 1];
+        ClRawVec<uint32_t>& closed = closed_part[t];
+        closed.reserve((size_t)(b - a) + 64);
+        std::vector<Open> stack;
+        if (a == 0) stack.push_back(Open{0, 0, 0});
+        else {
+            std::vector<Open> deepest_first;
+            uint32_t cur = kNone, leftmost = 0;
+            for (uint32_t j = a - 1; j >= 1; --j) {
+                const uint32_t v = lcp[j];
+                if (cur == kNone) { cur = v; leftmost = j; }
+                else if (v < cur) { deepest_first.push_back(Open{leftmost, j, cur}); cur = v; leftmost = j; }
+                else if (v == cur) leftmost = j;
+                if (cur == 0) break;
+            }
+            if (cur != kNone && cur != 0) deepest_first.push_back(Open{leftmost, 0, cur});
+            deepest_first.push_back(Open{0, 0, 0});
+            stack.assign(deepest_first.rbegin(), deepest_first.rend());
         }
-        const uint32_t v = closed[k];
-        if (nodes[v].parent != kNone) { dup0[nodes[v].parent] += dup0[v]; dup1[nodes[v].parent] += dup1[v]; }
+        if (a == 0) leaf_parent[0] = 0;
+        for (uint32_t i = std::max<uint32_t>(a, 1); i < b; ++i) {
+            const uint32_t li = lcp[i];
+            uint32_t last = kNone, left = i - 1;
+            bool fresh = true;
+            while (stack.back().depth > li) {
+                const Open v = stack.back();
+                stack.pop_back();
+                node_r[v.node] = i - 1;
+                closed.push_back(v.node);
+                left = v.l;
+                fresh = false;
+                if (stack.back().depth >= li) { node_parent[v.node] = stack.back().node; last = kNone; }
+                else last = v.node;
+            }
+            if (stack.back().depth < li) {
+                stack.push_back(Open{i, left, li});
+                node_l[i] = left;
+                if (last != kNone) node_parent[last] = i;
+                if (fresh) {   // the interval opens at leaf i-1
+                    if (i - 1 >= a) leaf_parent[i - 1] = i; else late_leaf_parent[t] = i;
+                }
+            }
+            leaf_parent[i] = stack.back().node;
+            const uint32_t prev = prev_of[i];
+            if (prev != kNone) {
+                // deepest open interval that also holds the previous occurrence: interval starts grow along the stack.  Copies of a node with
+                // a long shared context are neighbours in the suffix array, so the answer is mostly at or just under the top: look there first
+                size_t hi = stack.size() - 1;
+                int probes = 6;
+                while (hi > 0 && probes-- > 0 && stack[hi].l > prev) --hi;
+                if (hi > 0 && stack[hi].l > prev) {
+                    size_t lo = 0;
+                    --hi;
+                    while (lo < hi) {
+                        const size_t mid = (lo + hi + 1) / 2;
+                        if (stack[mid].l <= prev) lo = mid; else hi = mid - 1;
+                    }
+                    hi = lo;
+                }
+                __atomic_fetch_add(&dup[comp_of(i)][stack[hi].node], 1u, __ATOMIC_RELAXED);
+            }
+        }
+        if (b == n)
+            while (!stack.empty()) {
+                const Open v = stack.back();
+                stack.pop_back();
+                node_r[v.node] = n - 1;
+                closed.push_back(v.node);
+                if (!stack.empty()) node_parent[v.node] = stack.back().node;
+            }
+    });
+    for (unsigned t = 1; t < n_ranges; ++t)
+        if (late_leaf_parent[t] != kNone) leaf_parent[cut[t] - 1] = late_leaf_parent[t];
+    std::vector<uint64_t> closed_off(n_ranges + 1, 0);
+    for (unsigned t = 0; t < n_ranges; ++t) closed_off[t + 1] = closed_off[t] + closed_part[t].size();
+    const uint32_t n_nodes = (uint32_t)closed_off[n_ranges];
+    ClRawVec<uint32_t> closed(n_nodes), close_rank(n);
+    cl_pool_run(n_ranges, [&](unsigned t) {
+        const ClRawVec<uint32_t>& part = closed_part[t];
+        uint32_t k = (uint32_t)closed_off[t];
+        for (uint32_t v : part) { closed[k] = v; close_rank[v] = k; ++k; }
+    });
+    closed_part.clear();
+    // dup[c][p] := duplicates charged to the nodes opened at positions <= p
+    for (int c = 0; c < 2; ++c) {
+        std::vector<uint64_t> sum(n_ranges + 1, 0);
+        cl_pool_run(n_ranges, [&](unsigned t) { uint64_t a = 0; for (uint32_t i = cut[t]; i < cut[t + 1]; ++i) a += dup[c][i]; sum[t + 1] = a; });
+        for (unsigned t = 0; t < n_ranges; ++t) sum[t + 1] += sum[t];
+        cl_pool_run(n_ranges, [&](unsigned t) { uint32_t a = (uint32_t)sum[t]; for (uint32_t i = cut[t]; i < cut[t + 1]; ++i) { a += dup[c][i]; dup[c][i] = a; } });
     }
+    // distinct start nodes of graph c below node v = leaves - duplicates
     auto distinct = [&](uint32_t v, int c) -> uint64_t {
-        return (uint64_t)(before[c][nodes[v].r + 1] - before[c][nodes[v].l]) - (c ? dup1[v] : dup0[v]);
+        const uint32_t l = node_l[v], r = node_r[v];
+        const uint32_t dups = v ? dup[c][r] - dup[c][l] : dup[c][r];
+        return (uint64_t)(before(c, r + 1) - before(c, l)) - dups;
     };
-    if (st) { st->n_internal_nodes = nodes.size(); st->tree_ms = ms_since(t0); }
+    if (st) { st->n_internal_nodes = n_nodes; st->tree_ms = ms_since(t0); }
 
     // ---- the query (esa.hpp:290-431): every (parent, child) pair is independent.  The reference meets the children grouped under their
     //      parents, parents in closing order, children in closing order: evaluate them all side by side in closing order of the child and
     //      sort the few that pass by (closing rank of the parent, closing rank of the child)
     t0 = clk::now();
-    const uint32_t n_nodes = (uint32_t)nodes.size();
-    std::vector<uint32_t> close_rank(n_nodes);
-    for (uint32_t k = 0; k < n_nodes; ++k) {
-        if (k + 32 < n_nodes) __builtin_prefetch(&close_rank[closed[k + 32]], 1);
-        close_rank[closed[k]] = k;
-    }
     struct Kept { uint64_t key; Found f; };
     std::vector<std::vector<Kept>> kept_parts;
     std::mutex kept_mutex;
     cl_parallel_for(n_nodes, [&](uint64_t b, uint64_t e) {
         std::vector<Kept> mine;
         for (uint64_t x = b; x < e; ++x) {
-            const uint32_t C = closed[x], P = nodes[C].parent;
+            const uint32_t C = closed[x], P = node_parent[C];
             if (P == kNone) continue;
             const uint64_t c0 = distinct(C, 0);
             if (c0 == 0) continue;                   // esa.hpp:391-393: counts stay 0, total 0
@@ -205,14 +288,14 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
             if (c1 == 0) continue;
             unsigned __int128 total = (unsigned __int128)c0 * c1;   // sat_mult (:399-402)
             if (total > prm.max_count) continue;
-            const uint32_t d = nodes[P].depth;
+            const uint32_t d = depth_of(P);
             if (d != 0) {
                 if (!(c0 < distinct(P, 0) || c1 < distinct(P, 1))) continue;            // parent_more_frequent (:397)
                 // the sibling under the parent's suffix link (:352-362): drop the first character of C's string
-                const uint32_t q = isa[sa[nodes[C].l] + 1];
+                const uint32_t q = isa[sa[node_l[C]] + 1];
                 uint32_t L = leaf_parent[q];
-                while (nodes[L].parent != kNone && nodes[nodes[L].parent].depth >= d) L = nodes[L].parent;
-                if (nodes[L].depth < d) continue;   // a leaf: cannot be more frequent than an internal node's string
+                while (node_parent[L] != kNone && depth_of(node_parent[L]) >= d) L = node_parent[L];
+                if (depth_of(L) < d) continue;   // a leaf: cannot be more frequent than an internal node's string
                 if (!(c0 < distinct(L, 0) || c1 < distinct(L, 1))) continue;            // link_more_frequent (:396)
             }
             if (!(clhost::anchor_weight(prm.score, c0, c1, (uint64_t)d + 1, (uint64_t)d + 1) > 0.0)) continue;   // match_finder.hpp:162
@@ -236,13 +319,13 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
     out.set_off1.assign(m + 1, 0); out.set_off2.assign(m + 1, 0);
     // pass 1: the leaves that start a walk (first occurrence of a (graph, start node) in suffix-array order)
     std::vector<uint64_t> leaf_off(m + 1, 0);
-    for (uint64_t s = 0; s < m; ++s) leaf_off[s + 1] = leaf_off[s] + (nodes[matches[s].node].r - nodes[matches[s].node].l + 1);
-    std::vector<uint8_t> starts(leaf_off[m]);
+    for (uint64_t s = 0; s < m; ++s) leaf_off[s + 1] = leaf_off[s] + (node_r[matches[s].node] - node_l[matches[s].node] + 1);
+    ClRawVec<uint8_t> starts(leaf_off[m]);
     cl_parallel_for(m, [&](uint64_t b, uint64_t e) {
         std::vector<uint32_t> stamp[2];
         for (int c = 0; c < 2; ++c) stamp[c].assign(T.n_ids[c], kNone);
         for (uint64_t s = b; s < e; ++s) {
-            const Node& nd = nodes[matches[s].node];
+            const struct { uint32_t l, r; } nd{node_l[matches[s].node], node_r[matches[s].node]};
             uint64_t k1 = 0, k2 = 0;
             for (uint32_t i = nd.l; i <= nd.r; ++i) {
                 const uint32_t pos = sa[i];
@@ -276,7 +359,7 @@ int matches_from_esa(const cl_base_graph& g1, const cl_base_graph& g2, const cl_
     out.walk_off2[out.set_off2[m]] = node_off2[m];
     cl_parallel_for(m, [&](uint64_t b, uint64_t e) {
         for (uint64_t s = b; s < e; ++s) {
-            const Node& nd = nodes[matches[s].node];
+            const struct { uint32_t l, r; } nd{node_l[matches[s].node], node_r[matches[s].node]};
             const uint32_t len = matches[s].length;
             uint64_t a1 = out.set_off1[s], a2 = out.set_off2[s], p1 = node_off1[s], p2 = node_off2[s];
             for (uint32_t i = nd.l; i <= nd.r; ++i) {
@@ -325,7 +408,7 @@ int cl_find_matches_hooked(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     const uint32_t n = (uint32_t)T.text.size();
     const double text_ms = ms_since(t0);
     t0 = clk::now();
-    std::vector<uint32_t> sa(n), lcp(n), isa(n);
+    ClRawVec<uint32_t> sa(n), lcp(n), isa(n);
     ClSuffixStats ss;
     if ((rc = cl_match_suffix_array(ctx, T.text.data(), n, sa.data(), lcp.data(), isa.data(), &ss))) return rc;
     const double suffix_wall_ms = ms_since(t0);

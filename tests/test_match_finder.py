@@ -72,6 +72,20 @@ def test_msa_merges_match_reference_golden(m):
         assert _same(got, capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT}))
 
 
+def test_interval_tree_ranges_agree(monkeypatch):
+    """the host half walks the LCP-interval tree in ranges of suffix-array positions side by side (cl_match_api.cpp); CL_MATCH_TREE_GRAIN
+    sets their width: one position per range, a few, and one range for everything give the reference's sets — multi-path graphs with
+    repeats, where the open intervals in front of a range, the previous occurrences and the duplicate counts all cross range borders"""
+    names = [n for n in CASES if len(CASES[n][0].path_off) > 2 or len(CASES[n][1].path_off) > 2][:6] + list(CASES)[:4]
+    for grain in ("1", "2", "5", "37", "1000000000"):
+        monkeypatch.setenv("CL_MATCH_TREE_GRAIN", grain)
+        for name in names:
+            g1, g2, mc = CASES[name]
+            assert _same(_host_half(g1, g2, mc), _golden(name)), (grain, name)
+        _, graphs, _ = load_stitch_case("stitch4_30k_merge2.npz")
+        _check_merge(2, _host_half(graphs[0], graphs[1], 3000))
+
+
 def test_oracle_suffix_array_is_sorted_and_lcp_exact():
     rng = np.random.default_rng(3)
     for n, alphabet in ((1, 1), (2, 1), (50, 1), (300, 2), (2000, 4)):
