@@ -14,7 +14,9 @@ constexpr uint32_t kChainFarGroup = 1;    // consecutive blocks served by one fa
 constexpr uint32_t kChainFarStreams = 2;  // auxiliary streams the far launches alternate between
 constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group broadcast through LDS (more fall back to HBM)
 constexpr uint32_t kChainMacro = 1024;    // match pairs per launch of the walk kernel (one workgroup per chain combination)
-constexpr uint32_t kChainWalkMaxCombos = 96;  // the walk's workgroups wait for one another: all of them must be resident
+constexpr uint32_t kChainWalkMaxCombos = 256; // the walk's workgroups wait for one another: all of them must be resident (one per CU: the affine
+                                              // walk takes 96 VGPRs at 1 024 threads)
+constexpr uint32_t kChainWalkSweepCombos = 32; // up to here every workgroup reads every other's granule; beyond, one atomic maximum + arrival count per pair
 
 struct ClChainParams {
     double gap_open[3];
@@ -58,6 +60,7 @@ struct ClChainDevice {
     const uint32_t* group_end;  // [n_pairs] sorted index one past the last pair of the pair's group
     unsigned long long* xch;    // [n_combos][kChainMacro] {tag, value} granules: the walk's workgroups exchange their
                                 // combination's best candidate per pair (zeroed before every DP)
+    uint32_t* xred;             // null, or [n_pairs][2] {biased maximum, arrivals}: the exchange as a reduction (many combinations; zeroed before every DP)
     uint32_t* status;           // [1] set non-zero by a walk that gave up waiting for a sibling workgroup
     // branch-and-bound far pass (chain_far.hip); null / 0 when it is not in use
     int* far_rec;               // [r_pad][12] the records of every combination as the kernels consume them: insertion index, offset,

@@ -542,7 +542,24 @@ __global__ void __launch_bounds__(kChainMacro) chain_walk_kernel(ClChainDevice D
                 }
             }
             float best = fmaxf(w_init, cand);
-            if (n_combos > 1) {
+            if (n_combos > 1 && D.xred) {
+                // many combinations: instead of every workgroup reading every other's granule (n_combos^2 loads per pair), one atomic maximum
+                // and one arrival count per pair; the maximum of the same set of floats, whoever comes first
+                uint32_t* red = D.xred + 2 * (size_t)s;
+                if (cand != CL_CHAIN_NEG) __hip_atomic_fetch_max(red, (uint32_t)enc(cand) ^ 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(red + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load(red + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_combos) {
+                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(D.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        atomicExch(D.status, 1u);
+                        s_abort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t m = __hip_atomic_load(red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (m != 0) best = fmaxf(best, dec((int)(m ^ 0x80000000u)));
+            } else if (n_combos > 1) {
                 const unsigned long long tag = (unsigned long long)(s + 1u) << 32;
                 __hip_atomic_store(&D.xch[(size_t)c * kChainMacro + t], tag | (unsigned)__float_as_int(cand), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned spins = 0;

@@ -722,6 +722,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
     DevBuf<unsigned long long> d_xch;
+    DevBuf<uint32_t> d_xred;
     DevBuf<int> k_in, k_out;          // value index of the traceback (built on demand)
     DevBuf<uint32_t> i_in, i_out;
     DevBuf<char> vtemp;
@@ -739,7 +740,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     auto cleanup = [&]() {
         for (Combo& c : combos) c.release();
         d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release(); d_grp_base.release(); d_grp_total.release();
-        d_group_end.release(); d_status.release(); d_xch.release();
+        d_group_end.release(); d_status.release(); d_xch.release(); d_xred.release();
         k_in.release(); k_out.release(); i_in.release(); i_out.release(); vtemp.release();
         d_far_rec.release(); d_far_base.release(); d_seal_items.release(); d_far_temp.release();
         for (auto& b : d_far_perm) b.release();
@@ -816,6 +817,13 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             CH(d_status.alloc(ctx, 8));
             if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
                 hipMemsetAsync(d_status.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+            // the exchange between the walk's workgroups: granule sweep for few combinations, reduction for many (CL_CHAIN_WALK_REDUCE=0/1 pins it: A/B)
+            static const char* reduce_env = getenv("CL_CHAIN_WALK_REDUCE");
+            const bool reduce = reduce_env ? reduce_env[0] == '1' : combos.size() > kChainWalkSweepCombos;
+            if (reduce && combos.size() > 1) {
+                CH(d_xred.alloc(ctx, 2 * M));
+                if (hipMemsetAsync(d_xred.p, 0, 2 * M * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+            }
         }
         // LDS slots of the sequential kernel: records of a (block, group) are laid out in pair order
         std::vector<uint32_t> grp_base(M), grp_total(M);
@@ -848,6 +856,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     D.sparse = sparse ? 1u : 0u;
     D.group_end = d_group_end.p;
     D.xch = d_xch.p;
+    D.xred = d_xred.p;
     D.status = d_status.p;
 
 

@@ -24,6 +24,10 @@ VARIANTS = [
     ("sweep", {"CL_CHAIN_FAR_MODE": "sweep"}),
     ("no_far", {"CL_CHAIN_NO_FAR_PRUNE": "1"}),
     ("per_block", {"CL_CHAIN_NO_FAR_PRUNE": "1", "CL_CHAIN_OLD_WALK": "1"}),
+    # the walk's workgroups exchange their candidates through one atomic maximum + arrival count per pair (the way of merges with more than
+    # 32 chain combinations) instead of reading one another's granules
+    ("reduce", {"CL_CHAIN_WALK_REDUCE": "1"}),
+    ("granules", {"CL_CHAIN_WALK_REDUCE": "0"}),
 ]
 
 
@@ -46,7 +50,7 @@ def dense_input(gpu_ctx, tmp_path_factory):
 
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
-    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK"):
+    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
