@@ -945,7 +945,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 4     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 5     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1109,6 +1109,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
+    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
@@ -1633,6 +1634,29 @@ class Context:
         self._check(self.lib.cl_stitch_plan_create(self.handle, C.byref(bc), C.byref(params),
                                                    None if f is None else f.ctypes.data, C.byref(h)))
         return Plan(self, h, batch)
+
+    # ---- merge groups: one merge over several GPUs (cl_peer_api.cpp) ----
+    def peer_export(self):
+        """cl_context_peer_export: this context's handle (bytes) for the other members of a merge group"""
+        h = (C.c_ubyte * 128)()
+        self.lib.cl_context_peer_export.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.lib.cl_context_peer_export(self.handle, h))
+        return bytes(h)
+
+    def peer_group(self, members, my_index, epoch_base):
+        """cl_context_peer_group: members = every member's peer_export() in the group's order (own entry included); [] leaves the group"""
+        self.lib.cl_context_peer_group.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        if not members or len(members) <= 1:
+            self._check(self.lib.cl_context_peer_group(self.handle, 0, 0, None, 0))
+            return
+        buf = (C.c_ubyte * (128 * len(members))).from_buffer_copy(b"".join(members))
+        self._check(self.lib.cl_context_peer_group(self.handle, len(members), int(my_index), buf, int(epoch_base)))
+
+    def peer_stats(self):
+        st = (C.c_uint64 * 3)()
+        self.lib.cl_context_peer_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.lib.cl_context_peer_stats(self.handle, st))
+        return dict(shared_dps=int(st[0]), shared_far_launches=int(st[1]), merged_blocks=int(st[2]))
 
     def close(self):
         if self.handle:

@@ -91,6 +91,10 @@ constexpr int kFarBandShift = 16;   // shift buckets of 65536 by default (ClFarD
 // level + 2 dependent loads per node instead of the 6 .. 15 + 2 of a binary search.  All arrays live in ONE arena; the kernels keep the
 // table of their offsets in LDS (a lane picks its node's level at run time).
 constexpr int kFarTabWidth = 2 + 2 * kFarMaxLevels;   // words per level in ClFarDevice::tab
+constexpr uint32_t kPeerMaxMembers = 8;    // contexts that share the far pass of one merge
+constexpr uint32_t kPeerMaxCombos = 64;    // chain combinations of a DP whose far pass is shared (an inbox slot holds them all)
+constexpr uint32_t kPeerRing = 32;         // inbox slots: a member is never more than 2 * lag + 2 <= 18 macro-blocks ahead of another
+constexpr uint32_t kPeerSlotInts = kPeerMaxCombos * 1024u * 7u;   // (kChainMacro pairs per macro-block)
 
 struct ClFarDevice {
     uint32_t n_levels, r_pad;
@@ -108,6 +112,11 @@ struct ClFarDevice {
     double band_pen;             // least gap cost of a shift difference of one bucket width or more
     double slack_t0;             // rounding allowance of a bound: 2^-21 (|dp| + slack_t0 + slack_e0 |query shift| + |weight|)
     double slack_e0;
+    // far pass shared by the contexts of a merge group (one context per process / GPU, every member runs the same DP; cl_peer_api.cpp):
+    // this member bounds the queries of the combinations c = share_i + j * share_n only and stores what it finds — every query of those
+    // combinations, found or not — into the other members' inboxes as well ([combination][pair of the macro-block][7] encoded maxima)
+    uint32_t share_n, share_i;   // share_n <= 1: no sharing
+    int* peer_out[kPeerMaxMembers - 1];   // the block's slot in each other member's inbox (null: none)
 };
 
 #endif

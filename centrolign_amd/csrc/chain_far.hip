@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     __shared__ uint32_t s_tab[kFarMaxLevels * kFarTabWidth];
     if (threadIdx.x < kFarMaxLevels * kFarTabWidth) s_tab[threadIdx.x] = F.tab_dev[threadIdx.x];
     __syncthreads();
-    const uint32_t c = blockIdx.y;
+    const uint32_t c = F.share_n > 1 ? F.share_i + blockIdx.y * F.share_n : blockIdx.y;   // (a shared far pass: this member's combinations)
     const ClChainCombo cb = D.combos[c];
     const uint32_t sub = threadIdx.x & 7u;                       // lane within the query's group of eight
     const uint32_t grp = threadIdx.x >> 3;                       // group within the workgroup
@@ -351,7 +351,12 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         live = Q.qt != 0xFFFFFFFFu;
         if (live) { Q.qoff = cb.qoff[s]; Q.q = cb.q[s]; live = Q.qoff != 0; }
     }
-    if (!live) return;                                           // uniform over the group of eight
+    if (!live) {                                                 // uniform over the group of eight
+        if (F.share_n > 1 && sub < 7 && qi < count)               // the other members read every query of this combination: "nothing found"
+            for (uint32_t p = 0; p + 1 < F.share_n; ++p)
+                if (F.peer_out[p]) F.peer_out[p][((size_t)c * kChainMacro + qi) * 7 + sub] = enc(CL_CHAIN_NEG);
+        return;
+    }
     Q.w = D.weight[s];
     float best = D.init[s];
     int acc[7];
@@ -473,7 +478,24 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         v = max(v, __shfl_xor(v, 2));
         v = max(v, __shfl_xor(v, 4));
         if (sub == 0 && v > none) atomicMax(cb.acc + (size_t)s * 7 + k, v);
+        if (F.share_n > 1 && sub == 0)
+            for (uint32_t p = 0; p + 1 < F.share_n; ++p)
+                if (F.peer_out[p]) F.peer_out[p][((size_t)c * kChainMacro + qi) * 7 + k] = v;
     }
+    if (F.share_n > 1) __threadfence_system();   // the stores to the other devices are out before the stream's flag write that follows the kernel
+}
+
+// what the other members of the merge group found for the queries of THEIR combinations of this macro-block (the slot of this context's
+// inbox they stored into) joins this context's running maxima, in front of the walk of the macro-block
+__global__ void __launch_bounds__(256) far_merge_kernel(ClChainDevice D, const int* slot, uint32_t first, uint32_t count, uint32_t share_n, uint32_t share_i) {
+    const uint32_t c = blockIdx.y;
+    if (c % share_n == share_i) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t nk = D.sparse ? 1u : 7u;
+    if (i >= count * nk) return;
+    const uint32_t q = i / nk, k = i % nk;
+    const int v = slot[((size_t)c * kChainMacro + q) * 7 + k];
+    if (v > enc(CL_CHAIN_NEG)) atomicMax(D.combos[c].acc + (size_t)(first + q) * 7 + k, v);
 }
 
 }  // namespace
@@ -516,8 +538,15 @@ hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const
     return hipGetLastError();
 }
 
+hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t first, uint32_t count, uint32_t share_n, uint32_t share_i, hipStream_t stream) {
+    hipLaunchKernelGGL(far_merge_kernel, dim3((count * 7 + 255) / 256, D.n_combos), dim3(256), 0, stream, D, slot, first, count, share_n, share_i);
+    return hipGetLastError();
+}
+
 hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream) {
-    const dim3 grid((count + 31) / 32, D.n_combos);
+    const uint32_t mine = F.share_n > 1 ? (D.n_combos > F.share_i ? (D.n_combos - F.share_i + F.share_n - 1) / F.share_n : 0u) : D.n_combos;
+    if (mine == 0) return hipSuccess;
+    const dim3 grid((count + 31) / 32, mine);
     if (D.sparse) hipLaunchKernelGGL(far_prune_kernel<true>, grid, dim3(256), 0, stream, D, F, first, count, end_block);
     else hipLaunchKernelGGL(far_prune_kernel<false>, grid, dim3(256), 0, stream, D, F, first, count, end_block);
     return hipGetLastError();

@@ -830,6 +830,7 @@ void cl_context_destroy(cl_context* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     cl_pinned_release(ctx);
+    cl_peers_release(ctx);
     for (auto& ring : ctx->ev_ring) for (hipEvent_t e : ring) if (e) (void)hipEventDestroy(e);
     {
         std::lock_guard<std::mutex> lock(ctx->pool_mutex);

@@ -51,6 +51,7 @@ hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32
                                hipStream_t stream);
 hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, hipStream_t stream);
 hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream);
+hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t first, uint32_t count, uint32_t share_n, uint32_t share_i, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream);
 
@@ -318,6 +319,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     const ChainTimings before = tm;
     int rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, true);
     if (rc != kWalkStalled) return rc;
+    if (ctx->peers.n > 1) return CL_ERR_HIP;   // (inside a merge group the other members have gone on with this member's share: no second attempt)
     if (getenv("CL_CHAIN_TIMING")) fprintf(stderr, "[chain_dp_batch]   walk kernel stalled: repeating the DP on the per-block kernels\n");
     tm = before;
     rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, false);
@@ -1048,6 +1050,19 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         bool far_bb = use_far, far_decided = !use_far;
         static const char* far_mode_env = getenv("CL_CHAIN_FAR_MODE");   // A/B switch: "sweep" / "bb" pin the mode
         if (use_far && far_mode_env) { far_decided = true; far_bb = far_mode_env[0] != 's'; }
+        // A merge group (cl_peer_api.cpp) shares the far pass of this DP: every member takes the same decision from the same numbers — affine,
+        // 2 .. kPeerMaxCombos combinations, at least 16 macro-blocks — and the choice of far pass is not left to counts that differ by member
+        auto& peers = ctx->peers;
+        const bool shared = use_far && far_bb && peers.n > 1 && !sparse && combos.size() >= 2 && combos.size() <= kPeerMaxCombos && n_macro >= 16 &&
+                            !(far_mode_env && far_mode_env[0] == 's') && peers.epoch + 1 < (1u << 12);
+        uint32_t share_epoch = 0;
+        if (shared) {
+            far_decided = true;
+            share_epoch = ++peers.epoch;
+            ++peers.shared_dps;
+            F.share_n = peers.n;
+            F.share_i = peers.me;
+        }
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
             if (!far_decided && k >= 96 && (k & (k - 1)) == 0) {   // k = 128, 256, 512, ...
                 he = hipStreamSynchronize(ctx->stream);
@@ -1071,6 +1086,17 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     // CL_CHAIN_DEBUG_SKIP_FAR=1 (measurements only, WRONG RESULTS): the DP without its far launches = the serial walk / near chain alone,
                     // i.e. what a merge would cost its leader if other devices took the far pass off it
                     static const bool skip_far = getenv("CL_CHAIN_DEBUG_SKIP_FAR") != nullptr;
+                    if (shared) {
+                        // this member's combinations; what it finds goes into slot k of the others' inboxes, then its arrival word there
+                        ClFarDevice Fk = F;
+                        const uint32_t slot = k % kPeerRing, word = (share_epoch << 20) | (k + 1);
+                        uint32_t o = 0;
+                        for (uint32_t m = 0; m < peers.n; ++m) if (m != peers.me) Fk.peer_out[o++] = peers.peer_inbox[m] + (size_t)slot * kPeerSlotInts;
+                        if (he == hipSuccess) he = cl_chain_far_launch(D, Fk, first, count, near_lo, far_stream);
+                        for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m)
+                            if (m != peers.me) he = hipStreamWriteValue32(far_stream, peers.peer_flags[m] + (size_t)peers.me * kPeerRing + slot, word, 0);
+                        ++peers.shared_far_launches;
+                    } else
                     if (he == hipSuccess && !skip_far) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream);
                 } else if (use_far) {
                     // the all-pairs sweep has taken over (see the checkpoints below); same lag, so that sweeps run side by side
@@ -1096,6 +1122,14 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 he = cl_chain_launch_inter(Dn, first, count, near_lo, b0, max_recs(near_lo, b0) + Dn.lo_mask, kChainNearTile, ctx->stream);
             }
             if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
+            if (shared && near_lo > 0) {
+                // the other members' combinations of this macro-block: wait for their arrival words, fold their slot into the running maxima
+                const uint32_t slot = k % kPeerRing, word = (share_epoch << 20) | (k + 1);
+                for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m)
+                    if (m != peers.me) he = hipStreamWaitValue32(ctx->stream, peers.flags + (size_t)m * kPeerRing + slot, word, hipStreamWaitValueGte, 0xFFFFFFFFu);
+                if (he == hipSuccess) he = cl_chain_far_merge(D, peers.inbox + (size_t)slot * kPeerSlotInts, first, count, peers.n, peers.me, ctx->stream);
+                ++peers.merged_blocks;
+            }
             if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
             if (he == hipSuccess) he = cl_ring_event(ctx, 0, k, &ev_walk[k]);
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);

@@ -43,6 +43,17 @@ struct cl_context {
     // events the chaining DP records once per macro-block (walk done / far done / sealed): three rings, made once and reused — an event wait
     // refers to the record that precedes it, so a slot can be recorded again as soon as its waits have been enqueued (a few blocks later)
     hipEvent_t ev_ring[3][32] = {};
+    // the merge group this context shares the far pass of its chaining DPs with (cl_peer_api.cpp); n <= 1: none
+    struct Peers {
+        uint32_t n = 0, me = 0;
+        int* inbox = nullptr;          // [kPeerRing][kPeerSlotInts] what the others found, then [kPeerMaxMembers][kPeerRing] arrival words (one allocation, exported)
+        uint32_t* flags = nullptr;
+        int* peer_inbox[8] = {};       // the other members' inboxes and arrival words as this process sees them (index = member)
+        uint32_t* peer_flags[8] = {};
+        uint32_t epoch = 0;            // one per shared DP, the same on every member; arrival words hold epoch << 20 | macro-block + 1
+        uint64_t shared_dps = 0, shared_far_launches = 0, merged_blocks = 0;
+        std::vector<std::pair<std::string, void*>> opened;   // IPC handles this context has opened (kept until it is destroyed)
+    } peers;
     std::mutex pool_mutex;
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_size;
@@ -85,6 +96,7 @@ inline hipError_t cl_ring_event(cl_context* ctx, int kind, uint32_t k, hipEvent_
     return hipSuccess;
 }
 
+void cl_peers_release(cl_context* ctx);         // cl_peer_api.cpp
 bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not yet destroyed
 
 inline void cl_dev_free(cl_context* ctx, void* p) {

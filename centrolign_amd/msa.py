@@ -263,13 +263,27 @@ def _in_parallel(contexts, jobs):
 
 
 def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000,
-                                keep_merges=False, all_ranks=False, workers=1, make_context=None):
+                                keep_merges=False, all_ranks=False, workers=1, make_context=None, share_merges=0):
     """progressive_msa over `world` ranks; every rank calls it with the same arguments (its own ctx).  `group` must be a
     host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None — or, with
     all_ranks, their own dict (root None, stats of the merges they ran).  workers > 1: a rank that owns a whole subtree runs its
-    independent merges (and its share of the calibrations) side by side on that many contexts of its device, as progressive_msa does."""
+    independent merges (and its share of the calibrations) side by side on that many contexts of its device, as progressive_msa does.
+    share_merges = G > 1 (level 3): a merge whose children were built by different ranks is run by a MERGE GROUP of up to G of the
+    node's ranks (cl_peer_api.cpp): both children go to every member, every member runs the merge, and the far pass of its affine
+    chaining DP is divided between the members' devices by chain combination — peer stores into one another's memory, no collective."""
     import torch
     order = leaves_of(tree)
+    share_merges = int(share_merges) if hasattr(ctx, "peer_export") and world > 1 else 0
+    handles, merge_number = None, {}
+    if share_merges > 1:
+        handles = [None] * world
+        dist.all_gather_object(handles, ctx.peer_export(), group=group)
+
+        def number(t):   # internal nodes in post-order: the same on every rank, growing from a node to its ancestors (the epochs of cl_context_peer_group)
+            if not isinstance(t, str):
+                number(t[0]); number(t[1])
+                merge_number[newick(t)] = len(merge_number) + 1
+        number(tree)
     make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
     contexts = [ctx] + [make_context() for _ in range(max(1, int(workers)) - 1)]
     # level 1: leaf calibrations, round-robin; the scales meet by a SUM all-reduce of a vector that is zero except at the
@@ -338,6 +352,33 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
             return solve_local(t)
         left, right = split_ranks(t, ranks)
         g1, g2 = solve(t[0], left), solve(t[1], right)
+        combos = _count_leaves(t[0]) * _count_leaves(t[1])
+        if share_merges > 1 and 2 <= combos <= 64 and 16 * merge_number[newick(t)] + 16 < 4096:
+            members = [left[0], right[0]] + [r for r in ranks if r not in (left[0], right[0])][:share_merges - 2]
+            if rank not in members:
+                return None
+            # both children to every member (the two builders send; a graph is a few tens of MB of host arrays)
+            if rank == left[0]:
+                for m in members[1:]:
+                    send_graph(g1, m, dist, group)
+            else:
+                g1 = recv_graph(left[0], dist, group)
+            if rank == right[0]:
+                for m in members:
+                    if m != right[0]:
+                        send_graph(g2, m, dist, group)
+            else:
+                g2 = recv_graph(right[0], dist, group)
+            stats["graphs_received"] += (rank != left[0]) + (rank != right[0])
+            ctx.peer_group([handles[m] for m in members], members.index(rank), 16 * merge_number[newick(t)])
+            try:
+                r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
+            finally:
+                ctx.peer_group([], 0, 0)
+            stats["shared_merges"] = stats.get("shared_merges", 0) + 1
+            if rank != left[0]:
+                return None                      # (the members' results are the leader's, bit for bit; only the leader keeps and records it)
+            return record(r, g1, g2, t)
         if rank == right[0]:
             send_graph(g2, left[0], dist, group)
         if rank != left[0]:

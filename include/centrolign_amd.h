@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 4   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 5   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -136,6 +136,30 @@ cl_context* cl_context_create(int device_ordinal);
 void        cl_context_destroy(cl_context* ctx);
 const char* cl_last_error(const cl_context* ctx);
 const char* cl_device_name(const cl_context* ctx);
+
+/* ---- One merge over several GPUs: merge groups -----------------------------------------------------------------------------------
+ * (no counterpart in the single-threaded reference — the seam stays Core::align, include/centrolign/core.hpp:181-252.)
+ * The contexts of a merge group — one per process and device, up to CL_PEER_MAX_MEMBERS — are given the SAME two graphs and call the same
+ * cl_merge / cl_core_align / cl_anchor_chain.  Each runs the whole call; the far pass of the affine chaining DP (sparse_affine_chain_dp,
+ * include/centrolign/anchorer.hpp:2087-2416: the independent (chain of graph 1, chain of graph 2) tree sets) is divided between them by
+ * chain combination, and what a member finds goes straight into the other members' device memory (hipIpc-mapped; peer stores over xGMI),
+ * ordered by stream memory operations — no host round trip, no collective.  Every member returns the result of the single-context call,
+ * bit for bit.  Protocol: each member calls cl_context_peer_export once, the handles are exchanged by whatever transport the caller has
+ * (they are plain bytes), then every member calls cl_context_peer_group with the members' handles in the same order, its own index, and an
+ * epoch base that is the same on every member and grows from one group call to the next on every context (e.g. 16 x the merge's number in
+ * execution order: a merge shares at most a few DPs).  n_members <= 1 leaves the group.  DPs with fewer than 2 or more than 64 chain
+ * combinations, sparse (scale-estimate) DPs and short DPs are not shared.  A member that fails inside a shared DP leaves the others
+ * waiting: callers run members under a timeout. */
+#define CL_PEER_MAX_MEMBERS 8
+typedef struct cl_peer_handle { unsigned char bytes[128]; } cl_peer_handle;
+typedef struct cl_peer_stats {
+    uint64_t shared_dps;            /* chaining DPs whose far pass this context shared */
+    uint64_t shared_far_launches;   /* far launches it ran on its share of the combinations */
+    uint64_t merged_blocks;         /* macro-blocks whose other combinations came from the other members */
+} cl_peer_stats;
+int cl_context_peer_export(cl_context* ctx, cl_peer_handle* out);
+int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index, const cl_peer_handle* members, uint32_t epoch_base);
+int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out);
 
 /* po_poa<NumPW> for every problem of the batch; num_pw[k] in {1,2,3}. */
 int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw,

@@ -1,0 +1,86 @@
+"""GPU suite: one merge over several contexts (cl_peer_api.cpp).  The members of a merge group all run the same merge and
+share the far pass of its affine chaining DP by chain combination, storing what they find into one another's device memory; every member
+must return the single-context result.  Here on ONE device: two contexts in one process (two threads), and two processes (ranks of a gloo
+group started before any GPU call) running the distributed MSA driver with shared merges — the same code path N GPUs take, with peer
+stores that happen to stay on the device."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from centrolign_amd import capi, msa, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def two_plus_two(gpu_ctx, length=100000, seed=11):
+    seqs = synth.hor_sequences(seed, length, 4)
+    leaves = [capi.leaf_graph(s) for s in seqs]
+    scale = sum(gpu_ctx.leaf_intrinsic_scale(g) for g in leaves) / 4
+    left = gpu_ctx.merge(leaves[0], leaves[1], score_scale=scale)["fused"]
+    right = gpu_ctx.merge(leaves[2], leaves[3], score_scale=scale)["fused"]
+    return left, right, scale
+
+
+def test_two_contexts_share_the_far_pass_of_one_merge(gpu_ctx):
+    left, right, scale = two_plus_two(gpu_ctx)
+    want = gpu_ctx.merge(left, right, score_scale=scale)
+    assert want["align"]["chain_combinations"] == 4
+    members = [capi.Context(0), capi.Context(0)]
+    try:
+        handles = [c.peer_export() for c in members]
+        for rounds in range(2):                                   # a second merge of the same group: the epochs go on
+            for i, c in enumerate(members):
+                c.peer_group(handles, i, 16 * (rounds + 1))
+            got, errors = [None, None], []
+
+            def run(i):
+                try:
+                    got[i] = members[i].merge(left, right, score_scale=scale)
+                except Exception as e:   # noqa: BLE001
+                    errors.append(e)
+            threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+            [t.start() for t in threads]
+            [t.join(timeout=300) for t in threads]
+            assert not errors, errors
+            assert all(not t.is_alive() for t in threads), "a member is still waiting for the other"
+            for r in got:
+                assert capi.graphs_equal(r["fused"], want["fused"])
+                assert np.array_equal(r["alignment"], want["alignment"])
+        for c in members:
+            st = c.peer_stats()
+            assert st["shared_dps"] >= 2 and st["shared_far_launches"] > 100 and st["merged_blocks"] > 100, st
+        # out of the group again: an ordinary merge
+        st0 = members[0].peer_stats()
+        members[0].peer_group([], 0, 0)
+        assert capi.graphs_equal(members[0].merge(left, right, score_scale=scale)["fused"], want["fused"])
+        assert members[0].peer_stats() == st0
+    finally:
+        for c in members:
+            c.close()
+
+
+def test_two_ranks_on_one_device_print_the_reference_gfa(tmp_path):
+    """the distributed MSA driver with shared merges, two ranks (child processes under torch.distributed.run, gloo) on the one device: the
+    root merge of the ten-sequence golden (5 + 5 paths, 25 chain combinations) is run by both ranks as a merge group — IPC-mapped inboxes, stream memory operations —
+    and rank 0 prints the reference's GFA"""
+    import hashlib
+    import re
+    z = np.load(os.path.join(H.GOLDEN, "msa_text_big.npz"))
+    want = hashlib.sha256(bytes(z["msa10_30k.gfa"])).hexdigest()
+    port = 29500 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "merge_group_child.py"), "30000", "200000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = {int(m.group(1)): m for m in re.finditer(r"RANK (\d) shared_merges=(\d+) shared_dps=(\d+) far_launches=(\d+) merged_blocks=(\d+) sha=(\S+)", r.stdout)}
+    assert set(lines) == {0, 1}, r.stdout[-2000:]
+    for k in (0, 1):
+        assert int(lines[k].group(2)) == 1 and int(lines[k].group(3)) >= 1 and int(lines[k].group(4)) > 16 and int(lines[k].group(5)) > 16, lines[k].group(0)
+    assert lines[0].group(6) == want
