@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--length", type=int, default=1000000, help="sequence length (the headline is 1 000 000; smaller only for dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-skip", type=int, default=0, help="measurements only: CL_DEBUG_SKIP_TRACEBACK for the timed plans (1 no traceback, 3 no plane stores either); the line is then NOT a result")
+    ap.add_argument("--share-merges", type=int, default=4,
+                    help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
     args = ap.parse_args()
@@ -254,8 +256,10 @@ def main():
         host_group = None
     else:
         host_group = dist.new_group(backend="gloo") if not share else None
+        # merges whose children come from different ranks run as merge groups of up to --share-merges ranks (cl_peer_api.cpp): every member runs
+        # the merge, the far pass of its chaining DP is divided between the members' devices
         res = msa.progressive_msa_distributed(ctx, seqs, tree, dist, rank, world, group=host_group, keep_merges=True, all_ranks=True,
-                                              workers=args.workers)
+                                              workers=args.workers, share_merges=args.share_merges)
     msa_wall = time.perf_counter() - t0
     msa_wall = cd.max_over_ranks(msa_wall, dist, device="cpu" if share else "cuda")
     kept = res["stats"].get("kept", []) if res is not None and "stats" in res else []
@@ -342,8 +346,9 @@ def main():
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
                        "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes,
                        "workspace_bytes": int(sum(st.get("workspace_bytes", 0) for st in stats)),
+                       "merge_groups": None if world == 1 else (res["stats"].get("merge_groups") if res is not None and "stats" in res else None),
                        "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
-                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank), stitch batches on the rank that made them, no data-path collective; one merge still runs on one GPU, so msa_wall_s is bounded by the spine of the guide tree (DESIGN.md §5); no multi-GPU hardware curve has been measured by the builder" % (world, args.workers)},
+                                      "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank; merges across ranks run as merge groups of up to %d ranks: every member runs the merge, the far pass of its chaining DP is divided between their devices through peer stores, no collective), stitch batches on the rank that made them; msa_wall_s stays bounded by the serial walk of the spine's merges (DESIGN.md §5); no multi-GPU hardware curve has been measured by the builder (one-device runs of the multi-rank path only)" % (world, args.workers, args.share_merges)},
             "msa_wall_s": msa_wall,
             "msa": {"pipeline": "leaf graphs + 10 calibrations + 9 x (find_matches + Core::align + fuse) + write_gfa, no reference in the loop",
                     "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "score_scale": res["scale"],

@@ -1109,7 +1109,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
-    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats",
+    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
@@ -1651,6 +1651,11 @@ class Context:
             return
         buf = (C.c_ubyte * (128 * len(members))).from_buffer_copy(b"".join(members))
         self._check(self.lib.cl_context_peer_group(self.handle, len(members), int(my_index), buf, int(epoch_base)))
+
+    def peer_selftest(self, token, timeout_ms=5000):
+        """cl_context_peer_selftest: True when stores, arrival words and waits made it once round the current group"""
+        self.lib.cl_context_peer_selftest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        return self.lib.cl_context_peer_selftest(self.handle, int(token), int(timeout_ms)) == 0
 
     def peer_stats(self):
         st = (C.c_uint64 * 3)()

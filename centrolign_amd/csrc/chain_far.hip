@@ -538,6 +538,18 @@ hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const
     return hipGetLastError();
 }
 
+namespace {
+__global__ void peer_store_word_kernel(uint32_t* where, uint32_t value) {
+    *where = value;
+    __threadfence_system();
+}
+}
+// cl_context_peer_selftest: a kernel's store into (possibly another device's) memory
+hipError_t cl_peer_store_word(uint32_t* where, uint32_t value, hipStream_t stream) {
+    hipLaunchKernelGGL(peer_store_word_kernel, dim3(1), dim3(1), 0, stream, where, value);
+    return hipGetLastError();
+}
+
 hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t first, uint32_t count, uint32_t share_n, uint32_t share_i, hipStream_t stream) {
     hipLaunchKernelGGL(far_merge_kernel, dim3((count * 7 + 255) / 256, D.n_combos), dim3(256), 0, stream, D, slot, first, count, share_n, share_i);
     return hipGetLastError();

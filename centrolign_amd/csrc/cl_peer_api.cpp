@@ -15,10 +15,13 @@
 // Replaces nothing in the reference (it is single-threaded); the seam is still Core::align (core.hpp:181-252) through cl_merge.
 #include <unistd.h>
 
+#include <chrono>
 #include <cstring>
 
 #include "chain_device.h"
 #include "cl_internal.hpp"
+
+hipError_t cl_peer_store_word(uint32_t* where, uint32_t value, hipStream_t stream);   // chain_far.hip
 
 namespace {
 struct HandleBody {                 // what travels inside cl_peer_handle
@@ -32,6 +35,8 @@ static_assert(sizeof(HandleBody) <= sizeof(cl_peer_handle), "handle");
 constexpr uint32_t kMagic = 0x434C5045u;
 constexpr size_t kInboxInts = (size_t)kPeerRing * kPeerSlotInts;
 constexpr size_t kFlagWords = (size_t)kPeerMaxMembers * kPeerRing;
+constexpr size_t kTestWords = kPeerMaxMembers;   // behind the arrival words: one word per member for cl_context_peer_selftest
+constexpr size_t kTestInts = 8 * kPeerMaxMembers;   // the last ints of the inbox's last slot (beyond kPeerMaxCombos combinations nothing is stored there... see below)
 }
 
 extern "C" {
@@ -42,10 +47,10 @@ int cl_context_peer_export(cl_context* ctx, cl_peer_handle* out) {
     auto& P = ctx->peers;
     if (!P.inbox) {
         void* p = nullptr;
-        HIP_TRY(ctx, hipMalloc(&p, kInboxInts * sizeof(int) + kFlagWords * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(&p, kInboxInts * sizeof(int) + (kFlagWords + kTestWords + kTestInts) * sizeof(uint32_t)));
         P.inbox = static_cast<int*>(p);
         P.flags = reinterpret_cast<uint32_t*>(P.inbox + kInboxInts);
-        HIP_TRY(ctx, hipMemset(P.flags, 0, kFlagWords * sizeof(uint32_t)));   // arrival words start below every epoch
+        HIP_TRY(ctx, hipMemset(P.flags, 0, (kFlagWords + kTestWords + kTestInts) * sizeof(uint32_t)));   // arrival words start below every epoch
         HIP_TRY(ctx, hipDeviceSynchronize());
     }
     HandleBody h{};
@@ -88,6 +93,43 @@ int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index
     P.n = n_members;
     P.me = my_index;
     P.epoch = epoch_base;
+    return CL_OK;
+}
+
+// Every member of the current group calls this at the same time with the same token (> any earlier one): a kernel of this context stores the
+// token into a word of every other member's memory, the stream then raises this member's test word there, waits for the others' test words
+// here and reads back what their kernels stored.  CL_OK when everything arrived within timeout_ms — peer stores, stream memory operations and
+// their ordering work between these devices; CL_ERR_HIP otherwise (the context's stream may then be stuck behind a wait: destroy the context).
+int cl_context_peer_selftest(cl_context* ctx, uint32_t token, uint32_t timeout_ms) {
+    if (!ctx) return CL_ERR_INVALID_ARGUMENT;
+    auto& P = ctx->peers;
+    if (P.n <= 1) return CL_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    for (uint32_t m = 0; m < P.n; ++m) {
+        if (m == P.me) continue;
+        uint32_t* their_ints = P.peer_flags[m] + kFlagWords + kTestWords;
+        HIP_TRY(ctx, cl_peer_store_word(their_ints + 8 * P.me, token, s));                         // a kernel's store into the other device
+        HIP_TRY(ctx, hipStreamWriteValue32(s, P.peer_flags[m] + kFlagWords + P.me, token, 0));   // then the arrival word
+    }
+    for (uint32_t m = 0; m < P.n; ++m)
+        if (m != P.me) HIP_TRY(ctx, hipStreamWaitValue32(s, P.flags + kFlagWords + m, token, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    uint32_t* host = static_cast<uint32_t*>(cl_pinned(ctx, kTestInts * sizeof(uint32_t)));
+    if (!host) { cl_set_error(ctx, "cl_context_peer_selftest: no page-locked memory"); return CL_ERR_OUT_OF_MEMORY; }
+    HIP_TRY(ctx, hipMemcpyAsync(host, P.flags + kFlagWords + kTestWords, kTestInts * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    const auto t0 = std::chrono::steady_clock::now();
+    while (true) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { cl_set_error(ctx, "cl_context_peer_selftest: %s", hipGetErrorString(q)); return CL_ERR_HIP; }
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
+            cl_set_error(ctx, "cl_context_peer_selftest: the other members' arrival words did not come within %u ms", timeout_ms);
+            return CL_ERR_HIP;
+        }
+        usleep(200);
+    }
+    for (uint32_t m = 0; m < P.n; ++m)
+        if (m != P.me && host[8 * m] != token) { cl_set_error(ctx, "cl_context_peer_selftest: member %u's store did not arrive (%u instead of %u)", m, host[8 * m], token); return CL_ERR_HIP; }
     return CL_OK;
 }
 

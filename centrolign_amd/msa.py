@@ -263,7 +263,7 @@ def _in_parallel(contexts, jobs):
 
 
 def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000,
-                                keep_merges=False, all_ranks=False, workers=1, make_context=None, share_merges=0):
+                                keep_merges=False, all_ranks=False, workers=1, make_context=None, share_merges=0, min_shared_combos=9):
     """progressive_msa over `world` ranks; every rank calls it with the same arguments (its own ctx).  `group` must be a
     host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None — or, with
     all_ranks, their own dict (root None, stats of the merges they ran).  workers > 1: a rank that owns a whole subtree runs its
@@ -273,18 +273,33 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
     chaining DP is divided between the members' devices by chain combination — peer stores into one another's memory, no collective."""
     import torch
     order = leaves_of(tree)
+    make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
     share_merges = int(share_merges) if hasattr(ctx, "peer_export") and world > 1 else 0
-    handles, merge_number = None, {}
+    handles, merge_number, share_note = None, {}, None
     if share_merges > 1:
         handles = [None] * world
         dist.all_gather_object(handles, ctx.peer_export(), group=group)
+        # once round ALL ranks before anything depends on it: peer stores, stream memory operations and their order between these devices.
+        # Any rank that sees nothing within five seconds switches the whole job back to one rank per merge.
+        ok = torch.ones(1, dtype=torch.int32)
+        if world <= 8:
+            ctx.peer_group(handles, rank, 0)
+            ok[0] = 1 if ctx.peer_selftest(1) else 0
+            ctx.peer_group([], 0, 0)
+            if int(ok[0]) == 0:
+                ctx = make_context()   # (the old context's stream may be stuck behind a wait that nothing will satisfy: leave it alone)
+                handles = None
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        share_note = "merge groups of up to %d ranks" % share_merges
+        if int(ok[0]) == 0:
+            share_merges = 0
+            share_note = "merge groups OFF: the peer self-test failed on some rank"
 
         def number(t):   # internal nodes in post-order: the same on every rank, growing from a node to its ancestors (the epochs of cl_context_peer_group)
             if not isinstance(t, str):
                 number(t[0]); number(t[1])
                 merge_number[newick(t)] = len(merge_number) + 1
         number(tree)
-    make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
     contexts = [ctx] + [make_context() for _ in range(max(1, int(workers)) - 1)]
     # level 1: leaf calibrations, round-robin; the scales meet by a SUM all-reduce of a vector that is zero except at the
     # rank's own leaves (x + 0.0 is exact), and every rank takes the mean in leaf order like the reference (src/core.cpp:169-173)
@@ -300,6 +315,8 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
     scales = mine.tolist()
     scale = sum(scales) / len(scales)
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0, graphs_received=0)
+    if share_note:
+        stats["merge_groups"] = share_note
 
     def merge(g1, g2, t, c=None):
         r = (c or ctx).merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
@@ -353,7 +370,10 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
         left, right = split_ranks(t, ranks)
         g1, g2 = solve(t[0], left), solve(t[1], right)
         combos = _count_leaves(t[0]) * _count_leaves(t[1])
-        if share_merges > 1 and 2 <= combos <= 64 and 16 * merge_number[newick(t)] + 16 < 4096:
+        # (worth it from about nine combinations on: a far launch over one or two combinations is bound by the latency of a single query's
+        # search, not by how many queries it holds — 323 µs for one combination, ~900 µs for the 25 of a 5 + 5-path root — and every member
+        # needs both children's graphs)
+        if share_merges > 1 and min_shared_combos <= combos <= 64 and 16 * merge_number[newick(t)] + 16 < 4096:
             members = [left[0], right[0]] + [r for r in ranks if r not in (left[0], right[0])][:share_merges - 2]
             if rank not in members:
                 return None

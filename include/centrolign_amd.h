@@ -160,6 +160,10 @@ typedef struct cl_peer_stats {
 int cl_context_peer_export(cl_context* ctx, cl_peer_handle* out);
 int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index, const cl_peer_handle* members, uint32_t epoch_base);
 int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out);
+/* Every member of the current group at the same time, with the same token (greater than any earlier one): stores, arrival words and waits
+ * once round the group.  CL_OK when the mechanism works between these devices; on CL_ERR_HIP (nothing came within timeout_ms) destroy the
+ * context — its stream may be stuck behind a wait — and run merges on single contexts. */
+int cl_context_peer_selftest(cl_context* ctx, uint32_t token, uint32_t timeout_ms);
 
 /* po_poa<NumPW> for every problem of the batch; num_pw[k] in {1,2,3}. */
 int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw,
