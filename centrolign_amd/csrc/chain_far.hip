@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
 }
 
 // ---- the pass -------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kFarStack = 80;
+// stack entries per query: one round of cover nodes (<= W) + per level 7 more for each of the G entries opened per round (W + 21 G: 29 / 58 / 116)
+template <int G> struct FarStack { static constexpr uint32_t n = G == 1 ? 80u : G == 2 ? 96u : 160u; };
 constexpr uint32_t kFarCoverCache = 12;   // rounds of eight cover nodes whose bounds the probe leaves in LDS for the pass proper (96 nodes: 2.7 M records)
 
 struct FarQuery {
@@ -305,42 +306,59 @@ __device__ __forceinline__ float best_of(float best, const int (&acc)[7], const 
     return best;
 }
 
-// this lane's share of the next eight cover nodes of [0, p): aligned nodes, the nearest (smallest) first
-__device__ __forceinline__ void next_cover(uint32_t& p, uint32_t sub, uint32_t top, uint32_t& lvl, uint32_t& a) {
+// this lane's share of the next W cover nodes of [0, p) (lane li of the query's W): aligned nodes, the nearest (smallest) first
+template <int W>
+__device__ __forceinline__ void next_cover(uint32_t& p, uint32_t li, uint32_t top, uint32_t& lvl, uint32_t& a) {
     uint32_t pp = p;
     lvl = 0xFFu;
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
+    for (uint32_t j = 0; j < (uint32_t)W; ++j) {
         if (pp == 0) break;
         uint32_t l = (uint32_t)(__builtin_ctz(pp >> kFarLeafShift)) / kFarFanShift;
         if (l > top) l = top;
         const uint32_t nn = 1u << (kFarLeafShift + kFarFanShift * l);
-        if (j == sub) { lvl = l; a = pp - nn; }
+        if (j == li) { lvl = l; a = pp - nn; }
         pp -= nn;
     }
     p = pp;
 }
 
-// the node with the largest bound among the eight lanes of the group (ties: the smaller code), the same answer in every lane
+// the node with the largest bound among the W lanes of the query (ties: the smaller code), the same answer in every lane
+template <int W>
 __device__ __forceinline__ void group_argmax(double& b, uint32_t& code) {
 #pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
+    for (int m = 1; m < W; m <<= 1) {
         const double ob = __shfl_xor(b, m);
         const uint32_t oc = __shfl_xor(code, m);
         if (ob > b || (ob == b && oc < code)) { b = ob; code = oc; }
     }
 }
 
-template <bool SPARSE>
+template <int W>
+__device__ __forceinline__ float max_over_query(float x) {
+#pragma unroll
+    for (int m = 8; m < W; m <<= 1) x = fmaxf(x, __shfl_xor(x, m));
+    return x;
+}
+
+// G groups of eight lanes work on one query (W = 8 G lanes): the cover nodes are bounded W at a time, G stack entries are opened per round (eight
+// children each) and G surviving leaves are scanned side by side, each by one group of eight.  A query's search is a chain of dependent
+// loads — ≈ 140 of them with eight lanes, whatever the launch holds — so launches with few chain combinations (few queries) take more lanes
+// per query: the chain gets shorter and the device has the room.
+template <bool SPARSE, int G>
 __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDevice F, uint32_t first, uint32_t count, uint32_t end_block) {
+    constexpr int W = 8 * G;
+    constexpr uint32_t QPW = 256 / W;                            // queries per workgroup
     __shared__ uint32_t s_tab[kFarMaxLevels * kFarTabWidth];
     if (threadIdx.x < kFarMaxLevels * kFarTabWidth) s_tab[threadIdx.x] = F.tab_dev[threadIdx.x];
     __syncthreads();
     const uint32_t c = F.share_n > 1 ? F.share_i + blockIdx.y * F.share_n : blockIdx.y;   // (a shared far pass: this member's combinations)
     const ClChainCombo cb = D.combos[c];
-    const uint32_t sub = threadIdx.x & 7u;                       // lane within the query's group of eight
-    const uint32_t grp = threadIdx.x >> 3;                       // group within the workgroup
-    const uint32_t qi = blockIdx.x * 32 + grp;
+    const uint32_t sub = threadIdx.x & 7u;                       // lane within its group of eight
+    const uint32_t li = threadIdx.x & (W - 1u);                  // lane within the query's W
+    const uint32_t sg = li >> 3;                                 // group of eight within the query
+    const uint32_t grp = threadIdx.x / W;                        // query within the workgroup
+    const uint32_t qi = blockIdx.x * QPW + grp;
     const uint32_t s = first + qi;
     const uint32_t E = cb.prefix[end_block] & ~63u;              // records [0, E) are final, every node inside is sealed
     const int none = enc(CL_CHAIN_NEG);
@@ -351,10 +369,10 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         live = Q.qt != 0xFFFFFFFFu;
         if (live) { Q.qoff = cb.qoff[s]; Q.q = cb.q[s]; live = Q.qoff != 0; }
     }
-    if (!live) {                                                 // uniform over the group of eight
-        if (F.share_n > 1 && sub < 7 && qi < count)               // the other members read every query of this combination: "nothing found"
+    if (!live) {                                                 // uniform over the query's lanes
+        if (F.share_n > 1 && li < 7 && qi < count)                // the other members read every query of this combination: "nothing found"
             for (uint32_t p = 0; p + 1 < F.share_n; ++p)
-                if (F.peer_out[p]) F.peer_out[p][((size_t)c * kChainMacro + qi) * 7 + sub] = enc(CL_CHAIN_NEG);
+                if (F.peer_out[p]) F.peer_out[p][((size_t)c * kChainMacro + qi) * 7 + li] = enc(CL_CHAIN_NEG);
         return;
     }
     Q.w = D.weight[s];
@@ -376,11 +394,12 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     const long long qb = (long long)Q.q + (long long)F.sig_bias;
     Q.bq = qb < 0 ? 0xFFFF0000u : (uint32_t)(qb >> F.band_shift);
     const uint32_t top = F.n_levels - 1;
-    const uint32_t gsh = (threadIdx.x & 63u) & ~7u;             // where the group's eight lanes sit in a ballot
+    const uint32_t gsh = (threadIdx.x & 63u) & ~(uint32_t)(W - 1);   // where the query's W lanes sit in a ballot
+    const unsigned long long wmask = W == 64 ? ~0ull : ((1ull << W) - 1ull);
 
     // bounds of the cover nodes, computed once by the probe: they depend on the query alone, only what they are compared with changes
-    __shared__ double s_cover[32][kFarCoverCache][8];
-    uint32_t n_scanned = 0;
+    __shared__ double s_cover[QPW][kFarCoverCache][W];
+    uint32_t n_scanned = 0, probe_scans = 0;
     // ---- probe: follow the largest bound down to one leaf.  A query whose best predecessor lies far back (a pair on a distant
     //      diagonal chains from wherever the main chain passed its graph-2 position) would otherwise open every node between
     //      itself and that place before it knows what it is looking for.
@@ -390,31 +409,32 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         uint32_t p = E;
         for (uint32_t round = 0; p > 0; ++round) {
             uint32_t lvl, a = 0;
-            next_cover(p, sub, top, lvl, a);
+            next_cover<W>(p, li, top, lvl, a);
             if (lvl != 0xFFu) {
                 const double b = node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
-                if (round < kFarCoverCache) s_cover[grp][round][sub] = b;
+                if (round < kFarCoverCache) s_cover[grp][round][li] = b;
                 const uint32_t code = (lvl << 28) | (a >> kFarLeafShift);
                 if (b > pb || (b == pb && code < pcode)) { pb = b; pcode = code; }
             }
         }
-        group_argmax(pb, pcode);
+        group_argmax<W>(pb, pcode);
+        // the descent: the eight children of the best node, by the first group of eight (the others have nothing to add: one node, eight children)
         while (pcode != 0xFFFFFFFFu && (pcode >> 28) != 0 && pb > -HUGE_VAL) {
             const uint32_t lvl = (pcode >> 28) - 1;
             const uint32_t a = ((pcode & 0x0FFFFFFFu) << kFarLeafShift) + (sub << (kFarLeafShift + kFarFanShift * lvl));
-            pb = node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
-            pcode = (lvl << 28) | (a >> kFarLeafShift);
-            group_argmax(pb, pcode);
+            pb = sg == 0 ? node_bound<SPARSE>(F, s_tab, lvl, base + a, Q) : -HUGE_VAL;
+            pcode = sg == 0 ? (lvl << 28) | (a >> kFarLeafShift) : 0xFFFFFFFFu;
+            group_argmax<W>(pb, pcode);
         }
-        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL) {   // (uniform over the group)
-            scan_leaf<SPARSE>(rec, base + ((pcode & 0x0FFFFFFFu) << kFarLeafShift), sub, Q, acc);
-            best = best_of<SPARSE>(best, acc, Q, pen);
-            ++n_scanned;
+        if (pcode != 0xFFFFFFFFu && (pcode >> 28) == 0 && pb > -HUGE_VAL) {   // (uniform over the query's lanes)
+            if (sg == 0) scan_leaf<SPARSE>(rec, base + ((pcode & 0x0FFFFFFFu) << kFarLeafShift), sub, Q, acc);
+            best = max_over_query<W>(best_of<SPARSE>(best, acc, Q, pen));
+            ++probe_scans;
         }
     }
 
     // ---- the branch-and-bound proper, nearest nodes first
-    __shared__ uint32_t s_stack[32][kFarStack];
+    __shared__ uint32_t s_stack[QPW][FarStack<G>::n];
     volatile uint32_t* st = s_stack[grp];
     uint32_t sp = 0;
     uint32_t p = E;                                              // cover nodes still to hand out lie in [0, p)
@@ -424,61 +444,77 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
         uint32_t lvl = 0xFFu, a = 0;
         bool cached = false;
         if (sp > 0) {
-            const uint32_t e = st[sp - 1];
-            --sp;
-            lvl = (e >> 28) - 1;
-            a = ((e & 0x0FFFFFFFu) << kFarLeafShift) + ((7u - sub) << (kFarLeafShift + kFarFanShift * lvl));   // lane 0 takes the nearest child
+            // the top G entries, one per group of eight (the topmost — nearest — to the first group); a group without an entry sits the round out
+            const uint32_t take = sp < (uint32_t)G ? sp : (uint32_t)G;
+            if (sg < take) {
+                const uint32_t e = st[sp - 1 - sg];
+                lvl = (e >> 28) - 1;
+                a = ((e & 0x0FFFFFFFu) << kFarLeafShift) + ((7u - sub) << (kFarLeafShift + kFarFanShift * lvl));   // lane 0 takes the nearest child
+            }
+            sp -= take;
         } else if (p > 0) {
-            next_cover(p, sub, top, lvl, a);
+            next_cover<W>(p, li, top, lvl, a);
             cached = cover_round < kFarCoverCache;
             ++cover_round;
         } else {
             break;
         }
         double bnd = -HUGE_VAL;
-        if (lvl != 0xFFu) bnd = cached ? s_cover[grp][cover_round - 1][sub] : node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
+        if (lvl != 0xFFu) bnd = cached ? s_cover[grp][cover_round - 1][li] : node_bound<SPARSE>(F, s_tab, lvl, base + a, Q);
         bool hit = lvl != 0xFFu && bnd >= (double)best;
-        // surviving leaves, nearest (lane 0) first, by the eight lanes together; each is tested again against what the ones before it gave
-        uint32_t leaves = (uint32_t)(__ballot(hit && lvl == 0) >> gsh) & 0xFFu;
+        // surviving leaves, nearest (lane 0) first, G at a time — one per group of eight; each is tested again against what the rounds before gave
+        unsigned long long leaves = (__ballot(hit && lvl == 0) >> gsh) & wmask;
         while (leaves) {
-            const uint32_t j = (uint32_t)__builtin_ctz(leaves);
-            leaves &= leaves - 1;
-            const double bj = __shfl(bnd, (int)j, 8);
-            const uint32_t aj = __shfl(a, (int)j, 8);
-            if (bj >= (double)best) {
-                scan_leaf<SPARSE>(rec, base + aj, sub, Q, acc);
-                best = best_of<SPARSE>(best, acc, Q, pen);
-                ++n_scanned;
+            uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (!leaves) break;
+                const uint32_t j = (uint32_t)__builtin_ctzll(leaves);
+                leaves &= leaves - 1;
+                if ((uint32_t)g == sg) mine = j;
             }
+            const double bj = __shfl(bnd, (int)(mine & (W - 1)), W);
+            const uint32_t aj = __shfl(a, (int)(mine & (W - 1)), W);
+            const bool go = mine != 0xFFFFFFFFu && bj >= (double)best;
+            if (go) scan_leaf<SPARSE>(rec, base + aj, sub, Q, acc);
+            // (a group that scanned nothing brings its unchanged maxima: best_of is idempotent)
+            best = max_over_query<W>(best_of<SPARSE>(best, acc, Q, pen));
+            n_scanned += go && sub == 0 ? 1u : 0u;
         }
         // surviving inner nodes go on the stack, nearest (lane 0) on top
         const bool push = hit && lvl != 0 && bnd >= (double)best;
-        const uint32_t mask = (uint32_t)(__ballot(push) >> gsh) & 0xFFu;
+        const unsigned long long mask = (__ballot(push) >> gsh) & wmask;
         if (push) {
-            const uint32_t above = __popc(mask >> (sub + 1));    // surviving lanes farther than this one go below it
+            const uint32_t above = __popcll(mask >> (li + 1));   // surviving lanes farther than this one go below it
             st[sp + above] = (lvl << 28) | (a >> kFarLeafShift);
         }
-        sp += __popc(mask);
+        sp += __popcll(mask);
     }
     // bookkeeping for the host's choice between this pass and the all-pairs sweep (cl_chain_api.cpp): leaves this query scanned
     // against the leaves it had in range.  A scanned leaf costs about what sixteen leaves cost the sweep (divergent loads
     // instead of LDS broadcasts, plus the tests that led to it).
-    if (sub == 0) {
+    {
+        // total over the query: the probe's scan (the same in every lane) + what lane 0 of every group of eight counted in the pass proper
+        uint32_t tot = sub == 0 ? n_scanned : 0u;
+#pragma unroll
+        for (int m = 8; m < W; m <<= 1) tot += __shfl_xor(tot, m);
+        n_scanned = tot + probe_scans;
+    }
+    if (li == 0) {
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(D.status + 2);
         // only queries with a long history say anything about the trend (early ones open their few leaves whatever happens)
         const unsigned long long add_sc = E >= (1u << 16) ? n_scanned : 0u, add_in = E >= (1u << 16) ? (E >> kFarLeafShift) : 0u;
         if (add_in) { atomicAdd(cnt, add_sc); atomicAdd(cnt + 1, add_in); }
     }
-    // merge the eight lanes' maxima and hand them to the walk
+    // merge the lanes' maxima and hand them to the walk
     constexpr int NK = SPARSE ? 1 : 7;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         int v = acc[k];
-        v = max(v, __shfl_xor(v, 1));
-        v = max(v, __shfl_xor(v, 2));
-        v = max(v, __shfl_xor(v, 4));
-        if (sub == 0 && v > none) atomicMax(cb.acc + (size_t)s * 7 + k, v);
-        if (F.share_n > 1 && sub == 0)
+#pragma unroll
+        for (int m = 1; m < W; m <<= 1) v = max(v, __shfl_xor(v, m));
+        if (li == 0 && v > none) atomicMax(cb.acc + (size_t)s * 7 + k, v);
+        if (F.share_n > 1 && li == 0)
             for (uint32_t p = 0; p + 1 < F.share_n; ++p)
                 if (F.peer_out[p]) F.peer_out[p][((size_t)c * kChainMacro + qi) * 7 + k] = v;
     }
@@ -558,8 +594,18 @@ hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t 
 hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream) {
     const uint32_t mine = F.share_n > 1 ? (D.n_combos > F.share_i ? (D.n_combos - F.share_i + F.share_n - 1) / F.share_n : 0u) : D.n_combos;
     if (mine == 0) return hipSuccess;
-    const dim3 grid((count + 31) / 32, mine);
-    if (D.sparse) hipLaunchKernelGGL(far_prune_kernel<true>, grid, dim3(256), 0, stream, D, F, first, count, end_block);
-    else hipLaunchKernelGGL(far_prune_kernel<false>, grid, dim3(256), 0, stream, D, F, first, count, end_block);
+    // lanes per query (CL_CHAIN_FAR_LANES = 8 / 16 / 32 pins it): the fewer combinations a launch holds, the more lanes a query gets
+    static const int pinned = [] { const char* e = getenv("CL_CHAIN_FAR_LANES"); return e ? atoi(e) : 0; }();
+    // (10 x 1 Mbp, device time of a merge's two DPs with 8 / 16 / 32 lanes: 1 combination 348 / 303 / 293 ms, 4 combinations 583 / 512 / 476 ms, 25 combinations
+    // 1 193 / 1 115 / 1 090 ms)
+    const int lanes = pinned ? pinned : (mine <= 32 ? 32 : mine <= 128 ? 16 : 8);
+    const dim3 grid((count * (uint32_t)lanes + 255) / 256, mine);
+#define CL_FAR_LAUNCH(G) do { \
+        if (D.sparse) hipLaunchKernelGGL((far_prune_kernel<true, G>), grid, dim3(256), 0, stream, D, F, first, count, end_block); \
+        else hipLaunchKernelGGL((far_prune_kernel<false, G>), grid, dim3(256), 0, stream, D, F, first, count, end_block); } while (0)
+    if (lanes >= 32) CL_FAR_LAUNCH(4);
+    else if (lanes >= 16) CL_FAR_LAUNCH(2);
+    else CL_FAR_LAUNCH(1);
+#undef CL_FAR_LAUNCH
     return hipGetLastError();
 }
