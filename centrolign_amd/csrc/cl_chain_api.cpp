@@ -1018,6 +1018,28 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // consecutive far launches alternate between auxiliary streams: while their grids are small their latency floors overlap
     static const uint32_t far_streams = getenv("CL_CHAIN_FAR_STREAMS") ? std::min(4, std::max(1, atoi(getenv("CL_CHAIN_FAR_STREAMS")))) : kChainFarStreams;
     std::vector<hipEvent_t> ev_intra(n_blocks, nullptr), ev_far(n_blocks, nullptr);
+    // what the traceback's tie resolution needs of every combination — its records in (shift, slot) order with the implicit-heap layout of the
+    // reference's outer tree — depends on the records alone, not on the DP: built on the pool's threads while the device runs the DP (at the
+    // root of a ten-sequence tree the traceback spent 70 of its 166 ms building them on first use)
+    std::thread ortho_prebuild;
+    struct ThreadJoiner { std::thread& t; ~ThreadJoiner() { if (t.joinable()) t.join(); } } ortho_joiner{ortho_prebuild};
+    if (!sparse && K == 1 && M >= (1u << 16) && combos.size() > 1)
+        ortho_prebuild = std::thread([&] {
+            cl_parallel_for(combos.size(), [&](uint64_t b, uint64_t e) {
+                for (uint64_t ci = b; ci < e; ++ci) {
+                    Combo& c = combos[ci];
+                    Combo::SubRecs& sr = c.per_sub[0];
+                    sr.recs.resize(c.rec_s.size());
+                    std::iota(sr.recs.begin(), sr.recs.end(), 0u);
+                    sr.ortho_order = sr.recs;
+                    sort_by_key_then_slot(sr.ortho_order, M, [&](uint32_t r) { return (int64_t)c.sigma[r]; }, [&](uint32_t r) { return by_s[c.rec_s[r]]; });
+                    sr.ortho_heap = heap_of_rank(sr.ortho_order.size());
+                    sr.ortho_rank_of_heap.resize(sr.ortho_order.size());
+                    for (size_t r = 0; r < sr.ortho_order.size(); ++r) sr.ortho_rank_of_heap[sr.ortho_heap[r]] = (uint32_t)r;
+                    c.split_built = true;
+                }
+            }, 1);
+        });
     hipError_t he = hipEventRecord(ev0, ctx->stream);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
     for (uint32_t f = 0; f < far_streams && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
@@ -1230,6 +1252,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         }
     }
     if (he != hipSuccess) { cl_set_error(ctx, "download failed: %s", hipGetErrorString(he)); cleanup(); return CL_ERR_HIP; }
+    if (ortho_prebuild.joinable()) ortho_prebuild.join();
     lap("download");
     double t_split = 0, t_ortho = 0, t_diag = 0, t_gapfree = 0, t_cand = 0;   // CL_CHAIN_TIMING: where the traceback's time goes
     auto tnow = [] { return std::chrono::steady_clock::now(); };
