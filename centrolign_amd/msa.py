@@ -278,17 +278,25 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
     handles, merge_number, share_note = None, {}, None
     if share_merges > 1:
         handles = [None] * world
-        dist.all_gather_object(handles, ctx.peer_export(), group=group)
+        try:
+            mine = ctx.peer_export()
+        except capi.ClError:
+            mine = None                  # (no IPC export on this system: every rank will see the gap and go on without merge groups)
+        dist.all_gather_object(handles, mine, group=group)
         # once round ALL ranks before anything depends on it: peer stores, stream memory operations and their order between these devices.
         # Any rank that sees nothing within five seconds switches the whole job back to one rank per merge.
         ok = torch.ones(1, dtype=torch.int32)
-        if world <= 8:
-            ctx.peer_group(handles, rank, 0)
-            ok[0] = 1 if ctx.peer_selftest(1) else 0
-            ctx.peer_group([], 0, 0)
+        if any(h is None for h in handles):
+            ok[0] = 0
+        elif world <= 8:
+            try:
+                ctx.peer_group(handles, rank, 0)
+                ok[0] = 1 if ctx.peer_selftest(1) else 0
+                ctx.peer_group([], 0, 0)
+            except capi.ClError:
+                ok[0] = 0
             if int(ok[0]) == 0:
                 ctx = make_context()   # (the old context's stream may be stuck behind a wait that nothing will satisfy: leave it alone)
-                handles = None
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         share_note = "merge groups of up to %d ranks" % share_merges
         if int(ok[0]) == 0:
