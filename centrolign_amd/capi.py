@@ -474,6 +474,36 @@ def extract_stitch_batch(graph1, graph2, segments):
         lib.cl_owned_batch_free(h)
 
 
+def concat_stitch_batches(batches):
+    """the subproblems of several batches as ONE batch, in order (node ids inside a problem are local to it, so the flat arrays simply
+    follow one another with their offsets moved on): subproblems of different merges then share the plan's launches"""
+    sides = []
+    for si in (0, 1):
+        arrs = {k: [] for k in _SIDE_DTYPES}
+        base = {"node_off": 0, "prev_off": 0, "next_off": 0, "src_off": 0, "snk_off": 0}
+        have_next = all(b.side[si].next_off is not None for b in batches)
+        have_back = all(b.side[si].back_translation is not None for b in batches)
+        for i, b in enumerate(batches):
+            sd = b.side[si]
+            last = i + 1 == len(batches)
+            for off, idx in (("node_off", None), ("prev_off", "prev_idx"), ("next_off", "next_idx"), ("src_off", "src_idx"), ("snk_off", "snk_idx")):
+                if off == "next_off" and not have_next:
+                    continue
+                a = getattr(sd, off).astype(np.uint64)
+                arrs[off].append((a if last else a[:-1]) + np.uint64(base[off]))
+                base[off] += int(a[-1])
+                if idx:
+                    arrs[idx].append(getattr(sd, idx))
+            arrs["label"].append(sd.label)
+            if have_back:
+                arrs["back_translation"].append(sd.back_translation)
+        sides.append(GraphSide(**{k: (np.concatenate(v) if v else None) for k, v in arrs.items()}))
+    od = None
+    if all(b.only_deletion_alns is not None for b in batches):
+        od = np.concatenate([b.only_deletion_alns for b in batches])
+    return StitchBatch(sides[0], sides[1], od)
+
+
 class MatchSetsC(C.Structure):
     _fields_ = [("n_sets", C.c_uint64)] + [(n, C.c_void_p) for n in
                 ("set_off1", "walk_off1", "nodes1", "set_off2", "walk_off2", "nodes2", "count1", "count2", "full_length")]

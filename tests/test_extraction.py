@@ -51,3 +51,24 @@ def test_stitch_matches_reference(gpu_ctx, name):
     z, graphs, segs = load_stitch_case(name)
     got = gpu_ctx.stitch(graphs[0], graphs[1], segs)
     assert np.array_equal(got, z["stitched"].reshape(-1, 2))
+
+
+def test_concatenated_batches_hold_the_same_problems():
+    """capi.concat_stitch_batches: the subproblems of several batches as one batch (host only) — every problem keeps its nodes, edges, sources,
+    sinks, back-translation and only-deletion flag"""
+    cases = [load_stitch_case("stitch4_30k_merge%d.npz" % m) for m in (0, 2)]
+    batches = []
+    for _, graphs, seg in cases:
+        batches.append(capi.extract_stitch_batch(graphs[0], graphs[1], seg))
+    one = capi.concat_stitch_batches(batches)
+    assert one.n_problems == sum(b.n_problems for b in batches) and one.dp_cells() == sum(b.dp_cells() for b in batches)
+    at = 0
+    for b in batches:
+        for k in list(range(0, b.n_problems, max(1, b.n_problems // 40))) + [b.n_problems - 1]:
+            for si in (0, 1):
+                assert one.side[si].problem(at + k) == b.side[si].problem(k)
+                lo, hi = int(b.side[si].node_off[k]), int(b.side[si].node_off[k + 1])
+                lo1 = int(one.side[si].node_off[at + k])
+                assert np.array_equal(one.side[si].back_translation[lo1:lo1 + hi - lo], b.side[si].back_translation[lo:hi])
+            assert one.only_deletion_alns[at + k] == b.only_deletion_alns[k]
+        at += b.n_problems
