@@ -462,10 +462,19 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         cl_fasta_free(&fa);
         return code;
     };
-    for (uint64_t i = 0; i < plan.n_leaves; ++i) {
-        const uint64_t s = plan.leaf_sequence[i];
-        if ((rc = cl_leaf_graph(fa.sequences[s], fa.lengths[s], &graph[i]))) { cl_set_error(ctx, "sequence %s cannot be made into a graph", fa.names[s]); return fail(rc); }
-        paths[i].assign(1, s);
+    {   // the leaf graphs, side by side (25 ms each at 1 Mbp)
+        std::vector<int> leaf_rc(plan.n_leaves, CL_OK);
+        cl_parallel_for(plan.n_leaves, [&](uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                const uint64_t s = plan.leaf_sequence[i];
+                leaf_rc[i] = cl_leaf_graph(fa.sequences[s], fa.lengths[s], &graph[i]);
+            }
+        }, 1);
+        for (uint64_t i = 0; i < plan.n_leaves; ++i) {
+            const uint64_t s = plan.leaf_sequence[i];
+            if ((rc = leaf_rc[i])) { cl_set_error(ctx, "sequence %s cannot be made into a graph", fa.names[s]); return fail(rc); }
+            paths[i].assign(1, s);
+        }
     }
     cl_merge_params mp = params->merge;
     // worker contexts (n_workers > 1): the leaf calibrations, and every merge whose two children are there, run side by side, one thread per
