@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <unistd.h>
 #include <functional>
 #include <cmath>
 #include <cstdio>
@@ -1200,6 +1201,23 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     }
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     lap("enqueue (host)");
+    if (he == hipSuccess && ctx->peers.n > 1) {
+        // inside a merge group the serial stream waits for the other members' arrival words: a member that has failed would leave this
+        // call waiting for ever, so the wait is a poll with a limit (CL_PEER_TIMEOUT_S, default 600 s); past it the context is unusable
+        static const double limit_s = [] { const char* e = getenv("CL_PEER_TIMEOUT_S"); const double v = e ? atof(e) : 600.0; return v > 0 ? v : 600.0; }();
+        const auto t_wait = std::chrono::steady_clock::now();
+        while ((he = hipStreamQuery(ctx->stream)) == hipErrorNotReady) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > limit_s) {
+                (void)hipGetLastError();
+                cl_set_error(ctx, "chaining DP: the other members of the merge group did not deliver within %.0f s (a member failed?); this context cannot be used any more", limit_s);
+                for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
+                return CL_ERR_HIP;   // (device buffers of this DP are left to the stuck stream: releasing them would wait for it)
+            }
+            usleep(50);
+        }
+        if (he == hipErrorNotReady) he = hipSuccess;
+        (void)hipGetLastError();
+    }
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
     for (uint32_t f = 0; f < std::max<uint32_t>(far_streams, far_lag) && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
