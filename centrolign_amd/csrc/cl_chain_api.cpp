@@ -350,6 +350,36 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         const SetView ms(sb);
         sc[k].pair_lo = (uint32_t)pairs.size();
         if (sb.num_match_sets > sb.ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+        if (!sb.masked && sb.num_match_sets >= 4096) {
+            // (the usual case, no mask: every set's pairs have their place by a prefix sum over n1 * n2, the sets are filled in side by side)
+            const uint64_t ns = sb.num_match_sets;
+            std::vector<uint64_t> at(ns + 1, 0);
+            bool too_many = false;
+            for (uint64_t s = 0; s < ns; ++s) {
+                const uint64_t n1 = ms.n_walks(0, s), n2 = ms.n_walks(1, s);
+                too_many |= n1 >= 65535 || n2 >= 65535;
+                if (n1 && n2) min_len = std::min<uint64_t>(min_len, ms.length(s));
+                at[s + 1] = at[s] + n1 * n2;
+            }
+            if (too_many) { cl_set_error(ctx, "a match set has too many walks"); return CL_ERR_INVALID_ARGUMENT; }
+            const uint64_t base = pairs.size();
+            if (base + at[ns] >= (1ull << 31)) { cl_set_error(ctx, "too many match pairs"); return CL_ERR_INVALID_ARGUMENT; }
+            pairs.resize(base + at[ns]);
+            cl_parallel_for(ns, [&](uint64_t sb0, uint64_t se0) {
+                for (uint64_t s = sb0; s < se0; ++s) {
+                    const uint64_t n1 = ms.n_walks(0, s), n2 = ms.n_walks(1, s);
+                    Pair* out = pairs.data() + base + at[s];
+                    for (uint64_t j = 0; j < n1; ++j) {
+                        const uint64_t w1 = ms.walk(0, s, j);
+                        const uint32_t b1 = ms.front(0, w1), e1 = ms.back(0, w1);
+                        for (uint64_t q = 0; q < n2; ++q) {
+                            const uint64_t w2 = ms.walk(1, s, q);
+                            *out++ = Pair{(uint32_t)k, (uint32_t)s, (uint32_t)j, (uint32_t)q, b1, e1, ms.front(1, w2), ms.back(1, w2)};
+                        }
+                    }
+                }
+            }, 2048);
+        } else
         for (uint64_t s = 0; s < sb.num_match_sets; ++s) {
             const uint64_t n1 = ms.n_walks(0, s), n2 = ms.n_walks(1, s);
             if (n1 >= 65535 || n2 >= 65535) { cl_set_error(ctx, "match set %llu has too many walks", (unsigned long long)s); return CL_ERR_INVALID_ARGUMENT; }
@@ -1360,6 +1390,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             if (v > opt && v > sk.min_score) { opt = v; best_slot = slot; }
         }
         std::vector<uint32_t> chain_slots;
+        std::vector<std::pair<uint32_t, uint32_t>> edges;   // (scratch of the steps below)
+        std::vector<uint32_t> cand;
         uint64_t n_ties = 0;
         uint32_t here = best_slot;
         const uint32_t C1 = (uint32_t)sk.x[0]->chain_size(), C2 = (uint32_t)sk.x[1]->chain_size();
@@ -1372,7 +1404,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             const Pair& p = pairs[here];
             // the reference's candidate order: forward edges by the topological position of their source node, then chain1;
             // chain2 ascending; gap-free tree, then trees 0..5 (anchorer.hpp:2352-2413)
-            std::vector<std::pair<uint32_t, uint32_t>> edges;  // (position of from-node, p1)
+            edges.clear();                                      // (position of from-node, p1)
             for (uint32_t p1 = 0; p1 < C1; ++p1) {
                 const uint32_t pr = sk.x[0]->predecessor_index(p.b1, p1);
                 if (pr == kNone) continue;
@@ -1404,7 +1436,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             if (win_combo < 0) { cl_set_error(ctx, "traceback: no candidate reproduces dp of pair %u", here); cleanup(); return CL_ERR_HIP; }
             Combo& c = combos[win_combo];
             // every predecessor whose stored value equals the query's maximum and which lies in the query's range
-            std::vector<uint32_t> cand;
+            cand.clear();
             {
                 const auto t0 = tnow();
                 const int target = acc[win_combo][(size_t)s * 7 + win_kind];
