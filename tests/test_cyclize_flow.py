@@ -174,3 +174,25 @@ def test_cl_msa_with_cyclisation_prints_the_reference_gfa(gpu_ctx, tmp_path):
         got_r, st_r = gpu_ctx.msa(fasta, max_num_match_pairs=budget, cyclize=True, min_cyclizing_length=min_len, subproblems_prefix=prefix, restart=True)
         assert got_r == want and st_r["n_restarted"] >= 1 and st_r["n_bonds"] == st["n_bonds"]
         break   # (the second golden is covered step by step above; one end-to-end flow keeps the suite short)
+
+
+@pytest.mark.gpu
+def test_cl_msa_with_cyclisation_on_sixteen_sequences(gpu_ctx):
+    """a scaled BASELINE configs[4]: the -c flow on 16 sequences (six with a recent tandem duplication) over a balanced guide tree — merges of
+    up to 8 + 8 paths (64 chain combinations), 74 bonds, 455 polished regions — prints the GFA of the unmodified reference
+    (tests/golden/make_cyclize_wide.py; 1.8 minutes there), byte for byte, with worker contexts"""
+    import gzip
+    import hashlib
+    import json
+    from centrolign_amd import msa
+    gold = json.load(open(os.path.join(HERE, "golden", "cyclize_16x12k.json")))
+    seqs = synth.tandem_dup_sequences(41, 12000, 16, 4000, carriers=[0, 3, 5, 8, 9, 13], hor_div=0.08)
+    names = ["c%02d" % i for i in range(16)]
+    assert hashlib.sha256("".join(seqs).encode()).hexdigest() == gold["input_sha256"]
+    want = gzip.open(os.path.join(HERE, "golden", "cyclize_16x12k.gfa.gz")).read()
+    assert hashlib.sha256(want).hexdigest() == gold["gfa"]["sha256"]
+    fasta = "".join(">%s\n%s\n" % (a, b) for a, b in zip(names, seqs))
+    got, st = gpu_ctx.msa(fasta, newick=msa.newick(msa.balanced_tree(names)) + ";", max_num_match_pairs=gold["max_num_match_pairs"], cyclize=True,
+                          min_cyclizing_length=gold["min_cyclizing_length"], workers=4)
+    assert got == want
+    assert st["n_merges"] == 15 and st["n_bonds"] == 74 and st["n_polished_regions"] == 455
