@@ -97,6 +97,10 @@ inline hipError_t cl_ring_event(cl_context* ctx, int kind, uint32_t k, hipEvent_
 }
 
 void cl_peers_release(cl_context* ctx);         // cl_peer_api.cpp
+struct cl_polish_params;
+int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, const cl_base_graph* graph, const char* const* path_names, const char* newick,
+                                     const char* const* sequence_names, uint64_t n_sequences, const cl_merge_params* mp, const cl_polish_params* pp,
+                                     cl_owned_base_graph** out, uint64_t* n_regions_out);   // cl_polish_api.cpp
 bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not yet destroyed
 
 inline void cl_dev_free(cl_context* ctx, void* p) {

@@ -751,7 +751,7 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         for (uint64_t sq = 0; sq < fa.n_sequences; ++sq) sn.push_back(fa.names[sq]);
         cl_owned_base_graph* polished = nullptr;
         uint64_t n_regions = 0;
-        rc = cl_polish_cyclized_graph(ctx, &g, pn.data(), newick, sn.data(), sn.size(), &mp, &params->polish, &polished, &n_regions);
+        rc = cl_polish_cyclized_graph_workers(workers.data(), (unsigned)workers.size(), &g, pn.data(), newick, sn.data(), sn.size(), &mp, &params->polish, &polished, &n_regions);
         if (rc) return fail(rc);
         cl_owned_base_graph_free(graph[root]);
         graph[root] = polished;

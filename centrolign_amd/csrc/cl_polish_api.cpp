@@ -677,6 +677,18 @@ extern "C" {
 // realigned subgraphs put back in place of the old nodes (integrate_polished_subgraphs + purge_uncovered_nodes)
 int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const char* const* path_names, const char* newick, const char* const* sequence_names,
                              uint64_t n_sequences, const cl_merge_params* mp, const cl_polish_params* pp, cl_owned_base_graph** out, uint64_t* n_regions_out) {
+    return cl_polish_cyclized_graph_workers(&ctx, 1, graph, path_names, newick, sequence_names, n_sequences, mp, pp, out, n_regions_out);
+}
+
+}  // extern "C"
+
+// cl_polish_cyclized_graph with worker contexts (cl_msa hands over the contexts its merges ran on): the regions are realigned independently of
+// one another — the reference takes them one after the other, src/core.cpp:650-767 — so they are handed out to one thread per context; the
+// realigned subgraphs go back into the graph in region order afterwards, as in the reference
+int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, const cl_base_graph* graph, const char* const* path_names, const char* newick,
+                                     const char* const* sequence_names, uint64_t n_sequences, const cl_merge_params* mp, const cl_polish_params* pp,
+                                     cl_owned_base_graph** out, uint64_t* n_regions_out) {
+    cl_context* ctx = ctxs && n_ctx ? ctxs[0] : nullptr;
     if (!ctx || !graph || !path_names || !sequence_names || !mp || !pp || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     *out = nullptr;
     if (n_regions_out) *n_regions_out = 0;
@@ -706,13 +718,15 @@ int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const 
     ClGuideTreeView tree;
     std::string error;
     if ((rc = cl_processed_guide_tree(newick, sequence_names, n_sequences, tree, error))) { cl_set_error(ctx, "%s", error.c_str()); return rc; }
-    std::vector<Realigned> realigned;
+    std::vector<Realigned> realigned(regions.size());
     auto fail = [&](int code) { for (auto& r : realigned) cl_owned_base_graph_free(r.graph); return code; };
     cl_core_align_params ap = mp->align;
     ap.partition.score_boundaries = 1;
     static const char kDecode[] = "ACGTN";
     DebugDump dbg;
-    for (size_t ri = 0; ri < regions.size(); ++ri) {
+    auto realign_region = [&](cl_context* ctx, size_t ri) -> int {
+        int rc = CL_OK;
+        std::string error;
         const std::string rp = "region" + std::to_string(ri) + ".";
         std::map<uint64_t, std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> loc;
         for (auto it = st.begin(regions[ri].first); it != st.end(regions[ri].first); ++it) loc[it->first].first.push_back(it->second);
@@ -720,7 +734,7 @@ int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const 
         std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> intervals;
         std::vector<std::string> names, parents, seqs;
         for (auto& kv : loc) {
-            if (kv.second.first.size() != kv.second.second.size()) { cl_set_error(ctx, "Path starts or ends in the middle of a cycle realignment interval"); return fail(CL_ERR_INVALID_ARGUMENT); }
+            if (kv.second.first.size() != kv.second.second.size()) { cl_set_error(ctx, "Path starts or ends in the middle of a cycle realignment interval"); return CL_ERR_INVALID_ARGUMENT; }
             for (size_t k = 0; k < kv.second.first.size(); ++k) {
                 const uint64_t bg = kv.second.first[k], en = kv.second.second[k];
                 intervals.emplace_back(kv.first, bg, en);
@@ -735,12 +749,12 @@ int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const 
             }
         }
         std::string text;
-        if (!expanded_newick(tree, intervals, names, parents, text, error)) { cl_set_error(ctx, "%s", error.c_str()); return fail(CL_ERR_INVALID_ARGUMENT); }
+        if (!expanded_newick(tree, intervals, names, parents, text, error)) { cl_set_error(ctx, "%s", error.c_str()); return CL_ERR_INVALID_ARGUMENT; }
         if (dbg.f) { std::string all; for (const auto& nm : names) all += nm + "\n"; dbg.str(rp + "names", all); dbg.str(rp + "tree", text); }
         std::vector<const char*> name_ptr;
         for (const auto& nm : names) name_ptr.push_back(nm.c_str());
         cl_msa_plan plan;
-        if ((rc = cl_msa_plan_create(ctx, text.c_str(), name_ptr.data(), name_ptr.size(), &plan))) return fail(rc);
+        if ((rc = cl_msa_plan_create(ctx, text.c_str(), name_ptr.data(), name_ptr.size(), &plan))) return rc;
         const uint64_t n_slots = plan.n_leaves + plan.n_merges;
         std::vector<cl_owned_base_graph*> slot_graph(n_slots, nullptr);
         std::vector<SubPaths> slot_paths(n_slots);
@@ -786,13 +800,34 @@ int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const 
             cl_owned_base_graph_free(slot_graph[ia]); slot_graph[ia] = nullptr;
             cl_owned_base_graph_free(slot_graph[ib]); slot_graph[ib] = nullptr;
         }
-        if (rc) { drop(); return fail(rc); }
-        Realigned r;
-        r.graph = slot_graph[n_slots - 1];
+        if (rc) { drop(); return rc; }
+        realigned[ri].graph = slot_graph[n_slots - 1];
         slot_graph[n_slots - 1] = nullptr;
-        r.paths = slot_paths[n_slots - 1];
-        realigned.push_back(std::move(r));
+        realigned[ri].paths = slot_paths[n_slots - 1];
         drop();
+        return CL_OK;
+    };
+    const unsigned n_threads = dbg.f ? 1u : (unsigned)std::min<size_t>(std::max(1u, n_ctx), regions.size());   // (the debug dump is written in region order)
+    if (n_threads <= 1) {
+        for (size_t ri = 0; ri < regions.size(); ++ri)
+            if ((rc = realign_region(ctx, ri))) return fail(rc);
+    } else {
+        std::atomic<size_t> next{0};
+        std::atomic<int> first_rc{CL_OK};
+        std::vector<std::thread> threads;
+        for (unsigned t = 0; t < n_threads; ++t)
+            threads.emplace_back([&, t] {
+                (void)hipSetDevice(ctxs[t]->device);
+                for (size_t ri; first_rc.load() == CL_OK && (ri = next.fetch_add(1)) < regions.size();) {
+                    const int r = realign_region(ctxs[t], ri);
+                    if (r) {
+                        int expected = CL_OK;
+                        if (first_rc.compare_exchange_strong(expected, r) && ctxs[t] != ctx) cl_set_error(ctx, "%s", cl_last_error(ctxs[t]));
+                    }
+                }
+            });
+        for (auto& th : threads) th.join();
+        if ((rc = first_rc.load())) return fail(rc);
     }
     integrate(root, realigned);
     for (auto& r : realigned) cl_owned_base_graph_free(r.graph);
@@ -801,5 +836,3 @@ int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const 
     *out = result;
     return CL_OK;
 }
-
-}  // extern "C"
