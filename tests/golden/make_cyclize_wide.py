@@ -1,8 +1,8 @@
-"""Golden for the CLI's -c flow on MANY sequences (a scaled BASELINE configs[4]): 16 HOR arrays of ~12 kbp, six of them with a recent 4-kbp tandem
-duplication, balanced guide tree (root merge 8 + 8 paths = 64 chain combinations), -c with min_cyclizing_length 2 500 and 60 000 match
-pairs: the GFA the UNMODIFIED compiled reference prints (oracle/_ref/ref_cli), as text size + sha256 + the text itself (gzip).  1.8 minutes.
+"""Goldens for the CLI's -c flow on MANY sequences (BASELINE configs[4] scaled down): HOR arrays some of which carry a recent tandem duplication,
+balanced guide tree, -c with a small min_cyclizing_length and match-pair budget (CASES below): the GFA the UNMODIFIED compiled reference
+prints (oracle/_ref/ref_cli), as text size + sha256 + the text itself (gzip).
 
-usage (build container only):  python tests/golden/make_cyclize_wide.py [--from-dir DIR]   # DIR = an earlier run's directory (in.fa, out.gfa)
+usage (build container only):  python tests/golden/make_cyclize_wide.py CASE [--from-dir DIR]   # DIR = an earlier run's directory (in.fa, out.gfa)
 """
 import gzip
 import hashlib
@@ -16,19 +16,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-N, SEED, LENGTH, DUP, CARRIERS, HOR_DIV, MIN_LEN, BUDGET = 16, 41, 12000, 4000, [0, 3, 5, 8, 9, 13], 0.08, 2500, 60000
+CASES = {   # name: sequences, seed, length, duplicated bases, carriers, hor_div, min_cyclizing_length, max_num_match_pairs, name prefix, reference minutes
+    "cyclize_16x12k": (16, 41, 12000, 4000, [0, 3, 5, 8, 9, 13], 0.08, 2500, 60000, "c", 1.8),
+    # BASELINE configs[4]'s shape at small length: 50 sequences, root merge 25 + 25 paths = 625 chain combinations (beyond the walk kernel's 256: the
+    # per-block kernels), 133 bonds, 550 polished regions
+    "cyclize_50x8k": (50, 43, 8000, 3000, [1, 4, 7, 12, 18, 23, 29, 31, 36, 40, 44, 48], 0.08, 2000, 40000, "d", 5.1),
+}
 
 
-def workload():
+def workload(case):
     from centrolign_amd import msa, synth
-    seqs = synth.tandem_dup_sequences(SEED, LENGTH, N, DUP, carriers=CARRIERS, hor_div=HOR_DIV)
-    names = ["c%02d" % i for i in range(N)]
+    n, seed, length, dup, carriers, hor_div = CASES[case][:6]
+    seqs = synth.tandem_dup_sequences(seed, length, n, dup, carriers=carriers, hor_div=hor_div)
+    names = ["%s%02d" % (CASES[case][8], i) for i in range(n)]
     return names, seqs, msa.newick(msa.balanced_tree(names)) + ";"
 
 
 def main():
     from centrolign_amd import synth
-    names, seqs, newick = workload()
+    case = sys.argv[1]
+    n, seed, length, dup, carriers, hor_div, min_len, budget, prefix, minutes = CASES[case]
+    names, seqs, newick = workload(case)
     if "--from-dir" in sys.argv:
         d = sys.argv[sys.argv.index("--from-dir") + 1]
     else:
@@ -36,18 +44,18 @@ def main():
         synth.write_fasta(os.path.join(d, "in.fa"), seqs, names)
         open(os.path.join(d, "t.nwk"), "w").write(newick + "\n")
         subprocess.check_call(["bash", "-c", "cd %s && %s in.fa t.nwk - out.gfa 0 2 0 'b:cyclize_tandem_duplications=1;i:min_cyclizing_length=%d;i:max_num_match_pairs=%d' > ref.log 2>&1"
-                               % (d, os.path.join(ROOT, "oracle", "_ref", "ref_cli"), MIN_LEN, BUDGET)])
+                               % (d, os.path.join(ROOT, "oracle", "_ref", "ref_cli"), min_len, budget)])
     recs = open(os.path.join(d, "in.fa")).read().split(">")[1:]
     assert [r.split("\n", 1)[0] for r in recs] == names and ["".join(r.split("\n")[1:]) for r in recs] == list(seqs)
     gfa = open(os.path.join(d, "out.gfa"), "rb").read()
-    with open(os.path.join(HERE, "cyclize_16x12k.gfa.gz"), "wb") as f:
+    with open(os.path.join(HERE, case + ".gfa.gz"), "wb") as f:
         f.write(gzip.compress(gfa, 9, mtime=0))
-    out = {"workload": "tandem_dup_sequences(seed %d, %d, %d, dup %d, carriers %s, hor_div %g), names c00..c15, balanced tree" % (SEED, LENGTH, N, DUP, CARRIERS, HOR_DIV),
-           "newick": newick, "min_cyclizing_length": MIN_LEN, "max_num_match_pairs": BUDGET,
+    out = {"workload": "tandem_dup_sequences(seed %d, %d, %d, dup %d, carriers %s, hor_div %g), names %s00.., balanced tree" % (seed, length, n, dup, carriers, hor_div, prefix),
+           "newick": newick, "min_cyclizing_length": min_len, "max_num_match_pairs": budget,
            "input_sha256": hashlib.sha256("".join(seqs).encode()).hexdigest(),
-           "reference": "oracle/_ref/ref_cli -c (the unmodified reference), build container, 1 core, 1.8 minutes",
+           "reference": "oracle/_ref/ref_cli -c (the unmodified reference), build container, 1 core, %.1f minutes" % minutes,
            "gfa": {"sha256": hashlib.sha256(gfa).hexdigest(), "bytes": len(gfa)}}
-    with open(os.path.join(HERE, "cyclize_16x12k.json"), "w") as f:
+    with open(os.path.join(HERE, case + ".json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 

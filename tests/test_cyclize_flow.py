@@ -176,23 +176,32 @@ def test_cl_msa_with_cyclisation_prints_the_reference_gfa(gpu_ctx, tmp_path):
         break   # (the second golden is covered step by step above; one end-to-end flow keeps the suite short)
 
 
+WIDE = {   # tests/golden/make_cyclize_wide.py CASES: sequences, seed, length, duplicated bases, carriers, name prefix, merges, bonds, regions
+    "cyclize_16x12k": (16, 41, 12000, 4000, [0, 3, 5, 8, 9, 13], "c", 15, 74, 455),
+    "cyclize_50x8k": (50, 43, 8000, 3000, [1, 4, 7, 12, 18, 23, 29, 31, 36, 40, 44, 48], "d", 49, 133, 550),
+}
+
+
 @pytest.mark.gpu
-def test_cl_msa_with_cyclisation_on_sixteen_sequences(gpu_ctx):
-    """a scaled BASELINE configs[4]: the -c flow on 16 sequences (six with a recent tandem duplication) over a balanced guide tree — merges of
-    up to 8 + 8 paths (64 chain combinations), 74 bonds, 455 polished regions — prints the GFA of the unmodified reference
-    (tests/golden/make_cyclize_wide.py; 1.8 minutes there), byte for byte, with worker contexts"""
+@pytest.mark.parametrize("case", list(WIDE))
+def test_cl_msa_with_cyclisation_on_many_sequences(gpu_ctx, case):
+    """BASELINE configs[4] scaled down: the -c flow over a balanced guide tree on 16 sequences (merges up to 8 + 8 paths, 64 chain combinations)
+    and on 50 sequences (root merge 25 + 25 paths = 625 combinations: beyond the walk kernel, on the per-block kernels; 133 bonds, 550
+    polished regions realigned on the worker contexts) prints the GFA of the unmodified reference (tests/golden/make_cyclize_wide.py;
+    1.8 and 5.1 minutes there), byte for byte"""
     import gzip
     import hashlib
     import json
     from centrolign_amd import msa
-    gold = json.load(open(os.path.join(HERE, "golden", "cyclize_16x12k.json")))
-    seqs = synth.tandem_dup_sequences(41, 12000, 16, 4000, carriers=[0, 3, 5, 8, 9, 13], hor_div=0.08)
-    names = ["c%02d" % i for i in range(16)]
+    n, seed, length, dup, carriers, prefix, n_merges, n_bonds, n_regions = WIDE[case]
+    gold = json.load(open(os.path.join(HERE, "golden", case + ".json")))
+    seqs = synth.tandem_dup_sequences(seed, length, n, dup, carriers=carriers, hor_div=0.08)
+    names = ["%s%02d" % (prefix, i) for i in range(n)]
     assert hashlib.sha256("".join(seqs).encode()).hexdigest() == gold["input_sha256"]
-    want = gzip.open(os.path.join(HERE, "golden", "cyclize_16x12k.gfa.gz")).read()
+    want = gzip.open(os.path.join(HERE, "golden", case + ".gfa.gz")).read()
     assert hashlib.sha256(want).hexdigest() == gold["gfa"]["sha256"]
     fasta = "".join(">%s\n%s\n" % (a, b) for a, b in zip(names, seqs))
     got, st = gpu_ctx.msa(fasta, newick=msa.newick(msa.balanced_tree(names)) + ";", max_num_match_pairs=gold["max_num_match_pairs"], cyclize=True,
                           min_cyclizing_length=gold["min_cyclizing_length"], workers=4)
     assert got == want
-    assert st["n_merges"] == 15 and st["n_bonds"] == 74 and st["n_polished_regions"] == 455
+    assert st["n_merges"] == n_merges and st["n_bonds"] == n_bonds and st["n_polished_regions"] == n_regions
