@@ -629,12 +629,16 @@ namespace {
 
 void plan_free(cl_stitch_plan* pl) {
     if (!pl) return;
-    pl->d_desc.release();
+    // (one wait for the owning context's streams, then the sixteen blocks go back to its pool: cl_internal.hpp, cl_ctx_quiesce)
+    cl_context* owner = pl->d_desc.owner;
+    const bool q = owner && cl_context_live(owner);
+    if (q) cl_ctx_quiesce(owner);
+    pl->d_desc.release(q);
     for (int s = 0; s < 2; ++s) {
-        pl->d_lab[s].release(); pl->d_poff[s].release(); pl->d_pidx[s].release(); pl->d_snk[s].release();
+        pl->d_lab[s].release(q); pl->d_poff[s].release(q); pl->d_pidx[s].release(q); pl->d_snk[s].release(q);
     }
-    pl->d_planes.release(); pl->d_out_pairs.release(); pl->d_out_len.release(); pl->d_out_status.release();
-    pl->d_plist.release(); pl->d_out_score.release(); pl->d_aux.release();
+    pl->d_planes.release(q); pl->d_out_pairs.release(q); pl->d_out_len.release(q); pl->d_out_status.release(q);
+    pl->d_plist.release(q); pl->d_out_score.release(q); pl->d_aux.release(q);
     for (auto& g : pl->groups) {
         if (g.ev0) (void)hipEventDestroy(g.ev0);
         if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -1222,10 +1226,12 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
 
     // HBM
     pl->plist_host = plist;
-    if ((rc = pl->d_desc.upload(ctx, pl->desc)) || (rc = pl->d_plist.upload(ctx, plist)) || (rc = pl->d_aux.upload(ctx, sys_aux))) { plan_free(pl); return rc; }
+    // (the eleven copies are enqueued and waited for once: the host arrays live to the end of this function)
+    if ((rc = pl->d_desc.upload_async(ctx, pl->desc)) || (rc = pl->d_plist.upload_async(ctx, plist)) || (rc = pl->d_aux.upload_async(ctx, sys_aux))) { plan_free(pl); return rc; }
     for (int s = 0; s < 2; ++s)
-        if ((rc = pl->d_lab[s].upload(ctx, lab[s])) || (rc = pl->d_poff[s].upload(ctx, poff[s])) ||
-            (rc = pl->d_pidx[s].upload(ctx, pidx[s])) || (rc = pl->d_snk[s].upload(ctx, snk[s]))) { plan_free(pl); return rc; }
+        if ((rc = pl->d_lab[s].upload_async(ctx, lab[s])) || (rc = pl->d_poff[s].upload_async(ctx, poff[s])) ||
+            (rc = pl->d_pidx[s].upload_async(ctx, pidx[s])) || (rc = pl->d_snk[s].upload_async(ctx, snk[s]))) { plan_free(pl); return rc; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cl_set_error(ctx, "upload failed"); plan_free(pl); return CL_ERR_HIP; }
     if ((rc = pl->d_planes.alloc(ctx, plane_cursor)) || (rc = pl->d_out_pairs.alloc(ctx, out_cursor)) ||
         (rc = pl->d_out_len.alloc(ctx, pl->desc.size())) || (rc = pl->d_out_status.alloc(ctx, pl->desc.size())) ||
         (rc = pl->d_out_score.alloc(ctx, pl->desc.size()))) { plan_free(pl); return rc; }

@@ -196,9 +196,9 @@ struct Combo {
     };
     std::unordered_map<uint32_t, SubRecs> per_sub;
     bool split_built = false;
-    void release() {
-        d_rec_s.release(); d_ins_t.release(); d_off.release(); d_prefix.release(); d_qt.release(); d_qoff.release();
-        d_sigma.release(); d_q.release(); d_val.release(); d_acc.release(); d_own_rec.release();
+    void release(bool quiesced = false) {
+        d_rec_s.release(quiesced); d_ins_t.release(quiesced); d_off.release(quiesced); d_prefix.release(quiesced); d_qt.release(quiesced); d_qoff.release(quiesced);
+        d_sigma.release(quiesced); d_q.release(quiesced); d_val.release(quiesced); d_acc.release(quiesced); d_own_rec.release(quiesced);
     }
 };
 
@@ -771,21 +771,23 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     const bool use_walk = allow_walk && combos.size() <= kChainWalkMaxCombos && !old_walk_env;
     std::vector<ClChainCombo> hc(combos.size());
     auto cleanup = [&]() {
-        for (Combo& c : combos) c.release();
-        d_combos.release(); d_weight.release(); d_init.release(); d_dp.release(); d_rec_off.release(); d_rec_combo.release(); d_rec_pos.release(); d_group.release(); d_grp_base.release(); d_grp_total.release();
-        d_group_end.release(); d_status.release(); d_xch.release(); d_xred.release();
-        k_in.release(); k_out.release(); i_in.release(); i_out.release(); vtemp.release();
-        d_far_rec.release(); d_far_base.release(); d_seal_items.release(); d_far_temp.release();
-        for (auto& b : d_far_perm) b.release();
-        for (auto& b : d_far_u32) b.release();
-        d_far_arena.release(); d_far_tab.release();
+        cl_ctx_quiesce(ctx);   // once, for the ~40 blocks that go back to the pool below
+        for (Combo& c : combos) c.release(true);
+        d_combos.release(true); d_weight.release(true); d_init.release(true); d_dp.release(true); d_rec_off.release(true); d_rec_combo.release(true); d_rec_pos.release(true); d_group.release(true); d_grp_base.release(true); d_grp_total.release(true);
+        d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xred.release(true);
+        k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true);
+        d_far_rec.release(true); d_far_base.release(true); d_seal_items.release(true); d_far_temp.release(true);
+        for (auto& b : d_far_perm) b.release(true);
+        for (auto& b : d_far_u32) b.release(true);
+        d_far_arena.release(true); d_far_tab.release(true);
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
     for (size_t ci = 0; ci < combos.size(); ++ci) {
         Combo& c = combos[ci];
-        CH(c.d_rec_s.upload(ctx, c.rec_s)); CH(c.d_ins_t.upload(ctx, c.ins_t)); CH(c.d_off.upload(ctx, c.off));
-        CH(c.d_sigma.upload(ctx, c.sigma)); CH(c.d_prefix.upload(ctx, c.prefix));
-        CH(c.d_qt.upload(ctx, c.qt)); CH(c.d_qoff.upload(ctx, c.qoff)); CH(c.d_q.upload(ctx, c.q));
+        // (enqueued only: one wait for all of them below — a merge of small graphs used to spend most of its time in these round trips)
+        CH(c.d_rec_s.upload_async(ctx, c.rec_s)); CH(c.d_ins_t.upload_async(ctx, c.ins_t)); CH(c.d_off.upload_async(ctx, c.off));
+        CH(c.d_sigma.upload_async(ctx, c.sigma)); CH(c.d_prefix.upload_async(ctx, c.prefix));
+        CH(c.d_qt.upload_async(ctx, c.qt)); CH(c.d_qoff.upload_async(ctx, c.qoff)); CH(c.d_q.upload_async(ctx, c.q));
         CH(c.d_val.alloc(ctx, 7 * c.rec_s.size()));
         CH(c.d_acc.alloc(ctx, M * 7));
         if (hipMemsetD32Async((hipDeviceptr_t)c.d_acc.p, enc(CL_CHAIN_NEG), M * 7, ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetD32Async failed"); return CL_ERR_HIP; }
@@ -796,11 +798,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         hc[ci] = ClChainCombo{(uint32_t)c.rec_s.size(), c.d_rec_s.p, c.d_ins_t.p, c.d_off.p, c.d_sigma.p, c.d_val.p, c.d_prefix.p,
                               c.d_qt.p, c.d_qoff.p, c.d_q.p, c.d_acc.p, c.d_own_rec.p};
     }
-    CH(d_combos.upload(ctx, hc));
-    CH(d_weight.upload(ctx, weight));
-    CH(d_init.upload(ctx, init_w));
+    CH(d_combos.upload_async(ctx, hc));
+    CH(d_weight.upload_async(ctx, weight));
+    CH(d_init.upload_async(ctx, init_w));
     CH(d_dp.alloc(ctx, M));
-    CH(d_rec_off.upload(ctx, rec_off)); CH(d_rec_combo.upload(ctx, rec_combo)); CH(d_rec_pos.upload(ctx, rec_pos));
+    CH(d_rec_off.upload_async(ctx, rec_off)); CH(d_rec_combo.upload_async(ctx, rec_combo)); CH(d_rec_pos.upload_async(ctx, rec_pos));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP; }
     {
         // groups = maximal runs (in depth order) of pairs none of which can precede another: a predecessor m of m' ends
         // strictly before m' starts, so depth(b1(m')) >= depth(b1(m)) + len(m); a run is closed as soon as a pair starts at or

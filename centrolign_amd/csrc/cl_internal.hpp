@@ -103,13 +103,19 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
                                      cl_owned_base_graph** out, uint64_t* n_regions_out);   // cl_polish_api.cpp
 bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not yet destroyed
 
-inline void cl_dev_free(cl_context* ctx, void* p) {
+// every stream of the context has run dry: what cl_dev_free makes sure of before a block goes back to the pool.  A caller that releases dozens of
+// blocks at once (the end of a chaining DP: ~40 of them, each of which used to wait for all seven streams again — most of a small DP's time,
+// and a polishing step runs tens of thousands of small DPs) waits once and releases with quiesced = true.
+inline void cl_ctx_quiesce(cl_context* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < ctx->n_aux; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
+}
+inline void cl_dev_free(cl_context* ctx, void* p, bool quiesced = false) {
     if (!p) return;
     static const bool no_pool = getenv("CL_NO_POOL") != nullptr;
     if (no_pool || !ctx || !cl_context_live(ctx)) { (void)hipFree(p); return; }   // (a plan may outlive the context it was made on)
     // the block may be handed out again at once: wait for THIS context's streams (hipFree used to wait for the whole device)
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < ctx->n_aux; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
+    if (!quiesced) cl_ctx_quiesce(ctx);
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     auto it = ctx->pool_size.find(p);
     if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
@@ -212,8 +218,16 @@ struct DevBuf {
         if (!h.empty()) HIP_TRY(ctx, cl_copy_sync(ctx, p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
         return CL_OK;
     }
-    void release() {
-        if (p) cl_dev_free(owner, p);
+    // the copy is only enqueued: `h` must stay as it is until the caller has synchronised the context's stream
+    template <class Vec>
+    int upload_async(cl_context* ctx, const Vec& h) {
+        int rc = alloc(ctx, h.size());
+        if (rc) return rc;
+        if (!h.empty()) HIP_TRY(ctx, hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        return CL_OK;
+    }
+    void release(bool quiesced = false) {
+        if (p) cl_dev_free(owner, p, quiesced);
         p = nullptr;
         n = 0;
     }

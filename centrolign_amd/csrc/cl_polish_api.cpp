@@ -7,6 +7,7 @@
 // Host code (graph bookkeeping, as in the reference); the realignments themselves re-enter the hot path through cl_core_align.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <tuple>
 #include <deque>
@@ -724,6 +725,9 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
     ap.partition.score_boundaries = 1;
     static const char kDecode[] = "ACGTN";
     DebugDump dbg;
+    const bool timing = getenv("CL_POLISH_TIMING") != nullptr;   // (single worker: the sums are not atomic)
+    double t_induce = 0, t_align = 0, t_chain = 0, t_part = 0, t_stitch = 0;
+    uint64_t n_small_merges = 0;
     auto realign_region = [&](cl_context* ctx, size_t ri) -> int {
         int rc = CL_OK;
         std::string error;
@@ -774,7 +778,9 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
             l2[g2.src_id] = 7; l2[g2.snk_id] = 8;
             g1.label = l1.data();
             g2.label = l2.data();
+            const auto t_m0 = std::chrono::steady_clock::now();
             auto ms = induced_find_matches(a, hits[ri], g1, slot_paths[ia], g2, slot_paths[ib]);
+            const auto t_m1 = std::chrono::steady_clock::now();
             cl_match_sets view;
             cl_owned_match_sets_view(ms.get(), &view);
             if (dbg.f) {
@@ -790,6 +796,12 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
             }
             cl_core_align_result al;
             if ((rc = cl_core_align(ctx, &g1, &g2, &view, &ap, &al))) break;
+            if (timing) {
+                const auto t_m2 = std::chrono::steady_clock::now();
+                t_induce += std::chrono::duration<double, std::milli>(t_m1 - t_m0).count();
+                t_align += std::chrono::duration<double, std::milli>(t_m2 - t_m1).count();
+                t_chain += al.chain_ms; t_part += al.partition_ms; t_stitch += al.stitch_ms; ++n_small_merges;
+            }
             const uint64_t slot = plan.n_leaves + k;
             if (dbg.f) dbg.put(rp + "m" + std::to_string(k) + ".alignment", 2, al.alignment.pairs, 2 * al.alignment.n_pairs, 8);
             rc = cl_fuse(&g1, &g2, al.alignment.pairs, al.alignment.n_pairs, &slot_graph[slot]);
@@ -829,6 +841,8 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
         for (auto& th : threads) th.join();
         if ((rc = first_rc.load())) return fail(rc);
     }
+    if (timing) fprintf(stderr, "[cl_polish] %zu regions, %llu merges: induced matches %.0f ms, core_align %.0f ms (chain %.0f, partition %.0f, stitch %.0f)\n", regions.size(),
+                        (unsigned long long)n_small_merges, t_induce, t_align, t_chain, t_part, t_stitch);
     integrate(root, realigned);
     for (auto& r : realigned) cl_owned_base_graph_free(r.graph);
     cl_owned_base_graph* result = root.owned();
