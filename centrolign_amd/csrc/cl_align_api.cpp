@@ -51,6 +51,8 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
 ClPathMergeTables::ClPathMergeTables() : x1(new clhost::PathMergeTable()), x2(new clhost::PathMergeTable()) {}
 ClPathMergeTables::~ClPathMergeTables() { wait(); delete x1; delete x2; }
 void ClPathMergeTables::start(const cl_base_graph* g1, const cl_base_graph* g2) {
+    // (small graphs — the thousands of realignments of a polishing step — are done on the spot: a thread and a pool hand-off cost more than the tables)
+    if ((g1->n_nodes + 1) * (g1->n_paths + 1) + (g2->n_nodes + 1) * (g2->n_paths + 1) < (1u << 18)) { ok1 = x1->build(*g1); ok2 = x2->build(*g2); return; }
     builder = std::thread([this, g1, g2] { cl_pool_run(2, [&](unsigned t) { if (t) ok2 = x2->build(*g2); else ok1 = x1->build(*g1); }); });
 }
 void ClPathMergeTables::wait() { if (builder.joinable()) builder.join(); }

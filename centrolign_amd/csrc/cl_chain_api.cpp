@@ -1907,12 +1907,15 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     auto t_pre = now();
     PostSwitchTable sw1, sw2;
     PathsOfNode steps1, steps2;
-    cl_pool_run(4, [&](unsigned t) {
+    const bool small_graphs = (g1->n_nodes + 1) * (g1->n_paths + 1) + (g2->n_nodes + 1) * (g2->n_paths + 1) < (1u << 18);
+    cl_pool_run(small_graphs ? 1 : 4, [&](unsigned t0) {
+      for (unsigned t = t0; t < 4; t += small_graphs ? 1 : 4) {
         if (t == 0) sw1.build(*g1, x1);
         else if (t == 1) sw2.build(*g2, x2);
-        else if (!ap->do_fill_in_anchoring) return;
+        else if (!ap->do_fill_in_anchoring) continue;
         else if (t == 2) steps1.build(*g1);
         else steps2.build(*g2);
+      }
     });
     lap("post-switch tables, paths of nodes", t_pre);
     std::vector<uint64_t> cur(ms->n_sets);
