@@ -755,6 +755,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
     DevBuf<unsigned long long> d_xch;
+    DevBuf<char> d_pack;              // a small DP's arrays in one block (below)
+    size_t pack_dp_off = 0, pack_acc_stride = 0, pack_down_bytes = 0;
     DevBuf<uint32_t> d_xred;
     DevBuf<int> k_in, k_out;          // value index of the traceback (built on demand)
     DevBuf<uint32_t> i_in, i_out;
@@ -774,7 +776,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         cl_ctx_quiesce(ctx);   // once, for the ~40 blocks that go back to the pool below
         for (Combo& c : combos) c.release(true);
         d_combos.release(true); d_weight.release(true); d_init.release(true); d_dp.release(true); d_rec_off.release(true); d_rec_combo.release(true); d_rec_pos.release(true); d_group.release(true); d_grp_base.release(true); d_grp_total.release(true);
-        d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xred.release(true);
+        d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xred.release(true); d_pack.release(true);
         k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true);
         d_far_rec.release(true); d_far_base.release(true); d_seal_items.release(true); d_far_temp.release(true);
         for (auto& b : d_far_perm) b.release(true);
@@ -782,6 +784,58 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         d_far_arena.release(true); d_far_tab.release(true);
     };
 #define CH(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
+    // A SMALL DP (the thousands of realignments of a polishing step hold a few hundred match pairs each: 113 copies and 126 stream waits per merge,
+    // most of its time) packs every array below into ONE device block, filled on the host and sent with one copy; the DP values and every
+    // combination's query results lie together at its end and come back with one copy.  Large DPs keep an allocation and a copy per array.
+    size_t pack_total = 0;
+    auto reserve = [&](size_t bytes) { const size_t at = pack_total; pack_total += (bytes + 255) & ~(size_t)255; return at; };
+    struct PackOff { size_t rec_s, ins_t, off, sigma, prefix, qt, qoff, q, val, own, acc; };
+    std::vector<PackOff> po(combos.size());
+    for (size_t ci = 0; ci < combos.size(); ++ci) {
+        const Combo& c = combos[ci];
+        const size_t n = c.rec_s.size();
+        po[ci] = PackOff{reserve(n * 4), reserve(n * 4), reserve(n * 4), reserve(n * 4), reserve(c.prefix.size() * 4), reserve(M * 4), reserve(M * 4), reserve(M * 4),
+                         reserve(7 * n * 4), use_walk ? reserve(M * 4) : 0, 0};
+    }
+    const size_t o_combos = reserve(combos.size() * sizeof(ClChainCombo)), o_weight = reserve(M * 4), o_init = reserve(M * 4), o_rec_off = reserve((M + 1) * 4),
+                 o_rec_combo = reserve(rec_combo.size() * 4), o_rec_pos = reserve(rec_pos.size() * 4);
+    const size_t o_dp = reserve(M * 4);
+    for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].acc = reserve(M * 7 * 4);
+    const bool packed = pack_total <= (2u << 20) && !combos.empty();
+    if (packed) {
+        CH(d_pack.alloc(ctx, pack_total));
+        char* dev = d_pack.p;
+        std::vector<char> stage(pack_total);
+        auto put = [&](size_t at, const void* src, size_t bytes) { if (bytes) memcpy(stage.data() + at, src, bytes); };
+        for (size_t ci = 0; ci < combos.size(); ++ci) {
+            Combo& c = combos[ci];
+            const size_t n = c.rec_s.size();
+            const PackOff& o = po[ci];
+            put(o.rec_s, c.rec_s.data(), n * 4); put(o.ins_t, c.ins_t.data(), n * 4); put(o.off, c.off.data(), n * 4); put(o.sigma, c.sigma.data(), n * 4);
+            put(o.prefix, c.prefix.data(), c.prefix.size() * 4); put(o.qt, c.qt.data(), M * 4); put(o.qoff, c.qoff.data(), M * 4); put(o.q, c.q.data(), M * 4);
+            if (use_walk) memset(stage.data() + o.own, 0xFF, M * 4);
+            int* a = reinterpret_cast<int*>(stage.data() + o.acc);
+            for (size_t i = 0; i < (size_t)M * 7; ++i) a[i] = enc(CL_CHAIN_NEG);
+            c.d_rec_s.view((uint32_t*)(dev + o.rec_s), n); c.d_ins_t.view((uint32_t*)(dev + o.ins_t), n); c.d_off.view((uint32_t*)(dev + o.off), n);
+            c.d_sigma.view((int32_t*)(dev + o.sigma), n); c.d_prefix.view((uint32_t*)(dev + o.prefix), c.prefix.size());
+            c.d_qt.view((uint32_t*)(dev + o.qt), M); c.d_qoff.view((uint32_t*)(dev + o.qoff), M); c.d_q.view((int32_t*)(dev + o.q), M);
+            c.d_val.view((float*)(dev + o.val), 7 * n); c.d_acc.view((int*)(dev + o.acc), (size_t)M * 7);
+            if (use_walk) c.d_own_rec.view((uint32_t*)(dev + o.own), M);
+            hc[ci] = ClChainCombo{(uint32_t)n, c.d_rec_s.p, c.d_ins_t.p, c.d_off.p, c.d_sigma.p, c.d_val.p, c.d_prefix.p,
+                                  c.d_qt.p, c.d_qoff.p, c.d_q.p, c.d_acc.p, c.d_own_rec.p};
+        }
+        put(o_combos, hc.data(), hc.size() * sizeof(ClChainCombo)); put(o_weight, weight.data(), M * 4); put(o_init, init_w.data(), M * 4);
+        put(o_rec_off, rec_off.data(), (M + 1) * 4); put(o_rec_combo, rec_combo.data(), rec_combo.size() * 4); put(o_rec_pos, rec_pos.data(), rec_pos.size() * 4);
+        d_combos.view((ClChainCombo*)(dev + o_combos), hc.size()); d_weight.view((float*)(dev + o_weight), M); d_init.view((float*)(dev + o_init), M);
+        d_dp.view((float*)(dev + o_dp), M);
+        d_rec_off.view((uint32_t*)(dev + o_rec_off), M + 1); d_rec_combo.view((uint32_t*)(dev + o_rec_combo), rec_combo.size()); d_rec_pos.view((uint32_t*)(dev + o_rec_pos), rec_pos.size());
+        pack_dp_off = o_dp;
+        pack_acc_stride = combos.size() > 1 ? po[1].acc - po[0].acc : (((size_t)M * 7 * 4 + 255) & ~(size_t)255);
+        pack_down_bytes = pack_total - o_dp;
+        if (hipMemcpyAsync(dev, stage.data(), pack_total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP;
+        }
+    } else {
     for (size_t ci = 0; ci < combos.size(); ++ci) {
         Combo& c = combos[ci];
         // (enqueued only: one wait for all of them below — a merge of small graphs used to spend most of its time in these round trips)
@@ -804,6 +858,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     CH(d_dp.alloc(ctx, M));
     CH(d_rec_off.upload_async(ctx, rec_off)); CH(d_rec_combo.upload_async(ctx, rec_combo)); CH(d_rec_pos.upload_async(ctx, rec_pos));
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP; }
+    }
     {
         // groups = maximal runs (in depth order) of pairs none of which can precede another: a predecessor m of m' ends
         // strictly before m' starts, so depth(b1(m')) >= depth(b1(m)) + len(m); a run is closed as soon as a pair starts at or
@@ -1279,12 +1334,23 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
 
     lap("sync");
     std::vector<float> dp_sorted(M);
+    std::vector<std::vector<int>> acc_own;
+    std::vector<const int*> acc(combos.size(), nullptr);
+    std::vector<char> pack_host;
+    if (d_pack.p) {
+        // a small DP: its DP values and query results lie together at the end of the block
+        pack_host.resize(pack_down_bytes);
+        he = cl_copy_sync(ctx, pack_host.data(), d_pack.p + pack_dp_off, pack_down_bytes, hipMemcpyDeviceToHost);
+        if (he == hipSuccess) {
+            memcpy(dp_sorted.data(), pack_host.data(), M * sizeof(float));
+            const size_t first_acc = (size_t)((char*)combos[0].d_acc.p - d_pack.p) - pack_dp_off;
+            for (size_t ci = 0; ci < combos.size(); ++ci) acc[ci] = reinterpret_cast<const int*>(pack_host.data() + first_acc + ci * pack_acc_stride);
+        }
+    } else
     he = cl_copy_sync(ctx, dp_sorted.data(), d_dp.p, M * sizeof(float), hipMemcpyDeviceToHost);
     // the stored query results of every combination (7 per pair): into the context's page-locked area when it can be had — 35 MB per
     // combination at 1.25 M pairs, 25 combinations at the root of a 10-sequence tree
-    std::vector<std::vector<int>> acc_own;
-    std::vector<const int*> acc(combos.size(), nullptr);
-    if (he == hipSuccess) {
+    if (he == hipSuccess && !d_pack.p) {
         const size_t per = (size_t)M * 7;
         int* pin = (int*)cl_pinned(ctx, combos.size() * per * sizeof(int));
         if (pin) {

@@ -203,6 +203,8 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     cl_context* owner = nullptr;
+    bool is_view = false;   // p lies inside another DevBuf's block (small chaining DPs pack all their arrays into one): nothing to release
+    void view(T* at, size_t count) { release(); p = at; n = count; is_view = true; }
     int alloc(cl_context* ctx, size_t count) {
         release();
         n = count;
@@ -227,9 +229,10 @@ struct DevBuf {
         return CL_OK;
     }
     void release(bool quiesced = false) {
-        if (p) cl_dev_free(owner, p, quiesced);
+        if (p && !is_view) cl_dev_free(owner, p, quiesced);
         p = nullptr;
         n = 0;
+        is_view = false;
     }
 };
 
