@@ -795,11 +795,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         const Combo& c = combos[ci];
         const size_t n = c.rec_s.size();
         po[ci] = PackOff{reserve(n * 4), reserve(n * 4), reserve(n * 4), reserve(n * 4), reserve(c.prefix.size() * 4), reserve(M * 4), reserve(M * 4), reserve(M * 4),
-                         reserve(7 * n * 4), use_walk ? reserve(M * 4) : 0, 0};
+                         0, use_walk ? reserve(M * 4) : 0, 0};
     }
     const size_t o_combos = reserve(combos.size() * sizeof(ClChainCombo)), o_weight = reserve(M * 4), o_init = reserve(M * 4), o_rec_off = reserve((M + 1) * 4),
                  o_rec_combo = reserve(rec_combo.size() * 4), o_rec_pos = reserve(rec_pos.size() * 4);
-    const size_t o_dp = reserve(M * 4);
+    const size_t o_dp = reserve(M * 4);   // what comes back: the DP values, every combination's stored values (the traceback's value index) and query results
+    for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].val = reserve(7 * combos[ci].rec_s.size() * 4);
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].acc = reserve(M * 7 * 4);
     const bool packed = pack_total <= (2u << 20) && !combos.empty();
     if (packed) {
@@ -894,16 +895,17 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             for (size_t g = 0; g < hist.size(); ++g) if (hist[g]) fprintf(stderr, " %zu:%u", g, hist[g]);
             fprintf(stderr, "\n");
         }
-        CH(d_group.upload(ctx, group));
+        CH(d_group.upload_async(ctx, group));       // (these four copies are waited for together at the end of the block)
+        std::vector<uint32_t> group_end;
         if (use_walk) {
-            std::vector<uint32_t> group_end(M);
+            group_end.resize(M);
             for (uint64_t s1 = M; s1 > 0;) {
                 uint64_t s0 = s1 - 1;
                 while (s0 > 0 && group[s0 - 1] == group[s1 - 1]) --s0;
                 for (uint64_t s = s0; s < s1; ++s) group_end[s] = (uint32_t)s1;
                 s1 = s0;
             }
-            CH(d_group_end.upload(ctx, group_end));
+            CH(d_group_end.upload_async(ctx, group_end));
             CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
             CH(d_status.alloc(ctx, 8));
             if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
@@ -926,8 +928,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             for (uint64_t s = s0; s < s1; ++s) { grp_base[s] = rec_off[s] - rec_off[s0]; grp_total[s] = total; }
             s0 = s1;
         }
-        CH(d_grp_base.upload(ctx, grp_base));
-        CH(d_grp_total.upload(ctx, grp_total));
+        CH(d_grp_base.upload_async(ctx, grp_base));
+        CH(d_grp_total.upload_async(ctx, grp_total));
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP; }
     }
     ClChainDevice D{};
     D.n_pairs = (uint32_t)M;
@@ -1396,6 +1399,21 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         if (vbuilt[ci][kind]) return true;
         const auto t = std::chrono::steady_clock::now();
         const uint32_t n = (uint32_t)combos[ci].rec_s.size();
+        if (d_pack.p) {
+            // a small DP: the stored values came back with the DP values; the same order as the device's stable radix sort
+            const float* val = reinterpret_cast<const float*>(pack_host.data() + ((char*)combos[ci].d_val.p - d_pack.p - pack_dp_off)) + (size_t)kind * n;
+            auto& recs = vrecs[ci][kind];
+            recs.resize(n);
+            std::iota(recs.begin(), recs.end(), 0u);
+            std::vector<int> key(n);
+            for (uint32_t r = 0; r < n; ++r) key[r] = enc(val[r]);
+            std::stable_sort(recs.begin(), recs.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+            vkeys[ci][kind].resize(n);
+            for (uint32_t i = 0; i < n; ++i) vkeys[ci][kind][i] = key[recs[i]];
+            index_ms += ms_since(t);
+            vbuilt[ci][kind] = 1;
+            return true;
+        }
         hipError_t e = cl_chain_sort_values(combos[ci].d_val.p + (size_t)kind * n, n, k_in.p, i_in.p, k_out.p, i_out.p, vtemp.p, &vtemp_bytes, ctx->stream);
         vkeys[ci][kind].resize(n);
         vrecs[ci][kind].resize(n);
