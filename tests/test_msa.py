@@ -116,21 +116,27 @@ def test_gpu_cl_msa_ten_sequences(gpu_ctx):
     assert text4 == text and st4["n_merges"] == 9
 
 
+WIDE = {"wide_merge_24x7k": (24, 91, 7000, "q"), "wide_merge_50x5k": (50, 92, 5000, "r")}   # tests/golden/make_wide_merge.py CASES
+
+
 @pytest.mark.gpu
-def test_gpu_wide_merge_24_sequences(gpu_ctx):
-    """24 sequences of 7 kbp over a balanced tree: the root merge pairs 12 + 12 paths = 144 chain combinations, more than one walk launch
-    of the chaining DP takes (96; the rest go through the per-block path, cl_chain_api.cpp).  The GFA is the one the unmodified reference
-    printed (tests/golden/make_wide_merge.py, 26 CPU-minutes there), byte for byte, with one worker and with four"""
+@pytest.mark.parametrize("case", list(WIDE))
+def test_gpu_wide_merges(gpu_ctx, case):
+    """sequences over a balanced tree whose root merge pairs 12 + 12 paths = 144 chain combinations (the walk kernel with its reduction exchange,
+    cl_chain_api.cpp) and 25 + 25 paths = 625 (beyond the walk kernel's 256: the per-block kernels) — BASELINE configs[4]'s width at small
+    length.  The GFA is the one the unmodified reference printed (tests/golden/make_wide_merge.py: 26 and 34 CPU-minutes there), byte for
+    byte; the narrower case also with one worker"""
     import gzip
     import hashlib
     import json
-    gold = json.load(open(os.path.join(H.GOLDEN, "wide_merge_24x7k.json")))
-    names, seqs = ["q%02d" % i for i in range(24)], synth.hor_sequences(91, 7000, 24, indel_hor=1)
+    n, seed, length, prefix = WIDE[case]
+    gold = json.load(open(os.path.join(H.GOLDEN, case + ".json")))
+    names, seqs = ["%s%02d" % (prefix, i) for i in range(n)], synth.hor_sequences(seed, length, n, indel_hor=1)
     assert hashlib.sha256("".join(seqs).encode()).hexdigest() == gold["input_sha256"]
-    fasta = "".join(">%s\n%s\n" % (n, s) for n, s in zip(names, seqs))
-    want = gzip.open(os.path.join(H.GOLDEN, "wide_merge_24x7k.gfa.gz")).read()
+    fasta = "".join(">%s\n%s\n" % (nm, sq) for nm, sq in zip(names, seqs))
+    want = gzip.open(os.path.join(H.GOLDEN, case + ".gfa.gz")).read()
     assert hashlib.sha256(want).hexdigest() == gold["gfa"]["sha256"] and len(want) == gold["gfa"]["bytes"]
-    for workers in (1, 4):
+    for workers in ((1, 4) if n < 30 else (4,)):
         got, st = gpu_ctx.msa(fasta, newick=gold["newick"], workers=workers)
         assert got == want, workers
-        assert st["n_merges"] == 23
+        assert st["n_merges"] == n - 1
