@@ -799,6 +799,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     }
     const size_t o_combos = reserve(combos.size() * sizeof(ClChainCombo)), o_weight = reserve(M * 4), o_init = reserve(M * 4), o_rec_off = reserve((M + 1) * 4),
                  o_rec_combo = reserve(rec_combo.size() * 4), o_rec_pos = reserve(rec_pos.size() * 4);
+    const size_t o_xch = use_walk ? reserve(combos.size() * kChainMacro * sizeof(unsigned long long)) : 0, o_status = use_walk ? reserve(8 * sizeof(uint32_t)) : 0;   // zeroed
     const size_t o_dp = reserve(M * 4);   // what comes back: the DP values, every combination's stored values (the traceback's value index) and query results
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].val = reserve(7 * combos[ci].rec_s.size() * 4);
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].acc = reserve(M * 7 * 4);
@@ -829,6 +830,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         put(o_rec_off, rec_off.data(), (M + 1) * 4); put(o_rec_combo, rec_combo.data(), rec_combo.size() * 4); put(o_rec_pos, rec_pos.data(), rec_pos.size() * 4);
         d_combos.view((ClChainCombo*)(dev + o_combos), hc.size()); d_weight.view((float*)(dev + o_weight), M); d_init.view((float*)(dev + o_init), M);
         d_dp.view((float*)(dev + o_dp), M);
+        if (use_walk) { d_xch.view((unsigned long long*)(dev + o_xch), combos.size() * kChainMacro); d_status.view((uint32_t*)(dev + o_status), 8); }
         d_rec_off.view((uint32_t*)(dev + o_rec_off), M + 1); d_rec_combo.view((uint32_t*)(dev + o_rec_combo), rec_combo.size()); d_rec_pos.view((uint32_t*)(dev + o_rec_pos), rec_pos.size());
         pack_dp_off = o_dp;
         pack_acc_stride = combos.size() > 1 ? po[1].acc - po[0].acc : (((size_t)M * 7 * 4 + 255) & ~(size_t)255);
@@ -906,10 +908,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 s1 = s0;
             }
             CH(d_group_end.upload_async(ctx, group_end));
-            CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
-            CH(d_status.alloc(ctx, 8));
-            if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
-                hipMemsetAsync(d_status.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+            if (!d_pack.p) {   // (a small DP's pack holds them, zeroed)
+                CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
+                CH(d_status.alloc(ctx, 8));
+                if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
+                    hipMemsetAsync(d_status.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+            }
             // the exchange between the walk's workgroups: granule sweep for few combinations, reduction for many (CL_CHAIN_WALK_REDUCE=0/1 pins it: A/B)
             static const char* reduce_env = getenv("CL_CHAIN_WALK_REDUCE");
             const bool reduce = reduce_env ? reduce_env[0] == '1' : combos.size() > kChainWalkSweepCombos;
@@ -1386,8 +1390,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     std::vector<std::vector<char>> vbuilt(combos.size(), std::vector<char>(7, 0));
     size_t vtemp_bytes = 0;
     float index_ms = 0;
-    auto release_index = [&]() { k_in.release(); k_out.release(); i_in.release(); i_out.release(); vtemp.release(); };
-    {
+    // (the streams have run dry by now — the download above waited for them: one check for the five blocks)
+    auto release_index = [&]() { cl_ctx_quiesce(ctx); k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true); };
+    if (!d_pack.p) {   // (a small DP builds its value index on the host)
         uint32_t nmax = 0;
         for (const Combo& c : combos) nmax = std::max<uint32_t>(nmax, (uint32_t)c.rec_s.size());
         CH(k_in.alloc(ctx, nmax)); CH(k_out.alloc(ctx, nmax)); CH(i_in.alloc(ctx, nmax)); CH(i_out.alloc(ctx, nmax));
