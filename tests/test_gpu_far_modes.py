@@ -28,6 +28,9 @@ VARIANTS = [
     # 32 chain combinations) instead of reading one another's granules
     ("reduce", {"CL_CHAIN_WALK_REDUCE": "1"}),
     ("granules", {"CL_CHAIN_WALK_REDUCE": "0"}),
+    # lanes per far query: 32 by default at this width (four groups of eight per query); one and two groups
+    ("lanes8", {"CL_CHAIN_FAR_LANES": "8"}),
+    ("lanes16", {"CL_CHAIN_FAR_LANES": "16"}),
 ]
 
 
@@ -50,7 +53,7 @@ def dense_input(gpu_ctx, tmp_path_factory):
 
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
-    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE"):
+    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
