@@ -16,7 +16,8 @@ constexpr uint32_t kChainLdsRecs = 1024;  // records of one start-node group bro
 constexpr uint32_t kChainMacro = 1024;    // match pairs per launch of the walk kernel (one workgroup per chain combination)
 constexpr uint32_t kChainWalkMaxCombos = 256; // the walk's workgroups wait for one another: all of them must be resident (one per CU: the affine
                                               // walk takes 96 VGPRs at 1 024 threads)
-constexpr uint32_t kChainWalkSweepCombos = 32; // up to here every workgroup reads every other's granule; beyond, one atomic maximum + arrival count per pair
+constexpr uint32_t kChainWalkSweepCombos = 16; // up to here every workgroup reads every other's granule; beyond, one atomic maximum + arrival count per pair
+                                               // (10 x 1 Mbp, device time of a merge's DPs, granules / reduction: 4 combinations 480 / 502 ms, 25 combinations 1 091 / 1 052 ms)
 
 struct ClChainParams {
     double gap_open[3];

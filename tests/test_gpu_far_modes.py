@@ -25,7 +25,7 @@ VARIANTS = [
     ("no_far", {"CL_CHAIN_NO_FAR_PRUNE": "1"}),
     ("per_block", {"CL_CHAIN_NO_FAR_PRUNE": "1", "CL_CHAIN_OLD_WALK": "1"}),
     # the walk's workgroups exchange their candidates through one atomic maximum + arrival count per pair (the way of merges with more than
-    # 32 chain combinations) instead of reading one another's granules
+    # 16 chain combinations) instead of reading one another's granules
     ("reduce", {"CL_CHAIN_WALK_REDUCE": "1"}),
     ("granules", {"CL_CHAIN_WALK_REDUCE": "0"}),
     # lanes per far query: 32 by default at this width (four groups of eight per query); one and two groups
