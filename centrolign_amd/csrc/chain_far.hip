@@ -598,7 +598,7 @@ hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uin
     static const int pinned = [] { const char* e = getenv("CL_CHAIN_FAR_LANES"); return e ? atoi(e) : 0; }();
     // (10 x 1 Mbp, device time of a merge's two DPs with 8 / 16 / 32 lanes: 1 combination 348 / 303 / 293 ms, 4 combinations 583 / 512 / 476 ms, 25 combinations
     // 1 193 / 1 115 / 1 090 ms)
-    const int lanes = pinned ? pinned : (mine <= 32 ? 32 : mine <= 128 ? 16 : 8);
+    const int lanes = (pinned == 8 || pinned == 16 || pinned == 32) ? pinned : (mine <= 32 ? 32 : mine <= 128 ? 16 : 8);   // (a whole wave per query was tried: it does not terminate)
     const dim3 grid((count * (uint32_t)lanes + 255) / 256, mine);
 #define CL_FAR_LAUNCH(G) do { \
         if (D.sparse) hipLaunchKernelGGL((far_prune_kernel<true, G>), grid, dim3(256), 0, stream, D, F, first, count, end_block); \
