@@ -347,6 +347,8 @@ def main():
                        "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes,
                        "workspace_bytes": int(sum(st.get("workspace_bytes", 0) for st in stats)),
                        "merge_groups": None if world == 1 else (res["stats"].get("merge_groups") if res is not None and "stats" in res else None),
+                       # rank 0's share of the merges that ran as groups: chaining DPs shared, far launches on its combinations, macro-blocks whose other combinations came from the other members
+                       "merge_group_stats": None if world == 1 else dict(ctx.peer_stats(), shared_merges=res["stats"].get("shared_merges", 0) if res is not None and "stats" in res else 0),
                        "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
                                       "one MSA over %d ranks (sibling subtrees + leaf calibrations per rank, %d worker contexts inside a rank; merges across ranks run as merge groups of up to %d ranks: every member runs the merge, the far pass of its chaining DP is divided between their devices through peer stores, no collective), stitch batches on the rank that made them; msa_wall_s stays bounded by the serial walk of the spine's merges (DESIGN.md §5); no multi-GPU hardware curve has been measured by the builder (one-device runs of the multi-rank path only)" % (world, args.workers, args.share_merges)},
             "msa_wall_s": msa_wall,
