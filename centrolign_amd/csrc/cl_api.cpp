@@ -75,7 +75,16 @@ struct BigCache {
 };
 thread_local BigCache t_big_cache;
 }
+static void* big_alloc_raw(size_t bytes);
+// CL_BIG_POISON=1 (tests): every block is handed out filled with 0xA5 — code that relied on fresh mappings being zero shows at once instead of
+// after a block has been used before
 void* cl_big_alloc(size_t bytes) {
+    static const bool poison = getenv("CL_BIG_POISON") != nullptr;
+    void* p = big_alloc_raw(bytes);
+    if (poison && bytes) memset(p, 0xA5, bytes);
+    return p;
+}
+static void* big_alloc_raw(size_t bytes) {
     if (bytes >= kBigMin) {
         auto it = t_big_cache.free_blocks.lower_bound(bytes);
         if (it != t_big_cache.free_blocks.end() && it->first <= 2 * bytes) {
