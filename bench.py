@@ -203,6 +203,20 @@ def pairwise_section(ctx, with_reference):
     return out
 
 
+def spawn_ranks(n):
+    """`python -m torch.distributed.run --nproc-per-node n bench.py <the same arguments>` as a child; rank 0's JSON line goes to stdout"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,7 +230,15 @@ def main():
                     help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
+    ap.add_argument("--no-shard-stitch", action="store_true",
+                    help="N > 1: keep every merge's stitch batch on the rank that made it instead of dealing the subproblems of ALL batches over the ranks")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): start the N ranks ourselves, as a CHILD process, before anything here has touched the
+        # GPU (nothing has: torch is not even imported yet; a process that has initialised HIP must never exec another program), relay the
+        # ranks' output and leave with their exit code
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     from centrolign_amd import dist as cd
@@ -270,6 +292,22 @@ def main():
 
     # ---- 2. the stitch batches of this rank's merges, resident in HBM ----------------------------------------------------------
     batches = stitch_batches(kept)
+    stitch_sharding = None
+    if world > 1 and not args.no_shard_stitch:
+        # north_star: "the thousands of independent between-anchor stitch subproblems ... shard naturally across the GPUs".  A merge's batch is
+        # made where the merge ran; for the timed passes every batch goes to every rank once (host arrays over the host group — set-up, outside
+        # the timed region) and each rank keeps its share of EVERY batch: longest-processing-time assignment by DP cells (dist.shard_problems),
+        # so the few long sweeps that bound a launch are spread over the devices.  No exchange in the timed steps.
+        gathered = [None] * world
+        dist.all_gather_object(gathered, batches, group=host_group)
+        every = [mb for part in gathered for mb in part]
+        batches, cells_all = [], 0
+        for m, b in every:
+            cells_all += b.dp_cells()
+            mine = cd.shard_problems(b, world)[rank]
+            if len(mine):
+                batches.append((m, b.subset(mine)))
+        stitch_sharding = {"batches": len(every), "dp_cells_all_ranks": int(cells_all), "rule": "LPT by (n1+1)(n2+1) over the ranks, per batch"}
     if args.debug_skip:
         os.environ["CL_DEBUG_SKIP_TRACEBACK"] = str(args.debug_skip)
     # one context (= one HIP stream set) per batch: the nine merges are independent, their passes run side by side on the device
@@ -333,6 +371,15 @@ def main():
                                        "tree": tj.get("_commit", "round 2"), "limiter": tj.get("_limiter", {}).get(dom["kernel"])}
             except Exception:
                 traffic_profile = None
+        # the digest every run of the headline workload must print, whatever N: the single-rank GFA (profiles/r03_bench.json; tests/test_c3_full.py pins
+        # eight of its nine subproblems and the restarted root against the reference)
+        expected_sha = None
+        try:
+            with open(os.path.join(HERE, "tests", "golden", "c3_10x1M_subproblems.json")) as f:
+                expected_sha = json.load(f)["root_default_budget_self_digest"]["sha256"]
+        except (OSError, KeyError, ValueError):
+            pass
+        gfa_ok = None if (expected_sha is None or args.length != 1000000) else bool(gfa_sha == expected_sha)
         per_merge = res["stats"].get("per_merge", [])
         chain_ms = sum(m["chain_device_ms"] for m in per_merge)
         chain_pairs = sum(m["chain_match_pairs"] for m in per_merge)
@@ -341,10 +388,11 @@ def main():
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": ("INVALID (--debug-skip %d): " % args.debug_skip if args.debug_skip else "") + WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
+            "config": {"workload": ("INVALID (--debug-skip %d): " % args.debug_skip if args.debug_skip else "") + ("INVALID (the GFA differs from the single-rank digest): " if gfa_ok is False else "") + WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
-                       "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes,
+                       "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "gfa_is_the_single_rank_digest": gfa_ok,
+                       "stitch_sharding": stitch_sharding,
                        "workspace_bytes": int(sum(st.get("workspace_bytes", 0) for st in stats)),
                        "merge_groups": None if world == 1 else (res["stats"].get("merge_groups") if res is not None and "stats" in res else None),
                        # rank 0's share of the merges that ran as groups: chaining DPs shared, far launches on its combinations, macro-blocks whose other combinations came from the other members
@@ -372,7 +420,9 @@ def main():
                 ns_per_step = dom["ms"] * 1e6 / steps
                 latency = {"model": "latency", "dependent_steps": steps, "ns_per_step": ns_per_step, "single_wave_issue_floor_ns_per_step": issue_floor_ns,
                            "floor_over_measured": issue_floor_ns / ns_per_step, "longest_subproblem": dom.get("longest"),
-                           "note": "measured while the other eight plans run beside it; alone the same launch is faster (DESIGN.md §4.4)"}
+                           "note": "kernel_ms: the launch ALONE on its context's stream between two HIP events of its own (cl_stitch_plan_execute_profiled runs a plan's "
+                                   "launches one after the other, one plan at a time): a kernel duration, comparable with the rocprofv3 kernel trace under profiles/; "
+                                   "inside a timed step the nine plans' launches overlap and share hardware queues"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                                "kernel": dom["kernel"], "merge": dom["merge"], "kernel_ms": dom["ms"], "kernel_cells": dom["dp_cells"],
                                "kernel_problems": dom["n_problems"], "latency_model": latency, "traffic_profile": traffic_profile,
@@ -398,9 +448,18 @@ def main():
                                        "behind on side streams); its kernels are priced per kernel against HBM bytes/s and VALU issue in profiles/r03_pmc_summary.json "
                                        "(rocprofv3 --pmc passes; command recorded in the file), not here: the far pass skips >98 % of the pair evaluations an "
                                        "all-pairs sweep would make, so an evaluations/s figure says nothing about the hardware"}
+        # BASELINE.md §2 holds ONE figure for this metric, measured (not published) by the survey: the reference's po_poa at 38 M cells/s inside
+        # its 2 x 1 Mbp run on one Xeon core; the same-host figures are in cpu_baseline (measured here, every run)
+        out["vs_baseline"] = value / 38.0e6
+        out["vs_baseline_note"] = "value / 38 M cells/s: the reference's stitching rate in BASELINE.md §2 (survey's measurement, 2 x 1 Mbp, one Xeon core; nothing is published)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)
+            out["vs_cpu_baseline_same_host"] = value / out["cpu_baseline"]["value"]
             out["cpu_reference_wall"] = reference_leaf_merge(seqs, names)
+            if "seconds" in out["cpu_reference_wall"]:
+                out["cpu_reference_wall"]["whole_msa_here_s"] = msa_wall
+                out["cpu_reference_wall"]["note"] = ("the reference needs %.1f s for the FIRST of the nine merges on this host; the whole ten-sequence MSA takes %.2f s here "
+                                                     "(the reference cannot finish it: it runs out of memory at the root, tests/golden/c3_10x1M_subproblems.json)" % (out["cpu_reference_wall"]["seconds"], msa_wall))
         if world == 1 and not args.no_extras:
             out["chaining_c2"] = chaining_section(ctx, not args.no_cpu_baseline)
             out["pairwise_c2"] = pairwise_section(ctx, not args.no_cpu_baseline)

@@ -975,7 +975,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 5     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 6     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1688,10 +1688,10 @@ class Context:
         return self.lib.cl_context_peer_selftest(self.handle, int(token), int(timeout_ms)) == 0
 
     def peer_stats(self):
-        st = (C.c_uint64 * 3)()
+        st = (C.c_uint64 * 5)()
         self.lib.cl_context_peer_stats.argtypes = [C.c_void_p, C.c_void_p]
         self._check(self.lib.cl_context_peer_stats(self.handle, st))
-        return dict(shared_dps=int(st[0]), shared_far_launches=int(st[1]), merged_blocks=int(st[2]))
+        return dict(shared_dps=int(st[0]), shared_far_launches=int(st[1]), merged_blocks=int(st[2]), epoch_mark=int(st[3]), selftest_mark=int(st[4]))
 
     def close(self):
         if self.handle:

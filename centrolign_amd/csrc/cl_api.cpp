@@ -589,6 +589,7 @@ struct LaunchGroup {
     uint32_t count = 0;
     uint64_t cells = 0, bytes = 0;
     uint32_t ring_bytes = 0;  // general kernel: dynamic LDS of the ring variant (0 = planes read from HBM)
+    uint64_t est_cost = 0;    // longest sweep x the kernel's rough time per step: orders the groups and deals them over the streams
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -1228,7 +1229,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // microseconds per anti-diagonal step, roughly: planes in HBM 4-8, LDS ring 1.6-2.5, systolic DAG 0.45, chain 0.2-0.6
             return c * (g.kind == CL_KIND_GENERAL ? (g.ring_bytes ? 5 : 16) : 1);
         };
-        std::stable_sort(pl->groups.begin(), pl->groups.end(), [&](const LaunchGroup& x, const LaunchGroup& y) { return crit(x) > crit(y); });
+        for (LaunchGroup& g : pl->groups) g.est_cost = crit(g);
+        std::stable_sort(pl->groups.begin(), pl->groups.end(), [&](const LaunchGroup& x, const LaunchGroup& y) { return x.est_cost > y.est_cost; });
     }
     pl->stats.n_launches = pl->groups.size();
     lap("launch groups");
@@ -1276,24 +1278,44 @@ static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS
 
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
+static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, hipStream_t stream) {
+    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    if (g.kind == CL_KIND_SYS) return cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, stream);
+}
+
 static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
-    if (timed)   // the per-launch events exist only for plans that are profiled
+    if (timed) {
+        // the profiled pass: every launch ALONE on the context's stream between two events of its own, one after the other — an event pair
+        // round a launch that shares hardware queues with other launches measures the wait for the queue as well (round 3: 2.49 ms by events
+        // against 1.45 ms in the kernel trace for the dominant launch); like this the pair brackets the kernel and nothing else
         for (LaunchGroup& g : pl->groups)
             if (!g.ev0 && (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess)) g.ev0 = g.ev1 = nullptr;
+        for (const LaunchGroup& g : pl->groups) {
+            if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->stream));
+            HIP_TRY(ctx, launch_group(g, pl, ctx->stream));
+            if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->stream));
+        }
+        return CL_OK;
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     bool used[kNumAuxStreams] = {};
+    // the groups come longest first (cl_stitch_plan_create: estimated duration = longest sweep x the kernel's time per step); each goes to the
+    // stream with the least work so far (longest-processing-time rule), so that the one or two long sweeps of a batch start at once on streams
+    // of their own and the short launches queue up beside, not behind, them.  CL_STITCH_SCHED=rr deals them round-robin (rounds 1-3; A/B).
+    static const bool round_robin = [] { const char* e = getenv("CL_STITCH_SCHED"); return e && e[0] == 'r'; }();
+    const int n_streams = std::min(g_plan_streams, ctx->n_aux);
+    uint64_t load[kNumAuxStreams] = {};
     for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
         const LaunchGroup& g = pl->groups[gi];
-        int si = (int)(gi % (size_t)std::min(g_plan_streams, ctx->n_aux));
+        int si = (int)(gi % (size_t)n_streams);
+        if (!round_robin) {
+            si = 0;
+            for (int t = 1; t < n_streams; ++t) if (load[t] < load[si]) si = t;
+            load[si] += std::max<uint64_t>(1, g.est_cost);
+        }
         if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
-        if (timed && g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->aux[si]));
-        if (g.kind == CL_KIND_LINEAR)
-            HIP_TRY(ctx, cl_launch_popoa_linear(g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
-        else if (g.kind == CL_KIND_SYS)
-            HIP_TRY(ctx, cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
-        else
-            HIP_TRY(ctx, cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, ctx->aux[si]));
-        if (timed && g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->aux[si]));
+        HIP_TRY(ctx, launch_group(g, pl, ctx->aux[si]));
     }
     for (int si = 0; si < kNumAuxStreams; ++si)
         if (used[si]) {

@@ -1177,6 +1177,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         if (shared) {
             far_decided = true;
             share_epoch = ++peers.epoch;
+            peers.epoch_mark = std::max(peers.epoch_mark, peers.epoch);
             ++peers.shared_dps;
             F.share_n = peers.n;
             F.share_i = peers.me;
@@ -1207,7 +1208,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     if (shared) {
                         // this member's combinations; what it finds goes into slot k of the others' inboxes, then its arrival word there
                         ClFarDevice Fk = F;
-                        const uint32_t slot = k % kPeerRing, word = (share_epoch << 20) | (k + 1);
+                        // (the slot depends on the epoch's parity too: a member that has gone on to the next shared DP while another still folds the
+                        // last blocks of this one then writes the other half of the ring — 2 * lag + 2 <= 18 run-ahead inside a DP was the only bound before)
+                        const uint32_t slot = (k + (kPeerRing / 2) * (share_epoch & 1u)) % kPeerRing, word = (share_epoch << 20) | (k + 1);
                         uint32_t o = 0;
                         for (uint32_t m = 0; m < peers.n; ++m) if (m != peers.me) Fk.peer_out[o++] = peers.peer_inbox[m] + (size_t)slot * kPeerSlotInts;
                         if (he == hipSuccess) he = cl_chain_far_launch(D, Fk, first, count, near_lo, far_stream);
@@ -1242,7 +1245,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
             if (shared && near_lo > 0) {
                 // the other members' combinations of this macro-block: wait for their arrival words, fold their slot into the running maxima
-                const uint32_t slot = k % kPeerRing, word = (share_epoch << 20) | (k + 1);
+                const uint32_t slot = (k + (kPeerRing / 2) * (share_epoch & 1u)) % kPeerRing, word = (share_epoch << 20) | (k + 1);
                 for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m)
                     if (m != peers.me) he = hipStreamWaitValue32(ctx->stream, peers.flags + (size_t)m * kPeerRing + slot, word, hipStreamWaitValueGte, 0xFFFFFFFFu);
                 if (he == hipSuccess) he = cl_chain_far_merge(D, peers.inbox + (size_t)slot * kPeerSlotInts, first, count, peers.n, peers.me, ctx->stream);

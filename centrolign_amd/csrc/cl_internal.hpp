@@ -51,6 +51,9 @@ struct cl_context {
         int* peer_inbox[8] = {};       // the other members' inboxes and arrival words as this process sees them (index = member)
         uint32_t* peer_flags[8] = {};
         uint32_t epoch = 0;            // one per shared DP, the same on every member; arrival words hold epoch << 20 | macro-block + 1
+        uint32_t epoch_mark = 0;       // the highest epoch this context's inbox has ever been used with: the arrival words are never reset, so a group's
+                                       // epoch base must not lie below it (cl_context_peer_group refuses), and
+        uint32_t test_mark = 0;        // the highest token of cl_context_peer_selftest (a token at or below it would find its words already there)
         uint64_t shared_dps = 0, shared_far_launches = 0, merged_blocks = 0;
         std::vector<std::pair<std::string, void*>> opened;   // IPC handles this context has opened (kept until it is destroyed)
     } peers;

@@ -90,6 +90,12 @@ int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index
         P.peer_inbox[m] = static_cast<int*>(base);
         P.peer_flags[m] = reinterpret_cast<uint32_t*>(static_cast<int*>(base) + kInboxInts);
     }
+    // the arrival words of an inbox are never reset: a base below an epoch this context has already used would find its words at or above
+    // epoch << 20 | k + 1 waiting, every hipStreamWaitValue32(>=) would pass at once and the previous run's slots would be folded in
+    if (epoch_base < P.epoch_mark) {
+        cl_set_error(ctx, "cl_context_peer_group: epoch base %u lies below an epoch this context has already used (%u): epochs must grow (cl_context_peer_stats reports the mark)", epoch_base, P.epoch_mark);
+        return CL_ERR_INVALID_ARGUMENT;
+    }
     P.n = n_members;
     P.me = my_index;
     P.epoch = epoch_base;
@@ -104,6 +110,8 @@ int cl_context_peer_selftest(cl_context* ctx, uint32_t token, uint32_t timeout_m
     if (!ctx) return CL_ERR_INVALID_ARGUMENT;
     auto& P = ctx->peers;
     if (P.n <= 1) return CL_OK;
+    if (token <= P.test_mark) { cl_set_error(ctx, "cl_context_peer_selftest: token %u is not above the last one used (%u): the test would pass on stale words", token, P.test_mark); return CL_ERR_INVALID_ARGUMENT; }
+    P.test_mark = token;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     for (uint32_t m = 0; m < P.n; ++m) {
@@ -138,6 +146,8 @@ int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out) {
     out->shared_dps = ctx->peers.shared_dps;
     out->shared_far_launches = ctx->peers.shared_far_launches;
     out->merged_blocks = ctx->peers.merged_blocks;
+    out->epoch_mark = ctx->peers.epoch_mark;
+    out->selftest_mark = ctx->peers.test_mark;
     return CL_OK;
 }
 

@@ -291,12 +291,20 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
         # once round ALL ranks before anything depends on it: peer stores, stream memory operations and their order between these devices.
         # Any rank that sees nothing within five seconds switches the whole job back to one rank per merge.
         ok = torch.ones(1, dtype=torch.int32)
-        if any(h is None for h in handles):
+        # a context that has been in groups before: its arrival words are never reset, so this job's epochs and self-test token start above the
+        # highest any member has used (the library refuses anything else)
+        marks = torch.zeros(2, dtype=torch.int64)
+        if mine is not None:
+            st = ctx.peer_stats() if hasattr(ctx, "peer_stats") else {}
+            marks[0], marks[1] = st.get("epoch_mark", 0), st.get("selftest_mark", 0)
+        dist.all_reduce(marks, op=dist.ReduceOp.MAX, group=group)
+        epoch0, token = int(marks[0]), int(marks[1]) + 1
+        if any(h is None for h in handles) or world > 8:      # (more than one node's worth of ranks: no self-test round all of them, no groups)
             ok[0] = 0
         elif world <= 8:
             try:
-                ctx.peer_group(handles, rank, 0)
-                ok[0] = 1 if ctx.peer_selftest(1) else 0
+                ctx.peer_group(handles, rank, epoch0)
+                ok[0] = 1 if ctx.peer_selftest(token) else 0
                 ctx.peer_group([], 0, 0)
             except capi.ClError:
                 ok[0] = 0
@@ -386,7 +394,7 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
         # (worth it from about nine combinations on: a far launch over one or two combinations is bound by the latency of a single query's
         # search, not by how many queries it holds — 323 µs for one combination, ~900 µs for the 25 of a 5 + 5-path root — and every member
         # needs both children's graphs)
-        if share_merges > 1 and min_shared_combos <= combos <= 64 and 16 * merge_number[newick(t)] + 16 < 4096:
+        if share_merges > 1 and min_shared_combos <= combos <= 64 and epoch0 + 16 * merge_number[newick(t)] + 16 < 4096:
             members = [left[0], right[0]] + [r for r in ranks if r not in (left[0], right[0])][:share_merges - 2]
             if rank not in members:
                 return None
@@ -403,7 +411,7 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
             else:
                 g2 = recv_graph(right[0], dist, group)
             stats["graphs_received"] += (rank != left[0]) + (rank != right[0])
-            ctx.peer_group([handles[m] for m in members], members.index(rank), 16 * merge_number[newick(t)])
+            ctx.peer_group([handles[m] for m in members], members.index(rank), epoch0 + 16 * merge_number[newick(t)])
             try:
                 r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
             finally:

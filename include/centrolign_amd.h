@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 5   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 6   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -156,6 +156,9 @@ typedef struct cl_peer_stats {
     uint64_t shared_dps;            /* chaining DPs whose far pass this context shared */
     uint64_t shared_far_launches;   /* far launches it ran on its share of the combinations */
     uint64_t merged_blocks;         /* macro-blocks whose other combinations came from the other members */
+    uint64_t epoch_mark;            /* highest epoch this context's inbox has been used with: cl_context_peer_group refuses a base below it (the
+                                       arrival words are never reset); callers that reuse contexts start from the maximum over the members */
+    uint64_t selftest_mark;         /* highest token cl_context_peer_selftest has been given: the next one must be greater */
 } cl_peer_stats;
 int cl_context_peer_export(cl_context* ctx, cl_peer_handle* out);
 int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index, const cl_peer_handle* members, uint32_t epoch_base);

@@ -26,7 +26,8 @@ def test_bonds_bubbles_and_inconsistencies():
 
 
 def test_plan_and_formats():
-    for case in test_plan.CASES if hasattr(test_plan, "CASES") else []:
+    assert len(test_plan.CASES) > 0
+    for case in test_plan.CASES:
         test_plan.test_plan_equals_reference(case)
     test_plan.test_parse_fasta()
     test_io.test_texts_match_reference_golden()

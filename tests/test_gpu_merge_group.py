@@ -55,6 +55,18 @@ def test_two_contexts_share_the_far_pass_of_one_merge(gpu_ctx):
         for c in members:
             st = c.peer_stats()
             assert st["shared_dps"] >= 2 and st["shared_far_launches"] > 100 and st["merged_blocks"] > 100, st
+        # the arrival words are never reset: an epoch base below what this context has already used is refused (it would pass every wait at once and
+        # fold the previous run's slots in), and so is a self-test token that is not above the last one
+        assert members[0].peer_stats()["epoch_mark"] > 32
+        with pytest.raises(capi.ClError):
+            members[0].peer_group(handles, 0, 16)
+        for i, c in enumerate(members):
+            c.peer_group(handles, i, 64)
+        t = [threading.Thread(target=lambda c=c: c.peer_selftest(5)) for c in members]
+        [x.start() for x in t]
+        [x.join(timeout=60) for x in t]
+        assert members[0].peer_stats()["selftest_mark"] == 5
+        assert not members[0].peer_selftest(5)
         # out of the group again: an ordinary merge
         st0 = members[0].peer_stats()
         members[0].peer_group([], 0, 0)
