@@ -40,6 +40,8 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
                                  uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
 hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream);
+hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream);   // chain_walk2.hip
+uint32_t cl_chain_walk2_helpers(uint32_t qpt);
 hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
 // chain_far.hip
 hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias, uint32_t band_shift,
@@ -754,7 +756,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<ClChainCombo> d_combos;
     DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
-    DevBuf<unsigned long long> d_xch;
+    DevBuf<unsigned long long> d_xch, d_xdp, d_hacc;
     DevBuf<char> d_pack;              // a small DP's arrays in one block (below)
     size_t pack_dp_off = 0, pack_acc_stride = 0, pack_down_bytes = 0;
     DevBuf<uint32_t> d_xred;
@@ -776,7 +778,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         cl_ctx_quiesce(ctx);   // once, for the ~40 blocks that go back to the pool below
         for (Combo& c : combos) c.release(true);
         d_combos.release(true); d_weight.release(true); d_init.release(true); d_dp.release(true); d_rec_off.release(true); d_rec_combo.release(true); d_rec_pos.release(true); d_group.release(true); d_grp_base.release(true); d_grp_total.release(true);
-        d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xred.release(true); d_pack.release(true);
+        d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xdp.release(true); d_hacc.release(true); d_xred.release(true); d_pack.release(true);
         k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true);
         d_far_rec.release(true); d_far_base.release(true); d_seal_items.release(true); d_far_temp.release(true);
         for (auto& b : d_far_perm) b.release(true);
@@ -804,6 +806,16 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].val = reserve(7 * combos[ci].rec_s.size() * 4);
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].acc = reserve(M * 7 * 4);
     const bool packed = pack_total <= (2u << 20) && !combos.empty();
+    // the walk over several compute units per combination (chain_walk2.hip: a main workgroup with a window of 128 x qpt queries and helper
+    // workgroups for the rest of the macro-block) wherever main + helpers of every combination fit the chip at one workgroup per compute unit;
+    // CL_CHAIN_WALK2=0 keeps chain_walk_kernel (A/B), CL_CHAIN_WALK2_QPT=1/2 the window, CL_CHAIN_WALK2_HELPERS=n the helpers (0: the main
+    // workgroup evaluates everything itself out of LDS — the path it takes when a helper is late)
+    static const bool walk2_env = [] { const char* e = getenv("CL_CHAIN_WALK2"); return !e || e[0] != '0'; }();
+    static const uint32_t walk2_qpt = [] { const char* e = getenv("CL_CHAIN_WALK2_QPT"); return e && e[0] == '1' ? 1u : 2u; }();
+    static const int walk2_help_env = [] { const char* e = getenv("CL_CHAIN_WALK2_HELPERS"); return e ? atoi(e) : -1; }();
+    uint32_t walk2_help = cl_chain_walk2_helpers(walk2_qpt);
+    const bool use_walk2 = use_walk && !packed && walk2_env && ((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help) <= 256;
+    if (walk2_help_env >= 0) walk2_help = (uint32_t)std::min(walk2_help_env, 7);
     if (packed) {
         CH(d_pack.alloc(ctx, pack_total));
         char* dev = d_pack.p;
@@ -908,6 +920,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 s1 = s0;
             }
             CH(d_group_end.upload_async(ctx, group_end));
+            if (use_walk2) {
+                CH(d_xdp.alloc(ctx, combos.size() * kChainMacro));
+                CH(d_hacc.alloc(ctx, combos.size() * kChainMacro * 8));
+                if (hipMemsetAsync(d_xdp.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
+                    hipMemsetAsync(d_hacc.p, 0, combos.size() * kChainMacro * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+            }
             if (!d_pack.p) {   // (a small DP's pack holds them, zeroed)
                 CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
                 CH(d_status.alloc(ctx, 8));
@@ -955,6 +973,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     D.group_end = d_group_end.p;
     D.xch = d_xch.p;
     D.xred = d_xred.p;
+    D.xdp = d_xdp.p;
+    D.hacc = d_hacc.p;
     D.status = d_status.p;
 
 
@@ -1251,7 +1271,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess) he = cl_chain_far_merge(D, peers.inbox + (size_t)slot * kPeerSlotInts, first, count, peers.n, peers.me, ctx->stream);
                 ++peers.merged_blocks;
             }
-            if (he == hipSuccess) he = cl_chain_launch_walk(D, first, count, ctx->stream);
+            if (he == hipSuccess) he = use_walk2 ? cl_chain_launch_walk2(D, first, count, walk2_qpt, walk2_help, ctx->stream) : cl_chain_launch_walk(D, first, count, ctx->stream);
             if (he == hipSuccess) he = cl_ring_event(ctx, 0, k, &ev_walk[k]);
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
             if (use_far && far_bb && he == hipSuccess && k + far_lag + 1 < n_macro) {

@@ -41,8 +41,8 @@ def main():
     sparse = sys.argv[2] == "sparse"
     ctx = capi.Context(0)
     got = ctx.chain_sparse_affine(g1, g2, ms, scale=scale, want_dp=True, sparse=sparse, params=capi.default_chain_params(global_anchoring=True))
-    print("RESULT pairs=%d anchors=%d dp=%s chain=%s" % (got["n_pairs"], len(got["chain"]),
-          hashlib.sha256(got["dp"].view(np.uint32).tobytes()).hexdigest(), hashlib.sha256(np.ascontiguousarray(got["chain"]).tobytes()).hexdigest()))
+    print("RESULT pairs=%d anchors=%d dp=%s chain=%s device_ms=%.1f" % (got["n_pairs"], len(got["chain"]),
+          hashlib.sha256(got["dp"].view(np.uint32).tobytes()).hexdigest(), hashlib.sha256(np.ascontiguousarray(got["chain"]).tobytes()).hexdigest(), got["device_ms"]))
     ctx.close()
 
 

@@ -31,6 +31,14 @@ VARIANTS = [
     # lanes per far query: 32 by default at this width (four groups of eight per query); one and two groups
     ("lanes8", {"CL_CHAIN_FAR_LANES": "8"}),
     ("lanes16", {"CL_CHAIN_FAR_LANES": "16"}),
+    # round 4: the walk of a macro-block over several compute units per combination (chain_walk2.hip) is the default; one compute unit per
+    # combination as in rounds 2-3; a window of 128 instead of 256 queries; no helper workgroups at all (the main workgroup then evaluates
+    # everything itself out of LDS: the path it takes whenever a helper is late); too few helpers (some sub-blocks helped, some not)
+    ("walk1", {"CL_CHAIN_WALK2": "0"}),
+    ("walk2_window128", {"CL_CHAIN_WALK2_QPT": "1"}),
+    ("walk2_no_helpers", {"CL_CHAIN_WALK2_HELPERS": "0"}),
+    ("walk2_two_helpers", {"CL_CHAIN_WALK2_HELPERS": "2"}),
+    ("walk2_reduce", {"CL_CHAIN_WALK_REDUCE": "1", "CL_CHAIN_WALK2_QPT": "1"}),
 ]
 
 
@@ -53,7 +61,8 @@ def dense_input(gpu_ctx, tmp_path_factory):
 
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
-    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES"):
+    for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES", "CL_CHAIN_WALK2", "CL_CHAIN_WALK2_QPT",
+              "CL_CHAIN_WALK2_HELPERS"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
