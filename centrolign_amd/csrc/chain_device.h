@@ -64,6 +64,7 @@ struct ClChainDevice {
     uint32_t* xred;             // null, or [n_pairs][2] {biased maximum, arrivals}: the exchange as a reduction (many combinations; zeroed before every DP)
     unsigned long long* xdp;    // chain_walk2.hip: [n_combos][kChainMacro] {tag, DP value} granules a combination's main workgroup leaves for its helpers, and
     unsigned long long* hacc;   // [n_combos][kChainMacro][8] {tag, maximum} granules the helpers give back (both zeroed before every DP; null: chain_walk_kernel)
+    uint32_t debug;             // chain_walk2.hip: count and clock into status[8..23] (CL_CHAIN_WALK2_DEBUG)
     uint32_t* status;           // [1] set non-zero by a walk that gave up waiting for a sibling workgroup
     // branch-and-bound far pass (chain_far.hip); null / 0 when it is not in use
     int* far_rec;               // [r_pad][12] the records of every combination as the kernels consume them: insertion index, offset,

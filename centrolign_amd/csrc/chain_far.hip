@@ -179,6 +179,122 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
     }
 }
 
+// The same for a LARGE node (4 096 or 32 768 records), one workgroup of 1 024 threads per node (round 4; one wave took up to 0.9 ms for a
+// 32 768-record node, and every far launch behind it waited).  The node is swept in tiles of 8 192 records: a thread takes eight consecutive
+// positions of both orders — their record numbers and bucket keys are contiguous, the DP values come through sixteen gathers that are all
+// in flight together — scans them, the thread totals are scanned across the wave by shuffles and across the sixteen waves through LDS, and
+// two uniform carries go from tile to tile.  The bucket order is a SEGMENTED maximum; a segment starts where the bucket changes, which a
+// position reads off the static keys (its predecessor's key is in memory whatever thread owns it), so the scan operator is
+// (f1, v1) + (f2, v2) = (f1 | f2, f2 ? v2 : max(v1, v2)) on (a segment starts inside, maximum of the trailing segment).
+__global__ void __launch_bounds__(1024) far_seal_big_kernel(ClFarDevice F, const int* __restrict__ rec, const uint32_t* __restrict__ items, uint32_t item0) {
+    const uint32_t it = items[item0 + blockIdx.x];
+    const uint32_t l = it >> 28, node = it & 0x0FFFFFFFu;
+    const uint32_t shift = kFarLeafShift + kFarFanShift * l;
+    const uint32_t g0 = node << shift, n = 1u << shift;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t* __restrict__ perm_o = F.perm_o[l];
+    const uint32_t* __restrict__ perm_b = F.perm_b[l];
+    uint32_t* ord_o = F.arena + F.tab[l][0];
+    const bool banded = F.tab[l][1] != 0xFFFFFFFFu;   // sparse_chain_dp: one order only
+    uint32_t* ord_b = F.arena + (banded ? F.tab[l][1] : 0u);
+    __shared__ int s_wx[16], s_wy[16], s_wf[16], s_carry[2];
+    int carry_o = INT32_MIN, carry_b = INT32_MIN;     // by offset: maximum so far; by bucket: maximum of the segment that is open at the tile's start
+    for (uint32_t tile = 0; tile < n; tile += 8192) {
+        const uint32_t i0 = g0 + tile + t * 8;        // this thread's eight positions (n is a multiple of 8 192 or equals 4 096: t * 8 < n decides)
+        const bool in = tile + t * 8 < n;
+        int x[8], y[8];
+        uint32_t bk[8], bprev = 0xFFFFFFFEu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] = INT32_MIN; y[e] = INT32_MIN; bk[e] = 0xFFFFFFFFu; }
+        if (in) {
+            const uint4 pa = *reinterpret_cast<const uint4*>(perm_o + i0), pb = *reinterpret_cast<const uint4*>(perm_o + i0 + 4);
+            const uint32_t po[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = rec[(size_t)po[e] * 12 + 3];
+            if (banded) {
+                const uint4 qa = *reinterpret_cast<const uint4*>(perm_b + i0), qb = *reinterpret_cast<const uint4*>(perm_b + i0 + 4);
+                const uint32_t pq[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = rec[(size_t)pq[e] * 12 + 3];
+                const uint32_t* kb = ord_b + ((i0 >> 3) << 4);
+                const uint4 ka = *reinterpret_cast<const uint4*>(kb), kc = *reinterpret_cast<const uint4*>(kb + 4);
+                const uint32_t kk[8] = {ka.x, ka.y, ka.z, ka.w, kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bk[e] = kk[e] >> F.off_bits;
+                // the position in front of this thread's first one (the node's first position starts a segment whatever lies in front of the node)
+                if (i0 != g0) bprev = ord_b[(((i0 - 1) >> 3) << 4) + ((i0 - 1) & 7u)] >> F.off_bits;
+            }
+        }
+        // thread-local inclusive scans; the bucket order's: fy = a segment starts at or after the thread's first position, vy = maximum of the trailing segment
+#pragma unroll
+        for (int e = 1; e < 8; ++e) x[e] = max(x[e], x[e - 1]);
+        int fy = 0;
+        if (banded) {
+            fy = bk[0] != bprev ? 1 : 0;
+#pragma unroll
+            for (int e = 1; e < 8; ++e) {
+                const bool head = bk[e] != bk[e - 1];
+                if (!head) y[e] = max(y[e], y[e - 1]);
+                fy |= head ? 1 : 0;
+            }
+        }
+        // exclusive scan of the thread totals over the workgroup: in the wave by shuffles ...
+        int tx = x[7], ty = y[7], tf = fy;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ox = __shfl_up(tx, d), oy = __shfl_up(ty, d), of = __shfl_up(tf, d);
+            if ((int)lane >= d) {
+                tx = max(tx, ox);
+                if (!tf) ty = max(ty, oy);
+                tf |= of;
+            }
+        }
+        if (lane == 63) { s_wx[wave] = tx; s_wy[wave] = ty; s_wf[wave] = tf; }
+        __syncthreads();
+        // ... the waves before this one (and the tile's carries) ...
+        int px = carry_o, py = carry_b, pf = 0;
+        for (uint32_t w = 0; w < wave; ++w) {
+            px = max(px, s_wx[w]);
+            if (s_wf[w]) { py = s_wy[w]; pf = 1; } else py = max(py, s_wy[w]);
+        }
+        // ... then the lanes before this one in its wave
+        const int lx = __shfl_up(tx, 1), ly = __shfl_up(ty, 1), lf = __shfl_up(tf, 1);
+        if (lane > 0) {
+            px = max(px, lx);
+            if (lf) { py = ly; pf = 1; } else py = max(py, ly);
+        }
+        (void)pf;
+        if (in) {
+            uint32_t ox[8], oy[8];
+            bool open = true;                          // still inside the segment that was open in front of this thread
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ox[e] = (uint32_t)max(x[e], px);
+                if (banded) {
+                    if (bk[e] != (e == 0 ? bprev : bk[e - 1])) open = false;
+                    oy[e] = (uint32_t)(open ? max(y[e], py) : y[e]);
+                }
+            }
+            uint32_t* wo = ord_o + ((i0 >> 3) << 4) + 8;
+            *reinterpret_cast<uint4*>(wo) = make_uint4(ox[0], ox[1], ox[2], ox[3]);
+            *reinterpret_cast<uint4*>(wo + 4) = make_uint4(ox[4], ox[5], ox[6], ox[7]);
+            if (banded) {
+                uint32_t* wb = ord_b + ((i0 >> 3) << 4) + 8;
+                *reinterpret_cast<uint4*>(wb) = make_uint4(oy[0], oy[1], oy[2], oy[3]);
+                *reinterpret_cast<uint4*>(wb + 4) = make_uint4(oy[4], oy[5], oy[6], oy[7]);
+            }
+            if (t == 1023 || tile + (t + 1) * 8 >= n) {   // the tile's last thread hands its inclusive totals on
+                s_carry[0] = (int)ox[7];
+                s_carry[1] = banded ? (int)oy[7] : INT32_MIN;
+            }
+        }
+        __syncthreads();
+        carry_o = s_carry[0];
+        carry_b = s_carry[1];
+        __syncthreads();
+    }
+}
+
 // ---- the pass -------------------------------------------------------------------------------------------------------------
 // stack entries per query: one round of cover nodes (<= W) + per level 7 more for each of the G entries opened per round (W + 21 G: 29 / 58 / 116)
 template <int G> struct FarStack { static constexpr uint32_t n = G == 1 ? 80u : G == 2 ? 96u : 160u; };
@@ -568,9 +684,10 @@ hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32
     return hipGetLastError();
 }
 
-hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, hipStream_t stream) {
-    if (n_items == 0) return hipSuccess;
-    hipLaunchKernelGGL(far_seal_kernel, dim3(n_items), dim3(64), 0, stream, F, D.far_rec, items, item0);
+// the first n_big items are nodes of 4 096 records or more: a workgroup each; the others a wave each
+hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, uint32_t n_big, hipStream_t stream) {
+    if (n_big) hipLaunchKernelGGL(far_seal_big_kernel, dim3(n_big), dim3(1024), 0, stream, F, D.far_rec, items, item0);
+    if (n_items > n_big) hipLaunchKernelGGL(far_seal_kernel, dim3(n_items - n_big), dim3(64), 0, stream, F, D.far_rec, items, item0 + n_big);
     return hipGetLastError();
 }
 

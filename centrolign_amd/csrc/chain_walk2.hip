@@ -35,6 +35,15 @@
 
 namespace {
 
+// pointers of the walk's loops are GLOBAL (address space 1), never generic: a pending flat_ store makes the compiler wait for vmcnt(0) at every
+// later wait (flat operations may return out of order), i.e. for every store of the step
+typedef __attribute__((address_space(1))) int g_i32;
+typedef __attribute__((address_space(1))) float g_f32;
+typedef __attribute__((address_space(1))) unsigned int g_u32;
+typedef __attribute__((address_space(1))) unsigned long long g_u64;
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4i32 g_i32x4;
+
 constexpr uint32_t kSub = 32;                       // pairs per sub-block: the unit the window slides by and helpers own
 constexpr uint32_t kSlots = kChainMacro / 8;        // queries a main workgroup holds per QPT (eight lanes each)
 constexpr uint32_t kPollBatch = 64;                 // granules a helper's polling wave reads at a time
@@ -53,12 +62,36 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Values that are loaded once (vector memory) and used inside the walk's loop: the compiler's wait-count bookkeeping loses track of them round the
+// loop's back edge and puts an s_waitcnt vmcnt in front of their first use in EVERY iteration — which waits for the iteration's stores.  Taken
+// through a scalar register (uniform values) or an empty asm (per-lane values) after the prologue's barrier they are no longer "loaded" values.
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+template <class T> __device__ __forceinline__ T uni_ptr(T p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned long long r = ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+    return (T)r;
+}
+__device__ __forceinline__ double uni_f64(double x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    return __longlong_as_double((long long)(((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v)));
+}
+__device__ __forceinline__ double settled(double x) { asm volatile("" : "+v"(x)); return x; }
+
+// tag of a helper's granule: the macro-block (never 0, so zeroed memory never matches) and how many of the macro-block's records [0, cov) the value covers
+__device__ __forceinline__ uint32_t cover_tag(uint32_t block, uint32_t cov) { return ((block % 0x1FFFFFu) + 1u) << 11 | cov; }
+
 // maximum over the eight lanes of a query (aligned groups of eight lanes), the same in all of them: quad_perm [1,0,3,2], quad_perm [2,3,0,1],
 // row_half_mirror (lane i <- lane 7 - i of its half row)
 __device__ __forceinline__ int max8_i(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ uint32_t min8_u(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
     return v;
 }
 __device__ __forceinline__ float max8_f(float f) {
@@ -119,10 +152,11 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
     int* s_acc = reinterpret_cast<int*>(smem + L::acc);      // what the far and near passes found (the running maxima when the launch starts)
     int* s_flags = reinterpret_cast<int*>(smem + L::flags);  // [0] abort
 
+    const unsigned long long t_entry = D.debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const ClChainCombo cb = D.combos[c];
     const uint32_t t = threadIdx.x;
     const int none = enc(CL_CHAIN_NEG);
-    const uint32_t n_combos = D.n_combos;
+    const uint32_t n_combos = uni(D.n_combos);
     {   // stage the macro-block's queries: one pair per thread, coalesced
         int4 a = make_int4(-1, 0, 0, -1), b = make_int4(-1, -1, 0, (int)count);
         float2 ww = make_float2(0.f, CL_CHAIN_NEG);
@@ -145,17 +179,17 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
     __syncthreads();
 
     const uint32_t j = t & 7u, slot = t >> 3;
-    const uint32_t lane8 = (t & 63u) & ~7u;                  // where the query's eight lanes sit in a ballot
     // this lane's tree kind: the penalty and stored-value terms of kind j = 1 + pw (anchorer.hpp:2400, 2409; :2330, 2334)
     const uint32_t pw = j >= 1 && j <= 6 ? j - 1 : 0;
-    const double go_j = D.params.gap_open[pw / 2], ge_j = D.params.gap_extend[pw / 2], sc = D.params.scale;
-
+    const double go_j = settled(pw / 2 == 0 ? D.params.gap_open[0] : pw / 2 == 1 ? D.params.gap_open[1] : D.params.gap_open[2]);   // (selects, not a load indexed by the lane)
+    const double ge_j = settled(pw / 2 == 0 ? D.params.gap_extend[0] : pw / 2 == 1 ? D.params.gap_extend[1] : D.params.gap_extend[2]);
+    const double sc = uni_f64(D.params.scale);
     uint32_t qi[QPT], qt[QPT], qoff[QPT], pos[QPT], ins[QPT], off[QPT];
     int32_t q[QPT], sig[QPT];
     float w[QPT], w_init[QPT];
     int acc[QPT][7], ext[QPT];
     double pen[QPT], tt[QPT];
-    bool act[QPT], merged[QPT];
+    bool act[QPT];
     auto load_query = [&](int u, uint32_t nq) {
         qi[u] = nq;
         act[u] = nq < count;
@@ -163,7 +197,6 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
         for (int k = 0; k < 7; ++k) acc[u][k] = none;
         ext[u] = none; qt[u] = 0; qoff[u] = 0; q[u] = 0; pos[u] = 0xFFFFFFFFu; ins[u] = 0; off[u] = 0; sig[u] = 0; w[u] = 0.f; w_init[u] = CL_CHAIN_NEG;
         pen[u] = 0.0; tt[u] = 0.0;
-        merged[u] = nq < WIN;                                 // the first window needs no helper: nothing of this macro-block precedes it
         if (act[u]) {
             const int4 a = s_q[nq], b = s_st[nq];
             const float2 ww = s_w[nq];
@@ -180,43 +213,66 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
 #pragma unroll
     for (int u = 0; u < QPT; ++u) load_query(u, slot + kSlots * u);
 
-    unsigned long long* const hacc = D.hacc + (size_t)c * kChainMacro * 8;
+    g_u64* const hacc = uni_ptr((g_u64*)(D.hacc + (size_t)c * kChainMacro * 8));
+    g_u64* const xdp = uni_ptr((g_u64*)(D.xdp + (size_t)c * kChainMacro));
+    g_u64* const xch = uni_ptr((g_u64*)D.xch);
+    g_u32* const xred = uni_ptr((g_u32*)D.xred);
+    g_u32* const status = uni_ptr((g_u32*)D.status);
+    g_i32* const acc_out = uni_ptr((g_i32*)cb.acc);
+    g_f32* const val_out = uni_ptr((g_f32*)cb.val);
+    g_f32* const dp_out = uni_ptr((g_f32*)D.dp);
+    g_i32* const far_rec = uni_ptr((g_i32*)D.far_rec);
+    const uint32_t n_recs = uni(cb.n_recs);
+    const uint32_t far_base_c = uni(D.far_rec ? D.far_base[c] : 0u);
+    const bool dbg = D.debug != 0 && c == 0;
+    uint32_t n_steps = 0, n_fin = 0, n_polled = 0, n_lds = 0;
+    unsigned long long t_pre = 0, t_bar = 0, t_post = 0, t0 = 0, t1 = 0, t2 = 0, t_pre_f = 0, t_post_f = 0, t_post_last = 0;
+    uint32_t n_fsteps = 0, n_aqmiss = 0, n_tagmiss = 0;
+    unsigned long long px[QPT];   // the helper's granule of this lane's kind for query aq[u], asked for one step before the query is finalised
+    uint32_t aq[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) { px[u] = 0; aq[u] = 0xFFFFFFFFu; }
+    const uint32_t block = first / kChainMacro;
+    const unsigned long long t_loop = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t ci = 0;
+    uint32_t ge = count ? min((uint32_t)s_st[0].w, WIN) : 0u;
     while (ci < count) {
-        const uint32_t wb = ci & ~(kSub - 1u);
-        const uint32_t ge = min((uint32_t)s_st[ci].w, wb + WIN);   // (a group longer than the window is finalised in pieces: its pairs do not precede one another)
-        // what the helpers have delivered since the last step, for the queries that are not about to be finalised: the loads are issued here
-        // and looked at after the step's work
-        unsigned long long px[QPT];
-        bool pend[QPT];
+        // (a group longer than the window is finalised in pieces: its pairs do not precede one another.)  The end of the NEXT step's group is
+        // asked for now and waited for at the bottom of the step
+        const uint32_t nwb = ge & ~(kSub - 1u);
+        const uint32_t ge_next = ge < count ? (uint32_t)s_st[ge].w : count;
+        if (dbg) { t0 = __builtin_amdgcn_s_memrealtime(); ++n_steps; }
+        // ---- finalise the pairs [ci, ge): only what the other waves wait for — the record in LDS — happens in front of the barrier
+        float best_f[QPT];
+        int mine_f[QPT];
+        bool fin[QPT];
 #pragma unroll
         for (int u = 0; u < QPT; ++u) {
-            pend[u] = helped && act[u] && !merged[u] && j < NK && qi[u] >= ge;
-            px[u] = 0;
-            if (pend[u]) px[u] = __hip_atomic_load(&hacc[(size_t)qi[u] * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- finalise the pairs [ci, ge)
-#pragma unroll
-        for (int u = 0; u < QPT; ++u) {
-            const bool fin = act[u] && qi[u] >= ci && qi[u] < ge;   // uniform over the query's eight lanes
-            if (!fin) continue;
+            best_f[u] = CL_CHAIN_NEG; mine_f[u] = none;
+            fin[u] = act[u] && qi[u] >= ci && qi[u] < ge;   // uniform over the query's eight lanes
+            if (!fin[u]) continue;
             const uint32_t s = first + qi[u];
             const uint32_t m = qi[u] / kSub;
             const uint32_t bound = m >= BW ? (m - BW + 1u) * kSub : 0u;   // records [0, bound) were final before the query entered the window
+            if (dbg && j == 0) ++n_fin;
             if (bound) {
-                bool need = !merged[u] && j < NK;
-                bool mine_need = ((__ballot(need) >> lane8) & 0xFFull) != 0;
-                if (helped)
-                    for (int tries = 0; tries < 3 && mine_need; ++tries) {
-                        if (need) {
-                            const unsigned long long x = __hip_atomic_load(&hacc[(size_t)qi[u] * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((uint32_t)(x >> 32) == s + 1u) { ext[u] = max(ext[u], (int)(uint32_t)x); need = false; merged[u] = true; }
-                        }
-                        mine_need = ((__ballot(need) >> lane8) & 0xFFull) != 0;
+                // what the query's helper has covered so far: a granule per kind, tagged with the macro-block and the number of records [0, cov) it has
+                // seen (helpers publish while they go, so a late helper costs a few evaluations here, not a wait); the rest comes out of LDS, where
+                // every record of the macro-block lies, every eighth per lane.  No granule of this macro-block (helper not resident, none launched): all of it
+                uint32_t cov = bound;
+                if (j < NK) {
+                    cov = 0;
+                    if (dbg && j == 0 && aq[u] != qi[u]) ++n_aqmiss;
+                    if (helped && aq[u] == qi[u]) {
+                        const uint32_t tg = (uint32_t)(px[u] >> 32);
+                        if (dbg && j == 0 && (tg >> 11) != (cover_tag(block, 0) >> 11)) ++n_tagmiss;
+                        if ((tg >> 11) == (cover_tag(block, 0) >> 11)) { cov = min(tg & 0x7FFu, bound); ext[u] = max(ext[u], (int)(uint32_t)px[u]); }
                     }
-                if (mine_need && qoff[u] != 0) {
-                    // no helper result (late, not resident, none launched): the same records out of LDS, every eighth per lane
-                    for (uint32_t l = j; l < bound; l += 8) {
+                }
+                cov = min8_u(cov);
+                if (dbg && j == 0 && cov < bound) { ++n_polled; if (cov == 0) ++n_lds; }
+                if (cov < bound && qoff[u] != 0) {
+                    for (uint32_t l = cov + j; l < bound; l += 8) {
                         if (SPARSE) {
                             const int4 r = *reinterpret_cast<const int4*>(&s_rec[l * RW]);
                             acc[u][0] = max(acc[u][0], ((uint32_t)r.x <= qt[u] && (uint32_t)r.y < qoff[u]) ? r.z : INT32_MIN);
@@ -227,7 +283,6 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
                         }
                     }
                 }
-                merged[u] = true;
             }
             // the query's maxima: butterfly over its eight lanes, then lane k keeps kind k
             int mine = none;
@@ -245,17 +300,17 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
             }
             cand = max8_f(cand);
             float best = fmaxf(w_init[u], cand);
-            if (n_combos > 1 && D.xred) {
+            if (n_combos > 1 && xred) {
                 // many combinations: one atomic maximum and one arrival count per pair (chain_walk_kernel's reduction)
-                uint32_t* red = D.xred + 2 * (size_t)s;
+                g_u32* red = xred + 2 * (size_t)s;
                 if (j == 0) {
                     if (cand != CL_CHAIN_NEG) __hip_atomic_fetch_max(red, (uint32_t)enc(cand) ^ 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(red + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 unsigned spins = 0;
                 while (__hip_atomic_load(red + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_combos) {
-                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(D.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        atomicExch(D.status, 1u);
+                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_exchange(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_flags[0] = 1;
                         break;
                     }
@@ -266,7 +321,7 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
             } else if (n_combos > 1) {
                 // few combinations: every workgroup reads every other's {tag, candidate} granule of the pair (chain_walk_kernel's sweep)
                 const unsigned long long tag = (unsigned long long)(s + 1u) << 32;
-                if (j == 0) __hip_atomic_store(&D.xch[(size_t)c * kChainMacro + qi[u]], tag | (unsigned)__float_as_int(cand), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j == 0) __hip_atomic_store(&xch[(size_t)c * kChainMacro + qi[u]], tag | (unsigned)__float_as_int(cand), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned spins = 0;
                 while (true) {
                     bool ok = true;
@@ -275,7 +330,7 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
                         unsigned long long x[4];
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
-                            x[v] = cc + v < n_combos ? __hip_atomic_load(&D.xch[(size_t)(cc + v) * kChainMacro + qi[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag | (unsigned)__float_as_int(CL_CHAIN_NEG);
+                            x[v] = cc + v < n_combos ? __hip_atomic_load(&xch[(size_t)(cc + v) * kChainMacro + qi[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag | (unsigned)__float_as_int(CL_CHAIN_NEG);
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             ok = ok && (x[v] >> 32) == (tag >> 32);
@@ -283,30 +338,18 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
                         }
                     }
                     if (ok) { best = mx; break; }
-                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(D.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        atomicExch(D.status, 1u);
+                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_exchange(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_flags[0] = 1;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            // results: the DP value, the value every query returned (the traceback reads it), the granule the helpers follow
-            if (j < NK) cb.acc[(size_t)s * 7 + j] = mine;
-            if (j == 0) {
-                if (c == 0) D.dp[s] = best;
-                if (helped) __hip_atomic_store(&D.xdp[(size_t)c * kChainMacro + qi[u]], ((unsigned long long)(s + 1u) << 32) | (unsigned)__float_as_int(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            best_f[u] = best; mine_f[u] = mine;
             // the pair's record of this combination: the values stored in its trees (anchorer.hpp:2318-2342), kind k by lane k
             if (pos[u] != 0xFFFFFFFFu) {
-                const float v = stored_value(best, SPARSE ? 0u : j, tt[u]);
-                const int e = enc(v);
-                if (j < NK) cb.val[(size_t)j * cb.n_recs + pos[u]] = v;
-                if (D.far_rec) {   // the image the branch-and-bound far pass reads (chain_far.hip); its two pad words stay zero
-                    int* fr = D.far_rec + (size_t)(D.far_base[c] + pos[u]) * 12;
-                    if (j == 0) *reinterpret_cast<int4*>(fr) = make_int4((int)ins[u], (int)off[u], sig[u], e);
-                    else if (j < NK) fr[3 + j] = e;
-                }
+                const int e = enc(stored_value(best, SPARSE ? 0u : j, tt[u]));
                 if (SPARSE) {
                     if (j == 0) *reinterpret_cast<int4*>(&s_rec[qi[u] * RW]) = make_int4((int)ins[u], (int)off[u], e, 0);
                 } else {
@@ -318,13 +361,66 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
                 *reinterpret_cast<int4*>(&s_rec[qi[u] * RW]) = SPARSE ? make_int4(-1, -1, INT32_MIN, 0) : make_int4(-1, -1, 0, INT32_MIN);
             }
         }
+        if (dbg) {
+            t1 = __builtin_amdgcn_s_memrealtime();
+            bool anyfin = false;
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) anyfin = anyfin || fin[u];
+            if (__ballot(anyfin) != 0ull) { ++n_fsteps; t_pre_f += t1 - t0; t_post_f += t_post_last; }
+        }
+        lds_barrier();
+        if (dbg) t2 = __builtin_amdgcn_s_memrealtime();
+        if (n_combos > 1 && s_flags[0]) break;
         // ---- slide the window: the sub-blocks the walk has left make room for the next ones, which see this step's records too
-        const uint32_t nwb = ge & ~(kSub - 1u);
+        bool slid[QPT];
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) slid[u] = qi[u] < nwb;
+        {   // the waves that hold the NEXT step's pairs go first: their records-to-queries work and their finalisation are the step's critical chain,
+            // everything else (the other waves' share of this step's records) fills the issue slots they leave.  Those pairs also ask for their
+            // helpers' granules now: by the time they are finalised, a step of work later, the loads have come back
+            const uint32_t ge2 = min(ge_next, nwb + WIN);
+            bool nf[QPT], any = false;
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const uint32_t nq = slid[u] ? qi[u] + WIN : qi[u];
+                nf[u] = nq < count && nq >= ge && nq < ge2;
+                any = any || nf[u];
+            }
+            if (__ballot(any) != 0ull) {
+                __builtin_amdgcn_s_setprio(3);
+                if (helped) {
+#pragma unroll
+                    for (int u = 0; u < QPT; ++u) {
+                        const uint32_t nq = slid[u] ? qi[u] + WIN : qi[u];
+                        if (nf[u] && nq >= WIN && j < NK) { px[u] = __hip_atomic_load(&hacc[(size_t)nq * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aq[u] = nq; }
+                    }
+                }
+            } else __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- behind the barrier, off the other waves' path: what goes to memory for the pairs just finalised — the DP value, the value every query
+        //      returned (the traceback reads it), the granule the helpers follow, the record's stored values and its image for the far pass
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            if (!fin[u]) continue;
+            const uint32_t s = first + qi[u];
+            if (j < NK) acc_out[(size_t)s * 7 + j] = mine_f[u];
+            if (j == 0) {
+                if (c == 0) dp_out[s] = best_f[u];
+                if (helped) __hip_atomic_store(&xdp[qi[u]], ((unsigned long long)(s + 1u) << 32) | (unsigned)__float_as_int(best_f[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (pos[u] != 0xFFFFFFFFu && j < NK) {
+                const float v = stored_value(best_f[u], SPARSE ? 0u : j, tt[u]);
+                val_out[(size_t)j * n_recs + pos[u]] = v;
+                if (far_rec) {   // the image the branch-and-bound far pass reads (chain_far.hip); its two pad words stay zero
+                    g_i32* fr = far_rec + (size_t)(far_base_c + pos[u]) * 12;
+                    if (j == 0) *(g_i32x4*)fr = v4i32{(int)ins[u], (int)off[u], sig[u], enc(v)};
+                    else fr[3 + j] = enc(v);
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < QPT; ++u)
-            if (qi[u] < nwb) load_query(u, qi[u] + WIN);
-        lds_barrier();
-        if (s_flags[0]) break;
+            if (slid[u]) load_query(u, qi[u] + WIN);
         // ---- this step's records to the window's queries: every eighth record per lane, the two queries of a lane share the reads
         {
             bool go[QPT];
@@ -333,7 +429,18 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
             for (int u = 0; u < QPT; ++u) { go[u] = act[u] && qi[u] >= ge && qoff[u] != 0; any = any || go[u]; }
             if (any) {
                 if (SPARSE) {
-                    for (uint32_t l = ci + j; l < ge; l += 8) {
+                    uint32_t l = ci + j;
+                    for (; l + 24 < ge; l += 32) {   // four reads in flight: the loop is bound by LDS latency, not by its five operations per record
+                        int4 r[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const int4*>(&s_rec[(l + 8 * v) * RW]);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int u = 0; u < QPT; ++u)
+                                if (go[u]) acc[u][0] = max(acc[u][0], ((uint32_t)r[v].x <= qt[u] && (uint32_t)r[v].y < qoff[u]) ? r[v].z : INT32_MIN);
+                    }
+                    for (; l < ge; l += 8) {
                         const int4 r = *reinterpret_cast<const int4*>(&s_rec[l * RW]);
 #pragma unroll
                         for (int u = 0; u < QPT; ++u)
@@ -365,11 +472,18 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
                 }
             }
         }
-        // ---- the helper granules asked for at the top of the step
-#pragma unroll
-        for (int u = 0; u < QPT; ++u)
-            if (pend[u] && (uint32_t)(px[u] >> 32) == first + qi[u] + 1u) { ext[u] = max(ext[u], (int)(uint32_t)px[u]); merged[u] = true; }
         ci = ge;
+        ge = min(ge_next, (ci & ~(kSub - 1u)) + WIN);
+        if (dbg) { const unsigned long long t3 = __builtin_amdgcn_s_memrealtime(); t_pre += t1 - t0; t_bar += t2 - t1; t_post += t3 - t2; t_post_last = t3 - t2; }
+    }
+    if (dbg) {
+        if (t == 0) { atomicAdd(D.status + 22, (uint32_t)(t_loop - t_entry)); atomicAdd(D.status + 23, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_loop)); atomicAdd(D.status + 24, 1u);
+                      atomicAdd(D.status + 19, n_fsteps); atomicAdd(D.status + 20, (uint32_t)t_pre_f); atomicAdd(D.status + 21, (uint32_t)t_post_f); atomicAdd(D.status + 8, n_steps); atomicAdd(D.status + 12, (uint32_t)t_pre); atomicAdd(D.status + 13, (uint32_t)t_bar); atomicAdd(D.status + 14, (uint32_t)t_post); }
+        if (n_fin) atomicAdd(D.status + 9, n_fin);
+        if (n_polled) atomicAdd(D.status + 10, n_polled);
+        if (n_lds) atomicAdd(D.status + 11, n_lds);
+        if (n_aqmiss) atomicAdd(D.status + 25, n_aqmiss);
+        if (n_tagmiss) atomicAdd(D.status + 26, n_tagmiss);
     }
 }
 
@@ -416,26 +530,34 @@ __device__ __forceinline__ void walk2_helper(const ClChainDevice& D, const uint3
 #pragma unroll
     for (int k = 0; k < 7; ++k) acc[k] = none;
     bool published = !act;
-    const unsigned long long* xdp = D.xdp + (size_t)c * kChainMacro;
-    unsigned long long* hacc = D.hacc + (size_t)c * kChainMacro * 8;
+    const g_u64* xdp = (const g_u64*)(D.xdp + (size_t)c * kChainMacro);
+    g_u64* hacc = (g_u64*)(D.hacc + (size_t)c * kChainMacro * 8);
+    const g_u32* status = (const g_u32*)D.status;
     const double sc = D.params.scale;
+    const bool dbg = D.debug != 0 && c == 0 && h == 0;
+    uint32_t n_batches = 0, n_idle = 0;
+    const uint32_t block = first / kChainMacro;
+    constexpr uint32_t kEager = 128;     // a sub-block's maxima go out after every batch once its queries are this close to having seen everything they need
     uint32_t p = 0, b = 0;
+    // the polling wave keeps one load of the next granules in flight while the workgroup evaluates a batch
+    unsigned long long x = 0;
+    if (t < 64) x = t < pmax ? __hip_atomic_load(&xdp[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     while (p < pmax) {
         if (t < 64) {
-            // the polling wave: the longest run of fresh granules from p on, turned into records
+            // the longest run of fresh granules from p on, turned into records
             uint32_t n = 0;
-            unsigned long long x = 0;
             unsigned spins = 0;
             while (true) {
                 const bool in = p + t < pmax;
-                x = in ? __hip_atomic_load(&xdp[p + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 const bool ok = in && (uint32_t)(x >> 32) == first + p + t + 1u;
                 const unsigned long long bad = ~__ballot(ok);
                 n = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
                 if (n) break;
+                if (dbg) ++n_idle;
                 // the main workgroup has given up (a sibling combination never arrived), or is not there: nothing depends on this helper
-                if (++spins > (1u << 18) || ((spins & 255u) == 0 && __hip_atomic_load(D.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { n = 0xFFFFFFFFu; break; }
-                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 18) || ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { n = 0xFFFFFFFFu; break; }
+                __builtin_amdgcn_s_sleep(1);
+                x = in ? __hip_atomic_load(&xdp[p + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             }
             if (n != 0xFFFFFFFFu && t < n) {
                 const int4 st = s_stat[p + t];
@@ -459,6 +581,8 @@ __device__ __forceinline__ void walk2_helper(const ClChainDevice& D, const uint3
                 }
             }
             if (t == 0) s_n[b] = n;
+            // the next poll is on its way while the batch is evaluated
+            if (n != 0xFFFFFFFFu) x = p + n + t < pmax ? __hip_atomic_load(&xdp[p + n + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         }
         lds_barrier();
         const uint32_t n = s_n[b];
@@ -478,19 +602,23 @@ __device__ __forceinline__ void walk2_helper(const ClChainDevice& D, const uint3
             }
         }
         p += n;
-        if (!published && bound <= p) {
-            // every record the sub-block's queries need from here has been seen: the maxima go to the main workgroup, kind k by lane k
+        if (dbg) ++n_batches;
+        if (!published && bound <= p + kEager) {
+            // the maxima so far go to the main workgroup, kind k by lane k, tagged with how much they cover: it takes what is there when it finalises
+            // the query and evaluates the rest itself, so a helper that is a batch behind costs it eight evaluations, not a wait
+            const uint32_t cov = min(p, bound);
             int mine = none;
 #pragma unroll
             for (uint32_t k = 0; k < NK; ++k) {
                 const int r = max8_i(acc[k]);
                 mine = j == k ? r : mine;
             }
-            if (j < NK) __hip_atomic_store(&hacc[(size_t)qp * 8 + j], ((unsigned long long)(first + qp + 1u) << 32) | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            published = true;
+            if (j < NK) __hip_atomic_store(&hacc[(size_t)qp * 8 + j], ((unsigned long long)cover_tag(block, cov) << 32) | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            published = cov == bound;
         }
         b ^= 1u;
     }
+    if (dbg && t == 0) { atomicAdd(D.status + 16, n_batches); atomicAdd(D.status + 17, p); atomicAdd(D.status + 18, n_idle); }
 }
 
 // blockIdx.x = role * stride + c with stride a multiple of 8: the main workgroup of a combination (role 0) and its helpers (roles 1 ..) land on

@@ -52,7 +52,7 @@ hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* ke
 hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream);
 hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32_t n, uint32_t* arena, uint32_t ord_off, const uint32_t* ix, uint32_t n_ix,
                                hipStream_t stream);
-hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, hipStream_t stream);
+hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, uint32_t n_big, hipStream_t stream);
 hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream);
 hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t first, uint32_t count, uint32_t share_n, uint32_t share_i, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
@@ -769,6 +769,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<char> d_far_temp;
     ClFarDevice F{};
     std::vector<uint32_t> seal_off;   // [n_macro + 1] into d_seal_items
+    std::vector<uint32_t> seal_big;   // [n_macro] how many of a macro-block's items (its first ones) are nodes of 4 096 records or more
     // the walk kernel (one workgroup per combination, all resident) replaces the per-block intra launches up to
     // kChainWalkMaxCombos combinations; CL_CHAIN_OLD_WALK=1 forces the per-block path (A/B measurements)
     static const bool old_walk_env = getenv("CL_CHAIN_OLD_WALK") != nullptr;
@@ -801,7 +802,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     }
     const size_t o_combos = reserve(combos.size() * sizeof(ClChainCombo)), o_weight = reserve(M * 4), o_init = reserve(M * 4), o_rec_off = reserve((M + 1) * 4),
                  o_rec_combo = reserve(rec_combo.size() * 4), o_rec_pos = reserve(rec_pos.size() * 4);
-    const size_t o_xch = use_walk ? reserve(combos.size() * kChainMacro * sizeof(unsigned long long)) : 0, o_status = use_walk ? reserve(8 * sizeof(uint32_t)) : 0;   // zeroed
+    const size_t o_xch = use_walk ? reserve(combos.size() * kChainMacro * sizeof(unsigned long long)) : 0, o_status = use_walk ? reserve(32 * sizeof(uint32_t)) : 0;   // zeroed
     const size_t o_dp = reserve(M * 4);   // what comes back: the DP values, every combination's stored values (the traceback's value index) and query results
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].val = reserve(7 * combos[ci].rec_s.size() * 4);
     for (size_t ci = 0; ci < combos.size(); ++ci) po[ci].acc = reserve(M * 7 * 4);
@@ -842,7 +843,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         put(o_rec_off, rec_off.data(), (M + 1) * 4); put(o_rec_combo, rec_combo.data(), rec_combo.size() * 4); put(o_rec_pos, rec_pos.data(), rec_pos.size() * 4);
         d_combos.view((ClChainCombo*)(dev + o_combos), hc.size()); d_weight.view((float*)(dev + o_weight), M); d_init.view((float*)(dev + o_init), M);
         d_dp.view((float*)(dev + o_dp), M);
-        if (use_walk) { d_xch.view((unsigned long long*)(dev + o_xch), combos.size() * kChainMacro); d_status.view((uint32_t*)(dev + o_status), 8); }
+        if (use_walk) { d_xch.view((unsigned long long*)(dev + o_xch), combos.size() * kChainMacro); d_status.view((uint32_t*)(dev + o_status), 32); }
         d_rec_off.view((uint32_t*)(dev + o_rec_off), M + 1); d_rec_combo.view((uint32_t*)(dev + o_rec_combo), rec_combo.size()); d_rec_pos.view((uint32_t*)(dev + o_rec_pos), rec_pos.size());
         pack_dp_off = o_dp;
         pack_acc_stride = combos.size() > 1 ? po[1].acc - po[0].acc : (((size_t)M * 7 * 4 + 255) & ~(size_t)255);
@@ -928,9 +929,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
             if (!d_pack.p) {   // (a small DP's pack holds them, zeroed)
                 CH(d_xch.alloc(ctx, combos.size() * kChainMacro));
-                CH(d_status.alloc(ctx, 8));
+                CH(d_status.alloc(ctx, 32));
                 if (hipMemsetAsync(d_xch.p, 0, combos.size() * kChainMacro * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
-                    hipMemsetAsync(d_status.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+                    hipMemsetAsync(d_status.p, 0, 32 * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
             }
             // the exchange between the walk's workgroups: granule sweep for few combinations, reduction for many (CL_CHAIN_WALK_REDUCE=0/1 pins it: A/B)
             static const char* reduce_env = getenv("CL_CHAIN_WALK_REDUCE");
@@ -975,6 +976,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     D.xred = d_xred.p;
     D.xdp = d_xdp.p;
     D.hacc = d_hacc.p;
+    static const bool walk2_debug = getenv("CL_CHAIN_WALK2_DEBUG") != nullptr;   // in-kernel counters and clocks of the walk (status[8..]), printed with CL_CHAIN_TIMING
+    D.debug = use_walk2 && walk2_debug ? 1u : 0u;
     D.status = d_status.p;
 
 
@@ -1105,7 +1108,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
             std::vector<uint32_t> items;
             seal_off.assign(n_macro_all + 1, 0);
+            static const bool seal_wave_only = getenv("CL_CHAIN_SEAL_WAVE") != nullptr;   // A/B: every node by one wave (rounds 2-3)
+            seal_big.assign(n_macro_all, 0);
             for (uint32_t k = 0; k < n_macro_all; ++k) {
+                // large nodes first: they get a workgroup each (far_seal_big_kernel), the others a wave each
+                std::stable_sort(by_macro[k].begin(), by_macro[k].end(), [](uint32_t a, uint32_t b) { return (a >> 28) > (b >> 28); });
+                if (!seal_wave_only) for (uint32_t it : by_macro[k]) seal_big[k] += (it >> 28) >= 2 ? 1u : 0u;
                 items.insert(items.end(), by_macro[k].begin(), by_macro[k].end());
                 seal_off[k + 1] = (uint32_t)items.size();
             }
@@ -1256,12 +1264,26 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess) he = cl_ring_event(ctx, 1, k, &ev_far[k]);
                 if (he == hipSuccess) he = hipEventRecord(ev_far[k], far_stream);
             }
+            hipEvent_t ev_near_a = nullptr;
             if (he == hipSuccess && b0 > near_lo) {
-                // the far pass stops at a leaf boundary: the near launch starts there
+                // the far pass stops at a leaf boundary: the near launch starts there.  Only the records of macro-block k - 1 need walk(k - 1): they
+                // are swept on the serial stream; the older macro-blocks of the near range were final one walk earlier and are swept on a stream
+                // of their own beside walk(k - 1) — with CL_CHAIN_NEAR_SPLIT=1 only: by default one launch on the serial stream, as in rounds 2-3
+                static const bool near_split = [] { const char* e = getenv("CL_CHAIN_NEAR_SPLIT"); return e && e[0] == '1'; }();   // (measured SLOWER: 2 x 1 Mbp affine DP 162 -> 230 ms — the extra stream and its two event hops per macro-block cost more than the sweep they take off the serial stream; off unless asked for)
+                const uint32_t b_split = near_split && k >= 2 ? std::max(near_lo, (k - 1) * bpm) : near_lo;
                 ClChainDevice Dn = D;
                 if (use_far && near_lo > 0) Dn.lo_mask = 63u;
-                he = cl_chain_launch_inter(Dn, first, count, near_lo, b0, max_recs(near_lo, b0) + Dn.lo_mask, kChainNearTile, ctx->stream);
+                if (b_split > near_lo) {
+                    hipStream_t near_stream = ctx->aux[(use_far ? far_lag : far_streams) + 1];
+                    he = hipStreamWaitEvent(near_stream, ev_walk[k - 2], 0);
+                    if (he == hipSuccess) he = cl_chain_launch_inter(Dn, first, count, near_lo, b_split, max_recs(near_lo, b_split) + Dn.lo_mask, kChainNearTile, near_stream);
+                    if (he == hipSuccess) he = cl_ring_event(ctx, 3, k, &ev_near_a);
+                    if (he == hipSuccess) he = hipEventRecord(ev_near_a, near_stream);
+                    Dn.lo_mask = 0;
+                }
+                if (he == hipSuccess) he = cl_chain_launch_inter(Dn, first, count, b_split, b0, max_recs(b_split, b0) + Dn.lo_mask, kChainNearTile, ctx->stream);
             }
+            if (he == hipSuccess && ev_near_a) he = hipStreamWaitEvent(ctx->stream, ev_near_a, 0);
             if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
             if (shared && near_lo > 0) {
                 // the other members' combinations of this macro-block: wait for their arrival words, fold their slot into the running maxima
@@ -1276,7 +1298,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
             if (use_far && far_bb && he == hipSuccess && k + far_lag + 1 < n_macro) {
                 he = hipStreamWaitEvent(seal_stream, ev_walk[k], 0);
-                if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_stream);
+                if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_big[k], seal_stream);
                 if (he == hipSuccess) he = cl_ring_event(ctx, 2, k, &ev_seal[k]);
                 if (he == hipSuccess) he = hipEventRecord(ev_seal[k], seal_stream);
             }
@@ -1345,6 +1367,14 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         uint32_t status = 0;
         he = cl_copy_sync(ctx, &status, d_status.p, sizeof(status), hipMemcpyDeviceToHost);
         if (he != hipSuccess) return hip_fail(he, "chaining DP status");
+        if (D.debug) {
+            uint32_t dbg[32] = {};
+            (void)cl_copy_sync(ctx, dbg, d_status.p, sizeof(dbg), hipMemcpyDeviceToHost);
+            const double steps = std::max(1u, dbg[8]);
+            fprintf(stderr, "[chain_dp_batch]   walk2: %u steps of combination 0, %u queries finalised, %u polled at their finalisation, %u evaluated out of LDS (no helper result); "
+                            "wave 0 per step (100 MHz ticks): before the barrier %.1f, in the barrier %.1f, behind it %.1f; helper batches %u, records %u, polls without news %u; wave 0 finalised in %u steps: %.1f ticks before the barrier there, %.1f behind the barrier before; per launch: %.1f ticks in front of the loop, %.1f in it; not asked %u, no granule of the block %u\n",
+                    dbg[8], dbg[9], dbg[10], dbg[11], dbg[12] / steps, dbg[13] / steps, dbg[14] / steps, dbg[16], dbg[17], dbg[18], dbg[19], dbg[20] / (double)std::max(1u, dbg[19]), dbg[21] / (double)std::max(1u, dbg[19]), dbg[22] / (double)std::max(1u, dbg[24]), dbg[23] / (double)std::max(1u, dbg[24]), dbg[25], dbg[26]);
+        }
         static const bool debug_stall = getenv("CL_CHAIN_DEBUG_STALL") != nullptr;   // test hook: behave as if a wait had expired
         if (debug_stall) status = 1;
         if (status != 0) {

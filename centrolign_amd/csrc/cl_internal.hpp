@@ -42,7 +42,7 @@ struct cl_context {
     // pool holds more than kPoolCap bytes.
     // events the chaining DP records once per macro-block (walk done / far done / sealed): three rings, made once and reused — an event wait
     // refers to the record that precedes it, so a slot can be recorded again as soon as its waits have been enqueued (a few blocks later)
-    hipEvent_t ev_ring[3][32] = {};
+    hipEvent_t ev_ring[4][32] = {};
     // the merge group this context shares the far pass of its chaining DPs with (cl_peer_api.cpp); n <= 1: none
     struct Peers {
         uint32_t n = 0, me = 0;
