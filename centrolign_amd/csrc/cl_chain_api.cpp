@@ -812,10 +812,14 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // CL_CHAIN_WALK2=0 keeps chain_walk_kernel (A/B), CL_CHAIN_WALK2_QPT=1/2 the window, CL_CHAIN_WALK2_HELPERS=n the helpers (0: the main
     // workgroup evaluates everything itself out of LDS — the path it takes when a helper is late)
     static const bool walk2_env = [] { const char* e = getenv("CL_CHAIN_WALK2"); return !e || e[0] != '0'; }();
-    static const uint32_t walk2_qpt = [] { const char* e = getenv("CL_CHAIN_WALK2_QPT"); return e && e[0] == '1' ? 1u : 2u; }();
+    // (window: 2 x 1 Mbp affine / gap-free DP 157 / 90 ms with 128 queries, 165 / 92 ms with 256; 10 x 1 Mbp merges of 1 / 4 / 25 combinations, device time of
+    // both DPs on one context: 165 / 285 / 1 158 ms here against 273 / 390 / 874 ms on chain_walk_kernel — at 25 combinations 200 workgroups of 1 024 threads
+    // and 120 KB of LDS leave the far and near launches too little of the chip, so the one-workgroup walk stays above CL_CHAIN_WALK2_MAX combinations)
+    static const uint32_t walk2_qpt = [] { const char* e = getenv("CL_CHAIN_WALK2_QPT"); return e && e[0] == '2' ? 2u : 1u; }();
+    static const uint32_t walk2_max = [] { const char* e = getenv("CL_CHAIN_WALK2_MAX"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : 8u; }();
     static const int walk2_help_env = [] { const char* e = getenv("CL_CHAIN_WALK2_HELPERS"); return e ? atoi(e) : -1; }();
     uint32_t walk2_help = cl_chain_walk2_helpers(walk2_qpt);
-    const bool use_walk2 = use_walk && !packed && walk2_env && ((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help) <= 256;
+    const bool use_walk2 = use_walk && !packed && walk2_env && combos.size() <= walk2_max && ((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help) <= 256;
     if (walk2_help_env >= 0) walk2_help = (uint32_t)std::min(walk2_help_env, 7);
     if (packed) {
         CH(d_pack.alloc(ctx, pack_total));

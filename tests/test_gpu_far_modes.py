@@ -32,13 +32,13 @@ VARIANTS = [
     ("lanes8", {"CL_CHAIN_FAR_LANES": "8"}),
     ("lanes16", {"CL_CHAIN_FAR_LANES": "16"}),
     # round 4: the walk of a macro-block over several compute units per combination (chain_walk2.hip) is the default; one compute unit per
-    # combination as in rounds 2-3; a window of 128 instead of 256 queries; no helper workgroups at all (the main workgroup then evaluates
+    # combination as in rounds 2-3; a window of 256 instead of 128 queries; no helper workgroups at all (the main workgroup then evaluates
     # everything itself out of LDS: the path it takes whenever a helper is late); too few helpers (some sub-blocks helped, some not)
     ("walk1", {"CL_CHAIN_WALK2": "0"}),
-    ("walk2_window128", {"CL_CHAIN_WALK2_QPT": "1"}),
+    ("walk2_window256", {"CL_CHAIN_WALK2_QPT": "2"}),
     ("walk2_no_helpers", {"CL_CHAIN_WALK2_HELPERS": "0"}),
     ("walk2_two_helpers", {"CL_CHAIN_WALK2_HELPERS": "2"}),
-    ("walk2_reduce", {"CL_CHAIN_WALK_REDUCE": "1", "CL_CHAIN_WALK2_QPT": "1"}),
+    ("walk2_reduce", {"CL_CHAIN_WALK_REDUCE": "1", "CL_CHAIN_WALK2_QPT": "2"}),
     # large nodes of the far pass sealed by one wave each (rounds 2-3) instead of a workgroup each (far_seal_big_kernel); the near sweep as one launch
     ("seal_by_waves", {"CL_CHAIN_SEAL_WAVE": "1", "CL_CHAIN_FAR_MODE": "bb"}),
     ("near_in_two_launches", {"CL_CHAIN_NEAR_SPLIT": "1"}),
