@@ -25,6 +25,7 @@
 #include <sstream>
 
 #include "centrolign/core.hpp"
+#include "centrolign/gfa.hpp"
 #include "centrolign/parameters.hpp"
 #include "centrolign/stitcher.hpp"
 #include "centrolign/utility.hpp"
@@ -32,6 +33,7 @@
 #include "../include/centrolign_amd/stitch_adapter.hpp"
 #include "../include/centrolign_amd/core_adapter.hpp"
 #include "../include/centrolign_amd/seam_wrappers.hpp"
+#include "../include/centrolign_amd/core_facade.hpp"
 
 using namespace centrolign;
 
@@ -282,9 +284,51 @@ struct DemoCore : public Core {
 
 }  // namespace
 
+// "facade": the reference's own Core (files in, execute(), root subproblem out) beside centrolign_amd::Core of
+// include/centrolign_amd/core_facade.hpp, the same calls in the same order — and the same GFA / CIGAR text
+static int facade_mode(int argc, char** argv) {
+    const std::string fasta = argv[1], tree_file = (argc > 2 && std::string(argv[2]) != "-") ? argv[2] : "";
+    Parameters params;
+    params.set<std::string>("fasta_name", fasta);
+    if (argc > 3) params.set<int64_t>("max_num_match_pairs", atoll(argv[3]));
+    params.validate();
+    logging::level = logging::Silent;
+    std::string want;
+    {
+        std::ifstream fin(fasta);
+        auto parsed = parse_fasta(fin);
+        std::vector<std::string> names;
+        for (const auto& p : parsed) names.push_back(p.first);
+        std::string newick = in_order_newick_string(names);
+        if (!tree_file.empty()) { std::ifstream tin(tree_file); std::stringstream ss; ss << tin.rdbuf(); newick = ss.str(); }
+        Tree tree(newick);
+        Core core(std::move(parsed), std::move(tree));
+        params.apply(core);
+        core.execute();
+        std::stringstream out;
+        const auto& root = core.root_subproblem();
+        if (names.size() == 2) out << explicit_cigar(root.alignment, core.leaf_subproblem(names[0]).graph, core.leaf_subproblem(names[1]).graph) << '\n';
+        else write_gfa(root.graph, root.tableau, out);
+        want = out.str();
+    }
+    centrolign_amd::Core core(fasta, tree_file);
+    if (argc > 3) core.anchorer.max_num_match_pairs = (uint64_t)atoll(argv[3]);
+    core.execute();
+    std::string got = core.output();
+    while (!got.empty() && got.back() == '\n') got.pop_back();
+    while (!want.empty() && want.back() == '\n') want.pop_back();
+    const auto& root = core.root_subproblem();
+    printf("facade: root subproblem %llu nodes, %llu paths, %zu aligned pairs, complete %d; output %zu bytes %s the reference's Core (%zu bytes)\n",
+           (unsigned long long)root.graph.n_nodes, (unsigned long long)root.graph.n_paths, root.alignment.size(), (int)root.complete, got.size(),
+           got == want ? "==" : "!=", want.size());
+    printf(got == want ? "DROP-IN OK\n" : "DROP-IN FAILED\n");
+    return got == want ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <fasta> [newick|-] [max_num_match_pairs]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <fasta> [newick|-] [max_num_match_pairs] [core|seams|facade]\n", argv[0]); return 2; }
     try {
+        if (argc > 4 && std::string(argv[4]) == "facade") return facade_mode(argc, argv);
         Parameters params;
         params.set<std::string>("fasta_name", argv[1]);
         if (argc > 3) params.set<int64_t>("max_num_match_pairs", atoll(argv[3]));

@@ -79,3 +79,24 @@ def test_reference_signatures_at_the_seams(tmp_path, seed, length, n, max_pairs)
     assert p.stdout.count("anchor_chain wrapper == the reference (") >= (1 if n == 2 else 3)
     assert p.stdout.count("po_poa<1|2|3> wrapper == on") == (1 if n == 2 else 3)
     assert p.stdout.count("masked + split anchor_chain wrapper == the reference") == (1 if n == 2 else 3)
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/adapter_demo not built (needs the reference sources)")
+@pytest.mark.parametrize("seed,length,n,max_pairs", [(31, 40000, 2, 60000), (32, 20000, 5, 40000)])
+def test_core_facade_prints_what_the_references_core_prints(tmp_path, seed, length, n, max_pairs):
+    """include/centrolign_amd/core_facade.hpp: centrolign_amd::Core / Execution with the reference's member names (core.hpp:30-103,
+    execution.hpp:33-120) — Core(fasta, tree), tunables, execute(), root_subproblem() — beside the unmodified reference's Core on the
+    same files: the same CIGAR (two sequences) / GFA (five sequences, an unbalanced guide tree with an internal node of three leaves)"""
+    seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs)
+    nwk = "-"
+    if n == 5:
+        nwk = str(tmp_path / "tree.nwk")
+        with open(nwk, "w") as f:
+            f.write("((seq0,seq1),((seq2,seq3),seq4));")
+    p = subprocess.run([DEMO, fa, nwk, str(max_pairs), "facade"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    print(p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DROP-IN OK" in p.stdout and "== the reference's Core" in p.stdout
