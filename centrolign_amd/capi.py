@@ -663,7 +663,8 @@ class PolishParams(C.Structure):
 
 class MsaParams(C.Structure):
     """cl_msa_params"""
-    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int), ("n_workers", C.c_int), ("subproblems_prefix", C.c_char_p), ("restart", C.c_int),
+    _fields_ = [("merge", MergeParams), ("skip_calibration", C.c_int), ("n_workers", C.c_int), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int),
+                ("subproblems_prefix", C.c_char_p), ("restart", C.c_int),
                 ("induced_pairwise_prefix", C.c_char_p), ("cyclize", C.c_int), ("max_tandem_duplication_search_rounds", C.c_uint64),
                 ("bonds", BondParams), ("polish", PolishParams)]
 
@@ -975,7 +976,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 6     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 7     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1631,9 +1632,10 @@ class Context:
             self.lib.cl_merge_result_free(C.byref(out))
 
     def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False, subproblems_prefix=None,
-            restart=False, induced_pairwise_prefix=None, workers=1, cyclize=False, min_cyclizing_length=None):
+            restart=False, induced_pairwise_prefix=None, workers=1, cyclize=False, min_cyclizing_length=None, devices=None):
         """the whole CLI flow in the library (cl_msa): FASTA text (+ Newick text) -> explicit CIGAR (two sequences) or GFA; returns
-        (text bytes, stats dict).  cyclize = the CLI's -c, min_cyclizing_length its -y"""
+        (text bytes, stats dict).  cyclize = the CLI's -c, min_cyclizing_length its -y; devices = device ordinals the worker contexts are
+        spread over (worker w on devices[w % len(devices)]; one process, several GPUs)"""
         raw = fasta_text.encode() if isinstance(fasta_text, str) else bytes(fasta_text)
         mp = MsaParams()
         self.lib.cl_msa_params_default(C.byref(mp))
@@ -1641,6 +1643,10 @@ class Context:
         mp.merge.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
         mp.skip_calibration = int(skip_calibration)
         mp.n_workers = int(workers)
+        dev_arr = None
+        if devices:
+            dev_arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            mp.devices, mp.n_devices = C.cast(dev_arr, C.POINTER(C.c_int)), len(devices)
         mp.subproblems_prefix = subproblems_prefix.encode() if subproblems_prefix else None   # -S
         mp.restart = int(restart)                                                             # -R
         mp.induced_pairwise_prefix = induced_pairwise_prefix.encode() if induced_pairwise_prefix else None   # -A

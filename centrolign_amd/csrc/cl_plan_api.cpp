@@ -482,7 +482,7 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
     const int n_workers = std::max(1, std::min(params->n_workers, 16));
     std::vector<cl_context*> workers(1, ctx);
     for (int w = 1; w < n_workers; ++w) {
-        cl_context* c = cl_context_create(ctx->device);
+        cl_context* c = cl_context_create(params->devices && params->n_devices > 0 ? params->devices[w % params->n_devices] : ctx->device);
         if (!c) break;
         workers.push_back(c);
     }

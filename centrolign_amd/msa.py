@@ -51,7 +51,7 @@ def emit_subproblem(prefix, graph, paths):
 
 
 def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None, verbose=False,
-                    keep_merges=False, subproblems_prefix=None, restart=False):
+                    keep_merges=False, subproblems_prefix=None, restart=False, devices=None):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
@@ -65,6 +65,11 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
             leaves = dict(zip(order, pool.map(lambda nm: capi.leaf_graph(sequences[nm]), order)))
     else:
         leaves = {nm: capi.leaf_graph(sequences[nm]) for nm in order}
+    # devices = [ordinals]: worker w sits on devices[w % len(devices)] — one process, several GPUs (graphs are host arrays at the C ABI, so
+    # nothing travels between the devices but the calls); worker 0 is ctx itself
+    if make_context is None and devices:
+        _next = iter(range(1, 1 << 30))
+        make_context = lambda: capi.Context(int(devices[next(_next) % len(devices)]))   # noqa: E731
     make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
     contexts = [ctx] + [make_context() for _ in range(max(1, int(workers)) - 1)]
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0)

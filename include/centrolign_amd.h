@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 6   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 7   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -733,7 +733,11 @@ void cl_msa_plan_free(cl_msa_plan* p);
 typedef struct cl_msa_params {
     cl_merge_params merge;            /* merge.align.anchor.score_scale is overwritten by the calibration unless it is skipped */
     int             skip_calibration; /* --skip-calibration of the CLI */
-    int             n_workers;        /* contexts (threads) that run leaf calibrations and independent merges side by side on ctx's device; <= 1: one */
+    int             n_workers;        /* contexts (threads) that run leaf calibrations and independent merges side by side; <= 1: one */
+    const int*      devices;          /* where the worker contexts sit: worker w on device ordinal devices[w % n_devices] (worker 0 is ctx itself and stays on
+                                         ctx's device); NULL / n_devices 0: all on ctx's device.  One process, several GPUs: graphs are host arrays at this
+                                         boundary, so nothing travels between devices but the calls */
+    int             n_devices;
     const char*     subproblems_prefix;      /* -S: every finished subproblem is written as PREFIX_<hash>.gfa, one line each in PREFIX_info.txt
                                                 (Core::emit_subproblem, src/core.cpp:397-422); NULL: off */
     int             restart;                 /* -R: subproblems whose files exist are loaded instead of computed (Execution::restart,

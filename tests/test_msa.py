@@ -120,6 +120,20 @@ WIDE = {"wide_merge_24x7k": (24, 91, 7000, "q"), "wide_merge_50x5k": (50, 92, 50
 
 
 @pytest.mark.gpu
+def test_gpu_worker_contexts_on_a_list_of_devices(gpu_ctx):
+    """one process, several devices: the worker contexts of cl_msa / progressive_msa are spread over a list of device ordinals
+    (cl_msa_params.devices; worker w on devices[w % n]).  A box here has one GPU, so the list names it several times — the code path a
+    multi-GPU node takes (contexts created per ordinal, hipSetDevice at every entry point), with the reference's ten-sequence GFA"""
+    names, seqs, tree = synth.c3_workload(30000)
+    want = bytes(ZB["msa10_30k.gfa"])
+    r = msa.progressive_msa(gpu_ctx, seqs, tree, max_num_match_pairs=200000, workers=4, devices=[0, 0, 0])
+    assert msa.output_text(r) == want
+    fasta = "".join(">%s\n%s\n" % (nm, seqs[nm]) for nm in names)
+    got, st = gpu_ctx.msa(fasta, newick=synth.C3_NEWICK, max_num_match_pairs=200000, workers=3, devices=[0, 0])
+    assert got == want and st["n_merges"] == 9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", list(WIDE))
 def test_gpu_wide_merges(gpu_ctx, case):
     """sequences over a balanced tree whose root merge pairs 12 + 12 paths = 144 chain combinations (the walk kernel with its reduction exchange,
