@@ -230,6 +230,10 @@ def main():
                     help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
+    ap.add_argument("--plans", choices=("one", "nine"), default="one",
+                    help="the resident stitch batches of a rank as ONE plan (every subproblem of the nine merges in one batch: a dozen large launches) or as "
+                         "one plan per merge run side by side (rounds 1-3: ~110 small launches that share the hardware queues); the other layout is timed too "
+                         "and reported in config.other_plan_layout")
     ap.add_argument("--no-shard-stitch", action="store_true",
                     help="N > 1: keep every merge's stitch batch on the rank that made it instead of dealing the subproblems of ALL batches over the ranks")
     args = ap.parse_args()
@@ -312,25 +316,43 @@ def main():
         os.environ["CL_DEBUG_SKIP_TRACEBACK"] = str(args.debug_skip)
     # one context (= one HIP stream set) per batch: the nine merges are independent, their passes run side by side on the device
     # exactly as the worker contexts of the MSA above run sibling merges side by side
-    plan_ctx = [capi.Context(device) for _ in batches]
-    plans = [(m, c.plan(b)) for (m, b), c in zip(batches, plan_ctx)]
+    def make_plans(layout):
+        if layout == "one" and batches:
+            # every subproblem of the rank's merges in ONE batch: the launch groups (one per kernel shape) hold nine merges' worth of subproblems
+            # each, so a step is a dozen large launches instead of ~110 small ones that queue behind one another on the hardware queues
+            c = capi.Context(device)
+            return [c], [("all %d merges" % len(batches), c.plan(capi.StitchBatch.concat([b for _, b in batches])))]
+        cs = [capi.Context(device) for _ in batches]
+        return cs, [(m, c.plan(b)) for (m, b), c in zip(batches, cs)]
+
+    def run_steps(plans, warmup, steps):
+        def one_pass():
+            for _, p in plans:
+                p.execute()           # replays the captured hipGraph of the plan's kernel launches on its context's stream
+            return max([p.sync() for _, p in plans] or [0.0])   # HIP events around each plan's pass; the passes overlap
+        for _ in range(warmup):
+            one_pass()
+        barrier()
+        t0 = time.perf_counter()
+        dev = 0.0
+        for _ in range(steps):
+            dev += one_pass()
+        barrier()
+        return time.perf_counter() - t0, dev
+
+    # the other layout first, untimed for the line: it is reported beside the headline (config.other_plan_layout)
+    other = "nine" if args.plans == "one" else "one"
+    other_ctx, other_plans = make_plans(other)
+    other_elapsed, _ = run_steps(other_plans, min(args.warmup, 2), max(3, args.steps // 4))
+    other_ms = cd.max_over_ranks(other_elapsed, dist, device="cpu" if share else "cuda") / max(3, args.steps // 4) * 1e3
+    for _, p in other_plans:
+        p.destroy()
+    for c in other_ctx:
+        c.close()
+    plan_ctx, plans = make_plans(args.plans)
     stats = [p.stats() for _, p in plans]
     my_cells = sum(st["dp_cells"] for st in stats)
-
-    def one_pass():
-        for _, p in plans:
-            p.execute()           # replays the captured hipGraph of the plan's kernel launches on its context's stream
-        return max([p.sync() for _, p in plans] or [0.0])   # HIP events around each plan's pass; the passes overlap
-
-    for _ in range(args.warmup):
-        one_pass()
-    barrier()
-    t0 = time.perf_counter()
-    dev_ms = 0.0
-    for _ in range(args.steps):
-        dev_ms += one_pass()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, dev_ms = run_steps(plans, args.warmup, args.steps)
     elapsed = cd.max_over_ranks(elapsed, dist, device="cpu" if share else "cuda")
     total_cells = my_cells
     if dist is not None:
@@ -371,12 +393,12 @@ def main():
                                        "tree": tj.get("_commit", "round 2"), "limiter": tj.get("_limiter", {}).get(dom["kernel"])}
             except Exception:
                 traffic_profile = None
-        # the digest every run of the headline workload must print, whatever N: the single-rank GFA (profiles/r03_bench.json; tests/test_c3_full.py pins
-        # eight of its nine subproblems and the restarted root against the reference)
+        # the digest every run of the headline workload must print, whatever N: the GFA the unmodified REFERENCE prints for this configuration (its eight
+        # subproblems in the build container, its root merge — 36 minutes, 70 GB — on a GPU box's host: tests/golden/c3_10x1M_subproblems.json)
         expected_sha = None
         try:
             with open(os.path.join(HERE, "tests", "golden", "c3_10x1M_subproblems.json")) as f:
-                expected_sha = json.load(f)["root_default_budget_self_digest"]["sha256"]
+                expected_sha = json.load(f)["root_default_budget_reference"]["sha256"]   # the unmodified reference's GFA of this very configuration
         except (OSError, KeyError, ValueError):
             pass
         gfa_ok = None if (expected_sha is None or args.length != 1000000) else bool(gfa_sha == expected_sha)
@@ -388,10 +410,13 @@ def main():
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": ("INVALID (--debug-skip %d): " % args.debug_skip if args.debug_skip else "") + ("INVALID (the GFA differs from the single-rank digest): " if gfa_ok is False else "") + WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
+            "config": {"workload": ("INVALID (--debug-skip %d): " % args.debug_skip if args.debug_skip else "") + ("INVALID (the GFA differs from the reference's): " if gfa_ok is False else "") + WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
                        "subproblems": int(sum(st["n_problems"] for st in stats)), "dp_cells": int(total_cells),
-                       "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "gfa_is_the_single_rank_digest": gfa_ok,
+                       "msa_wall_s": msa_wall, "gfa_sha256": gfa_sha, "gfa_bytes": gfa_bytes, "gfa_is_the_references": gfa_ok,
+                       "plan_layout": "%s resident plan%s per rank (--plans %s)" % ("one" if args.plans == "one" else "nine", "" if args.plans == "one" else "s", args.plans),
+                       "other_plan_layout": {"layout": other, "ms_per_step": other_ms, "value": total_cells / (other_ms * 1e-3) if other_ms else None,
+                                             "note": "the same subproblems, %s; rounds 1-3 reported the nine-plan layout" % ("one plan per merge, nine contexts side by side" if other == "nine" else "all in one plan")},
                        "stitch_sharding": stitch_sharding,
                        "workspace_bytes": int(sum(st.get("workspace_bytes", 0) for st in stats)),
                        "merge_groups": None if world == 1 else (res["stats"].get("merge_groups") if res is not None and "stats" in res else None),

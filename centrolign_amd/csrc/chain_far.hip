@@ -30,6 +30,7 @@
 //
 // Compiled with -ffp-contract=off like chain_kernels.hip: the leaf evaluation must round like the reference's scalar code.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
@@ -685,9 +686,12 @@ hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32
 }
 
 // the first n_big items are nodes of 4 096 records or more: a workgroup each; the others a wave each
-hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, uint32_t n_big, hipStream_t stream) {
-    if (n_big) hipLaunchKernelGGL(far_seal_big_kernel, dim3(n_big), dim3(1024), 0, stream, F, D.far_rec, items, item0);
-    if (n_items > n_big) hipLaunchKernelGGL(far_seal_kernel, dim3(n_items - n_big), dim3(64), 0, stream, F, D.far_rec, items, item0 + n_big);
+// done (may be null): recorded behind the last launch, as part of that launch (see cl_chain_launch_walk2)
+hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, uint32_t n_big, hipStream_t stream, hipEvent_t done) {
+    const bool small = n_items > n_big;
+    if (n_big) hipExtLaunchKernelGGL(far_seal_big_kernel, dim3(n_big), dim3(1024), 0, stream, nullptr, small ? nullptr : done, 0, F, D.far_rec, items, item0);
+    if (small) hipExtLaunchKernelGGL(far_seal_kernel, dim3(n_items - n_big), dim3(64), 0, stream, nullptr, done, 0, F, D.far_rec, items, item0 + n_big);
+    else if (!n_big && done) return hipEventRecord(done, stream);
     return hipGetLastError();
 }
 
@@ -708,9 +712,9 @@ hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream) {
+hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream, hipEvent_t done) {
     const uint32_t mine = F.share_n > 1 ? (D.n_combos > F.share_i ? (D.n_combos - F.share_i + F.share_n - 1) / F.share_n : 0u) : D.n_combos;
-    if (mine == 0) return hipSuccess;
+    if (mine == 0) return done ? hipEventRecord(done, stream) : hipSuccess;
     // lanes per query (CL_CHAIN_FAR_LANES = 8 / 16 / 32 pins it): the fewer combinations a launch holds, the more lanes a query gets
     static const int pinned = [] { const char* e = getenv("CL_CHAIN_FAR_LANES"); return e ? atoi(e) : 0; }();
     // (10 x 1 Mbp, device time of a merge's two DPs with 8 / 16 / 32 lanes: 1 combination 348 / 303 / 293 ms, 4 combinations 583 / 512 / 476 ms, 25 combinations
@@ -718,8 +722,8 @@ hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uin
     const int lanes = (pinned == 8 || pinned == 16 || pinned == 32) ? pinned : (mine <= 32 ? 32 : mine <= 128 ? 16 : 8);   // (a whole wave per query was tried: it does not terminate)
     const dim3 grid((count * (uint32_t)lanes + 255) / 256, mine);
 #define CL_FAR_LAUNCH(G) do { \
-        if (D.sparse) hipLaunchKernelGGL((far_prune_kernel<true, G>), grid, dim3(256), 0, stream, D, F, first, count, end_block); \
-        else hipLaunchKernelGGL((far_prune_kernel<false, G>), grid, dim3(256), 0, stream, D, F, first, count, end_block); } while (0)
+        if (D.sparse) hipExtLaunchKernelGGL((far_prune_kernel<true, G>), grid, dim3(256), 0, stream, nullptr, done, 0, D, F, first, count, end_block); \
+        else hipExtLaunchKernelGGL((far_prune_kernel<false, G>), grid, dim3(256), 0, stream, nullptr, done, 0, D, F, first, count, end_block); } while (0)
     if (lanes >= 32) CL_FAR_LAUNCH(4);
     else if (lanes >= 16) CL_FAR_LAUNCH(2);
     else CL_FAR_LAUNCH(1);

@@ -22,6 +22,7 @@
 //
 // Compiled with -ffp-contract=off: the candidate values must round exactly like the reference's scalar code.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -676,9 +677,9 @@ hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hi
     return hipGetLastError();
 }
 
-hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream) {
-    if (D.sparse) hipLaunchKernelGGL(chain_walk_kernel<true>, dim3(D.n_combos), dim3(kChainMacro), 0, stream, D, first, count);
-    else hipLaunchKernelGGL(chain_walk_kernel<false>, dim3(D.n_combos), dim3(kChainMacro), 0, stream, D, first, count);
+hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done) {   // done: see cl_chain_launch_walk2
+    if (D.sparse) hipExtLaunchKernelGGL(chain_walk_kernel<true>, dim3(D.n_combos), dim3(kChainMacro), 0, stream, nullptr, done, 0, D, first, count);
+    else hipExtLaunchKernelGGL(chain_walk_kernel<false>, dim3(D.n_combos), dim3(kChainMacro), 0, stream, nullptr, done, 0, D, first, count);
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@
 //
 // Compiled with -ffp-contract=off like chain_kernels.hip: candidates and stored values must round like the reference's scalar code.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -637,7 +638,9 @@ __global__ void __launch_bounds__(kChainMacro) chain_walk2_kernel(ClChainDevice 
 // helpers a main workgroup of window `128 * qpt` needs for full coverage of a macro-block
 uint32_t cl_chain_walk2_helpers(uint32_t qpt) { return (kChainMacro / kSub - kSlots * qpt / kSub + kHelperSubs - 1) / kHelperSubs; }
 
-hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream) {
+// `done` (may be null): recorded when the launch has finished — the event record rides on the launch (hipExtLaunchKernel) instead of being a runtime
+// call of its own: the chaining DP is as long as the host needs for its calls
+hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream, hipEvent_t done) {
     static std::once_flag attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function
     std::call_once(attr_once, [] {
         const int cap = 160 * 1024;
@@ -650,12 +653,12 @@ hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_
     const dim3 grid(stride * (1u + n_help));
     if (D.sparse) {
         const size_t lds = W2Lds<true>::bytes;
-        if (qpt == 1) hipLaunchKernelGGL((chain_walk2_kernel<true, 1>), grid, dim3(kChainMacro), lds, stream, D, first, count, n_help, stride);
-        else hipLaunchKernelGGL((chain_walk2_kernel<true, 2>), grid, dim3(kChainMacro), lds, stream, D, first, count, n_help, stride);
+        if (qpt == 1) hipExtLaunchKernelGGL((chain_walk2_kernel<true, 1>), grid, dim3(kChainMacro), (uint32_t)lds, stream, nullptr, done, 0, D, first, count, n_help, stride);
+        else hipExtLaunchKernelGGL((chain_walk2_kernel<true, 2>), grid, dim3(kChainMacro), (uint32_t)lds, stream, nullptr, done, 0, D, first, count, n_help, stride);
     } else {
         const size_t lds = W2Lds<false>::bytes;
-        if (qpt == 1) hipLaunchKernelGGL((chain_walk2_kernel<false, 1>), grid, dim3(kChainMacro), lds, stream, D, first, count, n_help, stride);
-        else hipLaunchKernelGGL((chain_walk2_kernel<false, 2>), grid, dim3(kChainMacro), lds, stream, D, first, count, n_help, stride);
+        if (qpt == 1) hipExtLaunchKernelGGL((chain_walk2_kernel<false, 1>), grid, dim3(kChainMacro), (uint32_t)lds, stream, nullptr, done, 0, D, first, count, n_help, stride);
+        else hipExtLaunchKernelGGL((chain_walk2_kernel<false, 2>), grid, dim3(kChainMacro), (uint32_t)lds, stream, nullptr, done, 0, D, first, count, n_help, stride);
     }
     return hipGetLastError();
 }

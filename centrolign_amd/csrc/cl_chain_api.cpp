@@ -39,8 +39,8 @@
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
                                  uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
-hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream);
-hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream);   // chain_walk2.hip
+hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done);
+hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream, hipEvent_t done);   // chain_walk2.hip
 uint32_t cl_chain_walk2_helpers(uint32_t qpt);
 hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
 // chain_far.hip
@@ -52,8 +52,8 @@ hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* ke
 hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream);
 hipError_t cl_chain_far_layout(const uint32_t* perm, const uint32_t* key, uint32_t n, uint32_t* arena, uint32_t ord_off, const uint32_t* ix, uint32_t n_ix,
                                hipStream_t stream);
-hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, uint32_t n_big, hipStream_t stream);
-hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream);
+hipError_t cl_chain_far_seal(const ClChainDevice& D, const ClFarDevice& F, const uint32_t* items, uint32_t item0, uint32_t n_items, uint32_t n_big, hipStream_t stream, hipEvent_t done);
+hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uint32_t first, uint32_t count, uint32_t end_block, hipStream_t stream, hipEvent_t done);
 hipError_t cl_chain_far_merge(const ClChainDevice& D, const int* slot, uint32_t first, uint32_t count, uint32_t share_n, uint32_t share_i, hipStream_t stream);
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream);
@@ -1214,6 +1214,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             F.share_n = peers.n;
             F.share_i = peers.me;
         }
+        // the events that order the streams ride on the launches that they follow (hipExtLaunchKernel's stop event) instead of being runtime calls of
+        // their own: 3 of ~12 calls per macro-block.  CL_CHAIN_EXT_EVENTS=0: hipEventRecord as in rounds 2-3 (A/B)
+        static const bool ext_events = [] { const char* e = getenv("CL_CHAIN_EXT_EVENTS"); return !e || e[0] != '0'; }();
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
             if (!far_decided && k >= 96 && (k & (k - 1)) == 0) {   // k = 128, 256, 512, ...
                 he = hipStreamSynchronize(ctx->stream);
@@ -1229,6 +1232,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             const uint32_t first = k * kChainMacro, count = (uint32_t)std::min<uint64_t>(kChainMacro, M - first);
             const uint32_t lag = use_far ? far_lag : 1u;
             const uint32_t b0 = k * bpm, near_lo = k >= lag ? (k - lag) * bpm : 0;
+            bool far_recorded = false;
             if (near_lo > 0) {
                 hipStream_t far_stream = ctx->aux[k % (use_far ? far_lag : far_streams)];
                 if (use_far && far_bb) {
@@ -1245,12 +1249,16 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                         const uint32_t slot = (k + (kPeerRing / 2) * (share_epoch & 1u)) % kPeerRing, word = (share_epoch << 20) | (k + 1);
                         uint32_t o = 0;
                         for (uint32_t m = 0; m < peers.n; ++m) if (m != peers.me) Fk.peer_out[o++] = peers.peer_inbox[m] + (size_t)slot * kPeerSlotInts;
-                        if (he == hipSuccess) he = cl_chain_far_launch(D, Fk, first, count, near_lo, far_stream);
+                        if (he == hipSuccess) he = cl_chain_far_launch(D, Fk, first, count, near_lo, far_stream, nullptr);
                         for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m)
                             if (m != peers.me) he = hipStreamWriteValue32(far_stream, peers.peer_flags[m] + (size_t)peers.me * kPeerRing + slot, word, 0);
                         ++peers.shared_far_launches;
                     } else
-                    if (he == hipSuccess && !skip_far) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream);
+                    if (he == hipSuccess && !skip_far) {
+                        // (the launch records ev_far[k] itself: one runtime call less per macro-block — the DP is as long as the host needs for its calls)
+                        if (ext_events) { he = cl_ring_event(ctx, 1, k, &ev_far[k]); far_recorded = he == hipSuccess; }
+                        if (he == hipSuccess) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream, far_recorded ? ev_far[k] : nullptr);
+                    }
                 } else if (use_far) {
                     // the all-pairs sweep has taken over (see the checkpoints below); same lag, so that sweeps run side by side
                     he = hipStreamWaitEvent(far_stream, ev_walk[k - lag - 1], 0);
@@ -1265,8 +1273,10 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     }
                     if (he == hipSuccess) he = cl_chain_launch_inter(D, first, count, 0, near_lo, recs, tile, far_stream);
                 }
-                if (he == hipSuccess) he = cl_ring_event(ctx, 1, k, &ev_far[k]);
-                if (he == hipSuccess) he = hipEventRecord(ev_far[k], far_stream);
+                if (!far_recorded) {
+                    if (he == hipSuccess) he = cl_ring_event(ctx, 1, k, &ev_far[k]);
+                    if (he == hipSuccess) he = hipEventRecord(ev_far[k], far_stream);
+                }
             }
             hipEvent_t ev_near_a = nullptr;
             if (he == hipSuccess && b0 > near_lo) {
@@ -1297,14 +1307,15 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess) he = cl_chain_far_merge(D, peers.inbox + (size_t)slot * kPeerSlotInts, first, count, peers.n, peers.me, ctx->stream);
                 ++peers.merged_blocks;
             }
-            if (he == hipSuccess) he = use_walk2 ? cl_chain_launch_walk2(D, first, count, walk2_qpt, walk2_help, ctx->stream) : cl_chain_launch_walk(D, first, count, ctx->stream);
             if (he == hipSuccess) he = cl_ring_event(ctx, 0, k, &ev_walk[k]);
-            if (he == hipSuccess) he = hipEventRecord(ev_walk[k], ctx->stream);
+            if (he == hipSuccess) he = use_walk2 ? cl_chain_launch_walk2(D, first, count, walk2_qpt, walk2_help, ctx->stream, ext_events ? ev_walk[k] : nullptr)
+                                                 : cl_chain_launch_walk(D, first, count, ctx->stream, ext_events ? ev_walk[k] : nullptr);
+            if (he == hipSuccess && !ext_events) he = hipEventRecord(ev_walk[k], ctx->stream);
             if (use_far && far_bb && he == hipSuccess && k + far_lag + 1 < n_macro) {
                 he = hipStreamWaitEvent(seal_stream, ev_walk[k], 0);
-                if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_big[k], seal_stream);
                 if (he == hipSuccess) he = cl_ring_event(ctx, 2, k, &ev_seal[k]);
-                if (he == hipSuccess) he = hipEventRecord(ev_seal[k], seal_stream);
+                if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_big[k], seal_stream, ext_events ? ev_seal[k] : nullptr);
+                if (he == hipSuccess && !ext_events) he = hipEventRecord(ev_seal[k], seal_stream);
             }
         }
         if (use_far && he == hipSuccess) he = hipStreamSynchronize(seal_stream);

@@ -42,6 +42,8 @@ VARIANTS = [
     # large nodes of the far pass sealed by one wave each (rounds 2-3) instead of a workgroup each (far_seal_big_kernel); the near sweep as one launch
     ("seal_by_waves", {"CL_CHAIN_SEAL_WAVE": "1", "CL_CHAIN_FAR_MODE": "bb"}),
     ("near_in_two_launches", {"CL_CHAIN_NEAR_SPLIT": "1"}),
+    # the events between the streams as runtime calls of their own (rounds 2-3) instead of riding on the launches they follow
+    ("event_records", {"CL_CHAIN_EXT_EVENTS": "0"}),
 ]
 
 
@@ -65,7 +67,7 @@ def dense_input(gpu_ctx, tmp_path_factory):
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
     for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES", "CL_CHAIN_WALK2", "CL_CHAIN_WALK2_QPT",
-              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT"):
+              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
