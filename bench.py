@@ -230,7 +230,7 @@ def main():
                     help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
-    ap.add_argument("--plans", choices=("one", "nine"), default="one",
+    ap.add_argument("--plans", choices=("one", "nine"), default="nine",
                     help="the resident stitch batches of a rank as ONE plan (every subproblem of the nine merges in one batch: a dozen large launches) or as "
                          "one plan per merge run side by side (rounds 1-3: ~110 small launches that share the hardware queues); the other layout is timed too "
                          "and reported in config.other_plan_layout")

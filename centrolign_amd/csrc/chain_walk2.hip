@@ -154,6 +154,7 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
     int* s_flags = reinterpret_cast<int*>(smem + L::flags);  // [0] abort
 
     const unsigned long long t_entry = D.debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long c_entry = D.debug ? __builtin_amdgcn_s_memtime() : 0ull;
     const ClChainCombo cb = D.combos[c];
     const uint32_t t = threadIdx.x;
     const int none = enc(CL_CHAIN_NEG);
@@ -478,7 +479,8 @@ __device__ __forceinline__ void walk2_main(const ClChainDevice& D, const uint32_
         if (dbg) { const unsigned long long t3 = __builtin_amdgcn_s_memrealtime(); t_pre += t1 - t0; t_bar += t2 - t1; t_post += t3 - t2; t_post_last = t3 - t2; }
     }
     if (dbg) {
-        if (t == 0) { atomicAdd(D.status + 22, (uint32_t)(t_loop - t_entry)); atomicAdd(D.status + 23, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_loop)); atomicAdd(D.status + 24, 1u);
+        if (t == 0) { atomicAdd(D.status + 27, (uint32_t)(__builtin_amdgcn_s_memtime() - c_entry)); atomicAdd(D.status + 28, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_entry));
+                      atomicAdd(D.status + 22, (uint32_t)(t_loop - t_entry)); atomicAdd(D.status + 23, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_loop)); atomicAdd(D.status + 24, 1u);
                       atomicAdd(D.status + 19, n_fsteps); atomicAdd(D.status + 20, (uint32_t)t_pre_f); atomicAdd(D.status + 21, (uint32_t)t_post_f); atomicAdd(D.status + 8, n_steps); atomicAdd(D.status + 12, (uint32_t)t_pre); atomicAdd(D.status + 13, (uint32_t)t_bar); atomicAdd(D.status + 14, (uint32_t)t_post); }
         if (n_fin) atomicAdd(D.status + 9, n_fin);
         if (n_polled) atomicAdd(D.status + 10, n_polled);

@@ -1387,8 +1387,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             (void)cl_copy_sync(ctx, dbg, d_status.p, sizeof(dbg), hipMemcpyDeviceToHost);
             const double steps = std::max(1u, dbg[8]);
             fprintf(stderr, "[chain_dp_batch]   walk2: %u steps of combination 0, %u queries finalised, %u polled at their finalisation, %u evaluated out of LDS (no helper result); "
-                            "wave 0 per step (100 MHz ticks): before the barrier %.1f, in the barrier %.1f, behind it %.1f; helper batches %u, records %u, polls without news %u; wave 0 finalised in %u steps: %.1f ticks before the barrier there, %.1f behind the barrier before; per launch: %.1f ticks in front of the loop, %.1f in it; not asked %u, no granule of the block %u\n",
-                    dbg[8], dbg[9], dbg[10], dbg[11], dbg[12] / steps, dbg[13] / steps, dbg[14] / steps, dbg[16], dbg[17], dbg[18], dbg[19], dbg[20] / (double)std::max(1u, dbg[19]), dbg[21] / (double)std::max(1u, dbg[19]), dbg[22] / (double)std::max(1u, dbg[24]), dbg[23] / (double)std::max(1u, dbg[24]), dbg[25], dbg[26]);
+                            "wave 0 per step (100 MHz ticks): before the barrier %.1f, in the barrier %.1f, behind it %.1f; helper batches %u, records %u, polls without news %u; wave 0 finalised in %u steps: %.1f ticks before the barrier there, %.1f behind the barrier before; per launch: %.1f ticks in front of the loop, %.1f in it; not asked %u, no granule of the block %u; shader clock %.0f MHz (s_memtime against the 100 MHz s_memrealtime)\n",
+                    dbg[8], dbg[9], dbg[10], dbg[11], dbg[12] / steps, dbg[13] / steps, dbg[14] / steps, dbg[16], dbg[17], dbg[18], dbg[19], dbg[20] / (double)std::max(1u, dbg[19]), dbg[21] / (double)std::max(1u, dbg[19]), dbg[22] / (double)std::max(1u, dbg[24]), dbg[23] / (double)std::max(1u, dbg[24]), dbg[25], dbg[26], 100.0 * dbg[27] / (double)std::max(1u, dbg[28]));
         }
         static const bool debug_stall = getenv("CL_CHAIN_DEBUG_STALL") != nullptr;   // test hook: behave as if a wait had expired
         if (debug_stall) status = 1;

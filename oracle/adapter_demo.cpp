@@ -303,6 +303,7 @@ static int facade_mode(int argc, char** argv) {
         if (!tree_file.empty()) { std::ifstream tin(tree_file); std::stringstream ss; ss << tin.rdbuf(); newick = ss.str(); }
         Tree tree(newick);
         Core core(std::move(parsed), std::move(tree));
+        if (names.size() == 2) params.set<bool>("preserve_subproblems", true);   // as main() does: the CIGAR needs the leaves (src/main.cpp:272-276)
         params.apply(core);
         core.execute();
         std::stringstream out;
