@@ -230,7 +230,7 @@ def main():
                     help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
-    ap.add_argument("--plans", choices=("one", "nine"), default="nine",
+    ap.add_argument("--plans", choices=("one", "nine"), default="one",
                     help="the resident stitch batches of a rank as ONE plan (every subproblem of the nine merges in one batch: a dozen large launches) or as "
                          "one plan per merge run side by side (rounds 1-3: ~110 small launches that share the hardware queues); the other layout is timed too "
                          "and reported in config.other_plan_layout")
@@ -320,23 +320,29 @@ def main():
         if layout == "one" and batches:
             # every subproblem of the rank's merges in ONE batch: the launch groups (one per kernel shape) hold nine merges' worth of subproblems
             # each, so a step is a dozen large launches instead of ~110 small ones that queue behind one another on the hardware queues
+            prev = os.environ.get("CL_CTX_STREAMS")
+            os.environ["CL_CTX_STREAMS"] = prev or "8"      # eight streams for the sixteen launches of the one plan (measured: 6: 3.0-3.1, 8: 2.5-2.85, 10: 3.5, 12: 3.3 ms per step)
             c = capi.Context(device)
+            if prev is None:
+                del os.environ["CL_CTX_STREAMS"]
             return [c], [("all %d merges" % len(batches), c.plan(capi.StitchBatch.concat([b for _, b in batches])))]
         cs = [capi.Context(device) for _ in batches]
         return cs, [(m, c.plan(b)) for (m, b), c in zip(batches, cs)]
 
     def run_steps(plans, warmup, steps):
-        def one_pass():
+        def one_pass(wait):
             for _, p in plans:
-                p.execute()           # replays the captured hipGraph of the plan's kernel launches on its context's stream
-            return max([p.sync() for _, p in plans] or [0.0])   # HIP events around each plan's pass; the passes overlap
+                p.execute()           # the plan's launches, dealt over the context's streams by their measured durations (cl_stitch_plan_execute)
+            return max([p.sync() for _, p in plans] or [0.0]) if wait else 0.0   # HIP events around each plan's pass; the passes overlap
         for _ in range(warmup):
-            one_pass()
+            one_pass(True)
         barrier()
         t0 = time.perf_counter()
-        dev = 0.0
-        for _ in range(steps):
-            dev += one_pass()
+        # the K timed passes are ENQUEUED one behind the other (a plan's pass joins its context's stream before the next forks from it) and waited
+        # for once, by the barrier + synchronize that closes the timed region: no host round trip — and no idle device — between two passes
+        for _ in range(steps - 1):
+            one_pass(False)
+        dev = one_pass(True) * steps      # (device time of the last pass of the longest plan, as an indication)
         barrier()
         return time.perf_counter() - t0, dev
 
@@ -445,9 +451,9 @@ def main():
                 ns_per_step = dom["ms"] * 1e6 / steps
                 latency = {"model": "latency", "dependent_steps": steps, "ns_per_step": ns_per_step, "single_wave_issue_floor_ns_per_step": issue_floor_ns,
                            "floor_over_measured": issue_floor_ns / ns_per_step, "longest_subproblem": dom.get("longest"),
-                           "note": "kernel_ms: the launch ALONE on its context's stream between two HIP events of its own (cl_stitch_plan_execute_profiled runs a plan's "
-                                   "launches one after the other, one plan at a time): a kernel duration, comparable with the rocprofv3 kernel trace under profiles/; "
-                                   "inside a timed step the nine plans' launches overlap and share hardware queues"}
+                           "note": "kernel_ms: the launch ALONE on the device, the host's clock round launch + wait (cl_stitch_plan_execute_profiled; ~20 us of launch "
+                                   "and wake-up latency included).  HIP event pairs read about TWICE the duration the rocprofv3 kernel trace shows for these "
+                                   "launches (rounds 1-3 reported those; profiles/r04_*); inside a timed step the plans' launches overlap and share hardware queues"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                                "kernel": dom["kernel"], "merge": dom["merge"], "kernel_ms": dom["ms"], "kernel_cells": dom["dp_cells"],
                                "kernel_problems": dom["n_problems"], "latency_model": latency, "traffic_profile": traffic_profile,

@@ -51,8 +51,10 @@ const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e =
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
 constexpr uint64_t kRingLdsBytes = 128 * 1024;  // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU); launches are split at 64 KB
-// test hook: CL_NO_GRAPH=1 launches the kernels directly instead of replaying a captured hipGraph
-const bool g_no_graph = [] { const char* e = getenv("CL_NO_GRAPH"); return e && *e == '1'; }();
+// CL_STITCH_GRAPH=1 replays a captured hipGraph of a plan's launches instead of launching the kernels directly (rounds 1-3 did; measured in
+// round 4 on the 10 x 1 Mbp batches: one plan of 16 launches 4.24 ms per step through the graph, 3.12 ms launched directly — the graph's branches do
+// not start together); CL_NO_GRAPH=1 is the old name of "off"
+const bool g_no_graph = [] { const char* e = getenv("CL_STITCH_GRAPH"); return !(e && *e == '1'); }();
 
 }  // namespace
 
@@ -590,6 +592,8 @@ struct LaunchGroup {
     uint64_t cells = 0, bytes = 0;
     uint32_t ring_bytes = 0;  // general kernel: dynamic LDS of the ring variant (0 = planes read from HBM)
     uint64_t est_cost = 0;    // longest sweep x the kernel's rough time per step: orders the groups and deals them over the streams
+    float host_ms = 0.f;      // the profiled pass: the launch alone on the device, behind another launch (host's clock: two launches - one launch)
+    float host_idle_ms = 0.f; // ... and finding the device idle (one launch + wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -632,7 +636,7 @@ struct cl_stitch_plan {
     hipGraphExec_t graph_exec = nullptr;
     bool graph_tried = false;
     std::vector<uint32_t> plist_host;   // the launch groups' subproblem lists (cl_stitch_plan_launch_info)
-    bool executed = false, profiled = false;
+    bool executed = false, profiled = false, calibrated = false;
 };
 
 namespace {
@@ -810,7 +814,8 @@ cl_context* cl_context_create(int device_ordinal) {
     // streams of their own: CL_CTX_STREAMS (default 6: what one chaining DP keeps busy — four far launches in flight, the sealing stream and
     // a spare).  Every stream takes a share of the process's hardware queues (GPU_MAX_HW_QUEUES); streams that share a queue run their
     // launches one after the other, whichever context they belong to, so contexts that work side by side should not hold idle streams
-    static const int n_own = [] { const char* e = getenv("CL_CTX_STREAMS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kNumAuxStreams ? v : 6; }();
+    // (read at every creation: a caller that wants a context with more streams for one purpose — bench.py's resident stitch plan: eight — sets the variable round that call)
+    const int n_own = [] { const char* e = getenv("CL_CTX_STREAMS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kNumAuxStreams ? v : 6; }();
     ctx->n_aux = n_own;
     for (int i = 0; ok && i < kNumAuxStreams; ++i) {
         if (i < n_own) ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess;
@@ -1286,15 +1291,29 @@ static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, hipStre
 
 static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
     if (timed) {
-        // the profiled pass: every launch ALONE on the context's stream between two events of its own, one after the other — an event pair
-        // round a launch that shares hardware queues with other launches measures the wait for the queue as well (round 3: 2.49 ms by events
-        // against 1.45 ms in the kernel trace for the dominant launch); like this the pair brackets the kernel and nothing else
-        for (LaunchGroup& g : pl->groups)
-            if (!g.ev0 && (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess)) g.ev0 = g.ev1 = nullptr;
-        for (const LaunchGroup& g : pl->groups) {
-            if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, ctx->stream));
-            HIP_TRY(ctx, launch_group(g, pl, ctx->stream));
-            if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, ctx->stream));
+        // the profiled pass: every launch ALONE on the context's stream, the device idle before and after, timed by the HOST's clock round
+        // launch + wait.  HIP event pairs read about twice the kernel's duration in the rocprofv3 kernel trace here (round 4: 2.87 ms by events,
+        // 1.43 ms in the trace for the dominant launch, also with nothing else on the device); the host's clock round launch + wait reads the
+        // kernel plus ~20 us of launch and wake-up latency, i.e. agrees with the trace within a few per cent for the launches that matter
+        // (a launch that finds the device idle runs at about half speed — the dominant launch 2.9 ms against 1.45 ms behind another launch, with the
+        // shader clock already at its top in both cases: whatever ramps, ramps within the first launch — so the duration reported is that of a launch
+        // behind another one, which is what a launch inside a step is, and what the rocprofv3 kernel trace of a step shows)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (LaunchGroup& g : pl->groups) {
+            auto timed_run = [&](int n, float& ms) -> int {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < n; ++i) HIP_TRY(ctx, launch_group(g, pl, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return CL_OK;
+            };
+            // the launch behind another one = (two launches back to back) - (one launch): the first launch of a sequence finds the device idle
+            float one = 0.f, two = 0.f;
+            int rc = timed_run(1, one);
+            if (!rc) rc = timed_run(2, two);
+            if (rc) return rc;
+            g.host_ms = two > one ? two - one : one;
+            g.host_idle_ms = one;
         }
         return CL_OK;
     }
@@ -1328,6 +1347,19 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
 int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
     if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // A plan that is executed again (resident inputs, replayed passes) measures its launches ONCE — each alone on the device, the host's clock
+    // round launch + wait — and deals them over the streams by those durations from then on: a launch lasts as long as its longest sweep at a
+    // rate that depends on the subproblems' branching (0.25 .. 2.7 us per step), which the estimate of cl_stitch_plan_create cannot know.
+    // Measured on the 10 x 1 Mbp batches as one plan: 3.03 ms per step with the estimate (the stream that got 1.40 + 0.70 + 0.79 ms sets the
+    // pace), the sum of the sixteen launches is 12.8 ms over six streams.  CL_STITCH_CALIBRATE=0: the estimate only
+    static const bool calibrate = [] { const char* e = getenv("CL_STITCH_CALIBRATE"); return !e || e[0] != '0'; }();
+    if (calibrate && pl->executed && !pl->calibrated && pl->groups.size() > 2) {
+        pl->calibrated = true;
+        int rc = enqueue_groups(ctx, pl, true);
+        if (rc) return rc;
+        for (LaunchGroup& g : pl->groups) g.est_cost = (uint64_t)(g.host_ms * 1000.f) + 1;
+        std::stable_sort(pl->groups.begin(), pl->groups.end(), [](const LaunchGroup& x, const LaunchGroup& y) { return x.est_cost > y.est_cost; });
+    }
     // The launch DAG (one kernel per group, all independent) is captured once into a hipGraph and replayed:
     // a dozen kernels start together instead of trickling out at the host's enqueue rate.
     if (!pl->graph_tried && !g_no_graph && !pl->groups.empty()) {
@@ -1406,10 +1438,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
         const ClProbDesc& d = pl->desc[pl->plist_host[i]];
         if (d.n1 + d.n2 > out->max_sweep) { out->max_sweep = d.n1 + d.n2; out->max_n1 = d.n1; out->max_n2 = d.n2; }
     }
-    if (pl->profiled && g.ev0 && g.ev1) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        if (hipEventElapsedTime(&out->last_ms, g.ev0, g.ev1) != hipSuccess) out->last_ms = 0.f;
-    }
+    if (pl->profiled) out->last_ms = g.host_ms;
     return CL_OK;
 }
 
