@@ -772,7 +772,7 @@ class MatchSets:
 
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("dp_bytes", C.c_uint64), ("last_ms", C.c_float), ("lds_bytes", C.c_uint32), ("max_sweep", C.c_uint32),
+                ("dp_bytes", C.c_uint64), ("last_ms", C.c_float), ("in_pass_ms", C.c_float), ("lds_bytes", C.c_uint32), ("max_sweep", C.c_uint32),
                 ("max_n1", C.c_uint32), ("max_n2", C.c_uint32)]
 
 
@@ -1341,7 +1341,7 @@ class Plan:
             li = LaunchInfo()
             self.ctx._check(self.ctx.lib.cl_stitch_plan_launch_info(self.ctx.handle, self.handle, i, C.byref(li)))
             out.append(dict(kernel=li.kernel.decode(), n_problems=int(li.n_problems), dp_cells=int(li.dp_cells),
-                            dp_bytes=int(li.dp_bytes), ms=float(li.last_ms), lds_bytes=int(li.lds_bytes), max_sweep=int(li.max_sweep),
+                            dp_bytes=int(li.dp_bytes), ms=float(li.last_ms), in_pass_ms=float(li.in_pass_ms), lds_bytes=int(li.lds_bytes), max_sweep=int(li.max_sweep),
                             longest=(int(li.max_n1), int(li.max_n2))))
         return out
 

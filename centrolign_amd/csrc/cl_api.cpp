@@ -627,6 +627,7 @@ struct cl_stitch_plan {
     DevBuf<uint2> d_out_pairs;
     DevBuf<uint32_t> d_out_len, d_out_status, d_plist;
     DevBuf<int32_t> d_out_score;
+    DevBuf<unsigned long long> d_ticks;            // [2 per launch group] the launches' own clocks (ClDeviceBatch::ticks), zeroed in front of every pass
     std::vector<LaunchGroup> groups;
     ClDeviceBatch dev{};
     ClScoreParams sparams{};
@@ -1283,10 +1284,10 @@ static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS
 
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
-static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, hipStream_t stream) {
-    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves, g.count, pl->dev, pl->d_plist.p + g.first, pl->sparams, stream);
-    if (g.kind == CL_KIND_SYS) return cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, stream);
-    return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, pl->dev, pl->d_plist.p + g.first, pl->sparams, stream);
+static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const ClDeviceBatch& dev, hipStream_t stream) {
+    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    if (g.kind == CL_KIND_SYS) return cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
 }
 
 static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
@@ -1299,24 +1300,31 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
         // shader clock already at its top in both cases: whatever ramps, ramps within the first launch — so the duration reported is that of a launch
         // behind another one, which is what a launch inside a step is, and what the rocprofv3 kernel trace of a step shows)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (LaunchGroup& g : pl->groups) {
-            auto timed_run = [&](int n, float& ms) -> int {
-                const auto t0 = std::chrono::steady_clock::now();
-                for (int i = 0; i < n; ++i) HIP_TRY(ctx, launch_group(g, pl, ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                return CL_OK;
-            };
-            // the launch behind another one = (two launches back to back) - (one launch): the first launch of a sequence finds the device idle
-            float one = 0.f, two = 0.f;
-            int rc = timed_run(1, one);
-            if (!rc) rc = timed_run(2, two);
-            if (rc) return rc;
-            g.host_ms = two > one ? two - one : one;
-            g.host_idle_ms = one;
+        const size_t ng = pl->groups.size();
+        if (!pl->d_ticks.p) { int rc = pl->d_ticks.alloc(ctx, 2 * ng); if (rc) return rc; }
+        for (size_t gi = 0; gi < ng; ++gi) {
+            LaunchGroup& g = pl->groups[gi];
+            // the kernel's own clock: first workgroup's start, last workgroup's end (s_memrealtime, 100 MHz) — what the rocprofv3 kernel trace shows;
+            // beside it the host's clock round launch + wait
+            ClDeviceBatch dev = pl->dev;
+            dev.ticks = pl->d_ticks.p + 2 * gi;
+            HIP_TRY(ctx, launch_group(g, pl, dev, ctx->stream));   // (first run: whatever ramps with the device idle, ramps here)
+            HIP_TRY(ctx, hipMemsetAsync(dev.ticks, 0, 2 * sizeof(unsigned long long), ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const auto t0 = std::chrono::steady_clock::now();
+            HIP_TRY(ctx, launch_group(g, pl, dev, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            g.host_idle_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            unsigned long long got[2] = {0, 0};
+            HIP_TRY(ctx, cl_copy_sync(ctx, got, dev.ticks, sizeof(got), hipMemcpyDeviceToHost));
+            g.host_ms = got[0] && got[1] > ~got[0] ? (float)((double)(got[1] - ~got[0]) * 1e-5) : g.host_idle_ms;
         }
         return CL_OK;
     }
+    // every launch also leaves its own clock's start / end (two atomics per workgroup): cl_stitch_plan_launch_info reports the durations of the LAST pass,
+    // i.e. of launches that overlap with one another as they do in production
+    if (!pl->d_ticks.p && !pl->groups.empty()) { int rc = pl->d_ticks.alloc(ctx, 2 * pl->groups.size()); if (rc) return rc; }
+    if (pl->d_ticks.p) HIP_TRY(ctx, hipMemsetAsync(pl->d_ticks.p, 0, 2 * pl->groups.size() * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     bool used[kNumAuxStreams] = {};
     // the groups come longest first (cl_stitch_plan_create: estimated duration = longest sweep x the kernel's time per step); each goes to the
@@ -1334,7 +1342,9 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
             load[si] += std::max<uint64_t>(1, g.est_cost);
         }
         if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
-        HIP_TRY(ctx, launch_group(g, pl, ctx->aux[si]));
+        ClDeviceBatch dev = pl->dev;
+        dev.ticks = pl->d_ticks.p ? pl->d_ticks.p + 2 * gi : nullptr;
+        HIP_TRY(ctx, launch_group(g, pl, dev, ctx->aux[si]));
     }
     for (int si = 0; si < kNumAuxStreams; ++si)
         if (used[si]) {
@@ -1439,6 +1449,12 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
         if (d.n1 + d.n2 > out->max_sweep) { out->max_sweep = d.n1 + d.n2; out->max_n1 = d.n1; out->max_n2 = d.n2; }
     }
     if (pl->profiled) out->last_ms = g.host_ms;
+    if (pl->d_ticks.p && pl->executed) {   // the launch's own clock in the last pass (the caller has waited for it: cl_stitch_plan_sync)
+        unsigned long long got[2] = {0, 0};
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (cl_copy_sync(ctx, got, pl->d_ticks.p + 2 * index, sizeof(got), hipMemcpyDeviceToHost) == hipSuccess && got[0] && got[1] > ~got[0])
+            out->in_pass_ms = (float)((double)(got[1] - ~got[0]) * 1e-5);
+    }
     return CL_OK;
 }
 

@@ -49,6 +49,9 @@ struct ClDeviceBatch {
     uint32_t* out_len;        // pairs emitted per problem
     int32_t*  out_score;      // best sink-pair score per problem
     uint32_t* out_status;     // 0 = ok
+    unsigned long long* ticks; // null, or [2] (zeroed before the launch): max over the workgroups of ~(start tick) and of (end tick), 100 MHz ticks of
+                              // s_memrealtime — the launch's duration by the kernel's own clock, also inside a step where launches overlap (launches of
+                              // more than 4 096 workgroups sample every 64th: they are throughput-bound, their ends are within a wave of one another)
     int       skip_traceback; // measurement hook (CL_DEBUG_SKIP_TRACEBACK=1, scripts/stitch_dag_bench.py): the graph x graph kernels fill only
 };
 

@@ -440,6 +440,7 @@ __device__ void traceback_wave(const ClDeviceBatch& B, const ClProbDesc& pd, con
 template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -465,6 +466,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, c
         __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
     }
     if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -479,6 +481,7 @@ template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
     extern __shared__ int32_t lds[];
     constexpr int PL = 1 + 2 * NPW, BP = 1 + NPW;
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -662,6 +665,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, cons
     }
     __syncthreads();
     if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -686,6 +690,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     // one cell: NumPW 1: {M, V0, H0, -}; NumPW 2, 3: {M, V0, V1, V2 | M, H0, H1, H2} — what a vertical or a horizontal read needs is one
     // aligned 16-byte LDS read
     constexpr int CW = NPW == 1 ? 4 : 8;
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -931,6 +936,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     }
     __syncthreads();   // vmcnt(0): every plane value is in memory
     if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 template <int NPW>

@@ -344,6 +344,7 @@ __device__ __forceinline__ void linear_dispatch(const ClDeviceBatch& B, const Cl
 template <int W>
 __global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     switch (pd.npw) {
@@ -351,6 +352,7 @@ __global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, c
     case 2: linear_dispatch<2, W>(B, pd, prob, P); break;
     default: linear_dispatch<3, W>(B, pd, prob, P); break;
     }
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 }  // namespace

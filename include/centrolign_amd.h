@@ -215,8 +215,9 @@ typedef struct cl_launch_info {
     uint64_t n_problems;
     uint64_t dp_cells;
     uint64_t dp_bytes;           /* algorithmic bytes: cells * sizeof(cell_t<NumPW>) */
-    float    last_ms;            /* device duration of this launch in the last cl_stitch_plan_execute_profiled
-                                    (HIP events on its stream); valid after cl_stitch_plan_sync */
+    float    last_ms;            /* duration of this launch ALONE on the device in the last cl_stitch_plan_execute_profiled, by the kernel's own clock
+                                    (first workgroup's start to last workgroup's end, s_memrealtime); valid after cl_stitch_plan_sync */
+    float    in_pass_ms;         /* the same clock in the last cl_stitch_plan_execute, where the plan's launches run side by side (0: none yet) */
     uint32_t lds_bytes;          /* dynamic LDS per workgroup (0: static only) */
     uint32_t max_sweep;          /* the longest dependent chain of the launch: max n1 + n2 over its subproblems */
     uint32_t max_n1, max_n2;     /* the subproblem that has it */
