@@ -561,7 +561,7 @@ class MatchStats(C.Structure):
 class AnchorParams(C.Structure):
     """cl_anchor_params"""
     _fields_ = [("chain", ChainParams), ("max_num_match_pairs", C.c_uint64), ("score_scale", C.c_double),
-                ("autocalibrate_gap_penalties", C.c_int), ("do_fill_in_anchoring", C.c_int)]
+                ("autocalibrate_gap_penalties", C.c_int), ("do_fill_in_anchoring", C.c_int), ("chaining_algorithm_plus_one", C.c_int)]
 
 
 class AnchorChainResultC(C.Structure):
@@ -1451,7 +1451,7 @@ class Context:
         return sa, lcp, isa, int(rounds.value)
 
     def anchor_chain(self, graph1, graph2, matches, max_num_match_pairs=1250000, score_scale=1.0, autocalibrate=True,
-                     params=None, fill_in=True):
+                     params=None, fill_in=True, chaining_algorithm=None):
         """Anchorer::anchor_chain (include/centrolign/anchorer.hpp:958-996) without branch splitting.
         Returns dict(chain (n,3) [position in the reordered sets, idx1, idx2], gap_before/after,
         gap_score_before/after, score, count1, count2, full_length, walk_off, walk1, walk2, set_order, scale, n_ties)"""
@@ -1461,6 +1461,7 @@ class Context:
         ap.score_scale = float(score_scale)
         ap.autocalibrate_gap_penalties = int(autocalibrate)
         ap.do_fill_in_anchoring = int(fill_in)
+        ap.chaining_algorithm_plus_one = 0 if chaining_algorithm is None else int(chaining_algorithm) + 1   # the CLI's -g: 1 Sparse (ChainMerge tables), 2 SparseAffine
         g1, g2, mc, out = graph1.as_c(), graph2.as_c(), matches.as_c(), AnchorChainResultC()
         self._check(self.lib.cl_anchor_chain(self.handle, C.byref(g1), C.byref(g2), C.byref(mc), C.byref(ap), C.byref(out)))
         return self._anchor_chain_dict(out)

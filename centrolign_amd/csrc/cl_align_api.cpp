@@ -50,10 +50,13 @@ int cl_core_align(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph*
 
 ClPathMergeTables::ClPathMergeTables() : x1(new clhost::PathMergeTable()), x2(new clhost::PathMergeTable()) {}
 ClPathMergeTables::~ClPathMergeTables() { wait(); delete x1; delete x2; }
-void ClPathMergeTables::start(const cl_base_graph* g1, const cl_base_graph* g2) {
+void ClPathMergeTables::start(const cl_base_graph* g1, const cl_base_graph* g2, bool chain_merge) {
+    // chain_merge: ChainMerge tables (every node on one chain) instead of PathMerge, as Core::execute builds them when the chaining algorithm is not
+    // SparseAffine (core.hpp:350-357)
+    auto one = [chain_merge](clhost::PathMergeTable* x, const cl_base_graph* g) { return chain_merge ? x->build_chain_merge(*g) : x->build(*g); };
     // (small graphs — the thousands of realignments of a polishing step — are done on the spot: a thread and a pool hand-off cost more than the tables)
-    if ((g1->n_nodes + 1) * (g1->n_paths + 1) + (g2->n_nodes + 1) * (g2->n_paths + 1) < (1u << 18)) { ok1 = x1->build(*g1); ok2 = x2->build(*g2); return; }
-    builder = std::thread([this, g1, g2] { cl_pool_run(2, [&](unsigned t) { if (t) ok2 = x2->build(*g2); else ok1 = x1->build(*g1); }); });
+    if ((g1->n_nodes + 1) * (g1->n_paths + 1) + (g2->n_nodes + 1) * (g2->n_paths + 1) < (1u << 18)) { ok1 = one(x1, g1); ok2 = one(x2, g2); return; }
+    builder = std::thread([this, g1, g2, one] { cl_pool_run(2, [&](unsigned t) { if (t) ok2 = one(x2, g2); else ok1 = one(x1, g1); }); });
 }
 void ClPathMergeTables::wait() { if (builder.joinable()) builder.join(); }
 
@@ -67,7 +70,7 @@ int cl_core_align_prepared(cl_context* ctx, const cl_base_graph* g1, const cl_ba
     ClPathMergeTables& tabs = ready ? *ready : own;
     const bool timing = getenv("CL_CHAIN_TIMING") != nullptr;
     const auto t_tab = std::chrono::steady_clock::now();
-    if (!ready) own.start(g1, g2);
+    if (!ready) own.start(g1, g2, ap->anchor.chaining_algorithm_plus_one == 2);
     tabs.wait();
     if (!tabs.ok1 || !tabs.ok2) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
     const clhost::PathMergeTable &x1 = *tabs.x1, &x2 = *tabs.x2;

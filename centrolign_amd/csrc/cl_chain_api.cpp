@@ -246,6 +246,7 @@ namespace {
 struct ChainSub {
     const cl_base_graph* g[2] = {nullptr, nullptr};   // DP orientation: g[0] plays graph1
     bool tableau = true;                               // graphs carry sentinels: PathMerge gets the pseudo-path (path_merge.hpp:148-160)
+    bool chain_merge = false;                          // tables built here are ChainMerge tables (the CLI's -g 1: anchorer.hpp:659-660 with XMerge = ChainMerge)
     const cl_match_sets* ms = nullptr;                 // the sets; DP set s = ms set order[s] (identity if null), and with
     const uint64_t* order = nullptr;                   // swap_sides the DP's graph-1 walks are the sets' walks2
     bool swap_sides = false;                           // (anchorer.hpp:1179-1182), without copying anything
@@ -420,7 +421,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             for (int side = 0; side < 2; ++side) {
                 if (sb.x[side] && sb.sw[side]) { c.x[side] = sb.x[side]; c.sw[side] = sb.sw[side]; }
                 else {
-                    if (!c.own_x[side].build(*sb.g[side], sb.tableau)) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+                    if (!(sb.chain_merge ? c.own_x[side].build_chain_merge(*sb.g[side], sb.tableau) : c.own_x[side].build(*sb.g[side], sb.tableau))) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
                     c.own_sw[side].build(*sb.g[side], c.own_x[side]);
                     c.x[side] = &c.own_x[side];
                     c.sw[side] = &c.own_sw[side];
@@ -2047,9 +2048,16 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     const cl_chain_params& cp = ap->chain;
+    // the CLI's -g (Anchorer::chaining_algorithm): Sparse chains on ChainMerge tables, without a scale estimate (anchorer.hpp:975-984, core.hpp:350-357)
+    const int algo = ap->chaining_algorithm_plus_one ? ap->chaining_algorithm_plus_one - 1 : 2;
+    if (algo != 1 && algo != 2) { cl_set_error(ctx, "chaining algorithm %d is not offered by cl_anchor_chain (1 = Sparse, 2 = SparseAffine; Exhaustive: cl_chain_exhaustive)", algo); return CL_ERR_INVALID_ARGUMENT; }
+    const bool sparse_algo = algo == 1;
     clhost::PathMergeTable own_x1, own_x2;
     const clhost::PathMergeTable* const sx1 = cl_shared_table(g1), * const sx2 = cl_shared_table(g2);   // cl_core_align's, when it is the caller
-    if ((!sx1 && !own_x1.build(*g1)) || (!sx2 && !own_x2.build(*g2))) { cl_set_error(ctx, "graph is not acyclic"); return CL_ERR_CYCLIC_GRAPH; }
+    if ((!sx1 && !(sparse_algo ? own_x1.build_chain_merge(*g1) : own_x1.build(*g1))) || (!sx2 && !(sparse_algo ? own_x2.build_chain_merge(*g2) : own_x2.build(*g2)))) {
+        cl_set_error(ctx, "graph is not acyclic");
+        return CL_ERR_CYCLIC_GRAPH;
+    }
     const clhost::PathMergeTable& x1 = sx1 ? *sx1 : own_x1;
     const clhost::PathMergeTable& x2 = sx2 ? *sx2 : own_x2;
     // anchorer.hpp:1175: the DP runs with the graphs swapped when that makes its tables smaller
@@ -2192,6 +2200,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
             const uint64_t n_use = select_matches(in.view, cp, in.order, budget);
             ChainSub sb;
             sb.tableau = false;
+            sb.chain_merge = sparse_algo;
             sb.ms = &in.view;
             sb.order = in.order.data();
             sb.swap_sides = in.swap;
@@ -2336,6 +2345,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     int rc;
     std::vector<HAnchor> sc;   // the chain of the estimate: estimate_score_scale's chain_out (anchorer.hpp:1042-1044)
     if (override_scale && !scale_only) scale = *override_scale;   // anchorer.hpp:975-978
+    else if (sparse_algo && !scale_only) scale = 1.0;             // (:979: the estimate only adjusts gap penalties, which Sparse does not have)
     else if (ap->autocalibrate_gap_penalties) {
         if ((rc = run(true, 1.0, sc))) return rc;
         auto t = now();
@@ -2372,7 +2382,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     // ---- the affine chain (or, for cl_leaf_calibrate, the estimate's own chain)
     std::vector<HAnchor> ch;
     if (scale_only) ch.swap(sc);
-    else if ((rc = run(false, scale, ch))) return rc;
+    else if ((rc = run(sparse_algo, scale, ch))) return rc;
     const size_t na = ch.size();
     uint64_t total_walk = 0;
     for (const HAnchor& a : ch) total_walk += a.w1.size();

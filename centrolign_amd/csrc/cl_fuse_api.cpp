@@ -294,7 +294,7 @@ int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, 
     };
     // the PathMerge tables of the alignment need the graphs only: built beside the match finding
     ClPathMergeTables tables;
-    tables.start(&a, &b);
+    tables.start(&a, &b, prm->align.anchor.chaining_algorithm_plus_one == 2);
     cl_owned_match_sets* ms = nullptr;
     cl_match_stats mst;
     int rc = cl_find_matches_hooked(ctx, &a, &b, &prm->match, &ms, &mst, &start_pin);

@@ -314,7 +314,7 @@ struct ClPathMergeTables {
     ClPathMergeTables();
     ~ClPathMergeTables();
     ClPathMergeTables(const ClPathMergeTables&) = delete;
-    void start(const cl_base_graph* g1, const cl_base_graph* g2);
+    void start(const cl_base_graph* g1, const cl_base_graph* g2, bool chain_merge = false);
     void wait();
 };
 int cl_core_align_prepared(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* matches, const cl_core_align_params* ap,

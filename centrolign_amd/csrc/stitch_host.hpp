@@ -51,9 +51,66 @@ class PathMergeTable {
 public:
     static constexpr uint32_t kNone = std::numeric_limits<uint32_t>::max();
 
+    // ChainMerge (include/centrolign/chain_merge.hpp:100-160), the reachability structure Core::execute hands to Core::align when the chaining
+    // algorithm is not SparseAffine (core.hpp:350-357, the CLI's -g 0 / 1): a node belongs to ONE chain — the first path that covers it, with its
+    // index among that path's first-covered nodes — plus the sentinel chain; table[node][chain] = the last index on the chain that reaches the
+    // node, by propagation along the edges in topological order.  Same queries as PathMerge below, so every user of the table works on either
+    bool build_chain_merge(const cl_base_graph& g, bool tableau = true) {
+        g_ = &g;
+        n_ = g.n_nodes;
+        chains_ = g.n_paths + (tableau ? 1 : 0);
+        chain_mode_ = true;
+        path_head_.assign(n_, kNone);
+        index_.assign(chains_ * n_, kNone);
+        next_chain_.assign(chains_ * n_, kNone);
+        table_.assign(n_ * chains_, kNone);
+        chain_off_.assign(1, 0);
+        chain_nodes_.clear();
+        std::vector<uint32_t> own_index(n_, kNone);
+        for (uint64_t p = 0; p < g.n_paths; ++p) {
+            uint32_t index = 0;
+            for (uint64_t i = g.path_off[p]; i < g.path_off[p + 1]; ++i) {
+                const uint32_t v = g.path_nodes[i];
+                if (path_head_[v] != kNone) continue;
+                path_head_[v] = (uint32_t)p;
+                own_index[v] = index;
+                index_[p * n_ + v] = index++;
+                chain_nodes_.push_back(v);
+            }
+            chain_off_.push_back(chain_nodes_.size());
+        }
+        if (tableau) {
+            const uint64_t pp = g.n_paths;
+            path_head_[g.src_id] = (uint32_t)pp; own_index[g.src_id] = 0; index_[pp * n_ + g.src_id] = 0;
+            path_head_[g.snk_id] = (uint32_t)pp; own_index[g.snk_id] = 1; index_[pp * n_ + g.snk_id] = 1;
+            chain_nodes_.push_back((uint32_t)g.src_id);
+            chain_nodes_.push_back((uint32_t)g.snk_id);
+            chain_off_.push_back(chain_nodes_.size());
+        }
+        std::vector<uint32_t> order;
+        if (!topological_order(g, order)) return false;
+        for (uint32_t v : order) {
+            const uint32_t cv = path_head_[v];
+            if (cv == kNone) continue;                 // not covered by a path
+            const uint32_t* row = &table_[(uint64_t)v * chains_];
+            for (uint64_t e = g.next_off[v]; e < g.next_off[v + 1]; ++e) {
+                const uint32_t w = g.next_idx[e];
+                if (path_head_[w] == kNone) continue;
+                uint32_t* nrow = &table_[(uint64_t)w * chains_];
+                for (uint64_t c = 0; c < chains_; ++c) {   // (signed comparison: "none" is overwritten, chain_merge.hpp:148-156)
+                    const uint32_t cand = c == cv ? own_index[v] : row[c];
+                    if (cand != kNone && (nrow[c] == kNone || cand > nrow[c])) nrow[c] = cand;
+                }
+            }
+        }
+        return true;
+    }
+    bool chain_mode() const { return chain_mode_; }
+
     // path_merge.hpp:96-163; with a tableau the sentinel pseudo-path is chain number path_size()
     bool build(const cl_base_graph& g, bool tableau = true) {
         g_ = &g;
+        chain_mode_ = false;
         n_ = g.n_nodes;
         chains_ = g.n_paths + (tableau ? 1 : 0);
         path_head_.assign(n_, kNone);
@@ -109,6 +166,7 @@ public:
         for (uint32_t p = path_head_[node]; p != kNone; p = next_chain_[(uint64_t)p * n_ + node]) f(p);
     }
     uint64_t node_at(uint64_t chain, uint64_t index) const {
+        if (chain_mode_) return chain_nodes_[chain_off_[chain] + index];
         if (chain == g_->n_paths) return index ? g_->snk_id : g_->src_id;
         return g_->path_nodes[g_->path_off[chain] + index];
     }
@@ -117,6 +175,9 @@ private:
     const cl_base_graph* g_ = nullptr;
     uint64_t n_ = 0, chains_ = 0;
     std::vector<uint32_t> path_head_, index_, next_chain_, table_;
+    bool chain_mode_ = false;                       // built by build_chain_merge
+    std::vector<uint64_t> chain_off_;
+    std::vector<uint32_t> chain_nodes_;
 };
 
 // flat batch under construction (the cl_stitch_batch layout, owned)

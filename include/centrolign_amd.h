@@ -459,6 +459,10 @@ typedef struct cl_anchor_params {
     double   score_scale;                /* ScoreFunction::score_scale (calibrated per input, src/core.cpp:193) */
     int      autocalibrate_gap_penalties;/* Anchorer::autocalibrate_gap_penalties */
     int      do_fill_in_anchoring;       /* Anchorer::do_fill_in_anchoring (CLI default true) */
+    int      chaining_algorithm_plus_one;/* 0: the default, SparseAffine.  Otherwise Anchorer::ChainAlgorithm + 1 (the CLI's hidden -g, src/main.cpp:128-129):
+                                            2 = Sparse: no scale estimate, sparse_chain_dp for the chain and its fill-in, and — in cl_core_align / cl_merge —
+                                            ChainMerge tables (include/centrolign/chain_merge.hpp:100-225: every node on ONE chain) instead of PathMerge, as
+                                            Core::execute does (core.hpp:350-357); 3 = SparseAffine; 1 = Exhaustive is cl_chain_exhaustive, not offered here */
 } cl_anchor_params;
 
 typedef struct cl_anchor_chain_result {
