@@ -296,14 +296,15 @@ def budget_subset(ms, max_pairs, seed=0):
 
 
 def ref_anchor_chain(g1, g2, ms, max_num_match_pairs=1250000, score_scale=1.0, autocalibrate=True, params=None,
-                     global_anchoring=True, fill_in=False):
+                     global_anchoring=True, fill_in=False, chaining_algorithm=2):
     """the compiled reference's Anchorer::anchor_chain (anchorer.hpp:958-996) on flat inputs; same dict as
-    capi.Context.anchor_chain"""
+    capi.Context.anchor_chain.  chaining_algorithm = Anchorer::ChainAlgorithm (the CLI's hidden -g): 2 SparseAffine over PathMerge, 1 Sparse /
+    0 Exhaustive over ChainMerge (core.hpp:350-357)"""
     from centrolign_amd.capi import BaseGraphC
     lib = ref_lib()
-    lib.ref_anchor_chain.restype = C.c_int
-    lib.ref_anchor_chain.argtypes = [C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.POINTER(CloChainParams),
-                                     C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 13
+    lib.ref_anchor_chain_algo.restype = C.c_int
+    lib.ref_anchor_chain_algo.argtypes = [C.c_int, C.POINTER(BaseGraphC), C.POINTER(BaseGraphC), C.POINTER(CloMatchSets), C.POINTER(CloChainParams),
+                                          C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 13
     lib.ref_free.argtypes = [C.c_void_p]
     params = params or default_chain_params()
     c1, c2, mc = g1.as_c(), g2.as_c(), ms.as_c()
@@ -317,7 +318,7 @@ def ref_anchor_chain(g1, g2, ms, max_num_match_pairs=1250000, score_scale=1.0, a
     order = np.zeros(max(ms.n_sets, 1), np.uint64)
     scale = C.c_double(0)
     w1p, w2p = C.c_void_p(), C.c_void_p()
-    rc = lib.ref_anchor_chain(C.byref(c1), C.byref(c2), C.byref(mc), C.byref(params), int(global_anchoring), int(max_num_match_pairs),
+    rc = lib.ref_anchor_chain_algo(int(chaining_algorithm), C.byref(c1), C.byref(c2), C.byref(mc), C.byref(params), int(global_anchoring), int(max_num_match_pairs),
                               float(score_scale), int(autocalibrate), int(fill_in), 0, anchors.ctypes.data, gb.ctypes.data,
                               ga.ctypes.data, gsb.ctypes.data, gsa.ctypes.data, sc.ctypes.data, C.addressof(n), order.ctypes.data,
                               C.addressof(scale), counts.ctypes.data, walk_off.ctypes.data, C.addressof(w1p), C.addressof(w2p))

@@ -398,6 +398,90 @@ struct OpenAnchorer : public Anchorer {
     using Anchorer::exhaustive_chain_dp;
 };
 
+template <class XMerge>
+static int anchor_chain_with(int algo, const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, const clo_chain_params* cp,
+                     int global_anchoring, uint64_t max_num_match_pairs, double score_scale, int autocalibrate, int fill_in,
+                     int split_branching, uint64_t* anchors_out, int64_t* gap_before, int64_t* gap_after, double* gap_score_before,
+                     double* gap_score_after, double* score, uint64_t* n_anchors, uint64_t* set_order_out, double* scale_out,
+                     uint64_t* counts_out /* [3*n]: count1, count2, full_length */, uint64_t* walk_off_out /* [n+1] */,
+                     uint32_t** walk1_out, uint32_t** walk2_out /* malloc'ed, release with ref_free */) {
+    SentinelTableau t1, t2;
+    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
+    std::vector<match_set_t> sets(ms->n_sets);
+    std::map<std::vector<std::vector<uint64_t>>, uint64_t> identity;
+    for (uint64_t s = 0; s < ms->n_sets; ++s) {
+        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
+            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
+        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
+            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
+        sets[s].count1 = ms->count1[s];
+        sets[s].count2 = ms->count2[s];
+        sets[s].full_length = ms->full_length[s];
+        if (!identity.emplace(sets[s].walks1, s).second) return -2;   // sets must be told apart by their walks
+    }
+    ScoreFunction sf;
+    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
+    sf.pair_count_power = cp->pair_count_power;
+    sf.length_intercept = cp->length_intercept;
+    sf.length_decay_power = cp->length_decay_power;
+    sf.score_scale = score_scale;
+    OpenAnchorer an(sf);
+    for (int i = 0; i < 3; ++i) { an.gap_open[i] = cp->gap_open[i]; an.gap_extend[i] = cp->gap_extend[i]; }
+    an.global_anchoring = global_anchoring != 0;
+    an.max_num_match_pairs = max_num_match_pairs;
+    an.autocalibrate_gap_penalties = autocalibrate != 0;
+    an.do_fill_in_anchoring = fill_in != 0;
+    an.split_matches_at_branchpoints = split_branching != 0;
+    an.chaining_algorithm = (Anchorer::ChainAlgorithm)algo;
+    XMerge pm1(b1, t1), pm2(b2, t2);
+    // the two steps of the public entry, run one after the other so that the estimated scale can be reported
+    double scale = 1.0;
+    if (split_branching) return -3;   // (would have to run before the estimate; not exposed here)
+    std::vector<anchor_t> chain;
+    if (algo == (int)Anchorer::SparseAffine) {
+        if (autocalibrate) scale = an.estimate_score_scale(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, nullptr);
+        chain = an.anchor_chain(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, &scale);
+    } else {
+        chain = an.anchor_chain(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, nullptr);   // (no estimate, no override: anchorer.hpp:973-984)
+    }
+    if (scale_out) *scale_out = scale;
+    for (uint64_t k = 0; k < sets.size(); ++k) {
+        auto it = identity.find(sets[k].walks1);
+        if (it == identity.end()) return -4;
+        set_order_out[k] = it->second;
+    }
+    *n_anchors = chain.size();
+    {
+        uint64_t total = 0;
+        for (const auto& a : chain) total += a.walk1.size();
+        *walk1_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+        *walk2_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+        uint64_t pos = 0;
+        walk_off_out[0] = 0;
+        for (size_t i = 0; i < chain.size(); ++i) {
+            if (chain[i].walk1.size() != chain[i].walk2.size()) return -5;
+            for (size_t j = 0; j < chain[i].walk1.size(); ++j) { (*walk1_out)[pos + j] = (uint32_t)chain[i].walk1[j]; (*walk2_out)[pos + j] = (uint32_t)chain[i].walk2[j]; }
+            pos += chain[i].walk1.size();
+            walk_off_out[i + 1] = pos;
+        }
+    }
+    for (size_t i = 0; i < chain.size(); ++i) {
+        anchors_out[3 * i] = chain[i].match_set;
+        anchors_out[3 * i + 1] = chain[i].idx1;
+        anchors_out[3 * i + 2] = chain[i].idx2;
+        counts_out[3 * i] = chain[i].count1;
+        counts_out[3 * i + 1] = chain[i].count2;
+        counts_out[3 * i + 2] = chain[i].full_length;
+        gap_before[i] = chain[i].gap_before;
+        gap_after[i] = chain[i].gap_after;
+        gap_score_before[i] = chain[i].gap_score_before;
+        gap_score_after[i] = chain[i].gap_score_after;
+        score[i] = chain[i].score;
+    }
+    return 0;
+}
+
+
 extern "C" {
 
 /* algo 0: sparse_affine_chain_dp (anchorer.hpp:1812-2471), algo 1: sparse_chain_dp (:1511-1750); local anchoring,
@@ -470,77 +554,25 @@ int ref_anchor_chain(const cl_base_graph* g1, const cl_base_graph* g2, const clo
                      int global_anchoring, uint64_t max_num_match_pairs, double score_scale, int autocalibrate, int fill_in,
                      int split_branching, uint64_t* anchors_out, int64_t* gap_before, int64_t* gap_after, double* gap_score_before,
                      double* gap_score_after, double* score, uint64_t* n_anchors, uint64_t* set_order_out, double* scale_out,
-                     uint64_t* counts_out /* [3*n]: count1, count2, full_length */, uint64_t* walk_off_out /* [n+1] */,
-                     uint32_t** walk1_out, uint32_t** walk2_out /* malloc'ed, release with ref_free */) {
-    SentinelTableau t1, t2;
-    BaseGraph b1 = build_base_graph(g1, t1), b2 = build_base_graph(g2, t2);
-    std::vector<match_set_t> sets(ms->n_sets);
-    std::map<std::vector<std::vector<uint64_t>>, uint64_t> identity;
-    for (uint64_t s = 0; s < ms->n_sets; ++s) {
-        for (uint64_t w = ms->set_off1[s]; w < ms->set_off1[s + 1]; ++w)
-            sets[s].walks1.emplace_back(ms->nodes1 + ms->walk_off1[w], ms->nodes1 + ms->walk_off1[w + 1]);
-        for (uint64_t w = ms->set_off2[s]; w < ms->set_off2[s + 1]; ++w)
-            sets[s].walks2.emplace_back(ms->nodes2 + ms->walk_off2[w], ms->nodes2 + ms->walk_off2[w + 1]);
-        sets[s].count1 = ms->count1[s];
-        sets[s].count2 = ms->count2[s];
-        sets[s].full_length = ms->full_length[s];
-        if (!identity.emplace(sets[s].walks1, s).second) return -2;   // sets must be told apart by their walks
-    }
-    ScoreFunction sf;
-    sf.anchor_score_function = (ScoreFunction::AnchorScore)cp->anchor_score_function;
-    sf.pair_count_power = cp->pair_count_power;
-    sf.length_intercept = cp->length_intercept;
-    sf.length_decay_power = cp->length_decay_power;
-    sf.score_scale = score_scale;
-    OpenAnchorer an(sf);
-    for (int i = 0; i < 3; ++i) { an.gap_open[i] = cp->gap_open[i]; an.gap_extend[i] = cp->gap_extend[i]; }
-    an.global_anchoring = global_anchoring != 0;
-    an.max_num_match_pairs = max_num_match_pairs;
-    an.autocalibrate_gap_penalties = autocalibrate != 0;
-    an.do_fill_in_anchoring = fill_in != 0;
-    an.split_matches_at_branchpoints = split_branching != 0;
-    an.chaining_algorithm = Anchorer::SparseAffine;
-    PathMerge<uint32_t, uint8_t> pm1(b1, t1), pm2(b2, t2);
-    // the two steps of the public entry, run one after the other so that the estimated scale can be reported
-    double scale = 1.0;
-    if (split_branching) return -3;   // (would have to run before the estimate; not exposed here)
-    if (autocalibrate) scale = an.estimate_score_scale(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, nullptr);
-    std::vector<anchor_t> chain = an.anchor_chain(sets, b1, b2, t1, t2, pm1, pm2, false, nullptr, &scale);
-    if (scale_out) *scale_out = scale;
-    for (uint64_t k = 0; k < sets.size(); ++k) {
-        auto it = identity.find(sets[k].walks1);
-        if (it == identity.end()) return -4;
-        set_order_out[k] = it->second;
-    }
-    *n_anchors = chain.size();
-    {
-        uint64_t total = 0;
-        for (const auto& a : chain) total += a.walk1.size();
-        *walk1_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
-        *walk2_out = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
-        uint64_t pos = 0;
-        walk_off_out[0] = 0;
-        for (size_t i = 0; i < chain.size(); ++i) {
-            if (chain[i].walk1.size() != chain[i].walk2.size()) return -5;
-            for (size_t j = 0; j < chain[i].walk1.size(); ++j) { (*walk1_out)[pos + j] = (uint32_t)chain[i].walk1[j]; (*walk2_out)[pos + j] = (uint32_t)chain[i].walk2[j]; }
-            pos += chain[i].walk1.size();
-            walk_off_out[i + 1] = pos;
-        }
-    }
-    for (size_t i = 0; i < chain.size(); ++i) {
-        anchors_out[3 * i] = chain[i].match_set;
-        anchors_out[3 * i + 1] = chain[i].idx1;
-        anchors_out[3 * i + 2] = chain[i].idx2;
-        counts_out[3 * i] = chain[i].count1;
-        counts_out[3 * i + 1] = chain[i].count2;
-        counts_out[3 * i + 2] = chain[i].full_length;
-        gap_before[i] = chain[i].gap_before;
-        gap_after[i] = chain[i].gap_after;
-        gap_score_before[i] = chain[i].gap_score_before;
-        gap_score_after[i] = chain[i].gap_score_after;
-        score[i] = chain[i].score;
-    }
-    return 0;
+                     uint64_t* counts_out, uint64_t* walk_off_out, uint32_t** walk1_out, uint32_t** walk2_out) {
+    return anchor_chain_with<PathMerge<uint32_t, uint8_t>>((int)Anchorer::SparseAffine, g1, g2, ms, cp, global_anchoring, max_num_match_pairs, score_scale, autocalibrate, fill_in,
+                                                            split_branching, anchors_out, gap_before, gap_after, gap_score_before, gap_score_after, score, n_anchors, set_order_out,
+                                                            scale_out, counts_out, walk_off_out, walk1_out, walk2_out);
+}
+
+/* the same with Anchorer::chaining_algorithm = algo (the CLI's hidden -g: 0 Exhaustive, 1 Sparse) over ChainMerge structures, as Core::execute
+ * builds them for those algorithms (include/centrolign/core.hpp:350-357) */
+int ref_anchor_chain_algo(int algo, const cl_base_graph* g1, const cl_base_graph* g2, const clo_match_sets* ms, const clo_chain_params* cp,
+                          int global_anchoring, uint64_t max_num_match_pairs, double score_scale, int autocalibrate, int fill_in,
+                          int split_branching, uint64_t* anchors_out, int64_t* gap_before, int64_t* gap_after, double* gap_score_before,
+                          double* gap_score_after, double* score, uint64_t* n_anchors, uint64_t* set_order_out, double* scale_out,
+                          uint64_t* counts_out, uint64_t* walk_off_out, uint32_t** walk1_out, uint32_t** walk2_out) {
+    if (algo == (int)Anchorer::SparseAffine)
+        return ref_anchor_chain(g1, g2, ms, cp, global_anchoring, max_num_match_pairs, score_scale, autocalibrate, fill_in, split_branching, anchors_out, gap_before, gap_after,
+                                gap_score_before, gap_score_after, score, n_anchors, set_order_out, scale_out, counts_out, walk_off_out, walk1_out, walk2_out);
+    return anchor_chain_with<ChainMerge>(algo, g1, g2, ms, cp, global_anchoring, max_num_match_pairs, score_scale, autocalibrate, fill_in,
+                                         split_branching, anchors_out, gap_before, gap_after, gap_score_before, gap_score_after, score, n_anchors, set_order_out,
+                                         scale_out, counts_out, walk_off_out, walk1_out, walk2_out);
 }
 
 void ref_free(void* p) { free(p); }

@@ -90,6 +90,26 @@ def test_anchor_chain_matches_reference_golden(gpu_ctx, name, tag, glob, auto, f
         assert got["fill_in_pairs"] > 0 and len(got["chain"]) > 2 * len(z["g.chain"])
 
 
+@pytest.mark.parametrize("tag,glob,fill", [("s", True, True), ("sl", False, False)])
+@pytest.mark.parametrize("m", [0, 1, 2])
+def test_sparse_chaining_over_chain_merge_matches_the_reference(gpu_ctx, m, tag, glob, fill):
+    """the CLI's hidden -g 1: Anchorer::chaining_algorithm = Sparse — no scale estimate, sparse_chain_dp for the chain and its fill-in — over
+    ChainMerge structures (every node on ONE chain; include/centrolign/chain_merge.hpp:100-225), which is what Core::execute builds for that
+    setting (core.hpp:350-357).  Merge 2 pairs graphs of 2 + 2 paths.  Expected: the compiled reference (tests/golden/make_chainmerge_golden.py)"""
+    z = np.load(os.path.join(H.GOLDEN, "anchor4_30k_merge%d.npz" % m))
+    zg = np.load(os.path.join(H.GOLDEN, "chainmerge4_30k_g1.npz"))
+    _, graphs, _ = load_stitch_case("stitch4_30k_merge%d.npz" % m)
+    ms = capi.MatchSets(**{k: z["ms." + k] for k in capi.MatchSets._DT})
+    got = gpu_ctx.anchor_chain(graphs[0], graphs[1], ms, max_num_match_pairs=int(z["max_num_match_pairs"][0]), score_scale=float(z["score_scale"][0]),
+                               fill_in=fill, params=capi.default_chain_params(global_anchoring=glob), chaining_algorithm=1)
+    pre = "m%d.%s." % (m, tag)
+    assert got["scale"] == float(zg[pre + "scale"]) == 1.0
+    for k in ("set_order", "chain", "walk_off", "walk1", "walk2", "count1", "count2", "full_length", "gap_before", "gap_after",
+              "gap_score_before", "gap_score_after", "score"):
+        assert np.array_equal(got[k], zg[pre + k]), k
+    assert len(got["chain"]) != len(z[("f" if fill else "l") + ".chain"])      # (not the SparseAffine chain)
+
+
 @pytest.mark.parametrize("name", ANCHOR_FILES)
 def test_default_anchor_chain_with_splitting(gpu_ctx, name):
     """the default-configured Anchorer::anchor_chain: split_branching_matches, then chaining with fill-in, global anchoring"""
