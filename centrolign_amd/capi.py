@@ -1633,7 +1633,7 @@ class Context:
             self.lib.cl_merge_result_free(C.byref(out))
 
     def msa(self, fasta_text, newick=None, max_num_match_pairs=1250000, max_count=3000, skip_calibration=False, subproblems_prefix=None,
-            restart=False, induced_pairwise_prefix=None, workers=1, cyclize=False, min_cyclizing_length=None, devices=None):
+            restart=False, induced_pairwise_prefix=None, workers=1, cyclize=False, min_cyclizing_length=None, devices=None, chaining_algorithm=None):
         """the whole CLI flow in the library (cl_msa): FASTA text (+ Newick text) -> explicit CIGAR (two sequences) or GFA; returns
         (text bytes, stats dict).  cyclize = the CLI's -c, min_cyclizing_length its -y; devices = device ordinals the worker contexts are
         spread over (worker w on devices[w % len(devices)]; one process, several GPUs)"""
@@ -1643,6 +1643,8 @@ class Context:
         mp.merge.match.max_count = int(max_count)
         mp.merge.align.anchor.max_num_match_pairs = int(max_num_match_pairs)
         mp.skip_calibration = int(skip_calibration)
+        if chaining_algorithm is not None:
+            mp.merge.align.anchor.chaining_algorithm_plus_one = int(chaining_algorithm) + 1   # the CLI's -g: 1 Sparse over ChainMerge, 2 SparseAffine
         mp.n_workers = int(workers)
         dev_arr = None
         if devices:

@@ -15,6 +15,9 @@ from oracle import pyoracle as po  # noqa: E402
 from tests.test_extraction import load_stitch_case  # noqa: E402
 
 
+G1_EXTRA = ("msa4_30k", 4, 30000, 11, 60000)      # (a case where -g 1 prints another graph than the default: checked below)
+
+
 def main():
     out = {}
     for m in range(3):
@@ -28,6 +31,26 @@ def main():
                 out["m%d.%s.%s" % (m, tag, k)] = np.asarray(v)
             print("merge %d %s: %d anchors (SparseAffine/PathMerge had %d), paths %d + %d" % (m, tag, len(r["chain"]), len(z[("f" if fill else "l") + ".chain"]),
                                                                                              len(graphs[0].path_off) - 1, len(graphs[1].path_off) - 1))
+    # the whole CLI flow with -g 1 (src/main.cpp:129), by the compiled reference's own Core::execute (oracle/_ref/ref_cli): the end-to-end cases
+    # of tests/helpers.py:msa_cases() with more than two sequences
+    import subprocess
+    import tempfile
+    from centrolign_amd import msa, synth
+    from tests import helpers as H
+    cli = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
+    with tempfile.TemporaryDirectory() as d:
+        for name, n, length, seed, budget in H.msa_cases() + [G1_EXTRA]:
+            seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+            names = ["seq%d" % i for i in range(n)]
+            synth.write_fasta(os.path.join(d, name + ".fa"), seqs, names)
+            open(os.path.join(d, name + ".nwk"), "w").write(msa.newick(msa.balanced_tree(names)) + ";\n")
+            subprocess.check_call([cli, os.path.join(d, name + ".fa"), os.path.join(d, name + ".nwk"), "-", os.path.join(d, name + ".out"), str(budget), "0", "0",
+                                   "i:chaining_algorithm=1"])
+            out["cli." + name] = np.frombuffer(open(os.path.join(d, name + ".out"), "rb").read(), np.uint8)
+            print("cli -g 1 %s: %d bytes" % (name, len(out["cli." + name])))
+            if name == G1_EXTRA[0]:
+                subprocess.check_call([cli, os.path.join(d, name + ".fa"), os.path.join(d, name + ".nwk"), "-", os.path.join(d, name + ".g2"), str(budget), "0"])
+                assert open(os.path.join(d, name + ".g2"), "rb").read() != bytes(out["cli." + name])
     np.savez_compressed(os.path.join(HERE, "chainmerge4_30k_g1.npz"), **out)
 
 

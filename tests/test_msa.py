@@ -107,6 +107,22 @@ def test_gpu_cl_msa_is_the_cli_flow(gpu_ctx, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", H.msa_cases() + [("msa4_30k", 4, 30000, 11, 60000)], ids=lambda c: c[0])
+def test_gpu_cl_msa_with_the_sparse_chaining_algorithm(gpu_ctx, case):
+    """the CLI's -g 1 (src/main.cpp:129): every merge chains with Anchorer::Sparse over ChainMerge structures (include/centrolign/core.hpp:350-357);
+    text of the compiled reference's Core::execute with that setting (tests/golden/make_chainmerge_golden.py)"""
+    name, n, length, seed, budget = case
+    seqs = synth.hor_sequences(seed, length, n, seq_div=0.01, hor_div=0.03, indel_hor=2)
+    names = ["seq%d" % i for i in range(n)]
+    fasta = "".join(">%s\n%s\n" % (nm, s) for nm, s in zip(names, seqs))
+    want = bytes(np.load(os.path.join(H.GOLDEN, "chainmerge4_30k_g1.npz"))["cli." + name])
+    text, st = gpu_ctx.msa(fasta, msa.newick(msa.balanced_tree(names)) + ";", max_num_match_pairs=budget, chaining_algorithm=1)
+    assert text == (want.rstrip(b"\n") if n == 2 else want) and st["n_merges"] == n - 1
+    if name == "pair_60k":
+        assert want != bytes(Z[name])     # (another text than the default algorithm's; msa4_30k too: checked where the golden is made)
+
+
+@pytest.mark.gpu
 def test_gpu_cl_msa_ten_sequences(gpu_ctx):
     names, seqs, _ = synth.c3_workload(30000)
     fasta = "".join(">%s some description\n%s\n" % (nm, seqs[nm]) for nm in names)
