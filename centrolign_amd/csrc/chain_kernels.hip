@@ -664,6 +664,160 @@ __global__ void __launch_bounds__(kChainMacro) chain_walk_kernel(ClChainDevice D
     }
 }
 
+// chain_walk_fold_kernel — chain_walk_kernel for MORE combinations than workgroups can be resident (kChainWalkMaxCombos): workgroup c
+// walks the F combinations c, c + G, c + 2 G (G workgroups in all), thread t holding the query of pair first + t in each of them (F x 7
+// running maxima in registers) and F record images in LDS (F x 48 KB in the affine DP: F <= 3, a root of 27 + 27 paths).  A workgroup's
+// candidate for a pair is the maximum over its F combinations; the workgroups exchange through the atomic maximum + arrival count per
+// pair (D.xred), counted in workgroups.  Same arithmetic and same stored values as chain_walk_kernel, combination by combination.
+template <bool SPARSE, int F>
+__global__ void __launch_bounds__(kChainMacro) chain_walk_fold_kernel(ClChainDevice D, uint32_t first, uint32_t count) {
+    constexpr int NK = SPARSE ? 1 : 7;
+    constexpr int RW = SPARSE ? 4 : 12;
+    const uint32_t c0 = blockIdx.x, G = gridDim.x;
+    const uint32_t t = threadIdx.x, s = first + t;
+    const bool active = t < count;
+    const int none = enc(CL_CHAIN_NEG);
+    const uint32_t n_combos = D.n_combos;
+    bool has_q[F], has_rec[F];
+    uint32_t qt[F], qoff[F], pos[F];
+    int32_t q[F];
+    int acc[F][7];
+    float w = 0.f, w_init = CL_CHAIN_NEG;
+    if (active) { w = D.weight[s]; w_init = D.init[s]; }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        has_q[f] = has_rec[f] = false;
+        qt[f] = 0; qoff[f] = 0; pos[f] = 0xFFFFFFFFu; q[f] = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[f][k] = none;
+        const uint32_t c = c0 + f * G;
+        if (active && c < n_combos) {
+            const ClChainCombo& cb = D.combos[c];
+            qt[f] = cb.qt[s];
+            has_q[f] = qt[f] != 0xFFFFFFFFu;
+            if (has_q[f]) { qoff[f] = cb.qoff[s]; q[f] = cb.q[s]; }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[f][k] = cb.acc[(size_t)s * 7 + k];
+            pos[f] = cb.own_rec[s];
+            has_rec[f] = pos[f] != 0xFFFFFFFFu;
+        }
+        if (!has_q[f]) qoff[f] = 0;   // a record's offset is never below 0: such a lane accumulates nothing
+    }
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [F][kChainMacro][RW], then the abort flag
+    int (*s_rec)[kChainMacro][RW] = reinterpret_cast<int (*)[kChainMacro][RW]>(s_dyn);
+    int* s_abort = s_dyn + (size_t)F * kChainMacro * RW;
+    if (t == 0) *s_abort = 0;
+    __syncthreads();
+    const uint32_t end = first + count;
+    uint32_t cur = first;
+    while (cur < end) {
+        const uint32_t gend = min(D.group_end[cur], end);
+        if (active && s >= cur && s < gend) {
+            float cand = CL_CHAIN_NEG;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                if (!has_q[f]) continue;
+                if (SPARSE) {
+                    if (acc[f][0] != none) cand = fmaxf(cand, dec(acc[f][0]) + w);
+                } else {
+                    double pen[6];
+                    query_penalties(pen, q[f], D.params);
+                    cand = apply_candidates(cand, acc[f], w, pen);
+                }
+            }
+            float best = fmaxf(w_init, cand);
+            {
+                uint32_t* red = D.xred + 2 * (size_t)s;
+                if (cand != CL_CHAIN_NEG) __hip_atomic_fetch_max(red, (uint32_t)enc(cand) ^ 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(red + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load(red + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < G) {
+                    if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(D.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        atomicExch(D.status, 1u);
+                        *s_abort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t m = __hip_atomic_load(red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (m != 0) best = fmaxf(best, dec((int)(m ^ 0x80000000u)));
+            }
+            if (c0 == 0) D.dp[s] = best;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                if (has_rec[f]) {
+                    const ClChainCombo& cb = D.combos[c0 + f * G];
+                    const uint32_t ins = cb.ins_t[pos[f]], off = cb.off[pos[f]];
+                    const int32_t sig = cb.sigma[pos[f]];
+                    float v[7];
+                    v[0] = best;
+                    if (!SPARSE) {
+#pragma unroll
+                        for (int pw = 0; pw < 6; ++pw) {
+                            const double tt = D.params.scale * D.params.gap_extend[pw / 2] * (double)sig;
+                            v[1 + pw] = (pw % 2 == 1) ? (float)((double)best + tt) : (float)((double)best - tt);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) cb.val[(size_t)k * cb.n_recs + pos[f]] = v[k];
+                    if (D.far_rec) {
+                        int4* fr = reinterpret_cast<int4*>(D.far_rec + (size_t)(D.far_base[c0 + f * G] + pos[f]) * 12);
+                        fr[0] = make_int4((int)ins, (int)off, sig, enc(v[0]));
+                        if (!SPARSE) {
+                            fr[1] = make_int4(enc(v[1]), enc(v[2]), enc(v[3]), enc(v[4]));
+                            fr[2] = make_int4(enc(v[5]), enc(v[6]), 0, 0);
+                        }
+                    }
+                    if (SPARSE) {
+                        *reinterpret_cast<int4*>(&s_rec[f][t][0]) = make_int4((int)ins, (int)off, enc(best), 0);
+                    } else {
+                        *reinterpret_cast<int4*>(&s_rec[f][t][0]) = make_int4((int)ins, (int)off, sig, enc(v[0]));
+                        *reinterpret_cast<int4*>(&s_rec[f][t][4]) = make_int4(enc(v[1]), enc(v[2]), enc(v[3]), enc(v[4]));
+                        *reinterpret_cast<int4*>(&s_rec[f][t][8]) = make_int4(enc(v[5]), enc(v[6]), 0, 0);
+                    }
+                } else {
+                    *reinterpret_cast<int4*>(&s_rec[f][t][0]) = make_int4(-1, -1, 0, INT32_MIN);   // insertion index 0xFFFFFFFF: never a predecessor
+                }
+            }
+        }
+        lds_barrier();
+        if (*s_abort) break;
+        if (active && s >= gend) {
+            const uint32_t l0 = cur - first, l1 = gend - first;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                if (!has_q[f]) continue;
+                if (SPARSE) {
+                    for (uint32_t l = l0; l < l1; ++l) {
+                        const int4 r = *reinterpret_cast<const int4*>(&s_rec[f][l][0]);
+                        acc[f][0] = max(acc[f][0], ((uint32_t)r.x <= qt[f] && (uint32_t)r.y < qoff[f]) ? r.z : INT32_MIN);
+                    }
+                } else {
+                    for (uint32_t l = l0; l < l1; ++l) {
+                        const int4 a = *reinterpret_cast<const int4*>(&s_rec[f][l][0]);
+                        if (a.x == -1) continue;   // (most pairs have no record in a given combination when there are hundreds of them)
+                        const int4 b = *reinterpret_cast<const int4*>(&s_rec[f][l][4]);
+                        const int4 cc4 = *reinterpret_cast<const int4*>(&s_rec[f][l][8]);
+                        const int v[7] = {a.w, b.x, b.y, b.z, b.w, cc4.x, cc4.y};
+                        accumulate(acc[f], qt[f], qoff[f], q[f], (uint32_t)a.x, (uint32_t)a.y, a.z, v);
+                    }
+                }
+            }
+        }
+        cur = gend;
+    }
+    // keep the final maxima: the traceback needs the value every query returned
+    if (active) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const uint32_t c = c0 + f * G;
+            if (c >= n_combos) continue;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) D.combos[c].acc[(size_t)s * 7 + k] = acc[f][k];
+        }
+    }
+}
+
 // own_rec[c][s] = position of pair s's record in combination c (a pair has at most one record per combination)
 __global__ void __launch_bounds__(256) chain_own_rec_kernel(const ClChainCombo* combos) {
     const ClChainCombo cb = combos[blockIdx.y];
@@ -675,6 +829,59 @@ hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hi
     if (max_recs == 0) return hipSuccess;
     hipLaunchKernelGGL(chain_own_rec_kernel, dim3((max_recs + 255) / 256, D.n_combos), dim3(256), 0, stream, D.combos);
     return hipGetLastError();
+}
+
+// the query results of ONE pair in every combination (7 per combination), for a traceback that fetches rows as it goes instead of downloading
+// 28 bytes x pairs x combinations (cl_chain_api.cpp)
+__global__ void __launch_bounds__(256) chain_acc_row_kernel(const ClChainCombo* combos, uint32_t n_combos, uint32_t s, int* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_combos * 7) out[i] = combos[i / 7].acc[(size_t)s * 7 + i % 7];
+}
+
+// the dense query tables out of their factors (cl_chain_api.cpp: factored queries): combination c = (tag1, tag2); fa_d == nullptr: the gap-free DP (no shifts)
+__global__ void __launch_bounds__(256) chain_expand_queries_kernel(const uint32_t* fa_qt, const uint32_t* fa_d, const uint32_t* fb_qoff, const uint32_t* fb_d,
+                                                                   const uint32_t* combo_tags, uint32_t n_pairs, uint32_t* qt, uint32_t* qoff, int32_t* q) {
+    const uint32_t c = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_pairs) return;
+    const size_t a = (size_t)combo_tags[2 * c] * n_pairs + s, b = (size_t)combo_tags[2 * c + 1] * n_pairs + s, at = (size_t)c * n_pairs + s;
+    const uint32_t t = fa_qt[a];
+    const bool ok = t != 0xFFFFFFFFu;
+    qt[at] = t;
+    qoff[at] = ok ? fb_qoff[b] : 0u;
+    q[at] = ok && fa_d ? (int32_t)(fa_d[a] - fb_d[b]) : 0;
+}
+
+hipError_t cl_chain_expand_queries(const uint32_t* fa_qt, const uint32_t* fa_d, const uint32_t* fb_qoff, const uint32_t* fb_d, const uint32_t* combo_tags, uint32_t n_combos,
+                                   uint32_t n_pairs, uint32_t* qt, uint32_t* qoff, int32_t* q, hipStream_t stream) {
+    if (n_combos == 0 || n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(chain_expand_queries_kernel, dim3((n_pairs + 255) / 256, n_combos), dim3(256), 0, stream, fa_qt, fa_d, fb_qoff, fb_d, combo_tags, n_pairs, qt, qoff, q);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_acc_row(const ClChainDevice& D, uint32_t s, int* out, hipStream_t stream) {
+    hipLaunchKernelGGL(chain_acc_row_kernel, dim3((D.n_combos * 7 + 255) / 256), dim3(256), 0, stream, D.combos, D.n_combos, s, out);
+    return hipGetLastError();
+}
+
+// fold = combinations per workgroup (2 or 3; needs D.xred)
+template <bool SPARSE, int F>
+static hipError_t launch_walk_fold(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done) {
+    const size_t lds = (size_t)F * kChainMacro * (SPARSE ? 4 : 12) * sizeof(int) + 16;
+    static bool raised = false;   // (beyond 64 KB of dynamic LDS the kernel has to be told once)
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_walk_fold_kernel<SPARSE, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    const uint32_t G = (D.n_combos + F - 1) / F;
+    hipExtLaunchKernelGGL((chain_walk_fold_kernel<SPARSE, F>), dim3(G), dim3(kChainMacro), lds, stream, nullptr, done, 0, D, first, count);
+    return hipGetLastError();
+}
+
+hipError_t cl_chain_launch_walk_fold(const ClChainDevice& D, uint32_t fold, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done) {
+    if (!D.xred || fold < 2 || fold > 3) return hipErrorInvalidValue;
+    if (D.sparse) return fold == 2 ? launch_walk_fold<true, 2>(D, first, count, stream, done) : launch_walk_fold<true, 3>(D, first, count, stream, done);
+    return fold == 2 ? launch_walk_fold<false, 2>(D, first, count, stream, done) : launch_walk_fold<false, 3>(D, first, count, stream, done);
 }
 
 hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done) {   // done: see cl_chain_launch_walk2

@@ -40,9 +40,13 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
                                  uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
 hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done);
+hipError_t cl_chain_launch_walk_fold(const ClChainDevice& D, uint32_t fold, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done);
 hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream, hipEvent_t done);   // chain_walk2.hip
 uint32_t cl_chain_walk2_helpers(uint32_t qpt);
 hipError_t cl_chain_launch_own_rec(const ClChainDevice& D, uint32_t max_recs, hipStream_t stream);
+hipError_t cl_chain_acc_row(const ClChainDevice& D, uint32_t s, int* out, hipStream_t stream);
+hipError_t cl_chain_expand_queries(const uint32_t* fa_qt, const uint32_t* fa_d, const uint32_t* fb_qoff, const uint32_t* fb_d, const uint32_t* combo_tags, uint32_t n_combos,
+                                   uint32_t n_pairs, uint32_t* qt, uint32_t* qoff, int32_t* q, hipStream_t stream);
 // chain_far.hip
 hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uint32_t max_padded, uint32_t r_pad, int32_t sig_bias, uint32_t band_shift,
                              uint32_t off_bits, uint32_t* key_off, uint32_t* key_band, uint32_t* idx, hipStream_t stream);
@@ -711,9 +715,48 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         }
     }
     lap("records");
+    if (timing) {
+        size_t total = 0, largest = 0;
+        for (const Combo& c : combos) { total += c.rec_s.size(); largest = std::max(largest, c.rec_s.size()); }
+        fprintf(stderr, "[chain_dp_batch]   %zu pairs, %zu combinations, %zu records (largest combination %zu)\n", (size_t)M, combos.size(), total, largest);
+    }
     tm.n_combos = (uint32_t)combos.size();
     for (const Combo& c : combos) tm.pair_evals += 0.5 * (double)c.rec_s.size() * (double)M;
     const uint32_t n_blocks = (uint32_t)((M + kChainBlock - 1) / kChainBlock);
+    // The queries are dense — one per pair and combination — but they factor: the insertion bound depends on (pair, chain of graph 1) only, the offset
+    // bound on (pair, chain of graph 2), and the shift is a difference of one term of each (all modulo 2^32, as the reference's size_t arithmetic
+    // truncated).  A single-instance DP of some size keeps the factors on the host (n_tag[0] + n_tag[1] arrays instead of 3 x combinations: 0.5 GB
+    // instead of 9.4 GB at 25 + 25 paths and 1.25 M pairs) and lets the device multiply them out (chain_expand_queries_kernel); the traceback
+    // multiplies out the handful it looks at.  CL_CHAIN_DENSE_QUERIES=1: the dense tables of rounds 1-3 (A/B).
+    static const bool dense_env = getenv("CL_CHAIN_DENSE_QUERIES") != nullptr;
+    const bool factored = K == 1 && !dense_env && (uint64_t)combos.size() * M > 100000;
+    ClRawVec<uint32_t> fa_qt, fa_d, fb_qoff, fb_d;   // [tag][M]
+    if (factored) {
+        fa_qt.resize((size_t)n_tag[0] * M);
+        fb_qoff.resize((size_t)n_tag[1] * M);
+        if (!sparse) { fa_d.resize((size_t)n_tag[0] * M); fb_d.resize((size_t)n_tag[1] * M); }
+        cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
+            for (uint32_t s = (uint32_t)s_begin; s < s_end; ++s) {
+                const Pair& p = pairs[by_s[s]];
+                const SubCtx& c = sc[p.sub];
+                const bool start = c.has_start[p.b1];
+                for (uint32_t p1 = 0; p1 < c.x[0]->chain_size(); ++p1) {
+                    const uint32_t pr = start ? c.x[0]->predecessor_index(p.b1, p1) : kNone;
+                    // a forward edge exists only from a node that follows some match end (forward_edges.hpp:40-53)
+                    const bool ok = pr != kNone && c.after_end[c.x[0]->node_at(p1, pr)];
+                    const size_t at = (size_t)tag_of(p.sub, 0, p1) * M + s;
+                    fa_qt[at] = ok ? pr + c.off_a : kNone;
+                    if (!sparse) fa_d[at] = ok ? pr + c.sw[0]->distance(p.b1, p1) : 0u;
+                }
+                for (uint32_t p2 = 0; p2 < c.x[1]->chain_size(); ++p2) {
+                    const uint32_t pr2 = c.x[1]->predecessor_index(p.b2, p2);
+                    const size_t at = (size_t)tag_of(p.sub, 1, p2) * M + s;
+                    fb_qoff[at] = pr2 + 1u + c.off_b;
+                    if (!sparse) fb_d[at] = pr2 + c.sw[1]->distance(p.b2, p2);
+                }
+            }
+        });
+    } else {
     cl_parallel_for(combos.size(), [&](uint64_t c_begin, uint64_t c_end) {   // 15 MB per combination at 1.25 M pairs, 25 combinations at the root
         for (uint64_t ci = c_begin; ci < c_end; ++ci) {
             combos[ci].qt.assign(M, kNone);
@@ -741,6 +784,16 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         }
     }
     });
+    }
+    // the query of pair s in combination ci, whichever way it is kept
+    auto query_at = [&](size_t ci, uint32_t s, uint32_t& qt, uint32_t& qoff, int32_t& q) {
+        const Combo& c = combos[ci];
+        if (!factored) { qt = c.qt[s]; qoff = c.qoff[s]; q = c.q[s]; return; }
+        qt = fa_qt[(size_t)c.p1 * M + s];
+        if (qt == kNone) { qoff = 0; q = 0; return; }
+        qoff = fb_qoff[(size_t)c.p2 * M + s];
+        q = sparse ? 0 : (int32_t)(fa_d[(size_t)c.p1 * M + s] - fb_d[(size_t)c.p2 * M + s]);
+    };
     for (Combo& c : combos) {
         c.prefix.assign(n_blocks + 1, 0);
         size_t r = 0;
@@ -761,6 +814,10 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<char> d_pack;              // a small DP's arrays in one block (below)
     size_t pack_dp_off = 0, pack_acc_stride = 0, pack_down_bytes = 0;
     DevBuf<uint32_t> d_xred;
+    DevBuf<int> d_row;                // the traceback's row of query results, when it fetches them step by step
+    DevBuf<uint32_t> d_blk_rec, d_blk_q, d_blk_own, d_fa[4], d_ctags;   // factored queries: every combination's arrays as views into a few blocks
+    DevBuf<float> d_blk_val;
+    DevBuf<int> d_blk_acc;
     DevBuf<int> k_in, k_out;          // value index of the traceback (built on demand)
     DevBuf<uint32_t> i_in, i_out;
     DevBuf<char> vtemp;
@@ -774,14 +831,20 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // the walk kernel (one workgroup per combination, all resident) replaces the per-block intra launches up to
     // kChainWalkMaxCombos combinations; CL_CHAIN_OLD_WALK=1 forces the per-block path (A/B measurements)
     static const bool old_walk_env = getenv("CL_CHAIN_OLD_WALK") != nullptr;
-    const bool use_walk = allow_walk && combos.size() <= kChainWalkMaxCombos && !old_walk_env;
+    // beyond kChainWalkMaxCombos a workgroup of the walk takes two or three combinations (chain_walk_fold_kernel: 768 combinations, a root of
+    // 27 + 27 paths); CL_CHAIN_WALK_FOLD=2/3 folds smaller DPs too (tests)
+    static const uint32_t fold_env = [] { const char* e = getenv("CL_CHAIN_WALK_FOLD"); const int v = e ? atoi(e) : 0; return v == 2 || v == 3 ? (uint32_t)v : 0u; }();
+    const uint32_t walk_fold = std::max<uint32_t>(combos.size() > 1 ? fold_env : 0u, (uint32_t)((combos.size() + kChainWalkMaxCombos - 1) / kChainWalkMaxCombos));
+    const bool use_walk = allow_walk && walk_fold <= 3 && !old_walk_env;
     std::vector<ClChainCombo> hc(combos.size());
     auto cleanup = [&]() {
         cl_ctx_quiesce(ctx);   // once, for the ~40 blocks that go back to the pool below
         for (Combo& c : combos) c.release(true);
         d_combos.release(true); d_weight.release(true); d_init.release(true); d_dp.release(true); d_rec_off.release(true); d_rec_combo.release(true); d_rec_pos.release(true); d_group.release(true); d_grp_base.release(true); d_grp_total.release(true);
         d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xdp.release(true); d_hacc.release(true); d_xred.release(true); d_pack.release(true);
-        k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true);
+        k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true); d_row.release(true);
+        d_blk_rec.release(true); d_blk_q.release(true); d_blk_own.release(true); d_blk_val.release(true); d_blk_acc.release(true); d_ctags.release(true);
+        for (auto& b : d_fa) b.release(true);
         d_far_rec.release(true); d_far_base.release(true); d_seal_items.release(true); d_far_temp.release(true);
         for (auto& b : d_far_perm) b.release(true);
         for (auto& b : d_far_u32) b.release(true);
@@ -820,7 +883,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     static const uint32_t walk2_max = [] { const char* e = getenv("CL_CHAIN_WALK2_MAX"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : 8u; }();
     static const int walk2_help_env = [] { const char* e = getenv("CL_CHAIN_WALK2_HELPERS"); return e ? atoi(e) : -1; }();
     uint32_t walk2_help = cl_chain_walk2_helpers(walk2_qpt);
-    const bool use_walk2 = use_walk && !packed && walk2_env && combos.size() <= walk2_max && ((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help) <= 256;
+    const bool use_walk2 = use_walk && walk_fold <= 1 && !packed && walk2_env && combos.size() <= walk2_max && ((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help) <= 256;
     if (walk2_help_env >= 0) walk2_help = (uint32_t)std::min(walk2_help_env, 7);
     if (packed) {
         CH(d_pack.alloc(ctx, pack_total));
@@ -856,6 +919,55 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         if (hipMemcpyAsync(dev, stage.data(), pack_total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
             cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP;
         }
+    } else if (factored) {
+        // a few blocks instead of eleven allocations and eight copies per combination (625 combinations: 7 000 allocations, 5 000 copies)
+        const size_t C = combos.size();
+        std::vector<size_t> rbase(C + 1, 0);
+        for (size_t ci = 0; ci < C; ++ci) rbase[ci + 1] = rbase[ci] + combos[ci].rec_s.size();
+        const size_t R_all = rbase[C], pw = (size_t)n_blocks + 1;
+        ClRawVec<uint32_t> stage(4 * R_all + C * pw);
+        cl_parallel_for(C, [&](uint64_t c_begin, uint64_t c_end) {
+            for (uint64_t ci = c_begin; ci < c_end; ++ci) {
+                const Combo& c = combos[ci];
+                const size_t n = c.rec_s.size();
+                if (n) {
+                    memcpy(&stage[rbase[ci]], c.rec_s.data(), n * 4); memcpy(&stage[R_all + rbase[ci]], c.ins_t.data(), n * 4);
+                    memcpy(&stage[2 * R_all + rbase[ci]], c.off.data(), n * 4); memcpy(&stage[3 * R_all + rbase[ci]], c.sigma.data(), n * 4);
+                }
+                memcpy(&stage[4 * R_all + ci * pw], c.prefix.data(), pw * 4);
+            }
+        }, 1);
+        std::vector<uint32_t> ctags(2 * C);
+        for (size_t ci = 0; ci < C; ++ci) { ctags[2 * ci] = combos[ci].p1; ctags[2 * ci + 1] = combos[ci].p2; }
+        CH(d_blk_rec.upload_async(ctx, stage));
+        CH(d_ctags.upload_async(ctx, ctags));
+        CH(d_fa[0].upload_async(ctx, fa_qt)); CH(d_fa[1].upload_async(ctx, fb_qoff));
+        if (!sparse) { CH(d_fa[2].upload_async(ctx, fa_d)); CH(d_fa[3].upload_async(ctx, fb_d)); }
+        CH(d_blk_val.alloc(ctx, 7 * R_all));
+        CH(d_blk_q.alloc(ctx, 3 * C * (size_t)M));
+        CH(d_blk_acc.alloc(ctx, C * (size_t)M * 7));
+        CH(d_blk_own.alloc(ctx, C * (size_t)M));
+        if (hipMemsetD32Async((hipDeviceptr_t)d_blk_acc.p, enc(CL_CHAIN_NEG), C * (size_t)M * 7, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(d_blk_own.p, 0xFF, C * (size_t)M * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
+        if (cl_chain_expand_queries(d_fa[0].p, d_fa[2].p, d_fa[1].p, d_fa[3].p, d_ctags.p, (uint32_t)C, (uint32_t)M, d_blk_q.p, d_blk_q.p + C * (size_t)M,
+                                    (int32_t*)(d_blk_q.p + 2 * C * (size_t)M), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "query expansion failed"); return CL_ERR_HIP; }
+        for (size_t ci = 0; ci < C; ++ci) {
+            Combo& c = combos[ci];
+            const size_t n = c.rec_s.size();
+            c.d_rec_s.view(d_blk_rec.p + rbase[ci], n); c.d_ins_t.view(d_blk_rec.p + R_all + rbase[ci], n); c.d_off.view(d_blk_rec.p + 2 * R_all + rbase[ci], n);
+            c.d_sigma.view((int32_t*)(d_blk_rec.p + 3 * R_all + rbase[ci]), n); c.d_prefix.view(d_blk_rec.p + 4 * R_all + ci * pw, pw);
+            c.d_qt.view(d_blk_q.p + ci * (size_t)M, M); c.d_qoff.view(d_blk_q.p + (C + ci) * (size_t)M, M); c.d_q.view((int32_t*)(d_blk_q.p + (2 * C + ci) * (size_t)M), M);
+            c.d_val.view(d_blk_val.p + 7 * rbase[ci], 7 * n); c.d_acc.view(d_blk_acc.p + ci * (size_t)M * 7, (size_t)M * 7);
+            if (use_walk) c.d_own_rec.view(d_blk_own.p + ci * (size_t)M, M);
+            hc[ci] = ClChainCombo{(uint32_t)n, c.d_rec_s.p, c.d_ins_t.p, c.d_off.p, c.d_sigma.p, c.d_val.p, c.d_prefix.p,
+                                  c.d_qt.p, c.d_qoff.p, c.d_q.p, c.d_acc.p, c.d_own_rec.p};
+        }
+        CH(d_combos.upload_async(ctx, hc));
+        CH(d_weight.upload_async(ctx, weight));
+        CH(d_init.upload_async(ctx, init_w));
+        CH(d_dp.alloc(ctx, M));
+        CH(d_rec_off.upload_async(ctx, rec_off)); CH(d_rec_combo.upload_async(ctx, rec_combo)); CH(d_rec_pos.upload_async(ctx, rec_pos));
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP; }
     } else {
     for (size_t ci = 0; ci < combos.size(); ++ci) {
         Combo& c = combos[ci];
@@ -940,7 +1052,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
             // the exchange between the walk's workgroups: granule sweep for few combinations, reduction for many (CL_CHAIN_WALK_REDUCE=0/1 pins it: A/B)
             static const char* reduce_env = getenv("CL_CHAIN_WALK_REDUCE");
-            const bool reduce = reduce_env ? reduce_env[0] == '1' : combos.size() > kChainWalkSweepCombos;
+            const bool reduce = walk_fold > 1 || (reduce_env ? reduce_env[0] == '1' : combos.size() > kChainWalkSweepCombos);
             if (reduce && combos.size() > 1) {
                 CH(d_xred.alloc(ctx, 2 * M));
                 if (hipMemsetAsync(d_xred.p, 0, 2 * M * sizeof(uint32_t), ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetAsync failed"); return CL_ERR_HIP; }
@@ -1310,6 +1422,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
             if (he == hipSuccess) he = cl_ring_event(ctx, 0, k, &ev_walk[k]);
             if (he == hipSuccess) he = use_walk2 ? cl_chain_launch_walk2(D, first, count, walk2_qpt, walk2_help, ctx->stream, ext_events ? ev_walk[k] : nullptr)
+                                                 : walk_fold > 1 ? cl_chain_launch_walk_fold(D, walk_fold, first, count, ctx->stream, ext_events ? ev_walk[k] : nullptr)
                                                  : cl_chain_launch_walk(D, first, count, ctx->stream, ext_events ? ev_walk[k] : nullptr);
             if (he == hipSuccess && !ext_events) he = hipEventRecord(ev_walk[k], ctx->stream);
             if (use_far && far_bb && he == hipSuccess && k + far_lag + 1 < n_macro) {
@@ -1425,8 +1538,32 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     } else
     he = cl_copy_sync(ctx, dp_sorted.data(), d_dp.p, M * sizeof(float), hipMemcpyDeviceToHost);
     // the stored query results of every combination (7 per pair): into the context's page-locked area when it can be had — 35 MB per
-    // combination at 1.25 M pairs, 25 combinations at the root of a 10-sequence tree
-    if (he == hipSuccess && !d_pack.p) {
+    // combination at 1.25 M pairs, 25 combinations at the root of a 10-sequence tree.  Beyond kLazyAccBytes (a root of 25 + 25 paths: 625
+    // combinations, 21.9 GB at 1.25 M pairs — 4.3 s of copies into 22 GB of pageable memory, more than the DP itself) nothing is downloaded: the
+    // traceback reads the results of the pair it stands on and nothing else, so it fetches that row (7 x combinations words) step by step
+    // (chain_acc_row_kernel; a launch, a 17 KB copy and a wait per chain step).  CL_CHAIN_LAZY_ACC=0/1 pins the choice (tests).
+    constexpr size_t kLazyAccBytes = 1536ull << 20;
+    static const char* lazy_env = getenv("CL_CHAIN_LAZY_ACC");
+    const bool lazy_acc = !d_pack.p && (lazy_env ? lazy_env[0] == '1' : combos.size() * (size_t)M * 7 * sizeof(int) > kLazyAccBytes);
+    std::vector<int> row_host;
+    uint32_t row_s = kNone;
+    int* row_pin = nullptr;
+    if (he == hipSuccess && lazy_acc) {
+        rc = d_row.alloc(ctx, combos.size() * 7);
+        if (rc) { cleanup(); return rc; }
+        row_pin = (int*)cl_pinned(ctx, combos.size() * 7 * sizeof(int));
+        if (!row_pin) { row_host.resize(combos.size() * 7); row_pin = row_host.data(); }
+    }
+    // row of pair s: 7 words per combination
+    auto acc_row = [&](uint32_t s) -> const int* {
+        if (row_s == s) return row_pin;
+        hipError_t e = cl_chain_acc_row(D, s, d_row.p, ctx->stream);
+        if (e == hipSuccess) e = cl_copy_sync(ctx, row_pin, d_row.p, combos.size() * 7 * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { cl_set_error(ctx, "traceback: fetching the query results of pair %u failed: %s", s, hipGetErrorString(e)); return nullptr; }
+        row_s = s;
+        return row_pin;
+    };
+    if (he == hipSuccess && !d_pack.p && !lazy_acc) {
         const size_t per = (size_t)M * 7;
         int* pin = (int*)cl_pinned(ctx, combos.size() * per * sizeof(int));
         if (pin) {
@@ -1573,13 +1710,17 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (sk.has_start[p.b1] && sk.after_end[from]) edges.emplace_back(sk.pos1[from], p1);
             }
             std::sort(edges.begin(), edges.end());
+            const int* arow = nullptr;
+            if (lazy_acc && !(arow = acc_row(s))) { release_index(); cleanup(); return CL_ERR_HIP; }
             int win_combo = -1, win_kind = -1;
             for (size_t e = 0; e < edges.size() && win_combo < 0; ++e)
                 for (uint32_t p2 = 0; p2 < C2 && win_combo < 0; ++p2) {
                     const uint32_t ci = combo_of[(size_t)tag_of(k, 0, edges[e].second) * n_tag[1] + tag_of(k, 1, p2)];
                     if (ci == kNone) continue;  // empty trees
-                    const Combo& c = combos[ci];
-                    const int* a = &acc[ci][(size_t)s * 7];
+                    const int* a = lazy_acc ? arow + (size_t)ci * 7 : &acc[ci][(size_t)s * 7];
+                    uint32_t c_qt, c_qoff;
+                    int32_t c_q;
+                    query_at(ci, s, c_qt, c_qoff, c_q);
                     for (int kind = 0; kind < (sparse ? 1 : 7); ++kind) {
                         if (a[kind] == enc(CL_CHAIN_NEG)) continue;
                         const float stored = dec(a[kind]);
@@ -1587,8 +1728,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                         if (kind == 0) cand = stored + w;
                         else {
                             const int pw = kind - 1;
-                            const double pen = (pw % 2 == 1) ? local_scale * (cp->gap_open[pw / 2] + cp->gap_extend[pw / 2] * (double)c.q[s])
-                                                             : local_scale * (cp->gap_open[pw / 2] - cp->gap_extend[pw / 2] * (double)c.q[s]);
+                            const double pen = (pw % 2 == 1) ? local_scale * (cp->gap_open[pw / 2] + cp->gap_extend[pw / 2] * (double)c_q)
+                                                             : local_scale * (cp->gap_open[pw / 2] - cp->gap_extend[pw / 2] * (double)c_q);
                             cand = (float)((double)(stored + w) - pen);
                         }
                         if (cand == dpv) { win_combo = (int)ci; win_kind = kind; break; }
@@ -1596,16 +1737,19 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 }
             if (win_combo < 0) { cl_set_error(ctx, "traceback: no candidate reproduces dp of pair %u", here); cleanup(); return CL_ERR_HIP; }
             Combo& c = combos[win_combo];
+            uint32_t wq_t, wq_off;
+            int32_t wq;
+            query_at((size_t)win_combo, s, wq_t, wq_off, wq);
             // every predecessor whose stored value equals the query's maximum and which lies in the query's range
             cand.clear();
             {
                 const auto t0 = tnow();
-                const int target = acc[win_combo][(size_t)s * 7 + win_kind];
+                const int target = lazy_acc ? arow[(size_t)win_combo * 7 + win_kind] : acc[win_combo][(size_t)s * 7 + win_kind];
                 if (!value_index((size_t)win_combo, win_kind)) { release_index(); cleanup(); return CL_ERR_HIP; }
                 const auto& keys = vkeys[win_combo][win_kind];
                 const auto& recs = vrecs[win_combo][win_kind];
-                const uint32_t qt = c.qt[s], qoff = c.qoff[s];
-                const int32_t qq = c.q[s];
+                const uint32_t qt = wq_t, qoff = wq_off;
+                const int32_t qq = wq;
                 for (size_t i = std::lower_bound(keys.begin(), keys.end(), target) - keys.begin(); i < keys.size() && keys[i] == target; ++i) {
                     ++n_scanned;
                     const uint32_t r = recs[i];
@@ -1633,11 +1777,11 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     GapFreeTree* tree;
                     if (!sparse) {
                         Combo::SubRecs& sr = sub_recs(c, k);
-                        tree = &sr.diag_tree[c.q[s]];
+                        tree = &sr.diag_tree[wq];
                         if (!tree->built) {   // the records of this shift are one run of the (shift, slot) order
                             const auto t0 = tnow();
                             ortho_of(sr, c);
-                            const int32_t qq = c.q[s];
+                            const int32_t qq = wq;
                             auto it = std::partition_point(sr.ortho_order.begin(), sr.ortho_order.end(), [&](uint32_t r) { return c.sigma[r] < qq; });
                             for (; it != sr.ortho_order.end() && c.sigma[*it] == qq; ++it) tree->mem.push_back(GapFreeTree::Member{c.off[*it], slot_of_rec(*it), *it});
                             tadd(t_diag, t0);
@@ -1670,7 +1814,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     const size_t n = mem.size();
                     const auto& h = tree->heap;
                     const auto& rank_of_heap = tree->rank_of_heap;
-                    const size_t rhi = std::partition_point(mem.begin(), mem.end(), [&](const GapFreeTree::Member& m) { return m.off < c.qoff[s]; }) - mem.begin();
+                    const size_t rhi = std::partition_point(mem.begin(), mem.end(), [&](const GapFreeTree::Member& m) { return m.off < wq_off; }) - mem.begin();
                     std::vector<std::pair<size_t, uint32_t>> ch;  // (heap node, record)
                     for (uint32_t r : cand) {
                         const GapFreeTree::Member key{c.off[r], slot_of_rec(r), r};
@@ -1695,7 +1839,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     auto key_less = [&](uint32_t a, uint32_t b) { return c.sigma[a] != c.sigma[b] ? c.sigma[a] < c.sigma[b] : slot_of_rec(a) < slot_of_rec(b); };
                     ortho_of(sr, c);
                     const size_t n = sr.ortho_order.size();
-                    const int32_t qq = c.q[s];
+                    const int32_t qq = wq;
                     const bool odd = (win_kind - 1) % 2 == 1;
                     // rank interval of the key1 range: shift < query (odd trees) or shift > query (even trees)
                     size_t lo = 0, hi = n;
@@ -1765,6 +1909,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         for (uint32_t slot = 0; slot < M; ++slot) (*dp_out)[slot] = dp_sorted[s_of_slot[slot]];
     }
     cleanup();
+    lap("release");
     return CL_OK;
 #undef CH
 }

@@ -44,6 +44,14 @@ VARIANTS = [
     ("near_in_two_launches", {"CL_CHAIN_NEAR_SPLIT": "1"}),
     # the events between the streams as runtime calls of their own (rounds 2-3) instead of riding on the launches they follow
     ("event_records", {"CL_CHAIN_EXT_EVENTS": "0"}),
+    # the traceback fetches the query results of the pair it stands on step by step (the way of merges with hundreds of combinations, whose
+    # results would be tens of gigabytes) instead of downloading all of them
+    ("traceback_rows_on_demand", {"CL_CHAIN_LAZY_ACC": "1"}),
+    # two and three combinations per workgroup of the walk (chain_walk_fold_kernel: the way of merges with more than 256 combinations)
+    # the dense query tables built on the host as in rounds 1-3 (by default the host keeps their factors and the device multiplies them out)
+    ("dense_queries", {"CL_CHAIN_DENSE_QUERIES": "1"}),
+    ("walk_fold2", {"CL_CHAIN_WALK_FOLD": "2"}),
+    ("walk_fold3", {"CL_CHAIN_WALK_FOLD": "3", "CL_CHAIN_FAR_MODE": "bb"}),
 ]
 
 
@@ -67,7 +75,7 @@ def dense_input(gpu_ctx, tmp_path_factory):
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
     for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES", "CL_CHAIN_WALK2", "CL_CHAIN_WALK2_QPT",
-              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS"):
+              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS", "CL_CHAIN_LAZY_ACC", "CL_CHAIN_WALK_FOLD", "CL_CHAIN_DENSE_QUERIES"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
