@@ -1140,7 +1140,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
-    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest",
+    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_memory",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
@@ -1701,6 +1701,13 @@ class Context:
         self.lib.cl_context_peer_stats.argtypes = [C.c_void_p, C.c_void_p]
         self._check(self.lib.cl_context_peer_stats(self.handle, st))
         return dict(shared_dps=int(st[0]), shared_far_launches=int(st[1]), merged_blocks=int(st[2]), epoch_mark=int(st[3]), selftest_mark=int(st[4]))
+
+    def memory_stats(self, reset_peak=False):
+        """cl_context_memory: device bytes this context holds / held at most / keeps cached, hipMemGetInfo's free and total, page-locked host bytes"""
+        st = (C.c_uint64 * 6)()
+        self.lib.cl_context_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self._check(self.lib.cl_context_memory(self.handle, st, int(bool(reset_peak))))
+        return dict(zip(("live_bytes", "peak_bytes", "cached_bytes", "device_free_bytes", "device_total_bytes", "pinned_host_bytes"), [int(x) for x in st]))
 
     def close(self):
         if self.handle:

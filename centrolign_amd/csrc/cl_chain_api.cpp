@@ -1470,6 +1470,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     }
     if (he == hipSuccess) he = hipEventRecord(ev1, ctx->stream);
     lap("enqueue (host)");
+    if (timing) {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        fprintf(stderr, "[chain_dp_batch]   device memory held by the context: %.1f MB (%s queries, far pass %s: %u padded records in %u levels, %u + %u tags, walk %s)\n", ctx->dev_live_bytes / 1048576.0,
+                factored ? "factored" : "dense", use_far ? "on" : "off", use_far ? F.r_pad : 0u, use_far ? F.n_levels : 0u, n_tag[0], n_tag[1],
+                !use_walk ? "off" : use_walk2 ? "2" : walk_fold > 1 ? "fold" : "1");
+    }
     if (he == hipSuccess && ctx->peers.n > 1) {
         // inside a merge group the serial stream waits for the other members' arrival words: a member that has failed would leave this
         // call waiting for ever, so the wait is a poll with a limit (CL_PEER_TIMEOUT_S, default 600 s); past it the context is unusable

@@ -61,6 +61,7 @@ struct cl_context {
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_size;
     size_t pool_free_bytes = 0;
+    size_t dev_live_bytes = 0, dev_peak_bytes = 0;   // device bytes handed out by cl_dev_alloc and not yet given back; the high-water mark (cl_context_memory)
 };
 constexpr size_t kPoolCap = 24ull << 30;
 
@@ -79,6 +80,8 @@ inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
     if (it != ctx->pool_free.end() && it->first <= 2 * bytes + (1u << 20)) {
         *out = it->second;
         ctx->pool_free_bytes -= it->first;
+        ctx->dev_live_bytes += it->first;
+        ctx->dev_peak_bytes = std::max(ctx->dev_peak_bytes, ctx->dev_live_bytes);
         ctx->pool_free.erase(it);
         return hipSuccess;
     }
@@ -88,7 +91,11 @@ inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
         cl_pool_trim(ctx);
         e = hipMalloc(out, bytes);
     }
-    if (e == hipSuccess) ctx->pool_size[*out] = bytes;
+    if (e == hipSuccess) {
+        ctx->pool_size[*out] = bytes;
+        ctx->dev_live_bytes += bytes;
+        ctx->dev_peak_bytes = std::max(ctx->dev_peak_bytes, ctx->dev_live_bytes);
+    }
     return e;
 }
 
@@ -122,6 +129,7 @@ inline void cl_dev_free(cl_context* ctx, void* p, bool quiesced = false) {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     auto it = ctx->pool_size.find(p);
     if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
+    ctx->dev_live_bytes -= std::min(ctx->dev_live_bytes, it->second);
     if (ctx->pool_free_bytes + it->second > kPoolCap) { ctx->pool_size.erase(it); (void)hipFree(p); return; }
     ctx->pool_free.emplace(it->second, p);
     ctx->pool_free_bytes += it->second;

@@ -151,6 +151,27 @@ int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out) {
     return CL_OK;
 }
 
+int cl_context_memory(cl_context* ctx, cl_memory_stats* out, int reset_peak) {
+    if (!ctx || !out) return CL_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        out->live_bytes = ctx->dev_live_bytes;
+        out->peak_bytes = ctx->dev_peak_bytes;
+        out->cached_bytes = ctx->pool_free_bytes;
+        if (reset_peak) ctx->dev_peak_bytes = ctx->dev_live_bytes;
+    }
+    {
+        std::lock_guard<std::mutex> lock(ctx->pinned_mutex);
+        out->pinned_host_bytes = ctx->pinned_bytes;
+    }
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); cl_set_error(ctx, "hipMemGetInfo failed"); return CL_ERR_HIP; }
+    out->device_free_bytes = fr;
+    out->device_total_bytes = tot;
+    return CL_OK;
+}
+
 }  // extern "C"
 
 void cl_peers_release(cl_context* ctx) {

@@ -168,6 +168,16 @@ int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out);
  * context — its stream may be stuck behind a wait — and run merges on single contexts. */
 int cl_context_peer_selftest(cl_context* ctx, uint32_t token, uint32_t timeout_ms);
 
+/* Device memory of a context (the memory model): the bytes its calls hold at the moment, their high-water mark since the
+ * context was made (or since reset_peak), what its block cache keeps for the next call, and what the runtime reports for the whole device
+ * (hipMemGetInfo).  The reference has no counterpart (it logs the process's resident set, src/utility.cpp: log_memory_usage). */
+typedef struct cl_memory_stats {
+    uint64_t live_bytes, peak_bytes, cached_bytes;
+    uint64_t device_free_bytes, device_total_bytes;
+    uint64_t pinned_host_bytes;     /* page-locked host area of the context */
+} cl_memory_stats;
+int cl_context_memory(cl_context* ctx, cl_memory_stats* out, int reset_peak);
+
 /* po_poa<NumPW> for every problem of the batch; num_pw[k] in {1,2,3}. */
 int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw,
                     const cl_align_params* params, cl_stitch_result* out);
