@@ -976,7 +976,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 7     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 8     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
