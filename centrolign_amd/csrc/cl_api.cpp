@@ -35,6 +35,8 @@
 
 hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                                const ClScoreParams& P, hipStream_t stream);
+hipError_t cl_launch_popoa_strip(int npw, uint32_t threads, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const ClStripDevice& SD, const uint32_t* slist,
+                                 const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
@@ -49,6 +51,7 @@ thread_local std::string g_error;
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
 const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
+const bool g_no_strip = [] { const char* e = getenv("CL_NO_STRIP"); return e && *e == '1'; }();   // test hook: no strips of rows for large branching pairs (popoa_strip_kernel)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
 constexpr uint64_t kRingLdsBytes = 128 * 1024;  // LDS a general-kernel workgroup may take for its anti-diagonal ring (160 KB per CU); launches are split at 64 KB
 // CL_STITCH_GRAPH=1 replays a captured hipGraph of a plan's launches instead of launching the kernels directly (rounds 1-3 did; measured in
@@ -591,6 +594,7 @@ struct LaunchGroup {
     uint32_t count = 0;
     uint64_t cells = 0, bytes = 0;
     uint32_t ring_bytes = 0;  // general kernel: dynamic LDS of the ring variant (0 = planes read from HBM)
+    uint32_t prog_first = 0, prog_count = 0;   // strip kernel: first / count index into the strip list (first, count) and the progress words it zeroes before the launch
     uint64_t est_cost = 0;    // longest sweep x the kernel's rough time per step: orders the groups and deals them over the streams
     float host_ms = 0.f;      // the profiled pass: the launch alone on the device, behind another launch (host's clock: two launches - one launch)
     float host_idle_ms = 0.f; // ... and finding the device idle (one launch + wait)
@@ -627,6 +631,14 @@ struct cl_stitch_plan {
     DevBuf<uint2> d_out_pairs;
     DevBuf<uint32_t> d_out_len, d_out_status, d_plist;
     DevBuf<int32_t> d_out_score;
+    // strips of rows (popoa_strip_kernel)
+    std::vector<ClStripDesc> strips;
+    std::vector<uint32_t> strip_list;              // the strip launch groups' lists (into strips)
+    DevBuf<ClStripDesc> d_strips;
+    DevBuf<uint4> d_strip_recs;
+    DevBuf<uint32_t> d_strip_list, d_progress;
+    DevBuf<unsigned long long> d_handoff;
+    ClStripDevice sdev{};
     DevBuf<unsigned long long> d_ticks;            // [2 per launch group] the launches' own clocks (ClDeviceBatch::ticks), zeroed in front of every pass
     std::vector<LaunchGroup> groups;
     ClDeviceBatch dev{};
@@ -654,6 +666,7 @@ void plan_free(cl_stitch_plan* pl) {
     }
     pl->d_planes.release(q); pl->d_out_pairs.release(q); pl->d_out_len.release(q); pl->d_out_status.release(q);
     pl->d_plist.release(q); pl->d_out_score.release(q); pl->d_aux.release(q);
+    pl->d_strips.release(q); pl->d_strip_recs.release(q); pl->d_strip_list.release(q); pl->d_progress.release(q); pl->d_handoff.release(q);
     for (auto& g : pl->groups) {
         if (g.ev0) (void)hipEventDestroy(g.ev0);
         if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -908,6 +921,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         std::vector<uint32_t> poff[2], pidx[2], snk[2], order[2];
         std::vector<uint32_t> ring_need;   // per PO-POA problem: dynamic LDS of the ring / systolic variant (0 = not taken)
         std::vector<uint32_t> sys_aux;     // saved-column lists of the systolic kernel's problems, concatenated
+        std::vector<ClStripDesc> strips;   // strip kernel: prob = index into desc of this part; rec_base / hand_* / prog relative to this part
+        std::vector<uint4> strip_recs;
+        std::vector<uint32_t> strip_lds;   // per strip: dynamic LDS
+        uint64_t hand_words = 0;
         std::vector<ClProbDesc> desc;
         std::vector<uint64_t> po_problem;
         std::vector<uint32_t> pd_problem, host_problem;
@@ -1061,6 +1078,90 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 take_sys = best_bytes != UINT64_MAX && far_cols.size() <= 32 && (1ull << sys_log) >= span[sRow] + near_max + 1 && sys_bytes <= kSysLdsBytes &&
                            max_deg <= 63 && cp[n_cols] - cp[0] < (1u << 17);   // field widths of the column records
             }
+            // strips of rows (popoa_strip_kernel): pairs too large for one workgroup's LDS, one workgroup per strip of S rows, all strips of the pair in
+            // flight at once.  Taken when every column predecessor (a source's boundary column included) lies inside a ring of at most 64 columns,
+            // the row graph's predecessors within 32 rows (they become the next strip's ghost rows) and the pair is large enough to pay for it
+            bool take_strip = false;
+            uint32_t strip_log = 0, strip_S = 0, strip_n = 0, strip_g = 0;
+            if (!take_sys && !g_no_strip && !g_force_general && n_rows >= 192 && cells >= 300000 && n_cols < (1u << 28)) {
+                const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];
+                const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
+                const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
+                uint64_t nm = 0, max_deg = 0, gd = 0;
+                for (uint64_t j = 1; j <= n_cols; ++j) {
+                    max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
+                    for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) nm = std::max<uint64_t>(nm, j - P.pidx[sCol][e]);
+                    if (cl[j - 1] & 0x80) nm = std::max(nm, j);
+                }
+                for (uint64_t i = 1; i < n_rows; ++i)
+                    for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) gd = std::max<uint64_t>(gd, i - P.pidx[sRow][e]);
+                uint32_t lg = 1;
+                while ((1ull << lg) < span[sRow] + nm + 1 && lg < 14) ++lg;
+                const uint64_t cw = npw == 1 ? 4 : 8, row_bytes = ((1ull << lg) * cw + (cw == 8 ? 4 : 8)) * 4;
+                if (lg <= 6 && span[sRow] <= 32 && gd <= 32 && max_deg <= 63) {
+                    // the largest S (a multiple of 64, at most 768: 1 024 threads less the four ghost waves) whose rings and row lists fit
+                    auto rec_ring_log = [&](uint64_t n_loc) { uint32_t l = 5; while ((1ull << l) < n_loc + 48) ++l; return l; };   // popoa_strip_kernel's record ring
+                    auto strip_bytes = [&](uint64_t S) {
+                        uint64_t worst = 0;
+                        for (uint64_t a = 0; a < n_rows; a += S) {
+                            const uint64_t hi = std::min(n_rows - 1, a + S - 1), lo = std::max<uint64_t>(a, 1);
+                            const uint64_t edges = hi >= lo ? rp[hi] - rp[lo - 1] : 0, n_loc = (a ? gd : 0) + std::min(S, n_rows - a);
+                            worst = std::max<uint64_t>(worst, n_loc * row_bytes + ((uint64_t)16 << rec_ring_log(n_loc)) + edges * 4 + 16);
+                        }
+                        return worst;
+                    };
+                    uint64_t S = 768;
+                    while (S >= 64 && strip_bytes(S) > kSysLdsBytes) S -= 64;
+                    if (S >= 64) {
+                        const uint64_t n = (n_rows + S - 1) / S;
+                        const uint64_t even = ((n_rows + n - 1) / n + 63) / 64 * 64;   // the rows dealt evenly
+                        if (even <= S && strip_bytes(even) <= kSysLdsBytes) S = even;
+                        strip_S = (uint32_t)S; strip_n = (uint32_t)((n_rows + S - 1) / S); strip_g = (uint32_t)gd; strip_log = lg;
+                        take_strip = strip_n <= 200;   // (all strips of a pair must be resident together: one workgroup per compute unit)
+                    }
+                }
+                if (take_strip) {
+                    const uint32_t rec_base = (uint32_t)P.strip_recs.size();
+                    for (uint64_t j = 1; j <= n_cols; ++j) {
+                        const uint32_t b0 = cp[j - 1], deg = cp[j] - cp[j - 1], l = cl[j - 1], src = l >> 7, nq = deg + src;
+                        uint32_t x = 0;
+                        if (nq >= 1 && nq <= 2) {
+                            const uint32_t q0 = deg ? P.pidx[sCol][b0] : 0u, q1 = deg == 2 ? P.pidx[sCol][b0 + 1] : (src ? 0u : q0);
+                            x = ((uint32_t)j - q0) | (((uint32_t)j - q1) << 12);
+                        }
+                        // the general cell's predecessor list rides along as distances (z: first two, w: next two, x — free when the straight-line
+                        // cell does not apply — the fifth and sixth); longer lists are read from HBM
+                        const bool fast = nq >= 1 && nq <= 2, inl = deg <= 6;
+                        uint32_t dist[6] = {0, 0, 0, 0, 0, 0};
+                        for (uint32_t f = 0; f < deg && f < 6; ++f) dist[f] = (uint32_t)j - P.pidx[sCol][b0 + f];
+                        if (!fast && inl) x = dist[4] | (dist[5] << 12);
+                        P.strip_recs.push_back(make_uint4(x, (inl ? 1u << 16 : 0u) | (deg << 17) | (fast ? 1u << 23 : 0u) | ((l & 0x7Fu) << 24) | (src << 31),
+                                                          dist[0] | (dist[1] << 12), dist[2] | (dist[3] << 12)));
+                    }
+                    const uint64_t hand_per = (uint64_t)strip_g * (n_cols + 1) * (cw / 2);
+                    for (uint32_t j = 0; j < strip_n; ++j) {
+                        ClStripDesc sd{};
+                        const uint64_t a = (uint64_t)j * strip_S;
+                        sd.prob = (uint32_t)P.desc.size();
+                        sd.n_ghost = j ? strip_g : 0;
+                        sd.row_base = (uint32_t)(a - sd.n_ghost);
+                        sd.n_real = (uint32_t)std::min<uint64_t>(strip_S, n_rows - a);
+                        sd.n_out = j + 1 < strip_n ? strip_g : 0;
+                        sd.rec_base = rec_base;
+                        sd.hand_in = P.hand_words + (j ? (uint64_t)(j - 1) * hand_per : 0);
+                        sd.hand_out = P.hand_words + (uint64_t)j * hand_per;
+                        sd.prog = (uint32_t)P.strips.size();
+                        sd.strip = j; sd.n_strips = strip_n; sd.logH = strip_log;
+                        uint32_t lrw = 5;
+                        while ((1ull << lrw) < (uint64_t)sd.n_ghost + sd.n_real + 48) ++lrw;
+                        sd.logRW = lrw;
+                        const uint64_t hi = std::min<uint64_t>(n_rows - 1, a + strip_S - 1), lo = std::max<uint64_t>(a, 1);
+                        P.strip_lds.push_back((uint32_t)(((uint64_t)sd.n_ghost + sd.n_real) * row_bytes + (16ull << lrw) + (hi >= lo ? rp[hi] - rp[lo - 1] : 0) * 4 + 16));
+                        P.strips.push_back(sd);
+                    }
+                    P.hand_words += (uint64_t)(strip_n - 1) * hand_per;
+                }
+            }
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
             if (take_sys) {
@@ -1071,6 +1172,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 P.sys_aux.push_back((uint32_t)near_limit);
                 P.sys_aux.insert(P.sys_aux.end(), far_cols.begin(), far_cols.end());
                 P.ring_need.push_back((uint32_t)sys_bytes);
+            } else if (take_strip) {
+                d.kind = CL_KIND_STRIP;
+                d.pad = (uint16_t)(strip_log | (d.n2 < d.n1 ? 0x8000u : 0u));
+                P.ring_need.push_back(0);
             } else if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
                 d.pad = (uint16_t)(depth | (depth >= span[0] + span[1] + 1 ? 0x8000u : 0u));   // bit 15: the ring serves every read
                 P.ring_need.push_back((uint32_t)(depth * per_diag + topo_bytes));
@@ -1103,7 +1208,9 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     std::vector<uint32_t> poff[2], pidx[2], snk[2];
     poff[0].push_back(0);
     poff[1].push_back(0);
-    std::vector<uint32_t> ring_need, sys_aux;
+    std::vector<uint32_t> ring_need, sys_aux, strip_lds;
+    std::vector<uint4> strip_recs;
+    uint64_t hand_words = 0;
     uint64_t plane_cursor = 0, out_cursor = 0;
     for (PackPart& P : parts) {   // in order: the first failure is the one a serial pass would have met
         if (P.rc) { set_error(ctx, "%s", P.err.c_str()); plan_free(pl); return P.rc; }
@@ -1116,6 +1223,20 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         if (out_cursor + P.out_cursor >= (1ull << 32)) { set_error(ctx, "batch too large for 32-bit output offsets"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
         const uint32_t lab_base[2] = {(uint32_t)lab[0].size(), (uint32_t)lab[1].size()}, pidx_base[2] = {(uint32_t)pidx[0].size(), (uint32_t)pidx[1].size()};
         const uint32_t snk_base[2] = {(uint32_t)snk[0].size(), (uint32_t)snk[1].size()}, aux_base = (uint32_t)sys_aux.size();
+        if (strip_recs.size() + P.strip_recs.size() >= (1ull << 32)) { set_error(ctx, "batch too large for 32-bit device offsets"); plan_free(pl); return CL_ERR_INVALID_ARGUMENT; }
+        for (ClStripDesc sd : P.strips) {
+            sd.prob += (uint32_t)pl->desc.size();
+            sd.rec_base += (uint32_t)strip_recs.size();
+            sd.hand_in += hand_words; sd.hand_out += hand_words;
+            pl->strips.push_back(sd);
+        }
+        {   // the progress words are the strips' own indices
+            const size_t base = pl->strips.size() - P.strips.size();
+            for (size_t i = 0; i < P.strips.size(); ++i) pl->strips[base + i].prog = (uint32_t)(base + i);
+        }
+        strip_recs.insert(strip_recs.end(), P.strip_recs.begin(), P.strip_recs.end());
+        strip_lds.insert(strip_lds.end(), P.strip_lds.begin(), P.strip_lds.end());
+        hand_words += P.hand_words;
         for (size_t i = 0; i < P.desc.size(); ++i) {
             ClProbDesc d = P.desc[i];
             for (int s = 0; s < 2; ++s) { d.node_base[s] += lab_base[s]; d.snk_base[s] += snk_base[s]; }
@@ -1226,9 +1347,41 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 }
                 close_group(grp);
             }
+    // strips of rows: every strip of a pair is a workgroup of the same launch (they wait for one another: at most 224 workgroups per launch, whole pairs)
+    for (int npw = 3; npw >= 1; --npw) {
+        LaunchGroup grp;
+        auto open = [&]() { grp = LaunchGroup(); grp.kind = CL_KIND_STRIP; grp.npw = npw; grp.first = (uint32_t)pl->strip_list.size(); grp.prog_first = UINT32_MAX; };
+        auto close = [&]() {
+            grp.count = (uint32_t)pl->strip_list.size() - grp.first;
+            if (grp.count) pl->groups.push_back(grp);
+        };
+        open();
+        for (size_t i = 0; i < pl->strips.size();) {
+            const ClStripDesc& s0 = pl->strips[i];
+            const ClProbDesc& d = pl->desc[s0.prob];
+            if (d.npw != npw) { i += s0.n_strips; continue; }
+            if ((uint32_t)pl->strip_list.size() - grp.first + s0.n_strips > 224) { close(); open(); }
+            if (grp.prog_first == UINT32_MAX) grp.prog_first = (uint32_t)i;
+            uint32_t max_rows = 0;
+            for (uint32_t j = 0; j < s0.n_strips; ++j) {
+                pl->strip_list.push_back((uint32_t)(i + j));
+                grp.ring_bytes = std::max(grp.ring_bytes, strip_lds[i + j]);
+                max_rows = std::max(max_rows, pl->strips[i + j].n_real);
+            }
+            grp.prog_count = (uint32_t)(i + s0.n_strips) - grp.prog_first;
+            grp.block = std::max<int>(grp.block, 256 + (int)((max_rows + 63) / 64 * 64));
+            const uint64_t cells = (uint64_t)(d.n1 + 1) * (d.n2 + 1);
+            grp.cells += cells;
+            grp.bytes += cells * 4ull * (1 + 2 * npw);
+            grp.est_cost = std::max<uint64_t>(grp.est_cost, (uint64_t)d.n1 + d.n2 + 96ull * s0.n_strips);
+            i += s0.n_strips;
+        }
+        close();
+    }
     // longest-running launch first: a group's duration is set by its longest anti-diagonal sweep
     {
         auto crit = [&](const LaunchGroup& g) {
+            if (g.kind == CL_KIND_STRIP) return g.est_cost;
             uint64_t c = 0;
             for (uint32_t i = g.first; i < g.first + g.count; ++i)
                 c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
@@ -1248,7 +1401,11 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     for (int s = 0; s < 2; ++s)
         if ((rc = pl->d_lab[s].upload_async(ctx, lab[s])) || (rc = pl->d_poff[s].upload_async(ctx, poff[s])) ||
             (rc = pl->d_pidx[s].upload_async(ctx, pidx[s])) || (rc = pl->d_snk[s].upload_async(ctx, snk[s]))) { plan_free(pl); return rc; }
+    if (!pl->strips.empty() && ((rc = pl->d_strips.upload_async(ctx, pl->strips)) || (rc = pl->d_strip_recs.upload_async(ctx, strip_recs)) ||
+                                (rc = pl->d_strip_list.upload_async(ctx, pl->strip_list)) || (rc = pl->d_progress.alloc(ctx, pl->strips.size())) ||
+                                (rc = pl->d_handoff.alloc(ctx, hand_words)))) { plan_free(pl); return rc; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cl_set_error(ctx, "upload failed"); plan_free(pl); return CL_ERR_HIP; }
+    pl->sdev.strips = pl->d_strips.p; pl->sdev.recs = pl->d_strip_recs.p; pl->sdev.handoff = pl->d_handoff.p; pl->sdev.progress = pl->d_progress.p;
     if ((rc = pl->d_planes.alloc(ctx, plane_cursor)) || (rc = pl->d_out_pairs.alloc(ctx, out_cursor)) ||
         (rc = pl->d_out_len.alloc(ctx, pl->desc.size())) || (rc = pl->d_out_status.alloc(ctx, pl->desc.size())) ||
         (rc = pl->d_out_score.alloc(ctx, pl->desc.size()))) { plan_free(pl); return rc; }
@@ -1286,6 +1443,12 @@ static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
 static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const ClDeviceBatch& dev, hipStream_t stream) {
     if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    if (g.kind == CL_KIND_STRIP) {
+        // the strips' progress words start every pass at zero (the strips of a launch poll one another's)
+        hipError_t e = hipMemsetAsync(pl->d_progress.p + g.prog_first, 0, (size_t)g.prog_count * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        return cl_launch_popoa_strip(g.npw, (uint32_t)g.block, g.count, g.ring_bytes, dev, pl->sdev, pl->d_strip_list.p + g.first, pl->sparams, stream);
+    }
     if (g.kind == CL_KIND_SYS) return cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
 }
@@ -1439,13 +1602,14 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     memset(out, 0, sizeof(*out));
     if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
+    else if (g.kind == CL_KIND_STRIP) snprintf(out->kernel, sizeof(out->kernel), "popoa_strip_kernel<%d> x %d", g.npw, g.block);
     else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);
     out->n_problems = g.count;
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;
     out->lds_bytes = g.kind == CL_KIND_LINEAR ? 0u : g.ring_bytes;
     for (uint32_t i = g.first; i < g.first + g.count; ++i) {
-        const ClProbDesc& d = pl->desc[pl->plist_host[i]];
+        const ClProbDesc& d = pl->desc[g.kind == CL_KIND_STRIP ? pl->strips[pl->strip_list[i]].prob : pl->plist_host[i]];
         if (d.n1 + d.n2 > out->max_sweep) { out->max_sweep = d.n1 + d.n2; out->max_n1 = d.n1; out->max_n2 = d.n2; }
     }
     if (pl->profiled) out->last_ms = g.host_ms;

@@ -13,7 +13,8 @@
 #define CL_NEG_INF (INT32_MIN / 2)  // cell_t::mininf, alignment.hpp:740
 
 // kernel families
-enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1, CL_KIND_SYS = 2 };   // SYS: the systolic DAG kernel (popoa_sys_kernel)
+enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1, CL_KIND_SYS = 2, CL_KIND_STRIP = 3 };   // SYS: the systolic DAG kernel (popoa_sys_kernel); STRIP: the same sweep for
+                                                                                       // pairs whose rows do not fit one workgroup's LDS (popoa_strip_kernel)
 
 struct ClProbDesc {
     uint32_t n1, n2;          // node counts (both > 0)
@@ -53,6 +54,29 @@ struct ClDeviceBatch {
                               // s_memrealtime — the launch's duration by the kernel's own clock, also inside a step where launches overlap (launches of
                               // more than 4 096 workgroups sample every 64th: they are throughput-bound, their ends are within a wave of one another)
     int       skip_traceback; // measurement hook (CL_DEBUG_SKIP_TRACEBACK=1, scripts/stitch_dag_bench.py): the graph x graph kernels fill only
+};
+
+// popoa_strip_kernel: one workgroup per STRIP of consecutive rows of a large branching pair; strip j reads the last rows of strip j - 1 (its "ghost"
+// rows) from a hand-off area in HBM that strip j - 1 fills while it runs
+struct ClStripDesc {
+    uint32_t prob;        // the problem (ClDeviceBatch::desc)
+    uint32_t row_base;    // matrix row of timing index 0 (first ghost row; 0 in the first strip, whose timing index 0 is the boundary row)
+    uint32_t n_real;      // rows this strip computes
+    uint32_t n_ghost;     // rows in front of them that it reads from the hand-off area (0 in the first strip)
+    uint32_t n_out;       // its last rows that it writes to the hand-off area (0 in the last strip)
+    uint32_t rec_base;    // first column record of the problem (ClStripDevice::recs)
+    uint64_t hand_in;     // first 64-bit word of the incoming hand-off rows [n_ghost][columns + 1][cell words / 2]
+    uint64_t hand_out;    // ... of the outgoing ones [n_out][columns + 1][...]
+    uint32_t prog;        // this strip's progress word; the strips of a problem are consecutive (prog - strip = the first strip's)
+    uint32_t strip, n_strips;
+    uint32_t logH;        // ring depth per row
+    uint32_t logRW;       // column records in the LDS ring (a power of two above the strip's rows + 48)
+};
+struct ClStripDevice {
+    const ClStripDesc* strips;
+    const uint4* recs;                // per problem: one record per column (see popoa_strip_kernel)
+    unsigned long long* handoff;
+    uint32_t* progress;               // zeroed before every pass
 };
 
 #endif

@@ -939,6 +939,308 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// popoa_strip_kernel: the systolic sweep of popoa_sys_kernel for branching pairs whose rows do NOT fit one workgroup's LDS (round 4; SURVEY §7
+// step 5; the reference's ceiling is 40 M cells per pair, src/parameters.cpp:79).  The rows are cut into STRIPS of S consecutive rows (S a multiple
+// of 64), one workgroup per strip, all strips of a pair in flight at once on different compute units: strip j runs behind strip j - 1 and reads
+// that strip's last rows — every row one of its own rows has a predecessor in: its GHOST rows — from a hand-off area in HBM which strip j - 1
+// fills as it goes.  Waves 0-3 of a workgroup hold the ghost rows and nothing else: lane i of wave w stands for ghost row i at the steps t = w
+// (mod 4): it puts the cell it asked for four steps earlier into the row's LDS ring — exactly when a computing row would have written it — and
+// asks for the cell four columns on.  A wave's loads so have four steps (2-3 us) to arrive and wait for nothing but one another: no register
+// rotation, no stores in these waves.  The computing rows start at wave 4 and are the sys kernel's, with two differences: the column records (16 bytes, written by the host: the straight-line cell's two predecessor distances, and up to six
+// predecessor distances for the general cell, so that no cell of the sweep needs a global load) pass through a small LDS ring which wave 0
+// refills sixteen columns at a time, thirty-odd columns ahead of the first row — 16 bytes x columns do not fit LDS beside the rings — and there
+// are no saved columns (the host routes a pair here only when every column predecessor is
+// inside the ring).  The hand-off cells are written and read as 64-bit write-through / cache-bypassing atomics (agent scope, relaxed), and the
+// producer publishes "columns done" after a vmcnt(0) of the one wave that holds all its hand-off rows: the consumer polls that word before it
+// asks for a column, so no fence is ever needed while the sweep runs.  At its end a strip makes its planes visible (one fence) and marks itself
+// done; the last strip waits for all marks and runs the traceback.  Every wait is bounded: a strip that gives up marks itself failed, the marks
+// propagate, and the pair reports status 9.
+constexpr uint32_t kStripDone = 0x7FFFFFFFu, kStripFailed = 0xFFFFFFFFu;
+
+template <int NPW>
+__global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClStripDevice SD, const uint32_t* __restrict__ slist, ClScoreParams P) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    constexpr int CW = NPW == 1 ? 4 : 8;
+    constexpr int WW = CW / 2;   // 64-bit words of a cell
+    constexpr uint32_t GW = 4;   // ghost waves = steps a hand-off cell has to arrive
+    if (B.ticks && threadIdx.x == 0) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    const ClStripDesc sd = SD.strips[slist[blockIdx.x]];
+    const uint32_t prob = sd.prob;
+    const ClProbDesc pd = B.desc[prob];
+    const DiagGeom G(pd.n1, pd.n2);
+    Planes<NPW> pl;
+    pl.base = B.planes + pd.plane_base;
+    pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
+    const uint32_t tid = threadIdx.x;
+    const bool swap = pd.pad & 0x8000u;
+    const uint32_t H = 1u << sd.logH, hm = H - 1;
+    const uint32_t nC = swap ? pd.n1 : pd.n2;
+    const uint32_t baseR = swap ? pd.node_base[1] : pd.node_base[0], baseC = swap ? pd.node_base[0] : pd.node_base[1];
+    const uint32_t* const poffR = (swap ? B.poff[1] : B.poff[0]) + baseR;
+    const uint32_t* const poffC = (swap ? B.poff[0] : B.poff[1]) + baseC;
+    const uint32_t* const pidxR = swap ? B.pidx[1] : B.pidx[0];
+    const uint32_t* const pidxC = swap ? B.pidx[0] : B.pidx[1];
+    const uint8_t* const labRp = (swap ? B.lab[1] : B.lab[0]) + baseR;
+    const uint4* const recs = SD.recs + sd.rec_base;
+    const uint32_t g = sd.n_ghost, S = sd.n_real, n_loc = g + S;
+    const bool is_ghost = tid < 64 * GW;
+    const uint32_t gw = tid >> 6, gi = tid & 63u;
+    const uint32_t L = is_ghost ? gi : g + (tid - 64 * GW);       // timing index: this row works on column t - L at step t
+    const bool live = is_ghost ? gi < g : (tid - 64 * GW) < S;
+    const uint32_t r = sd.row_base + L;                           // matrix row
+    const uint32_t row_stride = H * CW + (CW == 8 ? 4u : 8u);     // (see popoa_sys_kernel: the lanes' 16-byte accesses fall on different bank groups)
+    int32_t* const ring = lds;
+    const uint32_t rmask = (1u << sd.logRW) - 1;
+    uint4* const rec_ring = reinterpret_cast<uint4*>(ring + n_loc * row_stride);   // record of column c in slot (c - 1) & rmask
+    uint32_t* const plR = reinterpret_cast<uint32_t*>(rec_ring + (rmask + 1));
+    const uint32_t r_lo = sd.row_base + g, r_hi = sd.row_base + n_loc - 1;   // computing rows
+    const uint32_t node_lo = r_lo ? r_lo : 1u;
+    const uint32_t eR0 = poffR[node_lo - 1], eR1 = r_hi >= node_lo ? poffR[r_hi] : eR0;
+    for (uint32_t i = tid; i < eR1 - eR0; i += blockDim.x) plR[i] = pidxR[eR0 + i] - sd.row_base;   // as timing indices
+    int* const fail_flag = reinterpret_cast<int*>(plR + (eR1 - eR0));
+    if (tid == 0) *fail_flag = 0;
+    for (uint32_t i = tid; i < 32 && i < nC; i += blockDim.x) rec_ring[i & rmask] = recs[i];   // columns 1 .. 32; the loop below goes on from 33
+    // this thread's row
+    uint32_t degR = 0, firstR = 0, labR = 0;
+    bool srcR = false;
+    if (!is_ghost && live && r >= 1) {
+        const uint32_t l = labRp[r - 1];
+        degR = poffR[r] - poffR[r - 1];
+        firstR = poffR[r - 1] - eR0;
+        labR = l & 0x7Fu;
+        srcR = l >> 7;
+    }
+    __syncthreads();
+    const bool fastR = !is_ghost && live && (r == 0 || (degR + (srcR ? 1u : 0u) <= 2 && degR + (srcR ? 1u : 0u) >= 1));
+    uint32_t rp0 = 0, rp1 = 0;
+    if (r && fastR && degR) {
+        rp0 = plR[firstR];
+        rp1 = degR == 2 ? plR[firstR + 1] : (srcR ? 0u : rp0);
+    }
+    // predecessor f of column c: up to six distances ride in the record (z, w: twelve bits each, in list order), longer lists stay in HBM
+    auto col_pred = [&](const uint4& rc, uint32_t c, uint32_t fc, uint32_t f) -> uint32_t {
+        if (!((rc.y >> 16) & 1u)) return pidxC[fc + f];
+        const uint32_t word = f < 2 ? rc.z : (f < 4 ? rc.w : rc.x);
+        return c - ((word >> (12 * (f & 1u))) & 0xFFFu);
+    };
+    auto cell_at = [&](uint32_t row_l, uint32_t col) -> const int32_t* { return ring + (row_l * row_stride + (col & hm) * CW); };
+    auto get_mv = [&](const int32_t* cell, int32_t& m, int32_t (&v)[NPW]) {
+        const int4 x = reinterpret_cast<const int4*>(cell)[0];
+        m = x.x; v[0] = x.y;
+        if (NPW > 1) v[1] = x.z;
+        if (NPW > 2) v[2] = x.w;
+    };
+    auto get_mh = [&](const int32_t* cell, int32_t& m, int32_t (&h)[NPW]) {
+        if (NPW == 1) { const int4 x = reinterpret_cast<const int4*>(cell)[0]; m = x.w; h[0] = x.z; }
+        else {
+            const int4 x = reinterpret_cast<const int4*>(cell)[1];
+            m = x.x; h[0] = x.y;
+            if (NPW > 1) h[1] = x.z;
+            if (NPW > 2) h[2] = x.w;
+        }
+    };
+    int32_t* const my_row = ring + L * row_stride;
+    int32_t* const plane0 = pl.M();
+    const size_t plane_stride = pl.cells;
+    const uint32_t last = n_loc - 1 + nC;
+    uint32_t off = G.off(sd.row_base);   // cells on the anti-diagonals before the one of step t (anti-diagonal row_base + t)
+    // ---- ghost rows: the hand-off pipeline ----
+    unsigned long long st[WW];
+#pragma unroll
+    for (int w = 0; w < WW; ++w) st[w] = 0;
+    const unsigned long long* const hin = SD.handoff + sd.hand_in + (size_t)gi * (nC + 1) * WW;
+    uint32_t* const prog_in = SD.progress + (sd.prog - 1);   // the strip in front (ghost lanes only: strip > 0)
+    uint32_t avail = 0;                                       // columns of the incoming rows known to be complete
+    bool failed = false;
+    auto fetch = [&](uint32_t col, unsigned long long (&dst)[WW]) {
+        if (col >= avail) {
+            unsigned spins = 0;
+            while (true) {
+                avail = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (avail > col) break;
+                if (++spins > (1u << 22)) { failed = true; avail = kStripFailed; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (avail == kStripFailed) failed = true;
+        }
+#pragma unroll
+        for (int w = 0; w < WW; ++w) dst[w] = __hip_atomic_load(hin + (size_t)col * WW + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (is_ghost && live && gw >= L && gw - L <= nC) fetch(gw - L, st);   // what this lane delivers at its first step, t = gw
+    // ---- wave 0, lanes 0-15: the column records, sixteen at a time (asked for at t = 0 (mod 16), stored four steps later) ----
+    uint4 rec_reg = make_uint4(0, 0, 0, 0);
+    uint32_t rec_col = 0;   // column whose record rec_reg holds (0: none)
+    const uint32_t out_first = S - sd.n_out;   // computing rows from here on are handed to the next strip
+    unsigned long long* const hout = SD.handoff + sd.hand_out;
+    for (uint32_t t = 0; t <= last; ++t) {
+        const uint32_t d = sd.row_base + t;
+        const uint32_t lo_d = G.lo(d), cnt_d = G.hi(d) - lo_d + 1;
+        if (is_ghost) {
+            if ((t & (GW - 1)) == gw && live) {
+                if (t >= L && t - L <= nC) {
+                    const uint32_t c = t - L;
+                    int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
+                    w[0] = make_int4((int)(unsigned)st[0], (int)(unsigned)(st[0] >> 32), (int)(unsigned)st[1], (int)(unsigned)(st[1] >> 32));
+                    if (NPW > 1) w[1] = make_int4((int)(unsigned)st[WW - 2], (int)(unsigned)(st[WW - 2] >> 32), (int)(unsigned)st[WW - 1], (int)(unsigned)(st[WW - 1] >> 32));
+                }
+                const uint32_t tn = t + GW;
+                if (tn >= L && tn - L <= nC) fetch(tn - L, st);
+            }
+            if (gw == 0 && gi < 16 && (t & (GW - 1)) == 0) {
+                if (rec_col) { rec_ring[(rec_col - 1) & rmask] = rec_reg; rec_col = 0; }
+                if ((t & 15u) == 0 && t + 33 + gi <= nC) { rec_col = t + 33 + gi; rec_reg = recs[rec_col - 1]; }
+            }
+        } else if (live) {
+            if (t >= L && t - L <= nC) {
+            const uint32_t c = t - L;
+            const uint4 rc = c ? rec_ring[(c - 1) & rmask] : make_uint4(0, 0, 0, 0);
+            int32_t M = CL_NEG_INF, V[NPW], Hh[NPW];
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; Hh[k] = CL_NEG_INF; }
+            uint32_t degC = 0, labC = 0;
+            bool srcC = false, fastC = false, inlineC = false;
+            if (c) { degC = (rc.y >> 17) & 63u; fastC = (rc.y >> 23) & 1u; labC = (rc.y >> 24) & 0x7Fu; srcC = rc.y >> 31; inlineC = (rc.y >> 16) & 1u; }
+            if (c && fastC && fastR) {
+                const uint32_t e0 = rc.x & 0xFFFu, e1 = (rc.x >> 12) & 0xFFFu;
+                const uint32_t o0 = ((c - e0) & hm) * CW, o1 = ((c - e1) & hm) * CW, oc = (c & hm) * CW;
+                int32_t mv0, mv1, mh0, mh1, vv0[NPW], vv1[NPW], hh0[NPW], hh1[NPW];
+                get_mv(ring + (rp0 * row_stride + oc), mv0, vv0);
+                get_mv(ring + (rp1 * row_stride + oc), mv1, vv1);
+                get_mh(my_row + o0, mh0, hh0);
+                get_mh(my_row + o1, mh1, hh1);
+                const int32_t d00 = ring[o0 + rp0 * row_stride], d01 = ring[o1 + rp0 * row_stride];
+                const int32_t d10 = ring[o0 + rp1 * row_stride], d11 = ring[o1 + rp1 * row_stride];
+                M = imax(imax(d00, d01), imax(d10, d11)) + ((labR == labC) ? P.match : -P.mismatch);
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) {
+                    V[k] = imax(imax(mv0 - P.oe[k], vv0[k] - P.ext[k]), imax(mv1 - P.oe[k], vv1[k] - P.ext[k]));
+                    Hh[k] = imax(imax(mh0 - P.oe[k], hh0[k] - P.ext[k]), imax(mh1 - P.oe[k], hh1[k] - P.ext[k]));
+                }
+                if (!r) {
+                    M = CL_NEG_INF;
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = CL_NEG_INF;
+                }
+            } else if (r && !c) {          // boundary column (alignment.hpp:832-845)
+                for (uint32_t e = 0; e < degR; ++e) {
+                    int32_t m, vv[NPW];
+                    get_mv(cell_at(plR[firstR + e], 0), m, vv);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], vv[k] - P.ext[k]);
+                }
+                if (srcR) {
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], -P.oe[k]);
+                }
+            } else if (!r && c) {   // boundary row (:864-877)
+                const uint32_t fc = inlineC ? 0u : poffC[c - 1];
+                for (uint32_t f = 0; f < degC; ++f) {
+                    int32_t m, hh[NPW];
+                    get_mh(cell_at(0, col_pred(rc, c, fc, f)), m, hh);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], hh[k] - P.ext[k]);
+                }
+                if (srcC) {
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], -P.oe[k]);
+                }
+            } else if (r && c) {    // interior, any degrees (:897-938 in pull form)
+                for (uint32_t e = 0; e < degR; ++e) {
+                    int32_t m, vv[NPW];
+                    get_mv(cell_at(plR[firstR + e], c), m, vv);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m - P.oe[k], vv[k] - P.ext[k]));
+                }
+                if (srcR) {
+                    const int32_t m = cell_at(0, c)[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], m - P.oe[k]);
+                }
+                const int32_t sc = (labR == labC) ? P.match : -P.mismatch;
+                const uint32_t fc = inlineC ? 0u : poffC[c - 1];
+                for (uint32_t f = 0; f < degC; ++f) {
+                    const uint32_t q = col_pred(rc, c, fc, f);
+                    int32_t m, hh[NPW];
+                    get_mh(cell_at(L, q), m, hh);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], hh[k] - P.ext[k]));
+                    for (uint32_t e = 0; e < degR; ++e) M = imax(M, cell_at(plR[firstR + e], q)[0] + sc);
+                    if (srcR) M = imax(M, cell_at(0, q)[0] + sc);
+                }
+                if (srcC) {
+                    const int32_t m = cell_at(L, 0)[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], m - P.oe[k]);
+                    for (uint32_t e = 0; e < degR; ++e) M = imax(M, cell_at(plR[firstR + e], 0)[0] + sc);
+                    if (srcR) M = imax(M, sc);   // the corner counts as 0 (:814-818)
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) M = imax(M, imax(V[k], Hh[k]));
+            const int32_t Ml = (r | c) ? M : 0, Mh = r ? M : (c ? CL_NEG_INF : 0);
+            const int4 w0 = NPW == 1 ? make_int4(Ml, V[0], Hh[0], Mh) : make_int4(Ml, V[0], V[NPW > 1 ? 1 : 0], V[NPW > 2 ? 2 : 0]);
+            const int4 w1 = make_int4(Mh, Hh[0], Hh[NPW > 1 ? 1 : 0], Hh[NPW > 2 ? 2 : 0]);
+            int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
+            w[0] = w0;
+            if (NPW > 1) w[1] = w1;
+            const uint32_t k_row = tid - 64 * GW;
+            if (k_row >= out_first) {   // a hand-off row: the cell goes to the next strip as well (write-through)
+                unsigned long long* dst = hout + ((size_t)(k_row - out_first) * (nC + 1) + c) * WW;
+                __hip_atomic_store(dst, (unsigned long long)(unsigned)w0.x | ((unsigned long long)(unsigned)w0.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, (unsigned long long)(unsigned)w0.z | ((unsigned long long)(unsigned)w0.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (NPW > 1) {
+                    __hip_atomic_store(dst + WW - 2, (unsigned long long)(unsigned)w1.x | ((unsigned long long)(unsigned)w1.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + WW - 1, (unsigned long long)(unsigned)w1.z | ((unsigned long long)(unsigned)w1.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            int32_t* dstp = plane0 + (off + ((swap ? c : r) - lo_d));
+            if (!(B.skip_traceback & 2)) {
+                dstp[0] = M;
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) {
+                    dstp[(size_t)(1 + k) * plane_stride] = swap ? Hh[k] : V[k];
+                    dstp[(size_t)(1 + NPW + k) * plane_stride] = swap ? V[k] : Hh[k];
+                }
+            }
+            // the last row of the strip has finished column c: every hand-off row (all of them lanes of this wave, and ahead of this one) has too
+            if (sd.n_out && k_row == S - 1 && (((c + 1) & 15u) == 0 || c == nC)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(SD.progress + sd.prog, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            }
+        }
+        off += cnt_d;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+    if (failed) *fail_flag = 1;
+    __threadfence();     // the planes of this strip, for the workgroup that runs the traceback
+    __syncthreads();
+    const bool strip_failed = *fail_flag != 0;
+    if (tid == 0) __hip_atomic_store(SD.progress + sd.prog, strip_failed ? kStripFailed : kStripDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sd.strip + 1 == sd.n_strips && tid < 64) {
+        bool bad = strip_failed;
+        for (uint32_t j = tid; j + 1 < sd.n_strips; j += 64) {
+            const uint32_t* word = SD.progress + (sd.prog - sd.strip + j);
+            unsigned spins = 0;
+            uint32_t v;
+            while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < kStripDone) {
+                if (++spins > (1u << 22)) { v = kStripFailed; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            bad |= v == kStripFailed;
+        }
+        bad = __any(bad);
+        __threadfence();
+        if (bad) {
+            if (tid == 0) { B.out_status[prob] = 9; B.out_len[prob] = 0; }
+        } else if (!B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    }
+    if (B.ticks && threadIdx.x == 0) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
 template <int NPW>
 void launch_sys_npw(int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P,
                     hipStream_t stream) {
@@ -991,6 +1293,27 @@ hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t l
     case 1: launch_sys_npw<1>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
     case 2: launch_sys_npw<2>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
     case 3: launch_sys_npw<3>(block, n_blocks, lds_bytes, B, plist, P, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// threads = 256 (the four ghost waves) + the largest strip's rows (a multiple of 64)
+hipError_t cl_launch_popoa_strip(int npw, uint32_t threads, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const ClStripDevice& SD, const uint32_t* slist,
+                                 const ClScoreParams& P, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    if (threads < 320 || threads > 1024 || (threads & 63u)) return hipErrorInvalidValue;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        const int cap = 160 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_strip_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_strip_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_strip_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    });
+    switch (npw) {
+    case 1: hipLaunchKernelGGL((popoa_strip_kernel<1>), dim3(n_blocks), dim3(threads), lds_bytes, stream, B, SD, slist, P); break;
+    case 2: hipLaunchKernelGGL((popoa_strip_kernel<2>), dim3(n_blocks), dim3(threads), lds_bytes, stream, B, SD, slist, P); break;
+    case 3: hipLaunchKernelGGL((popoa_strip_kernel<3>), dim3(n_blocks), dim3(threads), lds_bytes, stream, B, SD, slist, P); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

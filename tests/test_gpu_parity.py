@@ -211,6 +211,42 @@ def test_lopsided_and_large_dag_pairs(gpu_ctx):
         assert got.same_as(po.oracle_stitch_batch(small, force_num_pw=f)) is None
 
 
+def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
+    """popoa_strip_kernel (round 4): branching pairs whose rows do not fit one workgroup's LDS are cut into strips of rows, one workgroup per strip,
+    every strip reading the last rows of the one in front through a hand-off area in HBM while both run.  Against the oracle: both orientations,
+    one to twenty strips, sparse and dense bubbles, in-degrees beyond the six predecessors a column record carries, every NumPW"""
+    seen = set()
+    for kw, sizes in ((dict(), [(2000, 2000), (1000, 10000), (10000, 1000), (700, 900), (3000, 400), (192, 1700)]),
+                      (dict(extra_edge_p=0.02, skip_max=2), [(2000, 2000), (5500, 5500), (900, 700), (400, 6000)]),
+                      (dict(extra_edge_p=0.4, skip_max=6, alphabet=2), [(1500, 1300), (640, 2000)])):
+        b = synth.sized_dag_batch(sizes, seed=17, **kw)
+        plan = gpu_ctx.plan(b)
+        for li in plan.launches():
+            seen.add(li["kernel"].split("<")[0])
+        plan.destroy()
+        got = gpu_ctx.stitch_batch_align(b)
+        assert got.same_as(po.oracle_stitch_batch(b)) is None, kw
+    assert "popoa_strip_kernel" in seen, seen
+    for npw in (1, 2, 3):
+        b = synth.sized_dag_batch([(900, 1100), (2500, 400), (1300, 1300)], seed=60 + npw, extra_edge_p=0.1, skip_max=3)
+        f = np.full(b.n_problems, npw, np.uint8)
+        plan = gpu_ctx.plan(b, force_num_pw=f)
+        assert any(li["kernel"].startswith("popoa_strip_kernel<%d>" % npw) for li in plan.launches()), plan.launches()
+        plan.destroy()
+        got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+    # a plan executed again and again: the strips' progress words start every pass at zero
+    b = synth.sized_dag_batch([(2000, 2000), (800, 1500)], seed=3)
+    plan = gpu_ctx.plan(b)
+    want = po.oracle_stitch_batch(b)
+    for _ in range(3):
+        plan.execute(); plan.sync()
+        assert plan.collect().same_as(want) is None
+    plan.execute_profiled(); plan.sync()
+    assert plan.collect().same_as(want) is None
+    plan.destroy()
+
+
 def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
     """branching pairs whose per-row column rings fill the systolic kernel's LDS budget (launches with 98-160 KB of dynamic LDS), next to
     ones that overflow it and take the LDS-ring or the HBM-plane kernel: all against the oracle"""
