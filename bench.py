@@ -117,6 +117,32 @@ def reference_leaf_merge(seqs, names):
     return {"merge": "(%s,%s) incl. the two leaf calibrations" % (names[0], names[1]), "seconds": secs, "cores": 1, "kind": "reference", "phases_s": tm}
 
 
+def big_dag_section(ctx):
+    """one branching pair of 30 M cells (5 500 x 5 500 nodes: the reference's ceiling is 40 M, src/parameters.cpp:79) through popoa_strip_kernel — strips of
+    rows, one workgroup each, all in flight — and, in a child process with CL_NO_STRIP=1, through the anti-diagonal kernel it took in rounds 1-3"""
+    import subprocess
+    from centrolign_amd import synth
+    res = {}
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r)\n"
+            "from centrolign_amd import capi, synth\n"
+            "ctx = capi.Context(0); b = synth.sized_dag_batch([(5500, 5500)], seed=5, extra_edge_p=0.02, skip_max=2); plan = ctx.plan(b)\n"
+            "for _ in range(2): plan.execute(); plan.sync()\n"
+            "plan.execute_profiled(); plan.sync(); li = plan.launches()[0]\n"
+            "r = plan.collect(); print(json.dumps(dict(kernel=li['kernel'], ms=li['ms'], cells=li['dp_cells'], score=int(r.score[0]), pairs=hashlib.sha256(r.pairs.tobytes()).hexdigest()[:16])))\n" % HERE)
+    for key, env in (("strips", {}), ("anti_diagonal_kernel", {"CL_NO_STRIP": "1"})):
+        try:
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=180)
+            res[key] = json.loads(r.stdout.strip().splitlines()[-1])
+            res[key]["g_cells_per_s"] = res[key]["cells"] / res[key]["ms"] / 1e6
+        except Exception as e:   # noqa: BLE001
+            res[key] = {"error": str(e)[:200]}
+    if "ms" in res.get("strips", {}) and "ms" in res.get("anti_diagonal_kernel", {}):
+        res["speedup"] = res["anti_diagonal_kernel"]["ms"] / res["strips"]["ms"]
+        res["same_alignment"] = (res["strips"]["score"], res["strips"]["pairs"]) == (res["anti_diagonal_kernel"]["score"], res["anti_diagonal_kernel"]["pairs"])
+    res["workload"] = "synth.sized_dag_batch([(5500, 5500)], seed 5, extra_edge_p 0.02, skip_max 2): 30.3 M cells, NumPW 3"
+    return res
+
+
 def chaining_section(ctx, with_reference):
     """seam S3 at BASELINE configs[1] scale: Anchorer::anchor_chain in the CLI's default configuration on the match sets of the
     2 x 1 Mbp pair (bench_data/c2_chain_input.npz where it travelled with the repo, else made in place), the inner affine DP alone,
@@ -502,6 +528,7 @@ def main():
         if world == 1 and not args.no_extras:
             out["chaining_c2"] = chaining_section(ctx, not args.no_cpu_baseline)
             out["pairwise_c2"] = pairwise_section(ctx, not args.no_cpu_baseline)
+            out["big_dag_pair"] = big_dag_section(ctx)
         print(json.dumps(out))
     barrier()
     for _, p in plans:

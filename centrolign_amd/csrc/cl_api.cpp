@@ -1110,7 +1110,9 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         }
                         return worst;
                     };
-                    uint64_t S = 768;
+                    // CL_STRIP_ROWS=64..768 caps the rows per strip (measurements)
+                    static const uint64_t rows_env = [] { const char* e = getenv("CL_STRIP_ROWS"); const long v = e ? atol(e) : 0; return (uint64_t)(v >= 64 && v <= 768 ? v / 64 * 64 : 0); }();
+                    uint64_t S = rows_env ? rows_env : 256;   // (measured: a pair's duration hardly depends on the rows per strip between 64 and 768 — a step is a latency chain, not throughput — so strips are kept small: more of them run side by side and each leaves LDS for its neighbours)
                     while (S >= 64 && strip_bytes(S) > kSysLdsBytes) S -= 64;
                     if (S >= 64) {
                         const uint64_t n = (n_rows + S - 1) / S;
@@ -1125,13 +1127,16 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     for (uint64_t j = 1; j <= n_cols; ++j) {
                         const uint32_t b0 = cp[j - 1], deg = cp[j] - cp[j - 1], l = cl[j - 1], src = l >> 7, nq = deg + src;
                         uint32_t x = 0;
-                        if (nq >= 1 && nq <= 2) {
-                            const uint32_t q0 = deg ? P.pidx[sCol][b0] : 0u, q1 = deg == 2 ? P.pidx[sCol][b0 + 1] : (src ? 0u : q0);
-                            x = ((uint32_t)j - q0) | (((uint32_t)j - q1) << 12);
+                        if (nq >= 1 && nq <= 3) {   // the straight-line cell's three predecessor distances (8 bits each: all below the ring depth)
+                            uint32_t q[3], nl = 0;
+                            for (uint32_t f = 0; f < deg; ++f) q[nl++] = P.pidx[sCol][b0 + f];
+                            if (src) q[nl++] = 0u;
+                            for (; nl < 3; ++nl) q[nl] = q[0];
+                            x = ((uint32_t)j - q[0]) | (((uint32_t)j - q[1]) << 8) | (((uint32_t)j - q[2]) << 16);
                         }
                         // the general cell's predecessor list rides along as distances (z: first two, w: next two, x — free when the straight-line
                         // cell does not apply — the fifth and sixth); longer lists are read from HBM
-                        const bool fast = nq >= 1 && nq <= 2, inl = deg <= 6;
+                        const bool fast = nq >= 1 && nq <= 3, inl = deg <= 6;
                         uint32_t dist[6] = {0, 0, 0, 0, 0, 0};
                         for (uint32_t f = 0; f < deg && f < 6; ++f) dist[f] = (uint32_t)j - P.pidx[sCol][b0 + f];
                         if (!fast && inl) x = dist[4] | (dist[5] << 12);

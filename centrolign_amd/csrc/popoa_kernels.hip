@@ -1012,11 +1012,14 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
         srcR = l >> 7;
     }
     __syncthreads();
-    const bool fastR = !is_ghost && live && (r == 0 || (degR + (srcR ? 1u : 0u) <= 2 && degR + (srcR ? 1u : 0u) >= 1));
-    uint32_t rp0 = 0, rp1 = 0;
+    // the straight-line cell takes up to THREE predecessors per side here (a source's boundary index counted as one, missing ones repeating the
+    // first): fifteen independent LDS reads; graphs with many three-way joins would otherwise send a row through the loops at every step
+    const bool fastR = !is_ghost && live && (r == 0 || (degR + (srcR ? 1u : 0u) <= 3 && degR + (srcR ? 1u : 0u) >= 1));
+    uint32_t rp0 = 0, rp1 = 0, rp2 = 0;
     if (r && fastR && degR) {
         rp0 = plR[firstR];
-        rp1 = degR == 2 ? plR[firstR + 1] : (srcR ? 0u : rp0);
+        rp1 = degR >= 2 ? plR[firstR + 1] : (srcR ? 0u : rp0);
+        rp2 = degR == 3 ? plR[firstR + 2] : (degR == 2 && srcR ? 0u : rp0);
     }
     // predecessor f of column c: up to six distances ride in the record (z, w: twelve bits each, in list order), longer lists stay in HBM
     auto col_pred = [&](const uint4& rc, uint32_t c, uint32_t fc, uint32_t f) -> uint32_t {
@@ -1024,6 +1027,14 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
         const uint32_t word = f < 2 ? rc.z : (f < 4 ? rc.w : rc.x);
         return c - ((word >> (12 * (f & 1u))) & 0xFFFu);
     };
+    // up to four row predecessors in registers (a missing one repeats the first: the maxima do not care), so that the general cell's reads do not
+    // hang on list reads
+    uint32_t rpl[4] = {0, 0, 0, 0};
+    const bool few_rows = degR >= 1 && degR <= 4;
+    if (!is_ghost && live && few_rows) {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) rpl[e] = plR[firstR + (e < degR ? e : 0u)];
+    }
     auto cell_at = [&](uint32_t row_l, uint32_t col) -> const int32_t* { return ring + (row_l * row_stride + (col & hm) * CW); };
     auto get_mv = [&](const int32_t* cell, int32_t& m, int32_t (&v)[NPW]) {
         const int4 x = reinterpret_cast<const int4*>(cell)[0];
@@ -1051,7 +1062,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     for (int w = 0; w < WW; ++w) st[w] = 0;
     const unsigned long long* const hin = SD.handoff + sd.hand_in + (size_t)gi * (nC + 1) * WW;
     uint32_t* const prog_in = SD.progress + (sd.prog - 1);   // the strip in front (ghost lanes only: strip > 0)
-    uint32_t avail = 0;                                       // columns of the incoming rows known to be complete
+    uint32_t avail = 0, avail_next = 0;                       // columns of the incoming rows known to be complete; the word as asked for at the last active step
     bool failed = false;
     auto fetch = [&](uint32_t col, unsigned long long (&dst)[WW]) {
         if (col >= avail) {
@@ -1084,8 +1095,13 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                     w[0] = make_int4((int)(unsigned)st[0], (int)(unsigned)(st[0] >> 32), (int)(unsigned)st[1], (int)(unsigned)(st[1] >> 32));
                     if (NPW > 1) w[1] = make_int4((int)(unsigned)st[WW - 2], (int)(unsigned)(st[WW - 2] >> 32), (int)(unsigned)st[WW - 1], (int)(unsigned)(st[WW - 1] >> 32));
                 }
+                // the progress word asked for four steps ago has arrived with the cell: a blocking poll (a round trip to L2 with the whole workgroup waiting
+                // at the barrier) is left for the case that the strip in front really is not there yet
+                if (avail_next == kStripFailed) failed = true;
+                avail = avail_next > avail ? avail_next : avail;
                 const uint32_t tn = t + GW;
                 if (tn >= L && tn - L <= nC) fetch(tn - L, st);
+                avail_next = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (gw == 0 && gi < 16 && (t & (GW - 1)) == 0) {
                 if (rec_col) { rec_ring[(rec_col - 1) & rmask] = rec_reg; rec_col = 0; }
@@ -1102,20 +1118,24 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             bool srcC = false, fastC = false, inlineC = false;
             if (c) { degC = (rc.y >> 17) & 63u; fastC = (rc.y >> 23) & 1u; labC = (rc.y >> 24) & 0x7Fu; srcC = rc.y >> 31; inlineC = (rc.y >> 16) & 1u; }
             if (c && fastC && fastR) {
-                const uint32_t e0 = rc.x & 0xFFFu, e1 = (rc.x >> 12) & 0xFFFu;
-                const uint32_t o0 = ((c - e0) & hm) * CW, o1 = ((c - e1) & hm) * CW, oc = (c & hm) * CW;
-                int32_t mv0, mv1, mh0, mh1, vv0[NPW], vv1[NPW], hh0[NPW], hh1[NPW];
-                get_mv(ring + (rp0 * row_stride + oc), mv0, vv0);
-                get_mv(ring + (rp1 * row_stride + oc), mv1, vv1);
+                const uint32_t e0 = rc.x & 0xFFu, e1 = (rc.x >> 8) & 0xFFu, e2 = (rc.x >> 16) & 0xFFu;
+                const uint32_t o0 = ((c - e0) & hm) * CW, o1 = ((c - e1) & hm) * CW, o2 = ((c - e2) & hm) * CW, oc = (c & hm) * CW;
+                const uint32_t b0 = rp0 * row_stride, b1 = rp1 * row_stride, b2 = rp2 * row_stride;
+                int32_t mv0, mv1, mv2, mh0, mh1, mh2, vv0[NPW], vv1[NPW], vv2[NPW], hh0[NPW], hh1[NPW], hh2[NPW];
+                get_mv(ring + (b0 + oc), mv0, vv0);
+                get_mv(ring + (b1 + oc), mv1, vv1);
+                get_mv(ring + (b2 + oc), mv2, vv2);
                 get_mh(my_row + o0, mh0, hh0);
                 get_mh(my_row + o1, mh1, hh1);
-                const int32_t d00 = ring[o0 + rp0 * row_stride], d01 = ring[o1 + rp0 * row_stride];
-                const int32_t d10 = ring[o0 + rp1 * row_stride], d11 = ring[o1 + rp1 * row_stride];
-                M = imax(imax(d00, d01), imax(d10, d11)) + ((labR == labC) ? P.match : -P.mismatch);
+                get_mh(my_row + o2, mh2, hh2);
+                const int32_t d00 = ring[o0 + b0], d01 = ring[o1 + b0], d02 = ring[o2 + b0];
+                const int32_t d10 = ring[o0 + b1], d11 = ring[o1 + b1], d12 = ring[o2 + b1];
+                const int32_t d20 = ring[o0 + b2], d21 = ring[o1 + b2], d22 = ring[o2 + b2];
+                M = imax(imax(imax(imax(d00, d01), imax(d10, d11)), imax(imax(d02, d12), imax(d20, d21))), d22) + ((labR == labC) ? P.match : -P.mismatch);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) {
-                    V[k] = imax(imax(mv0 - P.oe[k], vv0[k] - P.ext[k]), imax(mv1 - P.oe[k], vv1[k] - P.ext[k]));
-                    Hh[k] = imax(imax(mh0 - P.oe[k], hh0[k] - P.ext[k]), imax(mh1 - P.oe[k], hh1[k] - P.ext[k]));
+                    V[k] = imax(imax(imax(mv0 - P.oe[k], vv0[k] - P.ext[k]), imax(mv1 - P.oe[k], vv1[k] - P.ext[k])), imax(mv2 - P.oe[k], vv2[k] - P.ext[k]));
+                    Hh[k] = imax(imax(imax(mh0 - P.oe[k], hh0[k] - P.ext[k]), imax(mh1 - P.oe[k], hh1[k] - P.ext[k])), imax(mh2 - P.oe[k], hh2[k] - P.ext[k]));
                 }
                 if (!r) {
                     M = CL_NEG_INF;
@@ -1144,6 +1164,41 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 if (srcC) {
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], -P.oe[k]);
+                }
+            } else if (r && c && (few_rows || !degR)) {    // interior, up to four row predecessors: every read of a column predecessor's cells at once
+                if (degR) {
+                    int32_t m[4], vv[4][NPW];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) get_mv(cell_at(rpl[e], c), m[e], vv[e]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m[e] - P.oe[k], vv[e][k] - P.ext[k]));
+                }
+                if (srcR) {
+                    const int32_t m = cell_at(0, c)[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], m - P.oe[k]);
+                }
+                const int32_t sc = (labR == labC) ? P.match : -P.mismatch;
+                const uint32_t fc = inlineC ? 0u : poffC[c - 1];
+                for (uint32_t f = 0; f < degC; ++f) {
+                    const uint32_t q = col_pred(rc, c, fc, f);
+                    int32_t m, hh[NPW];
+                    get_mh(cell_at(L, q), m, hh);
+                    const int32_t d0 = degR ? cell_at(rpl[0], q)[0] : CL_NEG_INF, d1 = degR ? cell_at(rpl[1], q)[0] : CL_NEG_INF;
+                    const int32_t d2 = degR ? cell_at(rpl[2], q)[0] : CL_NEG_INF, d3 = degR ? cell_at(rpl[3], q)[0] : CL_NEG_INF;
+                    const int32_t d4 = srcR ? cell_at(0, q)[0] : CL_NEG_INF;
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], hh[k] - P.ext[k]));
+                    M = imax(M, imax(imax(imax(d0, d1), imax(d2, d3)), d4) + sc);
+                }
+                if (srcC) {
+                    const int32_t m = cell_at(L, 0)[0];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], m - P.oe[k]);
+                    for (uint32_t e = 0; e < degR; ++e) M = imax(M, cell_at(plR[firstR + e], 0)[0] + sc);
+                    if (srcR) M = imax(M, sc);   // the corner counts as 0 (:814-818)
                 }
             } else if (r && c) {    // interior, any degrees (:897-938 in pull form)
                 for (uint32_t e = 0; e < degR; ++e) {
