@@ -82,8 +82,9 @@ std::vector<AnchorT> anchor_chain(Device& dev, const AnchorerT& anchorer, const 
                                   const XMerge& /*xmerge1*/, const XMerge& /*xmerge2*/, bool /*restrain_memory*/,
                                   MaskT* masked_matches = nullptr, double* override_scale = nullptr) {
     FlatBaseGraph g1(graph1, tableau1), g2(graph2, tableau2);
-    cl_anchor_params ap;
+    cl_anchor_params ap{};
     cl_chain_params_default(&ap.chain);
+    ap.chaining_algorithm_plus_one = (int)anchorer.chaining_algorithm + 1;   // (Sparse: the library builds ChainMerge tables itself, as core.hpp:350-357 passes them)
     for (int k = 0; k < 3; ++k) { ap.chain.gap_open[k] = anchorer.gap_open[k]; ap.chain.gap_extend[k] = anchorer.gap_extend[k]; }
     ap.chain.anchor_score_function = (int)score_function.anchor_score_function;
     ap.chain.pair_count_power = score_function.pair_count_power;
