@@ -1083,7 +1083,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // the row graph's predecessors within 32 rows (they become the next strip's ghost rows) and the pair is large enough to pay for it
             bool take_strip = false;
             uint32_t strip_log = 0, strip_S = 0, strip_n = 0, strip_g = 0;
-            if (!take_sys && !g_no_strip && !g_force_general && n_rows >= 192 && cells >= 300000 && n_cols < (1u << 28)) {
+            if (!take_sys && !g_no_strip && !g_force_general && n_rows >= 192 && cells >= 100000 && n_cols < (1u << 28)) {
                 const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];
                 const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
                 const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];

@@ -249,8 +249,8 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
 
 def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
     """branching pairs whose per-row column rings fill the systolic kernel's LDS budget (launches with 98-160 KB of dynamic LDS), next to
-    ones that overflow it and take the LDS-ring or the HBM-plane kernel: all against the oracle"""
-    sizes = [(480, 500), (510, 300), (300, 509), (440, 2000), (1000, 620), (255, 3000), (64, 5000)]
+    ones that overflow it and take the strip kernel, the LDS-ring or the HBM-plane kernel: all against the oracle"""
+    sizes = [(480, 500), (510, 300), (300, 509), (440, 2000), (1000, 620), (255, 3000), (64, 5000), (150, 4000), (191, 2500), (180, 500)]
     seen = set()
     for kw in (dict(extra_edge_p=0.02, skip_max=2), dict(extra_edge_p=0.05, skip_max=3), dict(extra_edge_p=0.15, skip_max=2)):
         b = synth.sized_dag_batch(sizes, seed=11, **kw)
@@ -260,4 +260,14 @@ def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
         plan.destroy()
         got = gpu_ctx.stitch_batch_align(b)
         assert got.same_as(po.oracle_stitch_batch(b)) is None, kw
-    assert ("popoa_sys_kernel", True) in seen and ("popoa_ring_kernel", False) in seen and ("popoa_general_kernel", False) in seen, seen
+    # (since round 4 the pairs of 192 rows and more that overflow the systolic kernel's LDS go to the strip kernel; the narrower ones still take the
+    # LDS-ring or the HBM-plane kernel)
+    names = {k for k, _ in seen}
+    assert ("popoa_sys_kernel", True) in seen and "popoa_strip_kernel" in names, seen
+    # ... and one whose column predecessors reach further back than any ring holds (a 1 500-column fork): not for the strips, not for the systolic kernel
+    b = synth.sized_dag_batch([(150, 4000), (400, 2000)], seed=12, extra_edge_p=0.05, skip_max=1500)
+    plan = gpu_ctx.plan(b)
+    kernels = {li["kernel"].split("<")[0] for li in plan.launches()}
+    plan.destroy()
+    assert kernels & {"popoa_ring_kernel", "popoa_general_kernel"}, kernels
+    assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
