@@ -1011,7 +1011,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             for (uint64_t i = 0; i < g[s].n_snk; ++i) P.snk[s].push_back(rank[g[s].snk[i]] + 1);
             P.order[s].insert(P.order[s].end(), order.begin(), order.end());
         }
-        d.kind = (linear && !g_force_general) ? CL_KIND_LINEAR : CL_KIND_GENERAL;
+        // (a chain pair of 4 096 rows and more would take the chain kernel's ONE workgroup through four and more passes: the strip kernel puts it on
+        // twenty compute units instead — 6 300 x 6 300: 22.4 -> ≈ 12 ms; such a pair always meets the strip kernel's conditions)
+        const bool big_linear = linear && !g_no_strip && !g_force_general && std::min(d.n1, d.n2) >= 4096 && std::min(d.n1, d.n2) <= 40000;
+        d.kind = (linear && !g_force_general && !big_linear) ? CL_KIND_LINEAR : CL_KIND_GENERAL;
         d.plane_base = P.plane_cursor;
         uint8_t lr = 0, lw = 0, ls = 0;
         if (d.kind == CL_KIND_LINEAR) {

@@ -235,6 +235,12 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
         plan.destroy()
         got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+    # a chain pair of 4 096 rows and more takes the strips too (the chain kernel would need four passes of its one workgroup)
+    b = synth.sized_dag_batch([(4500, 4200), (4100, 9000)], seed=8, extra_edge_p=0.0, n_alt=0)
+    plan = gpu_ctx.plan(b)
+    assert all(li["kernel"].startswith("popoa_strip_kernel") for li in plan.launches()), plan.launches()
+    plan.destroy()
+    assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
     # a plan executed again and again: the strips' progress words start every pass at zero
     b = synth.sized_dag_batch([(2000, 2000), (800, 1500)], seed=3)
     plan = gpu_ctx.plan(b)
