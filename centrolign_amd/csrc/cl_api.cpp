@@ -1369,14 +1369,17 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const ClProbDesc& d = pl->desc[s0.prob];
             if (d.npw != npw) { i += s0.n_strips; continue; }
             if ((uint32_t)pl->strip_list.size() - grp.first + s0.n_strips > 224) { close(); open(); }
-            if (grp.prog_first == UINT32_MAX) grp.prog_first = (uint32_t)i;
+            // a strip's progress word = its position in the launch lists: the words of a launch are one run, zeroed by that launch alone (launches of
+            // other NumPW run beside it on other streams and must not have their words touched)
+            if (grp.prog_first == UINT32_MAX) grp.prog_first = (uint32_t)pl->strip_list.size();
             uint32_t max_rows = 0;
             for (uint32_t j = 0; j < s0.n_strips; ++j) {
+                pl->strips[i + j].prog = (uint32_t)pl->strip_list.size();
                 pl->strip_list.push_back((uint32_t)(i + j));
                 grp.ring_bytes = std::max(grp.ring_bytes, strip_lds[i + j]);
                 max_rows = std::max(max_rows, pl->strips[i + j].n_real);
             }
-            grp.prog_count = (uint32_t)(i + s0.n_strips) - grp.prog_first;
+            grp.prog_count = (uint32_t)pl->strip_list.size() - grp.prog_first;
             grp.block = std::max<int>(grp.block, 256 + (int)((max_rows + 63) / 64 * 64));
             const uint64_t cells = (uint64_t)(d.n1 + 1) * (d.n2 + 1);
             grp.cells += cells;

@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             while (true) {
                 avail = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (avail > col) break;
-                if (++spins > (1u << 22)) { failed = true; avail = kStripFailed; break; }
+                if (++spins > (1u << 20)) { failed = true; avail = kStripFailed; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             if (avail == kStripFailed) failed = true;
@@ -1282,7 +1282,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             unsigned spins = 0;
             uint32_t v;
             while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < kStripDone) {
-                if (++spins > (1u << 22)) { v = kStripFailed; break; }
+                if (++spins > (1u << 20)) { v = kStripFailed; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
             bad |= v == kStripFailed;

@@ -235,6 +235,16 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
         plan.destroy()
         got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+    # pairs of different NumPW in one plan: their strip launches run side by side on different streams, each with progress words of its own
+    b = synth.sized_dag_batch([(600, 700), (1500, 900), (400, 2000), (1200, 1200), (800, 500), (2000, 700)], seed=21, extra_edge_p=0.05, skip_max=3)
+    f = np.array([2, 3, 1, 2, 3, 1], np.uint8)
+    plan = gpu_ctx.plan(b, force_num_pw=f)
+    assert len({li["kernel"] for li in plan.launches() if li["kernel"].startswith("popoa_strip_kernel")}) == 3, plan.launches()
+    want = po.oracle_stitch_batch(b, force_num_pw=f)
+    for _ in range(6):
+        plan.execute(); plan.sync()
+        assert plan.collect().same_as(want) is None
+    plan.destroy()
     # a chain pair of 4 096 rows and more takes the strips too (the chain kernel would need four passes of its one workgroup)
     b = synth.sized_dag_batch([(4500, 4200), (4100, 9000)], seed=8, extra_edge_p=0.0, n_alt=0)
     plan = gpu_ctx.plan(b)
