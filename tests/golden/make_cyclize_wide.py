@@ -21,8 +21,6 @@ CASES = {   # name: sequences, seed, length, duplicated bases, carriers, hor_div
     # BASELINE configs[4]'s shape at small length: 50 sequences, root merge 25 + 25 paths = 625 chain combinations (beyond the walk kernel's 256: the
     # per-block kernels), 133 bonds, 550 polished regions
     "cyclize_50x8k": (50, 43, 8000, 3000, [1, 4, 7, 12, 18, 23, 29, 31, 36, 40, 44, 48], 0.08, 2000, 40000, "d", 5.1),
-    # the same shape at 100 kbp per sequence: the verdict's "size that means something" (round 4)
-    "cyclize_50x100k": (50, 47, 100000, 20000, [1, 4, 7, 12, 18, 23, 29, 31, 36, 40, 44, 48], 0.08, 5000, 150000, "e", 0.0),
 }
 
 
