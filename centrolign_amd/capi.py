@@ -94,7 +94,7 @@ class StitchResultC(C.Structure):
 class PlanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("n_problems", "n_po_poa", "dp_cells", "dp_bytes", "n_linear", "max_cells", "workspace_bytes",
-                 "n_launches")]
+                 "n_launches", "n_strip_fallbacks")]
 
 
 class BaseGraphC(C.Structure):

@@ -1416,6 +1416,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                                 (rc = pl->d_strip_list.upload_async(ctx, pl->strip_list)) || (rc = pl->d_progress.alloc(ctx, pl->strips.size())) ||
                                 (rc = pl->d_handoff.alloc(ctx, hand_words)))) { plan_free(pl); return rc; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cl_set_error(ctx, "upload failed"); plan_free(pl); return CL_ERR_HIP; }
+    { static const bool dbg = [] { const char* e = getenv("CL_STRIP_DEBUG_FAIL"); return e && *e == '1'; }(); pl->sdev.debug_fail = dbg ? 1u : 0u; }
     pl->sdev.strips = pl->d_strips.p; pl->sdev.recs = pl->d_strip_recs.p; pl->sdev.handoff = pl->d_handoff.p; pl->sdev.progress = pl->d_progress.p;
     if ((rc = pl->d_planes.alloc(ctx, plane_cursor)) || (rc = pl->d_out_pairs.alloc(ctx, out_cursor)) ||
         (rc = pl->d_out_len.alloc(ctx, pl->desc.size())) || (rc = pl->d_out_status.alloc(ctx, pl->desc.size())) ||
@@ -1648,6 +1649,34 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
         HIP_TRY(ctx, cl_copy_sync(ctx, status.data(), pl->d_out_status.p, npo * 4, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, cl_copy_sync(ctx, score.data(), pl->d_out_score.p, npo * 4, hipMemcpyDeviceToHost));
         if (!pairs.empty()) HIP_TRY(ctx, cl_copy_sync(ctx, pairs.data(), pl->d_out_pairs.p, pairs.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+    }
+    // a pair whose strips gave up waiting for one another (status 9: popoa_strip_kernel's waits are bounded, and the strips of a launch can be kept apart
+    // by whatever else crowds the device) is run again by the anti-diagonal kernel, which waits for nobody — same planes, same output slots
+    {
+        std::vector<uint32_t> redo[4];
+        for (size_t i = 0; i < npo; ++i)
+            if (status[i] == 9 && pl->desc[i].kind == CL_KIND_STRIP) redo[pl->desc[i].npw].push_back((uint32_t)i);
+        bool any = false;
+        for (int npw = 1; npw <= 3; ++npw) {
+            if (redo[npw].empty()) continue;
+            any = true;
+            DevBuf<uint32_t> d_redo;
+            int rc = d_redo.upload(ctx, redo[npw]);
+            if (rc) return rc;
+            ClDeviceBatch dev = pl->dev;
+            dev.ticks = nullptr;
+            hipError_t e = cl_launch_popoa_general(npw, 1024, (uint32_t)redo[npw].size(), 0, dev, d_redo.p, pl->sparams, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            d_redo.release();
+            if (e != hipSuccess) { set_error(ctx, "re-running %zu pairs on the anti-diagonal kernel failed: %s", redo[npw].size(), hipGetErrorString(e)); return CL_ERR_HIP; }
+            pl->stats.n_strip_fallbacks += redo[npw].size();
+        }
+        if (any) {
+            HIP_TRY(ctx, cl_copy_sync(ctx, len.data(), pl->d_out_len.p, npo * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, cl_copy_sync(ctx, status.data(), pl->d_out_status.p, npo * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, cl_copy_sync(ctx, score.data(), pl->d_out_score.p, npo * 4, hipMemcpyDeviceToHost));
+            if (!pairs.empty()) HIP_TRY(ctx, cl_copy_sync(ctx, pairs.data(), pl->d_out_pairs.p, pairs.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+        }
     }
     const uint64_t n = pl->n_problems;
     uint64_t total = 0;

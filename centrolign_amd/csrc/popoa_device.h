@@ -77,6 +77,7 @@ struct ClStripDevice {
     const uint4* recs;                // per problem: one record per column (see popoa_strip_kernel)
     unsigned long long* handoff;
     uint32_t* progress;               // zeroed before every pass
+    uint32_t debug_fail;              // test hook (CL_STRIP_DEBUG_FAIL=1): every second pair's last strip reports failure, as if a wait had expired
 };
 
 #endif

@@ -1270,7 +1270,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
-    if (failed) *fail_flag = 1;
+    if (failed || (SD.debug_fail && (prob & 1u) && tid == 0)) *fail_flag = 1;
     __threadfence();     // the planes of this strip, for the workgroup that runs the traceback
     __syncthreads();
     const bool strip_failed = *fail_flag != 0;

@@ -216,6 +216,8 @@ typedef struct cl_plan_stats {
     uint64_t max_cells;          /* largest single matrix */
     uint64_t workspace_bytes;    /* HBM bytes held by the plan */
     uint64_t n_launches;         /* kernel launches per execute */
+    uint64_t n_strip_fallbacks;  /* pairs whose strips (popoa_strip_kernel) gave up waiting for one another and were run again by the anti-diagonal kernel, summed over
+                                    the plan's collects (0 unless the device is crowded beyond what the strips' bounded waits tolerate) */
 } cl_plan_stats;
 int cl_stitch_plan_stats(const cl_stitch_plan* plan, cl_plan_stats* stats_out);
 

@@ -263,6 +263,29 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
     plan.destroy()
 
 
+def test_strips_that_give_up_are_run_again_by_the_anti_diagonal_kernel():
+    """the strips of a pair wait for one another with a bound; a pair whose strips report failure (CL_STRIP_DEBUG_FAIL=1 makes every second pair do so — the
+    switch is read once, hence the child process) is run again by the kernel that waits for nobody, and the caller sees the same alignments"""
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from centrolign_amd import capi, synth\n"
+            "from oracle import pyoracle as po\n"
+            "ctx = capi.Context(0)\n"
+            "b = synth.sized_dag_batch([(900, 700), (1300, 800), (600, 2000), (2000, 600), (700, 700)], seed=33, extra_edge_p=0.05, skip_max=3)\n"
+            "plan = ctx.plan(b)\n"
+            "assert any(li['kernel'].startswith('popoa_strip_kernel') for li in plan.launches())\n"
+            "plan.execute(); plan.sync(); got = plan.collect()\n"
+            "print(json.dumps(dict(same=got.same_as(po.oracle_stitch_batch(b)) is None, fallbacks=plan.stats()['n_strip_fallbacks'])))\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CL_STRIP_DEBUG_FAIL="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["same"] and res["fallbacks"] >= 2, res
+
+
 def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
     """branching pairs whose per-row column rings fill the systolic kernel's LDS budget (launches with 98-160 KB of dynamic LDS), next to
     ones that overflow it and take the strip kernel, the LDS-ring or the HBM-plane kernel: all against the oracle"""
