@@ -1336,25 +1336,45 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     // systolic DAG kernel: (NumPW, workgroup size, LDS class) — a launch's dynamic LDS is that of its hungriest problem, and LDS decides
     // how many workgroups share a CU, so the many small problems must not ride with the few large ones
     const uint32_t lds_class[5] = {12 * 1024, 32 * 1024, 64 * 1024, 100 * 1024, (uint32_t)kSysLdsBytes};
+    // ... unless the smaller ones are so few that all workgroups of the merged launch are resident at once anyway: a launch lasts as long as its longest sweep
+    // whatever rides along, and every launch less is a millisecond less on the stream it would have occupied (the streams, not the device, are what a step
+    // runs out of: 10 x 1 Mbp, sixteen launches a step on eight streams).  CL_STITCH_MERGE_LDS=0: one launch per class as in rounds 2-3 (A/B)
+    static const bool merge_lds = [] { const char* e = getenv("CL_STITCH_MERGE_LDS"); return !e || e[0] != '0'; }();
     for (int bi = 2; bi >= 0; --bi)
-        for (int npw = 3; npw >= 1; --npw)
+        for (int npw = 3; npw >= 1; --npw) {
+            std::vector<uint32_t> of_class[5];
+            for (uint32_t i = 0; i < pl->desc.size(); ++i) {
+                const ClProbDesc& d = pl->desc[i];
+                const uint32_t rows = std::min(d.n1, d.n2) + 1;
+                const int b = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
+                if (d.kind != CL_KIND_SYS || d.npw != npw || b != bi) continue;
+                int c = 0;
+                while (c < 4 && ring_need[i] > lds_class[c]) ++c;
+                of_class[c].push_back(i);
+            }
+            LaunchGroup grp;
+            auto open = [&]() { grp = LaunchGroup(); grp.kind = CL_KIND_SYS; grp.npw = npw; grp.block = blocks[bi]; grp.first = (uint32_t)plist.size(); };
+            open();
             for (int lc = 4; lc >= 0; --lc) {
-                LaunchGroup grp;
-                grp.kind = CL_KIND_SYS; grp.npw = npw; grp.block = blocks[bi];
-                grp.first = (uint32_t)plist.size();
-                for (uint32_t i = 0; i < pl->desc.size(); ++i) {
-                    const ClProbDesc& d = pl->desc[i];
-                    const uint32_t rows = std::min(d.n1, d.n2) + 1;
-                    const int b = rows <= 64 ? 0 : rows <= 256 ? 1 : 2;
-                    if (d.kind != CL_KIND_SYS || d.npw != npw || b != bi) continue;
-                    int c = 0;
-                    while (c < 4 && ring_need[i] > lds_class[c]) ++c;
-                    if (c != lc) continue;
+                if (of_class[lc].empty()) continue;
+                const size_t have = plist.size() - grp.first;
+                if (have) {
+                    auto per_cu_at = [&](uint32_t lds) { return std::max<uint64_t>(1, std::min<uint64_t>((160u * 1024u) / std::max<uint32_t>(lds, 1u), 2048u / (uint32_t)blocks[bi])); };
+                    uint32_t own = 0;
+                    for (uint32_t i : of_class[lc]) own = std::max(own, ring_need[i]);
+                    // all resident at once.  (Also merging classes that leave the newcomers' workgroups per compute unit unchanged was measured and lost: 2.75 against
+                    // 2.55 ms per step — the long sweeps of the two classes then share a launch's tail)
+                    (void)own;
+                    const bool fits = have + of_class[lc].size() <= 256 * per_cu_at(grp.ring_bytes);
+                    if (!merge_lds || !fits) { close_group(grp); open(); }
+                }
+                for (uint32_t i : of_class[lc]) {
                     plist.push_back(i);
                     grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
                 }
-                close_group(grp);
             }
+            close_group(grp);
+        }
     // strips of rows: every strip of a pair is a workgroup of the same launch (they wait for one another: at most 224 workgroups per launch, whole pairs)
     for (int npw = 3; npw >= 1; --npw) {
         LaunchGroup grp;
