@@ -1082,25 +1082,48 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                            max_deg <= 63 && cp[n_cols] - cp[0] < (1u << 17);   // field widths of the column records
             }
             // strips of rows (popoa_strip_kernel): pairs too large for one workgroup's LDS, one workgroup per strip of S rows, all strips of the pair in
-            // flight at once.  Taken when every column predecessor (a source's boundary column included) lies inside a ring of at most 64 columns,
-            // the row graph's predecessors within 32 rows (they become the next strip's ghost rows) and the pair is large enough to pay for it
+            // flight at once.  Taken when the column predecessors (a source's boundary column included) lie inside a ring of at most 64 columns but for at
+            // most eight SAVED columns, the row graph's predecessors within 32 rows (they become the next strip's ghost rows) and the pair is large enough
             bool take_strip = false;
-            uint32_t strip_log = 0, strip_S = 0, strip_n = 0, strip_g = 0;
+            uint32_t strip_log = 0, strip_S = 0, strip_n = 0, strip_g = 0, strip_limit = 0;
+            std::vector<uint32_t> strip_far;
             if (!take_sys && !g_no_strip && !g_force_general && n_rows >= 192 && cells >= 100000 && n_cols < (1u << 28)) {
                 const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];
                 const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
                 const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
-                uint64_t nm = 0, max_deg = 0, gd = 0;
-                for (uint64_t j = 1; j <= n_cols; ++j) {
-                    max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
-                    for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) nm = std::max<uint64_t>(nm, j - P.pidx[sCol][e]);
-                    if (cl[j - 1] & 0x80) nm = std::max(nm, j);
-                }
+                uint64_t max_deg = 0, gd = 0;
+                for (uint64_t j = 1; j <= n_cols; ++j) max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
                 for (uint64_t i = 1; i < n_rows; ++i)
                     for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) gd = std::max<uint64_t>(gd, i - P.pidx[sRow][e]);
-                uint32_t lg = 1;
-                while ((1ull << lg) < span[sRow] + nm + 1 && lg < 14) ++lg;
-                const uint64_t cw = npw == 1 ? 4 : 8, row_bytes = ((1ull << lg) * cw + (cw == 8 ? 4 : 8)) * 4;
+                // the near limit decides the ring depth (LDS per row) against the number of saved columns (LDS per row as well: a slot each): the candidate with
+                // the smallest footprint per row wins, as for the systolic kernel above
+                const uint64_t cw = npw == 1 ? 4 : 8;
+                uint32_t lg = 15;
+                uint64_t row_bytes = UINT64_MAX;
+                {
+                    const uint64_t limits[6] = {2, 4, 8, 16, 32, 62};
+                    std::vector<uint32_t> cand;
+                    for (uint64_t limit : limits) {
+                        cand.clear();
+                        uint64_t nm = 0;
+                        for (uint64_t j = 1; j <= n_cols; ++j) {
+                            for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
+                                const uint64_t dist = j - P.pidx[sCol][e];
+                                if (dist > limit) cand.push_back(P.pidx[sCol][e]); else nm = std::max(nm, dist);
+                            }
+                            if (cl[j - 1] & 0x80) { if (j > limit) cand.push_back(0); else nm = std::max(nm, j); }
+                        }
+                        std::sort(cand.begin(), cand.end());
+                        cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+                        if (cand.size() > 8) continue;
+                        uint32_t l2 = 1;
+                        while ((1ull << l2) < span[sRow] + nm + 1 && l2 < 14) ++l2;
+                        if (l2 > 6) break;   // (a larger limit only deepens the ring)
+                        const uint64_t bytes = ((1ull << l2) * cw + (cw == 8 ? 4 : 8)) * 4 + cand.size() * cw * 4;
+                        if (bytes < row_bytes) { row_bytes = bytes; lg = l2; strip_limit = (uint32_t)limit; strip_far = cand; }
+                        if (cand.empty()) break;
+                    }
+                }
                 if (lg <= 6 && span[sRow] <= 32 && gd <= 32 && max_deg <= 63) {
                     // the largest S (a multiple of 64, at most 768: 1 024 threads less the four ghost waves) whose rings and row lists fit
                     auto rec_ring_log = [&](uint64_t n_loc) { uint32_t l = 5; while ((1ull << l) < n_loc + 48) ++l; return l; };   // popoa_strip_kernel's record ring
@@ -1109,7 +1132,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         for (uint64_t a = 0; a < n_rows; a += S) {
                             const uint64_t hi = std::min(n_rows - 1, a + S - 1), lo = std::max<uint64_t>(a, 1);
                             const uint64_t edges = hi >= lo ? rp[hi] - rp[lo - 1] : 0, n_loc = (a ? gd : 0) + std::min(S, n_rows - a);
-                            worst = std::max<uint64_t>(worst, n_loc * row_bytes + ((uint64_t)16 << rec_ring_log(n_loc)) + edges * 4 + 16);
+                            worst = std::max<uint64_t>(worst, n_loc * row_bytes + ((uint64_t)16 << rec_ring_log(n_loc)) + edges * 4 + 64);
                         }
                         return worst;
                     };
@@ -1129,21 +1152,29 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     const uint32_t rec_base = (uint32_t)P.strip_recs.size();
                     for (uint64_t j = 1; j <= n_cols; ++j) {
                         const uint32_t b0 = cp[j - 1], deg = cp[j] - cp[j - 1], l = cl[j - 1], src = l >> 7, nq = deg + src;
+                        // a predecessor column as a code: that many columns back (below 0x80: inside the ring), or 0x80 | its slot among the saved columns
+                        auto code = [&](uint32_t q) -> uint32_t {
+                            if ((uint32_t)j - q <= strip_limit) return (uint32_t)j - q;
+                            return 0x80u | (uint32_t)(std::lower_bound(strip_far.begin(), strip_far.end(), q) - strip_far.begin());
+                        };
                         uint32_t x = 0;
-                        if (nq >= 1 && nq <= 3) {   // the straight-line cell's three predecessor distances (8 bits each: all below the ring depth)
+                        if (nq >= 1 && nq <= 3) {   // the straight-line cell's three predecessors (8 bits each)
                             uint32_t q[3], nl = 0;
                             for (uint32_t f = 0; f < deg; ++f) q[nl++] = P.pidx[sCol][b0 + f];
                             if (src) q[nl++] = 0u;
                             for (; nl < 3; ++nl) q[nl] = q[0];
-                            x = ((uint32_t)j - q[0]) | (((uint32_t)j - q[1]) << 8) | (((uint32_t)j - q[2]) << 16);
+                            x = code(q[0]) | (code(q[1]) << 8) | (code(q[2]) << 16);
                         }
                         // the general cell's predecessor list rides along as distances (z: first two, w: next two, x — free when the straight-line
                         // cell does not apply — the fifth and sixth); longer lists are read from HBM
                         const bool fast = nq >= 1 && nq <= 3, inl = deg <= 6;
                         uint32_t dist[6] = {0, 0, 0, 0, 0, 0};
-                        for (uint32_t f = 0; f < deg && f < 6; ++f) dist[f] = (uint32_t)j - P.pidx[sCol][b0 + f];
+                        for (uint32_t f = 0; f < deg && f < 6; ++f) dist[f] = code(P.pidx[sCol][b0 + f]);
                         if (!fast && inl) x = dist[4] | (dist[5] << 12);
-                        P.strip_recs.push_back(make_uint4(x, (inl ? 1u << 16 : 0u) | (deg << 17) | (fast ? 1u << 23 : 0u) | ((l & 0x7Fu) << 24) | (src << 31),
+                        // bit 15: this column is itself a saved one, bits 12-14: in that slot
+                        const auto self = std::lower_bound(strip_far.begin(), strip_far.end(), (uint32_t)j);
+                        const uint32_t keep = self != strip_far.end() && *self == (uint32_t)j ? 0x8000u | ((uint32_t)(self - strip_far.begin()) << 12) : 0u;
+                        P.strip_recs.push_back(make_uint4(x, keep | (inl ? 1u << 16 : 0u) | (deg << 17) | (fast ? 1u << 23 : 0u) | ((l & 0x7Fu) << 24) | (src << 31),
                                                           dist[0] | (dist[1] << 12), dist[2] | (dist[3] << 12)));
                     }
                     const uint64_t hand_per = (uint64_t)strip_g * (n_cols + 1) * (cw / 2);
@@ -1164,7 +1195,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         while ((1ull << lrw) < (uint64_t)sd.n_ghost + sd.n_real + 48) ++lrw;
                         sd.logRW = lrw;
                         const uint64_t hi = std::min<uint64_t>(n_rows - 1, a + strip_S - 1), lo = std::max<uint64_t>(a, 1);
-                        P.strip_lds.push_back((uint32_t)(((uint64_t)sd.n_ghost + sd.n_real) * row_bytes + (16ull << lrw) + (hi >= lo ? rp[hi] - rp[lo - 1] : 0) * 4 + 16));
+                        P.strip_lds.push_back((uint32_t)(((uint64_t)sd.n_ghost + sd.n_real) * row_bytes + (16ull << lrw) + (hi >= lo ? rp[hi] - rp[lo - 1] : 0) * 4 + 64));
                         P.strips.push_back(sd);
                     }
                     P.hand_words += (uint64_t)(strip_n - 1) * hand_per;
@@ -1183,6 +1214,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             } else if (take_strip) {
                 d.kind = CL_KIND_STRIP;
                 d.pad = (uint16_t)(strip_log | (d.n2 < d.n1 ? 0x8000u : 0u));
+                d.aux_base = (uint32_t)P.sys_aux.size();   // {near limit, the saved columns ascending}, as for the systolic kernel
+                d.aux_cnt = (uint32_t)strip_far.size();
+                P.sys_aux.push_back(strip_limit);
+                P.sys_aux.insert(P.sys_aux.end(), strip_far.begin(), strip_far.end());
                 P.ring_need.push_back(0);
             } else if (!g_no_ring && depth * per_diag + topo_bytes <= kRingLdsBytes && (depth >= 8 || depth >= span[0] + span[1] + 1)) {
                 d.pad = (uint16_t)(depth | (depth >= span[0] + span[1] + 1 ? 0x8000u : 0u));   // bit 15: the ring serves every read
@@ -1250,7 +1285,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             for (int s = 0; s < 2; ++s) { d.node_base[s] += lab_base[s]; d.snk_base[s] += snk_base[s]; }
             d.plane_base += plane_cursor;
             d.out_base += (uint32_t)out_cursor;
-            if (d.kind == CL_KIND_SYS) d.aux_base += aux_base;
+            if (d.kind == CL_KIND_SYS || d.kind == CL_KIND_STRIP) d.aux_base += aux_base;
             pl->po_index[P.po_problem[i]] = (int32_t)pl->desc.size();
             pl->desc.push_back(d);
             pl->po_problem.push_back(P.po_problem[i]);

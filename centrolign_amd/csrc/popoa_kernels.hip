@@ -949,9 +949,9 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
 // asks for the cell four columns on.  A wave's loads so have four steps (2-3 us) to arrive and wait for nothing but one another: no register
 // rotation, no stores in these waves.  The computing rows start at wave 4 and are the sys kernel's, with two differences: the column records (16 bytes, written by the host: the straight-line cell's two predecessor distances, and up to six
 // predecessor distances for the general cell, so that no cell of the sweep needs a global load) pass through a small LDS ring which wave 0
-// refills sixteen columns at a time, thirty-odd columns ahead of the first row — 16 bytes x columns do not fit LDS beside the rings — and there
-// are no saved columns (the host routes a pair here only when every column predecessor is
-// inside the ring).  The hand-off cells are written and read as 64-bit write-through / cache-bypassing atomics (agent scope, relaxed), and the
+// refills sixteen columns at a time, thirty-odd columns ahead of the first row — 16 bytes x columns do not fit LDS beside the rings .  Columns that a later column reaches from further away than the ring holds (the fork in front of a long bubble; column 0 for a
+// late source) are SAVED columns as in the sys kernel, at most eight per pair: their cells are also written to an LDS area of their own ([slot][row], ghost
+// rows included) and read from there.  The hand-off cells are written and read as 64-bit write-through / cache-bypassing atomics (agent scope, relaxed), and the
 // producer publishes "columns done" after a vmcnt(0) of the one wave that holds all its hand-off rows: the consumer polls that word before it
 // asks for a column, so no fence is ever needed while the sweep runs.  At its end a strip makes its planes visible (one fence) and marks itself
 // done; the last strip waits for all marks and runs the traceback.  Every wait is bounded: a strip that gives up marks itself failed, the marks
@@ -991,14 +991,20 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     const uint32_t r = sd.row_base + L;                           // matrix row
     const uint32_t row_stride = H * CW + (CW == 8 ? 4u : 8u);     // (see popoa_sys_kernel: the lanes' 16-byte accesses fall on different bank groups)
     int32_t* const ring = lds;
+    const uint32_t K = pd.aux_cnt;                                                  // saved columns
+    int32_t* const saved = ring + n_loc * row_stride;                               // [K][n_loc][CW]
+    const uint32_t saved_off = n_loc * row_stride, slot_stride = n_loc * CW;
     const uint32_t rmask = (1u << sd.logRW) - 1;
-    uint4* const rec_ring = reinterpret_cast<uint4*>(ring + n_loc * row_stride);   // record of column c in slot (c - 1) & rmask
+    uint4* const rec_ring = reinterpret_cast<uint4*>(saved + K * slot_stride);     // record of column c in slot (c - 1) & rmask
     uint32_t* const plR = reinterpret_cast<uint32_t*>(rec_ring + (rmask + 1));
     const uint32_t r_lo = sd.row_base + g, r_hi = sd.row_base + n_loc - 1;   // computing rows
     const uint32_t node_lo = r_lo ? r_lo : 1u;
     const uint32_t eR0 = poffR[node_lo - 1], eR1 = r_hi >= node_lo ? poffR[r_hi] : eR0;
     for (uint32_t i = tid; i < eR1 - eR0; i += blockDim.x) plR[i] = pidxR[eR0 + i] - sd.row_base;   // as timing indices
-    int* const fail_flag = reinterpret_cast<int*>(plR + (eR1 - eR0));
+    uint32_t* const saved_col = plR + (eR1 - eR0);
+    for (uint32_t i = tid; i < K; i += blockDim.x) saved_col[i] = B.aux[pd.aux_base + 1 + i];
+    const bool save_col0 = K && B.aux[pd.aux_base + 1] == 0;   // the list is ascending
+    int* const fail_flag = reinterpret_cast<int*>(saved_col + K);
     if (tid == 0) *fail_flag = 0;
     for (uint32_t i = tid; i < 32 && i < nC; i += blockDim.x) rec_ring[i & rmask] = recs[i];   // columns 1 .. 32; the loop below goes on from 33
     // this thread's row
@@ -1025,7 +1031,8 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     auto col_pred = [&](const uint4& rc, uint32_t c, uint32_t fc, uint32_t f) -> uint32_t {
         if (!((rc.y >> 16) & 1u)) return pidxC[fc + f];
         const uint32_t word = f < 2 ? rc.z : (f < 4 ? rc.w : rc.x);
-        return c - ((word >> (12 * (f & 1u))) & 0xFFFu);
+        const uint32_t e = (word >> (12 * (f & 1u))) & 0xFFFu;
+        return (e & 0x80u) ? saved_col[e & 0x7Fu] : c - e;      // bit 7: saved column number (low bits), else that many columns back
     };
     // up to four row predecessors in registers (a missing one repeats the first: the maxima do not care), so that the general cell's reads do not
     // hang on list reads
@@ -1035,7 +1042,14 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e) rpl[e] = plR[firstR + (e < degR ? e : 0u)];
     }
-    auto cell_at = [&](uint32_t row_l, uint32_t col) -> const int32_t* { return ring + (row_l * row_stride + (col & hm) * CW); };
+    auto slot_of = [&](uint32_t col) { uint32_t s2 = 0; while (s2 + 1 < K && saved_col[s2] != col) ++s2; return s2; };
+    // where cell (row with timing index row_l, column col) lives at step t: in the row's ring while that row has not moved H columns past col, else in the
+    // saved area (the host saved every column that is read from further away)
+    uint32_t t = 0;
+    auto cell_at = [&](uint32_t row_l, uint32_t col) -> const int32_t* {
+        if (t - row_l - col < H) return ring + (row_l * row_stride + (col & hm) * CW);
+        return saved + (slot_of(col) * n_loc + row_l) * CW;
+    };
     auto get_mv = [&](const int32_t* cell, int32_t& m, int32_t (&v)[NPW]) {
         const int4 x = reinterpret_cast<const int4*>(cell)[0];
         m = x.x; v[0] = x.y;
@@ -1084,7 +1098,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     uint32_t rec_col = 0;   // column whose record rec_reg holds (0: none)
     const uint32_t out_first = S - sd.n_out;   // computing rows from here on are handed to the next strip
     unsigned long long* const hout = SD.handoff + sd.hand_out;
-    for (uint32_t t = 0; t <= last; ++t) {
+    for (t = 0; t <= last; ++t) {
         const uint32_t d = sd.row_base + t;
         const uint32_t lo_d = G.lo(d), cnt_d = G.hi(d) - lo_d + 1;
         if (is_ghost) {
@@ -1094,6 +1108,14 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                     int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
                     w[0] = make_int4((int)(unsigned)st[0], (int)(unsigned)(st[0] >> 32), (int)(unsigned)st[1], (int)(unsigned)(st[1] >> 32));
                     if (NPW > 1) w[1] = make_int4((int)(unsigned)st[WW - 2], (int)(unsigned)(st[WW - 2] >> 32), (int)(unsigned)st[WW - 1], (int)(unsigned)(st[WW - 1] >> 32));
+                    if (K) {   // a saved column keeps its cells of the ghost rows too
+                        const uint32_t ky = c ? rec_ring[(c - 1) & rmask].y : (save_col0 ? 0x8000u : 0u);
+                        if (ky & 0x8000u) {
+                            int4* sw = reinterpret_cast<int4*>(saved + (((ky >> 12) & 7u) * n_loc + L) * CW);
+                            sw[0] = w[0];
+                            if (NPW > 1) sw[1] = w[1];
+                        }
+                    }
                 }
                 // the progress word asked for four steps ago has arrived with the cell: a blocking poll (a round trip to L2 with the whole workgroup waiting
                 // at the barrier) is left for the case that the strip in front really is not there yet
@@ -1119,18 +1141,23 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             if (c) { degC = (rc.y >> 17) & 63u; fastC = (rc.y >> 23) & 1u; labC = (rc.y >> 24) & 0x7Fu; srcC = rc.y >> 31; inlineC = (rc.y >> 16) & 1u; }
             if (c && fastC && fastR) {
                 const uint32_t e0 = rc.x & 0xFFu, e1 = (rc.x >> 8) & 0xFFu, e2 = (rc.x >> 16) & 0xFFu;
-                const uint32_t o0 = ((c - e0) & hm) * CW, o1 = ((c - e1) & hm) * CW, o2 = ((c - e2) & hm) * CW, oc = (c & hm) * CW;
+                // bit 7 of a predecessor code: saved column number (low bits) instead of a distance — a cell of row x then sits at saved_off + slot * slot_stride + x * CW
+                const bool f0 = e0 & 0x80u, f1 = e1 & 0x80u, f2 = e2 & 0x80u;
+                const uint32_t o0 = f0 ? saved_off + (e0 & 0x7Fu) * slot_stride : ((c - e0) & hm) * CW;
+                const uint32_t o1 = f1 ? saved_off + (e1 & 0x7Fu) * slot_stride : ((c - e1) & hm) * CW;
+                const uint32_t o2 = f2 ? saved_off + (e2 & 0x7Fu) * slot_stride : ((c - e2) & hm) * CW, oc = (c & hm) * CW;
+                const uint32_t s0 = f0 ? (uint32_t)CW : row_stride, s1 = f1 ? (uint32_t)CW : row_stride, s2 = f2 ? (uint32_t)CW : row_stride;
                 const uint32_t b0 = rp0 * row_stride, b1 = rp1 * row_stride, b2 = rp2 * row_stride;
                 int32_t mv0, mv1, mv2, mh0, mh1, mh2, vv0[NPW], vv1[NPW], vv2[NPW], hh0[NPW], hh1[NPW], hh2[NPW];
                 get_mv(ring + (b0 + oc), mv0, vv0);
                 get_mv(ring + (b1 + oc), mv1, vv1);
                 get_mv(ring + (b2 + oc), mv2, vv2);
-                get_mh(my_row + o0, mh0, hh0);
-                get_mh(my_row + o1, mh1, hh1);
-                get_mh(my_row + o2, mh2, hh2);
-                const int32_t d00 = ring[o0 + b0], d01 = ring[o1 + b0], d02 = ring[o2 + b0];
-                const int32_t d10 = ring[o0 + b1], d11 = ring[o1 + b1], d12 = ring[o2 + b1];
-                const int32_t d20 = ring[o0 + b2], d21 = ring[o1 + b2], d22 = ring[o2 + b2];
+                get_mh(ring + (o0 + L * s0), mh0, hh0);
+                get_mh(ring + (o1 + L * s1), mh1, hh1);
+                get_mh(ring + (o2 + L * s2), mh2, hh2);
+                const int32_t d00 = ring[o0 + rp0 * s0], d01 = ring[o1 + rp0 * s1], d02 = ring[o2 + rp0 * s2];
+                const int32_t d10 = ring[o0 + rp1 * s0], d11 = ring[o1 + rp1 * s1], d12 = ring[o2 + rp1 * s2];
+                const int32_t d20 = ring[o0 + rp2 * s0], d21 = ring[o1 + rp2 * s1], d22 = ring[o2 + rp2 * s2];
                 M = imax(imax(imax(imax(d00, d01), imax(d10, d11)), imax(imax(d02, d12), imax(d20, d21))), d22) + ((labR == labC) ? P.match : -P.mismatch);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) {
@@ -1239,6 +1266,11 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
             w[0] = w0;
             if (NPW > 1) w[1] = w1;
+            if (c ? (rc.y >> 15) & 1u : (uint32_t)save_col0) {   // a saved column: its cells stay available for the far reads
+                int4* sw = reinterpret_cast<int4*>(saved + ((c ? (rc.y >> 12) & 7u : 0u) * n_loc + L) * CW);
+                sw[0] = w0;
+                if (NPW > 1) sw[1] = w1;
+            }
             const uint32_t k_row = tid - 64 * GW;
             if (k_row >= out_first) {   // a hand-off row: the cell goes to the next strip as well (write-through)
                 unsigned long long* dst = hout + ((size_t)(k_row - out_first) * (nC + 1) + c) * WW;

@@ -241,6 +241,34 @@ def sized_dag_batch(sizes, seed=0, extra_edge_p=0.15, skip_max=4, alphabet=4, n_
     return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
 
 
+def far_fork_batch(sizes, seed=0, n_far=3, far_min=200, far_max=1500, alphabet=4):
+    """graph pairs (n1 < n2 expected) whose SECOND graph has a few long-range skip edges — the fork in front of a bubble whose branches differ by a whole repeat
+    unit — on top of short bubbles in both: what the saved columns of the systolic and the strip kernel are for"""
+    rng = np.random.default_rng(seed)
+    b1, b2 = _SideBuilder(), _SideBuilder()
+    for n1, n2 in sizes:
+        lab, edges, src, snk = _random_dag(rng, n1, 0.05, 3, 0, 0, alphabet)
+        b1.add_graph(lab, edges, src, snk, rng.integers(0, 1 << 40, size=n1, dtype=np.uint64))
+        # second graph: built in topological positions, then shuffled like _random_dag does
+        topo = [(i, i + 1) for i in range(n2 - 1)]
+        for i in range(n2):
+            if rng.random() < 0.05:
+                j = i + 2 + int(rng.integers(0, 3))
+                if j < n2:
+                    topo.append((i, j))
+        for _ in range(n_far):
+            i = int(rng.integers(0, max(1, n2 - far_min - 2)))
+            j = min(n2 - 1, i + int(rng.integers(far_min, far_max)))
+            topo.append((i, j))
+        topo = list(dict.fromkeys(topo))
+        perm = rng.permutation(n2)
+        order = rng.permutation(len(topo))
+        edges2 = [(int(perm[topo[k][0]]), int(perm[topo[k][1]])) for k in order]
+        lab2 = rng.integers(1, 1 + alphabet, size=n2, dtype=np.uint8)
+        b2.add_graph(lab2, edges2, [int(perm[0])], [int(perm[n2 - 1])], rng.integers(0, 1 << 40, size=n2, dtype=np.uint64))
+    return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
+
+
 def hor_stitch_batch(seed, total_len, min_anchor=20, seq_div=0.005, hor_div=0.02, indel_hor=2, max_cells=40000000):
     """between-anchor subproblems of a simulated HOR pair (see module docstring).  Returns (batch, info)."""
     (s1, s2), (a1, a2) = hor_sequences(seed, total_len, 2, seq_div=seq_div, hor_div=hor_div, indel_hor=indel_hor,

@@ -235,6 +235,15 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
         plan.destroy()
         got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+    # a few forks that reach hundreds of columns back: SAVED columns (their cells kept in an LDS area of their own, ghost rows included), every NumPW
+    for npw in (1, 2, 3):
+        b = synth.far_fork_batch([(1200, 2500), (700, 4000), (2000, 2100)], seed=70 + npw, n_far=2 + npw)
+        f = np.full(b.n_problems, npw, np.uint8)
+        plan = gpu_ctx.plan(b, force_num_pw=f)
+        assert any(li["kernel"].startswith("popoa_strip_kernel") for li in plan.launches()), plan.launches()
+        plan.destroy()
+        got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
     # pairs of different NumPW in one plan: their strip launches run side by side on different streams, each with progress words of its own
     b = synth.sized_dag_batch([(600, 700), (1500, 900), (400, 2000), (1200, 1200), (800, 500), (2000, 700)], seed=21, extra_edge_p=0.05, skip_max=3)
     f = np.array([2, 3, 1, 2, 3, 1], np.uint8)
