@@ -1087,14 +1087,21 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             bool take_strip = false;
             uint32_t strip_log = 0, strip_S = 0, strip_n = 0, strip_g = 0, strip_limit = 0;
             std::vector<uint32_t> strip_far;
-            if (!take_sys && !g_no_strip && !g_force_general && n_rows >= 192 && cells >= 100000 && n_cols < (1u << 28)) {
-                const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];
-                const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
-                const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
+            // rows = the shorter graph; if ITS predecessors reach too far back for ghost rows (a long bubble) and the longer graph's do not, rows = the longer one
+            int strip_rows_side = sRow;
+            for (int attempt = 0; attempt < 2 && !take_strip; ++attempt) {
+                const int sR = attempt == 0 ? sRow : sCol, sC = 1 - sR;
+                const uint64_t nRw = (sR == 0 ? d.n1 : d.n2) + 1ull, nCl = sR == 0 ? d.n2 : d.n1;
+                if (take_sys || g_no_strip || g_force_general || nRw < 192 || cells < 100000 || nCl >= (1u << 28)) continue;
+                strip_rows_side = sR;
+                strip_far.clear();
+                const uint32_t* cp = P.poff[sC].data() + d.node_base[sC];
+                const uint8_t* cl = P.lab[sC].data() + d.node_base[sC];
+                const uint32_t* rp = P.poff[sR].data() + d.node_base[sR];
                 uint64_t max_deg = 0, gd = 0;
-                for (uint64_t j = 1; j <= n_cols; ++j) max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
-                for (uint64_t i = 1; i < n_rows; ++i)
-                    for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) gd = std::max<uint64_t>(gd, i - P.pidx[sRow][e]);
+                for (uint64_t j = 1; j <= nCl; ++j) max_deg = std::max<uint64_t>(max_deg, cp[j] - cp[j - 1]);
+                for (uint64_t i = 1; i < nRw; ++i)
+                    for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) gd = std::max<uint64_t>(gd, i - P.pidx[sR][e]);
                 // the near limit decides the ring depth (LDS per row) against the number of saved columns (LDS per row as well: a slot each): the candidate with
                 // the smallest footprint per row wins, as for the systolic kernel above
                 const uint64_t cw = npw == 1 ? 4 : 8;
@@ -1106,10 +1113,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     for (uint64_t limit : limits) {
                         cand.clear();
                         uint64_t nm = 0;
-                        for (uint64_t j = 1; j <= n_cols; ++j) {
+                        for (uint64_t j = 1; j <= nCl; ++j) {
                             for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
-                                const uint64_t dist = j - P.pidx[sCol][e];
-                                if (dist > limit) cand.push_back(P.pidx[sCol][e]); else nm = std::max(nm, dist);
+                                const uint64_t dist = j - P.pidx[sC][e];
+                                if (dist > limit) cand.push_back(P.pidx[sC][e]); else nm = std::max(nm, dist);
                             }
                             if (cl[j - 1] & 0x80) { if (j > limit) cand.push_back(0); else nm = std::max(nm, j); }
                         }
@@ -1117,21 +1124,21 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
                         if (cand.size() > 8) continue;
                         uint32_t l2 = 1;
-                        while ((1ull << l2) < span[sRow] + nm + 1 && l2 < 14) ++l2;
+                        while ((1ull << l2) < span[sR] + nm + 1 && l2 < 14) ++l2;
                         if (l2 > 6) break;   // (a larger limit only deepens the ring)
                         const uint64_t bytes = ((1ull << l2) * cw + (cw == 8 ? 4 : 8)) * 4 + cand.size() * cw * 4;
                         if (bytes < row_bytes) { row_bytes = bytes; lg = l2; strip_limit = (uint32_t)limit; strip_far = cand; }
                         if (cand.empty()) break;
                     }
                 }
-                if (lg <= 6 && span[sRow] <= 32 && gd <= 32 && max_deg <= 63) {
+                if (lg <= 6 && span[sR] <= 32 && gd <= 32 && max_deg <= 63) {
                     // the largest S (a multiple of 64, at most 768: 1 024 threads less the four ghost waves) whose rings and row lists fit
                     auto rec_ring_log = [&](uint64_t n_loc) { uint32_t l = 5; while ((1ull << l) < n_loc + 48) ++l; return l; };   // popoa_strip_kernel's record ring
                     auto strip_bytes = [&](uint64_t S) {
                         uint64_t worst = 0;
-                        for (uint64_t a = 0; a < n_rows; a += S) {
-                            const uint64_t hi = std::min(n_rows - 1, a + S - 1), lo = std::max<uint64_t>(a, 1);
-                            const uint64_t edges = hi >= lo ? rp[hi] - rp[lo - 1] : 0, n_loc = (a ? gd : 0) + std::min(S, n_rows - a);
+                        for (uint64_t a = 0; a < nRw; a += S) {
+                            const uint64_t hi = std::min(nRw - 1, a + S - 1), lo = std::max<uint64_t>(a, 1);
+                            const uint64_t edges = hi >= lo ? rp[hi] - rp[lo - 1] : 0, n_loc = (a ? gd : 0) + std::min(S, nRw - a);
                             worst = std::max<uint64_t>(worst, n_loc * row_bytes + ((uint64_t)16 << rec_ring_log(n_loc)) + edges * 4 + 64);
                         }
                         return worst;
@@ -1141,16 +1148,16 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     uint64_t S = rows_env ? rows_env : 256;   // (measured: a pair's duration hardly depends on the rows per strip between 64 and 768 — a step is a latency chain, not throughput — so strips are kept small: more of them run side by side and each leaves LDS for its neighbours)
                     while (S >= 64 && strip_bytes(S) > kSysLdsBytes) S -= 64;
                     if (S >= 64) {
-                        const uint64_t n = (n_rows + S - 1) / S;
-                        const uint64_t even = ((n_rows + n - 1) / n + 63) / 64 * 64;   // the rows dealt evenly
+                        const uint64_t n = (nRw + S - 1) / S;
+                        const uint64_t even = ((nRw + n - 1) / n + 63) / 64 * 64;   // the rows dealt evenly
                         if (even <= S && strip_bytes(even) <= kSysLdsBytes) S = even;
-                        strip_S = (uint32_t)S; strip_n = (uint32_t)((n_rows + S - 1) / S); strip_g = (uint32_t)gd; strip_log = lg;
+                        strip_S = (uint32_t)S; strip_n = (uint32_t)((nRw + S - 1) / S); strip_g = (uint32_t)gd; strip_log = lg;
                         take_strip = strip_n <= 200;   // (all strips of a pair must be resident together: one workgroup per compute unit)
                     }
                 }
                 if (take_strip) {
                     const uint32_t rec_base = (uint32_t)P.strip_recs.size();
-                    for (uint64_t j = 1; j <= n_cols; ++j) {
+                    for (uint64_t j = 1; j <= nCl; ++j) {
                         const uint32_t b0 = cp[j - 1], deg = cp[j] - cp[j - 1], l = cl[j - 1], src = l >> 7, nq = deg + src;
                         // a predecessor column as a code: that many columns back (below 0x80: inside the ring), or 0x80 | its slot among the saved columns
                         auto code = [&](uint32_t q) -> uint32_t {
@@ -1160,7 +1167,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         uint32_t x = 0;
                         if (nq >= 1 && nq <= 3) {   // the straight-line cell's three predecessors (8 bits each)
                             uint32_t q[3], nl = 0;
-                            for (uint32_t f = 0; f < deg; ++f) q[nl++] = P.pidx[sCol][b0 + f];
+                            for (uint32_t f = 0; f < deg; ++f) q[nl++] = P.pidx[sC][b0 + f];
                             if (src) q[nl++] = 0u;
                             for (; nl < 3; ++nl) q[nl] = q[0];
                             x = code(q[0]) | (code(q[1]) << 8) | (code(q[2]) << 16);
@@ -1169,7 +1176,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         // cell does not apply — the fifth and sixth); longer lists are read from HBM
                         const bool fast = nq >= 1 && nq <= 3, inl = deg <= 6;
                         uint32_t dist[6] = {0, 0, 0, 0, 0, 0};
-                        for (uint32_t f = 0; f < deg && f < 6; ++f) dist[f] = code(P.pidx[sCol][b0 + f]);
+                        for (uint32_t f = 0; f < deg && f < 6; ++f) dist[f] = code(P.pidx[sC][b0 + f]);
                         if (!fast && inl) x = dist[4] | (dist[5] << 12);
                         // bit 15: this column is itself a saved one, bits 12-14: in that slot
                         const auto self = std::lower_bound(strip_far.begin(), strip_far.end(), (uint32_t)j);
@@ -1177,14 +1184,14 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         P.strip_recs.push_back(make_uint4(x, keep | (inl ? 1u << 16 : 0u) | (deg << 17) | (fast ? 1u << 23 : 0u) | ((l & 0x7Fu) << 24) | (src << 31),
                                                           dist[0] | (dist[1] << 12), dist[2] | (dist[3] << 12)));
                     }
-                    const uint64_t hand_per = (uint64_t)strip_g * (n_cols + 1) * (cw / 2);
+                    const uint64_t hand_per = (uint64_t)strip_g * (nCl + 1) * (cw / 2);
                     for (uint32_t j = 0; j < strip_n; ++j) {
                         ClStripDesc sd{};
                         const uint64_t a = (uint64_t)j * strip_S;
                         sd.prob = (uint32_t)P.desc.size();
                         sd.n_ghost = j ? strip_g : 0;
                         sd.row_base = (uint32_t)(a - sd.n_ghost);
-                        sd.n_real = (uint32_t)std::min<uint64_t>(strip_S, n_rows - a);
+                        sd.n_real = (uint32_t)std::min<uint64_t>(strip_S, nRw - a);
                         sd.n_out = j + 1 < strip_n ? strip_g : 0;
                         sd.rec_base = rec_base;
                         sd.hand_in = P.hand_words + (j ? (uint64_t)(j - 1) * hand_per : 0);
@@ -1194,13 +1201,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         uint32_t lrw = 5;
                         while ((1ull << lrw) < (uint64_t)sd.n_ghost + sd.n_real + 48) ++lrw;
                         sd.logRW = lrw;
-                        const uint64_t hi = std::min<uint64_t>(n_rows - 1, a + strip_S - 1), lo = std::max<uint64_t>(a, 1);
+                        const uint64_t hi = std::min<uint64_t>(nRw - 1, a + strip_S - 1), lo = std::max<uint64_t>(a, 1);
                         P.strip_lds.push_back((uint32_t)(((uint64_t)sd.n_ghost + sd.n_real) * row_bytes + (16ull << lrw) + (hi >= lo ? rp[hi] - rp[lo - 1] : 0) * 4 + 64));
                         P.strips.push_back(sd);
                     }
                     P.hand_words += (uint64_t)(strip_n - 1) * hand_per;
                 }
-            }
+                        }
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
             if (take_sys) {
@@ -1213,7 +1220,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 P.ring_need.push_back((uint32_t)sys_bytes);
             } else if (take_strip) {
                 d.kind = CL_KIND_STRIP;
-                d.pad = (uint16_t)(strip_log | (d.n2 < d.n1 ? 0x8000u : 0u));
+                d.pad = (uint16_t)(strip_log | (strip_rows_side == 1 ? 0x8000u : 0u));   // bit 15: the rows are graph 2
                 d.aux_base = (uint32_t)P.sys_aux.size();   // {near limit, the saved columns ascending}, as for the systolic kernel
                 d.aux_cnt = (uint32_t)strip_far.size();
                 P.sys_aux.push_back(strip_limit);

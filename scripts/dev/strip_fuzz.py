@@ -27,7 +27,7 @@ for case in range(n_cases):
     kw = dict(extra_edge_p=float(rng.choice([0.0, 0.02, 0.1, 0.3])), skip_max=int(rng.choice([1, 2, 4, 8, 20, 40, 62])), n_alt=int(rng.integers(0, 4)),
               alphabet=int(rng.integers(2, 5)))
     if rng.random() < 0.35:   # far forks on the longer side: saved columns
-        sizes = [(min(a, b2), max(a, b2) + 1) for a, b2 in sizes]
+        sizes = [(min(a, b2), max(a, b2) + 1) if rng.random() < 0.6 else (max(a, b2) + 1, min(a, b2)) for a, b2 in sizes]
         kw = dict(n_far=int(rng.integers(1, 10)), far_min=int(rng.choice([70, 200, 600])), far_max=2000)
         b = synth.far_fork_batch(sizes, seed=int(rng.integers(0, 1 << 30)), **kw)
     else:

@@ -244,6 +244,12 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
         plan.destroy()
         got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+    # the far forks in the SHORTER graph: its predecessors reach too far back for ghost rows, so the longer graph gives the rows and the shorter one the columns
+    b = synth.far_fork_batch([(2500, 1200), (3000, 900), (1500, 1400)], seed=91, n_far=3)
+    plan = gpu_ctx.plan(b)
+    assert all(li["kernel"].startswith("popoa_strip_kernel") for li in plan.launches()), plan.launches()
+    plan.destroy()
+    assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
     # pairs of different NumPW in one plan: their strip launches run side by side on different streams, each with progress words of its own
     b = synth.sized_dag_batch([(600, 700), (1500, 900), (400, 2000), (1200, 1200), (800, 500), (2000, 700)], seed=21, extra_edge_p=0.05, skip_max=3)
     f = np.array([2, 3, 1, 2, 3, 1], np.uint8)
