@@ -73,10 +73,14 @@ void big_release(void* h) noexcept {
     BigHeader* hd = static_cast<BigHeader*>(h);
     if (hd->map) (void)munmap(hd->map, hd->map_bytes); else free(h);
 }
+// (over all threads of the process the caches keep at most kBigCacheProcessCap: MSA workers and pool threads each have one, and a thread that has
+// cached its share after one large merge may never need it again)
+constexpr size_t kBigCacheProcessCap = 24ull << 30;
+std::atomic<size_t> g_big_cached{0};
 struct BigCache {
     std::multimap<size_t, void*> free_blocks;   // capacity -> header
     size_t bytes = 0;
-    ~BigCache() { for (auto& b : free_blocks) big_release(b.second); }
+    ~BigCache() { for (auto& b : free_blocks) { g_big_cached -= b.first; big_release(b.second); } }
 };
 thread_local BigCache t_big_cache;
 }
@@ -95,6 +99,7 @@ static void* big_alloc_raw(size_t bytes) {
         if (it != t_big_cache.free_blocks.end() && it->first <= 2 * bytes) {
             void* h = it->second;
             t_big_cache.bytes -= it->first;
+            g_big_cached -= it->first;
             t_big_cache.free_blocks.erase(it);
             return static_cast<char*>(h) + 64;
         }
@@ -122,8 +127,8 @@ void cl_big_free(void* p) noexcept {
     if (!p) return;
     void* h = static_cast<char*>(p) - 64;
     const size_t cap = static_cast<BigHeader*>(h)->capacity;
-    if (cap >= kBigMin && t_big_cache.bytes + cap <= kBigCacheCap) {
-        try { t_big_cache.free_blocks.emplace(cap, h); t_big_cache.bytes += cap; return; } catch (...) {}
+    if (cap >= kBigMin && t_big_cache.bytes + cap <= kBigCacheCap && g_big_cached.load(std::memory_order_relaxed) + cap <= kBigCacheProcessCap) {
+        try { t_big_cache.free_blocks.emplace(cap, h); t_big_cache.bytes += cap; g_big_cached += cap; return; } catch (...) {}
     }
     big_release(h);
 }
