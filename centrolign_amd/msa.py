@@ -51,7 +51,7 @@ def emit_subproblem(prefix, graph, paths):
 
 
 def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count=3000, workers=1, make_context=None, verbose=False,
-                    keep_merges=False, subproblems_prefix=None, restart=False, devices=None):
+                    keep_merges=False, subproblems_prefix=None, restart=False, devices=None, calibration_contexts=None):
     """sequences: {name: str}.  Returns dict(root BaseGraph, paths [names in path order], alignment of the root merge, scale,
     scales, stats).  workers > 1: independent pieces of the job (the leaf calibrations; sibling merges of the guide tree) run
     side by side on one device, each worker thread with its own cl_context (the library calls release the GIL): one
@@ -75,7 +75,7 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
     stats = dict(match_ms=0.0, align_ms=0.0, fuse_ms=0.0, merges=0)
     last = {}
 
-    def in_parallel(jobs):
+    def in_parallel(jobs, contexts=contexts):
         """jobs: list of callables taking a context; results in order"""
         if len(contexts) == 1 or len(jobs) <= 1:
             return [job(contexts[0]) for job in jobs]
@@ -96,8 +96,26 @@ def progressive_msa(ctx, sequences, tree, max_num_match_pairs=1250000, max_count
 
     stats["timeline_s"] = [("leaf graphs done", _time.perf_counter() - _t0)]
     try:
-        scales = in_parallel([lambda c, nm=nm: c.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
-                              for nm in order])
+        # the calibrations are as many independent jobs as there are leaves and every merge waits for the mean of ALL scales; calibration_contexts = n gives
+        # them up to n contexts of their own for the duration instead of the merge workers'.  Off by default — measured (10 x 1 Mbp, four merge workers,
+        # scripts/dev/msa_calib_ab.py): the ten calibrations are done after 1.25 s on the four workers' contexts, after 1.26-1.38 s on eight, 1.56 s on ten:
+        # what they queue up for is not contexts (launches of many queues side by side slow one another)
+        calib = contexts
+        extra = []
+        if len(contexts) > 1 and len(order) > len(contexts) and calibration_contexts:
+            want = min(len(order), int(calibration_contexts))
+            try:
+                extra = [make_context() for _ in range(max(0, want - len(contexts)))]
+            except Exception:   # noqa: BLE001 (no more contexts to be had: the merge workers' ones do)
+                extra = []
+            calib = contexts + extra
+        try:
+            scales = in_parallel([lambda c, nm=nm: c.leaf_intrinsic_scale(leaves[nm], max_count=max_count, max_num_match_pairs=max_num_match_pairs)
+                                  for nm in order], calib)
+        finally:
+            for c in extra:
+                if hasattr(c, "close"):
+                    c.close()
         scale = sum(scales) / len(scales)                    # ScoreFunction::score_scale (src/core.cpp:169-184)
         stats["timeline_s"].append(("calibrations done", _time.perf_counter() - _t0))
 
