@@ -42,6 +42,19 @@ struct DiagGeom {
 
 __device__ __forceinline__ int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 
+// a plane pointer every lane holds the same value of (derived from a workgroup's problem descriptor), moved to scalar registers and kept in the GLOBAL
+// address space: stores through it take the "scalar base + 32-bit vector offset" form instead of a 64-bit vector add each (a generic pointer would make
+// them flat stores, which wait on two counters)
+typedef __attribute__((address_space(1))) int32_t g_i32;
+__device__ __forceinline__ void plane_store(g_i32* base, uint32_t byte_off, int32_t v) {   // byte_off < 2^32: a matrix has fewer than 2^30 cells
+    *reinterpret_cast<g_i32*>(reinterpret_cast<__attribute__((address_space(1))) char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ g_i32* uniform_plane(int32_t* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (g_i32*)(((uint64_t)hi << 32) | lo);
+}
+
 template <int NPW>
 struct Planes {
     int32_t* base;
@@ -766,6 +779,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
         rp0 = plR[firstR];
         rp1 = degR == 2 ? plR[firstR + 1] : (srcR ? 0u : rp0);
     }
+    const uint32_t rp0_rs = rp0 * row_stride, rp1_rs = rp1 * row_stride, r_rs = r * row_stride, rp0_cw = rp0 * CW, rp1_cw = rp1 * CW, r_cw = r * CW;
     __syncthreads();
     const uint32_t last = nR + nC;
     uint32_t off = 0;   // G.off(t): cells on the anti-diagonals before t
@@ -799,6 +813,16 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     int32_t* const my_row = ring + r * row_stride;
     int32_t* const plane0 = pl.M();
     const size_t plane_stride = pl.cells;
+    // the planes in graph-1 / graph-2 terms (I consumes a graph-1 node, D a graph-2 node): which of them take the row gaps and which the column gaps is the
+    // same for the whole launch, so the pointers are chosen once and a store is a uniform base plus one 32-bit index
+    g_i32* pV[NPW];
+    g_i32* pH[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        pV[k] = uniform_plane(plane0 + (size_t)(swap ? 1 + NPW + k : 1 + k) * plane_stride);
+        pH[k] = uniform_plane(plane0 + (size_t)(swap ? 1 + k : 1 + NPW + k) * plane_stride);
+    }
+    g_i32* const pM = uniform_plane(plane0);
     for (; t <= last; ++t) {
         const uint32_t lo_d = G.lo(t), cnt_d = G.hi(t) - lo_d + 1;
         if (r <= nR && t >= r && t - r <= nC) {
@@ -817,19 +841,20 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
             if (c && fastC && fastR) {
                 // the usual cell, straight-line: two predecessors per side (the second may repeat the first), eight independent LDS reads
                 // at addresses that are selects and multiply-adds of the column record
+                // (round 4: the row parts of the addresses are per-thread constants selected by the code's flag — six quarter-rate 32-bit multiplies and two
+                // 64-bit multiply-adds per step before — and the slot offset is a 24-bit multiply)
                 const uint32_t e0 = rc.x & 0xFFFu, e1 = (rc.x >> 12) & 0xFFFu;
                 const bool f0 = e0 & 0x800u, f1 = e1 & 0x800u;
-                const uint32_t o0 = f0 ? saved_off + (e0 & 0x7FFu) * slot_stride : ((c - e0) & hm) * CW;
-                const uint32_t o1 = f1 ? saved_off + (e1 & 0x7FFu) * slot_stride : ((c - e1) & hm) * CW;
-                const uint32_t s0 = f0 ? (uint32_t)CW : row_stride, s1 = f1 ? (uint32_t)CW : row_stride;
+                const uint32_t o0 = f0 ? saved_off + __umul24(e0 & 0x7FFu, slot_stride) : ((c - e0) & hm) * CW;
+                const uint32_t o1 = f1 ? saved_off + __umul24(e1 & 0x7FFu, slot_stride) : ((c - e1) & hm) * CW;
                 const uint32_t oc = (c & hm) * CW;
                 int32_t mv0, mv1, mh0, mh1, vv0[NPW], vv1[NPW], hh0[NPW], hh1[NPW];
-                get_mv(ring + (rp0 * row_stride + oc), mv0, vv0);
-                get_mv(ring + (rp1 * row_stride + oc), mv1, vv1);
-                get_mh(ring + (o0 + r * s0), mh0, hh0);
-                get_mh(ring + (o1 + r * s1), mh1, hh1);
-                const int32_t d00 = ring[o0 + rp0 * s0], d01 = ring[o1 + rp0 * s1];
-                const int32_t d10 = ring[o0 + rp1 * s0], d11 = ring[o1 + rp1 * s1];
+                get_mv(ring + (rp0_rs + oc), mv0, vv0);
+                get_mv(ring + (rp1_rs + oc), mv1, vv1);
+                get_mh(ring + (o0 + (f0 ? r_cw : r_rs)), mh0, hh0);
+                get_mh(ring + (o1 + (f1 ? r_cw : r_rs)), mh1, hh1);
+                const int32_t d00 = ring[o0 + (f0 ? rp0_cw : rp0_rs)], d01 = ring[o1 + (f1 ? rp0_cw : rp0_rs)];
+                const int32_t d10 = ring[o0 + (f0 ? rp1_cw : rp1_rs)], d11 = ring[o1 + (f1 ? rp1_cw : rp1_rs)];
                 M = imax(imax(d00, d01), imax(d10, d11)) + ((labR == labC) ? P.match : -P.mismatch);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) {
@@ -916,15 +941,15 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
                 sw[0] = w0;
                 if (NPW > 1) sw[1] = w1;
             }
-            // the planes in graph-1 / graph-2 terms: I consumes a graph-1 node, D a graph-2 node
-            int32_t* dst = plane0 + (off + ((swap ? c : r) - lo_d));
+            const uint32_t pidx = off + ((swap ? c : r) - lo_d);
             if (!(B.skip_traceback & 2)) {
-            dst[0] = M;
+                const uint32_t pb = pidx * 4u;
+                plane_store(pM, pb, M);
 #pragma unroll
-            for (int k = 0; k < NPW; ++k) {
-                dst[(size_t)(1 + k) * plane_stride] = swap ? Hh[k] : V[k];
-                dst[(size_t)(1 + NPW + k) * plane_stride] = swap ? V[k] : Hh[k];
-            }
+                for (int k = 0; k < NPW; ++k) {
+                    plane_store(pV[k], pb, V[k]);
+                    plane_store(pH[k], pb, Hh[k]);
+                }
             }
         }
         off += cnt_d;
@@ -1027,10 +1052,14 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
         rp1 = degR >= 2 ? plR[firstR + 1] : (srcR ? 0u : rp0);
         rp2 = degR == 3 ? plR[firstR + 2] : (degR == 2 && srcR ? 0u : rp0);
     }
+    const uint32_t rp_rs[3] = {rp0 * row_stride, rp1 * row_stride, rp2 * row_stride}, rp_cw[3] = {rp0 * CW, rp1 * CW, rp2 * CW}, L_rs = L * row_stride, L_cw = L * CW;
     // predecessor f of column c: up to six distances ride in the record (z, w: twelve bits each, in list order), longer lists stay in HBM
-    auto col_pred = [&](const uint4& rc, uint32_t c, uint32_t fc, uint32_t f) -> uint32_t {
-        if (!((rc.y >> 16) & 1u)) return pidxC[fc + f];
-        const uint32_t word = f < 2 ? rc.z : (f < 4 ? rc.w : rc.x);
+    // (the record's words are passed one by one: a reference to the uint4 made the compiler index it in scratch memory — a scratch store and several loads per step)
+    auto col_pred4 = [&](uint32_t rx, uint32_t ry, uint32_t rz, uint32_t rw, uint32_t c, uint32_t fc, uint32_t f) -> uint32_t {
+        if (!((ry >> 16) & 1u)) return pidxC[fc + f];
+        uint32_t word = rz;
+        word = f >= 2 ? rw : word;
+        word = f >= 4 ? rx : word;
         const uint32_t e = (word >> (12 * (f & 1u))) & 0xFFFu;
         return (e & 0x80u) ? saved_col[e & 0x7Fu] : c - e;      // bit 7: saved column number (low bits), else that many columns back
     };
@@ -1045,8 +1074,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     auto slot_of = [&](uint32_t col) { uint32_t s2 = 0; while (s2 + 1 < K && saved_col[s2] != col) ++s2; return s2; };
     // where cell (row with timing index row_l, column col) lives at step t: in the row's ring while that row has not moved H columns past col, else in the
     // saved area (the host saved every column that is read from further away)
-    uint32_t t = 0;
-    auto cell_at = [&](uint32_t row_l, uint32_t col) -> const int32_t* {
+    auto cell_at_t = [&](uint32_t t, uint32_t row_l, uint32_t col) -> const int32_t* {
         if (t - row_l - col < H) return ring + (row_l * row_stride + (col & hm) * CW);
         return saved + (slot_of(col) * n_loc + row_l) * CW;
     };
@@ -1068,17 +1096,23 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     int32_t* const my_row = ring + L * row_stride;
     int32_t* const plane0 = pl.M();
     const size_t plane_stride = pl.cells;
+    g_i32* pV[NPW];
+    g_i32* pH[NPW];   // (see popoa_sys_kernel: the planes that take the row gaps / the column gaps, chosen once; scalar base + 32-bit offset per store)
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        pV[k] = uniform_plane(plane0 + (size_t)(swap ? 1 + NPW + k : 1 + k) * plane_stride);
+        pH[k] = uniform_plane(plane0 + (size_t)(swap ? 1 + k : 1 + NPW + k) * plane_stride);
+    }
+    g_i32* const pM = uniform_plane(plane0);
     const uint32_t last = n_loc - 1 + nC;
     uint32_t off = G.off(sd.row_base);   // cells on the anti-diagonals before the one of step t (anti-diagonal row_base + t)
     // ---- ghost rows: the hand-off pipeline ----
-    unsigned long long st[WW];
-#pragma unroll
-    for (int w = 0; w < WW; ++w) st[w] = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;   // (scalars, not an array passed by reference: that one lived in scratch memory)
     const unsigned long long* const hin = SD.handoff + sd.hand_in + (size_t)gi * (nC + 1) * WW;
     uint32_t* const prog_in = SD.progress + (sd.prog - 1);   // the strip in front (ghost lanes only: strip > 0)
     uint32_t avail = 0, avail_next = 0;                       // columns of the incoming rows known to be complete; the word as asked for at the last active step
     bool failed = false;
-    auto fetch = [&](uint32_t col, unsigned long long (&dst)[WW]) {
+    auto fetch = [&](uint32_t col) {
         if (col >= avail) {
             unsigned spins = 0;
             while (true) {
@@ -1089,16 +1123,22 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             }
             if (avail == kStripFailed) failed = true;
         }
-#pragma unroll
-        for (int w = 0; w < WW; ++w) dst[w] = __hip_atomic_load(hin + (size_t)col * WW + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long* src = hin + (size_t)col * WW;
+        st0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (WW > 2) {
+            st2 = __hip_atomic_load(src + (WW > 2 ? 2 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st3 = __hip_atomic_load(src + (WW > 2 ? 3 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
-    if (is_ghost && live && gw >= L && gw - L <= nC) fetch(gw - L, st);   // what this lane delivers at its first step, t = gw
+    if (is_ghost && live && gw >= L && gw - L <= nC) fetch(gw - L);   // what this lane delivers at its first step, t = gw
     // ---- wave 0, lanes 0-15: the column records, sixteen at a time (asked for at t = 0 (mod 16), stored four steps later) ----
     uint4 rec_reg = make_uint4(0, 0, 0, 0);
     uint32_t rec_col = 0;   // column whose record rec_reg holds (0: none)
     const uint32_t out_first = S - sd.n_out;   // computing rows from here on are handed to the next strip
     unsigned long long* const hout = SD.handoff + sd.hand_out;
-    for (t = 0; t <= last; ++t) {
+    for (uint32_t t = 0; t <= last; ++t) {
+        auto cell_at = [&](uint32_t row_l, uint32_t col) -> const int32_t* { return cell_at_t(t, row_l, col); };
         const uint32_t d = sd.row_base + t;
         const uint32_t lo_d = G.lo(d), cnt_d = G.hi(d) - lo_d + 1;
         if (is_ghost) {
@@ -1106,8 +1146,8 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 if (t >= L && t - L <= nC) {
                     const uint32_t c = t - L;
                     int4* w = reinterpret_cast<int4*>(my_row + (c & hm) * CW);
-                    w[0] = make_int4((int)(unsigned)st[0], (int)(unsigned)(st[0] >> 32), (int)(unsigned)st[1], (int)(unsigned)(st[1] >> 32));
-                    if (NPW > 1) w[1] = make_int4((int)(unsigned)st[WW - 2], (int)(unsigned)(st[WW - 2] >> 32), (int)(unsigned)st[WW - 1], (int)(unsigned)(st[WW - 1] >> 32));
+                    w[0] = make_int4((int)(unsigned)st0, (int)(unsigned)(st0 >> 32), (int)(unsigned)st1, (int)(unsigned)(st1 >> 32));
+                    if (NPW > 1) w[1] = make_int4((int)(unsigned)st2, (int)(unsigned)(st2 >> 32), (int)(unsigned)st3, (int)(unsigned)(st3 >> 32));
                     if (K) {   // a saved column keeps its cells of the ghost rows too
                         const uint32_t ky = c ? rec_ring[(c - 1) & rmask].y : (save_col0 ? 0x8000u : 0u);
                         if (ky & 0x8000u) {
@@ -1122,7 +1162,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 if (avail_next == kStripFailed) failed = true;
                 avail = avail_next > avail ? avail_next : avail;
                 const uint32_t tn = t + GW;
-                if (tn >= L && tn - L <= nC) fetch(tn - L, st);
+                if (tn >= L && tn - L <= nC) fetch(tn - L);
                 avail_next = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (gw == 0 && gi < 16 && (t & (GW - 1)) == 0) {
@@ -1143,21 +1183,21 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 const uint32_t e0 = rc.x & 0xFFu, e1 = (rc.x >> 8) & 0xFFu, e2 = (rc.x >> 16) & 0xFFu;
                 // bit 7 of a predecessor code: saved column number (low bits) instead of a distance — a cell of row x then sits at saved_off + slot * slot_stride + x * CW
                 const bool f0 = e0 & 0x80u, f1 = e1 & 0x80u, f2 = e2 & 0x80u;
-                const uint32_t o0 = f0 ? saved_off + (e0 & 0x7Fu) * slot_stride : ((c - e0) & hm) * CW;
-                const uint32_t o1 = f1 ? saved_off + (e1 & 0x7Fu) * slot_stride : ((c - e1) & hm) * CW;
-                const uint32_t o2 = f2 ? saved_off + (e2 & 0x7Fu) * slot_stride : ((c - e2) & hm) * CW, oc = (c & hm) * CW;
-                const uint32_t s0 = f0 ? (uint32_t)CW : row_stride, s1 = f1 ? (uint32_t)CW : row_stride, s2 = f2 ? (uint32_t)CW : row_stride;
-                const uint32_t b0 = rp0 * row_stride, b1 = rp1 * row_stride, b2 = rp2 * row_stride;
+                const uint32_t o0 = f0 ? saved_off + __umul24(e0 & 0x7Fu, slot_stride) : ((c - e0) & hm) * CW;
+                const uint32_t o1 = f1 ? saved_off + __umul24(e1 & 0x7Fu, slot_stride) : ((c - e1) & hm) * CW;
+                const uint32_t o2 = f2 ? saved_off + __umul24(e2 & 0x7Fu, slot_stride) : ((c - e2) & hm) * CW, oc = (c & hm) * CW;
+                const uint32_t b0 = rp_rs[0], b1 = rp_rs[1], b2 = rp_rs[2];
                 int32_t mv0, mv1, mv2, mh0, mh1, mh2, vv0[NPW], vv1[NPW], vv2[NPW], hh0[NPW], hh1[NPW], hh2[NPW];
                 get_mv(ring + (b0 + oc), mv0, vv0);
                 get_mv(ring + (b1 + oc), mv1, vv1);
                 get_mv(ring + (b2 + oc), mv2, vv2);
-                get_mh(ring + (o0 + L * s0), mh0, hh0);
-                get_mh(ring + (o1 + L * s1), mh1, hh1);
-                get_mh(ring + (o2 + L * s2), mh2, hh2);
-                const int32_t d00 = ring[o0 + rp0 * s0], d01 = ring[o1 + rp0 * s1], d02 = ring[o2 + rp0 * s2];
-                const int32_t d10 = ring[o0 + rp1 * s0], d11 = ring[o1 + rp1 * s1], d12 = ring[o2 + rp1 * s2];
-                const int32_t d20 = ring[o0 + rp2 * s0], d21 = ring[o1 + rp2 * s1], d22 = ring[o2 + rp2 * s2];
+                // (the row parts of the addresses are per-thread constants selected by the code's flag: no multiplies in the step)
+                get_mh(ring + (o0 + (f0 ? L_cw : L_rs)), mh0, hh0);
+                get_mh(ring + (o1 + (f1 ? L_cw : L_rs)), mh1, hh1);
+                get_mh(ring + (o2 + (f2 ? L_cw : L_rs)), mh2, hh2);
+                const int32_t d00 = ring[o0 + (f0 ? rp_cw[0] : rp_rs[0])], d01 = ring[o1 + (f1 ? rp_cw[0] : rp_rs[0])], d02 = ring[o2 + (f2 ? rp_cw[0] : rp_rs[0])];
+                const int32_t d10 = ring[o0 + (f0 ? rp_cw[1] : rp_rs[1])], d11 = ring[o1 + (f1 ? rp_cw[1] : rp_rs[1])], d12 = ring[o2 + (f2 ? rp_cw[1] : rp_rs[1])];
+                const int32_t d20 = ring[o0 + (f0 ? rp_cw[2] : rp_rs[2])], d21 = ring[o1 + (f1 ? rp_cw[2] : rp_rs[2])], d22 = ring[o2 + (f2 ? rp_cw[2] : rp_rs[2])];
                 M = imax(imax(imax(imax(d00, d01), imax(d10, d11)), imax(imax(d02, d12), imax(d20, d21))), d22) + ((labR == labC) ? P.match : -P.mismatch);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) {
@@ -1184,7 +1224,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 const uint32_t fc = inlineC ? 0u : poffC[c - 1];
                 for (uint32_t f = 0; f < degC; ++f) {
                     int32_t m, hh[NPW];
-                    get_mh(cell_at(0, col_pred(rc, c, fc, f)), m, hh);
+                    get_mh(cell_at(0, col_pred4(rc.x, rc.y, rc.z, rc.w, c, fc, f)), m, hh);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], hh[k] - P.ext[k]);
                 }
@@ -1210,7 +1250,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 const int32_t sc = (labR == labC) ? P.match : -P.mismatch;
                 const uint32_t fc = inlineC ? 0u : poffC[c - 1];
                 for (uint32_t f = 0; f < degC; ++f) {
-                    const uint32_t q = col_pred(rc, c, fc, f);
+                    const uint32_t q = col_pred4(rc.x, rc.y, rc.z, rc.w, c, fc, f);
                     int32_t m, hh[NPW];
                     get_mh(cell_at(L, q), m, hh);
                     const int32_t d0 = degR ? cell_at(rpl[0], q)[0] : CL_NEG_INF, d1 = degR ? cell_at(rpl[1], q)[0] : CL_NEG_INF;
@@ -1242,7 +1282,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                 const int32_t sc = (labR == labC) ? P.match : -P.mismatch;
                 const uint32_t fc = inlineC ? 0u : poffC[c - 1];
                 for (uint32_t f = 0; f < degC; ++f) {
-                    const uint32_t q = col_pred(rc, c, fc, f);
+                    const uint32_t q = col_pred4(rc.x, rc.y, rc.z, rc.w, c, fc, f);
                     int32_t m, hh[NPW];
                     get_mh(cell_at(L, q), m, hh);
 #pragma unroll
@@ -1281,13 +1321,13 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
                     __hip_atomic_store(dst + WW - 1, (unsigned long long)(unsigned)w1.z | ((unsigned long long)(unsigned)w1.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            int32_t* dstp = plane0 + (off + ((swap ? c : r) - lo_d));
             if (!(B.skip_traceback & 2)) {
-                dstp[0] = M;
+                const uint32_t pb = (off + ((swap ? c : r) - lo_d)) * 4u;
+                plane_store(pM, pb, M);
 #pragma unroll
                 for (int k = 0; k < NPW; ++k) {
-                    dstp[(size_t)(1 + k) * plane_stride] = swap ? Hh[k] : V[k];
-                    dstp[(size_t)(1 + NPW + k) * plane_stride] = swap ? V[k] : Hh[k];
+                    plane_store(pV[k], pb, V[k]);
+                    plane_store(pH[k], pb, Hh[k]);
                 }
             }
             // the last row of the strip has finished column c: every hand-off row (all of them lanes of this wave, and ahead of this one) has too
