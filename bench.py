@@ -314,11 +314,32 @@ def main():
                                               workers=args.workers, share_merges=args.share_merges)
     msa_wall = time.perf_counter() - t0
     msa_wall = cd.max_over_ranks(msa_wall, dist, device="cpu" if share else "cuda")
-    kept = res["stats"].get("kept", []) if res is not None and "stats" in res else []
     gfa_sha = gfa_bytes = None
     if rank == 0:
         gfa = capi.write_gfa(res["root"], res["paths"])
         gfa_sha, gfa_bytes = hashlib.sha256(gfa).hexdigest(), len(gfa)
+    merge_groups_retry = None
+    if world > 1 and args.share_merges > 1 and args.length == 1000000:
+        # merge groups (one merge over several GPUs through peer stores) have only ever run between processes on ONE device here: if the GFA they give is not
+        # the reference's, the MSA is run again with one rank per merge and the line says so — a wrong multi-GPU result is never timed
+        want = None
+        try:
+            with open(os.path.join(HERE, "tests", "golden", "c3_10x1M_subproblems.json")) as f:
+                want = json.load(f)["root_default_budget_reference"]["sha256"]
+        except Exception:   # noqa: BLE001
+            pass
+        flag = torch.tensor([1 if (rank != 0 or want is None or gfa_sha == want) else 0], dtype=torch.int32)
+        dist.broadcast(flag, 0, group=host_group)
+        if int(flag.item()) == 0:
+            merge_groups_retry = {"first_gfa_sha256": gfa_sha, "first_msa_wall_s": msa_wall}
+            barrier()
+            t0 = time.perf_counter()
+            res = msa.progressive_msa_distributed(ctx, seqs, tree, dist, rank, world, group=host_group, keep_merges=True, all_ranks=True, workers=args.workers, share_merges=0)
+            msa_wall = cd.max_over_ranks(time.perf_counter() - t0, dist, device="cpu" if share else "cuda")
+            if rank == 0:
+                gfa = capi.write_gfa(res["root"], res["paths"])
+                gfa_sha, gfa_bytes = hashlib.sha256(gfa).hexdigest(), len(gfa)
+    kept = res["stats"].get("kept", []) if res is not None and "stats" in res else []
 
     # ---- 2. the stitch batches of this rank's merges, resident in HBM ----------------------------------------------------------
     batches = stitch_batches(kept)
@@ -469,6 +490,7 @@ def main():
                        "stitch_sharding": stitch_sharding,
                        "workspace_bytes": int(sum(st.get("workspace_bytes", 0) for st in stats)),
                        "merge_groups": None if world == 1 else (res["stats"].get("merge_groups") if res is not None and "stats" in res else None),
+                       "merge_groups_retry": merge_groups_retry,
                        # rank 0's share of the merges that ran as groups: chaining DPs shared, far launches on its combinations, macro-blocks whose other combinations came from the other members
                        "merge_group_stats": None if world == 1 else dict(ctx.peer_stats(), shared_merges=res["stats"].get("shared_merges", 0) if res is not None and "stats" in res else 0),
                        "parallelism": "1 GPU, %d worker contexts in the MSA" % args.workers if world == 1 else
