@@ -328,7 +328,8 @@ def main():
                 want = json.load(f)["root_default_budget_reference"]["sha256"]
         except Exception:   # noqa: BLE001
             pass
-        flag = torch.tensor([1 if (rank != 0 or want is None or gfa_sha == want) else 0], dtype=torch.int32)
+        force = os.environ.get("CL_BENCH_FORCE_RETRY") == "1"   # test hook: behave as if the first GFA had been wrong
+        flag = torch.tensor([1 if (rank != 0 or want is None or (gfa_sha == want and not force)) else 0], dtype=torch.int32)
         dist.broadcast(flag, 0, group=host_group)
         if int(flag.item()) == 0:
             merge_groups_retry = {"first_gfa_sha256": gfa_sha, "first_msa_wall_s": msa_wall}
