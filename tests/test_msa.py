@@ -123,6 +123,25 @@ def test_gpu_cl_msa_with_the_sparse_chaining_algorithm(gpu_ctx, case):
 
 
 @pytest.mark.gpu
+def test_gpu_context_memory_statistics():
+    """cl_context_memory: what a context's calls hold, held at most and keep cached, beside hipMemGetInfo's numbers"""
+    from centrolign_amd import capi
+    ctx = capi.Context(0)
+    try:
+        m0 = ctx.memory_stats()
+        assert m0["device_total_bytes"] > 200e9 and m0["device_free_bytes"] <= m0["device_total_bytes"] and m0["peak_bytes"] >= m0["live_bytes"]
+        seqs = synth.hor_sequences(5, 60000, 2)
+        g = [capi.leaf_graph(x) for x in seqs]
+        ctx.merge(g[0], g[1], score_scale=1.0, max_num_match_pairs=200000)
+        m1 = ctx.memory_stats()
+        assert m1["peak_bytes"] > 10 * 2 ** 20 and m1["peak_bytes"] >= m1["live_bytes"] and m1["cached_bytes"] > 0   # the merge's blocks went back to the context's cache
+        m2 = ctx.memory_stats(reset_peak=True)
+        assert m2["peak_bytes"] == m1["peak_bytes"] and ctx.memory_stats()["peak_bytes"] == m2["live_bytes"]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_cl_msa_ten_sequences(gpu_ctx):
     names, seqs, _ = synth.c3_workload(30000)
     fasta = "".join(">%s some description\n%s\n" % (nm, seqs[nm]) for nm in names)
