@@ -121,6 +121,9 @@ struct ClFarDevice {
     // combinations, found or not — into the other members' inboxes as well ([combination][pair of the macro-block][7] encoded maxima)
     uint32_t share_n, share_i;   // share_n <= 1: no sharing
     int* peer_out[kPeerMaxMembers - 1];   // the block's slot in each other member's inbox (null: none)
+    // XCD-aware far launch (CL_CHAIN_FAR_XCD=1): a 1-D grid whose workgroup w — dispatched to XCD w % 8 — takes a combination = w % 8 (mod 8), so that an XCD's L2 holds the
+    // search structures of every eighth combination instead of all of them.  xcd_x: workgroups per combination (0: the 2-D grid of rounds 2-4), xcd_n: combinations of the launch
+    uint32_t xcd_x, xcd_n;
 };
 
 #endif

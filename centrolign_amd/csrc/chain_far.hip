@@ -469,13 +469,26 @@ __global__ void __launch_bounds__(256) far_prune_kernel(ClChainDevice D, ClFarDe
     __shared__ uint32_t s_tab[kFarMaxLevels * kFarTabWidth];
     if (threadIdx.x < kFarMaxLevels * kFarTabWidth) s_tab[threadIdx.x] = F.tab_dev[threadIdx.x];
     __syncthreads();
-    const uint32_t c = F.share_n > 1 ? F.share_i + blockIdx.y * F.share_n : blockIdx.y;   // (a shared far pass: this member's combinations)
+    uint32_t by = blockIdx.y, bx = blockIdx.x;
+    if (F.xcd_x) {   // (see ClFarDevice: combination by XCD for the full rounds of eight combinations, the rest dealt as before)
+        const uint32_t full = (F.xcd_n & ~7u) * F.xcd_x;
+        if (blockIdx.x < full) {
+            const uint32_t j = blockIdx.x >> 3;
+            by = (blockIdx.x & 7u) + 8u * (j / F.xcd_x);
+            bx = j % F.xcd_x;
+        } else {
+            const uint32_t r = blockIdx.x - full;
+            by = (F.xcd_n & ~7u) + r / F.xcd_x;
+            bx = r % F.xcd_x;
+        }
+    }
+    const uint32_t c = F.share_n > 1 ? F.share_i + by * F.share_n : by;   // (a shared far pass: this member's combinations)
     const ClChainCombo cb = D.combos[c];
     const uint32_t sub = threadIdx.x & 7u;                       // lane within its group of eight
     const uint32_t li = threadIdx.x & (W - 1u);                  // lane within the query's W
     const uint32_t sg = li >> 3;                                 // group of eight within the query
     const uint32_t grp = threadIdx.x / W;                        // query within the workgroup
-    const uint32_t qi = blockIdx.x * QPW + grp;
+    const uint32_t qi = bx * QPW + grp;
     const uint32_t s = first + qi;
     const uint32_t E = cb.prefix[end_block] & ~63u;              // records [0, E) are final, every node inside is sealed
     const int none = enc(CL_CHAIN_NEG);
@@ -720,10 +733,19 @@ hipError_t cl_chain_far_launch(const ClChainDevice& D, const ClFarDevice& F, uin
     // (10 x 1 Mbp, device time of a merge's two DPs with 8 / 16 / 32 lanes: 1 combination 348 / 303 / 293 ms, 4 combinations 583 / 512 / 476 ms, 25 combinations
     // 1 193 / 1 115 / 1 090 ms)
     const int lanes = (pinned == 8 || pinned == 16 || pinned == 32) ? pinned : (mine <= 32 ? 32 : mine <= 128 ? 16 : 8);   // (a whole wave per query was tried: it does not terminate)
-    const dim3 grid((count * (uint32_t)lanes + 255) / 256, mine);
+    dim3 grid((count * (uint32_t)lanes + 255) / 256, mine);
+    ClFarDevice Fx = F;
+    // workgroup w of a 1-D grid goes to XCD w % 8: with eight and more combinations every full round of eight is pinned, combination c to XCD c % 8, so that an
+    // XCD's L2 holds the search structures of an eighth of the combinations (10 x 1 Mbp root, 25 combinations: HBM fetches per far launch 1 / 3, device time of the
+    // merge's DPs 874 -> 835 ms).  CL_CHAIN_FAR_XCD=0: the 2-D grid of rounds 2-4 (A/B)
+    static const bool xcd_env = [] { const char* e = getenv("CL_CHAIN_FAR_XCD"); return !e || e[0] != '0'; }();
+    if (xcd_env && mine >= 8) {
+        Fx.xcd_x = grid.x; Fx.xcd_n = mine;
+        grid = dim3(mine * grid.x, 1);
+    } else { Fx.xcd_x = 0; Fx.xcd_n = 0; }
 #define CL_FAR_LAUNCH(G) do { \
-        if (D.sparse) hipExtLaunchKernelGGL((far_prune_kernel<true, G>), grid, dim3(256), 0, stream, nullptr, done, 0, D, F, first, count, end_block); \
-        else hipExtLaunchKernelGGL((far_prune_kernel<false, G>), grid, dim3(256), 0, stream, nullptr, done, 0, D, F, first, count, end_block); } while (0)
+        if (D.sparse) hipExtLaunchKernelGGL((far_prune_kernel<true, G>), grid, dim3(256), 0, stream, nullptr, done, 0, D, Fx, first, count, end_block); \
+        else hipExtLaunchKernelGGL((far_prune_kernel<false, G>), grid, dim3(256), 0, stream, nullptr, done, 0, D, Fx, first, count, end_block); } while (0)
     if (lanes >= 32) CL_FAR_LAUNCH(4);
     else if (lanes >= 16) CL_FAR_LAUNCH(2);
     else CL_FAR_LAUNCH(1);
