@@ -524,7 +524,12 @@ def main():
                                    "kernel trace of a step shows (profiles/r04_*); kernel_ms_alone: the same clock with the launch alone on an otherwise idle device, where these "
                                    "latency-bound launches take about twice as long (the device does not run a lone small launch at full speed).  Rounds 1-3 reported HIP event pairs "
                                    "round the lone launch"}
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            # traffic: HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc is a pass of its own and
+            # cannot run inside this one); beside it the algorithmic bytes per launch of THIS run — their ratio is the re-read factor
+            traffic = traffic_profile["hbm_bytes_per_launch_mean_over_all_launches_of_that_kernel"] if traffic_profile else None
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE and WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes), mean over the kernel's launches in profiles/hbm_traffic_latest.json",
+                               "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
                                "kernel": dom["kernel"], "merge": dom["merge"], "kernel_launches": agg["launches"], "kernel_ms_all_launches": agg["ms"],
                                "kernel_ms_average": agg["ms"] / agg["launches"], "kernel_bytes_all_launches": agg["bytes"], "kernel_cells_all_launches": agg["cells"],
                                "kernel_problems_all_launches": agg["problems"],
@@ -534,8 +539,7 @@ def main():
                                                                   for n, v in by_kernel.items()), key=lambda x: -x["ms"])[:6],
                                "limiter": "dependent chain of the largest matrix (n1 + n2 steps of one workgroup), not HBM: see latency_model",
                                "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells, SURVEY.md §8d) of all launches of the dominant kernel / the sum of their durations by the kernels' own clocks inside the last timed pass of THIS run (kernel_ms, kernel_cells: its longest launch); "
-                                       "traffic (PMC HBM bytes of this very launch) cannot be collected in the same run and is null; traffic_profile quotes the "
-                                       "committed rocprofv3 summary with its provenance"}
+                                       "traffic: the committed rocprofv3 PMC summary of the same command (traffic_profile gives its provenance), never divided by this run's times"}
         if elapsed > 0:
             # the whole step against the same roofline: what the nine plans together stream per second if every cell's state moved once
             step_bytes = float(sum(st["dp_bytes"] for st in stats))
