@@ -1484,6 +1484,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         while ((he = hipStreamQuery(ctx->stream)) == hipErrorNotReady) {
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > limit_s) {
                 (void)hipGetLastError();
+                ctx->poisoned = true;
                 cl_set_error(ctx, "chaining DP: the other members of the merge group did not deliver within %.0f s (a member failed?); this context cannot be used any more", limit_s);
                 for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
                 return CL_ERR_HIP;   // (device buffers of this DP are left to the stuck stream: releasing them would wait for it)
@@ -2198,6 +2199,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
                              const double* override_scale = nullptr, bool keep_scale_chain = false) {
     if (!ctx || !g1 || !g2 || !ms || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
+    if (ctx->poisoned) { cl_set_error(ctx, "this context was given up after a merge-group wait expired: destroy it and make a new one"); return CL_ERR_HIP; }
     const cl_chain_params& cp = ap->chain;
     // the CLI's -g (Anchorer::chaining_algorithm): Sparse chains on ChainMerge tables, without a scale estimate (anchorer.hpp:975-984, core.hpp:350-357)
     const int algo = ap->chaining_algorithm_plus_one ? ap->chaining_algorithm_plus_one - 1 : 2;

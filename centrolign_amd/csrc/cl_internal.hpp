@@ -22,6 +22,7 @@ constexpr int kNumAuxStreams = 12;
 
 struct cl_context {
     int device = 0;
+    bool poisoned = false;   // a merge-group wait expired on this context: its serial stream is stuck behind a wait nobody will satisfy.  Calls fail at once, releases do not wait for it
     hipStream_t stream = nullptr;
     hipStream_t aux[kNumAuxStreams] = {};   // the first n_aux are streams of their own, the rest aliases of them (aux[i] = aux[i % n_aux])
     int n_aux = kNumAuxStreams;
@@ -117,6 +118,7 @@ bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not ye
 // blocks at once (the end of a chaining DP: ~40 of them, each of which used to wait for all seven streams again — most of a small DP's time,
 // and a polishing step runs tens of thousands of small DPs) waits once and releases with quiesced = true.
 inline void cl_ctx_quiesce(cl_context* ctx) {
+    if (ctx->poisoned) return;   // (its streams never run dry)
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < ctx->n_aux; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
 }
