@@ -252,8 +252,9 @@ def main():
     ap.add_argument("--length", type=int, default=1000000, help="sequence length (the headline is 1 000 000; smaller only for dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-skip", type=int, default=0, help="measurements only: CL_DEBUG_SKIP_TRACEBACK for the timed plans (1 no traceback, 3 no plane stores either); the line is then NOT a result")
-    ap.add_argument("--share-merges", type=int, default=4,
-                    help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge")
+    ap.add_argument("--share-merges", type=int, default=0,
+                    help="N > 1: ranks per merge group (one merge over several GPUs: the far pass of its chaining DP divided between them); 0 = one rank per merge "
+                         "(the default until merge groups have passed their self-test across real xGMI links: they have only run between processes on ONE device)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the MSA and the timed passes: the command the rocprofv3 summaries under profiles/ are taken with")
     ap.add_argument("--plans", choices=("one", "nine"), default="one",
@@ -553,9 +554,9 @@ def main():
             n_macro = sum(2 * -(-int(m["chain_match_pairs"]) // 1024) for m in per_merge)     # two whole-graph DPs per merge, 1024 pairs per macro-block
             out["chain_dp"] = {"model": "latency", "not_a_roofline": True, "device_ms": chain_ms, "match_pairs": int(chain_pairs), "macro_blocks": n_macro,
                                "us_per_macro_block": chain_ms * 1e3 / max(1, n_macro),
-                               "kernels": "chain_walk_kernel -> chain_inter_kernel (near) -> far_prune_kernel / far_seal_kernel, both whole-graph DPs of all nine merges",
+                               "kernels": "chain_walk2_kernel -> chain_inter_kernel (near) -> far_prune_kernel / far_seal(_big)_kernel, both whole-graph DPs of all nine merges",
                                "note": "the chaining DP is a chain of ~1 200 dependent macro-blocks per DP (walk + near pass on the serial stream, far pass two blocks "
-                                       "behind on side streams); its kernels are priced per kernel against HBM bytes/s and VALU issue in profiles/r03_pmc_summary.json "
+                                       "behind on side streams); its kernels are priced per kernel against HBM bytes/s and VALU issue in profiles/r04_pmc_summary.json "
                                        "(rocprofv3 --pmc passes; command recorded in the file), not here: the far pass skips >98 % of the pair evaluations an "
                                        "all-pairs sweep would make, so an evaluations/s figure says nothing about the hardware"}
         # BASELINE.md §2 holds ONE figure for this metric, measured (not published) by the survey: the reference's po_poa at 38 M cells/s inside
@@ -569,7 +570,7 @@ def main():
             if "seconds" in out["cpu_reference_wall"]:
                 out["cpu_reference_wall"]["whole_msa_here_s"] = msa_wall
                 out["cpu_reference_wall"]["note"] = ("the reference needs %.1f s for the FIRST of the nine merges on this host; the whole ten-sequence MSA takes %.2f s here "
-                                                     "(the reference cannot finish it: it runs out of memory at the root, tests/golden/c3_10x1M_subproblems.json)" % (out["cpu_reference_wall"]["seconds"], msa_wall))
+                                                     "(the reference needs 37.6 CPU-minutes for the eight lower merges and 36.1 for the root at the default budget, on two hosts: profiles/r04_c3_root_default_reference.json; its GFA is the one printed here, byte for byte)" % (out["cpu_reference_wall"]["seconds"], msa_wall))
         if world == 1 and not args.no_extras:
             out["chaining_c2"] = chaining_section(ctx, not args.no_cpu_baseline)
             out["pairwise_c2"] = pairwise_section(ctx, not args.no_cpu_baseline)

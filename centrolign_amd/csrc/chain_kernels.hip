@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "device_once.h"
 #include "chain_device.h"
 
 namespace {
@@ -867,12 +868,10 @@ hipError_t cl_chain_acc_row(const ClChainDevice& D, uint32_t s, int* out, hipStr
 template <bool SPARSE, int F>
 static hipError_t launch_walk_fold(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done) {
     const size_t lds = (size_t)F * kChainMacro * (SPARSE ? 4 : 12) * sizeof(int) + 16;
-    static bool raised = false;   // (beyond 64 KB of dynamic LDS the kernel has to be told once)
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_walk_fold_kernel<SPARSE, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    static ClDeviceOnce raised;   // (beyond 64 KB of dynamic LDS the kernel has to be told once per device)
+    hipError_t attr_rc = hipSuccess;
+    raised([&] { attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_walk_fold_kernel<SPARSE, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (attr_rc != hipSuccess) return attr_rc;
     const uint32_t G = (D.n_combos + F - 1) / F;
     hipExtLaunchKernelGGL((chain_walk_fold_kernel<SPARSE, F>), dim3(G), dim3(kChainMacro), lds, stream, nullptr, done, 0, D, first, count);
     return hipGetLastError();

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include "device_once.h"
 
 #include "chain_device.h"
 
@@ -643,8 +644,8 @@ uint32_t cl_chain_walk2_helpers(uint32_t qpt) { return (kChainMacro / kSub - kSl
 // `done` (may be null): recorded when the launch has finished — the event record rides on the launch (hipExtLaunchKernel) instead of being a runtime
 // call of its own: the chaining DP is as long as the host needs for its calls
 hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream, hipEvent_t done) {
-    static std::once_flag attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function
-    std::call_once(attr_once, [] {
+    static ClDeviceOnce attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function
+    attr_once([] {
         const int cap = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_walk2_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_walk2_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);

@@ -63,6 +63,7 @@ void ClPathMergeTables::wait() { if (builder.joinable()) builder.join(); }
 // cl_core_align; `ready`: the two PathMerge tables a caller started building earlier (cl_merge: beside the match finding)
 int cl_core_align_prepared(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* matches, const cl_core_align_params* ap,
                            cl_core_align_result* out, ClPathMergeTables* ready) {
+    cl_bind_device(ctx);
     if (!ctx || !g1 || !g2 || !matches || !ap || !out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     memset(out, 0, sizeof(*out));
     // the two PathMerge tables, built side by side and shared by every stage below (cl_internal.hpp: cl_shared_table)

@@ -672,6 +672,7 @@ void plan_free(cl_stitch_plan* pl) {
     pl->d_planes.release(q); pl->d_out_pairs.release(q); pl->d_out_len.release(q); pl->d_out_status.release(q);
     pl->d_plist.release(q); pl->d_out_score.release(q); pl->d_aux.release(q);
     pl->d_strips.release(q); pl->d_strip_recs.release(q); pl->d_strip_list.release(q); pl->d_progress.release(q); pl->d_handoff.release(q);
+    pl->d_ticks.release(q);
     for (auto& g : pl->groups) {
         if (g.ev0) (void)hipEventDestroy(g.ev0);
         if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -826,6 +827,8 @@ cl_context* cl_context_create(int device_ordinal) {
     cl_context* ctx = new (std::nothrow) cl_context();
     if (!ctx) return nullptr;
     ctx->device = device_ordinal;
+    int callers_device = -1;   // the caller's current device is put back: creating worker contexts on a list of devices must not move the calling thread
+    (void)hipGetDevice(&callers_device);
     hipDeviceProp_t prop;
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -847,6 +850,7 @@ cl_context* cl_context_create(int device_ordinal) {
         return nullptr;
     }
     ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (callers_device >= 0 && callers_device != device_ordinal) (void)hipSetDevice(callers_device);
     {
         std::lock_guard<std::mutex> lock(g_live_mutex);
         g_live_contexts.push_back(ctx);
@@ -977,7 +981,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             return;
         }
         uint64_t cells = (g[0].n + 1) * (g[1].n + 1);
-        if (cells >= (1ull << 31) || g[0].n_src == 0 || g[1].n_src == 0 || g[0].n_snk == 0 || g[1].n_snk == 0) { P.fail(cells >= (1ull << 31) ? CL_ERR_INVALID_ARGUMENT : CL_ERR_UNREACHABLE_SINK, "problem %llu: matrix too large for the device path or no sources/sinks", (unsigned long long)k); return; }
+        if (cells >= (1ull << 30) || g[0].n_src == 0 || g[1].n_src == 0 || g[0].n_snk == 0 || g[1].n_snk == 0) { P.fail(cells >= (1ull << 30) ? CL_ERR_INVALID_ARGUMENT : CL_ERR_UNREACHABLE_SINK, "problem %llu: matrix too large for the device path or no sources/sinks", (unsigned long long)k); return; }
         ClProbDesc d{};
         d.n1 = (uint32_t)g[0].n;
         d.n2 = (uint32_t)g[1].n;
@@ -1982,6 +1986,7 @@ void cl_alignment_free(cl_alignment* a) {
 
 int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_anchor_segments* sg,
               const cl_stitch_params* params, cl_alignment* out) {
+    cl_bind_device(ctx);
     if (!ctx || !g1 || !g2 || !sg || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     out->n_pairs = 0;
     out->pairs = nullptr;
@@ -2034,6 +2039,7 @@ int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2,
 // its own pairs FOLLOWED by the alignment of the gap in front of it (:216-231).
 int cl_internal_stitch(cl_context* ctx, const cl_base_graph* g, uint64_t n_anchors, const uint64_t* walk_off, const uint32_t* walk1,
                        const uint32_t* walk2, const cl_stitch_params* params, cl_alignment* out) {
+    cl_bind_device(ctx);
     if (!ctx || !g || !params || !out || (n_anchors && (!walk_off || !walk1 || !walk2))) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     out->n_pairs = 0;
     out->pairs = nullptr;

@@ -1974,11 +1974,13 @@ extern "C" {
 int cl_chain_sparse_affine(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
                            uint64_t num_match_sets, const cl_chain_params* cp, double local_scale, int want_dp,
                            cl_chain_result* out) {
+    cl_bind_device(ctx);
     return chain_dp_impl(ctx, g1, g2, ms, num_match_sets, cp, local_scale, want_dp, false, out);
 }
 
 int cl_chain_sparse(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
                     uint64_t num_match_sets, const cl_chain_params* cp, int want_dp, cl_chain_result* out) {
+    cl_bind_device(ctx);
     return chain_dp_impl(ctx, g1, g2, ms, num_match_sets, cp, 1.0, want_dp, true, out);
 }
 
@@ -2586,6 +2588,7 @@ int cl_anchor_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
 
 int cl_anchor_chain_masked(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms, const cl_anchor_params* ap,
                            const uint64_t* masked, uint64_t n_masked, const double* override_scale, cl_anchor_chain_result* out) {
+    cl_bind_device(ctx);
     if (n_masked && !masked) { cl_set_error(ctx, "null mask"); return CL_ERR_INVALID_ARGUMENT; }
     MaskSet mask;
     mask.v.resize(n_masked);
@@ -2658,6 +2661,7 @@ int cl_update_mask(const cl_match_sets* ms, uint64_t n_chain_pairs, const uint32
 // Anchorer::estimate_score_scale with its chain_out (anchorer.hpp:998-1047): out->scale and the chain the estimate was made on
 int cl_estimate_score_scale_chain(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
                                   const cl_anchor_params* ap, cl_anchor_chain_result* out) {
+    cl_bind_device(ctx);
     if (!ap || !out) return CL_ERR_INVALID_ARGUMENT;
     cl_anchor_params p = *ap;
     p.autocalibrate_gap_penalties = 1;
@@ -2666,6 +2670,7 @@ int cl_estimate_score_scale_chain(cl_context* ctx, const cl_base_graph* g1, cons
 
 int cl_estimate_score_scale(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_sets* ms,
                             const cl_anchor_params* ap, double* scale_out) {
+    cl_bind_device(ctx);
     if (!ap || !scale_out) return CL_ERR_INVALID_ARGUMENT;
     cl_anchor_params p = *ap;
     p.autocalibrate_gap_penalties = 1;

@@ -532,6 +532,7 @@ void cl_leaf_calibration_free(cl_leaf_calibration* c) {
 // tandem-duplication rounds will want them (:168-172)
 int cl_leaf_calibrate(cl_context* ctx, const cl_base_graph* leaf, const cl_match_params* mp, const cl_anchor_params* ap, double* scale_out,
                       cl_leaf_calibration** memo_out) {
+    cl_bind_device(ctx);
     if (!ctx || !leaf || !mp || !ap || !scale_out) return CL_ERR_INVALID_ARGUMENT;
     if (memo_out) *memo_out = nullptr;
     if (leaf->n_nodes == 0 || leaf->src_id >= leaf->n_nodes || leaf->snk_id >= leaf->n_nodes) return CL_ERR_INVALID_ARGUMENT;
@@ -573,6 +574,7 @@ void cl_alignment_list_free(cl_alignment_list* l) {
 // the main-diagonal chain, every bond stitched into an alignment in PATH POSITIONS, the mask extended by the chain (both ways round)
 int cl_leaf_bond_alignments(cl_context* ctx, const cl_base_graph* leaf, const cl_leaf_calibration* memo, const cl_anchor_params* ap,
                             const cl_stitch_params* sp, const cl_bond_params* bp, uint64_t max_rounds, cl_alignment_list* out) {
+    cl_bind_device(ctx);
     if (!ctx || !leaf || !memo || !ap || !sp || !bp || !out) return CL_ERR_INVALID_ARGUMENT;
     memset(out, 0, sizeof(*out));
     if (leaf->n_paths != 1) { cl_set_error(ctx, "cl_leaf_bond_alignments: a leaf has one path"); return CL_ERR_INVALID_ARGUMENT; }

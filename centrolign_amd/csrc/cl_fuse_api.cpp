@@ -146,6 +146,7 @@ int cl_fuse(const cl_base_graph* dest, const cl_base_graph* source, const uint64
 }
 
 int cl_leaf_intrinsic_scale(cl_context* ctx, const cl_base_graph* leaf, const cl_match_params* mp, const cl_anchor_params* ap, double* scale_out) {
+    cl_bind_device(ctx);
     if (!ctx || !leaf || !mp || !ap || !scale_out) return CL_ERR_INVALID_ARGUMENT;
     if (leaf->n_nodes == 0 || leaf->src_id >= leaf->n_nodes || leaf->snk_id >= leaf->n_nodes) return CL_ERR_INVALID_ARGUMENT;
     // the leaf against itself, the second copy under its own sentinel characters (src/core.cpp:128-133)
@@ -262,6 +263,7 @@ int cl_internal_fuse(const cl_base_graph* g, const uint64_t* pairs, uint64_t n_p
 }
 
 int cl_merge(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_merge_params* prm, cl_merge_result* out) {
+    cl_bind_device(ctx);
     if (!ctx || !g1 || !g2 || !prm || !out) return CL_ERR_INVALID_ARGUMENT;
     memset(out, 0, sizeof(*out));
     if (g1->n_nodes == 0 || g2->n_nodes == 0 || g1->src_id >= g1->n_nodes || g1->snk_id >= g1->n_nodes || g2->src_id >= g2->n_nodes ||

@@ -72,7 +72,13 @@ inline void cl_pool_trim(cl_context* ctx) {   // under pool_mutex
     ctx->pool_free_bytes = 0;
 }
 
+// The HIP runtime's "current device" is per thread, and the library is driven from threads it did not make (a host's pool, cl_msa's workers):
+// every public entry point that takes a context binds the calling thread to the context's device first, and so does every allocation (kernels
+// go to the context's streams, but hipMalloc, hipFuncSetAttribute and event creation follow the current device).
+inline void cl_bind_device(const cl_context* ctx) { if (ctx) (void)hipSetDevice(ctx->device); }
+
 inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
+    cl_bind_device(ctx);
     static const bool no_pool = getenv("CL_NO_POOL") != nullptr;
     if (no_pool) return hipMalloc(out, bytes);
     bytes = (bytes + 255) & ~(size_t)255;

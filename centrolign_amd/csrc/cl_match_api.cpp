@@ -398,6 +398,7 @@ int cl_find_matches(cl_context* ctx, const cl_base_graph* g1, const cl_base_grap
 // starts work there that would get in the device half's way (page-locking the traceback's download area stalls every HIP call of the process)
 int cl_find_matches_hooked(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2, const cl_match_params* prm, cl_owned_match_sets** out,
                            cl_match_stats* stats, const std::function<void()>* after_device_half) {
+    cl_bind_device(ctx);
     if (!ctx || !g1 || !g2 || !prm || !out) return CL_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (stats) *stats = cl_match_stats{};
@@ -436,6 +437,7 @@ int cl_match_joined_text(const cl_base_graph* g1, const cl_base_graph* g2, uint8
 }
 
 int cl_suffix_array_lcp(cl_context* ctx, const uint8_t* text, uint64_t n, uint32_t* sa, uint32_t* lcp, uint32_t* isa, uint32_t* rounds_out) {
+    cl_bind_device(ctx);
     if (!ctx || (n && (!text || !sa || !lcp || !isa)) || n >= 0x7FFFFFFFull) return CL_ERR_INVALID_ARGUMENT;
     ClSuffixStats ss;
     int rc = cl_match_suffix_array(ctx, text, (uint32_t)n, sa, lcp, isa, &ss);

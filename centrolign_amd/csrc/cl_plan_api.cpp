@@ -433,6 +433,7 @@ void cl_msa_params_default(cl_msa_params* p) {
 // explicit_cigar for two sequences, write_gfa otherwise.  Everything numerical happens behind the seams this function calls.
 int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const char* newick, const cl_msa_params* params, char** text_out,
            uint64_t* len_out, cl_msa_stats* stats) {
+    cl_bind_device(ctx);
     if (!ctx || !fasta_text || !params || !text_out || !len_out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     *text_out = nullptr;
     *len_out = 0;

@@ -678,6 +678,7 @@ extern "C" {
 // realigned subgraphs put back in place of the old nodes (integrate_polished_subgraphs + purge_uncovered_nodes)
 int cl_polish_cyclized_graph(cl_context* ctx, const cl_base_graph* graph, const char* const* path_names, const char* newick, const char* const* sequence_names,
                              uint64_t n_sequences, const cl_merge_params* mp, const cl_polish_params* pp, cl_owned_base_graph** out, uint64_t* n_regions_out) {
+    cl_bind_device(ctx);
     return cl_polish_cyclized_graph_workers(&ctx, 1, graph, path_names, newick, sequence_names, n_sequences, mp, pp, out, n_regions_out);
 }
 

@@ -11,6 +11,7 @@
 // popoa_ring_kernel: the same sweep for subproblems whose topology and a ring of recent anti-diagonals fit LDS (below).
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "popoa_device.h"
@@ -1403,8 +1404,8 @@ void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const
 hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                                const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    static std::once_flag attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function (worker threads launch concurrently)
-    std::call_once(attr_once, [] {
+    static ClDeviceOnce attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function (worker threads launch concurrently)
+    attr_once([] {
         const int cap = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -1430,8 +1431,8 @@ hipError_t cl_launch_popoa_strip(int npw, uint32_t threads, uint32_t n_blocks, u
                                  const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     if (threads < 320 || threads > 1024 || (threads & 63u)) return hipErrorInvalidValue;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [] {
+    static ClDeviceOnce attr_once;
+    attr_once([] {
         const int cap = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_strip_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_strip_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -1449,8 +1450,8 @@ hipError_t cl_launch_popoa_strip(int npw, uint32_t threads, uint32_t n_blocks, u
 hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32_t ring_bytes, const ClDeviceBatch& B,
                                    const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    static std::once_flag attr_once;
-    if (ring_bytes > 64 * 1024) std::call_once(attr_once, [] {
+    static ClDeviceOnce attr_once;
+    if (ring_bytes > 64 * 1024) attr_once([] {
         const int cap = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_ring_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);

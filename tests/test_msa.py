@@ -137,6 +137,14 @@ def test_gpu_context_memory_statistics():
         assert m1["peak_bytes"] > 10 * 2 ** 20 and m1["peak_bytes"] >= m1["live_bytes"] and m1["cached_bytes"] > 0   # the merge's blocks went back to the context's cache
         m2 = ctx.memory_stats(reset_peak=True)
         assert m2["peak_bytes"] == m1["peak_bytes"] and ctx.memory_stats()["peak_bytes"] == m2["live_bytes"]
+        # plans give back everything they took (round-4 advisor: every plan kept its block of launch clocks): live bytes
+        # after further merges and one-shot stitch batches equal live bytes after the first
+        base = ctx.memory_stats()["live_bytes"]
+        batch = synth.random_dag_batch(32, seed=5, max_n=40)
+        for _ in range(3):
+            ctx.merge(g[0], g[1], score_scale=1.0, max_num_match_pairs=200000)
+            ctx.stitch_batch_align(batch)
+        assert ctx.memory_stats()["live_bytes"] == base
     finally:
         ctx.close()
 
