@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcentrolign_amd.so")
+# CL_LIBRARY: another build of the SAME library (the sanitizer build, `make SAN=1` -> lib/san/: scripts/san_suite.sh); never a fallback
+LIB_PATH = os.environ.get("CL_LIBRARY") or os.path.join(_HERE, "lib", "libcentrolign_amd.so")
 
 CL_GAP = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -976,7 +977,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 8     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 9     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1138,9 +1139,19 @@ def load_library(path=None):
     return lib
 
 
+def fallback_counters(reset=False):
+    """cl_fallback_counters: dict(strip_fallbacks, walk_stalls, chain_dps, stitch_plans, strip_pairs) of this process"""
+    lib = load_library()
+    st = (C.c_uint64 * 5)()
+    lib.cl_fallback_counters.argtypes = [C.c_void_p, C.c_int]
+    lib.cl_fallback_counters.restype = None
+    lib.cl_fallback_counters(st, int(bool(reset)))
+    return dict(zip(("strip_fallbacks", "walk_stalls", "chain_dps", "stitch_plans", "strip_pairs"), [int(x) for x in st]))
+
+
 EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
-    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_memory",
+    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_memory", "cl_fallback_counters",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
@@ -1708,6 +1719,10 @@ class Context:
         self.lib.cl_context_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         self._check(self.lib.cl_context_memory(self.handle, st, int(bool(reset_peak))))
         return dict(zip(("live_bytes", "peak_bytes", "cached_bytes", "device_free_bytes", "device_total_bytes", "pinned_host_bytes"), [int(x) for x in st]))
+
+    def fallback_counters(self, reset=False):
+        """cl_fallback_counters (process-wide): second attempts the device path made by itself — strips re-run anti-diagonal-wise, walks re-run per block"""
+        return fallback_counters(reset)
 
     def close(self):
         if self.handle:

@@ -61,6 +61,7 @@ const bool g_no_graph = [] { const char* e = getenv("CL_STITCH_GRAPH"); return !
 
 }  // namespace
 
+ClFallbackCounters cl_fallbacks;
 std::atomic<size_t> cl_pinned_total{0};
 
 // ClRawVec's storage (cl_internal.hpp): blocks of a megabyte and more come from, and go back to, a per-thread cache (at most kBigCacheCap bytes
@@ -787,6 +788,17 @@ extern "C" {
 
 int cl_abi_version(void) { return CL_ABI_VERSION; }
 
+void cl_fallback_counters(cl_fallback_stats* out, int reset) {
+    if (out) {
+        out->strip_fallbacks = cl_fallbacks.strip_fallbacks.load();
+        out->walk_stalls = cl_fallbacks.walk_stalls.load();
+        out->chain_dps = cl_fallbacks.chain_dps.load();
+        out->stitch_plans = cl_fallbacks.stitch_plans.load();
+        out->strip_pairs = cl_fallbacks.strip_pairs.load();
+    }
+    if (reset) { cl_fallbacks.strip_fallbacks = 0; cl_fallbacks.walk_stalls = 0; cl_fallbacks.chain_dps = 0; cl_fallbacks.stitch_plans = 0; cl_fallbacks.strip_pairs = 0; }
+}
+
 void cl_stitch_params_default(cl_stitch_params* p) {
     // src/parameters.cpp:74-85 (the CLI's values; Stitcher's class defaults differ)
     p->alignment_params.match = 20;
@@ -1457,6 +1469,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             grp.bytes += cells * 4ull * (1 + 2 * npw);
             grp.est_cost = std::max<uint64_t>(grp.est_cost, (uint64_t)d.n1 + d.n2 + 96ull * s0.n_strips);
             i += s0.n_strips;
+            ++cl_fallbacks.strip_pairs;
         }
         close();
     }
@@ -1603,6 +1616,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
 int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
     if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ++cl_fallbacks.stitch_plans;
     // A plan that is executed again (resident inputs, replayed passes) measures its launches ONCE — each alone on the device, the host's clock
     // round launch + wait — and deals them over the streams by those durations from then on: a launch lasts as long as its longest sweep at a
     // rate that depends on the subproblems' branching (0.25 .. 2.7 us per step), which the estimate of cl_stitch_plan_create cannot know.
@@ -1741,6 +1755,7 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
             d_redo.release();
             if (e != hipSuccess) { set_error(ctx, "re-running %zu pairs on the anti-diagonal kernel failed: %s", redo[npw].size(), hipGetErrorString(e)); return CL_ERR_HIP; }
             pl->stats.n_strip_fallbacks += redo[npw].size();
+            cl_fallbacks.strip_fallbacks += redo[npw].size();
         }
         if (any) {
             HIP_TRY(ctx, cl_copy_sync(ctx, len.data(), pl->d_out_len.p, npo * 4, hipMemcpyDeviceToHost));

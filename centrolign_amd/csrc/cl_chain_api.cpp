@@ -325,8 +325,10 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
 static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
                           bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out) {
     const ChainTimings before = tm;
+    ++cl_fallbacks.chain_dps;
     int rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, true);
     if (rc != kWalkStalled) return rc;
+    ++cl_fallbacks.walk_stalls;
     if (ctx->peers.n > 1) return CL_ERR_HIP;   // (inside a merge group the other members have gone on with this member's share: no second attempt)
     if (getenv("CL_CHAIN_TIMING")) fprintf(stderr, "[chain_dp_batch]   walk kernel stalled: repeating the DP on the per-block kernels\n");
     tm = before;

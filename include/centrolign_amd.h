@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 8   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 9   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -177,6 +177,17 @@ typedef struct cl_memory_stats {
     uint64_t pinned_host_bytes;     /* page-locked host area of the context */
 } cl_memory_stats;
 int cl_context_memory(cl_context* ctx, cl_memory_stats* out, int reset_peak);
+
+/* Process-wide counts of the second attempts the device path makes by itself (all contexts, since the library was loaded or since reset):
+ * a long run is "clean" when both fallback counts are zero.  The reference has no counterpart (its CPU path has no co-residency to lose). */
+typedef struct cl_fallback_stats {
+    uint64_t strip_fallbacks;   /* pairs whose strips of rows (popoa_strip_kernel) gave up waiting for one another and were run again anti-diagonal-wise */
+    uint64_t walk_stalls;       /* chaining DPs whose walk kernel's workgroups were not co-resident in time and that were run again on the per-block kernels */
+    uint64_t chain_dps;         /* chaining DPs run on the device */
+    uint64_t stitch_plans;      /* stitch plans executed */
+    uint64_t strip_pairs;       /* pairs that took the strips at all */
+} cl_fallback_stats;
+void cl_fallback_counters(cl_fallback_stats* out, int reset);
 
 /* po_poa<NumPW> for every problem of the batch; num_pw[k] in {1,2,3}. */
 int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw,
