@@ -1151,7 +1151,7 @@ def fallback_counters(reset=False):
 
 EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
-    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_memory", "cl_fallback_counters",
+    "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_peer_steal", "cl_context_memory", "cl_fallback_counters",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
     "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
@@ -1708,10 +1708,17 @@ class Context:
         return self.lib.cl_context_peer_selftest(self.handle, int(token), int(timeout_ms)) == 0
 
     def peer_stats(self):
-        st = (C.c_uint64 * 5)()
+        st = (C.c_uint64 * 6)()
         self.lib.cl_context_peer_stats.argtypes = [C.c_void_p, C.c_void_p]
         self._check(self.lib.cl_context_peer_stats(self.handle, st))
-        return dict(shared_dps=int(st[0]), shared_far_launches=int(st[1]), merged_blocks=int(st[2]), epoch_mark=int(st[3]), selftest_mark=int(st[4]))
+        return dict(shared_dps=int(st[0]), shared_far_launches=int(st[1]), merged_blocks=int(st[2]), epoch_mark=int(st[3]), selftest_mark=int(st[4]), steals=int(st[5]))
+
+    def peer_steal(self, job):
+        """cl_context_peer_steal: the next chunk number of job `job` from the group's one atomic counter (member 0's exported memory); local count without a group"""
+        out = C.c_uint32(0)
+        self.lib.cl_context_peer_steal.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        self._check(self.lib.cl_context_peer_steal(self.handle, int(job), C.byref(out)))
+        return int(out.value)
 
     def memory_stats(self, reset_peak=False):
         """cl_context_memory: device bytes this context holds / held at most / keeps cached, hipMemGetInfo's free and total, page-locked host bytes"""

@@ -713,6 +713,27 @@ __global__ void peer_store_word_kernel(uint32_t* where, uint32_t value) {
     *where = value;
     __threadfence_system();
 }
+// cl_context_peer_steal: the next chunk of job `job` from the group's counter word — job << 32 | chunks handed out — which lives in member 0's exported
+// memory (another device's, over xGMI, for every other member: system-scope atomics).  The first member to arrive for a job finds an older job in the
+// word and replaces it by job << 32 | 1 (it has chunk 0): nobody resets anything, job numbers only grow.  *out = chunk, or 0xFFFFFFFF when the word
+// already holds a LATER job (the caller's job number is stale)
+__global__ void peer_steal_kernel(unsigned long long* word, uint32_t job, uint32_t* out) {
+    unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    while (true) {
+        const uint32_t have = (uint32_t)(v >> 32);
+        if (have > job) { *out = 0xFFFFFFFFu; break; }
+        const unsigned long long want = have == job ? v + 1 : ((unsigned long long)job << 32) | 1ull;
+        if (__hip_atomic_compare_exchange_strong(word, &v, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+            *out = have == job ? (uint32_t)v : 0u;
+            break;
+        }
+    }
+    __threadfence_system();
+}
+}
+hipError_t cl_peer_steal(unsigned long long* word, uint32_t job, uint32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(peer_steal_kernel, dim3(1), dim3(1), 0, stream, word, job, out);
+    return hipGetLastError();
 }
 // cl_context_peer_selftest: a kernel's store into (possibly another device's) memory
 hipError_t cl_peer_store_word(uint32_t* where, uint32_t value, hipStream_t stream) {

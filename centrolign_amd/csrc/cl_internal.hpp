@@ -55,7 +55,8 @@ struct cl_context {
         uint32_t epoch_mark = 0;       // the highest epoch this context's inbox has ever been used with: the arrival words are never reset, so a group's
                                        // epoch base must not lie below it (cl_context_peer_group refuses), and
         uint32_t test_mark = 0;        // the highest token of cl_context_peer_selftest (a token at or below it would find its words already there)
-        uint64_t shared_dps = 0, shared_far_launches = 0, merged_blocks = 0;
+        uint64_t shared_dps = 0, shared_far_launches = 0, merged_blocks = 0, steals = 0;
+        uint32_t steal_job = 0, steal_next = 0;   // cl_context_peer_steal without a group: a local counter
         std::vector<std::pair<std::string, void*>> opened;   // IPC handles this context has opened (kept until it is destroyed)
     } peers;
     std::mutex pool_mutex;
@@ -84,7 +85,10 @@ inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     auto it = ctx->pool_free.lower_bound(bytes);
-    if (it != ctx->pool_free.end() && it->first <= 2 * bytes + (1u << 20)) {
+    // a cached block serves a request of at least half its size — small and medium blocks; from 256 MB on the slack is an eighth: a 34 GB request that
+    // took a 60 GB block made a context "hold" 87 GB where its arrays needed 61 (50 x 100 kbp root, round 5), which is what the memory model is checked against
+    const size_t slack = bytes >= ((size_t)256 << 20) ? bytes / 8 : bytes + (1u << 20);
+    if (it != ctx->pool_free.end() && it->first <= bytes + slack) {
         *out = it->second;
         ctx->pool_free_bytes -= it->first;
         ctx->dev_live_bytes += it->first;

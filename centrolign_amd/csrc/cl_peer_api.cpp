@@ -22,6 +22,7 @@
 #include "cl_internal.hpp"
 
 hipError_t cl_peer_store_word(uint32_t* where, uint32_t value, hipStream_t stream);   // chain_far.hip
+hipError_t cl_peer_steal(unsigned long long* word, uint32_t job, uint32_t* out, hipStream_t stream);
 
 namespace {
 struct HandleBody {                 // what travels inside cl_peer_handle
@@ -37,6 +38,9 @@ constexpr size_t kInboxInts = (size_t)kPeerRing * kPeerSlotInts;
 constexpr size_t kFlagWords = (size_t)kPeerMaxMembers * kPeerRing;
 constexpr size_t kTestWords = kPeerMaxMembers;   // behind the arrival words: one word per member for cl_context_peer_selftest
 constexpr size_t kTestInts = 8 * kPeerMaxMembers;   // the last ints of the inbox's last slot (beyond kPeerMaxCombos combinations nothing is stored there... see below)
+constexpr size_t kStealWords = 4;                   // behind those: the group's work-stealing counter (64 bits, 8-byte aligned) + the word a steal's answer lands in
+constexpr size_t kTailWords = kFlagWords + kTestWords + kTestInts + kStealWords;
+static_assert(((kInboxInts + kFlagWords + kTestWords + kTestInts) * sizeof(uint32_t)) % 8 == 0, "the steal counter is a 64-bit word");
 }
 
 extern "C" {
@@ -47,10 +51,10 @@ int cl_context_peer_export(cl_context* ctx, cl_peer_handle* out) {
     auto& P = ctx->peers;
     if (!P.inbox) {
         void* p = nullptr;
-        HIP_TRY(ctx, hipMalloc(&p, kInboxInts * sizeof(int) + (kFlagWords + kTestWords + kTestInts) * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(&p, kInboxInts * sizeof(int) + kTailWords * sizeof(uint32_t)));
         P.inbox = static_cast<int*>(p);
         P.flags = reinterpret_cast<uint32_t*>(P.inbox + kInboxInts);
-        HIP_TRY(ctx, hipMemset(P.flags, 0, (kFlagWords + kTestWords + kTestInts) * sizeof(uint32_t)));   // arrival words start below every epoch
+        HIP_TRY(ctx, hipMemset(P.flags, 0, kTailWords * sizeof(uint32_t)));   // arrival words start below every epoch, the steal counter below every job
         HIP_TRY(ctx, hipDeviceSynchronize());
     }
     HandleBody h{};
@@ -141,6 +145,32 @@ int cl_context_peer_selftest(cl_context* ctx, uint32_t token, uint32_t timeout_m
     return CL_OK;
 }
 
+// Work stealing between the members of the current group (north_star: the stitch subproblems of a merge shard across the GPUs "for work-stealing only").
+// Every member holds the same list of chunks (the subproblems in LPT order, cut at a cell count: centrolign_amd/dist.py) and pulls chunk numbers from ONE
+// counter until they run out — the counter is a 64-bit word in member 0's exported memory, job << 32 | chunks handed out, advanced by a one-thread kernel with
+// system-scope atomics (peer atomics over xGMI between devices; plain L2 atomics between processes on one device).  `job` must be the same on every member
+// and larger than any job the group has used (the first member to arrive takes the word over: nothing is reset, nobody waits for anybody).
+// *chunk_out = the chunk this call won: the caller stops when it is >= its number of chunks.  A group of one (or no group) counts locally.
+int cl_context_peer_steal(cl_context* ctx, uint32_t job, uint32_t* chunk_out) {
+    if (!ctx || !chunk_out) { cl_set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    auto& P = ctx->peers;
+    if (P.n <= 1) {   // nobody to share with
+        if (job != P.steal_job) { P.steal_job = job; P.steal_next = 0; }
+        *chunk_out = P.steal_next++;
+        return CL_OK;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t* tail = (P.me == 0 ? P.flags : P.peer_flags[0]) + kFlagWords + kTestWords + kTestInts;
+    uint32_t* answer = P.flags + kFlagWords + kTestWords + kTestInts + 2;   // in this member's own memory
+    HIP_TRY(ctx, cl_peer_steal(reinterpret_cast<unsigned long long*>(tail), job, answer, ctx->stream));
+    uint32_t got = 0;
+    HIP_TRY(ctx, cl_copy_sync(ctx, &got, answer, sizeof(got), hipMemcpyDeviceToHost));
+    if (got == 0xFFFFFFFFu) { cl_set_error(ctx, "cl_context_peer_steal: job %u is older than the job the group's counter holds: job numbers must grow", job); return CL_ERR_INVALID_ARGUMENT; }
+    *chunk_out = got;
+    ++P.steals;
+    return CL_OK;
+}
+
 int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out) {
     if (!ctx || !out) return CL_ERR_INVALID_ARGUMENT;
     out->shared_dps = ctx->peers.shared_dps;
@@ -148,6 +178,7 @@ int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out) {
     out->merged_blocks = ctx->peers.merged_blocks;
     out->epoch_mark = ctx->peers.epoch_mark;
     out->selftest_mark = ctx->peers.test_mark;
+    out->steals = ctx->peers.steals;
     return CL_OK;
 }
 

@@ -77,3 +77,50 @@ def gather_results(result, idx, n_problems, dist, rank):
             pairs[int(off[k]):int(off[k + 1])] = p[int(aln_off[j]):int(aln_off[j + 1])]
         score[pidx], route[pidx], num_pw[pidx] = sc, ro, pw
     return StitchResult(off, pairs, score, route, num_pw)
+
+
+def steal_chunks(batch, chunk_cells=2000000):
+    """the subproblems of ONE batch in LPT order (descending DP cells, stable) cut into chunks of about chunk_cells cells: the list every rank of a
+    work-stealing pass holds.  A chunk is an index array in ascending problem order; chunk 0 holds the largest subproblems."""
+    n1, n2 = batch.sizes()
+    cells = (n1 + 1) * (n2 + 1)
+    order = np.argsort(-cells, kind="stable")
+    chunks, cur, load = [], [], 0
+    for k in order:
+        cur.append(int(k))
+        load += int(cells[k])
+        if load >= chunk_cells:
+            chunks.append(np.array(sorted(cur), dtype=np.int64))
+            cur, load = [], 0
+    if cur:
+        chunks.append(np.array(sorted(cur), dtype=np.int64))
+    return chunks
+
+
+def stitch_by_stealing(ctx, batch, steal, chunk_cells=2000000, params=None, run=None):
+    """One rank's part of a work-stealing stitch pass (north_star: subproblems shard across the GPUs "for work-stealing only"): every rank holds the same
+    chunk list (steal_chunks) and pulls chunk numbers from ONE atomic counter until they run out — `steal()` returns the next number: in production
+    ctx.peer_steal(job) (a 64-bit word in member 0's exported device memory, system-scope atomics over xGMI: cl_context_peer_steal), in the gloo tests
+    the rendezvous store's fetch-add.  Returns (problem indices this rank ran, StitchResult over them in that order, chunk numbers taken); the caller
+    gathers with gather_results.  No collective and no rank-to-rank exchange while the pass runs (the reference runs them one after the other:
+    stitcher.hpp:157-203)."""
+    from .capi import StitchResult
+    chunks = steal_chunks(batch, chunk_cells)
+    run = run or (lambda sub: ctx.stitch_batch_align(sub, params))
+    took, idx_parts, res_parts = [], [], []
+    while True:
+        c = int(steal())
+        if c >= len(chunks):
+            break
+        took.append(c)
+        idx = chunks[c]
+        idx_parts.append(idx)
+        res_parts.append(run(batch.subset(idx)))
+    if not idx_parts:
+        return np.zeros(0, np.int64), StitchResult(np.zeros(1, np.uint64), np.zeros((0, 2), np.uint64), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.uint8)), took
+    idx = np.concatenate(idx_parts)
+    lens = np.concatenate([np.diff(r.aln_off.astype(np.int64)) for r in res_parts])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    pairs = np.concatenate([np.asarray(r.pairs, np.uint64).reshape(-1, 2) for r in res_parts]) if int(off[-1]) else np.zeros((0, 2), np.uint64)
+    cat = lambda name, dt: np.concatenate([np.asarray(getattr(r, name), dt) for r in res_parts])
+    return idx, StitchResult(off, pairs, cat("score", np.int64), cat("route", np.uint8), cat("num_pw", np.uint8)), took

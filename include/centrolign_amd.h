@@ -159,10 +159,17 @@ typedef struct cl_peer_stats {
     uint64_t epoch_mark;            /* highest epoch this context's inbox has been used with: cl_context_peer_group refuses a base below it (the
                                        arrival words are never reset); callers that reuse contexts start from the maximum over the members */
     uint64_t selftest_mark;         /* highest token cl_context_peer_selftest has been given: the next one must be greater */
+    uint64_t steals;                /* chunks this context pulled through cl_context_peer_steal's shared counter */
 } cl_peer_stats;
 int cl_context_peer_export(cl_context* ctx, cl_peer_handle* out);
 int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index, const cl_peer_handle* members, uint32_t epoch_base);
 int cl_context_peer_stats(const cl_context* ctx, cl_peer_stats* out);
+/* Work stealing inside the current group: the next chunk number of job `job` from ONE atomic counter in member 0's exported memory (system-scope
+ * atomics of a one-thread kernel: peer atomics over xGMI, no collective, no host exchange).  Every member calls it with the same job number — larger than
+ * any job the group has used — until the chunk it gets is >= its number of chunks; chunk lists are the caller's (centrolign_amd/dist.py: the stitch
+ * subproblems of a merge in LPT order).  Without a group the count is local.  The reference has no counterpart (stitcher.hpp:157-203 runs the subproblems
+ * one after the other). */
+int cl_context_peer_steal(cl_context* ctx, uint32_t job, uint32_t* chunk_out);
 /* Every member of the current group at the same time, with the same token (greater than any earlier one): stores, arrival words and waits
  * once round the group.  CL_OK when the mechanism works between these devices; on CL_ERR_HIP (nothing came within timeout_ms) destroy the
  * context — its stream may be stuck behind a wait — and run merges on single contexts. */

@@ -96,3 +96,58 @@ def test_two_ranks_on_one_device_print_the_reference_gfa(tmp_path):
     for k in (0, 1):
         assert int(lines[k].group(2)) == 1 and int(lines[k].group(3)) >= 1 and int(lines[k].group(4)) > 16 and int(lines[k].group(5)) > 16, lines[k].group(0)
     assert lines[0].group(6) == want
+
+
+def test_two_contexts_steal_chunks_from_one_counter(gpu_ctx):
+    """cl_context_peer_steal inside ONE process: two member contexts (threads) pull the chunks of a stitch batch from the counter word in member 0's memory;
+    every chunk is run exactly once and the pieces together are the unsharded result"""
+    from centrolign_amd import dist as cd
+    batch = synth.random_dag_batch(160, seed=33, max_n=50)
+    want = gpu_ctx.stitch_batch_align(batch)
+    n_chunks = len(cd.steal_chunks(batch, 5000))
+    assert n_chunks > 8
+    members = [capi.Context(0), capi.Context(0)]
+    try:
+        handles = [c.peer_export() for c in members]
+        for i, c in enumerate(members):
+            c.peer_group(handles, i, 1)
+        out, errors = [None, None], []
+
+        def run(i):
+            try:
+                out[i] = cd.stitch_by_stealing(members[i], batch, lambda: members[i].peer_steal(3), chunk_cells=5000)
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        [t.start() for t in threads]
+        [t.join(timeout=300) for t in threads]
+        assert not errors, errors
+        assert sorted(out[0][2] + out[1][2]) == list(range(n_chunks))
+        got = {}
+        for idx, res, _ in out:
+            for j, k in enumerate(idx):
+                got[int(k)] = res.alignment(j)
+        assert len(got) == batch.n_problems
+        for k in range(batch.n_problems):
+            assert np.array_equal(got[k], want.alignment(k)), k
+        assert members[0].peer_stats()["steals"] + members[1].peer_stats()["steals"] == n_chunks + 2   # (each member's last pull finds the list exhausted)
+        # without a group the count is local: one context takes every chunk
+        gpu_ctx.peer_group([], 0, 0)
+        idx, res, took = cd.stitch_by_stealing(gpu_ctx, batch, lambda: gpu_ctx.peer_steal(1), chunk_cells=5000)
+        assert took == list(range(n_chunks)) and sorted(idx.tolist()) == list(range(batch.n_problems))
+    finally:
+        for c in members:
+            c.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_device_steal_stitch_chunks(world):
+    """north_star's work stealing with its production transport: `world` processes on the one device, one atomic counter in rank 0's hipIpc-exported memory,
+    chunks of the LPT-ordered subproblem list; compared with the unsharded pass and the static LPT sharding (tests/steal_child.py)"""
+    port = 29500 + ((os.getpid() + 7 * world) % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "steal_child.py"), "240", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "STEAL OK world=%d" % world in r.stdout, r.stdout[-2000:]
