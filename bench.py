@@ -360,7 +360,27 @@ def main():
             mine = cd.shard_problems(b, world)[rank]
             if len(mine):
                 batches.append((m, b.subset(mine)))
-        stitch_sharding = {"batches": len(every), "dp_cells_all_ranks": int(cells_all), "rule": "LPT by (n1+1)(n2+1) over the ranks, per batch"}
+        stitch_sharding = {"batches": len(every), "dp_cells_all_ranks": int(cells_all), "rule": "LPT by (n1+1)(n2+1) over the ranks, per batch",
+                           "applies_to": "the RESIDENT plans of the timed steps (a plan's share is fixed when it is made)"}
+        # north_star's work stealing, as it would run on batches that are NOT resident: every rank holds every batch, the ranks' contexts form a group and pull
+        # chunks of the LPT-ordered subproblem list (2 M cells each) from ONE atomic counter in rank 0's exported device memory (cl_context_peer_steal: system-scope
+        # atomics over xGMI; no collective).  One untimed-for-the-headline pass, reported beside the static sharding; a failure never costs the line
+        try:
+            big = capi.StitchBatch.concat([b for _, b in every])
+            handles = [None] * world
+            dist.all_gather_object(handles, ctx.peer_export(), group=host_group)
+            ctx.peer_group(handles, rank, 2000)
+            dist.barrier(group=host_group)
+            t0 = time.perf_counter()
+            idx, res_steal, took = cd.stitch_by_stealing(ctx, big, lambda: ctx.peer_steal(1), chunk_cells=2000000)
+            t_steal = cd.max_over_ranks(time.perf_counter() - t0, dist, device="cpu")
+            parts = [None] * world
+            dist.all_gather_object(parts, (len(took), int(sum(((np.diff(big.side[0].node_off).astype(np.int64)[idx] + 1) * (np.diff(big.side[1].node_off).astype(np.int64)[idx] + 1))))), group=host_group)
+            stitch_sharding["work_stealing_pass"] = {"seconds_max_over_ranks": t_steal, "chunk_cells": 2000000, "chunks_and_cells_per_rank": parts,
+                                                     "note": "plan + execute + collect per chunk (nothing resident): not comparable with ms_per_step; what it shows is the balance the one counter gives"}
+            ctx.peer_group([], 0, 0)
+        except Exception as e:   # noqa: BLE001
+            stitch_sharding["work_stealing_pass"] = {"error": repr(e)[:300]}
     if args.debug_skip:
         os.environ["CL_DEBUG_SKIP_TRACEBACK"] = str(args.debug_skip)
     # one context (= one HIP stream set) per batch: the nine merges are independent, their passes run side by side on the device

@@ -33,6 +33,7 @@
 #include "stitch_host.hpp"
 #include "wfa_host.hpp"
 
+hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                                const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_strip(int npw, uint32_t threads, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const ClStripDevice& SD, const uint32_t* slist,
@@ -50,6 +51,7 @@ thread_local std::string g_error;
 // test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
 const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
+const bool g_no_lane = [] { const char* e = getenv("CL_NO_LANE"); return e && *e == '1'; }();   // test hook / A-B: no register kernel for near-chain pairs (popoa_lane_kernel)
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
 const bool g_no_strip = [] { const char* e = getenv("CL_NO_STRIP"); return e && *e == '1'; }();   // test hook: no strips of rows for large branching pairs (popoa_strip_kernel)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
@@ -1062,7 +1064,76 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // further away (the fork in front of a long bubble; column 0 for a late source) are SAVED columns with LDS of their own
             const int sRow = d.n2 < d.n1 ? 1 : 0, sCol = 1 - sRow;
             const uint64_t n_rows = std::min(d.n1, d.n2) + 1, n_cols = std::max(d.n1, d.n2);
-            bool take_sys = !g_no_sys && n_rows <= 1024;
+            // near-chain pairs in registers (popoa_lane_kernel, popoa_lane.h): every node one to four predecessors (a source's boundary index counted), the row
+            // graph's within 4 ranks, the column graph's within 4 columns or in at most sixteen SAVED columns (two per column at most); rows = the shorter graph.
+            // Two shapes of the cell: predecessors up to 2 rows / 3 columns back, or 4 / 4
+            bool take_lane = false;
+            uint32_t lane_dr = 0, lane_dc = 0, lane_slots = 0;
+            std::vector<uint32_t> lane_words;
+            if (!g_no_lane && !g_force_general && n_rows <= 1024 && n_cols < (1u << 28)) {
+                const uint32_t nR = (uint32_t)n_rows - 1, nCl = (uint32_t)n_cols;
+                const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
+                const uint8_t* rl = P.lab[sRow].data() + d.node_base[sRow];
+                const uint32_t* cp = P.poff[sCol].data() + d.node_base[sCol];
+                const uint8_t* cl = P.lab[sCol].data() + d.node_base[sCol];
+                uint32_t max_rd = 0;
+                bool ok = true;
+                for (uint32_t i = 1; i <= nR && ok; ++i) {
+                    if (rp[i] - rp[i - 1] + (rl[i - 1] >> 7) == 0) ok = false;
+                    for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) max_rd = std::max(max_rd, i - P.pidx[sRow][e]);
+                }
+                ok = ok && max_rd <= 4;
+                for (int shape = max_rd <= 2 ? 0 : 1; shape < 2 && ok && !take_lane; ++shape) {
+                    const uint32_t near = shape == 0 ? 3u : 4u;
+                    std::vector<uint32_t> far;
+                    uint32_t max_cd = 0;
+                    bool fits = true;
+                    for (uint32_t j = 1; j <= nCl && fits; ++j) {
+                        uint32_t nf = 0;
+                        if (cp[j] - cp[j - 1] + (cl[j - 1] >> 7) == 0) fits = false;
+                        for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
+                            const uint32_t dist = j - P.pidx[sCol][e];
+                            if (dist > near) { far.push_back(P.pidx[sCol][e]); ++nf; } else max_cd = std::max(max_cd, dist);
+                        }
+                        if (nf > 2) fits = false;
+                    }
+                    std::sort(far.begin(), far.end());
+                    far.erase(std::unique(far.begin(), far.end()), far.end());
+                    if (!fits || far.size() > 16 || far.size() * n_rows * (1 + npw) * 4 > 64 * 1024) continue;
+                    take_lane = true;
+                    lane_dr = shape == 0 ? 2 : 4; lane_dc = near; lane_slots = (uint32_t)far.size();
+                    // shortest walk from a source, in nodes (the boundary cells' closed form)
+                    lane_words.assign(2ull * nR + 2ull * nCl, 0u);
+                    uint32_t* rowrec = lane_words.data(), *rowdist = rowrec + nR, *colrec = rowdist + nR, *coldist = colrec + nCl;
+                    for (uint32_t i = 1; i <= nR; ++i) {
+                        uint32_t mask = 0, best = (rl[i - 1] >> 7) ? 1u : UINT32_MAX;
+                        for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) {
+                            const uint32_t pr = P.pidx[sRow][e];
+                            mask |= 1u << (i - pr - 1);
+                            best = std::min(best, rowdist[pr - 1] == UINT32_MAX ? UINT32_MAX : rowdist[pr - 1] + 1);
+                        }
+                        rowdist[i - 1] = best;
+                        rowrec[i - 1] = mask | ((uint32_t)(rl[i - 1] >> 7) << 4) | ((uint32_t)(rl[i - 1] & 0x7Fu) << 8);
+                        if (best == UINT32_MAX) take_lane = false;   // (not reachable from a source: never in an extracted subgraph)
+                    }
+                    for (uint32_t j = 1; j <= nCl; ++j) {
+                        uint32_t mask = 0, nf = 0, slots = 0, best = (cl[j - 1] >> 7) ? 1u : UINT32_MAX;
+                        for (uint32_t e = cp[j - 1]; e < cp[j]; ++e) {
+                            const uint32_t q = P.pidx[sCol][e];
+                            if (j - q <= near) mask |= 1u << (j - q - 1);
+                            else { slots |= (uint32_t)(std::lower_bound(far.begin(), far.end(), q) - far.begin()) << (20 + 4 * nf); ++nf; }
+                            best = std::min(best, coldist[q - 1] == UINT32_MAX ? UINT32_MAX : coldist[q - 1] + 1);
+                        }
+                        coldist[j - 1] = best;
+                        const auto self = std::lower_bound(far.begin(), far.end(), j);
+                        const uint32_t keep = self != far.end() && *self == j ? (1u << 15) | ((uint32_t)(self - far.begin()) << 16) : 0u;
+                        colrec[j - 1] = mask | ((uint32_t)(cl[j - 1] >> 7) << 4) | (nf << 5) | ((uint32_t)(cl[j - 1] & 0x7Fu) << 8) | keep | slots;
+                        if (best == UINT32_MAX) take_lane = false;
+                    }
+                    if (!take_lane) break;
+                }
+            }
+            bool take_sys = !take_lane && !g_no_sys && n_rows <= 1024;
             uint32_t sys_log = 0;
             uint64_t sys_bytes = 0;
             uint64_t near_limit = 8;
@@ -1113,7 +1184,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             for (int attempt = 0; attempt < 2 && !take_strip; ++attempt) {
                 const int sR = attempt == 0 ? sRow : sCol, sC = 1 - sR;
                 const uint64_t nRw = (sR == 0 ? d.n1 : d.n2) + 1ull, nCl = sR == 0 ? d.n2 : d.n1;
-                if (take_sys || g_no_strip || g_force_general || nRw < 192 || cells < 100000 || nCl >= (1u << 28)) continue;
+                if (take_lane || take_sys || g_no_strip || g_force_general || nRw < 192 || cells < 100000 || nCl >= (1u << 28)) continue;
                 strip_rows_side = sR;
                 strip_far.clear();
                 const uint32_t* cp = P.poff[sC].data() + d.node_base[sC];
@@ -1231,7 +1302,17 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                         }
             uint64_t depth = 1;   // a power of two (the kernel masks instead of dividing): enough for every read, or all that fits
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
-            if (take_sys) {
+            if (take_lane) {
+                d.kind = CL_KIND_LANE;
+                d.pad = (uint16_t)(lane_dr | (lane_dc << 4) | (d.n2 < d.n1 ? 0x8000u : 0u));   // DR | DC << 4 | rows = graph 2
+                d.aux_base = (uint32_t)P.sys_aux.size();   // rowrec | rowdist | colrec | coldist (popoa_lane.h)
+                d.aux_cnt = lane_slots;
+                P.sys_aux.insert(P.sys_aux.end(), lane_words.begin(), lane_words.end());
+                P.ring_need.push_back((uint32_t)(lane_slots * n_rows * (1 + npw) * 4));
+                // the hand-off rows between the strips of 64 rows lie behind the planes: [strips - 1][DR][1 + NumPW][columns]
+                const uint64_t n_strips = (n_rows - 1 + 63) / 64;
+                P.plane_cursor += ((n_strips - 1) * lane_dr * (1 + npw) * n_cols + 3) / 4 * 4;
+            } else if (take_sys) {
                 d.kind = CL_KIND_SYS;
                 d.pad = (uint16_t)(sys_log | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | rows = graph 2
                 d.aux_base = (uint32_t)P.sys_aux.size();   // {near limit, the saved columns ascending}
@@ -1313,7 +1394,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             for (int s = 0; s < 2; ++s) { d.node_base[s] += lab_base[s]; d.snk_base[s] += snk_base[s]; }
             d.plane_base += plane_cursor;
             d.out_base += (uint32_t)out_cursor;
-            if (d.kind == CL_KIND_SYS || d.kind == CL_KIND_STRIP) d.aux_base += aux_base;
+            if (d.kind == CL_KIND_SYS || d.kind == CL_KIND_STRIP || d.kind == CL_KIND_LANE) d.aux_base += aux_base;
             pl->po_index[P.po_problem[i]] = (int32_t)pl->desc.size();
             pl->desc.push_back(d);
             pl->po_problem.push_back(P.po_problem[i]);
@@ -1373,6 +1454,27 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * pl->desc[plist[i]].npw);
         }
         auto sweep = [&](uint32_t x) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 + (pl->desc[x].npw == 3 ? 64 : 0); };
+        std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return sweep(x) > sweep(y); });
+        pl->groups.push_back(grp);
+    }
+    // near-chain pairs in registers: one launch per workgroup shape as well (strips of 64 rows over 1 / 4 / 16 waves), longest sweep first
+    for (int gi = 0; gi < 3; ++gi) {
+        LaunchGroup grp;
+        const int lane_waves[3] = {8, 4, 1};   // (sixteen waves would leave a wave 128 registers: the 4 / 4 shape at NumPW 3 needs 180)
+        grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = lane_waves[gi];
+        grp.first = (uint32_t)plist.size();
+        for (uint32_t i = 0; i < pl->desc.size(); ++i) {
+            const ClProbDesc& d = pl->desc[i];
+            const uint32_t rows = std::min(d.n1, d.n2);
+            if (d.kind == CL_KIND_LANE && (rows <= 64 ? 1 : rows <= 256 ? 4 : 8) == grp.waves) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
+        }
+        grp.count = (uint32_t)plist.size() - grp.first;
+        if (!grp.count) continue;
+        for (uint32_t i = grp.first; i < plist.size(); ++i) {
+            grp.cells += cells_of(plist[i]);
+            grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * pl->desc[plist[i]].npw);
+        }
+        auto sweep = [&](uint32_t x) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 + 96ull * (std::min(pl->desc[x].n1, pl->desc[x].n2) / 64); };
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return sweep(x) > sweep(y); });
         pl->groups.push_back(grp);
     }
@@ -1545,6 +1647,7 @@ static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const C
         if (e != hipSuccess) return e;
         return cl_launch_popoa_strip(g.npw, (uint32_t)g.block, g.count, g.ring_bytes, dev, pl->sdev, pl->d_strip_list.p + g.first, pl->sparams, stream);
     }
+    if (g.kind == CL_KIND_LANE) return cl_launch_popoa_lane(g.waves, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     if (g.kind == CL_KIND_SYS) return cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
 }
@@ -1698,6 +1801,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
     if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
+    else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), "popoa_lane_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
     else if (g.kind == CL_KIND_STRIP) snprintf(out->kernel, sizeof(out->kernel), "popoa_strip_kernel<%d> x %d", g.npw, g.block);
     else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);

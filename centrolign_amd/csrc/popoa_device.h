@@ -13,7 +13,7 @@
 #define CL_NEG_INF (INT32_MIN / 2)  // cell_t::mininf, alignment.hpp:740
 
 // kernel families
-enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1, CL_KIND_SYS = 2, CL_KIND_STRIP = 3 };   // SYS: the systolic DAG kernel (popoa_sys_kernel); STRIP: the same sweep for
+enum { CL_KIND_GENERAL = 0, CL_KIND_LINEAR = 1, CL_KIND_SYS = 2, CL_KIND_STRIP = 3, CL_KIND_LANE = 4 };   // LANE: near-chain pairs in registers (popoa_lane_kernel, popoa_lane.h)   // SYS: the systolic DAG kernel (popoa_sys_kernel); STRIP: the same sweep for
                                                                                        // pairs whose rows do not fit one workgroup's LDS (popoa_strip_kernel)
 
 struct ClProbDesc {

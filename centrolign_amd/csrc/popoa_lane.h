@@ -1,0 +1,336 @@
+// popoa_lane.h — popoa_lane_kernel: the register / DPP systolic sweep of popoa_linear_kernel (popoa_linear.hip) for NEAR-CHAIN graph pairs.  Included by
+// popoa_kernels.hip inside its anonymous namespace (DiagGeom, Planes, plane_store, traceback_wave are that file's).
+//
+// Same recurrences as every other PO-POA kernel here — the reference's po_poa_internal in pull form (include/centrolign/alignment.hpp:813-938; SURVEY.md
+// Appendix A) — for the pairs that bound a stitch pass of a progressive MSA: the long sweeps of BASELINE configs[2] are all pairs of graphs that are chains
+// but for a few SNP / short-indel bubbles (predecessors 1-3 ranks back, in-degree 2, rarely 3) and one or two forks in front of a bubble as long as a repeat
+// unit (a predecessor 2 059 ranks back).  popoa_sys_kernel gives such a pair a thread per row, an LDS ring per row and a workgroup barrier per step: 0.6-0.8 us
+// per step, 70 % of a wave's cycles parked on the barrier / LDS round trip (profiles/r04_pmc_summary.json).  Here nothing but registers and DPP moves is touched
+// in a step of the usual cell, and waves never wait for one another inside a chunk of 32 steps:
+//   * rows (the shorter graph) lie across the lanes, strips of 64 rows, one row per lane; lane l of a strip works on column t - l + 1 at step t;
+//   * ROW predecessors (1 .. DR ranks back) arrive on a CONVEYOR: stage d of lane l holds M and the row-consuming gap values V_k of row a - d at the lane's
+//     current column — stage 1 is wave_shr:1 of the upper lane's last cell, stage d wave_shr:1 of the upper lane's stage d - 1 one step earlier;
+//   * COLUMN predecessors 1 .. DC columns back are the lane's own history registers (M, H_k), the diagonal terms the history of the conveyor's M;
+//     a column that a later column reaches from further away is a SAVED column as in popoa_sys_kernel: its cells go to LDS ([slot][row]: M, H_k), and only
+//     lanes whose column has such a predecessor read them (a wave-divergent branch taken a few dozen steps per pair);
+//   * the boundary row and column are closed forms: a boundary cell's gap value is -(open_k + extend_k * L) with L the number of nodes on the shortest walk
+//     from a source (alignment.hpp:832-894 on a DAG: the maximum over walks of a value that only depends on the walk's length); the host packs L per node
+//     (topology, no DP arithmetic), the prologue writes those cells' planes;
+//   * a node's predecessors are a MASK over the distances (any subset of 1 .. DR / 1 .. DC), a source flag (the boundary index is a predecessor) and, for
+//     columns, up to two saved columns: every maximum below runs over all distances with the absent ones forced to -inf, so the usual cell is branch-free;
+//   * strips are pipelined over the W waves of the workgroup exactly as in popoa_linear_kernel: chunks of 32 steps, one barrier per chunk, strip s + 1
+//     three chunks behind strip s, the last DR rows of a strip handed on through a small area behind the planes (M, V_k per column);
+//   * the int32 planes go to HBM anti-diagonal-major, fire and forget, as in popoa_sys_kernel: traceback_wave reads them afterwards.
+// Model of the data movement, checked against the plain pull-form DP: scripts/dev/nearchain_model.py.
+//
+// Records (host: cl_api.cpp, pack_lane_problem), uint32 each, at ClDeviceBatch::aux + ClProbDesc::aux_base: rowrec[nR] | rowdist[nR] | colrec[nC] | coldist[nC]
+//   rowrec: bits 0-3 predecessor distances (bit d - 1) | bit 4 source | bits 8-14 label
+//   colrec: bits 0-3 near predecessor distances | bit 4 source | bits 5-6 number of saved-column predecessors | bits 8-14 label | bit 15 this column is saved,
+//           bits 16-19 in that slot | bits 20-23, 24-27 the slots of its saved-column predecessors
+//   *dist : nodes on the shortest walk from a source to the node, the node included
+// ClProbDesc::pad: bit 15 rows = graph 2 | bits 0-3 DR needed | bits 4-7 DC needed;  aux_cnt = saved columns (LDS: aux_cnt * (nR + 1) * (1 + NumPW) ints)
+
+constexpr uint32_t kLaneChunk = 32;
+constexpr uint32_t kLaneLag = 2 + 62 / kLaneChunk;
+
+// lane l <- lane l-1 ; lane 0 <- fill (wave_shr:1) / lane l <- lane l+1 (wave_shl:1): gfx9-family whole-wave DPP controls, as in popoa_linear.hip
+__device__ __forceinline__ int32_t lane_shift_in(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t lane_rotate_down(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+
+template <int NPW>
+__device__ __forceinline__ int32_t lane_bnd_gap(const ClScoreParams& P, int k, uint32_t len) { return -P.oe[k] - (int32_t)(len - 1) * P.ext[k]; }
+template <int NPW>
+__device__ __forceinline__ int32_t lane_bnd_m(const ClScoreParams& P, uint32_t len) {
+    int32_t m = lane_bnd_gap<NPW>(P, 0, len);
+#pragma unroll
+    for (int k = 1; k < NPW; ++k) m = imax(m, lane_bnd_gap<NPW>(P, k, len));
+    return m;
+}
+
+template <int NPW, int DR, int DC, int W>
+__device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* __restrict__ saved) {
+    constexpr uint32_t C = kLaneChunk;
+    constexpr int CW = 1 + NPW;   // a saved cell: M, H_k
+    const bool swap = pd.pad & 0x8000u;
+    const uint32_t nR = swap ? pd.n2 : pd.n1, nC = swap ? pd.n1 : pd.n2;
+    const uint32_t* const rowrec = B.aux + pd.aux_base;
+    const uint32_t* const rowdist = rowrec + nR;
+    const uint32_t* const colrec = rowdist + nR;
+    const uint32_t* const coldist = colrec + nC;
+    const DiagGeom G(pd.n1, pd.n2);
+    Planes<NPW> pl;
+    pl.base = B.planes + pd.plane_base;
+    pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // V = the gap family that consumes ROW nodes, H = column nodes: I / D of the reference when the rows are graph 1, D / I when they are graph 2
+    g_i32* pV[NPW];
+    g_i32* pH[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        pV[k] = uniform_plane(pl.base + (size_t)(swap ? 1 + NPW + k : 1 + k) * pl.cells);
+        pH[k] = uniform_plane(pl.base + (size_t)(swap ? 1 + k : 1 + NPW + k) * pl.cells);
+    }
+    g_i32* const pM = uniform_plane(pl.base);
+    // hand-off rows between strips, behind the planes: [strip][DR][1 + NPW][nC] int32
+    int32_t* const brow = pl.base + (((size_t)pl.cells * (1 + 2 * NPW) + 3) & ~(size_t)3);
+    const uint32_t S = (nR + 63u) / 64u, Cn = (nC + 63u + C - 1) / C;
+    auto cell_index = [&](uint32_t row, uint32_t col) { return swap ? G.idx(col, row) : G.idx(row, col); };
+
+    // ---- prologue: the boundary cells' planes (closed forms; the traceback reads them) ----
+    if (!(B.skip_traceback & 2)) {
+        for (uint32_t i = tid; i <= nR; i += 64 * W) {
+            const uint32_t pb = cell_index(i, 0) * 4u;
+            const uint32_t len = i ? rowdist[i - 1] : 0u;
+            plane_store(pM, pb, i ? lane_bnd_m<NPW>(P, len) : CL_NEG_INF);
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) {
+                plane_store(pV[k], pb, i ? lane_bnd_gap<NPW>(P, k, len) : CL_NEG_INF);
+                plane_store(pH[k], pb, CL_NEG_INF);
+            }
+        }
+        for (uint32_t j = tid + 1; j <= nC; j += 64 * W) {
+            const uint32_t pb = cell_index(0, j) * 4u;
+            const uint32_t len = coldist[j - 1];
+            plane_store(pM, pb, lane_bnd_m<NPW>(P, len));
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) {
+                plane_store(pV[k], pb, CL_NEG_INF);
+                plane_store(pH[k], pb, lane_bnd_gap<NPW>(P, k, len));
+            }
+        }
+    }
+
+    const uint32_t Pm = Cn > kLaneLag * W ? Cn : kLaneLag * W;   // macro-step period of one round of W strips
+    const uint32_t total = ((S - 1) / W) * Pm + kLaneLag * ((S - 1) % W) + Cn;
+
+    // per-strip register state
+    int32_t lastM = CL_NEG_INF, lastV[NPW];
+    int32_t convM[DR], convV[DR][NPW], convMh[DR][DC];
+    int32_t Mh[DC], Hh[NPW][DC], bMh[DC];
+    int32_t crec = 0, cbm = CL_NEG_INF;
+    int32_t frec = 0, fbm = CL_NEG_INF, fM[DR], fV[DR][NPW];
+    uint32_t rrec = 0, labR = 0, row = 0;      // this lane's row (1-based; 0 = none)
+    int32_t ownBnd = CL_NEG_INF, predBnd[DR];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) lastV[k] = CL_NEG_INF;
+#pragma unroll
+    for (int d = 0; d < DR; ++d) {
+        convM[d] = CL_NEG_INF; fM[d] = CL_NEG_INF; predBnd[d] = CL_NEG_INF;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) { convV[d][k] = CL_NEG_INF; fV[d][k] = CL_NEG_INF; }
+#pragma unroll
+        for (int e = 0; e < DC; ++e) convMh[d][e] = CL_NEG_INF;
+    }
+#pragma unroll
+    for (int e = 0; e < DC; ++e) {
+        Mh[e] = CL_NEG_INF; bMh[e] = CL_NEG_INF;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) Hh[k][e] = CL_NEG_INF;
+    }
+
+    for (uint32_t m = 0; m < total; ++m) {
+        const int32_t mm = (int32_t)m - (int32_t)(kLaneLag * wave);
+        if (mm >= 0) {
+            const uint32_t j = (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = j * W + wave;
+            if (s < S && c < Cn) {
+                if (c == 0) {
+                    // a new strip: this lane's row and what is fixed for it
+                    row = s * 64u + lane + 1u;
+                    const bool real = row <= nR;
+                    rrec = real ? rowrec[row - 1] : 0u;
+                    labR = (rrec >> 8) & 0x7Fu;
+                    ownBnd = real ? lane_bnd_m<NPW>(P, rowdist[row - 1]) : CL_NEG_INF;
+#pragma unroll
+                    for (int d = 0; d < DR; ++d) predBnd[d] = (real && row > (uint32_t)(d + 1)) ? lane_bnd_m<NPW>(P, rowdist[row - 2 - d]) : CL_NEG_INF;
+                    lastM = CL_NEG_INF; crec = 0; cbm = CL_NEG_INF;
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) lastV[k] = CL_NEG_INF;
+#pragma unroll
+                    for (int d = 0; d < DR; ++d) {
+                        convM[d] = CL_NEG_INF;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) convV[d][k] = CL_NEG_INF;
+#pragma unroll
+                        for (int e = 0; e < DC; ++e) convMh[d][e] = CL_NEG_INF;
+                    }
+#pragma unroll
+                    for (int e = 0; e < DC; ++e) {
+                        Mh[e] = CL_NEG_INF; bMh[e] = CL_NEG_INF;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) Hh[k][e] = CL_NEG_INF;
+                    }
+                }
+                const uint32_t t0 = c * C;
+                {   // this chunk's C columns as lane 0 will see them: records, the boundary row's Mf, the rows above the strip
+                    const uint32_t colb = t0 + lane + 1;
+                    const bool v = lane < C && colb <= nC;
+                    frec = v ? (int32_t)colrec[colb - 1] : 0;
+                    fbm = v ? lane_bnd_m<NPW>(P, coldist[colb - 1]) : CL_NEG_INF;
+                    if (s > 0) {
+                        const int32_t* src = brow + (size_t)(s - 1) * DR * CW * nC + (colb - 1);
+#pragma unroll
+                        for (int d = 0; d < DR; ++d) {
+                            fM[d] = v ? src[(size_t)(d * CW) * nC] : CL_NEG_INF;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) fV[d][k] = v ? src[(size_t)(d * CW + 1 + k) * nC] : CL_NEG_INF;
+                        }
+                    }
+                }
+                int32_t* const bout = brow + (size_t)s * DR * CW * nC;
+                const bool hands_on = s + 1 < S && lane >= 64u - DR;
+                const bool real = row <= nR;
+                const uint32_t rmask = rrec & 0xFu;
+                const bool rsrc = (rrec >> 4) & 1u;
+                for (uint32_t jj = 0; jj < C; ++jj) {
+                    const uint32_t t = t0 + jj;
+                    // histories of what the moves below replace: the conveyor's M and the boundary row's Mf one step ago
+#pragma unroll
+                    for (int d = 0; d < DR; ++d) {
+#pragma unroll
+                        for (int e = DC - 1; e > 0; --e) convMh[d][e] = convMh[d][e - 1];
+                        convMh[d][0] = convM[d];
+                    }
+#pragma unroll
+                    for (int e = DC - 1; e > 0; --e) bMh[e] = bMh[e - 1];
+                    bMh[0] = cbm;
+                    // the conveyor moves one lane: stage d takes the upper lane's stage d - 1, stage 1 its last cell; lane 0 the rows above the strip
+#pragma unroll
+                    for (int d = DR - 1; d > 0; --d) {
+                        convM[d] = lane_shift_in(convM[d - 1], fM[d]);
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) convV[d][k] = lane_shift_in(convV[d - 1][k], fV[d][k]);
+                    }
+                    convM[0] = lane_shift_in(lastM, fM[0]);
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) convV[0][k] = lane_shift_in(lastV[k], fV[0][k]);
+                    if (s > 0) {
+#pragma unroll
+                        for (int d = 0; d < DR; ++d) {
+                            fM[d] = lane_rotate_down(fM[d]);
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) fV[d][k] = lane_rotate_down(fV[d][k]);
+                        }
+                    }
+                    crec = lane_shift_in(crec, frec);
+                    frec = lane_rotate_down(frec);
+                    cbm = lane_shift_in(cbm, fbm);
+                    fbm = lane_rotate_down(fbm);
+                    const uint32_t b = t - lane + 1;   // this lane's column (1-based); wraps while the lane has not started
+                    if ((uint32_t)(b - 1) < nC && real) {
+                        const uint32_t cr = (uint32_t)crec;
+                        const uint32_t cmask = cr & 0xFu, nfar = (cr >> 5) & 3u;
+                        const bool csrc = (cr >> 4) & 1u;
+                        const int32_t sc = (labR == ((cr >> 8) & 0x7Fu)) ? P.match : -P.mismatch;
+                        int32_t V[NPW], H[NPW], Md = CL_NEG_INF;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; H[k] = CL_NEG_INF; }
+                        // row predecessors (a - d - 1 .. ): M and V_k at this column from the conveyor, the diagonal terms from its history
+#pragma unroll
+                        for (int d = 0; d < DR; ++d) {
+                            const bool on = (rmask >> d) & 1u;
+                            const int32_t mu = on ? convM[d] : CL_NEG_INF;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(mu - P.oe[k], (on ? convV[d][k] : CL_NEG_INF) - P.ext[k]));
+#pragma unroll
+                            for (int e = 0; e < DC; ++e) Md = imax(Md, (on && ((cmask >> e) & 1u)) ? convMh[d][e] : CL_NEG_INF);
+                            Md = imax(Md, (on && csrc) ? predBnd[d] : CL_NEG_INF);
+                        }
+                        if (rsrc) {   // the boundary row is a predecessor: opens only (alignment.hpp:907-916 with p == n1), diagonal from Mf(0, q), the corner counts 0
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], cbm - P.oe[k]);
+#pragma unroll
+                            for (int e = 0; e < DC; ++e) Md = imax(Md, ((cmask >> e) & 1u) ? bMh[e] : CL_NEG_INF);
+                            Md = imax(Md, csrc ? 0 : CL_NEG_INF);
+                        }
+                        // column predecessors: the lane's own history
+#pragma unroll
+                        for (int e = 0; e < DC; ++e) {
+                            const bool on = (cmask >> e) & 1u;
+                            const int32_t ml = on ? Mh[e] : CL_NEG_INF;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) H[k] = imax(H[k], imax(ml - P.oe[k], (on ? Hh[k][e] : CL_NEG_INF) - P.ext[k]));
+                        }
+                        if (csrc) {
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) H[k] = imax(H[k], ownBnd - P.oe[k]);
+                        }
+                        if (nfar) {   // saved-column predecessors (the fork in front of a long bubble): LDS, a few dozen steps per pair
+                            for (uint32_t f = 0; f < nfar; ++f) {
+                                const uint32_t slot = (cr >> (20 + 4 * f)) & 0xFu;
+                                const int32_t* col = saved + (size_t)slot * (nR + 1) * CW;
+                                const int32_t* mine = col + (size_t)row * CW;
+                                const int32_t ml = mine[0];
+#pragma unroll
+                                for (int k = 0; k < NPW; ++k) H[k] = imax(H[k], imax(ml - P.oe[k], mine[1 + k] - P.ext[k]));
+#pragma unroll
+                                for (int d = 0; d < DR; ++d)
+                                    if ((rmask >> d) & 1u) Md = imax(Md, col[(size_t)(row - 1 - d) * CW]);
+                                if (rsrc) Md = imax(Md, col[0]);
+                            }
+                        }
+                        int32_t Mf = Md + sc;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) Mf = imax(Mf, imax(V[k], H[k]));
+                        if (!(B.skip_traceback & 2)) {
+                            const uint32_t pb = cell_index(row, b) * 4u;
+                            plane_store(pM, pb, Mf);
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) {
+                                plane_store(pV[k], pb, V[k]);
+                                plane_store(pH[k], pb, H[k]);
+                            }
+                        }
+                        // the new cell becomes "one column ago"; the lane below takes M / V_k on its next step
+#pragma unroll
+                        for (int e = DC - 1; e > 0; --e) {
+                            Mh[e] = Mh[e - 1];
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) Hh[k][e] = Hh[k][e - 1];
+                        }
+                        Mh[0] = Mf;
+                        lastM = Mf;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) { Hh[k][0] = H[k]; lastV[k] = V[k]; }
+                        if ((cr >> 15) & 1u) {   // a saved column: its cells stay available for the far reads
+                            int32_t* w = saved + ((size_t)((cr >> 16) & 0xFu) * (nR + 1) + row) * CW;
+                            w[0] = Mf;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) w[1 + k] = H[k];
+                            if (row == 1) saved[(size_t)((cr >> 16) & 0xFu) * (nR + 1) * CW] = cbm;   // the boundary row's Mf at this column
+                        }
+                        if (hands_on) {   // the last DR rows of a full strip feed the next strip's conveyor
+                            int32_t* o = bout + (size_t)((63u - lane) * CW) * nC + (b - 1);
+                            o[0] = Mf;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) o[(size_t)(1 + k) * nC] = V[k];
+                        }
+                    }
+                }
+            }
+        }
+        if (W > 1) __syncthreads();
+    }
+    __syncthreads();   // vmcnt(0): every plane value is in memory
+    if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+}
+
+template <int NPW, int W>
+__device__ __forceinline__ void lane_dispatch(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* saved) {
+    // two shapes of the cell: predecessors up to 2 rows / 3 columns back (every pair of the 10 x 1 Mbp MSA), and up to 4 / 4
+    if ((pd.pad & 0xFu) <= 2u && ((pd.pad >> 4) & 0xFu) <= 3u) lane_body<NPW, 2, 3, W>(B, pd, prob, P, saved);
+    else lane_body<NPW, 4, 4, W>(B, pd, prob, P, saved);
+}
+
+template <int W>
+__global__ void __launch_bounds__(64 * W) popoa_lane_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    const uint32_t prob = plist[blockIdx.x];
+    const ClProbDesc pd = B.desc[prob];
+    switch (pd.npw) {
+    case 1: lane_dispatch<1, W>(B, pd, prob, P, lds); break;
+    case 2: lane_dispatch<2, W>(B, pd, prob, P, lds); break;
+    default: lane_dispatch<3, W>(B, pd, prob, P, lds); break;
+    }
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}

@@ -269,6 +269,82 @@ def far_fork_batch(sizes, seed=0, n_far=3, far_min=200, far_max=1500, alphabet=4
     return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
 
 
+def _bubble_graph_edges(rng, n, p_snp, p_del, n_long, long_min, long_max, alphabet):
+    """a DAG of about n nodes as a progressive MSA makes them: a chain interrupted by SNP bubbles (fork -> one of two single nodes -> join), short deletion bubbles (a stretch
+    of 1-3 nodes that an edge jumps over) and n_long LONG bubbles (two branches of long_min .. long_max nodes: the whole-repeat-unit indel, whose fork is read from a repeat
+    unit further on).  Built in topological positions; returns (labels, edges, sources, sinks) with ids shuffled as _random_dag does"""
+    edges, tails, k = [], None, 0            # tails: nodes the next node hangs under
+    def node():
+        nonlocal k
+        k += 1
+        return k - 1
+    long_at = sorted(int(x) for x in rng.integers(0, max(1, n), n_long))
+    while k < n or tails is None:
+        here = k
+        if long_at and here >= long_at[0]:
+            long_at.pop(0)
+            la, lb = int(rng.integers(long_min, long_max + 1)), int(rng.integers(0, 4))   # one branch a repeat unit long, the other short or empty (an indel)
+            fork = tails
+            ends = []
+            for length in (la, lb):
+                prev = fork
+                for _ in range(length):
+                    v = node()
+                    for u in (prev or []):
+                        edges.append((u, v))
+                    prev = [v]
+                ends += prev if length else (fork or [])
+            tails = ends if fork is not None or ends else None
+            if tails is None:
+                continue
+            continue
+        x = rng.random()
+        if x < p_snp and tails is not None:
+            a, b = node(), node()
+            for u in tails:
+                edges.append((u, a)); edges.append((u, b))
+            tails = [a, b]
+        elif x < p_snp + p_del and tails is not None:
+            skip_from = tails
+            prev = tails
+            for _ in range(int(rng.integers(1, 4))):
+                v = node()
+                for u in prev:
+                    edges.append((u, v))
+                prev = [v]
+            tails = list(dict.fromkeys(prev + skip_from))
+        else:
+            v = node()
+            for u in (tails or []):
+                edges.append((u, v))
+            tails = [v]
+    v = node()                                # one closing node: a single sink
+    for u in tails:
+        edges.append((u, v))
+    n_nodes = k
+    indeg = np.zeros(n_nodes, np.int64)
+    for _, w in edges:
+        indeg[w] += 1
+    sources = [i for i in range(n_nodes) if indeg[i] == 0]
+    perm = rng.permutation(n_nodes)
+    order = rng.permutation(len(edges))
+    edges = list(dict.fromkeys((int(perm[edges[i][0]]), int(perm[edges[i][1]])) for i in order))
+    labels = rng.integers(1, 1 + alphabet, size=n_nodes, dtype=np.uint8)
+    return labels, edges, [int(perm[i]) for i in sources], [int(perm[n_nodes - 1])]
+
+
+def near_chain_batch(sizes, seed=0, p_snp=0.04, p_del=0.03, n_long=(0, 1), long_min=150, long_max=400, alphabet=4, related=True):
+    """graph pairs shaped like the long stitch subproblems of a progressive MSA over HOR arrays (scripts/dev/batch_structure.py on the 10 x 1 Mbp batches): chains with
+    SNP and short deletion bubbles (predecessors 1-3 ranks back) and, in the second graph of a pair, n_long[1] long bubbles; what popoa_lane_kernel is for"""
+    rng = np.random.default_rng(seed)
+    b1, b2 = _SideBuilder(), _SideBuilder()
+    for n1, n2 in sizes:
+        for bld, n, nl in ((b1, n1, n_long[0]), (b2, n2, n_long[1])):
+            lab, edges, src, snk = _bubble_graph_edges(rng, n, p_snp, p_del, nl, long_min, long_max, alphabet)
+            bld.add_graph(lab, edges, src, snk, rng.integers(0, 1 << 40, size=len(lab), dtype=np.uint64))
+    return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
+
+
 def hor_stitch_batch(seed, total_len, min_anchor=20, seq_div=0.005, hor_div=0.02, indel_hor=2, max_cells=40000000):
     """between-anchor subproblems of a simulated HOR pair (see module docstring).  Returns (batch, info)."""
     (s1, s2), (a1, a2) = hor_sequences(seed, total_len, 2, seq_div=seq_div, hor_div=hor_div, indel_hor=indel_hor,

@@ -325,3 +325,55 @@ def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
     plan.destroy()
     assert kernels & {"popoa_ring_kernel", "popoa_general_kernel"}, kernels
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+
+
+def _kernels(plan):
+    return {li["kernel"].split("<")[0] for li in plan.launches() if li["n_problems"]}
+
+
+def test_near_chain_pairs_in_registers(gpu_ctx):
+    """popoa_lane_kernel (popoa_lane.h): graph pairs that are chains but for SNP / short-deletion bubbles and a long bubble or two — the long sweeps of a progressive MSA's stitch
+    passes — swept in registers with DPP moves (row predecessors on a conveyor, column predecessors in the lane's history, saved columns in LDS).  Every workgroup shape
+    (1 / 4 / 8 waves: strips of 64 rows pipelined over the waves, hand-off rows behind the planes; more than 512 rows: a second round of strips), both orientations,
+    every NumPW, both shapes of the cell (predecessors 2 rows / 3 columns back, 4 / 4), against the oracle"""
+    # lopsided pairs, the long graph with a long bubble (a saved column): 1 wave, 4 waves, 8 waves, two rounds
+    sizes = [(5, 2100), (30, 700), (64, 300), (65, 400), (165, 2225), (256, 500), (300, 330), (420, 418), (512, 520), (600, 640), (1000, 1010)]
+    b = synth.near_chain_batch(sizes, seed=5, n_long=(0, 1))
+    plan = gpu_ctx.plan(b)
+    plan.execute(); plan.sync()
+    names = [li["kernel"] for li in plan.launches() if li["n_problems"]]
+    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<4>", "popoa_lane_kernel<8>"} <= set(names), names
+    assert sum(li["n_problems"] for li in plan.launches() if li["kernel"].startswith("popoa_lane_kernel")) >= len(sizes) - 1, plan.launches()
+    want = po.oracle_stitch_batch(b)
+    assert plan.collect().same_as(want) is None
+    for _ in range(3):                      # a resident plan executed again
+        plan.execute(); plan.sync()
+        assert plan.collect().same_as(want) is None
+    plan.destroy()
+    # the other orientation (graph 2 gives the rows), long bubbles in the ROW graph too (then it is not a lane pair: whatever kernel takes it must agree)
+    for seed, nl in ((6, (1, 0)), (7, (1, 1)), (8, (0, 2))):
+        b = synth.near_chain_batch([(700, 30), (2100, 12), (300, 64), (500, 200), (330, 300), (90, 90)], seed=seed, n_long=nl)
+        assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None, (seed, nl)
+    # every NumPW forced, tie-heavy parameters (match = mismatch = 1: every equality test of the traceback is exercised on the planes this kernel writes)
+    for npw in (1, 2, 3):
+        b = synth.near_chain_batch([(40, 900), (130, 600), (280, 300), (700, 90), (20, 20), (3, 400)], seed=20 + npw, p_snp=0.08, p_del=0.06, n_long=(0, 1))
+        f = np.full(b.n_problems, npw, np.uint8)
+        plan = gpu_ctx.plan(b, force_num_pw=f)
+        assert "popoa_lane_kernel" in _kernels(plan), plan.launches()
+        plan.destroy()
+        got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+        tp = H.tie_params()
+        got = gpu_ctx.po_poa_batch(b, f, tp.alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f, params=tp)) is None, ("ties", npw)
+    # dense bubbles: predecessors up to four ranks back in both graphs (the 4 / 4 shape), in-degrees up to 4, several sources
+    b = synth.sized_dag_batch([(50, 60), (200, 220), (400, 90), (64, 1000), (520, 530), (7, 7), (1, 30), (30, 1)], seed=44, extra_edge_p=0.3, skip_max=3, n_alt=2)
+    plan = gpu_ctx.plan(b)
+    assert "popoa_lane_kernel" in _kernels(plan), plan.launches()
+    plan.destroy()
+    assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+    # many small near-chain pairs in one launch
+    rng = np.random.default_rng(9)
+    sizes = [(int(rng.integers(1, 120)), int(rng.integers(1, 400))) for _ in range(300)]
+    b = synth.near_chain_batch(sizes, seed=10, n_long=(0, 0))
+    assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
