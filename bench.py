@@ -548,8 +548,24 @@ def main():
             # traffic: HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc is a pass of its own and
             # cannot run inside this one); beside it the algorithmic bytes per launch of THIS run — their ratio is the re-read factor
             traffic = traffic_profile["hbm_bytes_per_launch_mean_over_all_launches_of_that_kernel"] if traffic_profile else None
+            traffic_unit = "HBM bytes per launch (FETCH_SIZE and WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes), mean over the kernel's launches in profiles/hbm_traffic_latest.json (NOT launch-matched)"
+            # launch-matched (round 5): profiles/dominant_launches_latest.json holds one row per launch of the timed step — scripts/dominant_launches.sh: kernel trace + FETCH_SIZE +
+            # WRITE_SIZE passes over the step alone — and the rows of THIS run's launches of the dominant kernel (same kernel, subproblems and cells) give the traffic
+            traffic_rows = None
+            try:
+                with open(os.path.join(HERE, "profiles", "dominant_launches_latest.json")) as f:
+                    dl = json.load(f)
+                mine = {(e["n_problems"], e["dp_cells"]) for e in launches if e["kernel"] == dom["kernel"]}
+                rows = [r for r in dl["launches"] if r["kernel"] == dom["kernel"] and (r["subproblems"], r["dp_cells"]) in mine and "hbm_bytes" in r]
+                if rows and len(rows) == len(mine):
+                    traffic = sum(r["hbm_bytes"] for r in rows) / len(rows)
+                    traffic_unit = "HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH.md) of the SAME launches (kernel, subproblems, cells matched) in profiles/dominant_launches_latest.json"
+                    traffic_rows = {"file": "profiles/dominant_launches_latest.json", "command": dl.get("command"), "tree": dl.get("tree"),
+                                    "rows": [{k: r.get(k) for k in ("subproblems", "dp_cells", "algorithmic_bytes", "hbm_bytes", "duration_us_mean", "hbm_over_algorithmic")} for r in rows]}
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE and WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes), mean over the kernel's launches in profiles/hbm_traffic_latest.json",
+                               "traffic_unit": traffic_unit, "traffic_launch_matched": traffic_rows,
                                "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
                                "kernel": dom["kernel"], "merge": dom["merge"], "kernel_launches": agg["launches"], "kernel_ms_all_launches": agg["ms"],
                                "kernel_ms_average": agg["ms"] / agg["launches"], "kernel_bytes_all_launches": agg["bytes"], "kernel_cells_all_launches": agg["cells"],

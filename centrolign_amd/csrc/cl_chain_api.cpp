@@ -1332,6 +1332,33 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         // the events that order the streams ride on the launches that they follow (hipExtLaunchKernel's stop event) instead of being runtime calls of
         // their own: 3 of ~12 calls per macro-block.  CL_CHAIN_EXT_EVENTS=0: hipEventRecord as in rounds 2-3 (A/B)
         static const bool ext_events = [] { const char* e = getenv("CL_CHAIN_EXT_EVENTS"); return !e || e[0] != '0'; }();
+        // Round 5: far(k) goes out as soon as the seal it waits for has been enqueued — at the end of iteration k - lag - 1 instead of iteration k — so that the
+        // serial stream can take far(k)'s event IN FRONT of near(k) (far(k) has had lag + 1 blocks to finish by then) instead of between near(k) and walk(k): there the
+        // cross-stream hop sat between two dependent launches of the serial chain (kernel trace, round 4: gap 7.4 | near 22.8 | gap 14.9 | walk 55.2 us against ~7 us
+        // for a plain launch-to-launch dependency).  CL_CHAIN_FAR_WAIT_LATE=1: as in round 4 (A/B).  Not inside a merge group (the peers' slots are per iteration)
+        static const bool far_early = getenv("CL_CHAIN_FAR_WAIT_LATE") == nullptr;
+        std::vector<uint8_t> far_issued(n_macro, 0);   // 1: far(k) is out, 2: ... and was sent early
+        auto issue_far_bb = [&](uint32_t kk, bool early) -> hipError_t {
+            const uint32_t first_k = kk * kChainMacro, count_k = (uint32_t)std::min<uint64_t>(kChainMacro, M - first_k), near_lo_k = (kk - far_lag) * bpm;
+            hipStream_t far_stream = ctx->aux[kk % far_lag];
+            // every node inside the records [0, prefix[near_lo]) was sealed by seal(kk - lag - 1) or earlier
+            hipError_t e = hipStreamWaitEvent(far_stream, ev_seal[kk - far_lag - 1], 0);
+            // CL_CHAIN_DEBUG_SKIP_FAR=1 (measurements only, WRONG RESULTS): the DP without its far launches = the serial walk / near chain alone,
+            // i.e. what a merge would cost its leader if other devices took the far pass off it
+            static const bool skip_far = getenv("CL_CHAIN_DEBUG_SKIP_FAR") != nullptr;
+            bool recorded = false;
+            if (e == hipSuccess && !skip_far) {
+                // (the launch records ev_far[kk] itself: one runtime call less per macro-block)
+                if (ext_events) { e = cl_ring_event(ctx, 1, kk, &ev_far[kk]); recorded = e == hipSuccess; }
+                if (e == hipSuccess) e = cl_chain_far_launch(D, F, first_k, count_k, near_lo_k, far_stream, recorded ? ev_far[kk] : nullptr);
+            }
+            if (!recorded) {
+                if (e == hipSuccess) e = cl_ring_event(ctx, 1, kk, &ev_far[kk]);
+                if (e == hipSuccess) e = hipEventRecord(ev_far[kk], far_stream);
+            }
+            far_issued[kk] = early ? 2 : 1;
+            return e;
+        };
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
             if (!far_decided && k >= 96 && (k & (k - 1)) == 0) {   // k = 128, 256, 512, ...
                 he = hipStreamSynchronize(ctx->stream);
@@ -1350,13 +1377,12 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             bool far_recorded = false;
             if (near_lo > 0) {
                 hipStream_t far_stream = ctx->aux[k % (use_far ? far_lag : far_streams)];
-                if (use_far && far_bb) {
+                if (far_issued[k]) far_recorded = true;   // (sent at the end of iteration k - lag - 1)
+                else if (use_far && far_bb && !shared) { he = issue_far_bb(k, false); far_recorded = true; }
+                else if (use_far && far_bb) {
                     // every node inside the records [0, prefix[near_lo]) was sealed by seal(k - lag - 1) or earlier
                     he = hipStreamWaitEvent(far_stream, ev_seal[k - lag - 1], 0);
-                    // CL_CHAIN_DEBUG_SKIP_FAR=1 (measurements only, WRONG RESULTS): the DP without its far launches = the serial walk / near chain alone,
-                    // i.e. what a merge would cost its leader if other devices took the far pass off it
-                    static const bool skip_far = getenv("CL_CHAIN_DEBUG_SKIP_FAR") != nullptr;
-                    if (shared) {
+                    {
                         // this member's combinations; what it finds goes into slot k of the others' inboxes, then its arrival word there
                         ClFarDevice Fk = F;
                         // (the slot depends on the epoch's parity too: a member that has gone on to the next shared DP while another still folds the
@@ -1368,11 +1394,6 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                         for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m)
                             if (m != peers.me) he = hipStreamWriteValue32(far_stream, peers.peer_flags[m] + (size_t)peers.me * kPeerRing + slot, word, 0);
                         ++peers.shared_far_launches;
-                    } else
-                    if (he == hipSuccess && !skip_far) {
-                        // (the launch records ev_far[k] itself: one runtime call less per macro-block — the DP is as long as the host needs for its calls)
-                        if (ext_events) { he = cl_ring_event(ctx, 1, k, &ev_far[k]); far_recorded = he == hipSuccess; }
-                        if (he == hipSuccess) he = cl_chain_far_launch(D, F, first, count, near_lo, far_stream, far_recorded ? ev_far[k] : nullptr);
                     }
                 } else if (use_far) {
                     // the all-pairs sweep has taken over (see the checkpoints below); same lag, so that sweeps run side by side
@@ -1394,6 +1415,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 }
             }
             hipEvent_t ev_near_a = nullptr;
+            // the serial stream takes the event of a far(k) that went out early IN FRONT of the near launch (see issue_far_bb above)
+            bool far_waited = false;
+            if (he == hipSuccess && ev_far[k] && far_issued[k] == 2) { he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0); far_waited = true; }
             if (he == hipSuccess && b0 > near_lo) {
                 // the far pass stops at a leaf boundary: the near launch starts there.  Only the records of macro-block k - 1 need walk(k - 1): they
                 // are swept on the serial stream; the older macro-blocks of the near range were final one walk earlier and are swept on a stream
@@ -1413,7 +1437,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess) he = cl_chain_launch_inter(Dn, first, count, b_split, b0, max_recs(b_split, b0) + Dn.lo_mask, kChainNearTile, ctx->stream);
             }
             if (he == hipSuccess && ev_near_a) he = hipStreamWaitEvent(ctx->stream, ev_near_a, 0);
-            if (he == hipSuccess && ev_far[k]) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
+            if (he == hipSuccess && ev_far[k] && !far_waited) he = hipStreamWaitEvent(ctx->stream, ev_far[k], 0);
             if (shared && near_lo > 0) {
                 // the other members' combinations of this macro-block: wait for their arrival words, fold their slot into the running maxima
                 const uint32_t slot = (k + (kPeerRing / 2) * (share_epoch & 1u)) % kPeerRing, word = (share_epoch << 20) | (k + 1);
@@ -1432,6 +1456,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess) he = cl_ring_event(ctx, 2, k, &ev_seal[k]);
                 if (he == hipSuccess) he = cl_chain_far_seal(D, F, d_seal_items.p, seal_off[k], seal_off[k + 1] - seal_off[k], seal_big[k], seal_stream, ext_events ? ev_seal[k] : nullptr);
                 if (he == hipSuccess && !ext_events) he = hipEventRecord(ev_seal[k], seal_stream);
+                if (he == hipSuccess && far_early && !shared) he = issue_far_bb(k + far_lag + 1, true);
             }
         }
         if (use_far && he == hipSuccess) he = hipStreamSynchronize(seal_stream);

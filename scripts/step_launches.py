@@ -1,0 +1,62 @@
+"""The timed stitch step of bench.py alone — the stitch subproblems of the nine merges of BASELINE configs[2] as ONE resident plan, W warm-up passes, K timed passes — for the
+profiler: run under `rocprofv3 --kernel-trace` / `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (scripts/dominant_launches.sh) its dispatches are the step's launches and nothing
+else, so that a per-LAUNCH table (duration, HBM bytes, algorithmic bytes) can be made from one command (profiles/r05_dominant_launches.json).
+The batches come from bench_data/c3_batches.npz (scripts/dev/dump_c3_batches.py; made here by running the MSA when the file is absent).
+usage: python3 scripts/step_launches.py [--steps K] [--warmup W] [--json OUT]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from centrolign_amd import capi  # noqa: E402
+
+
+def load_batch(path):
+    z = np.load(path)
+    sides = [capi.GraphSide(**{k: (z["side%d.%s" % (si, k)] if ("side%d.%s" % (si, k)) in z.files else None) for k in capi._SIDE_DTYPES}) for si in (0, 1)]
+    return capi.StitchBatch(sides[0], sides[1], z["only_deletion_alns"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    path = os.path.join(ROOT, "bench_data", "c3_batches.npz")
+    if not os.path.exists(path):
+        import subprocess
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "dev", "dump_c3_batches.py"), path])
+    batch = load_batch(path)
+    os.environ.setdefault("CL_CTX_STREAMS", "8")      # as bench.py's one-plan layout
+    ctx = capi.Context(0)
+    plan = ctx.plan(batch)
+    for _ in range(args.warmup):
+        plan.execute(); plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps - 1):
+        plan.execute()
+    plan.execute(); plan.sync()
+    import ctypes
+    elapsed = time.perf_counter() - t0
+    st = plan.stats()
+    launches = plan.launches()
+    out = dict(steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, dp_cells=int(st["dp_cells"]), cells_per_s=st["dp_cells"] * args.steps / elapsed,
+               launches=launches)
+    text = json.dumps(out)
+    if args.json:
+        with open(args.json, "w") as f:
+            f.write(text + "\n")
+    print(text)
+    plan.destroy()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,8 @@ VARIANTS = [
     ("near_in_two_launches", {"CL_CHAIN_NEAR_SPLIT": "1"}),
     # the events between the streams as runtime calls of their own (rounds 2-3) instead of riding on the launches they follow
     ("event_records", {"CL_CHAIN_EXT_EVENTS": "0"}),
+    ("far_sent_at_its_own_block", {"CL_CHAIN_FAR_WAIT_LATE": "1"}),   # round 4's order: far(k) enqueued at iteration k, its event taken between near(k) and walk(k)
+    ("far_sent_at_its_own_block_bb", {"CL_CHAIN_FAR_WAIT_LATE": "1", "CL_CHAIN_FAR_MODE": "bb"}),
     # the traceback fetches the query results of the pair it stands on step by step (the way of merges with hundreds of combinations, whose
     # results would be tens of gigabytes) instead of downloading all of them
     ("traceback_rows_on_demand", {"CL_CHAIN_LAZY_ACC": "1"}),
@@ -75,7 +77,7 @@ def dense_input(gpu_ctx, tmp_path_factory):
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
     for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES", "CL_CHAIN_WALK2", "CL_CHAIN_WALK2_QPT",
-              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS", "CL_CHAIN_LAZY_ACC", "CL_CHAIN_WALK_FOLD", "CL_CHAIN_DENSE_QUERIES"):
+              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS", "CL_CHAIN_LAZY_ACC", "CL_CHAIN_WALK_FOLD", "CL_CHAIN_DENSE_QUERIES", "CL_CHAIN_FAR_WAIT_LATE"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
