@@ -99,6 +99,15 @@ constexpr uint32_t kPeerMaxMembers = 8;    // contexts that share the far pass o
 constexpr uint32_t kPeerMaxCombos = 64;    // chain combinations of a DP whose far pass is shared (an inbox slot holds them all)
 constexpr uint32_t kPeerRing = 32;         // inbox slots: a member is never more than 2 * lag + 2 <= 18 macro-blocks ahead of another
 constexpr uint32_t kPeerSlotInts = kPeerMaxCombos * 1024u * 7u;   // (kChainMacro pairs per macro-block)
+// the words behind the inbox slots of an exported allocation (cl_peer_api.cpp), in uint32 units from its `flags` pointer
+constexpr uint32_t kPeerFlagWords = kPeerMaxMembers * kPeerRing;   // arrival words [member][slot]
+constexpr uint32_t kPeerTestWords = kPeerMaxMembers;               // cl_context_peer_selftest: one arrival word per member
+constexpr uint32_t kPeerTestInts = 8 * kPeerMaxMembers;            // ... and where the members' kernels store
+constexpr uint32_t kPeerStealWords = 4;                            // cl_context_peer_steal: the 64-bit counter (member 0's is the group's) + where a steal's answer lands
+constexpr uint32_t kPeerDoneWords = kPeerMaxMembers;               // "member m has folded every slot of shared DP e": the next shared DP's peer stores wait for it
+constexpr uint32_t kPeerStealAt = kPeerFlagWords + kPeerTestWords + kPeerTestInts;
+constexpr uint32_t kPeerDoneAt = kPeerStealAt + kPeerStealWords;
+constexpr uint32_t kPeerTailWords = kPeerDoneAt + kPeerDoneWords;
 
 struct ClFarDevice {
     uint32_t n_levels, r_pad;

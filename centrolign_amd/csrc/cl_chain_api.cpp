@@ -1328,6 +1328,16 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             ++peers.shared_dps;
             F.share_n = peers.n;
             F.share_i = peers.me;
+            // The ring slots of an inbox are reused by the NEXT shared DP: a member that has gone on to it must not store into a slot another member has
+            // not folded yet (round-4 advisor: slots k and k' collide whenever k - k' = 16 mod 32, whatever the epochs' parity).  Every member raises its
+            // "done" word in the others' memory when its serial stream has passed the last block of a shared DP; the far streams — the only ones that
+            // store into other inboxes — wait for the words of the previous shared DP before their first launch of this one
+            for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m) {
+                if (m == peers.me) continue;
+                for (uint32_t f = 0; f < far_lag && he == hipSuccess; ++f)
+                    he = hipStreamWaitValue32(ctx->aux[f], peers.flags + kPeerDoneAt + m, peers.last_shared_epoch, hipStreamWaitValueGte, 0xFFFFFFFFu);
+            }
+            peers.last_shared_epoch = share_epoch;
         }
         // the events that order the streams ride on the launches that they follow (hipExtLaunchKernel's stop event) instead of being runtime calls of
         // their own: 3 of ~12 calls per macro-block.  CL_CHAIN_EXT_EVENTS=0: hipEventRecord as in rounds 2-3 (A/B)
@@ -1458,6 +1468,10 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess && !ext_events) he = hipEventRecord(ev_seal[k], seal_stream);
                 if (he == hipSuccess && far_early && !shared) he = issue_far_bb(k + far_lag + 1, true);
             }
+        }
+        if (shared) {   // this member has folded every slot of the DP (stream order: behind its last walk)
+            for (uint32_t m = 0; m < peers.n && he == hipSuccess; ++m)
+                if (m != peers.me) he = hipStreamWriteValue32(ctx->stream, peers.peer_flags[m] + kPeerDoneAt + peers.me, share_epoch, 0);
         }
         if (use_far && he == hipSuccess) he = hipStreamSynchronize(seal_stream);
         // (the walk path's events are the context's ring events: nothing to destroy)

@@ -52,6 +52,7 @@ struct cl_context {
         int* peer_inbox[8] = {};       // the other members' inboxes and arrival words as this process sees them (index = member)
         uint32_t* peer_flags[8] = {};
         uint32_t epoch = 0;            // one per shared DP, the same on every member; arrival words hold epoch << 20 | macro-block + 1
+        uint32_t last_shared_epoch = 0; // the shared DP before this one (its "done" words are what the next one's peer stores wait for)
         uint32_t epoch_mark = 0;       // the highest epoch this context's inbox has ever been used with: the arrival words are never reset, so a group's
                                        // epoch base must not lie below it (cl_context_peer_group refuses), and
         uint32_t test_mark = 0;        // the highest token of cl_context_peer_selftest (a token at or below it would find its words already there)

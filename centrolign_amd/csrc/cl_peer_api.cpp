@@ -35,12 +35,8 @@ struct HandleBody {                 // what travels inside cl_peer_handle
 static_assert(sizeof(HandleBody) <= sizeof(cl_peer_handle), "handle");
 constexpr uint32_t kMagic = 0x434C5045u;
 constexpr size_t kInboxInts = (size_t)kPeerRing * kPeerSlotInts;
-constexpr size_t kFlagWords = (size_t)kPeerMaxMembers * kPeerRing;
-constexpr size_t kTestWords = kPeerMaxMembers;   // behind the arrival words: one word per member for cl_context_peer_selftest
-constexpr size_t kTestInts = 8 * kPeerMaxMembers;   // the last ints of the inbox's last slot (beyond kPeerMaxCombos combinations nothing is stored there... see below)
-constexpr size_t kStealWords = 4;                   // behind those: the group's work-stealing counter (64 bits, 8-byte aligned) + the word a steal's answer lands in
-constexpr size_t kTailWords = kFlagWords + kTestWords + kTestInts + kStealWords;
-static_assert(((kInboxInts + kFlagWords + kTestWords + kTestInts) * sizeof(uint32_t)) % 8 == 0, "the steal counter is a 64-bit word");
+constexpr size_t kFlagWords = kPeerFlagWords, kTestWords = kPeerTestWords, kTestInts = kPeerTestInts, kTailWords = kPeerTailWords;   // (chain_device.h)
+static_assert(((kInboxInts + kPeerStealAt) * sizeof(uint32_t)) % 8 == 0, "the steal counter is a 64-bit word");
 }
 
 extern "C" {
@@ -103,6 +99,7 @@ int cl_context_peer_group(cl_context* ctx, uint32_t n_members, uint32_t my_index
     P.n = n_members;
     P.me = my_index;
     P.epoch = epoch_base;
+    P.last_shared_epoch = 0;   // (a new group: its members' "done" words refer to DPs shared from now on)
     return CL_OK;
 }
 
@@ -160,8 +157,8 @@ int cl_context_peer_steal(cl_context* ctx, uint32_t job, uint32_t* chunk_out) {
         return CL_OK;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t* tail = (P.me == 0 ? P.flags : P.peer_flags[0]) + kFlagWords + kTestWords + kTestInts;
-    uint32_t* answer = P.flags + kFlagWords + kTestWords + kTestInts + 2;   // in this member's own memory
+    uint32_t* tail = (P.me == 0 ? P.flags : P.peer_flags[0]) + kPeerStealAt;
+    uint32_t* answer = P.flags + kPeerStealAt + 2;   // in this member's own memory
     HIP_TRY(ctx, cl_peer_steal(reinterpret_cast<unsigned long long*>(tail), job, answer, ctx->stream));
     uint32_t got = 0;
     HIP_TRY(ctx, cl_copy_sync(ctx, &got, answer, sizeof(got), hipMemcpyDeviceToHost));
