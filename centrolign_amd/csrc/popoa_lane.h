@@ -110,6 +110,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     int32_t crec = 0, cbm = CL_NEG_INF;
     int32_t frec = 0, fbm = CL_NEG_INF, fM[DR], fV[DR][NPW];
     uint32_t rrec = 0, labR = 0, row = 0;      // this lane's row (1-based; 0 = none)
+    uint32_t pidx = 0;                         // its current cell in the planes
     int32_t ownBnd = CL_NEG_INF, predBnd[DR];
 #pragma unroll
     for (int k = 0; k < NPW; ++k) lastV[k] = CL_NEG_INF;
@@ -271,14 +272,21 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                         int32_t Mf = Md + sc;
 #pragma unroll
                         for (int k = 0; k < NPW; ++k) Mf = imax(Mf, imax(V[k], H[k]));
+                        // where the cell lies in the anti-diagonal-major planes: closed form at the lane's first column, then one step along the column axis —
+                        // idx(a1, a2 + 1) - idx(a1, a2) = hi(d) + 1 - lo(d + 1) with d = a1 + a2, one more when the columns are graph 1 (DiagGeom)
+                        if (b == 1) pidx = cell_index(row, 1);
                         if (!(B.skip_traceback & 2)) {
-                            const uint32_t pb = cell_index(row, b) * 4u;
+                            const uint32_t pb = pidx * 4u;
                             plane_store(pM, pb, Mf);
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) {
                                 plane_store(pV[k], pb, V[k]);
                                 plane_store(pH[k], pb, H[k]);
                             }
+                        }
+                        {
+                            const uint32_t dg = row + b;
+                            pidx += (dg < pd.n1 ? dg : pd.n1) + (swap ? 2u : 1u) - (dg + 1 > pd.n2 ? dg + 1 - pd.n2 : 0u);
                         }
                         // the new cell becomes "one column ago"; the lane below takes M / V_k on its next step
 #pragma unroll

@@ -34,3 +34,12 @@ def test_plan_and_formats():
     test_io.test_induced_pairwise_cigar_matches_the_reference()
     test_despecify.test_golden()
     test_extraction.test_concatenated_batches_hold_the_same_problems()
+
+
+@pytest.mark.parametrize("tag,routes", [("ad_linear", (3, 4)), ("w_linear", (5,)), ("w_dags", (5,)), ("mixed_dags", (1, 2, 3, 4, 6))])
+def test_host_routes_of_do_alignment(tag, routes):
+    """pure deletion, greedy_partial_alignment, deletion_wfa_po_poa and pwfa_po_poa (include/centrolign/alignment.hpp:1178-2338) against the compiled
+    reference's committed results (tests/golden/host_routes.npz, made by tests/golden/make_golden.py from Stitcher::subalign): the independent check of the
+    two WFA variants on the GPU box — they are host algorithms, the goldens are the reference's own output (missing #4)"""
+    from tests import test_host_routes
+    test_host_routes.test_host_routes_match_reference_golden(tag, routes)
