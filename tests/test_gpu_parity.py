@@ -251,7 +251,8 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
     plan.destroy()
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
     # pairs of different NumPW in one plan: their strip launches run side by side on different streams, each with progress words of its own
-    b = synth.sized_dag_batch([(600, 700), (1500, 900), (400, 2000), (1200, 1200), (800, 500), (2000, 700)], seed=21, extra_edge_p=0.05, skip_max=3)
+    # (more than 1 024 rows each: shorter near-chain pairs are popoa_lane_kernel's since round 5)
+    b = synth.sized_dag_batch([(1100, 1200), (1500, 1100), (1300, 2000), (1200, 1200), (1800, 1500), (2000, 1700)], seed=21, extra_edge_p=0.05, skip_max=3)
     f = np.array([2, 3, 1, 2, 3, 1], np.uint8)
     plan = gpu_ctx.plan(b, force_num_pw=f)
     assert len({li["kernel"] for li in plan.launches() if li["kernel"].startswith("popoa_strip_kernel")}) == 3, plan.launches()
