@@ -33,7 +33,7 @@
 #include "stitch_host.hpp"
 #include "wfa_host.hpp"
 
-hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, hipStream_t stream);
+hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, uint32_t* lane_sync /* null: one workgroup per pair */, hipStream_t stream);
 hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist,
                                const ClScoreParams& P, hipStream_t stream);
 hipError_t cl_launch_popoa_strip(int npw, uint32_t threads, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const ClStripDevice& SD, const uint32_t* slist,
@@ -51,7 +51,10 @@ thread_local std::string g_error;
 // test hook: CL_FORCE_GENERAL=1 in the environment routes chain x chain problems to the general kernel too
 const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); return e && *e == '1'; }();
 const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
-const bool g_no_lane = [] { const char* e = getenv("CL_NO_LANE"); return e && *e == '1'; }();   // test hook / A-B: no register kernel for near-chain pairs (popoa_lane_kernel)
+// test hook / A-B, read at every plan creation (tests switch it inside one process): no register kernel for near-chain pairs (popoa_lane_kernel) — the pairs then take
+// the kernels of rounds 1-4 (systolic, strips, rings), which stay the route of everything that is not a near-chain pair
+static bool no_lane_now() { const char* e = getenv("CL_NO_LANE"); return e && *e == '1'; }
+#define g_no_lane no_lane_now()
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
 const bool g_no_strip = [] { const char* e = getenv("CL_NO_STRIP"); return e && *e == '1'; }();   // test hook: no strips of rows for large branching pairs (popoa_strip_kernel)
 const bool g_no_ring = [] { const char* e = getenv("CL_NO_RING"); return e && *e == '1'; }();   // test hook: HBM-plane general kernel only
@@ -647,6 +650,7 @@ struct cl_stitch_plan {
     DevBuf<uint32_t> d_strip_list, d_progress;
     DevBuf<unsigned long long> d_handoff;
     ClStripDevice sdev{};
+    DevBuf<uint32_t> d_lane_sync;                  // wide near-chain pairs (popoa_lane_kernel): progress / done words per group, zeroed in front of every launch
     DevBuf<unsigned long long> d_ticks;            // [2 per launch group] the launches' own clocks (ClDeviceBatch::ticks), zeroed in front of every pass
     std::vector<LaunchGroup> groups;
     ClDeviceBatch dev{};
@@ -675,7 +679,7 @@ void plan_free(cl_stitch_plan* pl) {
     pl->d_planes.release(q); pl->d_out_pairs.release(q); pl->d_out_len.release(q); pl->d_out_status.release(q);
     pl->d_plist.release(q); pl->d_out_score.release(q); pl->d_aux.release(q);
     pl->d_strips.release(q); pl->d_strip_recs.release(q); pl->d_strip_list.release(q); pl->d_progress.release(q); pl->d_handoff.release(q);
-    pl->d_ticks.release(q);
+    pl->d_ticks.release(q); pl->d_lane_sync.release(q);
     for (auto& g : pl->groups) {
         if (g.ev0) (void)hipEventDestroy(g.ev0);
         if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -1069,8 +1073,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // Two shapes of the cell: predecessors up to 2 rows / 3 columns back, or 4 / 4
             bool take_lane = false;
             uint32_t lane_dr = 0, lane_dc = 0, lane_slots = 0;
+            uint64_t lane_lds = 0;
             std::vector<uint32_t> lane_words;
-            if (!g_no_lane && !g_force_general && n_rows <= 1024 && n_cols < (1u << 28)) {
+            // WIDE: more than 1 024 rows — the strips of 64 rows dealt to groups of eight, a workgroup each, on different compute units (popoa_lane.h); at most 128 groups
+            const bool lane_wide = n_rows > 1025;
+            const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 7) / 8 : 1;
+            static const bool no_wide = [] { const char* e = getenv("CL_NO_LANE_WIDE"); return e && *e == '1'; }();   // A/B: wide pairs on popoa_strip_kernel as in round 4
+            if (!g_no_lane && !g_force_general && lane_groups <= 128 && !(lane_wide && (no_wide || g_no_strip)) && n_cols < (1u << 28)) {
                 const uint32_t nR = (uint32_t)n_rows - 1, nCl = (uint32_t)n_cols;
                 const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
                 const uint8_t* rl = P.lab[sRow].data() + d.node_base[sRow];
@@ -1099,12 +1108,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     }
                     std::sort(far.begin(), far.end());
                     far.erase(std::unique(far.begin(), far.end()), far.end());
-                    if (!fits || far.size() > 16 || far.size() * n_rows * (1 + npw) * 4 > 64 * 1024) continue;
-                    take_lane = true;
                     lane_dr = shape == 0 ? 2 : 4; lane_dc = near; lane_slots = (uint32_t)far.size();
+                    lane_lds = (uint64_t)lane_slots * (lane_dr + (lane_wide ? 512 : n_rows - 1) + 1) * (1 + npw) * 4;
+                    if (!fits || far.size() > 16 || lane_lds > 64 * 1024) continue;
+                    take_lane = true;
                     // shortest walk from a source, in nodes (the boundary cells' closed form)
-                    lane_words.assign(2ull * nR + 2ull * nCl, 0u);
-                    uint32_t* rowrec = lane_words.data(), *rowdist = rowrec + nR, *colrec = rowdist + nR, *coldist = colrec + nCl;
+                    lane_words.assign(1 + 2ull * nR + 2ull * nCl, 0u);   // [0]: a wide pair's first progress word (set when the launch groups are made)
+                    uint32_t* rowrec = lane_words.data() + 1, *rowdist = rowrec + nR, *colrec = rowdist + nR, *coldist = colrec + nCl;
                     for (uint32_t i = 1; i <= nR; ++i) {
                         uint32_t mask = 0, best = (rl[i - 1] >> 7) ? 1u : UINT32_MAX;
                         for (uint32_t e = rp[i - 1]; e < rp[i]; ++e) {
@@ -1304,14 +1314,15 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             while (depth < span[0] + span[1] + 1 && 2 * depth * per_diag + topo_bytes <= kRingLdsBytes && depth < 16384) depth *= 2;
             if (take_lane) {
                 d.kind = CL_KIND_LANE;
-                d.pad = (uint16_t)(lane_dr | (lane_dc << 4) | (d.n2 < d.n1 ? 0x8000u : 0u));   // DR | DC << 4 | rows = graph 2
-                d.aux_base = (uint32_t)P.sys_aux.size();   // rowrec | rowdist | colrec | coldist (popoa_lane.h)
+                d.pad = (uint16_t)(lane_dr | (lane_dc << 4) | ((uint32_t)(lane_groups - 1) << 8) | (d.n2 < d.n1 ? 0x8000u : 0u));   // DR | DC << 4 | groups - 1 << 8 | rows = graph 2
+                d.aux_base = (uint32_t)P.sys_aux.size();   // sync | rowrec | rowdist | colrec | coldist (popoa_lane.h)
                 d.aux_cnt = lane_slots;
                 P.sys_aux.insert(P.sys_aux.end(), lane_words.begin(), lane_words.end());
-                P.ring_need.push_back((uint32_t)(lane_slots * n_rows * (1 + npw) * 4));
-                // the hand-off rows between the strips of 64 rows lie behind the planes: [strips - 1][DR][1 + NumPW][columns]
+                P.ring_need.push_back((uint32_t)lane_lds);
+                // the hand-off rows between the strips of 64 rows lie behind the planes: [strips - 1][DR][1 + NumPW][columns]; behind them, for a wide pair, the
+                // saved-column cells a group hands to the next: [groups][saved columns][DR]
                 const uint64_t n_strips = (n_rows - 1 + 63) / 64;
-                P.plane_cursor += ((n_strips - 1) * lane_dr * (1 + npw) * n_cols + 3) / 4 * 4;
+                P.plane_cursor += ((n_strips - 1) * lane_dr * (1 + npw) * n_cols + (lane_groups > 1 ? lane_groups * lane_slots * lane_dr : 0) + 3) / 4 * 4;
             } else if (take_sys) {
                 d.kind = CL_KIND_SYS;
                 d.pad = (uint16_t)(sys_log | (d.n2 < d.n1 ? 0x8000u : 0u));   // log2 H | rows = graph 2
@@ -1466,7 +1477,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         for (uint32_t i = 0; i < pl->desc.size(); ++i) {
             const ClProbDesc& d = pl->desc[i];
             const uint32_t rows = std::min(d.n1, d.n2);
-            if (d.kind == CL_KIND_LANE && (rows <= 64 ? 1 : rows <= 256 ? 4 : 8) == grp.waves) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
+            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : rows <= 256 ? 4 : 8) == grp.waves) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
         }
         grp.count = (uint32_t)plist.size() - grp.first;
         if (!grp.count) continue;
@@ -1477,6 +1488,34 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         auto sweep = [&](uint32_t x) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 + 96ull * (std::min(pl->desc[x].n1, pl->desc[x].n2) / 64); };
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return sweep(x) > sweep(y); });
         pl->groups.push_back(grp);
+    }
+    // wide near-chain pairs: a pair's groups are consecutive workgroups of one launch (they wait for one another: at most 224 workgroups per launch, whole pairs);
+    // their progress / done words are a run of the plan's lane_sync array, zeroed in front of the launch
+    uint32_t lane_sync_words = 0;
+    {
+        LaunchGroup grp;
+        auto open = [&]() { grp = LaunchGroup(); grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = 8; grp.block = 1; grp.first = (uint32_t)plist.size(); grp.prog_first = lane_sync_words; };
+        auto close = [&]() {
+            grp.count = (uint32_t)plist.size() - grp.first;
+            grp.prog_count = lane_sync_words - grp.prog_first;
+            if (grp.count) pl->groups.push_back(grp);
+        };
+        open();
+        std::vector<uint32_t> wide;
+        for (uint32_t i = 0; i < pl->desc.size(); ++i) if (pl->desc[i].kind == CL_KIND_LANE && ((pl->desc[i].pad >> 8) & 0x7Fu)) wide.push_back(i);
+        std::stable_sort(wide.begin(), wide.end(), [&](uint32_t x, uint32_t y) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 > (uint64_t)pl->desc[y].n1 + pl->desc[y].n2; });
+        for (uint32_t i : wide) {
+            const ClProbDesc& d = pl->desc[i];
+            const uint32_t ng = ((d.pad >> 8) & 0x7Fu) + 1u;
+            if ((uint32_t)plist.size() - grp.first + ng > 224) { close(); open(); }
+            sys_aux[d.aux_base] = lane_sync_words;
+            lane_sync_words += 2 * ng;
+            for (uint32_t g2 = 0; g2 < ng; ++g2) plist.push_back(i);
+            grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]);
+            grp.cells += cells_of(i);
+            grp.bytes += cells_of(i) * 4ull * (1 + 2 * d.npw);
+        }
+        close();
     }
     lap("pack + route");
     const int blocks[3] = {64, 256, 1024};
@@ -1579,6 +1618,14 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     {
         auto crit = [&](const LaunchGroup& g) {
             if (g.kind == CL_KIND_STRIP) return g.est_cost;
+            if (g.kind == CL_KIND_LANE && g.block == 1) {   // wide: every 64 rows add a lag of three chunks
+                uint64_t c = 0;
+                for (uint32_t i = g.first; i < g.first + g.count; ++i) {
+                    const ClProbDesc& d = pl->desc[plist[i]];
+                    c = std::max<uint64_t>(c, (uint64_t)std::max(d.n1, d.n2) + 5ull * std::min(d.n1, d.n2) / 2);
+                }
+                return c / 3;
+            }
             uint64_t c = 0;
             for (uint32_t i = g.first; i < g.first + g.count; ++i)
                 c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
@@ -1601,6 +1648,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     if (!pl->strips.empty() && ((rc = pl->d_strips.upload_async(ctx, pl->strips)) || (rc = pl->d_strip_recs.upload_async(ctx, strip_recs)) ||
                                 (rc = pl->d_strip_list.upload_async(ctx, pl->strip_list)) || (rc = pl->d_progress.alloc(ctx, pl->strips.size())) ||
                                 (rc = pl->d_handoff.alloc(ctx, hand_words)))) { plan_free(pl); return rc; }
+    if (lane_sync_words && (rc = pl->d_lane_sync.alloc(ctx, lane_sync_words))) { plan_free(pl); return rc; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cl_set_error(ctx, "upload failed"); plan_free(pl); return CL_ERR_HIP; }
     { static const bool dbg = [] { const char* e = getenv("CL_STRIP_DEBUG_FAIL"); return e && *e == '1'; }(); pl->sdev.debug_fail = dbg ? 1u : 0u; }
     pl->sdev.strips = pl->d_strips.p; pl->sdev.recs = pl->d_strip_recs.p; pl->sdev.handoff = pl->d_handoff.p; pl->sdev.progress = pl->d_progress.p;
@@ -1647,7 +1695,12 @@ static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const C
         if (e != hipSuccess) return e;
         return cl_launch_popoa_strip(g.npw, (uint32_t)g.block, g.count, g.ring_bytes, dev, pl->sdev, pl->d_strip_list.p + g.first, pl->sparams, stream);
     }
-    if (g.kind == CL_KIND_LANE) return cl_launch_popoa_lane(g.waves, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    if (g.kind == CL_KIND_LANE && g.block == 1) {
+        hipError_t e = hipMemsetAsync(pl->d_lane_sync.p + g.prog_first, 0, (size_t)g.prog_count * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        return cl_launch_popoa_lane(g.waves, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, pl->d_lane_sync.p, stream);
+    }
+    if (g.kind == CL_KIND_LANE) return cl_launch_popoa_lane(g.waves, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, nullptr, stream);
     if (g.kind == CL_KIND_SYS) return cl_launch_popoa_sys(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
 }
@@ -1801,11 +1854,15 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
     if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
-    else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), "popoa_lane_kernel<%d>", g.waves);
+    else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), g.block == 1 ? "popoa_lane_kernel<%d, wide>" : "popoa_lane_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
     else if (g.kind == CL_KIND_STRIP) snprintf(out->kernel, sizeof(out->kernel), "popoa_strip_kernel<%d> x %d", g.npw, g.block);
     else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);
     out->n_problems = g.count;
+    if (g.kind == CL_KIND_LANE && g.block == 1) {   // (a wide pair takes a workgroup per group of eight strips: count the pairs)
+        out->n_problems = 0;
+        for (uint32_t i = g.first; i < g.first + g.count; ++i) out->n_problems += i == g.first || pl->plist_host[i] != pl->plist_host[i - 1];
+    }
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;
     out->lds_bytes = g.kind == CL_KIND_LINEAR ? 0u : g.ring_bytes;
@@ -1844,7 +1901,7 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
     {
         std::vector<uint32_t> redo[4];
         for (size_t i = 0; i < npo; ++i)
-            if (status[i] == 9 && pl->desc[i].kind == CL_KIND_STRIP) redo[pl->desc[i].npw].push_back((uint32_t)i);
+            if (status[i] == 9 && (pl->desc[i].kind == CL_KIND_STRIP || pl->desc[i].kind == CL_KIND_LANE)) redo[pl->desc[i].npw].push_back((uint32_t)i);
         bool any = false;
         for (int npw = 1; npw <= 3; ++npw) {
             if (redo[npw].empty()) continue;

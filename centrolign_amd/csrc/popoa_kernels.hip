@@ -1403,13 +1403,18 @@ void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const
 
 // host-callable launcher (C++ linkage, used by cl_api.cpp only)
 // ring_bytes > 0: the LDS-ring variant (every problem of the launch has its ring depth in ClProbDesc::pad and fits ring_bytes)
-hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, hipStream_t stream) {
+hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, uint32_t* lane_sync, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     if (lds_bytes > 64 * 1024) return hipErrorInvalidValue;   // (the planner keeps the saved columns of a pair below that)
+    if (lane_sync) {   // wide pairs: a workgroup per group of eight strips
+        if (W != 8) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((popoa_lane_kernel<8, true>), dim3(n_blocks), dim3(512), lds_bytes, stream, B, plist, P, lane_sync);
+        return hipGetLastError();
+    }
     switch (W) {
-    case 1: hipLaunchKernelGGL((popoa_lane_kernel<1>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P); break;
-    case 4: hipLaunchKernelGGL((popoa_lane_kernel<4>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P); break;
-    case 8: hipLaunchKernelGGL((popoa_lane_kernel<8>), dim3(n_blocks), dim3(512), lds_bytes, stream, B, plist, P); break;
+    case 1: hipLaunchKernelGGL((popoa_lane_kernel<1, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
+    case 4: hipLaunchKernelGGL((popoa_lane_kernel<4, false>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
+    case 8: hipLaunchKernelGGL((popoa_lane_kernel<8, false>), dim3(n_blocks), dim3(512), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

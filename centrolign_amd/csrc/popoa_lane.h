@@ -21,14 +21,24 @@
 //   * strips are pipelined over the W waves of the workgroup exactly as in popoa_linear_kernel: chunks of 32 steps, one barrier per chunk, strip s + 1
 //     three chunks behind strip s, the last DR rows of a strip handed on through a small area behind the planes (M, V_k per column);
 //   * the int32 planes go to HBM anti-diagonal-major, fire and forget, as in popoa_sys_kernel: traceback_wave reads them afterwards.
+//   * WIDE pairs (more rows than one workgroup's eight waves take in a round or two — chain pairs of 4 096 rows and more, branching pairs above 1 024 rows): the strips are
+//     dealt to GROUPS of eight, one workgroup per group, all groups of a pair consecutive workgroups of one launch on different compute units.  Group g's first strip
+//     follows group g - 1's last strip exactly as a strip follows its upper neighbour inside a workgroup, three chunks behind — across compute units that takes a
+//     PROGRESS word per group ("chunks my last strip has finished": release fence at agent scope, then a relaxed store) which wave 0 of the next group polls before every
+//     chunk (then an agent-scope acquire: the compute unit's L1 is not refreshed by another unit's stores); the saved-column cells of a group's last DR rows travel
+//     through a small area behind the hand-off rows.  Every wait is bounded: a group that gives up marks itself failed, the marks propagate, the pair reports status 9
+//     and cl_stitch_plan_collect runs it again on the anti-diagonal kernel (as for popoa_strip_kernel).  The last group waits for every group's "done" mark and runs
+//     the traceback.
 // Model of the data movement, checked against the plain pull-form DP: scripts/dev/nearchain_model.py.
 //
-// Records (host: cl_api.cpp, pack_lane_problem), uint32 each, at ClDeviceBatch::aux + ClProbDesc::aux_base: rowrec[nR] | rowdist[nR] | colrec[nC] | coldist[nC]
+// Records (host: cl_api.cpp), uint32 each, at ClDeviceBatch::aux + ClProbDesc::aux_base: sync | rowrec[nR] | rowdist[nR] | colrec[nC] | coldist[nC]
+//   sync  : a WIDE pair's first progress word in the plan's lane_sync array (progress[groups] | done[groups]); 0 otherwise
 //   rowrec: bits 0-3 predecessor distances (bit d - 1) | bit 4 source | bits 8-14 label
 //   colrec: bits 0-3 near predecessor distances | bit 4 source | bits 5-6 number of saved-column predecessors | bits 8-14 label | bit 15 this column is saved,
 //           bits 16-19 in that slot | bits 20-23, 24-27 the slots of its saved-column predecessors
 //   *dist : nodes on the shortest walk from a source to the node, the node included
-// ClProbDesc::pad: bit 15 rows = graph 2 | bits 0-3 DR needed | bits 4-7 DC needed;  aux_cnt = saved columns (LDS: aux_cnt * (nR + 1) * (1 + NumPW) ints)
+// ClProbDesc::pad: bit 15 rows = graph 2 | bits 0-3 DR needed | bits 4-7 DC needed | bits 8-14 groups - 1 (0: one workgroup);
+// aux_cnt = saved columns (LDS: aux_cnt * (DR + rows of a workgroup + 1) * (1 + NumPW) ints)
 
 constexpr uint32_t kLaneChunk = 32;
 constexpr uint32_t kLaneLag = 2 + 62 / kLaneChunk;
@@ -47,13 +57,17 @@ __device__ __forceinline__ int32_t lane_bnd_m(const ClScoreParams& P, uint32_t l
     return m;
 }
 
-template <int NPW, int DR, int DC, int W>
-__device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* __restrict__ saved) {
+constexpr uint32_t kLaneFailed = 0xFFFFFFFFu;
+constexpr uint32_t kLanePolls = 1u << 20;   // x ~1 us: a group waits about a second for its upper neighbour before it gives the pair up
+
+template <int NPW, int DR, int DC, int W, bool WIDE>
+__device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* __restrict__ saved,
+                                          uint32_t grp, uint32_t* __restrict__ lane_sync) {
     constexpr uint32_t C = kLaneChunk;
     constexpr int CW = 1 + NPW;   // a saved cell: M, H_k
     const bool swap = pd.pad & 0x8000u;
     const uint32_t nR = swap ? pd.n2 : pd.n1, nC = swap ? pd.n1 : pd.n2;
-    const uint32_t* const rowrec = B.aux + pd.aux_base;
+    const uint32_t* const rowrec = B.aux + pd.aux_base + 1;
     const uint32_t* const rowdist = rowrec + nR;
     const uint32_t* const colrec = rowdist + nR;
     const uint32_t* const coldist = colrec + nC;
@@ -74,10 +88,22 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     // hand-off rows between strips, behind the planes: [strip][DR][1 + NPW][nC] int32
     int32_t* const brow = pl.base + (((size_t)pl.cells * (1 + 2 * NPW) + 3) & ~(size_t)3);
     const uint32_t S = (nR + 63u) / 64u, Cn = (nC + 63u + C - 1) / C;
+    // WIDE: this workgroup is group `grp` of n_groups and takes the strips grp * W .. in one round; rows_here = the rows an LDS slot of saved cells spans
+    const uint32_t n_groups = WIDE ? ((pd.pad >> 8) & 0x7Fu) + 1u : 1u;
+    const uint32_t rowbase = WIDE ? grp * W * 64u : 0u;
+    const uint32_t area = (DR + (WIDE ? W * 64u : nR) + 1u) * CW;     // ints per saved column: [0] the boundary row's Mf, [DR - d] ghost rows (unused), [DR + local row]
+    uint32_t* const progress = WIDE ? lane_sync + B.aux[pd.aux_base] : nullptr;
+    uint32_t* const done = WIDE ? progress + n_groups : nullptr;
+    // saved-column cells (M) of a group's last DR rows, for the next group's first rows: behind the hand-off rows, [group][slot][DR]
+    // (kept in the GLOBAL address space: a generic pointer here lets the optimiser fold the "ghost row or LDS" choice below into ONE flat load from a selected address,
+    // and the backend then emits an illegal compare against src_shared_base)
+    g_i32* const sx = (g_i32*)(brow + (size_t)(S > 0 ? S - 1 : 0) * DR * CW * nC);
+    __shared__ uint32_t gave_up;
+    if (WIDE) { if (tid == 0) gave_up = 0; __syncthreads(); }
     auto cell_index = [&](uint32_t row, uint32_t col) { return swap ? G.idx(col, row) : G.idx(row, col); };
 
     // ---- prologue: the boundary cells' planes (closed forms; the traceback reads them) ----
-    if (!(B.skip_traceback & 2)) {
+    if (!(B.skip_traceback & 2) && (!WIDE || grp == 0)) {
         for (uint32_t i = tid; i <= nR; i += 64 * W) {
             const uint32_t pb = cell_index(i, 0) * 4u;
             const uint32_t len = i ? rowdist[i - 1] : 0u;
@@ -101,7 +127,9 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     }
 
     const uint32_t Pm = Cn > kLaneLag * W ? Cn : kLaneLag * W;   // macro-step period of one round of W strips
-    const uint32_t total = ((S - 1) / W) * Pm + kLaneLag * ((S - 1) % W) + Cn;
+    const uint32_t strips_here = WIDE ? (S - grp * W < (uint32_t)W ? S - grp * W : (uint32_t)W) : 0u;
+    const uint32_t total = WIDE ? kLaneLag * (strips_here - 1) + Cn : ((S - 1) / W) * Pm + kLaneLag * ((S - 1) % W) + Cn;
+    bool dead = false;   // WIDE: this group has given the pair up (its upper neighbour did not deliver in time, or failed itself)
 
     // per-strip register state
     int32_t lastM = CL_NEG_INF, lastV[NPW];
@@ -131,8 +159,28 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
 
     for (uint32_t m = 0; m < total; ++m) {
         const int32_t mm = (int32_t)m - (int32_t)(kLaneLag * wave);
-        if (mm >= 0) {
-            const uint32_t j = (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = j * W + wave;
+        if (WIDE && grp > 0 && wave == 0 && !dead && m < Cn) {
+            // chunk m of this group's first strip needs the columns of that chunk from the last row of the group above: its last strip must have finished
+            // m + lag chunks (what the barrier per macro-step guarantees between neighbouring waves of one workgroup)
+            const uint32_t need = m + kLaneLag < Cn ? m + kLaneLag : Cn;
+            uint32_t v = 0, polls = 0;
+            while (true) {
+                v = __hip_atomic_load(progress + (grp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= need || ++polls > kLanePolls) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (v == kLaneFailed || v < need) { if (lane == 0) gave_up = 1; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (this compute unit's L1 may hold lines of the hand-off rows from before they were written)
+        }
+        if (WIDE && grp > 0) {   // the verdict of wave 0 reaches every wave before anybody works on the chunk
+            __syncthreads();
+            if (gave_up && !dead) {
+                dead = true;
+                if (tid == 0) __hip_atomic_store(progress + grp, kLaneFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (mm >= 0 && !dead) {
+            const uint32_t j = WIDE ? 0u : (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = (WIDE ? grp * W : j * W) + wave;
             if (s < S && c < Cn) {
                 if (c == 0) {
                     // a new strip: this lane's row and what is fixed for it
@@ -258,14 +306,20 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                         if (nfar) {   // saved-column predecessors (the fork in front of a long bubble): LDS, a few dozen steps per pair
                             for (uint32_t f = 0; f < nfar; ++f) {
                                 const uint32_t slot = (cr >> (20 + 4 * f)) & 0xFu;
-                                const int32_t* col = saved + (size_t)slot * (nR + 1) * CW;
-                                const int32_t* mine = col + (size_t)row * CW;
+                                const int32_t* col = saved + (size_t)slot * area;
+                                const int32_t* mine = col + (size_t)(DR + row - rowbase) * CW;
                                 const int32_t ml = mine[0];
 #pragma unroll
                                 for (int k = 0; k < NPW; ++k) H[k] = imax(H[k], imax(ml - P.oe[k], mine[1 + k] - P.ext[k]));
 #pragma unroll
                                 for (int d = 0; d < DR; ++d)
-                                    if ((rmask >> d) & 1u) Md = imax(Md, col[(size_t)(row - 1 - d) * CW]);
+                                    if ((rmask >> d) & 1u) {
+                                        const uint32_t pr = row - 1 - d;   // the predecessor row: this workgroup's, or one of the last DR rows of the group above
+                                        int32_t far_m;   // (two loads under a branch: a select between a global and an LDS address makes the backend emit an illegal compare)
+                                        if (WIDE && pr <= rowbase) far_m = sx[((size_t)(grp - 1) * pd.aux_cnt + slot) * DR + (rowbase - pr)];
+                                        else far_m = col[(size_t)(DR + pr - rowbase) * CW];
+                                        Md = imax(Md, far_m);
+                                    }
                                 if (rsrc) Md = imax(Md, col[0]);
                             }
                         }
@@ -300,11 +354,13 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
 #pragma unroll
                         for (int k = 0; k < NPW; ++k) { Hh[k][0] = H[k]; lastV[k] = V[k]; }
                         if ((cr >> 15) & 1u) {   // a saved column: its cells stay available for the far reads
-                            int32_t* w = saved + ((size_t)((cr >> 16) & 0xFu) * (nR + 1) + row) * CW;
+                            const uint32_t slot = (cr >> 16) & 0xFu;
+                            int32_t* w = saved + (size_t)slot * area + (size_t)(DR + row - rowbase) * CW;
                             w[0] = Mf;
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) w[1 + k] = H[k];
-                            if (row == 1) saved[(size_t)((cr >> 16) & 0xFu) * (nR + 1) * CW] = cbm;   // the boundary row's Mf at this column
+                            if (row == rowbase + 1) saved[(size_t)slot * area] = cbm;   // the boundary row's Mf at this column
+                            if (WIDE && hands_on && wave + 1 == strips_here) sx[((size_t)grp * pd.aux_cnt + slot) * DR + (63u - lane)] = Mf;   // for the next group's first rows
                         }
                         if (hands_on) {   // the last DR rows of a full strip feed the next strip's conveyor
                             int32_t* o = bout + (size_t)((63u - lane) * CW) * nC + (b - 1);
@@ -316,29 +372,57 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                 }
             }
         }
+        if (WIDE && grp + 1 < n_groups && wave + 1 == strips_here && mm >= 0 && (uint32_t)mm < Cn && !dead) {
+            // the last strip of the group has finished chunk mm: its hand-off rows (and saved-column cells) become visible to the other compute units, then the count
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(progress + grp, (uint32_t)mm + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (W > 1) __syncthreads();
     }
     __syncthreads();   // vmcnt(0): every plane value is in memory
-    if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+    if (!WIDE) {
+        if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
+        return;
+    }
+    // WIDE: every wave's planes out to the other compute units, then this group's mark; the last group collects the marks and walks back
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done + grp, dead ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (grp + 1 != n_groups || tid >= 64) return;
+    bool ok = !dead;
+    for (uint32_t g2 = 0; g2 + 1 < n_groups && ok; ++g2) {
+        uint32_t v = 0, polls = 0;
+        while ((v = __hip_atomic_load(done + g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++polls <= kLanePolls) __builtin_amdgcn_s_sleep(8);
+        ok = v == 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!ok) {
+        if (lane == 0) { B.out_len[prob] = 0; B.out_status[prob] = 9; }   // cl_stitch_plan_collect runs the pair again, on the anti-diagonal kernel
+        return;
+    }
+    if (!B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
 }
 
-template <int NPW, int W>
-__device__ __forceinline__ void lane_dispatch(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* saved) {
+template <int NPW, int W, bool WIDE>
+__device__ __forceinline__ void lane_dispatch(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* saved, uint32_t grp, uint32_t* lane_sync) {
     // two shapes of the cell: predecessors up to 2 rows / 3 columns back (every pair of the 10 x 1 Mbp MSA), and up to 4 / 4
-    if ((pd.pad & 0xFu) <= 2u && ((pd.pad >> 4) & 0xFu) <= 3u) lane_body<NPW, 2, 3, W>(B, pd, prob, P, saved);
-    else lane_body<NPW, 4, 4, W>(B, pd, prob, P, saved);
+    if ((pd.pad & 0xFu) <= 2u && ((pd.pad >> 4) & 0xFu) <= 3u) lane_body<NPW, 2, 3, W, WIDE>(B, pd, prob, P, saved, grp, lane_sync);
+    else lane_body<NPW, 4, 4, W, WIDE>(B, pd, prob, P, saved, grp, lane_sync);
 }
 
-template <int W>
-__global__ void __launch_bounds__(64 * W) popoa_lane_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
+// WIDE: a pair's groups are consecutive workgroups of the launch (plist repeats the pair once per group); lane_sync: the plan's progress / done words
+template <int W, bool WIDE>
+__global__ void __launch_bounds__(64 * W) popoa_lane_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P, uint32_t* lane_sync) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint32_t prob = plist[blockIdx.x];
+    uint32_t grp = 0;
+    if (WIDE) while (grp < blockIdx.x && plist[blockIdx.x - grp - 1] == prob) ++grp;
     const ClProbDesc pd = B.desc[prob];
     switch (pd.npw) {
-    case 1: lane_dispatch<1, W>(B, pd, prob, P, lds); break;
-    case 2: lane_dispatch<2, W>(B, pd, prob, P, lds); break;
-    default: lane_dispatch<3, W>(B, pd, prob, P, lds); break;
+    case 1: lane_dispatch<1, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync); break;
+    case 2: lane_dispatch<2, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync); break;
+    default: lane_dispatch<3, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync); break;
     }
     if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }

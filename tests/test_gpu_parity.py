@@ -211,10 +211,13 @@ def test_lopsided_and_large_dag_pairs(gpu_ctx):
         assert got.same_as(po.oracle_stitch_batch(small, force_num_pw=f)) is None
 
 
-def test_strips_of_rows_for_large_branching_pairs(gpu_ctx):
-    """popoa_strip_kernel (round 4): branching pairs whose rows do not fit one workgroup's LDS are cut into strips of rows, one workgroup per strip,
+def test_strips_of_rows_for_large_branching_pairs(gpu_ctx, monkeypatch):
+    """(CL_NO_LANE=1: since round 5 near-chain pairs — most of these — take popoa_lane_kernel first; the strips stay the route of large pairs with denser bubbles, and this
+    test keeps them covered on the same inputs as in round 4.)
+    popoa_strip_kernel (round 4): branching pairs whose rows do not fit one workgroup's LDS are cut into strips of rows, one workgroup per strip,
     every strip reading the last rows of the one in front through a hand-off area in HBM while both run.  Against the oracle: both orientations,
     one to twenty strips, sparse and dense bubbles, in-degrees beyond the six predecessors a column record carries, every NumPW"""
+    monkeypatch.setenv("CL_NO_LANE", "1")
     seen = set()
     for kw, sizes in ((dict(), [(2000, 2000), (1000, 10000), (10000, 1000), (700, 900), (3000, 400), (192, 1700)]),
                       (dict(extra_edge_p=0.02, skip_max=2), [(2000, 2000), (5500, 5500), (900, 700), (400, 6000)]),
@@ -295,16 +298,18 @@ def test_strips_that_give_up_are_run_again_by_the_anti_diagonal_kernel():
             "plan.execute(); plan.sync(); got = plan.collect()\n"
             "print(json.dumps(dict(same=got.same_as(po.oracle_stitch_batch(b)) is None, fallbacks=plan.stats()['n_strip_fallbacks'])))\n"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CL_STRIP_DEBUG_FAIL="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CL_STRIP_DEBUG_FAIL="1", CL_NO_LANE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["same"] and res["fallbacks"] >= 2, res
 
 
-def test_dag_pairs_at_the_lds_ceiling(gpu_ctx):
-    """branching pairs whose per-row column rings fill the systolic kernel's LDS budget (launches with 98-160 KB of dynamic LDS), next to
+def test_dag_pairs_at_the_lds_ceiling(gpu_ctx, monkeypatch):
+    """(CL_NO_LANE=1, as for the strips above: the systolic kernel's LDS classes on the inputs of rounds 2-4.)
+    branching pairs whose per-row column rings fill the systolic kernel's LDS budget (launches with 98-160 KB of dynamic LDS), next to
     ones that overflow it and take the strip kernel, the LDS-ring or the HBM-plane kernel: all against the oracle"""
+    monkeypatch.setenv("CL_NO_LANE", "1")
     sizes = [(480, 500), (510, 300), (300, 509), (440, 2000), (1000, 620), (255, 3000), (64, 5000), (150, 4000), (191, 2500), (180, 500)]
     seen = set()
     for kw in (dict(extra_edge_p=0.02, skip_max=2), dict(extra_edge_p=0.05, skip_max=3), dict(extra_edge_p=0.15, skip_max=2)):
@@ -373,6 +378,30 @@ def test_near_chain_pairs_in_registers(gpu_ctx):
     assert "popoa_lane_kernel" in _kernels(plan), plan.launches()
     plan.destroy()
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+    # WIDE pairs: more than 1 024 rows — groups of eight strips, a workgroup each, on different compute units, progress words between them; chain pairs of 4 096 rows
+    # and more take this route too; saved columns whose cells cross a group boundary; every NumPW; a resident plan executed again
+    b = synth.near_chain_batch([(1100, 1200), (2000, 2100), (5000, 1500), (1500, 5200), (1030, 300)], seed=31, n_long=(0, 2), long_min=300, long_max=700)
+    plan = gpu_ctx.plan(b)
+    assert any(li["kernel"] == "popoa_lane_kernel<8, wide>" for li in plan.launches()), plan.launches()
+    want = po.oracle_stitch_batch(b)
+    for _ in range(3):
+        plan.execute(); plan.sync()
+        assert plan.collect().same_as(want) is None
+    assert plan.stats()["n_strip_fallbacks"] == 0
+    plan.destroy()
+    for npw in (1, 2, 3):
+        b = synth.sized_dag_batch([(1300, 1300), (2500, 1100), (1100, 2600)], seed=80 + npw, extra_edge_p=0.1, skip_max=3)
+        f = np.full(b.n_problems, npw, np.uint8)
+        plan = gpu_ctx.plan(b, force_num_pw=f)
+        assert all(li["kernel"] == "popoa_lane_kernel<8, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
+        plan.destroy()
+        got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+    lin = synth.linear_batch([(4100, 4300), (6300, 6300), (4096, 9000)], seed=14)
+    plan = gpu_ctx.plan(lin)
+    assert all(li["kernel"] == "popoa_lane_kernel<8, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
+    plan.destroy()
+    assert gpu_ctx.stitch_batch_align(lin).same_as(po.oracle_stitch_batch(lin)) is None
     # many small near-chain pairs in one launch
     rng = np.random.default_rng(9)
     sizes = [(int(rng.integers(1, 120)), int(rng.integers(1, 400))) for _ in range(300)]
