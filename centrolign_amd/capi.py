@@ -851,6 +851,29 @@ class StitchBatch:
         return StitchBatch(sides[0], sides[1], od)
 
     @staticmethod
+    def from_c(bc):
+        """a StitchBatch over COPIES of the arrays of a cl_stitch_batch the library handed to a callback (StitchBatchC)"""
+        n = int(bc.n_problems)
+
+        def arr(ptr, dt, count):
+            if not ptr:
+                return None
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(max(int(count), 1),))[:int(count)].copy()
+        sides = []
+        for si in range(2):
+            s = bc.side[si]
+            node_off = arr(s.node_off, np.uint64, n + 1)
+            nodes = int(node_off[-1])
+            prev_off = arr(s.prev_off, np.uint64, nodes + 1)
+            next_off = arr(s.next_off, np.uint64, nodes + 1)
+            src_off, snk_off = arr(s.src_off, np.uint64, n + 1), arr(s.snk_off, np.uint64, n + 1)
+            sides.append(GraphSide(node_off=node_off, label=arr(s.label, np.uint8, nodes), prev_off=prev_off, prev_idx=arr(s.prev_idx, np.uint32, prev_off[-1]),
+                                   next_off=next_off, next_idx=None if next_off is None else arr(s.next_idx, np.uint32, next_off[-1]),
+                                   src_off=src_off, src_idx=arr(s.src_idx, np.uint32, src_off[-1]), snk_off=snk_off, snk_idx=arr(s.snk_idx, np.uint32, snk_off[-1]),
+                                   back_translation=arr(s.back_translation, np.uint64, nodes)))
+        return StitchBatch(sides[0], sides[1], arr(bc.only_deletion_alns, np.uint8, n))
+
+    @staticmethod
     def concat(batches):
         sides = []
         for si in range(2):
@@ -1153,7 +1176,7 @@ EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
     "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_peer_steal", "cl_context_memory", "cl_fallback_counters",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
-    "cl_stitch_result_free", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
+    "cl_stitch_result_free", "cl_stitch_result_alloc", "cl_context_set_stitch_hook", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
@@ -1405,6 +1428,40 @@ class Context:
             return StitchResult.from_c(rc)
         finally:
             self.lib.cl_stitch_result_free(C.byref(rc))
+
+    def set_stitch_hook(self, fn, min_cells=0):
+        """cl_context_set_stitch_hook: from now on cl_stitch (hence merge / core_align) on this context hands every extracted batch of at least min_cells DP cells to
+        fn(batch: StitchBatch, params: StitchParams) -> StitchResult for the WHOLE batch in its order, instead of aligning it alone (several devices share a merge's
+        subproblems: centrolign_amd.msa).  fn = None removes the hook."""
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(StitchBatchC), C.POINTER(StitchParams), C.POINTER(StitchResultC))
+        self.lib.cl_context_set_stitch_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        self.lib.cl_stitch_result_alloc.argtypes = [C.POINTER(StitchResultC), C.c_uint64, C.c_uint64]
+        if fn is None:
+            self._check(self.lib.cl_context_set_stitch_hook(self.handle, None, None, 0))
+            self._stitch_hook = None
+            return
+
+        def tramp(_user, _ctx, bc, pc, out):
+            try:
+                res = fn(StitchBatch.from_c(bc.contents), pc.contents)
+                n, tot = res.n_problems, int(res.aln_off[-1])
+                if self.lib.cl_stitch_result_alloc(out, n, tot) != 0:
+                    return -5
+                o = out.contents
+                C.memmove(o.aln_off, np.ascontiguousarray(res.aln_off, np.uint64).ctypes.data, 8 * (n + 1))
+                if tot:
+                    C.memmove(o.pairs, np.ascontiguousarray(res.pairs, np.uint64).ctypes.data, 16 * tot)
+                if n:
+                    C.memmove(o.score, np.ascontiguousarray(res.score, np.int64).ctypes.data, 8 * n)
+                    C.memmove(o.route, np.ascontiguousarray(res.route, np.uint8).ctypes.data, n)
+                    C.memmove(o.num_pw, np.ascontiguousarray(res.num_pw, np.uint8).ctypes.data, n)
+                return 0
+            except Exception as e:   # noqa: BLE001 (an exception must not cross the C frames)
+                self._stitch_hook_error = e
+                return -1
+        cb = HOOK(tramp)
+        self._stitch_hook = cb          # (kept alive as long as the library may call it)
+        self._check(self.lib.cl_context_set_stitch_hook(self.handle, C.cast(cb, C.c_void_p), None, int(min_cells)))
 
     def stitch(self, graph1, graph2, segments, params=None):
         """Stitcher::stitch (include/centrolign/stitcher.hpp:104-206): stitched Alignment as an (n, 2) uint64 array"""

@@ -905,6 +905,27 @@ void cl_stitch_result_free(cl_stitch_result* r) {
     memset(r, 0, sizeof(*r));
 }
 
+int cl_stitch_result_alloc(cl_stitch_result* out, uint64_t n_problems, uint64_t n_pairs) {
+    if (!out) return CL_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    out->n_problems = n_problems;
+    out->aln_off = (uint64_t*)calloc(n_problems + 1, sizeof(uint64_t));
+    out->pairs = (uint64_t*)malloc((n_pairs ? n_pairs : 1) * 2 * sizeof(uint64_t));
+    out->score = (int64_t*)calloc(n_problems ? n_problems : 1, sizeof(int64_t));
+    out->route = (uint8_t*)calloc(n_problems ? n_problems : 1, 1);
+    out->num_pw = (uint8_t*)calloc(n_problems ? n_problems : 1, 1);
+    if (!out->aln_off || !out->pairs || !out->score || !out->route || !out->num_pw) { cl_stitch_result_free(out); return CL_ERR_OUT_OF_MEMORY; }
+    return CL_OK;
+}
+
+int cl_context_set_stitch_hook(cl_context* ctx, cl_stitch_hook_fn fn, void* user, uint64_t min_cells) {
+    if (!ctx) return CL_ERR_INVALID_ARGUMENT;
+    ctx->stitch_hook = fn;
+    ctx->stitch_hook_user = fn ? user : nullptr;
+    ctx->stitch_hook_min_cells = min_cells;
+    return CL_OK;
+}
+
 int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params,
                           const uint8_t* force_num_pw, cl_stitch_plan** plan_out) {
     if (!ctx || !batch || !params || !plan_out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
@@ -2177,7 +2198,23 @@ int cl_stitch(cl_context* ctx, const cl_base_graph* g1, const cl_base_graph* g2,
     if (rc) { if (ctx) ctx->error = g_error; return rc; }
     lap("extraction");
     cl_stitch_result res;
-    rc = cl_stitch_batch_align(ctx, cl_owned_batch_view(ob), params, &res);
+    const cl_stitch_batch* bv = cl_owned_batch_view(ob);
+    bool hooked = false;
+    if (ctx->stitch_hook) {   // several devices take the merge's subproblems (cl_context_set_stitch_hook)
+        uint64_t cells = 0;
+        for (uint64_t q = 0; q < bv->n_problems; ++q) {
+            const uint64_t a = bv->side[0].node_off[q + 1] - bv->side[0].node_off[q], b = bv->side[1].node_off[q + 1] - bv->side[1].node_off[q];
+            if (a && b) cells += (a + 1) * (b + 1);
+        }
+        hooked = cells >= ctx->stitch_hook_min_cells;
+    }
+    if (hooked) {
+        memset(&res, 0, sizeof(res));
+        rc = ctx->stitch_hook(ctx->stitch_hook_user, ctx, bv, params, &res);
+        ++ctx->stitch_hook_calls;
+        if (!rc && res.n_problems != bv->n_problems) { cl_stitch_result_free(&res); set_error(ctx, "the stitch hook returned %llu results for %llu subproblems", (unsigned long long)res.n_problems, (unsigned long long)bv->n_problems); rc = CL_ERR_INVALID_ARGUMENT; }
+        else if (rc) set_error(ctx, "the stitch hook failed (%d)", rc);
+    } else rc = cl_stitch_batch_align(ctx, bv, params, &res);
     lap("batch align");
     cl_owned_batch_free(ob);
     if (rc) return rc;

@@ -60,6 +60,10 @@ struct cl_context {
         uint32_t steal_job = 0, steal_next = 0;   // cl_context_peer_steal without a group: a local counter
         std::vector<std::pair<std::string, void*>> opened;   // IPC handles this context has opened (kept until it is destroyed)
     } peers;
+    // cl_context_set_stitch_hook: the subproblems of a merge aligned by several devices (cl_api.cpp, cl_stitch)
+    int (*stitch_hook)(void*, cl_context*, const cl_stitch_batch*, const cl_stitch_params*, cl_stitch_result*) = nullptr;
+    void* stitch_hook_user = nullptr;
+    uint64_t stitch_hook_min_cells = 0, stitch_hook_calls = 0;
     std::mutex pool_mutex;
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_size;

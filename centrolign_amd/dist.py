@@ -53,6 +53,54 @@ def shard_problems(batch, world):
     return [np.array(sorted(b), dtype=np.int64) for b in bins]
 
 
+def exchange_objects(obj, members, rank, dist, group=None):
+    """every member of `members` (ranks of the host group, the same list on each) gets every member's object, in the list's order — point to point, no collective
+    (a subset of the ranks must not need a process group of its own): pairs meet in rank order, the lower rank sends first"""
+    import pickle
+    import torch
+    out = []
+    blob = torch.from_numpy(np.frombuffer(pickle.dumps(obj, protocol=4), np.uint8).copy())
+
+    def send(dst):
+        dist.send(torch.tensor([blob.numel()], dtype=torch.int64), dst, group=group)
+        dist.send(blob, dst, group=group)
+
+    def recv(src):
+        n = torch.zeros(1, dtype=torch.int64)
+        dist.recv(n, src, group=group)
+        buf = torch.zeros(int(n.item()), dtype=torch.uint8)
+        dist.recv(buf, src, group=group)
+        return pickle.loads(buf.numpy().tobytes())
+    for m in members:
+        if m == rank:
+            out.append(obj)
+        elif rank < m:
+            send(m); out.append(recv(m))
+        else:
+            got = recv(m); send(m); out.append(got)
+    return out
+
+
+def assemble_results(parts, n_problems):
+    """parts: [(problem indices, aln_off, pairs, score, route, num_pw)] covering every problem exactly once -> the batch-order StitchResult"""
+    from .capi import StitchResult
+    lens = np.zeros(n_problems, dtype=np.int64)
+    for pidx, aln_off, _, _, _, _ in parts:
+        lens[pidx] = np.diff(np.asarray(aln_off).astype(np.int64))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    pairs = np.zeros((int(off[-1]), 2), dtype=np.uint64)
+    score = np.zeros(n_problems, np.int64)
+    route = np.zeros(n_problems, np.uint8)
+    num_pw = np.zeros(n_problems, np.uint8)
+    for pidx, aln_off, p, sc, ro, pw in parts:
+        p = np.asarray(p, np.uint64).reshape(-1, 2)
+        for j, k in enumerate(pidx):
+            pairs[int(off[k]):int(off[k + 1])] = p[int(aln_off[j]):int(aln_off[j + 1])]
+        if len(pidx):
+            score[pidx], route[pidx], num_pw[pidx] = sc, ro, pw
+    return StitchResult(off, pairs, score, route, num_pw)
+
+
 def gather_results(result, idx, n_problems, dist, rank):
     """rank 0 receives every rank's (problem indices, StitchResult) and reassembles the batch-order result"""
     from .capi import StitchResult

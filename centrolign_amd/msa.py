@@ -291,14 +291,19 @@ def _in_parallel(contexts, jobs):
 
 
 def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=None, max_num_match_pairs=1250000, max_count=3000,
-                                keep_merges=False, all_ranks=False, workers=1, make_context=None, share_merges=0, min_shared_combos=9):
+                                keep_merges=False, all_ranks=False, workers=1, make_context=None, share_merges=0, min_shared_combos=9,
+                                steal_stitch_cells=4000000, steal_chunk_cells=2000000):
     """progressive_msa over `world` ranks; every rank calls it with the same arguments (its own ctx).  `group` must be a
     host-tensor (gloo) process group.  Rank 0 returns the result dict (root graph, paths, scale, …), the others None — or, with
     all_ranks, their own dict (root None, stats of the merges they ran).  workers > 1: a rank that owns a whole subtree runs its
     independent merges (and its share of the calibrations) side by side on that many contexts of its device, as progressive_msa does.
     share_merges = G > 1 (level 3): a merge whose children were built by different ranks is run by a MERGE GROUP of up to G of the
     node's ranks (cl_peer_api.cpp): both children go to every member, every member runs the merge, and the far pass of its affine
-    chaining DP is divided between the members' devices by chain combination — peer stores into one another's memory, no collective."""
+    chaining DP is divided between the members' devices by chain combination — peer stores into one another's memory, no collective.
+    Inside a merge group the merge's STITCH subproblems are shared as well (north_star: "shard naturally across the GPUs ... for work-stealing only"): a batch of at
+    least steal_stitch_cells DP cells (0 / None: never) goes through the context's stitch hook (cl_context_set_stitch_hook) — every member pulls chunks of
+    steal_chunk_cells cells of the LPT-ordered subproblem list from the group's ONE atomic counter (cl_context_peer_steal: a word in the leader's device memory),
+    aligns them and hands its pieces to the other members over the host group, so that every member goes on with the complete, identical alignment."""
     import torch
     order = leaves_of(tree)
     make_context = make_context or (lambda: capi.Context(getattr(ctx, "device", 0)))
@@ -435,9 +440,25 @@ def progressive_msa_distributed(ctx, sequences, tree, dist, rank, world, group=N
                 g2 = recv_graph(right[0], dist, group)
             stats["graphs_received"] += (rank != left[0]) + (rank != right[0])
             ctx.peer_group([handles[m] for m in members], members.index(rank), epoch0 + 16 * merge_number[newick(t)])
+            hooked = [0]
+            if steal_stitch_cells and hasattr(ctx, "set_stitch_hook"):
+                from . import dist as cd
+                job0 = epoch0 + 16 * merge_number[newick(t)]     # (the steal counter's job numbers grow like the epochs; up to 16 hooked batches per merge)
+
+                def hook(batch, params, members=members, job0=job0):
+                    job = job0 + hooked[0]
+                    hooked[0] += 1
+                    idx, res, took = cd.stitch_by_stealing(ctx, batch, lambda: ctx.peer_steal(job), chunk_cells=steal_chunk_cells, params=params)
+                    parts = cd.exchange_objects((idx, res.aln_off, res.pairs, res.score, res.route, res.num_pw), members, rank, dist, group)
+                    st = stats.setdefault("stitch_stealing", dict(batches=0, chunks_taken=0, problems_taken=0, problems_all=0))
+                    st["batches"] += 1; st["chunks_taken"] += len(took); st["problems_taken"] += len(idx); st["problems_all"] += batch.n_problems
+                    return cd.assemble_results(parts, batch.n_problems)
+                ctx.set_stitch_hook(hook, steal_stitch_cells)
             try:
                 r = ctx.merge(g1, g2, score_scale=scale, max_num_match_pairs=max_num_match_pairs, max_count=max_count)
             finally:
+                if steal_stitch_cells and hasattr(ctx, "set_stitch_hook"):
+                    ctx.set_stitch_hook(None)
                 ctx.peer_group([], 0, 0)
             stats["shared_merges"] = stats.get("shared_merges", 0) + 1
             if rank != left[0]:

@@ -205,6 +205,17 @@ int cl_stitch_batch_align(cl_context* ctx, const cl_stitch_batch* batch, const c
                           cl_stitch_result* out);
 
 void cl_stitch_result_free(cl_stitch_result* r);
+/* arrays of a result for n_problems problems and n_pairs aligned pairs in all, for a caller that fills them itself (a stitch hook); freed by cl_stitch_result_free */
+int  cl_stitch_result_alloc(cl_stitch_result* out, uint64_t n_problems, uint64_t n_pairs);
+
+/* Stitch hook: where the subproblems of ONE merge are aligned by several devices.  When set on a context, cl_stitch (hence cl_core_align, cl_merge) hands every
+ * extracted batch of at least min_cells DP cells to the hook instead of aligning it on this context alone; the hook returns the complete result, in the batch's order
+ * — typically every member of a merge group (cl_context_peer_group) runs the same merge, pulls chunks of the LPT-ordered subproblem list from the group's counter
+ * (cl_context_peer_steal), aligns them with cl_stitch_batch_align and exchanges the pieces with the other members (centrolign_amd/msa.py does that over the
+ * host group).  Subproblems are independent by construction (stitcher.hpp:157-203 only concatenates), so the result is the single-context one bit for bit.
+ * fn == NULL removes the hook.  A non-zero return of the hook fails the call. */
+typedef int (*cl_stitch_hook_fn)(void* user, cl_context* ctx, const cl_stitch_batch* batch, const cl_stitch_params* params, cl_stitch_result* out);
+int  cl_context_set_stitch_hook(cl_context* ctx, cl_stitch_hook_fn fn, void* user, uint64_t min_cells);
 
 /* --- split form: prepare once, execute many times, collect ------------------------------------------- */
 /* Validates, routes, topologically orders and packs the batch, and copies it to HBM (synchronous).

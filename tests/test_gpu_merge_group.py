@@ -96,6 +96,11 @@ def test_two_ranks_on_one_device_print_the_reference_gfa(tmp_path):
     for k in (0, 1):
         assert int(lines[k].group(2)) == 1 and int(lines[k].group(3)) >= 1 and int(lines[k].group(4)) > 16 and int(lines[k].group(5)) > 16, lines[k].group(0)
     assert lines[0].group(6) == want
+    # ... and the root merge's stitch subproblems were shared too: both members pulled chunks from the one counter, together every subproblem exactly once
+    steal = {int(m.group(1)): [int(x) for x in m.groups()[1:]] for m in re.finditer(r"STEAL (\d) batches=(\d+) chunks=(\d+) problems=(\d+) of=(\d+) steals=(\d+)", r.stdout)}
+    assert set(steal) == {0, 1}, r.stdout[-2000:]
+    assert steal[0][0] == steal[1][0] >= 1 and steal[0][3] == steal[1][3] and steal[0][2] + steal[1][2] == steal[0][3], steal
+    assert steal[0][1] + steal[1][1] >= 2 and steal[0][4] >= steal[0][1], steal
 
 
 def test_two_contexts_steal_chunks_from_one_counter(gpu_ctx):
