@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--budget", type=int, default=1250000)
     ap.add_argument("--dup", type=int, default=0, help="duplicated bases of the carriers (default: 3 %% of the length, at least 3000)")
     ap.add_argument("--min-cyclizing-length", type=int, default=None)
+    ap.add_argument("--carriers", type=int, default=0, help="how many sequences carry the tandem duplication (default: every third)")
     ap.add_argument("--twice", action="store_true", help="run again with one worker and compare the text")
     ap.add_argument("--json", default=None)
     ap.add_argument("--log", default=None, help="stderr of the library (CL_CHAIN_TIMING=1) goes here; default gpurun_out/configs4_N_LENGTH[_c].log")
@@ -56,9 +57,11 @@ def main():
     t0 = time.time()
     dup = args.dup or max(3000, args.length * 3 // 100)
     carriers = sorted(set(range(1, args.n, 3)))
+    if args.carriers:
+        carriers = carriers[:args.carriers]
     if args.cyclize:
         seqs = synth.tandem_dup_sequences(43, args.length, args.n, dup, carriers=carriers, hor_div=0.08)
-        rec["workload"] = "tandem_dup_sequences(seed 43, %d, %d, dup %d, carriers every third from 1, hor_div 0.08), balanced tree" % (args.length, args.n, dup)
+        rec["workload"] = "tandem_dup_sequences(seed 43, %d, %d, dup %d, carriers %s, hor_div 0.08), balanced tree" % (args.length, args.n, dup, carriers)
     else:
         seqs = synth.hor_sequences(43, args.length, args.n)
         rec["workload"] = "hor_sequences(seed 43, %d, %d), balanced tree" % (args.length, args.n)
