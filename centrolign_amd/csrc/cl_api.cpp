@@ -1114,7 +1114,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 }
                 ok = ok && max_rd <= 4;
                 for (int shape = max_rd <= 2 ? 0 : 1; shape < 2 && ok && !take_lane; ++shape) {
-                    const uint32_t near = shape == 0 ? 3u : 4u;
+                    const uint32_t near = 3u;   // (the lane's history rings hold the last three columns; further back = a saved column)
                     std::vector<uint32_t> far;
                     uint32_t max_cd = 0;
                     bool fits = true;
@@ -1130,8 +1130,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     std::sort(far.begin(), far.end());
                     far.erase(std::unique(far.begin(), far.end()), far.end());
                     lane_dr = shape == 0 ? 2 : 4; lane_dc = near; lane_slots = (uint32_t)far.size();
-                    lane_lds = (uint64_t)lane_slots * (lane_dr + (lane_wide ? 512 : n_rows - 1) + 1) * (1 + npw) * 4;
-                    if (!fits || far.size() > 16 || lane_lds > 64 * 1024) continue;
+                    // LDS of a workgroup: the hand-off window between neighbouring strips ([waves - 1][DR][1 + NumPW][128 columns]) + the saved columns
+                    const uint64_t lane_w = lane_wide ? 8 : (n_rows - 1 <= 64 ? 1 : n_rows - 1 <= 256 ? 4 : 8);
+                    lane_lds = (lane_w > 1 ? (lane_w - 1) * lane_dr * (1 + npw) * 128 * 4 : 0) + (uint64_t)lane_slots * (lane_dr + (lane_wide ? 512 : n_rows - 1) + 1) * (1 + npw) * 4;
+                    if (!fits || far.size() > 16 || lane_lds > 150 * 1024) continue;
                     take_lane = true;
                     // shortest walk from a source, in nodes (the boundary cells' closed form)
                     lane_words.assign(1 + 2ull * nR + 2ull * nCl, 0u);   // [0]: a wide pair's first progress word (set when the launch groups are made)

@@ -93,6 +93,10 @@ inline hipError_t cl_dev_alloc(cl_context* ctx, size_t bytes, void** out) {
     // a cached block serves a request of at least half its size — small and medium blocks; from 256 MB on the slack is an eighth: a 34 GB request that
     // took a 60 GB block made a context "hold" 87 GB where its arrays needed 61 (50 x 100 kbp root, round 5), which is what the memory model is checked against
     const size_t slack = bytes >= ((size_t)256 << 20) ? bytes / 8 : bytes + (1u << 20);
+    static const bool alloc_log = getenv("CL_ALLOC_LOG") != nullptr;   // measurements (scripts/memory_model.py): every request of 64 MB and more
+    if (alloc_log && bytes >= ((size_t)64 << 20))
+        fprintf(stderr, "[cl_dev_alloc] %.1f MB asked, %s (live before: %.1f MB)\n", bytes / 1048576.0,
+                it != ctx->pool_free.end() && it->first <= bytes + slack ? "a cached block serves it" : "fresh hipMalloc", ctx->dev_live_bytes / 1048576.0);
     if (it != ctx->pool_free.end() && it->first <= bytes + slack) {
         *out = it->second;
         ctx->pool_free_bytes -= it->first;

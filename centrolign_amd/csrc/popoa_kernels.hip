@@ -1405,7 +1405,15 @@ void launch_general_npw(int block, uint32_t n_blocks, uint32_t ring_bytes, const
 // ring_bytes > 0: the LDS-ring variant (every problem of the launch has its ring depth in ClProbDesc::pad and fits ring_bytes)
 hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, uint32_t* lane_sync, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    if (lds_bytes > 64 * 1024) return hipErrorInvalidValue;   // (the planner keeps the saved columns of a pair below that)
+    if (lds_bytes > 150 * 1024) return hipErrorInvalidValue;   // (the planner keeps the hand-off window + the saved columns of a pair below that)
+    static ClDeviceOnce attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function and device
+    attr_once([] {
+        const int cap = 160 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    });
     if (lane_sync) {   // wide pairs: a workgroup per group of eight strips
         if (W != 8) return hipErrorInvalidValue;
         hipLaunchKernelGGL((popoa_lane_kernel<8, true>), dim3(n_blocks), dim3(512), lds_bytes, stream, B, plist, P, lane_sync);

@@ -10,13 +10,20 @@
 //   * rows (the shorter graph) lie across the lanes, strips of 64 rows, one row per lane; lane l of a strip works on column t - l + 1 at step t;
 //   * ROW predecessors (1 .. DR ranks back) arrive on a CONVEYOR: stage d of lane l holds M and the row-consuming gap values V_k of row a - d at the lane's
 //     current column — stage 1 is wave_shr:1 of the upper lane's last cell, stage d wave_shr:1 of the upper lane's stage d - 1 one step earlier;
-//   * COLUMN predecessors 1 .. DC columns back are the lane's own history registers (M, H_k), the diagonal terms the history of the conveyor's M;
+//   * COLUMN predecessors 1 .. 3 columns back are the lane's own history (M, H_k), the diagonal terms the history of the conveyor's M: RINGS of four registers whose
+//     slot numbers are compile-time constants (the step loop is unrolled by four), so that nothing is moved to age a value — a conveyor move writes straight into the
+//     ring slot of its step;
+//   * the usual step — every active lane on a chain row at a chain column: one predecessor one back on both sides, no source, no saved column — is decided per step by
+//     one ballot and takes a straight-line cell of ~25 instructions (popoa_linear_kernel's); any other step takes the general cell below (masks over the distances);
+//   * nothing in a chunk of 32 steps loads from global memory: the chunk's column records are fetched one chunk ahead, and a strip's last DR rows reach the next strip
+//     of the same round through a window of 128 columns in LDS (the next ROUND's first strip, and a WIDE pair's next group, read them from the area behind the planes);
+//     on gfx9 loads and stores share one counter, a load in the loop would wait for every plane store in front of it;
 //     a column that a later column reaches from further away is a SAVED column as in popoa_sys_kernel: its cells go to LDS ([slot][row]: M, H_k), and only
 //     lanes whose column has such a predecessor read them (a wave-divergent branch taken a few dozen steps per pair);
 //   * the boundary row and column are closed forms: a boundary cell's gap value is -(open_k + extend_k * L) with L the number of nodes on the shortest walk
 //     from a source (alignment.hpp:832-894 on a DAG: the maximum over walks of a value that only depends on the walk's length); the host packs L per node
 //     (topology, no DP arithmetic), the prologue writes those cells' planes;
-//   * a node's predecessors are a MASK over the distances (any subset of 1 .. DR / 1 .. DC), a source flag (the boundary index is a predecessor) and, for
+//   * a node's predecessors are a MASK over the distances (any subset of 1 .. DR / 1 .. 3), a source flag (the boundary index is a predecessor) and, for
 //     columns, up to two saved columns: every maximum below runs over all distances with the absent ones forced to -inf, so the usual cell is branch-free;
 //   * strips are pipelined over the W waves of the workgroup exactly as in popoa_linear_kernel: chunks of 32 steps, one barrier per chunk, strip s + 1
 //     three chunks behind strip s, the last DR rows of a strip handed on through a small area behind the planes (M, V_k per column);
@@ -34,7 +41,7 @@
 // Records (host: cl_api.cpp), uint32 each, at ClDeviceBatch::aux + ClProbDesc::aux_base: sync | rowrec[nR] | rowdist[nR] | colrec[nC] | coldist[nC]
 //   sync  : a WIDE pair's first progress word in the plan's lane_sync array (progress[groups] | done[groups]); 0 otherwise
 //   rowrec: bits 0-3 predecessor distances (bit d - 1) | bit 4 source | bits 8-14 label
-//   colrec: bits 0-3 near predecessor distances | bit 4 source | bits 5-6 number of saved-column predecessors | bits 8-14 label | bit 15 this column is saved,
+//   colrec: bits 0-2 near predecessor distances (1 .. 3 columns back) | bit 4 source | bits 5-6 number of saved-column predecessors | bits 8-14 label | bit 15 this column is saved,
 //           bits 16-19 in that slot | bits 20-23, 24-27 the slots of its saved-column predecessors
 //   *dist : nodes on the shortest walk from a source to the node, the node included
 // ClProbDesc::pad: bit 15 rows = graph 2 | bits 0-3 DR needed | bits 4-7 DC needed | bits 8-14 groups - 1 (0: one workgroup);
@@ -42,6 +49,9 @@
 
 constexpr uint32_t kLaneChunk = 32;
 constexpr uint32_t kLaneLag = 2 + 62 / kLaneChunk;
+constexpr uint32_t kLaneWindow = 128;      // columns of hand-off rows kept in LDS per strip boundary: the consumer reads chunk c while the producer writes chunk c + lag
+constexpr uint32_t kLaneFailed = 0xFFFFFFFFu;
+constexpr uint32_t kLanePolls = 1u << 20;   // x ~1 us: a group waits about a second for its upper neighbour before it gives the pair up
 
 // lane l <- lane l-1 ; lane 0 <- fill (wave_shr:1) / lane l <- lane l+1 (wave_shl:1): gfx9-family whole-wave DPP controls, as in popoa_linear.hip
 __device__ __forceinline__ int32_t lane_shift_in(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
@@ -57,14 +67,14 @@ __device__ __forceinline__ int32_t lane_bnd_m(const ClScoreParams& P, uint32_t l
     return m;
 }
 
-constexpr uint32_t kLaneFailed = 0xFFFFFFFFu;
-constexpr uint32_t kLanePolls = 1u << 20;   // x ~1 us: a group waits about a second for its upper neighbour before it gives the pair up
+template <int Q> struct LaneQ { static constexpr int value = Q; };
 
-template <int NPW, int DR, int DC, int W, bool WIDE>
-__device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* __restrict__ saved,
+// LDS of a workgroup: hand-off window [W - 1][DR][1 + NPW][kLaneWindow] ints (W > 1) | saved columns [aux_cnt][DR + rows + 1][1 + NPW]
+template <int NPW, int DR, int W, bool WIDE>
+__device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* __restrict__ lds,
                                           uint32_t grp, uint32_t* __restrict__ lane_sync) {
     constexpr uint32_t C = kLaneChunk;
-    constexpr int CW = 1 + NPW;   // a saved cell: M, H_k
+    constexpr int CW = 1 + NPW;   // a handed-on / saved cell: M, then V_k (hand-off) or H_k (saved column)
     const bool swap = pd.pad & 0x8000u;
     const uint32_t nR = swap ? pd.n2 : pd.n1, nC = swap ? pd.n1 : pd.n2;
     const uint32_t* const rowrec = B.aux + pd.aux_base + 1;
@@ -85,13 +95,15 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
         pH[k] = uniform_plane(pl.base + (size_t)(swap ? 1 + k : 1 + NPW + k) * pl.cells);
     }
     g_i32* const pM = uniform_plane(pl.base);
-    // hand-off rows between strips, behind the planes: [strip][DR][1 + NPW][nC] int32
+    // hand-off rows between strips that are NOT neighbours in one round, behind the planes: [strip][DR][1 + NPW][nC] int32
     int32_t* const brow = pl.base + (((size_t)pl.cells * (1 + 2 * NPW) + 3) & ~(size_t)3);
     const uint32_t S = (nR + 63u) / 64u, Cn = (nC + 63u + C - 1) / C;
     // WIDE: this workgroup is group `grp` of n_groups and takes the strips grp * W .. in one round; rows_here = the rows an LDS slot of saved cells spans
     const uint32_t n_groups = WIDE ? ((pd.pad >> 8) & 0x7Fu) + 1u : 1u;
     const uint32_t rowbase = WIDE ? grp * W * 64u : 0u;
     const uint32_t area = (DR + (WIDE ? W * 64u : nR) + 1u) * CW;     // ints per saved column: [0] the boundary row's Mf, [DR - d] ghost rows (unused), [DR + local row]
+    int32_t* const hand = lds;                                        // the LDS hand-off window
+    int32_t* const saved = lds + (W > 1 ? (W - 1) * DR * CW * kLaneWindow : 0);
     uint32_t* const progress = WIDE ? lane_sync + B.aux[pd.aux_base] : nullptr;
     uint32_t* const done = WIDE ? progress + n_groups : nullptr;
     // saved-column cells (M) of a group's last DR rows, for the next group's first rows: behind the hand-off rows, [group][slot][DR]
@@ -131,31 +143,37 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     const uint32_t total = WIDE ? kLaneLag * (strips_here - 1) + Cn : ((S - 1) / W) * Pm + kLaneLag * ((S - 1) % W) + Cn;
     bool dead = false;   // WIDE: this group has given the pair up (its upper neighbour did not deliver in time, or failed itself)
 
-    // per-strip register state
-    int32_t lastM = CL_NEG_INF, lastV[NPW];
-    int32_t convM[DR], convV[DR][NPW], convMh[DR][DC];
-    int32_t Mh[DC], Hh[NPW][DC], bMh[DC];
-    int32_t crec = 0, cbm = CL_NEG_INF;
-    int32_t frec = 0, fbm = CL_NEG_INF, fM[DR], fV[DR][NPW];
+    // ---- per-strip register state.  Rings: slot Q = the value of the current step (Q = step & 3), slot (Q - e) & 3 the value e steps ago ----
+    int32_t Mh[4], Hh[NPW][4];        // the lane's own cells: Mf and H_k of the last columns
+    int32_t cMh[DR][4];               // conveyor stage d: M of row (own - d - 1) at the lane's current column and at the last columns
+    int32_t cV[DR][NPW], lastV[NPW];  // ... its V_k (current column only); the lane's own V_k of the last column
+    int32_t bMr[4];                   // the boundary row's Mf at the lane's column, travelling with the column record
+    int32_t crec = 0;
+    int32_t frec = 0, fbm = CL_NEG_INF, nrec = 0, nbm = CL_NEG_INF, fM[DR], fV[DR][NPW];
     uint32_t rrec = 0, labR = 0, row = 0;      // this lane's row (1-based; 0 = none)
     uint32_t pidx = 0;                         // its current cell in the planes
     int32_t ownBnd = CL_NEG_INF, predBnd[DR];
+    bool rowslow = false, strip_dr1 = true;
+    auto reset_strip = [&]() {
+        crec = 0;
 #pragma unroll
-    for (int k = 0; k < NPW; ++k) lastV[k] = CL_NEG_INF;
+        for (int q = 0; q < 4; ++q) {
+            Mh[q] = CL_NEG_INF; bMr[q] = CL_NEG_INF;
 #pragma unroll
-    for (int d = 0; d < DR; ++d) {
-        convM[d] = CL_NEG_INF; fM[d] = CL_NEG_INF; predBnd[d] = CL_NEG_INF;
+            for (int k = 0; k < NPW; ++k) Hh[k][q] = CL_NEG_INF;
 #pragma unroll
-        for (int k = 0; k < NPW; ++k) { convV[d][k] = CL_NEG_INF; fV[d][k] = CL_NEG_INF; }
+            for (int d = 0; d < DR; ++d) cMh[d][q] = CL_NEG_INF;
+        }
 #pragma unroll
-        for (int e = 0; e < DC; ++e) convMh[d][e] = CL_NEG_INF;
-    }
+        for (int k = 0; k < NPW; ++k) lastV[k] = CL_NEG_INF;
 #pragma unroll
-    for (int e = 0; e < DC; ++e) {
-        Mh[e] = CL_NEG_INF; bMh[e] = CL_NEG_INF;
+        for (int d = 0; d < DR; ++d) {
+            fM[d] = CL_NEG_INF; predBnd[d] = CL_NEG_INF;
 #pragma unroll
-        for (int k = 0; k < NPW; ++k) Hh[k][e] = CL_NEG_INF;
-    }
+            for (int k = 0; k < NPW; ++k) { cV[d][k] = CL_NEG_INF; fV[d][k] = CL_NEG_INF; }
+        }
+    };
+    reset_strip();
 
     for (uint32_t m = 0; m < total; ++m) {
         const int32_t mm = (int32_t)m - (int32_t)(kLaneLag * wave);
@@ -182,40 +200,43 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
         if (mm >= 0 && !dead) {
             const uint32_t j = WIDE ? 0u : (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = (WIDE ? grp * W : j * W) + wave;
             if (s < S && c < Cn) {
+                const bool real = (s * 64u + lane + 1u) <= nR;
+                const uint32_t t0 = c * C;
+                auto fetch_columns = [&](uint32_t first, int32_t& rec, int32_t& bm) {   // lanes 0 .. C - 1: the records of columns first + 1 ..
+                    const uint32_t colb = first + lane + 1;
+                    const bool v = lane < C && colb <= nC;
+                    rec = v ? (int32_t)colrec[colb - 1] : 0;
+                    bm = v ? lane_bnd_m<NPW>(P, coldist[colb - 1]) : CL_NEG_INF;
+                };
                 if (c == 0) {
                     // a new strip: this lane's row and what is fixed for it
+                    reset_strip();
                     row = s * 64u + lane + 1u;
-                    const bool real = row <= nR;
                     rrec = real ? rowrec[row - 1] : 0u;
                     labR = (rrec >> 8) & 0x7Fu;
                     ownBnd = real ? lane_bnd_m<NPW>(P, rowdist[row - 1]) : CL_NEG_INF;
 #pragma unroll
                     for (int d = 0; d < DR; ++d) predBnd[d] = (real && row > (uint32_t)(d + 1)) ? lane_bnd_m<NPW>(P, rowdist[row - 2 - d]) : CL_NEG_INF;
-                    lastM = CL_NEG_INF; crec = 0; cbm = CL_NEG_INF;
-#pragma unroll
-                    for (int k = 0; k < NPW; ++k) lastV[k] = CL_NEG_INF;
-#pragma unroll
-                    for (int d = 0; d < DR; ++d) {
-                        convM[d] = CL_NEG_INF;
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) convV[d][k] = CL_NEG_INF;
-#pragma unroll
-                        for (int e = 0; e < DC; ++e) convMh[d][e] = CL_NEG_INF;
-                    }
-#pragma unroll
-                    for (int e = 0; e < DC; ++e) {
-                        Mh[e] = CL_NEG_INF; bMh[e] = CL_NEG_INF;
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) Hh[k][e] = CL_NEG_INF;
-                    }
+                    rowslow = real && (rrec & 0x1Fu) != 1u;                           // anything but "one predecessor, the row above"
+                    strip_dr1 = __ballot(real && (rrec & 0xEu)) == 0ull;               // no row of the strip reaches further than one row up: the conveyor's first stage does
+                    fetch_columns(0, nrec, nbm);
                 }
-                const uint32_t t0 = c * C;
-                {   // this chunk's C columns as lane 0 will see them: records, the boundary row's Mf, the rows above the strip
+                // this chunk's columns were fetched a chunk ago; the next chunk's are asked for now and not waited for before the chunk is over
+                frec = nrec; fbm = nbm;
+                fetch_columns(t0 + C, nrec, nbm);
+                const bool from_lds = W > 1 && s > 0 && (WIDE ? wave > 0 : (s % W) != 0);   // the rows above the strip: the previous wave's, through the LDS window ...
+                if (s > 0) {
                     const uint32_t colb = t0 + lane + 1;
                     const bool v = lane < C && colb <= nC;
-                    frec = v ? (int32_t)colrec[colb - 1] : 0;
-                    fbm = v ? lane_bnd_m<NPW>(P, coldist[colb - 1]) : CL_NEG_INF;
-                    if (s > 0) {
+                    if (from_lds) {
+                        const int32_t* src = hand + (size_t)(wave - 1) * DR * CW * kLaneWindow + ((colb - 1) & (kLaneWindow - 1));
+#pragma unroll
+                        for (int d = 0; d < DR; ++d) {
+                            fM[d] = v ? src[(d * CW) * kLaneWindow] : CL_NEG_INF;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) fV[d][k] = v ? src[(d * CW + 1 + k) * kLaneWindow] : CL_NEG_INF;
+                        }
+                    } else {   // ... or the previous round's / group's last strip, from the area behind the planes
                         const int32_t* src = brow + (size_t)(s - 1) * DR * CW * nC + (colb - 1);
 #pragma unroll
                         for (int d = 0; d < DR; ++d) {
@@ -227,34 +248,27 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                 }
                 int32_t* const bout = brow + (size_t)s * DR * CW * nC;
                 const bool hands_on = s + 1 < S && lane >= 64u - DR;
-                const bool real = row <= nR;
+                const bool to_lds = W > 1 && s + 1 < S && (WIDE ? wave + 1 < (uint32_t)W : ((s + 1) % W) != 0);
+                int32_t* const hout = hand + (size_t)wave * DR * CW * kLaneWindow + (size_t)((63u - lane) * CW) * kLaneWindow;
                 const uint32_t rmask = rrec & 0xFu;
                 const bool rsrc = (rrec >> 4) & 1u;
-                for (uint32_t jj = 0; jj < C; ++jj) {
-                    const uint32_t t = t0 + jj;
-                    // histories of what the moves below replace: the conveyor's M and the boundary row's Mf one step ago
+
+                // one step of the sweep; Q = step & 3 names the ring slots.  DRS = conveyor stages that are run (1 when no row of the strip needs more)
+                auto step = [&](auto qc, auto drs, uint32_t t) {
+                    constexpr int Q = decltype(qc)::value, P1 = (Q + 3) & 3, P2 = (Q + 2) & 3, P3 = (Q + 1) & 3, DRS = decltype(drs)::value;
+                    // the conveyor moves one lane: stage d takes the upper lane's stage d - 1 of the last step, stage 1 its last cell; lane 0 the rows above the strip
 #pragma unroll
-                    for (int d = 0; d < DR; ++d) {
+                    for (int d = DRS - 1; d > 0; --d) {
+                        cMh[d][Q] = lane_shift_in(cMh[d - 1][P1], fM[d]);
 #pragma unroll
-                        for (int e = DC - 1; e > 0; --e) convMh[d][e] = convMh[d][e - 1];
-                        convMh[d][0] = convM[d];
+                        for (int k = 0; k < NPW; ++k) cV[d][k] = lane_shift_in(cV[d - 1][k], fV[d][k]);
                     }
+                    cMh[0][Q] = lane_shift_in(Mh[P1], fM[0]);
 #pragma unroll
-                    for (int e = DC - 1; e > 0; --e) bMh[e] = bMh[e - 1];
-                    bMh[0] = cbm;
-                    // the conveyor moves one lane: stage d takes the upper lane's stage d - 1, stage 1 its last cell; lane 0 the rows above the strip
-#pragma unroll
-                    for (int d = DR - 1; d > 0; --d) {
-                        convM[d] = lane_shift_in(convM[d - 1], fM[d]);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) convV[d][k] = lane_shift_in(convV[d - 1][k], fV[d][k]);
-                    }
-                    convM[0] = lane_shift_in(lastM, fM[0]);
-#pragma unroll
-                    for (int k = 0; k < NPW; ++k) convV[0][k] = lane_shift_in(lastV[k], fV[0][k]);
+                    for (int k = 0; k < NPW; ++k) cV[0][k] = lane_shift_in(lastV[k], fV[0][k]);
                     if (s > 0) {
 #pragma unroll
-                        for (int d = 0; d < DR; ++d) {
+                        for (int d = 0; d < DRS; ++d) {
                             fM[d] = lane_rotate_down(fM[d]);
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) fV[d][k] = lane_rotate_down(fV[d][k]);
@@ -262,46 +276,62 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                     }
                     crec = lane_shift_in(crec, frec);
                     frec = lane_rotate_down(frec);
-                    cbm = lane_shift_in(cbm, fbm);
+                    bMr[Q] = lane_shift_in(bMr[P1], fbm);
                     fbm = lane_rotate_down(fbm);
                     const uint32_t b = t - lane + 1;   // this lane's column (1-based); wraps while the lane has not started
-                    if ((uint32_t)(b - 1) < nC && real) {
-                        const uint32_t cr = (uint32_t)crec;
-                        const uint32_t cmask = cr & 0xFu, nfar = (cr >> 5) & 3u;
+                    const bool active = (uint32_t)(b - 1) < nC && real;
+                    const uint32_t cr = (uint32_t)crec;
+                    const bool slow = active && (rowslow || (cr & 0x7Fu) != 1u);
+                    int32_t Mf = CL_NEG_INF, V[NPW], H[NPW];
+                    if (__ballot(slow) == 0ull) {
+                        // the usual step: every active lane on a chain row at a chain column (alignment.hpp:907-936 with one predecessor each)
+                        const int32_t sc = (labR == ((cr >> 8) & 0x7Fu)) ? P.match : -P.mismatch;
+                        Mf = cMh[0][P1] + sc;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) {
+                            V[k] = imax(cMh[0][Q] - P.oe[k], cV[0][k] - P.ext[k]);
+                            H[k] = imax(Mh[P1] - P.oe[k], Hh[k][P1] - P.ext[k]);
+                            Mf = imax(Mf, imax(V[k], H[k]));
+                        }
+                    } else if (active) {
+                        const uint32_t cmask = cr & 0x7u, nfar = (cr >> 5) & 3u;
                         const bool csrc = (cr >> 4) & 1u;
                         const int32_t sc = (labR == ((cr >> 8) & 0x7Fu)) ? P.match : -P.mismatch;
-                        int32_t V[NPW], H[NPW], Md = CL_NEG_INF;
+                        int32_t Md = CL_NEG_INF;
 #pragma unroll
                         for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; H[k] = CL_NEG_INF; }
-                        // row predecessors (a - d - 1 .. ): M and V_k at this column from the conveyor, the diagonal terms from its history
+                        const bool c1 = cmask & 1u, c2 = cmask & 2u, c3 = cmask & 4u;
+                        // row predecessors: M and V_k at this column from the conveyor, the diagonal terms from its history
 #pragma unroll
-                        for (int d = 0; d < DR; ++d) {
+                        for (int d = 0; d < DRS; ++d) {
                             const bool on = (rmask >> d) & 1u;
-                            const int32_t mu = on ? convM[d] : CL_NEG_INF;
+                            const int32_t mu = on ? cMh[d][Q] : CL_NEG_INF;
 #pragma unroll
-                            for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(mu - P.oe[k], (on ? convV[d][k] : CL_NEG_INF) - P.ext[k]));
-#pragma unroll
-                            for (int e = 0; e < DC; ++e) Md = imax(Md, (on && ((cmask >> e) & 1u)) ? convMh[d][e] : CL_NEG_INF);
+                            for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(mu - P.oe[k], (on ? cV[d][k] : CL_NEG_INF) - P.ext[k]));
+                            Md = imax(Md, (on && c1) ? cMh[d][P1] : CL_NEG_INF);
+                            Md = imax(Md, (on && c2) ? cMh[d][P2] : CL_NEG_INF);
+                            Md = imax(Md, (on && c3) ? cMh[d][P3] : CL_NEG_INF);
                             Md = imax(Md, (on && csrc) ? predBnd[d] : CL_NEG_INF);
                         }
-                        if (rsrc) {   // the boundary row is a predecessor: opens only (alignment.hpp:907-916 with p == n1), diagonal from Mf(0, q), the corner counts 0
+                        // the boundary row as a predecessor: opens only (alignment.hpp:907-916 with p == n1), diagonal from Mf(0, q), the corner counts 0
+                        {
+                            const int32_t bnow = rsrc ? bMr[Q] : CL_NEG_INF;
 #pragma unroll
-                            for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], cbm - P.oe[k]);
-#pragma unroll
-                            for (int e = 0; e < DC; ++e) Md = imax(Md, ((cmask >> e) & 1u) ? bMh[e] : CL_NEG_INF);
-                            Md = imax(Md, csrc ? 0 : CL_NEG_INF);
+                            for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], bnow - P.oe[k]);
+                            Md = imax(Md, (rsrc && c1) ? bMr[P1] : CL_NEG_INF);
+                            Md = imax(Md, (rsrc && c2) ? bMr[P2] : CL_NEG_INF);
+                            Md = imax(Md, (rsrc && c3) ? bMr[P3] : CL_NEG_INF);
+                            Md = imax(Md, (rsrc && csrc) ? 0 : CL_NEG_INF);
                         }
-                        // column predecessors: the lane's own history
+                        // column predecessors: the lane's own history; the boundary column opens only
+                        {
+                            const int32_t m1 = c1 ? Mh[P1] : CL_NEG_INF, m2 = c2 ? Mh[P2] : CL_NEG_INF, m3 = c3 ? Mh[P3] : CL_NEG_INF, m0 = csrc ? ownBnd : CL_NEG_INF;
 #pragma unroll
-                        for (int e = 0; e < DC; ++e) {
-                            const bool on = (cmask >> e) & 1u;
-                            const int32_t ml = on ? Mh[e] : CL_NEG_INF;
-#pragma unroll
-                            for (int k = 0; k < NPW; ++k) H[k] = imax(H[k], imax(ml - P.oe[k], (on ? Hh[k][e] : CL_NEG_INF) - P.ext[k]));
-                        }
-                        if (csrc) {
-#pragma unroll
-                            for (int k = 0; k < NPW; ++k) H[k] = imax(H[k], ownBnd - P.oe[k]);
+                            for (int k = 0; k < NPW; ++k) {
+                                const int32_t ho = imax(imax(m1, m2), imax(m3, m0)) - P.oe[k];
+                                const int32_t he = imax(imax(c1 ? Hh[k][P1] : CL_NEG_INF, c2 ? Hh[k][P2] : CL_NEG_INF), c3 ? Hh[k][P3] : CL_NEG_INF) - P.ext[k];
+                                H[k] = imax(ho, he);
+                            }
                         }
                         if (nfar) {   // saved-column predecessors (the fork in front of a long bubble): LDS, a few dozen steps per pair
                             for (uint32_t f = 0; f < nfar; ++f) {
@@ -323,9 +353,11 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                                 if (rsrc) Md = imax(Md, col[0]);
                             }
                         }
-                        int32_t Mf = Md + sc;
+                        Mf = Md + sc;
 #pragma unroll
                         for (int k = 0; k < NPW; ++k) Mf = imax(Mf, imax(V[k], H[k]));
+                    }
+                    if (active) {
                         // where the cell lies in the anti-diagonal-major planes: closed form at the lane's first column, then one step along the column axis —
                         // idx(a1, a2 + 1) - idx(a1, a2) = hi(d) + 1 - lo(d + 1) with d = a1 + a2, one more when the columns are graph 1 (DiagGeom)
                         if (b == 1) pidx = cell_index(row, 1);
@@ -342,34 +374,43 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                             const uint32_t dg = row + b;
                             pidx += (dg < pd.n1 ? dg : pd.n1) + (swap ? 2u : 1u) - (dg + 1 > pd.n2 ? dg + 1 - pd.n2 : 0u);
                         }
-                        // the new cell becomes "one column ago"; the lane below takes M / V_k on its next step
+                        // the new cell is this step's ring entry; the lane below takes M / V_k on its next step
+                        Mh[Q] = Mf;
 #pragma unroll
-                        for (int e = DC - 1; e > 0; --e) {
-                            Mh[e] = Mh[e - 1];
-#pragma unroll
-                            for (int k = 0; k < NPW; ++k) Hh[k][e] = Hh[k][e - 1];
-                        }
-                        Mh[0] = Mf;
-                        lastM = Mf;
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) { Hh[k][0] = H[k]; lastV[k] = V[k]; }
+                        for (int k = 0; k < NPW; ++k) { Hh[k][Q] = H[k]; lastV[k] = V[k]; }
                         if ((cr >> 15) & 1u) {   // a saved column: its cells stay available for the far reads
                             const uint32_t slot = (cr >> 16) & 0xFu;
                             int32_t* w = saved + (size_t)slot * area + (size_t)(DR + row - rowbase) * CW;
                             w[0] = Mf;
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) w[1 + k] = H[k];
-                            if (row == rowbase + 1) saved[(size_t)slot * area] = cbm;   // the boundary row's Mf at this column
+                            if (row == rowbase + 1) saved[(size_t)slot * area] = bMr[Q];   // the boundary row's Mf at this column
                             if (WIDE && hands_on && wave + 1 == strips_here) sx[((size_t)grp * pd.aux_cnt + slot) * DR + (63u - lane)] = Mf;   // for the next group's first rows
                         }
                         if (hands_on) {   // the last DR rows of a full strip feed the next strip's conveyor
-                            int32_t* o = bout + (size_t)((63u - lane) * CW) * nC + (b - 1);
-                            o[0] = Mf;
+                            if (to_lds) {
+                                int32_t* o = hout + ((b - 1) & (kLaneWindow - 1));
+                                o[0] = Mf;
 #pragma unroll
-                            for (int k = 0; k < NPW; ++k) o[(size_t)(1 + k) * nC] = V[k];
+                                for (int k = 0; k < NPW; ++k) o[(1 + k) * kLaneWindow] = V[k];
+                            } else {
+                                int32_t* o = bout + (size_t)((63u - lane) * CW) * nC + (b - 1);
+                                o[0] = Mf;
+#pragma unroll
+                                for (int k = 0; k < NPW; ++k) o[(size_t)(1 + k) * nC] = V[k];
+                            }
                         }
                     }
-                }
+                };
+                auto run_chunk = [&](auto drs) {
+                    for (uint32_t jj = 0; jj < C; jj += 4) {
+                        step(LaneQ<0>{}, drs, t0 + jj);
+                        step(LaneQ<1>{}, drs, t0 + jj + 1);
+                        step(LaneQ<2>{}, drs, t0 + jj + 2);
+                        step(LaneQ<3>{}, drs, t0 + jj + 3);
+                    }
+                };
+                if (DR > 1 && !strip_dr1) run_chunk(LaneQ<DR>{}); else run_chunk(LaneQ<1>{});
             }
         }
         if (WIDE && grp + 1 < n_groups && wave + 1 == strips_here && mm >= 0 && (uint32_t)mm < Cn && !dead) {
@@ -404,10 +445,10 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
 }
 
 template <int NPW, int W, bool WIDE>
-__device__ __forceinline__ void lane_dispatch(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* saved, uint32_t grp, uint32_t* lane_sync) {
-    // two shapes of the cell: predecessors up to 2 rows / 3 columns back (every pair of the 10 x 1 Mbp MSA), and up to 4 / 4
-    if ((pd.pad & 0xFu) <= 2u && ((pd.pad >> 4) & 0xFu) <= 3u) lane_body<NPW, 2, 3, W, WIDE>(B, pd, prob, P, saved, grp, lane_sync);
-    else lane_body<NPW, 4, 4, W, WIDE>(B, pd, prob, P, saved, grp, lane_sync);
+__device__ __forceinline__ void lane_dispatch(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, int32_t* lds, uint32_t grp, uint32_t* lane_sync) {
+    // two shapes: row predecessors up to 2 ranks back (every pair of the 10 x 1 Mbp MSA), or up to 4; column predecessors up to 3 columns back in both
+    if ((pd.pad & 0xFu) <= 2u) lane_body<NPW, 2, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync);
+    else lane_body<NPW, 4, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync);
 }
 
 // WIDE: a pair's groups are consecutive workgroups of the launch (plist repeats the pair once per group); lane_sync: the plan's progress / done words
