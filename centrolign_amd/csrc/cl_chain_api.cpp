@@ -1157,9 +1157,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             F.band_pen = sparse ? 0.0 : pw;
             F.slack_t0 = local_scale * emax * (double)std::max<int64_t>(std::llabs(smin), std::llabs(smax)) + local_scale * omax;
             F.slack_e0 = local_scale * emax;
-            CH(d_far_rec.alloc(ctx, (size_t)R * 12));
+            // (the record image — 48 B per padded record — is allocated below, once the arena is known to fit 32-bit offsets: at the root of a 50-sequence MSA
+            // it is 33 GB, and round 4 allocated it BEFORE finding out that the far pass could not be used there: the context held 105 GB for a DP of 71)
             CH(d_far_base.upload(ctx, base));
-            D.far_rec = d_far_rec.p;
             D.far_base = d_far_base.p;
             // the arena: per level the two blocked orders (2 R words each) and their index arrays (R / 8, R / 64, ...)
             uint64_t words = 0;
@@ -1177,6 +1177,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
             if (words >= (1ull << 32)) use_far = false;
             if (use_far) {
+            CH(d_far_rec.alloc(ctx, (size_t)R * 12));
+            D.far_rec = d_far_rec.p;
             CH(d_far_arena.alloc(ctx, words));
             CH(d_far_tab.upload(ctx, tab));
             F.arena = d_far_arena.p;

@@ -1408,11 +1408,12 @@ hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, co
     if (lds_bytes > 150 * 1024) return hipErrorInvalidValue;   // (the planner keeps the hand-off window + the saved columns of a pair below that)
     static ClDeviceOnce attr_once;   // more than 64 KB of dynamic LDS needs the opt-in once per function and device
     attr_once([] {
-        const int cap = 160 * 1024;
+        const int cap = 159 * 1024;   // (the kernel has a few bytes of static LDS as well: 160 KB of dynamic LDS is refused, and the refusal would surface as the NEXT launch's error)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipGetLastError();
     });
     if (lane_sync) {   // wide pairs: a workgroup per group of eight strips
         if (W != 8) return hipErrorInvalidValue;
