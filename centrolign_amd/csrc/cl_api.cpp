@@ -1492,18 +1492,26 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         pl->groups.push_back(grp);
     }
     // near-chain pairs in registers: one launch per workgroup shape as well (strips of 64 rows over 1 / 4 / 16 waves), longest sweep first
-    for (int gi = 0; gi < 3; ++gi) {
+    // The LONG sweeps (1 024 steps and more: a handful of pairs that bound the pass) get launches of their own whose workgroups ask for more than half a compute
+    // unit's LDS: one workgroup per compute unit, so that a long sweep's waves do not share their SIMDs with another pair's (190 registers per lane leave room for two
+    // waves per SIMD, and two waves on a SIMD each run at half speed — for a launch that lasts as long as its longest sweep that doubles its duration).
+    // CL_LANE_LONG=0: no such split (A/B)
+    static const bool lane_long_split = [] { const char* e = getenv("CL_LANE_LONG"); return !e || e[0] != '0'; }();
+    for (int gi = 0; gi < 6; ++gi) {
         LaunchGroup grp;
         const int lane_waves[3] = {8, 4, 1};   // (sixteen waves would leave a wave 128 registers: the 4 / 4 shape at NumPW 3 needs 180)
-        grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = lane_waves[gi];
+        const bool long_ones = gi < 3;
+        grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = lane_waves[gi % 3];
         grp.first = (uint32_t)plist.size();
         for (uint32_t i = 0; i < pl->desc.size(); ++i) {
             const ClProbDesc& d = pl->desc[i];
             const uint32_t rows = std::min(d.n1, d.n2);
-            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : rows <= 256 ? 4 : 8) == grp.waves) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
+            const bool is_long = lane_long_split && (uint64_t)d.n1 + d.n2 >= 1024;
+            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : rows <= 256 ? 4 : 8) == grp.waves && is_long == long_ones) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
         }
         grp.count = (uint32_t)plist.size() - grp.first;
         if (!grp.count) continue;
+        if (long_ones) grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, 81u * 1024u);   // more than half of 160 KB: one workgroup per compute unit
         for (uint32_t i = grp.first; i < plist.size(); ++i) {
             grp.cells += cells_of(plist[i]);
             grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * pl->desc[plist[i]].npw);

@@ -217,6 +217,13 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                     ownBnd = real ? lane_bnd_m<NPW>(P, rowdist[row - 1]) : CL_NEG_INF;
 #pragma unroll
                     for (int d = 0; d < DR; ++d) predBnd[d] = (real && row > (uint32_t)(d + 1)) ? lane_bnd_m<NPW>(P, rowdist[row - 2 - d]) : CL_NEG_INF;
+                    if (row == 1u && real) {
+                        // the first row's only predecessor is the boundary row (it is a source and nothing lies above it): for strip 0 the boundary row IS the row above
+                        // the strip — lane 0's conveyor feed carries Mf(0, column) with no gap values to extend (alignment.hpp:907-916 with p == n1 opens only) — so the
+                        // row is an ordinary chain row for the cell below, its corner term Mf(0, 0) counting 0 (:814-818)
+                        rrec = (rrec & ~0x1Fu) | 1u;
+                        predBnd[0] = 0;
+                    }
                     rowslow = real && (rrec & 0x1Fu) != 1u;                           // anything but "one predecessor, the row above"
                     strip_dr1 = __ballot(real && (rrec & 0xEu)) == 0ull;               // no row of the strip reaches further than one row up: the conveyor's first stage does
                     fetch_columns(0, nrec, nbm);
@@ -225,6 +232,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                 frec = nrec; fbm = nbm;
                 fetch_columns(t0 + C, nrec, nbm);
                 const bool from_lds = W > 1 && s > 0 && (WIDE ? wave > 0 : (s % W) != 0);   // the rows above the strip: the previous wave's, through the LDS window ...
+                if (s == 0) fM[0] = fbm;   // ... for the first strip the boundary row (its gap values stay -inf: nothing extends out of it)
                 if (s > 0) {
                     const uint32_t colb = t0 + lane + 1;
                     const bool v = lane < C && colb <= nC;
@@ -266,9 +274,12 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                     cMh[0][Q] = lane_shift_in(Mh[P1], fM[0]);
 #pragma unroll
                     for (int k = 0; k < NPW; ++k) cV[0][k] = lane_shift_in(lastV[k], fV[0][k]);
+                    fM[0] = lane_rotate_down(fM[0]);
                     if (s > 0) {
 #pragma unroll
-                        for (int d = 0; d < DRS; ++d) {
+                        for (int k = 0; k < NPW; ++k) fV[0][k] = lane_rotate_down(fV[0][k]);
+#pragma unroll
+                        for (int d = 1; d < DRS; ++d) {
                             fM[d] = lane_rotate_down(fM[d]);
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) fV[d][k] = lane_rotate_down(fV[d][k]);
@@ -384,7 +395,10 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                             w[0] = Mf;
 #pragma unroll
                             for (int k = 0; k < NPW; ++k) w[1 + k] = H[k];
-                            if (row == rowbase + 1) saved[(size_t)slot * area] = bMr[Q];   // the boundary row's Mf at this column
+                            if (row == rowbase + 1) {
+                                saved[(size_t)slot * area] = bMr[Q];                        // the boundary row's Mf at this column: for source rows ...
+                                if (rowbase == 0) saved[(size_t)slot * area + DR * CW] = bMr[Q];   // ... and as "row 0" for row 1, whose row predecessor it is
+                            }
                             if (WIDE && hands_on && wave + 1 == strips_here) sx[((size_t)grp * pd.aux_cnt + slot) * DR + (63u - lane)] = Mf;   // for the next group's first rows
                         }
                         if (hands_on) {   // the last DR rows of a full strip feed the next strip's conveyor
