@@ -357,7 +357,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                                     if ((rmask >> d) & 1u) {
                                         const uint32_t pr = row - 1 - d;   // the predecessor row: this workgroup's, or one of the last DR rows of the group above
                                         int32_t far_m;   // (two loads under a branch: a select between a global and an LDS address makes the backend emit an illegal compare)
-                                        if (WIDE && pr <= rowbase) far_m = sx[((size_t)(grp - 1) * pd.aux_cnt + slot) * DR + (rowbase - pr)];
+                                        if (WIDE && grp > 0 && pr <= rowbase) far_m = sx[((size_t)(grp - 1) * pd.aux_cnt + slot) * DR + (rowbase - pr)];
                                         else far_m = col[(size_t)(DR + pr - rowbase) * CW];
                                         Md = imax(Md, far_m);
                                     }
