@@ -1069,7 +1069,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // the shorter graph goes across the lanes; strips of 64 rows are pipelined over the waves
             ls = d.n2 < d.n1;
             const uint32_t nshort = std::min(d.n1, d.n2), nlong = std::max(d.n1, d.n2);
-            if (nshort <= 64) { lr = 1; lw = 1; }
+            // (lw = 2: FOUR pairs per wave, 16 lanes each — popoa_linear_quad_kernel; CL_NO_LINEAR_QUADS=1: one pair per wave as in rounds 1-4)
+            static const bool no_quads = [] { const char* e = getenv("CL_NO_LINEAR_QUADS"); return e && *e == '1'; }();
+            if (nshort <= 16 && !no_quads) { lr = 1; lw = 2; }
+            else if (nshort <= 64) { lr = 1; lw = 1; }
             else if (nshort <= 128 && nlong < 300) { lr = 2; lw = 1; }
             else if (nshort <= 256) { lr = 1; lw = 4; }
             else { lr = 1; lw = 16; }
@@ -1100,7 +1103,12 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const bool lane_wide = n_rows > 1025;
             const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 7) / 8 : 1;
             static const bool no_wide = [] { const char* e = getenv("CL_NO_LANE_WIDE"); return e && *e == '1'; }();   // A/B: wide pairs on popoa_strip_kernel as in round 4
-            if (!g_no_lane && !g_force_general && lane_groups <= 128 && !(lane_wide && (no_wide || g_no_strip)) && n_cols < (1u << 28)) {
+            // which pairs: the register kernel wins where a launch lasts as long as its longest sweep (alone on the device: 2 225 x 165 0.88 ms against 1.32 ms on the systolic
+            // kernel, 2 130 x 35 0.83 against 1.17, 441 x 433 0.60 against 0.71); on the thousands of small pairs that fill a launch's workgroups it issues about as many
+            // instructions per cell as the systolic kernel and its launches, dealt by (waves, long / short), interleave worse: pairs below CL_LANE_MIN_SWEEP rows + columns
+            // (default below) stay where they were
+            static const uint64_t lane_min_sweep = [] { const char* e = getenv("CL_LANE_MIN_SWEEP"); return e ? (uint64_t)atoll(e) : (uint64_t)512; }();
+            if (!g_no_lane && !g_force_general && lane_groups <= 128 && !(lane_wide && (no_wide || g_no_strip)) && n_cols < (1u << 28) && n_rows - 1 + n_cols >= lane_min_sweep) {
                 const uint32_t nR = (uint32_t)n_rows - 1, nCl = (uint32_t)n_cols;
                 const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
                 const uint8_t* rl = P.lab[sRow].data() + d.node_base[sRow];
@@ -1491,6 +1499,26 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return sweep(x) > sweep(y); });
         pl->groups.push_back(grp);
     }
+    // small chain pairs, four per wave (popoa_linear_quad_kernel): quads of one NumPW, longest first so that a quad's pairs are about as long as one another
+    {
+        LaunchGroup grp;
+        grp.kind = CL_KIND_LINEAR; grp.npw = 0; grp.waves = 2;
+        grp.first = (uint32_t)plist.size();
+        for (int npw = 3; npw >= 1; --npw) {
+            std::vector<uint32_t> q;
+            for (uint32_t i = 0; i < pl->desc.size(); ++i)
+                if (pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == 2 && pl->desc[i].npw == npw) q.push_back(i);
+            std::stable_sort(q.begin(), q.end(), [&](uint32_t x, uint32_t y) { return std::max(pl->desc[x].n1, pl->desc[x].n2) > std::max(pl->desc[y].n1, pl->desc[y].n2); });
+            for (uint32_t i : q) {
+                plist.push_back(i);
+                grp.cells += cells_of(i);
+                grp.bytes += cells_of(i) * 4ull * (1 + 2 * npw);
+            }
+            while ((plist.size() - grp.first) % 4) plist.push_back(0xFFFFFFFFu);
+        }
+        grp.count = (uint32_t)plist.size() - grp.first;
+        if (grp.count) pl->groups.push_back(grp);
+    }
     // near-chain pairs in registers: one launch per workgroup shape as well (strips of 64 rows over 1 / 4 / 16 waves), longest sweep first
     // The LONG sweeps (1 024 steps and more: a handful of pairs that bound the pass) get launches of their own whose workgroups ask for more than half a compute
     // unit's LDS: one workgroup per compute unit, so that a long sweep's waves do not share their SIMDs with another pair's (190 registers per lane leave room for two
@@ -1659,7 +1687,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             }
             uint64_t c = 0;
             for (uint32_t i = g.first; i < g.first + g.count; ++i)
-                c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
+                if (plist[i] != 0xFFFFFFFFu) c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
             // microseconds per anti-diagonal step, roughly: planes in HBM 4-8, LDS ring 1.6-2.5, systolic DAG 0.45, chain 0.2-0.6
             return c * (g.kind == CL_KIND_GENERAL ? (g.ring_bytes ? 5 : 16) : 1);
         };
@@ -1719,7 +1747,7 @@ static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
 static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const ClDeviceBatch& dev, hipStream_t stream) {
-    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves == 2 ? 0 : g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     if (g.kind == CL_KIND_STRIP) {
         // the strips' progress words start every pass at zero (the strips of a launch poll one another's)
         hipError_t e = hipMemsetAsync(pl->d_progress.p + g.prog_first, 0, (size_t)g.prog_count * sizeof(uint32_t), stream);
@@ -1884,7 +1912,8 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     if (!ctx || !pl || !out || index < 0 || index >= (int)pl->groups.size()) return CL_ERR_INVALID_ARGUMENT;
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
-    if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
+    if (g.kind == CL_KIND_LINEAR && g.waves == 2) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_quad_kernel");
+    else if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), g.block == 1 ? "popoa_lane_kernel<%d, wide>" : "popoa_lane_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
     else if (g.kind == CL_KIND_STRIP) snprintf(out->kernel, sizeof(out->kernel), "popoa_strip_kernel<%d> x %d", g.npw, g.block);
@@ -1897,7 +1926,12 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;
     out->lds_bytes = g.kind == CL_KIND_LINEAR ? 0u : g.ring_bytes;
+    if (g.kind == CL_KIND_LINEAR && g.waves == 2) {   // (the quads' list is padded with "no pair")
+        out->n_problems = 0;
+        for (uint32_t i = g.first; i < g.first + g.count; ++i) out->n_problems += pl->plist_host[i] != 0xFFFFFFFFu;
+    }
     for (uint32_t i = g.first; i < g.first + g.count; ++i) {
+        if (g.kind != CL_KIND_STRIP && pl->plist_host[i] == 0xFFFFFFFFu) continue;
         const ClProbDesc& d = pl->desc[g.kind == CL_KIND_STRIP ? pl->strips[pl->strip_list[i]].prob : pl->plist_host[i]];
         if (d.n1 + d.n2 > out->max_sweep) { out->max_sweep = d.n1 + d.n2; out->max_n1 = d.n1; out->max_n2 = d.n2; }
     }

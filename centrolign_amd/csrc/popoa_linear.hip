@@ -355,6 +355,117 @@ __global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, c
     if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// ---- four small chain pairs per wave -------------------------------------------------------------------------------------------------------------------
+// A stitch pass of a progressive MSA is bound by VALU issue over the whole device, and half of its subproblems are chain pairs whose shorter side has at most
+// 16 nodes (10 x 1 Mbp: 57 000 of 107 000 pairs, 2 % of the cells, a quarter of all wave-steps): one such pair per wave leaves 48 of 64 lanes idle for n + 63
+// steps.  Here a wave takes FOUR of them: lanes 16 g .. 16 g + 15 are pair g's rows, the systolic moves are the ROW forms of the same DPP controls
+// (row_shr:1 / row_shl:1 act inside rows of 16 lanes: lane 0 of a row keeps the fill), the column feed is a chunk of 16 columns per segment.  Same cell, same
+// codes at the same addresses as linear_body<NPW, 1, 1, SWAP> (a pair's code buffer is indexed by ITS step and ITS lane), so linear_traceback walks them
+// unchanged, one pair after the other.  The quad's pairs have the same NumPW (host: cl_api.cpp sorts them by NumPW and length); 0xFFFFFFFF = no pair.
+__device__ __forceinline__ int32_t seg_shift_in(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }   // row_shr:1
+__device__ __forceinline__ int32_t seg_rotate_down(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x101, 0xf, 0xf, false); }               // row_shl:1
+
+template <int NPW>
+__device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32_t* __restrict__ quad, const ClScoreParams& P) {
+    using code_t = typename CodeT<NPW>::type;
+    constexpr uint32_t CQ = 16;   // columns per chunk = lanes of a segment
+    const uint32_t lane = threadIdx.x & 63u, seg = lane >> 4, l = lane & 15u;
+    const uint32_t prob = quad[seg];
+    const bool have = prob != 0xFFFFFFFFu;
+    ClProbDesc pd = B.desc[have ? prob : quad[0]];
+    const bool swp = pd.pad & 1u;
+    const uint32_t nr = have ? (swp ? pd.n2 : pd.n1) : 0u, nc = have ? (swp ? pd.n1 : pd.n2) : 0u;
+    const uint8_t* labR = B.lab[swp ? 1 : 0] + pd.node_base[swp ? 1 : 0];
+    const uint8_t* labC = B.lab[swp ? 0 : 1] + pd.node_base[swp ? 0 : 1];
+    code_t* codes = reinterpret_cast<code_t*>(B.planes + pd.plane_base);
+    // the longest pair of the quad sets the number of steps (its last row reaches its last column at step nc + nr - 2)
+    uint32_t last = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)nc, g * 16), r = (uint32_t)__builtin_amdgcn_readlane((int)nr, g * 16);
+        if (c && r && c + r > last) last = c + r;
+    }
+    const uint32_t a = l + 1;   // this lane's row (1-based)
+    int32_t Mleft = boundary_m<NPW>(P, a), Hleft[NPW], lastM, lastV[NPW], prevUpM = l == 0 ? 0 : boundary_m<NPW>(P, l), c2 = 0xff;
+    const int32_t labr = a <= nr ? (int32_t)(labR[a - 1] & 0x7f) : 0xfe;
+    int32_t bM = CL_NEG_INF, myc2 = 0xff;
+    lastM = Mleft;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) { Hleft[k] = CL_NEG_INF; lastV[k] = CL_NEG_INF; }
+    for (uint32_t t0 = 0; t0 + 1 < last; t0 += CQ) {
+        {   // this chunk's 16 columns as seen by the segment's lane 0: label and the boundary row's Mf (V_k of the boundary row = -inf)
+            const uint32_t colb = t0 + l + 1;
+            const bool v = colb <= nc;
+            myc2 = v ? (int32_t)(labC[colb - 1] & 0x7f) : 0xff;
+            bM = v ? boundary_m<NPW>(P, colb) : CL_NEG_INF;
+        }
+        for (uint32_t jj = 0; jj < CQ; ++jj) {
+            const uint32_t t = t0 + jj;
+            const int32_t upM = seg_shift_in(lastM, bM);
+            bM = seg_rotate_down(bM);
+            int32_t upV[NPW];
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) upV[k] = seg_shift_in(lastV[k], CL_NEG_INF);
+            c2 = seg_shift_in(c2, myc2);
+            myc2 = seg_rotate_down(myc2);
+            const uint32_t b = t - l + 1;   // this lane's column (1-based); wraps when not started
+            if ((uint32_t)(b - 1) < nc && l < nr) {
+                const int32_t sc = labr == c2 ? P.match : -P.mismatch;
+                int32_t Mf = prevUpM + sc;
+                int32_t V[NPW], H[NPW];
+                uint32_t code = 0;
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) {
+                    const int32_t vo = upM - P.oe[k], ho = Mleft - P.oe[k];
+                    V[k] = imax(vo, upV[k] - P.ext[k]);
+                    H[k] = imax(ho, Hleft[k] - P.ext[k]);
+                    code |= (V[k] == vo ? 1u : 0u) << (3 + k);
+                    code |= (H[k] == ho ? 1u : 0u) << (3 + NPW + k);
+                    Mf = imax(Mf, imax(V[k], H[k]));
+                }
+                uint32_t cc = 0;
+#pragma unroll
+                for (int k = NPW - 1; k >= 0; --k) {  // lowest k, I before D, wins (alignment.hpp:1048-1066); rows are graph 2 when swapped: vertical gaps are D_k then
+                    const uint32_t vcode = swp ? 2u * k + 2u : 2u * k + 1u, hcode = swp ? 2u * k + 1u : 2u * k + 2u;
+                    if (swp) { cc = Mf == V[k] ? vcode : cc; cc = Mf == H[k] ? hcode : cc; }
+                    else { cc = Mf == H[k] ? hcode : cc; cc = Mf == V[k] ? vcode : cc; }
+                }
+                code |= cc;
+                codes[((size_t)t * 64 + l)] = (code_t)code;
+                Mleft = Mf;
+                lastM = Mf;
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) { Hleft[k] = H[k]; lastV[k] = V[k]; }
+            }
+            prevUpM = upM;
+        }
+    }
+    if (have && a == nr) B.out_score[prob] = Mleft;
+    __syncthreads();   // the codes are in memory
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t pg = quad[g];
+        if (pg == 0xFFFFFFFFu) continue;
+        const ClProbDesc pdg = B.desc[pg];
+        const bool sw = pdg.pad & 1u;
+        LinearGeom G;
+        G.init<1>(sw ? pdg.n2 : pdg.n1, sw ? pdg.n1 : pdg.n2);
+        const code_t* cg = reinterpret_cast<const code_t*>(B.planes + pdg.plane_base);
+        if (sw) linear_traceback<NPW, 1, true>(B, pdg, G, cg, P, pg, lane);
+        else linear_traceback<NPW, 1, false>(B, pdg, G, cg, P, pg, lane);
+    }
+}
+
+__global__ void __launch_bounds__(64) popoa_linear_quad_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    const uint32_t* quad = plist + 4u * blockIdx.x;
+    switch (B.desc[quad[0]].npw) {
+    case 1: linear_quad<1>(B, quad, P); break;
+    case 2: linear_quad<2>(B, quad, P); break;
+    default: linear_quad<3>(B, quad, P); break;
+    }
+    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
 }  // namespace
 
 // bytes of workspace a chain problem needs (codes + strip hand-off rows); mirrors the kernel's layout.
@@ -372,6 +483,7 @@ hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch&
                                   const ClScoreParams& P, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     switch (W) {
+    case 0: hipLaunchKernelGGL(popoa_linear_quad_kernel, dim3(n_blocks / 4), dim3(64), 0, stream, B, plist, P); break;   // four small pairs per wave: n_blocks list entries, four per workgroup
     case 1: hipLaunchKernelGGL((popoa_linear_kernel<1>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P); break;
     case 4: hipLaunchKernelGGL((popoa_linear_kernel<4>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P); break;
     case 16: hipLaunchKernelGGL((popoa_linear_kernel<16>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P); break;

@@ -410,3 +410,26 @@ def test_near_chain_pairs_in_registers(gpu_ctx):
     sizes = [(int(rng.integers(1, 120)), int(rng.integers(1, 400))) for _ in range(300)]
     b = synth.near_chain_batch(sizes, seed=10, n_long=(0, 0))
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+
+
+def test_small_chain_pairs_four_per_wave(gpu_ctx):
+    """popoa_linear_quad_kernel: chain pairs whose shorter side has at most 16 nodes, four to a wave (16 lanes each, row-wise DPP moves): every length of the short side,
+    either orientation, long and short partners in one quad, counts that are not a multiple of four, every NumPW, tie-heavy scoring; against the oracle"""
+    rng = np.random.default_rng(3)
+    sizes = [(a, int(rng.integers(1, 400))) for a in range(1, 17)] + [(int(rng.integers(1, 400)), a) for a in range(1, 17)] + [(16, 16), (1, 1), (16, 2000), (2000, 16), (3, 3)]
+    sizes += [(int(rng.integers(1, 17)), int(rng.integers(1, 60))) for _ in range(401)]
+    b = synth.linear_batch(sizes, seed=8)
+    plan = gpu_ctx.plan(b)
+    assert any(li["kernel"] == "popoa_linear_quad_kernel" and li["n_problems"] >= 400 for li in plan.launches()), plan.launches()
+    want = po.oracle_stitch_batch(b)
+    for _ in range(2):
+        plan.execute(); plan.sync()
+        assert plan.collect().same_as(want) is None
+    plan.destroy()
+    for npw in (1, 2, 3):
+        f = np.full(b.n_problems, npw, np.uint8)
+        got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+        tp = H.tie_params()
+        got = gpu_ctx.po_poa_batch(b, f, tp.alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f, params=tp)) is None, ("ties", npw)
