@@ -1107,7 +1107,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // kernel, 2 130 x 35 0.83 against 1.17, 441 x 433 0.60 against 0.71); on the thousands of small pairs that fill a launch's workgroups it issues about as many
             // instructions per cell as the systolic kernel and its launches, dealt by (waves, long / short), interleave worse: pairs below CL_LANE_MIN_SWEEP rows + columns
             // (default below) stay where they were
-            static const uint64_t lane_min_sweep = [] { const char* e = getenv("CL_LANE_MIN_SWEEP"); return e ? (uint64_t)atoll(e) : (uint64_t)512; }();
+            const uint64_t lane_min_sweep = [] { const char* e = getenv("CL_LANE_MIN_SWEEP"); return e ? (uint64_t)atoll(e) : (uint64_t)512; }();   // (read per plan: tests)
             if (!g_no_lane && !g_force_general && lane_groups <= 128 && !(lane_wide && (no_wide || g_no_strip)) && n_cols < (1u << 28) && n_rows - 1 + n_cols >= lane_min_sweep) {
                 const uint32_t nR = (uint32_t)n_rows - 1, nCl = (uint32_t)n_cols;
                 const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];

@@ -337,11 +337,13 @@ def _kernels(plan):
     return {li["kernel"].split("<")[0] for li in plan.launches() if li["n_problems"]}
 
 
-def test_near_chain_pairs_in_registers(gpu_ctx):
-    """popoa_lane_kernel (popoa_lane.h): graph pairs that are chains but for SNP / short-deletion bubbles and a long bubble or two — the long sweeps of a progressive MSA's stitch
+def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
+    """(CL_LANE_MIN_SWEEP=0: by default only pairs of 512 rows + columns and more take this kernel — where it pays — here every eligible pair does.)
+    popoa_lane_kernel (popoa_lane.h): graph pairs that are chains but for SNP / short-deletion bubbles and a long bubble or two — the long sweeps of a progressive MSA's stitch
     passes — swept in registers with DPP moves (row predecessors on a conveyor, column predecessors in the lane's history, saved columns in LDS).  Every workgroup shape
     (1 / 4 / 8 waves: strips of 64 rows pipelined over the waves, hand-off rows behind the planes; more than 512 rows: a second round of strips), both orientations,
     every NumPW, both shapes of the cell (predecessors 2 rows / 3 columns back, 4 / 4), against the oracle"""
+    monkeypatch.setenv("CL_LANE_MIN_SWEEP", "0")
     # lopsided pairs, the long graph with a long bubble (a saved column): 1 wave, 4 waves, 8 waves, two rounds
     sizes = [(5, 2100), (30, 700), (64, 300), (65, 400), (165, 2225), (256, 500), (300, 330), (420, 418), (512, 520), (600, 640), (1000, 1010)]
     b = synth.near_chain_batch(sizes, seed=5, n_long=(0, 1))
