@@ -1523,8 +1523,9 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     // The LONG sweeps (1 024 steps and more: a handful of pairs that bound the pass) get launches of their own whose workgroups ask for more than half a compute
     // unit's LDS: one workgroup per compute unit, so that a long sweep's waves do not share their SIMDs with another pair's (190 registers per lane leave room for two
     // waves per SIMD, and two waves on a SIMD each run at half speed — for a launch that lasts as long as its longest sweep that doubles its duration).
-    // CL_LANE_LONG=0: no such split (A/B)
-    static const bool lane_long_split = [] { const char* e = getenv("CL_LANE_LONG"); return !e || e[0] != '0'; }();
+    // CL_LANE_LONG=1 switches the split on.  Measured (10 x 1 Mbp, the timed step): it does not pay — 2.69 ms per step with it, 2.46 without at the default
+    // routing threshold: the compute units of the long launches are shared with the OTHER kernels' workgroups anyway, and one launch more queues on the streams
+    static const bool lane_long_split = [] { const char* e = getenv("CL_LANE_LONG"); return e && e[0] == '1'; }();
     for (int gi = 0; gi < 6; ++gi) {
         LaunchGroup grp;
         const int lane_waves[3] = {8, 4, 1};   // (sixteen waves would leave a wave 128 registers: the 4 / 4 shape at NumPW 3 needs 180)
