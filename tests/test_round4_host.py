@@ -28,7 +28,9 @@ def test_memory_model_of_the_chaining_dp():
     # pair x combination is what dominates a wide merge: 44 bytes each
     assert abs(m.chain_dp_bytes(10 ** 6, 10 ** 6, 400, 20, 20, False) - m.chain_dp_bytes(10 ** 6, 10 ** 6, 200, 20, 20, False) - 200 * (44 * 10 ** 6 + 4 * (10 ** 6 // 256 + 2) + 104 + 8192)) < 10 ** 6
     p = m.predict(50, 5000000, 1250000)
-    assert p["combinations"] == 625 and 30e9 < p["dp_bytes"]["affine"] < 40e9   # 35 GB of the 288
+    # round 5 (measured on 50 x 100 kbp and 50 x 1 Mbp, profiles/r05_configs4.json): the gap-free DP keeps one record per pair (35 GB), the affine DP one per pair and
+    # chain combination its nodes lie on — 0.64 of pairs x combinations at 625 combinations — 61-71 GB of the 288
+    assert p["combinations"] == 625 and 30e9 < p["dp_bytes"]["gap-free"] < 40e9 and 55e9 < p["dp_bytes"]["affine"] < 75e9
 
 
 def test_far_fork_batch_makes_valid_pairs_with_long_range_edges():
