@@ -1102,7 +1102,10 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // WIDE: more than 1 024 rows — the strips of 64 rows dealt to groups of eight, a workgroup each, on different compute units (popoa_lane.h); at most 128 groups
             const bool lane_wide = n_rows > 1025;
             const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 7) / 8 : 1;
-            static const bool no_wide = [] { const char* e = getenv("CL_NO_LANE_WIDE"); return e && *e == '1'; }();   // A/B: wide pairs on popoa_strip_kernel as in round 4
+            // WIDE pairs are OFF unless CL_LANE_WIDE=1 (read per plan): measured slower than what they would replace — 5 500 x 5 500 branching 17.9 ms against 13.6 ms on
+            // popoa_strip_kernel, 6 300 x 6 300 chains 15.3 against 13.4 ms, 2 048 x 2 048 bubbles 6.5 against 4.8 ms — the per-chunk progress poll, the release fence of a
+            // group's last wave and two waves per SIMD cost more than the registers save; parity-tested (tests/test_gpu_parity.py), not tuned
+            const bool no_wide = [] { const char* e = getenv("CL_LANE_WIDE"); return !(e && *e == '1'); }();
             // which pairs: the register kernel wins where a launch lasts as long as its longest sweep (alone on the device: 2 225 x 165 0.88 ms against 1.32 ms on the systolic
             // kernel, 2 130 x 35 0.83 against 1.17, 441 x 433 0.60 against 0.71); on the thousands of small pairs that fill a launch's workgroups it issues about as many
             // instructions per cell as the systolic kernel and its launches, dealt by (waves, long / short), interleave worse: pairs below CL_LANE_MIN_SWEEP rows + columns

@@ -18,7 +18,9 @@ command = sys.argv[2] if len(sys.argv) > 2 else ""
 
 def short(name):
     n = name.split("::")[-1]
-    return n.split("(")[0].strip()
+    n = n.split("(")[0].strip()
+    # the plan names the lane kernel's launches "<W>" / "<W, wide>": the profiler prints the template arguments as they are
+    return n.replace(", false>", ">").replace(", true>", ", wide>")
 
 
 def rows_of(pattern):

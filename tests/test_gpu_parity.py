@@ -344,6 +344,7 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     (1 / 4 / 8 waves: strips of 64 rows pipelined over the waves, hand-off rows behind the planes; more than 512 rows: a second round of strips), both orientations,
     every NumPW, both shapes of the cell (predecessors 2 rows / 3 columns back, 4 / 4), against the oracle"""
     monkeypatch.setenv("CL_LANE_MIN_SWEEP", "0")
+    monkeypatch.setenv("CL_LANE_WIDE", "1")       # (pairs above 1 024 rows over several workgroups: off by default — parity-tested here, slower than the strips so far)
     # lopsided pairs, the long graph with a long bubble (a saved column): 1 wave, 4 waves, 8 waves, two rounds
     sizes = [(5, 2100), (30, 700), (64, 300), (65, 400), (165, 2225), (256, 500), (300, 330), (420, 418), (512, 520), (600, 640), (1000, 1010)]
     b = synth.near_chain_batch(sizes, seed=5, n_long=(0, 1))
