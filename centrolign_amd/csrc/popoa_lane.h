@@ -142,6 +142,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     const uint32_t strips_here = WIDE ? (S - grp * W < (uint32_t)W ? S - grp * W : (uint32_t)W) : 0u;
     const uint32_t total = WIDE ? kLaneLag * (strips_here - 1) + Cn : ((S - 1) / W) * Pm + kLaneLag * ((S - 1) % W) + Cn;
     bool dead = false;   // WIDE: this group has given the pair up (its upper neighbour did not deliver in time, or failed itself)
+    uint32_t seen = 0;   // WIDE, wave 0: the upper neighbour's progress as last read (no new read while it already covers the chunk)
 
     // ---- per-strip register state.  Rings: slot Q = the value of the current step (Q = step & 3), slot (Q - e) & 3 the value e steps ago ----
     int32_t Mh[4], Hh[NPW][4];        // the lane's own cells: Mf and H_k of the last columns
@@ -177,26 +178,6 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
 
     for (uint32_t m = 0; m < total; ++m) {
         const int32_t mm = (int32_t)m - (int32_t)(kLaneLag * wave);
-        if (WIDE && grp > 0 && wave == 0 && !dead && m < Cn) {
-            // chunk m of this group's first strip needs the columns of that chunk from the last row of the group above: its last strip must have finished
-            // m + lag chunks (what the barrier per macro-step guarantees between neighbouring waves of one workgroup)
-            const uint32_t need = m + kLaneLag < Cn ? m + kLaneLag : Cn;
-            uint32_t v = 0, polls = 0;
-            while (true) {
-                v = __hip_atomic_load(progress + (grp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v >= need || ++polls > kLanePolls) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (v == kLaneFailed || v < need) { if (lane == 0) gave_up = 1; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (this compute unit's L1 may hold lines of the hand-off rows from before they were written)
-        }
-        if (WIDE && grp > 0) {   // the verdict of wave 0 reaches every wave before anybody works on the chunk
-            __syncthreads();
-            if (gave_up && !dead) {
-                dead = true;
-                if (tid == 0) __hip_atomic_store(progress + grp, kLaneFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         if (mm >= 0 && !dead) {
             const uint32_t j = WIDE ? 0u : (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = (WIDE ? grp * W : j * W) + wave;
             if (s < S && c < Cn) {
@@ -232,6 +213,22 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                 frec = nrec; fbm = nbm;
                 fetch_columns(t0 + C, nrec, nbm);
                 const bool from_lds = W > 1 && s > 0 && (WIDE ? wave > 0 : (s % W) != 0);   // the rows above the strip: the previous wave's, through the LDS window ...
+                bool starved = false;
+                if (WIDE && grp > 0 && wave == 0) {
+                    // chunk c of this group's first strip needs the columns of that chunk from the last rows of the group above: its last strip must have finished
+                    // c + lag chunks (what the barrier per macro-step guarantees between neighbouring waves of one workgroup).  The hand-off words are written
+                    // through to memory (sc1 stores) and read past the caches (sc1 loads): no fence runs while the sweep runs (as in popoa_strip_kernel)
+                    const uint32_t need = c + kLaneLag < Cn ? c + kLaneLag : Cn;
+                    uint32_t polls = 0;
+                    while (seen < need && seen != kLaneFailed) {
+                        seen = __hip_atomic_load(progress + (grp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen >= need || ++polls > kLanePolls) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    starved = seen == kLaneFailed || seen < need;
+                    if (starved && lane == 0) gave_up = 1;
+                }
+                if (!starved) {
                 if (s == 0) fM[0] = fbm;   // ... for the first strip the boundary row (its gap values stay -inf: nothing extends out of it)
                 if (s > 0) {
                     const uint32_t colb = t0 + lane + 1;
@@ -246,11 +243,12 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                         }
                     } else {   // ... or the previous round's / group's last strip, from the area behind the planes
                         const int32_t* src = brow + (size_t)(s - 1) * DR * CW * nC + (colb - 1);
+                        auto ld = [&](const int32_t* q) { return WIDE ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q; };   // (another compute unit wrote them)
 #pragma unroll
                         for (int d = 0; d < DR; ++d) {
-                            fM[d] = v ? src[(size_t)(d * CW) * nC] : CL_NEG_INF;
+                            fM[d] = v ? ld(src + (size_t)(d * CW) * nC) : CL_NEG_INF;
 #pragma unroll
-                            for (int k = 0; k < NPW; ++k) fV[d][k] = v ? src[(size_t)(d * CW + 1 + k) * nC] : CL_NEG_INF;
+                            for (int k = 0; k < NPW; ++k) fV[d][k] = v ? ld(src + (size_t)(d * CW + 1 + k) * nC) : CL_NEG_INF;
                         }
                     }
                 }
@@ -357,7 +355,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                                     if ((rmask >> d) & 1u) {
                                         const uint32_t pr = row - 1 - d;   // the predecessor row: this workgroup's, or one of the last DR rows of the group above
                                         int32_t far_m;   // (two loads under a branch: a select between a global and an LDS address makes the backend emit an illegal compare)
-                                        if (WIDE && grp > 0 && pr <= rowbase) far_m = sx[((size_t)(grp - 1) * pd.aux_cnt + slot) * DR + (rowbase - pr)];
+                                        if (WIDE && grp > 0 && pr <= rowbase) far_m = __hip_atomic_load((const int32_t*)sx + ((size_t)(grp - 1) * pd.aux_cnt + slot) * DR + (rowbase - pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         else far_m = col[(size_t)(DR + pr - rowbase) * CW];
                                         Md = imax(Md, far_m);
                                     }
@@ -399,7 +397,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                                 saved[(size_t)slot * area] = bMr[Q];                        // the boundary row's Mf at this column: for source rows ...
                                 if (rowbase == 0) saved[(size_t)slot * area + DR * CW] = bMr[Q];   // ... and as "row 0" for row 1, whose row predecessor it is
                             }
-                            if (WIDE && hands_on && wave + 1 == strips_here) sx[((size_t)grp * pd.aux_cnt + slot) * DR + (63u - lane)] = Mf;   // for the next group's first rows
+                            if (WIDE && hands_on && wave + 1 == strips_here) __hip_atomic_store((int32_t*)sx + ((size_t)grp * pd.aux_cnt + slot) * DR + (63u - lane), Mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next group's first rows
                         }
                         if (hands_on) {   // the last DR rows of a full strip feed the next strip's conveyor
                             if (to_lds) {
@@ -409,9 +407,15 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                                 for (int k = 0; k < NPW; ++k) o[(1 + k) * kLaneWindow] = V[k];
                             } else {
                                 int32_t* o = bout + (size_t)((63u - lane) * CW) * nC + (b - 1);
-                                o[0] = Mf;
+                                if (WIDE) {
+                                    __hip_atomic_store(o, Mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                                for (int k = 0; k < NPW; ++k) o[(size_t)(1 + k) * nC] = V[k];
+                                    for (int k = 0; k < NPW; ++k) __hip_atomic_store(o + (size_t)(1 + k) * nC, V[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else {
+                                    o[0] = Mf;
+#pragma unroll
+                                    for (int k = 0; k < NPW; ++k) o[(size_t)(1 + k) * nC] = V[k];
+                                }
                             }
                         }
                     }
@@ -425,14 +429,19 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                     }
                 };
                 if (DR > 1 && !strip_dr1) run_chunk(LaneQ<DR>{}); else run_chunk(LaneQ<1>{});
+                }   // (not starved)
             }
         }
         if (WIDE && grp + 1 < n_groups && wave + 1 == strips_here && mm >= 0 && (uint32_t)mm < Cn && !dead) {
             // the last strip of the group has finished chunk mm: its hand-off rows (and saved-column cells) become visible to the other compute units, then the count
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave holds every hand-off row of the group: its write-through stores have arrived
             if (lane == 0) __hip_atomic_store(progress + grp, (uint32_t)mm + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (W > 1) __syncthreads();
+        if (WIDE && grp > 0 && !dead && gave_up) {   // wave 0 did not get its columns in time (or the group above failed): the whole group gives the pair up
+            dead = true;
+            if (tid == 0) __hip_atomic_store(progress + grp, kLaneFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();   // vmcnt(0): every plane value is in memory
     if (!WIDE) {
