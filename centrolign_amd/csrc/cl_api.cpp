@@ -1099,13 +1099,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             uint32_t lane_dr = 0, lane_dc = 0, lane_slots = 0;
             uint64_t lane_lds = 0;
             std::vector<uint32_t> lane_words;
-            // WIDE: more than 1 024 rows — the strips of 64 rows dealt to groups of eight, a workgroup each, on different compute units (popoa_lane.h); at most 128 groups
-            const bool lane_wide = n_rows > 1025;
-            const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 7) / 8 : 1;
-            // WIDE pairs are OFF unless CL_LANE_WIDE=1 (read per plan): measured slower than what they would replace — 5 500 x 5 500 branching 17.9 ms against 13.6 ms on
-            // popoa_strip_kernel, 6 300 x 6 300 chains 15.3 against 13.4 ms, 2 048 x 2 048 bubbles 6.5 against 4.8 ms — the per-chunk progress poll, the release fence of a
-            // group's last wave and two waves per SIMD cost more than the registers save; parity-tested (tests/test_gpu_parity.py), not tuned
-            const bool no_wide = [] { const char* e = getenv("CL_LANE_WIDE"); return !(e && *e == '1'); }();
+            // Four waves per workgroup — one per SIMD — whatever the number of rows: with eight waves every step ran 2.7 x slower (0.93 against 0.34 us: two waves per
+            // SIMD and a barrier of eight per chunk).  More strips of 64 rows than waves take further rounds; above 512 rows (WIDE) the strips are dealt to groups of
+            // four, a workgroup each, on different compute units (popoa_lane.h), at most 128 groups.  CL_LANE_WIDE=0 (read per plan): no wide pairs — up to 1 024 rows
+            // in rounds of one workgroup, beyond that the strips of popoa_strip_kernel as in round 4
+            const bool no_wide = [] { const char* e = getenv("CL_LANE_WIDE"); return e && *e == '0'; }();
+            const bool lane_wide = n_rows > 513 && !(no_wide && n_rows <= 1025);
+            const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 3) / 4 : 1;
             // which pairs: the register kernel wins where a launch lasts as long as its longest sweep (alone on the device: 2 225 x 165 0.88 ms against 1.32 ms on the systolic
             // kernel, 2 130 x 35 0.83 against 1.17, 441 x 433 0.60 against 0.71); on the thousands of small pairs that fill a launch's workgroups it issues about as many
             // instructions per cell as the systolic kernel and its launches, dealt by (waves, long / short), interleave worse: pairs below CL_LANE_MIN_SWEEP rows + columns
@@ -1142,8 +1142,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     far.erase(std::unique(far.begin(), far.end()), far.end());
                     lane_dr = shape == 0 ? 2 : 4; lane_dc = near; lane_slots = (uint32_t)far.size();
                     // LDS of a workgroup: the hand-off window between neighbouring strips ([waves - 1][DR][1 + NumPW][128 columns]) + the saved columns
-                    const uint64_t lane_w = lane_wide ? 8 : (n_rows - 1 <= 64 ? 1 : n_rows - 1 <= 256 ? 4 : 8);
-                    lane_lds = (lane_w > 1 ? (lane_w - 1) * lane_dr * (1 + npw) * 128 * 4 : 0) + (uint64_t)lane_slots * (lane_dr + (lane_wide ? 512 : n_rows - 1) + 1) * (1 + npw) * 4;
+                    const uint64_t lane_w = n_rows - 1 <= 64 ? 1 : 4;
+                    lane_lds = (lane_w > 1 ? (lane_w - 1) * lane_dr * (1 + npw) * 128 * 4 : 0) + (uint64_t)lane_slots * (lane_dr + (lane_wide ? 256 : n_rows - 1) + 1) * (1 + npw) * 4;
                     if (!fits || far.size() > 16 || lane_lds > 150 * 1024) continue;
                     take_lane = true;
                     // shortest walk from a source, in nodes (the boundary cells' closed form)
@@ -1531,7 +1531,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     static const bool lane_long_split = [] { const char* e = getenv("CL_LANE_LONG"); return e && e[0] == '1'; }();
     for (int gi = 0; gi < 6; ++gi) {
         LaunchGroup grp;
-        const int lane_waves[3] = {8, 4, 1};   // (sixteen waves would leave a wave 128 registers: the 4 / 4 shape at NumPW 3 needs 180)
+        const int lane_waves[3] = {0, 4, 1};   // (one wave per SIMD; no launches of eight waves any more)
         const bool long_ones = gi < 3;
         grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = lane_waves[gi % 3];
         grp.first = (uint32_t)plist.size();
@@ -1539,7 +1539,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const ClProbDesc& d = pl->desc[i];
             const uint32_t rows = std::min(d.n1, d.n2);
             const bool is_long = lane_long_split && (uint64_t)d.n1 + d.n2 >= 1024;
-            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : rows <= 256 ? 4 : 8) == grp.waves && is_long == long_ones) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
+            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : 4) == grp.waves && is_long == long_ones) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
         }
         grp.count = (uint32_t)plist.size() - grp.first;
         if (!grp.count) continue;
@@ -1557,7 +1557,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     uint32_t lane_sync_words = 0;
     {
         LaunchGroup grp;
-        auto open = [&]() { grp = LaunchGroup(); grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = 8; grp.block = 1; grp.first = (uint32_t)plist.size(); grp.prog_first = lane_sync_words; };
+        auto open = [&]() { grp = LaunchGroup(); grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = 4; grp.block = 1; grp.first = (uint32_t)plist.size(); grp.prog_first = lane_sync_words; };
         auto close = [&]() {
             grp.count = (uint32_t)plist.size() - grp.first;
             grp.prog_count = lane_sync_words - grp.prog_first;

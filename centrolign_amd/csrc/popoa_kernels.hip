@@ -1411,19 +1411,17 @@ hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, co
         const int cap = 159 * 1024;   // (the kernel has a few bytes of static LDS as well: 160 KB of dynamic LDS is refused, and the refusal would surface as the NEXT launch's error)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipGetLastError();
     });
     if (lane_sync) {   // wide pairs: a workgroup per group of eight strips
-        if (W != 8) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((popoa_lane_kernel<8, true>), dim3(n_blocks), dim3(512), lds_bytes, stream, B, plist, P, lane_sync);
+        if (W != 4) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((popoa_lane_kernel<4, true>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P, lane_sync);
         return hipGetLastError();
     }
     switch (W) {
     case 1: hipLaunchKernelGGL((popoa_lane_kernel<1, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
     case 4: hipLaunchKernelGGL((popoa_lane_kernel<4, false>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
-    case 8: hipLaunchKernelGGL((popoa_lane_kernel<8, false>), dim3(n_blocks), dim3(512), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

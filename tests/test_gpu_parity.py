@@ -341,17 +341,16 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     """(CL_LANE_MIN_SWEEP=0: by default only pairs of 512 rows + columns and more take this kernel — where it pays — here every eligible pair does.)
     popoa_lane_kernel (popoa_lane.h): graph pairs that are chains but for SNP / short-deletion bubbles and a long bubble or two — the long sweeps of a progressive MSA's stitch
     passes — swept in registers with DPP moves (row predecessors on a conveyor, column predecessors in the lane's history, saved columns in LDS).  Every workgroup shape
-    (1 / 4 / 8 waves: strips of 64 rows pipelined over the waves, hand-off rows behind the planes; more than 512 rows: a second round of strips), both orientations,
+    (1 / 4 waves: strips of 64 rows pipelined over the waves, further rounds for more than 256 rows, several workgroups above 512 rows), both orientations,
     every NumPW, both shapes of the cell (predecessors 2 rows / 3 columns back, 4 / 4), against the oracle"""
     monkeypatch.setenv("CL_LANE_MIN_SWEEP", "0")
-    monkeypatch.setenv("CL_LANE_WIDE", "1")       # (pairs above 1 024 rows over several workgroups: off by default — parity-tested here, slower than the strips so far)
     # lopsided pairs, the long graph with a long bubble (a saved column): 1 wave, 4 waves, 8 waves, two rounds
     sizes = [(5, 2100), (30, 700), (64, 300), (65, 400), (165, 2225), (256, 500), (300, 330), (420, 418), (512, 520), (600, 640), (1000, 1010)]
     b = synth.near_chain_batch(sizes, seed=5, n_long=(0, 1))
     plan = gpu_ctx.plan(b)
     plan.execute(); plan.sync()
     names = [li["kernel"] for li in plan.launches() if li["n_problems"]]
-    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<4>", "popoa_lane_kernel<8>"} <= set(names), names
+    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<4>", "popoa_lane_kernel<4, wide>"} <= set(names), names
     # (the generator's deletion bubbles behind an SNP bubble reach five ranks back now and then: such a pair is not a lane pair)
     assert sum(li["n_problems"] for li in plan.launches() if li["kernel"].startswith("popoa_lane_kernel")) >= len(sizes) // 2, plan.launches()
     want = po.oracle_stitch_batch(b)
@@ -386,7 +385,7 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     # and more take this route too; saved columns whose cells cross a group boundary; every NumPW; a resident plan executed again
     b = synth.near_chain_batch([(1100, 1200), (2000, 2100), (1500, 5200), (3000, 3100)], seed=31, p_snp=0.03, p_del=0.01, n_long=(0, 1), long_min=300, long_max=700)
     plan = gpu_ctx.plan(b)
-    assert sum(li["n_problems"] for li in plan.launches() if li["kernel"] == "popoa_lane_kernel<8, wide>") >= 3, plan.launches()
+    assert sum(li["n_problems"] for li in plan.launches() if li["kernel"] == "popoa_lane_kernel<4, wide>") >= 3, plan.launches()
     want = po.oracle_stitch_batch(b)
     for _ in range(3):
         plan.execute(); plan.sync()
@@ -399,13 +398,13 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
         b = synth.sized_dag_batch([(1300, 1300), (2500, 1100), (1100, 2600)], seed=80 + npw, extra_edge_p=0.1, skip_max=2)
         f = np.full(b.n_problems, npw, np.uint8)
         plan = gpu_ctx.plan(b, force_num_pw=f)
-        assert all(li["kernel"] == "popoa_lane_kernel<8, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
+        assert all(li["kernel"] == "popoa_lane_kernel<4, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
         plan.destroy()
         got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
     lin = synth.linear_batch([(4100, 4300), (6300, 6300), (4096, 9000)], seed=14)
     plan = gpu_ctx.plan(lin)
-    assert all(li["kernel"] == "popoa_lane_kernel<8, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
+    assert all(li["kernel"] == "popoa_lane_kernel<4, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
     plan.destroy()
     assert gpu_ctx.stitch_batch_align(lin).same_as(po.oracle_stitch_batch(lin)) is None
     # many small near-chain pairs in one launch
