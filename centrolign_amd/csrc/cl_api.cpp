@@ -1099,19 +1099,23 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             uint32_t lane_dr = 0, lane_dc = 0, lane_slots = 0;
             uint64_t lane_lds = 0;
             std::vector<uint32_t> lane_words;
-            // Four waves per workgroup — one per SIMD — whatever the number of rows: with eight waves every step ran 2.7 x slower (0.93 against 0.34 us: two waves per
-            // SIMD and a barrier of eight per chunk).  More strips of 64 rows than waves take further rounds; above 512 rows (WIDE) the strips are dealt to groups of
-            // four, a workgroup each, on different compute units (popoa_lane.h), at most 128 groups.  CL_LANE_WIDE=0 (read per plan): no wide pairs — up to 1 024 rows
-            // in rounds of one workgroup, beyond that the strips of popoa_strip_kernel as in round 4
-            const bool no_wide = [] { const char* e = getenv("CL_LANE_WIDE"); return e && *e == '0'; }();
-            const bool lane_wide = n_rows > 513 && !(no_wide && n_rows <= 1025);
-            const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 3) / 4 : 1;
+            // Which workgroup shapes (measured on one pair alone, profiles/r05_lane_probe.txt and DESIGN.md §4.3): one, two or three ACTIVE waves of a workgroup run a
+            // step in 0.24 / 0.30 / 0.30 us, four in 0.55 us, eight in 0.93 us; strips dealt to several workgroups (WIDE: groups of three strips, progress words between
+            // them) pay ~14 us per chunk of 32 steps for the hand-off across compute units (write-through stores against a 64-deep store queue, reads past the caches).
+            // So by default the register kernel takes pairs of up to 192 rows — where it is 1.4-1.5 x faster than the systolic kernel on a long sweep — and leaves the
+            // rest where round 4 had it.  CL_LANE_MAX_ROWS (default 192; up to 1 024: further rounds of four waves) and CL_LANE_WIDE=1 (pairs above 192 rows over
+            // several workgroups, up to 128 groups) widen it: parity-tested (tests/test_gpu_parity.py), slower than the strips on 5 500 x 5 500 (16.6 against 12.7 ms)
+            const bool want_wide = [] { const char* e = getenv("CL_LANE_WIDE"); return e && *e == '1'; }();
+            const uint64_t lane_max_rows = [] { const char* e = getenv("CL_LANE_MAX_ROWS"); const long v = e ? atol(e) : 192; return (uint64_t)(v < 1 ? 1 : v > 1024 ? 1024 : v); }();
+            const bool no_wide = !want_wide;
+            const bool lane_wide = want_wide && n_rows > 193;
+            const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 2) / 3 : 1;
             // which pairs: the register kernel wins where a launch lasts as long as its longest sweep (alone on the device: 2 225 x 165 0.88 ms against 1.32 ms on the systolic
             // kernel, 2 130 x 35 0.83 against 1.17, 441 x 433 0.60 against 0.71); on the thousands of small pairs that fill a launch's workgroups it issues about as many
             // instructions per cell as the systolic kernel and its launches, dealt by (waves, long / short), interleave worse: pairs below CL_LANE_MIN_SWEEP rows + columns
             // (default below) stay where they were
             const uint64_t lane_min_sweep = [] { const char* e = getenv("CL_LANE_MIN_SWEEP"); return e ? (uint64_t)atoll(e) : (uint64_t)512; }();   // (read per plan: tests)
-            if (!g_no_lane && !g_force_general && lane_groups <= 128 && !(lane_wide && (no_wide || g_no_strip)) && n_cols < (1u << 28) && n_rows - 1 + n_cols >= lane_min_sweep) {
+            if (!g_no_lane && !g_force_general && lane_groups <= 128 && (lane_wide || n_rows - 1 <= lane_max_rows) && !(lane_wide && (no_wide || g_no_strip)) && n_cols < (1u << 28) && n_rows - 1 + n_cols >= lane_min_sweep) {
                 const uint32_t nR = (uint32_t)n_rows - 1, nCl = (uint32_t)n_cols;
                 const uint32_t* rp = P.poff[sRow].data() + d.node_base[sRow];
                 const uint8_t* rl = P.lab[sRow].data() + d.node_base[sRow];
@@ -1143,7 +1147,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     lane_dr = shape == 0 ? 2 : 4; lane_dc = near; lane_slots = (uint32_t)far.size();
                     // LDS of a workgroup: the hand-off window between neighbouring strips ([waves - 1][DR][1 + NumPW][128 columns]) + the saved columns
                     const uint64_t lane_w = n_rows - 1 <= 64 ? 1 : 4;
-                    lane_lds = (lane_w > 1 ? (lane_w - 1) * lane_dr * (1 + npw) * 128 * 4 : 0) + (uint64_t)lane_slots * (lane_dr + (lane_wide ? 256 : n_rows - 1) + 1) * (1 + npw) * 4;
+                    lane_lds = (lane_w > 1 ? (lane_w - 1) * lane_dr * (1 + npw) * 128 * 4 : 0) + (uint64_t)lane_slots * (lane_dr + (lane_wide ? 192 : n_rows - 1) + 1) * (1 + npw) * 4;
                     if (!fits || far.size() > 16 || lane_lds > 150 * 1024) continue;
                     take_lane = true;
                     // shortest walk from a source, in nodes (the boundary cells' closed form)

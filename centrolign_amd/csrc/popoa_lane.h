@@ -49,6 +49,8 @@
 
 constexpr uint32_t kLaneChunk = 32;
 constexpr uint32_t kLaneLag = 2 + 62 / kLaneChunk;
+constexpr uint32_t kLaneGroupStrips = 3;   // WIDE: strips (= active waves) per workgroup.  Measured on one pair alone: one, two or three active waves of a workgroup run a step
+                                           // in 0.24 / 0.30 / 0.30 us, FOUR in 0.55 us (two of them end up sharing a SIMD's issue slots): a group is three strips
 constexpr uint32_t kLaneWindow = 128;      // columns of hand-off rows kept in LDS per strip boundary: the consumer reads chunk c while the producer writes chunk c + lag
 constexpr uint32_t kLaneFailed = 0xFFFFFFFFu;
 constexpr uint32_t kLanePolls = 1u << 20;   // x ~1 us: a group waits about a second for its upper neighbour before it gives the pair up
@@ -100,8 +102,9 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     const uint32_t S = (nR + 63u) / 64u, Cn = (nC + 63u + C - 1) / C;
     // WIDE: this workgroup is group `grp` of n_groups and takes the strips grp * W .. in one round; rows_here = the rows an LDS slot of saved cells spans
     const uint32_t n_groups = WIDE ? ((pd.pad >> 8) & 0x7Fu) + 1u : 1u;
-    const uint32_t rowbase = WIDE ? grp * W * 64u : 0u;
-    const uint32_t area = (DR + (WIDE ? W * 64u : nR) + 1u) * CW;     // ints per saved column: [0] the boundary row's Mf, [DR - d] ghost rows (unused), [DR + local row]
+    constexpr uint32_t GS = WIDE ? kLaneGroupStrips : (uint32_t)W;   // strips of a round / group (WIDE: one wave of the workgroup stays idle)
+    const uint32_t rowbase = WIDE ? grp * GS * 64u : 0u;
+    const uint32_t area = (DR + (WIDE ? GS * 64u : nR) + 1u) * CW;     // ints per saved column: [0] the boundary row's Mf, [DR - d] ghost rows (unused), [DR + local row]
     int32_t* const hand = lds;                                        // the LDS hand-off window
     int32_t* const saved = lds + (W > 1 ? (W - 1) * DR * CW * kLaneWindow : 0);
     uint32_t* const progress = WIDE ? lane_sync + B.aux[pd.aux_base] : nullptr;
@@ -139,7 +142,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     }
 
     const uint32_t Pm = Cn > kLaneLag * W ? Cn : kLaneLag * W;   // macro-step period of one round of W strips
-    const uint32_t strips_here = WIDE ? (S - grp * W < (uint32_t)W ? S - grp * W : (uint32_t)W) : 0u;
+    const uint32_t strips_here = WIDE ? (S - grp * GS < GS ? S - grp * GS : GS) : 0u;
     const uint32_t total = WIDE ? kLaneLag * (strips_here - 1) + Cn : ((S - 1) / W) * Pm + kLaneLag * ((S - 1) % W) + Cn;
     bool dead = false;   // WIDE: this group has given the pair up (its upper neighbour did not deliver in time, or failed itself)
     uint32_t seen = 0;   // WIDE, wave 0: the upper neighbour's progress as last read (no new read while it already covers the chunk)
@@ -179,8 +182,8 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
     for (uint32_t m = 0; m < total; ++m) {
         const int32_t mm = (int32_t)m - (int32_t)(kLaneLag * wave);
         if (mm >= 0 && !dead) {
-            const uint32_t j = WIDE ? 0u : (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = (WIDE ? grp * W : j * W) + wave;
-            if (s < S && c < Cn) {
+            const uint32_t j = WIDE ? 0u : (uint32_t)mm / Pm, c = (uint32_t)mm - j * Pm, s = (WIDE ? grp * GS : j * W) + wave;
+            if (s < S && c < Cn && (!WIDE || wave < GS)) {
                 const bool real = (s * 64u + lane + 1u) <= nR;
                 const uint32_t t0 = c * C;
                 auto fetch_columns = [&](uint32_t first, int32_t& rec, int32_t& bm) {   // lanes 0 .. C - 1: the records of columns first + 1 ..
@@ -218,7 +221,11 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                     // chunk c of this group's first strip needs the columns of that chunk from the last rows of the group above: its last strip must have finished
                     // c + lag chunks (what the barrier per macro-step guarantees between neighbouring waves of one workgroup).  The hand-off words are written
                     // through to memory (sc1 stores) and read past the caches (sc1 loads): no fence runs while the sweep runs (as in popoa_strip_kernel)
-                    const uint32_t need = c + kLaneLag < Cn ? c + kLaneLag : Cn;
+                    // (the group STARTS two chunks later than it must: both groups advance at the same rate, so the word it reads is then usually two or three chunks
+                    // ahead of the need, one read serves several chunks and hardly ever has to wait — a group that starts the moment it can finds its upper neighbour
+                    // exactly at the need in every chunk and pays the publish + poll round trip, ~15 us, per chunk)
+                    const uint32_t want = c == 0 ? c + kLaneLag + 2 : c + kLaneLag;
+                    const uint32_t need = want < Cn ? want : Cn;
                     uint32_t polls = 0;
                     while (seen < need && seen != kLaneFailed) {
                         seen = __hip_atomic_load(progress + (grp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -254,7 +261,7 @@ __device__ __forceinline__ void lane_body(const ClDeviceBatch& B, const ClProbDe
                 }
                 int32_t* const bout = brow + (size_t)s * DR * CW * nC;
                 const bool hands_on = s + 1 < S && lane >= 64u - DR;
-                const bool to_lds = W > 1 && s + 1 < S && (WIDE ? wave + 1 < (uint32_t)W : ((s + 1) % W) != 0);
+                const bool to_lds = W > 1 && s + 1 < S && (WIDE ? wave + 1 < GS : ((s + 1) % W) != 0);
                 int32_t* const hout = hand + (size_t)wave * DR * CW * kLaneWindow + (size_t)((63u - lane) * CW) * kLaneWindow;
                 const uint32_t rmask = rrec & 0xFu;
                 const bool rsrc = (rrec >> 4) & 1u;

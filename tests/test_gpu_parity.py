@@ -344,13 +344,15 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     (1 / 4 waves: strips of 64 rows pipelined over the waves, further rounds for more than 256 rows, several workgroups above 512 rows), both orientations,
     every NumPW, both shapes of the cell (predecessors 2 rows / 3 columns back, 4 / 4), against the oracle"""
     monkeypatch.setenv("CL_LANE_MIN_SWEEP", "0")
+    monkeypatch.setenv("CL_LANE_MAX_ROWS", "1024")   # (default 192 rows: up to three active waves; beyond, rounds of four waves — slower per step, parity-tested here)
+    monkeypatch.setenv("CL_LANE_WIDE", "0")
     # lopsided pairs, the long graph with a long bubble (a saved column): 1 wave, 4 waves, 8 waves, two rounds
     sizes = [(5, 2100), (30, 700), (64, 300), (65, 400), (165, 2225), (256, 500), (300, 330), (420, 418), (512, 520), (600, 640), (1000, 1010)]
     b = synth.near_chain_batch(sizes, seed=5, n_long=(0, 1))
     plan = gpu_ctx.plan(b)
     plan.execute(); plan.sync()
     names = [li["kernel"] for li in plan.launches() if li["n_problems"]]
-    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<4>", "popoa_lane_kernel<4, wide>"} <= set(names), names
+    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<4>"} <= set(names), names
     # (the generator's deletion bubbles behind an SNP bubble reach five ranks back now and then: such a pair is not a lane pair)
     assert sum(li["n_problems"] for li in plan.launches() if li["kernel"].startswith("popoa_lane_kernel")) >= len(sizes) // 2, plan.launches()
     want = po.oracle_stitch_batch(b)
@@ -381,7 +383,8 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     assert "popoa_lane_kernel" in _kernels(plan), plan.launches()
     plan.destroy()
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
-    # WIDE pairs: more than 1 024 rows — groups of eight strips, a workgroup each, on different compute units, progress words between them; chain pairs of 4 096 rows
+    monkeypatch.setenv("CL_LANE_WIDE", "1")
+    # WIDE pairs (CL_LANE_WIDE=1: off by default, slower than the strips so far): more than 192 rows — groups of eight strips, a workgroup each, on different compute units, progress words between them; chain pairs of 4 096 rows
     # and more take this route too; saved columns whose cells cross a group boundary; every NumPW; a resident plan executed again
     b = synth.near_chain_batch([(1100, 1200), (2000, 2100), (1500, 5200), (3000, 3100)], seed=31, p_snp=0.03, p_del=0.01, n_long=(0, 1), long_min=300, long_max=700)
     plan = gpu_ctx.plan(b)
