@@ -1102,11 +1102,12 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // Which workgroup shapes (measured on one pair alone, profiles/r05_lane_probe.txt and DESIGN.md §4.3): one, two or three ACTIVE waves of a workgroup run a
             // step in 0.24 / 0.30 / 0.30 us, four in 0.55 us, eight in 0.93 us; strips dealt to several workgroups (WIDE: groups of three strips, progress words between
             // them) pay ~14 us per chunk of 32 steps for the hand-off across compute units (write-through stores against a 64-deep store queue, reads past the caches).
-            // So by default the register kernel takes pairs of up to 192 rows — where it is 1.4-1.5 x faster than the systolic kernel on a long sweep — and leaves the
-            // rest where round 4 had it.  CL_LANE_MAX_ROWS (default 192; up to 1 024: further rounds of four waves) and CL_LANE_WIDE=1 (pairs above 192 rows over
-            // several workgroups, up to 128 groups) widen it: parity-tested (tests/test_gpu_parity.py), slower than the strips on 5 500 x 5 500 (16.6 against 12.7 ms)
+            // Inside the timed step of 10 x 1 Mbp (sixteen launches side by side, three runs each): register kernel for pairs up to 192 rows 2.49-2.58 ms, up to 512 or
+            // 1 024 rows (further rounds of four waves) 2.30-2.35 ms, not at all 2.57 ms — so the default is 1 024 rows (CL_LANE_MAX_ROWS), in one workgroup.
+            // CL_LANE_WIDE=1 deals pairs above 192 rows to several workgroups (up to 128 groups): parity-tested (tests/test_gpu_parity.py), slower than the strips
+            // on 5 500 x 5 500 (16.6 against 12.7 ms), off by default
             const bool want_wide = [] { const char* e = getenv("CL_LANE_WIDE"); return e && *e == '1'; }();
-            const uint64_t lane_max_rows = [] { const char* e = getenv("CL_LANE_MAX_ROWS"); const long v = e ? atol(e) : 192; return (uint64_t)(v < 1 ? 1 : v > 1024 ? 1024 : v); }();
+            const uint64_t lane_max_rows = [] { const char* e = getenv("CL_LANE_MAX_ROWS"); const long v = e ? atol(e) : 1024; return (uint64_t)(v < 1 ? 1 : v > 1024 ? 1024 : v); }();
             const bool no_wide = !want_wide;
             const bool lane_wide = want_wide && n_rows > 193;
             const uint64_t lane_groups = lane_wide ? ((n_rows - 1 + 63) / 64 + 2) / 3 : 1;
