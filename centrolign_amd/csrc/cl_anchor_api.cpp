@@ -383,25 +383,6 @@ namespace {
 typedef std::vector<std::pair<size_t, size_t>> Intervals;
 const double kPartMinInf = std::numeric_limits<double>::lowest();
 
-// PartitionClient::traceback (partition_client.hpp:29-53)
-Intervals partition_traceback(const std::vector<std::pair<double, double>>& dp, const std::vector<size_t>& backpointer, size_t tb_idx) {
-    Intervals partition;
-    bool in_interval = true;
-    while (tb_idx > 0) {
-        if (in_interval) {
-            const size_t prev = backpointer[tb_idx];
-            partition.emplace_back(prev, tb_idx);
-            tb_idx = prev;
-            in_interval = false;
-        } else {
-            in_interval = (dp[tb_idx].first == dp[tb_idx - 1].second);
-            --tb_idx;
-        }
-    }
-    std::reverse(partition.begin(), partition.end());
-    return partition;
-}
-
 struct PartCtx {
     const cl_partition_params* pp;
     double min_score() const { return pp->minimum_segment_score * pp->score_scale; }
@@ -415,164 +396,192 @@ struct PartCtx {
     }
 };
 
-// partitioner.hpp:215-270
+// ---- segment selection over the chain's anchors: the three rules of Partitioner (partitioner.hpp:215-684) ---------------------------------------
+// What all three rules share, in this library's own terms.  A CUT is a position between two items (0 .. n).  Per cut i the table keeps
+//   rest[i]: the best total of segments chosen among items 0 .. i - 1 with item i - 1 in no segment (or i == 0),
+//   shut[i]: the best total with a segment ENDING at cut i, and from[i], the cut where that segment starts.
+// A segment [a, i) is worth (prefix[i] - prefix[a]) - min_score on top of rest[a]; the rules differ in which starts a are admissible for an end i.
+// The results have to be the reference's to the last bit — exact ties between candidate segments (a cut on either side of a zero-score item) are decided
+// by rounding — so the sums are formed in the operation order of the reference AS BUILT (-O3 -ffast-math regroups the source's expressions; read off
+// the disassembly of oracle/_ref): a segment's total is  (start term - min_score) + prefix[end]  with start term = rest[a] - prefix[a].
+struct SegmentTable {
+    std::vector<double> rest, shut;
+    std::vector<size_t> from;
+    size_t best_end = 0;
+    explicit SegmentTable(size_t n_items) : rest(n_items + 1, kPartMinInf), shut(n_items + 1, kPartMinInf), from(n_items + 1, (size_t)-1) { rest[0] = 0; shut[0] = 0; }
+    size_t cuts() const { return rest.size(); }
+    void carry(size_t i) { rest[i] = std::max(rest[i - 1], shut[i - 1]); }
+    void close_at(size_t i, double total, size_t start) { shut[i] = total; from[i] = start; }
+    void note_end(size_t i) { if (shut[i] > shut[best_end]) best_end = i; }
+    double start_term(size_t a, const std::vector<double>& prefix) const { return rest[a] - prefix[a]; }
+    // back from the best end: a segment, then cuts without one until the value says a segment ends again (PartitionClient::traceback, partition_client.hpp:29-53)
+    Intervals segments() const {
+        Intervals out;
+        bool at_segment_end = true;
+        for (size_t i = best_end; i > 0;) {
+            if (at_segment_end) {
+                out.emplace_back(from[i], i);
+                i = from[i];
+                at_segment_end = false;
+            } else {
+                at_segment_end = rest[i] == shut[i - 1];
+                --i;
+            }
+        }
+        std::reverse(out.begin(), out.end());
+        return out;
+    }
+};
+
+// rule 1 (partitioner.hpp:215-270): any start; the best start term so far is carried along
 Intervals maximum_weight_partition(const PartCtx& pc, const std::vector<double>& data) {
     const double min_score = pc.min_score();
-    std::vector<double> prefix_sum(data.size() + 1, 0);
-    for (size_t i = 0; i < data.size(); ++i) prefix_sum[i + 1] = prefix_sum[i] + pc.adjust(data[i], i, data.size());
-    std::vector<std::pair<double, double>> dp(data.size() + 1, std::make_pair(kPartMinInf, kPartMinInf));
-    std::vector<size_t> backpointer(dp.size(), (size_t)-1);
-    dp[0].first = 0;
-    dp[0].second = 0;
-    size_t prefix_argmax = 0, tb_idx = 0;
-    for (size_t i = 1; i < dp.size(); ++i) {
-        dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
-        // as built (see window_average_constrained_partition below): (prefix - min) + (dp - prefix)
-        dp[i].second = (prefix_sum[i] - min_score) + (dp[prefix_argmax].first - prefix_sum[prefix_argmax]);
-        backpointer[i] = prefix_argmax;
-        if (dp[i].first - prefix_sum[i] > dp[prefix_argmax].first - prefix_sum[prefix_argmax]) prefix_argmax = i;
-        if (dp[i].second > dp[tb_idx].second) tb_idx = i;
+    const size_t n = data.size();
+    std::vector<double> prefix(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) prefix[i + 1] = prefix[i] + pc.adjust(data[i], i, n);
+    SegmentTable T(n);
+    size_t best_start = 0;
+    for (size_t i = 1; i < T.cuts(); ++i) {
+        T.carry(i);
+        T.close_at(i, (prefix[i] - min_score) + T.start_term(best_start, prefix), best_start);
+        if (T.start_term(i, prefix) > T.start_term(best_start, prefix)) best_start = i;
+        T.note_end(i);
     }
-    return partition_traceback(dp, backpointer, tb_idx);
+    return T.segments();
 }
 
-typedef std::pair<double, size_t> PartKey;
-typedef clhost::MaxTree<PartKey, double> PartTree;
+// Starts indexed by their "surplus" — prefix of (score - weight x minimum average) — so that "segments whose average meets the minimum" is a key range:
+// a static-shape max-tree over (surplus, cut) holding the start terms that are currently admissible (search_trees.hpp)
+typedef std::pair<double, size_t> SurplusKey;
+typedef clhost::MaxTree<SurplusKey, double> StartTree;
 
-// partitioner.hpp:272-351
+// rule 2 (partitioner.hpp:272-351): starts whose segment to i has at least the minimum average
 Intervals average_constrained_partition(const PartCtx& pc, const std::vector<std::pair<double, double>>& data) {
     const double min_score = pc.min_score(), min_average = pc.min_average();
-    auto adjusted = [&](size_t i) { return pc.adjust(data[i].first, i, data.size()); };
-    std::vector<double> prefix_sum(data.size()), fractional(data.size());
-    if (!data.empty()) {
-        prefix_sum.front() = data.front().first;
-        fractional.front() = data.front().first - data.front().second * min_average;
+    const size_t n = data.size();
+    auto score = [&](size_t i) { return pc.adjust(data[i].first, i, n); };
+    // (item-indexed here, as the reference has them: prefix[i] / surplus[i] include item i; the first item enters unadjusted)
+    std::vector<double> prefix(n), surplus(n);
+    if (n) {
+        prefix[0] = data[0].first;
+        surplus[0] = data[0].first - data[0].second * min_average;
     }
-    for (size_t i = 1; i < data.size(); ++i) {
-        prefix_sum[i] = prefix_sum[i - 1] + adjusted(i);
-        fractional[i] = fractional[i - 1] + adjusted(i) - data[i].second * min_average;
+    for (size_t i = 1; i < n; ++i) {
+        prefix[i] = prefix[i - 1] + score(i);
+        surplus[i] = surplus[i - 1] + score(i) - data[i].second * min_average;
     }
-    std::vector<std::pair<double, double>> dp(data.size() + 1, std::make_pair(kPartMinInf, kPartMinInf));
-    std::vector<size_t> backpointer(dp.size(), (size_t)-1);
-    std::vector<std::pair<PartKey, double>> tree_data;
-    tree_data.reserve(data.size() + 1);
-    for (size_t i = 0; i < data.size(); ++i) tree_data.emplace_back(PartKey(fractional[i], i + 1), kPartMinInf);
-    tree_data.emplace_back(PartKey(0, 0), 0);
-    dp.front().first = 0;
-    dp.front().second = 0;
-    PartTree tree(tree_data);
-    size_t opt_idx = 0;
-    for (size_t i = 1; i < dp.size(); ++i) {
-        dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
-        const size_t mx = tree.range_max(PartKey(kPartMinInf, 0), PartKey(fractional[i - 1], (size_t)-1));
-        if (mx != tree.end() && tree.val[mx] != kPartMinInf) {
-            dp[i].second = (tree.val[mx] - min_score) + prefix_sum[i - 1];   // as built
-            backpointer[i] = tree.key[mx].second;
-            if (dp[i].second > dp[opt_idx].second) opt_idx = i;
+    std::vector<std::pair<SurplusKey, double>> leaves;
+    leaves.reserve(n + 1);
+    for (size_t i = 0; i < n; ++i) leaves.emplace_back(SurplusKey(surplus[i], i + 1), kPartMinInf);
+    leaves.emplace_back(SurplusKey(0, 0), 0);
+    StartTree starts(leaves);
+    SegmentTable T(n);
+    for (size_t i = 1; i < T.cuts(); ++i) {
+        T.carry(i);
+        const size_t hit = starts.range_max(SurplusKey(kPartMinInf, 0), SurplusKey(surplus[i - 1], (size_t)-1));
+        if (hit != starts.end() && starts.val[hit] != kPartMinInf) {
+            T.close_at(i, (starts.val[hit] - min_score) + prefix[i - 1], starts.key[hit].second);
+            T.note_end(i);
         }
-        tree.update(tree.find(PartKey(fractional[i - 1], i)), dp[i].first - prefix_sum[i - 1]);
+        starts.update(starts.find(SurplusKey(surplus[i - 1], i)), T.rest[i] - prefix[i - 1]);
     }
-    return partition_traceback(dp, backpointer, opt_idx);
+    return T.segments();
 }
 
-// partitioner.hpp:353-684
+// Where a window of `length` units of weight that begins at item i (going right) or ends at item i (going left) stops, and whether that window — completed, when the
+// sequence runs out first, by what the item next to the run-out would contribute (partitioner.hpp:383-443) — has the minimum average
+struct WindowReach {
+    std::vector<int64_t> stop[2];     // [0]: first item beyond the window going right, [1]: going left (-1 = ran off the front)
+    std::vector<char> meets[2];
+    template <class Score>
+    WindowReach(const std::vector<std::pair<double, double>>& data, Score score, double length, double min_average) {
+        const int64_t n = (int64_t)data.size();
+        for (int dir = 0; dir < 2; ++dir) {
+            stop[dir].resize(data.size());
+            meets[dir].resize(data.size());
+            const int64_t step = dir == 0 ? 1 : -1;
+            double in_score = 0.0, in_weight = 0.0;
+            int64_t edge = dir == 0 ? 0 : n - 1;
+            for (int64_t i = edge; i < n && i >= 0; i += step) {
+                while (edge < n && edge >= 0 && in_weight < length) {
+                    in_score += score((size_t)edge);
+                    in_weight += data[edge].second;
+                    edge += step;
+                }
+                stop[dir][i] = edge;
+                if ((edge < 0 || edge >= n) && in_weight < length) {
+                    // the sequence ran out inside the window: as the neighbour we came from, or the window as far as it goes
+                    if (i - step >= 0 && i - step < n) meets[dir][i] = meets[dir][i - step];
+                    else meets[dir][i] = in_score >= min_average * in_weight;
+                } else {
+                    const double last_score = data[edge - step].first, last_weight = data[edge - step].second;
+                    meets[dir][i] = last_weight * in_score + (length - in_weight) * last_score >= last_weight * min_average * length;
+                }
+                in_score -= score((size_t)i);
+                in_weight -= data[i].second;
+            }
+        }
+    }
+};
+
+// rule 3 (partitioner.hpp:353-684): minimum average over the segment AND over every window of window_length inside it.  Starts closer than a window to the end stay in
+// the tree (rule 2 decides for them); a start that falls a window behind leaves the tree and competes as the ONE best "far" start, valid as long as no window
+// beginning between it and the end's last full window, and none ending between its first full window and the end, misses the average (counts of failing windows)
 Intervals window_average_constrained_partition(const PartCtx& pc, const std::vector<std::pair<double, double>>& data) {
     const double min_score = pc.min_score(), min_average = pc.min_average(), window_length = pc.pp->window_length;
-    const int64_t n = (int64_t)data.size();
-    auto adjusted = [&](size_t i) { return pc.adjust(data[i].first, i, data.size()); };
-    std::vector<char> meets_left(data.size()), meets_right(data.size());
-    std::vector<int64_t> leftward_partner(data.size()), rightward_partner(data.size());
-    for (int dir = 0; dir < 2; ++dir) {
-        const bool forward = dir == 0;
-        double window_score = 0.0, window_weight = 0.0;
-        int64_t end = forward ? 0 : n - 1;
-        const int64_t incr = forward ? 1 : -1;
-        auto& meets = forward ? meets_left : meets_right;
-        auto& partner = forward ? rightward_partner : leftward_partner;
-        for (int64_t i = end; i < n && i >= 0; i += incr) {
-            while (end < n && end >= 0 && window_weight < window_length) {
-                window_score += adjusted((size_t)end);
-                window_weight += data[end].second;
-                end += incr;
-            }
-            partner[i] = end;
-            if ((end < 0 || end >= n) && window_weight < window_length) {
-                if (i - incr >= 0 && i - incr < n) meets[i] = meets[i - incr];
-                else meets[i] = (window_score >= min_average * window_weight);
-            } else {
-                const double final_score = data[end - incr].first, final_weight = data[end - incr].second;
-                meets[i] = (final_weight * window_score + (window_length - window_weight) * final_score >= final_weight * min_average * window_length);
-            }
-            window_score -= adjusted((size_t)i);
-            window_weight -= data[i].second;
-        }
+    const size_t n = data.size();
+    auto score = [&](size_t i) { return pc.adjust(data[i].first, i, n); };
+    const WindowReach reach(data, score, window_length, min_average);
+    const std::vector<int64_t>& right_stop = reach.stop[0];
+    const std::vector<int64_t>& left_stop = reach.stop[1];
+    std::vector<double> prefix(n + 1), surplus(n + 1);
+    std::vector<int> fails_right(n + 1), fails_left(n + 1);      // windows that miss the average among those beginning (going right) / ending (going left) before each cut
+    for (size_t i = 0; i < n; ++i) {
+        prefix[i + 1] = prefix[i] + score(i);
+        surplus[i + 1] = surplus[i] + score(i) - data[i].second * min_average;
+        fails_right[i + 1] = fails_right[i] + (int)!reach.meets[0][i];
+        fails_left[i + 1] = fails_left[i] + (int)!reach.meets[1][i];
     }
-    std::vector<double> prefix_sum(data.size() + 1), fractional(data.size() + 1);
-    std::vector<int> left_fail(data.size() + 1), right_fail(data.size() + 1);
-    for (size_t i = 0; i < data.size(); ++i) {
-        prefix_sum[i + 1] = prefix_sum[i] + adjusted(i);
-        fractional[i + 1] = fractional[i] + adjusted(i) - data[i].second * min_average;
-        left_fail[i + 1] = left_fail[i] + (int)!meets_left[i];
-        right_fail[i + 1] = right_fail[i] + (int)!meets_right[i];
-    }
-    std::vector<std::pair<PartKey, double>> tree_data;
-    tree_data.reserve(fractional.size() + 1);
-    for (size_t i = 0; i < fractional.size(); ++i) tree_data.emplace_back(PartKey(fractional[i], i), kPartMinInf);
-    tree_data.front().second = 0;
-    PartTree tree(tree_data);
-    std::vector<std::pair<double, double>> dp(data.size() + 1, std::make_pair(kPartMinInf, kPartMinInf));
-    std::vector<size_t> backpointer(dp.size(), (size_t)-1);
-    dp.front().first = 0;
-    dp.front().second = 0;
-    size_t tb_idx = 0, window_begin = 0;
-    double window_weight = 0.0;
-    size_t outside_argmax = (size_t)-1, argmax_partner = (size_t)-1, k = 0, l = 0, final_l = data.size();
-    {
-        double tail_weight = 0.0;
-        while (final_l != 0 && tail_weight + data[final_l - 1].second < window_length) {
-            tail_weight += data[final_l - 1].second;
-            --final_l;
-        }
-    }
-    for (size_t i = 1; i < dp.size(); ++i) {
-        while (l < final_l && rightward_partner[l] <= (int64_t)i) ++l;
-        if (outside_argmax != (size_t)-1 &&
-            (left_fail[outside_argmax] != left_fail[l] || right_fail[argmax_partner] != right_fail[i]))
-            outside_argmax = (size_t)-1;
-        window_weight += data[i - 1].second;
-        while (window_begin < data.size() && window_weight > window_length) {
-            window_weight -= data[window_begin].second;
-            const size_t it = tree.find(PartKey(fractional[window_begin], window_begin));
-            tree.update(it, kPartMinInf);
-            const size_t j = tree.key[it].second;
-            while (k < data.size() && leftward_partner[k] + 1 < (int64_t)j) ++k;
-            if ((left_fail[j] == left_fail[l] && right_fail[k] == right_fail[i]) &&
-                (outside_argmax == (size_t)-1 || dp[j].first - prefix_sum[j] > dp[outside_argmax].first - prefix_sum[outside_argmax])) {
-                outside_argmax = j;
-                argmax_partner = k;
+    std::vector<std::pair<SurplusKey, double>> leaves;
+    leaves.reserve(n + 2);
+    for (size_t i = 0; i <= n; ++i) leaves.emplace_back(SurplusKey(surplus[i], i), kPartMinInf);
+    leaves.front().second = 0;
+    StartTree starts(leaves);
+    SegmentTable T(n);
+    size_t behind = 0;                 // the first start still inside the current window
+    double behind_weight = 0.0;        // weight between `behind` and the end
+    size_t far_start = (size_t)-1, far_start_reach = (size_t)-1;   // the best start a window or more behind, and the item its first full window stops at
+    size_t last_window = 0, reach_cursor = 0;
+    size_t no_window_from = n;         // items from here on have no full window to their right
+    for (double tail = 0.0; no_window_from != 0 && tail + data[no_window_from - 1].second < window_length; --no_window_from) tail += data[no_window_from - 1].second;
+    for (size_t i = 1; i < T.cuts(); ++i) {
+        while (last_window < no_window_from && right_stop[last_window] <= (int64_t)i) ++last_window;
+        if (far_start != (size_t)-1 && (fails_right[far_start] != fails_right[last_window] || fails_left[far_start_reach] != fails_left[i])) far_start = (size_t)-1;
+        behind_weight += data[i - 1].second;
+        while (behind < n && behind_weight > window_length) {
+            behind_weight -= data[behind].second;
+            const size_t leaf = starts.find(SurplusKey(surplus[behind], behind));
+            starts.update(leaf, kPartMinInf);
+            const size_t a = starts.key[leaf].second;
+            while (reach_cursor < n && left_stop[reach_cursor] + 1 < (int64_t)a) ++reach_cursor;
+            if (fails_right[a] == fails_right[last_window] && fails_left[reach_cursor] == fails_left[i] &&
+                (far_start == (size_t)-1 || T.start_term(a, prefix) > T.start_term(far_start, prefix))) {
+                far_start = a;
+                far_start_reach = reach_cursor;
             }
-            ++window_begin;
+            ++behind;
         }
-        dp[i].first = std::max(dp[i - 1].first, dp[i - 1].second);
-        const size_t mx = tree.range_max(PartKey(kPartMinInf, 0), PartKey(fractional[i], (size_t)-1));
-        if (mx != tree.end() && tree.val[mx] != kPartMinInf) {
-            // operation order of the reference AS BUILT (-O3 -ffast-math regroups partitioner.hpp's "prefix_sum[i] + max - min_score"
-            // and "dp[a].first + prefix_sum[i] - prefix_sum[a] - min_score"; disassembly of oracle/_ref): exact ties between
-            // candidate segments — a boundary on either side of a zero-score item — are decided by the last bit
-            dp[i].second = (tree.val[mx] - min_score) + prefix_sum[i];
-            backpointer[i] = tree.key[mx].second;
+        T.carry(i);
+        const size_t hit = starts.range_max(SurplusKey(kPartMinInf, 0), SurplusKey(surplus[i], (size_t)-1));
+        if (hit != starts.end() && starts.val[hit] != kPartMinInf) T.close_at(i, (starts.val[hit] - min_score) + prefix[i], starts.key[hit].second);
+        if (far_start != (size_t)-1) {
+            const double total = T.start_term(far_start, prefix) + (prefix[i] - min_score);
+            if (total > T.shut[i]) T.close_at(i, total, far_start);
         }
-        if (outside_argmax != (size_t)-1) {
-            const double outside_score = (dp[outside_argmax].first - prefix_sum[outside_argmax]) + (prefix_sum[i] - min_score);
-            if (outside_score > dp[i].second) {
-                dp[i].second = outside_score;
-                backpointer[i] = outside_argmax;
-            }
-        }
-        if (dp[i].second > dp[tb_idx].second) tb_idx = i;
-        tree.update(tree.find(PartKey(fractional[i], i)), dp[i].first - prefix_sum[i]);
+        T.note_end(i);
+        starts.update(starts.find(SurplusKey(surplus[i], i)), T.start_term(i, prefix));
     }
-    return partition_traceback(dp, backpointer, tb_idx);
+    return T.segments();
 }
 
 // utility.hpp:255-285

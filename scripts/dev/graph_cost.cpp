@@ -14,6 +14,9 @@
 #include <vector>
 
 __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
+// the library's kernels take their descriptors BY VALUE (ClChainDevice + ClFarDevice: ~760 bytes of kernel arguments): does that cost host time per launch?  (third argument "big")
+struct BigArgs { int x[190]; };
+__global__ void empty_big_kernel(BigArgs a, int* p) { if (p && threadIdx.x == 9999) *p = a.x[7]; }
 __global__ void spin_kernel(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) {} }   // 100 MHz ticks
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -21,6 +24,8 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 128, lag = 2;
+    const bool big = argc > 2 && argv[2][0] == 'b';
+    BigArgs ba{};
     hipStream_t s0, far[2], seal;
     CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
     for (auto& s : far) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -43,15 +48,18 @@ int main(int argc, char** argv) {
             hipStream_t fs = far[k & 1];
             if (k > lag) {
                 CK(hipStreamWaitEvent(fs, ev_seal[k - lag - 1], 0));
-                if (ext) hipExtLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, fs, nullptr, ev_far[k], 0, (int*)nullptr);
+                if (ext && big) hipExtLaunchKernelGGL(empty_big_kernel, dim3(64), dim3(256), 0, fs, nullptr, ev_far[k], 0, ba, (int*)nullptr);
+                else if (ext) hipExtLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, fs, nullptr, ev_far[k], 0, (int*)nullptr);
                 else { hipLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, fs, (int*)nullptr); CK(hipEventRecord(ev_far[k], fs)); }
             }
-            hipLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, s0, (int*)nullptr);          // near
+            if (big) hipLaunchKernelGGL(empty_big_kernel, dim3(64), dim3(256), 0, s0, ba, (int*)nullptr);
+            else hipLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, s0, (int*)nullptr);          // near
             if (k > lag) CK(hipStreamWaitEvent(s0, ev_far[k], 0));
             if (ext) hipExtLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, nullptr, ev_walk[k], 0, 2000LL);   // walk: 20 us
             else { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s0, 2000LL); CK(hipEventRecord(ev_walk[k], s0)); }
             CK(hipStreamWaitEvent(seal, ev_walk[k], 0));
-            if (ext) hipExtLaunchKernelGGL(empty_kernel, dim3(8), dim3(64), 0, seal, nullptr, ev_seal[k], 0, (int*)nullptr);
+            if (ext && big) hipExtLaunchKernelGGL(empty_big_kernel, dim3(8), dim3(64), 0, seal, nullptr, ev_seal[k], 0, ba, (int*)nullptr);
+            else if (ext) hipExtLaunchKernelGGL(empty_kernel, dim3(8), dim3(64), 0, seal, nullptr, ev_seal[k], 0, (int*)nullptr);
             else { hipLaunchKernelGGL(empty_kernel, dim3(8), dim3(64), 0, seal, (int*)nullptr); CK(hipEventRecord(ev_seal[k], seal)); }
         }
         for (int f = 0; f < 2; ++f) { CK(hipEventRecord(join_far[f], far[f])); CK(hipStreamWaitEvent(s0, join_far[f], 0)); }
@@ -65,7 +73,7 @@ int main(int argc, char** argv) {
         double t1 = now_ms();
         CK(hipStreamSynchronize(s0));
         double t2 = now_ms();
-        printf("direct, %d macro-blocks: enqueue %.2f ms (%.1f us per block), until done %.2f ms\n", B, t1 - t0, (t1 - t0) * 1e3 / B, t2 - t0);
+        printf("direct%s, %d macro-blocks: enqueue %.2f ms (%.1f us per block), until done %.2f ms\n", big ? " (760-byte arguments)" : "", B, t1 - t0, (t1 - t0) * 1e3 / B, t2 - t0);
     }
     for (int rep = 0; rep < 2; ++rep) {
         hipGraph_t g; hipGraphExec_t ge;
