@@ -279,80 +279,102 @@ inline std::vector<uint64_t> shortest_path(const Side& g, uint64_t from, uint64_
     return path;
 }
 
-// alignment.hpp:2036-2282.  `sh` is the short graph (node_id1 of the result), `lg` the long one.
+// ---- two-sided search around one long deletion (alignment.hpp:2036-2282) -----------------------------------------------------------------------------
+// `sh` is the short graph (node_id1 of the result), `lg` the long one.  Two Dijkstra fronts, one from the sources and one from the sinks, advance in turn
+// (the one with the lower floor first) until a position of one front in match state can be joined to one of the other by a pure deletion in the long graph;
+// the search then runs `scope` score units longer — no single step costs more — and the cheapest junction among everything the fronts landed on is taken.
+
+// one front of the search, with what it has landed on: short node -> (long node, score) in match state.  `landed` is ITERATED when the junction is chosen:
+// the reference keeps the same std::unordered_map<uint64_t, ...> with the same insertion sequence, which is what makes the iteration order (and with it the
+// choice among equally good junctions) the same
+struct DeletionFront {
+    BackMap back;
+    BucketQueue queue;
+    int64_t floor = 0;     // the lowest score still queued
+    std::unordered_map<uint64_t, std::vector<std::pair<uint64_t, int64_t>>> landed;
+    DeletionFront(const Side& sh, const Side& lg, const WfaParams& wp) : back(sh.n, lg.n, wp.npw) { queue.emplace_back(); }
+    void seed(uint64_t a, uint64_t b) { queue.back().push(Item{Pos{~0ull, ~0ull, 0}, Pos{a, b, 0}}); }
+};
+
+// where the two halves are joined: the short node both fronts reached, the long nodes either side of the deletion
+struct DeletionJunction {
+    int64_t score = std::numeric_limits<int64_t>::max();
+    uint64_t short_node = ~0ull, long_before = ~0ull, long_after = ~0ull;
+};
+
 inline Alignment deletion_wfa_po_poa(const Side& sh, const Side& lg, const WfaParams& wp) {
+    const int64_t never = std::numeric_limits<int64_t>::max();
+    const std::pair<uint64_t, uint64_t> nowhere(~0ull, ~0ull);
     int64_t scope = wp.mismatch;
     for (int i = 0; i < wp.npw; ++i) scope = std::max<int64_t>(scope, (int64_t)wp.gap_open[i] + wp.gap_extend[i]);
-    BackMap back_fwd(sh.n, lg.n, wp.npw), back_rev(sh.n, lg.n, wp.npw);
-    MinDistance min_distance(lg);
-    int64_t qmin_fwd = 0, qmin_rev = 0;
-    BucketQueue queue_fwd, queue_rev;
-    queue_fwd.emplace_back();
-    queue_fwd.back().push(Item{Pos{~0ull, ~0ull, 0}, Pos{sh.n, lg.n, 0}});
-    queue_rev.emplace_back();
+    MinDistance long_hops(lg);
+    DeletionFront from_sources(sh, lg, wp), from_sinks(sh, lg, wp);
+    from_sources.seed(sh.n, lg.n);
     for (uint64_t a : sh.sinks)
-        for (uint64_t b : lg.sinks) queue_rev.back().push(Item{Pos{~0ull, ~0ull, 0}, Pos{a, b, 0}});
-    const std::unordered_set<uint64_t> src_short(sh.sources.begin(), sh.sources.end()), src_long(lg.sources.begin(), lg.sources.end());
-    auto next_short = [&](uint64_t v) -> const std::vector<uint64_t>& { return v == sh.n ? sh.sources : sh.next[v]; };
-    auto next_long = [&](uint64_t v) -> const std::vector<uint64_t>& { return v == lg.n ? lg.sources : lg.next[v]; };
-    auto prev_short = [&](uint64_t v) { std::vector<uint64_t> p = sh.prev[v]; if (src_short.count(v)) p.push_back(sh.n); return p; };
-    auto prev_long = [&](uint64_t v) { std::vector<uint64_t> p = lg.prev[v]; if (src_long.count(v)) p.push_back(lg.n); return p; };
-    auto no_prune = [](const Pos&, int64_t) { return false; };
-    // short node -> (long node, score) records; ITERATED below: the same container type and insertion sequence as the
-    // reference's std::unordered_map<uint64_t, ...> give the same iteration order
-    std::unordered_map<uint64_t, std::vector<std::pair<uint64_t, int64_t>>> fwd_score, rev_score;
-    int64_t stop_score = std::numeric_limits<int64_t>::max();
-    auto update_fwd = [&](const Pos& p, int64_t s) {
-        if (p.comp == 0) fwd_score[p.a].emplace_back(p.b, s);
-        if (stop_score == std::numeric_limits<int64_t>::max()) {
-            auto it = rev_score.find(p.a);
-            if (it != rev_score.end())
-                for (const auto& rp : it->second)
-                    if (p.b == rp.first || (p.b != lg.n && rp.first != lg.n && min_distance(p.b, rp.first) != -1)) stop_score = s + scope;
-        }
+        for (uint64_t b : lg.sinks) from_sinks.seed(a, b);
+    int64_t search_until = never;      // set once, when the fronts first become joinable
+
+    // a long-graph deletion from `before` to `after` exists (or none is needed)
+    auto joinable = [&](uint64_t before, uint64_t after) { return before == after || (before != lg.n && after != lg.n && long_hops(before, after) != -1); };
+    // what a front does with a position it settles: record match-state landings, and look for a first junction with the other front
+    auto settle = [&](DeletionFront& mine, const DeletionFront& other, bool mine_is_before) {
+        return [&mine, &other, mine_is_before, &search_until, &joinable, never, scope](const Pos& p, int64_t score) {
+            if (p.comp == 0) mine.landed[p.a].emplace_back(p.b, score);
+            if (search_until != never) return;
+            const auto met = other.landed.find(p.a);
+            if (met == other.landed.end()) return;
+            for (const auto& there : met->second)
+                if (mine_is_before ? joinable(p.b, there.first) : joinable(there.first, p.b)) search_until = score + scope;
+        };
     };
-    auto update_rev = [&](const Pos& p, int64_t s) {
-        if (p.comp == 0) rev_score[p.a].emplace_back(p.b, s);
-        if (stop_score == std::numeric_limits<int64_t>::max()) {
-            auto it = fwd_score.find(p.a);
-            if (it != fwd_score.end())
-                for (const auto& fp : it->second)
-                    if (p.b == fp.first || (p.b != lg.n && fp.first != lg.n && min_distance(fp.first, p.b) != -1)) stop_score = s + scope;
-        }
-    };
-    auto stop = [&](uint64_t, uint64_t, int) { return qmin_fwd >= stop_score && qmin_rev >= stop_score; };
-    auto no_greedy = [](uint64_t, uint64_t) { return false; };
-    std::pair<uint64_t, uint64_t> end_fwd(~0ull, ~0ull), end_rev(~0ull, ~0ull);
-    const std::pair<uint64_t, uint64_t> null(~0ull, ~0ull);
-    while (end_fwd == null && end_rev == null) {
-        if (qmin_fwd <= qmin_rev)
-            end_fwd = wfa_iteration<true>(queue_fwd, qmin_fwd, back_fwd, sh, lg, wp, no_prune, update_fwd, next_short, next_long, stop, no_greedy);
+    const auto settle_fwd = settle(from_sources, from_sinks, true), settle_rev = settle(from_sinks, from_sources, false);
+    auto finished = [&](uint64_t, uint64_t, int) { return from_sources.floor >= search_until && from_sinks.floor >= search_until; };
+    auto keep_all = [](const Pos&, int64_t) { return false; };
+    auto never_greedy = [](uint64_t, uint64_t) { return false; };
+    // neighbours with the dummy start (node id n) in front of the sources
+    const std::unordered_set<uint64_t> short_sources(sh.sources.begin(), sh.sources.end()), long_sources(lg.sources.begin(), lg.sources.end());
+    auto after_short = [&](uint64_t v) -> const std::vector<uint64_t>& { return v == sh.n ? sh.sources : sh.next[v]; };
+    auto after_long = [&](uint64_t v) -> const std::vector<uint64_t>& { return v == lg.n ? lg.sources : lg.next[v]; };
+    auto before_short = [&](uint64_t v) { std::vector<uint64_t> p = sh.prev[v]; if (short_sources.count(v)) p.push_back(sh.n); return p; };
+    auto before_long = [&](uint64_t v) { std::vector<uint64_t> p = lg.prev[v]; if (long_sources.count(v)) p.push_back(lg.n); return p; };
+
+    for (bool done = false; !done;) {
+        if (from_sources.floor <= from_sinks.floor)
+            done = wfa_iteration<true>(from_sources.queue, from_sources.floor, from_sources.back, sh, lg, wp, keep_all, settle_fwd, after_short, after_long, finished, never_greedy) != nowhere;
         else
-            end_rev = wfa_iteration<false>(queue_rev, qmin_rev, back_rev, sh, lg, wp, no_prune, update_rev, prev_short, prev_long, stop, no_greedy);
+            done = wfa_iteration<false>(from_sinks.queue, from_sinks.floor, from_sinks.back, sh, lg, wp, keep_all, settle_rev, before_short, before_long, finished, never_greedy) != nowhere;
     }
-    int64_t opt_score = std::numeric_limits<int64_t>::max();
-    uint64_t opt_short = ~0ull, opt_long_fwd = ~0ull, opt_long_rev = ~0ull;
-    for (const auto& fwd_rec : fwd_score) {
-        auto it = rev_score.find(fwd_rec.first);
-        if (it == rev_score.end()) continue;
-        for (const auto& fp : fwd_rec.second) {
-            if (fp.first == lg.n) continue;
-            for (const auto& rp : it->second) {
-                if (rp.first == lg.n) continue;
-                const int64_t dist = min_distance(fp.first, rp.first);
-                if (dist == -1) continue;
-                int64_t score = (int64_t)(wp.gap_open[0] + (uint64_t)wp.gap_extend[0] * (uint64_t)dist);
-                for (int i = 1; i < wp.npw; ++i) score = std::min<int64_t>(score, (int64_t)(wp.gap_open[i] + (uint64_t)wp.gap_extend[i] * (uint64_t)dist));
-                score += fp.second + rp.second;
-                if (score < opt_score) { opt_score = score; opt_short = fwd_rec.first; opt_long_fwd = fp.first; opt_long_rev = rp.first; }
+
+    // the cheapest junction: landing scores of both sides plus the cheapest gap component for the hops between them
+    auto deletion_cost = [&](int64_t hops) {
+        int64_t cost = (int64_t)(wp.gap_open[0] + (uint64_t)wp.gap_extend[0] * (uint64_t)hops);
+        for (int i = 1; i < wp.npw; ++i) cost = std::min<int64_t>(cost, (int64_t)(wp.gap_open[i] + (uint64_t)wp.gap_extend[i] * (uint64_t)hops));
+        return cost;
+    };
+    DeletionJunction best;
+    for (const auto& at_short : from_sources.landed) {
+        const auto met = from_sinks.landed.find(at_short.first);
+        if (met == from_sinks.landed.end()) continue;
+        for (const auto& before : at_short.second) {
+            if (before.first == lg.n) continue;
+            for (const auto& after : met->second) {
+                if (after.first == lg.n) continue;
+                const int64_t hops = long_hops(before.first, after.first);
+                if (hops == -1) continue;
+                const int64_t total = deletion_cost(hops) + (before.second + after.second);
+                if (total < best.score) {
+                    best.score = total;
+                    best.short_node = at_short.first; best.long_before = before.first; best.long_after = after.first;
+                }
             }
         }
     }
-    Alignment aln = wfa_traceback(back_fwd, opt_short, opt_long_fwd, sh, lg);
-    const Alignment rev = wfa_traceback_rev(back_rev, opt_short, opt_long_rev);
-    const std::vector<uint64_t> between = shortest_path(lg, opt_long_fwd, opt_long_rev);
-    for (size_t i = 1; i < between.size(); ++i) aln.emplace_back(kGap, between[i]);
-    for (const auto& pr : rev) aln.push_back(pr);
+    // left half, the deleted stretch of the long graph, right half
+    Alignment aln = wfa_traceback(from_sources.back, best.short_node, best.long_before, sh, lg);
+    const std::vector<uint64_t> deleted = shortest_path(lg, best.long_before, best.long_after);
+    for (size_t i = 1; i < deleted.size(); ++i) aln.emplace_back(kGap, deleted[i]);
+    const Alignment right = wfa_traceback_rev(from_sinks.back, best.short_node, best.long_after);
+    aln.insert(aln.end(), right.begin(), right.end());
     return aln;
 }
 
