@@ -140,6 +140,23 @@ def big_dag_section(ctx):
         res["speedup"] = res["anti_diagonal_kernel"]["ms"] / res["strips"]["ms"]
         res["same_alignment"] = (res["strips"]["score"], res["strips"]["pairs"]) == (res["anti_diagonal_kernel"]["score"], res["anti_diagonal_kernel"]["pairs"])
     res["workload"] = "synth.sized_dag_batch([(5500, 5500)], seed 5, extra_edge_p 0.02, skip_max 2): 30.3 M cells, NumPW 3"
+    # long bubbles with two long branches in BOTH graphs (missing #3): in the reference's topological order both graphs read a branch back and the pair
+    # is left to the anti-diagonal kernel (CL_RANK_ORDER=lifo: rounds 1-4); ranked by level (the default choice, choose_rank_order in cl_api.cpp) it meets the strips' conditions
+    code2 = code.replace("synth.sized_dag_batch([(5500, 5500)], seed=5, extra_edge_p=0.02, skip_max=2)",
+                         "synth.near_chain_batch([(5000, 5200)], seed=3, p_snp=0.03, p_del=0.01, n_long=(3, 3), long_min=200, long_max=400, long_other=16)")
+    ff = {}
+    for key, env in (("level_order", {}), ("reference_order", {"CL_RANK_ORDER": "lifo"})):
+        try:
+            r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, **env), capture_output=True, text=True, timeout=180)
+            ff[key] = json.loads(r.stdout.strip().splitlines()[-1])
+            ff[key]["g_cells_per_s"] = ff[key]["cells"] / ff[key]["ms"] / 1e6
+        except Exception as e:   # noqa: BLE001
+            ff[key] = {"error": str(e)[:200]}
+    if "ms" in ff.get("level_order", {}) and "ms" in ff.get("reference_order", {}):
+        ff["speedup"] = ff["reference_order"]["ms"] / ff["level_order"]["ms"]
+        ff["same_alignment"] = (ff["level_order"]["score"], ff["level_order"]["pairs"]) == (ff["reference_order"]["score"], ff["reference_order"]["pairs"])
+    ff["workload"] = "synth.near_chain_batch([(5000, 5200)], seed 3, n_long (3, 3), long 200-400, long_other 16): two-long-branch bubbles in both graphs"
+    res["far_forks_in_both_graphs"] = ff
     return res
 
 

@@ -112,7 +112,7 @@ constexpr uint32_t kPeerTailWords = kPeerDoneAt + kPeerDoneWords;
 struct ClFarDevice {
     uint32_t n_levels, r_pad;
     uint32_t* arena;             // all search structures of all levels
-    // per level, in words from `arena`: [0] the blocked offset order (2 * r_pad words: 8 keys | 8 running maxima per block), [1] the blocked
+    // per level, in BLOCKS OF 8 WORDS from `arena` (far_at, chain_far.hip: 2^35 words): [0] the blocked offset order (2 * r_pad words: 8 keys | 8 running maxima per block), [1] the blocked
     // (bucket << off_bits | offset) order (0xFFFFFFFF: sparse_chain_dp has none), [2 + j] every 8^(j+1)-th key of the offset order,
     // [2 + kFarMaxLevels + j] the same for the bucket order  (j = 0 .. level)
     uint32_t tab[kFarMaxLevels][kFarTabWidth];

@@ -97,6 +97,10 @@ __global__ void __launch_bounds__(256) far_node_key_kernel(const uint32_t* order
     if (i < n) node_key[i] = order[i] >> shift;
 }
 
+// a table entry (ClFarDevice::tab) is a position in the arena in BLOCKS OF 8 WORDS: every structure starts on a 32-byte block, and 32 bits of blocks reach 2^35 words
+// (the arena of a 50-sequence root — 625 combinations, 690 M records — is 1.2 x 10^10 words; with word offsets the far pass was off there: round 5)
+template <class T> __device__ __forceinline__ T* far_at(T* arena, uint32_t blocks) { return arena + ((size_t)blocks << 3); }
+
 // the keys of one order of one level into their search tree: position i of the node-wise ascending order holds record perm[i]; its key
 // goes to the blocked array (8 keys | 8 running maxima per block) and, when i is a multiple of 8^j, to index array j
 __global__ void __launch_bounds__(256) far_layout_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ key, uint32_t n, uint32_t* arena, uint32_t ord_off,
@@ -104,11 +108,12 @@ __global__ void __launch_bounds__(256) far_layout_kernel(const uint32_t* __restr
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = key[perm[i]];
-    arena[ord_off + ((i >> 3) << 4) + (i & 7u)] = k;
+    // (ord_off, ix*: table entries, in blocks of 8 words — far_at)
+    far_at(arena, ord_off)[((i >> 3) << 4) + (i & 7u)] = k;
     const uint32_t ix[4] = {ix0, ix1, ix2, ix3};
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j)
-        if (j < n_ix && (i & ((8u << (3 * j)) - 1u)) == 0) arena[ix[j] + (i >> (3 * (j + 1)))] = k;
+        if (j < n_ix && (i & ((8u << (3 * j)) - 1u)) == 0) far_at(arena, ix[j])[i >> (3 * (j + 1))] = k;
 }
 
 // ---- sealing: running maxima of the DP value in the node's two orders ----------------------------------------------------
@@ -121,9 +126,9 @@ __global__ void __launch_bounds__(64) far_seal_kernel(ClFarDevice F, const int* 
     const uint32_t lane = threadIdx.x;
     const uint32_t* __restrict__ perm_o = F.perm_o[l];
     const uint32_t* __restrict__ perm_b = F.perm_b[l];
-    uint32_t* ord_o = F.arena + F.tab[l][0];
+    uint32_t* ord_o = far_at(F.arena, F.tab[l][0]);
     const bool banded = F.tab[l][1] != 0xFFFFFFFFu;   // sparse_chain_dp: one order only
-    uint32_t* ord_b = F.arena + (banded ? F.tab[l][1] : 0u);
+    uint32_t* ord_b = far_at(F.arena, banded ? F.tab[l][1] : 0u);
     int carry_o = INT32_MIN, carry_b = INT32_MIN;
     uint32_t carry_bucket = 0xFFFFFFFEu;
     // the values come through two dependent gathers (order -> record -> dp): U chunks of 64 are fetched together so that a large node pays
@@ -195,9 +200,9 @@ __global__ void __launch_bounds__(1024) far_seal_big_kernel(ClFarDevice F, const
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t* __restrict__ perm_o = F.perm_o[l];
     const uint32_t* __restrict__ perm_b = F.perm_b[l];
-    uint32_t* ord_o = F.arena + F.tab[l][0];
+    uint32_t* ord_o = far_at(F.arena, F.tab[l][0]);
     const bool banded = F.tab[l][1] != 0xFFFFFFFFu;   // sparse_chain_dp: one order only
-    uint32_t* ord_b = F.arena + (banded ? F.tab[l][1] : 0u);
+    uint32_t* ord_b = far_at(F.arena, banded ? F.tab[l][1] : 0u);
     __shared__ int s_wx[16], s_wy[16], s_wf[16], s_carry[2];
     int carry_o = INT32_MIN, carry_b = INT32_MIN;     // by offset: maximum so far; by bucket: maximum of the segment that is open at the tile's start
     for (uint32_t tile = 0; tile < n; tile += 8192) {
@@ -347,11 +352,11 @@ __device__ __forceinline__ double node_bound(const ClFarDevice& F, const uint32_
     uint32_t po = g0 >> (3 * (lvl + 1)), p0 = po, p1 = po, p2 = po;   // entry numbers in the current index array: the node's top block
     bool none = false;
     for (uint32_t j = lvl + 1; j >= 1; --j) {
-        const uint32_t* io = A + t[2 + (j - 1)];
+        const uint32_t* io = far_at(A, t[2 + (j - 1)]);
         const Blk8 eo = load8(io + po);
         uint32_t co, c0 = 1, c1 = 1, c2 = 1;
         if (!SPARSE) {
-            const uint32_t* ib = A + t[2 + kFarMaxLevels + (j - 1)];
+            const uint32_t* ib = far_at(A, t[2 + kFarMaxLevels + (j - 1)]);
             const Blk8 e0 = load8(ib + p0), e1 = load8(ib + p1), e2 = load8(ib + p2);
             c0 = count_lt(e0, xb[0]); c1 = count_lt(e1, xb[1]); c2 = count_lt(e2, xb[2]);
         }
@@ -362,11 +367,11 @@ __device__ __forceinline__ double node_bound(const ClFarDevice& F, const uint32_
     }
     if (none) return -HUGE_VAL;
     // po .. p2 are positions (multiples of 8) in the ascending orders: blocks of 16 words
-    const uint32_t* oo = A + t[0] + 2 * (size_t)po;
+    const uint32_t* oo = far_at(A, t[0]) + 2 * (size_t)po;
     const Blk8 ko = load8(oo), mo = load8(oo + 8);
     int dband = INT32_MIN;
     if (!SPARSE) {
-        const uint32_t* ob = A + t[1];
+        const uint32_t* ob = far_at(A, t[1]);
         const Blk8 k0 = load8(ob + 2 * (size_t)p0), m0 = load8(ob + 2 * (size_t)p0 + 8);
         const Blk8 k1 = load8(ob + 2 * (size_t)p1), m1 = load8(ob + 2 * (size_t)p1 + 8);
         const Blk8 k2 = load8(ob + 2 * (size_t)p2), m2 = load8(ob + 2 * (size_t)p2 + 8);

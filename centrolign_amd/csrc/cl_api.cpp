@@ -270,6 +270,60 @@ bool topological_order(const GraphView& g, const NextLists& nx, std::vector<uint
     return order.size() == n;
 }
 
+// Which topological order the DEVICE ranks a subgraph's nodes by.  Nothing in the result depends on it: the DP's values are those of any topological order and every
+// tie of the traceback is decided by the order of a node's previous() list and of the sink list, both of which are kept as they come.  What depends
+// on it is how far back a row (column) of the matrix reads.  The reference's order (Kahn with a LIFO stack, topological_order.hpp:12-60) lays the branches of a bubble
+// out one after the other: the second branch's first node and the node that closes the bubble read a whole branch back — a "far fork", which the register kernel
+// cannot take, which deepens the systolic kernels' rings by the branch length, and which on BOTH sides of a large pair left only the anti-diagonal sweep.  The LEVEL
+// order (by the longest path from a source, ties in the reference's order) interleaves the branches: inside a bubble of two branches every node reads two ranks back,
+// whatever the branches' length; what remains far is the difference of the branches' lengths, once, at the closing node.  Per graph the order with fewer far reads
+// (more than four ranks back: the register kernel's reach) wins, then the one with the smaller reach, then the reference's — so chains and graphs whose bubbles are
+// single nodes keep the order they had.  CL_RANK_ORDER=lifo|level forces one (measurements, tests).  `order` / `rank` come in as the reference's order and leave as the choice.
+// (read when a plan is made, so that a test can make plans both ways)
+int rank_order_now() { const char* e = getenv("CL_RANK_ORDER"); return !e ? 0 : !strcmp(e, "lifo") ? 1 : !strcmp(e, "level") ? 2 : 0; }
+void choose_rank_order(const GraphView& g, int g_rank_order, std::vector<uint32_t>& order, std::vector<uint32_t>& rank, std::vector<uint32_t>& level, std::vector<uint32_t>& scratch) {
+    const uint64_t n = g.n;
+    if (g_rank_order == 1 || n < 4) return;
+    auto reach = [&](uint64_t& far, uint64_t& longest) {
+        far = longest = 0;
+        for (uint64_t v = 0; v < n; ++v)
+            for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) {
+                const uint64_t back = rank[v] - rank[g.prev_idx[e]];
+                far += back > 4;
+                longest = std::max(longest, back);
+            }
+        for (uint64_t i = 0; i < g.n_src; ++i) {   // a source reads the boundary, index 0
+            const uint64_t back = (uint64_t)rank[g.src[i]] + 1;
+            far += back > 4;
+            longest = std::max(longest, back);
+        }
+    };
+    uint64_t far_ref, longest_ref;
+    reach(far_ref, longest_ref);
+    if (longest_ref <= 1 + (g.n_src > 1) && g_rank_order != 2) return;   // a chain
+    level.assign(n, 0);
+    uint32_t deepest = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint32_t v = order[r];
+        uint32_t l = 0;
+        for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) l = std::max(l, level[g.prev_idx[e]] + 1);
+        level[v] = l;
+        deepest = std::max(deepest, l);
+    }
+    // counting sort by level, stable in the reference's order
+    scratch.assign((size_t)deepest + 2, 0);
+    for (uint64_t v = 0; v < n; ++v) ++scratch[level[v] + 1];
+    for (uint32_t l = 0; l <= deepest; ++l) scratch[l + 1] += scratch[l];
+    std::vector<uint32_t> by_level(n);
+    for (uint64_t r = 0; r < n; ++r) by_level[scratch[level[order[r]]]++] = order[r];
+    std::vector<uint32_t> rank_ref(rank);
+    for (uint32_t r = 0; r < n; ++r) rank[by_level[r]] = r;
+    uint64_t far_lvl, longest_lvl;
+    reach(far_lvl, longest_lvl);
+    if (g_rank_order == 2 || far_lvl < far_ref || (far_lvl == far_ref && longest_lvl < longest_ref)) order.swap(by_level);
+    else rank.swap(rank_ref);
+}
+
 // src/stitcher.cpp:31-52
 int choose_num_pw(uint64_t n1, uint64_t n2, const cl_align_params& p) {
     uint64_t cutoffs[2];
@@ -993,6 +1047,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
     };
     struct Scratch { std::vector<uint32_t> order, st, indeg, rank; };
+    const int rank_order = rank_order_now();
     auto pack_one = [&](uint64_t k, PackPart& P, Scratch& S) {
         std::vector<uint32_t>& order = S.order; std::vector<uint32_t>& st = S.st; std::vector<uint32_t>& indeg = S.indeg; std::vector<uint32_t>& rank = S.rank;
         GraphView g[2] = {view(batch->side[0], k), view(batch->side[1], k)};
@@ -1033,6 +1088,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             if (!topological_order(g[s], nx, order, st, indeg)) { P.fail(CL_ERR_CYCLIC_GRAPH, "problem %llu: graph %d is not acyclic", (unsigned long long)k, s + 1); return; }
             rank.resize(g[s].n);
             for (uint32_t r = 0; r < g[s].n; ++r) rank[order[r]] = r;
+            choose_rank_order(g[s], rank_order, order, rank, st, indeg);
             if (P.lab[s].size() + g[s].n >= (1ull << 32) || P.pidx[s].size() + (g[s].prev_off[g[s].n] - g[s].prev_off[0]) >= (1ull << 32)) { P.fail(CL_ERR_INVALID_ARGUMENT, "batch too large for 32-bit device offsets"); return; }
             d.node_base[s] = (uint32_t)P.lab[s].size();
             size_t lab0 = P.lab[s].size();

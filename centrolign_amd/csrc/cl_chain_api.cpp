@@ -1162,20 +1162,33 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             CH(d_far_base.upload(ctx, base));
             D.far_base = d_far_base.p;
             // the arena: per level the two blocked orders (2 R words each) and their index arrays (R / 8, R / 64, ...)
-            uint64_t words = 0;
+            // Table entries are positions in blocks of 8 words (far_at, chain_far.hip): 2^35 words.  CL_CHAIN_FAR_ARENA_SKIP=<words> leaves that many words unused in
+            // front (tests: positions beyond 2^32 words on a small DP; the pages are never touched)
+            static const uint64_t skip_env = [] { const char* e = getenv("CL_CHAIN_FAR_ARENA_SKIP"); return e ? (uint64_t)strtoull(e, nullptr, 10) & ~7ull : 0ull; }();
+            uint64_t words = skip_env;
             std::vector<uint32_t> tab((size_t)kFarMaxLevels * kFarTabWidth, 0xFFFFFFFFu);
             for (uint32_t l = 0; l < n_levels; ++l) {
                 for (int side = 0; side < (sparse ? 1 : 2); ++side) {
-                    tab[l * kFarTabWidth + side] = (uint32_t)words;
+                    tab[l * kFarTabWidth + side] = (uint32_t)(words >> 3);
                     words += 2ull * R;
                     for (uint32_t j = 0; j <= l; ++j) {
-                        tab[l * kFarTabWidth + 2 + side * kFarMaxLevels + j] = (uint32_t)words;
+                        tab[l * kFarTabWidth + 2 + side * kFarMaxLevels + j] = (uint32_t)(words >> 3);
                         words += ((uint64_t)R >> (3 * (j + 1))) + 8;
                         words = (words + 7) & ~7ull;    // 32-byte blocks stay aligned
                     }
                 }
             }
-            if (words >= (1ull << 32)) use_far = false;
+            if (words >= (1ull << 35) - 8) use_far = false;
+            if (use_far && (uint64_t)R >= (1ull << 27)) {
+                // a far pass this large (the root of a 50-sequence MSA: 690 M padded records, 185 B each with the sorts' scratch) is taken only if the device has
+                // the room now — the DP is correct without it, an allocation that fails half-way would end the merge
+                size_t free_b = 0, total_b = 0;
+                const uint64_t need = (uint64_t)R * (48 + 7 * 4 + 8 * 2 + n_levels * (sparse ? 1 : 2) * 4) + words * 4;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + need / 8 + (8ull << 30) > (uint64_t)free_b) {
+                    if (timing) fprintf(stderr, "[chain_dp_batch]   far pass not taken: it needs %.1f GB, the device has %.1f GB free\n", need * 1.125 / 1e9, free_b / 1e9);
+                    use_far = false;
+                }
+            }
             if (use_far) {
             CH(d_far_rec.alloc(ctx, (size_t)R * 12));
             D.far_rec = d_far_rec.p;

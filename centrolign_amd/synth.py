@@ -269,7 +269,7 @@ def far_fork_batch(sizes, seed=0, n_far=3, far_min=200, far_max=1500, alphabet=4
     return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
 
 
-def _bubble_graph_edges(rng, n, p_snp, p_del, n_long, long_min, long_max, alphabet):
+def _bubble_graph_edges(rng, n, p_snp, p_del, n_long, long_min, long_max, alphabet, long_other=None):
     """a DAG of about n nodes as a progressive MSA makes them: a chain interrupted by SNP bubbles (fork -> one of two single nodes -> join), short deletion bubbles (a stretch
     of 1-3 nodes that an edge jumps over) and n_long LONG bubbles (two branches of long_min .. long_max nodes: the whole-repeat-unit indel, whose fork is read from a repeat
     unit further on).  Built in topological positions; returns (labels, edges, sources, sinks) with ids shuffled as _random_dag does"""
@@ -284,6 +284,8 @@ def _bubble_graph_edges(rng, n, p_snp, p_del, n_long, long_min, long_max, alphab
         if long_at and here >= long_at[0]:
             long_at.pop(0)
             la, lb = int(rng.integers(long_min, long_max + 1)), int(rng.integers(0, 4))   # one branch a repeat unit long, the other short or empty (an indel)
+            if long_other is not None:   # ... or BOTH long (two diverged copies of the unit): the other branch differs by up to long_other nodes
+                lb = max(1, la + int(rng.integers(-long_other, long_other + 1)))
             fork = tails
             ends = []
             for length in (la, lb):
@@ -333,14 +335,14 @@ def _bubble_graph_edges(rng, n, p_snp, p_del, n_long, long_min, long_max, alphab
     return labels, edges, [int(perm[i]) for i in sources], [int(perm[n_nodes - 1])]
 
 
-def near_chain_batch(sizes, seed=0, p_snp=0.04, p_del=0.03, n_long=(0, 1), long_min=150, long_max=400, alphabet=4, related=True):
+def near_chain_batch(sizes, seed=0, p_snp=0.04, p_del=0.03, n_long=(0, 1), long_min=150, long_max=400, alphabet=4, related=True, long_other=None):
     """graph pairs shaped like the long stitch subproblems of a progressive MSA over HOR arrays (scripts/dev/batch_structure.py on the 10 x 1 Mbp batches): chains with
     SNP and short deletion bubbles (predecessors 1-3 ranks back) and, in the second graph of a pair, n_long[1] long bubbles; what popoa_lane_kernel is for"""
     rng = np.random.default_rng(seed)
     b1, b2 = _SideBuilder(), _SideBuilder()
     for n1, n2 in sizes:
         for bld, n, nl in ((b1, n1, n_long[0]), (b2, n2, n_long[1])):
-            lab, edges, src, snk = _bubble_graph_edges(rng, n, p_snp, p_del, nl, long_min, long_max, alphabet)
+            lab, edges, src, snk = _bubble_graph_edges(rng, n, p_snp, p_del, nl, long_min, long_max, alphabet, long_other)
             bld.add_graph(lab, edges, src, snk, rng.integers(0, 1 << 40, size=len(lab), dtype=np.uint64))
     return StitchBatch(b1.finish(), b2.finish(), np.zeros(len(sizes), np.uint8))
 

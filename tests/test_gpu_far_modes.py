@@ -54,6 +54,10 @@ VARIANTS = [
     ("dense_queries", {"CL_CHAIN_DENSE_QUERIES": "1"}),
     ("walk_fold2", {"CL_CHAIN_WALK_FOLD": "2"}),
     ("walk_fold3", {"CL_CHAIN_WALK_FOLD": "3", "CL_CHAIN_FAR_MODE": "bb"}),
+    # round 5: the far pass's search structures beyond 2^32 words of their arena (table entries count blocks of 8 words: the root of a 50-sequence MSA needs
+    # 1.2 x 10^10 words): 4.4 x 10^9 words are left unused in front of this DP's structures (17.6 GB that are allocated and never touched)
+    ("arena_beyond_32_bits", {"CL_CHAIN_FAR_ARENA_SKIP": "4400000000", "CL_CHAIN_FAR_MODE": "bb"}),
+    ("arena_beyond_32_bits_fold3", {"CL_CHAIN_FAR_ARENA_SKIP": "9000000008", "CL_CHAIN_FAR_MODE": "bb", "CL_CHAIN_WALK_FOLD": "3"}),
 ]
 
 
