@@ -10,3 +10,9 @@ timeout 1500 python scripts/configs4_walk.py 50 1000000 --workers 1 --json $OUT/
 grep -n "far pass\|device memory held" $OUT/c4_50x1M_far.log | tail -12 | cut -c1-260
 grep -n "cl_anchor_chain\]   prep" $OUT/c4_50x1M_far.log | tail -4
 rm -f $OUT/*.log
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o t -- python3 $R/scripts/step_launches.py --steps 6 --warmup 2 --json $OUT/tl.json > /dev/null 2>$OUT/tl.err
+cd $R
+python3 scripts/dev/step_timeline.py $OUT/tl 13 | tee $OUT/step_timeline.txt
+rm -rf $OUT/tl
