@@ -1411,6 +1411,7 @@ hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, co
         const int cap = 159 * 1024;   // (the kernel has a few bytes of static LDS as well: 160 KB of dynamic LDS is refused, and the refusal would surface as the NEXT launch's error)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_lane_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipGetLastError();
     });
@@ -1421,6 +1422,7 @@ hipError_t cl_launch_popoa_lane(int W, uint32_t n_blocks, uint32_t lds_bytes, co
     }
     switch (W) {
     case 1: hipLaunchKernelGGL((popoa_lane_kernel<1, false>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
+    case 3: hipLaunchKernelGGL((popoa_lane_kernel<3, false>), dim3(n_blocks), dim3(192), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
     case 4: hipLaunchKernelGGL((popoa_lane_kernel<4, false>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P, (uint32_t*)nullptr); break;
     default: return hipErrorInvalidValue;
     }

@@ -18,7 +18,7 @@ t0 = min(int(r["Start_Timestamp"]) for r in last)
 last.sort(key=lambda r: int(r["Start_Timestamp"]))
 for r in last:
     name = r["Kernel_Name"].split("::")[-1].split("(")[0]
-    wg = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
+    wg = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) // max(1, int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1))
     print("%-34s %6d wg  queue %-4s  start %8.1f us  end %8.1f us  (%7.1f)" % (name[:34], wg, r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                                          (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 print("step span %.1f us" % ((max(int(r["End_Timestamp"]) for r in last) - t0) / 1e3))

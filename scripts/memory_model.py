@@ -45,12 +45,15 @@ def predict(n_seq, length, budget):
         # records: the gap-free DP keeps one per pair; the affine DP one per pair and chain combination the pair's two nodes lie on.  On HOR arrays of 0.5 %
         # divergence most nodes of a merged graph lie on most of its paths: measured 50 x 100 kbp (profiles/r05_configs4.json) records / (pairs x combinations) =
         # 0.95 (4 combinations), 0.90 (9-12), 0.84 (36-42), 0.75 (156), 0.64 (625) ~ 1.03 x combinations^-0.075
-        R = M if sparse else int(M * C * min(1.0, 1.03 * C ** -0.075))
+        # (at 50 x 1 Mbp the root keeps more: 0.79-0.89 of pairs x combinations, 617-696 M records in four runs — longer arrays, fewer pairs per node under the same budget)
+        R = M if sparse else int(M * C * min(1.0, (1.03 * C ** -0.075) if length < 500000 else max(0.89, 1.03 * C ** -0.075) if C > 100 else 1.03 * C ** -0.075))
         levels = 1
-        while levels < 6 and (64 << (3 * levels)) <= max(1, R // max(1, C)) * 4:
+        while levels < 4 and (64 << (3 * levels)) <= max(1, R // max(1, C)) * 4:   # (kFarMaxLevels = 4)
             levels += 1
         pad = R + C * (64 << (3 * (levels - 1))) // 2
-        far = C <= 256   # (beyond 256 combinations the walk folds combinations and the far pass is off: cl_chain_api.cpp)
+        # the far pass runs whenever its arena fits 2^35 words and the device has the room (cl_chain_api.cpp; up to round 4 the arena was addressed in words: off beyond
+        # 2^32, i.e. at the 625-combination root of 50 sequences, which then swept all pairs: 196 s instead of 36)
+        far = True
         rows.append(("gap-free" if sparse else "affine", chain_dp_bytes(M, R, C, half1, half2, sparse, pad if far else 0, levels if far else 0, "fold" if C > 256 else "1")))
     return dict(n_seq=n_seq, length=length, budget=budget, combinations=C, dp_bytes=dict(rows),
                 host_tables_bytes=2 * 2 * 4 * int(length * 1.2) * half1 + 2 * 4 * int(length * 1.2) * half1)   # PathMerge index + table per side, post-switch distances

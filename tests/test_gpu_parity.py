@@ -337,8 +337,11 @@ def _kernels(plan):
     return {li["kernel"].split("<")[0] for li in plan.launches() if li["n_problems"]}
 
 
-def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
-    """(CL_LANE_MIN_SWEEP=0: by default only pairs of 512 rows + columns and more take this kernel — where it pays — here every eligible pair does.)
+@pytest.mark.parametrize("round_waves", [3, 4])
+def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch, round_waves):
+    """(round_waves: strips per round of a pair above 64 rows = waves of its workgroup: three by default — a workgroup's step costs 0.30 us with three active waves, 0.55 with
+    four —, four as first built: CL_LANE_WAVES.)
+    (CL_LANE_MIN_SWEEP=0: by default only pairs of 512 rows + columns and more take this kernel — where it pays — here every eligible pair does.)
     popoa_lane_kernel (popoa_lane.h): graph pairs that are chains but for SNP / short-deletion bubbles and a long bubble or two — the long sweeps of a progressive MSA's stitch
     passes — swept in registers with DPP moves (row predecessors on a conveyor, column predecessors in the lane's history, saved columns in LDS).  Every workgroup shape
     (1 / 4 waves: strips of 64 rows pipelined over the waves, further rounds for more than 256 rows, several workgroups above 512 rows), both orientations,
@@ -346,13 +349,14 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     monkeypatch.setenv("CL_LANE_MIN_SWEEP", "0")
     monkeypatch.setenv("CL_LANE_MAX_ROWS", "1024")   # (default 192 rows: up to three active waves; beyond, rounds of four waves — slower per step, parity-tested here)
     monkeypatch.setenv("CL_LANE_WIDE", "0")
+    monkeypatch.setenv("CL_LANE_WAVES", str(round_waves))
     # lopsided pairs, the long graph with a long bubble (a saved column): 1 wave, 4 waves, 8 waves, two rounds
     sizes = [(5, 2100), (30, 700), (64, 300), (65, 400), (165, 2225), (256, 500), (300, 330), (420, 418), (512, 520), (600, 640), (1000, 1010)]
     b = synth.near_chain_batch(sizes, seed=5, n_long=(0, 1))
     plan = gpu_ctx.plan(b)
     plan.execute(); plan.sync()
     names = [li["kernel"] for li in plan.launches() if li["n_problems"]]
-    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<4>"} <= set(names), names
+    assert {"popoa_lane_kernel<1>", "popoa_lane_kernel<%d>" % round_waves} <= set(names), names
     # (the generator's deletion bubbles behind an SNP bubble reach five ranks back now and then: such a pair is not a lane pair)
     assert sum(li["n_problems"] for li in plan.launches() if li["kernel"].startswith("popoa_lane_kernel")) >= len(sizes) // 2, plan.launches()
     want = po.oracle_stitch_batch(b)
@@ -383,6 +387,8 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch):
     assert "popoa_lane_kernel" in _kernels(plan), plan.launches()
     plan.destroy()
     assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+    if round_waves != 4:
+        return
     monkeypatch.setenv("CL_LANE_WIDE", "1")
     # WIDE pairs (CL_LANE_WIDE=1: off by default, slower than the strips so far): more than 192 rows — groups of eight strips, a workgroup each, on different compute units, progress words between them; chain pairs of 4 096 rows
     # and more take this route too; saved columns whose cells cross a group boundary; every NumPW; a resident plan executed again
