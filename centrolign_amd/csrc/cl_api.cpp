@@ -53,10 +53,16 @@ const bool g_force_general = [] { const char* e = getenv("CL_FORCE_GENERAL"); re
 const bool g_no_sys = [] { const char* e = getenv("CL_NO_SYS"); return e && *e == '1'; }();     // test hook: no systolic DAG kernel
 // test hook / A-B, read at every plan creation (tests switch it inside one process): no register kernel for near-chain pairs (popoa_lane_kernel) — the pairs then take
 // the kernels of rounds 1-4 (systolic, strips, rings), which stay the route of everything that is not a near-chain pair
-// strips of a near-chain pair that one round of popoa_lane_kernel takes = waves of its workgroup.  Measured on a pair alone (profiles/r05_lane_probe.txt): a step of the
-// workgroup costs 0.24 / 0.30 / 0.30 us with one / two / three ACTIVE waves but 0.55 us with four — so rounds of THREE strips (192 rows: 1.6 ns per row and step)
-// beat rounds of four (2.1 ns) for every pair above 256 rows.  CL_LANE_WAVES=4 restores the rounds of four (first form of round 5)
-static uint32_t lane_round_waves() { const char* e = getenv("CL_LANE_WAVES"); return e && *e == '4' ? 4u : 3u; }
+// strips of a near-chain pair that one round of popoa_lane_kernel takes = waves of its workgroup: FOUR when the pairs have the compute units to themselves, THREE in a
+// plan whose other launches share them.  Measured (profiles/r05_lane_waves_ab.txt): a pair alone, or 150 pairs of 512 x 512 alone on the device, run 20 % faster in rounds
+// of four (fewer rounds: 441 x 433 0.66 against 0.80 ms) — but the timed step of 10 x 1 Mbp (116 000 subproblems, sixteen launches side by side) takes 2.23-2.31 ms with
+// rounds of three against 2.32-2.43 ms with four: a workgroup's waves meet at a barrier per chunk of 32 steps and run at the pace of the slowest SIMD, and with the other
+// kernels' waves on the same SIMDs three are held up less than four.  The plan's size stands for "shared": 2 048 subproblems and more.  CL_LANE_WAVES=3|4 forces one
+static uint32_t lane_round_waves(uint64_t n_problems) {
+    const char* e = getenv("CL_LANE_WAVES");
+    if (e && (*e == '3' || *e == '4')) return (uint32_t)(*e - '0');
+    return n_problems >= 2048 ? 3u : 4u;
+}
 static bool no_lane_now() { const char* e = getenv("CL_NO_LANE"); return e && *e == '1'; }
 #define g_no_lane no_lane_now()
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
@@ -1052,6 +1058,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     };
     struct Scratch { std::vector<uint32_t> order, st, indeg, rank; };
     const int rank_order = rank_order_now();
+    const uint32_t lane_rw = lane_round_waves(n);
     auto pack_one = [&](uint64_t k, PackPart& P, Scratch& S) {
         std::vector<uint32_t>& order = S.order; std::vector<uint32_t>& st = S.st; std::vector<uint32_t>& indeg = S.indeg; std::vector<uint32_t>& rank = S.rank;
         GraphView g[2] = {view(batch->side[0], k), view(batch->side[1], k)};
@@ -1207,7 +1214,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     far.erase(std::unique(far.begin(), far.end()), far.end());
                     lane_dr = shape == 0 ? 2 : 4; lane_dc = near; lane_slots = (uint32_t)far.size();
                     // LDS of a workgroup: the hand-off window between neighbouring strips ([waves - 1][DR][1 + NumPW][128 columns]) + the saved columns
-                    const uint64_t lane_w = n_rows - 1 <= 64 ? 1 : lane_round_waves();
+                    const uint64_t lane_w = n_rows - 1 <= 64 ? 1 : lane_rw;
                     lane_lds = (lane_w > 1 ? (lane_w - 1) * lane_dr * (1 + npw) * 128 * 4 : 0) + (uint64_t)lane_slots * (lane_dr + (lane_wide ? 192 : n_rows - 1) + 1) * (1 + npw) * 4;
                     if (!fits || far.size() > 16 || lane_lds > 150 * 1024) continue;
                     take_lane = true;
@@ -1596,7 +1603,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     static const bool lane_long_split = [] { const char* e = getenv("CL_LANE_LONG"); return e && e[0] == '1'; }();
     for (int gi = 0; gi < 6; ++gi) {
         LaunchGroup grp;
-        const int lane_waves[3] = {0, (int)lane_round_waves(), 1};   // (one wave per SIMD; no launches of eight waves any more)
+        const int lane_waves[3] = {0, (int)lane_rw, 1};   // (one wave per SIMD; no launches of eight waves any more)
         const bool long_ones = gi < 3;
         grp.kind = CL_KIND_LANE; grp.npw = 0; grp.waves = lane_waves[gi % 3];
         grp.first = (uint32_t)plist.size();
@@ -1604,7 +1611,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const ClProbDesc& d = pl->desc[i];
             const uint32_t rows = std::min(d.n1, d.n2);
             const bool is_long = lane_long_split && (uint64_t)d.n1 + d.n2 >= 1024;
-            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : (int)lane_round_waves()) == grp.waves && is_long == long_ones) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
+            if (d.kind == CL_KIND_LANE && !((d.pad >> 8) & 0x7Fu) && (rows <= 64 ? 1 : (int)lane_rw) == grp.waves && is_long == long_ones) { plist.push_back(i); grp.ring_bytes = std::max<uint32_t>(grp.ring_bytes, ring_need[i]); }
         }
         grp.count = (uint32_t)plist.size() - grp.first;
         if (!grp.count) continue;
