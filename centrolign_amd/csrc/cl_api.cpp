@@ -726,6 +726,7 @@ struct cl_stitch_plan {
     bool graph_tried = false;
     std::vector<uint32_t> plist_host;   // the launch groups' subproblem lists (cl_stitch_plan_launch_info)
     bool executed = false, profiled = false, calibrated = false;
+    int recalibrations_left = -1, concurrent_passes = 0;   // second stage of the launch scheduling: see cl_stitch_plan_execute
 };
 
 namespace {
@@ -1059,6 +1060,12 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     struct Scratch { std::vector<uint32_t> order, st, indeg, rank; };
     const int rank_order = rank_order_now();
     const uint32_t lane_rw = lane_round_waves(n);
+    // waves of popoa_linear_kernel's workgroup for chain pairs of 65-256 rows / above (rounds of W strips): CL_LINEAR_WAVES_MID=3|4 [4], CL_LINEAR_WAVES_BIG=3|4|8|16
+    // [8 up to 512 rows, 16 above].  Measured (profiles/r05_linear_waves_ab.txt): the timed step of 10 x 1 Mbp 2.29-2.31 ms with sixteen waves for every pair above 256
+    // rows, 2.16-2.22 with eight, 2.15-2.24 with four, 2.16-2.19 with three; alone on the device 512^2 x 150 runs the same with 16 / 8 / 4 (105 G cells/s), 2 048^2 x 10
+    // 15.9 / 14.3 / 10.4 G cells/s — so eight where eight strips are all there are, sixteen above.  Three waves for 65-256 rows: slower in the step (2.25-2.37)
+    auto waves_env = [](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return (uint8_t)(v == 3 || v == 4 || v == 8 || v == 16 ? v : dflt); };
+    const uint8_t lin_mid = waves_env("CL_LINEAR_WAVES_MID", 4), lin_big = waves_env("CL_LINEAR_WAVES_BIG", 0);
     auto pack_one = [&](uint64_t k, PackPart& P, Scratch& S) {
         std::vector<uint32_t>& order = S.order; std::vector<uint32_t>& st = S.st; std::vector<uint32_t>& indeg = S.indeg; std::vector<uint32_t>& rank = S.rank;
         GraphView g[2] = {view(batch->side[0], k), view(batch->side[1], k)};
@@ -1141,8 +1148,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             if (nshort <= 16 && !no_quads) { lr = 1; lw = 2; }
             else if (nshort <= 64) { lr = 1; lw = 1; }
             else if (nshort <= 128 && nlong < 300) { lr = 2; lw = 1; }
-            else if (nshort <= 256) { lr = 1; lw = 4; }
-            else { lr = 1; lw = 16; }
+            else if (nshort <= 256) { lr = 1; lw = lin_mid; }
+            else { lr = 1; lw = lin_big ? lin_big : nshort <= 512 ? 8 : 16; }   // (up to eight strips: eight waves — with sixteen, half of them only stand at the barriers)
             d.pad = (uint16_t)(ls | (lr << 1));  // read by linear_dispatch
             P.plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
             P.ring_need.push_back(0);
@@ -1557,8 +1564,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         pl->groups.push_back(grp);
     };
     // chain kernel: one launch per workgroup shape; the problems are ordered by the length of their sweep
-    const int lin_waves[3] = {16, 4, 1};
-    for (int gi = 0; gi < 3; ++gi) {
+    const int lin_waves[5] = {16, 8, 4, 3, 1};
+    for (int gi = 0; gi < 5; ++gi) {
         LaunchGroup grp;
         grp.kind = CL_KIND_LINEAR; grp.npw = 0; grp.waves = lin_waves[gi];
         grp.first = (uint32_t)plist.size();
@@ -1921,6 +1928,31 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
         for (LaunchGroup& g : pl->groups) g.est_cost = (uint64_t)(g.host_ms * 1000.f) + 1;
         std::stable_sort(pl->groups.begin(), pl->groups.end(), [](const LaunchGroup& x, const LaunchGroup& y) { return x.est_cost > y.est_cost; });
     }
+    // Second stage: a launch alone and the same launch among fifteen others are different things — in the timed step of 10 x 1 Mbp the chain kernel's launch of 221 long
+    // pairs takes 0.4 ms alone and 1.7 ms in the step (its sixteen waves per workgroup wait for SIMDs they share), so the first stage put a 0.28 ms launch behind it on
+    // its stream, and that stream ended the step 0.2 ms after every other one (scripts/dev/step_timeline.py).  So the pass after the first concurrent one deals
+    // the launches out again by the durations their OWN clocks showed inside the previous pass (first workgroup's start to last workgroup's end, queueing for
+    // compute units included — which is what a stream is busy for).  One wait for the stream + one small copy + one more graph capture, once per plan.  CL_STITCH_CALIBRATE=1: first stage only
+    static const bool second_stage = [] { const char* e = getenv("CL_STITCH_CALIBRATE"); return !e || e[0] == '2'; }();
+    // (how often: once — the third pass of a plan, which is still a warm-up pass of bench.py; CL_STITCH_RECAL=0..3 for measurements)
+    static const int recal_env = [] { const char* e = getenv("CL_STITCH_RECAL"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : v > 3 ? 3 : v; }();
+    if (pl->recalibrations_left < 0) pl->recalibrations_left = recal_env;
+    if (calibrate && second_stage && pl->calibrated && pl->concurrent_passes >= 1 && pl->recalibrations_left > 0 && pl->groups.size() > 2 && pl->d_ticks.p) {
+        --pl->recalibrations_left;
+        pl->concurrent_passes = 0;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> got(2 * pl->groups.size());
+        HIP_TRY(ctx, cl_copy_sync(ctx, got.data(), pl->d_ticks.p, got.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        bool all = true;
+        for (size_t gi = 0; gi < pl->groups.size(); ++gi) all = all && got[2 * gi] && got[2 * gi + 1] > ~got[2 * gi];
+        if (all) {
+            for (size_t gi = 0; gi < pl->groups.size(); ++gi) pl->groups[gi].est_cost = (got[2 * gi + 1] - ~got[2 * gi]) / 100 + 1;   // 100 MHz clock -> us
+            std::stable_sort(pl->groups.begin(), pl->groups.end(), [](const LaunchGroup& x, const LaunchGroup& y) { return x.est_cost > y.est_cost; });
+            if (pl->graph_exec) { (void)hipGraphExecDestroy(pl->graph_exec); pl->graph_exec = nullptr; }
+            if (pl->graph) { (void)hipGraphDestroy(pl->graph); pl->graph = nullptr; }
+            pl->graph_tried = false;
+        }
+    }
     // The launch DAG (one kernel per group, all independent) is captured once into a hipGraph and replayed:
     // a dozen kernels start together instead of trickling out at the host's enqueue rate.
     if (!pl->graph_tried && !g_no_graph && !pl->groups.empty()) {
@@ -1950,6 +1982,7 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
     }
     HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
     pl->executed = true;
+    if (pl->calibrated) ++pl->concurrent_passes;
     return CL_OK;
 }
 

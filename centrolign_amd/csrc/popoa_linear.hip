@@ -485,7 +485,9 @@ hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch&
     switch (W) {
     case 0: hipLaunchKernelGGL(popoa_linear_quad_kernel, dim3(n_blocks / 4), dim3(64), 0, stream, B, plist, P); break;   // four small pairs per wave: n_blocks list entries, four per workgroup
     case 1: hipLaunchKernelGGL((popoa_linear_kernel<1>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P); break;
+    case 3: hipLaunchKernelGGL((popoa_linear_kernel<3>), dim3(n_blocks), dim3(192), 0, stream, B, plist, P); break;
     case 4: hipLaunchKernelGGL((popoa_linear_kernel<4>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P); break;
+    case 8: hipLaunchKernelGGL((popoa_linear_kernel<8>), dim3(n_blocks), dim3(512), 0, stream, B, plist, P); break;
     case 16: hipLaunchKernelGGL((popoa_linear_kernel<16>), dim3(n_blocks), dim3(1024), 0, stream, B, plist, P); break;
     default: return hipErrorInvalidValue;
     }
