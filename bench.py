@@ -424,11 +424,12 @@ def main():
             one_pass(True)
         barrier()
         t0 = time.perf_counter()
-        # the K timed passes are ENQUEUED one behind the other (a plan's pass joins its context's stream before the next forks from it) and waited
-        # for once, by the barrier + synchronize that closes the timed region: no host round trip — and no idle device — between two passes
+        # the K timed passes are ENQUEUED one behind the other and waited for once, by the barrier + synchronize that closes the timed region: no host round trip
+        # between two passes, and (second half of round 5) no join of the plan's streams either — a launch group follows its own launch of the pass before in stream
+        # order, the passes overlap; the trace showed 0.4-0.6 ms of idle device per 2.2 ms step while every stream waited for the slowest one and two event hops
         for _ in range(steps - 1):
             one_pass(False)
-        dev = one_pass(True) * steps      # (device time of the last pass of the longest plan, as an indication)
+        dev = one_pass(True) * steps      # (HIP events from the last pass's enqueue to its end, as an indication: see "device_ms_from_the_last_pass_enqueue_to_its_end")
         barrier()
         return time.perf_counter() - t0, dev
 
@@ -540,7 +541,11 @@ def main():
                     "match_s": res["stats"]["match_ms"] / 1e3, "align_s_summed_over_contexts": res["stats"]["align_ms"] / 1e3,
                     "per_merge": [{k: m[k] for k in ("merge", "paths1", "paths2", "match_sets", "chain_match_pairs", "chain_combinations", "match_ms",
                                                      "align_ms", "chain_ms", "chain_device_ms", "partition_ms", "stitch_ms", "fuse_ms")} for m in per_merge]},
-            "device_ms_per_step_longest_plan": dev_ms / args.steps,
+            # (up to the first half of round 5 a pass joined its context's stream before the next one forked from it, and this was the device time of the last pass;
+            # now the passes of a resident plan overlap — a stream starts pass i + 1 when ITS launches of pass i are done (cl_stitch_join, cl_api.cpp) — and the events
+            # round the last pass span everything that was still running when it was enqueued: CL_STITCH_JOIN=eager restores the join per pass)
+            "device_ms_from_the_last_pass_enqueue_to_its_end": dev_ms / args.steps,
+            "passes": "the K timed passes are enqueued back to back; a launch group runs on the same stream in every pass, so stream order is the only order between passes and they overlap (no join of the eight streams between passes); the barrier + synchronize that closes the timed region waits for all of them",
             "launches": sorted(launches, key=lambda e: -e["ms"])[:12],
         }
         if dom is not None:

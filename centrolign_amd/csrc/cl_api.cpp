@@ -726,7 +726,9 @@ struct cl_stitch_plan {
     bool graph_tried = false;
     std::vector<uint32_t> plist_host;   // the launch groups' subproblem lists (cl_stitch_plan_launch_info)
     bool executed = false, profiled = false, calibrated = false;
-    int recalibrations_left = -1, concurrent_passes = 0;   // second stage of the launch scheduling: see cl_stitch_plan_execute
+    int recalibrations_left = -1, concurrent_passes = 0;
+    uint32_t tick_pass = 0;      // number of the last concurrent pass (ClDeviceBatch::tick_pass), 1 .. 65 535
+    bool stop_pending = false;   // the last pass's end is not marked on the context's stream yet (lazy join)   // second stage of the launch scheduling: see cl_stitch_plan_execute
 };
 
 namespace {
@@ -1847,7 +1849,35 @@ static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const C
     return cl_launch_popoa_general(g.npw, g.block, g.count, g.ring_bytes, dev, pl->d_plist.p + g.first, pl->sparams, stream);
 }
 
-static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
+// a launch's two tick words (popoa_device.h: pass << 48 | 48 bits of ~start, of end; 100 MHz) -> its duration in microseconds, 0 if the words are not of one pass
+static double tick_span_us(unsigned long long w0, unsigned long long w1) {
+    constexpr unsigned long long mask = 0xFFFFFFFFFFFFull;
+    if (!w0 || !w1 || (w0 >> 48) != (w1 >> 48)) return 0.0;
+    const unsigned long long start = ~w0 & mask, end = w1 & mask;
+    return end > start ? (double)(end - start) * 1e-2 : 0.0;
+}
+
+// The context's stream waits for the stitch launches that were handed to the auxiliary streams.  A pass of a plan does NOT do this by itself any more (second half of
+// round 5): the launches of a resident plan's next pass follow this pass's launches in STREAM order (a launch group goes to the same stream in every pass and reads
+// and writes nothing but its own subproblems), so passes that are enqueued back to back overlap — a stream starts pass i + 1 when ITS launches of pass i are done —
+// instead of leaving every stream idle until the slowest one and two event hops are through (0.25-0.5 ms of 2.3 per step of 10 x 1 Mbp: scripts/dev/step_timeline.py).
+// Whatever needs a pass to be complete joins first: cl_stitch_plan_sync / _collect / _execute_profiled / _destroy, a re-dealing of the launches, the chaining DP.
+extern "C++" int cl_stitch_join(cl_context* ctx) {   // (C++ linkage: declared in cl_internal.hpp for the chaining DP, not part of the C ABI)
+    for (int si = 0; si < kNumAuxStreams && ctx->stitch_join_pending; ++si)
+        if (ctx->stitch_join_pending & (1u << si)) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[si], 0));
+            ctx->stitch_join_pending &= ~(1u << si);
+        }
+    return CL_OK;
+}
+static int plan_mark_stop(cl_context* ctx, cl_stitch_plan* pl) {
+    int rc = cl_stitch_join(ctx);
+    if (rc) return rc;
+    if (pl->stop_pending) { HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream)); pl->stop_pending = false; }
+    return CL_OK;
+}
+
+static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed, bool join_now = false) {
     if (timed) {
         // the profiled pass: every launch ALONE on the context's stream, the device idle before and after, timed by the HOST's clock round
         // launch + wait.  HIP event pairs read about twice the kernel's duration in the rocprofv3 kernel trace here (round 4: 2.87 ms by events,
@@ -1856,6 +1886,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
         // (a launch that finds the device idle runs at about half speed — the dominant launch 2.9 ms against 1.45 ms behind another launch, with the
         // shader clock already at its top in both cases: whatever ramps, ramps within the first launch — so the duration reported is that of a launch
         // behind another one, which is what a launch inside a step is, and what the rocprofv3 kernel trace of a step shows)
+        { int rc = plan_mark_stop(ctx, pl); if (rc) return rc; }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const size_t ng = pl->groups.size();
         if (!pl->d_ticks.p) { int rc = pl->d_ticks.alloc(ctx, 2 * ng); if (rc) return rc; }
@@ -1865,6 +1896,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
             // beside it the host's clock round launch + wait
             ClDeviceBatch dev = pl->dev;
             dev.ticks = pl->d_ticks.p + 2 * gi;
+            dev.tick_pass = 0xFFFFu;
             HIP_TRY(ctx, launch_group(g, pl, dev, ctx->stream));   // (first run: whatever ramps with the device idle, ramps here)
             HIP_TRY(ctx, hipMemsetAsync(dev.ticks, 0, 2 * sizeof(unsigned long long), ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1874,14 +1906,24 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
             g.host_idle_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             unsigned long long got[2] = {0, 0};
             HIP_TRY(ctx, cl_copy_sync(ctx, got, dev.ticks, sizeof(got), hipMemcpyDeviceToHost));
-            g.host_ms = got[0] && got[1] > ~got[0] ? (float)((double)(got[1] - ~got[0]) * 1e-5) : g.host_idle_ms;
+            const double us = tick_span_us(got[0], got[1]);
+            g.host_ms = us > 0 ? (float)(us * 1e-3) : g.host_idle_ms;
         }
         return CL_OK;
     }
     // every launch also leaves its own clock's start / end (two atomics per workgroup): cl_stitch_plan_launch_info reports the durations of the LAST pass,
     // i.e. of launches that overlap with one another as they do in production
-    if (!pl->d_ticks.p && !pl->groups.empty()) { int rc = pl->d_ticks.alloc(ctx, 2 * pl->groups.size()); if (rc) return rc; }
-    if (pl->d_ticks.p) HIP_TRY(ctx, hipMemsetAsync(pl->d_ticks.p, 0, 2 * pl->groups.size() * sizeof(unsigned long long), ctx->stream));
+    // (the words are not zeroed between passes: a pass's number in their top bits makes its clocks win over every earlier pass's; zeroed when the number wraps and
+    // after the profiled pass, whose launches carry the highest number)
+    const bool fresh = !pl->d_ticks.p;
+    if (fresh && !pl->groups.empty()) { int rc = pl->d_ticks.alloc(ctx, 2 * pl->groups.size()); if (rc) return rc; }
+    if (pl->d_ticks.p && (fresh || pl->tick_pass == 0 || pl->tick_pass >= 0xFFFEu)) {
+        int rc = plan_mark_stop(ctx, pl);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(pl->d_ticks.p, 0, 2 * pl->groups.size() * sizeof(unsigned long long), ctx->stream));
+        pl->tick_pass = 0;
+    }
+    ++pl->tick_pass;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     bool used[kNumAuxStreams] = {};
     // the groups come longest first (cl_stitch_plan_create: estimated duration = longest sweep x the kernel's time per step); each goes to the
@@ -1890,24 +1932,42 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed) {
     static const bool round_robin = [] { const char* e = getenv("CL_STITCH_SCHED"); return e && e[0] == 'r'; }();
     const int n_streams = std::min(g_plan_streams, ctx->n_aux);
     uint64_t load[kNumAuxStreams] = {};
+    std::vector<int> stream_of(pl->groups.size());
     for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
-        const LaunchGroup& g = pl->groups[gi];
         int si = (int)(gi % (size_t)n_streams);
         if (!round_robin) {
             si = 0;
             for (int t = 1; t < n_streams; ++t) if (load[t] < load[si]) si = t;
-            load[si] += std::max<uint64_t>(1, g.est_cost);
+            load[si] += std::max<uint64_t>(1, pl->groups[gi].est_cost);
         }
-        if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
-        ClDeviceBatch dev = pl->dev;
-        dev.ticks = pl->d_ticks.p ? pl->d_ticks.p + 2 * gi : nullptr;
-        HIP_TRY(ctx, launch_group(g, pl, dev, ctx->aux[si]));
+        stream_of[gi] = si;
     }
+    // In which order the launches are ISSUED: the device starts about four launches at a time (a hardware queue that is handing out a launch's workgroups is busy until
+    // the last of them has a compute unit — for the 34 716 workgroups of the short chain pairs that is the launch's whole duration), and in the step of 10 x 1 Mbp the
+    // launch that ends the step — 66 long near-chain pairs, 1.27 ms — was started 0.43 ms after the first one (scripts/dev/step_timeline.py).  Launches of few workgroups
+    // (at most two per compute unit: resident at once, their queue is free again at once) therefore go first, the wide ones after them; each on the stream the
+    // longest-processing-time rule gave it.  CL_STITCH_ORDER=cost: in the order of their durations (up to the first half of round 5)
+    static const bool light_first = [] { const char* e = getenv("CL_STITCH_ORDER"); return !(e && e[0] == 'c'); }();
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
+            const LaunchGroup& g = pl->groups[gi];
+            const bool light = light_first && g.count <= 512;
+            if (light != (pass == 0)) continue;
+            const int si = stream_of[gi];
+            if (!used[si]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[si], ctx->ev_fork, 0)); used[si] = true; }
+            ClDeviceBatch dev = pl->dev;
+            dev.ticks = pl->d_ticks.p ? pl->d_ticks.p + 2 * gi : nullptr;
+            dev.tick_pass = pl->tick_pass;
+            HIP_TRY(ctx, launch_group(g, pl, dev, ctx->aux[si]));
+        }
+    static const bool eager_join = [] { const char* e = getenv("CL_STITCH_JOIN"); return e && e[0] == 'e'; }();   // CL_STITCH_JOIN=eager: every pass joins (up to the first half of round 5)
     for (int si = 0; si < kNumAuxStreams; ++si)
         if (used[si]) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join[si], ctx->aux[si]));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[si], 0));
+            ctx->stitch_join_pending |= 1u << si;
         }
+    pl->stop_pending = true;
+    if (eager_join || join_now) return plan_mark_stop(ctx, pl);
     return CL_OK;
 }
 
@@ -1927,6 +1987,7 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
         if (rc) return rc;
         for (LaunchGroup& g : pl->groups) g.est_cost = (uint64_t)(g.host_ms * 1000.f) + 1;
         std::stable_sort(pl->groups.begin(), pl->groups.end(), [](const LaunchGroup& x, const LaunchGroup& y) { return x.est_cost > y.est_cost; });
+        pl->tick_pass = 0;
     }
     // Second stage: a launch alone and the same launch among fifteen others are different things — in the timed step of 10 x 1 Mbp the chain kernel's launch of 221 long
     // pairs takes 0.4 ms alone and 1.7 ms in the step (its sixteen waves per workgroup wait for SIMDs they share), so the first stage put a 0.28 ms launch behind it on
@@ -1940,13 +2001,15 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
     if (calibrate && second_stage && pl->calibrated && pl->concurrent_passes >= 1 && pl->recalibrations_left > 0 && pl->groups.size() > 2 && pl->d_ticks.p) {
         --pl->recalibrations_left;
         pl->concurrent_passes = 0;
+        { int rc = plan_mark_stop(ctx, pl); if (rc) return rc; }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<unsigned long long> got(2 * pl->groups.size());
         HIP_TRY(ctx, cl_copy_sync(ctx, got.data(), pl->d_ticks.p, got.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         bool all = true;
-        for (size_t gi = 0; gi < pl->groups.size(); ++gi) all = all && got[2 * gi] && got[2 * gi + 1] > ~got[2 * gi];
+        for (size_t gi = 0; gi < pl->groups.size(); ++gi) all = all && tick_span_us(got[2 * gi], got[2 * gi + 1]) > 0;
         if (all) {
-            for (size_t gi = 0; gi < pl->groups.size(); ++gi) pl->groups[gi].est_cost = (got[2 * gi + 1] - ~got[2 * gi]) / 100 + 1;   // 100 MHz clock -> us
+            for (size_t gi = 0; gi < pl->groups.size(); ++gi) pl->groups[gi].est_cost = (uint64_t)tick_span_us(got[2 * gi], got[2 * gi + 1]) + 1;
+            pl->tick_pass = 0;   // (the words belong to the launches in their OLD order: start afresh)
             std::stable_sort(pl->groups.begin(), pl->groups.end(), [](const LaunchGroup& x, const LaunchGroup& y) { return x.est_cost > y.est_cost; });
             if (pl->graph_exec) { (void)hipGraphExecDestroy(pl->graph_exec); pl->graph_exec = nullptr; }
             if (pl->graph) { (void)hipGraphDestroy(pl->graph); pl->graph = nullptr; }
@@ -1959,7 +2022,7 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
         pl->graph_tried = true;
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = enqueue_groups(ctx, pl, false);
+            int rc = enqueue_groups(ctx, pl, false, true);   // (a capture has to end with every forked stream joined)
             hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
             if (rc == CL_OK && e == hipSuccess && graph &&
                 hipGraphInstantiate(&pl->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
@@ -1976,11 +2039,12 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
     HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
     if (pl->graph_exec) {
         HIP_TRY(ctx, hipGraphLaunch(pl->graph_exec, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
+        pl->stop_pending = false;
     } else {
-        int rc = enqueue_groups(ctx, pl, false);
+        int rc = enqueue_groups(ctx, pl, false);   // (the end of the pass is marked when somebody joins: plan_mark_stop)
         if (rc) return rc;
     }
-    HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
     pl->executed = true;
     if (pl->calibrated) ++pl->concurrent_passes;
     return CL_OK;
@@ -1989,21 +2053,24 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
 int cl_stitch_plan_execute_profiled(cl_context* ctx, cl_stitch_plan* pl) {
     if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = plan_mark_stop(ctx, pl); if (rc) return rc; }
     HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
     int rc = enqueue_groups(ctx, pl, true);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(pl->ev_stop, ctx->stream));
     pl->executed = true;
     pl->profiled = true;
+    pl->tick_pass = 0;   // (the profiled launches left the highest pass number in the tick words: the next concurrent pass zeroes them)
     return CL_OK;
 }
 
 int cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* pl, float* ms_out) {
     if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = plan_mark_stop(ctx, pl); if (rc) return rc; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ms_out) {
-        *ms_out = 0.f;
+        *ms_out = 0.f;   // (from the last pass's enqueue on the stream to its end: with passes enqueued back to back, the time they all took from there)
         if (pl->executed) HIP_TRY(ctx, hipEventElapsedTime(ms_out, pl->ev_start, pl->ev_stop));
     }
     return CL_OK;
@@ -2048,8 +2115,8 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     if (pl->d_ticks.p && pl->executed) {   // the launch's own clock in the last pass (the caller has waited for it: cl_stitch_plan_sync)
         unsigned long long got[2] = {0, 0};
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        if (cl_copy_sync(ctx, got, pl->d_ticks.p + 2 * index, sizeof(got), hipMemcpyDeviceToHost) == hipSuccess && got[0] && got[1] > ~got[0])
-            out->in_pass_ms = (float)((double)(got[1] - ~got[0]) * 1e-5);
+        if (cl_copy_sync(ctx, got, pl->d_ticks.p + 2 * index, sizeof(got), hipMemcpyDeviceToHost) == hipSuccess && tick_span_us(got[0], got[1]) > 0)
+            out->in_pass_ms = (float)(tick_span_us(got[0], got[1]) * 1e-3);
     }
     return CL_OK;
 }
@@ -2059,6 +2126,7 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
     memset(out, 0, sizeof(*out));
     if (!pl->executed && !pl->desc.empty()) { set_error(ctx, "plan was not executed"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = plan_mark_stop(ctx, pl); if (rc) return rc; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t npo = pl->desc.size();
     std::vector<uint32_t> len(npo), status(npo);

@@ -339,6 +339,7 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
 static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
                                bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out, bool allow_walk) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { const int jrc = cl_stitch_join(ctx); if (jrc) return jrc; }   // (a stitch pass of this context may still be out on the auxiliary streams this DP is about to use)
     const auto T0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     const size_t K = subs.size();

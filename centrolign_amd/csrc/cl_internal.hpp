@@ -28,6 +28,7 @@ struct cl_context {
     int n_aux = kNumAuxStreams;
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[kNumAuxStreams] = {};
+    uint32_t stitch_join_pending = 0;   // aux streams whose last stitch launches the context's stream has not been made to wait for yet (cl_stitch_join, cl_api.cpp)
     std::string error;
     std::string name;
     // page-locked host staging area, grown on demand and kept for the context's lifetime (cl_pinned): device-to-host copies into it run
@@ -140,6 +141,7 @@ bool cl_context_live(const cl_context* ctx);   // cl_api.cpp: created and not ye
 // every stream of the context has run dry: what cl_dev_free makes sure of before a block goes back to the pool.  A caller that releases dozens of
 // blocks at once (the end of a chaining DP: ~40 of them, each of which used to wait for all seven streams again — most of a small DP's time,
 // and a polishing step runs tens of thousands of small DPs) waits once and releases with quiesced = true.
+int cl_stitch_join(cl_context* ctx);   // cl_api.cpp: the context's stream waits for the stitch launches still out on the auxiliary streams
 inline void cl_ctx_quiesce(cl_context* ctx) {
     if (ctx->poisoned) return;   // (its streams never run dry)
     (void)hipStreamSynchronize(ctx->stream);

@@ -50,11 +50,23 @@ struct ClDeviceBatch {
     uint32_t* out_len;        // pairs emitted per problem
     int32_t*  out_score;      // best sink-pair score per problem
     uint32_t* out_status;     // 0 = ok
-    unsigned long long* ticks; // null, or [2] (zeroed before the launch): max over the workgroups of ~(start tick) and of (end tick), 100 MHz ticks of
+    unsigned long long* ticks; // null, or [2]: pass << 48 | the low 48 bits of — max over the workgroups of — ~(start tick) and (end tick), 100 MHz ticks of
                               // s_memrealtime — the launch's duration by the kernel's own clock, also inside a step where launches overlap (launches of
                               // more than 4 096 workgroups sample every 64th: they are throughput-bound, their ends are within a wave of one another)
+    uint32_t  tick_pass;      // the pass's number (1 .. 65 535), the top 16 bits of both tick words: a later pass's clocks replace an earlier pass's without a reset in between
     int       skip_traceback; // measurement hook (CL_DEBUG_SKIP_TRACEBACK=1, scripts/stitch_dag_bench.py): the graph x graph kernels fill only
 };
+
+#if defined(__HIPCC__)
+constexpr unsigned long long kTickMask = 0xFFFFFFFFFFFFull;
+// every kernel of the stitch path calls these as its first and last statement (`sampled`: which workgroups take part)
+__device__ __forceinline__ void cl_tick_start(const ClDeviceBatch& B, bool sampled) {
+    if (B.ticks && threadIdx.x == 0 && sampled) atomicMax(B.ticks, ((unsigned long long)B.tick_pass << 48) | (~(unsigned long long)__builtin_amdgcn_s_memrealtime() & kTickMask));
+}
+__device__ __forceinline__ void cl_tick_end(const ClDeviceBatch& B, bool sampled) {
+    if (B.ticks && threadIdx.x == 0 && sampled) atomicMax(B.ticks + 1, ((unsigned long long)B.tick_pass << 48) | ((unsigned long long)__builtin_amdgcn_s_memrealtime() & kTickMask));
+}
+#endif
 
 // popoa_strip_kernel: one workgroup per STRIP of consecutive rows of a large branching pair; strip j reads the last rows of strip j - 1 (its "ghost"
 // rows) from a hand-off area in HBM that strip j - 1 fills while it runs

@@ -454,7 +454,7 @@ __device__ void traceback_wave(const ClDeviceBatch& B, const ClProbDesc& pd, con
 template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_general_kernel(ClDeviceBatch B, c
         __syncthreads();  // s_waitcnt vmcnt(0) + barrier: this anti-diagonal is visible to the whole workgroup
     }
     if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -495,7 +495,7 @@ template <int NPW, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
     extern __shared__ int32_t lds[];
     constexpr int PL = 1 + 2 * NPW, BP = 1 + NPW;
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_ring_kernel(ClDeviceBatch B, cons
     }
     __syncthreads();
     if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     // one cell: NumPW 1: {M, V0, H0, -}; NumPW 2, 3: {M, V0, V1, V2 | M, H0, H1, H2} — what a vertical or a horizontal read needs is one
     // aligned 16-byte LDS read
     constexpr int CW = NPW == 1 ? 4 : 8;
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     const DiagGeom G(pd.n1, pd.n2);
@@ -962,7 +962,7 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
     }
     __syncthreads();   // vmcnt(0): every plane value is in memory
     if (tid < 64 && !B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
     constexpr int CW = NPW == 1 ? 4 : 8;
     constexpr int WW = CW / 2;   // 64-bit words of a cell
     constexpr uint32_t GW = 4;   // ghost waves = steps a hand-off cell has to arrive
-    if (B.ticks && threadIdx.x == 0) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, true);
     const ClStripDesc sd = SD.strips[slist[blockIdx.x]];
     const uint32_t prob = sd.prob;
     const ClProbDesc pd = B.desc[prob];
@@ -1366,7 +1366,7 @@ __global__ void __launch_bounds__(1024) popoa_strip_kernel(ClDeviceBatch B, ClSt
             if (tid == 0) { B.out_status[prob] = 9; B.out_len[prob] = 0; }
         } else if (!B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
     }
-    if (B.ticks && threadIdx.x == 0) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, true);
 }
 
 template <int NPW>

@@ -485,7 +485,7 @@ __device__ __forceinline__ void lane_dispatch(const ClDeviceBatch& B, const ClPr
 template <int W, bool WIDE>
 __global__ void __launch_bounds__(64 * W) popoa_lane_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P, uint32_t* lane_sync) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
     const uint32_t prob = plist[blockIdx.x];
     uint32_t grp = 0;
     if (WIDE) while (grp < blockIdx.x && plist[blockIdx.x - grp - 1] == prob) ++grp;
@@ -495,5 +495,5 @@ __global__ void __launch_bounds__(64 * W) popoa_lane_kernel(ClDeviceBatch B, con
     case 2: lane_dispatch<2, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync); break;
     default: lane_dispatch<3, W, WIDE>(B, pd, prob, P, lds, grp, lane_sync); break;
     }
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }

@@ -344,7 +344,7 @@ __device__ __forceinline__ void linear_dispatch(const ClDeviceBatch& B, const Cl
 template <int W>
 __global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist,
                                                               ClScoreParams P) {
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
     const uint32_t prob = plist[blockIdx.x];
     const ClProbDesc pd = B.desc[prob];
     switch (pd.npw) {
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, c
     case 2: linear_dispatch<2, W>(B, pd, prob, P); break;
     default: linear_dispatch<3, W>(B, pd, prob, P); break;
     }
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }
 
 // ---- four small chain pairs per wave -------------------------------------------------------------------------------------------------------------------
@@ -456,14 +456,14 @@ __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32
 }
 
 __global__ void __launch_bounds__(64) popoa_linear_quad_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
     const uint32_t* quad = plist + 4u * blockIdx.x;
     switch (B.desc[quad[0]].npw) {
     case 1: linear_quad<1>(B, quad, P); break;
     case 2: linear_quad<2>(B, quad, P); break;
     default: linear_quad<3>(B, quad, P); break;
     }
-    if (B.ticks && threadIdx.x == 0 && (gridDim.x <= 4096u || (blockIdx.x & 63u) == 0)) atomicMax(B.ticks + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }
 
 }  // namespace

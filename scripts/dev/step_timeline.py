@@ -22,3 +22,10 @@ for r in last:
     print("%-34s %6d wg  queue %-4s  start %8.1f us  end %8.1f us  (%7.1f)" % (name[:34], wg, r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                                          (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 print("step span %.1f us" % ((max(int(r["End_Timestamp"]) for r in last) - t0) / 1e3))
+# the last steps as intervals: what lies between the end of one step's last kernel and the start of the next step's first one is not kernel time
+prev_end = None
+for k in range(min(5, len(rows) // per), 0, -1):
+    chunk = rows[len(rows) - k * per: len(rows) - (k - 1) * per]
+    a, b = min(int(r["Start_Timestamp"]) for r in chunk), max(int(r["End_Timestamp"]) for r in chunk)
+    print("step -%d: span %8.1f us%s" % (k, (b - a) / 1e3, "" if prev_end is None else "   gap since the previous step's last kernel %7.1f us" % ((a - prev_end) / 1e3)))
+    prev_end = b
