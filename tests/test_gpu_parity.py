@@ -486,3 +486,44 @@ def test_small_chain_pairs_four_per_wave(gpu_ctx):
         tp = H.tie_params()
         got = gpu_ctx.po_poa_batch(b, f, tp.alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f, params=tp)) is None, ("ties", npw)
+
+
+def test_passes_of_a_resident_plan_overlap(gpu_ctx, monkeypatch):
+    """(second half of round 5) A pass of a plan no longer makes the context's stream wait for the auxiliary streams its launches went to: the next pass's launches follow in
+    stream order, passes enqueued back to back overlap, and whoever needs a pass complete joins first (cl_stitch_join: sync, collect, the profiled pass, a re-dealing of
+    the launches, the chaining DP, destroy).  Every kernel kind in one plan, twenty passes without a wait between them — through the first-stage and the second-stage
+    re-dealing of the launches — then the results; a second plan of the same context interleaved pass by pass; a chaining DP of the same context right behind an
+    unjoined pass; the launch clocks (pass-tagged, never zeroed between passes) give a duration for every launch of the last pass; and the same with a join per pass"""
+    sizes = [(5, 2100), (300, 330), (40, 44), (12, 9), (700, 650), (64, 300), (2000, 2000), (1500, 1300), (130, 4000)] + [(int(a), int(b)) for a, b in np.random.default_rng(5).integers(1, 90, (400, 2))]
+    b = synth.near_chain_batch(sizes[:8], seed=61, n_long=(0, 1))
+    b = capi.StitchBatch.concat([b, synth.linear_batch(sizes, seed=62), synth.sized_dag_batch([(500, 500), (64, 1000), (255, 256), (1200, 1100)], seed=63)])
+    want = po.oracle_stitch_batch(b)
+    other = synth.sized_dag_batch([(90, 100), (400, 380), (30, 900)], seed=64)
+    want_other = po.oracle_stitch_batch(other)
+    for join in ("", "eager"):
+        if join:
+            monkeypatch.setenv("CL_STITCH_JOIN", join)
+        plan = gpu_ctx.plan(b)
+        assert len({li["kernel"].split("<")[0] for li in plan.launches() if li["n_problems"]}) >= 4, plan.launches()
+        for _ in range(20):
+            plan.execute()
+        assert plan.collect().same_as(want) is None, join
+        plan.sync()
+        assert all(li["in_pass_ms"] > 0 for li in plan.launches() if li["n_problems"]), plan.launches()
+        plan2 = gpu_ctx.plan(other)
+        for _ in range(6):
+            plan.execute(); plan2.execute()
+        assert plan2.collect().same_as(want_other) is None, join
+        assert plan.collect().same_as(want) is None, join
+        # a chaining DP on the same context (its far launches use the same auxiliary streams) right behind a pass nobody has joined
+        z = np.load(os.path.join(H.GOLDEN, sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("chain4_"))[0]))
+        from tests.test_extraction import load_stitch_case
+        name = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("chain4_"))[0]
+        _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
+        ms = capi.MatchSets(**{k: z["a.ms." + k] for k in capi.MatchSets._DT})
+        plan.execute()
+        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z["a.scale"][0]))
+        assert np.array_equal(got["chain"], z["a.chain_affine"])
+        plan.execute_profiled(); plan.execute(); plan.execute()
+        assert plan.collect().same_as(want) is None, join
+        plan2.destroy(); plan.destroy()
