@@ -521,9 +521,13 @@ def test_passes_of_a_resident_plan_overlap(gpu_ctx, monkeypatch):
         name = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("chain4_"))[0]
         _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
         ms = capi.MatchSets(**{k: z["a.ms." + k] for k in capi.MatchSets._DT})
+        cp = capi.default_chain_params(global_anchoring=False)
+        plan.sync()
+        quiet = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z["a.scale"][0]), params=cp, want_dp=True)
+        assert np.array_equal(quiet["chain"], z["a.chain_affine"])
         plan.execute()
-        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z["a.scale"][0]))
-        assert np.array_equal(got["chain"], z["a.chain_affine"])
+        got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z["a.scale"][0]), params=cp, want_dp=True)
+        assert np.array_equal(got["chain"], quiet["chain"]) and np.array_equal(got["dp"].view(np.uint32), quiet["dp"].view(np.uint32))
         plan.execute_profiled(); plan.execute(); plan.execute()
         assert plan.collect().same_as(want) is None, join
         plan2.destroy(); plan.destroy()
