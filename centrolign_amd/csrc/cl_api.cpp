@@ -63,6 +63,12 @@ static uint32_t lane_round_waves(uint64_t n_problems) {
     if (e && (*e == '3' || *e == '4')) return (uint32_t)(*e - '0');
     return n_problems >= 2048 ? 3u : 4u;
 }
+// two chain pairs of 17-32 rows per wave (popoa_linear_duo_kernel): alone on the device 32 x 32 pairs run at 215 instead of 130 G cells/s — but the step of 10 x 1 Mbp
+// gets SLOWER with it, 1.79-1.96 against 1.54-1.65 ms (five runs each, profiles/r05_step_spread.txt): the 17 000 such pairs cost the one-pair-per-wave launch nothing
+// there (it lasts as long as its longest thin pair, 0.43 ms with or without them) and their workgroups fill idle SIMD slots beside the latency-bound launches; taken out,
+// they are one launch more in the step.  So: in plans that have the device to themselves (fewer than 2 048 subproblems), as the register kernel's rounds of four.
+// CL_LINEAR_DUOS=0|1 forces
+static bool duos_now(uint64_t n_problems) { const char* e = getenv("CL_LINEAR_DUOS"); return e && (*e == '0' || *e == '1') ? *e == '1' : n_problems < 2048; }
 static bool no_lane_now() { const char* e = getenv("CL_NO_LANE"); return e && *e == '1'; }
 #define g_no_lane no_lane_now()
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
@@ -1147,7 +1153,9 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const uint32_t nshort = std::min(d.n1, d.n2), nlong = std::max(d.n1, d.n2);
             // (lw = 2: FOUR pairs per wave, 16 lanes each — popoa_linear_quad_kernel; CL_NO_LINEAR_QUADS=1: one pair per wave as in rounds 1-4)
             static const bool no_quads = [] { const char* e = getenv("CL_NO_LINEAR_QUADS"); return e && *e == '1'; }();
+            const bool no_duos = !duos_now(n);
             if (nshort <= 16 && !no_quads) { lr = 1; lw = 2; }
+            else if (nshort <= 32 && !no_duos) { lr = 1; lw = 5; }   // (lw = 5: TWO pairs per wave, 32 lanes each — popoa_linear_duo_kernel; see duos_now)
             else if (nshort <= 64) { lr = 1; lw = 1; }
             else if (nshort <= 128 && nlong < 300) { lr = 2; lw = 1; }
             else if (nshort <= 256) { lr = 1; lw = lin_mid; }
@@ -1563,6 +1571,31 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             grp.bytes += cells_of(plist[i]) * 4ull * (1 + 2 * grp.npw);
         }
         std::stable_sort(plist.begin() + grp.first, plist.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
+        // A launch of thousands of workgroups is bound by throughput, not by its longest sweep, and inside a step that shares the device it lasts twice as long as alone
+        // (10 x 1 Mbp: 2 651 pairs of the systolic kernel, 0.70 ms alone, 1.45-1.5 ms in the step — the longest launch of the step, alone on its stream).  Such a
+        // launch is dealt into PARTS (every parts-th pair of the list by size, so that the parts are alike) which the streams can take separately.
+        // CL_STITCH_SPLIT=<workgroups per part> [0: never]
+        // Measured (profiles/r05_step_spread.txt): it LOSES — 1.58-1.59 ms per step undivided, 1.70-1.81 in parts of 1 400, 1.87-1.99 in parts of 900 (more launches
+        // on the same eight streams cost more than the better balance brings) — so off by default
+        static const uint32_t split_at = [] { const char* e = getenv("CL_STITCH_SPLIT"); const long v = e ? atol(e) : 0; return (uint32_t)(v < 0 ? 0 : v); }();
+        const uint32_t parts = grp.kind == CL_KIND_SYS && split_at && grp.count > split_at + split_at / 2 ? (grp.count + split_at - 1) / split_at : 1;
+        if (parts > 1) {
+            std::vector<uint32_t> all(plist.begin() + grp.first, plist.end());
+            plist.resize(grp.first);
+            for (uint32_t part = 0; part < parts; ++part) {
+                LaunchGroup sub = grp;
+                sub.first = (uint32_t)plist.size();
+                sub.cells = sub.bytes = 0;
+                for (size_t i = part; i < all.size(); i += parts) {
+                    plist.push_back(all[i]);
+                    sub.cells += cells_of(all[i]);
+                    sub.bytes += cells_of(all[i]) * 4ull * (1 + 2 * grp.npw);
+                }
+                sub.count = (uint32_t)plist.size() - sub.first;
+                pl->groups.push_back(sub);
+            }
+            return;
+        }
         pl->groups.push_back(grp);
     };
     // chain kernel: one launch per workgroup shape; the problems are ordered by the length of their sweep
@@ -1585,23 +1618,25 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     }
     // small chain pairs, four per wave (popoa_linear_quad_kernel): quads of one NumPW, longest first so that a quad's pairs are about as long as one another
     {
+      for (int marker : {2, 5}) {   // 2: four pairs per wave (quads), 5: two (duos)
         LaunchGroup grp;
-        grp.kind = CL_KIND_LINEAR; grp.npw = 0; grp.waves = 2;
+        grp.kind = CL_KIND_LINEAR; grp.npw = 0; grp.waves = marker;
         grp.first = (uint32_t)plist.size();
         for (int npw = 3; npw >= 1; --npw) {
             std::vector<uint32_t> q;
             for (uint32_t i = 0; i < pl->desc.size(); ++i)
-                if (pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == 2 && pl->desc[i].npw == npw) q.push_back(i);
+                if (pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == marker && pl->desc[i].npw == npw) q.push_back(i);
             std::stable_sort(q.begin(), q.end(), [&](uint32_t x, uint32_t y) { return std::max(pl->desc[x].n1, pl->desc[x].n2) > std::max(pl->desc[y].n1, pl->desc[y].n2); });
             for (uint32_t i : q) {
                 plist.push_back(i);
                 grp.cells += cells_of(i);
                 grp.bytes += cells_of(i) * 4ull * (1 + 2 * npw);
             }
-            while ((plist.size() - grp.first) % 4) plist.push_back(0xFFFFFFFFu);
+            while ((plist.size() - grp.first) % (marker == 2 ? 4 : 2)) plist.push_back(0xFFFFFFFFu);
         }
         grp.count = (uint32_t)plist.size() - grp.first;
         if (grp.count) pl->groups.push_back(grp);
+      }
     }
     // near-chain pairs in registers: one launch per workgroup shape as well (strips of 64 rows over 1 / 4 / 16 waves), longest sweep first
     // The LONG sweeps (1 024 steps and more: a handful of pairs that bound the pass) get launches of their own whose workgroups ask for more than half a compute
@@ -1832,7 +1867,7 @@ static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
 static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const ClDeviceBatch& dev, hipStream_t stream) {
-    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves == 2 ? 0 : g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
+    if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves == 2 ? 0 : g.waves == 5 ? -2 : g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     if (g.kind == CL_KIND_STRIP) {
         // the strips' progress words start every pass at zero (the strips of a launch poll one another's)
         hipError_t e = hipMemsetAsync(pl->d_progress.p + g.prog_first, 0, (size_t)g.prog_count * sizeof(uint32_t), stream);
@@ -1941,6 +1976,17 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed, bool 
             load[si] += std::max<uint64_t>(1, pl->groups[gi].est_cost);
         }
         stream_of[gi] = si;
+    }
+    static const bool sched_log = getenv("CL_STITCH_SCHED_LOG") != nullptr;   // the deal, once per change of the groups' order: stream, estimated duration, workgroups, kind
+    if (sched_log && pl->tick_pass <= 1) {
+        fprintf(stderr, "[stitch plan] launches over %d streams (calibrated %d, re-dealings left %d):", n_streams, (int)pl->calibrated, pl->recalibrations_left);
+        for (int t = 0; t < n_streams; ++t) {
+            fprintf(stderr, "  s%d %llu us [", t, (unsigned long long)load[t]);
+            for (size_t gi = 0; gi < pl->groups.size(); ++gi)
+                if (stream_of[gi] == t) fprintf(stderr, " k%d/w%d/b%d x%u:%llu", pl->groups[gi].kind, pl->groups[gi].waves, pl->groups[gi].block, pl->groups[gi].count, (unsigned long long)pl->groups[gi].est_cost);
+            fprintf(stderr, " ]");
+        }
+        fprintf(stderr, "\n");
     }
     // In which order the launches are ISSUED: the device starts about four launches at a time (a hardware queue that is handing out a launch's workgroups is busy until
     // the last of them has a compute unit — for the 34 716 workgroups of the short chain pairs that is the launch's whole duration), and in the step of 10 x 1 Mbp the
@@ -2089,6 +2135,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
     if (g.kind == CL_KIND_LINEAR && g.waves == 2) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_quad_kernel");
+    else if (g.kind == CL_KIND_LINEAR && g.waves == 5) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_duo_kernel");
     else if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), g.block == 1 ? "popoa_lane_kernel<%d, wide>" : "popoa_lane_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
@@ -2102,7 +2149,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     out->dp_cells = g.cells;
     out->dp_bytes = g.bytes;
     out->lds_bytes = g.kind == CL_KIND_LINEAR ? 0u : g.ring_bytes;
-    if (g.kind == CL_KIND_LINEAR && g.waves == 2) {   // (the quads' list is padded with "no pair")
+    if (g.kind == CL_KIND_LINEAR && (g.waves == 2 || g.waves == 5)) {   // (the quads' and duos' lists are padded with "no pair")
         out->n_problems = 0;
         for (uint32_t i = g.first; i < g.first + g.count; ++i) out->n_problems += pl->plist_host[i] != 0xFFFFFFFFu;
     }

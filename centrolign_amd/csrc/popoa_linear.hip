@@ -362,14 +362,28 @@ __global__ void __launch_bounds__(64 * W) popoa_linear_kernel(ClDeviceBatch B, c
 // (row_shr:1 / row_shl:1 act inside rows of 16 lanes: lane 0 of a row keeps the fill), the column feed is a chunk of 16 columns per segment.  Same cell, same
 // codes at the same addresses as linear_body<NPW, 1, 1, SWAP> (a pair's code buffer is indexed by ITS step and ITS lane), so linear_traceback walks them
 // unchanged, one pair after the other.  The quad's pairs have the same NumPW (host: cl_api.cpp sorts them by NumPW and length); 0xFFFFFFFF = no pair.
-__device__ __forceinline__ int32_t seg_shift_in(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }   // row_shr:1
-__device__ __forceinline__ int32_t seg_rotate_down(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x101, 0xf, 0xf, false); }               // row_shl:1
+// SEG = lanes of a segment = rows a pair may have: 16 (four pairs per wave, the ROW forms of the DPP moves) or 32 (two pairs per wave — round 5, second half: the
+// 17 000 pairs of 17-32 rows of a 10 x 1 Mbp step cost a wave 110 steps each alone, 80 steps per two here; the wave forms of the moves, and the one lane that would
+// take its neighbour segment's value — lane 32 — takes the fill by a select).  rotate_down needs no such care: what enters a segment's last lane from the next
+// segment reaches lane 0 only after SEG more rotations, and a chunk of SEG columns is reloaded by then
+template <int SEG>
+__device__ __forceinline__ int32_t seg_shift_in(int32_t v, int32_t fill, uint32_t l) {
+    if (SEG == 16) return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    const int32_t r = __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);          // wave_shr:1
+    return l == 0 ? fill : r;
+}
+template <int SEG>
+__device__ __forceinline__ int32_t seg_rotate_down(int32_t v) {
+    return SEG == 16 ? __builtin_amdgcn_update_dpp(v, v, 0x101, 0xf, 0xf, false)             // row_shl:1
+                     : __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);            // wave_shl:1
+}
 
-template <int NPW>
+template <int NPW, int SEG>
 __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32_t* __restrict__ quad, const ClScoreParams& P) {
     using code_t = typename CodeT<NPW>::type;
-    constexpr uint32_t CQ = 16;   // columns per chunk = lanes of a segment
-    const uint32_t lane = threadIdx.x & 63u, seg = lane >> 4, l = lane & 15u;
+    constexpr uint32_t CQ = SEG;   // columns per chunk = lanes of a segment
+    constexpr int NSEG = 64 / SEG;
+    const uint32_t lane = threadIdx.x & 63u, seg = lane / SEG, l = lane % SEG;
     const uint32_t prob = quad[seg];
     const bool have = prob != 0xFFFFFFFFu;
     ClProbDesc pd = B.desc[have ? prob : quad[0]];
@@ -378,11 +392,11 @@ __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32
     const uint8_t* labR = B.lab[swp ? 1 : 0] + pd.node_base[swp ? 1 : 0];
     const uint8_t* labC = B.lab[swp ? 0 : 1] + pd.node_base[swp ? 0 : 1];
     code_t* codes = reinterpret_cast<code_t*>(B.planes + pd.plane_base);
-    // the longest pair of the quad sets the number of steps (its last row reaches its last column at step nc + nr - 2)
+    // the longest pair of the wave sets the number of steps (its last row reaches its last column at step nc + nr - 2)
     uint32_t last = 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)nc, g * 16), r = (uint32_t)__builtin_amdgcn_readlane((int)nr, g * 16);
+    for (int g = 0; g < NSEG; ++g) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)nc, g * SEG), r = (uint32_t)__builtin_amdgcn_readlane((int)nr, g * SEG);
         if (c && r && c + r > last) last = c + r;
     }
     const uint32_t a = l + 1;   // this lane's row (1-based)
@@ -393,7 +407,7 @@ __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32
 #pragma unroll
     for (int k = 0; k < NPW; ++k) { Hleft[k] = CL_NEG_INF; lastV[k] = CL_NEG_INF; }
     for (uint32_t t0 = 0; t0 + 1 < last; t0 += CQ) {
-        {   // this chunk's 16 columns as seen by the segment's lane 0: label and the boundary row's Mf (V_k of the boundary row = -inf)
+        {   // this chunk's columns as seen by the segment's lane 0: label and the boundary row's Mf (V_k of the boundary row = -inf)
             const uint32_t colb = t0 + l + 1;
             const bool v = colb <= nc;
             myc2 = v ? (int32_t)(labC[colb - 1] & 0x7f) : 0xff;
@@ -401,13 +415,13 @@ __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32
         }
         for (uint32_t jj = 0; jj < CQ; ++jj) {
             const uint32_t t = t0 + jj;
-            const int32_t upM = seg_shift_in(lastM, bM);
-            bM = seg_rotate_down(bM);
+            const int32_t upM = seg_shift_in<SEG>(lastM, bM, l);
+            bM = seg_rotate_down<SEG>(bM);
             int32_t upV[NPW];
 #pragma unroll
-            for (int k = 0; k < NPW; ++k) upV[k] = seg_shift_in(lastV[k], CL_NEG_INF);
-            c2 = seg_shift_in(c2, myc2);
-            myc2 = seg_rotate_down(myc2);
+            for (int k = 0; k < NPW; ++k) upV[k] = seg_shift_in<SEG>(lastV[k], CL_NEG_INF, l);
+            c2 = seg_shift_in<SEG>(c2, myc2, l);
+            myc2 = seg_rotate_down<SEG>(myc2);
             const uint32_t b = t - l + 1;   // this lane's column (1-based); wraps when not started
             if ((uint32_t)(b - 1) < nc && l < nr) {
                 const int32_t sc = labr == c2 ? P.match : -P.mismatch;
@@ -442,7 +456,7 @@ __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32
     }
     if (have && a == nr) B.out_score[prob] = Mleft;
     __syncthreads();   // the codes are in memory
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NSEG; ++g) {
         const uint32_t pg = quad[g];
         if (pg == 0xFFFFFFFFu) continue;
         const ClProbDesc pdg = B.desc[pg];
@@ -455,16 +469,19 @@ __device__ __forceinline__ void linear_quad(const ClDeviceBatch& B, const uint32
     }
 }
 
-__global__ void __launch_bounds__(64) popoa_linear_quad_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
+template <int SEG>
+__device__ __forceinline__ void linear_pack_entry(const ClDeviceBatch& B, const uint32_t* __restrict__ plist, const ClScoreParams& P) {
     cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
-    const uint32_t* quad = plist + 4u * blockIdx.x;
+    const uint32_t* quad = plist + (64u / SEG) * blockIdx.x;
     switch (B.desc[quad[0]].npw) {
-    case 1: linear_quad<1>(B, quad, P); break;
-    case 2: linear_quad<2>(B, quad, P); break;
-    default: linear_quad<3>(B, quad, P); break;
+    case 1: linear_quad<1, SEG>(B, quad, P); break;
+    case 2: linear_quad<2, SEG>(B, quad, P); break;
+    default: linear_quad<3, SEG>(B, quad, P); break;
     }
     cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
 }
+__global__ void __launch_bounds__(64) popoa_linear_quad_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) { linear_pack_entry<16>(B, plist, P); }
+__global__ void __launch_bounds__(64) popoa_linear_duo_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) { linear_pack_entry<32>(B, plist, P); }
 
 }  // namespace
 
@@ -484,6 +501,7 @@ hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch&
     if (n_blocks == 0) return hipSuccess;
     switch (W) {
     case 0: hipLaunchKernelGGL(popoa_linear_quad_kernel, dim3(n_blocks / 4), dim3(64), 0, stream, B, plist, P); break;   // four small pairs per wave: n_blocks list entries, four per workgroup
+    case -2: hipLaunchKernelGGL(popoa_linear_duo_kernel, dim3(n_blocks / 2), dim3(64), 0, stream, B, plist, P); break;   // two pairs of 17-32 rows per wave
     case 1: hipLaunchKernelGGL((popoa_linear_kernel<1>), dim3(n_blocks), dim3(64), 0, stream, B, plist, P); break;
     case 3: hipLaunchKernelGGL((popoa_linear_kernel<3>), dim3(n_blocks), dim3(192), 0, stream, B, plist, P); break;
     case 4: hipLaunchKernelGGL((popoa_linear_kernel<4>), dim3(n_blocks), dim3(256), 0, stream, B, plist, P); break;

@@ -531,3 +531,33 @@ def test_passes_of_a_resident_plan_overlap(gpu_ctx, monkeypatch):
         plan.execute_profiled(); plan.execute(); plan.execute()
         assert plan.collect().same_as(want) is None, join
         plan2.destroy(); plan.destroy()
+
+
+def test_chain_pairs_two_per_wave(gpu_ctx, monkeypatch):
+    """popoa_linear_duo_kernel (second half of round 5): chain pairs whose shorter side has 17 to 32 nodes, two to a wave (32 lanes each; the wave forms of the DPP moves,
+    lane 32 takes its fill by a select): every length of the short side, either orientation, partners of very different length, an odd count, every NumPW, tie-heavy
+    scoring; against the oracle, and the same pairs one per wave (CL_LINEAR_DUOS=0); in plans of 2 048 subproblems and more the kernel is not taken by default"""
+    rng = np.random.default_rng(4)
+    sizes = [(a, int(rng.integers(1, 500))) for a in range(17, 33)] + [(int(rng.integers(17, 500)), a) for a in range(17, 33)] + [(32, 32), (17, 17), (32, 3000), (3000, 17), (20, 21)]
+    sizes += [(int(rng.integers(17, 33)), int(rng.integers(17, 90))) for _ in range(300)]
+    b = synth.linear_batch(sizes, seed=9)
+    plan = gpu_ctx.plan(b)
+    assert any(li["kernel"] == "popoa_linear_duo_kernel" and li["n_problems"] == len(sizes) for li in plan.launches()), plan.launches()
+    want = po.oracle_stitch_batch(b)
+    for _ in range(2):
+        plan.execute(); plan.sync()
+        assert plan.collect().same_as(want) is None
+    plan.destroy()
+    for npw in (1, 2, 3):
+        f = np.full(b.n_problems, npw, np.uint8)
+        got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
+        tp = H.tie_params()
+        got = gpu_ctx.po_poa_batch(b, f, tp.alignment_params)
+        assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f, params=tp)) is None, ("ties", npw)
+    monkeypatch.setenv("CL_LINEAR_DUOS", "0")
+    plan = gpu_ctx.plan(b)
+    assert not any(li["kernel"] == "popoa_linear_duo_kernel" for li in plan.launches()), plan.launches()
+    plan.execute(); plan.sync()
+    assert plan.collect().same_as(want) is None
+    plan.destroy()
