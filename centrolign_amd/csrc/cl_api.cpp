@@ -1159,7 +1159,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             else if (nshort <= 64) { lr = 1; lw = 1; }
             else if (nshort <= 128 && nlong < 300) { lr = 2; lw = 1; }
             else if (nshort <= 256) { lr = 1; lw = lin_mid; }
-            else { lr = 1; lw = lin_big ? lin_big : nshort <= 512 ? 8 : 16; }   // (up to eight strips: eight waves — with sixteen, half of them only stand at the barriers)
+            else { lr = 1; lw = lin_big ? lin_big : (nshort <= 512 || n >= 2048) ? 8 : 16; }   // (up to eight strips: eight waves — with sixteen, half of them only stand at the barriers; above, sixteen only in plans that have the device to themselves: the one such pair of the 10 x 1 Mbp step as a launch of its own costs the step 3 %, 1.61 against 1.56 ms, three runs each)
             d.pad = (uint16_t)(ls | (lr << 1));  // read by linear_dispatch
             P.plane_cursor += (cl_linear_workspace_bytes(nshort, nlong, npw, lr) + 15) / 16 * 4;
             P.ring_need.push_back(0);
@@ -1749,7 +1749,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                     // 2.55 ms per step — the long sweeps of the two classes then share a launch's tail)
                     (void)own;
                     const bool fits = have + of_class[lc].size() <= 256 * per_cu_at(grp.ring_bytes);
-                    if (!merge_lds || !fits) { close_group(grp); open(); }
+                    static const bool merge_all = [] { const char* e = getenv("CL_STITCH_MERGE_ALL"); return e && e[0] == '1'; }();   // (measurement: one launch per kernel shape whatever the LDS classes)
+                    if (!merge_all && (!merge_lds || !fits)) { close_group(grp); open(); }
                 }
                 for (uint32_t i : of_class[lc]) {
                     plist.push_back(i);
