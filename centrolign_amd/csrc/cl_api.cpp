@@ -1718,7 +1718,12 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             }
     // systolic DAG kernel: (NumPW, workgroup size, LDS class) — a launch's dynamic LDS is that of its hungriest problem, and LDS decides
     // how many workgroups share a CU, so the many small problems must not ride with the few large ones
-    const uint32_t lds_class[5] = {12 * 1024, 32 * 1024, 64 * 1024, 100 * 1024, (uint32_t)kSysLdsBytes};
+    // CL_STITCH_LDS_CLASSES=a,b,c,d (KB; four boundaries below the ceiling) for measurements
+    uint32_t lds_class[5] = {12 * 1024, 32 * 1024, 64 * 1024, 100 * 1024, (uint32_t)kSysLdsBytes};
+    if (const char* e = getenv("CL_STITCH_LDS_CLASSES")) {
+        unsigned a = 0, b = 0, c = 0, d = 0;
+        if (sscanf(e, "%u,%u,%u,%u", &a, &b, &c, &d) == 4 && a < b && b < c && c < d && d * 1024u < (uint32_t)kSysLdsBytes) { lds_class[0] = a * 1024; lds_class[1] = b * 1024; lds_class[2] = c * 1024; lds_class[3] = d * 1024; }
+    }
     // ... unless the smaller ones are so few that all workgroups of the merged launch are resident at once anyway: a launch lasts as long as its longest sweep
     // whatever rides along, and every launch less is a millisecond less on the stream it would have occupied (the streams, not the device, are what a step
     // runs out of: 10 x 1 Mbp, sixteen launches a step on eight streams).  CL_STITCH_MERGE_LDS=0: one launch per class as in rounds 2-3 (A/B)
