@@ -67,8 +67,8 @@ static uint32_t lane_round_waves(uint64_t n_problems) {
 // gets SLOWER with it, 1.79-1.96 against 1.54-1.65 ms (five runs each, profiles/r05_step_spread.txt): the 17 000 such pairs cost the one-pair-per-wave launch nothing
 // there (it lasts as long as its longest thin pair, 0.43 ms with or without them) and their workgroups fill idle SIMD slots beside the latency-bound launches; taken out,
 // they are one launch more in the step.  So: in plans that have the device to themselves (fewer than 2 048 subproblems), as the register kernel's rounds of four.
-// CL_LINEAR_DUOS=0|1 forces
-static bool duos_now(uint64_t n_problems) { const char* e = getenv("CL_LINEAR_DUOS"); return e && (*e == '0' || *e == '1') ? *e == '1' : n_problems < 2048; }
+// ... or in which such pairs are at least half of everything (a batch of them alone).  CL_LINEAR_DUOS=0|1 forces.  (-1: decided once the plan is packed)
+static int duos_forced() { const char* e = getenv("CL_LINEAR_DUOS"); return e && (*e == '0' || *e == '1') ? *e - '0' : -1; }
 static bool no_lane_now() { const char* e = getenv("CL_NO_LANE"); return e && *e == '1'; }
 #define g_no_lane no_lane_now()
 constexpr uint64_t kSysLdsBytes = 159 * 1024;    // LDS a systolic-DAG workgroup may take (rings of every row + the column records)
@@ -1153,7 +1153,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             const uint32_t nshort = std::min(d.n1, d.n2), nlong = std::max(d.n1, d.n2);
             // (lw = 2: FOUR pairs per wave, 16 lanes each — popoa_linear_quad_kernel; CL_NO_LINEAR_QUADS=1: one pair per wave as in rounds 1-4)
             static const bool no_quads = [] { const char* e = getenv("CL_NO_LINEAR_QUADS"); return e && *e == '1'; }();
-            const bool no_duos = !duos_now(n);
+            const bool no_duos = duos_forced() == 0;   // (whether the plan takes the kernel at all is decided when every pair is known: below)
             if (nshort <= 16 && !no_quads) { lr = 1; lw = 2; }
             else if (nshort <= 32 && !no_duos) { lr = 1; lw = 5; }   // (lw = 5: TWO pairs per wave, 32 lanes each — popoa_linear_duo_kernel; see duos_now)
             else if (nshort <= 64) { lr = 1; lw = 1; }
@@ -1598,6 +1598,14 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
         pl->groups.push_back(grp);
     };
+    // two pairs per wave only where it pays (duos_forced): the pairs marked for it run one per wave otherwise — same codes, same workspace
+    if (duos_forced() < 0) {
+        uint64_t marked = 0;
+        for (uint32_t i = 0; i < pl->desc.size(); ++i) marked += pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == 5;
+        if (!(n < 2048 || 2 * marked >= pl->desc.size()))
+            for (uint32_t i = 0; i < pl->desc.size(); ++i)
+                if (pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == 5) pl->lin_waves[i] = 1;
+    }
     // chain kernel: one launch per workgroup shape; the problems are ordered by the length of their sweep
     const int lin_waves[5] = {16, 8, 4, 3, 1};
     for (int gi = 0; gi < 5; ++gi) {
