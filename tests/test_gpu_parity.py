@@ -561,3 +561,71 @@ def test_chain_pairs_two_per_wave(gpu_ctx, monkeypatch):
     plan.execute(); plan.sync()
     assert plan.collect().same_as(want) is None
     plan.destroy()
+
+
+def test_strips_and_wide_launches_on_a_busy_device(gpu_ctx):
+    """ The strips of a pair wait for one another and rely on being resident together; the walk of the chaining DP and the wide form of the
+    register kernel have waits of the same kind.  Here the device is otherwise FULL: three more contexts on threads of their own run chaining DPs (walk + far launches
+    on six streams each) and stitch plans of thousands of small pairs back to back while this context runs pairs on the strips twenty times.  Every pass must give the
+    oracle's alignments; a strip that gives up is re-run anti-diagonal-wise by design (counted, reported), a wrong result or a hang is a failure"""
+    import threading
+    from tests.test_extraction import load_stitch_case
+    name = sorted(f for f in os.listdir(H.GOLDEN) if f.startswith("chain4_"))[0]
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
+    ms = capi.MatchSets(**{k: z["a.ms." + k] for k in capi.MatchSets._DT})
+    cp = capi.default_chain_params(global_anchoring=False)
+    filler = synth.linear_batch([(int(a), int(b)) for a, b in np.random.default_rng(12).integers(20, 300, (6000, 2))], seed=13)
+    stop = threading.Event()
+    errors = []
+    rounds = {"chain": 0, "stitch": 0}
+
+    def chain_worker():
+        try:
+            c = capi.Context(0)
+            while not stop.is_set():
+                got = c.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z["a.scale"][0]), params=cp)
+                rounds["chain"] += 1
+                if not np.array_equal(got["chain"], z["a.chain_affine"]):
+                    errors.append("chain differs under load")
+                    break
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    def stitch_worker():
+        try:
+            c = capi.Context(0)
+            p = c.plan(filler)
+            while not stop.is_set():
+                for _ in range(10):
+                    p.execute()
+                p.sync()
+                rounds["stitch"] += 1
+            p.destroy(); c.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=chain_worker), threading.Thread(target=chain_worker), threading.Thread(target=stitch_worker)]
+    for t in threads:
+        t.start()
+    try:
+        b = synth.sized_dag_batch([(2000, 2000), (1500, 4000), (5500, 5500), (900, 1300)], seed=23, extra_edge_p=0.05, skip_max=3)
+        want = po.oracle_stitch_batch(b)
+        plan = gpu_ctx.plan(b)
+        assert any(li["kernel"].startswith("popoa_strip_kernel") for li in plan.launches()), plan.launches()
+        fallbacks, passes = 0, 0
+        while passes < 20 or ((rounds["chain"] < 6 or rounds["stitch"] < 6) and passes < 2000 and not errors):   # (until the other contexts have really been at work beside it)
+            plan.execute(); plan.sync()
+            assert plan.collect().same_as(want) is None
+            fallbacks = plan.stats()["n_strip_fallbacks"]
+            passes += 1
+        plan.destroy()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join(timeout=300)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+    assert rounds["chain"] >= 6 and rounds["stitch"] >= 6, rounds
+    print("strip passes %d beside %d chaining DPs and %d x 10 stitch passes of 6 000 pairs on other contexts; strip fallbacks: %d" % (passes, rounds["chain"], rounds["stitch"], fallbacks))
