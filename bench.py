@@ -447,6 +447,15 @@ def main():
     my_cells = sum(st["dp_cells"] for st in stats)
     elapsed, dev_ms = run_steps(plans, args.warmup, args.steps)
     elapsed = cd.max_over_ranks(elapsed, dist, device="cpu" if share else "cuda")
+    # beside the line: the same plans with a join of each plan's streams after EVERY pass (how rounds 1-4 and the first half of round 5 timed the step), a few passes
+    os.environ["CL_STITCH_JOIN"] = "eager"
+    try:
+        j_steps = max(3, args.steps // 4)
+        j_elapsed, _ = run_steps(plans, 1, j_steps)
+        join_per_pass_ms = cd.max_over_ranks(j_elapsed, dist, device="cpu" if share else "cuda") / j_steps * 1e3
+    finally:
+        del os.environ["CL_STITCH_JOIN"]
+    run_steps(plans, 1, 2)   # (the launches' own clocks reported below are those of overlapping passes again)
     # every launch's own clock in the LAST timed pass (launches side by side, as in production): kernel name + subproblem count identify a launch
     in_pass = {}
     for m, p in plans:
@@ -545,6 +554,8 @@ def main():
             # now the passes of a resident plan overlap — a stream starts pass i + 1 when ITS launches of pass i are done (cl_stitch_join, cl_api.cpp) — and the events
             # round the last pass span everything that was still running when it was enqueued: CL_STITCH_JOIN=eager restores the join per pass)
             "device_ms_from_the_last_pass_enqueue_to_its_end": dev_ms / args.steps,
+            "with_a_join_per_pass": {"ms_per_step": join_per_pass_ms, "value": total_cells / (join_per_pass_ms * 1e-3) if join_per_pass_ms else None,
+                                     "note": "CL_STITCH_JOIN=eager: the context's stream waits for all eight streams after every pass, the next pass forks from it — the timing of rounds 1-4"},
             "passes": "the K timed passes are enqueued back to back; a launch group runs on the same stream in every pass, so stream order is the only order between passes and they overlap (no join of the eight streams between passes); the barrier + synchronize that closes the timed region waits for all of them",
             "launches": sorted(launches, key=lambda e: -e["ms"])[:12],
         }

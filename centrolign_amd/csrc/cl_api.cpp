@@ -931,7 +931,12 @@ cl_context* cl_context_create(int device_ordinal) {
     const int n_own = [] { const char* e = getenv("CL_CTX_STREAMS"); int v = e ? atoi(e) : 0; return v >= 1 && v <= kNumAuxStreams ? v : 6; }();
     ctx->n_aux = n_own;
     for (int i = 0; ok && i < kNumAuxStreams; ++i) {
-        if (i < n_own) ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess;
+        // CL_CTX_PRIO_STREAMS=k: the first k auxiliary streams get the device's highest priority — a stitch plan deals its longest launches to them first
+        // (measurement knob, read at every creation like CL_CTX_STREAMS)
+        const int n_prio = [] { const char* e = getenv("CL_CTX_PRIO_STREAMS"); int v = e ? atoi(e) : 0; return v >= 0 && v <= kNumAuxStreams ? v : 0; }();
+        int prio_lo = 0, prio_hi = 0;
+        if (n_prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (i < n_own) ok = (i < n_prio ? hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking)) == hipSuccess;
         else ctx->aux[i] = ctx->aux[i % n_own];
         ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -2020,7 +2025,7 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed, bool 
             dev.tick_pass = pl->tick_pass;
             HIP_TRY(ctx, launch_group(g, pl, dev, ctx->aux[si]));
         }
-    static const bool eager_join = [] { const char* e = getenv("CL_STITCH_JOIN"); return e && e[0] == 'e'; }();   // CL_STITCH_JOIN=eager: every pass joins (up to the first half of round 5)
+    const bool eager_join = [] { const char* e = getenv("CL_STITCH_JOIN"); return e && e[0] == 'e'; }();   // CL_STITCH_JOIN=eager: every pass joins (up to the first half of round 5); read per pass: bench.py times both
     for (int si = 0; si < kNumAuxStreams; ++si)
         if (used[si]) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join[si], ctx->aux[si]));
