@@ -447,6 +447,11 @@ def main():
     my_cells = sum(st["dp_cells"] for st in stats)
     elapsed, dev_ms = run_steps(plans, args.warmup, args.steps)
     elapsed = cd.max_over_ranks(elapsed, dist, device="cpu" if share else "cuda")
+    # every launch's own clock in the LAST timed pass (launches side by side, as in production): kernel name + subproblem count identify a launch
+    in_pass = {}
+    for m, p in plans:
+        for li in p.launches():
+            in_pass[(m, li["kernel"], li["n_problems"], li["dp_cells"])] = li["in_pass_ms"]
     # beside the line: the same plans with a join of each plan's streams after EVERY pass (how rounds 1-4 and the first half of round 5 timed the step), a few passes
     os.environ["CL_STITCH_JOIN"] = "eager"
     try:
@@ -455,12 +460,6 @@ def main():
         join_per_pass_ms = cd.max_over_ranks(j_elapsed, dist, device="cpu" if share else "cuda") / j_steps * 1e3
     finally:
         del os.environ["CL_STITCH_JOIN"]
-    run_steps(plans, 1, 2)   # (the launches' own clocks reported below are those of overlapping passes again)
-    # every launch's own clock in the LAST timed pass (launches side by side, as in production): kernel name + subproblem count identify a launch
-    in_pass = {}
-    for m, p in plans:
-        for li in p.launches():
-            in_pass[(m, li["kernel"], li["n_problems"], li["dp_cells"])] = li["in_pass_ms"]
     total_cells = my_cells
     if dist is not None:
         t = torch.tensor([float(my_cells)], dtype=torch.float64, device="cpu" if share else "cuda")
