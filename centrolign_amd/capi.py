@@ -212,6 +212,22 @@ def host_route_align(batch, k, params=None):
     return int(route.value), pairs
 
 
+def stitch_rank_order(batch, k, side, mode="auto"):
+    """cl_stitch_rank_order: the topological order the device ranks subgraph `side` of subproblem k by ("auto": the packer's choice, "lifo": the reference's order,
+    "level": by longest path from a source); no device needed.  Returns (order: uint32 local node ids by rank, reads more than four ranks back, longest read)"""
+    lib = load_library()
+    bc = batch.as_c()
+    n = int(batch.side[side].node_off[k + 1] - batch.side[side].node_off[k])
+    order = np.zeros(max(n, 1), np.uint32)
+    far, longest = C.c_uint32(0), C.c_uint32(0)
+    lib.cl_stitch_rank_order.restype = C.c_int
+    lib.cl_stitch_rank_order.argtypes = [C.POINTER(StitchBatchC), C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rc = lib.cl_stitch_rank_order(C.byref(bc), int(k), int(side), {"auto": 0, "lifo": 1, "level": 2}[mode], order.ctypes.data, C.byref(far), C.byref(longest))
+    if rc != 0:
+        raise ClError(rc, "cl_stitch_rank_order")
+    return order[:n], int(far.value), int(longest.value)
+
+
 def partition_anchors(graph1, graph2, chain, score_scale=1.0, score_boundaries=False, use_annotated_score=False, **overrides):
     """Partitioner::partition_anchors (include/centrolign/partitioner.hpp:72-213), host only.  `chain` is the dict that
     Context.anchor_chain returns (walk_off, walk1, walk2, count1, count2, full_length, chain[:,0] = match set, score).
@@ -1000,7 +1016,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 9     # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 10    # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1184,7 +1200,7 @@ EXPORTED_SYMBOLS = [
     "cl_parse_fasta", "cl_fasta_free", "cl_msa_plan_create", "cl_msa_plan_free", "cl_msa_params_default", "cl_msa",
     "cl_read_gfa", "cl_subproblem_hash_hex", "cl_internal_fuse", "cl_induced_pairwise_cigar",
     "cl_anchor_chain", "cl_anchor_chain_result_free", "cl_anchor_chain_masked", "cl_generate_diagonal_mask", "cl_update_mask", "cl_internal_stitch",
-    "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align",
+    "cl_partition_params_default", "cl_partition_anchors", "cl_host_route_align", "cl_stitch_rank_order",
     "cl_core_align_params_default", "cl_core_align", "cl_core_align_result_free",
     "cl_split_params_default", "cl_split_branching_matches", "cl_owned_match_sets_view", "cl_owned_match_sets_free",
     "cl_estimate_score_scale", "cl_leaf_intrinsic_scale", "cl_leaf_graph", "cl_explicit_cigar", "cl_write_gfa",

@@ -2426,6 +2426,31 @@ int cl_host_route_align(const cl_stitch_batch* batch, uint64_t k, const cl_stitc
     return CL_OK;
 }
 
+int cl_stitch_rank_order(const cl_stitch_batch* batch, uint64_t k, int side, int mode, uint32_t* order_out, uint32_t* far_reads_out, uint32_t* longest_read_out) {
+    if (!batch || k >= batch->n_problems || side < 0 || side > 1 || mode < 0 || mode > 2 || !order_out) return CL_ERR_INVALID_ARGUMENT;
+    const GraphView g = view(batch->side[side], k);
+    NextLists nx;
+    nx.build(g);
+    std::vector<uint32_t> order, st, indeg, rank(g.n);
+    if (!topological_order(g, nx, order, st, indeg)) return CL_ERR_CYCLIC_GRAPH;
+    for (uint32_t r = 0; r < g.n; ++r) rank[order[r]] = r;
+    choose_rank_order(g, mode, order, rank, st, indeg);
+    uint32_t far = 0, longest = 0;
+    for (uint64_t v = 0; v < g.n; ++v) {
+        if (order[rank[v]] != v) return CL_ERR_INVALID_ARGUMENT;   // (cannot happen: order and rank are inverse permutations)
+        for (uint64_t e = g.prev_off[v]; e < g.prev_off[v + 1]; ++e) {
+            const uint32_t back = rank[v] - rank[g.prev_idx[e]];
+            far += back > 4;
+            longest = std::max(longest, back);
+        }
+    }
+    for (uint64_t i = 0; i < g.n_src; ++i) { far += rank[g.src[i]] + 1 > 4; longest = std::max(longest, rank[g.src[i]] + 1); }
+    std::copy(order.begin(), order.end(), order_out);
+    if (far_reads_out) *far_reads_out = far;
+    if (longest_read_out) *longest_read_out = longest;
+    return CL_OK;
+}
+
 int cl_po_poa_batch(cl_context* ctx, const cl_stitch_batch* batch, const uint8_t* num_pw, const cl_align_params* params,
                     cl_stitch_result* out) {
     if (!ctx || !batch || !num_pw || !params || !out) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 9   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 10   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -273,6 +273,14 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int 
  * pairs_out is malloc'ed, AlignedPair layout, translated through back_translation; release with free(). */
 int cl_host_route_align(const cl_stitch_batch* batch, uint64_t problem, const cl_stitch_params* params, int* route_out,
                         uint64_t** pairs_out, uint64_t* n_pairs_out);
+
+/* The topological order the DEVICE ranks the nodes of one subgraph by (no counterpart in the reference, whose DP runs in the order of
+ * topological_order.hpp:12-60 — any topological order gives the same DP values, and the traceback's ties follow the previous() and sink
+ * lists, which are kept): mode 0 = the packer's choice between the reference's order (1) and the order by level — longest path from a
+ * source, ties in the reference's order (2) —, whichever makes fewer rows read more than four ranks back, then the shorter longest read.
+ * order_out[rank] = local node id (n entries); the two counts describe the order returned.  Host only, no device needed. */
+int cl_stitch_rank_order(const cl_stitch_batch* batch, uint64_t problem, int side, int mode, uint32_t* order_out,
+                         uint32_t* far_reads_out /* may be NULL */, uint32_t* longest_read_out /* may be NULL */);
 
 /* --- Stitcher::stitch proper: from a partitioned anchor chain to the stitched base-level alignment ----------------
  * (include/centrolign/stitcher.hpp:34-38,104-206).  The two merge graphs are passed as flat views of BaseGraph
