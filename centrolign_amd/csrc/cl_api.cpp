@@ -2086,6 +2086,11 @@ int cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* pl) {
     if (!pl->graph_tried && !g_no_graph && !pl->groups.empty()) {
         pl->graph_tried = true;
         hipGraph_t graph = nullptr;
+        // (nothing uncaptured may be waited for inside a capture: join what is out first; and the launch clocks are zeroed by a node of the graph — a replayed
+        // pass carries the same pass number every time)
+        { int rc = plan_mark_stop(ctx, pl); if (rc) return rc; }
+        pl->tick_pass = 0;
+        if (!pl->d_ticks.p) { int rc = pl->d_ticks.alloc(ctx, 2 * pl->groups.size()); if (rc) return rc; }   // (no allocation inside a capture)
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = enqueue_groups(ctx, pl, false, true);   // (a capture has to end with every forked stream joined)
             hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
