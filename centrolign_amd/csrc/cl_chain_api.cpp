@@ -1185,6 +1185,13 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 // the room now — the DP is correct without it, an allocation that fails half-way would end the merge
                 size_t free_b = 0, total_b = 0;
                 const uint64_t need = (uint64_t)R * (48 + 7 * 4 + 8 * 2 + n_levels * (sparse ? 1 : 2) * 4) + words * 4;
+                // ... and only if the context's last affine DP did not end up sweeping all pairs anyway: on 50 x 100 kbp (dense matches: a third of the leaves opened)
+                // the DPs of the 156-combination merges choose the sweep, the 625-combination root then does too, and the sweep inside the far pass is 15 % slower than
+                // without its structures (163 against 142 s); on 50 x 1 Mbp they choose branch-and-bound (1.3 % opened) and the root takes 36 instead of 196 s
+                if (!sparse && ctx->far_last_choice == 2) {
+                    if (timing) fprintf(stderr, "[chain_dp_batch]   far pass not taken: the context's last affine DP chose the all-pairs sweep\n");
+                    use_far = false;
+                } else
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + need / 8 + (8ull << 30) > (uint64_t)free_b) {
                     if (timing) fprintf(stderr, "[chain_dp_batch]   far pass not taken: it needs %.1f GB, the device has %.1f GB free\n", need * 1.125 / 1e9, free_b / 1e9);
                     use_far = false;
@@ -1386,6 +1393,14 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             return e;
         };
         for (uint32_t k = 0; k < n_macro && he == hipSuccess; ++k) {
+            if (far_decided && timing && use_far && k >= 256 && (k & (k - 1)) == 0) {   // (CL_CHAIN_TIMING: how the opened share moves after the decision)
+                unsigned long long cnt[2] = {0, 0};
+                if (hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                    for (uint32_t f = 0; f < far_lag; ++f) (void)hipStreamSynchronize(ctx->aux[f]);
+                    if (cl_copy_sync(ctx, cnt, d_status.p + 2, sizeof(cnt), hipMemcpyDeviceToHost) == hipSuccess)
+                        fprintf(stderr, "[chain_dp_batch]   far pass after %u macro-blocks: %llu of %llu leaves opened so far (%s)\n", k, cnt[0], cnt[1], far_bb ? "branch-and-bound" : "all-pairs sweep");
+                }
+            }
             if (!far_decided && k >= 96 && (k & (k - 1)) == 0) {   // k = 128, 256, 512, ...
                 he = hipStreamSynchronize(ctx->stream);
                 for (uint32_t f = 0; f < far_lag && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
@@ -1394,6 +1409,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 if (he == hipSuccess && cnt[1] >= (1ull << 22)) {
                     far_decided = true;
                     far_bb = cnt[0] * 16 <= cnt[1];
+                    if (!sparse) ctx->far_last_choice = far_bb ? 1 : 2;
                     if (timing) fprintf(stderr, "[chain_dp_batch]   far pass after %u macro-blocks: %llu of %llu leaves opened -> %s\n", k, cnt[0], cnt[1], far_bb ? "branch-and-bound" : "all-pairs sweep");
                 }
             }

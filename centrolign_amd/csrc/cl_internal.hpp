@@ -28,6 +28,7 @@ struct cl_context {
     int n_aux = kNumAuxStreams;
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[kNumAuxStreams] = {};
+    int far_last_choice = 0;            // what the last affine chaining DP of this context with a far pass decided at its checkpoint: 1 branch-and-bound, 2 all-pairs sweep (0: none yet)
     uint32_t stitch_join_pending = 0;   // aux streams whose last stitch launches the context's stream has not been made to wait for yet (cl_stitch_join, cl_api.cpp)
     std::string error;
     std::string name;
