@@ -53,7 +53,7 @@ def predict(n_seq, length, budget):
         pad = R + C * (64 << (3 * (levels - 1))) // 2
         # the far pass runs whenever its arena fits 2^35 words and the device has the room (cl_chain_api.cpp; up to round 4 the arena was addressed in words: off beyond
         # 2^32, i.e. at the 625-combination root of 50 sequences, which then swept all pairs: 196 s instead of 36)
-        far = True
+        far = True   # (taken at a wide root only where the context's DPs prune — cl_chain_api.cpp, far_last_choice — and where the device has the room: this is the upper figure)
         rows.append(("gap-free" if sparse else "affine", chain_dp_bytes(M, R, C, half1, half2, sparse, pad if far else 0, levels if far else 0, "fold" if C > 256 else "1")))
     return dict(n_seq=n_seq, length=length, budget=budget, combinations=C, dp_bytes=dict(rows),
                 host_tables_bytes=2 * 2 * 4 * int(length * 1.2) * half1 + 2 * 4 * int(length * 1.2) * half1)   # PathMerge index + table per side, post-switch distances
