@@ -9,7 +9,7 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $OUT/pytest
 step() { rm -f /tmp/s.json; timeout 200 python scripts/step_launches.py --steps 30 --warmup 5 --json /tmp/s.json > /dev/null 2>>$OUT/step.err; python -c "import json;d=json.load(open('/tmp/s.json'));print('%.3f ms per step'%(d['ms_per_step']))"; }
 for i in 1 2 3; do
   echo "two pairs of 17-32 rows per wave (default): $(step)" | tee -a $OUT/ab.txt
-  echo "CL_NO_LINEAR_DUOS=1: $(CL_NO_LINEAR_DUOS=1 step)" | tee -a $OUT/ab.txt
+  echo "CL_LINEAR_DUOS=0: $(CL_LINEAR_DUOS=0 step)" | tee -a $OUT/ab.txt
 done
 tail -3 $OUT/step.err
 timeout 300 python scripts/stress_set.py --json $OUT/stress.json 2>&1 | grep "32^2" | cut -c1-200
