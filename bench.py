@@ -608,16 +608,16 @@ def main():
                                                                   for n, v in by_kernel.items()), key=lambda x: -x["ms"])[:6],
                                "limiter": "dependent chain of the largest matrix (n1 + n2 steps of one workgroup), not HBM: see latency_model",
                                "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells, SURVEY.md §8d) of all launches of the dominant kernel / the sum of their durations by the kernels' own clocks inside the last timed pass of THIS run (kernel_ms, kernel_cells: its longest launch); "
-                                       "traffic: the committed rocprofv3 PMC summary of the same command (traffic_profile gives its provenance), never divided by this run's times"}
+                                       "traffic: HBM bytes per launch of the SAME launches (matched by kernel, subproblems, cells) from the committed per-launch profile (traffic_launch_matched / traffic_profile give its provenance), never divided by this run's times"}
         if elapsed > 0:
-            # the whole step against the same roofline: what the nine plans together stream per second if every cell's state moved once
+            # the whole step against the same roofline: what the plan's launches together stream per second if every cell's state moved once
             step_bytes = float(sum(st["dp_bytes"] for st in stats))
             if dist is not None:
                 step_bytes *= total_cells / max(1.0, float(my_cells))   # (other ranks' batches: same bytes per cell on average)
             ach = step_bytes * args.steps / elapsed / 1e9
             out["roofline_pass"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                                    "note": "ALGORITHMIC bytes of all launches of a step / the step's wall-clock: the nine plans' launches overlap, so the "
-                                            "pass as a whole sits much closer to the roofline than its longest (latency-bound) launch, which `roofline` reports"}
+                                    "note": "ALGORITHMIC bytes of all launches of a step / the step's wall-clock: the plan's launches run side by side on eight streams (and consecutive passes "
+                                            "overlap), so the pass as a whole sits much closer to the roofline than its dominant kernel's launches, which `roofline` reports"}
         if chain_ms > 0:
             n_macro = sum(2 * -(-int(m["chain_match_pairs"]) // 1024) for m in per_merge)     # two whole-graph DPs per merge, 1024 pairs per macro-block
             out["chain_dp"] = {"model": "latency", "not_a_roofline": True, "device_ms": chain_ms, "match_pairs": int(chain_pairs), "macro_blocks": n_macro,
