@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.cl_abi_version() == capi.ABI_VERSION
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """round-5 verdict: C++-mangled internals (cl_big_alloc, cl_stitch_join, kernel stubs ...) used to be visible beside the C entry points; the link now goes
+    through centrolign_amd/csrc/exports.map (global: cl_*; local: *)"""
+    import subprocess
+    path = os.path.join(ROOT, "centrolign_amd", "lib", "libcentrolign_amd.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    header = open(os.path.join(ROOT, "include", "centrolign_amd.h")).read()
+    declared = set(re.findall(r"\b(cl_[a-z_0-9]+)\s*\(", header)) - {"cl_t"}
+    stray = sorted(n for n in names if n not in declared)
+    assert not stray, "symbols exported beside the C ABI: %s" % stray[:10]
+
+
 def test_default_params_match_cli_values():
     lib = capi.load_library()
     p = capi.StitchParams()
