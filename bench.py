@@ -338,26 +338,24 @@ def main():
         gfa_sha, gfa_bytes = hashlib.sha256(gfa).hexdigest(), len(gfa)
     merge_groups_retry = None
     if world > 1 and args.share_merges > 1 and args.length == 1000000:
-        # merge groups (one merge over several GPUs through peer stores) have only ever run between processes on ONE device here: if the GFA they give is not
-        # the reference's, the MSA is run again with one rank per merge and the line says so — a wrong multi-GPU result is never timed
+        # merge groups (one merge over several GPUs through peer stores) have only ever run between processes on ONE device here.  A GFA that is not the reference's is a
+        # HARD failure (round-5 verdict item 8; round-4 advisor: a silent second run with one rank per merge masked exactly the class of fault a ring-slot collision would be):
+        # every rank leaves with a non-zero exit code and no line is printed
         want = None
         try:
             with open(os.path.join(HERE, "tests", "golden", "c3_10x1M_subproblems.json")) as f:
                 want = json.load(f)["root_default_budget_reference"]["sha256"]
         except Exception:   # noqa: BLE001
             pass
-        force = os.environ.get("CL_BENCH_FORCE_RETRY") == "1"   # test hook: behave as if the first GFA had been wrong
+        force = os.environ.get("CL_BENCH_FORCE_RETRY") == "1"   # test hook: behave as if the GFA had been wrong
         flag = torch.tensor([1 if (rank != 0 or want is None or (gfa_sha == want and not force)) else 0], dtype=torch.int32)
         dist.broadcast(flag, 0, group=host_group)
         if int(flag.item()) == 0:
-            merge_groups_retry = {"first_gfa_sha256": gfa_sha, "first_msa_wall_s": msa_wall}
-            barrier()
-            t0 = time.perf_counter()
-            res = msa.progressive_msa_distributed(ctx, seqs, tree, dist, rank, world, group=host_group, keep_merges=True, all_ranks=True, workers=args.workers, share_merges=0)
-            msa_wall = cd.max_over_ranks(time.perf_counter() - t0, dist, device="cpu" if share else "cuda")
             if rank == 0:
-                gfa = capi.write_gfa(res["root"], res["paths"])
-                gfa_sha, gfa_bytes = hashlib.sha256(gfa).hexdigest(), len(gfa)
+                print("bench.py: the MSA run with merge groups of %d ranks printed GFA %s, the reference's is %s: wrong multi-GPU result, nothing is timed" % (args.share_merges, gfa_sha, want), file=sys.stderr)
+            ctx.close()
+            dist.destroy_process_group()
+            sys.exit(3)
     kept = res["stats"].get("kept", []) if res is not None and "stats" in res else []
 
     # ---- 2. the stitch batches of this rank's merges, resident in HBM ----------------------------------------------------------
@@ -447,6 +445,35 @@ def main():
     my_cells = sum(st["dp_cells"] for st in stats)
     elapsed, dev_ms = run_steps(plans, args.warmup, args.steps)
     elapsed = cd.max_over_ranks(elapsed, dist, device="cpu" if share else "cuda")
+    # round-5 verdict, weak #7: the timed region is 20 x 1.5 ms with a run-to-run spread of +-5 %.  `value` stays the contract's ONE block of K steps (above); four more
+    # blocks of K steps follow, and the line carries the minimum and the median of the five so that a reader sees where the headline block fell
+    more_blocks = []
+    for _ in range(4):
+        e2, _ = run_steps(plans, 0, args.steps)
+        more_blocks.append(cd.max_over_ranks(e2, dist, device="cpu" if share else "cuda") / args.steps * 1e3)
+    # HIP events round every launch ON ITS STREAM inside a concurrent pass (cl_stitch_plan_execute_evented), with plain passes enqueued in front of and behind it so that
+    # the evented pass overlaps its neighbours exactly as a timed pass does: the durations roofline.frac is priced with (they agree with the rocprofv3 kernel trace of the
+    # step up to the stream's launch gap; the kernels' own clocks, which round 5 priced with, start at the first workgroup and miss the dispatch's wait for compute units
+    # and the end-of-kernel write-back: profiles/r06_clock_gap.json)
+    event_acc, event_n = {}, 0
+    for _ in range(max(3, min(8, args.steps // 2))):
+        for _, p in plans:
+            p.execute(); p.execute()
+        for _, p in plans:
+            p.execute_evented()
+        for _, p in plans:
+            p.execute(); p.execute()
+        for m, p in plans:
+            p.sync()
+            for li in p.launches():
+                if li["event_ms"] > 0:
+                    key = (m, li["kernel"], li["n_problems"], li["dp_cells"])
+                    event_acc[key] = event_acc.get(key, 0.0) + li["event_ms"]
+        event_n += 1
+    for _, p in plans:        # one plain pass, waited for: the launches' own clocks of a pass WITHOUT events (in_pass_ms below)
+        p.execute()
+    for _, p in plans:
+        p.sync()
     # every launch's own clock in the LAST timed pass (launches side by side, as in production): kernel name + subproblem count identify a launch
     in_pass = {}
     for m, p in plans:
@@ -475,7 +502,8 @@ def main():
             p.execute_profiled()
             p.sync()
             for li in p.launches():
-                e = acc.setdefault((li["kernel"], li["n_problems"], li["dp_cells"]), dict(li, ms=0.0, merge=m, in_pass_ms=in_pass.get((m, li["kernel"], li["n_problems"], li["dp_cells"]), 0.0)))
+                e = acc.setdefault((li["kernel"], li["n_problems"], li["dp_cells"]), dict(li, ms=0.0, merge=m, in_pass_ms=in_pass.get((m, li["kernel"], li["n_problems"], li["dp_cells"]), 0.0),
+                                                                                          event_ms=event_acc.get((m, li["kernel"], li["n_problems"], li["dp_cells"]), 0.0) / max(1, event_n)))
                 e["ms"] += li["ms"]
         for e in acc.values():
             e["ms"] /= prof_steps
@@ -490,9 +518,10 @@ def main():
         by_kernel = {}
         for e in launches:
             k = by_kernel.setdefault(e["kernel"], {"ms": 0.0, "bytes": 0, "cells": 0, "problems": 0, "launches": 0, "longest": e})
-            dur = e.get("in_pass_ms") or e["ms"]
+            dur = e.get("event_ms") or e.get("in_pass_ms") or e["ms"]
             k["ms"] += dur; k["bytes"] += e["dp_bytes"]; k["cells"] += e["dp_cells"]; k["problems"] += e["n_problems"]; k["launches"] += 1
-            if dur > (k["longest"].get("in_pass_ms") or k["longest"]["ms"]):
+            k["clock_ms"] = k.get("clock_ms", 0.0) + (e.get("in_pass_ms") or e["ms"])
+            if dur > (k["longest"].get("event_ms") or k["longest"].get("in_pass_ms") or k["longest"]["ms"]):
                 k["longest"] = e
         dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"]) if by_kernel else None
         dom = by_kernel[dom_name]["longest"] if dom_name else None
@@ -527,6 +556,9 @@ def main():
             "metric": "stitcher PO-POA DP cells/s (10 x 1 Mbp synthetic HOR MSA, every between-anchor subproblem of all nine merges, fill + traceback)",
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "timed_blocks": {"ms_per_step": [elapsed / args.steps * 1e3] + more_blocks, "min": min([elapsed / args.steps * 1e3] + more_blocks),
+                             "median": sorted([elapsed / args.steps * 1e3] + more_blocks)[2],
+                             "note": "five timed blocks of K steps each, every one bracketed by barrier + synchronize; value / ms_per_step are the FIRST block (the contract's K steps), the others show the run-to-run spread"},
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": ("INVALID (--debug-skip %d): " % args.debug_skip if args.debug_skip else "") + ("INVALID (the GFA differs from the reference's): " if gfa_ok is False else "") + WORKLOAD if args.length == 1000000 else "DRY RUN at %d bp per sequence, not the headline: " % args.length + WORKLOAD,
                        "sequences": len(names), "sequence_length": args.length, "merges": len(per_merge) if world == 1 else 9,
@@ -559,9 +591,10 @@ def main():
             "launches": sorted(launches, key=lambda e: -e["ms"])[:12],
         }
         if dom is not None:
-            dom_ms = dom.get("in_pass_ms") or dom["ms"]      # inside a timed pass (what production sees); `kernel_ms_alone` beside it
+            dom_ms = dom.get("event_ms") or dom.get("in_pass_ms") or dom["ms"]      # inside a concurrent pass, HIP events on the launch's stream; `kernel_ms_alone` beside it
             agg = by_kernel[dom_name]
             achieved = agg["bytes"] / (agg["ms"] * 1e-3) / 1e9
+            achieved_clock = agg["bytes"] / (agg["clock_ms"] * 1e-3) / 1e9 if agg.get("clock_ms") else None
             # latency model of the same launch: its duration is the dependent sweep of its longest subproblem (rows on lanes, one column per
             # step), so what can be acted on is the time per step against what ONE wave can issue: ~195 instructions per step in the systolic
             # DAG kernel, 4 cycles per 64-wide VALU instruction, 2.4 GHz
@@ -596,7 +629,18 @@ def main():
                                     "rows": [{k: r.get(k) for k in ("subproblems", "dp_cells", "algorithmic_bytes", "hbm_bytes", "duration_us_mean", "hbm_over_algorithmic")} for r in rows]}
             except (OSError, KeyError, ValueError):
                 pass
+            # the same figure from the committed rocprofv3 kernel trace of the step (scripts/dominant_launches.sh -> profiles/dominant_launches_latest.json), launch-matched:
+            # what a reader recomputes from profiles/ alone
+            frac_profile = None
+            if traffic_rows and all(r.get("duration_us_mean") for r in traffic_rows["rows"]):
+                pb = sum(r["algorithmic_bytes"] for r in traffic_rows["rows"]); pt = sum(r["duration_us_mean"] for r in traffic_rows["rows"]) * 1e-6
+                frac_profile = {"file": "profiles/dominant_launches_latest.json", "algorithmic_bytes": pb, "kernel_seconds": pt, "achieved_GB_per_s": pb / pt / 1e9, "frac": pb / pt / 8e12,
+                                "note": "sum of algorithmic bytes / sum of rocprofv3 kernel-trace durations of the SAME launches (kernel, subproblems, cells) in the committed profile"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                               "durations_from": "HIP events round each launch on its own stream inside a concurrent pass of THIS run (cl_stitch_plan_execute_evented; plain passes in front and behind), mean of %d evented passes" % event_n,
+                               "frac_kernel_clock": achieved_clock / 8000.0 if achieved_clock else None,
+                               "frac_kernel_clock_note": "the same bytes over the kernels' own s_memrealtime clocks (first workgroup's start to last workgroup's end) in a plain concurrent pass: what round 5 printed as frac; it leaves out the dispatch's wait for compute units behind the other launches and the end-of-kernel write-back (profiles/r06_clock_gap.json)",
+                               "frac_from_committed_profile": frac_profile,
                                "traffic_unit": traffic_unit, "traffic_launch_matched": traffic_rows,
                                "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
                                "kernel": dom["kernel"], "merge": dom["merge"], "kernel_launches": agg["launches"], "kernel_ms_all_launches": agg["ms"],
@@ -607,7 +651,7 @@ def main():
                                "kernels_by_time_in_pass": sorted(({"kernel": n, "ms": v["ms"], "launches": v["launches"], "GB_per_s": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else None}
                                                                   for n, v in by_kernel.items()), key=lambda x: -x["ms"])[:6],
                                "limiter": "dependent chain of the largest matrix (n1 + n2 steps of one workgroup), not HBM: see latency_model",
-                               "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells, SURVEY.md §8d) of all launches of the dominant kernel / the sum of their durations by the kernels' own clocks inside the last timed pass of THIS run (kernel_ms, kernel_cells: its longest launch); "
+                               "note": "achieved = ALGORITHMIC bytes (sizeof(cell_t<NumPW>) x cells, SURVEY.md §8d) of all launches of the dominant kernel / the sum of their durations by HIP events on the launches' streams inside concurrent passes of THIS run (kernel_ms, kernel_cells: its longest launch); "
                                        "traffic: HBM bytes per launch of the SAME launches (matched by kernel, subproblems, cells) from the committed per-launch profile (traffic_launch_matched / traffic_profile give its provenance), never divided by this run's times"}
         if elapsed > 0:
             # the whole step against the same roofline: what the plan's launches together stream per second if every cell's state moved once
@@ -627,6 +671,37 @@ def main():
                                        "behind on side streams); its kernels are priced per kernel against HBM bytes/s and VALU issue in profiles/r04_pmc_summary.json "
                                        "(rocprofv3 --pmc passes; command recorded in the file), not here: the far pass skips >98 % of the pair evaluations an "
                                        "all-pairs sweep would make, so an evaluations/s figure says nothing about the hardware"}
+            # the chaining kernels against the hardware's bounds (last bullet; unit = match pair): the committed rocprofv3 passes of the chaining seam
+            # (scripts/chain_roofline.sh: kernel trace + FETCH_SIZE + WRITE_SIZE + SQ counters over scripts/anchor_bench.py) per kernel — HBM bytes/s against 8 TB/s and
+            # VALU wave-instructions/s against the chip's issue capacity — quoted with their provenance, never divided by this run's times
+            try:
+                with open(os.path.join(HERE, "profiles", "chain_roofline_latest.json")) as f:
+                    cr = json.load(f)
+                keep = ("kernel", "calls", "avg_us", "share_pct", "hbm_bytes_per_call", "hbm_bytes_per_match_pair", "hbm_GB_per_s", "hbm_frac", "valu_wave_insts_per_call",
+                        "valu_wave_insts_per_match_pair", "valu_G_per_s", "valu_issue_frac", "wave_cycles_issuing_valu", "wave_cycles_parked_on_waitcnt_or_barrier", "bound")
+                out["roofline_chain"] = {"file": "profiles/chain_roofline_latest.json", "command": cr.get("command"), "tree": cr.get("tree"), "peaks": cr.get("peaks"), "unit": cr.get("unit"),
+                                         "kernels": [{k: e.get(k) for k in keep} for e in cr.get("kernels", [])[:8]],
+                                         "this_run": {"chain_device_ms_all_merges": chain_ms, "match_pairs_all_merges": int(chain_pairs), "us_per_macro_block": chain_ms * 1e3 / max(1, n_macro)}}
+            except (OSError, KeyError, ValueError):
+                out["roofline_chain"] = None
+        # in situ (round-5 verdict, weak #3): what ONE production pass of the stitcher costs inside the MSA — cl_core_align's stitch_ms = extraction + rank-space packing + upload +
+        # DP + collect + translate — against the resident plan's timed step; and the same batches one-shot on an otherwise idle device (cl_stitch_batch_align: plan + H2D + DP + D2H)
+        try:
+            situ_ms = sum(m["stitch_ms"] for m in per_merge)
+            situ_cells = sum(b.dp_cells() for _, b in batches) if world == 1 else None
+            one_shot = None
+            if world == 1:
+                t_os = time.perf_counter()
+                for _, b in batches:
+                    ctx.stitch_batch_align(b)
+                one_shot = time.perf_counter() - t_os
+            out["in_situ"] = {"stitch_ms_summed_over_merges": situ_ms, "dp_cells": situ_cells,
+                              "cells_per_s_inside_the_msa": (situ_cells / (situ_ms * 1e-3)) if situ_cells and situ_ms else None,
+                              "one_shot_s_all_batches": one_shot, "cells_per_s_one_shot": (situ_cells / one_shot) if situ_cells and one_shot else None,
+                              "note": "stitch_ms (cl_align_api.cpp) = subgraph extraction + rank-space packing + H2D + fill + traceback + D2H + translate, per merge, with the MSA's other worker contexts beside it; "
+                                      "one_shot = cl_stitch_batch_align per batch (plan create + upload + execute + collect + translate) on an idle device, batches already extracted; `value` is the resident plan re-executed (inputs in HBM, K passes overlapping)"}
+        except Exception as e:   # noqa: BLE001
+            out["in_situ"] = {"error": repr(e)[:200]}
         # BASELINE.md §2 holds ONE figure for this metric, measured (not published) by the survey: the reference's po_poa at 38 M cells/s inside
         # its 2 x 1 Mbp run on one Xeon core; the same-host figures are in cpu_baseline (measured here, every run)
         out["vs_baseline"] = value / 38.0e6

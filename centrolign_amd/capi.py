@@ -790,7 +790,7 @@ class MatchSets:
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("n_problems", C.c_uint64), ("dp_cells", C.c_uint64),
                 ("dp_bytes", C.c_uint64), ("last_ms", C.c_float), ("in_pass_ms", C.c_float), ("lds_bytes", C.c_uint32), ("max_sweep", C.c_uint32),
-                ("max_n1", C.c_uint32), ("max_n2", C.c_uint32)]
+                ("max_n1", C.c_uint32), ("max_n2", C.c_uint32), ("event_ms", C.c_float)]
 
 
 _SIDE_DTYPES = dict(node_off=np.uint64, label=np.uint8, prev_off=np.uint64, prev_idx=np.uint32,
@@ -1016,7 +1016,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 10    # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 11    # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1056,6 +1056,8 @@ def load_library(path=None):
     lib.cl_stitch_plan_execute.argtypes = [C.c_void_p, C.c_void_p]
     lib.cl_stitch_plan_execute_profiled.restype = C.c_int
     lib.cl_stitch_plan_execute_profiled.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cl_stitch_plan_execute_evented.restype = C.c_int
+    lib.cl_stitch_plan_execute_evented.argtypes = [C.c_void_p, C.c_void_p]
     lib.cl_stitch_plan_sync.restype = C.c_int
     lib.cl_stitch_plan_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.cl_stitch_plan_collect.restype = C.c_int
@@ -1192,7 +1194,7 @@ EXPORTED_SYMBOLS = [
     "cl_abi_version", "cl_device_count", "cl_context_create", "cl_context_destroy", "cl_last_error",
     "cl_context_peer_export", "cl_context_peer_group", "cl_context_peer_stats", "cl_context_peer_selftest", "cl_context_peer_steal", "cl_context_memory", "cl_fallback_counters",
     "cl_device_name", "cl_stitch_params_default", "cl_po_poa_batch", "cl_stitch_batch_align",
-    "cl_stitch_result_free", "cl_stitch_result_alloc", "cl_context_set_stitch_hook", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_sync",
+    "cl_stitch_result_free", "cl_stitch_result_alloc", "cl_context_set_stitch_hook", "cl_stitch_plan_create", "cl_stitch_plan_execute", "cl_stitch_plan_execute_profiled", "cl_stitch_plan_execute_evented", "cl_stitch_plan_sync",
     "cl_stitch_plan_collect", "cl_stitch_plan_destroy", "cl_stitch_plan_stats",
     "cl_stitch_plan_launch_count", "cl_stitch_plan_launch_info",
     "cl_extract_stitch_batch", "cl_owned_batch_view", "cl_owned_batch_free", "cl_stitch", "cl_alignment_free",
@@ -1366,6 +1368,10 @@ class Plan:
     def execute_profiled(self):
         self.ctx._check(self.ctx.lib.cl_stitch_plan_execute_profiled(self.ctx.handle, self.handle))
 
+    def execute_evented(self):
+        """one concurrent pass with HIP events round every launch on its stream: launches()[i]["event_ms"] after sync()"""
+        self.ctx._check(self.ctx.lib.cl_stitch_plan_execute_evented(self.ctx.handle, self.handle))
+
     def sync(self):
         ms = C.c_float(0)
         self.ctx._check(self.ctx.lib.cl_stitch_plan_sync(self.ctx.handle, self.handle, C.byref(ms)))
@@ -1392,7 +1398,7 @@ class Plan:
             self.ctx._check(self.ctx.lib.cl_stitch_plan_launch_info(self.ctx.handle, self.handle, i, C.byref(li)))
             out.append(dict(kernel=li.kernel.decode(), n_problems=int(li.n_problems), dp_cells=int(li.dp_cells),
                             dp_bytes=int(li.dp_bytes), ms=float(li.last_ms), in_pass_ms=float(li.in_pass_ms), lds_bytes=int(li.lds_bytes), max_sweep=int(li.max_sweep),
-                            longest=(int(li.max_n1), int(li.max_n2))))
+                            longest=(int(li.max_n1), int(li.max_n2)), event_ms=float(li.event_ms)))
         return out
 
     def destroy(self):

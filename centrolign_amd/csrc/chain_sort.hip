@@ -1,9 +1,11 @@
 // chain_sort.hip — value index for the chaining traceback: for one tree kind of one chain combination, the records'
-// stored values (order-preserving integer encoding) sorted together with their record numbers (hipCUB radix sort).
+// stored values (order-preserving integer encoding) sorted together with their record numbers (rocPRIM radix sort).
 // The host then finds "all predecessors whose stored value equals this query's maximum" by binary search instead of
 // scanning a million records per traceback step.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 
 namespace {
@@ -20,10 +22,10 @@ __global__ void chain_keys_kernel(const float* __restrict__ val, uint32_t n, int
 // sorts (enc(val[r]), r) by key; temp storage is (re)allocated by the caller through the two-call protocol
 hipError_t cl_chain_sort_values(const float* val, uint32_t n, int* keys_in, uint32_t* idx_in, int* keys_out, uint32_t* idx_out,
                                 void* temp, size_t* temp_bytes, hipStream_t stream) {
-    if (temp == nullptr) return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, 32, stream);
+    if (temp == nullptr) return rocprim::radix_sort_pairs(nullptr, *temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u, 32u, stream);
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(chain_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, val, n, keys_in, idx_in);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, 32, stream);
+    return rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u, 32u, stream);
 }

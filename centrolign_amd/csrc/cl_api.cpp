@@ -679,7 +679,8 @@ struct LaunchGroup {
     uint64_t est_cost = 0;    // longest sweep x the kernel's rough time per step: orders the groups and deals them over the streams
     float host_ms = 0.f;      // the profiled pass: the launch alone on the device, behind another launch (host's clock: two launches - one launch)
     float host_idle_ms = 0.f; // ... and finding the device idle (one launch + wait)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // cl_stitch_plan_execute_evented: HIP events round this launch on ITS stream in a concurrent pass
+    bool evented = false;
 };
 
 }  // namespace
@@ -734,6 +735,7 @@ struct cl_stitch_plan {
     bool executed = false, profiled = false, calibrated = false;
     int recalibrations_left = -1, concurrent_passes = 0;
     uint32_t tick_pass = 0;      // number of the last concurrent pass (ClDeviceBatch::tick_pass), 1 .. 65 535
+    bool event_pass = false;     // the pass being enqueued brackets every launch with HIP events (cl_stitch_plan_execute_evented)
     bool stop_pending = false;   // the last pass's end is not marked on the context's stream yet (lazy join)   // second stage of the launch scheduling: see cl_stitch_plan_execute
 };
 
@@ -2023,7 +2025,13 @@ static int enqueue_groups(cl_context* ctx, cl_stitch_plan* pl, bool timed, bool 
             ClDeviceBatch dev = pl->dev;
             dev.ticks = pl->d_ticks.p ? pl->d_ticks.p + 2 * gi : nullptr;
             dev.tick_pass = pl->tick_pass;
+            if (pl->event_pass) {
+                LaunchGroup& ge = pl->groups[gi];
+                if (!ge.ev0) { HIP_TRY(ctx, hipEventCreate(&ge.ev0)); HIP_TRY(ctx, hipEventCreate(&ge.ev1)); }
+                HIP_TRY(ctx, hipEventRecord(ge.ev0, ctx->aux[si]));
+            }
             HIP_TRY(ctx, launch_group(g, pl, dev, ctx->aux[si]));
+            if (pl->event_pass) { HIP_TRY(ctx, hipEventRecord(pl->groups[gi].ev1, ctx->aux[si])); pl->groups[gi].evented = true; }
         }
     const bool eager_join = [] { const char* e = getenv("CL_STITCH_JOIN"); return e && e[0] == 'e'; }();   // CL_STITCH_JOIN=eager: every pass joins (up to the first half of round 5); read per pass: bench.py times both
     for (int si = 0; si < kNumAuxStreams; ++si)
@@ -2134,6 +2142,23 @@ int cl_stitch_plan_execute_profiled(cl_context* ctx, cl_stitch_plan* pl) {
     return CL_OK;
 }
 
+// A concurrent pass exactly as cl_stitch_plan_execute enqueues one without a graph — the same launches on the same streams, side by side, following the pass before in
+// stream order — with a pair of HIP events round every launch ON ITS STREAM.  An event pair spans from the moment the stream reaches the launch (the end of whatever
+// preceded it there) to the launch's completion, end-of-kernel cache write-back included: what the rocprofv3 kernel trace of a step shows as the dispatch's duration plus
+// the stream's launch gap, i.e. an UPPER bound of the trace's duration where the kernel's own clock (first workgroup's start to last workgroup's end) is a lower bound.
+// bench.py prices roofline.frac with these (round-5 verdict: the printed fraction must be the one profiles/ reproduces).
+int cl_stitch_plan_execute_evented(cl_context* ctx, cl_stitch_plan* pl) {
+    if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(pl->ev_start, ctx->stream));
+    pl->event_pass = true;
+    const int rc = enqueue_groups(ctx, pl, false);
+    pl->event_pass = false;
+    if (rc) return rc;
+    pl->executed = true;
+    return CL_OK;
+}
+
 int cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* pl, float* ms_out) {
     if (!ctx || !pl) { set_error(ctx, "null argument"); return CL_ERR_INVALID_ARGUMENT; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2183,6 +2208,11 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
         if (d.n1 + d.n2 > out->max_sweep) { out->max_sweep = d.n1 + d.n2; out->max_n1 = d.n1; out->max_n2 = d.n2; }
     }
     if (pl->profiled) out->last_ms = g.host_ms;
+    if (g.evented && hipEventQuery(g.ev1) == hipSuccess) {
+        float ems = 0.f;
+        if (hipEventElapsedTime(&ems, g.ev0, g.ev1) == hipSuccess) out->event_ms = ems;
+        else (void)hipGetLastError();
+    }
     if (pl->d_ticks.p && pl->executed) {   // the launch's own clock in the last pass (the caller has waited for it: cl_stitch_plan_sync)
         unsigned long long got[2] = {0, 0};
         HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -2,7 +2,7 @@
 // algorithm (include/centrolign/path_esa.hpp:101-123,174-200).  Both of those are sequential pointer chases; here:
 //
 //   * suffix array by PREFIX DOUBLING: suffixes are ranked by their first 8 characters (one 64-bit key per position,
-//     one radix sort), then by (rank[i], rank[i + h]) for h = 8, 16, 32, ... (one key-building kernel, one hipCUB radix
+//     one radix sort), then by (rank[i], rank[i + h]) for h = 8, 16, 32, ... (one key-building kernel, one rocPRIM radix
 //     sort over just the bits a rank pair needs, one flag + scan + scatter to re-rank) until every rank is unique.  The
 //     text ends in a unique smallest character (path_esa.hpp:113-117), so ranks past the end never decide a comparison.
 //   * the rank array of EVERY round is kept (4 bytes x text length x ~log2(longest repeat) — nothing next to 288 GB), which
@@ -12,7 +12,9 @@
 //
 // Everything is HBM-streaming integer work: per round ~ (8 + 4) B x n of key/rank traffic on top of the radix sort's passes.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 
 #include <vector>
@@ -115,8 +117,8 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
     lap("allocations");
     HIP_TRY(ctx, hipMemcpyAsync(text.p, h_text, n, hipMemcpyHostToDevice, s));
     size_t sort_bytes = 0, scan_bytes = 0;
-    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (int)n, 0, 64, s));
-    HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, flag.p, dense.p, (int)n, s));
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 64u, s));
+    HIP_TRY(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, flag.p, dense.p, (size_t)n, rocprim::plus<uint32_t>(), s));
     if ((rc = temp.alloc(ctx, sort_bytes > scan_bytes ? sort_bytes : scan_bytes))) return rc;
     size_t temp_bytes = temp.n;
 
@@ -133,13 +135,13 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
     for (uint32_t h = 0;; h = h ? h * 2 : 8) {
         if (h == 0) {
             hipLaunchKernelGGL(first_keys_kernel, grid, block, 0, s, text.p, n, key_in.p, idx_in.p);
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (int)n, 0, 64, s));
+            HIP_TRY(ctx, rocprim::radix_sort_pairs(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 64u, s));
         } else {
             hipLaunchKernelGGL(pair_keys_kernel, grid, block, 0, s, level.back().p, n, h, bits, key_in.p, idx_in.p);
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (int)n, 0, (int)(2 * bits), s));
+            HIP_TRY(ctx, rocprim::radix_sort_pairs(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 2 * bits, s));
         }
         hipLaunchKernelGGL(head_flags_kernel, grid, block, 0, s, key_out.p, n, flag.p);
-        HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(temp.p, temp_bytes, flag.p, dense.p, (int)n, s));
+        HIP_TRY(ctx, rocprim::inclusive_scan(temp.p, temp_bytes, flag.p, dense.p, (size_t)n, rocprim::plus<uint32_t>(), s));
         level.emplace_back();
         if ((rc = level.back().alloc(ctx, n))) return rc;
         hipLaunchKernelGGL(scatter_rank_kernel, grid, block, 0, s, idx_out.p, dense.p, n, level.back().p);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 10   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 11   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -228,6 +228,8 @@ int  cl_stitch_plan_execute(cl_context* ctx, cl_stitch_plan* plan);
 /* Same work, launched kernel by kernel with HIP events around every launch so that cl_stitch_plan_launch_info can
  * report per-kernel durations (the unprofiled execute replays a captured hipGraph instead). */
 int  cl_stitch_plan_execute_profiled(cl_context* ctx, cl_stitch_plan* plan);
+/* one concurrent pass (as cl_stitch_plan_execute) with HIP events round every launch on its stream: cl_launch_info.event_ms (ABI 11) */
+int  cl_stitch_plan_execute_evented(cl_context* ctx, cl_stitch_plan* plan);
 /* Waits for the stream; returns the device time of the LAST execute in ms (HIP events on the context's
  * stream) through *ms_out if not NULL. */
 int  cl_stitch_plan_sync(cl_context* ctx, cl_stitch_plan* plan, float* ms_out);
@@ -262,6 +264,9 @@ typedef struct cl_launch_info {
     uint32_t lds_bytes;          /* dynamic LDS per workgroup (0: static only) */
     uint32_t max_sweep;          /* the longest dependent chain of the launch: max n1 + n2 over its subproblems */
     uint32_t max_n1, max_n2;     /* the subproblem that has it */
+    float    event_ms;           /* HIP events round this launch on its stream in the last cl_stitch_plan_execute_evented (launches side by side as in
+                                    cl_stitch_plan_execute): from the stream reaching the launch to its completion — agrees with the rocprofv3 kernel trace of a
+                                    step up to the stream's launch gap; 0: none yet.  (ABI 11) */
 } cl_launch_info;
 int cl_stitch_plan_launch_count(const cl_stitch_plan* plan);
 int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* plan, int index, cl_launch_info* info_out);

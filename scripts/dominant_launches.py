@@ -54,10 +54,27 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     ctr[c] = acc
 
 
+# what follows the timed passes in the command (scripts/step_launches.py --evented N --alone): N rounds of [plain, evented, plain] and, at the very end, every launch alone (twice)
+n_ev, n_alone = int(plan.get("evented_rounds", 0) or 0), 2 if plan.get("alone") else 0
+tail = 3 * n_ev + n_alone
+
+
 def timed(vals):
-    """the dispatches of the timed passes: the last `steps` of warmup + steps (+ one profiled pass the plan runs by itself to calibrate its streams)"""
+    """the dispatches of the timed passes: `steps` dispatches in front of the tail (evented rounds, alone launches) — warm-up and the plan's own calibration pass come before them"""
     vals = sorted(vals)
+    vals = vals[:len(vals) - tail] if tail else vals
     return [v for _, v in vals[-steps:]]
+
+
+def evented(vals):
+    vals = sorted(vals)
+    vals = vals[len(vals) - tail:len(vals) - n_alone] if n_ev else []
+    return [v for i, (_, v) in enumerate(vals) if i % 3 == 1]
+
+
+def alone(vals):
+    vals = sorted(vals)
+    return [vals[-1][1]] if n_alone and vals else []
 
 
 table = []
@@ -75,6 +92,20 @@ for (kernel, n_prob), li in sorted(want.items(), key=lambda kv: -kv[1]["dp_bytes
     if d:
         row["duration_us_mean"] = sum(d) / len(d) / 1e3
         row["duration_us_min_max"] = [min(d) / 1e3, max(d) / 1e3]
+    # the other clocks of the SAME process (the run under --kernel-trace): the kernel's own clock in the last timed pass, HIP events on the launch's stream in the evented
+    # passes with the trace's duration of those very dispatches, the launch alone by both clocks — what explains the gap between trace and own clock (round-5 verdict, item 2)
+    if li.get("in_pass_ms"):
+        row["own_clock_in_pass_us"] = li["in_pass_ms"] * 1e3
+    if li.get("event_ms"):
+        row["hip_events_in_pass_us"] = li["event_ms"] * 1e3
+        ev = evented(dur.get(key, []))
+        if ev:
+            row["trace_us_of_the_evented_dispatches"] = sum(ev) / len(ev) / 1e3
+    if li.get("alone_ms"):
+        row["own_clock_alone_us"] = li["alone_ms"] * 1e3
+        al = alone(dur.get(key, []))
+        if al:
+            row["trace_us_alone"] = al[0] / 1e3
     if f and w:
         fetch, write = sum(f) / len(f) * 1024 * 2, sum(w) / len(w) * 1024
         row.update(fetch_bytes_x2=fetch, write_bytes=write, hbm_bytes=fetch + write, hbm_over_algorithmic=(fetch + write) / max(1, li["dp_bytes"]))

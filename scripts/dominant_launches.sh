@@ -1,7 +1,7 @@
 #!/bin/bash
 # One command, three profiler passes (kernel trace; FETCH_SIZE; WRITE_SIZE — they do not fit one pass on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"; PMC passes carry
 # --kernel-trace only) over scripts/step_launches.py = the timed stitch step of bench.py and nothing else; scripts/dominant_launches.py joins them per LAUNCH
-# -> profiles/r05_dominant_launches.json (duration, HBM bytes read x 2 + written as the guide prescribes, algorithmic bytes) which bench.py's roofline.traffic reads.
+# -> profiles/r06_dominant_launches.json (duration, HBM bytes read x 2 + written as the guide prescribes, algorithmic bytes) which bench.py's roofline.traffic reads.
 # Run via gpurun from the repo root; the program itself follows "--" (no wrapper).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/dom
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 10 --warmup 3"
+ARGS="--steps 10 --warmup 3 --evented 4 --alone"
 python3 $R/scripts/step_launches.py $ARGS --json $OUT/plain.json > /dev/null 2>$OUT/plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/scripts/step_launches.py $ARGS --json $OUT/trace.json > /dev/null 2>$OUT/trace.err
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--evented", type=int, default=0, help="after the timed passes: N rounds of [plain pass, pass with HIP events round every launch on its stream, plain pass] (cl_stitch_plan_execute_evented)")
+    ap.add_argument("--alone", action="store_true", help="at the very end: every launch ALONE on the device (cl_stitch_plan_execute_profiled: each launched twice, the second one timed)")
     args = ap.parse_args()
     path = os.path.join(ROOT, "bench_data", "c3_batches.npz")
     if not os.path.exists(path):
@@ -47,8 +49,20 @@ def main():
     plan.sync()
     elapsed = time.perf_counter() - t0
     st = plan.stats()
-    launches = plan.launches()
-    out = dict(steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, host_enqueue_ms_per_step=enqueued / args.steps * 1e3, dp_cells=int(st["dp_cells"]), cells_per_s=st["dp_cells"] * args.steps / elapsed,
+    launches = plan.launches()          # in_pass_ms: the launches' own clocks in the last timed pass
+    if args.evented:
+        acc = {}
+        for _ in range(args.evented):
+            plan.execute(); plan.execute_evented(); plan.execute(); plan.sync()
+            for i, li in enumerate(plan.launches()):
+                acc[i] = acc.get(i, 0.0) + li["event_ms"]
+        for i, li in enumerate(launches):
+            li["event_ms"] = acc.get(i, 0.0) / args.evented
+    if args.alone:
+        plan.execute_profiled(); plan.sync()
+        for li, la in zip(launches, plan.launches()):
+            li["alone_ms"] = la["ms"]
+    out = dict(steps=args.steps, warmup=args.warmup, evented_rounds=args.evented, alone=bool(args.alone), ms_per_step=elapsed / args.steps * 1e3, host_enqueue_ms_per_step=enqueued / args.steps * 1e3, dp_cells=int(st["dp_cells"]), cells_per_s=st["dp_cells"] * args.steps / elapsed,
                launches=launches)
     text = json.dumps(out)
     if args.json:
