@@ -156,17 +156,26 @@ void replay_units(size_t n, const std::vector<uint32_t>& rank_of_heap, size_t rl
 // records ordered by (key, slot): slots are unique, so a placement by slot followed by a stable counting sort on the key
 // replaces the comparison sort (the big trees of a 1 Mbp problem hold every match pair)
 template <class KeyF, class SlotF>
-void sort_by_key_then_slot(std::vector<uint32_t>& items, uint64_t n_slots, KeyF key, SlotF slot) {
+void sort_by_key_then_slot(std::vector<uint32_t>& items, uint64_t n_slots, KeyF key, SlotF slot, bool already_by_slot = false) {
     if (items.size() < 4096) {
         std::sort(items.begin(), items.end(), [&](uint32_t a, uint32_t b) { return key(a) != key(b) ? key(a) < key(b) : slot(a) < slot(b); });
         return;
     }
-    std::vector<uint32_t> at(n_slots, 0xFFFFFFFFu), by_slot;
-    for (uint32_t it : items) at[slot(it)] = it;
-    by_slot.reserve(items.size());
-    for (uint64_t sl = 0; sl < n_slots; ++sl) if (at[sl] != 0xFFFFFFFFu) by_slot.push_back(at[sl]);
+    std::vector<uint32_t> by_slot;
+    if (already_by_slot) by_slot = items;   // (the caller's list comes in slot order: a run of one shift of the (shift, slot) order)
+    else {
+        std::vector<uint32_t> at(n_slots, 0xFFFFFFFFu);
+        for (uint32_t it : items) at[slot(it)] = it;
+        by_slot.reserve(items.size());
+        for (uint64_t sl = 0; sl < n_slots; ++sl) if (at[sl] != 0xFFFFFFFFu) by_slot.push_back(at[sl]);
+    }
     int64_t lo = INT64_MAX, hi = INT64_MIN;
     for (uint32_t it : by_slot) { lo = std::min<int64_t>(lo, key(it)); hi = std::max<int64_t>(hi, key(it)); }
+    if ((uint64_t)(hi - lo) > 64 * (uint64_t)by_slot.size() + (1u << 16)) {   // keys far sparser than items: a comparison sort on the key alone (stable: slot order is kept)
+        std::stable_sort(by_slot.begin(), by_slot.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+        items.swap(by_slot);
+        return;
+    }
     std::vector<uint32_t> start((size_t)(hi - lo) + 2, 0);
     for (uint32_t it : by_slot) ++start[(size_t)(key(it) - lo) + 1];
     for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
@@ -247,8 +256,28 @@ void cl_chain_result_free(cl_chain_result* r) {
 // the whole batch is one all-pairs sweep over the concatenated match pairs.
 namespace {
 
+// what the DP needs of its graph 1 alone — topological positions and depths (longest path from a source) — so that the two whole-graph DPs of one cl_anchor_chain
+// (the gap-free one of the scale estimate, the affine one) share one walk over the graph
+struct GraphOrder {
+    std::vector<uint32_t> pos, depth;
+    void build(const cl_base_graph& g) {
+        std::vector<uint32_t> order;
+        clhost::topological_order(g, order);
+        pos.resize(g.n_nodes);
+        for (uint32_t i = 0; i < order.size(); ++i) pos[order[i]] = i;
+        // depth = longest path from a source: a predecessor m of m' ends strictly before m' starts, so
+        // depth(b1(m')) >= depth(b1(m)) + len(m); pairs whose start depths fall into one window of min_len consecutive
+        // depths can never precede one another and are finalised together on the device ("group")
+        depth.assign(g.n_nodes, 0);
+        for (uint32_t v : order)
+            for (uint64_t e = g.next_off[v]; e < g.next_off[v + 1]; ++e)
+                depth[g.next_idx[e]] = std::max(depth[g.next_idx[e]], depth[v] + 1);
+    }
+};
+
 struct ChainSub {
     const cl_base_graph* g[2] = {nullptr, nullptr};   // DP orientation: g[0] plays graph1
+    const GraphOrder* order1 = nullptr;                // of g[0], prebuilt (built here if null)
     bool tableau = true;                               // graphs carry sentinels: PathMerge gets the pseudo-path (path_merge.hpp:148-160)
     bool chain_merge = false;                          // tables built here are ChainMerge tables (the CLI's -g 1: anchorer.hpp:659-660 with XMerge = ChainMerge)
     const cl_match_sets* ms = nullptr;                 // the sets; DP set s = ms set order[s] (identity if null), and with
@@ -279,7 +308,8 @@ struct SubCtx {
     PostSwitchTable own_sw[2];
     const clhost::PathMergeTable* x[2] = {nullptr, nullptr};
     const PostSwitchTable* sw[2] = {nullptr, nullptr};
-    std::vector<uint32_t> pos1, depth1;
+    GraphOrder own_order;
+    const uint32_t *pos1 = nullptr, *depth1 = nullptr;
     std::vector<char> has_start, after_end;
     std::vector<std::pair<uint32_t, uint32_t>> walk_marks;   // (first, last node) of every graph-1 walk when some pairs are masked
     uint32_t pair_lo = 0, pair_hi = 0;
@@ -441,17 +471,10 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             c.off_b = (uint32_t)run_b;
             run_a += sb.g[0]->n_nodes + 2;
             const cl_base_graph& g1 = *sb.g[0];
-            std::vector<uint32_t> order1;
-            clhost::topological_order(g1, order1);
-            c.pos1.resize(g1.n_nodes);
-            for (uint32_t i = 0; i < order1.size(); ++i) c.pos1[order1[i]] = i;
-            // depth = longest path from a source: a predecessor m of m' ends strictly before m' starts, so
-            // depth(b1(m')) >= depth(b1(m)) + len(m); pairs whose start depths fall into one window of min_len consecutive
-            // depths can never precede one another and are finalised together on the device ("group")
-            c.depth1.assign(g1.n_nodes, 0);
-            for (uint32_t v : order1)
-                for (uint64_t e = g1.next_off[v]; e < g1.next_off[v + 1]; ++e)
-                    c.depth1[g1.next_idx[e]] = std::max(c.depth1[g1.next_idx[e]], c.depth1[v] + 1);
+            const GraphOrder* go = sb.order1;
+            if (!go) { c.own_order.build(g1); go = &c.own_order; }
+            c.pos1 = go->pos.data();
+            c.depth1 = go->depth.data();
             c.has_start.assign(g1.n_nodes, 0);
             c.after_end.assign(g1.n_nodes, 0);
             for (uint32_t s = c.pair_lo; s < c.pair_hi; ++s) { c.has_start[pairs[s].b1] = 1; c.after_end[pairs[s].e1] = 1; }
@@ -1114,9 +1137,24 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     if (use_far) {
         uint32_t max_n = 0;
         int64_t smin = INT64_MAX, smax = INT64_MIN;
-        for (const Combo& c : combos) {
-            max_n = std::max<uint32_t>(max_n, (uint32_t)c.rec_s.size());
-            for (int32_t sg : c.sigma) { smin = std::min<int64_t>(smin, sg); smax = std::max<int64_t>(smax, sg); }
+        uint32_t max_off = 0;
+        {   // extremes of the shifts and offsets: one pass over every record (27 M at the root of ten sequences), combination by combination on the pool's threads
+            std::vector<int64_t> lo(combos.size(), INT64_MAX), hi(combos.size(), INT64_MIN);
+            std::vector<uint32_t> mo(combos.size(), 0);
+            cl_parallel_for(combos.size(), [&](uint64_t b, uint64_t e) {
+                for (uint64_t ci = b; ci < e; ++ci) {
+                    const Combo& c = combos[ci];
+                    int32_t l = INT32_MAX, h = INT32_MIN;
+                    uint32_t m = 0;
+                    const size_t n = c.rec_s.size();
+                    for (size_t r = 0; r < n; ++r) { const int32_t sg = c.sigma[r]; l = std::min(l, sg); h = std::max(h, sg); m = std::max(m, c.off[r]); }
+                    if (n) { lo[ci] = l; hi[ci] = h; mo[ci] = m; }
+                }
+            }, 1);
+            for (size_t ci = 0; ci < combos.size(); ++ci) {
+                max_n = std::max<uint32_t>(max_n, (uint32_t)combos[ci].rec_s.size());
+                smin = std::min(smin, lo[ci]); smax = std::max(smax, hi[ci]); max_off = std::max(max_off, mo[ci]);
+            }
         }
         uint32_t n_levels = 1;
         while (n_levels < (uint32_t)kFarMaxLevels && (64ull << (kFarFanShift * n_levels)) <= max_n) ++n_levels;
@@ -1133,8 +1171,6 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         // bucket key: bucket << off_bits | offset, off_bits enough for the largest offset + 1 (what a query's offset bound can be)
         static const int band_env = [] { const char* e = getenv("CL_CHAIN_FAR_BAND"); int v = e ? atoi(e) : 0; return v >= 4 && v <= 24 ? v : kFarBandShift; }();
         uint32_t band_shift = (uint32_t)band_env;
-        uint32_t max_off = 0;
-        for (const Combo& c : combos) for (uint32_t o : c.off) max_off = std::max(max_off, o);
         uint32_t off_bits = 1;
         while (off_bits < 31 && ((uint64_t)max_off + 1) >> off_bits) ++off_bits;
         // buckets are numbered from 1; bucket + 2 must stay below 2^(32 - off_bits) - 1 (the query's upper neighbour bucket, and the padding key above all)
@@ -1287,9 +1323,43 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // what the traceback's tie resolution needs of every combination — its records in (shift, slot) order with the implicit-heap layout of the
     // reference's outer tree — depends on the records alone, not on the DP: built on the pool's threads while the device runs the DP (at the
     // root of a ten-sequence tree the traceback spent 70 of its 166 ms building them on first use)
+    std::unordered_map<uint64_t, GapFreeTree> sparse_trees;   // sparse mode: (chain2 tag, instance) -> tree
+    auto finish_tree = [&](GapFreeTree* tree, bool by_slot) {    // members -> (offset, slot) order + the implicit heap layout
+        {
+            std::vector<uint32_t> idx(tree->mem.size());
+            std::iota(idx.begin(), idx.end(), 0u);
+            const auto& m0 = tree->mem;
+            sort_by_key_then_slot(idx, M, [&](uint32_t i) { return (int64_t)m0[i].off; }, [&](uint32_t i) { return m0[i].slot; }, by_slot);
+            std::vector<GapFreeTree::Member> sorted(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) sorted[i] = m0[idx[i]];
+            tree->mem.swap(sorted);
+        }
+        tree->heap = heap_of_rank(tree->mem.size());
+        tree->rank_of_heap.resize(tree->mem.size());
+        for (size_t r = 0; r < tree->mem.size(); ++r) tree->rank_of_heap[tree->heap[r]] = (uint32_t)r;
+        tree->built = true;
+    };
     std::thread ortho_prebuild;
     struct ThreadJoiner { std::thread& t; ~ThreadJoiner() { if (t.joinable()) t.join(); } } ortho_joiner{ortho_prebuild};
-    if (!sparse && K == 1 && M >= (1u << 16) && combos.size() > 1)
+    if (sparse && K == 1 && M >= (1u << 16)) {
+        // the gap-free DP's trees — one per chain of graph 2, holding every record filed under it, keyed (offset, slot) — depend on the records alone as well: a tie on a
+        // tree of 1.25 M members cost the traceback 19 ms on first use (a leaf merge of 10 x 1 Mbp); built here beside the device's DP
+        std::vector<uint32_t> p2s;
+        for (const Combo& c : combos) if (std::find(p2s.begin(), p2s.end(), c.p2) == p2s.end()) p2s.push_back(c.p2);
+        for (uint32_t p2 : p2s) sparse_trees[((uint64_t)p2 << 32) | 0u];   // (the map is complete before the thread starts: no insertion races with the traceback)
+        ortho_prebuild = std::thread([&, p2s] {
+            cl_parallel_for(p2s.size(), [&](uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e; ++i) {
+                    GapFreeTree* tree = &sparse_trees.find(((uint64_t)p2s[i] << 32) | 0u)->second;
+                    for (Combo& oc : combos)
+                        if (oc.p2 == p2s[i])
+                            for (uint32_t r = 0; r < oc.rec_s.size(); ++r) tree->mem.push_back(GapFreeTree::Member{oc.off[r], by_s[oc.rec_s[r]], r});
+                    finish_tree(tree, false);
+                }
+            }, 1);
+        });
+    }
+    if (!sparse && K == 1 && M >= (1u << 16))
         ortho_prebuild = std::thread([&] {
             cl_parallel_for(combos.size(), [&](uint64_t b, uint64_t e) {
                 for (uint64_t ci = b; ci < e; ++ci) {
@@ -1719,7 +1789,6 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     tm.index_ms += ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
 
-    std::unordered_map<uint64_t, GapFreeTree> sparse_trees;   // sparse mode: (chain2 tag, instance) -> tree
     // records of one instance inside a combination (the reference's trees belong to ONE chaining call)
     auto sub_recs = [&](Combo& c, uint32_t k) -> Combo::SubRecs& {
         if (!c.split_built) {
@@ -1875,19 +1944,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                     }
                     if (!tree->built) {
                         const auto t0 = tnow();
-                        {
-                            std::vector<uint32_t> idx(tree->mem.size());
-                            std::iota(idx.begin(), idx.end(), 0u);
-                            const auto& m0 = tree->mem;
-                            sort_by_key_then_slot(idx, M, [&](uint32_t i) { return (int64_t)m0[i].off; }, [&](uint32_t i) { return m0[i].slot; });
-                            std::vector<GapFreeTree::Member> sorted(idx.size());
-                            for (size_t i = 0; i < idx.size(); ++i) sorted[i] = m0[idx[i]];
-                            tree->mem.swap(sorted);
-                        }
-                        tree->heap = heap_of_rank(tree->mem.size());
-                        tree->rank_of_heap.resize(tree->mem.size());
-                        for (size_t r = 0; r < tree->mem.size(); ++r) tree->rank_of_heap[tree->heap[r]] = (uint32_t)r;
-                        tree->built = true;
+                        finish_tree(tree, !sparse);   // (affine: the members are a run of the (shift, slot) order, i.e. in slot order already)
                         tadd(t_gapfree, t0);
                     }
                     const auto& mem = tree->mem;
@@ -2167,18 +2224,54 @@ uint64_t select_matches(const cl_match_sets& ms, const cl_chain_params& cp, std:
     uint64_t total = 0;
     for (uint64_t s : cur) total += n_pairs(s);
     if (total <= local_max) return n;
-    std::vector<double> wfull(n);   // the sort key, evaluated once per set instead of twice per comparison
-    for (size_t i = 0; i < n; ++i) { const uint64_t s = cur[i]; wfull[i] = anchor_weight(cp, ms.count1[s], ms.count2[s], ms.full_length[s], ms.full_length[s]); }
-    std::vector<size_t> order(n);
-    std::iota(order.begin(), order.end(), (size_t)0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t i, size_t j) { return wfull[i] > wfull[j]; });
+    // the sort key and the weight at the set's own length, evaluated once per set (two pow() each) on the pool's threads: 150 000 - 310 000 sets per merge of 10 x 1 Mbp
+    std::vector<double> wfull(n), wlen(n);
+    std::atomic<bool> plain{true};   // no NaN among the keys (anchor weights of counts >= 1 never are): the radix order below is then the comparison sort's
+    cl_parallel_for(n, [&](uint64_t b, uint64_t e) {
+        bool ok = true;
+        for (uint64_t i = b; i < e; ++i) {
+            const uint64_t s = cur[i];
+            wfull[i] = anchor_weight(cp, ms.count1[s], ms.count2[s], ms.full_length[s], ms.full_length[s]);
+            const uint64_t w0 = ms.set_off1[s];
+            const uint64_t len = ms.walk_off1[w0 + 1] - ms.walk_off1[w0];
+            wlen[i] = anchor_weight(cp, ms.count1[s], ms.count2[s], len, len);
+            ok = ok && wfull[i] == wfull[i];
+        }
+        if (!ok) plain = false;
+    }, 8192);
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (plain && n >= 4096 && n < (1ull << 32)) {
+        // std::stable_sort(order, wfull[i] > wfull[j]) as a stable LSD radix sort on the order-preserving integer image of the doubles (descending; -0.0 == +0.0
+        // as the comparison has it): four passes of 16 bits over the indices instead of n log n comparisons through two indirections
+        std::vector<uint64_t> key(n);
+        for (size_t i = 0; i < n; ++i) {
+            double w = wfull[i];
+            if (w == 0.0) w = 0.0;   // -0.0 -> +0.0
+            uint64_t b;
+            memcpy(&b, &w, 8);
+            b = (b >> 63) ? ~b : b | 0x8000000000000000ull;   // ascending in the double's order ...
+            key[i] = ~b;                                        // ... descending
+        }
+        std::vector<uint32_t> tmp(n);
+        std::vector<uint32_t> cnt(65536 + 1);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int sh = 16 * pass;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (size_t i = 0; i < n; ++i) ++cnt[((key[i] >> sh) & 0xFFFF) + 1];
+            if (cnt[((key[0] >> sh) & 0xFFFF) + 1] == n) continue;   // every key has this digit
+            for (size_t d = 0; d < 65536; ++d) cnt[d + 1] += cnt[d];
+            for (size_t k = 0; k < n; ++k) { const uint32_t i = order[k]; tmp[cnt[(key[i] >> sh) & 0xFFFF]++] = i; }
+            order.swap(tmp);
+        }
+    } else {
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t i, uint32_t j) { return wfull[i] > wfull[j]; });
+    }
     size_t removed = 0;
     uint64_t left = local_max;
     for (size_t i = 0; i < order.size(); ++i) {
         const uint64_t s = cur[order[i]];
-        const uint64_t w0 = ms.set_off1[s];
-        const uint64_t len = ms.walk_off1[w0 + 1] - ms.walk_off1[w0];
-        if (anchor_weight(cp, ms.count1[s], ms.count2[s], len, len) < 0.0) { removed += order.size() - i; break; }
+        if (wlen[order[i]] < 0.0) { removed += order.size() - i; break; }
         const uint64_t pc = n_pairs(s);
         if (left >= pc) { left -= pc; std::swap(order[i - removed], order[i]); }
         else ++removed;
@@ -2300,11 +2393,13 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
     auto t_pre = now();
     PostSwitchTable sw1, sw2;
     PathsOfNode steps1, steps2;
+    GraphOrder order_dp1;   // of the graph that plays graph 1 in the DPs
     const bool small_graphs = (g1->n_nodes + 1) * (g1->n_paths + 1) + (g2->n_nodes + 1) * (g2->n_paths + 1) < (1u << 18);
-    cl_pool_run(small_graphs ? 1 : 4, [&](unsigned t0) {
-      for (unsigned t = t0; t < 4; t += small_graphs ? 1 : 4) {
+    cl_pool_run(small_graphs ? 1 : 5, [&](unsigned t0) {
+      for (unsigned t = t0; t < 5; t += small_graphs ? 1 : 5) {
         if (t == 0) sw1.build(*g1, x1);
         else if (t == 1) sw2.build(*g2, x2);
+        else if (t == 4) order_dp1.build(swap ? *g2 : *g1);
         else if (!ap->do_fill_in_anchoring) continue;
         else if (t == 2) steps1.build(*g1);
         else steps2.build(*g2);
@@ -2529,6 +2624,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         if (mask) subs[0].masked = [mask](uint64_t set, uint32_t i1, uint32_t i2) { return mask->has(set, i1, i2); };
         subs[0].x[0] = swap ? &x2 : &x1; subs[0].x[1] = swap ? &x1 : &x2;
         subs[0].sw[0] = swap ? &sw2 : &sw1; subs[0].sw[1] = swap ? &sw1 : &sw2;
+        subs[0].order1 = &order_dp1;
         std::vector<ChainSubResult> res;
         ChainTimings tm;
         int rc = chain_dp_batch(ctx, subs, &cp, anchor_scale, sparse, res, tm, nullptr);
