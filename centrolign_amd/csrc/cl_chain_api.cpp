@@ -2638,7 +2638,8 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
         const ChainSubResult& r = res[0];
         const size_t na = r.chain.size() / 3;
         anchors.assign(na, HAnchor());
-        for (size_t i = 0; i < na; ++i) {
+        cl_parallel_for(na, [&](uint64_t i_begin, uint64_t i_end) {
+        for (size_t i = i_begin; i < i_end; ++i) {
             HAnchor& h = anchors[i];
             h.match_set = r.chain[3 * i];
             h.idx1 = r.chain[3 * i + 1];
@@ -2659,6 +2660,7 @@ static int anchor_chain_impl(cl_context* ctx, const cl_base_graph* g1, const cl_
                 h.gsa = r.gap_score[i + 1];
             }
         }
+        }, 512);
         lap("anchors", t);
         if (ap->do_fill_in_anchoring) return fill_in(anchors, sparse, anchor_scale);
         return CL_OK;
