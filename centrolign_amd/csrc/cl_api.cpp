@@ -1746,17 +1746,15 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     // workgroup sizes of the systolic kernel: 64 / 128 / 256 / 1024 threads (round 6: pairs of 65-128 rows — two thirds of the subproblems that used to take 256 threads in
     // the step of 10 x 1 Mbp — get two waves instead of four: a barrier between two waves, no idle waves at it).  CL_SYS_BLOCK128=1 for measurements
     static const bool block128 = [] { const char* e = getenv("CL_SYS_BLOCK128"); return e && e[0] == '1'; }();   // (measured and lost: 1.51-1.52 -> 1.61-1.68 ms per step — two more launches on the step's streams; off unless asked for)
-    // ... and, by default, ONE wave with R = 2 / 4 rows per lane for pairs of 65-128 / 129-256 rows (popoa_sysr_kernel: (columns + rows / R) steps, no barrier; LaunchGroup::block 130 /
-    // 260 name the two shapes).  CL_SYS_ROWS_PER_LANE=0: a row per lane on two / four waves (A/B)
-    static const bool rows_per_lane = [] { const char* e = getenv("CL_SYS_ROWS_PER_LANE"); return !e || e[0] != '0'; }();
-    const int sys_blocks[4] = {64, rows_per_lane ? 130 : 128, rows_per_lane ? 260 : 256, 1024};
+    // (one wave with two / four rows per lane — popoa_sysr_kernel, commit 2b07e99 — was measured and lost as well: 3.37 against 1.56 ms per step, profiles/r06_rows_per_lane_ab.txt)
+    const int sys_blocks[4] = {64, 128, 256, 1024};
     for (int bi = 3; bi >= 0; --bi)
         for (int npw = 3; npw >= 1; --npw) {
             std::vector<uint32_t> of_class[5];
             for (uint32_t i = 0; i < pl->desc.size(); ++i) {
                 const ClProbDesc& d = pl->desc[i];
                 const uint32_t rows = std::min(d.n1, d.n2) + 1;
-                const int b = rows <= 64 ? 0 : (rows <= 128 && (block128 || rows_per_lane)) ? 1 : rows <= 256 ? 2 : 3;
+                const int b = rows <= 64 ? 0 : (rows <= 128 && block128) ? 1 : rows <= 256 ? 2 : 3;
                 if (d.kind != CL_KIND_SYS || d.npw != npw || b != bi) continue;
                 int c = 0;
                 while (c < 4 && ring_need[i] > lds_class[c]) ++c;
@@ -1769,7 +1767,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 if (of_class[lc].empty()) continue;
                 const size_t have = plist.size() - grp.first;
                 if (have) {
-                    auto per_cu_at = [&](uint32_t lds) { return std::max<uint64_t>(1, std::min<uint64_t>((160u * 1024u) / std::max<uint32_t>(lds, 1u), 2048u / (uint32_t)(sys_blocks[bi] == 130 || sys_blocks[bi] == 260 ? 64 : sys_blocks[bi]))); };
+                    auto per_cu_at = [&](uint32_t lds) { return std::max<uint64_t>(1, std::min<uint64_t>((160u * 1024u) / std::max<uint32_t>(lds, 1u), 2048u / (uint32_t)sys_blocks[bi])); };
                     uint32_t own = 0;
                     for (uint32_t i : of_class[lc]) own = std::max(own, ring_need[i]);
                     // all resident at once.  (Also merging classes that leave the newcomers' workgroups per compute unit unchanged was measured and lost: 2.75 against
@@ -2194,7 +2192,6 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     else if (g.kind == CL_KIND_LINEAR && g.waves == 5) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_duo_kernel");
     else if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), g.block == 1 ? "popoa_lane_kernel<%d, wide>" : "popoa_lane_kernel<%d>", g.waves);
-    else if (g.kind == CL_KIND_SYS && (g.block == 130 || g.block == 260)) snprintf(out->kernel, sizeof(out->kernel), "popoa_sysr_kernel<%d, %d>", g.npw, g.block == 130 ? 2 : 4);
     else if (g.kind == CL_KIND_SYS) snprintf(out->kernel, sizeof(out->kernel), "popoa_sys_kernel<%d, %d>", g.npw, g.block);
     else if (g.kind == CL_KIND_STRIP) snprintf(out->kernel, sizeof(out->kernel), "popoa_strip_kernel<%d> x %d", g.npw, g.block);
     else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);

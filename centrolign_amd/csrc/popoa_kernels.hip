@@ -966,281 +966,6 @@ __global__ void __launch_bounds__(BLOCK) popoa_sys_kernel(ClDeviceBatch B, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// popoa_sysr_kernel (round 6): the systolic sweep of popoa_sys_kernel for pairs of 65 .. 256 rows on ONE wave: lane l owns the R consecutive rows R l .. R l + R - 1
-// (R = 2 up to 128 rows, 4 up to 256) and at step t works on column t - l of all of them, one after the other — row R l + j reads row R l + j - 1 of the same column
-// a few instructions after the lane wrote it (LDS operations of one wave complete in order) and rows of earlier lanes from earlier steps.  What this buys over a
-// row per lane on 2 / 4 waves: (n2 + rows / R) steps instead of (n2 + rows) — the sweep's ramp, where half the lanes of a square pair idle, shrinks by R —, no
-// workgroup barrier at all (the per-step barrier of the multi-wave kernel and its idle waves are gone), and the column's record is decoded once for R cells.  Inside a
-// timed step the device is bound by VALU issue over ALL its launches (profiles/r05_step_valu_overlap.txt): wave-instructions per cell are what counts there, and this
-// kernel issues 0.55-0.65 of the multi-wave kernel's for the same pair.  Same LDS layout (ring per row, saved columns, column records), the rows' ring bases skewed by
-// lane instead of padded by row (neighbouring lanes' 16-byte accesses then differ by R x row stride - cell + skew: an odd multiple of four words); same planes, same
-// traceback (traceback_wave).  A cell (r, c) lies on anti-diagonal r + c, which is no longer the step number: every row carries its own running plane offset.
-template <int NPW, int R>
-__global__ void __launch_bounds__(64) popoa_sysr_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P) {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    constexpr int CW = NPW == 1 ? 4 : 8;
-    constexpr uint32_t SKEW = CW == 8 ? 4u : 8u;
-    cl_tick_start(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
-    const uint32_t prob = plist[blockIdx.x];
-    const ClProbDesc pd = B.desc[prob];
-    const DiagGeom G(pd.n1, pd.n2);
-    Planes<NPW> pl;
-    pl.base = B.planes + pd.plane_base;
-    pl.cells = (pd.n1 + 1) * (pd.n2 + 1);
-    const uint32_t lane = threadIdx.x;
-    const bool swap = pd.pad & 0x8000u;
-    const uint32_t logH = pd.pad & 31u, H = 1u << logH, hm = H - 1;
-    const uint32_t nR = swap ? pd.n2 : pd.n1, nC = swap ? pd.n1 : pd.n2;
-    const uint32_t K = pd.aux_cnt;
-    const uint32_t baseR = swap ? pd.node_base[1] : pd.node_base[0], baseC = swap ? pd.node_base[0] : pd.node_base[1];
-    const uint32_t* const poffR = (swap ? B.poff[1] : B.poff[0]) + baseR;
-    const uint32_t* const poffC = (swap ? B.poff[0] : B.poff[1]) + baseC;
-    const uint32_t* const pidxR = swap ? B.pidx[1] : B.pidx[0];
-    const uint32_t* const pidxC = swap ? B.pidx[0] : B.pidx[1];
-    const uint8_t* const labRp = (swap ? B.lab[1] : B.lab[0]) + baseR;
-    const uint8_t* const labCp = (swap ? B.lab[0] : B.lab[1]) + baseC;
-    // LDS (int32 units): ring [nR + 1 rows][H x CW] with row r at r x rs + (r / R) x SKEW | saved columns [K][nR + 1][CW] | column records [nC] (uint2) | row predecessor
-    // lists | column predecessor lists | saved column numbers [K]
-    const uint32_t rs = H * CW;
-    auto row_base = [&](uint32_t row) { return row * rs + (row / (uint32_t)R) * SKEW; };
-    int32_t* const ring = lds;
-    int32_t* const saved = ring + (nR + 1) * rs + 64u * SKEW;
-    uint2* const recC = reinterpret_cast<uint2*>(saved + K * (nR + 1) * CW);
-    const uint32_t eR0 = poffR[0], eR1 = poffR[nR], eC0 = poffC[0], eC1 = poffC[nC];
-    uint32_t* const plR = reinterpret_cast<uint32_t*>(recC + nC);
-    uint32_t* const plC = plR + (eR1 - eR0);
-    uint32_t* const saved_col = plC + (eC1 - eC0);
-    for (uint32_t i = lane; i < eR1 - eR0; i += 64) plR[i] = pidxR[eR0 + i];
-    for (uint32_t i = lane; i < eC1 - eC0; i += 64) plC[i] = pidxC[eC0 + i];
-    const uint32_t near_limit = B.aux[pd.aux_base];
-    for (uint32_t i = lane; i < K; i += 64) saved_col[i] = B.aux[pd.aux_base + 1 + i];
-    __syncthreads();
-    // column records exactly as popoa_sys_kernel's
-    auto slot_of = [&](uint32_t col) { uint32_t k = 0; while (k + 1 < K && saved_col[k] != col) ++k; return k; };
-    auto pred_code = [&](uint32_t c, uint32_t q) { return c - q > near_limit ? 0x800u | slot_of(q) : c - q; };
-    for (uint32_t i = lane; i < nC; i += 64) {
-        const uint32_t c = i + 1, b0 = poffC[i] - eC0, deg = poffC[i + 1] - poffC[i], l = labCp[i], src = l >> 7, nq = deg + src;
-        uint32_t x = 0;
-        if (nq >= 1 && nq <= 2) {
-            const uint32_t q0 = deg ? plC[b0] : 0u, q1 = deg == 2 ? plC[b0 + 1] : (src ? 0u : q0);
-            x = pred_code(c, q0) | (pred_code(c, q1) << 12);
-        }
-        bool is_saved = false;
-        for (uint32_t k = 0; k < K; ++k) is_saved |= saved_col[k] == c;
-        if (is_saved) x |= (1u << 26) | (slot_of(c) << 27);
-        recC[i] = make_uint2(x, b0 | (deg << 17) | ((nq >= 1 && nq <= 2) ? 1u << 23 : 0u) | ((l & 0x7Fu) << 24) | (src << 31));
-    }
-    const bool save_col0 = K && saved_col[0] == 0;
-    // this lane's R rows (rows beyond nR idle)
-    uint32_t degR[R], firstR[R], labR[R], r_rb[R], rp0_rb[R], rp1_rb[R], rp0_cw[R], rp1_cw[R], poff_run[R];
-    bool srcR[R], fastR[R], live[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const uint32_t r = lane * R + j;
-        degR[j] = 0; firstR[j] = 0; labR[j] = 0; srcR[j] = false;
-        live[j] = r <= nR;
-        if (r >= 1 && r <= nR) {
-            const uint32_t l = labRp[r - 1];
-            degR[j] = poffR[r] - poffR[r - 1];
-            firstR[j] = poffR[r - 1] - eR0;
-            labR[j] = l & 0x7Fu;
-            srcR[j] = l >> 7;
-        }
-        fastR[j] = r == 0 || (r <= nR && degR[j] + (srcR[j] ? 1u : 0u) <= 2 && degR[j] + (srcR[j] ? 1u : 0u) >= 1);
-        uint32_t rp0 = 0, rp1 = 0;
-        if (r && fastR[j] && degR[j]) {
-            rp0 = plR[firstR[j]];
-            rp1 = degR[j] == 2 ? plR[firstR[j] + 1] : (srcR[j] ? 0u : rp0);
-        }
-        r_rb[j] = row_base(r); rp0_rb[j] = row_base(rp0); rp1_rb[j] = row_base(rp1);
-        rp0_cw[j] = rp0 * CW; rp1_cw[j] = rp1 * CW;
-        poff_run[j] = live[j] ? G.off(r) : 0u;   // cells on the anti-diagonals before r + 0
-    }
-    __syncthreads();
-    const uint32_t last = nC + nR / (uint32_t)R;
-    uint32_t t = 0;
-    auto where = [&](uint32_t row, uint32_t col) -> const int32_t* {
-        if (t - row / (uint32_t)R - col < H) return ring + (row_base(row) + (col & hm) * CW);
-        return saved + (slot_of(col) * (nR + 1) + row) * CW;
-    };
-    auto get_mv = [&](const int32_t* cell, int32_t& m, int32_t (&v)[NPW]) {
-        const int4 x = reinterpret_cast<const int4*>(cell)[0];
-        m = x.x; v[0] = x.y;
-        if (NPW > 1) v[1] = x.z;
-        if (NPW > 2) v[2] = x.w;
-    };
-    auto get_mh = [&](const int32_t* cell, int32_t& m, int32_t (&h)[NPW]) {
-        if (NPW == 1) { const int4 x = reinterpret_cast<const int4*>(cell)[0]; m = x.w; h[0] = x.z; }
-        else {
-            const int4 x = reinterpret_cast<const int4*>(cell)[1];
-            m = x.x; h[0] = x.y;
-            if (NPW > 1) h[1] = x.z;
-            if (NPW > 2) h[2] = x.w;
-        }
-    };
-    auto get_m = [&](uint32_t row, uint32_t col) -> int32_t { return where(row, col)[0]; };
-    const uint32_t saved_off = (uint32_t)(saved - ring), slot_stride = (nR + 1) * CW;
-    int32_t* const plane0 = pl.M();
-    const size_t plane_stride = pl.cells;
-    g_i32* pV[NPW];
-    g_i32* pH[NPW];
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-        pV[k] = uniform_plane(plane0 + (size_t)(swap ? 1 + NPW + k : 1 + k) * plane_stride);
-        pH[k] = uniform_plane(plane0 + (size_t)(swap ? 1 + k : 1 + NPW + k) * plane_stride);
-    }
-    g_i32* const pM = uniform_plane(plane0);
-    for (; t <= last; ++t) {
-        if (t >= lane && t - lane <= nC) {
-            const uint32_t c = t - lane;
-            uint32_t degC = 0, firstC = 0, labC = 0, keep_slot = 0;
-            bool srcC = false, keep = !c && save_col0, fastC = false;
-            uint2 rc = make_uint2(0, 0);
-            uint32_t o0 = 0, o1 = 0;
-            bool f0 = false, f1 = false;
-            const uint32_t oc = (c & hm) * CW;
-            if (c) {
-                rc = recC[c - 1];
-                firstC = rc.y & 0x1FFFFu; degC = (rc.y >> 17) & 63u; fastC = (rc.y >> 23) & 1u; labC = (rc.y >> 24) & 0x7Fu; srcC = rc.y >> 31;
-                keep = (rc.x >> 26) & 1u; keep_slot = rc.x >> 27;
-                const uint32_t e0 = rc.x & 0xFFFu, e1 = (rc.x >> 12) & 0xFFFu;
-                f0 = e0 & 0x800u; f1 = e1 & 0x800u;
-                o0 = f0 ? saved_off + __umul24(e0 & 0x7FFu, slot_stride) : ((c - e0) & hm) * CW;
-                o1 = f1 ? saved_off + __umul24(e1 & 0x7FFu, slot_stride) : ((c - e1) & hm) * CW;
-            }
-            // phase A: what the straight-line cells read from EARLIER columns (own row's two predecessor columns, the four diagonal cells) does not depend on anything
-            // this step writes: all R rows' reads go out together
-            int32_t mh0[R], mh1[R], hh0[R][NPW], hh1[R][NPW], d00[R], d01[R], d10[R], d11[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                mh0[j] = mh1[j] = d00[j] = d01[j] = d10[j] = d11[j] = CL_NEG_INF;
-#pragma unroll
-                for (int k = 0; k < NPW; ++k) { hh0[j][k] = CL_NEG_INF; hh1[j][k] = CL_NEG_INF; }
-                if (live[j] && c && fastC && fastR[j]) {
-                    const uint32_t r_cw = (lane * R + j) * CW;
-                    get_mh(ring + (o0 + (f0 ? r_cw : r_rb[j])), mh0[j], hh0[j]);
-                    get_mh(ring + (o1 + (f1 ? r_cw : r_rb[j])), mh1[j], hh1[j]);
-                    d00[j] = ring[o0 + (f0 ? rp0_cw[j] : rp0_rb[j])]; d01[j] = ring[o1 + (f1 ? rp0_cw[j] : rp0_rb[j])];
-                    d10[j] = ring[o0 + (f0 ? rp1_cw[j] : rp1_rb[j])]; d11[j] = ring[o1 + (f1 ? rp1_cw[j] : rp1_rb[j])];
-                }
-            }
-            // phase B: the R cells of this column, top row first (a row may read the row above it of the same column)
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (!live[j]) continue;
-                const uint32_t r = lane * R + j;
-                int32_t M = CL_NEG_INF, V[NPW], Hh[NPW];
-#pragma unroll
-                for (int k = 0; k < NPW; ++k) { V[k] = CL_NEG_INF; Hh[k] = CL_NEG_INF; }
-                if (c && fastC && fastR[j]) {
-                    int32_t mv0, mv1, vv0[NPW], vv1[NPW];
-                    get_mv(ring + (rp0_rb[j] + oc), mv0, vv0);
-                    get_mv(ring + (rp1_rb[j] + oc), mv1, vv1);
-                    M = imax(imax(d00[j], d01[j]), imax(d10[j], d11[j])) + ((labR[j] == labC) ? P.match : -P.mismatch);
-#pragma unroll
-                    for (int k = 0; k < NPW; ++k) {
-                        V[k] = imax(imax(mv0 - P.oe[k], vv0[k] - P.ext[k]), imax(mv1 - P.oe[k], vv1[k] - P.ext[k]));
-                        Hh[k] = imax(imax(mh0[j] - P.oe[k], hh0[j][k] - P.ext[k]), imax(mh1[j] - P.oe[k], hh1[j][k] - P.ext[k]));
-                    }
-                    if (!r) {
-                        M = CL_NEG_INF;
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) V[k] = CL_NEG_INF;
-                    }
-                } else if (r && !c) {          // boundary column (alignment.hpp:832-845)
-                    for (uint32_t e = 0; e < degR[j]; ++e) {
-                        const uint32_t p = plR[firstR[j] + e];
-                        int32_t m, vv[NPW];
-                        get_mv(where(p, 0), m, vv);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], vv[k] - P.ext[k]);
-                    }
-                    if (srcR[j]) {
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], -P.oe[k]);
-                    }
-                } else if (!r && c) {   // boundary row (:864-877)
-                    for (uint32_t f = 0; f < degC; ++f) {
-                        const uint32_t q = plC[firstC + f];
-                        int32_t m, hh[NPW];
-                        get_mh(where(0, q), m, hh);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], hh[k] - P.ext[k]);
-                    }
-                    if (srcC) {
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], -P.oe[k]);
-                    }
-                } else if (r && c) {    // interior, any degrees (:897-938 in pull form)
-                    for (uint32_t e = 0; e < degR[j]; ++e) {
-                        const uint32_t p = plR[firstR[j] + e];
-                        int32_t m, vv[NPW];
-                        get_mv(where(p, c), m, vv);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], imax(m - P.oe[k], vv[k] - P.ext[k]));
-                    }
-                    if (srcR[j]) {
-                        const int32_t m = get_m(0, c);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) V[k] = imax(V[k], m - P.oe[k]);
-                    }
-                    const int32_t s = (labR[j] == labC) ? P.match : -P.mismatch;
-                    for (uint32_t f = 0; f < degC; ++f) {
-                        const uint32_t q = plC[firstC + f];
-                        int32_t m, hh[NPW];
-                        get_mh(where(r, q), m, hh);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], imax(m - P.oe[k], hh[k] - P.ext[k]));
-                        for (uint32_t e = 0; e < degR[j]; ++e) {
-                            const uint32_t p = plR[firstR[j] + e];
-                            M = imax(M, get_m(p, q) + s);
-                        }
-                        if (srcR[j]) M = imax(M, get_m(0, q) + s);
-                    }
-                    if (srcC) {
-                        const int32_t m = get_m(r, 0);
-#pragma unroll
-                        for (int k = 0; k < NPW; ++k) Hh[k] = imax(Hh[k], m - P.oe[k]);
-                        for (uint32_t e = 0; e < degR[j]; ++e) {
-                            const uint32_t p = plR[firstR[j] + e];
-                            M = imax(M, get_m(p, 0) + s);
-                        }
-                        if (srcR[j]) M = imax(M, s);   // the corner counts as 0 (:814-818)
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NPW; ++k) M = imax(M, imax(V[k], Hh[k]));
-                const int32_t Ml = (r | c) ? M : 0, Mh = r ? M : (c ? CL_NEG_INF : 0);
-                const int4 w0 = NPW == 1 ? make_int4(Ml, V[0], Hh[0], Mh) : make_int4(Ml, V[0], V[NPW > 1 ? 1 : 0], V[NPW > 2 ? 2 : 0]);
-                const int4 w1 = make_int4(Mh, Hh[0], Hh[NPW > 1 ? 1 : 0], Hh[NPW > 2 ? 2 : 0]);
-                int4* w = reinterpret_cast<int4*>(ring + r_rb[j] + oc);
-                w[0] = w0;
-                if (NPW > 1) w[1] = w1;
-                if (keep) {
-                    int4* sw = reinterpret_cast<int4*>(saved + ((c ? keep_slot : 0u) * (nR + 1) + r) * CW);
-                    sw[0] = w0;
-                    if (NPW > 1) sw[1] = w1;
-                }
-                const uint32_t dgl = r + c, lo_d = G.lo(dgl);
-                if (!(B.skip_traceback & 2)) {
-                    const uint32_t pb = (poff_run[j] + ((swap ? c : r) - lo_d)) * 4u;
-                    plane_store(pM, pb, M);
-#pragma unroll
-                    for (int k = 0; k < NPW; ++k) {
-                        plane_store(pV[k], pb, V[k]);
-                        plane_store(pH[k], pb, Hh[k]);
-                    }
-                }
-                poff_run[j] += G.hi(dgl) - lo_d + 1;
-            }
-        }
-    }
-    __syncthreads();   // vmcnt(0): every plane value is in memory
-    if (!B.skip_traceback) traceback_wave<NPW>(B, pd, G, pl, P, prob);
-    cl_tick_end(B, gridDim.x <= 4096u || (blockIdx.x & 63u) == 0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // popoa_strip_kernel: the systolic sweep of popoa_sys_kernel for branching pairs whose rows do NOT fit one workgroup's LDS (round 4; SURVEY §7
 // step 5; the reference's ceiling is 40 M cells per pair, src/parameters.cpp:79).  The rows are cut into STRIPS of S consecutive rows (S a multiple
 // of 64), one workgroup per strip, all strips of a pair in flight at once on different compute units: strip j runs behind strip j - 1 and reads
@@ -1648,8 +1373,6 @@ template <int NPW>
 void launch_sys_npw(int block, uint32_t n_blocks, uint32_t lds_bytes, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P,
                     hipStream_t stream) {
     if (block <= 64) hipLaunchKernelGGL((popoa_sys_kernel<NPW, 64>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P);
-    else if (block == 130) hipLaunchKernelGGL((popoa_sysr_kernel<NPW, 2>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P);   // (130 / 260: R = 2 / 4 rows per lane on one wave)
-    else if (block == 260) hipLaunchKernelGGL((popoa_sysr_kernel<NPW, 4>), dim3(n_blocks), dim3(64), lds_bytes, stream, B, plist, P);
     else if (block <= 128) hipLaunchKernelGGL((popoa_sys_kernel<NPW, 128>), dim3(n_blocks), dim3(128), lds_bytes, stream, B, plist, P);
     else if (block <= 256) hipLaunchKernelGGL((popoa_sys_kernel<NPW, 256>), dim3(n_blocks), dim3(256), lds_bytes, stream, B, plist, P);
     else hipLaunchKernelGGL((popoa_sys_kernel<NPW, 1024>), dim3(n_blocks), dim3(1024), lds_bytes, stream, B, plist, P);
@@ -1715,20 +1438,14 @@ hipError_t cl_launch_popoa_sys(int npw, int block, uint32_t n_blocks, uint32_t l
         const int cap = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sysr_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sysr_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sysr_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sysr_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sysr_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sysr_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&popoa_sys_kernel<3, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     });

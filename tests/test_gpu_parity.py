@@ -630,31 +630,3 @@ def test_strips_and_wide_launches_on_a_busy_device(gpu_ctx):
     assert rounds["chain"] >= 6 and rounds["stitch"] >= 6, rounds
     print("strip passes %d beside %d chaining DPs and %d x 10 stitch passes of 6 000 pairs on other contexts; strip fallbacks: %d" % (passes, rounds["chain"], rounds["stitch"], fallbacks))
 
-
-@pytest.mark.gpu
-def test_rows_per_lane_systolic_kernel(gpu_ctx, monkeypatch):
-    """popoa_sysr_kernel (round 6): DAG pairs of 65-256 rows on ONE wave, two or four consecutive rows per lane — sizes on both sides of every boundary (64 / 65 rows: the
-    one-row kernel; 128 / 129: R = 2 / 4; 256 / 257: the multi-wave kernel), either graph the shorter one, sparse and dense bubbles (every cell on the general path), far
-    forks (saved columns), every NumPW, default and tie-heavy scoring, against the oracle; and the same pairs with CL_SYS_ROWS_PER_LANE=0 (a row per lane) give the same"""
-    monkeypatch.setenv("CL_NO_LANE", "1")      # (near-chain pairs would take popoa_lane_kernel first)
-    sizes = [(64, 300), (65, 300), (66, 67), (300, 65), (100, 100), (127, 500), (128, 128), (128, 2000), (129, 129), (129, 700), (200, 190), (700, 129), (255, 256), (256, 255),
-             (256, 256), (256, 1500), (257, 300), (90, 3000), (3000, 131), (250, 80)]
-    seen = set()
-    for kw in (dict(extra_edge_p=0.02, skip_max=2), dict(extra_edge_p=0.15, skip_max=4), dict(extra_edge_p=0.4, skip_max=6, alphabet=2)):
-        b = synth.sized_dag_batch(sizes, seed=91, **kw)
-        plan = gpu_ctx.plan(b)
-        seen |= {li["kernel"] for li in plan.launches() if li["n_problems"]}
-        plan.destroy()
-        got = gpu_ctx.stitch_batch_align(b)
-        assert got.same_as(po.oracle_stitch_batch(b)) is None, kw
-    assert any(k.startswith("popoa_sysr_kernel") and k.endswith(", 2>") for k in seen) and any(k.startswith("popoa_sysr_kernel") and k.endswith(", 4>") for k in seen), seen
-    tp = H.tie_params()
-    for npw in (1, 2, 3):
-        b = synth.sized_dag_batch(sizes[:17], seed=92 + npw, extra_edge_p=0.1, skip_max=3, n_alt=2)
-        f = np.full(b.n_problems, npw, np.uint8)
-        for params in (capi.default_stitch_params(), tp):
-            got = gpu_ctx.po_poa_batch(b, f, params.alignment_params)
-            assert got.same_as(po.oracle_stitch_batch(b, params, force_num_pw=f)) is None, npw
-    # far forks: saved columns read from the rows' own lanes
-    ff = synth.far_fork_batch([(100, 1200), (128, 900), (200, 1500), (256, 2000), (70, 800)], seed=93, n_far=3, far_min=100, far_max=600)
-    assert gpu_ctx.stitch_batch_align(ff).same_as(po.oracle_stitch_batch(ff)) is None
