@@ -31,9 +31,7 @@
 // Compiled with -ffp-contract=off like chain_kernels.hip: the leaf evaluation must round like the reference's scalar code.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include "cl_radix.h"
 #include <stdint.h>
 
 #include "chain_device.h"
@@ -681,16 +679,12 @@ hipError_t cl_chain_far_init(const ClChainDevice& D, const uint32_t* d_base, uin
     return hipGetLastError();
 }
 
-size_t cl_chain_far_sort_temp_bytes(uint32_t n) {
-    size_t a = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 32u, (hipStream_t)0);
-    return a + 256;
-}
+size_t cl_chain_far_sort_temp_bytes(uint32_t n) { return clradix::sort_temp_bytes<uint32_t>(n) + 256; }
 
-// order_out = idx sorted by key (32-bit keys, bits [0, end_bit))
+// order_out = idx sorted by key (32-bit keys, bits [0, end_bit)); stable
 hipError_t cl_chain_far_sort32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                                uint32_t n, int end_bit, hipStream_t stream) {
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit, stream);
+    return clradix::sort_pairs<uint32_t>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit, stream);
 }
 
 hipError_t cl_chain_far_node_keys(const uint32_t* order, uint32_t n, uint32_t shift, uint32_t* node_key, hipStream_t stream) {

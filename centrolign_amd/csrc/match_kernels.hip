@@ -2,8 +2,8 @@
 // algorithm (include/centrolign/path_esa.hpp:101-123,174-200).  Both of those are sequential pointer chases; here:
 //
 //   * suffix array by PREFIX DOUBLING: suffixes are ranked by their first 8 characters (one 64-bit key per position,
-//     one radix sort), then by (rank[i], rank[i + h]) for h = 8, 16, 32, ... (one key-building kernel, one rocPRIM radix
-//     sort over just the bits a rank pair needs, one flag + scan + scatter to re-rank) until every rank is unique.  The
+//     one radix sort), then by (rank[i], rank[i + h]) for h = 8, 16, 32, ... (one key-building kernel, one radix sort
+//     (cl_radix.h: stable LSD passes over just the bytes a rank pair needs, one flag + scan + scatter to re-rank) until every rank is unique.  The
 //     text ends in a unique smallest character (path_esa.hpp:113-117), so ranks past the end never decide a comparison.
 //   * the rank array of EVERY round is kept (4 bytes x text length x ~log2(longest repeat) — nothing next to 288 GB), which
 //     turns the LCP of two suffixes into a descent over the rounds: equal round-k ranks mean the next 8 * 2^k characters
@@ -12,14 +12,12 @@
 //
 // Everything is HBM-streaming integer work: per round ~ (8 + 4) B x n of key/rank traffic on top of the radix sort's passes.
 #include <hip/hip_runtime.h>
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 
 #include <vector>
 
 #include "cl_internal.hpp"
+#include "cl_radix.h"
 #include "match_device.h"
 
 namespace {
@@ -116,9 +114,7 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
         return rc;
     lap("allocations");
     HIP_TRY(ctx, hipMemcpyAsync(text.p, h_text, n, hipMemcpyHostToDevice, s));
-    size_t sort_bytes = 0, scan_bytes = 0;
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 64u, s));
-    HIP_TRY(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, flag.p, dense.p, (size_t)n, rocprim::plus<uint32_t>(), s));
+    const size_t sort_bytes = clradix::sort_temp_bytes<uint64_t>(n), scan_bytes = clradix::scan_temp_bytes(n);
     if ((rc = temp.alloc(ctx, sort_bytes > scan_bytes ? sort_bytes : scan_bytes))) return rc;
     size_t temp_bytes = temp.n;
 
@@ -135,13 +131,13 @@ int cl_match_suffix_array(cl_context* ctx, const uint8_t* h_text, uint32_t n, ui
     for (uint32_t h = 0;; h = h ? h * 2 : 8) {
         if (h == 0) {
             hipLaunchKernelGGL(first_keys_kernel, grid, block, 0, s, text.p, n, key_in.p, idx_in.p);
-            HIP_TRY(ctx, rocprim::radix_sort_pairs(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 64u, s));
+            HIP_TRY(ctx, clradix::sort_pairs<uint64_t>(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 64u, s));
         } else {
             hipLaunchKernelGGL(pair_keys_kernel, grid, block, 0, s, level.back().p, n, h, bits, key_in.p, idx_in.p);
-            HIP_TRY(ctx, rocprim::radix_sort_pairs(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 2 * bits, s));
+            HIP_TRY(ctx, clradix::sort_pairs<uint64_t>(temp.p, temp_bytes, key_in.p, key_out.p, idx_in.p, idx_out.p, (size_t)n, 0u, 2 * bits, s));
         }
         hipLaunchKernelGGL(head_flags_kernel, grid, block, 0, s, key_out.p, n, flag.p);
-        HIP_TRY(ctx, rocprim::inclusive_scan(temp.p, temp_bytes, flag.p, dense.p, (size_t)n, rocprim::plus<uint32_t>(), s));
+        HIP_TRY(ctx, clradix::inclusive_sum(temp.p, temp_bytes, flag.p, dense.p, (size_t)n, s));
         level.emplace_back();
         if ((rc = level.back().alloc(ctx, n))) return rc;
         hipLaunchKernelGGL(scatter_rank_kernel, grid, block, 0, s, idx_out.p, dense.p, n, level.back().p);
