@@ -43,6 +43,8 @@ hipError_t cl_launch_popoa_general(int npw, int block, uint32_t n_blocks, uint32
 hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
                                   const ClScoreParams& P, hipStream_t stream);
 size_t cl_linear_workspace_bytes(uint32_t nr, uint32_t nc, int npw, int R);
+hipError_t cl_launch_popoa_linear_span(uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, uint32_t* sync, hipStream_t stream);
+uint32_t cl_linear_span_groups(uint32_t nr);
 
 namespace {
 
@@ -1150,7 +1152,11 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
         // (a chain pair of 4 096 rows and more would take the chain kernel's ONE workgroup through four and more passes: the strip kernel puts it on
         // twenty compute units instead — 6 300 x 6 300: 22.4 -> ≈ 12 ms; such a pair always meets the strip kernel's conditions)
-        const bool big_linear = linear && !g_no_strip && !g_force_general && std::min(d.n1, d.n2) >= 4096 && std::min(d.n1, d.n2) <= 40000;
+        // round 6: chain pairs of more than 1 024 rows span SEVERAL workgroups (popoa_linear_span_kernel, popoa_linear.hip: groups of four strips on different compute units, one
+        // round): 2 048 x 2 048 and 6 300 x 6 300 leave the sixteen-wave workgroup's rounds / the DAG strip kernel.  CL_LINEAR_SPAN=0: the routing of rounds 4-5 (A/B)
+        static const bool span_env = [] { const char* e = getenv("CL_LINEAR_SPAN"); return !e || e[0] != '0'; }();
+        const bool span_linear = span_env && linear && !g_force_general && std::min(d.n1, d.n2) > 1024 && std::min(d.n1, d.n2) <= 40000;
+        const bool big_linear = !span_linear && linear && !g_no_strip && !g_force_general && std::min(d.n1, d.n2) >= 4096 && std::min(d.n1, d.n2) <= 40000;
         d.kind = (linear && !g_force_general && !big_linear) ? CL_KIND_LINEAR : CL_KIND_GENERAL;
         d.plane_base = P.plane_cursor;
         uint8_t lr = 0, lw = 0, ls = 0;
@@ -1161,7 +1167,8 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
             // (lw = 2: FOUR pairs per wave, 16 lanes each — popoa_linear_quad_kernel; CL_NO_LINEAR_QUADS=1: one pair per wave as in rounds 1-4)
             static const bool no_quads = [] { const char* e = getenv("CL_NO_LINEAR_QUADS"); return e && *e == '1'; }();
             const bool no_duos = duos_forced() == 0;   // (whether the plan takes the kernel at all is decided when every pair is known: below)
-            if (nshort <= 16 && !no_quads) { lr = 1; lw = 2; }
+            if (span_linear) { lr = 1; lw = 40; }   // (lw = 40: the pair's strips over several workgroups)
+            else if (nshort <= 16 && !no_quads) { lr = 1; lw = 2; }
             else if (nshort <= 32 && !no_duos) { lr = 1; lw = 5; }   // (lw = 5: TWO pairs per wave, 32 lanes each — popoa_linear_duo_kernel; see duos_now)
             else if (nshort <= 64) { lr = 1; lw = 1; }
             else if (nshort <= 128 && nlong < 300) { lr = 2; lw = 1; }
@@ -1711,6 +1718,33 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         }
         close();
     }
+    // chain pairs that span several workgroups (popoa_linear_span_kernel): as the wide pairs above — a pair's groups are consecutive workgroups of one launch, at most 224
+    // workgroups per launch, whole pairs; progress / done words in the same lane_sync array (ClProbDesc::aux_base = the pair's first word, aux_cnt = its groups)
+    {
+        LaunchGroup grp;
+        auto open = [&]() { grp = LaunchGroup(); grp.kind = CL_KIND_LINEAR; grp.npw = 0; grp.waves = 40; grp.first = (uint32_t)plist.size(); grp.prog_first = lane_sync_words; };
+        auto close = [&]() {
+            grp.count = (uint32_t)plist.size() - grp.first;
+            grp.prog_count = lane_sync_words - grp.prog_first;
+            if (grp.count) pl->groups.push_back(grp);
+        };
+        open();
+        std::vector<uint32_t> span;
+        for (uint32_t i = 0; i < pl->desc.size(); ++i) if (pl->desc[i].kind == CL_KIND_LINEAR && pl->lin_waves[i] == 40) span.push_back(i);
+        std::stable_sort(span.begin(), span.end(), [&](uint32_t x, uint32_t y) { return (uint64_t)pl->desc[x].n1 + pl->desc[x].n2 > (uint64_t)pl->desc[y].n1 + pl->desc[y].n2; });
+        for (uint32_t i : span) {
+            ClProbDesc& d = pl->desc[i];
+            const uint32_t ng = cl_linear_span_groups(std::min(d.n1, d.n2));
+            if ((uint32_t)plist.size() - grp.first + ng > 224) { close(); open(); }
+            d.aux_base = lane_sync_words;
+            d.aux_cnt = ng;
+            lane_sync_words += 2 * ng;
+            for (uint32_t g2 = 0; g2 < ng; ++g2) plist.push_back(i);
+            grp.cells += cells_of(i);
+            grp.bytes += cells_of(i) * 4ull * (1 + 2 * d.npw);
+        }
+        close();
+    }
     lap("pack + route");
     const int blocks[3] = {64, 256, 1024};
     for (int bi = 2; bi >= 0; --bi)
@@ -1832,6 +1866,13 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
                 return c / 3;
             }
             uint64_t c = 0;
+            if (g.kind == CL_KIND_LINEAR && g.waves == 40) {   // one round over several workgroups: columns + 1.5 x rows steps
+                for (uint32_t i = g.first; i < g.first + g.count; ++i) {
+                    const ClProbDesc& d = pl->desc[plist[i]];
+                    c = std::max<uint64_t>(c, (uint64_t)std::max(d.n1, d.n2) + 3ull * std::min(d.n1, d.n2) / 2);
+                }
+                return c / 3;
+            }
             for (uint32_t i = g.first; i < g.first + g.count; ++i)
                 if (plist[i] != 0xFFFFFFFFu) c = std::max<uint64_t>(c, (uint64_t)pl->desc[plist[i]].n1 + pl->desc[plist[i]].n2);
             // microseconds per anti-diagonal step, roughly: planes in HBM 4-8, LDS ring 1.6-2.5, systolic DAG 0.45, chain 0.2-0.6
@@ -1872,6 +1913,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
     pl->dev.out_len = pl->d_out_len.p;
     pl->dev.out_score = pl->d_out_score.p;
     pl->dev.out_status = pl->d_out_status.p;
+    { const char* e = getenv("CL_SPAN_DEBUG_FAIL"); pl->dev.debug_span_fail = e && e[0] == '1' ? 1 : 0; }   // test hook: every spanning chain pair reports status 9
     { const char* e = getenv("CL_DEBUG_SKIP_TRACEBACK"); pl->dev.skip_traceback = e ? atoi(e) : 0; }   // measurement hook: 1 no traceback, 3 also no plane stores in the systolic kernel
     pl->sparams.match = (int32_t)ap.match;
     pl->sparams.mismatch = (int32_t)ap.mismatch;
@@ -1893,6 +1935,11 @@ static const int g_plan_streams = [] { const char* e = getenv("CL_STITCH_STREAMS
 // Enqueue every launch group of the plan as a fork/join over the auxiliary streams; `timed` adds per-launch
 // HIP events (used by the profiled path only: event records cost host time and are not capturable everywhere).
 static hipError_t launch_group(const LaunchGroup& g, cl_stitch_plan* pl, const ClDeviceBatch& dev, hipStream_t stream) {
+    if (g.kind == CL_KIND_LINEAR && g.waves == 40) {   // the pairs' progress / done words start every pass at zero
+        hipError_t e = hipMemsetAsync(pl->d_lane_sync.p + g.prog_first, 0, (size_t)g.prog_count * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        return cl_launch_popoa_linear_span(g.count, dev, pl->d_plist.p + g.first, pl->sparams, pl->d_lane_sync.p, stream);
+    }
     if (g.kind == CL_KIND_LINEAR) return cl_launch_popoa_linear(g.waves == 2 ? 0 : g.waves == 5 ? -2 : g.waves, g.count, dev, pl->d_plist.p + g.first, pl->sparams, stream);
     if (g.kind == CL_KIND_STRIP) {
         // the strips' progress words start every pass at zero (the strips of a launch poll one another's)
@@ -2188,7 +2235,8 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     if (!ctx || !pl || !out || index < 0 || index >= (int)pl->groups.size()) return CL_ERR_INVALID_ARGUMENT;
     const LaunchGroup& g = pl->groups[index];
     memset(out, 0, sizeof(*out));
-    if (g.kind == CL_KIND_LINEAR && g.waves == 2) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_quad_kernel");
+    if (g.kind == CL_KIND_LINEAR && g.waves == 40) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_span_kernel");
+    else if (g.kind == CL_KIND_LINEAR && g.waves == 2) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_quad_kernel");
     else if (g.kind == CL_KIND_LINEAR && g.waves == 5) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_duo_kernel");
     else if (g.kind == CL_KIND_LINEAR) snprintf(out->kernel, sizeof(out->kernel), "popoa_linear_kernel<%d>", g.waves);
     else if (g.kind == CL_KIND_LANE) snprintf(out->kernel, sizeof(out->kernel), g.block == 1 ? "popoa_lane_kernel<%d, wide>" : "popoa_lane_kernel<%d>", g.waves);
@@ -2196,7 +2244,7 @@ int cl_stitch_plan_launch_info(cl_context* ctx, const cl_stitch_plan* pl, int in
     else if (g.kind == CL_KIND_STRIP) snprintf(out->kernel, sizeof(out->kernel), "popoa_strip_kernel<%d> x %d", g.npw, g.block);
     else snprintf(out->kernel, sizeof(out->kernel), "%s<%d, %d>", g.ring_bytes ? "popoa_ring_kernel" : "popoa_general_kernel", g.npw, g.block);
     out->n_problems = g.count;
-    if (g.kind == CL_KIND_LANE && g.block == 1) {   // (a wide pair takes a workgroup per group of eight strips: count the pairs)
+    if ((g.kind == CL_KIND_LANE && g.block == 1) || (g.kind == CL_KIND_LINEAR && g.waves == 40)) {   // (a wide / spanning pair takes a workgroup per group of strips: count the pairs)
         out->n_problems = 0;
         for (uint32_t i = g.first; i < g.first + g.count; ++i) out->n_problems += i == g.first || pl->plist_host[i] != pl->plist_host[i - 1];
     }
@@ -2251,6 +2299,25 @@ int cl_stitch_plan_collect(cl_context* ctx, cl_stitch_plan* pl, cl_stitch_result
         for (size_t i = 0; i < npo; ++i)
             if (status[i] == 9 && (pl->desc[i].kind == CL_KIND_STRIP || pl->desc[i].kind == CL_KIND_LANE)) redo[pl->desc[i].npw].push_back((uint32_t)i);
         bool any = false;
+        {   // ... and a chain pair whose groups gave up waiting for one another (popoa_linear_span_kernel) by the one-workgroup chain kernel: same codes, same hand-off rows
+            std::vector<uint32_t> again;
+            for (size_t i = 0; i < npo; ++i)
+                if (status[i] == 9 && pl->desc[i].kind == CL_KIND_LINEAR) again.push_back((uint32_t)i);
+            if (!again.empty()) {
+                any = true;
+                DevBuf<uint32_t> d_again;
+                int rc = d_again.upload(ctx, again);
+                if (rc) return rc;
+                ClDeviceBatch dev = pl->dev;
+                dev.ticks = nullptr;
+                hipError_t e = cl_launch_popoa_linear(16, (uint32_t)again.size(), dev, d_again.p, pl->sparams, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                d_again.release();
+                if (e != hipSuccess) { set_error(ctx, "re-running %zu chain pairs on one workgroup each failed: %s", again.size(), hipGetErrorString(e)); return CL_ERR_HIP; }
+                pl->stats.n_strip_fallbacks += again.size();
+                cl_fallbacks.strip_fallbacks += again.size();
+            }
+        }
         for (int npw = 1; npw <= 3; ++npw) {
             if (redo[npw].empty()) continue;
             any = true;

@@ -54,6 +54,7 @@ struct ClDeviceBatch {
                               // s_memrealtime — the launch's duration by the kernel's own clock, also inside a step where launches overlap (launches of
                               // more than 4 096 workgroups sample every 64th: they are throughput-bound, their ends are within a wave of one another)
     uint32_t  tick_pass;      // the pass's number (1 .. 65 535), the top 16 bits of both tick words: a later pass's clocks replace an earlier pass's without a reset in between
+    int       debug_span_fail; // test hook (CL_SPAN_DEBUG_FAIL=1): every chain pair that spans several workgroups reports failure (status 9), as if a wait had expired
     int       skip_traceback; // measurement hook (CL_DEBUG_SKIP_TRACEBACK=1, scripts/stitch_dag_bench.py): the graph x graph kernels fill only
 };
 

@@ -324,6 +324,210 @@ __device__ __forceinline__ void linear_body(const ClDeviceBatch& B, const ClProb
     if (wave == 0) linear_traceback<NPW, R, SWAP>(B, pd, G, codes, P, prob, lane);
 }
 
+// ---- large chain pairs over SEVERAL workgroups (round 6) -------------------------------------------------------------------------------------------------------
+// A chain pair of thousands of rows on ONE workgroup sweeps its strips in rounds of W (2 048 x 2 048 on sixteen waves: two rounds, 0.43 us per step at sixteen waves a
+// barrier; 6 300 x 6 300 was handed to the DAG strip kernel at 1.0 us per step: 13.3 ms).  Here the strips of a pair are dealt over GROUPS of kSpanW = 4 strips, one
+// workgroup per group, every group in ONE round, all groups of the pair in flight on different compute units: inside a group the strips follow one another through the
+// area behind the codes exactly as in linear_body (kLag chunks apart, one barrier per chunk); the FIRST strip of group g follows the LAST strip of group g - 1 the same way
+// across compute units.  That hand-off row (Mf, V_k per column) is written through to memory (agent-scope relaxed atomic stores) and read past the caches (agent-scope
+// relaxed atomic loads), and a PROGRESS word per group — "chunks my last strip has finished", stored after a vmcnt(0) of the one wave that holds the group's hand-off row —
+// is what the next group's wave 0 polls before a chunk: no fence while the sweep runs (the protocol of popoa_strip_kernel and of the WIDE popoa_lane_kernel).  Codes and
+// hand-off layout are linear_body's, so linear_traceback walks them unchanged and a pair whose groups gave up waiting for one another (status 9; every wait is bounded)
+// is simply run again by popoa_linear_kernel<16> on the same workspace (cl_stitch_plan_collect).  The wavefront's slope stays one row per step: (columns + 1.5 x rows)
+// steps instead of rounds x (columns + 1 024): 6 300 x 6 300 in 15 800 steps of ~0.25 us.
+constexpr uint32_t kSpanW = 4;                 // strips (waves) per group
+constexpr uint32_t kSpanFailed = 0xFFFFFFFFu;
+constexpr uint32_t kSpanPolls = 1u << 20;      // x ~1 us
+constexpr uint32_t kSpanPublish = 2;           // chunks between two progress stores of a group (each costs its last wave a vmcnt(0))
+
+template <int NPW, bool SWAP>
+__device__ __forceinline__ void linear_span_body(const ClDeviceBatch& B, const ClProbDesc& pd, uint32_t prob, const ClScoreParams& P, uint32_t grp, uint32_t* sync) {
+    using code_t = typename CodeT<NPW>::type;
+    constexpr uint32_t C = kChunk, W = kSpanW;
+    LinearGeom G;
+    G.init<1>(SWAP ? pd.n2 : pd.n1, SWAP ? pd.n1 : pd.n2);
+    const uint32_t nr = G.nr, nc = G.nc, steps = G.steps;
+    const uint8_t* labR = B.lab[SWAP ? 1 : 0] + pd.node_base[SWAP ? 1 : 0];
+    const uint8_t* labC = B.lab[SWAP ? 0 : 1] + pd.node_base[SWAP ? 0 : 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    code_t* codes = reinterpret_cast<code_t*>(B.planes + pd.plane_base);
+    const size_t code_bytes = ((size_t)G.S * steps * 64 * sizeof(code_t) + 15) & ~(size_t)15;
+    int32_t* brow = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(codes) + code_bytes);
+    const uint32_t n_groups = pd.aux_cnt;
+    uint32_t* const progress = sync + pd.aux_base;
+    uint32_t* const done = progress + n_groups;
+    const uint32_t s = grp * W + wave;                                          // this wave's strip (none if s >= S)
+    const uint32_t strips_here = G.S - grp * W < W ? G.S - grp * W : W;
+    const uint32_t total = kLag * (strips_here - 1) + G.Cn;
+    __shared__ uint32_t gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    __syncthreads();
+    bool dead = false;
+    uint32_t seen = 0;
+
+    int32_t Mleft, Hleft[NPW], labr = 0xfe;
+    int32_t lastM = 0, lastV[NPW], prevUpM = 0, c2 = 0xff;
+    int32_t bM = 0, bV[NPW], myc2 = 0xff;
+    Mleft = 0;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) { lastV[k] = CL_NEG_INF; bV[k] = CL_NEG_INF; Hleft[k] = CL_NEG_INF; }
+
+    for (uint32_t m = 0; m < total; ++m) {
+        const int32_t mm = (int32_t)m - (int32_t)(kLag * wave);
+        if (mm >= 0 && s < G.S && (uint32_t)mm < G.Cn && !dead) {
+            const uint32_t c = (uint32_t)mm;
+            const uint32_t row0 = s * 64 + lane;   // 0-based row of this lane; row index = row0 + 1
+            if (c == 0) {
+                const uint32_t a = row0 + 1;
+                Mleft = boundary_m<NPW>(P, a);
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) Hleft[k] = CL_NEG_INF;
+                labr = a <= nr ? (int32_t)(labR[a - 1] & 0x7f) : 0xfe;
+                lastM = Mleft;
+                prevUpM = row0 == 0 ? 0 : boundary_m<NPW>(P, row0);
+                c2 = 0xff;
+            }
+            const uint32_t t0 = c * C;
+            bool starved = false;
+            const bool across = wave == 0 && grp > 0;   // the row above this strip belongs to another workgroup
+            if (across) {
+                // chunk c needs the upper group's last strip to have finished chunk c + kLag - 1 (see kLag); the first chunk waits for two more, so that the word read
+                // is usually ahead of the need afterwards and one read serves several chunks
+                const uint32_t want = c == 0 ? c + kLag + kSpanPublish : c + kLag;
+                const uint32_t need = want < G.Cn ? want : G.Cn;
+                uint32_t polls = 0;
+                while (seen < need && seen != kSpanFailed) {
+                    seen = __hip_atomic_load(progress + (grp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen >= need || ++polls > kSpanPolls) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                starved = seen == kSpanFailed || seen < need;
+                if (starved && lane == 0) gave_up = 1;
+            }
+            if (!starved) {
+                {   // this chunk's C columns as seen by lane 0: labels and the row above the strip
+                    const uint32_t colb = t0 + lane + 1;
+                    const bool v = lane < C && colb <= nc;
+                    myc2 = v ? (int32_t)(labC[colb - 1] & 0x7f) : 0xff;
+                    if (s == 0) {
+                        bM = v ? boundary_m<NPW>(P, colb) : CL_NEG_INF;
+                    } else {
+                        const int32_t* src = brow + (size_t)(s - 1) * (1 + NPW) * steps + (colb - 1);
+                        if (across) {
+                            bM = v ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : CL_NEG_INF;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) bV[k] = v ? __hip_atomic_load(src + (size_t)(1 + k) * steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : CL_NEG_INF;
+                        } else {
+                            bM = v ? src[0] : CL_NEG_INF;
+#pragma unroll
+                            for (int k = 0; k < NPW; ++k) bV[k] = v ? src[(size_t)(1 + k) * steps] : CL_NEG_INF;
+                        }
+                    }
+                }
+                code_t* cw = codes + ((size_t)s * steps + t0) * 64 + lane;
+                int32_t* bout = brow + (size_t)s * (1 + NPW) * steps;
+                const bool hand_off_lane = s + 1 < G.S && lane == 63;
+                const bool hand_across = wave + 1 == W;   // (the next strip, if any, is another workgroup's first)
+#pragma unroll 2
+                for (uint32_t jj = 0; jj < C; ++jj) {
+                    const uint32_t t = t0 + jj;
+                    const int32_t upM = shift_in(lastM, bM);
+                    bM = rotate_down(bM);
+                    int32_t upV[NPW];
+#pragma unroll
+                    for (int k = 0; k < NPW; ++k) { upV[k] = shift_in(lastV[k], bV[k]); bV[k] = rotate_down(bV[k]); }
+                    c2 = shift_in(c2, myc2);
+                    myc2 = rotate_down(myc2);
+                    const uint32_t b = t - lane + 1;
+                    if ((uint32_t)(b - 1) < nc && row0 < nr) {
+                        const int32_t sc = labr == c2 ? P.match : -P.mismatch;
+                        int32_t Mf = prevUpM + sc;
+                        int32_t V[NPW], H[NPW];
+                        uint32_t code = 0;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) {
+                            const int32_t vo = upM - P.oe[k], ho = Mleft - P.oe[k];
+                            V[k] = imax(vo, upV[k] - P.ext[k]);
+                            H[k] = imax(ho, Hleft[k] - P.ext[k]);
+                            code |= (V[k] == vo ? 1u : 0u) << (3 + k);
+                            code |= (H[k] == ho ? 1u : 0u) << (3 + NPW + k);
+                            Mf = imax(Mf, imax(V[k], H[k]));
+                        }
+                        uint32_t cc = 0;
+#pragma unroll
+                        for (int k = NPW - 1; k >= 0; --k) {
+                            if (SWAP) { cc = Mf == V[k] ? 2u * k + 2u : cc; cc = Mf == H[k] ? 2u * k + 1u : cc; }
+                            else { cc = Mf == H[k] ? 2u * k + 2u : cc; cc = Mf == V[k] ? 2u * k + 1u : cc; }
+                        }
+                        code |= cc;
+                        Mleft = Mf;
+                        lastM = Mf;
+#pragma unroll
+                        for (int k = 0; k < NPW; ++k) { Hleft[k] = H[k]; lastV[k] = V[k]; }
+                        cw[(size_t)jj * 64] = (code_t)code;
+                        if (hand_off_lane) {
+                            if (hand_across) {
+                                __hip_atomic_store(bout + (b - 1), Mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                for (int k = 0; k < NPW; ++k) __hip_atomic_store(bout + (size_t)(1 + k) * steps + (b - 1), V[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                bout[b - 1] = Mf;
+#pragma unroll
+                                for (int k = 0; k < NPW; ++k) bout[(size_t)(1 + k) * steps + (b - 1)] = V[k];
+                            }
+                        }
+                    }
+                    prevUpM = upM;
+                }
+                if (s + 1 == G.S && c + 1 == G.Cn && row0 + 1 == nr) B.out_score[prob] = Mleft;
+            }
+        }
+        if (grp + 1 < n_groups && wave + 1 == strips_here && mm >= 0 && (uint32_t)mm < G.Cn && !dead && (((uint32_t)mm + 1) % kSpanPublish == 0 || (uint32_t)mm + 1 == G.Cn)) {
+            // the group's last strip has finished chunk mm: its hand-off row becomes visible to the other compute units, then the count
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(progress + grp, (uint32_t)mm + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (grp > 0 && !dead && gave_up) {
+            dead = true;
+            if (threadIdx.x == 0) __hip_atomic_store(progress + grp, kSpanFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // every wave's codes out to the other compute units, then this group's mark; the last group collects the marks and walks back
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done + grp, dead ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (grp + 1 != n_groups || threadIdx.x >= 64) return;
+    bool ok = !dead;
+    for (uint32_t g2 = 0; g2 + 1 < n_groups && ok; ++g2) {
+        uint32_t v = 0, polls = 0;
+        while ((v = __hip_atomic_load(done + g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++polls <= kSpanPolls) __builtin_amdgcn_s_sleep(8);
+        ok = v == 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!ok || B.debug_span_fail) {
+        if (lane == 0) { B.out_len[prob] = 0; B.out_status[prob] = 9; }
+        return;
+    }
+    linear_traceback<NPW, 1, SWAP>(B, pd, G, codes, P, prob, lane);
+}
+
+// a pair's groups are consecutive workgroups of the launch (plist repeats the pair once per group); sync: the plan's progress / done words
+__global__ void __launch_bounds__(64 * kSpanW) popoa_linear_span_kernel(ClDeviceBatch B, const uint32_t* __restrict__ plist, ClScoreParams P, uint32_t* sync) {
+    cl_tick_start(B, true);
+    const uint32_t prob = plist[blockIdx.x];
+    const ClProbDesc pd = B.desc[prob];
+    uint32_t grp = 0;
+    while (grp < blockIdx.x && plist[blockIdx.x - grp - 1] == prob) ++grp;
+    const bool swap = pd.pad & 1u;
+    switch (pd.npw) {
+    case 1: if (swap) linear_span_body<1, true>(B, pd, prob, P, grp, sync); else linear_span_body<1, false>(B, pd, prob, P, grp, sync); break;
+    case 2: if (swap) linear_span_body<2, true>(B, pd, prob, P, grp, sync); else linear_span_body<2, false>(B, pd, prob, P, grp, sync); break;
+    default: if (swap) linear_span_body<3, true>(B, pd, prob, P, grp, sync); else linear_span_body<3, false>(B, pd, prob, P, grp, sync); break;
+    }
+    cl_tick_end(B, true);
+}
+
 // One kernel per workgroup shape (W waves).  The (NumPW, rows per lane, orientation) variant of each subproblem
 // is picked at run time from its descriptor, so a whole stitch pass is three launches that start together
 // instead of a dozen that queue behind each other on the hardware queues.
@@ -495,6 +699,14 @@ size_t cl_linear_workspace_bytes(uint32_t nr, uint32_t nc, int npw, int R) {
     const size_t brow_bytes = S * (size_t)(1 + npw) * steps * sizeof(int32_t);
     return code_bytes + brow_bytes;
 }
+
+// the chain pairs that span several workgroups (popoa_linear_span_kernel): n_blocks = groups over all pairs of the launch, sync = the plan's progress / done words
+hipError_t cl_launch_popoa_linear_span(uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist, const ClScoreParams& P, uint32_t* sync, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(popoa_linear_span_kernel, dim3(n_blocks), dim3(64 * kSpanW), 0, stream, B, plist, P, sync);
+    return hipGetLastError();
+}
+uint32_t cl_linear_span_groups(uint32_t nr) { return ((nr + 63u) / 64u + kSpanW - 1u) / kSpanW; }
 
 hipError_t cl_launch_popoa_linear(int W, uint32_t n_blocks, const ClDeviceBatch& B, const uint32_t* plist,
                                   const ClScoreParams& P, hipStream_t stream) {

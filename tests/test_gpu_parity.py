@@ -630,3 +630,37 @@ def test_strips_and_wide_launches_on_a_busy_device(gpu_ctx):
     assert rounds["chain"] >= 6 and rounds["stitch"] >= 6, rounds
     print("strip passes %d beside %d chaining DPs and %d x 10 stitch passes of 6 000 pairs on other contexts; strip fallbacks: %d" % (passes, rounds["chain"], rounds["stitch"], fallbacks))
 
+
+@pytest.mark.gpu
+def test_large_chain_pairs_span_several_workgroups(gpu_ctx, monkeypatch):
+    """popoa_linear_span_kernel (round 6): chain pairs of more than 1 024 rows, their strips dealt over groups of four on different compute units (hand-off rows written
+    through to memory, a progress word per group) — sizes on both sides of the routing boundary, either graph the shorter one, one / two / many groups, a last group of fewer
+    than four strips, every NumPW, default and tie-heavy scoring, against the oracle; and with CL_SPAN_DEBUG_FAIL=1 every such pair reports a failed wait and is run again
+    by the one-workgroup chain kernel on the same workspace: the same alignments, counted in n_strip_fallbacks"""
+    sizes = [(1024, 1100), (1025, 1100), (1100, 1025), (1280, 1281), (1300, 4000), (4000, 1290), (2048, 2048), (2049, 2300), (3000, 2500), (4096, 4100), (1030, 9000)]
+    b = synth.linear_batch(sizes, seed=71)
+    plan = gpu_ctx.plan(b)
+    names = {li["kernel"]: li["n_problems"] for li in plan.launches() if li["n_problems"]}
+    plan.destroy()
+    assert names.get("popoa_linear_span_kernel") == len(sizes) - 1, names          # (1 024 rows: still one workgroup)
+    want = po.oracle_stitch_batch(b)
+    assert gpu_ctx.stitch_batch_align(b).same_as(want) is None
+    tp = H.tie_params()
+    small = synth.linear_batch([(1025, 1200), (1500, 1100), (2100, 2050), (1300, 3000)], seed=72, divergence=0.3)
+    for npw in (1, 2, 3):
+        f = np.full(small.n_problems, npw, np.uint8)
+        for params in (capi.default_stitch_params(), tp):
+            got = gpu_ctx.po_poa_batch(small, f, params.alignment_params)
+            assert got.same_as(po.oracle_stitch_batch(small, params, force_num_pw=f)) is None, npw
+    # one pair at the size the stress set holds (6 300 x 6 300: 25 groups)
+    big = synth.linear_batch([(6300, 6300)], seed=73)
+    assert gpu_ctx.stitch_batch_align(big).same_as(po.oracle_stitch_batch(big)) is None
+    # every wait "expires": the pairs come back from the one-workgroup kernel
+    monkeypatch.setenv("CL_SPAN_DEBUG_FAIL", "1")
+    plan = gpu_ctx.plan(b)
+    plan.execute()
+    got = plan.collect()
+    st = plan.stats()
+    plan.destroy()
+    assert got.same_as(want) is None and st["n_strip_fallbacks"] == len(sizes) - 1
+

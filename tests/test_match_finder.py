@@ -161,6 +161,24 @@ def test_gpu_suffix_array_and_lcp_match_oracle(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_suffix_array_at_the_radix_sort_boundaries(gpu_ctx):
+    """round 6: the suffix array's sorts and scans are the library's own (csrc/cl_radix.h: tiles of 2 048 keys, waves of 512, rounds of 64 lanes).  Text lengths on both sides of
+    every boundary, alphabets that put keys in every byte value of a digit (labels up to 127) and in a single one (all keys equal in the first rounds), against the oracle"""
+    rng = np.random.default_rng(29)
+    texts = []
+    for n in (2, 3, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6145, 10240, 65536, 65537):
+        for alphabet in (1, 3, 127):
+            texts.append(np.concatenate([rng.integers(1, alphabet + 1, n - 1), [0]]).astype(np.uint8))
+    texts.append(np.concatenate([np.tile(np.array([5, 9, 5, 9, 5, 100], np.uint8), 3000), [0]]).astype(np.uint8))   # short period: every doubling round re-sorts large equal groups
+    for text in texts:
+        sa, lcp, isa, rounds = gpu_ctx.suffix_array_lcp(text)
+        want_sa, want_lcp = po.oracle_suffix_array_lcp(text)
+        assert np.array_equal(sa, want_sa), (len(text), int(text.max()))
+        assert np.array_equal(lcp, want_lcp), (len(text), int(text.max()))
+        assert np.array_equal(isa[sa], np.arange(len(text)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", list(CASES))
 def test_gpu_find_matches_matches_reference_golden(gpu_ctx, name):
     g1, g2, mc = CASES[name]
