@@ -194,8 +194,8 @@ struct Combo {
     uint32_t p1 = 0, p2 = 0;
     ClRawVec<uint32_t> rec_s, ins_t, off;   // (filled completely by the record / query passes)
     ClRawVec<int32_t> sigma;
-    ClRawVec<uint32_t> qt, qoff;
-    ClRawVec<int32_t> q;
+    uint32_t *qt = nullptr, *qoff = nullptr;   // dense queries [M]: slices of ONE block per array for all combinations (chain_dp_batch_impl: dense_qt / dense_qoff / dense_q) —
+    int32_t* q = nullptr;                      // a polishing step runs thousands of small DPs over hundreds of combinations: three heap blocks per combination were most of their "queries" phase
     std::vector<uint32_t> prefix;
     // device
     DevBuf<uint32_t> d_rec_s, d_ins_t, d_off, d_prefix, d_qt, d_qoff, d_own_rec;
@@ -757,6 +757,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     static const bool dense_env = getenv("CL_CHAIN_DENSE_QUERIES") != nullptr;
     const bool factored = K == 1 && !dense_env && (uint64_t)combos.size() * M > 100000;
     ClRawVec<uint32_t> fa_qt, fa_d, fb_qoff, fb_d;   // [tag][M]
+    ClRawVec<uint32_t> dense_qt, dense_qoff;         // [combination][M] (the dense tables: small and batched DPs)
+    ClRawVec<int32_t> dense_q;
     if (factored) {
         fa_qt.resize((size_t)n_tag[0] * M);
         fb_qoff.resize((size_t)n_tag[1] * M);
@@ -783,13 +785,15 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             }
         });
     } else {
-    cl_parallel_for(combos.size(), [&](uint64_t c_begin, uint64_t c_end) {   // 15 MB per combination at 1.25 M pairs, 25 combinations at the root
-        for (uint64_t ci = c_begin; ci < c_end; ++ci) {
-            combos[ci].qt.assign(M, kNone);
-            combos[ci].qoff.assign(M, 0);
-            combos[ci].q.assign(M, 0);
-        }
-    }, 1);
+    dense_qt.resize(combos.size() * (size_t)M);
+    dense_qoff.resize(combos.size() * (size_t)M);
+    dense_q.resize(combos.size() * (size_t)M);
+    for (size_t ci = 0; ci < combos.size(); ++ci) { combos[ci].qt = dense_qt.data() + ci * (size_t)M; combos[ci].qoff = dense_qoff.data() + ci * (size_t)M; combos[ci].q = dense_q.data() + ci * (size_t)M; }
+    cl_parallel_for(combos.size() * (size_t)M, [&](uint64_t b, uint64_t e) {   // 15 MB per combination at 1.25 M pairs, 25 combinations at the root
+        std::fill(dense_qt.data() + b, dense_qt.data() + e, kNone);
+        std::memset(dense_qoff.data() + b, 0, (e - b) * sizeof(uint32_t));
+        std::memset(dense_q.data() + b, 0, (e - b) * sizeof(int32_t));
+    }, 1u << 18);
     cl_parallel_for(M, [&](uint64_t s_begin, uint64_t s_end) {
     for (uint32_t s = (uint32_t)s_begin; s < s_end; ++s) {
         const Pair& p = pairs[by_s[s]];
@@ -921,7 +925,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             const size_t n = c.rec_s.size();
             const PackOff& o = po[ci];
             put(o.rec_s, c.rec_s.data(), n * 4); put(o.ins_t, c.ins_t.data(), n * 4); put(o.off, c.off.data(), n * 4); put(o.sigma, c.sigma.data(), n * 4);
-            put(o.prefix, c.prefix.data(), c.prefix.size() * 4); put(o.qt, c.qt.data(), M * 4); put(o.qoff, c.qoff.data(), M * 4); put(o.q, c.q.data(), M * 4);
+            put(o.prefix, c.prefix.data(), c.prefix.size() * 4); put(o.qt, c.qt, M * 4); put(o.qoff, c.qoff, M * 4); put(o.q, c.q, M * 4);
             if (use_walk) memset(stage.data() + o.own, 0xFF, M * 4);
             int* a = reinterpret_cast<int*>(stage.data() + o.acc);
             for (size_t i = 0; i < (size_t)M * 7; ++i) a[i] = enc(CL_CHAIN_NEG);
@@ -1000,7 +1004,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         // (enqueued only: one wait for all of them below — a merge of small graphs used to spend most of its time in these round trips)
         CH(c.d_rec_s.upload_async(ctx, c.rec_s)); CH(c.d_ins_t.upload_async(ctx, c.ins_t)); CH(c.d_off.upload_async(ctx, c.off));
         CH(c.d_sigma.upload_async(ctx, c.sigma)); CH(c.d_prefix.upload_async(ctx, c.prefix));
-        CH(c.d_qt.upload_async(ctx, c.qt)); CH(c.d_qoff.upload_async(ctx, c.qoff)); CH(c.d_q.upload_async(ctx, c.q));
+        struct Slice { const void* p; size_t n; const void* data() const { return p; } size_t size() const { return n; } bool empty() const { return n == 0; } };
+        CH(c.d_qt.upload_async(ctx, Slice{c.qt, (size_t)M})); CH(c.d_qoff.upload_async(ctx, Slice{c.qoff, (size_t)M})); CH(c.d_q.upload_async(ctx, Slice{c.q, (size_t)M}));
         CH(c.d_val.alloc(ctx, 7 * c.rec_s.size()));
         CH(c.d_acc.alloc(ctx, M * 7));
         if (hipMemsetD32Async((hipDeviceptr_t)c.d_acc.p, enc(CL_CHAIN_NEG), M * 7, ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "hipMemsetD32Async failed"); return CL_ERR_HIP; }
