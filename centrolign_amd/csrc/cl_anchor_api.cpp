@@ -224,6 +224,8 @@ namespace {
 
 bool build_bubbles(const cl_base_graph& g1, const cl_base_graph& g2, Bubbles& b1, Bubbles& b2) {
     bool ok1 = false, ok2 = false;
+    // (small graphs — the thousands of realignments of a polishing step — one after the other on the spot: a pool hand-off costs more than both decompositions)
+    if (g1.n_nodes + g2.n_nodes < (1u << 16)) { ok1 = b1.build(g1); ok2 = b2.build(g2); return ok1 && ok2; }
     cl_pool_run(2, [&](unsigned t) { if (t) ok2 = b2.build(g2); else ok1 = b1.build(g1); });
     return ok1 && ok2;
 }
