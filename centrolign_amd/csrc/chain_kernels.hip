@@ -901,6 +901,115 @@ hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, u
     return hipGetLastError();
 }
 
+// ---- chaining DPs over MORE combinations than the walk kernels take (round 6) ---------------------------------------------------------------------------------
+// Beyond 768 chain combinations (27 + 27 paths) a DP used to fall to chain_intra_kernel: ONE workgroup that, per group of pairs, loops over every combination per pair and
+// re-reads a group's records from HBM once they exceed its LDS — 584 ms for a realignment of 316 match pairs over 2 601 combinations (51 + 51 paths: fourteen such DPs were
+// 8.2 of the 12.7 s a polishing step of the 50 x 8 kbp golden took).  The groups stay the unit of order (pairs of a group cannot precede one another); inside a group
+// everything is parallel over the combinations, three small launches per group:
+//   chain_group_reduce_kernel  dp of the group's pairs: the maximum over the combinations of the candidates their running maxima give (integer atomic maximum on the
+//                              order-preserving encoding, started at the value of a chain that begins at the pair);
+//   chain_group_store_kernel   the values the group's records keep in their trees (anchorer.hpp:2318-2342), one thread per record, and dp itself;
+//   chain_group_push_kernel    the group's records against the queries of every LATER pair (chain_inter_kernel's tile loop; the group's records of a combination are found
+//                              by two binary searches in its sorted record list), merged into the running maxima.
+// Same arithmetic as chain_intra_kernel (apply_candidates, the stored values in double), maxima are order-free: bit-identical dp.
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) chain_group_reduce_kernel(ClChainDevice D, uint32_t s0, uint32_t s1, int* __restrict__ dp_enc) {
+    const uint32_t s = s0 + blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (s >= s1 || c >= D.n_combos) return;
+    const ClChainCombo cc = D.combos[c];
+    if (cc.qt[s] == 0xFFFFFFFFu) return;
+    int a[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) a[k] = cc.acc[(size_t)s * 7 + k];
+    double pen[6];
+    query_penalties(pen, cc.q[s], D.params);
+    const float best = apply_candidates(CL_CHAIN_NEG, a, D.weight[s], pen);
+    if (best != CL_CHAIN_NEG) atomicMax(dp_enc + s, enc(best));
+}
+
+__global__ void __launch_bounds__(256) chain_group_store_kernel(ClChainDevice D, uint32_t s0, uint32_t s1, const int* __restrict__ dp_enc) {
+    const uint32_t r_lo = D.rec_off[s0], r_hi = D.rec_off[s1];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < s1 - s0) D.dp[s0 + i] = dec(dp_enc[s0 + i]);
+    const uint32_t r = r_lo + i;
+    if (r >= r_hi) return;
+    // the pair of record r: the last s in [s0, s1) with rec_off[s] <= r
+    uint32_t lo = s0, hi = s1;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (D.rec_off[mid] <= r) lo = mid; else hi = mid; }
+    const float best = dec(dp_enc[lo]);
+    const uint32_t c = D.rec_combo[r], pos = D.rec_pos[r];
+    const ClChainCombo cc = D.combos[c];
+    const int32_t sg = cc.sigma[pos];
+    float v[7];
+    v[0] = best;
+#pragma unroll
+    for (int pw = 0; pw < 6; ++pw) {
+        const double t = D.params.scale * D.params.gap_extend[pw / 2] * (double)sg;
+        v[1 + pw] = (pw % 2 == 1) ? (float)((double)best + t) : (float)((double)best - t);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) cc.val[(size_t)k * cc.n_recs + pos] = v[k];
+}
+
+// the records of the pairs [s0, s1) of combination blockIdx.z against the queries of the pairs [s1 + 256 blockIdx.y, ...): tile blockIdx.x of 256 records
+__global__ void __launch_bounds__(256) chain_group_push_kernel(ClChainDevice D, uint32_t s0, uint32_t s1, uint32_t n_pairs) {
+    const ClChainCombo cb = D.combos[blockIdx.z];
+    const uint32_t rec_lo = lower_bound_u32(cb.rec_s, cb.n_recs, s0), rec_hi = lower_bound_u32(cb.rec_s, cb.n_recs, s1);
+    const uint32_t tile0 = rec_lo + blockIdx.x * 256;
+    if (tile0 >= rec_hi) return;
+    const uint32_t tile_end = min(tile0 + 256u, rec_hi);
+    const uint32_t s = s1 + blockIdx.y * 256 + threadIdx.x;
+    const bool active = s < n_pairs;
+    uint32_t qt = 0, qoff = 0;
+    int32_t q = 0;
+    if (active && cb.qt[s] != 0xFFFFFFFFu) { qt = cb.qt[s]; qoff = cb.qoff[s]; q = cb.q[s]; }
+    int acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = INT32_MIN;
+    __shared__ __attribute__((aligned(16))) int s_rec[256][12];
+    {
+        const uint32_t r = tile0 + threadIdx.x;
+        if (r < tile_end) {
+            s_rec[threadIdx.x][0] = (int)cb.ins_t[r];
+            s_rec[threadIdx.x][1] = (int)cb.off[r];
+            s_rec[threadIdx.x][2] = D.sparse ? 0 : cb.sigma[r];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) s_rec[threadIdx.x][3 + i] = (D.sparse && i) ? INT32_MIN : enc(cb.val[(size_t)i * cb.n_recs + r]);
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = tile_end - tile0;
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const int4 a = *reinterpret_cast<const int4*>(&s_rec[j][0]);
+        const int4 b = *reinterpret_cast<const int4*>(&s_rec[j][4]);
+        const int4 c = *reinterpret_cast<const int4*>(&s_rec[j][8]);
+        const int v[7] = {a.w, b.x, b.y, b.z, b.w, c.x, c.y};
+        accumulate(acc, qt, qoff, q, (uint32_t)a.x, (uint32_t)a.y, a.z, v);
+    }
+    if (qoff != 0) {
+        int* dst = cb.acc + (size_t)s * 7;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            if (acc[i] > enc(CL_CHAIN_NEG)) atomicMax(dst + i, acc[i]);
+    }
+}
+
+// one group of pairs [s0, s1): reduce -> store -> push.  n_group_recs: records of the group's pairs over all combinations (the store grid); a combination holds at most one
+// record per pair, so s1 - s0 bounds what it holds of the group (the push grid)
+hipError_t cl_chain_launch_group(const ClChainDevice& D, uint32_t s0, uint32_t s1, uint32_t n_group_recs, int* dp_enc, hipStream_t stream) {
+    hipLaunchKernelGGL(chain_group_reduce_kernel, dim3(s1 - s0, (D.n_combos + 255) / 256), dim3(256), 0, stream, D, s0, s1, dp_enc);
+    const uint32_t n_store = n_group_recs > s1 - s0 ? n_group_recs : s1 - s0;
+    hipLaunchKernelGGL(chain_group_store_kernel, dim3((n_store + 255) / 256), dim3(256), 0, stream, D, s0, s1, dp_enc);
+    if (s1 < D.n_pairs && n_group_recs)
+        hipLaunchKernelGGL(chain_group_push_kernel, dim3((s1 - s0 + 255) / 256, (D.n_pairs - s1 + 255) / 256, D.n_combos), dim3(256), 0, stream, D, s0, s1, D.n_pairs);
+    return hipGetLastError();
+}
+
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream) {
     static const bool no_sparse_intra = getenv("CL_CHAIN_NO_SPARSE_INTRA") != nullptr;   // A/B switch for measurements
     if (D.sparse && D.n_combos == 1 && !no_sparse_intra) hipLaunchKernelGGL(chain_intra_sparse_kernel, dim3(1), dim3(kChainBlock), 0, stream, D, block_first, block_count, near_blocks);

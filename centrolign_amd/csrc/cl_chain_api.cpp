@@ -39,6 +39,7 @@
 hipError_t cl_chain_launch_inter(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t src_block_lo,
                                  uint32_t src_block_hi, uint32_t max_recs, uint32_t tile_recs, hipStream_t stream);
 hipError_t cl_chain_launch_intra(const ClChainDevice& D, uint32_t block_first, uint32_t block_count, uint32_t near_blocks, hipStream_t stream);
+hipError_t cl_chain_launch_group(const ClChainDevice& D, uint32_t s0, uint32_t s1, uint32_t n_group_recs, int* dp_enc, hipStream_t stream);   // chain_kernels.hip: many combinations
 hipError_t cl_chain_launch_walk(const ClChainDevice& D, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done);
 hipError_t cl_chain_launch_walk_fold(const ClChainDevice& D, uint32_t fold, uint32_t first, uint32_t count, hipStream_t stream, hipEvent_t done);
 hipError_t cl_chain_launch_walk2(const ClChainDevice& D, uint32_t first, uint32_t count, uint32_t qpt, uint32_t n_help, hipStream_t stream, hipEvent_t done);   // chain_walk2.hip
@@ -841,6 +842,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<float> d_weight, d_init, d_dp;
     DevBuf<uint32_t> d_rec_off, d_rec_combo, d_rec_pos, d_group, d_grp_base, d_grp_total, d_group_end, d_status;
     DevBuf<unsigned long long> d_xch, d_xdp, d_hacc;
+    DevBuf<int> d_dp_enc;             // DPs over more combinations than the walk kernels take: the running dp maxima of the per-group path, order-preserving encoding
     DevBuf<char> d_pack;              // a small DP's arrays in one block (below)
     size_t pack_dp_off = 0, pack_acc_stride = 0, pack_down_bytes = 0;
     DevBuf<uint32_t> d_xred;
@@ -856,6 +858,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     DevBuf<uint32_t> d_far_base, d_far_u32[7], d_far_perm[2 * kFarMaxLevels], d_far_arena, d_far_tab, d_seal_items;
     DevBuf<char> d_far_temp;
     ClFarDevice F{};
+    std::vector<uint32_t> group_first;   // first pair of every group + M (the per-group path of DPs over more combinations than the walk kernels take)
     std::vector<uint32_t> seal_off;   // [n_macro + 1] into d_seal_items
     std::vector<uint32_t> seal_big;   // [n_macro] how many of a macro-block's items (its first ones) are nodes of 4 096 records or more
     // the walk kernel (one workgroup per combination, all resident) replaces the per-block intra launches up to
@@ -871,7 +874,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         cl_ctx_quiesce(ctx);   // once, for the ~40 blocks that go back to the pool below
         for (Combo& c : combos) c.release(true);
         d_combos.release(true); d_weight.release(true); d_init.release(true); d_dp.release(true); d_rec_off.release(true); d_rec_combo.release(true); d_rec_pos.release(true); d_group.release(true); d_grp_base.release(true); d_grp_total.release(true);
-        d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xdp.release(true); d_hacc.release(true); d_xred.release(true); d_pack.release(true);
+        d_dp_enc.release(true); d_group_end.release(true); d_status.release(true); d_xch.release(true); d_xdp.release(true); d_hacc.release(true); d_xred.release(true); d_pack.release(true);
         k_in.release(true); k_out.release(true); i_in.release(true); i_out.release(true); vtemp.release(true); d_row.release(true);
         d_blk_rec.release(true); d_blk_q.release(true); d_blk_own.release(true); d_blk_val.release(true); d_blk_acc.release(true); d_ctags.release(true);
         for (auto& b : d_fa) b.release(true);
@@ -1029,6 +1032,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         // beyond the smallest depth(b1) + len of the run.  The device finalises a whole group at once.
         std::vector<uint32_t> group(M);
         std::vector<std::vector<uint32_t>> set_len(K);
+        group_first.clear();
         for (size_t k = 0; k < K; ++k) {
             if (sc[k].pair_hi == sc[k].pair_lo) continue;
             const SetView ms(subs[k]);
@@ -1045,7 +1049,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
             else if (start >= min_end) { ++gid; min_end = end; }
             else min_end = std::min(min_end, end);
             group[s] = gid;
+            if (s == 0 || group[s] != group[s - 1]) group_first.push_back(s);
         }
+        group_first.push_back((uint32_t)M);
         if (timing) {   // groups per block of kChainBlock pairs (each costs the sequential kernel two barriers + one LDS broadcast)
             std::vector<uint32_t> hist;
             for (uint64_t b0 = 0; b0 < M; b0 += kChainBlock) {
@@ -1102,6 +1108,15 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         CH(d_grp_base.upload_async(ctx, grp_base));
         CH(d_grp_total.upload_async(ctx, grp_total));
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); cl_set_error(ctx, "upload failed"); return CL_ERR_HIP; }
+    }
+    // more combinations than the walk kernels take: group by group, parallel over the combinations (chain_kernels.hip: chain_group_*; CL_CHAIN_GROUP_PATH=0: the one-workgroup
+    // per-block kernels of rounds 1-5, A/B)
+    static const bool group_path_env = [] { const char* e = getenv("CL_CHAIN_GROUP_PATH"); return !e || e[0] != '0'; }();
+    const bool group_path = group_path_env && walk_fold > 3 && !old_walk_env;
+    if (group_path) {
+        std::vector<int> dp0(M);
+        for (uint64_t s2 = 0; s2 < M; ++s2) dp0[s2] = enc(init_w[s2]);
+        CH(d_dp_enc.upload(ctx, dp0));
     }
     ClChainDevice D{};
     D.n_pairs = (uint32_t)M;
@@ -1583,6 +1598,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         if (use_far && he == hipSuccess) he = hipStreamSynchronize(seal_stream);
         // (the walk path's events are the context's ring events: nothing to destroy)
         ev_far.assign(ev_far.size(), nullptr);
+    } else if (group_path) {
+        for (size_t gi = 0; gi + 1 < group_first.size() && he == hipSuccess; ++gi)
+            he = cl_chain_launch_group(D, group_first[gi], group_first[gi + 1], rec_off[group_first[gi + 1]] - rec_off[group_first[gi]], d_dp_enc.p, ctx->stream);
     } else {
         uint32_t near_lo = 0;   // first block the current group's far launch did not cover
         for (uint32_t b = 0; b < n_blocks && he == hipSuccess; ++b) {

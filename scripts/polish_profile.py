@@ -45,6 +45,23 @@ def main():
         if m:
             k = m.group(1) + " " + re.sub(r"\d+", "#", m.group(2).strip())[:58]
             acc[k] += float(m.group(3)); cnt[k] += 1
+    # the small DPs by their number of chain combinations: how many there are, and where the waits for the device go
+    buckets = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    cur = None
+    for ln in open(log, errors="replace"):
+        m = re.match(r"\[chain_dp_batch\]\s+(\d+) pairs, (\d+) combinations, (\d+) records", ln)
+        if m:
+            cur = (int(m.group(1)), int(m.group(2)), int(m.group(3)))
+        m = re.match(r"\[chain_dp_batch\]\s+sync\s+([\d.]+) ms", ln)
+        if m and cur:
+            c = cur[1]
+            b = "1" if c == 1 else "2-8" if c <= 8 else "9-64" if c <= 64 else "65-256" if c <= 256 else "257-768" if c <= 768 else "> 768"
+            e = buckets[b]; e[0] += 1; e[1] += float(m.group(1)); e[2] += cur[0]; e[3] += cur[2]
+            cur = None
+    for b in ("1", "2-8", "9-64", "65-256", "257-768", "> 768"):
+        if b in buckets:
+            n_, t_, p_, r_ = buckets[b]
+            print("  DPs of %-8s combinations: %6d, waiting for the device %8.1f ms (%.3f each), %.0f pairs and %.0f records each" % (b, n_, t_, t_ / n_, p_ / n_, r_ / n_))
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:18]:
         print("  %-72s %9.1f ms  x %6d  (%.3f each)" % (k, v, cnt[k], v / cnt[k]))
     os.remove(log)
