@@ -868,7 +868,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // 27 + 27 paths); CL_CHAIN_WALK_FOLD=2/3 folds smaller DPs too (tests)
     static const uint32_t fold_env = [] { const char* e = getenv("CL_CHAIN_WALK_FOLD"); const int v = e ? atoi(e) : 0; return v == 2 || v == 3 ? (uint32_t)v : 0u; }();
     const uint32_t walk_fold = std::max<uint32_t>(combos.size() > 1 ? fold_env : 0u, (uint32_t)((combos.size() + kChainWalkMaxCombos - 1) / kChainWalkMaxCombos));
-    const bool use_walk = allow_walk && walk_fold <= 3 && !old_walk_env;
+    static const bool group_forced_env = [] { const char* e = getenv("CL_CHAIN_GROUP_PATH"); return e && e[0] == 'f'; }();
+    const bool use_walk = allow_walk && walk_fold <= 3 && !old_walk_env && !group_forced_env;
     std::vector<ClChainCombo> hc(combos.size());
     auto cleanup = [&]() {
         cl_ctx_quiesce(ctx);   // once, for the ~40 blocks that go back to the pool below
@@ -1112,7 +1113,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // more combinations than the walk kernels take: group by group, parallel over the combinations (chain_kernels.hip: chain_group_*; CL_CHAIN_GROUP_PATH=0: the one-workgroup
     // per-block kernels of rounds 1-5, A/B)
     static const bool group_path_env = [] { const char* e = getenv("CL_CHAIN_GROUP_PATH"); return !e || e[0] != '0'; }();
-    const bool group_path = group_path_env && walk_fold > 3 && !old_walk_env;
+    static const bool group_path_forced = [] { const char* e = getenv("CL_CHAIN_GROUP_PATH"); return e && e[0] == 'f'; }();   // =force: every DP, whatever its combinations (tests)
+    const bool group_path = group_path_forced || (group_path_env && walk_fold > 3 && !old_walk_env);
     if (group_path) {
         std::vector<int> dp0(M);
         for (uint64_t s2 = 0; s2 < M; ++s2) dp0[s2] = enc(init_w[s2]);

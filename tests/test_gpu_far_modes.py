@@ -81,7 +81,8 @@ def dense_input(gpu_ctx, tmp_path_factory):
 def run_variant(path, kind, env_extra):
     env = dict(os.environ, CL_CHAIN_TIMING="1", **env_extra)
     for k in ("CL_CHAIN_FAR_MODE", "CL_CHAIN_NO_FAR_PRUNE", "CL_CHAIN_OLD_WALK", "CL_CHAIN_WALK_REDUCE", "CL_CHAIN_FAR_LANES", "CL_CHAIN_WALK2", "CL_CHAIN_WALK2_QPT",
-              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS", "CL_CHAIN_LAZY_ACC", "CL_CHAIN_WALK_FOLD", "CL_CHAIN_DENSE_QUERIES", "CL_CHAIN_FAR_WAIT_LATE"):
+              "CL_CHAIN_WALK2_HELPERS", "CL_CHAIN_SEAL_WAVE", "CL_CHAIN_NEAR_SPLIT", "CL_CHAIN_EXT_EVENTS", "CL_CHAIN_LAZY_ACC", "CL_CHAIN_WALK_FOLD", "CL_CHAIN_DENSE_QUERIES", "CL_CHAIN_FAR_WAIT_LATE",
+              "CL_CHAIN_GROUP_PATH"):
         if k not in env_extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "far_ab_child.py"), path, kind], env=env, capture_output=True, text=True, timeout=900)
@@ -105,3 +106,28 @@ def test_every_far_mode_gives_the_same_dp_values_and_chain(dense_input, kind):
     assert int(want[0]) > 300000 and int(want[1]) > 10
     for name, got in results.items():
         assert got == want, "%s differs from the per-block all-pairs path: %s vs %s" % (name, got, want)
+
+
+@pytest.mark.parametrize("kind", ["affine", "sparse"])
+def test_the_group_by_group_path_of_wide_merges_gives_the_same_dp_values(gpu_ctx, tmp_path, kind):
+    """round 6: chaining DPs over more than 768 combinations run group by group, parallel over the combinations (chain_group_reduce / _store / _push kernels; the -c
+    goldens of 50 sequences hold fourteen such DPs and are compared as whole GFAs in tests/test_cyclize_flow.py).  Here the path is FORCED (CL_CHAIN_GROUP_PATH=force) on a
+    multi-combination DP small enough for an all-pairs sweep — the root merge of a 4 x 30 kbp MSA, 2 + 2 paths, ~40 k match pairs — and every DP value and the chain are
+    those of the default path (walk kernels + far pass) and of the round-1 per-block kernels"""
+    seqs = synth.hor_sequences(13, 30000, 4)
+    leaves = [capi.leaf_graph(s) for s in seqs]
+    scale = sum(gpu_ctx.leaf_intrinsic_scale(g) for g in leaves) / 4
+    left = gpu_ctx.merge(leaves[0], leaves[1], score_scale=scale)["fused"]
+    right = gpu_ctx.merge(leaves[2], leaves[3], score_scale=scale)["fused"]
+    from bench import relabelled
+    g1, g2 = relabelled(left, 5, 6), relabelled(right, 7, 8)
+    ms = po.budget_subset(gpu_ctx.find_matches(g1, g2), 40000, seed=6)
+    assert ms.n_pairs() > 20000
+    path = str(tmp_path / "group.npz")
+    far_ab_child.save_input(path, g1, g2, ms, 0.7)
+    want, _ = run_variant(path, kind, {})
+    forced, _ = run_variant(path, kind, {"CL_CHAIN_GROUP_PATH": "force"})
+    per_block, _ = run_variant(path, kind, {"CL_CHAIN_NO_FAR_PRUNE": "1", "CL_CHAIN_OLD_WALK": "1", "CL_CHAIN_GROUP_PATH": "0"})
+    assert int(want[0]) > 20000 and int(want[1]) > 5
+    assert forced == want and per_block == want
+
