@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <unistd.h>
 #include <functional>
 #include <cmath>
@@ -346,6 +348,33 @@ struct SetView {
 }  // namespace
 
 constexpr int kWalkStalled = -1000;   // internal: the walk kernel's workgroups were not all resident (chain_dp_batch retries without it)
+
+// The walk's workgroups take a compute unit each (1 024 threads, up to 120 KB of LDS) and wait for one another: the DPs of several contexts of ONE process that are in
+// flight together must fit the device together, or a walk gives up its bounded wait and the whole DP is repeated on the per-block kernels — 184 s instead of 11 s for a
+// 156-combination merge of 50 x 1 Mbp beside three other workers (round 6, profiles/r06_configs4.json).  So a DP books the compute units its walk launches need before it
+// enqueues them and gives them back when the device is done with it; a DP that does not fit beside the ones in flight waits for them (two 156-combination walks never
+// fitted 256 units: they took turns by stalling).  Per device; the stall fallback stays for what is left (other processes on the device).
+namespace {
+struct WalkUnits {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t in_use[16] = {};
+    static constexpr uint32_t kBudget = 232;   // of 256: the far / near / seal launches of the same DPs need room as well
+    void take(int device, uint32_t need) {
+        need = std::min(need, kBudget);
+        std::unique_lock<std::mutex> lock(m);
+        uint32_t& u = in_use[device & 15];
+        cv.wait(lock, [&] { return u == 0 || u + need <= kBudget; });
+        u += need;
+    }
+    void give(int device, uint32_t need) {
+        need = std::min(need, kBudget);
+        { std::lock_guard<std::mutex> lock(m); in_use[device & 15] -= need; }
+        cv.notify_all();
+    }
+};
+WalkUnits g_walk_units;
+}  // namespace
 
 static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
                                bool sparse, std::vector<ChainSubResult>& results, ChainTimings& tm, std::vector<float>* dp_out, bool allow_walk);
@@ -1398,6 +1427,11 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                 }
             }, 1);
         });
+    // compute units the walk launches of this DP occupy at a time (see WalkUnits)
+    const uint32_t walk_units = !use_walk ? 0u : use_walk2 ? (uint32_t)(((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help))
+                                                           : (uint32_t)((combos.size() + std::max<uint32_t>(walk_fold, 1u) - 1) / std::max<uint32_t>(walk_fold, 1u));
+    struct UnitsHeld { int device; uint32_t n; bool held; ~UnitsHeld() { if (held) g_walk_units.give(device, n); } } units_held{ctx->device, walk_units, false};
+    if (walk_units && ctx->peers.n <= 1) { g_walk_units.take(ctx->device, walk_units); units_held.held = true; }
     hipError_t he = hipEventRecord(ev0, ctx->stream);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
     for (uint32_t f = 0; f < far_streams && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
@@ -1664,6 +1698,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     }
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
     for (uint32_t f = 0; f < std::max<uint32_t>(far_streams, far_lag) && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
+    if (units_held.held) { g_walk_units.give(ctx->device, walk_units); units_held.held = false; }   // (the device is done with this DP's launches)
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
