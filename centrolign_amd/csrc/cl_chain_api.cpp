@@ -374,6 +374,7 @@ struct WalkUnits {
     }
 };
 WalkUnits g_walk_units;
+thread_local bool g_walk_exclusive = false;   // this thread's DP books the whole budget (the second attempt after a stall)
 }  // namespace
 
 static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& subs, const cl_chain_params* cp, double local_scale,
@@ -390,6 +391,18 @@ static int chain_dp_batch(cl_context* ctx, const std::vector<ChainSub>& subs, co
     if (rc != kWalkStalled) return rc;
     ++cl_fallbacks.walk_stalls;
     if (ctx->peers.n > 1) return CL_ERR_HIP;   // (inside a merge group the other members have gone on with this member's share: no second attempt)
+    // round 6: ONE more attempt on the walk kernels with the device's whole walk budget booked for this DP (no other DP of the process in flight beside it) before the
+    // per-block kernels, which take minutes where the walk takes seconds (a 156-combination DP of 1.19 M pairs: 184 s against 11 s)
+    static const char* debug_stall = getenv("CL_CHAIN_DEBUG_STALL");   // (test hook: "first" = only the shared attempt "stalls"; any other value = every walk does: straight to the per-block kernels)
+    if (!debug_stall || !strcmp(debug_stall, "first")) {
+        if (getenv("CL_CHAIN_TIMING")) fprintf(stderr, "[chain_dp_batch]   walk kernel stalled: repeating the DP alone on the device\n");
+        tm = before;
+        g_walk_exclusive = true;
+        rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, true);
+        g_walk_exclusive = false;
+        if (rc != kWalkStalled) return rc;
+        ++cl_fallbacks.walk_stalls;
+    }
     if (getenv("CL_CHAIN_TIMING")) fprintf(stderr, "[chain_dp_batch]   walk kernel stalled: repeating the DP on the per-block kernels\n");
     tm = before;
     rc = chain_dp_batch_impl(ctx, subs, cp, local_scale, sparse, results, tm, dp_out, false);
@@ -1430,8 +1443,9 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     // compute units the walk launches of this DP occupy at a time (see WalkUnits)
     const uint32_t walk_units = !use_walk ? 0u : use_walk2 ? (uint32_t)(((combos.size() + 7) & ~(size_t)7) * (1 + walk2_help))
                                                            : (uint32_t)((combos.size() + std::max<uint32_t>(walk_fold, 1u) - 1) / std::max<uint32_t>(walk_fold, 1u));
-    struct UnitsHeld { int device; uint32_t n; bool held; ~UnitsHeld() { if (held) g_walk_units.give(device, n); } } units_held{ctx->device, walk_units, false};
-    if (walk_units && ctx->peers.n <= 1) { g_walk_units.take(ctx->device, walk_units); units_held.held = true; }
+    const uint32_t walk_units_booked = g_walk_exclusive && walk_units ? WalkUnits::kBudget : walk_units;
+    struct UnitsHeld { int device; uint32_t n; bool held; ~UnitsHeld() { if (held) g_walk_units.give(device, n); } } units_held{ctx->device, walk_units_booked, false};
+    if (walk_units && ctx->peers.n <= 1) { g_walk_units.take(ctx->device, walk_units_booked); units_held.held = true; }
     hipError_t he = hipEventRecord(ev0, ctx->stream);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev_fork, ctx->stream);
     for (uint32_t f = 0; f < far_streams && he == hipSuccess; ++f) he = hipStreamWaitEvent(ctx->aux[f], ctx->ev_fork, 0);
@@ -1698,7 +1712,7 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
     }
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
     for (uint32_t f = 0; f < std::max<uint32_t>(far_streams, far_lag) && he == hipSuccess; ++f) he = hipStreamSynchronize(ctx->aux[f]);
-    if (units_held.held) { g_walk_units.give(ctx->device, walk_units); units_held.held = false; }   // (the device is done with this DP's launches)
+    if (units_held.held) { g_walk_units.give(ctx->device, walk_units_booked); units_held.held = false; }   // (the device is done with this DP's launches)
     for (auto e : ev_intra) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_far) if (e) (void)hipEventDestroy(e);
     if (he != hipSuccess) return hip_fail(he, "chaining DP kernels");
@@ -1714,8 +1728,8 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
                             "wave 0 per step (100 MHz ticks): before the barrier %.1f, in the barrier %.1f, behind it %.1f; helper batches %u, records %u, polls without news %u; wave 0 finalised in %u steps: %.1f ticks before the barrier there, %.1f behind the barrier before; per launch: %.1f ticks in front of the loop, %.1f in it; not asked %u, no granule of the block %u; shader clock %.0f MHz (s_memtime against the 100 MHz s_memrealtime)\n",
                     dbg[8], dbg[9], dbg[10], dbg[11], dbg[12] / steps, dbg[13] / steps, dbg[14] / steps, dbg[16], dbg[17], dbg[18], dbg[19], dbg[20] / (double)std::max(1u, dbg[19]), dbg[21] / (double)std::max(1u, dbg[19]), dbg[22] / (double)std::max(1u, dbg[24]), dbg[23] / (double)std::max(1u, dbg[24]), dbg[25], dbg[26], 100.0 * dbg[27] / (double)std::max(1u, dbg[28]));
         }
-        static const bool debug_stall = getenv("CL_CHAIN_DEBUG_STALL") != nullptr;   // test hook: behave as if a wait had expired
-        if (debug_stall) status = 1;
+        static const char* debug_stall = getenv("CL_CHAIN_DEBUG_STALL");   // test hook: behave as if a wait had expired ("first": not in the attempt that has the device to itself)
+        if (debug_stall && !(g_walk_exclusive && !strcmp(debug_stall, "first"))) status = 1;
         if (status != 0) {
             cl_set_error(ctx, "chaining DP: a workgroup of the walk kernel gave up waiting for its siblings (%zu combinations not all resident?)", combos.size());
             (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);

@@ -177,10 +177,12 @@ def test_gpu_sparse_chain_is_optimal(gpu_ctx, name):
         assert abs(float(got["dp"].max()) - want) < 1e-3 * max(1.0, want)   # the float DP value of the chain's last anchor
 
 
-def test_walk_stall_falls_back_to_the_per_block_kernels():
-    """the walk kernel needs all its workgroups resident; if one of its bounded waits ever expires, the DP is repeated on the per-block
-    kernels.  CL_CHAIN_DEBUG_STALL=1 makes every walk attempt report a stall (the variable is read once, hence the child process): the
-    multi-path golden chains must still come out"""
+@pytest.mark.parametrize("mode, message", [("1", "on the per-block kernels"), ("first", "alone on the device")])
+def test_walk_stall_falls_back_to_the_per_block_kernels(mode, message):
+    """the walk kernel needs all its workgroups resident; if one of its bounded waits ever expires, the DP is repeated — once more on the walk
+    kernels with the device's walk budget booked for it alone, then on the per-block kernels.  CL_CHAIN_DEBUG_STALL=1 makes every walk attempt
+    report a stall, =first only the shared one (the variable is read once, hence the child process): the multi-path golden chains must still
+    come out either way"""
     import subprocess
     import sys
     code = (
@@ -198,7 +200,8 @@ def test_walk_stall_falls_back_to_the_per_block_kernels():
         "    got = ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z[tag + '.scale'][0]), params=capi.default_chain_params(global_anchoring=True))\n"
         "    assert np.array_equal(got['chain'], z[tag + '.chain_affine_global']), tag\n"
         "print('fallback ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, CL_CHAIN_DEBUG_STALL="1", CL_CHAIN_TIMING="1")
+    env = dict(os.environ, CL_CHAIN_DEBUG_STALL=mode, CL_CHAIN_TIMING="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "walk kernel stalled" in r.stderr
+    assert "walk kernel stalled: repeating the DP " + message in r.stderr
+    assert ("on the per-block kernels" in r.stderr) == (mode == "1")
