@@ -1016,7 +1016,7 @@ class StitchResult:
 
 
 _lib = None
-ABI_VERSION = 11    # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
+ABI_VERSION = 12    # CL_ABI_VERSION of include/centrolign_amd.h these ctypes structures mirror
 
 
 def load_library(path=None):
@@ -1181,13 +1181,13 @@ def load_library(path=None):
 
 
 def fallback_counters(reset=False):
-    """cl_fallback_counters: dict(strip_fallbacks, walk_stalls, chain_dps, stitch_plans, strip_pairs) of this process"""
+    """cl_fallback_counters: dict(strip_fallbacks, walk_stalls, chain_dps, stitch_plans, strip_pairs, bond_trims_past_the_end) of this process"""
     lib = load_library()
-    st = (C.c_uint64 * 5)()
+    st = (C.c_uint64 * 6)()
     lib.cl_fallback_counters.argtypes = [C.c_void_p, C.c_int]
     lib.cl_fallback_counters.restype = None
     lib.cl_fallback_counters(st, int(bool(reset)))
-    return dict(zip(("strip_fallbacks", "walk_stalls", "chain_dps", "stitch_plans", "strip_pairs"), [int(x) for x in st]))
+    return dict(zip(("strip_fallbacks", "walk_stalls", "chain_dps", "stitch_plans", "strip_pairs", "bond_trims_past_the_end"), [int(x) for x in st]))
 
 
 EXPORTED_SYMBOLS = [

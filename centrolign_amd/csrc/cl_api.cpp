@@ -878,8 +878,9 @@ void cl_fallback_counters(cl_fallback_stats* out, int reset) {
         out->chain_dps = cl_fallbacks.chain_dps.load();
         out->stitch_plans = cl_fallbacks.stitch_plans.load();
         out->strip_pairs = cl_fallbacks.strip_pairs.load();
+        out->bond_trims_past_the_end = cl_fallbacks.bond_trims_past_the_end.load();
     }
-    if (reset) { cl_fallbacks.strip_fallbacks = 0; cl_fallbacks.walk_stalls = 0; cl_fallbacks.chain_dps = 0; cl_fallbacks.stitch_plans = 0; cl_fallbacks.strip_pairs = 0; }
+    if (reset) { cl_fallbacks.strip_fallbacks = 0; cl_fallbacks.walk_stalls = 0; cl_fallbacks.chain_dps = 0; cl_fallbacks.stitch_plans = 0; cl_fallbacks.strip_pairs = 0; cl_fallbacks.bond_trims_past_the_end = 0; }
 }
 
 void cl_stitch_params_default(cl_stitch_params* p) {
@@ -1154,7 +1155,7 @@ int cl_stitch_plan_create(cl_context* ctx, const cl_stitch_batch* batch, const c
         // twenty compute units instead — 6 300 x 6 300: 22.4 -> ≈ 12 ms; such a pair always meets the strip kernel's conditions)
         // round 6: chain pairs of more than 1 024 rows span SEVERAL workgroups (popoa_linear_span_kernel, popoa_linear.hip: groups of four strips on different compute units, one
         // round): 2 048 x 2 048 and 6 300 x 6 300 leave the sixteen-wave workgroup's rounds / the DAG strip kernel.  CL_LINEAR_SPAN=0: the routing of rounds 4-5 (A/B)
-        static const bool span_env = [] { const char* e = getenv("CL_LINEAR_SPAN"); return !e || e[0] != '0'; }();
+        const bool span_env = [] { const char* e = getenv("CL_LINEAR_SPAN"); return !e || e[0] != '0'; }();   // (read per plan: the tests of the older routes switch it)
         const bool span_linear = span_env && linear && !g_force_general && std::min(d.n1, d.n2) > 1024 && std::min(d.n1, d.n2) <= 40000;
         const bool big_linear = !span_linear && linear && !g_no_strip && !g_force_general && std::min(d.n1, d.n2) >= 4096 && std::min(d.n1, d.n2) <= 40000;
         d.kind = (linear && !g_force_general && !big_linear) ? CL_KIND_LINEAR : CL_KIND_GENERAL;

@@ -12,6 +12,9 @@
 //
 // Host code, like the reference's; the device work is inside the calls it makes (cl_anchor_chain_masked, cl_internal_stitch).
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -154,8 +157,13 @@ void trim_partition_ends(std::vector<std::pair<size_t, size_t>>& part, const std
             len -= shared[iv.second].len; opt -= shared[iv.second].opt; sec -= shared[iv.second].sec;
             // (the reference takes off intervening_segments[interval.second], the segment BEHIND the entry it removes, not the one in front of it,
             // src/bonder.cpp:753-757; for the last shared segment that index is one past the end of its vector: what it reads there is not defined —
-            // in practice allocator bookkeeping, denormal or zero as a double — and counts as nothing here)
+            // mostly allocator bookkeeping, denormal or zero as a double, sometimes not: the reference's -c output changes with MALLOC_PERTURB_ and, on some inputs,
+            // from run to run (scripts/fuzz_msa.py, profiles/r06_fuzz_msa.json) — and counts as nothing here)
             if (wbeg != iv.second && iv.second < between.size()) { len -= between[iv.second].len; opt -= between[iv.second].opt; sec -= between[iv.second].sec; }
+            else if (wbeg != iv.second) {
+                ++cl_fallbacks.bond_trims_past_the_end;   // (cl_fallback_counters: a run that stood here has no defined counterpart in the reference)
+                if (getenv("CL_BOND_DEBUG")) fprintf(stderr, "[identify_bonds] end trim of the LAST shared segment (%zu of %zu): the reference reads intervening_segments[%zu] of %zu here\n", iv.second, shared.size(), iv.second, between.size());
+            }
             part_opt = 0.0; part_sec = 0.0;
             grow_left();
         }

@@ -129,7 +129,7 @@ inline hipError_t cl_ring_event(cl_context* ctx, int kind, uint32_t k, hipEvent_
 }
 
 // cl_fallback_counters (process-wide, cl_api.cpp)
-struct ClFallbackCounters { std::atomic<uint64_t> strip_fallbacks{0}, walk_stalls{0}, chain_dps{0}, stitch_plans{0}, strip_pairs{0}; };
+struct ClFallbackCounters { std::atomic<uint64_t> strip_fallbacks{0}, walk_stalls{0}, chain_dps{0}, stitch_plans{0}, strip_pairs{0}, bond_trims_past_the_end{0}; };
 extern ClFallbackCounters cl_fallbacks;
 
 void cl_peers_release(cl_context* ctx);         // cl_peer_api.cpp

@@ -768,7 +768,13 @@ int cl_msa(cl_context* ctx, const char* fasta_text, uint64_t fasta_len, const ch
         cl_owned_base_graph_view(graph[first], &g1);
         cl_owned_base_graph_view(graph[last], &g2);
         (void)root_children;
-        rc = cl_explicit_cigar(&g1, &g2, root_aln.pairs, root_aln.n_pairs, text_out, len_out);
+        uint64_t n_text = 0;
+        rc = cl_explicit_cigar(&g1, &g2, root_aln.pairs, root_aln.n_pairs, text_out, &n_text);
+        if (rc == CL_OK) {   // main() prints the CIGAR and a line end (src/main.cpp:295): the text handed back is what the CLI writes to its standard output
+            char* with_nl = (char*)realloc(*text_out, n_text + 2);
+            if (!with_nl) { free(*text_out); *text_out = nullptr; rc = CL_ERR_OUT_OF_MEMORY; }
+            else { with_nl[n_text] = '\n'; with_nl[n_text + 1] = '\0'; *text_out = with_nl; if (len_out) *len_out = n_text + 1; }
+        }
     } else {
         std::vector<const char*> names;
         for (uint64_t s : paths[root]) names.push_back(fa.names[s]);

@@ -318,7 +318,7 @@ inline Alignment deletion_wfa_po_poa(const Side& sh, const Side& lg, const WfaPa
     auto joinable = [&](uint64_t before, uint64_t after) { return before == after || (before != lg.n && after != lg.n && long_hops(before, after) != -1); };
     // what a front does with a position it settles: record match-state landings, and look for a first junction with the other front
     auto settle = [&](DeletionFront& mine, const DeletionFront& other, bool mine_is_before) {
-        return [&mine, &other, mine_is_before, &search_until, &joinable, never, scope](const Pos& p, int64_t score) {
+        return [&mine, &other, mine_is_before, &search_until, &joinable, scope](const Pos& p, int64_t score) {
             if (p.comp == 0) mine.landed[p.a].emplace_back(p.b, score);
             if (search_until != never) return;
             const auto met = other.landed.find(p.a);

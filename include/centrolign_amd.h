@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 11   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
+#define CL_ABI_VERSION 12   /* bumped whenever a struct layout or an entry point's signature changes; capi.py refuses a library of another version */
 
 /* AlignedPair::gap (src/alignment.cpp:11) */
 #define CL_GAP UINT64_MAX
@@ -193,6 +193,11 @@ typedef struct cl_fallback_stats {
     uint64_t chain_dps;         /* chaining DPs run on the device */
     uint64_t stitch_plans;      /* stitch plans executed */
     uint64_t strip_pairs;       /* pairs that took the strips at all */
+    uint64_t bond_trims_past_the_end;   /* (ABI 12) cl_identify_bonds calls' end trims that stood where the reference's result is UNDEFINED: Bonder::trim_partition_ends
+                                         * (src/bonder.cpp:753-757) takes off intervening_segments[interval.second] — one element PAST that vector when the interval ends at
+                                         * the last shared segment — and goes on with whatever the heap holds there (its output changes with MALLOC_PERTURB_ and, on some
+                                         * inputs, from run to run: profiles/r06_fuzz_msa.json).  This library counts that element as zeros.  A -c run whose text differs
+                                         * from a reference run's with this count non-zero is such a case, not a parity loss */
 } cl_fallback_stats;
 void cl_fallback_counters(cl_fallback_stats* out, int reset);
 
@@ -769,7 +774,8 @@ int  cl_apply_bonds(const cl_base_graph* root, uint64_t n_alignments, const uint
  *   as indices into `names`, and the merges in execution order.  A merge's operands are SLOTS: slot i < n_leaves is leaf i of that
  *   order, slot n_leaves + k is the result of merge k; merge_children[2k] is graph 1 of merge k (the node's first child).
  * cl_msa: main() from the parsed inputs on (src/main.cpp:239-301): plan, leaf graphs, calibration (score_scale = mean intrinsic
- *   scale in leaf order), cl_merge per node, then explicit_cigar for two sequences / write_gfa otherwise.  text_out is malloc'ed. */
+ *   scale in leaf order), cl_merge per node, then explicit_cigar + a line end for two sequences (src/main.cpp:295) / write_gfa otherwise: the text is
+ *   byte for byte what the CLI writes to its standard output.  text_out is malloc'ed. */
 typedef struct cl_fasta {
     uint64_t            n_sequences;
     const char* const*  names;       /* NUL-terminated */

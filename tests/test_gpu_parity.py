@@ -264,12 +264,20 @@ def test_strips_of_rows_for_large_branching_pairs(gpu_ctx, monkeypatch):
         plan.execute(); plan.sync()
         assert plan.collect().same_as(want) is None
     plan.destroy()
-    # a chain pair of 4 096 rows and more takes the strips too (the chain kernel would need four passes of its one workgroup)
+    # a chain pair of 4 096 rows and more took the strips too in rounds 4-5 (the chain kernel would need four passes of its one workgroup); since round 6 chain
+    # pairs above 1 024 rows span several workgroups of the chain kernel (popoa_linear_span_kernel), and CL_LINEAR_SPAN=0 is the older routing
     b = synth.sized_dag_batch([(4500, 4200), (4100, 9000)], seed=8, extra_edge_p=0.0, n_alt=0)
+    want = po.oracle_stitch_batch(b)
+    plan = gpu_ctx.plan(b)
+    assert all(li["kernel"] == "popoa_linear_span_kernel" for li in plan.launches() if li["n_problems"]), plan.launches()
+    plan.destroy()
+    assert gpu_ctx.stitch_batch_align(b).same_as(want) is None
+    monkeypatch.setenv("CL_LINEAR_SPAN", "0")
     plan = gpu_ctx.plan(b)
     assert all(li["kernel"].startswith("popoa_strip_kernel") for li in plan.launches()), plan.launches()
     plan.destroy()
-    assert gpu_ctx.stitch_batch_align(b).same_as(po.oracle_stitch_batch(b)) is None
+    assert gpu_ctx.stitch_batch_align(b).same_as(want) is None
+    monkeypatch.delenv("CL_LINEAR_SPAN")
     # a plan executed again and again: the strips' progress words start every pass at zero
     b = synth.sized_dag_batch([(2000, 2000), (800, 1500)], seed=3)
     plan = gpu_ctx.plan(b)
@@ -412,10 +420,17 @@ def test_near_chain_pairs_in_registers(gpu_ctx, monkeypatch, round_waves):
         got = gpu_ctx.po_poa_batch(b, f, capi.default_stitch_params().alignment_params)
         assert got.same_as(po.oracle_stitch_batch(b, force_num_pw=f)) is None, npw
     lin = synth.linear_batch([(4100, 4300), (6300, 6300), (4096, 9000)], seed=14)
+    want_lin = po.oracle_stitch_batch(lin)
+    plan = gpu_ctx.plan(lin)   # (round 6: chain pairs above 1 024 rows go to the chain kernel over several workgroups whatever CL_LANE_WIDE says ...)
+    assert all(li["kernel"] == "popoa_linear_span_kernel" for li in plan.launches() if li["n_problems"]), plan.launches()
+    plan.destroy()
+    assert gpu_ctx.stitch_batch_align(lin).same_as(want_lin) is None
+    monkeypatch.setenv("CL_LINEAR_SPAN", "0")   # (... and with the older routing they are WIDE pairs)
     plan = gpu_ctx.plan(lin)
     assert all(li["kernel"] == "popoa_lane_kernel<4, wide>" for li in plan.launches() if li["n_problems"]), plan.launches()
     plan.destroy()
-    assert gpu_ctx.stitch_batch_align(lin).same_as(po.oracle_stitch_batch(lin)) is None
+    assert gpu_ctx.stitch_batch_align(lin).same_as(want_lin) is None
+    monkeypatch.delenv("CL_LINEAR_SPAN")
     # many small near-chain pairs in one launch
     rng = np.random.default_rng(9)
     sizes = [(int(rng.integers(1, 120)), int(rng.integers(1, 400))) for _ in range(300)]
