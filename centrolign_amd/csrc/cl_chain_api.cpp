@@ -433,6 +433,26 @@ static int chain_dp_batch_impl(cl_context* ctx, const std::vector<ChainSub>& sub
         const SetView ms(sb);
         sc[k].pair_lo = (uint32_t)pairs.size();
         if (sb.num_match_sets > sb.ms->n_sets) { cl_set_error(ctx, "num_match_sets exceeds the number of sets"); return CL_ERR_INVALID_ARGUMENT; }
+        {   // the sets are the caller's: a walk is a non-empty run of node ids of its graph (anything else would index the tables below out of range)
+            std::atomic<uint64_t> bad_set{UINT64_MAX};
+            cl_parallel_for(sb.num_match_sets, [&](uint64_t sb0, uint64_t se0) {
+                for (uint64_t s = sb0; s < se0; ++s)
+                    for (int side = 0; side < 2; ++side) {
+                        const uint64_t n_nodes = sb.g[side]->n_nodes;
+                        for (uint64_t j = 0; j < ms.n_walks(side, s); ++j) {
+                            const uint64_t w = ms.walk(side, s, j);
+                            if (ms.wo[side][w + 1] <= ms.wo[side][w] || ms.front(side, w) >= n_nodes || ms.back(side, w) >= n_nodes) { bad_set = s; return; }
+                        }
+                    }
+            }, 4096);
+            if (bad_set.load() != UINT64_MAX) {
+                const uint64_t s = bad_set.load();
+                cl_set_error(ctx, "match set %llu (of %llu) holds an empty walk or a node id outside its graph (%llu and %llu nodes; the set has %llu x %llu walks of length %llu)",
+                             (unsigned long long)s, (unsigned long long)sb.num_match_sets, (unsigned long long)sb.g[0]->n_nodes, (unsigned long long)sb.g[1]->n_nodes,
+                             (unsigned long long)ms.n_walks(0, s), (unsigned long long)ms.n_walks(1, s), (unsigned long long)(ms.n_walks(0, s) ? ms.length(s) : 0));
+                return CL_ERR_INVALID_ARGUMENT;
+            }
+        }
         if (!sb.masked && sb.num_match_sets >= 4096) {
             // (the usual case, no mask: every set's pairs have their place by a prefix sum over n1 * n2, the sets are filled in side by side)
             const uint64_t ns = sb.num_match_sets;

@@ -385,9 +385,14 @@ std::vector<std::vector<PathHitSet>> induce_matches(const cl_base_graph& g, cons
 struct SubPaths { std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> of; };   // per path (full-graph path, begin, end)
 
 // InducedMatchFinderComponentView::find_matches (induced_match_finder.hpp:100-372) as owned match sets
+// *past_the_paths: a hit that starts ONE step behind a stretch is taken for the stretch as well (the upper bound (path_end + 1, 0) lets a location of walk 0 at
+// path_end + 1 through, induced_match_finder.hpp:190): its clipped end is path_end - match_begin = -1 as a size_t and it is read from the step behind the subpath — the
+// next path's first node, which the reference then aligns like any other; behind the LAST path of a graph there is nothing to read (the reference ends in a segmentation
+// fault on such an input: scripts/fuzz_msa.py found one).  Inside the arrays this function does what the reference does; past them it stops and says so
 std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& full, const std::vector<PathHitSet>& path_hits, const cl_base_graph& g1,
-                                                          const SubPaths& sp1, const cl_base_graph& g2, const SubPaths& sp2) {
+                                                          const SubPaths& sp1, const cl_base_graph& g2, const SubPaths& sp2, bool* past_the_paths) {
     std::unique_ptr<cl_owned_match_sets> out(new cl_owned_match_sets());
+    *past_the_paths = false;
     std::unordered_set<uint64_t> parent_seen;
     uint64_t len1 = 0, len2 = 0;
     for (int side = 0; side < 2; ++side) {
@@ -434,6 +439,7 @@ std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& f
                     origin_walks.insert(l->second);
                     const uint64_t begin = mb < pb ? pb - mb : 0, end = me > pe ? pe - mb : hs.length;
                     const uint64_t offset = mb < pb ? 0 : mb - pb;
+                    if (g.path_off[p] + offset >= g.path_off[g.n_paths]) { *past_the_paths = true; return out; }
                     const uint64_t node = g.path_nodes[g.path_off[p] + offset];
                     if (initial.emplace(node, begin).second) iv.emplace_back(begin, end, do1, p, offset);
                     ++observed;
@@ -462,6 +468,7 @@ std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& f
                         if (std::get<2>(iv[idx]) != (side == 0)) continue;
                         const uint64_t b = std::get<4>(iv[idx]) + (last - std::get<0>(iv[idx])), e = b + (next - last);
                         const uint32_t* path = g.path_nodes + g.path_off[std::get<3>(iv[idx])];
+                        if (e < b || g.path_off[std::get<3>(iv[idx])] + e > g.path_off[g.n_paths]) { *past_the_paths = true; return out; }
                         nodes.insert(nodes.end(), path + b, path + e);
                         walk_off.push_back(nodes.size());
                     }
@@ -742,6 +749,7 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
             if (kv.second.first.size() != kv.second.second.size()) { cl_set_error(ctx, "Path starts or ends in the middle of a cycle realignment interval"); return CL_ERR_INVALID_ARGUMENT; }
             for (size_t k = 0; k < kv.second.first.size(); ++k) {
                 const uint64_t bg = kv.second.first[k], en = kv.second.second[k];
+                if (getenv("CL_POLISH_DEBUG")) fprintf(stderr, "[polish] region %zu (nodes %llu .. %llu): path %llu occurrence %zu = steps %llu .. %llu\n", ri, (unsigned long long)regions[ri].first, (unsigned long long)regions[ri].second, (unsigned long long)kv.first, k, (unsigned long long)bg, (unsigned long long)en);
                 intervals.emplace_back(kv.first, bg, en);
                 parents.push_back(path_names[kv.first]);
                 names.push_back(parents.back() + ":" + std::to_string(bg) + "-" + std::to_string(en));
@@ -780,10 +788,28 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
             g1.label = l1.data();
             g2.label = l2.data();
             const auto t_m0 = std::chrono::steady_clock::now();
-            auto ms = induced_find_matches(a, hits[ri], g1, slot_paths[ia], g2, slot_paths[ib]);
+            bool past_the_paths = false;
+            auto ms = induced_find_matches(a, hits[ri], g1, slot_paths[ia], g2, slot_paths[ib], &past_the_paths);
+            if (past_the_paths) {
+                cl_set_error(ctx, "polishing region %zu: a match that starts one step behind a realigned stretch is read past the end of the subproblem's paths "
+                                  "(include/centrolign/induced_match_finder.hpp:190-205 does the same and the reference ends in a segmentation fault on such an input)", ri);
+                rc = CL_ERR_INVALID_ARGUMENT;
+                break;
+            }
             const auto t_m1 = std::chrono::steady_clock::now();
             cl_match_sets view;
             cl_owned_match_sets_view(ms.get(), &view);
+            if (getenv("CL_POLISH_DEBUG")) {
+                for (int side = 0; side < 2; ++side) {
+                    const cl_base_graph& g = side ? g2 : g1;
+                    const SubPaths& sp = side ? slot_paths[ib] : slot_paths[ia];
+                    bool shown = false;
+                    for (uint64_t p = 0; p < g.n_paths; ++p) {
+                        const uint64_t plen = g.path_off[p + 1] - g.path_off[p], want = std::get<2>(sp.of[p]) - std::get<1>(sp.of[p]) + 1;
+                        if (plen != want && !shown) { shown = true; fprintf(stderr, "[polish] region %zu merge %llu side %d: path %llu of the slot graph has %llu steps, its stretch %llu .. %llu has %llu (graph: %llu paths, stretches: %zu)\n", ri, (unsigned long long)k, side, (unsigned long long)p, (unsigned long long)plen, (unsigned long long)std::get<1>(sp.of[p]), (unsigned long long)std::get<2>(sp.of[p]), (unsigned long long)want, (unsigned long long)g.n_paths, sp.of.size()); }
+                    }
+                }
+            }
             if (dbg.f) {
                 std::vector<uint64_t> flat;
                 for (uint64_t st_ = 0; st_ < view.n_sets; ++st_) {
