@@ -205,3 +205,50 @@ def test_cl_msa_with_cyclisation_on_many_sequences(gpu_ctx, case):
                           min_cyclizing_length=gold["min_cyclizing_length"], workers=4)
     assert got == want
     assert st["n_merges"] == n_merges and st["n_bonds"] == n_bonds and st["n_polished_regions"] == n_regions
+
+
+def test_identify_bonds_where_the_reference_reads_past_a_vector():
+    """host only.  Bonder::trim_partition_ends takes off intervening_segments[interval.second] when it trims an interval's end (src/bonder.cpp:753-757): one element PAST
+    that vector when the interval ends at the last shared segment, i.e. whatever the heap holds there (the unmodified reference's -c text changes with MALLOC_PERTURB_ and,
+    on some inputs, from run to run: profiles/r06_reference_undefined_read.json; an ASan build reports the read: profiles/r06_reference_asan_report.txt).  cl_identify_bonds
+    counts that element as zeros and says so in cl_fallback_counters.  Two recorded leaf rounds of scripts/fuzz_msa.py that stand at that spot (the reference's chains in,
+    its bonds out): in one the reference's run happened to read nothing that matters and the bonds are its bonds; in the other it stopped trimming early — every interval
+    is the reference's except that the trimmed one is a PREFIX of the reference's"""
+    z = np.load(os.path.join(HERE, "golden", "bonds_past_the_end.npz"))
+    for tag in ("agrees", "differs"):
+        leaf = synth.base_graph_from_sequence(z[tag + ".sequence"].tobytes().decode(), (5, 6))
+        opt = {k: z["%s.opt.%s" % (tag, k)] for k in CHAIN_KEYS}
+        sec = {k: z["%s.sec.%s" % (tag, k)] for k in CHAIN_KEYS}
+        capi.fallback_counters(reset=True)
+        got = capi.identify_bonds(leaf, opt, sec, capi.bond_params(min_length=int(z[tag + ".min_length"][0])), deduplicate=False)
+        assert capi.fallback_counters()["bond_trims_past_the_end"] >= 1, tag
+        want = {k: z["%s.raw_bonds.%s" % (tag, k)] for k in BOND_KEYS + ("score",)}
+        same = all(np.array_equal(got[k], want[k]) for k in BOND_KEYS) and np.array_equal(got["score"].view(np.uint64), want["score"].view(np.uint64))
+        assert same == (tag == "agrees"), tag
+        if not same:
+            assert len(got["interval_off"]) == len(want["interval_off"])
+            shorter = 0
+            for iv in range(len(want["interval_off"]) - 1):
+                a, b = int(want["interval_off"][iv]), int(want["interval_off"][iv + 1])
+                ga, gb = int(got["interval_off"][iv]), int(got["interval_off"][iv + 1])
+                assert gb - ga <= b - a
+                shorter += (gb - ga) < (b - a)
+                for k in ("offset1", "offset2"):
+                    assert np.array_equal(got[k][ga:gb], want[k][a:a + gb - ga]), (iv, k)
+                assert np.array_equal(got["length"][ga:gb - 1], want["length"][a:a + gb - ga - 1]), iv     # (the cut may fall inside the last bond)
+            assert shorter == 1
+
+
+@pytest.mark.gpu
+def test_polishing_stops_where_the_reference_reads_past_the_last_path(gpu_ctx):
+    """device.  InducedMatchFinderComponentView::find_matches lets a hit that starts ONE step behind a realigned stretch through (upper bound (path_end + 1, 0),
+    include/centrolign/induced_match_finder.hpp:190) and reads it from the step behind the subpath; behind the last path of a subproblem graph there is nothing to read.
+    The unmodified reference ends in a segmentation fault on this input (two sequences, one with a 5-kbp tandem duplication; scripts/fuzz_msa.py seed 3); the library
+    returns an error that says where it stands — and keeps working afterwards"""
+    seqs = synth.tandem_dup_sequences(439391627, 14000, 2, 5000, carriers=[1], seq_div=0.01, hor_div=0.02)
+    fasta = "".join(">q%02d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    with pytest.raises(capi.ClError) as e:
+        gpu_ctx.msa(fasta, newick="(q00,q01);", max_num_match_pairs=8000, cyclize=True, min_cyclizing_length=2500)
+    assert "read past the end of the subproblem's paths" in str(e.value)
+    text, st = gpu_ctx.msa(fasta, newick="(q00,q01);", max_num_match_pairs=8000)
+    assert text.endswith(b"\n") and st["n_merges"] == 1

@@ -205,3 +205,20 @@ def test_walk_stall_falls_back_to_the_per_block_kernels(mode, message):
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "walk kernel stalled: repeating the DP " + message in r.stderr
     assert ("on the per-block kernels" in r.stderr) == (mode == "1")
+
+
+def test_match_sets_with_nodes_outside_their_graph_are_refused(gpu_ctx):
+    """the chaining DP indexes per-node tables with the first and last node of every walk: a set whose walk is empty or names a node the graph does not have is an
+    error of the caller's (CL_ERR_INVALID_ARGUMENT with the set's number), not a crash — found by scripts/fuzz_msa.py on an input the reference dies on"""
+    name = FILES[0]
+    z = np.load(os.path.join(H.GOLDEN, name))
+    _, graphs, _ = load_stitch_case(name.replace("chain4_", "stitch4_"))
+    ms = capi.MatchSets(**{k: z["a.ms." + k] for k in capi.MatchSets._DT})
+    for field, graph in (("nodes1", graphs[0]), ("nodes2", graphs[1])):
+        bad = capi.MatchSets(**{k: getattr(ms, k).copy() for k in capi.MatchSets._DT})
+        getattr(bad, field)[-1] = len(graph.label) + 7
+        with pytest.raises(capi.ClError) as e:
+            gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], bad)
+        assert "node id outside its graph" in str(e.value)
+    got = gpu_ctx.chain_sparse_affine(graphs[0], graphs[1], ms, scale=float(z["a.scale"][0]), params=capi.default_chain_params(global_anchoring=False))
+    assert np.array_equal(got["chain"], z["a.chain_affine"])   # (and the context is as good as before)
