@@ -30,13 +30,18 @@ def random_tree(rng, names):
     return nodes[0]
 
 
-def one_case(rng):
+def one_case(rng, more=False):
     n = rng.choice([2, 3, 3, 4, 5, 6, 7])
     length = rng.choice([4500, 6000, 9000, 14000])
     seed = rng.randrange(1 << 30)
     cyc = rng.random() < 0.4
     kw = dict(seq_div=rng.choice([0.002, 0.01, 0.03]), hor_div=rng.choice([0.02, 0.08]))
     p = dict(n=n, length=length, seed=seed, cyclize=cyc, budget=rng.choice([2000, 8000, 30000]), workers=rng.choice([1, 3]), **kw)
+    if more:   # (--more-switches: the CLI's -m, the hidden -g 1 = Anchorer::Sparse over ChainMerge structures, and the developer switch that skips the calibration)
+        p["max_count"] = rng.choice([3000, 3000, 300, 50])
+        if not cyc:
+            p["skip_calibration"] = rng.random() < 0.2
+            p["chaining_algorithm"] = 1 if rng.random() < 0.2 else None
     if cyc:
         p["dup"] = rng.choice([1500, 3000, 5000])
         p["carriers"] = sorted(rng.sample(range(n), rng.randrange(1, n + 1)))
@@ -56,6 +61,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--more-switches", action="store_true", help="also vary max_count, skip_calibration and the chaining algorithm")
     ap.add_argument("--jobs", type=int, default=max(2, min(24, (os.cpu_count() or 4) - 4)), help="reference runs side by side (one core each)")
     ap.add_argument("--ref-timeout", type=float, default=400.0, help="a reference run that takes longer is dropped (counted)")
     args = ap.parse_args()
@@ -77,6 +83,12 @@ def main():
         synth.write_fasta(os.path.join(d, "in.fa"), seqs, names)
         open(os.path.join(d, "t.nwk"), "w").write(newick + "\n")
         over = "i:max_num_match_pairs=%d" % p["budget"]
+        if "max_count" in p:
+            over += ";i:max_count=%d" % p["max_count"]
+        if p.get("skip_calibration"):
+            over += ";b:skip_calibration=1"
+        if p.get("chaining_algorithm") is not None:
+            over += ";i:chaining_algorithm=%d" % p["chaining_algorithm"]
         if p["cyclize"]:
             over += ";b:cyclize_tandem_duplications=1;i:min_cyclizing_length=%d" % p["min_cyclizing_length"]
         t0 = time.time()
@@ -92,7 +104,7 @@ def main():
     pending = set()
     while True:
         while len(pending) < args.jobs and time.time() < t_end:
-            c = one_case(rng)
+            c = one_case(rng, args.more_switches)
             if c is not None:
                 pending.add(pool.submit(reference, c))
         if not pending:
@@ -115,7 +127,8 @@ def main():
                 rec = dict(p, returncode=rc, newick=newick)
                 try:   # (what the library does with the input the reference died on)
                     fa_text = "".join(">%s\n%s\n" % (nm, sq) for nm, sq in zip(names, seqs))
-                    got, st = ctx.msa(fa_text, newick=newick, max_num_match_pairs=p["budget"], workers=p["workers"], cyclize=p["cyclize"], min_cyclizing_length=p.get("min_cyclizing_length"))
+                    got, st = ctx.msa(fa_text, newick=newick, max_num_match_pairs=p["budget"], workers=p["workers"], cyclize=p["cyclize"], min_cyclizing_length=p.get("min_cyclizing_length"),
+                                      max_count=p.get("max_count", 3000))
                     rec["library"] = dict(completed=True, bytes=len(got), n_bonds=int(st.get("n_bonds", 0)), n_polished_regions=int(st.get("n_polished_regions", 0)))
                 except Exception as e:   # noqa: BLE001
                     rec["library"] = dict(completed=False, error=repr(e))
@@ -125,7 +138,8 @@ def main():
             t0 = time.time()
             try:
                 got, st = ctx.msa(fasta, newick=newick, max_num_match_pairs=p["budget"], workers=p["workers"], cyclize=p["cyclize"],
-                                  min_cyclizing_length=p.get("min_cyclizing_length"))
+                                  min_cyclizing_length=p.get("min_cyclizing_length"), max_count=p.get("max_count", 3000), skip_calibration=bool(p.get("skip_calibration")),
+                                  chaining_algorithm=p.get("chaining_algorithm"))
             except Exception as e:   # noqa: BLE001
                 got, st = b"", {}
                 print("library failed on %s: %r" % (json.dumps(p), e), flush=True)
