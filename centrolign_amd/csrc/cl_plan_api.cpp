@@ -421,6 +421,7 @@ int cl_msa_plan_create(cl_context* ctx, const char* newick, const char* const* n
 void cl_msa_params_default(cl_msa_params* p) {
     memset(p, 0, sizeof(*p));
     cl_merge_params_default(&p->merge);
+    p->merge.align.anchor.score_scale = 0.303092;   // ScoreFunction::score_scale as the CLI starts with (include/centrolign/score_function.hpp:39): what a run with skip_calibration keeps
     p->skip_calibration = 0;
     p->cyclize = 0;
     p->max_tandem_duplication_search_rounds = 3;   // src/parameters.cpp:90

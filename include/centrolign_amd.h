@@ -797,7 +797,7 @@ void cl_msa_plan_free(cl_msa_plan* p);
 
 typedef struct cl_msa_params {
     cl_merge_params merge;            /* merge.align.anchor.score_scale is overwritten by the calibration unless it is skipped */
-    int             skip_calibration; /* --skip-calibration of the CLI */
+    int             skip_calibration; /* --skip-calibration of the CLI: merge.align.anchor.score_scale stays what the caller set (cl_msa_params_default: 0.303092, the CLI's own start value) */
     int             n_workers;        /* contexts (threads) that run leaf calibrations and independent merges side by side; <= 1: one */
     const int*      devices;          /* where the worker contexts sit: worker w on device ordinal devices[w % n_devices] (worker 0 is ctx itself and stays on
                                          ctx's device); NULL / n_devices 0: all on ctx's device.  One process, several GPUs: graphs are host arrays at this

@@ -197,3 +197,18 @@ def test_gpu_wide_merges(gpu_ctx, case):
         got, st = gpu_ctx.msa(fasta, newick=gold["newick"], workers=workers)
         assert got == want, workers
         assert st["n_merges"] == n - 1
+
+
+@pytest.mark.gpu
+def test_gpu_cl_msa_with_the_calibration_skipped(gpu_ctx):
+    """the CLI's developer switch skip_calibration (src/core.cpp:66): the run keeps ScoreFunction::score_scale's start value 0.303092 (include/centrolign/score_function.hpp:39)
+    — cl_msa_params_default's — and prints another text than the calibrated run; both byte for byte the compiled reference's (tests/golden/make_skip_calibration.py; the
+    input is one scripts/fuzz_msa.py found: before round 6's end the library kept 1.0)"""
+    from tests.golden.make_skip_calibration import CASE
+    z = np.load(os.path.join(H.GOLDEN, "msa_skip_calibration.npz"))
+    seqs = synth.hor_sequences(CASE["seed"], CASE["length"], CASE["n"], seq_div=CASE["seq_div"], hor_div=CASE["hor_div"])
+    fasta = "".join(">q%02d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    text, st = gpu_ctx.msa(fasta, newick=CASE["newick"], max_num_match_pairs=CASE["budget"], skip_calibration=True)
+    assert text == z["skipped"].tobytes() and st["score_scale"] == 0.303092
+    text, st = gpu_ctx.msa(fasta, newick=CASE["newick"], max_num_match_pairs=CASE["budget"], workers=3)
+    assert text == z["calibrated"].tobytes()
