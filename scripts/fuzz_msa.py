@@ -30,22 +30,25 @@ def random_tree(rng, names):
     return nodes[0]
 
 
-def one_case(rng, more=False):
+def one_case(rng, more=False, big=False):
     n = rng.choice([2, 3, 3, 4, 5, 6, 7])
     length = rng.choice([4500, 6000, 9000, 14000])
+    if big:   # (--big: the regime of the far pass, several macro-blocks per DP, helpers of the walk, larger stitch problems; the reference needs minutes per case)
+        n = rng.choice([2, 3, 3, 4, 5])
+        length = rng.choice([30000, 50000, 80000])
     seed = rng.randrange(1 << 30)
     cyc = rng.random() < 0.4
     kw = dict(seq_div=rng.choice([0.002, 0.01, 0.03]), hor_div=rng.choice([0.02, 0.08]))
-    p = dict(n=n, length=length, seed=seed, cyclize=cyc, budget=rng.choice([2000, 8000, 30000]), workers=rng.choice([1, 3]), **kw)
+    p = dict(n=n, length=length, seed=seed, cyclize=cyc, budget=rng.choice([60000, 150000, 400000] if big else [2000, 8000, 30000]), workers=rng.choice([1, 3]), **kw)
     if more:   # (--more-switches: the CLI's -m, the hidden -g 1 = Anchorer::Sparse over ChainMerge structures, and the developer switch that skips the calibration)
         p["max_count"] = rng.choice([3000, 3000, 300, 50])
         if not cyc:
             p["skip_calibration"] = rng.random() < 0.2
             p["chaining_algorithm"] = 1 if rng.random() < 0.2 else None
     if cyc:
-        p["dup"] = rng.choice([1500, 3000, 5000])
+        p["dup"] = rng.choice([8000, 15000] if big else [1500, 3000, 5000])
         p["carriers"] = sorted(rng.sample(range(n), rng.randrange(1, n + 1)))
-        p["min_cyclizing_length"] = rng.choice([1000, 2500])
+        p["min_cyclizing_length"] = rng.choice([4000, 6000] if big else [1000, 2500])
         seqs = synth.tandem_dup_sequences(seed, length, n, p["dup"], carriers=p["carriers"], **kw)
     else:
         seqs = synth.hor_sequences(seed, length, n, **kw)
@@ -62,6 +65,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--json", default=None)
     ap.add_argument("--more-switches", action="store_true", help="also vary max_count, skip_calibration and the chaining algorithm")
+    ap.add_argument("--big", action="store_true", help="2-5 sequences of 30-80 kbp, budgets 60 000-400 000 (minutes of reference time per case)")
     ap.add_argument("--jobs", type=int, default=max(2, min(24, (os.cpu_count() or 4) - 4)), help="reference runs side by side (one core each)")
     ap.add_argument("--ref-timeout", type=float, default=400.0, help="a reference run that takes longer is dropped (counted)")
     args = ap.parse_args()
@@ -104,7 +108,7 @@ def main():
     pending = set()
     while True:
         while len(pending) < args.jobs and time.time() < t_end:
-            c = one_case(rng, args.more_switches)
+            c = one_case(rng, args.more_switches, args.big)
             if c is not None:
                 pending.add(pool.submit(reference, c))
         if not pending:
