@@ -386,9 +386,9 @@ struct SubPaths { std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> of; };  
 
 // InducedMatchFinderComponentView::find_matches (induced_match_finder.hpp:100-372) as owned match sets
 // *past_the_paths: a hit that starts ONE step behind a stretch is taken for the stretch as well (the upper bound (path_end + 1, 0) lets a location of walk 0 at
-// path_end + 1 through, induced_match_finder.hpp:190): its clipped end is path_end - match_begin = -1 as a size_t and it is read from the step behind the subpath — the
-// next path's first node, which the reference then aligns like any other; behind the LAST path of a graph there is nothing to read (the reference ends in a segmentation
-// fault on such an input: scripts/fuzz_msa.py found one).  Inside the arrays this function does what the reference does; past them it stops and says so
+// path_end + 1 through, induced_match_finder.hpp:190): its clipped end is path_end - match_begin = -1 as a size_t, and it is read from the step BEHIND the subproblem's
+// path — in the reference past the end of that path's own vector (whatever the heap holds; the runs scripts/fuzz_msa.py met ended in a segmentation fault).  Nothing can
+// be "the same" there: this function stops and says so instead of reading on into the next path's nodes
 std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& full, const std::vector<PathHitSet>& path_hits, const cl_base_graph& g1,
                                                           const SubPaths& sp1, const cl_base_graph& g2, const SubPaths& sp2, bool* past_the_paths) {
     std::unique_ptr<cl_owned_match_sets> out(new cl_owned_match_sets());
@@ -439,7 +439,7 @@ std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& f
                     origin_walks.insert(l->second);
                     const uint64_t begin = mb < pb ? pb - mb : 0, end = me > pe ? pe - mb : hs.length;
                     const uint64_t offset = mb < pb ? 0 : mb - pb;
-                    if (g.path_off[p] + offset >= g.path_off[g.n_paths]) { *past_the_paths = true; return out; }
+                    if (offset >= g.path_off[p + 1] - g.path_off[p]) { *past_the_paths = true; return out; }
                     const uint64_t node = g.path_nodes[g.path_off[p] + offset];
                     if (initial.emplace(node, begin).second) iv.emplace_back(begin, end, do1, p, offset);
                     ++observed;
@@ -468,7 +468,7 @@ std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& f
                         if (std::get<2>(iv[idx]) != (side == 0)) continue;
                         const uint64_t b = std::get<4>(iv[idx]) + (last - std::get<0>(iv[idx])), e = b + (next - last);
                         const uint32_t* path = g.path_nodes + g.path_off[std::get<3>(iv[idx])];
-                        if (e < b || g.path_off[std::get<3>(iv[idx])] + e > g.path_off[g.n_paths]) { *past_the_paths = true; return out; }
+                        if (e < b || e > g.path_off[std::get<3>(iv[idx]) + 1] - g.path_off[std::get<3>(iv[idx])]) { *past_the_paths = true; return out; }
                         nodes.insert(nodes.end(), path + b, path + e);
                         walk_off.push_back(nodes.size());
                     }
@@ -792,7 +792,7 @@ int cl_polish_cyclized_graph_workers(cl_context* const* ctxs, unsigned n_ctx, co
             auto ms = induced_find_matches(a, hits[ri], g1, slot_paths[ia], g2, slot_paths[ib], &past_the_paths);
             if (past_the_paths) {
                 cl_set_error(ctx, "polishing region %zu: a match that starts one step behind a realigned stretch is read past the end of the subproblem's paths "
-                                  "(include/centrolign/induced_match_finder.hpp:190-205 does the same and the reference ends in a segmentation fault on such an input)", ri);
+                                  "(include/centrolign/induced_match_finder.hpp:190-205 reads past its path's vector there; the reference ends in a segmentation fault on such an input)", ri);
                 rc = CL_ERR_INVALID_ARGUMENT;
                 break;
             }

@@ -3,7 +3,7 @@
 binary guide trees, random divergence, match-pair budgets that bite or do not, with and without tandem duplications under -c (bond search, apply_bonds, polishing), one
 or three worker contexts.  Byte-for-byte comparison of the output text.  A -c case that differs while the library's counter bond_trims_past_the_end is non-zero is run
 through the unmodified reference again with MALLOC_PERTURB_=1 / 85 / 170 / 255 (glibc's fill byte for freed and fresh heap memory) and once more as it is: if the reference's own text
-changes, its result on that input is undefined (Bonder::trim_partition_ends reads one element past a vector, src/bonder.cpp:753-757) and the case is listed apart.
+changes (or, failing that, if the recorded flow of oracle/ref_driver.cpp — another program round the same unmodified objects, another heap — prints another text), its result on that input is undefined (Bonder::trim_partition_ends reads one element past a vector, src/bonder.cpp:753-757) and the case is listed apart.
 usage: python3 scripts/fuzz_msa.py [--seconds T] [--seed S] [--json OUT]; exit code 1 on any difference (each printed with its parameters)"""
 import argparse
 import hashlib
@@ -171,6 +171,24 @@ def main():
                         for f in os.listdir(d2):
                             os.remove(os.path.join(d2, f))
                         os.rmdir(d2)
+                    if len(shas) == 1:
+                        # the same text under every fill byte: what the reference reads past its vector may be LIVE data of its neighbours on the heap.  Another program
+                        # round the same unmodified objects — the recorded flow of oracle/ref_driver.cpp, whose dumps make other allocations in between — has another heap
+                        d3 = tempfile.mkdtemp(prefix="fuzz_msa_")
+                        synth.write_fasta(os.path.join(d3, "in.fa"), seqs, names)
+                        open(os.path.join(d3, "t.nwk"), "w").write(newick + "\n")
+                        over3 = "i:min_cyclizing_length=%d;i:max_num_match_pairs=%d" % (p["min_cyclizing_length"], p["budget"]) + (";i:max_count=%d" % p["max_count"] if "max_count" in p else "")
+                        code = ("import sys; sys.path.insert(0, %r); from oracle import pyoracle as po; po.ref_cyclize_dump('in.fa', 't.nwk', 'd.bin', 'out.txt', %r)" % (ROOT, over3))
+                        try:
+                            r3 = subprocess.run([sys.executable, "-c", code], cwd=d3, capture_output=True, text=True, timeout=args.ref_timeout)
+                            if r3.returncode == 0:
+                                shas.add(hashlib.sha256(open(os.path.join(d3, "out.txt"), "rb").read()).hexdigest())
+                                p["reference_recorded_flow_text"] = hashlib.sha256(open(os.path.join(d3, "out.txt"), "rb").read()).hexdigest()
+                        except subprocess.TimeoutExpired:
+                            pass
+                        for f in os.listdir(d3):
+                            os.remove(os.path.join(d3, f))
+                        os.rmdir(d3)
                     p["reference_texts_under_other_heap_fill_bytes"] = sorted(shas)
                     p["library_text_is_one_of_them"] = p["got_sha256"] in shas
                     if len(shas) > 1:
