@@ -436,10 +436,17 @@ std::unique_ptr<cl_owned_match_sets> induced_find_matches(const cl_base_graph& f
                 auto hi = std::upper_bound(it->second.begin(), it->second.end(), std::make_pair(pe + 1, (uint64_t)0));
                 for (auto l = lo; l != hi; ++l) {
                     const uint64_t mb = l->first, me = mb + hs.length;
+                    const uint64_t offset = mb < pb ? 0 : mb - pb;
+                    if (offset >= g.path_off[p + 1] - g.path_off[p]) {
+                        // CL_POLISH_SKIP_STRAY_HITS=1: what the bound evidently means — a hit that begins behind the stretch is none of the stretch's — instead of the error: for
+                        // inputs the reference dies on, so nothing it prints can be compared with
+                        static const bool skip = [] { const char* e = getenv("CL_POLISH_SKIP_STRAY_HITS"); return e && e[0] == '1'; }();
+                        if (skip) continue;
+                        *past_the_paths = true;
+                        return out;
+                    }
                     origin_walks.insert(l->second);
                     const uint64_t begin = mb < pb ? pb - mb : 0, end = me > pe ? pe - mb : hs.length;
-                    const uint64_t offset = mb < pb ? 0 : mb - pb;
-                    if (offset >= g.path_off[p + 1] - g.path_off[p]) { *past_the_paths = true; return out; }
                     const uint64_t node = g.path_nodes[g.path_off[p] + offset];
                     if (initial.emplace(node, begin).second) iv.emplace_back(begin, end, do1, p, offset);
                     ++observed;

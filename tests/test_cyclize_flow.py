@@ -252,3 +252,26 @@ def test_polishing_stops_where_the_reference_reads_past_the_last_path(gpu_ctx):
     assert "read past the end of the subproblem's paths" in str(e.value)
     text, st = gpu_ctx.msa(fasta, newick="(q00,q01);", max_num_match_pairs=8000)
     assert text.endswith(b"\n") and st["n_merges"] == 1
+
+
+@pytest.mark.gpu
+def test_stray_hits_can_be_left_out_instead(tmp_path):
+    """device.  CL_POLISH_SKIP_STRAY_HITS=1 (read once: a child process): the hit that begins one step behind a realigned stretch is none of the stretch's — what the bound
+    of induced_match_finder.hpp:190 evidently means — and an input the reference dies on goes through: five sequences, 16 bonds, 52 polished regions, and every path of the
+    GFA spells its sequence"""
+    import subprocess
+    import sys
+    code = (
+        "import re, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from centrolign_amd import capi, synth\n"
+        "seqs = synth.tandem_dup_sequences(518117772, 9000, 5, 5000, carriers=[0, 2], seq_div=0.03, hor_div=0.02)\n"
+        "names = ['q%%02d' %% i for i in range(5)]\n"
+        "fasta = ''.join('>%%s\\n%%s\\n' %% (nm, s) for nm, s in zip(names, seqs))\n"
+        "text, st = capi.Context(0).msa(fasta, newick='((q00,q01),(q02,(q03,q04)));', max_num_match_pairs=8000, cyclize=True, min_cyclizing_length=1000)\n"
+        "seg = {m.group(1): m.group(2) for m in re.finditer(r'^S\\t(\\S+)\\t(\\S+)', text.decode(), re.M)}\n"
+        "paths = {m.group(1): ''.join(seg[x[:-1]] for x in m.group(2).split(',')) for m in re.finditer(r'^P\\t(\\S+)\\t(\\S+)', text.decode(), re.M)}\n"
+        "assert paths == dict(zip(names, seqs))\n"
+        "print('RESULT', st['n_bonds'], st['n_polished_regions'])\n" % os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CL_POLISH_SKIP_STRAY_HITS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RESULT 16 52" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
